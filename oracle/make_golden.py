@@ -1,0 +1,141 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on CPU.
+
+Run in the build container only (needs /root/reference; the GPU box does not
+have it):   python oracle/make_golden.py
+
+Recipe: pre-seed ``sys.modules`` with empty ``imageio``
+/ ``configargparse`` (train.py:11, 985 import them, the hot path never touches
+them), make ``Tensor.get_device`` return the device object (the reference is
+CUDA-only as written: get_device() == -1 on CPU breaks every ``device=``
+argument), build ``ray_bending`` / ``NeRF`` with the arguments of
+train.py:564-630 (``create_nerf`` itself calls .cuda() unconditionally), load
+the seeded synthetic weights of ``nonrigid_nerf_amd.synthetic`` into them, and
+call the reference ``train.render`` -> ``batchify_rays`` -> ``render_rays``.
+
+Each fixture stores the seeds/config needed to regenerate the inputs and the
+reference outputs (fp32).  Weights are NOT stored (4 MB per scene): they are a
+pure function of the seed on torch's CPU generator.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from math import gcd
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = os.environ.get("NRNERF_REFERENCE", "/root/reference")
+
+from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for m in ("imageio", "configargparse"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    torch.Tensor.get_device = lambda self: self.device
+    import run_nerf_helpers as H
+    import train as T
+    T.DEBUG = False
+    T.device = torch.device("cpu")
+    return H, T
+
+
+def reference_kwargs(H, T, scene):
+    cfg = scene.cfg
+    S, I = cfg.N_samples, cfg.N_importance
+    embed_fn, input_ch = H.get_embedder(cfg.multires, 0)
+    rb = None
+    if scene.bender is not None:
+        rb = H.ray_bending(input_ch, cfg.latent_size, "simple_neural", embed_fn)
+        rb.load_state_dict({k: v.clone() for k, v in scene.bender.items()}, strict=True)
+    embeddirs_fn, input_ch_views = (None, 0)
+    netchunk = 1024 * 64
+    if cfg.use_viewdirs:
+        embeddirs_fn, input_ch_views = H.get_embedder(cfg.multires_views, 0)
+        lcm = S * (S + I) // gcd(S, S + I)
+        netchunk = (netchunk // lcm) * lcm                      # train.py:584-592
+
+    def mk(arrays, ns):
+        m = H.NeRF(D=cfg.netdepth, W=cfg.netwidth, input_ch=input_ch, output_ch=cfg.output_ch,
+                   skips=list(cfg.skips), input_ch_views=input_ch_views, use_viewdirs=cfg.use_viewdirs,
+                   ray_bender=rb, ray_bending_latent_size=cfg.latent_size, embeddirs_fn=embeddirs_fn,
+                   num_ray_samples=ns, approx_nonrigid_viewdirs=True,
+                   time_conditioned_baseline=cfg.time_conditioned_baseline)
+        m.load_state_dict({k: v.clone() for k, v in arrays.items()}, strict=True)
+        return m
+
+    coarse = mk(scene.coarse, S)
+    fine = mk(scene.fine, S + I) if scene.fine is not None else None
+
+    def network_query_fn(inputs, viewdirs, api, network_fn, detailed_output=False):   # train.py:633-649
+        return T.run_network(inputs, viewdirs, api, network_fn, embed_fn=embed_fn,
+                             embeddirs_fn=embeddirs_fn, netchunk=netchunk,
+                             detailed_output=detailed_output)
+
+    kw = dict(network_query_fn=network_query_fn, perturb=0.0, N_importance=I, network_fine=fine,
+              N_samples=S, network_fn=coarse, ray_bender=rb, use_viewdirs=cfg.use_viewdirs,
+              white_bkgd=False, raw_noise_std=0.0, ndc=False, lindisp=False,
+              near=cfg.near, far=cfg.far)                        # train.py:698-719
+    return kw, rb, coarse, fine
+
+
+CASES = {
+    # name: (SceneConfig kwargs, n_rays, chunk, detailed_output, retraw, knobs)
+    "coarse_only_1k":   (dict(N_importance=0), 1024, 32768, False, False, {}),
+    "headline_64_128":  (dict(), 192, 32768, False, True, {}),
+    "detailed_64_128":  (dict(), 24, 32768, True, True, {}),
+    "ragged_chunks":    (dict(N_importance=64), 37, 16, False, False, {}),
+    "knobs_64_64":      (dict(N_importance=64), 24, 32768, True, False,
+                         dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5, removal_threshold=0.6)),
+    "viewdirs_64_64":   (dict(N_importance=64, use_viewdirs=True), 48, 32768, False, True, {}),
+    "no_bender_64_64":  (dict(N_importance=64, ray_bending=False), 48, 32768, False, False, {}),
+}
+
+
+def run_case(H, T, name, seed=0):
+    cfg_kw, n, chunk, detailed, retraw, knobs = CASES[name]
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, seed)
+    rays, latents = make_rays(n, seed, cfg)
+    kw, rb, coarse, fine = reference_kwargs(H, T, scene)
+    if rb is not None:
+        rb.rigidity_test_time_cutoff = knobs.get("rigidity_test_time_cutoff")
+        rb.test_time_scaling = knobs.get("test_time_scaling")
+    for m in (coarse, fine):
+        if m is not None:
+            m.test_time_nonrigid_object_removal_threshold = knobs.get("removal_threshold")
+    rays_d = rays[:, 3:6]
+    with torch.no_grad():
+        rgb, disp, acc, extras = T.render(rays[:, 0:3], rays_d, chunk=chunk,
+                                          additional_pixel_information={"ray_bending_latents": latents},
+                                          detailed_output=detailed, retraw=retraw, **kw)
+    out = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, **extras}
+    arrays = {"out__" + k: v.detach().cpu().numpy().astype(np.float32) for k, v in out.items()}
+    meta = dict(seed=seed, n_rays=n, chunk=chunk, detailed=int(detailed), retraw=int(retraw))
+    arrays["meta_json"] = np.frombuffer(
+        __import__("json").dumps(dict(cfg=cfg_kw, knobs=knobs, **meta)).encode(), dtype=np.uint8)
+    # inputs are stored too so a generator drift is detected rather than silently re-based
+    arrays["in__rays"] = rays.numpy()
+    arrays["in__latents"] = latents.numpy()
+    return arrays, out
+
+
+def main():
+    H, T = import_reference()
+    os.makedirs(os.path.join(REPO, "tests", "golden"), exist_ok=True)
+    for name in CASES:
+        arrays, out = run_case(H, T, name)
+        path = os.path.join(REPO, "tests", "golden", name + ".npz")
+        np.savez_compressed(path, **arrays)
+        acc = out["acc_map"]
+        print(f"{name:18s} keys={len(out):2d} acc[min/mean/max]={acc.min():.3f}/{acc.mean():.3f}/{acc.max():.3f} "
+              f"nan_disp={int(torch.isnan(out['disp_map']).sum())} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

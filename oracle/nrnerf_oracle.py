@@ -1,0 +1,259 @@
+"""CPU oracle for the NR-NeRF per-ray hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a checker, not a product path: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  ``nonrigid_nerf_amd`` never imports anything under ``oracle/``;
+the product fails loudly if the HIP library is missing.
+
+What it is: a functional restatement, in plain PyTorch CPU ops, of the
+algorithm of ``render_rays`` (reference train.py:792-980) and everything it
+calls.  The reference's arithmetic *is* PyTorch eager ops (third-party
+``pytorch``, pinned =1.6.0 in environment.yml:8, torch 2.10 here), so the
+restatement uses the same primitives (linear, relu, sin/cos, cumprod, cumsum,
+searchsorted, sort) and is dtype-generic: fp32 gives the reference's own
+numbers, fp64 gives a higher-precision yardstick.
+
+Parity pinning: the reference ships no golden vectors or tests for this path
+(SURVEY.md section 4).  The oracle is therefore pinned against outputs of the
+reference itself, generated in the build container by ``oracle/make_golden.py``
+(which imports /root/reference unmodified) and committed under
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks the oracle against
+them bit-for-bit-tolerance on every run.
+
+Inputs are plain tensors and ``{state_dict key: tensor}`` dicts (see
+``nonrigid_nerf_amd.synthetic``), not modules.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class Knobs:
+    """Test-time editing knobs (free_viewpoint_rendering.py:264-283)."""
+    rigidity_test_time_cutoff: float | None = None     # run_nerf_helpers.py:563-564
+    test_time_scaling: float | None = None             # run_nerf_helpers.py:568-569
+    removal_threshold: float | None = None             # run_nerf_helpers.py:308-311
+
+
+def posenc(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
+    """[x, sin(2^k x), cos(2^k x)]_k  -- Embedder.embed, run_nerf_helpers.py:120-150.
+
+    Frequencies are ``2 ** linspace(0, L-1, L)`` = exact powers of two
+    (run_nerf_helpers.py:137, 157-164); layout: identity, then per frequency
+    sin(xyz) followed by cos(xyz).
+    """
+    cols = [x]
+    for k in range(n_freqs):
+        xs = x * float(2 ** k)
+        cols.append(torch.sin(xs))
+        cols.append(torch.cos(xs))
+    return torch.cat(cols, -1)
+
+
+def _lin(arrs, name, x, dtype):
+    w = arrs[name + ".weight"].to(dtype)
+    b = arrs.get(name + ".bias")
+    return F.linear(x, w, None if b is None else b.to(dtype))
+
+
+def bend_points(pts, latents, bender, knobs: Knobs | None = None):
+    """ray_bending.forward, run_nerf_helpers.py:507-584.
+
+    pts [M,3], latents [M,L] -> bent points [M,3] plus the three detail
+    tensors the reference exposes (unmasked_offsets, rigidity_mask,
+    masked_offsets).
+    """
+    dt = pts.dtype
+    knobs = knobs or Knobs()
+    n_off = 1 + max(int(k.split(".")[1]) for k in bender if k.startswith("network."))
+    h = torch.cat([pts, latents.to(dt)], -1)                       # :525
+    for i in range(n_off):
+        h = _lin(bender, f"network.{i}", h, dt)                    # :527
+        if i != n_off - 1:
+            h = F.relu(h)                                          # :533-536
+    unmasked = h
+    n_rig = 1 + max(int(k.split(".")[1]) for k in bender if k.startswith("rigidity_network."))
+    h = pts                                                        # :546
+    for i in range(n_rig):
+        h = _lin(bender, f"rigidity_network.{i}", h, dt)
+        if i != n_rig - 1:
+            h = F.relu(h)
+    mask = (torch.tanh(h) + 1) / 2                                 # :559-561
+    if knobs.rigidity_test_time_cutoff is not None:
+        mask = torch.where(mask <= knobs.rigidity_test_time_cutoff, torch.zeros_like(mask), mask)  # :563-564
+    masked = mask * unmasked                                       # :567
+    if knobs.test_time_scaling is not None:
+        masked = masked * knobs.test_time_scaling                  # :568-569
+    return pts + masked, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
+
+
+def finite_difference_dirs(bent, samples_per_ray: int):
+    """NeRF.viewdirs_via_finite_differences (backward), run_nerf_helpers.py:316-356."""
+    p = bent.view(-1, samples_per_ray, 3)
+    diff = p[:, 1:] - p[:, :-1]
+    diff = diff / (torch.norm(diff, dim=-1, keepdim=True) + 0.000001)
+    return torch.cat([diff[:, :1], diff], 1).reshape(-1, 3)
+
+
+def canonical_mlp(enc, net, cfg, enc_dirs=None, latents=None):
+    """NeRF.forward after bending, run_nerf_helpers.py:272-306."""
+    dt = enc.dtype
+    D = cfg.netdepth
+    x_in = enc if not cfg.time_conditioned_baseline else torch.cat([enc, latents.to(dt)], -1)  # :273-274
+    h = x_in
+    for i in range(D):
+        h = F.relu(_lin(net, f"pts_linears.{i}", h, dt))           # :276-277
+        if i in cfg.skips:
+            h = torch.cat([x_in, h], -1)                           # :278-282
+    if cfg.use_viewdirs:
+        alpha = _lin(net, "alpha_linear", h, dt)                   # :285
+        feat = _lin(net, "feature_linear", h, dt)                  # :286
+        h = F.relu(_lin(net, "views_linears.0", torch.cat([feat, enc_dirs], -1), dt))  # :296-301
+        return torch.cat([_lin(net, "rgb_linear", h, dt), alpha], -1)   # :303-304
+    return _lin(net, "output_linear", h, dt)                       # :306
+
+
+def query_network(pts, viewdirs, latents, net, bender, cfg, knobs=None, detailed=False):
+    """run_network + NeRF.forward (train.py:57-105, run_nerf_helpers.py:240-314).
+
+    pts [N,S,3]; viewdirs [N,3] or None; latents [N,L].  Returns raw [N,S,C]
+    and (if ``detailed``) the per-sample detail dict, reshaped [N,S,-1].
+    """
+    N, S, _ = pts.shape
+    dt = pts.dtype
+    flat = pts.reshape(-1, 3)
+    lat = latents[:, None, :].expand(N, S, latents.shape[-1]).reshape(N * S, -1)   # train.py:79-87
+    details = {}
+    if detailed:
+        details["initial_input_pts"] = flat.clone()                # rnh:250-252
+    if bender is not None:
+        bent, bd = bend_points(flat, lat, bender, knobs)           # rnh:268
+        if detailed:
+            details.update(bd)
+    else:
+        bent = flat
+    if detailed:
+        details["input_pts"] = bent.clone()                        # rnh:270
+    enc = posenc(bent, cfg.multires)                               # rnh:582-584
+    enc_dirs = None
+    if cfg.use_viewdirs:
+        if bender is not None:
+            dirs = finite_difference_dirs(bent, S)                 # rnh:288-290
+        else:
+            dirs = viewdirs[:, None, :].expand(N, S, 3).reshape(-1, 3).to(dt)   # train.py:73-76
+        enc_dirs = posenc(dirs, cfg.multires_views)
+    raw = canonical_mlp(enc, net, cfg, enc_dirs, lat)
+    if detailed and knobs is not None and knobs.removal_threshold is not None and bender is not None:
+        kill = details["rigidity_mask"].flatten() >= knobs.removal_threshold       # rnh:308-311
+        raw = raw.clone()
+        raw[kill, 3] *= 0.0
+    raw = raw.reshape(N, S, -1)
+    if detailed:
+        details = {k: v.reshape(N, S, -1) for k, v in details.items()}             # train.py:95-98
+        return raw, details
+    return raw
+
+
+def composite(raw, z_vals, rays_d):
+    """raw2outputs (raw_noise_std=0, white_bkgd=False), train.py:724-789."""
+    dists = z_vals[..., 1:] - z_vals[..., :-1]                                     # :743
+    dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)          # :744-746
+    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)                       # :748
+    rgb = torch.sigmoid(raw[..., :3])                                              # :750
+    alpha = 1.0 - torch.exp(-F.relu(raw[..., 3]) * dists)                          # :740-741, 761
+    trans = torch.cumprod(
+        torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]   # :763-775
+    weights = alpha * trans
+    rgb_map = torch.sum(weights[..., None] * rgb, -2)                              # :776
+    depth_map = torch.sum(weights * z_vals, -1)                                    # :778
+    acc_map = torch.sum(weights, -1)                                               # :779
+    disp_map = 1.0 / torch.max(1e-10 * torch.ones_like(depth_map), depth_map / acc_map)   # :781-784
+    return rgb_map, disp_map, acc_map, alpha, weights, depth_map
+
+
+def sample_pdf_det(bins, weights, n_samples: int):
+    """sample_pdf with det=True (test time), run_nerf_helpers.py:651-698."""
+    weights = weights + 1e-5                                                       # :654
+    pdf = weights / torch.sum(weights, -1, keepdim=True)                           # :655
+    cdf = torch.cumsum(pdf, -1)                                                    # :656
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)                     # :657-659
+    u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=torch.float32).to(cdf.dtype)   # :663
+    u = u.expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()                  # :664, 680
+    inds = torch.searchsorted(cdf, u, right=False)                                 # :681
+    below = torch.clamp(inds - 1, min=0)                                           # :683
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)                               # :684
+    cdf_lo, cdf_hi = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)    # :690
+    bin_lo, bin_hi = torch.gather(bins, -1, below), torch.gather(bins, -1, above)  # :691
+    denom = cdf_hi - cdf_lo                                                        # :693
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)               # :694
+    t = (u - cdf_lo) / denom                                                       # :695
+    return bin_lo + t * (bin_hi - bin_lo)                                          # :696
+
+
+def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=False,
+                knobs: Knobs | None = None, dtype=torch.float32):
+    """render_rays with perturb=0, raw_noise_std=0, lindisp=False (train.py:792-980).
+
+    ``scene`` is a ``nonrigid_nerf_amd.synthetic.Scene`` (or anything with
+    ``cfg``, ``bender``, ``coarse``, ``fine``).  Output dict: same keys/shapes
+    as the reference.
+    """
+    cfg = scene.cfg
+    S, I = cfg.N_samples, cfg.N_importance
+    if I == 0 and detailed_output:
+        # train.py:900-908 vs 967-970: the reference itself raises here.
+        raise UnboundLocalError("reference render_rays cannot do detailed_output with N_importance == 0")
+    rb = ray_batch.to(dtype)
+    rays_o, rays_d = rb[:, 0:3], rb[:, 3:6]                                        # :842
+    viewdirs = rb[:, -3:] if rb.shape[-1] > 8 else None                            # :843
+    near, far = rb[:, 6:7], rb[:, 7:8]                                             # :844-845
+    t_vals = torch.linspace(0.0, 1.0, steps=S, dtype=torch.float32).to(dtype)      # :847
+    z_vals = (near * (1.0 - t_vals) + far * t_vals).expand(rb.shape[0], S)         # :849, 853
+    pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]             # :871-873
+    lat = latents.to(dtype)
+    out = query_network(pts, viewdirs, lat, scene.coarse, scene.bender, cfg, knobs, detailed_output)
+    raw, details = out if detailed_output else (out, None)
+    rgb_map, disp_map, acc_map, alpha, weights, _ = composite(raw, z_vals, rays_d)  # :898
+    ret = {}
+    if I > 0:
+        rgb0, disp0, acc0, alpha0, weights0 = rgb_map, disp_map, acc_map, alpha, weights   # :902-908
+        z_mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])                         # :910
+        z_samples = sample_pdf_det(z_mid, weights[..., 1:-1], I)                   # :911-918
+        z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)             # :920
+        pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]         # :921-923
+        net = scene.fine if scene.fine is not None else scene.coarse               # :925
+        out = query_network(pts, viewdirs, lat, net, scene.bender, cfg, knobs, detailed_output)
+        raw, fine_details = out if detailed_output else (out, None)
+        rgb_map, disp_map, acc_map, alpha, weights, _ = composite(raw, z_vals, rays_d)   # :943-950
+    ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)                # :952
+    if retraw:
+        ret["raw"] = raw                                                           # :953-954
+    if I > 0:
+        ret.update(rgb0=rgb0, disp0=disp0, acc0=acc0,
+                   z_std=torch.std(z_samples, dim=-1, unbiased=False))             # :955-959
+        if detailed_output:
+            ret["fine_visibility_weights"] = weights                               # :962
+            ret["fine_opacity_alpha"] = alpha                                      # :964
+            for k, v in fine_details.items():
+                ret["fine_" + k] = v                                               # :965-966
+    if detailed_output:
+        ret["visibility_weights"] = weights0                                       # :969
+        ret["opacity_alpha"] = alpha0                                              # :970
+        ret.update(details)                                                        # :971-972
+    # internal extra (not a reference key): the merged sample depths, handy for stage-wise parity
+    ret["_z_vals"] = z_vals
+    return ret
+
+
+def batchify_rays(rays_flat, latents, scene, chunk=1024 * 32, **kw):
+    """batchify_rays, train.py:108-137: chunk loop + per-key concatenation."""
+    pieces = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        r = render_rays(rays_flat[i:i + chunk], latents[i:i + chunk], scene, **kw)
+        for k, v in r.items():
+            pieces.setdefault(k, []).append(v)
+    return {k: torch.cat(v, 0) for k, v in pieces.items()}
