@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""Headline benchmark: rendered rays/s of the NR-NeRF per-ray hot path at 64+128 samples/ray.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one ``batchify_rays`` pass (reference train.py:108-137) over one 512x384 frame worth of
+synthetic rays per GPU (196 608 rays = the reference's 6 chunks of 32 768; BASELINE.json config 2:
+64 coarse + 128 importance samples, 8x256 canonical MLPs + ray bender, bf16 contractions with fp32
+accumulation) with inputs already resident in HBM, plus -- for N > 1 -- the all-gather of the rendered
+pixels over RCCL/xGMI (config 3).  Weak scaling: every rank renders its own frame-sized shard.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  "roofline":     the dominant kernel (fine-pass network kernel) against the dense bf16 MFMA peak, from
+                  HIP events recorded around that kernel on the render stream during the timed steps;
+  "cpu_baseline": the CPU oracle (a PyTorch-CPU port of the reference path, oracle/nrnerf_oracle.py)
+                  timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}       # dense MFMA, MI355X_MICROARCH.md
+ALGO_MFLOP_PER_RAY = 260.18                                        # SURVEY.md section 8d (64 + 192 evaluations)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=196608, help="rays per GPU per step (default: one 512x384 frame)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the same workload timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from nonrigid_nerf_amd import render as R
+    from nonrigid_nerf_amd.distributed import gather_pixels
+    from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
+
+    cfg = SceneConfig()                                   # 64 + 128, W = 256, bender on, latent 32
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = build_modules(scene, device=dev)
+    R.set_precision(args.precision)
+    rays, latents = make_rays(args.rays, seed=100 + rank, cfg=cfg)
+    rays, latents = rays.to(dev), latents.to(dev)
+    api = {"ray_bending_latents": latents}
+    kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples,
+              N_importance=cfg.N_importance, perturb=0.0, raw_noise_std=0.0)
+    model = R.get_model(coarse, fine, device=dev)          # weights packed once, outside the timed region
+
+    def step():
+        out = R.batchify_rays(rays, api, chunk=1024 * 32, **kw)
+        packed = torch.cat([out["rgb_map"], out["disp_map"][:, None], out["acc_map"][:, None]], -1)
+        return gather_pixels(packed) if world > 1 else packed
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        model.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = model.profile_end()
+    assert img.shape == (world * args.rays, 5)
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_rays = world * args.rays * args.steps
+    value = total_rays / dt
+
+    if rank == 0:
+        k = prof["net_fine"]
+        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        peak = PEAK_TFLOPS[args.precision]
+        roofline = {"bound": "mfma", "kernel": "net_kernel (fine pass, 192 samples/ray)",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
+                    "issued_mfma_tflops": round(k["mfma_flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else 0.0,
+                    "traffic": None,
+                    "other_kernels_ms_per_step": {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()}}
+        res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": "BASELINE config 2: example_sequence-shaped frame (512x384 = 196608 rays/GPU/step), "
+                                      "64 coarse + 128 importance samples, netwidth 256, ray bender on, latent 32",
+                          "rays_per_gpu_per_step": args.rays, "N_samples": 64, "N_importance": 128,
+                          "parallelism": f"rays sharded over {world} rank(s)" + (", all-gather of [rgb,disp,acc] over RCCL" if world > 1 else "")},
+               "mflop_per_ray_algorithmic": ALGO_MFLOP_PER_RAY,
+               "end_to_end_tflops": round(value * ALGO_MFLOP_PER_RAY * 1e6 / 1e12, 2),
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(scene, cfg, args.cpu_rays)
+        print(json.dumps(res), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, cfg, n):
+    """The CPU oracle (PyTorch-CPU port of reference render_rays/batchify_rays) on ``n`` rays of the same workload."""
+    from nonrigid_nerf_amd.synthetic import make_rays
+    from oracle import nrnerf_oracle as O
+    rays, latents = make_rays(n, seed=100, cfg=cfg)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        O.batchify_rays(rays[:1024], latents[:1024], scene, chunk=1024)      # warm-up
+        t0 = time.perf_counter()
+        O.batchify_rays(rays, latents, scene, chunk=1024)
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{n} rays of the same 64+128 workload, chunk 1024, torch {torch.__version__} CPU, "
+                      f"{threads} threads of {os.cpu_count()} host cores, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/*
+ * nrnerf.h -- C ABI of libnrnerf_hip.so: the MI355X-native per-ray renderer that
+ * replaces NR-NeRF's render_rays / batchify_rays hot path.
+ *
+ * Boundary being replaced (reference facebookresearch/nonrigid_nerf):
+ *   batchify_rays          train.py:108-137   (chunk loop; subsumed: one nrnerf_render call takes any n_rays)
+ *   render_rays            train.py:792-980   (whole per-ray algorithm)
+ *     run_network/batchify train.py:57-105, 27-54
+ *     Embedder.embed       run_nerf_helpers.py:120-168
+ *     NeRF.forward         run_nerf_helpers.py:240-314
+ *     ray_bending.forward  run_nerf_helpers.py:507-584
+ *     raw2outputs          train.py:724-789
+ *     sample_pdf           run_nerf_helpers.py:651-698
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer in nrnerf_render_args is a DEVICE pointer the
+ *     caller owns (inputs, outputs and workspace).  nrnerf_render allocates nothing.
+ *   - weights in nrnerf_model_desc are HOST pointers, fp32, PyTorch nn.Linear layout
+ *     ([out_features, in_features] row-major); they are packed into MFMA fragment order and
+ *     copied to the device once, at nrnerf_model_create.
+ *   - every function returns 0 (NRNERF_OK) or a negative nrnerf_status; nothing throws or
+ *     aborts across the ABI.  nrnerf_render is asynchronous on the given hipStream_t.
+ *   - no global mutable state: safe to call from several host threads on different devices /
+ *     models (the reference's DataParallel wrapper does that, train.py:300-323).
+ */
+#ifndef NRNERF_H
+#define NRNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRNERF_ABI_VERSION 1
+
+typedef enum nrnerf_status {
+    NRNERF_OK = 0,
+    NRNERF_ERR_INVALID = -1,      /* bad argument (null pointer, negative size, misaligned buffer) */
+    NRNERF_ERR_UNSUPPORTED = -2,  /* architecture / flag combination this build has no kernel for */
+    NRNERF_ERR_HIP = -3,          /* a HIP runtime call failed (no device, launch failure, ...) */
+    NRNERF_ERR_WORKSPACE = -4,    /* workspace smaller than nrnerf_workspace_bytes() */
+    NRNERF_ERR_NOMEM = -5
+} nrnerf_status;
+
+/* arithmetic type of the MLP contractions (accumulation is always fp32; positional encoding,
+ * point generation, compositing and sampling are always fp32) */
+typedef enum nrnerf_precision {
+    NRNERF_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32, the parity mode */
+    NRNERF_PREC_BF16 = 1,  /* v_mfma_f32_32x32x16_bf16: the headline throughput mode */
+    NRNERF_PREC_F16 = 2    /* v_mfma_f32_32x32x16_f16 */
+} nrnerf_precision;
+
+/* one nn.Linear: weight [out_features, in_features] row-major fp32, bias [out_features] or NULL */
+typedef struct nrnerf_linear {
+    const float* weight;
+    const float* bias;
+    int32_t out_features;
+    int32_t in_features;
+} nrnerf_linear;
+
+/* canonical NeRF MLP (reference NeRF.__init__, run_nerf_helpers.py:172-238) */
+typedef struct nrnerf_mlp_desc {
+    int32_t depth;            /* D: number of pts_linears (8) */
+    int32_t width;            /* W (256) */
+    int32_t skip;             /* index i after which [input, h] are concatenated (4); -1 = none */
+    int32_t output_ch;        /* rows of output_linear (4, or 5 when N_importance > 0; train.py:593) */
+    int32_t use_viewdirs;     /* 0: output_linear head; 1: alpha/feature/views/rgb head */
+    int32_t time_conditioned; /* naive baseline: latent appended to the net input (rnh:207-209) */
+    const nrnerf_linear* pts_linears;   /* [depth] */
+    nrnerf_linear output_linear;        /* use_viewdirs == 0 */
+    nrnerf_linear alpha_linear;         /* use_viewdirs == 1 ... */
+    nrnerf_linear feature_linear;
+    nrnerf_linear views_linear;         /* views_linears[0] */
+    nrnerf_linear rgb_linear;
+} nrnerf_mlp_desc;
+
+/* ray-bending deformation + rigidity networks (reference ray_bending, run_nerf_helpers.py:388-505) */
+typedef struct nrnerf_bender_desc {
+    int32_t latent_size;      /* 32 */
+    int32_t depth;            /* network_depth (5) */
+    int32_t hidden;           /* hidden_dimensions (64) */
+    int32_t rigidity_depth;   /* 3 */
+    int32_t rigidity_hidden;  /* 32 */
+    const nrnerf_linear* network;           /* [depth]; last layer has bias == NULL */
+    const nrnerf_linear* rigidity_network;  /* [rigidity_depth] */
+} nrnerf_bender_desc;
+
+typedef struct nrnerf_model_desc {
+    uint32_t struct_size;     /* sizeof(nrnerf_model_desc), for forward compatibility */
+    int32_t precision;        /* nrnerf_precision */
+    int32_t multires;         /* L of the xyz encoding (10) */
+    int32_t multires_views;   /* L of the direction encoding (4); ignored without viewdirs */
+    int32_t device;           /* HIP device ordinal the model lives on */
+    const nrnerf_bender_desc* bender;   /* NULL: no ray bending (plain NeRF) */
+    const nrnerf_mlp_desc* coarse;      /* network_fn */
+    const nrnerf_mlp_desc* fine;        /* network_fine; NULL: reuse coarse (train.py:925) */
+} nrnerf_model_desc;
+
+typedef struct nrnerf_model nrnerf_model;   /* opaque: packed weights resident in HBM */
+
+/* per-sample detail tensors of one pass ("detailed_output", train.py:960-972); any may be NULL */
+typedef struct nrnerf_sample_outputs {
+    float* visibility_weights;  /* [N, S]    */
+    float* opacity_alpha;       /* [N, S]    */
+    float* initial_input_pts;   /* [N, S, 3] */
+    float* unmasked_offsets;    /* [N, S, 3] */
+    float* masked_offsets;      /* [N, S, 3] */
+    float* input_pts;           /* [N, S, 3]  bent points */
+    float* rigidity_mask;       /* [N, S, 1] */
+} nrnerf_sample_outputs;
+
+typedef struct nrnerf_render_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_render_args) */
+    int32_t n_rays;             /* N (any size; the chunk loop of batchify_rays is not needed) */
+    int32_t n_samples;          /* N_samples  (S, coarse)        <= 256 */
+    int32_t n_importance;       /* N_importance (I); S' = S + I   <= 256 */
+    /* inputs */
+    const float* rays;          /* [N, ray_stride]: o3, d3, near, far (, unit viewdir3)  train.py:397-399 */
+    int32_t ray_stride;         /* floats per row: 8 or 11 */
+    const float* latents;       /* [N, latent_size] ray_bending_latents; may be NULL without bender */
+    int32_t latent_stride;      /* floats between rows; 0 = one code broadcast to every ray */
+    /* test-time editing knobs, read per call (free_viewpoint_rendering.py:264-283) */
+    int32_t has_rigidity_cutoff;   float rigidity_cutoff;     /* mask[mask <= cutoff] = 0   rnh:563-564 */
+    int32_t has_test_time_scaling; float test_time_scaling;   /* masked_offsets *= scaling  rnh:568-569 */
+    int32_t has_removal_threshold; float removal_threshold;   /* sigma *= 0 where mask >= thr; applied only
+                                                                  when per-sample details are requested, as in
+                                                                  the reference (rnh:308-311) */
+    int32_t detailed_output;    /* mirrors the reference flag (gates the removal threshold) */
+    /* outputs: final pass (fine if I > 0, else coarse) */
+    float* rgb_map;             /* [N, 3] */
+    float* disp_map;            /* [N]    */
+    float* acc_map;             /* [N]    */
+    float* raw;                 /* [N, S', C] or NULL ("retraw"); C = output_ch, or 4 with viewdirs */
+    /* outputs: coarse pass when I > 0 (NULL allowed) */
+    float* rgb0;                /* [N, 3] */
+    float* disp0;               /* [N]    */
+    float* acc0;                /* [N]    */
+    float* z_std;               /* [N]    */
+    float* z_vals;              /* [N, S'] merged, sorted sample depths (not a reference key; NULL allowed) */
+    nrnerf_sample_outputs coarse;   /* keys without prefix  */
+    nrnerf_sample_outputs fine;     /* keys with "fine_" prefix (I > 0) */
+    /* scratch */
+    void* workspace;            /* >= nrnerf_workspace_bytes(), 256-byte aligned */
+    size_t workspace_bytes;
+} nrnerf_render_args;
+
+/* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */
+#define NRNERF_NUM_KERNELS 4
+typedef struct nrnerf_profile {
+    /* 0: coarse network, 1: coarse composite+sample_pdf+merge, 2: fine network, 3: fine composite */
+    double ms[NRNERF_NUM_KERNELS];
+    int64_t launches[NRNERF_NUM_KERNELS];
+    double flops[NRNERF_NUM_KERNELS];        /* algorithmic 2*MAC, unpadded */
+    double mfma_flops[NRNERF_NUM_KERNELS];   /* issued MFMA flops incl. padding */
+} nrnerf_profile;
+
+int nrnerf_abi_version(void);
+const char* nrnerf_strerror(int status);
+
+int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out);
+void nrnerf_model_destroy(nrnerf_model* model);
+
+size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples,
+                              int32_t n_importance);
+
+/* hip_stream: a hipStream_t (NULL = the null stream).  Asynchronous. */
+int nrnerf_render(const nrnerf_model* model, const nrnerf_render_args* args, void* hip_stream);
+
+/* profiling: records hipEvents around each kernel of subsequent nrnerf_render calls on this model */
+int nrnerf_profile_begin(nrnerf_model* model);
+int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchronises the recorded events */
+
+/* Host-only packing (no device needed): writes the MFMA-fragment weight stream + unit table + bias
+ * table of one pass exactly as nrnerf_model_create uploads them.  which: 0 = coarse, 1 = fine.
+ * Any output pointer may be NULL to query sizes only.  Used by the CPU-side packing tests. */
+typedef struct nrnerf_packed_info {
+    uint64_t stream_bytes;     /* fragment stream */
+    uint32_t n_units;          /* unit table has n_units + 1 uint32 entries (offsets in 16-byte words) */
+    uint32_t n_bias_tiles;     /* bias table: n_bias_tiles * 32 floats */
+    uint32_t frag_bytes;       /* 1024 (bf16/f16) or 256 (f32) */
+    uint32_t slot_bytes;       /* LDS ring slot size the kernel uses */
+    uint32_t mfma_per_block;   /* MFMA instructions per 32-sample block */
+} nrnerf_packed_info;
+int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_info* info,
+                     void* stream_out, size_t stream_cap, uint32_t* unit_table_out,
+                     float* bias_table_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRNERF_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of ``lib/libnrnerf_hip.so`` (C ABI: ``include/nrnerf.h``).
+
+The structures below mirror the header field for field.  There is no fallback: if the
+shared library is missing or does not load, importing the render path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnrnerf_hip.so")
+
+ABI_VERSION = 1
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
+PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
+NUM_KERNELS = 4
+KERNEL_NAMES = ("net_coarse", "composite_sample_coarse", "net_fine", "composite_fine")
+
+_fp = C.POINTER(C.c_float)
+
+
+class Linear(C.Structure):
+    _fields_ = [("weight", _fp), ("bias", _fp), ("out_features", C.c_int32), ("in_features", C.c_int32)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("width", C.c_int32), ("skip", C.c_int32), ("output_ch", C.c_int32),
+                ("use_viewdirs", C.c_int32), ("time_conditioned", C.c_int32),
+                ("pts_linears", C.POINTER(Linear)),
+                ("output_linear", Linear), ("alpha_linear", Linear), ("feature_linear", Linear),
+                ("views_linear", Linear), ("rgb_linear", Linear)]
+
+
+class BenderDesc(C.Structure):
+    _fields_ = [("latent_size", C.c_int32), ("depth", C.c_int32), ("hidden", C.c_int32),
+                ("rigidity_depth", C.c_int32), ("rigidity_hidden", C.c_int32),
+                ("network", C.POINTER(Linear)), ("rigidity_network", C.POINTER(Linear))]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("precision", C.c_int32), ("multires", C.c_int32),
+                ("multires_views", C.c_int32), ("device", C.c_int32),
+                ("bender", C.POINTER(BenderDesc)), ("coarse", C.POINTER(MlpDesc)), ("fine", C.POINTER(MlpDesc))]
+
+
+class SampleOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("visibility_weights", "opacity_alpha", "initial_input_pts",
+                                           "unmasked_offsets", "masked_offsets", "input_pts", "rigidity_mask")]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+                ("n_importance", C.c_int32),
+                ("rays", C.c_void_p), ("ray_stride", C.c_int32),
+                ("latents", C.c_void_p), ("latent_stride", C.c_int32),
+                ("has_rigidity_cutoff", C.c_int32), ("rigidity_cutoff", C.c_float),
+                ("has_test_time_scaling", C.c_int32), ("test_time_scaling", C.c_float),
+                ("has_removal_threshold", C.c_int32), ("removal_threshold", C.c_float),
+                ("detailed_output", C.c_int32),
+                ("rgb_map", C.c_void_p), ("disp_map", C.c_void_p), ("acc_map", C.c_void_p), ("raw", C.c_void_p),
+                ("rgb0", C.c_void_p), ("disp0", C.c_void_p), ("acc0", C.c_void_p), ("z_std", C.c_void_p),
+                ("z_vals", C.c_void_p),
+                ("coarse", SampleOutputs), ("fine", SampleOutputs),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * NUM_KERNELS), ("launches", C.c_int64 * NUM_KERNELS),
+                ("flops", C.c_double * NUM_KERNELS), ("mfma_flops", C.c_double * NUM_KERNELS)]
+
+
+class PackedInfo(C.Structure):
+    _fields_ = [("stream_bytes", C.c_uint64), ("n_units", C.c_uint32), ("n_bias_tiles", C.c_uint32),
+                ("frag_bytes", C.c_uint32), ("slot_bytes", C.c_uint32), ("mfma_per_block", C.c_uint32)]
+
+
+EXPORTS = {
+    "nrnerf_abi_version": (C.c_int, []),
+    "nrnerf_strerror": (C.c_char_p, [C.c_int]),
+    "nrnerf_model_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    "nrnerf_model_destroy": (None, [C.c_void_p]),
+    "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
+    "nrnerf_profile_begin": (C.c_int, [C.c_void_p]),
+    "nrnerf_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
+    "nrnerf_pack_host": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(PackedInfo), C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_uint32), _fp]),
+}
+
+_lib = None
+
+
+class NrnerfError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        super().__init__(f"{where}: {strerror(status)} (status {status})")
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises if it is missing: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C nonrigid_nerf_amd/csrc -j8`). nonrigid_nerf_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)          # AttributeError if the .so does not export what nrnerf.h declares
+            fn.restype, fn.argtypes = res, args
+        v = lib.nrnerf_abi_version()
+        if v != ABI_VERSION:
+            raise ImportError(f"libnrnerf_hip.so ABI version {v}, binding expects {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def strerror(status: int) -> str:
+    return load().nrnerf_strerror(status).decode()
+
+
+def check(status: int, where: str):
+    if status != OK:
+        raise NrnerfError(status, where)

@@ -1,0 +1,450 @@
+// nrnerf_api.cpp -- C ABI of libnrnerf_hip.so (include/nrnerf.h): weight packing into the MFMA
+// fragment stream described by nrnerf_plan.h, model lifetime, workspace carving, kernel sequencing.
+//
+// Kernel sequence of one nrnerf_render call (reference render_rays, train.py:792-980):
+//   K0  network kernel, coarse weights, z = linspace(near, far, S)        -> raw_c [N,S,4]
+//   K1  composite (+ sample_pdf + merge + z_std when I > 0)               -> rgb0/disp0/acc0 or final; z_fine [N,S+I]
+//   K2  network kernel, fine weights, z = z_fine                          -> raw_f [N,S+I,4]
+//   K3  composite                                                         -> rgb/disp/acc
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "nrnerf.h"
+#include "nrnerf_kernels.h"
+#include "nrnerf_plan.h"
+
+using namespace nrn;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// host-side element conversion
+// ------------------------------------------------------------------------------------------
+inline uint16_t f32_to_bf16(float f) {       // round to nearest even, NaN preserved
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline uint16_t f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+struct PackedPass {
+    std::vector<uint8_t> stream;
+    std::vector<uint32_t> unit_off;   // nunits + 1, in 16-byte words
+    std::vector<float> bias;          // ntiles * 32
+    int ntiles = 0, nunits = 0, frag_bytes = 0, slot_bytes = 0, mfma_per_block = 0;
+};
+
+const nrnerf_linear* layer_source(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, const LayerSpec& sp) {
+    switch (sp.kind) {
+        case LK_BEND_IN: case LK_BEND_HID: case LK_BEND_OUT: return &d.bender->network[sp.index];
+        case LK_RIG_IN: case LK_RIG_HID: case LK_RIG_OUT: return &d.bender->rigidity_network[sp.index];
+        case LK_TR_IN: case LK_TR_HID: case LK_TR_SKIP: return &mlp.pts_linears[sp.index];
+        case LK_HEAD: return &mlp.output_linear;
+    }
+    return nullptr;
+}
+
+template <class SH, class A, bool HAS_BEND>
+void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out) {
+    using PL = Plan<SH, A, HAS_BEND>;
+    constexpr int KH = SH::KH;
+    const Tables& T = PL::TB;
+    out.ntiles = T.ntiles; out.nunits = T.nunits;
+    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = PL::SLOT_BYTES; out.mfma_per_block = T.mfma_per_block;
+    size_t nfrags = 0;
+    for (int l = 0; l < T.nlayers; ++l) nfrags += (size_t)T.layers[l].ns * T.layers[l].nt;
+    out.stream.assign(nfrags * SH::FRAG_BYTES, 0);
+    out.unit_off.assign(T.nunits + 1, 0);
+    out.bias.assign((size_t)T.ntiles * 32, 0.0f);
+    size_t pos = 0;
+    for (int l = 0; l < T.nlayers; ++l) {
+        const LayerSpec& sp = T.layers[l];
+        const nrnerf_linear* lin = layer_source(d, mlp, sp);
+        for (int t = 0; t < sp.nt; ++t) {
+            const TileInfo& ti = T.tiles[sp.tile0 + t];
+            if (ti.starts_unit) out.unit_off[ti.unit] = (uint32_t)(pos / 16);
+            for (int s = 0; s < sp.ns; ++s) {
+                uint8_t* fr = out.stream.data() + pos;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    const int row = out_row<A>(sp.kind, t, i, lin->out_features);
+                    for (int e = 0; e < KH; ++e) {
+                        const int col = in_col<SH, A>(sp.kind, s, h, e, lin->in_features);
+                        const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
+                        if (KH == 1) {
+                            std::memcpy(fr + lane * 4, &w, 4);
+                        } else {
+                            const uint16_t q = (precision == NRNERF_PREC_BF16) ? f32_to_bf16(w) : f32_to_f16(w);
+                            std::memcpy(fr + (lane * KH + e) * 2, &q, 2);
+                        }
+                    }
+                }
+                pos += SH::FRAG_BYTES;
+            }
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = out_row<A>(sp.kind, t, tile_row(r, h), lin->out_features);
+                    out.bias[(size_t)(sp.tile0 + t) * 32 + h * 16 + r] = (row >= 0 && lin->bias) ? lin->bias[row] : 0.0f;
+                }
+        }
+    }
+    out.unit_off[T.nunits] = (uint32_t)(pos / 16);
+}
+
+bool linear_is(const nrnerf_linear& l, int out_f, int in_f, bool need_bias) {
+    return l.weight && l.out_features == out_f && l.in_features == in_f && (!need_bias || l.bias);
+}
+
+// Does (desc, mlp) match the architecture this build has kernels for?  (ArchDefault: 8x256 trunk with
+// skip after layer 4, L = 10, bender 5x64, rigidity 3x32, latent 32, no view-dependent head.)
+int check_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
+    using A = ArchDefault;
+    if (d.precision < 0 || d.precision > 2) return NRNERF_ERR_INVALID;
+    if (d.multires != A::L) return NRNERF_ERR_UNSUPPORTED;
+    if (m.use_viewdirs || m.time_conditioned) return NRNERF_ERR_UNSUPPORTED;
+    if (m.depth != A::D || m.width != A::W || m.skip != A::SKIP) return NRNERF_ERR_UNSUPPORTED;
+    if (m.output_ch != 4 && m.output_ch != 5) return NRNERF_ERR_UNSUPPORTED;
+    if (!m.pts_linears) return NRNERF_ERR_INVALID;
+    const int enc = 3 + 6 * A::L;
+    for (int i = 0; i < A::D; ++i) {
+        const int in_f = (i == 0) ? enc : ((i - 1 == A::SKIP) ? A::W + enc : A::W);
+        if (!linear_is(m.pts_linears[i], A::W, in_f, true)) return NRNERF_ERR_INVALID;
+    }
+    if (!linear_is(m.output_linear, m.output_ch, A::W, true)) return NRNERF_ERR_INVALID;
+    if (d.bender) {
+        const nrnerf_bender_desc& b = *d.bender;
+        if (b.latent_size != A::LAT || b.depth != A::BD || b.hidden != A::BW || b.rigidity_depth != A::RD ||
+            b.rigidity_hidden != A::RW)
+            return NRNERF_ERR_UNSUPPORTED;
+        if (!b.network || !b.rigidity_network) return NRNERF_ERR_INVALID;
+        for (int i = 0; i < A::BD; ++i) {
+            const int in_f = (i == 0) ? 3 + A::LAT : A::BW, out_f = (i == A::BD - 1) ? 3 : A::BW;
+            if (!linear_is(b.network[i], out_f, in_f, i != A::BD - 1)) return NRNERF_ERR_INVALID;
+        }
+        for (int i = 0; i < A::RD; ++i) {
+            const int in_f = (i == 0) ? 3 : A::RW, out_f = (i == A::RD - 1) ? 1 : A::RW;
+            if (!linear_is(b.rigidity_network[i], out_f, in_f, true)) return NRNERF_ERR_INVALID;
+        }
+    }
+    return NRNERF_OK;
+}
+
+int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out) {
+    int rc = check_arch(d, m);
+    if (rc != NRNERF_OK) return rc;
+    using A = ArchDefault;
+    const bool bend = d.bender != nullptr;
+    if (d.precision == NRNERF_PREC_F32) {
+        if (bend) pack_pass<ShapeF32, A, true>(d, m, d.precision, out); else pack_pass<ShapeF32, A, false>(d, m, d.precision, out);
+    } else {
+        if (bend) pack_pass<Shape16, A, true>(d, m, d.precision, out); else pack_pass<Shape16, A, false>(d, m, d.precision, out);
+    }
+    return NRNERF_OK;
+}
+
+// algorithmic MACs per sample, unpadded
+double algo_macs(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
+    double macs = 0;
+    for (int i = 0; i < m.depth; ++i) macs += (double)m.pts_linears[i].in_features * m.pts_linears[i].out_features;
+    macs += (double)m.output_linear.in_features * m.output_linear.out_features;
+    if (d.bender) {
+        for (int i = 0; i < d.bender->depth; ++i) macs += (double)d.bender->network[i].in_features * d.bender->network[i].out_features;
+        for (int i = 0; i < d.bender->rigidity_depth; ++i)
+            macs += (double)d.bender->rigidity_network[i].in_features * d.bender->rigidity_network[i].out_features;
+    }
+    return macs;
+}
+
+struct PassDev {
+    void* stream = nullptr;
+    uint32_t* unit_off = nullptr;
+    float* bias = nullptr;
+    double algo_flops_per_sample = 0;      // 2 * MAC
+    double mfma_flops_per_sample = 0;      // issued, incl. padding
+    int output_ch = 4;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct nrnerf_model {
+    int device = 0, precision = 0, has_bend = 0, num_cus = 0, latent_size = 0;
+    PassDev coarse, fine;
+    bool fine_is_coarse = false;
+    // profiling (guarded; the render path itself is otherwise read-only on the handle)
+    mutable std::mutex prof_mu;
+    mutable bool prof_on = false;
+    struct Ev { int kernel; hipEvent_t a, b; double flops, mfma; };
+    mutable std::vector<Ev> prof_events;
+};
+
+namespace {
+
+int upload_pass(const PackedPass& pk, PassDev& dev) {
+    if (hipMalloc(&dev.stream, pk.stream.size()) != hipSuccess) return NRNERF_ERR_NOMEM;
+    if (hipMalloc((void**)&dev.unit_off, pk.unit_off.size() * 4) != hipSuccess) return NRNERF_ERR_NOMEM;
+    if (hipMalloc((void**)&dev.bias, pk.bias.size() * 4) != hipSuccess) return NRNERF_ERR_NOMEM;
+    if (hipMemcpy(dev.stream, pk.stream.data(), pk.stream.size(), hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
+    if (hipMemcpy(dev.unit_off, pk.unit_off.data(), pk.unit_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
+    if (hipMemcpy(dev.bias, pk.bias.data(), pk.bias.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
+    return NRNERF_OK;
+}
+void free_pass(PassDev& dev) {
+    if (dev.stream) (void)hipFree(dev.stream);
+    if (dev.unit_off) (void)hipFree(dev.unit_off);
+    if (dev.bias) (void)hipFree(dev.bias);
+    dev = PassDev{};
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrnerf_abi_version(void) { return NRNERF_ABI_VERSION; }
+
+const char* nrnerf_strerror(int status) {
+    switch (status) {
+        case NRNERF_OK: return "ok";
+        case NRNERF_ERR_INVALID: return "invalid argument";
+        case NRNERF_ERR_UNSUPPORTED: return "unsupported architecture or flag combination (no kernel compiled for it)";
+        case NRNERF_ERR_HIP: return "HIP runtime error (no device, or a launch/copy failed)";
+        case NRNERF_ERR_WORKSPACE: return "workspace too small or misaligned";
+        case NRNERF_ERR_NOMEM: return "out of device memory";
+    }
+    return "unknown status";
+}
+
+int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_info* info, void* stream_out,
+                     size_t stream_cap, uint32_t* unit_table_out, float* bias_table_out) {
+    if (!desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
+    const nrnerf_mlp_desc* m = (which == 1 && desc->fine) ? desc->fine : desc->coarse;
+    PackedPass pk;
+    int rc = pack_dispatch(*desc, *m, pk);
+    if (rc != NRNERF_OK) return rc;
+    if (info) {
+        info->stream_bytes = pk.stream.size();
+        info->n_units = (uint32_t)pk.nunits;
+        info->n_bias_tiles = (uint32_t)pk.ntiles;
+        info->frag_bytes = (uint32_t)pk.frag_bytes;
+        info->slot_bytes = (uint32_t)pk.slot_bytes;
+        info->mfma_per_block = (uint32_t)pk.mfma_per_block;
+    }
+    if (stream_out) {
+        if (stream_cap < pk.stream.size()) return NRNERF_ERR_INVALID;
+        std::memcpy(stream_out, pk.stream.data(), pk.stream.size());
+    }
+    if (unit_table_out) std::memcpy(unit_table_out, pk.unit_off.data(), pk.unit_off.size() * 4);
+    if (bias_table_out) std::memcpy(bias_table_out, pk.bias.data(), pk.bias.size() * 4);
+    return NRNERF_OK;
+}
+
+int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
+    if (!out) return NRNERF_ERR_INVALID;
+    *out = nullptr;
+    if (!desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
+    PackedPass pc, pf;
+    int rc = pack_dispatch(*desc, *desc->coarse, pc);
+    if (rc != NRNERF_OK) return rc;
+    if (desc->fine) {
+        rc = pack_dispatch(*desc, *desc->fine, pf);
+        if (rc != NRNERF_OK) return rc;
+    }
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) return NRNERF_ERR_HIP;
+    if (hipSetDevice(desc->device) != hipSuccess) return NRNERF_ERR_HIP;
+    nrnerf_model* m = new (std::nothrow) nrnerf_model();
+    if (!m) { (void)hipSetDevice(prev); return NRNERF_ERR_NOMEM; }
+    m->device = desc->device;
+    m->precision = desc->precision;
+    m->has_bend = desc->bender != nullptr;
+    m->latent_size = desc->bender ? desc->bender->latent_size : 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, desc->device) != hipSuccess) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_HIP; }
+    m->num_cus = prop.multiProcessorCount;
+    const double mfma_flop = 2.0 * 32 * 32 * (desc->precision == NRNERF_PREC_F32 ? 2 : 16);
+    rc = upload_pass(pc, m->coarse);
+    m->coarse.algo_flops_per_sample = 2.0 * algo_macs(*desc, *desc->coarse);
+    m->coarse.mfma_flops_per_sample = pc.mfma_per_block * mfma_flop / 32.0;
+    m->coarse.output_ch = desc->coarse->output_ch;
+    if (rc == NRNERF_OK && desc->fine) {
+        rc = upload_pass(pf, m->fine);
+        m->fine.algo_flops_per_sample = 2.0 * algo_macs(*desc, *desc->fine);
+        m->fine.mfma_flops_per_sample = pf.mfma_per_block * mfma_flop / 32.0;
+        m->fine.output_ch = desc->fine->output_ch;
+    } else {
+        m->fine = m->coarse;
+        m->fine_is_coarse = true;
+    }
+    (void)hipSetDevice(prev);
+    if (rc != NRNERF_OK) { nrnerf_model_destroy(m); return rc; }
+    *out = m;
+    return NRNERF_OK;
+}
+
+void nrnerf_model_destroy(nrnerf_model* m) {
+    if (!m) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(m->device);
+    for (auto& e : m->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (!m->fine_is_coarse) free_pass(m->fine);
+    free_pass(m->coarse);
+    (void)hipSetDevice(prev);
+    delete m;
+}
+
+size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples, int32_t n_importance) {
+    (void)model;
+    if (n_rays <= 0 || n_samples <= 0 || n_importance < 0) return 0;
+    const size_t N = (size_t)n_rays, S = (size_t)n_samples, SF = S + (size_t)n_importance;
+    size_t b = align_up(N * S * 4 * sizeof(float), 256);
+    if (n_importance > 0) b += align_up(N * SF * sizeof(float), 256) + align_up(N * SF * 4 * sizeof(float), 256);
+    return b;
+}
+
+int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_stream) {
+    if (!m || !a || a->struct_size != sizeof(nrnerf_render_args)) return NRNERF_ERR_INVALID;
+    if (a->n_rays < 0 || a->n_samples < 2 || a->n_importance < 0) return NRNERF_ERR_INVALID;
+    if (a->n_samples > 256 || a->n_samples + a->n_importance > 256) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_rays == 0) return NRNERF_OK;
+    if (!a->rays || a->ray_stride < 8 || !a->rgb_map || !a->disp_map || !a->acc_map) return NRNERF_ERR_INVALID;
+    if (m->has_bend && (!a->latents || a->latent_stride < 0)) return NRNERF_ERR_INVALID;
+    const size_t need = nrnerf_workspace_bytes(m, a->n_rays, a->n_samples, a->n_importance);
+    if (!a->workspace || a->workspace_bytes < need || ((uintptr_t)a->workspace & 255)) return NRNERF_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int N = a->n_rays, S = a->n_samples, I = a->n_importance, SF = S + I;
+
+    char* ws = (char*)a->workspace;
+    float* raw_c = (float*)ws;
+    ws += align_up((size_t)N * S * 4 * sizeof(float), 256);
+    float* z_fine = nullptr; float* raw_f = nullptr;
+    if (I > 0) {
+        z_fine = (float*)ws; ws += align_up((size_t)N * SF * sizeof(float), 256);
+        raw_f = (float*)ws;
+    }
+
+    Knobs kn{};
+    kn.has_cutoff = a->has_rigidity_cutoff; kn.cutoff = a->rigidity_cutoff;
+    kn.has_scaling = a->has_test_time_scaling; kn.scaling = a->test_time_scaling;
+    kn.has_removal = a->has_removal_threshold; kn.removal = a->removal_threshold;
+    kn.detailed = a->detailed_output;
+
+    bool prof;
+    { std::lock_guard<std::mutex> g(m->prof_mu); prof = m->prof_on; }
+    auto timed = [&](int kernel, double flops, double mfma, auto&& launch) -> hipError_t {
+        if (!prof) return launch();
+        nrnerf_model::Ev ev{kernel, nullptr, nullptr, flops, mfma};
+        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return hipErrorUnknown;
+        (void)hipEventRecord(ev.a, stream);
+        hipError_t e = launch();
+        (void)hipEventRecord(ev.b, stream);
+        std::lock_guard<std::mutex> g(m->prof_mu);
+        m->prof_events.push_back(ev);
+        return e;
+    };
+
+    auto sample_out = [](const nrnerf_sample_outputs& o) {
+        return SampleOut{o.visibility_weights, o.opacity_alpha, o.initial_input_pts, o.unmasked_offsets,
+                         o.masked_offsets, o.input_pts, o.rigidity_mask};
+    };
+
+    // ---- K0: coarse network
+    NetArgs na{};
+    na.rays = a->rays; na.ray_stride = a->ray_stride;
+    na.latents = a->latents; na.lat_stride = a->latent_stride;
+    na.z = nullptr; na.n_rays = N; na.S = S;
+    na.wstream = m->coarse.stream; na.unit_off = m->coarse.unit_off; na.bias = m->coarse.bias;
+    na.raw4 = raw_c;
+    na.raw_out = (I == 0) ? a->raw : nullptr;
+    na.raw_ch = m->coarse.output_ch;
+    na.ex = sample_out(a->coarse);
+    na.knobs = kn;
+    hipError_t e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
+                         [&] { return launch_net(m->precision, m->has_bend, 0, na, m->num_cus, stream); });
+    if (e != hipSuccess) return NRNERF_ERR_HIP;
+
+    // ---- K1: coarse composite (+ sampling)
+    CompositeArgs ca{};
+    ca.rays = a->rays; ca.ray_stride = a->ray_stride;
+    ca.raw4 = raw_c; ca.z = nullptr; ca.n_rays = N; ca.S = S; ca.n_importance = I;
+    if (I > 0) {
+        // rgb0/disp0/acc0 are optional for the caller but the kernel always writes them: park them in raw_f
+        // (not yet written) when the caller passed NULL.
+        ca.rgb = a->rgb0 ? a->rgb0 : raw_f;
+        ca.disp = a->disp0 ? a->disp0 : raw_f + (size_t)N * 3;
+        ca.acc = a->acc0 ? a->acc0 : raw_f + (size_t)N * 4;
+        ca.z_std = a->z_std; ca.z_out = z_fine; ca.z_user = nullptr;
+    } else {
+        ca.rgb = a->rgb_map; ca.disp = a->disp_map; ca.acc = a->acc_map;
+        ca.z_std = nullptr; ca.z_out = nullptr; ca.z_user = a->z_vals;
+    }
+    ca.vis = a->coarse.visibility_weights; ca.alpha = a->coarse.opacity_alpha;
+    e = timed(1, 0, 0, [&] { return launch_composite(ca, stream); });
+    if (e != hipSuccess) return NRNERF_ERR_HIP;
+    if (I == 0) return NRNERF_OK;
+
+    // ---- K2: fine network on the merged depths
+    NetArgs nf = na;
+    nf.z = z_fine; nf.S = SF;
+    nf.wstream = m->fine.stream; nf.unit_off = m->fine.unit_off; nf.bias = m->fine.bias;
+    nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
+    nf.ex = sample_out(a->fine);
+    e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
+              [&] { return launch_net(m->precision, m->has_bend, 0, nf, m->num_cus, stream); });
+    if (e != hipSuccess) return NRNERF_ERR_HIP;
+
+    // ---- K3: fine composite
+    CompositeArgs cf{};
+    cf.rays = a->rays; cf.ray_stride = a->ray_stride;
+    cf.raw4 = raw_f; cf.z = z_fine; cf.n_rays = N; cf.S = SF; cf.n_importance = 0;
+    cf.rgb = a->rgb_map; cf.disp = a->disp_map; cf.acc = a->acc_map;
+    cf.z_std = nullptr; cf.z_out = nullptr; cf.z_user = a->z_vals;
+    cf.vis = a->fine.visibility_weights; cf.alpha = a->fine.opacity_alpha;
+    e = timed(3, 0, 0, [&] { return launch_composite(cf, stream); });
+    if (e != hipSuccess) return NRNERF_ERR_HIP;
+    return NRNERF_OK;
+}
+
+int nrnerf_profile_begin(nrnerf_model* m) {
+    if (!m) return NRNERF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(m->prof_mu);
+    for (auto& e : m->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    m->prof_events.clear();
+    m->prof_on = true;
+    return NRNERF_OK;
+}
+
+int nrnerf_profile_end(nrnerf_model* m, nrnerf_profile* out) {
+    if (!m || !out) return NRNERF_ERR_INVALID;
+    std::lock_guard<std::mutex> g(m->prof_mu);
+    m->prof_on = false;
+    std::memset(out, 0, sizeof(*out));
+    int rc = NRNERF_OK;
+    for (auto& e : m->prof_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) != hipSuccess || hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) rc = NRNERF_ERR_HIP;
+        out->ms[e.kernel] += ms;
+        out->launches[e.kernel] += 1;
+        out->flops[e.kernel] += e.flops;
+        out->mfma_flops[e.kernel] += e.mfma;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    m->prof_events.clear();
+    return rc;
+}
+
+}  // extern "C"

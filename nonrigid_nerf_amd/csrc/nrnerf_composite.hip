@@ -1,0 +1,207 @@
+// nrnerf_composite.hip -- per-ray kernels: alpha compositing (reference raw2outputs,
+// train.py:724-789), inverse-CDF hierarchical sampling (sample_pdf, run_nerf_helpers.py:651-698),
+// the sort-merge of coarse and importance depths (train.py:920) and z_std (train.py:959).
+//
+// One wavefront per ray.  Lane l owns the EPL consecutive samples l*EPL .. l*EPL+EPL-1, so the
+// exclusive transmittance product and the CDF are a short in-lane serial scan followed by one
+// 64-lane prefix scan (DPP/ds_swizzle shuffles); importance samples are drawn by a per-lane
+// binary search of the CDF held in LDS; the merge ranks every depth against all others (stable,
+// so it equals torch.sort's value output for any input order).  All fp32, HBM traffic is the
+// 16 B/sample raw read plus the per-ray outputs.
+#include <hip/hip_runtime.h>
+
+#include "nrnerf_kernels.h"
+
+namespace nrn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int RAYS_PER_WG = 4;
+static constexpr int MAXS = 256;        // S and S+I are limited to 256 (4 samples per lane)
+
+__device__ __forceinline__ float c_lin01(int i, int n) {     // torch.linspace(0,1,n)[i], fp32
+    if (n <= 1) return 0.0f;
+    const float step = __fdiv_rn(1.0f, (float)(n - 1));
+    return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// inclusive prefix scans over the 64 lanes
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v *= t; }
+    return v;
+}
+
+template <int EPL, bool SAMPLE>
+__global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const CompositeArgs a) {
+    __shared__ float s_cdf[RAYS_PER_WG][MAXS];
+    __shared__ float s_bins[RAYS_PER_WG][MAXS];
+    __shared__ float s_z[RAYS_PER_WG][MAXS + 4];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray_raw = blockIdx.x * RAYS_PER_WG + wave;
+    const bool ray_ok = ray_raw < a.n_rays;
+    const int ray = ray_ok ? ray_raw : a.n_rays - 1;
+    const int S = a.S;
+
+    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    const float dx = rp[3], dy = rp[4], dz = rp[5];
+    const float near = rp[6], far = rp[7];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);                 // train.py:748
+
+    // ---- load this lane's samples
+    float z[EPL + 1], sig[EPL], col[EPL][3];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        const int ic = i < S ? i : S - 1;
+        if (a.z) z[k] = a.z[(size_t)ray * S + ic];
+        else {
+            const float t = c_lin01(ic, S);
+            z[k] = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));   // train.py:849
+        }
+        const f32x4 r = *(const f32x4*)(a.raw4 + ((size_t)ray * S + ic) * 4);
+        col[k][0] = r[0]; col[k][1] = r[1]; col[k][2] = r[2]; sig[k] = r[3];
+    }
+    z[EPL] = __shfl_down(z[0], 1);     // first depth of the next lane
+
+    // ---- alpha, transmittance, weights (train.py:740-775)
+    float alpha[EPL], w[EPL];
+    float run = 1.0f;                  // product of (1 - alpha + 1e-10) over this lane's samples so far
+    float texcl[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        float dist = (i == S - 1) ? 1e10f : __fsub_rn(z[k + 1], z[k]);      // :743-746
+        dist = __fmul_rn(dist, dnorm);                                      // :748
+        const float s = fmaxf(sig[k], 0.0f);
+        alpha[k] = (i < S) ? __fsub_rn(1.0f, expf(-__fmul_rn(s, dist))) : 0.0f;   // :741
+        texcl[k] = run;
+        run = __fmul_rn(run, (i < S) ? __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f) : 1.0f);
+    }
+    const float incl = wave_scan_mul(run, lane);
+    float before = __shfl_up(incl, 1);
+    if (lane == 0) before = 1.0f;
+    float sr = 0.f, sg = 0.f, sb = 0.f, sdepth = 0.f, sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        w[k] = (i < S) ? __fmul_rn(alpha[k], __fmul_rn(before, texcl[k])) : 0.0f;
+        const float r = 1.0f / (1.0f + expf(-col[k][0]));                   // sigmoid, :750
+        const float g = 1.0f / (1.0f + expf(-col[k][1]));
+        const float b = 1.0f / (1.0f + expf(-col[k][2]));
+        sr += w[k] * r; sg += w[k] * g; sb += w[k] * b;
+        sdepth += w[k] * z[k]; sacc += w[k];
+        if (ray_ok && i < S) {
+            if (a.vis) a.vis[(size_t)ray * S + i] = w[k];
+            if (a.alpha) a.alpha[(size_t)ray * S + i] = alpha[k];
+            if (a.z_user) a.z_user[(size_t)ray * S + i] = z[k];
+        }
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sdepth = wave_sum(sdepth); sacc = wave_sum(sacc);
+    if (ray_ok && lane == 0) {
+        a.rgb[(size_t)ray * 3 + 0] = sr; a.rgb[(size_t)ray * 3 + 1] = sg; a.rgb[(size_t)ray * 3 + 2] = sb;   // :776
+        a.acc[ray] = sacc;                                                                                    // :779
+        const float q = sdepth / sacc;                               // 0/0 = NaN when acc == 0 ...
+        a.disp[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));      // ... which torch.max propagates (:781-784)
+    }
+
+    if constexpr (SAMPLE) {
+        const int I = a.n_importance;
+        const int nb = S - 1;          // bins = mid-points; cdf has nb entries (run_nerf_helpers.py:657-659)
+        // ---- pdf / cdf over weights[1:-1] + 1e-5 (rnh:654-659)
+        float v[EPL], vs = 0.f;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int i = lane * EPL + k;
+            v[k] = (i >= 1 && i <= S - 2) ? __fadd_rn(w[k], 1e-5f) : 0.0f;
+            vs += v[k];
+        }
+        const float total = wave_sum(vs);
+        float lrun = 0.f, lpre[EPL];
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) { lrun += __fdiv_rn(v[k], total); lpre[k] = lrun; }      // pdf = w / sum (:655)
+        const float lincl = wave_scan_add(lrun, lane);
+        const float lbase = lincl - lrun;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int i = lane * EPL + k;
+            if (i < nb) {
+                s_cdf[wave][i] = (i == 0) ? 0.0f : lbase + lpre[k];                            // cumsum (:656)
+                s_bins[wave][i] = __fmul_rn(0.5f, __fadd_rn(z[k + 1], z[k]));                  // train.py:910
+            }
+            if (i < S) s_z[wave][i] = z[k];
+        }
+        __syncthreads();
+        // ---- inverse CDF at u = linspace(0,1,I) (det=True), rnh:663-696
+        float zsum = 0.f;
+        for (int k = lane; k < I; k += 64) {
+            const float u = c_lin01(k, I);
+            int lo = 0, hi = nb;       // lower_bound: first idx with cdf[idx] >= u  (searchsorted right=False)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cdf[wave][mid] < u) lo = mid + 1; else hi = mid; }
+            const int below = lo - 1 > 0 ? lo - 1 : 0;                                         // :683
+            const int above = lo < nb - 1 ? lo : nb - 1;                                       // :684
+            const float c0 = s_cdf[wave][below], c1 = s_cdf[wave][above];
+            const float b0 = s_bins[wave][below], b1 = s_bins[wave][above];
+            float denom = __fsub_rn(c1, c0);                                                   // :693
+            if (denom < 1e-5f) denom = 1.0f;                                                   // :694
+            const float t = __fdiv_rn(__fsub_rn(u, c0), denom);                                // :695
+            const float zs = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));                   // :696
+            s_z[wave][S + k] = zs;
+            zsum += zs;
+        }
+        __syncthreads();
+        const int n = S + I;
+        // ---- z_std (population std of the importance samples), train.py:959
+        const float mean = wave_sum(zsum) / (float)I;
+        float var = 0.f;
+        for (int k = lane; k < I; k += 64) { const float d = s_z[wave][S + k] - mean; var += d * d; }
+        var = wave_sum(var) / (float)I;
+        if (ray_ok && lane == 0 && a.z_std) a.z_std[ray] = sqrtf(var);
+        // ---- merge: stable rank of every depth among all n (== torch.sort values), train.py:920
+        for (int idx = lane; idx < n; idx += 64) {
+            const float mine = s_z[wave][idx];
+            int rank = 0;
+            for (int jj = 0; jj < n; ++jj) {
+                const float o = s_z[wave][jj];
+                rank += (o < mine || (o == mine && jj < idx)) ? 1 : 0;
+            }
+            if (ray_ok) a.z_out[(size_t)ray * n + rank] = mine;
+        }
+    }
+}
+
+template <int EPL>
+static hipError_t launch_epl(const CompositeArgs& a, hipStream_t stream) {
+    const int grid = (a.n_rays + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    if (grid <= 0) return hipSuccess;
+    if (a.n_importance > 0)
+        hipLaunchKernelGGL((composite_kernel<EPL, true>), dim3(grid), dim3(RAYS_PER_WG * 64), 0, stream, a);
+    else
+        hipLaunchKernelGGL((composite_kernel<EPL, false>), dim3(grid), dim3(RAYS_PER_WG * 64), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream) {
+    if (a.S < 2 || a.S > MAXS || a.S + a.n_importance > MAXS) return hipErrorInvalidValue;
+    const int epl = (a.S + 63) / 64;
+    switch (epl) {
+        case 1: return launch_epl<1>(a, stream);
+        case 2: return launch_epl<2>(a, stream);
+        case 3: return launch_epl<3>(a, stream);
+        case 4: return launch_epl<4>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace nrn

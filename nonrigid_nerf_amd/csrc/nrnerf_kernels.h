@@ -1,0 +1,65 @@
+// nrnerf_kernels.h -- host-visible launch interface of the HIP kernels (internal, C++).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nrn {
+
+// device pointers of one pass' optional per-sample detail outputs (nullable)
+struct SampleOut {
+    float* vis;        // [N,S]   visibility_weights   (composite kernel)
+    float* alpha;      // [N,S]   opacity_alpha        (composite kernel)
+    float* init_pts;   // [N,S,3] initial_input_pts    (network kernel)
+    float* unmasked;   // [N,S,3]
+    float* masked;     // [N,S,3]
+    float* in_pts;     // [N,S,3] bent points
+    float* rigidity;   // [N,S,1]
+};
+
+struct Knobs {
+    int has_cutoff;  float cutoff;
+    int has_scaling; float scaling;
+    int has_removal; float removal;     // only honoured when `detailed` (reference quirk, rnh:308-311)
+    int detailed;
+};
+
+// One pass (coarse or fine) of the per-sample network over n_rays * S samples.
+struct NetArgs {
+    const float* rays;   int ray_stride;
+    const float* latents; int lat_stride;
+    const float* z;          // [N,S] sample depths, or nullptr: coarse linspace between near and far
+    int n_rays, S;
+    const void* wstream;     // packed fragment stream of this pass
+    const uint32_t* unit_off;    // [NUNITS+1] offsets in 16-byte words
+    const float* bias;       // [NTILES*32]
+    float* raw4;             // [N,S,4] rgb + sigma workspace consumed by the composite kernel
+    float* raw_out;          // [N,S,raw_ch] user-visible raw ("retraw") or nullptr
+    int raw_ch;
+    SampleOut ex;
+    Knobs knobs;
+};
+
+struct CompositeArgs {
+    const float* rays;   int ray_stride;
+    const float* raw4;       // [N,S,4]
+    const float* z;          // [N,S] or nullptr: coarse linspace
+    int n_rays, S;
+    int n_importance;        // I: > 0 -> also run sample_pdf + merge and write z_out [N,S+I], z_std
+    float* rgb; float* disp; float* acc;     // [N,3],[N],[N]
+    float* z_std;            // [N] or nullptr
+    float* z_out;            // [N,S+I] merged sorted depths (workspace, required when I > 0)
+    float* z_user;           // optional user copy of the depths of THIS pass ([N,S]) or nullptr
+    float* vis; float* alpha;    // [N,S] optional
+};
+
+// precision ids match nrnerf_precision
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+
+struct NetLaunchInfo { int grid; int block; size_t lds_bytes; };
+
+// returns hipSuccess or an error; `arch_id` selects a compiled architecture (0 = default 8x256)
+hipError_t launch_net(int precision, bool has_bend, int arch_id, const NetArgs& a, int num_cus,
+                      hipStream_t stream);
+hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream);
+
+}  // namespace nrn

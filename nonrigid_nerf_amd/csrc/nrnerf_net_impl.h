@@ -1,0 +1,441 @@
+#pragma once
+// nrnerf_net_impl.h -- the fused per-sample network kernel for gfx950 (MI355X).
+//
+// One launch evaluates, for every sample of every ray of a pass:
+//   point generation           (reference train.py:847-873 / 921-923)
+//   ray_bending offset MLP + rigidity MLP + masking      (run_nerf_helpers.py:507-577)
+//   positional encoding of the bent point                (run_nerf_helpers.py:120-150, 582-584)
+//   8x256 trunk with skip concatenation + output head    (run_nerf_helpers.py:272-306)
+// and writes raw[N,S,4] for the composite kernel.  Nothing else touches HBM: the 95-float
+// per-sample network input the reference materialises (train.py:88-90) never exists.
+//
+// Execution model:
+//   * a wave owns a block of 32 consecutive samples of one ray; lane = sample (lane & 31), the
+//     two lane halves split the k (feature) index as the MFMA B operand requires;
+//   * every layer is D^T = W * H^T on v_mfma_f32_32x32x16_{bf16,f16} (or 32x32x2_f32): weights are
+//     the A operand, activations the B operand, and the D tile is already (a permutation of) the
+//     next layer's B operand -- activations stay in VGPRs from the encoding to the head;
+//   * weights are a linear stream of pre-permuted A fragments in HBM/L2 (nrnerf_plan.h); the
+//     workgroup stages it through an LDS ring unit by unit, all waves consume each unit;
+//   * workgroups are persistent: grid = #CUs, each loops over tiles of WAVES blocks.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "nrnerf_kernels.h"
+#include "nrnerf_plan.h"
+
+namespace nrn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// precision policies
+// ------------------------------------------------------------------------------------------
+struct PolBF16 : Shape<8> {
+    typedef __bf16 frag __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    template <int E>
+    static __device__ __forceinline__ void set(frag& f, float v) { f[E] = (__bf16)v; }
+    static __device__ __forceinline__ float round(float v) { return (float)(__bf16)v; }
+};
+struct PolF16 : Shape<8> {
+    typedef _Float16 frag __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    template <int E>
+    static __device__ __forceinline__ void set(frag& f, float v) { f[E] = (_Float16)v; }
+    static __device__ __forceinline__ float round(float v) { return (float)(_Float16)v; }
+};
+struct PolF32 : Shape<1> {
+    typedef float frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    template <int E>
+    static __device__ __forceinline__ void set(frag& f, float v) { f = v; }
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+
+// ------------------------------------------------------------------------------------------
+// weight stream: HBM/L2 -> registers -> LDS ring (2 slots), one unit ahead.
+//   next_unit(): publish the staged unit into the free slot, barrier, start fetching the one after.
+// All waves of the workgroup call next_unit() at the same (compile-time) points.
+// ------------------------------------------------------------------------------------------
+template <class P, int WAVES, int SLOT_BYTES, int NUNITS>
+struct WStream {
+    static constexpr int SLOT_PIECES = SLOT_BYTES / 1024;               // 1 KiB = one wave-wide 16 B load
+    static constexpr int PIECES = (SLOT_PIECES + WAVES - 1) / WAVES;
+    static_assert(SLOT_BYTES % 1024 == 0, "slot must be a multiple of 1 KiB");
+    const char* g;
+    const uint32_t* uoff;
+    char* ring;
+    int cur;          // slot holding the current unit
+    int u_next;       // unit whose fetch is issued next
+    int staged_bytes;
+    uint4 st[PIECES];
+    int wave, lane;
+
+    __device__ __forceinline__ void init(const void* stream, const uint32_t* unit_off, char* lds, int w, int l) {
+        g = (const char*)stream; uoff = unit_off; ring = lds; cur = 1; u_next = 0; wave = w; lane = l;
+        fetch();
+    }
+    __device__ __forceinline__ void fetch() {
+        const uint32_t o0 = uoff[u_next], o1 = uoff[u_next + 1];
+        staged_bytes = (int)(o1 - o0) * 16;
+        const char* src = g + (size_t)o0 * 16 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = wave + WAVES * i;
+            if (p * 1024 < staged_bytes) st[i] = *(const uint4*)(src + p * 1024);
+        }
+        u_next = (u_next + 1 == NUNITS) ? 0 : u_next + 1;
+    }
+    __device__ __forceinline__ void next_unit() {
+        char* dst = ring + (cur ^ 1) * SLOT_BYTES + lane * 16;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = wave + WAVES * i;
+            if (p * 1024 < staged_bytes) *(uint4*)(dst + p * 1024) = st[i];
+        }
+        __syncthreads();
+        cur ^= 1;
+        fetch();
+    }
+    // A fragment `fidx` of the current unit for this lane
+    __device__ __forceinline__ typename P::frag frag(int fidx) const {
+        const char* p = ring + cur * SLOT_BYTES + fidx * P::FRAG_BYTES + lane * (P::FRAG_BYTES / 64);
+        return *(const typename P::frag*)p;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// one dense layer: for every output tile t, acc = bias; acc += A(t,s) * B(s) over the input slabs;
+// `epi(t, acc)` consumes the 32x32 fp32 tile.  B slabs come from in0 (first NS0) then in1.
+// ------------------------------------------------------------------------------------------
+template <class P, class PL, int LI, int NS0, int NS1, class ST, class IN0, class IN1, class EPI>
+__device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, const IN0& in0, const IN1& in1, EPI&& epi) {
+    constexpr LayerSpec spec = PL::TB.layers[LI];
+    static_assert(spec.ns == NS0 + NS1, "slab count mismatch between kernel and plan");
+    static_for<0, spec.nt>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t];
+        if constexpr (ti.starts_unit) st.next_unit();
+        const f32x4* bp = (const f32x4*)(bias_lds + (spec.tile0 + t) * 32 + h * 16);
+        f32x16 acc;
+        {
+            const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+            acc = f32x16{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3],
+                         b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
+        }
+        static_for<0, NS0>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            acc = P::mfma(st.frag(ti.fbase + s), in0[s], acc);
+        });
+        static_for<0, NS1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            acc = P::mfma(st.frag(ti.fbase + NS0 + s), in1[s], acc);
+        });
+        epi(tc, acc);
+    });
+}
+
+// relu + convert a D tile into the SP B-operand slabs it provides to the next layer
+template <class P, bool RELU, int T, class OUT>
+__device__ __forceinline__ void pack_tile(const f32x16& acc, OUT& out) {
+    static_for<0, P::SP>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        static_for<0, P::KH>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            float v = acc[u * P::KH + e];
+            if (RELU) v = fmaxf(v, 0.0f);
+            P::template set<e>(out[T * P::SP + u], v);
+        });
+    });
+}
+
+// torch.linspace(0, 1, n)[i] in fp32 (ATen RangeFactories: symmetric two-sided evaluation)
+__device__ __forceinline__ float lin01(int i, int n) {
+    if (n <= 1) return 0.0f;
+    const float step = __fdiv_rn(1.0f, (float)(n - 1));
+    return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
+}
+
+struct Empty {
+    template <class T> __device__ __forceinline__ float operator[](T) const { return 0.f; }
+};
+
+template <class P, class A, bool HAS_BEND, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
+    using PL = Plan<P, A, HAS_BEND>;
+    using frag = typename P::frag;
+    constexpr int KH = P::KH, SP = P::SP;
+    constexpr int NS_ENC = PL::NS_ENC;
+    constexpr int NT_W = PL::NT_W;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    float* bias_lds = (float*)(smem + 2 * PL::SLOT_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+    const int j = lane & 31;
+
+    for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = a.bias[i];
+
+    WStream<P, WAVES, PL::SLOT_BYTES, PL::NUNITS> st;
+    st.init(a.wstream, a.unit_off, ring, wave, lane);
+    __syncthreads();
+
+    const int S = a.S;
+    const int bpr = (S + 31) >> 5;                 // 32-sample blocks per ray
+    const long long nblocks = (long long)a.n_rays * bpr;
+    const long long ntiles = (nblocks + WAVES - 1) / WAVES;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long blk = tile * WAVES + wave;
+        const bool blk_ok = blk < nblocks;
+        const long long b = blk_ok ? blk : nblocks - 1;
+        const int ray = (int)(b / bpr);
+        const int sidx = (int)(b % bpr) * 32 + j;
+        const bool ok = blk_ok && sidx < S;
+        const int sc = sidx < S ? sidx : S - 1;
+
+        const float* rp = a.rays + (size_t)ray * a.ray_stride;
+        const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+        float z;
+        if (a.z) {
+            z = a.z[(size_t)ray * S + sc];
+        } else {
+            const float near = rp[6], far = rp[7];
+            const float t = lin01(sc, S);
+            z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));      // train.py:849
+        }
+        float p[3] = {__fadd_rn(ox, __fmul_rn(dx, z)), __fadd_rn(oy, __fmul_rn(dy, z)),
+                      __fadd_rn(oz, __fmul_rn(dz, z))};                                  // train.py:871-873
+        const size_t so = (size_t)ray * S + sc;     // flat sample index for per-sample outputs
+        const bool writer = ok && h == 0;
+
+        if (writer && a.ex.init_pts) {
+            a.ex.init_pts[so * 3 + 0] = p[0]; a.ex.init_pts[so * 3 + 1] = p[1]; a.ex.init_pts[so * 3 + 2] = p[2];
+        }
+
+        float rig_mask = 0.0f;
+        if constexpr (HAS_BEND) {
+            constexpr int NS_BIN = PL::NS_BIN, NS_RIN = PL::NS_RIN;
+            constexpr int NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
+            const float* lat = a.latents + (size_t)ray * a.lat_stride;
+            // hi/lo split of the coordinates for the 16-bit modes (same weight columns, nrnerf_plan.h)
+            float phi[3], plo[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { phi[c] = P::round(p[c]); plo[c] = P::HILO ? p[c] - phi[c] : 0.0f; }
+            auto binval = [&](auto idxc) -> float {
+                constexpr int idx = decltype(idxc)::value;
+                if constexpr (idx < 3) return phi[idx];
+                else if constexpr (idx < 6) return plo[idx - 3];
+                else if constexpr (idx < 8) return 0.0f;
+                else if constexpr (idx - 8 < A::LAT) return lat[idx - 8];
+                else return 0.0f;
+            };
+            frag bin[NS_BIN];
+            static_for<0, NS_BIN>([&](auto sc_) {
+                constexpr int s = decltype(sc_)::value;
+                static_for<0, KH>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    const float v0 = binval(std::integral_constant<int, (2 * s) * KH + e>{});
+                    const float v1 = binval(std::integral_constant<int, (2 * s + 1) * KH + e>{});
+                    P::template set<e>(bin[s], h ? v1 : v0);
+                });
+            });
+            // ---- offset MLP (run_nerf_helpers.py:525-541)
+            frag ba[NB], bb[NB];
+            Empty none;
+            dense<P, PL, PL::L_BEND0, NS_BIN, 0>(st, bias_lds, h, bin, none, [&](auto tc, const f32x16& acc) {
+                pack_tile<P, true, decltype(tc)::value>(acc, ba);
+            });
+            static_for<1, A::BD - 1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i % 2 == 1) {
+                    dense<P, PL, PL::L_BEND0 + i, NB, 0>(st, bias_lds, h, ba, none, [&](auto tc, const f32x16& acc) {
+                        pack_tile<P, true, decltype(tc)::value>(acc, bb);
+                    });
+                } else {
+                    dense<P, PL, PL::L_BEND0 + i, NB, 0>(st, bias_lds, h, bb, none, [&](auto tc, const f32x16& acc) {
+                        pack_tile<P, true, decltype(tc)::value>(acc, ba);
+                    });
+                }
+            });
+            float off[3];
+            auto take_off = [&](auto, const f32x16& acc) { off[0] = acc[0]; off[1] = acc[1]; off[2] = acc[2]; };
+            if constexpr ((A::BD - 2) % 2 == 1) dense<P, PL, PL::L_BEND0 + A::BD - 1, NB, 0>(st, bias_lds, h, bb, none, take_off);
+            else dense<P, PL, PL::L_BEND0 + A::BD - 1, NB, 0>(st, bias_lds, h, ba, none, take_off);
+            // ---- rigidity MLP (run_nerf_helpers.py:545-561); input = xyz only
+            frag rin[NS_RIN];
+            auto rinval = [&](auto idxc) -> float {
+                constexpr int idx = decltype(idxc)::value;
+                if constexpr (idx < 3) return phi[idx];
+                else if constexpr (idx < 6) return plo[idx - 3];
+                else return 0.0f;
+            };
+            static_for<0, NS_RIN>([&](auto sc_) {
+                constexpr int s = decltype(sc_)::value;
+                static_for<0, KH>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    const float v0 = rinval(std::integral_constant<int, (2 * s) * KH + e>{});
+                    const float v1 = rinval(std::integral_constant<int, (2 * s + 1) * KH + e>{});
+                    P::template set<e>(rin[s], h ? v1 : v0);
+                });
+            });
+            frag ra[NR], rb[NR];
+            dense<P, PL, PL::L_RIG0, NS_RIN, 0>(st, bias_lds, h, rin, none, [&](auto tc, const f32x16& acc) {
+                pack_tile<P, true, decltype(tc)::value>(acc, ra);
+            });
+            static_for<1, A::RD - 1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i % 2 == 1) {
+                    dense<P, PL, PL::L_RIG0 + i, NR, 0>(st, bias_lds, h, ra, none, [&](auto tc, const f32x16& acc) {
+                        pack_tile<P, true, decltype(tc)::value>(acc, rb);
+                    });
+                } else {
+                    dense<P, PL, PL::L_RIG0 + i, NR, 0>(st, bias_lds, h, rb, none, [&](auto tc, const f32x16& acc) {
+                        pack_tile<P, true, decltype(tc)::value>(acc, ra);
+                    });
+                }
+            });
+            float logit;
+            auto take_logit = [&](auto, const f32x16& acc) { logit = acc[0]; };
+            if constexpr ((A::RD - 2) % 2 == 1) dense<P, PL, PL::L_RIG0 + A::RD - 1, NR, 0>(st, bias_lds, h, rb, none, take_logit);
+            else dense<P, PL, PL::L_RIG0 + A::RD - 1, NR, 0>(st, bias_lds, h, ra, none, take_logit);
+
+            rig_mask = (tanhf(logit) + 1.0f) / 2.0f;                                  // rnh:559-561
+            if (a.knobs.has_cutoff && rig_mask <= a.knobs.cutoff) rig_mask = 0.0f;    // rnh:563-564
+            float mo[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                mo[c] = __fmul_rn(rig_mask, off[c]);                                  // rnh:567
+                if (a.knobs.has_scaling) mo[c] = __fmul_rn(mo[c], a.knobs.scaling);   // rnh:568-569
+            }
+            if (writer) {
+                if (a.ex.unmasked) { a.ex.unmasked[so * 3 + 0] = off[0]; a.ex.unmasked[so * 3 + 1] = off[1]; a.ex.unmasked[so * 3 + 2] = off[2]; }
+                if (a.ex.masked) { a.ex.masked[so * 3 + 0] = mo[0]; a.ex.masked[so * 3 + 1] = mo[1]; a.ex.masked[so * 3 + 2] = mo[2]; }
+                if (a.ex.rigidity) a.ex.rigidity[so] = rig_mask;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = __fadd_rn(p[c], mo[c]);                // rnh:570
+        }
+        if (writer && a.ex.in_pts) {
+            a.ex.in_pts[so * 3 + 0] = p[0]; a.ex.in_pts[so * 3 + 1] = p[1]; a.ex.in_pts[so * 3 + 2] = p[2];
+        }
+
+        // ---- positional encoding of the (bent) point, directly in B-operand order
+        constexpr int F0 = enc_F0(A::L);
+        constexpr int NSLOT = NS_ENC * KH;
+        float ev[NSLOT];
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) ev[q] = 0.0f;
+        ev[0] = h ? p[2] : p[0];
+        ev[1] = h ? 0.0f : p[1];
+        const float fscale = h ? (float)(1 << F0) : 1.0f;
+        static_for<0, F0>([&](auto fc) {
+            constexpr int fl = decltype(fc)::value;
+            static_for<0, 3>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const float arg = p[c] * (fscale * (float)(1 << fl));     // exact: power-of-two scaling
+                float sv, cv;
+                sincosf(arg, &sv, &cv);
+                ev[2 + 2 * (3 * fl + c)] = sv;
+                ev[2 + 2 * (3 * fl + c) + 1] = cv;
+            });
+        });
+        frag enc[NS_ENC];
+        static_for<0, NS_ENC>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            static_for<0, KH>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                P::template set<e>(enc[s], ev[s * KH + e]);
+            });
+        });
+
+        // ---- trunk (run_nerf_helpers.py:272-282) and head (:306)
+        constexpr int NH = NT_W * SP;
+        frag ha[NH], hb[NH];
+        Empty none;
+        dense<P, PL, PL::L_TRUNK0, NS_ENC, 0>(st, bias_lds, h, enc, none, [&](auto tc, const f32x16& acc) {
+            pack_tile<P, true, decltype(tc)::value>(acc, ha);
+        });
+        static_for<1, A::D>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr bool skip = (i - 1 == A::SKIP);
+            if constexpr (i % 2 == 1) {
+                if constexpr (skip)
+                    dense<P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lds, h, enc, ha, [&](auto tc, const f32x16& acc) {
+                        pack_tile<P, true, decltype(tc)::value>(acc, hb); });
+                else
+                    dense<P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lds, h, ha, none, [&](auto tc, const f32x16& acc) {
+                        pack_tile<P, true, decltype(tc)::value>(acc, hb); });
+            } else {
+                if constexpr (skip)
+                    dense<P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lds, h, enc, hb, [&](auto tc, const f32x16& acc) {
+                        pack_tile<P, true, decltype(tc)::value>(acc, ha); });
+                else
+                    dense<P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lds, h, hb, none, [&](auto tc, const f32x16& acc) {
+                        pack_tile<P, true, decltype(tc)::value>(acc, ha); });
+            }
+        });
+        float raw[5];
+        auto take_raw = [&](auto, const f32x16& acc) {
+            raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; raw[3] = acc[3]; raw[4] = acc[4];
+        };
+        if constexpr ((A::D - 1) % 2 == 1) dense<P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, hb, none, take_raw);
+        else dense<P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, ha, none, take_raw);
+
+        if (HAS_BEND && a.knobs.detailed && a.knobs.has_removal && rig_mask >= a.knobs.removal)
+            raw[3] = raw[3] * 0.0f;                                                  // rnh:308-311
+        if (writer) {
+            *(f32x4*)(a.raw4 + so * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+            if (a.raw_out) {
+                float* ro = a.raw_out + so * a.raw_ch;
+                ro[0] = raw[0]; ro[1] = raw[1]; ro[2] = raw[2]; ro[3] = raw[3];
+                if (a.raw_ch > 4) ro[4] = raw[4];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch (one explicit instantiation per translation unit, see nrnerf_net_inst.hip)
+// ------------------------------------------------------------------------------------------
+template <class P, class A, bool HAS_BEND, int WAVES>
+static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) {
+    using PL = Plan<P, A, HAS_BEND>;
+    const size_t lds = 2 * (size_t)PL::SLOT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float);
+    auto kern = net_kernel<P, A, HAS_BEND, WAVES>;
+    static bool attr_set = false;    // idempotent; racing threads set the same value
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int bpr = (a.S + 31) / 32;
+    const long long nblocks = (long long)a.n_rays * bpr;
+    const long long ntiles = (nblocks + WAVES - 1) / WAVES;
+    if (ntiles <= 0) return hipSuccess;
+    const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace nrn

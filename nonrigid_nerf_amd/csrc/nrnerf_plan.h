@@ -1,0 +1,237 @@
+// nrnerf_plan.h -- the single source of truth shared by the host weight packer and the
+// device network kernel: which MFMA fragments exist, in which order they are streamed, how
+// they are grouped into LDS staging units, and which reference weight element every fragment
+// element holds.
+//
+// Dataflow the plan describes: every wave owns one "block" of 32
+// consecutive samples of one ray.  Each layer is computed TRANSPOSED, D^T = W * H^T, with the
+// weights as the MFMA A operand and the activations as the B operand
+// (v_mfma_f32_32x32x16_{bf16,f16} or v_mfma_f32_32x32x2_f32).  The D tile (32 output
+// features x 32 samples) lands with lane = sample and registers = features, which -- up to a
+// fixed permutation of the k index -- is exactly the B-operand layout of the next layer.  The
+// permutation is folded into the packed weights here, so activations never leave registers.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define NRN_HD __host__ __device__
+#else
+#define NRN_HD
+#endif
+
+namespace nrn {
+
+constexpr NRN_HD int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr NRN_HD int imax(int a, int b) { return a > b ? a : b; }
+
+// Row (0..31) of a 32x32 MFMA D tile held by accumulator register r (0..15) of a lane in
+// half h (= lane >> 5).  CDNA4 C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*h.
+constexpr NRN_HD int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Operand shape of one precision policy.  KH = k elements per lane per MFMA.
+//   bf16/f16: 32x32x16, a lane holds 8 consecutive k (KH = 8), lanes 32..63 hold k 8..15
+//   f32     : 32x32x2,  a lane holds 1 k         (KH = 1), lanes 32..63 hold k = 1
+template <int KH_>
+struct Shape {
+    static constexpr int KH = KH_;
+    static constexpr int KS = 2 * KH_;             // k per MFMA
+    static constexpr int SP = 16 / KH_;            // B-operand slabs produced by one 32-feature D tile
+    static constexpr int ELEM_BYTES = (KH_ == 1) ? 4 : 2;
+    static constexpr int FRAG_BYTES = 64 * KH_ * ELEM_BYTES;   // one A fragment: 1024 (16-bit) / 256 (f32)
+    static constexpr bool HILO = (KH_ != 1);       // 16-bit modes feed xyz to the bender as hi + lo halves
+    static constexpr int UNIT_MIN_FRAGS = (KH_ == 1) ? 128 : 16;   // staging granularity target (32 / 16 KiB)
+};
+
+template <int W_, int D_, int SKIP_, int L_, int BW_, int BD_, int RW_, int RD_, int LAT_>
+struct ArchT {
+    static constexpr int W = W_, D = D_, SKIP = SKIP_, L = L_;
+    static constexpr int BW = BW_, BD = BD_, RW = RW_, RD = RD_, LAT = LAT_;
+    static_assert(W_ % 32 == 0 && BW_ % 32 == 0 && RW_ % 32 == 0, "widths must be multiples of 32");
+    static_assert(LAT_ % 8 == 0, "latent size must be a multiple of 8");
+};
+
+// ---------------------------------------------------------------------------------------
+// Input vectors of the three first layers, as per-lane-half slot lists.
+// ---------------------------------------------------------------------------------------
+// Positional encoding (reference Embedder, run_nerf_helpers.py:120-150; column order
+// [x y z, sin(2^0 xyz), cos(2^0 xyz), sin(2^1 xyz), ...]).  The two lane halves of a sample
+// split the frequencies: half 0 evaluates f in [0, F0), half 1 f in [F0, L), so both run the
+// same code with a different scale.  Per-half slot q: 0,1 = identity coords (x,y | z,0), then
+// for each local frequency fl and coordinate c the pair (sin, cos).
+constexpr NRN_HD int enc_F0(int L) { return (L + 1) / 2; }
+constexpr NRN_HD int enc_slots(int L) { return 2 + 6 * enc_F0(L); }
+constexpr NRN_HD int enc_col(int L, int h, int q) {
+    if (q == 0) return h ? 2 : 0;
+    if (q == 1) return h ? -1 : 1;
+    int pi = (q - 2) / 2, fn = (q - 2) % 2, fl = pi / 3, c = pi % 3;
+    int f = h * enc_F0(L) + fl;
+    if (fl >= enc_F0(L) || f >= L) return -1;
+    return 3 + 6 * f + 3 * fn + c;
+}
+// Bender input [xyz, latent] (run_nerf_helpers.py:525): logical vector
+//   v[0..2] = xyz (hi part), v[3..5] = xyz lo part (16-bit modes, same weight columns), v[6..7] = 0,
+//   v[8 .. 8+LAT) = latent.  Lane half h, slab s, element e holds v[(2s+h)*KH + e].
+constexpr NRN_HD int bin_len(int LAT) { return 8 + LAT; }
+constexpr NRN_HD int bin_col(int idx, int LAT, bool hilo) {
+    if (idx < 3) return idx;
+    if (idx < 6) return hilo ? idx - 3 : -1;
+    if (idx < 8) return -1;
+    return (idx - 8 < LAT) ? 3 + (idx - 8) : -1;
+}
+// Rigidity input = xyz only (run_nerf_helpers.py:546): v[0..2] hi, v[3..5] lo, v[6..7] = 0.
+constexpr NRN_HD int rin_len() { return 8; }
+constexpr NRN_HD int rin_col(int idx, bool hilo) {
+    if (idx < 3) return idx;
+    if (idx < 6) return hilo ? idx - 3 : -1;
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------
+// Layer list
+// ---------------------------------------------------------------------------------------
+enum LayerKind : int {
+    LK_BEND_IN = 0, LK_BEND_HID, LK_BEND_OUT, LK_RIG_IN, LK_RIG_HID, LK_RIG_OUT,
+    LK_TR_IN, LK_TR_HID, LK_TR_SKIP, LK_HEAD
+};
+
+struct LayerSpec {
+    int kind;     // LayerKind
+    int index;    // index into the reference ModuleList (network[i] / rigidity_network[i] / pts_linears[i])
+    int ns;       // input slabs (MFMAs per output tile)
+    int nt;       // output tiles of 32 rows
+    int tile0;    // global index of the layer's first tile
+};
+
+struct TileInfo {
+    int layer;        // index into layers[]
+    int t;            // tile within the layer
+    int starts_unit;  // 1: a new staging unit begins with this tile
+    int fbase;        // fragment index of this tile's first fragment inside its unit
+    int unit;         // unit index
+};
+
+constexpr int MAX_LAYERS = 40;
+constexpr int MAX_TILES = 256;
+
+struct Tables {
+    LayerSpec layers[MAX_LAYERS];
+    TileInfo tiles[MAX_TILES];
+    int unit_frags[MAX_TILES];
+    int nlayers, ntiles, nunits, slot_frags, mfma_per_block;
+};
+
+template <class SH, class A, bool HAS_BEND>
+constexpr Tables build_tables() {
+    constexpr int KH = SH::KH, SP = SH::SP;
+    constexpr int NS_ENC = cdiv(enc_slots(A::L), KH);
+    constexpr int NS_BIN = cdiv(bin_len(A::LAT), 2 * KH);
+    constexpr int NS_RIN = cdiv(rin_len(), 2 * KH);
+    constexpr int NT_W = A::W / 32, NT_BW = A::BW / 32, NT_RW = A::RW / 32;
+    Tables T{};
+    int nl = 0, tile0 = 0;
+    auto add = [&](int kind, int index, int ns, int nt) {
+        T.layers[nl] = LayerSpec{kind, index, ns, nt, tile0};
+        tile0 += nt;
+        ++nl;
+    };
+    if (HAS_BEND) {
+        add(LK_BEND_IN, 0, NS_BIN, NT_BW);
+        for (int i = 1; i < A::BD - 1; ++i) add(LK_BEND_HID, i, NT_BW * SP, NT_BW);
+        add(LK_BEND_OUT, A::BD - 1, NT_BW * SP, 1);
+        add(LK_RIG_IN, 0, NS_RIN, NT_RW);
+        for (int i = 1; i < A::RD - 1; ++i) add(LK_RIG_HID, i, NT_RW * SP, NT_RW);
+        add(LK_RIG_OUT, A::RD - 1, NT_RW * SP, 1);
+    }
+    add(LK_TR_IN, 0, NS_ENC, NT_W);
+    for (int i = 1; i < A::D; ++i) {
+        if (i - 1 == A::SKIP) add(LK_TR_SKIP, i, NS_ENC + NT_W * SP, NT_W);
+        else add(LK_TR_HID, i, NT_W * SP, NT_W);
+    }
+    add(LK_HEAD, 0, NT_W * SP, 1);
+    T.nlayers = nl;
+    T.ntiles = tile0;
+    // greedy grouping of whole tiles into staging units of at most `cap` fragments
+    int cap = SH::UNIT_MIN_FRAGS;
+    for (int l = 0; l < nl; ++l) cap = imax(cap, T.layers[l].ns);
+    int unit = -1, used = cap + 1, mf = 0;
+    for (int l = 0; l < nl; ++l) {
+        for (int t = 0; t < T.layers[l].nt; ++t) {
+            int ns = T.layers[l].ns;
+            int gi = T.layers[l].tile0 + t;
+            bool fresh = used + ns > cap;
+            if (fresh) { ++unit; used = 0; }
+            T.tiles[gi] = TileInfo{l, t, fresh ? 1 : 0, used, unit};
+            used += ns;
+            T.unit_frags[unit] = used;
+            mf += ns;
+        }
+    }
+    T.nunits = unit + 1;
+    T.slot_frags = cap;
+    T.mfma_per_block = mf;
+    return T;
+}
+
+template <class SH, class A, bool HAS_BEND>
+struct Plan {
+    static constexpr int KH = SH::KH, SP = SH::SP;
+    static constexpr int NS_ENC = cdiv(enc_slots(A::L), KH);
+    static constexpr int NS_BIN = cdiv(bin_len(A::LAT), 2 * KH);
+    static constexpr int NS_RIN = cdiv(rin_len(), 2 * KH);
+    static constexpr int NT_W = A::W / 32, NT_BW = A::BW / 32, NT_RW = A::RW / 32;
+    static constexpr Tables TB = build_tables<SH, A, HAS_BEND>();
+    static constexpr int NLAYERS = TB.nlayers;
+    static constexpr int NTILES = TB.ntiles;
+    static constexpr int NUNITS = TB.nunits;
+    static constexpr int SLOT_FRAGS = TB.slot_frags;
+    static constexpr int SLOT_BYTES = SLOT_FRAGS * SH::FRAG_BYTES;
+    static constexpr int MFMA_PER_BLOCK = TB.mfma_per_block;
+    static_assert(TB.ntiles <= MAX_TILES && TB.nlayers <= MAX_LAYERS, "plan too large");
+    // indices into layers[]
+    static constexpr int L_BEND0 = 0;
+    static constexpr int L_RIG0 = HAS_BEND ? A::BD : 0;
+    static constexpr int L_TRUNK0 = HAS_BEND ? (A::BD + A::RD) : 0;
+    static constexpr int L_HEAD = NLAYERS - 1;
+};
+
+// ---------------------------------------------------------------------------------------
+// Element maps: which reference weight element a fragment element holds.
+// ---------------------------------------------------------------------------------------
+// A fragment (layer, tile t, slab s) holds, for lane l (row i = l & 31, half h = l >> 5) and
+// element e < KH:   W_ref[ out_row(t, i) ][ in_col(s, h, e) ]   (0 where either is -1).
+template <class SH, class A>
+constexpr NRN_HD int in_col(int kind, int s, int h, int e, int in_features) {
+    constexpr int KH = SH::KH, SP = SH::SP;
+    constexpr int NS_ENC = cdiv(enc_slots(A::L), KH);
+    auto hidden = [&](int s2, int base) {
+        int tp = s2 / SP, u = s2 % SP, r = u * KH + e;
+        int col = 32 * tp + tile_row(r, h);
+        return (base + col < in_features) ? base + col : -1;
+    };
+    auto enc = [&](int s2) {
+        int q = s2 * KH + e;
+        return (q < enc_slots(A::L)) ? enc_col(A::L, h, q) : -1;
+    };
+    switch (kind) {
+        case LK_BEND_IN: return bin_col((2 * s + h) * KH + e, A::LAT, SH::HILO);
+        case LK_RIG_IN:  return rin_col((2 * s + h) * KH + e, SH::HILO);
+        case LK_TR_IN:   return enc(s);
+        case LK_TR_SKIP: return (s < NS_ENC) ? enc(s) : hidden(s - NS_ENC, 3 + 6 * A::L);
+        default:         return hidden(s, 0);
+    }
+}
+template <class A>
+constexpr NRN_HD int out_row(int kind, int t, int i, int out_features) {
+    switch (kind) {
+        case LK_BEND_OUT: return (i < 8 && (i & 3) < 3) ? (i & 3) : -1;     // xyz offsets duplicated for both lane halves
+        case LK_RIG_OUT:  return (i == 0 || i == 4) ? 0 : -1;               // rigidity logit duplicated likewise
+        case LK_HEAD:     return (i < 4) ? i : ((i == 8 && out_features > 4) ? 4 : -1);   // rgb,sigma in acc[0..3], ch 4 in acc[4]
+        default:          return (32 * t + i < out_features) ? 32 * t + i : -1;
+    }
+}
+
+using ArchDefault = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32>;
+using ShapeF32 = Shape<1>;
+using Shape16 = Shape<8>;
+
+}  // namespace nrn

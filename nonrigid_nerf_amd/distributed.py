@@ -1,0 +1,56 @@
+"""Multi-GPU rendering: rays sharded by rank, one all-gather of the rendered pixels.
+
+Replaces the reference's ``torch.nn.DataParallel(render_wrapper_class)`` (train.py:300-323): there,
+every call re-broadcasts all parameters from GPU0, scatters rays and gathers every output to GPU0
+from one Python thread per GPU.  Here it is one process per GPU (``torch.distributed``; backend
+"nccl" is RCCL over xGMI on ROCm), weights packed once per rank, rays split into contiguous
+``ceil(n / G)`` slices exactly like DataParallel's dim-0 scatter, and a single all-gather of the
+packed ``[rgb3, disp, acc]`` pixels (20 B/ray; 3.9 MB for a 512x384 frame).  Rays are independent
+(SURVEY.md section 8e), so there is no other exchange step.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int, rank: int):
+    """Contiguous ceil(n/world) slices, last ranks possibly short/empty (DataParallel's scatter rule)."""
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n), per
+
+
+def render_sharded(render_fn, rays: torch.Tensor, latents: torch.Tensor | None, group=None):
+    """Render ``rays`` cooperatively; every rank returns the full ``[n, 5]`` = (rgb, disp, acc) image.
+
+    ``render_fn(rays_shard, latents_shard) -> dict`` with ``rgb_map [m,3]``, ``disp_map [m]``,
+    ``acc_map [m]`` (e.g. a closure over ``nonrigid_nerf_amd.render.batchify_rays``).  Every rank
+    must pass the same ``rays`` / ``latents`` (as DataParallel's caller does on GPU0).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = rays.shape[0]
+    lo, hi, per = shard_bounds(n, world, rank)
+    packed = torch.zeros(per, 5, dtype=torch.float32, device=rays.device)
+    if hi > lo:
+        out = render_fn(rays[lo:hi], latents[lo:hi] if latents is not None else None)
+        packed[:hi - lo, 0:3] = out["rgb_map"]
+        packed[:hi - lo, 3] = out["disp_map"]
+        packed[:hi - lo, 4] = out["acc_map"]
+    if world == 1:
+        return packed[:n]
+    full = torch.empty(world * per, 5, dtype=torch.float32, device=rays.device)
+    dist.all_gather_into_tensor(full, packed, group=group)
+    return full[:n]
+
+
+def gather_pixels(packed_local: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather equally sized per-rank pixel blocks ``[m, 5]`` -> ``[world * m, 5]`` (weak-scaling bench)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return packed_local
+    full = torch.empty(world * packed_local.shape[0], packed_local.shape[1], dtype=packed_local.dtype,
+                       device=packed_local.device)
+    dist.all_gather_into_tensor(full, packed_local.contiguous(), group=group)
+    return full

@@ -1,0 +1,397 @@
+"""Drop-in replacements for the reference's ``render_rays`` / ``batchify_rays``.
+
+Call contract mirrored:
+
+* ``render()`` (train.py:402-408) calls ``batchify_rays(rays, additional_pixel_information,
+  chunk=..., detailed_output=..., **kwargs)``, which calls ``render_rays(rays_flat[i:i+chunk],
+  additional_pixel_information={"ray_bending_latents": ...}, detailed_output=..., **kwargs)``
+  (train.py:125-130).  Both are looked up as module globals, so ``install(train)`` rebinds them
+  for every caller (``render_path``, ``determine_nerf_volume_extent``, free_viewpoint_rendering.py).
+* weights are read from the ``network_fn`` / ``network_fine`` modules (``pts_linears``,
+  ``output_linear``) and from ``network_fn.ray_bender[0]`` (``network``, ``rigidity_network``);
+  ``network_query_fn`` is ignored (the encoding / chunking it closes over is fused in the kernel).
+* the editing knobs free_viewpoint_rendering.py:264-283 mutates on the modules are read per call.
+* output: dict with exactly the reference's keys / shapes / dtypes (train.py:952-972), freshly
+  allocated on the rays' device.
+
+Everything is computed by ``libnrnerf_hip.so``.  Configurations the library has no kernel for
+(autograd, stochastic sampling, exact non-rigid view directions, ...) are handed back to the
+*reference's own* function when one was saved by ``install``; otherwise they raise.  There is
+no CPU or PyTorch re-implementation in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DEFAULT_PRECISION = os.environ.get("NRNERF_PRECISION", "bf16")
+_state = threading.local()
+_fallbacks = {}          # {"render_rays": fn, "batchify_rays": fn} saved by install()
+_MAX_RAYS_PER_LAUNCH = 1 << 20
+
+
+def set_precision(p: str):
+    """Arithmetic type of the MLP contractions: "bf16" (default, headline), "f16" or "f32" (exact parity mode)."""
+    global _DEFAULT_PRECISION
+    if p not in _lib.PRECISIONS:
+        raise ValueError(f"unknown precision {p!r}")
+    _DEFAULT_PRECISION = p
+
+
+def get_precision() -> str:
+    return _DEFAULT_PRECISION
+
+
+class Unsupported(NotImplementedError):
+    """The requested configuration has no HIP kernel (and no reference function was saved to defer to)."""
+
+
+# --------------------------------------------------------------------------------------------
+# packed model handle
+# --------------------------------------------------------------------------------------------
+def _np32(t: torch.Tensor) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+
+
+class _Keep:
+    """Keeps the numpy arrays and ctypes arrays referenced by a descriptor alive."""
+    def __init__(self):
+        self.objs = []
+
+    def linear(self, mod) -> _lib.Linear:
+        w = _np32(mod.weight)
+        b = _np32(mod.bias) if getattr(mod, "bias", None) is not None else None
+        self.objs += [w, b]
+        fp = C.POINTER(C.c_float)
+        return _lib.Linear(w.ctypes.data_as(fp), b.ctypes.data_as(fp) if b is not None else fp(),
+                           w.shape[0], w.shape[1])
+
+    def linear_array(self, mods):
+        arr = (_lib.Linear * len(mods))(*[self.linear(m) for m in mods])
+        self.objs.append(arr)
+        return arr
+
+
+def _mlp_desc(net, keep: _Keep) -> _lib.MlpDesc:
+    d = _lib.MlpDesc()
+    d.depth, d.width = int(net.D), int(net.W)
+    skips = list(net.skips)
+    if len(skips) > 1:
+        raise Unsupported("more than one skip connection")
+    d.skip = int(skips[0]) if skips else -1
+    d.use_viewdirs = int(bool(net.use_viewdirs))
+    d.time_conditioned = int(bool(getattr(net, "time_conditioned_baseline", False)))
+    arr = keep.linear_array(list(net.pts_linears))
+    d.pts_linears = C.cast(arr, C.POINTER(_lib.Linear))
+    if net.use_viewdirs:
+        d.output_ch = 4
+        d.alpha_linear = keep.linear(net.alpha_linear)
+        d.feature_linear = keep.linear(net.feature_linear)
+        d.views_linear = keep.linear(net.views_linears[0])
+        d.rgb_linear = keep.linear(net.rgb_linear)
+    else:
+        d.output_linear = keep.linear(net.output_linear)
+        d.output_ch = int(net.output_linear.weight.shape[0])
+    return d
+
+
+def _bender_desc(rb, keep: _Keep) -> _lib.BenderDesc:
+    if getattr(rb, "ray_bending_mode", "simple_neural") != "simple_neural":
+        raise Unsupported(f"ray_bending_mode {rb.ray_bending_mode!r}")
+    if not getattr(rb, "use_rigidity_network", True) or getattr(rb, "use_positionally_encoded_input", False):
+        raise Unsupported("bender without rigidity network / with encoded input")
+    if list(getattr(rb, "skips", [])) or list(getattr(rb, "rigidity_skips", [])):
+        raise Unsupported("bender skip connections")
+    d = _lib.BenderDesc()
+    d.latent_size = int(rb.ray_bending_latent_size)
+    d.depth = len(rb.network)
+    d.hidden = int(rb.network[0].weight.shape[0])
+    d.rigidity_depth = len(rb.rigidity_network)
+    d.rigidity_hidden = int(rb.rigidity_network[0].weight.shape[0])
+    na, ra = keep.linear_array(list(rb.network)), keep.linear_array(list(rb.rigidity_network))
+    d.network = C.cast(na, C.POINTER(_lib.Linear))
+    d.rigidity_network = C.cast(ra, C.POINTER(_lib.Linear))
+    return d
+
+
+def build_model_desc(network_fn, network_fine, precision: str, device_index: int):
+    """ModelDesc for the C ABI from reference-style modules.  Returns (desc, keepalive)."""
+    keep = _Keep()
+    rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
+    desc = _lib.ModelDesc()
+    desc.struct_size = C.sizeof(_lib.ModelDesc)
+    desc.precision = _lib.PRECISIONS[precision]
+    if (int(network_fn.input_ch) - 3) % 6:
+        raise Unsupported("i_embed=-1 (identity embedding)")          # get_embedder, rnh:153-155
+    desc.multires = (int(network_fn.input_ch) - 3) // 6
+    icv = int(getattr(network_fn, "input_ch_views", 0))
+    desc.multires_views = (icv - 3) // 6 if icv >= 3 else 0
+    desc.device = device_index
+    cm = _mlp_desc(network_fn, keep)
+    keep.objs.append(cm)
+    desc.coarse = C.pointer(cm)
+    if network_fine is not None:
+        fm = _mlp_desc(network_fine, keep)
+        keep.objs.append(fm)
+        desc.fine = C.pointer(fm)
+    if rb is not None:
+        bd = _bender_desc(rb, keep)
+        keep.objs.append(bd)
+        desc.bender = C.pointer(bd)
+    return desc, keep
+
+
+def _fingerprint(mods):
+    fp = []
+    for m in mods:
+        if m is None:
+            fp.append(None)
+            continue
+        fp.append(tuple((p.data_ptr(), p._version) for p in m.parameters()))
+    return tuple(fp)
+
+
+class Model:
+    """Owns one ``nrnerf_model`` handle (packed weights resident in HBM on one device)."""
+
+    def __init__(self, network_fn, network_fine=None, precision: str | None = None, device=None):
+        self.lib = _lib.load()
+        self.precision = precision or _DEFAULT_PRECISION
+        dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
+        if dev.type != "cuda":
+            raise RuntimeError("nonrigid_nerf_amd renders on a ROCm device only (got %s)" % dev)
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
+        self.has_bender = bool(desc.bender)
+        self.latent_size = desc.bender.contents.latent_size if self.has_bender else 0
+        self.output_ch = desc.fine.contents.output_ch if desc.fine else desc.coarse.contents.output_ch
+        self.coarse_output_ch = desc.coarse.contents.output_ch
+        handle = C.c_void_p()
+        _lib.check(self.lib.nrnerf_model_create(C.byref(desc), C.byref(handle)), "nrnerf_model_create")
+        self.handle = handle
+        self._ws = None
+        del keep
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.nrnerf_model_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def profile_begin(self):
+        _lib.check(self.lib.nrnerf_profile_begin(self.handle), "nrnerf_profile_begin")
+
+    def profile_end(self) -> dict:
+        p = _lib.Profile()
+        _lib.check(self.lib.nrnerf_profile_end(self.handle, C.byref(p)), "nrnerf_profile_end")
+        return {name: dict(ms=p.ms[i], launches=p.launches[i], flops=p.flops[i], mfma_flops=p.mfma_flops[i])
+                for i, name in enumerate(_lib.KERNEL_NAMES)}
+
+    def render(self, rays: torch.Tensor, latents: torch.Tensor | None, N_samples: int, N_importance: int = 0,
+               retraw: bool = False, detailed_output: bool = False, rigidity_cutoff=None, test_time_scaling=None,
+               removal_threshold=None, want_z_vals: bool = False) -> dict:
+        """One ``render_rays`` worth of work on ``rays [N, 8|11]``; returns the reference's output dict."""
+        N = int(rays.shape[0])
+        S, I = int(N_samples), int(N_importance)
+        SF = S + I
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        rays = rays.to(**f32).contiguous()
+        a = _lib.RenderArgs()
+        a.struct_size = C.sizeof(_lib.RenderArgs)
+        a.n_rays, a.n_samples, a.n_importance = N, S, I
+        a.rays, a.ray_stride = rays.data_ptr(), rays.shape[1]
+        if self.has_bender:
+            if latents is None:
+                raise ValueError("ray_bending_latents are required when a ray bender is present")
+            if latents.dim() == 2 and latents.shape[0] == N and latents.stride(0) == 0 and latents.stride(1) == 1 \
+                    and latents.dtype == torch.float32 and latents.device == dev:
+                a.latents, a.latent_stride = latents.data_ptr(), 0          # frame code expanded per ray (train.py:465)
+            else:
+                latents = latents.to(**f32).contiguous()
+                a.latents, a.latent_stride = latents.data_ptr(), latents.shape[1]
+        out = {}
+
+        def new(key, *shape):
+            t = torch.empty(*shape, **f32)
+            out[key] = t
+            return t.data_ptr()
+
+        a.rgb_map, a.disp_map, a.acc_map = new("rgb_map", N, 3), new("disp_map", N), new("acc_map", N)
+        if retraw:
+            a.raw = new("raw", N, SF, self.output_ch if I > 0 else self.coarse_output_ch)
+        if I > 0:
+            a.rgb0, a.disp0, a.acc0, a.z_std = new("rgb0", N, 3), new("disp0", N), new("acc0", N), new("z_std", N)
+        if want_z_vals:
+            a.z_vals = new("_z_vals", N, SF)
+        if detailed_output:
+            def fill(so, prefix, ns):
+                so.visibility_weights = new(prefix + "visibility_weights", N, ns)
+                so.opacity_alpha = new(prefix + "opacity_alpha", N, ns)
+                so.initial_input_pts = new(prefix + "initial_input_pts", N, ns, 3)
+                so.input_pts = new(prefix + "input_pts", N, ns, 3)
+                if self.has_bender:
+                    so.unmasked_offsets = new(prefix + "unmasked_offsets", N, ns, 3)
+                    so.masked_offsets = new(prefix + "masked_offsets", N, ns, 3)
+                    so.rigidity_mask = new(prefix + "rigidity_mask", N, ns, 1)
+            fill(a.coarse, "", S)
+            if I > 0:
+                fill(a.fine, "fine_", SF)
+        a.detailed_output = int(detailed_output)
+        if rigidity_cutoff is not None:
+            a.has_rigidity_cutoff, a.rigidity_cutoff = 1, float(rigidity_cutoff)
+        if test_time_scaling is not None:
+            a.has_test_time_scaling, a.test_time_scaling = 1, float(test_time_scaling)
+        if removal_threshold is not None:
+            a.has_removal_threshold, a.removal_threshold = 1, float(removal_threshold)
+        nbytes = self.lib.nrnerf_workspace_bytes(self.handle, N, S, I)
+        ws = self._workspace(nbytes + 256)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        a.workspace, a.workspace_bytes = base, nbytes
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(self.lib.nrnerf_render(self.handle, C.byref(a), C.c_void_p(stream)), "nrnerf_render")
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# model cache (weights are packed once per (modules, version) -- no per-call broadcast as in DataParallel)
+# --------------------------------------------------------------------------------------------
+_cache = weakref.WeakKeyDictionary()
+_cache_lock = threading.Lock()
+
+
+def get_model(network_fn, network_fine=None, precision: str | None = None, device=None) -> Model:
+    precision = precision or _DEFAULT_PRECISION
+    rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
+    dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
+    key = (id(network_fine) if network_fine is not None else None, id(rb) if rb is not None else None, precision, str(dev))
+    fp = _fingerprint([network_fn, network_fine, rb])
+    with _cache_lock:
+        per = _cache.setdefault(network_fn, {})
+        hit = per.get(key)
+        if hit is not None and hit[0] == fp:
+            return hit[1]
+        model = Model(network_fn, network_fine, precision, dev)
+        per[key] = (fp, model)
+        return model
+
+
+# --------------------------------------------------------------------------------------------
+# eligibility + the two drop-in entry points
+# --------------------------------------------------------------------------------------------
+def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importance, lindisp, perturb, white_bkgd,
+                     raw_noise_std, pytest, latents):
+    if torch.is_grad_enabled() and (ray_batch.requires_grad or (latents is not None and latents.requires_grad)
+                                    or any(p.requires_grad for p in network_fn.parameters())):
+        return "autograd is enabled (training path)"
+    if perturb and perturb > 0.0:
+        return "perturb > 0 (stratified sampling draws from torch's RNG)"
+    if raw_noise_std and raw_noise_std > 0.0:
+        return "raw_noise_std > 0"
+    if lindisp or white_bkgd or pytest:
+        return "lindisp / white_bkgd / pytest flags"
+    if ray_batch.device.type != "cuda":
+        return "rays are not on a ROCm device"
+    if getattr(network_fn, "use_viewdirs", False):
+        return "use_viewdirs (view-dependent head not compiled in this build)"
+    if getattr(network_fn, "time_conditioned_baseline", False):
+        return "time_conditioned_baseline"
+    if N_samples < 2 or N_samples + N_importance > 256:
+        return "more than 256 samples per ray"
+    a = getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None)
+    b = getattr(network_fine, "test_time_nonrigid_object_removal_threshold", a) if network_fine is not None else a
+    if a != b:
+        return "different removal thresholds on coarse and fine networks"
+    return None
+
+
+def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retraw=False, lindisp=False, perturb=0.0,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.0,
+                additional_pixel_information=None, detailed_output=False, verbose=False, pytest=False,
+                **dummy_kwargs):
+    """Signature and semantics of reference ``render_rays`` (train.py:792-809)."""
+    latents = None
+    if additional_pixel_information is not None:
+        latents = additional_pixel_information.get("ray_bending_latents")
+    why = _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importance, lindisp, perturb,
+                           white_bkgd, raw_noise_std, pytest, latents)
+    if why is None and N_importance == 0 and detailed_output:
+        # the reference raises UnboundLocalError here (train.py:900-908 vs 967-970); keep that contract
+        raise UnboundLocalError("local variable 'visibility_weights_0' referenced before assignment "
+                                "(reference render_rays cannot do detailed_output with N_importance == 0)")
+    if why is None:
+        try:
+            model = get_model(network_fn, network_fine if N_importance > 0 else None, device=ray_batch.device)
+        except (Unsupported, _lib.NrnerfError) as e:
+            if isinstance(e, _lib.NrnerfError) and e.status != _lib.ERR_UNSUPPORTED:
+                raise
+            why = str(e)
+    if why is not None:
+        ref = _fallbacks.get("render_rays")
+        if ref is None:
+            raise Unsupported(f"no HIP kernel for this call ({why}) and no reference function installed to defer to")
+        return ref(ray_batch, network_fn, network_query_fn, N_samples, retraw=retraw, lindisp=lindisp,
+                   perturb=perturb, N_importance=N_importance, network_fine=network_fine, white_bkgd=white_bkgd,
+                   raw_noise_std=raw_noise_std, additional_pixel_information=additional_pixel_information,
+                   detailed_output=detailed_output, verbose=verbose, pytest=pytest, **dummy_kwargs)
+    rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
+    return model.render(
+        ray_batch, latents, N_samples, N_importance, retraw=retraw, detailed_output=detailed_output,
+        rigidity_cutoff=getattr(rb, "rigidity_test_time_cutoff", None) if rb is not None else None,
+        test_time_scaling=getattr(rb, "test_time_scaling", None) if rb is not None else None,
+        removal_threshold=getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None),
+        want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)))
+
+
+def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, detailed_output=False, **kwargs):
+    """Signature and semantics of reference ``batchify_rays`` (train.py:108-137).
+
+    ``chunk`` exists in the reference to bound memory and "does not affect final results"
+    (train.py:344-345).  The fused kernels need ~5 KB of scratch per ray instead of the reference's
+    ~70 KB, so rays are processed in launches of up to 2^20 rays (or ``chunk`` if larger).
+    """
+    n = rays_flat.shape[0]
+    step = max(int(chunk), _MAX_RAYS_PER_LAUNCH)
+    lat = additional_pixel_information["ray_bending_latents"] if additional_pixel_information else None
+    pieces = {}
+    for i in range(0, n, step):
+        api = {"ray_bending_latents": lat[i:i + step, :]} if lat is not None else None    # train.py:119-123
+        ret = render_rays(rays_flat[i:i + step], additional_pixel_information=api,
+                          detailed_output=detailed_output, **kwargs)
+        for k, v in ret.items():
+            pieces.setdefault(k, []).append(v)
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in pieces.items()}
+
+
+def install(train_module, precision: str | None = None):
+    """Rebind ``train_module.render_rays`` / ``.batchify_rays`` to the HIP path.
+
+    The originals are kept and used only for calls the library has no kernel for (training with
+    autograd, stochastic sampling, ...).  Returns a callable that undoes the patch.
+    """
+    _lib.load()      # fail now, loudly, if the library is missing
+    if precision is not None:
+        set_precision(precision)
+    orig = (train_module.render_rays, train_module.batchify_rays)
+    _fallbacks["render_rays"], _fallbacks["batchify_rays"] = orig
+    train_module.render_rays = render_rays
+    train_module.batchify_rays = batchify_rays
+
+    def uninstall():
+        train_module.render_rays, train_module.batchify_rays = orig
+        _fallbacks.clear()
+    return uninstall

@@ -1,0 +1,221 @@
+"""GPU parity tests proper: the HIP path (through the Python boundary -> C ABI -> kernels) against
+(a) the committed reference outputs in tests/golden, (b) the CPU oracle on the same seeded inputs,
+(c) size-independent properties at BASELINE.json's full sizes.
+
+fp32 MFMA mode is held to the fp32 tolerances of SURVEY.md section 8c (rgb/acc atol 1e-4, disp rtol 1e-3,
+equal_nan); bf16/f16 are judged by PSNR against the fp32 reference render (>= 40 dB) as BASELINE.md states.
+
+The one discrete decision of the algorithm whose outcome legitimately depends on fp32 rounding -- sample_pdf's
+`denom < 1e-5` branch (run_nerf_helpers.py:694; see tests/test_oracle_golden.py) -- is handled by checking the
+fine pass against the oracle evaluated AT THE DEPTHS THE GPU CHOSE (tight), and the depths themselves
+statistically (almost all equal, the rest inside one coarse bin).
+"""
+import pytest
+import torch
+
+from nonrigid_nerf_amd import render as R
+from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
+from oracle import nrnerf_oracle as O
+from tests.helpers import compare_dict, load_golden, psnr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def hip_render(scene, rays, latents, precision, chunk=1 << 20, retraw=False, detailed=False, knobs=None,
+               want_z=True, use_batchify=True):
+    cfg = scene.cfg
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    knobs = knobs or {}
+    if rb is not None:
+        rb.rigidity_test_time_cutoff = knobs.get("rigidity_test_time_cutoff")
+        rb.test_time_scaling = knobs.get("test_time_scaling")
+    for m in (coarse, fine):
+        if m is not None:
+            m.test_time_nonrigid_object_removal_threshold = knobs.get("removal_threshold")
+    R.set_precision(precision)
+    kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples,
+              N_importance=cfg.N_importance, perturb=0.0, raw_noise_std=0.0, white_bkgd=False, lindisp=False,
+              retraw=retraw, ray_bender=rb, _want_z_vals=want_z)
+    api = {"ray_bending_latents": latents.to(DEV)}
+    with torch.no_grad():
+        if use_batchify:
+            out = R.batchify_rays(rays.to(DEV), api, chunk=chunk, detailed_output=detailed, **kw)
+        else:
+            out = R.render_rays(rays.to(DEV), additional_pixel_information=api, detailed_output=detailed, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu() for k, v in out.items()}
+
+
+def oracle_fine_given_z(scene, rays, latents, z_vals, knobs=None, detailed=False):
+    """The oracle's fine pass evaluated at given merged depths (train.py:921-950)."""
+    cfg = scene.cfg
+    rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+    pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]
+    net = scene.fine if scene.fine is not None else scene.coarse
+    out = O.query_network(pts, None, latents, net, scene.bender, cfg, knobs, detailed)
+    raw, det = out if detailed else (out, {})
+    rgb, disp, acc, alpha, w, _ = O.composite(raw, z_vals, rays_d)
+    res = dict(rgb_map=rgb, disp_map=disp, acc_map=acc, raw=raw)
+    if detailed:
+        res.update(fine_visibility_weights=w, fine_opacity_alpha=alpha, **{"fine_" + k: v for k, v in det.items()})
+    return res
+
+
+COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "initial_input_pts",
+               "unmasked_offsets", "masked_offsets", "input_pts", "rigidity_mask"]
+
+
+@pytest.mark.parametrize("name", ["coarse_only_1k", "headline_64_128", "detailed_64_128", "ragged_chunks",
+                                  "knobs_64_64", "no_bender_64_64"])
+def test_fp32_mode_matches_reference_golden(name):
+    meta, cfg, scene, rays, latents, ref = load_golden(name)
+    got = hip_render(scene, rays, latents, "f32", chunk=meta["chunk"], retraw=bool(meta["retraw"]),
+                     detailed=bool(meta["detailed"]), knobs=meta["knobs"])
+    assert set(k for k in got if not k.startswith("_")) == set(ref.keys()), \
+        (sorted(set(got) ^ set(ref.keys())))
+    for k in ref:
+        assert got[k].shape == ref[k].shape and got[k].dtype == torch.float32, k
+    fails = []
+    if cfg.N_importance == 0:
+        fails += compare_dict(got, ref)
+    else:
+        # 1. coarse pass: no discrete decisions -> fp32 tolerance on everything the reference returns for it
+        fails += compare_dict(got, ref, keys=[k for k in COARSE_KEYS if k in ref])
+        # 2. merged depths: identical up to rounding for almost every sample
+        zo = O.batchify_rays(rays, latents, scene, chunk=meta["chunk"], knobs=O.Knobs(**meta["knobs"]))["_z_vals"]
+        zg = got["_z_vals"]
+        assert (zg[:, 1:] >= zg[:, :-1]).all(), "merged depths are not sorted"
+        moved = ((zg - zo).abs() > 2e-5).float().mean().item()
+        assert moved < 0.01, f"{moved:.4f} of merged depths differ from the oracle"
+        assert float((zg - zo).abs().max()) < 1.1 / (cfg.N_samples - 1), "a depth moved by more than one coarse bin"
+        fails += compare_dict(got, ref, keys=["z_std"], frac_ok=0.1, outlier_atol=1e-2)
+        # 3. fine pass at the depths the GPU chose: tight
+        fine = oracle_fine_given_z(scene, rays, latents, zg, O.Knobs(**meta["knobs"]), bool(meta["detailed"]))
+        fails += compare_dict(got, fine, keys=[k for k in fine if k in got])
+        # 4. end to end against the reference outputs, allowing the few rays whose sample moved
+        fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], frac_ok=0.10, outlier_atol=2e-2)
+    assert not fails, "\n".join(fails)
+
+
+@pytest.mark.parametrize("precision,min_psnr", [("bf16", 40.0), ("f16", 46.0)])
+def test_16bit_modes_psnr_vs_fp32_reference(precision, min_psnr):
+    """PSNR(ours, reference render) >= 40 dB for the reduced-precision modes."""
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(4096, 7, cfg)
+    ref = O.batchify_rays(rays, latents, scene, chunk=1024)
+    got = hip_render(scene, rays, latents, precision)
+    p_fine, p_coarse = psnr(got["rgb_map"], ref["rgb_map"]), psnr(got["rgb0"], ref["rgb0"])
+    p_acc = psnr(got["acc_map"], ref["acc_map"])
+    print(f"[{precision}] PSNR rgb_map {p_fine:.1f} dB, rgb0 {p_coarse:.1f} dB, acc {p_acc:.1f} dB")
+    assert p_coarse >= min_psnr and p_fine >= min_psnr - 2.0, (p_coarse, p_fine)
+
+
+def test_fp32_mode_vs_oracle_4k_rays():
+    """Same comparison as the golden test on a fresh seed and 4096 rays (oracle finishes in seconds)."""
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 2)
+    rays, latents = make_rays(4096, 11, cfg)
+    ref = O.batchify_rays(rays, latents, scene, chunk=1024)
+    got = hip_render(scene, rays, latents, "f32")
+    fails = compare_dict(got, ref, keys=["rgb0", "disp0", "acc0"])
+    fine = oracle_fine_given_z(scene, rays, latents, got["_z_vals"])
+    fails += compare_dict(got, fine, keys=["rgb_map", "disp_map", "acc_map"])
+    fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], frac_ok=0.10, outlier_atol=2e-2)
+    assert not fails, "\n".join(fails)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_full_size_properties(precision):
+    """BASELINE config 2 size (32768-ray chunk, 64+128): properties that need no oracle."""
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 0)
+    n = 32768 if precision == "bf16" else 8192
+    rays, latents = make_rays(n, 3, cfg)
+    a = hip_render(scene, rays, latents, precision, detailed=True)
+    # determinism / chunk invariance (train.py:344-345): split launch == single launch, bit for bit
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    R.set_precision(precision)
+    model = R.get_model(coarse, fine)
+    parts = [model.render(rays[i:i + 5000].to(DEV), latents[i:i + 5000].to(DEV), 64, 128, want_z_vals=True)
+             for i in range(0, n, 5000)]
+    torch.cuda.synchronize()
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std", "_z_vals"):
+        cat = torch.cat([p[k] for p in parts], 0).cpu()
+        assert torch.equal(torch.nan_to_num(cat), torch.nan_to_num(a[k])), f"{k} depends on the launch split"
+    # compositing identities
+    w = a["fine_visibility_weights"]
+    assert torch.allclose(w.sum(-1), a["acc_map"], atol=2e-5)
+    assert (w >= 0).all() and (a["acc_map"] <= 1 + 1e-4).all()
+    assert (a["fine_opacity_alpha"] >= 0).all() and (a["fine_opacity_alpha"] <= 1).all()
+    z = a["_z_vals"]
+    assert (z[:, 1:] >= z[:, :-1]).all() and (z >= cfg.near - 1e-6).all() and (z <= cfg.far + 1e-6).all()
+    # the coarse depths are a subset of the merged depths (train.py:920)
+    t = torch.linspace(0, 1, 64)
+    zc = cfg.near * (1 - t) + cfg.far * t
+    assert (torch.isclose(z[:, :, None], zc[None, None, :], atol=1e-6, rtol=0).any(1)).all()
+    # bending identities (run_nerf_helpers.py:567-570)
+    assert torch.allclose(a["fine_masked_offsets"], a["fine_rigidity_mask"] * a["fine_unmasked_offsets"], atol=1e-6)
+    assert torch.allclose(a["fine_input_pts"], a["fine_initial_input_pts"] + a["fine_masked_offsets"], atol=1e-6)
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+    assert torch.allclose(a["fine_initial_input_pts"], pts, atol=1e-6)
+    assert not torch.isnan(a["rgb_map"]).any() and not torch.isinf(a["rgb_map"]).any()
+
+
+def test_broadcast_latent_equals_expanded():
+    """render_path hands one frame code expanded to all rays (train.py:464-466): stride-0 path == materialised."""
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(777, 5, cfg)
+    one = latents[:1]
+    a = hip_render(scene, rays, one.expand(777, -1), "f32", use_batchify=False)
+    b = hip_render(scene, rays, one.expand(777, -1).contiguous(), "f32", use_batchify=False)
+    for k in a:
+        assert torch.equal(torch.nan_to_num(a[k]), torch.nan_to_num(b[k])), k
+
+
+def test_boundary_contract_errors_and_fallback():
+    cfg = SceneConfig(use_viewdirs=True, N_importance=64)
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(8, 0, cfg)
+    with pytest.raises(R.Unsupported):
+        hip_render(scene, rays, latents, "f32")
+    # detailed_output with N_importance == 0 raises like the reference (train.py:900-908 vs 967-970)
+    cfg0 = SceneConfig(N_importance=0)
+    scene0 = make_scene(cfg0, 0)
+    rays0, lat0 = make_rays(8, 0, cfg0)
+    with pytest.raises(UnboundLocalError):
+        hip_render(scene0, rays0, lat0, "f32", detailed=True)
+
+    # install(): unsupported calls go to the saved reference function, supported ones to the HIP path
+    class FakeTrain:
+        calls = []
+
+        @staticmethod
+        def render_rays(ray_batch, *a, **k):
+            FakeTrain.calls.append("render_rays")
+            return {"rgb_map": torch.zeros(ray_batch.shape[0], 3)}
+
+        @staticmethod
+        def batchify_rays(*a, **k):
+            FakeTrain.calls.append("batchify_rays")
+            return {}
+
+    undo = R.install(FakeTrain, precision="f32")
+    try:
+        rb, coarse, fine = build_modules(scene0, device=DEV)
+        api = {"ray_bending_latents": lat0.to(DEV)}
+        with torch.no_grad():
+            out = FakeTrain.batchify_rays(rays0.to(DEV), api, network_fn=coarse, network_query_fn=None, N_samples=64,
+                                          perturb=1.0)          # stochastic sampling -> reference
+            assert FakeTrain.calls == ["render_rays"] and out["rgb_map"].shape == (8, 3)
+            out = FakeTrain.batchify_rays(rays0.to(DEV), api, network_fn=coarse, network_query_fn=None, N_samples=64,
+                                          perturb=0.0)          # supported -> HIP
+            assert FakeTrain.calls == ["render_rays"] and out["rgb_map"].is_cuda
+        # with autograd on (training, train.py:152-287) the call is deferred to the reference as well
+        out = FakeTrain.batchify_rays(rays0.to(DEV), api, network_fn=coarse, network_query_fn=None, N_samples=64)
+        assert FakeTrain.calls == ["render_rays", "render_rays"]
+    finally:
+        undo()
+    assert FakeTrain.render_rays.__name__ == "render_rays" and FakeTrain.render_rays is not R.render_rays

@@ -1,0 +1,253 @@
+"""CPU checks of the host logic in libnrnerf_hip.so: symbol export, descriptor validation and the
+MFMA-fragment weight packer (``nrnerf_pack_host``).
+
+The packer is checked by *emulating the kernel's register dataflow* in numpy from the documented
+CDNA4 MFMA layouts (nrnerf_plan.h): A fragment lane l, element e = A[i = l&31][k = KH*(l>>5)+e];
+B slab lane (j, h), element e = B[k = KH*h+e][j]; D register r of lane (j, h) = D[tile_row(r,h)][j];
+the next layer's B slab t*SP+u takes element e from D register u*KH+e.  If the packed stream,
+bias table and unit table are right, chaining those rules over every layer must reproduce the
+plain ``F.linear`` network.  No compute entry point of the library is called (no GPU needed).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from nonrigid_nerf_amd import _lib
+from nonrigid_nerf_amd.render import build_model_desc
+from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_scene
+
+
+def tile_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    assert lib.nrnerf_abi_version() == _lib.ABI_VERSION
+    for name in _lib.EXPORTS:
+        assert hasattr(lib, name), name
+    # every prototype in the public header is bound
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(_lib._HERE), "include", "nrnerf.h")).read()
+    declared = set(re.findall(r"\b(nrnerf_[a-z_]+)\s*\(", hdr)) - {"nrnerf_workspace_bytes"} | {"nrnerf_workspace_bytes"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.strerror(0) == "ok" and "unsupported" in _lib.strerror(_lib.ERR_UNSUPPORTED)
+
+
+def _pack(scene_cfg, precision, which):
+    scene = make_scene(scene_cfg, 3)
+    rb, coarse, fine = build_modules(scene)
+    desc, keep = build_model_desc(coarse, fine, precision, 0)
+    lib = _lib.load()
+    info = _lib.PackedInfo()
+    null_u32 = C.POINTER(C.c_uint32)()
+    null_f = C.POINTER(C.c_float)()
+    _lib.check(lib.nrnerf_pack_host(C.byref(desc), which, C.byref(info), None, 0, null_u32, null_f), "size query")
+    stream = np.zeros(info.stream_bytes, dtype=np.uint8)
+    units = np.zeros(info.n_units + 1, dtype=np.uint32)
+    bias = np.zeros(info.n_bias_tiles * 32, dtype=np.float32)
+    _lib.check(lib.nrnerf_pack_host(C.byref(desc), which, C.byref(info), stream.ctypes.data_as(C.c_void_p),
+                                    stream.nbytes, units.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                    bias.ctypes.data_as(C.POINTER(C.c_float))), "pack")
+    return scene, (rb, coarse, fine), info, stream, units, bias
+
+
+class FragReader:
+    """Walks the packed stream fragment by fragment, decoding A[32][2*KH] matrices."""
+    def __init__(self, stream, precision, frag_bytes):
+        self.KH = 1 if precision == "f32" else 8
+        if precision == "f32":
+            self.vals = stream.view(np.float32).astype(np.float64)
+        elif precision == "bf16":
+            u = stream.view(np.uint16).astype(np.uint32) << 16
+            self.vals = u.view(np.float32).astype(np.float64)
+        else:
+            self.vals = stream.view(np.float16).astype(np.float64)
+        self.per = 64 * self.KH
+        assert frag_bytes == self.per * (4 if precision == "f32" else 2)
+        self.pos = 0
+
+    def next(self):
+        f = self.vals[self.pos * self.per:(self.pos + 1) * self.per].reshape(64, self.KH)
+        self.pos += 1
+        A = np.zeros((32, 2 * self.KH))
+        for lane in range(64):
+            A[lane & 31, self.KH * (lane >> 5):self.KH * (lane >> 5) + self.KH] = f[lane]
+        return A
+
+
+def dense_emul(fr, bias_tab, tile0, ns, nt, slabs):
+    """slabs: [ns][2*KH][nsamp] -> list of nt D tiles [32][nsamp]."""
+    out = []
+    for t in range(nt):
+        b = np.zeros(32)
+        for h in range(2):
+            for r in range(16):
+                b[tile_row(r, h)] = bias_tab[(tile0 + t) * 32 + h * 16 + r]
+        D = np.repeat(b[:, None], slabs[0].shape[1], 1)
+        for s in range(ns):
+            D = D + fr.next() @ slabs[s]
+        out.append(D)
+    return out
+
+
+def repack(tiles, KH, relu=True, rnd=None):
+    """D tiles -> B slabs of the next layer (the in-register hand-off)."""
+    SP = 16 // KH
+    slabs = []
+    for D in tiles:
+        X = np.maximum(D, 0) if relu else D
+        if rnd is not None:
+            X = rnd(X)
+        for u in range(SP):
+            sl = np.zeros((2 * KH, D.shape[1]))
+            for h in range(2):
+                for e in range(KH):
+                    sl[KH * h + e] = X[tile_row(u * KH + e, h)]
+            slabs.append(sl)
+    return slabs
+
+
+def enc_slabs(p, L, KH, rnd):
+    """Kernel-side positional encoding order: per half h slots [id0,id1,(sin,cos) per (fl,c)], f = h*F0+fl."""
+    F0 = (L + 1) // 2
+    nslot = -(-(2 + 6 * F0) // KH) * KH
+    ev = np.zeros((2, nslot, p.shape[0]))
+    for h in range(2):
+        ev[h, 0] = p[:, 2] if h else p[:, 0]
+        ev[h, 1] = 0 if h else p[:, 1]
+        for fl in range(F0):
+            for c in range(3):
+                arg = p[:, c] * float(2 ** (h * F0 + fl))
+                ev[h, 2 + 2 * (3 * fl + c)] = np.sin(arg)
+                ev[h, 2 + 2 * (3 * fl + c) + 1] = np.cos(arg)
+    ns = nslot // KH
+    slabs = []
+    for s in range(ns):
+        sl = np.zeros((2 * KH, p.shape[0]))
+        for h in range(2):
+            sl[KH * h:KH * h + KH] = ev[h, s * KH:(s + 1) * KH]
+        slabs.append(rnd(sl))
+    return slabs
+
+
+def vec_slabs(v, KH, rnd):
+    """Logical input vector v [len, nsamp] -> slabs with element (s,h,e) = v[(2s+h)*KH+e]."""
+    n = -(-v.shape[0] // (2 * KH))
+    vp = np.zeros((n * 2 * KH, v.shape[1]))
+    vp[:v.shape[0]] = v
+    return [rnd(vp[s * 2 * KH:(s + 1) * 2 * KH]) for s in range(n)]
+
+
+def rounder(precision):
+    if precision == "f32":
+        return lambda x: x
+    dt = torch.bfloat16 if precision == "bf16" else torch.float16
+    return lambda x: torch.from_numpy(np.asarray(x, dtype=np.float32)).to(dt).to(torch.float64).numpy()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("bend", [True, False])
+def test_packed_stream_reproduces_the_network(precision, bend):
+    cfg = SceneConfig(N_importance=128, ray_bending=bend)
+    scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=1)
+    KH = 1 if precision == "f32" else 8
+    SP = 16 // KH
+    rnd = rounder(precision)
+    hilo = precision != "f32"
+    fr = FragReader(stream, precision, info.frag_bytes)
+    gen = torch.Generator().manual_seed(5)
+    ns_ = 32
+    p = (torch.randn(ns_, 3, generator=gen) * 0.4).double().numpy()
+    lat = (torch.randn(ns_, 32, generator=gen) * 0.1).double().numpy()
+    tile0 = 0
+    pt = torch.from_numpy(p)
+    mfma = 0
+    if bend:
+        hi = rnd(p) if hilo else p
+        lo = (p - hi) if hilo else np.zeros_like(p)
+        v = np.concatenate([hi.T, lo.T, np.zeros((2, ns_)), lat.T], 0)             # bin vector (nrnerf_plan.h)
+        slabs = vec_slabs(v, KH, rnd)
+        nt_b = 2
+        tiles = dense_emul(fr, bias, tile0, len(slabs), nt_b, slabs); mfma += len(slabs) * nt_b; tile0 += nt_b
+        for _ in range(3):
+            slabs = repack(tiles, KH, True, rnd)
+            tiles = dense_emul(fr, bias, tile0, len(slabs), nt_b, slabs); mfma += len(slabs) * nt_b; tile0 += nt_b
+        slabs = repack(tiles, KH, True, rnd)
+        D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
+        off = D[0:3]                         # lanes of half 0, acc[0..2]
+        assert np.allclose(D[4:7], off)      # duplicated rows feed half 1
+        v = np.concatenate([hi.T, lo.T, np.zeros((2, ns_))], 0)
+        slabs = vec_slabs(v, KH, rnd)
+        tiles = dense_emul(fr, bias, tile0, len(slabs), 1, slabs); mfma += len(slabs); tile0 += 1
+        slabs = repack(tiles, KH, True, rnd)
+        tiles = dense_emul(fr, bias, tile0, len(slabs), 1, slabs); mfma += len(slabs); tile0 += 1
+        slabs = repack(tiles, KH, True, rnd)
+        D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
+        logit = D[0]
+        assert np.allclose(D[4], logit)
+        # reference (fp64 torch) bender
+        with torch.no_grad():
+            h = torch.cat([pt, torch.from_numpy(lat)], -1)
+            for i, l in enumerate(rb.network):
+                h = F.linear(h, l.weight.double(), None if l.bias is None else l.bias.double())
+                if i != len(rb.network) - 1:
+                    h = F.relu(h)
+            r = pt
+            for i, l in enumerate(rb.rigidity_network):
+                r = F.linear(r, l.weight.double(), l.bias.double())
+                if i != len(rb.rigidity_network) - 1:
+                    r = F.relu(r)
+        tol = 1e-9 if precision == "f32" else (3e-2 if precision == "bf16" else 4e-3)
+        scale = float(h.abs().max())
+        assert np.abs(off.T - h.numpy()).max() <= tol * max(scale, 1e-3) + 1e-12, "bender offsets"
+        assert np.abs(logit - r.numpy()[:, 0]).max() <= tol * max(float(r.abs().max()), 1.0), "rigidity logit"
+    # ---- trunk
+    slabs_enc = enc_slabs(p, 10, KH, rnd)
+    tiles = dense_emul(fr, bias, tile0, len(slabs_enc), 8, slabs_enc); mfma += len(slabs_enc) * 8; tile0 += 8
+    for i in range(1, 8):
+        slabs = repack(tiles, KH, True, rnd)
+        if i - 1 == 4:
+            slabs = slabs_enc + slabs
+        tiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs); mfma += len(slabs) * 8; tile0 += 8
+    slabs = repack(tiles, KH, True, rnd)
+    D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
+    raw = np.stack([D[0], D[1], D[2], D[3], D[8]], -1)       # acc[0..4] of half-0 lanes
+    assert fr.pos * info.frag_bytes == info.stream_bytes, "stream fully consumed"
+    assert tile0 == info.n_bias_tiles and mfma == info.mfma_per_block
+    with torch.no_grad():
+        cols = [pt]
+        for k in range(10):
+            cols += [torch.sin(pt * 2.0 ** k), torch.cos(pt * 2.0 ** k)]
+        x = torch.cat(cols, -1)
+        h = x
+        for i, l in enumerate(fine.pts_linears):
+            h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
+            if i == 4:
+                h = torch.cat([x, h], -1)
+        ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
+    tol = 1e-9 if precision == "f32" else (6e-2 if precision == "bf16" else 8e-3)
+    err = np.abs(raw - ref).max()
+    assert err <= tol * np.abs(ref).max(), f"trunk+head mismatch {err} vs scale {np.abs(ref).max()}"
+    # unit table: monotone, 16-byte words, last entry = stream size, every unit fits a slot
+    assert units[0] == 0 and int(units[-1]) * 16 == info.stream_bytes
+    sizes = np.diff(units.astype(np.int64)) * 16
+    assert (sizes > 0).all() and sizes.max() <= info.slot_bytes and (sizes % info.frag_bytes == 0).all()
+
+
+def test_unsupported_architectures_are_rejected():
+    lib = _lib.load()
+    for kw in (dict(netwidth=128), dict(netdepth=6), dict(multires=8), dict(bend_hidden=32), dict(latent_size=16)):
+        scene = make_scene(SceneConfig(**kw), 0)
+        rb, coarse, fine = build_modules(scene)
+        desc, keep = build_model_desc(coarse, fine, "bf16", 0)
+        info = _lib.PackedInfo()
+        rc = lib.nrnerf_pack_host(C.byref(desc), 0, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)())
+        assert rc == _lib.ERR_UNSUPPORTED, (kw, rc)
+    bad = _lib.ModelDesc()
+    assert lib.nrnerf_pack_host(C.byref(bad), 0, None, None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_INVALID
+    out = C.c_void_p()
+    assert lib.nrnerf_model_create(None, C.byref(out)) == _lib.ERR_INVALID
