@@ -65,7 +65,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
     out.ntiles = T.ntiles; out.nunits = T.nunits;
     out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = PL::SLOT_BYTES; out.mfma_per_block = T.mfma_per_block;
     size_t nfrags = 0;
-    for (int l = 0; l < T.nlayers; ++l) nfrags += (size_t)T.layers[l].ns * T.layers[l].nt;
+    for (int l = 0; l < T.nlayers; ++l) nfrags += (size_t)T.layers[l].ns * T.layers[l].nt * (1 + T.layers[l].split);
     out.stream.assign(nfrags * SH::FRAG_BYTES, 0);
     out.unit_off.assign(T.nunits + 1, 0);
     out.bias.assign((size_t)T.ntiles * 32, 0.0f);
@@ -77,22 +77,28 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
             const TileInfo& ti = T.tiles[sp.tile0 + t];
             if (ti.starts_unit) out.unit_off[ti.unit] = (uint32_t)(pos / 16);
             for (int s = 0; s < sp.ns; ++s) {
-                uint8_t* fr = out.stream.data() + pos;
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int i = lane & 31, h = lane >> 5;
-                    const int row = out_row<A>(sp.kind, t, i, lin->out_features);
-                    for (int e = 0; e < KH; ++e) {
-                        const int col = in_col<SH, A>(sp.kind, s, h, e, lin->in_features);
-                        const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
-                        if (KH == 1) {
-                            std::memcpy(fr + lane * 4, &w, 4);
-                        } else {
-                            const uint16_t q = (precision == NRNERF_PREC_BF16) ? f32_to_bf16(w) : f32_to_f16(w);
-                            std::memcpy(fr + (lane * KH + e) * 2, &q, 2);
+                // split layers: fragment pair (hi, lo) with lo = f16(w - f16(w)); others: one fragment
+                for (int part = 0; part <= sp.split; ++part) {
+                    uint8_t* fr = out.stream.data() + pos;
+                    const bool as_f16 = (precision == NRNERF_PREC_F16) || frag_is_f16<SH, A>(sp.kind, s);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 31, h = lane >> 5;
+                        const int row = out_row<A>(sp.kind, t, i, lin->out_features);
+                        for (int e = 0; e < KH; ++e) {
+                            const int col = in_col<SH, A>(sp.kind, s, h, e, lin->in_features);
+                            const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
+                            if (KH == 1) {
+                                std::memcpy(fr + lane * 4, &w, 4);
+                            } else {
+                                float v = w;
+                                if (part == 1) v = w - (float)(_Float16)w;
+                                const uint16_t q = as_f16 ? f32_to_f16(v) : f32_to_bf16(v);
+                                std::memcpy(fr + (lane * KH + e) * 2, &q, 2);
+                            }
                         }
                     }
+                    pos += SH::FRAG_BYTES;
                 }
-                pos += SH::FRAG_BYTES;
             }
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r) {

@@ -113,39 +113,82 @@ struct WStream {
         cur ^= 1;
         fetch();
     }
-    // A fragment `fidx` of the current unit for this lane
-    __device__ __forceinline__ typename P::frag frag(int fidx) const {
+    // A fragment `fidx` of the current unit for this lane, typed by the policy that consumes it
+    template <class PX>
+    __device__ __forceinline__ typename PX::frag frag(int fidx) const {
+        static_assert(PX::FRAG_BYTES == P::FRAG_BYTES, "mixed policies must share the fragment size");
         const char* p = ring + cur * SLOT_BYTES + fidx * P::FRAG_BYTES + lane * (P::FRAG_BYTES / 64);
-        return *(const typename P::frag*)p;
+        return *(const typename PX::frag*)p;
     }
 };
 
 // ------------------------------------------------------------------------------------------
 // one dense layer: for every output tile t, acc = bias; acc += A(t,s) * B(s) over the input slabs;
-// `epi(t, acc)` consumes the 32x32 fp32 tile.  B slabs come from in0 (first NS0) then in1.
+// `epi(t, acc)` consumes the 32x32 fp32 tile.  B slabs come from in0 (first NS0, policy P0) then
+// in1 (NS1, policy P1): the skip layer mixes f16 encoding slabs with bf16 hidden slabs in one
+// fp32 accumulator.
 // ------------------------------------------------------------------------------------------
-template <class P, class PL, int LI, int NS0, int NS1, class ST, class IN0, class IN1, class EPI>
+__device__ __forceinline__ f32x16 load_bias(const float* bias_lds, int tile, int h) {
+    const f32x4* bp = (const f32x4*)(bias_lds + tile * 32 + h * 16);
+    const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+    return f32x16{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3],
+                  b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
+}
+
+template <class P0, class P1, class PL, int LI, int NS0, int NS1, class ST, class IN0, class IN1, class EPI>
 __device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, const IN0& in0, const IN1& in1, EPI&& epi) {
     constexpr LayerSpec spec = PL::TB.layers[LI];
-    static_assert(spec.ns == NS0 + NS1, "slab count mismatch between kernel and plan");
+    static_assert(spec.ns == NS0 + NS1 && spec.split == 0, "slab count mismatch between kernel and plan");
     static_for<0, spec.nt>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t];
         if constexpr (ti.starts_unit) st.next_unit();
-        const f32x4* bp = (const f32x4*)(bias_lds + (spec.tile0 + t) * 32 + h * 16);
-        f32x16 acc;
-        {
-            const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-            acc = f32x16{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3],
-                         b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
-        }
+        f32x16 acc = load_bias(bias_lds, spec.tile0 + t, h);
         static_for<0, NS0>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            acc = P::mfma(st.frag(ti.fbase + s), in0[s], acc);
+            acc = P0::mfma(st.template frag<P0>(ti.fbase + s), in0[s], acc);
         });
         static_for<0, NS1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            acc = P::mfma(st.frag(ti.fbase + NS0 + s), in1[s], acc);
+            acc = P1::mfma(st.template frag<P1>(ti.fbase + NS0 + s), in1[s], acc);
+        });
+        epi(tc, acc);
+    });
+}
+
+// Activations of the bender / rigidity MLPs: value = hi (+ lo in the split 16-bit modes).
+template <class PE, int N, bool SPLIT>
+struct Act {
+    typename PE::frag hi[N];
+    typename PE::frag lo[SPLIT ? N : 1];
+    template <int S, int E>
+    __device__ __forceinline__ void set(float v) {
+        PE::template set<E>(hi[S], v);
+        if constexpr (SPLIT) PE::template set<E>(lo[S], v - PE::round(v));
+    }
+};
+
+// dense layer of the bender: 3-term split product  Whi*xhi + Whi*xlo + Wlo*xhi  when SPLIT
+template <class PE, bool SPLIT, class PL, int LI, int NS, class ST, class ACT, class EPI>
+__device__ __forceinline__ void dense_b(ST& st, const float* bias_lds, int h, const ACT& in, EPI&& epi) {
+    constexpr LayerSpec spec = PL::TB.layers[LI];
+    static_assert(spec.ns == NS && spec.split == (SPLIT ? 1 : 0), "bender layer mismatch between kernel and plan");
+    static_for<0, spec.nt>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t];
+        if constexpr (ti.starts_unit) st.next_unit();
+        f32x16 acc = load_bias(bias_lds, spec.tile0 + t, h);
+        static_for<0, NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (SPLIT) {
+                const auto whi = st.template frag<PE>(ti.fbase + 2 * s);
+                const auto wlo = st.template frag<PE>(ti.fbase + 2 * s + 1);
+                acc = PE::mfma(wlo, in.hi[s], acc);
+                acc = PE::mfma(whi, in.lo[s], acc);
+                acc = PE::mfma(whi, in.hi[s], acc);
+            } else {
+                acc = PE::mfma(st.template frag<PE>(ti.fbase + s), in.hi[s], acc);
+            }
         });
         epi(tc, acc);
     });
@@ -164,6 +207,16 @@ __device__ __forceinline__ void pack_tile(const f32x16& acc, OUT& out) {
         });
     });
 }
+template <class PE, int T, class ACT>
+__device__ __forceinline__ void pack_act(const f32x16& acc, ACT& out) {
+    static_for<0, PE::SP>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        static_for<0, PE::KH>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            out.template set<T * PE::SP + u, e>(fmaxf(acc[u * PE::KH + e], 0.0f));
+        });
+    });
+}
 
 // torch.linspace(0, 1, n)[i] in fp32 (ATen RangeFactories: symmetric two-sided evaluation)
 __device__ __forceinline__ float lin01(int i, int n) {
@@ -179,7 +232,9 @@ struct Empty {
 template <class P, class A, bool HAS_BEND, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
     using PL = Plan<P, A, HAS_BEND>;
-    using frag = typename P::frag;
+    using frag = typename P::frag;                                                   // hidden activations
+    using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;                      // encodings, bender (nrnerf_plan.h frag_is_f16)
+    using efrag = typename PE::frag;
     constexpr int KH = P::KH, SP = P::SP;
     constexpr int NS_ENC = PL::NS_ENC;
     constexpr int NT_W = PL::NT_W;
@@ -237,57 +292,51 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
         if constexpr (HAS_BEND) {
             constexpr int NS_BIN = PL::NS_BIN, NS_RIN = PL::NS_RIN;
             constexpr int NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
+            constexpr bool SPLIT = P::SPLIT;
             const float* lat = a.latents + (size_t)ray * a.lat_stride;
-            // hi/lo split of the coordinates for the 16-bit modes (same weight columns, nrnerf_plan.h)
-            float phi[3], plo[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { phi[c] = P::round(p[c]); plo[c] = P::HILO ? p[c] - phi[c] : 0.0f; }
             auto binval = [&](auto idxc) -> float {
                 constexpr int idx = decltype(idxc)::value;
-                if constexpr (idx < 3) return phi[idx];
-                else if constexpr (idx < 6) return plo[idx - 3];
+                if constexpr (idx < 3) return p[idx];
                 else if constexpr (idx < 8) return 0.0f;
                 else if constexpr (idx - 8 < A::LAT) return lat[idx - 8];
                 else return 0.0f;
             };
-            frag bin[NS_BIN];
+            Act<PE, NS_BIN, SPLIT> bin;
             static_for<0, NS_BIN>([&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
                 static_for<0, KH>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
                     const float v0 = binval(std::integral_constant<int, (2 * s) * KH + e>{});
                     const float v1 = binval(std::integral_constant<int, (2 * s + 1) * KH + e>{});
-                    P::template set<e>(bin[s], h ? v1 : v0);
+                    bin.template set<s, e>(h ? v1 : v0);
                 });
             });
             // ---- offset MLP (run_nerf_helpers.py:525-541)
-            frag ba[NB], bb[NB];
-            Empty none;
-            dense<P, PL, PL::L_BEND0, NS_BIN, 0>(st, bias_lds, h, bin, none, [&](auto tc, const f32x16& acc) {
-                pack_tile<P, true, decltype(tc)::value>(acc, ba);
+            Act<PE, NB, SPLIT> ba, bb;
+            dense_b<PE, SPLIT, PL, PL::L_BEND0, NS_BIN>(st, bias_lds, h, bin, [&](auto tc, const f32x16& acc) {
+                pack_act<PE, decltype(tc)::value>(acc, ba);
             });
             static_for<1, A::BD - 1>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i % 2 == 1) {
-                    dense<P, PL, PL::L_BEND0 + i, NB, 0>(st, bias_lds, h, ba, none, [&](auto tc, const f32x16& acc) {
-                        pack_tile<P, true, decltype(tc)::value>(acc, bb);
+                    dense_b<PE, SPLIT, PL, PL::L_BEND0 + i, NB>(st, bias_lds, h, ba, [&](auto tc, const f32x16& acc) {
+                        pack_act<PE, decltype(tc)::value>(acc, bb);
                     });
                 } else {
-                    dense<P, PL, PL::L_BEND0 + i, NB, 0>(st, bias_lds, h, bb, none, [&](auto tc, const f32x16& acc) {
-                        pack_tile<P, true, decltype(tc)::value>(acc, ba);
+                    dense_b<PE, SPLIT, PL, PL::L_BEND0 + i, NB>(st, bias_lds, h, bb, [&](auto tc, const f32x16& acc) {
+                        pack_act<PE, decltype(tc)::value>(acc, ba);
                     });
                 }
             });
             float off[3];
             auto take_off = [&](auto, const f32x16& acc) { off[0] = acc[0]; off[1] = acc[1]; off[2] = acc[2]; };
-            if constexpr ((A::BD - 2) % 2 == 1) dense<P, PL, PL::L_BEND0 + A::BD - 1, NB, 0>(st, bias_lds, h, bb, none, take_off);
-            else dense<P, PL, PL::L_BEND0 + A::BD - 1, NB, 0>(st, bias_lds, h, ba, none, take_off);
+            if constexpr ((A::BD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lds, h, bb, take_off);
+            else dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lds, h, ba, take_off);
             // ---- rigidity MLP (run_nerf_helpers.py:545-561); input = xyz only
-            frag rin[NS_RIN];
+            Act<PE, NS_RIN, SPLIT> rin;
             auto rinval = [&](auto idxc) -> float {
                 constexpr int idx = decltype(idxc)::value;
-                if constexpr (idx < 3) return phi[idx];
-                else if constexpr (idx < 6) return plo[idx - 3];
+                if constexpr (idx < 3) return p[idx];
                 else return 0.0f;
             };
             static_for<0, NS_RIN>([&](auto sc_) {
@@ -296,29 +345,29 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
                     constexpr int e = decltype(ec)::value;
                     const float v0 = rinval(std::integral_constant<int, (2 * s) * KH + e>{});
                     const float v1 = rinval(std::integral_constant<int, (2 * s + 1) * KH + e>{});
-                    P::template set<e>(rin[s], h ? v1 : v0);
+                    rin.template set<s, e>(h ? v1 : v0);
                 });
             });
-            frag ra[NR], rb[NR];
-            dense<P, PL, PL::L_RIG0, NS_RIN, 0>(st, bias_lds, h, rin, none, [&](auto tc, const f32x16& acc) {
-                pack_tile<P, true, decltype(tc)::value>(acc, ra);
+            Act<PE, NR, SPLIT> ra, rb;
+            dense_b<PE, SPLIT, PL, PL::L_RIG0, NS_RIN>(st, bias_lds, h, rin, [&](auto tc, const f32x16& acc) {
+                pack_act<PE, decltype(tc)::value>(acc, ra);
             });
             static_for<1, A::RD - 1>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i % 2 == 1) {
-                    dense<P, PL, PL::L_RIG0 + i, NR, 0>(st, bias_lds, h, ra, none, [&](auto tc, const f32x16& acc) {
-                        pack_tile<P, true, decltype(tc)::value>(acc, rb);
+                    dense_b<PE, SPLIT, PL, PL::L_RIG0 + i, NR>(st, bias_lds, h, ra, [&](auto tc, const f32x16& acc) {
+                        pack_act<PE, decltype(tc)::value>(acc, rb);
                     });
                 } else {
-                    dense<P, PL, PL::L_RIG0 + i, NR, 0>(st, bias_lds, h, rb, none, [&](auto tc, const f32x16& acc) {
-                        pack_tile<P, true, decltype(tc)::value>(acc, ra);
+                    dense_b<PE, SPLIT, PL, PL::L_RIG0 + i, NR>(st, bias_lds, h, rb, [&](auto tc, const f32x16& acc) {
+                        pack_act<PE, decltype(tc)::value>(acc, ra);
                     });
                 }
             });
             float logit;
             auto take_logit = [&](auto, const f32x16& acc) { logit = acc[0]; };
-            if constexpr ((A::RD - 2) % 2 == 1) dense<P, PL, PL::L_RIG0 + A::RD - 1, NR, 0>(st, bias_lds, h, rb, none, take_logit);
-            else dense<P, PL, PL::L_RIG0 + A::RD - 1, NR, 0>(st, bias_lds, h, ra, none, take_logit);
+            if constexpr ((A::RD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lds, h, rb, take_logit);
+            else dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lds, h, ra, take_logit);
 
             rig_mask = (tanhf(logit) + 1.0f) / 2.0f;                                  // rnh:559-561
             if (a.knobs.has_cutoff && rig_mask <= a.knobs.cutoff) rig_mask = 0.0f;    // rnh:563-564
@@ -360,12 +409,12 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
                 ev[2 + 2 * (3 * fl + c) + 1] = cv;
             });
         });
-        frag enc[NS_ENC];
+        efrag enc[NS_ENC];
         static_for<0, NS_ENC>([&](auto sc_) {
             constexpr int s = decltype(sc_)::value;
             static_for<0, KH>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
-                P::template set<e>(enc[s], ev[s * KH + e]);
+                PE::template set<e>(enc[s], ev[s * KH + e]);
             });
         });
 
@@ -373,7 +422,7 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
         constexpr int NH = NT_W * SP;
         frag ha[NH], hb[NH];
         Empty none;
-        dense<P, PL, PL::L_TRUNK0, NS_ENC, 0>(st, bias_lds, h, enc, none, [&](auto tc, const f32x16& acc) {
+        dense<PE, P, PL, PL::L_TRUNK0, NS_ENC, 0>(st, bias_lds, h, enc, none, [&](auto tc, const f32x16& acc) {
             pack_tile<P, true, decltype(tc)::value>(acc, ha);
         });
         static_for<1, A::D>([&](auto ic) {
@@ -381,17 +430,17 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
             constexpr bool skip = (i - 1 == A::SKIP);
             if constexpr (i % 2 == 1) {
                 if constexpr (skip)
-                    dense<P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lds, h, enc, ha, [&](auto tc, const f32x16& acc) {
+                    dense<PE, P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lds, h, enc, ha, [&](auto tc, const f32x16& acc) {
                         pack_tile<P, true, decltype(tc)::value>(acc, hb); });
                 else
-                    dense<P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lds, h, ha, none, [&](auto tc, const f32x16& acc) {
+                    dense<P, P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lds, h, ha, none, [&](auto tc, const f32x16& acc) {
                         pack_tile<P, true, decltype(tc)::value>(acc, hb); });
             } else {
                 if constexpr (skip)
-                    dense<P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lds, h, enc, hb, [&](auto tc, const f32x16& acc) {
+                    dense<PE, P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lds, h, enc, hb, [&](auto tc, const f32x16& acc) {
                         pack_tile<P, true, decltype(tc)::value>(acc, ha); });
                 else
-                    dense<P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lds, h, hb, none, [&](auto tc, const f32x16& acc) {
+                    dense<P, P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lds, h, hb, none, [&](auto tc, const f32x16& acc) {
                         pack_tile<P, true, decltype(tc)::value>(acc, ha); });
             }
         });
@@ -399,8 +448,8 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
         auto take_raw = [&](auto, const f32x16& acc) {
             raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; raw[3] = acc[3]; raw[4] = acc[4];
         };
-        if constexpr ((A::D - 1) % 2 == 1) dense<P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, hb, none, take_raw);
-        else dense<P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, ha, none, take_raw);
+        if constexpr ((A::D - 1) % 2 == 1) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, hb, none, take_raw);
+        else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, ha, none, take_raw);
 
         if (HAS_BEND && a.knobs.detailed && a.knobs.has_removal && rig_mask >= a.knobs.removal)
             raw[3] = raw[3] * 0.0f;                                                  // rnh:308-311

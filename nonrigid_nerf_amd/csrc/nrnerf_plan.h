@@ -38,7 +38,12 @@ struct Shape {
     static constexpr int SP = 16 / KH_;            // B-operand slabs produced by one 32-feature D tile
     static constexpr int ELEM_BYTES = (KH_ == 1) ? 4 : 2;
     static constexpr int FRAG_BYTES = 64 * KH_ * ELEM_BYTES;   // one A fragment: 1024 (16-bit) / 256 (f32)
-    static constexpr bool HILO = (KH_ != 1);       // 16-bit modes feed xyz to the bender as hi + lo halves
+    // 16-bit modes evaluate the bender / rigidity MLPs with a 3-term split product
+    //   W x ~= Whi xhi + Whi xlo + Wlo xhi      (hi = f16(v), lo = f16(v - hi))
+    // which is fp32-equivalent for this purpose: the offsets feed a 2^9-frequency encoding, so plain
+    // 16-bit offsets cost 10+ dB of PSNR.  Split layers stream two A fragments
+    // (hi, lo) per (tile, slab) and issue three MFMAs.
+    static constexpr bool SPLIT = (KH_ != 1);
     static constexpr int UNIT_MIN_FRAGS = (KH_ == 1) ? 128 : 16;   // staging granularity target (32 / 16 KiB)
 };
 
@@ -69,22 +74,17 @@ constexpr NRN_HD int enc_col(int L, int h, int q) {
     return 3 + 6 * f + 3 * fn + c;
 }
 // Bender input [xyz, latent] (run_nerf_helpers.py:525): logical vector
-//   v[0..2] = xyz (hi part), v[3..5] = xyz lo part (16-bit modes, same weight columns), v[6..7] = 0,
-//   v[8 .. 8+LAT) = latent.  Lane half h, slab s, element e holds v[(2s+h)*KH + e].
+//   v[0..2] = xyz, v[3..7] = 0 (keeps the latent 8-aligned), v[8 .. 8+LAT) = latent.
+// Lane half h, slab s, element e holds v[(2s+h)*KH + e].
 constexpr NRN_HD int bin_len(int LAT) { return 8 + LAT; }
-constexpr NRN_HD int bin_col(int idx, int LAT, bool hilo) {
+constexpr NRN_HD int bin_col(int idx, int LAT) {
     if (idx < 3) return idx;
-    if (idx < 6) return hilo ? idx - 3 : -1;
     if (idx < 8) return -1;
     return (idx - 8 < LAT) ? 3 + (idx - 8) : -1;
 }
-// Rigidity input = xyz only (run_nerf_helpers.py:546): v[0..2] hi, v[3..5] lo, v[6..7] = 0.
+// Rigidity input = xyz only (run_nerf_helpers.py:546): v[0..2] = xyz, rest 0.
 constexpr NRN_HD int rin_len() { return 8; }
-constexpr NRN_HD int rin_col(int idx, bool hilo) {
-    if (idx < 3) return idx;
-    if (idx < 6) return hilo ? idx - 3 : -1;
-    return -1;
-}
+constexpr NRN_HD int rin_col(int idx) { return (idx < 3) ? idx : -1; }
 
 // ---------------------------------------------------------------------------------------
 // Layer list
@@ -97,9 +97,10 @@ enum LayerKind : int {
 struct LayerSpec {
     int kind;     // LayerKind
     int index;    // index into the reference ModuleList (network[i] / rigidity_network[i] / pts_linears[i])
-    int ns;       // input slabs (MFMAs per output tile)
+    int ns;       // input slabs per output tile
     int nt;       // output tiles of 32 rows
     int tile0;    // global index of the layer's first tile
+    int split;    // 1: 3-term split product (2 A fragments and 3 MFMAs per slab)
 };
 
 struct TileInfo {
@@ -130,7 +131,8 @@ constexpr Tables build_tables() {
     Tables T{};
     int nl = 0, tile0 = 0;
     auto add = [&](int kind, int index, int ns, int nt) {
-        T.layers[nl] = LayerSpec{kind, index, ns, nt, tile0};
+        const int split = (SH::SPLIT && kind <= LK_RIG_OUT) ? 1 : 0;
+        T.layers[nl] = LayerSpec{kind, index, ns, nt, tile0, split};
         tile0 += nt;
         ++nl;
     };
@@ -152,18 +154,18 @@ constexpr Tables build_tables() {
     T.ntiles = tile0;
     // greedy grouping of whole tiles into staging units of at most `cap` fragments
     int cap = SH::UNIT_MIN_FRAGS;
-    for (int l = 0; l < nl; ++l) cap = imax(cap, T.layers[l].ns);
+    for (int l = 0; l < nl; ++l) cap = imax(cap, T.layers[l].ns * (1 + T.layers[l].split));
     int unit = -1, used = cap + 1, mf = 0;
     for (int l = 0; l < nl; ++l) {
         for (int t = 0; t < T.layers[l].nt; ++t) {
-            int ns = T.layers[l].ns;
+            int nf = T.layers[l].ns * (1 + T.layers[l].split);      // fragments of this tile
             int gi = T.layers[l].tile0 + t;
-            bool fresh = used + ns > cap;
+            bool fresh = used + nf > cap;
             if (fresh) { ++unit; used = 0; }
             T.tiles[gi] = TileInfo{l, t, fresh ? 1 : 0, used, unit};
-            used += ns;
+            used += nf;
             T.unit_frags[unit] = used;
-            mf += ns;
+            mf += T.layers[l].ns * (T.layers[l].split ? 3 : 1);
         }
     }
     T.nunits = unit + 1;
@@ -213,12 +215,21 @@ constexpr NRN_HD int in_col(int kind, int s, int h, int e, int in_features) {
         return (q < enc_slots(A::L)) ? enc_col(A::L, h, q) : -1;
     };
     switch (kind) {
-        case LK_BEND_IN: return bin_col((2 * s + h) * KH + e, A::LAT, SH::HILO);
-        case LK_RIG_IN:  return rin_col((2 * s + h) * KH + e, SH::HILO);
+        case LK_BEND_IN: return bin_col((2 * s + h) * KH + e, A::LAT);
+        case LK_RIG_IN:  return rin_col((2 * s + h) * KH + e);
         case LK_TR_IN:   return enc(s);
         case LK_TR_SKIP: return (s < NS_ENC) ? enc(s) : hidden(s - NS_ENC, 3 + 6 * A::L);
         default:         return hidden(s, 0);
     }
+}
+// 16-bit modes: which fragments are f16 regardless of the hidden type -- everything whose B operand
+// is bounded by construction (coordinates, latent codes, sin/cos) or feeds the encoding (the bender).
+template <class SH, class A>
+constexpr NRN_HD bool frag_is_f16(int kind, int s) {
+    constexpr int NS_ENC = cdiv(enc_slots(A::L), SH::KH);
+    if (kind <= LK_RIG_OUT || kind == LK_TR_IN) return true;
+    if (kind == LK_TR_SKIP) return s < NS_ENC;
+    return false;
 }
 template <class A>
 constexpr NRN_HD int out_row(int kind, int t, int i, int out_features) {

@@ -83,7 +83,8 @@ def test_fp32_mode_matches_reference_golden(name):
         # 1. coarse pass: no discrete decisions -> fp32 tolerance on everything the reference returns for it
         fails += compare_dict(got, ref, keys=[k for k in COARSE_KEYS if k in ref])
         # 2. merged depths: identical up to rounding for almost every sample
-        zo = O.batchify_rays(rays, latents, scene, chunk=meta["chunk"], knobs=O.Knobs(**meta["knobs"]))["_z_vals"]
+        zo = O.batchify_rays(rays, latents, scene, chunk=meta["chunk"], knobs=O.Knobs(**meta["knobs"]),
+                             detailed_output=bool(meta["detailed"]))["_z_vals"]   # the removal knob only acts when detailed
         zg = got["_z_vals"]
         assert (zg[:, 1:] >= zg[:, :-1]).all(), "merged depths are not sorted"
         moved = ((zg - zo).abs() > 2e-5).float().mean().item()
@@ -98,7 +99,7 @@ def test_fp32_mode_matches_reference_golden(name):
     assert not fails, "\n".join(fails)
 
 
-@pytest.mark.parametrize("precision,min_psnr", [("bf16", 40.0), ("f16", 46.0)])
+@pytest.mark.parametrize("precision,min_psnr", [("bf16", 40.0), ("f16", 55.0)])
 def test_16bit_modes_psnr_vs_fp32_reference(precision, min_psnr):
     """PSNR(ours, reference render) >= 40 dB for the reduced-precision modes."""
     cfg = SceneConfig()

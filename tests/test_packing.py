@@ -56,22 +56,27 @@ def _pack(scene_cfg, precision, which):
 
 
 class FragReader:
-    """Walks the packed stream fragment by fragment, decoding A[32][2*KH] matrices."""
+    """Walks the packed stream fragment by fragment, decoding A[32][2*KH] matrices.
+
+    In the 16-bit modes a fragment is f16 when its B operand is bounded by construction or feeds the
+    encoding (bender, rigidity, encoding slabs; nrnerf_plan.h frag_is_f16) and bf16/f16 otherwise.
+    """
     def __init__(self, stream, precision, frag_bytes):
         self.KH = 1 if precision == "f32" else 8
+        self.precision = precision
         if precision == "f32":
-            self.vals = stream.view(np.float32).astype(np.float64)
-        elif precision == "bf16":
-            u = stream.view(np.uint16).astype(np.uint32) << 16
-            self.vals = u.view(np.float32).astype(np.float64)
+            self.f32 = stream.view(np.float32).astype(np.float64)
         else:
-            self.vals = stream.view(np.float16).astype(np.float64)
+            u = stream.view(np.uint16).astype(np.uint32) << 16
+            self.bf16 = u.view(np.float32).astype(np.float64)
+            self.f16 = stream.view(np.float16).astype(np.float64)
         self.per = 64 * self.KH
         assert frag_bytes == self.per * (4 if precision == "f32" else 2)
         self.pos = 0
 
-    def next(self):
-        f = self.vals[self.pos * self.per:(self.pos + 1) * self.per].reshape(64, self.KH)
+    def next(self, as_f16=False):
+        vals = self.f32 if self.precision == "f32" else (self.f16 if (as_f16 or self.precision == "f16") else self.bf16)
+        f = vals[self.pos * self.per:(self.pos + 1) * self.per].reshape(64, self.KH)
         self.pos += 1
         A = np.zeros((32, 2 * self.KH))
         for lane in range(64):
@@ -79,8 +84,11 @@ class FragReader:
         return A
 
 
-def dense_emul(fr, bias_tab, tile0, ns, nt, slabs):
-    """slabs: [ns][2*KH][nsamp] -> list of nt D tiles [32][nsamp]."""
+def dense_emul(fr, bias_tab, tile0, ns, nt, slabs, split=False, f16_slabs=0):
+    """slabs: [ns][2*KH][nsamp] -> list of nt D tiles [32][nsamp].
+
+    split: every slab has a (hi, lo) fragment pair whose sum is the weight (3-term split product).
+    f16_slabs: the first f16_slabs slabs are f16 fragments even in bf16 mode (-1: all)."""
     out = []
     for t in range(nt):
         b = np.zeros(32)
@@ -89,7 +97,13 @@ def dense_emul(fr, bias_tab, tile0, ns, nt, slabs):
                 b[tile_row(r, h)] = bias_tab[(tile0 + t) * 32 + h * 16 + r]
         D = np.repeat(b[:, None], slabs[0].shape[1], 1)
         for s in range(ns):
-            D = D + fr.next() @ slabs[s]
+            f16 = f16_slabs < 0 or s < f16_slabs
+            A = fr.next(f16)
+            if split:
+                lo = fr.next(f16)
+                assert np.abs(lo).max() <= np.abs(A).max() * 2.0 ** -10 + 1e-30
+                A = A + lo
+            D = D + A @ slabs[s]
         out.append(D)
     return out
 
@@ -157,7 +171,9 @@ def test_packed_stream_reproduces_the_network(precision, bend):
     KH = 1 if precision == "f32" else 8
     SP = 16 // KH
     rnd = rounder(precision)
-    hilo = precision != "f32"
+    split = precision != "f32"                 # bender layers use the 3-term split product in 16-bit modes
+    rnd_b = (lambda x: x)                      # hi + lo carries ~22 bits: emulate as exact
+    rnd_e = rounder("f16") if split else rnd   # encoding slabs are f16 in both 16-bit modes
     fr = FragReader(stream, precision, info.frag_bytes)
     gen = torch.Generator().manual_seed(5)
     ns_ = 32
@@ -167,26 +183,26 @@ def test_packed_stream_reproduces_the_network(precision, bend):
     pt = torch.from_numpy(p)
     mfma = 0
     if bend:
-        hi = rnd(p) if hilo else p
-        lo = (p - hi) if hilo else np.zeros_like(p)
-        v = np.concatenate([hi.T, lo.T, np.zeros((2, ns_)), lat.T], 0)             # bin vector (nrnerf_plan.h)
-        slabs = vec_slabs(v, KH, rnd)
+        m3 = 3 if split else 1
+        kwb = dict(split=split, f16_slabs=-1)
+        v = np.concatenate([p.T, np.zeros((5, ns_)), lat.T], 0)                    # bin vector (nrnerf_plan.h)
+        slabs = vec_slabs(v, KH, rnd_b)
         nt_b = 2
-        tiles = dense_emul(fr, bias, tile0, len(slabs), nt_b, slabs); mfma += len(slabs) * nt_b; tile0 += nt_b
+        tiles = dense_emul(fr, bias, tile0, len(slabs), nt_b, slabs, **kwb); mfma += m3 * len(slabs) * nt_b; tile0 += nt_b
         for _ in range(3):
-            slabs = repack(tiles, KH, True, rnd)
-            tiles = dense_emul(fr, bias, tile0, len(slabs), nt_b, slabs); mfma += len(slabs) * nt_b; tile0 += nt_b
-        slabs = repack(tiles, KH, True, rnd)
-        D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
+            slabs = repack(tiles, KH, True, rnd_b)
+            tiles = dense_emul(fr, bias, tile0, len(slabs), nt_b, slabs, **kwb); mfma += m3 * len(slabs) * nt_b; tile0 += nt_b
+        slabs = repack(tiles, KH, True, rnd_b)
+        D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs, **kwb)[0]; mfma += m3 * len(slabs); tile0 += 1
         off = D[0:3]                         # lanes of half 0, acc[0..2]
         assert np.allclose(D[4:7], off)      # duplicated rows feed half 1
-        v = np.concatenate([hi.T, lo.T, np.zeros((2, ns_))], 0)
-        slabs = vec_slabs(v, KH, rnd)
-        tiles = dense_emul(fr, bias, tile0, len(slabs), 1, slabs); mfma += len(slabs); tile0 += 1
-        slabs = repack(tiles, KH, True, rnd)
-        tiles = dense_emul(fr, bias, tile0, len(slabs), 1, slabs); mfma += len(slabs); tile0 += 1
-        slabs = repack(tiles, KH, True, rnd)
-        D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
+        v = np.concatenate([p.T, np.zeros((5, ns_))], 0)
+        slabs = vec_slabs(v, KH, rnd_b)
+        tiles = dense_emul(fr, bias, tile0, len(slabs), 1, slabs, **kwb); mfma += m3 * len(slabs); tile0 += 1
+        slabs = repack(tiles, KH, True, rnd_b)
+        tiles = dense_emul(fr, bias, tile0, len(slabs), 1, slabs, **kwb); mfma += m3 * len(slabs); tile0 += 1
+        slabs = repack(tiles, KH, True, rnd_b)
+        D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs, **kwb)[0]; mfma += m3 * len(slabs); tile0 += 1
         logit = D[0]
         assert np.allclose(D[4], logit)
         # reference (fp64 torch) bender
@@ -201,18 +217,20 @@ def test_packed_stream_reproduces_the_network(precision, bend):
                 r = F.linear(r, l.weight.double(), l.bias.double())
                 if i != len(rb.rigidity_network) - 1:
                     r = F.relu(r)
-        tol = 1e-9 if precision == "f32" else (3e-2 if precision == "bf16" else 4e-3)
+        tol = 1e-9 if precision == "f32" else 2e-6     # split product: weights carry hi + lo (~22 bits)
         scale = float(h.abs().max())
         assert np.abs(off.T - h.numpy()).max() <= tol * max(scale, 1e-3) + 1e-12, "bender offsets"
         assert np.abs(logit - r.numpy()[:, 0]).max() <= tol * max(float(r.abs().max()), 1.0), "rigidity logit"
     # ---- trunk
-    slabs_enc = enc_slabs(p, 10, KH, rnd)
-    tiles = dense_emul(fr, bias, tile0, len(slabs_enc), 8, slabs_enc); mfma += len(slabs_enc) * 8; tile0 += 8
+    slabs_enc = enc_slabs(p, 10, KH, rnd_e)
+    tiles = dense_emul(fr, bias, tile0, len(slabs_enc), 8, slabs_enc, f16_slabs=-1); mfma += len(slabs_enc) * 8; tile0 += 8
     for i in range(1, 8):
         slabs = repack(tiles, KH, True, rnd)
+        n16 = 0
         if i - 1 == 4:
             slabs = slabs_enc + slabs
-        tiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs); mfma += len(slabs) * 8; tile0 += 8
+            n16 = len(slabs_enc)
+        tiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs, f16_slabs=n16); mfma += len(slabs) * 8; tile0 += 8
     slabs = repack(tiles, KH, True, rnd)
     D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
     raw = np.stack([D[0], D[1], D[2], D[3], D[8]], -1)       # acc[0..4] of half-0 lanes
