@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -62,20 +63,18 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
     using PL = Plan<SH, A, HAS_BEND>;
     constexpr int KH = SH::KH;
     const Tables& T = PL::TB;
-    out.ntiles = T.ntiles; out.nunits = T.nunits;
-    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = PL::SLOT_BYTES; out.mfma_per_block = T.mfma_per_block;
-    size_t nfrags = 0;
-    for (int l = 0; l < T.nlayers; ++l) nfrags += (size_t)T.layers[l].ns * T.layers[l].nt * (1 + T.layers[l].split);
-    out.stream.assign(nfrags * SH::FRAG_BYTES, 0);
-    out.unit_off.assign(T.nunits + 1, 0);
+    out.ntiles = T.ntiles; out.nunits = T.nunits_padded;
+    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES; out.mfma_per_block = T.mfma_per_block;
+    out.stream.assign((size_t)T.nunits_padded * SH::UNIT_BYTES, 0);       // zero padded to whole units
+    out.unit_off.assign(T.nunits_padded + 1, 0);
+    for (int u = 0; u <= T.nunits_padded; ++u) out.unit_off[u] = (uint32_t)((size_t)u * SH::UNIT_BYTES / 16);
     out.bias.assign((size_t)T.ntiles * 32, 0.0f);
     size_t pos = 0;
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
         const nrnerf_linear* lin = layer_source(d, mlp, sp);
         for (int t = 0; t < sp.nt; ++t) {
-            const TileInfo& ti = T.tiles[sp.tile0 + t];
-            if (ti.starts_unit) out.unit_off[ti.unit] = (uint32_t)(pos / 16);
+            if (pos != (size_t)T.tiles[sp.tile0 + t].gbase * SH::FRAG_BYTES) std::abort();   // plan/packer drift
             for (int s = 0; s < sp.ns; ++s) {
                 // split layers: fragment pair (hi, lo) with lo = f16(w - f16(w)); others: one fragment
                 for (int part = 0; part <= sp.split; ++part) {
@@ -91,7 +90,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                                 std::memcpy(fr + lane * 4, &w, 4);
                             } else {
                                 float v = w;
-                                if (part == 1) v = w - (float)(_Float16)w;
+                                if (part == 1) v = (w - (float)(_Float16)w) * SH::LO_SCALE;
                                 const uint16_t q = as_f16 ? f32_to_f16(v) : f32_to_bf16(v);
                                 std::memcpy(fr + (lane * KH + e) * 2, &q, 2);
                             }
@@ -107,7 +106,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                 }
         }
     }
-    out.unit_off[T.nunits] = (uint32_t)(pos / 16);
+    if (pos != (size_t)T.nfrags * SH::FRAG_BYTES) std::abort();
 }
 
 bool linear_is(const nrnerf_linear& l, int out_f, int in_f, bool need_bias) {
@@ -373,7 +372,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.rays = a->rays; na.ray_stride = a->ray_stride;
     na.latents = a->latents; na.lat_stride = a->latent_stride;
     na.z = nullptr; na.n_rays = N; na.S = S;
-    na.wstream = m->coarse.stream; na.unit_off = m->coarse.unit_off; na.bias = m->coarse.bias;
+    na.wstream = m->coarse.stream; na.bias = m->coarse.bias;
     na.raw4 = raw_c;
     na.raw_out = (I == 0) ? a->raw : nullptr;
     na.raw_ch = m->coarse.output_ch;
@@ -406,7 +405,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // ---- K2: fine network on the merged depths
     NetArgs nf = na;
     nf.z = z_fine; nf.S = SF;
-    nf.wstream = m->fine.stream; nf.unit_off = m->fine.unit_off; nf.bias = m->fine.bias;
+    nf.wstream = m->fine.stream; nf.bias = m->fine.bias;
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
     e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,

@@ -29,8 +29,7 @@ struct NetArgs {
     const float* latents; int lat_stride;
     const float* z;          // [N,S] sample depths, or nullptr: coarse linspace between near and far
     int n_rays, S;
-    const void* wstream;     // packed fragment stream of this pass
-    const uint32_t* unit_off;    // [NUNITS+1] offsets in 16-byte words
+    const void* wstream;     // packed fragment stream of this pass (whole 16 KiB units, nrnerf_plan.h)
     const float* bias;       // [NTILES*32]
     float* raw4;             // [N,S,4] rgb + sigma workspace consumed by the composite kernel
     float* raw_out;          // [N,S,raw_ch] user-visible raw ("retraw") or nullptr

@@ -29,19 +29,54 @@ namespace nrn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// compile-time loop, in order, instantiation depth log2(N - I) (the f32 layers have > 1000 steps)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
+    if constexpr (N - I == 1) {
         f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
+    } else if constexpr (N - I > 1) {
+        constexpr int M = I + (N - I) / 2;
+        static_for<I, M>(f);
+        static_for<M, N>(f);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // precision policies
 // ------------------------------------------------------------------------------------------
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// accumulator registers 8U..8U+7 -> one 16-bit B slab, optionally through relu: 4 x v_cvt_pk_{bf16,f16}_f32 and
+// 4 x v_pk_max_i16 (relu on the packed pairs: negative 16-bit floats are negative int16; the sign survives
+// rounding).  Written pair-wise because hipcc only selects the packed conversion for 2-vectors.
+template <class F8, class F2, int U, bool RELU>
+__device__ __forceinline__ F8 pack16(const f32x16& c) {
+    u32x4 w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x2 t = {c[8 * U + 2 * k], c[8 * U + 2 * k + 1]};
+        const F2 p = __builtin_convertvector(t, F2);
+        s16x2 q = __builtin_bit_cast(s16x2, p);
+        if (RELU) q = __builtin_elementwise_max(q, (s16x2)(short)0);
+        w[k] = __builtin_bit_cast(unsigned, q);
+    }
+    return __builtin_bit_cast(F8, w);
+}
+
+// relu(x) for a finite-or-inf float as ONE integer max: negative floats are negative as signed ints.
+// (fmaxf on an MFMA result costs two v_max_f32: hipcc inserts a canonicalising max first.)
+__device__ __forceinline__ float relu_bits(float x) {
+    return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0));
+}
 struct PolBF16 : Shape<8> {
     typedef __bf16 frag __attribute__((ext_vector_type(8)));
+    static constexpr int PF = 4;             // A-fragment software prefetch depth (16 VGPRs)
+    typedef __bf16 frag2 __attribute__((ext_vector_type(2)));
+    template <int U, bool RELU>
+    static __device__ __forceinline__ frag from_acc(const f32x16& c) { return pack16<frag, frag2, U, RELU>(c); }
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
@@ -51,6 +86,10 @@ struct PolBF16 : Shape<8> {
 };
 struct PolF16 : Shape<8> {
     typedef _Float16 frag __attribute__((ext_vector_type(8)));
+    static constexpr int PF = 4;
+    typedef _Float16 frag2 __attribute__((ext_vector_type(2)));
+    template <int U, bool RELU>
+    static __device__ __forceinline__ frag from_acc(const f32x16& c) { return pack16<frag, frag2, U, RELU>(c); }
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
@@ -60,6 +99,9 @@ struct PolF16 : Shape<8> {
 };
 struct PolF32 : Shape<1> {
     typedef float frag;
+    static constexpr int PF = 8;
+    template <int U, bool RELU>
+    static __device__ __forceinline__ frag from_acc(const f32x16& c) { return RELU ? relu_bits(c[U]) : c[U]; }
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
     }
@@ -69,57 +111,75 @@ struct PolF32 : Shape<1> {
 };
 
 // ------------------------------------------------------------------------------------------
-// weight stream: HBM/L2 -> registers -> LDS ring (2 slots), one unit ahead.
-//   next_unit(): publish the staged unit into the free slot, barrier, start fetching the one after.
-// All waves of the workgroup call next_unit() at the same (compile-time) points.
+// weight stream: HBM/L2 -> LDS ring by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip).
+//
+// The stream is a sequence of 16 KiB units; unit U lives in ring slot U % RING.  All waves of the
+// workgroup consume every unit, each wave DMAs PW 1-KiB pieces of it.  advance<U>() is called (at a
+// compile-time-known point) right before the first fragment of unit U is read:
+//     s_waitcnt vmcnt((RING-2)*PW) lgkmcnt(0)   my pieces of unit U have landed (U+1, U+2 may still fly);
+//                                               my ds_reads of unit U-1 have completed
+//     s_barrier                                 => everyone's pieces landed, everyone is done with U-1
+//     issue DMA of unit U+RING-1 into slot (U-1) % RING
+// vmcnt retires in order, so other VMEM traffic in flight (the per-block ray loads / raw stores) can only
+// make the counted wait stricter, never weaker.
 // ------------------------------------------------------------------------------------------
-template <class P, int WAVES, int SLOT_BYTES, int NUNITS>
-struct WStream {
-    static constexpr int SLOT_PIECES = SLOT_BYTES / 1024;               // 1 KiB = one wave-wide 16 B load
-    static constexpr int PIECES = (SLOT_PIECES + WAVES - 1) / WAVES;
-    static_assert(SLOT_BYTES % 1024 == 0, "slot must be a multiple of 1 KiB");
-    const char* g;
-    const uint32_t* uoff;
-    char* ring;
-    int cur;          // slot holding the current unit
-    int u_next;       // unit whose fetch is issued next
-    int staged_bytes;
-    uint4 st[PIECES];
-    int wave, lane;
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
 
-    __device__ __forceinline__ void init(const void* stream, const uint32_t* unit_off, char* lds, int w, int l) {
-        g = (const char*)stream; uoff = unit_off; ring = lds; cur = 1; u_next = 0; wave = w; lane = l;
-        fetch();
+template <class P, int WAVES, int NUP>
+struct WRing {
+    static constexpr int UNIT = P::UNIT_BYTES;
+    static constexpr int PW = UNIT / 1024 / WAVES;          // DMA instructions per wave per unit
+    static_assert(UNIT % (1024 * WAVES) == 0, "unit must split evenly over the waves");
+    static_assert(NUP % RING == 0 && NUP >= RING, "unit count must be a padded multiple of the ring depth");
+    const char* ubase;     // stream + this wave's piece offset: wave-uniform, lives in SGPRs
+    unsigned lane16;       // lane * 16: the only per-lane part of a DMA source address (saddr + voffset form)
+    char* ring;            // LDS ring base
+    int wave_off;          // this wave's piece offset inside a unit (wave-uniform)
+    int lane_off;          // lane * (FRAG_BYTES / 64)
+
+    __device__ __forceinline__ void init(const void* stream, char* lds, int wave, int lane) {
+        wave_off = wave * PW * 1024;
+        ubase = (const char*)stream + wave_off;
+        lane16 = (unsigned)lane * 16u;
+        ring = lds;
+        lane_off = lane * (P::FRAG_BYTES / 64);
+        static_for<0, RING - 1>([&](auto uc) { issue<decltype(uc)::value>(); });
     }
-    __device__ __forceinline__ void fetch() {
-        const uint32_t o0 = uoff[u_next], o1 = uoff[u_next + 1];
-        staged_bytes = (int)(o1 - o0) * 16;
-        const char* src = g + (size_t)o0 * 16 + lane * 16;
+    template <int V>
+    __device__ __forceinline__ void issue() {
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int p = wave + WAVES * i;
-            if (p * 1024 < staged_bytes) st[i] = *(const uint4*)(src + p * 1024);
+        for (int i = 0; i < PW; ++i) {
+            // The offset is a compile-time constant, but hiding it from the optimiser stops LICM from hoisting
+            // one 64-bit per-lane address per (unit, piece) out of the persistent loop (134 spilled VGPR pairs,
+            // and every scratch reload drains the DMA queue with a vmcnt(0)).  Cost: s_mov + s_add/s_addc.
+            unsigned off = (unsigned)(V * UNIT + i * 1024);
+            asm volatile("" : "+s"(off));
+            const char* src = (ubase + off) + lane16;
+            char* dst = ring + (V % RING) * UNIT + wave_off + i * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
-        u_next = (u_next + 1 == NUNITS) ? 0 : u_next + 1;
     }
-    __device__ __forceinline__ void next_unit() {
-        char* dst = ring + (cur ^ 1) * SLOT_BYTES + lane * 16;
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int p = wave + WAVES * i;
-            if (p * 1024 < staged_bytes) *(uint4*)(dst + p * 1024) = st[i];
-        }
-        __syncthreads();
-        cur ^= 1;
-        fetch();
+    template <int U>
+    __device__ __forceinline__ void advance() {
+        wait_vm_lgkm0<(RING - 2) * PW>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue<(U + RING - 1) % NUP>();
     }
-    // A fragment `fidx` of the current unit for this lane, typed by the policy that consumes it
-    template <class PX>
-    __device__ __forceinline__ typename PX::frag frag(int fidx) const {
+    // fragment GF (index in the whole stream) for this lane; advances the ring when GF opens a new unit
+    template <class PX, int GF>
+    __device__ __forceinline__ typename PX::frag frag() {
         static_assert(PX::FRAG_BYTES == P::FRAG_BYTES, "mixed policies must share the fragment size");
-        const char* p = ring + cur * SLOT_BYTES + fidx * P::FRAG_BYTES + lane * (P::FRAG_BYTES / 64);
+        constexpr int UF = P::UNIT_FRAGS;
+        if constexpr (GF % UF == 0) advance<GF / UF>();
+        const char* p = ring + ((GF / UF) % RING) * UNIT + (GF % UF) * P::FRAG_BYTES + lane_off;
         return *(const typename PX::frag*)p;
     }
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -135,24 +195,33 @@ __device__ __forceinline__ f32x16 load_bias(const float* bias_lds, int tile, int
                   b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
 }
 
+// Fragments are prefetched PF steps ahead across the whole layer (all tiles form one flat sequence), so a
+// ds_read_b128 is in flight for ~PF MFMAs before its consumer instead of being waited for immediately.
 template <class P0, class P1, class PL, int LI, int NS0, int NS1, class ST, class IN0, class IN1, class EPI>
 __device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, const IN0& in0, const IN1& in1, EPI&& epi) {
     constexpr LayerSpec spec = PL::TB.layers[LI];
     static_assert(spec.ns == NS0 + NS1 && spec.split == 0, "slab count mismatch between kernel and plan");
-    static_for<0, spec.nt>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t];
-        if constexpr (ti.starts_unit) st.next_unit();
-        f32x16 acc = load_bias(bias_lds, spec.tile0 + t, h);
-        static_for<0, NS0>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            acc = P0::mfma(st.template frag<P0>(ti.fbase + s), in0[s], acc);
-        });
-        static_for<0, NS1>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            acc = P1::mfma(st.template frag<P1>(ti.fbase + NS0 + s), in1[s], acc);
-        });
-        epi(tc, acc);
+    constexpr int NS = NS0 + NS1, Q = spec.nt * NS, PF = P1::PF;
+    constexpr int G0 = PL::TB.tiles[spec.tile0].gbase;
+    // raw 16-byte (or 4-byte) fragment registers; typed at the MFMA by the policy of the slab
+    typename P1::frag a[PF];
+    auto load = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int s = q % NS;
+        if constexpr (s < NS0) a[q % PF] = __builtin_bit_cast(typename P1::frag, st.template frag<P0, G0 + q>());
+        else a[q % PF] = st.template frag<P1, G0 + q>();
+    };
+    static_for<0, (PF < Q ? PF : Q)>([&](auto qc) { load(qc); });
+    f32x16 acc;
+    static_for<0, Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int t = q / NS, s = q % NS;
+        if constexpr (s == 0) acc = load_bias(bias_lds, spec.tile0 + t, h);
+        const typename P1::frag cur = a[q % PF];
+        if constexpr (q + PF < Q) load(std::integral_constant<int, q + PF>{});
+        if constexpr (s < NS0) acc = P0::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[s], acc);
+        else acc = P1::mfma(cur, in1[s - NS0], acc);
+        if constexpr (s == NS - 1) epi(std::integral_constant<int, t>{}, acc);
     });
 }
 
@@ -164,7 +233,7 @@ struct Act {
     template <int S, int E>
     __device__ __forceinline__ void set(float v) {
         PE::template set<E>(hi[S], v);
-        if constexpr (SPLIT) PE::template set<E>(lo[S], v - PE::round(v));
+        if constexpr (SPLIT) PE::template set<E>(lo[S], (v - PE::round(v)) * PE::LO_SCALE);
     }
 };
 
@@ -176,20 +245,21 @@ __device__ __forceinline__ void dense_b(ST& st, const float* bias_lds, int h, co
     static_for<0, spec.nt>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t];
-        if constexpr (ti.starts_unit) st.next_unit();
         f32x16 acc = load_bias(bias_lds, spec.tile0 + t, h);
+        f32x16 corr = {};       // 2^11-scaled cross terms
         static_for<0, NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             if constexpr (SPLIT) {
-                const auto whi = st.template frag<PE>(ti.fbase + 2 * s);
-                const auto wlo = st.template frag<PE>(ti.fbase + 2 * s + 1);
-                acc = PE::mfma(wlo, in.hi[s], acc);
-                acc = PE::mfma(whi, in.lo[s], acc);
+                const auto whi = st.template frag<PE, ti.gbase + 2 * s>();
+                const auto wlo = st.template frag<PE, ti.gbase + 2 * s + 1>();
+                corr = PE::mfma(wlo, in.hi[s], corr);
+                corr = PE::mfma(whi, in.lo[s], corr);
                 acc = PE::mfma(whi, in.hi[s], acc);
             } else {
-                acc = PE::mfma(st.template frag<PE>(ti.fbase + s), in.hi[s], acc);
+                acc = PE::mfma(st.template frag<PE, ti.gbase + s>(), in.hi[s], acc);
             }
         });
+        if constexpr (SPLIT) acc += corr * (1.0f / PE::LO_SCALE);
         epi(tc, acc);
     });
 }
@@ -199,12 +269,7 @@ template <class P, bool RELU, int T, class OUT>
 __device__ __forceinline__ void pack_tile(const f32x16& acc, OUT& out) {
     static_for<0, P::SP>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        static_for<0, P::KH>([&](auto ec) {
-            constexpr int e = decltype(ec)::value;
-            float v = acc[u * P::KH + e];
-            if (RELU) v = fmaxf(v, 0.0f);
-            P::template set<e>(out[T * P::SP + u], v);
-        });
+        out[T * P::SP + u] = P::template from_acc<u, RELU>(acc);
     });
 }
 template <class PE, int T, class ACT>
@@ -213,7 +278,7 @@ __device__ __forceinline__ void pack_act(const f32x16& acc, ACT& out) {
         constexpr int u = decltype(uc)::value;
         static_for<0, PE::KH>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
-            out.template set<T * PE::SP + u, e>(fmaxf(acc[u * PE::KH + e], 0.0f));
+            out.template set<T * PE::SP + u, e>(relu_bits(acc[u * PE::KH + e]));
         });
     });
 }
@@ -239,21 +304,21 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
     constexpr int NS_ENC = PL::NS_ENC;
     constexpr int NT_W = PL::NT_W;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // one array: ring | bias (G17: 16-B aligned carve)
     char* ring = smem;
-    float* bias_lds = (float*)(smem + 2 * PL::SLOT_BYTES);
+    float* bias_lds = (float*)(smem + RING * P::UNIT_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform (SGPR)
     const int h = lane >> 5;
     const int j = lane & 31;
 
     for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = a.bias[i];
-
-    WStream<P, WAVES, PL::SLOT_BYTES, PL::NUNITS> st;
-    st.init(a.wstream, a.unit_off, ring, wave, lane);
     __syncthreads();
+
+    WRing<P, WAVES, PL::NUP> st;
+    st.init(a.wstream, ring, wave, lane);
 
     const int S = a.S;
     const int bpr = (S + 31) >> 5;                 // 32-sample blocks per ray
@@ -461,7 +526,10 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
                 if (a.raw_ch > 4) ro[4] = raw[4];
             }
         }
+        // padding units (keep the ring phase identical every pass and prime the next pass' first units)
+        static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
     }
+    st.drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
 // ------------------------------------------------------------------------------------------
@@ -470,7 +538,7 @@ __global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
 template <class P, class A, bool HAS_BEND, int WAVES>
 static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) {
     using PL = Plan<P, A, HAS_BEND>;
-    const size_t lds = 2 * (size_t)PL::SLOT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float);
+    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float);
     auto kern = net_kernel<P, A, HAS_BEND, WAVES>;
     static bool attr_set = false;    // idempotent; racing threads set the same value
     if (!attr_set) {

@@ -39,12 +39,16 @@ struct Shape {
     static constexpr int ELEM_BYTES = (KH_ == 1) ? 4 : 2;
     static constexpr int FRAG_BYTES = 64 * KH_ * ELEM_BYTES;   // one A fragment: 1024 (16-bit) / 256 (f32)
     // 16-bit modes evaluate the bender / rigidity MLPs with a 3-term split product
-    //   W x ~= Whi xhi + Whi xlo + Wlo xhi      (hi = f16(v), lo = f16(v - hi))
+    //   W x ~= Whi xhi + 2^-11 (Whi xlo + Wlo xhi)     hi = f16(v), lo = f16((v - hi) * 2^11)
     // which is fp32-equivalent for this purpose: the offsets feed a 2^9-frequency encoding, so plain
-    // 16-bit offsets cost 10+ dB of PSNR.  Split layers stream two A fragments
-    // (hi, lo) per (tile, slab) and issue three MFMAs.
+    // 16-bit offsets cost 10+ dB of PSNR.  The lo parts are kept pre-scaled by
+    // 2^11 (exact) and accumulated separately: unscaled they are f16 subnormals (w*2^-12 < 6.1e-5),
+    // which the matrix pipe does not keep (measured: the Wlo term vanished).  Split layers stream two
+    // A fragments (hi, lo) per (tile, slab) and issue three MFMAs.
     static constexpr bool SPLIT = (KH_ != 1);
-    static constexpr int UNIT_MIN_FRAGS = (KH_ == 1) ? 128 : 16;   // staging granularity target (32 / 16 KiB)
+    static constexpr float LO_SCALE = 2048.0f;
+    static constexpr int UNIT_BYTES = 16384;                      // staging granularity of the LDS ring
+    static constexpr int UNIT_FRAGS = UNIT_BYTES / FRAG_BYTES;    // 16 (16-bit) / 64 (f32) fragments per unit
 };
 
 template <int W_, int D_, int SKIP_, int L_, int BW_, int BD_, int RW_, int RD_, int LAT_>
@@ -106,10 +110,14 @@ struct LayerSpec {
 struct TileInfo {
     int layer;        // index into layers[]
     int t;            // tile within the layer
-    int starts_unit;  // 1: a new staging unit begins with this tile
-    int fbase;        // fragment index of this tile's first fragment inside its unit
-    int unit;         // unit index
+    int gbase;        // index, in the whole stream, of this tile's first fragment
 };
+
+// The stream is cut into fixed units of UNIT_BYTES regardless of tile boundaries; fragment g lives in
+// unit g / UNIT_FRAGS, which the kernel stages in LDS ring slot (g / UNIT_FRAGS) % RING.  Everything is
+// compile-time, so the kernel needs no table: it knows statically when a fragment index crosses into a
+// new unit.  The unit count is padded to a multiple of RING so the slot of unit 0 is the same every pass.
+constexpr int RING = 4;
 
 constexpr int MAX_LAYERS = 40;
 constexpr int MAX_TILES = 256;
@@ -117,8 +125,7 @@ constexpr int MAX_TILES = 256;
 struct Tables {
     LayerSpec layers[MAX_LAYERS];
     TileInfo tiles[MAX_TILES];
-    int unit_frags[MAX_TILES];
-    int nlayers, ntiles, nunits, slot_frags, mfma_per_block;
+    int nlayers, ntiles, nfrags, nunits, nunits_padded, mfma_per_block;
 };
 
 template <class SH, class A, bool HAS_BEND>
@@ -152,24 +159,17 @@ constexpr Tables build_tables() {
     add(LK_HEAD, 0, NT_W * SP, 1);
     T.nlayers = nl;
     T.ntiles = tile0;
-    // greedy grouping of whole tiles into staging units of at most `cap` fragments
-    int cap = SH::UNIT_MIN_FRAGS;
-    for (int l = 0; l < nl; ++l) cap = imax(cap, T.layers[l].ns * (1 + T.layers[l].split));
-    int unit = -1, used = cap + 1, mf = 0;
+    int g = 0, mf = 0;
     for (int l = 0; l < nl; ++l) {
         for (int t = 0; t < T.layers[l].nt; ++t) {
-            int nf = T.layers[l].ns * (1 + T.layers[l].split);      // fragments of this tile
-            int gi = T.layers[l].tile0 + t;
-            bool fresh = used + nf > cap;
-            if (fresh) { ++unit; used = 0; }
-            T.tiles[gi] = TileInfo{l, t, fresh ? 1 : 0, used, unit};
-            used += nf;
-            T.unit_frags[unit] = used;
+            T.tiles[T.layers[l].tile0 + t] = TileInfo{l, t, g};
+            g += T.layers[l].ns * (1 + T.layers[l].split);
             mf += T.layers[l].ns * (T.layers[l].split ? 3 : 1);
         }
     }
-    T.nunits = unit + 1;
-    T.slot_frags = cap;
+    T.nfrags = g;
+    T.nunits = cdiv(g, SH::UNIT_FRAGS);
+    T.nunits_padded = cdiv(T.nunits, RING) * RING;
     T.mfma_per_block = mf;
     return T;
 }
@@ -184,9 +184,10 @@ struct Plan {
     static constexpr Tables TB = build_tables<SH, A, HAS_BEND>();
     static constexpr int NLAYERS = TB.nlayers;
     static constexpr int NTILES = TB.ntiles;
-    static constexpr int NUNITS = TB.nunits;
-    static constexpr int SLOT_FRAGS = TB.slot_frags;
-    static constexpr int SLOT_BYTES = SLOT_FRAGS * SH::FRAG_BYTES;
+    static constexpr int NFRAGS = TB.nfrags;
+    static constexpr int NUNITS = TB.nunits;                 // units holding real fragments
+    static constexpr int NUP = TB.nunits_padded;             // units streamed per pass (multiple of RING)
+    static constexpr int UF = SH::UNIT_FRAGS;
     static constexpr int MFMA_PER_BLOCK = TB.mfma_per_block;
     static_assert(TB.ntiles <= MAX_TILES && TB.nlayers <= MAX_LAYERS, "plan too large");
     // indices into layers[]

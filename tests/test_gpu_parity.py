@@ -105,11 +105,14 @@ def test_16bit_modes_psnr_vs_fp32_reference(precision, min_psnr):
     cfg = SceneConfig()
     scene = make_scene(cfg, 0)
     rays, latents = make_rays(4096, 7, cfg)
-    ref = O.batchify_rays(rays, latents, scene, chunk=1024)
-    got = hip_render(scene, rays, latents, precision)
+    ref = O.batchify_rays(rays, latents, scene, chunk=1024, retraw=True, detailed_output=True)
+    got = hip_render(scene, rays, latents, precision, retraw=True, detailed=True)
     p_fine, p_coarse = psnr(got["rgb_map"], ref["rgb_map"]), psnr(got["rgb0"], ref["rgb0"])
     p_acc = psnr(got["acc_map"], ref["acc_map"])
-    print(f"[{precision}] PSNR rgb_map {p_fine:.1f} dB, rgb0 {p_coarse:.1f} dB, acc {p_acc:.1f} dB")
+    rms = lambda k: float((got[k] - ref[k]).pow(2).mean().sqrt())
+    print(f"[{precision}] PSNR rgb_map {p_fine:.1f} dB, rgb0 {p_coarse:.1f} dB, acc {p_acc:.1f} dB | rmse: "
+          f"coarse bent pts {rms('input_pts'):.2e}, offsets {rms('unmasked_offsets'):.2e}, rigidity {rms('rigidity_mask'):.2e}, "
+          f"coarse weights {rms('visibility_weights'):.2e}, fine raw {rms('raw'):.2e}")
     assert p_coarse >= min_psnr and p_fine >= min_psnr - 2.0, (p_coarse, p_fine)
 
 
