@@ -21,12 +21,15 @@ def main(path):
     for r in rows:
         print(f"{r[1]:6d} {r[2]:13.1f} {r[3]:12.1f} {r[4]:12.1f} {r[5]:12.1f} {100 * r[2] / tot:6.2f}  "
               f"{r[6]:7d} {r[7]:5d} {r[8]:5d} {r[9]:5d} {r[10]:5d} {r[11]:7d} {r[12]:7d}  {r[0]}")
-    # the network kernel is launched with two grid shapes per render (coarse 64, fine 192 samples/ray): split them
-    print("\n# per (kernel, grid) -- separates the coarse and fine passes of net_kernel")
-    for r in cur.execute(
-            "select name, grid_x, count(*), avg(duration)/1e3, min(duration)/1e3 from kernels "
-            "where name like '%net_kernel%' or name like '%composite%' group by name, grid_x, lds_size order by name"):
-        print(f"  grid {r[1]:8d}  calls {r[2]:4d}  avg {r[3]:12.1f} us  min {r[4]:12.1f} us  {r[0][:90]}")
+    # net_kernel runs twice per render with the same grid (persistent): coarse pass (64 samples/ray) then fine pass
+    # (192 samples/ray).  Launch order alternates, so split by parity of the launch index.
+    print("\n# net_kernel by pass (launches alternate coarse, fine)")
+    for name, in cur.execute("select distinct name from kernels where name like '%net_kernel%'").fetchall():
+        d = [r[0] / 1e3 for r in cur.execute("select duration from kernels where name = ? order by start", (name,))]
+        for label, part in (("coarse (even launches)", d[0::2]), ("fine   (odd launches) ", d[1::2])):
+            if part:
+                print(f"  {label}: calls {len(part):4d}  avg {sum(part) / len(part):12.1f} us  min {min(part):12.1f} us  "
+                      f"max {max(part):12.1f} us   {name[:70]}")
 
 
 if __name__ == "__main__":
