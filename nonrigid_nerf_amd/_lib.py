@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnrnerf_hip.so")
+# NRNERF_LIB selects an alternative build of the same library (tuning experiments, see csrc/Makefile)
+LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
 ABI_VERSION = 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM = 0, -1, -2, -3, -4, -5

@@ -24,6 +24,10 @@
 #include "nrnerf_kernels.h"
 #include "nrnerf_plan.h"
 
+#ifndef NRN_EPI_DELAY
+#define NRN_EPI_DELAY 4      // MFMAs of the next tile issued before the previous tile's epilogue
+#endif
+
 namespace nrn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -212,16 +216,25 @@ __device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, cons
         else a[q % PF] = st.template frag<P1, G0 + q>();
     };
     static_for<0, (PF < Q ? PF : Q)>([&](auto qc) { load(qc); });
-    f32x16 acc;
+    // Two accumulator sets, used alternately by consecutive tiles: while tile t's chain runs in accs[t & 1],
+    // the other set is first drained by tile t-1's epilogue (DLY MFMAs into tile t, so the VALU work overlaps
+    // the matrix pipe instead of waiting on the chain's last result) and then pre-loaded with tile t+1's bias.
+    constexpr int DLY = (NS - 1 < NRN_EPI_DELAY) ? NS - 1 : NRN_EPI_DELAY;
+    f32x16 accs[2];
+    accs[0] = load_bias(bias_lds, spec.tile0, h);
+    if constexpr (spec.nt > 1) accs[1] = load_bias(bias_lds, spec.tile0 + 1, h);
     static_for<0, Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int t = q / NS, s = q % NS;
-        if constexpr (s == 0) acc = load_bias(bias_lds, spec.tile0 + t, h);
         const typename P1::frag cur = a[q % PF];
         if constexpr (q + PF < Q) load(std::integral_constant<int, q + PF>{});
-        if constexpr (s < NS0) acc = P0::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[s], acc);
-        else acc = P1::mfma(cur, in1[s - NS0], acc);
-        if constexpr (s == NS - 1) epi(std::integral_constant<int, t>{}, acc);
+        if constexpr (s < NS0) accs[t & 1] = P0::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[s], accs[t & 1]);
+        else accs[t & 1] = P1::mfma(cur, in1[s - NS0], accs[t & 1]);
+        if constexpr (t > 0 && s == DLY) {
+            epi(std::integral_constant<int, t - 1>{}, accs[(t - 1) & 1]);
+            if constexpr (t + 1 < spec.nt) accs[(t + 1) & 1] = load_bias(bias_lds, spec.tile0 + t + 1, h);
+        }
+        if constexpr (t == spec.nt - 1 && s == NS - 1) epi(std::integral_constant<int, t>{}, accs[t & 1]);
     });
 }
 

@@ -19,6 +19,14 @@
 #define NRN_HD
 #endif
 
+// build-time tuning knobs of the LDS weight ring (Makefile: TUNE="-DNRN_UNIT_BYTES=32768 -DNRN_RING=3")
+#ifndef NRN_UNIT_BYTES
+#define NRN_UNIT_BYTES 16384
+#endif
+#ifndef NRN_RING
+#define NRN_RING 4
+#endif
+
 namespace nrn {
 
 constexpr NRN_HD int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -47,7 +55,7 @@ struct Shape {
     // A fragments (hi, lo) per (tile, slab) and issue three MFMAs.
     static constexpr bool SPLIT = (KH_ != 1);
     static constexpr float LO_SCALE = 2048.0f;
-    static constexpr int UNIT_BYTES = 16384;                      // staging granularity of the LDS ring
+    static constexpr int UNIT_BYTES = NRN_UNIT_BYTES;             // staging granularity of the LDS ring
     static constexpr int UNIT_FRAGS = UNIT_BYTES / FRAG_BYTES;    // 16 (16-bit) / 64 (f32) fragments per unit
 };
 
@@ -117,7 +125,7 @@ struct TileInfo {
 // unit g / UNIT_FRAGS, which the kernel stages in LDS ring slot (g / UNIT_FRAGS) % RING.  Everything is
 // compile-time, so the kernel needs no table: it knows statically when a fragment index crosses into a
 // new unit.  The unit count is padded to a multiple of RING so the slot of unit 0 is the same every pass.
-constexpr int RING = 4;
+constexpr int RING = NRN_RING;
 
 constexpr int MAX_LAYERS = 40;
 constexpr int MAX_TILES = 256;

@@ -235,8 +235,8 @@ def test_packed_stream_reproduces_the_network(precision, bend):
     D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
     raw = np.stack([D[0], D[1], D[2], D[3], D[8]], -1)       # acc[0..4] of half-0 lanes
     used = fr.pos * info.frag_bytes          # the stream is zero-padded to whole 16 KiB units, a multiple of the ring depth
-    assert used <= info.stream_bytes < used + 4 * info.slot_bytes and not stream[used:].any(), "stream fully consumed"
-    assert info.stream_bytes == info.n_units * info.slot_bytes and info.n_units % 4 == 0 and info.slot_bytes == 16384
+    assert used <= info.stream_bytes < used + 8 * info.slot_bytes and not stream[used:].any(), "stream fully consumed"
+    assert info.stream_bytes == info.n_units * info.slot_bytes and info.slot_bytes % 16384 == 0
     assert tile0 == info.n_bias_tiles and mfma == info.mfma_per_block
     with torch.no_grad():
         cols = [pt]
