@@ -156,7 +156,9 @@ def test_16bit_modes_psnr_full_pipeline(precision):
           f"({int(flips.sum())}/{flips.numel()} flipped), rgb0 {p0:.1f} dB; rmse bent pts {rms('input_pts'):.1e}, "
           f"coarse weights {rms('visibility_weights'):.1e}")
     assert flips.float().mean().item() <= flip_bar
-    assert p_keep >= psnr_bar - 2.0, p_keep       # the coarse pass' own flips still move a few fine samples
+    # rays whose COARSE last sample flipped are still in `keep` (the coarse raw is not an output when I > 0); they get
+    # differently placed fine samples, which costs a few dB here relative to the coarse-only test
+    assert p_keep >= {"bf16": 38.0, "f16": 44.0}[precision], p_keep
     assert p_all >= 30.0, p_all                    # regression guard on the raw number
 
 
