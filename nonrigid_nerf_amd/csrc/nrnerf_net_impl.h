@@ -24,6 +24,9 @@
 #include "nrnerf_kernels.h"
 #include "nrnerf_plan.h"
 
+#ifndef NRN_PF16
+#define NRN_PF16 4
+#endif
 #ifndef NRN_EPI_DELAY
 #define NRN_EPI_DELAY 4      // MFMAs of the next tile issued before the previous tile's epilogue
 #endif
@@ -77,7 +80,7 @@ __device__ __forceinline__ float relu_bits(float x) {
 }
 struct PolBF16 : Shape<8> {
     typedef __bf16 frag __attribute__((ext_vector_type(8)));
-    static constexpr int PF = 4;             // A-fragment software prefetch depth (16 VGPRs)
+    static constexpr int PF = NRN_PF16;      // A-fragment software prefetch depth (4 VGPRs each)
     typedef __bf16 frag2 __attribute__((ext_vector_type(2)));
     template <int U, bool RELU>
     static __device__ __forceinline__ frag from_acc(const f32x16& c) { return pack16<frag, frag2, U, RELU>(c); }
@@ -90,7 +93,7 @@ struct PolBF16 : Shape<8> {
 };
 struct PolF16 : Shape<8> {
     typedef _Float16 frag __attribute__((ext_vector_type(8)));
-    static constexpr int PF = 4;
+    static constexpr int PF = NRN_PF16;
     typedef _Float16 frag2 __attribute__((ext_vector_type(2)));
     template <int U, bool RELU>
     static __device__ __forceinline__ frag from_acc(const f32x16& c) { return pack16<frag, frag2, U, RELU>(c); }
@@ -308,7 +311,7 @@ struct Empty {
 };
 
 template <class P, class A, bool HAS_BEND, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) net_kernel(const NetArgs a) {
+__global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(const NetArgs a) {
     using PL = Plan<P, A, HAS_BEND>;
     using frag = typename P::frag;                                                   // hidden activations
     using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;                      // encodings, bender (nrnerf_plan.h frag_is_f16)
@@ -563,7 +566,10 @@ static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) 
     const long long nblocks = (long long)a.n_rays * bpr;
     const long long ntiles = (nblocks + WAVES - 1) / WAVES;
     if (ntiles <= 0) return hipSuccess;
-    const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
+    // persistent grid: 16-bit builds keep 8 waves per CU resident (one 8-wave or two 4-wave workgroups, each with
+    // its own LDS ring); the fp32 build one 4-wave workgroup (512 registers per wave)
+    const long long resident = (long long)num_cus * ((P::KH == 1) ? 1 : 8 / WAVES);
+    const int grid = (int)(ntiles < resident ? ntiles : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }
