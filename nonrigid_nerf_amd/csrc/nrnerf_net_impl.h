@@ -122,23 +122,32 @@ struct PolF32 : Shape<1> {
 //
 // The stream is a sequence of 16 KiB units; unit U lives in ring slot U % RING.  All waves of the
 // workgroup consume every unit, each wave DMAs PW 1-KiB pieces of it.  advance<U>() is called (at a
-// compile-time-known point) right before the first fragment of unit U is read:
-//     s_waitcnt vmcnt((RING-2)*PW) lgkmcnt(0)   my pieces of unit U have landed (U+1, U+2 may still fly);
-//                                               my ds_reads of unit U-1 have completed
-//     s_barrier                                 => everyone's pieces landed, everyone is done with U-1
-//     issue DMA of unit U+RING-1 into slot (U-1) % RING
+// compile-time-known point) right before the first fragment of unit U is read.  With LAG = NRN_RING_LAG:
+//     s_waitcnt vmcnt((RING-LAG-1)*PW) [lgkmcnt(0) if LAG == 1]   my pieces of unit U have landed
+//     s_barrier                                 => everyone's pieces of U landed
+//     issue DMA of unit U+RING-LAG into the slot of unit U-LAG
+// Why the recycled slot is free.  LAG = 1: every wave waited lgkmcnt(0) before the barrier, so its reads of
+// U-1 have retired (this also drains the fragment prefetch queue, a stall).  LAG = 2: a wave arriving at
+// barrier U has issued the MFMAs of every fragment of unit U-2 (the prefetch runs at most PF < 16 fragments
+// ahead), hence waited for those reads; no drain needed, at the price of one more ring slot per unit of lead.
 // vmcnt retires in order, so other VMEM traffic in flight (the per-block ray loads / raw stores) can only
 // make the counted wait stricter, never weaker.
 // ------------------------------------------------------------------------------------------
+#ifndef NRN_RING_LAG
+#define NRN_RING_LAG 1
+#endif
 template <int N>
-__device__ __forceinline__ void wait_vm_lgkm0() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+__device__ __forceinline__ void wait_ring() {
+    if constexpr (NRN_RING_LAG == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <class P, int WAVES, int NUP>
 struct WRing {
     static constexpr int UNIT = P::UNIT_BYTES;
     static constexpr int PW = UNIT / 1024 / WAVES;          // DMA instructions per wave per unit
+    static constexpr int LAG = NRN_RING_LAG;                // recycle the slot of unit U - LAG at advance<U>
+    static_assert(LAG >= 1 && RING - LAG >= 2, "need at least one unit of DMA lead");
     static_assert(UNIT % (1024 * WAVES) == 0, "unit must split evenly over the waves");
     static_assert(NUP % RING == 0 && NUP >= RING, "unit count must be a padded multiple of the ring depth");
     const char* ubase;     // stream + this wave's piece offset: wave-uniform, lives in SGPRs
@@ -153,7 +162,7 @@ struct WRing {
         lane16 = (unsigned)lane * 16u;
         ring = lds;
         lane_off = lane * (P::FRAG_BYTES / 64);
-        static_for<0, RING - 1>([&](auto uc) { issue<decltype(uc)::value>(); });
+        static_for<0, RING - LAG>([&](auto uc) { issue<decltype(uc)::value>(); });
     }
     template <int V>
     __device__ __forceinline__ void issue() {
@@ -172,10 +181,10 @@ struct WRing {
     }
     template <int U>
     __device__ __forceinline__ void advance() {
-        wait_vm_lgkm0<(RING - 2) * PW>();
+        wait_ring<(RING - LAG - 1) * PW>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue<(U + RING - 1) % NUP>();
+        issue<(U + RING - LAG) % NUP>();
     }
     // fragment GF (index in the whole stream) for this lane; advances the ring when GF opens a new unit
     template <class PX, int GF>
@@ -335,6 +344,9 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 
     WRing<P, WAVES, PL::NUP> st;
     st.init(a.wstream, ring, wave, lane);
+#ifdef NRN_PRIO_YOUNG
+    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // second-dispatched half loses VALU arbitration otherwise
+#endif
 
     const int S = a.S;
     const int bpr = (S + 31) >> 5;                 // 32-sample blocks per ray
