@@ -54,13 +54,17 @@ const nrnerf_linear* layer_source(const nrnerf_model_desc& d, const nrnerf_mlp_d
         case LK_RIG_IN: case LK_RIG_HID: case LK_RIG_OUT: return &d.bender->rigidity_network[sp.index];
         case LK_TR_IN: case LK_TR_HID: case LK_TR_SKIP: return &mlp.pts_linears[sp.index];
         case LK_HEAD: return &mlp.output_linear;
+        case LK_ALPHA: return &mlp.alpha_linear;
+        case LK_FEAT: return &mlp.feature_linear;
+        case LK_VIEWS: return &mlp.views_linear;
+        case LK_RGB: return &mlp.rgb_linear;
     }
     return nullptr;
 }
 
-template <class SH, class A, bool HAS_BEND>
+template <class SH, class A, bool HAS_BEND, bool VIEWS>
 void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out) {
-    using PL = Plan<SH, A, HAS_BEND>;
+    using PL = Plan<SH, A, HAS_BEND, VIEWS>;
     constexpr int KH = SH::KH;
     const Tables& T = PL::TB;
     out.ntiles = T.ntiles; out.nunits = T.nunits_padded;
@@ -119,7 +123,8 @@ int check_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
     using A = ArchDefault;
     if (d.precision < 0 || d.precision > 2) return NRNERF_ERR_INVALID;
     if (d.multires != A::L) return NRNERF_ERR_UNSUPPORTED;
-    if (m.use_viewdirs || m.time_conditioned) return NRNERF_ERR_UNSUPPORTED;
+    if (m.time_conditioned) return NRNERF_ERR_UNSUPPORTED;
+    if (m.use_viewdirs && d.multires_views != A::LV) return NRNERF_ERR_UNSUPPORTED;
     if (m.depth != A::D || m.width != A::W || m.skip != A::SKIP) return NRNERF_ERR_UNSUPPORTED;
     if (m.output_ch != 4 && m.output_ch != 5) return NRNERF_ERR_UNSUPPORTED;
     if (!m.pts_linears) return NRNERF_ERR_INVALID;
@@ -128,7 +133,14 @@ int check_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
         const int in_f = (i == 0) ? enc : ((i - 1 == A::SKIP) ? A::W + enc : A::W);
         if (!linear_is(m.pts_linears[i], A::W, in_f, true)) return NRNERF_ERR_INVALID;
     }
-    if (!linear_is(m.output_linear, m.output_ch, A::W, true)) return NRNERF_ERR_INVALID;
+    if (m.use_viewdirs) {
+        if (m.output_ch != 4) return NRNERF_ERR_INVALID;
+        if (!linear_is(m.alpha_linear, 1, A::W, true) || !linear_is(m.feature_linear, A::W, A::W, true) ||
+            !linear_is(m.views_linear, A::W / 2, A::W + 3 + 6 * A::LV, true) || !linear_is(m.rgb_linear, 3, A::W / 2, true))
+            return NRNERF_ERR_INVALID;
+    } else if (!linear_is(m.output_linear, m.output_ch, A::W, true)) {
+        return NRNERF_ERR_INVALID;
+    }
     if (d.bender) {
         const nrnerf_bender_desc& b = *d.bender;
         if (b.latent_size != A::LAT || b.depth != A::BD || b.hidden != A::BW || b.rigidity_depth != A::RD ||
@@ -151,12 +163,15 @@ int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPa
     int rc = check_arch(d, m);
     if (rc != NRNERF_OK) return rc;
     using A = ArchDefault;
-    const bool bend = d.bender != nullptr;
-    if (d.precision == NRNERF_PREC_F32) {
-        if (bend) pack_pass<ShapeF32, A, true>(d, m, d.precision, out); else pack_pass<ShapeF32, A, false>(d, m, d.precision, out);
-    } else {
-        if (bend) pack_pass<Shape16, A, true>(d, m, d.precision, out); else pack_pass<Shape16, A, false>(d, m, d.precision, out);
-    }
+    const bool bend = d.bender != nullptr, views = m.use_viewdirs != 0;
+    auto go = [&](auto sh) {
+        using SH = decltype(sh);
+        if (bend && views) pack_pass<SH, A, true, true>(d, m, d.precision, out);
+        else if (bend) pack_pass<SH, A, true, false>(d, m, d.precision, out);
+        else if (views) pack_pass<SH, A, false, true>(d, m, d.precision, out);
+        else pack_pass<SH, A, false, false>(d, m, d.precision, out);
+    };
+    if (d.precision == NRNERF_PREC_F32) go(ShapeF32{}); else go(Shape16{});
     return NRNERF_OK;
 }
 
@@ -164,7 +179,12 @@ int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPa
 double algo_macs(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
     double macs = 0;
     for (int i = 0; i < m.depth; ++i) macs += (double)m.pts_linears[i].in_features * m.pts_linears[i].out_features;
-    macs += (double)m.output_linear.in_features * m.output_linear.out_features;
+    if (m.use_viewdirs) {
+        for (const nrnerf_linear* l : {&m.alpha_linear, &m.feature_linear, &m.views_linear, &m.rgb_linear})
+            macs += (double)l->in_features * l->out_features;
+    } else {
+        macs += (double)m.output_linear.in_features * m.output_linear.out_features;
+    }
     if (d.bender) {
         for (int i = 0; i < d.bender->depth; ++i) macs += (double)d.bender->network[i].in_features * d.bender->network[i].out_features;
         for (int i = 0; i < d.bender->rigidity_depth; ++i)
@@ -187,7 +207,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 struct nrnerf_model {
-    int device = 0, precision = 0, has_bend = 0, num_cus = 0, latent_size = 0;
+    int device = 0, precision = 0, has_bend = 0, views = 0, num_cus = 0, latent_size = 0;
     PassDev coarse, fine;
     bool fine_is_coarse = false;
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
@@ -265,6 +285,7 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     int rc = pack_dispatch(*desc, *desc->coarse, pc);
     if (rc != NRNERF_OK) return rc;
     if (desc->fine) {
+        if ((desc->fine->use_viewdirs != 0) != (desc->coarse->use_viewdirs != 0)) return NRNERF_ERR_INVALID;
         rc = pack_dispatch(*desc, *desc->fine, pf);
         if (rc != NRNERF_OK) return rc;
     }
@@ -276,6 +297,7 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     m->device = desc->device;
     m->precision = desc->precision;
     m->has_bend = desc->bender != nullptr;
+    m->views = desc->coarse->use_viewdirs != 0;
     m->latent_size = desc->bender ? desc->bender->latent_size : 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, desc->device) != hipSuccess) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_HIP; }
@@ -328,6 +350,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     if (a->n_rays == 0) return NRNERF_OK;
     if (!a->rays || a->ray_stride < 8 || !a->rgb_map || !a->disp_map || !a->acc_map) return NRNERF_ERR_INVALID;
     if (m->has_bend && (!a->latents || a->latent_stride < 0)) return NRNERF_ERR_INVALID;
+    if (m->views && !m->has_bend && a->ray_stride < 11) return NRNERF_ERR_INVALID;   // needs the unit view directions
     const size_t need = nrnerf_workspace_bytes(m, a->n_rays, a->n_samples, a->n_importance);
     if (!a->workspace || a->workspace_bytes < need || ((uintptr_t)a->workspace & 255)) return NRNERF_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -379,7 +402,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.ex = sample_out(a->coarse);
     na.knobs = kn;
     hipError_t e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
-                         [&] { return launch_net(m->precision, m->has_bend, 0, na, m->num_cus, stream); });
+                         [&] { return launch_net(m->precision, m->has_bend, m->views, 0, na, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K1: coarse composite (+ sampling)
@@ -409,7 +432,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
     e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
-              [&] { return launch_net(m->precision, m->has_bend, 0, nf, m->num_cus, stream); });
+              [&] { return launch_net(m->precision, m->has_bend, m->views, 0, nf, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K3: fine composite

@@ -57,7 +57,7 @@ enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
 struct NetLaunchInfo { int grid; int block; size_t lds_bytes; };
 
 // returns hipSuccess or an error; `arch_id` selects a compiled architecture (0 = default 8x256)
-hipError_t launch_net(int precision, bool has_bend, int arch_id, const NetArgs& a, int num_cus,
+hipError_t launch_net(int precision, bool has_bend, bool views, int arch_id, const NetArgs& a, int num_cus,
                       hipStream_t stream);
 hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream);
 

@@ -134,7 +134,7 @@ struct PolF32 : Shape<1> {
 // make the counted wait stricter, never weaker.
 // ------------------------------------------------------------------------------------------
 #ifndef NRN_RING_LAG
-#define NRN_RING_LAG 1
+#define NRN_RING_LAG 2
 #endif
 template <int N>
 __device__ __forceinline__ void wait_ring() {
@@ -319,9 +319,9 @@ struct Empty {
     template <class T> __device__ __forceinline__ float operator[](T) const { return 0.f; }
 };
 
-template <class P, class A, bool HAS_BEND, int WAVES>
+template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(const NetArgs a) {
-    using PL = Plan<P, A, HAS_BEND>;
+    using PL = Plan<P, A, HAS_BEND, VIEWS>;
     using frag = typename P::frag;                                                   // hidden activations
     using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;                      // encodings, bender (nrnerf_plan.h frag_is_f16)
     using efrag = typename PE::frag;
@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
     extern __shared__ __attribute__((aligned(16))) char smem[];     // one array: ring | bias (G17: 16-B aligned carve)
     char* ring = smem;
     float* bias_lds = (float*)(smem + RING * P::UNIT_BYTES);
+    float* mailbox = bias_lds + PL::NTILES * 32;      // [2][WAVES][4]: last bent point of each block (VIEWS only)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -351,12 +352,28 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
     const int S = a.S;
     const int bpr = (S + 31) >> 5;                 // 32-sample blocks per ray
     const long long nblocks = (long long)a.n_rays * bpr;
-    const long long ntiles = (nblocks + WAVES - 1) / WAVES;
+    // Block -> workgroup assignment.  Default: tiles of WAVES consecutive blocks, strided over the grid.  VIEWS: every
+    // workgroup owns a contiguous range of whole rays, because a sample's direction needs the bent point of the sample
+    // before it (run_nerf_helpers.py:339-351) and that neighbour must be produced by the same workgroup.
+    long long blk_begin, blk_end, tile_stride;
+    if constexpr (VIEWS) {
+        const long long rays_per_wg = (a.n_rays + gridDim.x - 1) / gridDim.x;
+        blk_begin = (long long)blockIdx.x * rays_per_wg * bpr;
+        blk_end = blk_begin + rays_per_wg * bpr;
+        if (blk_end > nblocks) blk_end = nblocks;
+        if (blk_begin > nblocks) blk_begin = nblocks;
+        tile_stride = WAVES;
+    } else {
+        blk_begin = (long long)blockIdx.x * WAVES;
+        blk_end = nblocks;
+        tile_stride = (long long)gridDim.x * WAVES;
+    }
 
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long blk = tile * WAVES + wave;
-        const bool blk_ok = blk < nblocks;
-        const long long b = blk_ok ? blk : nblocks - 1;
+    int iter = 0;
+    for (long long tile0 = blk_begin; tile0 < blk_end; tile0 += tile_stride, ++iter) {
+        const long long blk = tile0 + wave;
+        const bool blk_ok = blk < blk_end;
+        const long long b = blk_ok ? blk : blk_end - 1;
         const int ray = (int)(b / bpr);
         const int sidx = (int)(b % bpr) * 32 + j;
         const bool ok = blk_ok && sidx < S;
@@ -482,6 +499,66 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             a.ex.in_pts[so * 3 + 0] = p[0]; a.ex.in_pts[so * 3 + 1] = p[1]; a.ex.in_pts[so * 3 + 2] = p[2];
         }
 
+        // ---- view direction of the sample (VIEWS): finite difference of the bent points along the ray, or the ray's own
+        //      unit direction without a bender (run_nerf_helpers.py:288-290, 339-351; train.py:73-76)
+        constexpr int NS_ENCV = PL::NS_ENCV;
+        efrag encv[VIEWS ? NS_ENCV : 1];
+        if constexpr (VIEWS) {
+            float dirv[3];
+            if constexpr (HAS_BEND) {
+                if (j == 31 && h == 0) {
+                    float* mb = mailbox + ((iter & 1) * WAVES + wave) * 4;
+                    mb[0] = p[0]; mb[1] = p[1]; mb[2] = p[2];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float prev[3], next[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { prev[c] = __shfl_up(p[c], 1); next[c] = __shfl_down(p[c], 1); }
+                const bool first_in_ray = (sidx == 0);
+                // the neighbour of lane 0 lives in the previous block: previous wave of this tile, or the last wave of the
+                // previous tile of this workgroup (double-buffered by tile parity).  Read after the next ring barrier.
+                __builtin_amdgcn_s_barrier();
+                if (j == 0 && !first_in_ray) {
+                    const float* mb = (wave > 0) ? mailbox + ((iter & 1) * WAVES + wave - 1) * 4
+                                                 : mailbox + (((iter + 1) & 1) * WAVES + WAVES - 1) * 4;
+                    prev[0] = mb[0]; prev[1] = mb[1]; prev[2] = mb[2];
+                }
+                float dd[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dd[c] = first_in_ray ? __fsub_rn(next[c], p[c]) : __fsub_rn(p[c], prev[c]);
+                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dd[0], dd[0]), __fmul_rn(dd[1], dd[1])), __fmul_rn(dd[2], dd[2])));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dirv[c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f));
+            } else {
+                dirv[0] = rp[8]; dirv[1] = rp[9]; dirv[2] = rp[10];
+            }
+            constexpr int F0V = enc_F0(A::LV);
+            constexpr int NSLOTV = NS_ENCV * KH;
+            float evv[NSLOTV];
+#pragma unroll
+            for (int q = 0; q < NSLOTV; ++q) evv[q] = 0.0f;
+            evv[0] = h ? dirv[2] : dirv[0];
+            evv[1] = h ? 0.0f : dirv[1];
+            const float vscale = h ? (float)(1 << F0V) : 1.0f;
+            static_for<0, F0V>([&](auto fc) {
+                constexpr int fl = decltype(fc)::value;
+                static_for<0, 3>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    float sv, cv;
+                    sincosf(dirv[c] * (vscale * (float)(1 << fl)), &sv, &cv);
+                    evv[2 + 2 * (3 * fl + c)] = sv;
+                    evv[2 + 2 * (3 * fl + c) + 1] = cv;
+                });
+            });
+            static_for<0, NS_ENCV>([&](auto sc_) {
+                constexpr int s = decltype(sc_)::value;
+                static_for<0, KH>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    PE::template set<e>(encv[s], evv[s * KH + e]);
+                });
+            });
+        }
+
         // ---- positional encoding of the (bent) point, directly in B-operand order
         constexpr int F0 = enc_F0(A::L);
         constexpr int NSLOT = NS_ENC * KH;
@@ -537,12 +614,30 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                         pack_tile<P, true, decltype(tc)::value>(acc, ha); });
             }
         });
-        float raw[5];
-        auto take_raw = [&](auto, const f32x16& acc) {
-            raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; raw[3] = acc[3]; raw[4] = acc[4];
-        };
-        if constexpr ((A::D - 1) % 2 == 1) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, hb, none, take_raw);
-        else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, ha, none, take_raw);
+        float raw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        constexpr bool LAST_IN_B = ((A::D - 1) % 2 == 1);       // buffer holding the trunk output
+        if constexpr (!VIEWS) {
+            auto take_raw = [&](auto, const f32x16& acc) {
+                raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; raw[3] = acc[3]; raw[4] = acc[4];
+            };
+            if constexpr (LAST_IN_B) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, hb, none, take_raw);
+            else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, ha, none, take_raw);
+        } else {
+            // view-dependent head (run_nerf_helpers.py:284-304): alpha and feature from the trunk output, then
+            // relu(views_linear([feature, enc(dir)])) and rgb_linear; output = [rgb, alpha]
+            auto head = [&](auto& hx, auto& hy) {
+                dense<P, P, PL, PL::L_ALPHA, NH, 0>(st, bias_lds, h, hx, none, [&](auto, const f32x16& acc) { raw[3] = acc[0]; });
+                dense<P, P, PL, PL::L_FEAT, NH, 0>(st, bias_lds, h, hx, none, [&](auto tc, const f32x16& acc) {
+                    pack_tile<P, false, decltype(tc)::value>(acc, hy); });
+                constexpr int NV = (NT_W / 2) * SP;
+                frag hv[NV];
+                dense<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH>(st, bias_lds, h, encv, hy, [&](auto tc, const f32x16& acc) {
+                    pack_tile<P, true, decltype(tc)::value>(acc, hv); });
+                dense<P, P, PL, PL::L_RGB, NV, 0>(st, bias_lds, h, hv, none, [&](auto, const f32x16& acc) {
+                    raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; });
+            };
+            if constexpr (LAST_IN_B) head(hb, ha); else head(ha, hb);
+        }
 
         if (HAS_BEND && a.knobs.detailed && a.knobs.has_removal && rig_mask >= a.knobs.removal)
             raw[3] = raw[3] * 0.0f;                                                  // rnh:308-311
@@ -563,11 +658,11 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 // ------------------------------------------------------------------------------------------
 // launch (one explicit instantiation per translation unit, see nrnerf_net_inst.hip)
 // ------------------------------------------------------------------------------------------
-template <class P, class A, bool HAS_BEND, int WAVES>
+template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES>
 static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) {
-    using PL = Plan<P, A, HAS_BEND>;
-    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float);
-    auto kern = net_kernel<P, A, HAS_BEND, WAVES>;
+    using PL = Plan<P, A, HAS_BEND, VIEWS>;
+    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * 4 * sizeof(float);
+    auto kern = net_kernel<P, A, HAS_BEND, VIEWS, WAVES>;
     static bool attr_set = false;    // idempotent; racing threads set the same value
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -581,7 +676,12 @@ static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) 
     // persistent grid: 16-bit builds keep 8 waves per CU resident (one 8-wave or two 4-wave workgroups, each with
     // its own LDS ring); the fp32 build one 4-wave workgroup (512 registers per wave)
     const long long resident = (long long)num_cus * ((P::KH == 1) ? 1 : 8 / WAVES);
-    const int grid = (int)(ntiles < resident ? ntiles : resident);
+    long long want = ntiles;
+    if (VIEWS) {    // contiguous whole-ray ranges: no more workgroups than ray groups that fill a tile
+        const long long rays_per_tile = (WAVES + bpr - 1) / bpr;
+        want = ((long long)a.n_rays + rays_per_tile - 1) / rays_per_tile;
+    }
+    const int grid = (int)(want < resident ? (want > 0 ? want : 1) : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }

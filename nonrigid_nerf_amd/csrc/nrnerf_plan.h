@@ -59,9 +59,9 @@ struct Shape {
     static constexpr int UNIT_FRAGS = UNIT_BYTES / FRAG_BYTES;    // 16 (16-bit) / 64 (f32) fragments per unit
 };
 
-template <int W_, int D_, int SKIP_, int L_, int BW_, int BD_, int RW_, int RD_, int LAT_>
+template <int W_, int D_, int SKIP_, int L_, int BW_, int BD_, int RW_, int RD_, int LAT_, int LV_ = 4>
 struct ArchT {
-    static constexpr int W = W_, D = D_, SKIP = SKIP_, L = L_;
+    static constexpr int W = W_, D = D_, SKIP = SKIP_, L = L_, LV = LV_;     // LV: frequencies of the direction encoding
     static constexpr int BW = BW_, BD = BD_, RW = RW_, RD = RD_, LAT = LAT_;
     static_assert(W_ % 32 == 0 && BW_ % 32 == 0 && RW_ % 32 == 0, "widths must be multiples of 32");
     static_assert(LAT_ % 8 == 0, "latent size must be a multiple of 8");
@@ -103,7 +103,12 @@ constexpr NRN_HD int rin_col(int idx) { return (idx < 3) ? idx : -1; }
 // ---------------------------------------------------------------------------------------
 enum LayerKind : int {
     LK_BEND_IN = 0, LK_BEND_HID, LK_BEND_OUT, LK_RIG_IN, LK_RIG_HID, LK_RIG_OUT,
-    LK_TR_IN, LK_TR_HID, LK_TR_SKIP, LK_HEAD
+    LK_TR_IN, LK_TR_HID, LK_TR_SKIP, LK_HEAD,
+    // view-dependent head (reference NeRF.forward, run_nerf_helpers.py:284-304)
+    LK_ALPHA,    // alpha_linear:   trunk output -> 1   (rows duplicated for both lane halves)
+    LK_FEAT,     // feature_linear: trunk output -> W   (no activation)
+    LK_VIEWS,    // views_linears[0]: [feature W, direction encoding] -> W/2, relu; slabs: direction encoding first
+    LK_RGB       // rgb_linear: W/2 -> 3
 };
 
 struct LayerSpec {
@@ -136,10 +141,11 @@ struct Tables {
     int nlayers, ntiles, nfrags, nunits, nunits_padded, mfma_per_block;
 };
 
-template <class SH, class A, bool HAS_BEND>
+template <class SH, class A, bool HAS_BEND, bool VIEWS = false>
 constexpr Tables build_tables() {
     constexpr int KH = SH::KH, SP = SH::SP;
     constexpr int NS_ENC = cdiv(enc_slots(A::L), KH);
+    constexpr int NS_ENCV = cdiv(enc_slots(A::LV), KH);
     constexpr int NS_BIN = cdiv(bin_len(A::LAT), 2 * KH);
     constexpr int NS_RIN = cdiv(rin_len(), 2 * KH);
     constexpr int NT_W = A::W / 32, NT_BW = A::BW / 32, NT_RW = A::RW / 32;
@@ -164,7 +170,14 @@ constexpr Tables build_tables() {
         if (i - 1 == A::SKIP) add(LK_TR_SKIP, i, NS_ENC + NT_W * SP, NT_W);
         else add(LK_TR_HID, i, NT_W * SP, NT_W);
     }
-    add(LK_HEAD, 0, NT_W * SP, 1);
+    if (VIEWS) {
+        add(LK_ALPHA, 0, NT_W * SP, 1);
+        add(LK_FEAT, 0, NT_W * SP, NT_W);
+        add(LK_VIEWS, 0, NS_ENCV + NT_W * SP, NT_W / 2);
+        add(LK_RGB, 0, (NT_W / 2) * SP, 1);
+    } else {
+        add(LK_HEAD, 0, NT_W * SP, 1);
+    }
     T.nlayers = nl;
     T.ntiles = tile0;
     int g = 0, mf = 0;
@@ -182,14 +195,15 @@ constexpr Tables build_tables() {
     return T;
 }
 
-template <class SH, class A, bool HAS_BEND>
+template <class SH, class A, bool HAS_BEND, bool VIEWS = false>
 struct Plan {
     static constexpr int KH = SH::KH, SP = SH::SP;
     static constexpr int NS_ENC = cdiv(enc_slots(A::L), KH);
+    static constexpr int NS_ENCV = cdiv(enc_slots(A::LV), KH);
     static constexpr int NS_BIN = cdiv(bin_len(A::LAT), 2 * KH);
     static constexpr int NS_RIN = cdiv(rin_len(), 2 * KH);
     static constexpr int NT_W = A::W / 32, NT_BW = A::BW / 32, NT_RW = A::RW / 32;
-    static constexpr Tables TB = build_tables<SH, A, HAS_BEND>();
+    static constexpr Tables TB = build_tables<SH, A, HAS_BEND, VIEWS>();
     static constexpr int NLAYERS = TB.nlayers;
     static constexpr int NTILES = TB.ntiles;
     static constexpr int NFRAGS = TB.nfrags;
@@ -202,7 +216,9 @@ struct Plan {
     static constexpr int L_BEND0 = 0;
     static constexpr int L_RIG0 = HAS_BEND ? A::BD : 0;
     static constexpr int L_TRUNK0 = HAS_BEND ? (A::BD + A::RD) : 0;
-    static constexpr int L_HEAD = NLAYERS - 1;
+    static constexpr int L_HEAD = NLAYERS - 1;                 // output_linear (no view dependence)
+    static constexpr int L_ALPHA = L_TRUNK0 + A::D;            // view-dependent head: alpha, feature, views, rgb
+    static constexpr int L_FEAT = L_ALPHA + 1, L_VIEWS = L_ALPHA + 2, L_RGB = L_ALPHA + 3;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -223,11 +239,18 @@ constexpr NRN_HD int in_col(int kind, int s, int h, int e, int in_features) {
         int q = s2 * KH + e;
         return (q < enc_slots(A::L)) ? enc_col(A::L, h, q) : -1;
     };
+    constexpr int NS_ENCV = cdiv(enc_slots(A::LV), KH);
     switch (kind) {
         case LK_BEND_IN: return bin_col((2 * s + h) * KH + e, A::LAT);
         case LK_RIG_IN:  return rin_col((2 * s + h) * KH + e);
         case LK_TR_IN:   return enc(s);
         case LK_TR_SKIP: return (s < NS_ENC) ? enc(s) : hidden(s - NS_ENC, 3 + 6 * A::L);
+        case LK_VIEWS: {     // reference column order is [feature W, direction encoding]; our slab order is the reverse
+            if (s >= NS_ENCV) return hidden(s - NS_ENCV, 0);
+            int q = s * KH + e;
+            int c = (q < enc_slots(A::LV)) ? enc_col(A::LV, h, q) : -1;
+            return c < 0 ? -1 : A::W + c;
+        }
         default:         return hidden(s, 0);
     }
 }
@@ -236,8 +259,10 @@ constexpr NRN_HD int in_col(int kind, int s, int h, int e, int in_features) {
 template <class SH, class A>
 constexpr NRN_HD bool frag_is_f16(int kind, int s) {
     constexpr int NS_ENC = cdiv(enc_slots(A::L), SH::KH);
+    constexpr int NS_ENCV = cdiv(enc_slots(A::LV), SH::KH);
     if (kind <= LK_RIG_OUT || kind == LK_TR_IN) return true;
     if (kind == LK_TR_SKIP) return s < NS_ENC;
+    if (kind == LK_VIEWS) return s < NS_ENCV;
     return false;
 }
 template <class A>
@@ -245,6 +270,8 @@ constexpr NRN_HD int out_row(int kind, int t, int i, int out_features) {
     switch (kind) {
         case LK_BEND_OUT: return (i < 8 && (i & 3) < 3) ? (i & 3) : -1;     // xyz offsets duplicated for both lane halves
         case LK_RIG_OUT:  return (i == 0 || i == 4) ? 0 : -1;               // rigidity logit duplicated likewise
+        case LK_ALPHA:    return (i == 0 || i == 4) ? 0 : -1;
+        case LK_RGB:      return (i < 8 && (i & 3) < 3) ? (i & 3) : -1;
         case LK_HEAD:     return (i < 4) ? i : ((i == 8 && out_features > 4) ? 4 : -1);   // rgb,sigma in acc[0..3], ch 4 in acc[4]
         default:          return (32 * t + i < out_features) ? 32 * t + i : -1;
     }

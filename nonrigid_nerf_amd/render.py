@@ -307,7 +307,11 @@ def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importanc
     if ray_batch.device.type != "cuda":
         return "rays are not on a ROCm device"
     if getattr(network_fn, "use_viewdirs", False):
-        return "use_viewdirs (view-dependent head not compiled in this build)"
+        has_bender = bool(getattr(network_fn, "ray_bender", None)) and network_fn.ray_bender[0] is not None
+        if has_bender and not getattr(network_fn, "approx_nonrigid_viewdirs", True):
+            return "exact non-rigid view directions (autograd Jacobian, run_nerf_helpers.py:358-385)"
+        if not has_bender and ray_batch.shape[-1] < 11:
+            return "use_viewdirs without view directions in the ray batch"
     if getattr(network_fn, "time_conditioned_baseline", False):
         return "time_conditioned_baseline"
     if N_samples < 2 or N_samples + N_importance > 256:

@@ -164,9 +164,9 @@ def rounder(precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("bend", [True, False])
-def test_packed_stream_reproduces_the_network(precision, bend):
-    cfg = SceneConfig(N_importance=128, ray_bending=bend)
+@pytest.mark.parametrize("bend,views", [(True, False), (False, False), (True, True), (False, True)])
+def test_packed_stream_reproduces_the_network(precision, bend, views):
+    cfg = SceneConfig(N_importance=128, ray_bending=bend, use_viewdirs=views)
     scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=1)
     KH = 1 if precision == "f32" else 8
     SP = 16 // KH
@@ -232,8 +232,24 @@ def test_packed_stream_reproduces_the_network(precision, bend):
             n16 = len(slabs_enc)
         tiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs, f16_slabs=n16); mfma += len(slabs) * 8; tile0 += 8
     slabs = repack(tiles, KH, True, rnd)
-    D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
-    raw = np.stack([D[0], D[1], D[2], D[3], D[8]], -1)       # acc[0..4] of half-0 lanes
+    dirs = (torch.randn(ns_, 3, generator=gen)).double()
+    dirs = (dirs / dirs.norm(dim=-1, keepdim=True)).numpy()
+    if views:
+        D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1        # alpha_linear
+        alpha = D[0]
+        assert np.allclose(D[4], alpha)
+        ftiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs); mfma += len(slabs) * 8; tile0 += 8   # feature_linear
+        fslabs = repack(ftiles, KH, False, rnd)
+        dslabs = enc_slabs(dirs, 4, KH, rnd_e)
+        vs = dslabs + fslabs
+        vtiles = dense_emul(fr, bias, tile0, len(vs), 4, vs, f16_slabs=len(dslabs)); mfma += len(vs) * 4; tile0 += 4
+        vslabs = repack(vtiles, KH, True, rnd)
+        D = dense_emul(fr, bias, tile0, len(vslabs), 1, vslabs)[0]; mfma += len(vslabs); tile0 += 1     # rgb_linear
+        assert np.allclose(D[4:7], D[0:3])
+        raw = np.stack([D[0], D[1], D[2], alpha], -1)
+    else:
+        D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1
+        raw = np.stack([D[0], D[1], D[2], D[3], D[8]], -1)       # acc[0..4] of half-0 lanes
     used = fr.pos * info.frag_bytes          # the stream is zero-padded to whole 16 KiB units, a multiple of the ring depth
     assert used <= info.stream_bytes < used + 8 * info.slot_bytes and not stream[used:].any(), "stream fully consumed"
     assert info.stream_bytes == info.n_units * info.slot_bytes and info.slot_bytes % 16384 == 0
@@ -248,8 +264,18 @@ def test_packed_stream_reproduces_the_network(precision, bend):
             h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
             if i == 4:
                 h = torch.cat([x, h], -1)
-        ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
-    tol = 1e-9 if precision == "f32" else (6e-2 if precision == "bf16" else 8e-3)
+        if views:
+            lin = lambda m, x: F.linear(x, m.weight.double(), m.bias.double())
+            dt = torch.from_numpy(dirs)
+            dcols = [dt]
+            for k in range(4):
+                dcols += [torch.sin(dt * 2.0 ** k), torch.cos(dt * 2.0 ** k)]
+            al = lin(fine.alpha_linear, h)
+            hv = F.relu(lin(fine.views_linears[0], torch.cat([lin(fine.feature_linear, h), torch.cat(dcols, -1)], -1)))
+            ref = torch.cat([lin(fine.rgb_linear, hv), al], -1).numpy()
+        else:
+            ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
+    tol = 1e-9 if precision == "f32" else (8e-2 if precision == "bf16" else 1e-2)
     err = np.abs(raw - ref).max()
     assert err <= tol * np.abs(ref).max(), f"trunk+head mismatch {err} vs scale {np.abs(ref).max()}"
     # unit table: uniform 16 KiB units (offsets in 16-byte words)
