@@ -168,15 +168,41 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
         for (int k = lane; k < I; k += 64) { const float d = s_z[wave][S + k] - mean; var += d * d; }
         var = wave_sum(var) / (float)I;
         if (ray_ok && lane == 0 && a.z_std) a.z_std[ray] = sqrtf(var);
-        // ---- merge: stable rank of every depth among all n (== torch.sort values), train.py:920
-        for (int idx = lane; idx < n; idx += 64) {
-            const float mine = s_z[wave][idx];
-            int rank = 0;
-            for (int jj = 0; jj < n; ++jj) {
-                const float o = s_z[wave][jj];
-                rank += (o < mine || (o == mine && jj < idx)) ? 1 : 0;
+        // ---- merge (train.py:920): the values torch.sort would return, via the stable rank of every depth.
+        // Coarse depths are strictly increasing.  If the importance samples are non-decreasing too (the inverse CDF is
+        // monotone; rounding can break it by an ulp), ranks follow from one binary search into the other list:
+        //   rank(coarse i) = i + #{samples <  z_i}          (stable: ties keep the concatenation order, coarse first)
+        //   rank(sample k) = k + #{coarse  <= s_k}
+        // Otherwise fall back to counting against all n elements (correct for any input order).
+        bool mono = true;
+        for (int k = lane; k < I; k += 64)
+            if (k > 0 && s_z[wave][S + k] < s_z[wave][S + k - 1]) mono = false;
+        mono = __all(mono);
+        if (mono) {
+            for (int idx = lane; idx < n; idx += 64) {
+                const float mine = s_z[wave][idx];
+                int lo, hi, rank;
+                if (idx < S) {      // count samples strictly below
+                    lo = 0; hi = I;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[wave][S + mid] < mine) lo = mid + 1; else hi = mid; }
+                    rank = idx + lo;
+                } else {            // count coarse depths <= mine
+                    lo = 0; hi = S;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[wave][mid] <= mine) lo = mid + 1; else hi = mid; }
+                    rank = (idx - S) + lo;
+                }
+                if (ray_ok) a.z_out[(size_t)ray * n + rank] = mine;
             }
-            if (ray_ok) a.z_out[(size_t)ray * n + rank] = mine;
+        } else {
+            for (int idx = lane; idx < n; idx += 64) {
+                const float mine = s_z[wave][idx];
+                int rank = 0;
+                for (int jj = 0; jj < n; ++jj) {
+                    const float o = s_z[wave][jj];
+                    rank += (o < mine || (o == mine && jj < idx)) ? 1 : 0;
+                }
+                if (ray_ok) a.z_out[(size_t)ray * n + rank] = mine;
+            }
         }
     }
 }

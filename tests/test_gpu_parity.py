@@ -63,6 +63,12 @@ def oracle_fine_given_z(scene, rays, latents, z_vals, knobs=None, detailed=False
     return res
 
 
+# Finite-difference view directions (run_nerf_helpers.py:339-351) divide by |p_j - p_{j-1}| + 1e-6.  Where an
+# importance sample lands within ~1e-6 of its neighbour the difference is pure fp32 cancellation noise, in the
+# reference as much as here, and the colour logits of that one sample are arbitrary (its weight is ~0, so no map
+# changes).  Allow that for < 0.05 % of the raw entries; everything else stays at the fp32 tolerance.
+FD_DIRS_RAW = dict(frac_ok=5e-4, outlier_atol=5.0)
+
 COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "initial_input_pts",
                "unmasked_offsets", "masked_offsets", "input_pts", "rigidity_mask"]
 
@@ -94,7 +100,11 @@ def test_fp32_mode_matches_reference_golden(name):
         fails += compare_dict(got, ref, keys=["z_std"], frac_ok=0.1, outlier_atol=1e-2)
         # 3. fine pass at the depths the GPU chose: tight
         fine = oracle_fine_given_z(scene, rays, latents, zg, O.Knobs(**meta["knobs"]), bool(meta["detailed"]))
-        fails += compare_dict(got, fine, keys=[k for k in fine if k in got])
+        if cfg.use_viewdirs and cfg.ray_bending:
+            fails += compare_dict(got, fine, keys=[k for k in fine if k in got and k != "raw"])
+            fails += compare_dict(got, fine, keys=["raw"], **FD_DIRS_RAW)
+        else:
+            fails += compare_dict(got, fine, keys=[k for k in fine if k in got])
         # 4. end to end against the reference outputs, allowing the few rays whose sample moved
         fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], frac_ok=0.10, outlier_atol=2e-2)
     assert not fails, "\n".join(fails)
@@ -238,7 +248,8 @@ def test_viewdirs_fp32_vs_oracle(bend):
     assert got["raw"].shape == ref["raw"].shape == (513, 192, 4)
     fails = compare_dict(got, ref, keys=["rgb0", "disp0", "acc0"])
     fine = oracle_fine_given_z(scene, rays, latents, got["_z_vals"])
-    fails += compare_dict(got, fine, keys=["rgb_map", "disp_map", "acc_map", "raw"])
+    fails += compare_dict(got, fine, keys=["rgb_map", "disp_map", "acc_map"])
+    fails += compare_dict(got, fine, keys=["raw"], **(FD_DIRS_RAW if bend else {}))
     fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], frac_ok=0.10, outlier_atol=2e-2)
     assert not fails, "\n".join(fails)
     got16 = hip_render(scene, rays, latents, "bf16")

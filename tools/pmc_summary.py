@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc counter CSVs (one directory per pass) for net_kernel into the text + json committed
+under profiles/.  FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads
+on gfx950; FETCH_SIZE / WRITE_SIZE are in KiB.
+
+    python tools/pmc_summary.py gpurun_out/pmcA gpurun_out/pmcB ... > profiles/r01_pmc_summary.txt
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def main(dirs):
+    per = collections.defaultdict(dict)       # (pass, dispatch) -> counters
+    for d in dirs:
+        for f in glob.glob(d + "/*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if "net_kernel" not in r["Kernel_Name"]:
+                    continue
+                k = (d, int(r["Dispatch_Id"]))
+                per[k][r["Counter_Name"]] = float(r["Counter_Value"])
+                per[k]["_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    # launches alternate coarse / fine within a pass; take the median of each counter over the fine launches
+    out = {}
+    for label, parity in (("coarse", 0), ("fine", 1)):
+        agg = collections.defaultdict(list)
+        for d in dirs:
+            ids = sorted(i for (dd, i) in per if dd == d)
+            for n, i in enumerate(ids):
+                if n % 2 == parity:
+                    for c, v in per[(d, i)].items():
+                        agg[c].append(v)
+        out[label] = {c: sorted(v)[len(v) // 2] for c, v in agg.items()}
+    print("# rocprofv3 --pmc summary, net_kernel (median over launches), bench.py workload (196608 rays, 64+128)")
+    for label in ("coarse", "fine"):
+        c = out[label]
+        print(f"\n[{label} pass]  duration {c.get('_us', 0):.1f} us")
+        for k in sorted(c):
+            if k != "_us":
+                print(f"  {k:32s} {c[k]:.6g}")
+        if "GRBM_GUI_ACTIVE" in c:
+            clk = c["GRBM_GUI_ACTIVE"] / 8 / c["_us"] * 1e-3     # summed over the 8 XCDs
+            print(f"  -> effective shader clock            {clk:.2f} GHz")
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                print(f"  -> MFMA pipe busy                    {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * c['GRBM_GUI_ACTIVE'] / 8):.3f} of SIMD-cycles")
+        if "SQ_WAVE_CYCLES" in c:
+            for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+                if k in c:
+                    print(f"  -> {k:20s} / SQ_WAVE_CYCLES = {c[k] / c['SQ_WAVE_CYCLES']:.3f}")
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            rd, wr = 2 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
+            print(f"  -> HBM traffic per launch: read {rd / 1e6:.1f} MB (2 x FETCH_SIZE), write {wr / 1e6:.1f} MB, total {(rd + wr) / 1e9:.3f} GB")
+            out[label]["hbm_bytes_per_launch"] = rd + wr
+    json.dump(out, open("profiles/r01_pmc_fine.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
