@@ -27,9 +27,6 @@
 #ifndef NRN_PF16
 #define NRN_PF16 4
 #endif
-#ifndef NRN_LOADERS
-#define NRN_LOADERS 8        // waves per workgroup that issue the LDS-DMA of the weight ring
-#endif
 #ifndef NRN_EPI_DELAY
 #define NRN_EPI_DELAY 4      // MFMAs of the next tile issued before the previous tile's epilogue
 #endif
@@ -148,25 +145,21 @@ __device__ __forceinline__ void wait_ring() {
 template <class P, int WAVES, int NUP>
 struct WRing {
     static constexpr int UNIT = P::UNIT_BYTES;
-    // Loader waves: the first LOADERS waves of the workgroup (one per SIMD when LOADERS == 4: a workgroup's waves are
-    // dealt to the SIMDs cyclically) issue all DMA pieces; their SIMD partners go straight back to MFMA work after the
-    // barrier instead of both waves of a SIMD paying the DMA issue cost at the same moment.
-    static constexpr int LOADERS = (NRN_LOADERS < WAVES) ? NRN_LOADERS : WAVES;
-    static constexpr int PW = UNIT / 1024 / LOADERS;        // DMA instructions per loader wave per unit
+    // (Tried and rejected on MI355X: letting only 2 or 4 "loader" waves issue the DMA so their SIMD partners keep the
+    //  matrix pipe busy -- 2-4 % slower, and the wave-uniform branches alone cost 7 %.)
+    static constexpr int PW = UNIT / 1024 / WAVES;          // DMA instructions per wave per unit
     static constexpr int LAG = NRN_RING_LAG;                // recycle the slot of unit U - LAG at advance<U>
     static_assert(LAG >= 1 && RING - LAG >= 2, "need at least one unit of DMA lead");
-    static_assert(UNIT % (1024 * LOADERS) == 0, "unit must split evenly over the loader waves");
+    static_assert(UNIT % (1024 * WAVES) == 0, "unit must split evenly over the waves");
     static_assert(NUP % RING == 0 && NUP >= RING, "unit count must be a padded multiple of the ring depth");
     const char* ubase;     // stream + this wave's piece offset: wave-uniform, lives in SGPRs
     unsigned lane16;       // lane * 16: the only per-lane part of a DMA source address (saddr + voffset form)
     char* ring;            // LDS ring base
     int wave_off;          // this wave's piece offset inside a unit (wave-uniform)
     int lane_off;          // lane * (FRAG_BYTES / 64)
-    bool loader;           // wave-uniform
 
     __device__ __forceinline__ void init(const void* stream, char* lds, int wave, int lane) {
-        loader = wave < LOADERS;
-        wave_off = (loader ? wave : 0) * PW * 1024;
+        wave_off = wave * PW * 1024;
         ubase = (const char*)stream + wave_off;
         lane16 = (unsigned)lane * 16u;
         ring = lds;
@@ -175,7 +168,6 @@ struct WRing {
     }
     template <int V>
     __device__ __forceinline__ void issue() {
-        if (!loader) return;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             // The offset is a compile-time constant, but hiding it from the optimiser stops LICM from hoisting
@@ -191,8 +183,7 @@ struct WRing {
     }
     template <int U>
     __device__ __forceinline__ void advance() {
-        if (loader) wait_ring<(RING - LAG - 1) * PW>();
-        else if constexpr (LAG == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_ring<(RING - LAG - 1) * PW>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue<(U + RING - LAG) % NUP>();

@@ -256,6 +256,52 @@ def test_viewdirs_fp32_vs_oracle(bend):
     assert psnr(got16["rgb0"], ref["rgb0"]) > 30.0
 
 
+@pytest.mark.parametrize("S,I,n,views", [(48, 37, 5, False), (33, 0, 1, False), (64, 192, 3, False), (2, 0, 7, False),
+                                         (40, 24, 9, True), (256, 0, 2, False)])
+def test_ragged_sample_counts_vs_oracle(S, I, n, views):
+    """Sample counts that are not multiples of the 32-sample block or the 64-lane wave, one ray, the 256-sample cap."""
+    cfg = SceneConfig(N_samples=S, N_importance=I, use_viewdirs=views)
+    scene = make_scene(cfg, 4)
+    rays, latents = make_rays(n, 13, cfg)
+    ref = O.batchify_rays(rays, latents, scene, retraw=True)
+    got = hip_render(scene, rays, latents, "f32", retraw=True)
+    assert got["raw"].shape == ref["raw"].shape
+    if I == 0:
+        fails = compare_dict(got, ref, keys=[k for k in ref if not k.startswith("_")])
+    else:
+        fails = compare_dict(got, ref, keys=["rgb0", "disp0", "acc0"])
+        fine = oracle_fine_given_z(scene, rays, latents, got["_z_vals"])
+        fails += compare_dict(got, fine, keys=["rgb_map", "disp_map", "acc_map"])
+        fails += compare_dict(got, fine, keys=["raw"], **(FD_DIRS_RAW if views else {}))
+    assert not fails, "\n".join(fails)
+
+
+def test_more_than_256_samples_is_unsupported():
+    cfg = SceneConfig(N_samples=128, N_importance=192)
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(4, 0, cfg)
+    with pytest.raises(R.Unsupported):
+        hip_render(scene, rays, latents, "f32")
+
+
+def test_million_ray_launch_bf16():
+    """2^20 + 3 rays in one call (one launch of 2^20, one of 3): 288 GB sizing, no chunk loop needed (train.py:108-137)."""
+    cfg = SceneConfig(N_importance=0)
+    scene = make_scene(cfg, 0)
+    n = (1 << 20) + 3
+    rays, latents = make_rays(4099, 21, cfg)
+    reps = (n + 4098) // 4099
+    rays_big, lat_big = rays.repeat(reps, 1)[:n], latents.repeat(reps, 1)[:n]
+    got = hip_render(scene, rays_big, lat_big, "bf16", want_z=False)
+    assert got["rgb_map"].shape == (n, 3)
+    # periodic input -> periodic output, bit for bit, across the launch split as well
+    for k in ("rgb_map", "acc_map"):
+        a = got[k]
+        assert torch.equal(torch.nan_to_num(a[:4099]), torch.nan_to_num(a[4099 * 255:4099 * 256]))
+        tail = a[(1 << 20):]
+        assert torch.equal(torch.nan_to_num(tail), torch.nan_to_num(a[(1 << 20) % 4099:(1 << 20) % 4099 + 3]))
+
+
 def test_boundary_contract_errors_and_fallback():
     cfg = SceneConfig(netwidth=128, N_importance=64)        # no kernel compiled for W = 128
     scene = make_scene(cfg, 0)
