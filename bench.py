@@ -111,7 +111,8 @@ def main():
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
                     "issued_mfma_tflops": round(k["mfma_flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else 0.0,
-                    "traffic": None,
+                    "traffic": pmc_traffic(args),
+                    "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_summary.txt); algorithmic 7.86e8",
                     "other_kernels_ms_per_step": {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()}}
         res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -131,6 +132,20 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the fine-pass network kernel for THIS workload, from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_summary.py; counters cannot be read from inside the process).  None when
+    the run does not match the profiled configuration."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_fine.json")
+    if args.rays != 196608 or args.precision != "bf16" or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return float(json.load(f)["fine"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(scene, cfg, n):
