@@ -168,6 +168,18 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
 /* hip_stream: a hipStream_t (NULL = the null stream).  Asynchronous. */
 int nrnerf_render(const nrnerf_model* model, const nrnerf_render_args* args, void* hip_stream);
 
+/* Camera rays of one frame, generated on the device: reference get_rays (run_nerf_helpers.py:588-605) followed by
+ * the packing of render() (train.py:380-399).  rays_out [H*W, ray_stride] (device), row j*W+i =
+ * [origin3, direction3, near, far (, unit direction3 when ray_stride == 11)].  c2w: host pointer to the 3x4
+ * camera-to-world matrix, row-major. */
+typedef struct nrnerf_camera {
+    float c2w[12];
+    float focal_x, focal_y, center_x, center_y;
+    int32_t height, width;
+} nrnerf_camera;
+int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_plane, float* rays_out,
+                         int32_t ray_stride, void* hip_stream);
+
 /* profiling: records hipEvents around each kernel of subsequent nrnerf_render calls on this model */
 int nrnerf_profile_begin(nrnerf_model* model);
 int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchronises the recorded events */

@@ -76,6 +76,11 @@ class PackedInfo(C.Structure):
                 ("frag_bytes", C.c_uint32), ("slot_bytes", C.c_uint32), ("mfma_per_block", C.c_uint32)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("c2w", C.c_float * 12), ("focal_x", C.c_float), ("focal_y", C.c_float), ("center_x", C.c_float),
+                ("center_y", C.c_float), ("height", C.c_int32), ("width", C.c_int32)]
+
+
 EXPORTS = {
     "nrnerf_abi_version": (C.c_int, []),
     "nrnerf_strerror": (C.c_char_p, [C.c_int]),
@@ -83,6 +88,7 @@ EXPORTS = {
     "nrnerf_model_destroy": (None, [C.c_void_p]),
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
+    "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "nrnerf_profile_begin": (C.c_int, [C.c_void_p]),
     "nrnerf_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "nrnerf_pack_host": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(PackedInfo), C.c_void_p, C.c_size_t,

@@ -447,6 +447,18 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     return NRNERF_OK;
 }
 
+int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_plane, float* rays_out,
+                         int32_t ray_stride, void* hip_stream) {
+    if (!cam || !rays_out || (ray_stride != 8 && ray_stride != 11)) return NRNERF_ERR_INVALID;
+    if (cam->height <= 0 || cam->width <= 0 || cam->focal_x == 0.0f || cam->focal_y == 0.0f) return NRNERF_ERR_INVALID;
+    RayGenArgs a{};
+    std::memcpy(a.c2w, cam->c2w, sizeof(a.c2w));
+    a.fx = cam->focal_x; a.fy = cam->focal_y; a.cx = cam->center_x; a.cy = cam->center_y;
+    a.H = cam->height; a.W = cam->width; a.near = near_plane; a.far = far_plane;
+    a.rays = rays_out; a.ray_stride = ray_stride;
+    return launch_raygen(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
 int nrnerf_profile_begin(nrnerf_model* m) {
     if (!m) return NRNERF_ERR_INVALID;
     std::lock_guard<std::mutex> g(m->prof_mu);

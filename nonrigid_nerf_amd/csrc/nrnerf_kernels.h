@@ -51,6 +51,16 @@ struct CompositeArgs {
     float* vis; float* alpha;    // [N,S] optional
 };
 
+struct RayGenArgs {
+    float c2w[12];            // camera-to-world [3,4], row-major
+    float fx, fy, cx, cy;
+    int H, W;
+    float near, far;
+    float* rays;              // [H*W, ray_stride]
+    int ray_stride;           // 8, or 11 to append the unit view direction
+};
+hipError_t launch_raygen(const RayGenArgs& a, hipStream_t stream);
+
 // precision ids match nrnerf_precision
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
 

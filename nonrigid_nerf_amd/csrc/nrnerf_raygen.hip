@@ -1,0 +1,43 @@
+// nrnerf_raygen.hip -- camera rays of one frame, generated on the device (reference get_rays,
+// run_nerf_helpers.py:588-605, plus the packing render() does, train.py:380-399).
+//
+// Pixel (row j, column i) -> direction in camera frame ((i-cx)/fx, -(j-cy)/fy, -1), rotated by c2w[:3,:3];
+// origin = c2w[:3,3].  Output row (j*W + i) = [o3, d3, near, far (, d/|d|)]: exactly the `rays` tensor
+// batchify_rays receives, so a frame costs 12 floats of input instead of 32-44 B/ray of HBM reads by a torch
+// meshgrid pipeline.
+#include <hip/hip_runtime.h>
+
+#include "nrnerf_kernels.h"
+
+namespace nrn {
+
+__global__ void __launch_bounds__(256) raygen_kernel(const RayGenArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)a.H * a.W;
+    if (idx >= n) return;
+    const int j = (int)(idx / a.W), i = (int)(idx % a.W);
+    const float d0 = __fdiv_rn(__fsub_rn((float)i, a.cx), a.fx);
+    const float d1 = -__fdiv_rn(__fsub_rn((float)j, a.cy), a.fy);
+    const float d2 = -1.0f;
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)     // torch.sum(dirs[..., None, :] * c2w[:3,:3], -1)
+        d[r] = __fadd_rn(__fadd_rn(__fmul_rn(d0, a.c2w[r * 4 + 0]), __fmul_rn(d1, a.c2w[r * 4 + 1])), __fmul_rn(d2, a.c2w[r * 4 + 2]));
+    float* out = a.rays + idx * a.ray_stride;
+    out[0] = a.c2w[3]; out[1] = a.c2w[7]; out[2] = a.c2w[11];
+    out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+    out[6] = a.near; out[7] = a.far;
+    if (a.ray_stride >= 11) {
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+        out[8] = __fdiv_rn(d[0], nrm); out[9] = __fdiv_rn(d[1], nrm); out[10] = __fdiv_rn(d[2], nrm);
+    }
+}
+
+hipError_t launch_raygen(const RayGenArgs& a, hipStream_t stream) {
+    const long long n = (long long)a.H * a.W;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace nrn

@@ -1,0 +1,114 @@
+"""Frame driver: drop-in for the reference's ``render_path`` (train.py:419-553) on top of the HIP path.
+
+What changes relative to the reference loop:
+
+* rays are generated on the device from ``(c2w, intrinsics)`` by ``nrnerf_generate_rays`` (reference get_rays,
+  run_nerf_helpers.py:588-605, plus render()'s packing, train.py:380-399) -- 12 floats of input per frame;
+* the frame's latent code is passed once (``latent_stride = 0``) instead of being expanded per pixel
+  (train.py:464-466) and per sample (train.py:82-87);
+* one ``batchify_rays`` launch sequence per frame, no chunk loop, no DataParallel scatter/gather;
+* frame f+1 is enqueued while frame f's pixels travel to pinned host memory on a side stream (the reference
+  blocks on ``.cpu().numpy()`` for every output key of every frame, train.py:481-497).
+
+Image writing (``savedir``) is not reproduced: it is host-side I/O that needs imageio (train.py:506-545).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import render as R
+
+
+def generate_rays(c2w, intrin: dict, near: float, far: float, use_viewdirs: bool, device) -> torch.Tensor:
+    """``rays [H*W, 8|11]`` on ``device`` for one camera (row-major pixels), via the C ABI."""
+    lib = _lib.load()
+    H, W = int(intrin["height"]), int(intrin["width"])
+    cam = _lib.Camera()
+    m = np.asarray(torch.as_tensor(c2w).detach().cpu().float().numpy())[:3, :4].reshape(-1)
+    for k in range(12):
+        cam.c2w[k] = float(m[k])
+    cam.focal_x, cam.focal_y = float(intrin["focal_x"]), float(intrin["focal_y"])
+    cam.center_x, cam.center_y = float(intrin["center_x"]), float(intrin["center_y"])
+    cam.height, cam.width = H, W
+    stride = 11 if use_viewdirs else 8
+    dev = torch.device(device)
+    rays = torch.empty(H * W, stride, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.nrnerf_generate_rays(C.byref(cam), float(near), float(far), C.c_void_p(rays.data_ptr()),
+                                            stride, C.c_void_p(stream)), "nrnerf_generate_rays")
+    return rays
+
+
+def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_latents, gt_imgs=None, savedir=None,
+                render_factor=0, detailed_output=False, parallelized_render_function=None):
+    """Signature and return value of reference ``render_path`` (train.py:419-431, 547-553).
+
+    ``render_kwargs`` is the dict ``create_nerf`` builds (train.py:698-719) plus ``near`` / ``far``; the networks
+    are read from it.  ``parallelized_render_function`` (the DataParallel wrapper) is accepted and ignored: for
+    several GPUs use one process per GPU and ``nonrigid_nerf_amd.distributed``.
+    """
+    if savedir is not None:
+        raise NotImplementedError("image writing is host-side I/O outside the accelerated path (train.py:506-545)")
+    if render_factor != 0:                                           # train.py:434-446
+        scaled = []
+        for intrin in intrinsics:
+            s = dict(intrin)
+            s["height"], s["width"] = intrin["height"] // render_factor, intrin["width"] // render_factor
+            for k in ("focal_x", "focal_y", "center_x", "center_y"):
+                s[k] = intrin[k] / render_factor
+            scaled.append(s)
+        intrinsics = scaled
+    kw = dict(render_kwargs)
+    near, far = kw.pop("near"), kw.pop("far")
+    use_viewdirs = bool(kw.pop("use_viewdirs", False))
+    for k in ("ndc", "c2w_staticcam"):
+        kw.pop(k, None)
+    net = kw["network_fn"]
+    dev = next(net.parameters()).device
+    copy_stream = torch.cuda.Stream(device=dev)
+    pending = []          # (pinned rgb, pinned disp, event, H, W, details)
+    with torch.no_grad():
+        for i, (c2w, intrin) in enumerate(zip(render_poses, intrinsics)):
+            H, W = int(intrin["height"]), int(intrin["width"])
+            rays = generate_rays(torch.as_tensor(c2w)[:3, :4], intrin, near, far, use_viewdirs, dev)
+            code = torch.as_tensor(ray_bending_latents[i]).to(dev, torch.float32).reshape(1, -1)
+            api = {"ray_bending_latents": code.expand(H * W, code.shape[-1])}          # stride-0 view, never materialised
+            out = R.batchify_rays(rays, api, chunk=chunk, detailed_output=detailed_output, **kw)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                rgb_h = torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True)
+                disp_h = torch.empty((H, W), dtype=torch.float32, pin_memory=True)
+                rgb_h.copy_(out["rgb_map"].view(H, W, 3), non_blocking=True)
+                disp_h.copy_(out["disp_map"].view(H, W), non_blocking=True)
+                details = None
+                if detailed_output:
+                    details = {}
+                    for k, v in out.items():
+                        if k in ("rgb_map", "disp_map", "acc_map"):
+                            continue
+                        hbuf = torch.empty((H, W) + tuple(v.shape[1:]), dtype=v.dtype, pin_memory=True)
+                        hbuf.copy_(v.view((H, W) + tuple(v.shape[1:])), non_blocking=True)
+                        details[k] = hbuf
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            for t in out.values():
+                t.record_stream(copy_stream)
+            pending.append((rgb_h, disp_h, ev, details))
+    rgbs, disps, all_details = [], [], []
+    for rgb_h, disp_h, ev, details in pending:
+        ev.synchronize()
+        rgbs.append(rgb_h.numpy())
+        disps.append(disp_h.numpy())
+        if detailed_output:
+            all_details.append({k: v.numpy() for k, v in details.items()})
+    rgbs, disps = np.stack(rgbs, 0), np.stack(disps, 0)
+    if detailed_output:
+        return rgbs, disps, all_details
+    return rgbs, disps

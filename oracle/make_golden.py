@@ -125,9 +125,35 @@ def run_case(H, T, name, seed=0):
     return arrays, out
 
 
+def synthetic_camera(k, H=24, W=32):
+    """A small, deterministic camera: pose k of a little orbit, intrinsics scaled from example_sequence (hwf 384,512,256.6)."""
+    import math
+    a = 0.35 * k - 0.4
+    R = torch.tensor([[math.cos(a), 0.0, math.sin(a)], [0.05 * k, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+    R = torch.linalg.qr(R)[0]
+    t = torch.tensor([[0.1 * math.sin(a)], [0.02 * k], [0.15 - 0.03 * k]])
+    c2w = torch.cat([R, t], 1).float()
+    intrin = dict(height=H, width=W, focal_x=256.6 * W / 512, focal_y=256.6 * H / 384 * 1.01,
+                  center_x=W / 2 - 0.3, center_y=H / 2 + 0.2, ray_bending_latent_size=32)
+    return c2w, intrin
+
+
+def run_raygen(H_ref):
+    """Reference get_rays (run_nerf_helpers.py:588-605) on three synthetic cameras."""
+    arrays = {}
+    for k in range(3):
+        c2w, intrin = synthetic_camera(k)
+        ro, rd = H_ref.get_rays(c2w, intrin)
+        arrays[f"out__rays_o_{k}"] = ro.numpy().astype(np.float32)
+        arrays[f"out__rays_d_{k}"] = rd.numpy().astype(np.float32)
+        arrays[f"in__c2w_{k}"] = c2w.numpy()
+    return arrays
+
+
 def main():
     H, T = import_reference()
     os.makedirs(os.path.join(REPO, "tests", "golden"), exist_ok=True)
+    np.savez_compressed(os.path.join(REPO, "tests", "golden", "raygen.npz"), **run_raygen(H))
     for name in CASES:
         arrays, out = run_case(H, T, name)
         path = os.path.join(REPO, "tests", "golden", name + ".npz")

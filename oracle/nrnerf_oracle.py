@@ -257,3 +257,46 @@ def batchify_rays(rays_flat, latents, scene, chunk=1024 * 32, **kw):
         for k, v in r.items():
             pieces.setdefault(k, []).append(v)
     return {k: torch.cat(v, 0) for k, v in pieces.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# frame driver: ray generation + per-frame render loop
+# ------------------------------------------------------------------------------------------------
+def get_rays(c2w, intrin, dtype=torch.float32):
+    """get_rays, run_nerf_helpers.py:588-605.  c2w [3,4]; intrin dict with height, width, focal_x/y, center_x/y.
+    Returns rays_o, rays_d of shape [H, W, 3]."""
+    H, W = intrin["height"], intrin["width"]
+    c2w = torch.as_tensor(c2w, dtype=dtype)
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, dtype=dtype), torch.linspace(0, H - 1, H, dtype=dtype),
+                          indexing="ij")                                                        # :592
+    i, j = i.t(), j.t()                                                                          # :593-594
+    dirs = torch.stack([(i - intrin["center_x"]) / intrin["focal_x"],
+                        -(j - intrin["center_y"]) / intrin["focal_y"], -torch.ones_like(i)], -1)  # :599
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)                                     # :602
+    rays_o = c2w[:3, -1].expand(rays_d.shape)                                                    # :604
+    return rays_o, rays_d
+
+
+def pack_rays(rays_o, rays_d, near, far, use_viewdirs):
+    """The `rays` tensor render() builds for batchify_rays, train.py:380-399."""
+    rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    cols = [rays_o, rays_d, near * torch.ones_like(rays_d[:, :1]), far * torch.ones_like(rays_d[:, :1])]
+    if use_viewdirs:
+        cols.append(rays_d / torch.norm(rays_d, dim=-1, keepdim=True))                          # :380
+    return torch.cat(cols, -1)
+
+
+def render_path(render_poses, intrinsics, scene, ray_bending_latents, chunk=1024 * 32, **kw):
+    """render_path, train.py:419-553 (no image writing): per frame get_rays, one latent code expanded to every
+    pixel (:464-466), render, reshape to [H, W, ...].  Returns rgbs [F,H,W,3], disps [F,H,W] as float32 tensors."""
+    cfg = scene.cfg
+    rgbs, disps = [], []
+    for c2w, intrin, code in zip(render_poses, intrinsics, ray_bending_latents):
+        ro, rd = get_rays(torch.as_tensor(c2w)[:3, :4], intrin)
+        H, W = ro.shape[:2]
+        rays = pack_rays(ro, rd, cfg.near, cfg.far, cfg.use_viewdirs)
+        lat = torch.as_tensor(code).reshape(1, -1).expand(H * W, -1)
+        out = batchify_rays(rays, lat, scene, chunk=chunk, **kw)
+        rgbs.append(out["rgb_map"].reshape(H, W, 3))
+        disps.append(out["disp_map"].reshape(H, W))
+    return torch.stack(rgbs, 0), torch.stack(disps, 0)

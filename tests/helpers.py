@@ -10,7 +10,20 @@ import torch
 from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "raygen.npz")
+
+
+def synthetic_camera(k, H=24, W=32):
+    """Same cameras as oracle/make_golden.py::synthetic_camera (inputs of tests/golden/raygen.npz)."""
+    import math
+    a = 0.35 * k - 0.4
+    R = torch.tensor([[math.cos(a), 0.0, math.sin(a)], [0.05 * k, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+    R = torch.linalg.qr(R)[0]
+    t = torch.tensor([[0.1 * math.sin(a)], [0.02 * k], [0.15 - 0.03 * k]])
+    c2w = torch.cat([R, t], 1).float()
+    intrin = dict(height=H, width=W, focal_x=256.6 * W / 512, focal_y=256.6 * H / 384 * 1.01,
+                  center_x=W / 2 - 0.3, center_y=H / 2 + 0.2, ray_bending_latent_size=32)
+    return c2w, intrin
 
 
 def load_golden(name):

@@ -56,3 +56,17 @@ def test_chunk_invariance():
     a = O.batchify_rays(rays, lat, scene, chunk=7)
     b = O.batchify_rays(rays, lat, scene, chunk=4096)
     assert not compare_dict(a, b, tol_scale=0.01)
+
+
+def test_oracle_get_rays_matches_reference():
+    """get_rays (run_nerf_helpers.py:588-605) against tests/golden/raygen.npz, produced by the reference."""
+    import os
+    import numpy as np
+    from tests.helpers import GOLDEN_DIR, synthetic_camera
+    z = np.load(os.path.join(GOLDEN_DIR, "raygen.npz"))
+    for k in range(3):
+        c2w, intrin = synthetic_camera(k)
+        assert np.array_equal(c2w.numpy(), z[f"in__c2w_{k}"]), "camera generator drifted from the fixture"
+        ro, rd = O.get_rays(c2w, intrin)
+        assert torch.equal(ro, torch.from_numpy(z[f"out__rays_o_{k}"]))
+        assert torch.allclose(rd, torch.from_numpy(z[f"out__rays_d_{k}"]), rtol=0, atol=1e-7)
