@@ -73,16 +73,18 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
     out.unit_off.assign(T.nunits_padded + 1, 0);
     for (int u = 0; u <= T.nunits_padded; ++u) out.unit_off[u] = (uint32_t)((size_t)u * SH::UNIT_BYTES / 16);
     out.bias.assign((size_t)T.ntiles * 32, 0.0f);
-    size_t pos = 0;
+    size_t written = 0;
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
         const nrnerf_linear* lin = layer_source(d, mlp, sp);
         for (int t = 0; t < sp.nt; ++t) {
-            if (pos != (size_t)T.tiles[sp.tile0 + t].gbase * SH::FRAG_BYTES) std::abort();   // plan/packer drift
+            const TileInfo& ti = T.tiles[sp.tile0 + t];
             for (int s = 0; s < sp.ns; ++s) {
-                // split layers: fragment pair (hi, lo) with lo = f16(w - f16(w)); others: one fragment
+                // split layers: fragment pair (hi, lo) with lo = f16((w - f16(w)) * 2^11); others: one fragment
                 for (int part = 0; part <= sp.split; ++part) {
-                    uint8_t* fr = out.stream.data() + pos;
+                    const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride + part;
+                    if (fi >= (size_t)T.nfrags) std::abort();                       // plan/packer drift
+                    uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
                     const bool as_f16 = (precision == NRNERF_PREC_F16) || frag_is_f16<SH, A>(sp.kind, s);
                     for (int lane = 0; lane < 64; ++lane) {
                         const int i = lane & 31, h = lane >> 5;
@@ -100,7 +102,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                             }
                         }
                     }
-                    pos += SH::FRAG_BYTES;
+                    ++written;
                 }
             }
             for (int h = 0; h < 2; ++h)
@@ -110,7 +112,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                 }
         }
     }
-    if (pos != (size_t)T.nfrags * SH::FRAG_BYTES) std::abort();
+    if (written != (size_t)T.nfrags) std::abort();
 }
 
 bool linear_is(const nrnerf_linear& l, int out_f, int in_f, bool need_bias) {

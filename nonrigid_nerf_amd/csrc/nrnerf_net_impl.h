@@ -213,42 +213,76 @@ __device__ __forceinline__ f32x16 load_bias(const float* bias_lds, int tile, int
                   b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
 }
 
-// Fragments are prefetched PF steps ahead across the whole layer (all tiles form one flat sequence), so a
-// ds_read_b128 is in flight for ~PF MFMAs before its consumer instead of being waited for immediately.
+// Position q of a layer's fragment sequence (stream order, nrnerf_plan.h) -> (tile, slab).  Tiles are paired with
+// interleaved slabs; an odd last tile follows alone.
+template <int NT, int NS>
+struct SeqPos {
+    static constexpr int NPAIR = NT / 2;
+    static constexpr int tile(int q) { return q < NPAIR * 2 * NS ? 2 * (q / (2 * NS)) + (q & 1) : NT - 1; }
+    static constexpr int slab(int q) { return q < NPAIR * 2 * NS ? (q % (2 * NS)) / 2 : q - NPAIR * 2 * NS; }
+    static constexpr bool last_of_tile(int q) { return slab(q) == NS - 1; }
+};
+
+#ifndef NRN_NACC
+#define NRN_NACC 2      // accumulator sets per wave (4: the previous pair's epilogue overlaps the next pair's MFMAs, but the
+                        // 32 extra registers spill inside the trunk at 256 VGPRs)
+#endif
+
+// Fragments are prefetched PF steps ahead across the whole layer (one flat sequence), so a ds_read_b128 is in
+// flight for ~PF MFMAs before its consumer.  Two tiles run as interleaved accumulator chains (see nrnerf_plan.h);
+// with NACC = 4 the chains of pair p+1 start in fresh accumulator sets while pair p's epilogue (convert, relu) is
+// issued DLY steps later, so the VALU work overlaps the matrix pipe.
 template <class P0, class P1, class PL, int LI, int NS0, int NS1, class ST, class IN0, class IN1, class EPI>
 __device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, const IN0& in0, const IN1& in1, EPI&& epi) {
     constexpr LayerSpec spec = PL::TB.layers[LI];
     static_assert(spec.ns == NS0 + NS1 && spec.split == 0, "slab count mismatch between kernel and plan");
-    constexpr int NS = NS0 + NS1, Q = spec.nt * NS, PF = P1::PF;
+    constexpr int NS = NS0 + NS1, NT = spec.nt, Q = NT * NS, PF = P1::PF;
+    using SQ = SeqPos<NT, NS>;
     constexpr int G0 = PL::TB.tiles[spec.tile0].gbase;
-    // raw 16-byte (or 4-byte) fragment registers; typed at the MFMA by the policy of the slab
+    constexpr int NACC = (NT >= 4) ? NRN_NACC : (NT >= 2 ? 2 : 1);
     typename P1::frag a[PF];
     auto load = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        constexpr int s = q % NS;
+        constexpr int s = SQ::slab(q);
         if constexpr (s < NS0) a[q % PF] = __builtin_bit_cast(typename P1::frag, st.template frag<P0, G0 + q>());
         else a[q % PF] = st.template frag<P1, G0 + q>();
     };
     static_for<0, (PF < Q ? PF : Q)>([&](auto qc) { load(qc); });
-    // Two accumulator sets, used alternately by consecutive tiles: while tile t's chain runs in accs[t & 1],
-    // the other set is first drained by tile t-1's epilogue (DLY MFMAs into tile t, so the VALU work overlaps
-    // the matrix pipe instead of waiting on the chain's last result) and then pre-loaded with tile t+1's bias.
     constexpr int DLY = (NS - 1 < NRN_EPI_DELAY) ? NS - 1 : NRN_EPI_DELAY;
-    f32x16 accs[2];
-    accs[0] = load_bias(bias_lds, spec.tile0, h);
-    if constexpr (spec.nt > 1) accs[1] = load_bias(bias_lds, spec.tile0 + 1, h);
+    f32x16 accs[NACC];
+    static_for<0, (NACC < NT ? NACC : NT)>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (NACC == 4 || t < 2) accs[t % NACC] = load_bias(bias_lds, spec.tile0 + t, h);
+    });
     static_for<0, Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        constexpr int t = q / NS, s = q % NS;
+        constexpr int t = SQ::tile(q), s = SQ::slab(q);
         const typename P1::frag cur = a[q % PF];
         if constexpr (q + PF < Q) load(std::integral_constant<int, q + PF>{});
-        if constexpr (s < NS0) accs[t & 1] = P0::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[s], accs[t & 1]);
-        else accs[t & 1] = P1::mfma(cur, in1[s - NS0], accs[t & 1]);
-        if constexpr (t > 0 && s == DLY) {
-            epi(std::integral_constant<int, t - 1>{}, accs[(t - 1) & 1]);
-            if constexpr (t + 1 < spec.nt) accs[(t + 1) & 1] = load_bias(bias_lds, spec.tile0 + t + 1, h);
+        if constexpr (s < NS0) accs[t % NACC] = P0::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[s], accs[t % NACC]);
+        else accs[t % NACC] = P1::mfma(cur, in1[s - NS0], accs[t % NACC]);
+        if constexpr (NACC == 4) {
+            // delayed epilogue of the previous pair, then pre-load the biases of the pair after this one
+            if constexpr (t >= 2 && (t & 1) == 1 && s == DLY) {
+                constexpr int tp = (t & ~1) - 2;
+                epi(std::integral_constant<int, tp>{}, accs[tp % NACC]);
+                epi(std::integral_constant<int, tp + 1>{}, accs[(tp + 1) % NACC]);
+                if constexpr (tp + 4 < NT) accs[(tp + 4) % NACC] = load_bias(bias_lds, spec.tile0 + tp + 4, h);
+                if constexpr (tp + 5 < NT) accs[(tp + 5) % NACC] = load_bias(bias_lds, spec.tile0 + tp + 5, h);
+            }
+            if constexpr (q == Q - 1) {     // drain: the last pair (or the odd tile, plus the pair before it)
+                constexpr int first = (NT & 1) ? (NT >= 3 ? NT - 3 : NT - 1) : NT - 2;
+                static_for<first, NT>([&](auto tc) { epi(tc, accs[decltype(tc)::value % NACC]); });
+            }
+        } else {
+            if constexpr (SQ::last_of_tile(q) && (((t & 1) == 1) || t == NT - 1)) {
+                // pair finished: epilogue of its tile(s), then the next pair's biases
+                if constexpr ((t & 1) == 1) epi(std::integral_constant<int, t - 1>{}, accs[(t - 1) % NACC]);
+                epi(std::integral_constant<int, t>{}, accs[t % NACC]);
+                if constexpr (t + 1 < NT) accs[(t + 1) % NACC] = load_bias(bias_lds, spec.tile0 + t + 1, h);
+                if constexpr (t + 2 < NT) accs[(t + 2) % NACC] = load_bias(bias_lds, spec.tile0 + t + 2, h);
+            }
         }
-        if constexpr (t == spec.nt - 1 && s == NS - 1) epi(std::integral_constant<int, t>{}, accs[t & 1]);
     });
 }
 
@@ -264,30 +298,48 @@ struct Act {
     }
 };
 
-// dense layer of the bender: 3-term split product  Whi*xhi + Whi*xlo + Wlo*xhi  when SPLIT
+// dense layer of the bender: 3-term split product  Whi*xhi + 2^-11 (Whi*xlo + Wlo*xhi)  when SPLIT.  The two tiles of
+// a pair advance together, so no accumulator is written by two consecutive MFMAs.
 template <class PE, bool SPLIT, class PL, int LI, int NS, class ST, class ACT, class EPI>
 __device__ __forceinline__ void dense_b(ST& st, const float* bias_lds, int h, const ACT& in, EPI&& epi) {
     constexpr LayerSpec spec = PL::TB.layers[LI];
     static_assert(spec.ns == NS && spec.split == (SPLIT ? 1 : 0), "bender layer mismatch between kernel and plan");
-    static_for<0, spec.nt>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t];
-        f32x16 acc = load_bias(bias_lds, spec.tile0 + t, h);
-        f32x16 corr = {};       // 2^11-scaled cross terms
+    constexpr int NT = spec.nt;
+    static_for<0, (NT + 1) / 2>([&](auto pc) {
+        constexpr int t0 = 2 * decltype(pc)::value;
+        constexpr int W = (t0 + 1 < NT) ? 2 : 1;          // tiles in this group
+        f32x16 acc[W], corr[W];
+        static_for<0, W>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            acc[u] = load_bias(bias_lds, spec.tile0 + t0 + u, h);
+            corr[u] = f32x16{};
+        });
         static_for<0, NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             if constexpr (SPLIT) {
-                const auto whi = st.template frag<PE, ti.gbase + 2 * s>();
-                const auto wlo = st.template frag<PE, ti.gbase + 2 * s + 1>();
-                corr = PE::mfma(wlo, in.hi[s], corr);
-                corr = PE::mfma(whi, in.lo[s], corr);
-                acc = PE::mfma(whi, in.hi[s], acc);
+                typename PE::frag whi[W], wlo[W];
+                static_for<0, W>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t0 + u];
+                    whi[u] = st.template frag<PE, ti.gbase + s * ti.gstride>();
+                    wlo[u] = st.template frag<PE, ti.gbase + s * ti.gstride + 1>();
+                });
+                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; corr[u] = PE::mfma(wlo[u], in.hi[s], corr[u]); });
+                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; acc[u] = PE::mfma(whi[u], in.hi[s], acc[u]); });
+                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; corr[u] = PE::mfma(whi[u], in.lo[s], corr[u]); });
             } else {
-                acc = PE::mfma(st.template frag<PE, ti.gbase + s>(), in.hi[s], acc);
+                static_for<0, W>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t0 + u];
+                    acc[u] = PE::mfma(st.template frag<PE, ti.gbase + s * ti.gstride>(), in.hi[s], acc[u]);
+                });
             }
         });
-        if constexpr (SPLIT) acc += corr * (1.0f / PE::LO_SCALE);
-        epi(tc, acc);
+        static_for<0, W>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (SPLIT) acc[u] += corr[u] * (1.0f / PE::LO_SCALE);
+            epi(std::integral_constant<int, t0 + u>{}, acc[u]);
+        });
     });
 }
 

@@ -87,24 +87,37 @@ class FragReader:
 def dense_emul(fr, bias_tab, tile0, ns, nt, slabs, split=False, f16_slabs=0):
     """slabs: [ns][2*KH][nsamp] -> list of nt D tiles [32][nsamp].
 
-    split: every slab has a (hi, lo) fragment pair whose sum is the weight (3-term split product).
+    Stream order (nrnerf_plan.h): tiles in pairs with interleaved slabs -- (2p,0) (2p+1,0) (2p,1) (2p+1,1) ... --
+    an odd last tile alone.  split: every (tile, slab) has a (hi, lo * 2^11) fragment pair (3-term split product).
     f16_slabs: the first f16_slabs slabs are f16 fragments even in bf16 mode (-1: all)."""
-    out = []
-    for t in range(nt):
+    def bias_of(t):
         b = np.zeros(32)
         for h in range(2):
             for r in range(16):
                 b[tile_row(r, h)] = bias_tab[(tile0 + t) * 32 + h * 16 + r]
-        D = np.repeat(b[:, None], slabs[0].shape[1], 1)
+        return np.repeat(b[:, None], slabs[0].shape[1], 1)
+
+    def next_A(s):
+        f16 = f16_slabs < 0 or s < f16_slabs
+        A = fr.next(f16)
+        if split:
+            lo = fr.next(f16) / 2048.0       # lo parts are stored pre-scaled by 2^11 (no f16 subnormals)
+            assert np.abs(lo).max() <= np.abs(A).max() * 2.0 ** -10 + 1e-30
+            A = A + lo
+        return A
+
+    out = [None] * nt
+    for p in range(0, nt - 1, 2):
+        D0, D1 = bias_of(p), bias_of(p + 1)
         for s in range(ns):
-            f16 = f16_slabs < 0 or s < f16_slabs
-            A = fr.next(f16)
-            if split:
-                lo = fr.next(f16) / 2048.0       # lo parts are stored pre-scaled by 2^11 (no f16 subnormals)
-                assert np.abs(lo).max() <= np.abs(A).max() * 2.0 ** -10 + 1e-30
-                A = A + lo
-            D = D + A @ slabs[s]
-        out.append(D)
+            D0 = D0 + next_A(s) @ slabs[s]
+            D1 = D1 + next_A(s) @ slabs[s]
+        out[p], out[p + 1] = D0, D1
+    if nt & 1:
+        D = bias_of(nt - 1)
+        for s in range(ns):
+            D = D + next_A(s) @ slabs[s]
+        out[nt - 1] = D
     return out
 
 
