@@ -197,7 +197,6 @@ double algo_macs(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
 
 struct PassDev {
     void* stream = nullptr;
-    uint32_t* unit_off = nullptr;
     float* bias = nullptr;
     double algo_flops_per_sample = 0;      // 2 * MAC
     double mfma_flops_per_sample = 0;      // issued, incl. padding
@@ -223,16 +222,13 @@ namespace {
 
 int upload_pass(const PackedPass& pk, PassDev& dev) {
     if (hipMalloc(&dev.stream, pk.stream.size()) != hipSuccess) return NRNERF_ERR_NOMEM;
-    if (hipMalloc((void**)&dev.unit_off, pk.unit_off.size() * 4) != hipSuccess) return NRNERF_ERR_NOMEM;
     if (hipMalloc((void**)&dev.bias, pk.bias.size() * 4) != hipSuccess) return NRNERF_ERR_NOMEM;
     if (hipMemcpy(dev.stream, pk.stream.data(), pk.stream.size(), hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
-    if (hipMemcpy(dev.unit_off, pk.unit_off.data(), pk.unit_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
     if (hipMemcpy(dev.bias, pk.bias.data(), pk.bias.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
     return NRNERF_OK;
 }
 void free_pass(PassDev& dev) {
     if (dev.stream) (void)hipFree(dev.stream);
-    if (dev.unit_off) (void)hipFree(dev.unit_off);
     if (dev.bias) (void)hipFree(dev.bias);
     dev = PassDev{};
 }

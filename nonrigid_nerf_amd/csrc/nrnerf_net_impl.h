@@ -415,9 +415,6 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 
     WRing<P, WAVES, PL::NUP> st;
     st.init(a.wstream, ring, wave, lane);
-#ifdef NRN_PRIO_YOUNG
-    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // second-dispatched half loses VALU arbitration otherwise
-#endif
 
     const int S = a.S;
     const int bpr = (S + 31) >> 5;                 // 32-sample blocks per ray

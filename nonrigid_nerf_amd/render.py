@@ -32,7 +32,6 @@ import torch
 from . import _lib
 
 _DEFAULT_PRECISION = os.environ.get("NRNERF_PRECISION", "bf16")
-_state = threading.local()
 _fallbacks = {}          # {"render_rays": fn, "batchify_rays": fn} saved by install()
 _MAX_RAYS_PER_LAUNCH = 1 << 20
 
