@@ -119,10 +119,10 @@ bool linear_is(const nrnerf_linear& l, int out_f, int in_f, bool need_bias) {
     return l.weight && l.out_features == out_f && l.in_features == in_f && (!need_bias || l.bias);
 }
 
-// Does (desc, mlp) match the architecture this build has kernels for?  (ArchDefault: 8x256 trunk with
-// skip after layer 4, L = 10, bender 5x64, rigidity 3x32, latent 32, no view-dependent head.)
-int check_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
-    using A = ArchDefault;
+// Does (desc, mlp) match compiled architecture A?  (ArchDefault: 8x256 trunk with skip after layer 4, L = 10, bender
+// 5x64, rigidity 3x32, latent 32, optional view-dependent head with L = 4; ArchDeepBend: the same with a 7-layer bender.)
+template <class A>
+int check_arch_t(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
     if (d.precision < 0 || d.precision > 2) return NRNERF_ERR_INVALID;
     if (d.multires != A::L) return NRNERF_ERR_UNSUPPORTED;
     if (m.time_conditioned) return NRNERF_ERR_UNSUPPORTED;
@@ -161,10 +161,8 @@ int check_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
     return NRNERF_OK;
 }
 
-int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out) {
-    int rc = check_arch(d, m);
-    if (rc != NRNERF_OK) return rc;
-    using A = ArchDefault;
+template <class A>
+void pack_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out) {
     const bool bend = d.bender != nullptr, views = m.use_viewdirs != 0;
     auto go = [&](auto sh) {
         using SH = decltype(sh);
@@ -174,7 +172,26 @@ int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPa
         else pack_pass<SH, A, false, false>(d, m, d.precision, out);
     };
     if (d.precision == NRNERF_PREC_F32) go(ShapeF32{}); else go(Shape16{});
-    return NRNERF_OK;
+}
+
+// picks the compiled architecture (nrnerf_plan.h ArchById) the description matches; *arch_id receives its id
+int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, int* arch_id = nullptr) {
+    int rc = check_arch_t<ArchDefault>(d, m);
+    if (rc == NRNERF_OK) {
+        pack_arch<ArchDefault>(d, m, out);
+        if (arch_id) *arch_id = 0;
+        return NRNERF_OK;
+    }
+    if (rc == NRNERF_ERR_UNSUPPORTED && d.bender) {     // arch 1 is a bender variant: only compiled with a bender
+        const int rc1 = check_arch_t<ArchDeepBend>(d, m);
+        if (rc1 == NRNERF_OK) {
+            pack_arch<ArchDeepBend>(d, m, out);
+            if (arch_id) *arch_id = 1;
+            return NRNERF_OK;
+        }
+        if (rc1 != NRNERF_ERR_UNSUPPORTED) return rc1;
+    }
+    return rc;
 }
 
 // algorithmic MACs per sample, unpadded
@@ -208,7 +225,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 struct nrnerf_model {
-    int device = 0, precision = 0, has_bend = 0, views = 0, num_cus = 0, latent_size = 0;
+    int device = 0, precision = 0, has_bend = 0, views = 0, arch_id = 0, num_cus = 0, latent_size = 0;
     PassDev coarse, fine;
     bool fine_is_coarse = false;
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
@@ -280,12 +297,14 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     *out = nullptr;
     if (!desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
     PackedPass pc, pf;
-    int rc = pack_dispatch(*desc, *desc->coarse, pc);
+    int arch_id = 0, arch_f = 0;
+    int rc = pack_dispatch(*desc, *desc->coarse, pc, &arch_id);
     if (rc != NRNERF_OK) return rc;
     if (desc->fine) {
         if ((desc->fine->use_viewdirs != 0) != (desc->coarse->use_viewdirs != 0)) return NRNERF_ERR_INVALID;
-        rc = pack_dispatch(*desc, *desc->fine, pf);
+        rc = pack_dispatch(*desc, *desc->fine, pf, &arch_f);
         if (rc != NRNERF_OK) return rc;
+        if (arch_f != arch_id) return NRNERF_ERR_INVALID;
     }
     int prev = 0;
     if (hipGetDevice(&prev) != hipSuccess) return NRNERF_ERR_HIP;
@@ -296,6 +315,7 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     m->precision = desc->precision;
     m->has_bend = desc->bender != nullptr;
     m->views = desc->coarse->use_viewdirs != 0;
+    m->arch_id = arch_id;
     m->latent_size = desc->bender ? desc->bender->latent_size : 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, desc->device) != hipSuccess) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_HIP; }
@@ -400,7 +420,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.ex = sample_out(a->coarse);
     na.knobs = kn;
     hipError_t e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
-                         [&] { return launch_net(m->precision, m->has_bend, m->views, 0, na, m->num_cus, stream); });
+                         [&] { return launch_net(m->precision, m->has_bend, m->views, m->arch_id, na, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K1: coarse composite (+ sampling)
@@ -430,7 +450,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
     e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
-              [&] { return launch_net(m->precision, m->has_bend, m->views, 0, nf, m->num_cus, stream); });
+              [&] { return launch_net(m->precision, m->has_bend, m->views, m->arch_id, nf, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K3: fine composite

@@ -1,23 +1,26 @@
-// nrnerf_net.hip -- host-side dispatch over the compiled network-kernel variants.
+// nrnerf_net.hip -- host-side dispatch over the compiled network-kernel variants
+// (architecture x precision x bender x view-dependent head; see the VARIANTS list in the Makefile).
 #include "nrnerf_kernels.h"
 
 namespace nrn {
+typedef hipError_t (*launch_fn)(const NetArgs&, int, hipStream_t);
 #define NRN_DECL(n) hipError_t launch_net_##n(const NetArgs&, int, hipStream_t);
-NRN_DECL(f32_bend) NRN_DECL(f32_nobend) NRN_DECL(bf16_bend) NRN_DECL(bf16_nobend) NRN_DECL(f16_bend) NRN_DECL(f16_nobend)
-NRN_DECL(f32_bend_views) NRN_DECL(f32_nobend_views) NRN_DECL(bf16_bend_views) NRN_DECL(bf16_nobend_views)
-NRN_DECL(f16_bend_views) NRN_DECL(f16_nobend_views)
+#define NRN_ARCH0(p) NRN_DECL(a0_##p##_bend) NRN_DECL(a0_##p##_nobend) NRN_DECL(a0_##p##_bend_views) NRN_DECL(a0_##p##_nobend_views)
+#define NRN_ARCH1(p) NRN_DECL(a1_##p##_bend) NRN_DECL(a1_##p##_bend_views)
+NRN_ARCH0(f32) NRN_ARCH0(bf16) NRN_ARCH0(f16) NRN_ARCH1(f32) NRN_ARCH1(bf16) NRN_ARCH1(f16)
 #undef NRN_DECL
 
+// [arch][precision][has_bend][views]; nullptr = not compiled (arch 1 exists only with a bender: it IS a bender variant)
+#define NRN_ROW0(p) {{launch_net_a0_##p##_nobend, launch_net_a0_##p##_nobend_views}, {launch_net_a0_##p##_bend, launch_net_a0_##p##_bend_views}}
+#define NRN_ROW1(p) {{nullptr, nullptr}, {launch_net_a1_##p##_bend, launch_net_a1_##p##_bend_views}}
+static const launch_fn TABLE[2][3][2][2] = {
+    {NRN_ROW0(f32), NRN_ROW0(bf16), NRN_ROW0(f16)},
+    {NRN_ROW1(f32), NRN_ROW1(bf16), NRN_ROW1(f16)},
+};
+
 hipError_t launch_net(int precision, bool has_bend, bool views, int arch_id, const NetArgs& a, int num_cus, hipStream_t stream) {
-    if (arch_id != 0) return hipErrorInvalidValue;
-#define NRN_PICK(p) (views ? (has_bend ? launch_net_##p##_bend_views(a, num_cus, stream) : launch_net_##p##_nobend_views(a, num_cus, stream)) \
-                           : (has_bend ? launch_net_##p##_bend(a, num_cus, stream) : launch_net_##p##_nobend(a, num_cus, stream)))
-    switch (precision) {
-        case PREC_F32:  return NRN_PICK(f32);
-        case PREC_BF16: return NRN_PICK(bf16);
-        case PREC_F16:  return NRN_PICK(f16);
-    }
-#undef NRN_PICK
-    return hipErrorInvalidValue;
+    if (arch_id < 0 || arch_id > 1 || precision < 0 || precision > 2) return hipErrorInvalidValue;
+    const launch_fn f = TABLE[arch_id][precision][has_bend ? 1 : 0][views ? 1 : 0];
+    return f ? f(a, num_cus, stream) : hipErrorInvalidValue;
 }
 }  // namespace nrn

@@ -290,7 +290,11 @@ constexpr NRN_HD int out_row(int kind, int t, int i, int out_features) {
     }
 }
 
-using ArchDefault = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32>;
+using ArchDefault = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32>;      // arch id 0: the reference's shipped configuration
+using ArchDeepBend = ArchT<256, 8, 4, 10, 64, 7, 32, 3, 32>;     // arch id 1: deeper ray-bending MLP (BASELINE config 4)
+constexpr int NUM_ARCHS = 2;
+template <int ID> struct ArchById { using type = ArchDefault; };
+template <> struct ArchById<1> { using type = ArchDeepBend; };
 using ShapeF32 = Shape<1>;
 using Shape16 = Shape<8>;
 

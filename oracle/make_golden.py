@@ -52,6 +52,14 @@ def reference_kwargs(H, T, scene):
     rb = None
     if scene.bender is not None:
         rb = H.ray_bending(input_ch, cfg.latent_size, "simple_neural", embed_fn)
+        if cfg.bend_depth != rb.network_depth:
+            # the reference hard-codes depth 5 (run_nerf_helpers.py:406-407); its forward() only loops over
+            # self.network, so a deeper offset MLP is the same module with a longer ModuleList (BASELINE config 4)
+            hd = rb.hidden_dimensions
+            rb.network_depth = cfg.bend_depth
+            rb.network = torch.nn.ModuleList(
+                [torch.nn.Linear(3 + cfg.latent_size, hd)] + [torch.nn.Linear(hd, hd) for _ in range(cfg.bend_depth - 2)]
+                + [torch.nn.Linear(hd, 3, bias=False)])
         rb.load_state_dict({k: v.clone() for k, v in scene.bender.items()}, strict=True)
     embeddirs_fn, input_ch_views = (None, 0)
     netchunk = 1024 * 64
@@ -94,6 +102,7 @@ CASES = {
                          dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5, removal_threshold=0.6)),
     "viewdirs_64_64":   (dict(N_importance=64, use_viewdirs=True), 48, 32768, False, True, {}),
     "no_bender_64_64":  (dict(N_importance=64, ray_bending=False), 48, 32768, False, False, {}),
+    "config4_deep_bender_viewdirs": (dict(N_importance=64, use_viewdirs=True, bend_depth=7), 40, 32768, True, True, {}),
 }
 
 

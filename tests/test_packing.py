@@ -298,13 +298,21 @@ def test_packed_stream_reproduces_the_network(precision, bend, views):
 
 def test_unsupported_architectures_are_rejected():
     lib = _lib.load()
-    for kw in (dict(netwidth=128), dict(netdepth=6), dict(multires=8), dict(bend_hidden=32), dict(latent_size=16)):
+    for kw in (dict(netwidth=128), dict(netdepth=6), dict(multires=8), dict(bend_hidden=32), dict(latent_size=16),
+               dict(bend_depth=6), dict(bend_depth=7, ray_bending=True, rigidity_depth=4)):
         scene = make_scene(SceneConfig(**kw), 0)
         rb, coarse, fine = build_modules(scene)
         desc, keep = build_model_desc(coarse, fine, "bf16", 0)
         info = _lib.PackedInfo()
         rc = lib.nrnerf_pack_host(C.byref(desc), 0, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)())
         assert rc == _lib.ERR_UNSUPPORTED, (kw, rc)
+    # the deeper-bender architecture of BASELINE config 4 IS compiled (arch id 1)
+    scene = make_scene(SceneConfig(bend_depth=7, use_viewdirs=True), 0)
+    rb, coarse, fine = build_modules(scene)
+    desc, keep = build_model_desc(coarse, fine, "bf16", 0)
+    info = _lib.PackedInfo()
+    assert lib.nrnerf_pack_host(C.byref(desc), 1, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == 0
+    assert info.mfma_per_block == 976 - 16 + 16 + 128 + 72 + 8 + 3 * (6 + 5 * 8 + 4) + 15
     bad = _lib.ModelDesc()
     assert lib.nrnerf_pack_host(C.byref(bad), 0, None, None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_INVALID
     out = C.c_void_p()
