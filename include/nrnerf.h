@@ -139,6 +139,11 @@ typedef struct nrnerf_render_args {
     float* acc0;                /* [N]    */
     float* z_std;               /* [N]    */
     float* z_vals;              /* [N, S'] merged, sorted sample depths (not a reference key; NULL allowed) */
+    /* surface reduction of the final pass (what free_viewpoint_rendering.py:621-658 extracts from the per-sample
+     * detail tensors on the host): the sample whose accumulated visibility weight is closest to 0.5.  All NULL = off. */
+    float* surface_pts;         /* [N, 3] bent point at that sample   (fine_input_pts[median]) */
+    float* surface_rigidity;    /* [N]    rigidity mask at that sample (0 without a bender)    */
+    int32_t* median_index;      /* [N]    index of that sample                                 */
     nrnerf_sample_outputs coarse;   /* keys without prefix  */
     nrnerf_sample_outputs fine;     /* keys with "fine_" prefix (I > 0) */
     /* scratch */

@@ -62,6 +62,7 @@ class RenderArgs(C.Structure):
                 ("rgb_map", C.c_void_p), ("disp_map", C.c_void_p), ("acc_map", C.c_void_p), ("raw", C.c_void_p),
                 ("rgb0", C.c_void_p), ("disp0", C.c_void_p), ("acc0", C.c_void_p), ("z_std", C.c_void_p),
                 ("z_vals", C.c_void_p),
+                ("surface_pts", C.c_void_p), ("surface_rigidity", C.c_void_p), ("median_index", C.c_void_p),
                 ("coarse", SampleOutputs), ("fine", SampleOutputs),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 

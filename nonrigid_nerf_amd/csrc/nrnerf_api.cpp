@@ -358,6 +358,7 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
     const size_t N = (size_t)n_rays, S = (size_t)n_samples, SF = S + (size_t)n_importance;
     size_t b = align_up(N * S * 4 * sizeof(float), 256);
     if (n_importance > 0) b += align_up(N * SF * sizeof(float), 256) + align_up(N * SF * 4 * sizeof(float), 256);
+    b += align_up(N * SF * 4 * sizeof(float), 256);      // bent point + rigidity of the final pass (surface reduction)
     return b;
 }
 
@@ -380,8 +381,10 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     float* z_fine = nullptr; float* raw_f = nullptr;
     if (I > 0) {
         z_fine = (float*)ws; ws += align_up((size_t)N * SF * sizeof(float), 256);
-        raw_f = (float*)ws;
+        raw_f = (float*)ws; ws += align_up((size_t)N * SF * 4 * sizeof(float), 256);
     }
+    const bool surface = a->surface_pts || a->surface_rigidity || a->median_index;
+    float* bent4 = surface ? (float*)ws : nullptr;
 
     Knobs kn{};
     kn.has_cutoff = a->has_rigidity_cutoff; kn.cutoff = a->rigidity_cutoff;
@@ -417,6 +420,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.raw4 = raw_c;
     na.raw_out = (I == 0) ? a->raw : nullptr;
     na.raw_ch = m->coarse.output_ch;
+    na.bent4 = (I == 0) ? bent4 : nullptr;
     na.ex = sample_out(a->coarse);
     na.knobs = kn;
     hipError_t e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
@@ -439,6 +443,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         ca.z_std = nullptr; ca.z_out = nullptr; ca.z_user = a->z_vals;
     }
     ca.vis = a->coarse.visibility_weights; ca.alpha = a->coarse.opacity_alpha;
+    if (I == 0 && surface) { ca.bent4 = bent4; ca.surf_pts = a->surface_pts; ca.surf_rig = a->surface_rigidity; ca.med_idx = a->median_index; }
     e = timed(1, 0, 0, [&] { return launch_composite(ca, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
     if (I == 0) return NRNERF_OK;
@@ -449,6 +454,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.wstream = m->fine.stream; nf.bias = m->fine.bias;
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
+    nf.bent4 = bent4;
     e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
               [&] { return launch_net(m->precision, m->has_bend, m->views, m->arch_id, nf, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
@@ -460,6 +466,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     cf.rgb = a->rgb_map; cf.disp = a->disp_map; cf.acc = a->acc_map;
     cf.z_std = nullptr; cf.z_out = nullptr; cf.z_user = a->z_vals;
     cf.vis = a->fine.visibility_weights; cf.alpha = a->fine.opacity_alpha;
+    if (surface) { cf.bent4 = bent4; cf.surf_pts = a->surface_pts; cf.surf_rig = a->surface_rigidity; cf.med_idx = a->median_index; }
     e = timed(3, 0, 0, [&] { return launch_composite(cf, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
     return NRNERF_OK;

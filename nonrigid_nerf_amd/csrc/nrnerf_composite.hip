@@ -116,6 +116,36 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
         a.disp[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));      // ... which torch.max propagates (:781-784)
     }
 
+    // ---- surface reduction: index of the sample whose accumulated visibility is closest to 0.5 (first one on ties),
+    //      and the bent point / rigidity there (free_viewpoint_rendering.py:621-648 does this on the host from the
+    //      full per-sample tensors: ~15 KB/ray of D2H traffic instead of 20 B/ray)
+    if (a.bent4) {
+        float lsum = 0.f, cs[EPL];
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) { lsum += w[k]; cs[k] = lsum; }
+        const float base = wave_scan_add(lsum, lane) - lsum;
+        float best = 3.0e38f;
+        int bidx = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int i = lane * EPL + k;
+            const float dist = fabsf((base + cs[k]) - 0.5f);
+            if (i < S && dist < best) { best = dist; bidx = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        }
+        if (ray_ok && lane == 0) {
+            const f32x4 b = *(const f32x4*)(a.bent4 + ((size_t)ray * S + bidx) * 4);
+            if (a.surf_pts) { a.surf_pts[(size_t)ray * 3] = b[0]; a.surf_pts[(size_t)ray * 3 + 1] = b[1]; a.surf_pts[(size_t)ray * 3 + 2] = b[2]; }
+            if (a.surf_rig) a.surf_rig[ray] = b[3];
+            if (a.med_idx) a.med_idx[ray] = bidx;
+        }
+    }
+
     if constexpr (SAMPLE) {
         const int I = a.n_importance;
         const int nb = S - 1;          // bins = mid-points; cdf has nb entries (run_nerf_helpers.py:657-659)

@@ -34,6 +34,7 @@ struct NetArgs {
     float* raw4;             // [N,S,4] rgb + sigma workspace consumed by the composite kernel
     float* raw_out;          // [N,S,raw_ch] user-visible raw ("retraw") or nullptr
     int raw_ch;
+    float* bent4;            // [N,S,4] bent point xyz + rigidity mask per sample (surface reduction) or nullptr
     SampleOut ex;
     Knobs knobs;
 };
@@ -49,6 +50,11 @@ struct CompositeArgs {
     float* z_out;            // [N,S+I] merged sorted depths (workspace, required when I > 0)
     float* z_user;           // optional user copy of the depths of THIS pass ([N,S]) or nullptr
     float* vis; float* alpha;    // [N,S] optional
+    // surface reduction (free_viewpoint_rendering.py:621-658): sample whose accumulated visibility is closest to 0.5
+    const float* bent4;          // [N,S,4] from the network kernel, or nullptr: no reduction
+    float* surf_pts;             // [N,3] bent point at that sample
+    float* surf_rig;             // [N]   rigidity mask at that sample
+    int* med_idx;                // [N]   its index
 };
 
 struct RayGenArgs {

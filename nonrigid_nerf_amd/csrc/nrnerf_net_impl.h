@@ -565,6 +565,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         if (writer && a.ex.in_pts) {
             a.ex.in_pts[so * 3 + 0] = p[0]; a.ex.in_pts[so * 3 + 1] = p[1]; a.ex.in_pts[so * 3 + 2] = p[2];
         }
+        if (writer && a.bent4) *(f32x4*)(a.bent4 + so * 4) = f32x4{p[0], p[1], p[2], rig_mask};
 
         // ---- view direction of the sample (VIEWS): finite difference of the bent points along the ray, or the ray's own
         //      unit direction without a bender (run_nerf_helpers.py:288-290, 339-351; train.py:73-76)

@@ -45,12 +45,16 @@ def generate_rays(c2w, intrin: dict, near: float, far: float, use_viewdirs: bool
 
 
 def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_latents, gt_imgs=None, savedir=None,
-                render_factor=0, detailed_output=False, parallelized_render_function=None):
+                render_factor=0, detailed_output=False, parallelized_render_function=None, surface_outputs=False):
     """Signature and return value of reference ``render_path`` (train.py:419-431, 547-553).
 
     ``render_kwargs`` is the dict ``create_nerf`` builds (train.py:698-719) plus ``near`` / ``far``; the networks
     are read from it.  ``parallelized_render_function`` (the DataParallel wrapper) is accepted and ignored: for
     several GPUs use one process per GPU and ``nonrigid_nerf_amd.distributed``.
+
+    ``surface_outputs=True`` (extension) additionally returns, per frame, ``{"surface_pts" [H,W,3], "surface_rigidity"
+    [H,W], "median_index" [H,W]}`` -- the reduction free_viewpoint_rendering.py:621-658 computes from the detailed
+    outputs -- without moving the per-sample tensors to the host.
     """
     if savedir is not None:
         raise NotImplementedError("image writing is host-side I/O outside the accelerated path (train.py:506-545)")
@@ -78,7 +82,7 @@ def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_late
             rays = generate_rays(torch.as_tensor(c2w)[:3, :4], intrin, near, far, use_viewdirs, dev)
             code = torch.as_tensor(ray_bending_latents[i]).to(dev, torch.float32).reshape(1, -1)
             api = {"ray_bending_latents": code.expand(H * W, code.shape[-1])}          # stride-0 view, never materialised
-            out = R.batchify_rays(rays, api, chunk=chunk, detailed_output=detailed_output, **kw)
+            out = R.batchify_rays(rays, api, chunk=chunk, detailed_output=detailed_output, _surface=surface_outputs, **kw)
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(copy_stream):
@@ -88,10 +92,12 @@ def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_late
                 rgb_h.copy_(out["rgb_map"].view(H, W, 3), non_blocking=True)
                 disp_h.copy_(out["disp_map"].view(H, W), non_blocking=True)
                 details = None
-                if detailed_output:
+                if detailed_output or surface_outputs:
                     details = {}
                     for k, v in out.items():
                         if k in ("rgb_map", "disp_map", "acc_map"):
+                            continue
+                        if not detailed_output and k not in ("surface_pts", "surface_rigidity", "median_index"):
                             continue
                         hbuf = torch.empty((H, W) + tuple(v.shape[1:]), dtype=v.dtype, pin_memory=True)
                         hbuf.copy_(v.view((H, W) + tuple(v.shape[1:])), non_blocking=True)
@@ -106,9 +112,9 @@ def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_late
         ev.synchronize()
         rgbs.append(rgb_h.numpy())
         disps.append(disp_h.numpy())
-        if detailed_output:
+        if detailed_output or surface_outputs:
             all_details.append({k: v.numpy() for k, v in details.items()})
     rgbs, disps = np.stack(rgbs, 0), np.stack(disps, 0)
-    if detailed_output:
+    if detailed_output or surface_outputs:
         return rgbs, disps, all_details
     return rgbs, disps

@@ -201,7 +201,7 @@ class Model:
 
     def render(self, rays: torch.Tensor, latents: torch.Tensor | None, N_samples: int, N_importance: int = 0,
                retraw: bool = False, detailed_output: bool = False, rigidity_cutoff=None, test_time_scaling=None,
-               removal_threshold=None, want_z_vals: bool = False) -> dict:
+               removal_threshold=None, want_z_vals: bool = False, surface: bool = False) -> dict:
         """One ``render_rays`` worth of work on ``rays [N, 8|11]``; returns the reference's output dict."""
         N = int(rays.shape[0])
         S, I = int(N_samples), int(N_importance)
@@ -236,6 +236,11 @@ class Model:
             a.rgb0, a.disp0, a.acc0, a.z_std = new("rgb0", N, 3), new("disp0", N), new("acc0", N), new("z_std", N)
         if want_z_vals:
             a.z_vals = new("_z_vals", N, SF)
+        if surface:      # not reference keys: the reduction free_viewpoint_rendering.py:621-658 does on the host
+            a.surface_pts, a.surface_rigidity = new("surface_pts", N, 3), new("surface_rigidity", N)
+            idx = torch.empty(N, dtype=torch.int32, device=dev)
+            out["median_index"] = idx
+            a.median_index = idx.data_ptr()
         if detailed_output:
             def fill(so, prefix, ns):
                 so.visibility_weights = new(prefix + "visibility_weights", N, ns)
@@ -357,7 +362,7 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
         rigidity_cutoff=getattr(rb, "rigidity_test_time_cutoff", None) if rb is not None else None,
         test_time_scaling=getattr(rb, "test_time_scaling", None) if rb is not None else None,
         removal_threshold=getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None),
-        want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)))
+        want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)), surface=bool(dummy_kwargs.get("_surface", False)))
 
 
 def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, detailed_output=False, **kwargs):

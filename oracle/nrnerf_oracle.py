@@ -300,3 +300,14 @@ def render_path(render_poses, intrinsics, scene, ray_bending_latents, chunk=1024
         rgbs.append(out["rgb_map"].reshape(H, W, 3))
         disps.append(out["disp_map"].reshape(H, W))
     return torch.stack(rgbs, 0), torch.stack(disps, 0)
+
+
+def surface_from_details(visibility_weights, input_pts, rigidity_mask=None):
+    """The per-pixel reduction free_viewpoint_rendering.py:621-648 performs on the detailed outputs: the sample whose
+    accumulated visibility is closest to 0.5, the bent point there and the rigidity there."""
+    acc = torch.cumsum(visibility_weights, dim=-1)                                  # fvr:623-625
+    idx = torch.min(torch.abs(acc - 0.5), dim=-1)[1]                                # fvr:626-628
+    n = visibility_weights.shape[0]
+    pts = input_pts[torch.arange(n), idx, :]                                        # fvr:631-637
+    rig = rigidity_mask.reshape(n, -1)[torch.arange(n), idx] if rigidity_mask is not None else None   # fvr:648-654
+    return idx, pts, rig

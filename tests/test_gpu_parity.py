@@ -392,3 +392,38 @@ def test_render_path_driver_vs_oracle():
     assert (both_nan | ((d - rd_).abs() <= 1e-4 + 1e-3 * rd_.abs())).all()
     half_rgb, half_disp = render_path([p.to(DEV) for p in poses], intrins, 1024 * 32, kw, codes.to(DEV), render_factor=2)
     assert half_rgb.shape == (3, 12, 16, 3) and half_disp.shape == (3, 12, 16)       # train.py:434-446
+
+
+def test_surface_reduction_matches_host_side_reduction():
+    """free_viewpoint_rendering.py:621-658 picks, per pixel, the sample whose accumulated visibility is closest to 0.5
+    and reads the bent point and rigidity there.  The in-kernel reduction must agree with doing exactly that on the
+    detailed outputs of the same render (bit-identical weights), and with the oracle up to near-ties."""
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(2048, 17, cfg)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    R.set_precision("f32")
+    model = R.get_model(coarse, fine)
+    with torch.no_grad():
+        out = model.render(rays.to(DEV), latents.to(DEV), 64, 128, detailed_output=True, surface=True)
+    torch.cuda.synchronize()
+    out = {k: v.cpu() for k, v in out.items()}
+    idx, pts, rig = O.surface_from_details(out["fine_visibility_weights"], out["fine_input_pts"], out["fine_rigidity_mask"])
+    same = out["median_index"].long() == idx
+    assert same.float().mean() > 0.995            # cumsum order differs (scan vs sequential): only exact near-ties may move
+    acc = torch.cumsum(out["fine_visibility_weights"], -1)
+    d_ours = (acc[torch.arange(2048), out["median_index"].long()] - 0.5).abs()
+    d_ref = (acc[torch.arange(2048), idx] - 0.5).abs()
+    assert torch.allclose(d_ours, d_ref, atol=1e-6)
+    assert torch.equal(out["surface_pts"][same], pts[same]) and torch.equal(out["surface_rigidity"][same], rig[same])
+    assert torch.equal(out["surface_pts"], out["fine_input_pts"][torch.arange(2048), out["median_index"].long()])
+    # coarse-only render: reduction over the coarse pass
+    cfg0 = SceneConfig(N_importance=0)
+    scene0 = make_scene(cfg0, 0)
+    rb0, c0, _ = build_modules(scene0, device=DEV)
+    m0 = R.get_model(c0, None)
+    with torch.no_grad():
+        o0 = m0.render(rays[:100].to(DEV), latents[:100].to(DEV), 64, 0, surface=True)
+    ref0 = O.render_rays(rays[:100], latents[:100], scene0, retraw=True)
+    w0 = O.composite(ref0["raw"], ref0["_z_vals"], rays[:100, 3:6])[4]
+    assert (o0["median_index"].cpu().long() == O.surface_from_details(w0, torch.zeros(100, 64, 3))[0]).float().mean() > 0.97
