@@ -120,16 +120,23 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
     //      and the bent point / rigidity there (free_viewpoint_rendering.py:621-648 does this on the host from the
     //      full per-sample tensors: ~15 KB/ray of D2H traffic instead of 20 B/ray)
     if (a.bent4) {
-        float lsum = 0.f, cs[EPL];
+        // cumsum in strictly sequential order (carry handed from lane to lane): zero-weight plateaus then give
+        // bit-identical prefixes, hence exact ties that resolve to the first index, as with torch.cumsum on the host
+        float carry = 0.f, base = 0.f;
+        for (int l = 0; l < 64; ++l) {
+            float e = carry;
 #pragma unroll
-        for (int k = 0; k < EPL; ++k) { lsum += w[k]; cs[k] = lsum; }
-        const float base = wave_scan_add(lsum, lane) - lsum;
-        float best = 3.0e38f;
+            for (int k = 0; k < EPL; ++k) e = __fadd_rn(e, w[k]);
+            if (lane == l) base = carry;
+            carry = __shfl(e, l);
+        }
+        float best = 3.0e38f, run_c = base;
         int bidx = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
             const int i = lane * EPL + k;
-            const float dist = fabsf((base + cs[k]) - 0.5f);
+            run_c = __fadd_rn(run_c, w[k]);
+            const float dist = fabsf(__fsub_rn(run_c, 0.5f));
             if (i < S && dist < best) { best = dist; bidx = i; }
         }
 #pragma unroll

@@ -410,7 +410,7 @@ def test_surface_reduction_matches_host_side_reduction():
     out = {k: v.cpu() for k, v in out.items()}
     idx, pts, rig = O.surface_from_details(out["fine_visibility_weights"], out["fine_input_pts"], out["fine_rigidity_mask"])
     same = out["median_index"].long() == idx
-    assert same.float().mean() > 0.995            # cumsum order differs (scan vs sequential): only exact near-ties may move
+    assert same.float().mean() > 0.999            # same sequential cumsum: plateaus of zero weight tie exactly, first index wins
     acc = torch.cumsum(out["fine_visibility_weights"], -1)
     d_ours = (acc[torch.arange(2048), out["median_index"].long()] - 0.5).abs()
     d_ref = (acc[torch.arange(2048), idx] - 0.5).abs()
