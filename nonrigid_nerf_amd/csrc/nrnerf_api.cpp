@@ -125,12 +125,14 @@ template <class A>
 int check_arch_t(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
     if (d.precision < 0 || d.precision > 2) return NRNERF_ERR_INVALID;
     if (d.multires != A::L) return NRNERF_ERR_UNSUPPORTED;
-    if (m.time_conditioned) return NRNERF_ERR_UNSUPPORTED;
+    if ((m.time_conditioned != 0) != (A::TCB != 0)) return NRNERF_ERR_UNSUPPORTED;
+    if (A::TCB && d.bender) return NRNERF_ERR_UNSUPPORTED;      // the reference forbids the combination (train.py:574-576)
     if (m.use_viewdirs && d.multires_views != A::LV) return NRNERF_ERR_UNSUPPORTED;
     if (m.depth != A::D || m.width != A::W || m.skip != A::SKIP) return NRNERF_ERR_UNSUPPORTED;
     if (m.output_ch != 4 && m.output_ch != 5) return NRNERF_ERR_UNSUPPORTED;
     if (!m.pts_linears) return NRNERF_ERR_INVALID;
-    const int enc = 3 + 6 * A::L;
+    const int enc = 3 + 6 * A::L + (A::TCB ? A::LAT : 0);
+    if (A::TCB && m.pts_linears[0].in_features != enc) return NRNERF_ERR_UNSUPPORTED;     // other latent size
     for (int i = 0; i < A::D; ++i) {
         const int in_f = (i == 0) ? enc : ((i - 1 == A::SKIP) ? A::W + enc : A::W);
         if (!linear_is(m.pts_linears[i], A::W, in_f, true)) return NRNERF_ERR_INVALID;
@@ -182,6 +184,15 @@ int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPa
         if (arch_id) *arch_id = 0;
         return NRNERF_OK;
     }
+    if (rc == NRNERF_ERR_UNSUPPORTED && !d.bender && m.time_conditioned) {
+        const int rc2 = check_arch_t<ArchTimeCond>(d, m);
+        if (rc2 == NRNERF_OK) {
+            pack_arch<ArchTimeCond>(d, m, out);
+            if (arch_id) *arch_id = 2;
+            return NRNERF_OK;
+        }
+        return rc2;
+    }
     if (rc == NRNERF_ERR_UNSUPPORTED && d.bender) {     // arch 1 is a bender variant: only compiled with a bender
         const int rc1 = check_arch_t<ArchDeepBend>(d, m);
         if (rc1 == NRNERF_OK) {
@@ -225,7 +236,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 struct nrnerf_model {
-    int device = 0, precision = 0, has_bend = 0, views = 0, arch_id = 0, num_cus = 0, latent_size = 0;
+    int device = 0, precision = 0, has_bend = 0, views = 0, arch_id = 0, needs_latents = 0, num_cus = 0, latent_size = 0;
     PassDev coarse, fine;
     bool fine_is_coarse = false;
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
@@ -316,6 +327,7 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     m->has_bend = desc->bender != nullptr;
     m->views = desc->coarse->use_viewdirs != 0;
     m->arch_id = arch_id;
+    m->needs_latents = m->has_bend || desc->coarse->time_conditioned;
     m->latent_size = desc->bender ? desc->bender->latent_size : 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, desc->device) != hipSuccess) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_HIP; }
@@ -368,7 +380,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     if (a->n_samples > 256 || a->n_samples + a->n_importance > 256) return NRNERF_ERR_UNSUPPORTED;
     if (a->n_rays == 0) return NRNERF_OK;
     if (!a->rays || a->ray_stride < 8 || !a->rgb_map || !a->disp_map || !a->acc_map) return NRNERF_ERR_INVALID;
-    if (m->has_bend && (!a->latents || a->latent_stride < 0)) return NRNERF_ERR_INVALID;
+    if (m->needs_latents && (!a->latents || a->latent_stride < 0)) return NRNERF_ERR_INVALID;
     if (m->views && !m->has_bend && a->ray_stride < 11) return NRNERF_ERR_INVALID;   // needs the unit view directions
     const size_t need = nrnerf_workspace_bytes(m, a->n_rays, a->n_samples, a->n_importance);
     if (!a->workspace || a->workspace_bytes < need || ((uintptr_t)a->workspace & 255)) return NRNERF_ERR_WORKSPACE;

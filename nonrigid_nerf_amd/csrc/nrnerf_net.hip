@@ -7,19 +7,22 @@ typedef hipError_t (*launch_fn)(const NetArgs&, int, hipStream_t);
 #define NRN_DECL(n) hipError_t launch_net_##n(const NetArgs&, int, hipStream_t);
 #define NRN_ARCH0(p) NRN_DECL(a0_##p##_bend) NRN_DECL(a0_##p##_nobend) NRN_DECL(a0_##p##_bend_views) NRN_DECL(a0_##p##_nobend_views)
 #define NRN_ARCH1(p) NRN_DECL(a1_##p##_bend) NRN_DECL(a1_##p##_bend_views)
-NRN_ARCH0(f32) NRN_ARCH0(bf16) NRN_ARCH0(f16) NRN_ARCH1(f32) NRN_ARCH1(bf16) NRN_ARCH1(f16)
+#define NRN_ARCH2(p) NRN_DECL(a2_##p##_nobend) NRN_DECL(a2_##p##_nobend_views)
+NRN_ARCH0(f32) NRN_ARCH0(bf16) NRN_ARCH0(f16) NRN_ARCH1(f32) NRN_ARCH1(bf16) NRN_ARCH1(f16) NRN_ARCH2(f32) NRN_ARCH2(bf16) NRN_ARCH2(f16)
 #undef NRN_DECL
 
-// [arch][precision][has_bend][views]; nullptr = not compiled (arch 1 exists only with a bender: it IS a bender variant)
+// [arch][precision][has_bend][views]; nullptr = not compiled (arch 1 is a bender variant, arch 2 excludes a bender)
 #define NRN_ROW0(p) {{launch_net_a0_##p##_nobend, launch_net_a0_##p##_nobend_views}, {launch_net_a0_##p##_bend, launch_net_a0_##p##_bend_views}}
 #define NRN_ROW1(p) {{nullptr, nullptr}, {launch_net_a1_##p##_bend, launch_net_a1_##p##_bend_views}}
-static const launch_fn TABLE[2][3][2][2] = {
+#define NRN_ROW2(p) {{launch_net_a2_##p##_nobend, launch_net_a2_##p##_nobend_views}, {nullptr, nullptr}}
+static const launch_fn TABLE[3][3][2][2] = {
     {NRN_ROW0(f32), NRN_ROW0(bf16), NRN_ROW0(f16)},
     {NRN_ROW1(f32), NRN_ROW1(bf16), NRN_ROW1(f16)},
+    {NRN_ROW2(f32), NRN_ROW2(bf16), NRN_ROW2(f16)},
 };
 
 hipError_t launch_net(int precision, bool has_bend, bool views, int arch_id, const NetArgs& a, int num_cus, hipStream_t stream) {
-    if (arch_id < 0 || arch_id > 1 || precision < 0 || precision > 2) return hipErrorInvalidValue;
+    if (arch_id < 0 || arch_id > 2 || precision < 0 || precision > 2) return hipErrorInvalidValue;
     const launch_fn f = TABLE[arch_id][precision][has_bend ? 1 : 0][views ? 1 : 0];
     return f ? f(a, num_cus, stream) : hipErrorInvalidValue;
 }

@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 
         // ---- positional encoding of the (bent) point, directly in B-operand order
         constexpr int F0 = enc_F0(A::L);
-        constexpr int NSLOT = NS_ENC * KH;
+        constexpr int NSLOT = PL::NS_ENC_XYZ * KH;
         float ev[NSLOT];
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) ev[q] = 0.0f;
@@ -649,13 +649,26 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             });
         });
         efrag enc[NS_ENC];
-        static_for<0, NS_ENC>([&](auto sc_) {
+        static_for<0, PL::NS_ENC_XYZ>([&](auto sc_) {
             constexpr int s = decltype(sc_)::value;
             static_for<0, KH>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
                 PE::template set<e>(enc[s], ev[s * KH + e]);
             });
         });
+        if constexpr (A::TCB) {      // time-conditioned baseline: the ray's latent code follows the encoding (rnh:273-274)
+            const float* lat = a.latents + (size_t)ray * a.lat_stride;
+            static_for<PL::NS_ENC_XYZ, NS_ENC>([&](auto sc_) {
+                constexpr int s = decltype(sc_)::value;
+                static_for<0, KH>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    constexpr int i0 = (2 * (s - PL::NS_ENC_XYZ)) * KH + e, i1 = i0 + KH;
+                    const float v0 = (i0 < A::LAT) ? lat[i0 < A::LAT ? i0 : 0] : 0.0f;
+                    const float v1 = (i1 < A::LAT) ? lat[i1 < A::LAT ? i1 : 0] : 0.0f;
+                    PE::template set<e>(enc[s], h ? v1 : v0);
+                });
+            });
+        }
 
         // ---- trunk (run_nerf_helpers.py:272-282) and head (:306)
         constexpr int NH = NT_W * SP;

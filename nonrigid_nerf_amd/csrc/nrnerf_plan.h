@@ -59,9 +59,12 @@ struct Shape {
     static constexpr int UNIT_FRAGS = UNIT_BYTES / FRAG_BYTES;    // 16 (16-bit) / 64 (f32) fragments per unit
 };
 
-template <int W_, int D_, int SKIP_, int L_, int BW_, int BD_, int RW_, int RD_, int LAT_, int LV_ = 4>
+template <int W_, int D_, int SKIP_, int L_, int BW_, int BD_, int RW_, int RD_, int LAT_, int LV_ = 4, int TCB_ = 0>
 struct ArchT {
     static constexpr int W = W_, D = D_, SKIP = SKIP_, L = L_, LV = LV_;     // LV: frequencies of the direction encoding
+    // TCB: "time-conditioned baseline" (run_nerf_helpers.py:207-209, 273-282): no bender, the latent code is appended
+    // to the network input and again at the skip connection
+    static constexpr int TCB = TCB_;
     static constexpr int BW = BW_, BD = BD_, RW = RW_, RD = RD_, LAT = LAT_;
     static_assert(W_ % 32 == 0 && BW_ % 32 == 0 && RW_ % 32 == 0, "widths must be multiples of 32");
     static_assert(LAT_ % 8 == 0, "latent size must be a multiple of 8");
@@ -85,6 +88,11 @@ constexpr NRN_HD int enc_col(int L, int h, int q) {
     if (fl >= enc_F0(L) || f >= L) return -1;
     return 3 + 6 * f + 3 * fn + c;
 }
+// Slabs of the trunk's input: the xyz encoding, plus (TCB) the latent code as extra slabs, element (s,h,e) of the
+// latent part = latent[(2s+h)*KH + e].
+template <class SH, class A> constexpr NRN_HD int ns_enc_xyz() { return cdiv(enc_slots(A::L), SH::KH); }
+template <class SH, class A> constexpr NRN_HD int ns_trunk_in() { return ns_enc_xyz<SH, A>() + (A::TCB ? cdiv(A::LAT, 2 * SH::KH) : 0); }
+
 // Bender input [xyz, latent] (run_nerf_helpers.py:525): logical vector
 //   v[0..2] = xyz, v[3..7] = 0 (keeps the latent 8-aligned), v[8 .. 8+LAT) = latent.
 // Lane half h, slab s, element e holds v[(2s+h)*KH + e].
@@ -150,7 +158,7 @@ struct Tables {
 template <class SH, class A, bool HAS_BEND, bool VIEWS = false>
 constexpr Tables build_tables() {
     constexpr int KH = SH::KH, SP = SH::SP;
-    constexpr int NS_ENC = cdiv(enc_slots(A::L), KH);
+    constexpr int NS_ENC = ns_trunk_in<SH, A>();
     constexpr int NS_ENCV = cdiv(enc_slots(A::LV), KH);
     constexpr int NS_BIN = cdiv(bin_len(A::LAT), 2 * KH);
     constexpr int NS_RIN = cdiv(rin_len(), 2 * KH);
@@ -211,7 +219,8 @@ constexpr Tables build_tables() {
 template <class SH, class A, bool HAS_BEND, bool VIEWS = false>
 struct Plan {
     static constexpr int KH = SH::KH, SP = SH::SP;
-    static constexpr int NS_ENC = cdiv(enc_slots(A::L), KH);
+    static constexpr int NS_ENC = ns_trunk_in<SH, A>();          // xyz encoding slabs (+ latent slabs when A::TCB)
+    static constexpr int NS_ENC_XYZ = ns_enc_xyz<SH, A>();
     static constexpr int NS_ENCV = cdiv(enc_slots(A::LV), KH);
     static constexpr int NS_BIN = cdiv(bin_len(A::LAT), 2 * KH);
     static constexpr int NS_RIN = cdiv(rin_len(), 2 * KH);
@@ -242,13 +251,18 @@ struct Plan {
 template <class SH, class A>
 constexpr NRN_HD int in_col(int kind, int s, int h, int e, int in_features) {
     constexpr int KH = SH::KH, SP = SH::SP;
-    constexpr int NS_ENC = cdiv(enc_slots(A::L), KH);
+    constexpr int NS_ENC = ns_trunk_in<SH, A>(), NS_XYZ = ns_enc_xyz<SH, A>();
+    constexpr int IN_CH = 3 + 6 * A::L + (A::TCB ? A::LAT : 0);       // width of the trunk's input vector
     auto hidden = [&](int s2, int base) {
         int tp = s2 / SP, u = s2 % SP, r = u * KH + e;
         int col = 32 * tp + tile_row(r, h);
         return (base + col < in_features) ? base + col : -1;
     };
     auto enc = [&](int s2) {
+        if (s2 >= NS_XYZ) {                      // TCB latent slabs: reference column = 63 + latent index
+            int li = (2 * (s2 - NS_XYZ) + h) * KH + e;
+            return (li < A::LAT) ? 3 + 6 * A::L + li : -1;
+        }
         int q = s2 * KH + e;
         return (q < enc_slots(A::L)) ? enc_col(A::L, h, q) : -1;
     };
@@ -257,7 +271,7 @@ constexpr NRN_HD int in_col(int kind, int s, int h, int e, int in_features) {
         case LK_BEND_IN: return bin_col((2 * s + h) * KH + e, A::LAT);
         case LK_RIG_IN:  return rin_col((2 * s + h) * KH + e);
         case LK_TR_IN:   return enc(s);
-        case LK_TR_SKIP: return (s < NS_ENC) ? enc(s) : hidden(s - NS_ENC, 3 + 6 * A::L);
+        case LK_TR_SKIP: return (s < NS_ENC) ? enc(s) : hidden(s - NS_ENC, IN_CH);
         case LK_VIEWS: {     // reference column order is [feature W, direction encoding]; our slab order is the reverse
             if (s >= NS_ENCV) return hidden(s - NS_ENCV, 0);
             int q = s * KH + e;
@@ -271,7 +285,7 @@ constexpr NRN_HD int in_col(int kind, int s, int h, int e, int in_features) {
 // is bounded by construction (coordinates, latent codes, sin/cos) or feeds the encoding (the bender).
 template <class SH, class A>
 constexpr NRN_HD bool frag_is_f16(int kind, int s) {
-    constexpr int NS_ENC = cdiv(enc_slots(A::L), SH::KH);
+    constexpr int NS_ENC = ns_trunk_in<SH, A>();
     constexpr int NS_ENCV = cdiv(enc_slots(A::LV), SH::KH);
     if (kind <= LK_RIG_OUT || kind == LK_TR_IN) return true;
     if (kind == LK_TR_SKIP) return s < NS_ENC;
@@ -292,9 +306,11 @@ constexpr NRN_HD int out_row(int kind, int t, int i, int out_features) {
 
 using ArchDefault = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32>;      // arch id 0: the reference's shipped configuration
 using ArchDeepBend = ArchT<256, 8, 4, 10, 64, 7, 32, 3, 32>;     // arch id 1: deeper ray-bending MLP (BASELINE config 4)
-constexpr int NUM_ARCHS = 2;
+using ArchTimeCond = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32, 4, 1>;  // arch id 2: time-conditioned baseline (no bender)
+constexpr int NUM_ARCHS = 3;
 template <int ID> struct ArchById { using type = ArchDefault; };
 template <> struct ArchById<1> { using type = ArchDeepBend; };
+template <> struct ArchById<2> { using type = ArchTimeCond; };
 using ShapeF32 = Shape<1>;
 using Shape16 = Shape<8>;
 

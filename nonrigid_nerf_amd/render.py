@@ -169,6 +169,7 @@ class Model:
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
         self.has_bender = bool(desc.bender)
+        self.needs_latents = self.has_bender or bool(desc.coarse.contents.time_conditioned)
         self.latent_size = desc.bender.contents.latent_size if self.has_bender else 0
         self.output_ch = desc.fine.contents.output_ch if desc.fine else desc.coarse.contents.output_ch
         self.coarse_output_ch = desc.coarse.contents.output_ch
@@ -213,9 +214,9 @@ class Model:
         a.struct_size = C.sizeof(_lib.RenderArgs)
         a.n_rays, a.n_samples, a.n_importance = N, S, I
         a.rays, a.ray_stride = rays.data_ptr(), rays.shape[1]
-        if self.has_bender:
+        if self.needs_latents:
             if latents is None:
-                raise ValueError("ray_bending_latents are required when a ray bender is present")
+                raise ValueError("ray_bending_latents are required (ray bender or time-conditioned baseline)")
             if latents.dim() == 2 and latents.shape[0] == N and latents.stride(0) == 0 and latents.stride(1) == 1 \
                     and latents.dtype == torch.float32 and latents.device == dev:
                 a.latents, a.latent_stride = latents.data_ptr(), 0          # frame code expanded per ray (train.py:465)
@@ -316,8 +317,6 @@ def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importanc
             return "exact non-rigid view directions (autograd Jacobian, run_nerf_helpers.py:358-385)"
         if not has_bender and ray_batch.shape[-1] < 11:
             return "use_viewdirs without view directions in the ray batch"
-    if getattr(network_fn, "time_conditioned_baseline", False):
-        return "time_conditioned_baseline"
     if N_samples < 2 or N_samples + N_importance > 256:
         return "more than 256 samples per ray"
     a = getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None)

@@ -102,6 +102,7 @@ CASES = {
                          dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5, removal_threshold=0.6)),
     "viewdirs_64_64":   (dict(N_importance=64, use_viewdirs=True), 48, 32768, False, True, {}),
     "no_bender_64_64":  (dict(N_importance=64, ray_bending=False), 48, 32768, False, False, {}),
+    "time_conditioned_64_64": (dict(N_importance=64, ray_bending=False, time_conditioned_baseline=True), 48, 32768, False, True, {}),
     "config4_deep_bender_viewdirs": (dict(N_importance=64, use_viewdirs=True, bend_depth=7), 40, 32768, True, True, {}),
 }
 

@@ -75,7 +75,8 @@ COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "
 
 
 @pytest.mark.parametrize("name", ["coarse_only_1k", "headline_64_128", "detailed_64_128", "ragged_chunks",
-                                  "knobs_64_64", "no_bender_64_64", "viewdirs_64_64", "config4_deep_bender_viewdirs"])
+                                  "knobs_64_64", "no_bender_64_64", "viewdirs_64_64", "config4_deep_bender_viewdirs",
+                                  "time_conditioned_64_64"])
 def test_fp32_mode_matches_reference_golden(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
     got = hip_render(scene, rays, latents, "f32", chunk=meta["chunk"], retraw=bool(meta["retraw"]),

@@ -177,9 +177,10 @@ def rounder(precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("bend,views", [(True, False), (False, False), (True, True), (False, True)])
-def test_packed_stream_reproduces_the_network(precision, bend, views):
-    cfg = SceneConfig(N_importance=128, ray_bending=bend, use_viewdirs=views)
+@pytest.mark.parametrize("bend,views,tcb", [(True, False, False), (False, False, False), (True, True, False),
+                                            (False, True, False), (False, False, True)])
+def test_packed_stream_reproduces_the_network(precision, bend, views, tcb):
+    cfg = SceneConfig(N_importance=128, ray_bending=bend, use_viewdirs=views, time_conditioned_baseline=tcb)
     scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=1)
     KH = 1 if precision == "f32" else 8
     SP = 16 // KH
@@ -236,6 +237,8 @@ def test_packed_stream_reproduces_the_network(precision, bend, views):
         assert np.abs(logit - r.numpy()[:, 0]).max() <= tol * max(float(r.abs().max()), 1.0), "rigidity logit"
     # ---- trunk
     slabs_enc = enc_slabs(p, 10, KH, rnd_e)
+    if tcb:        # time-conditioned baseline: latent slabs follow the encoding (element (s,h,e) = latent[(2s+h)*KH+e])
+        slabs_enc = slabs_enc + vec_slabs(lat.T, KH, rnd_e)
     tiles = dense_emul(fr, bias, tile0, len(slabs_enc), 8, slabs_enc, f16_slabs=-1); mfma += len(slabs_enc) * 8; tile0 += 8
     for i in range(1, 8):
         slabs = repack(tiles, KH, True, rnd)
@@ -271,7 +274,7 @@ def test_packed_stream_reproduces_the_network(precision, bend, views):
         cols = [pt]
         for k in range(10):
             cols += [torch.sin(pt * 2.0 ** k), torch.cos(pt * 2.0 ** k)]
-        x = torch.cat(cols, -1)
+        x = torch.cat(cols + ([torch.from_numpy(lat)] if tcb else []), -1)
         h = x
         for i, l in enumerate(fine.pts_linears):
             h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
