@@ -33,6 +33,17 @@
 
 namespace nrn {
 
+// Opt-in phase timing (make TUNE=-DNRN_TIMING SUFFIX=_timing; tools/timing_probe.py): the waves of workgroup 0
+// accumulate s_memtime deltas per phase and around every ring barrier.  Costs ~10 % and is never in the shipped build.
+#ifdef NRN_TIMING
+static __device__ unsigned long long g_nrn_timing[8][8];
+#define NRN_NOW() __builtin_amdgcn_s_memtime()
+#define NRN_TACC(slot, t0) tacc[slot] += NRN_NOW() - (t0)
+#else
+#define NRN_NOW() 0ull
+#define NRN_TACC(slot, t0) ((void)0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -157,6 +168,9 @@ struct WRing {
     char* ring;            // LDS ring base
     int wave_off;          // this wave's piece offset inside a unit (wave-uniform)
     int lane_off;          // lane * (FRAG_BYTES / 64)
+#ifdef NRN_TIMING
+    unsigned long long bar_cycles = 0, bar_count = 0;
+#endif
 
     __device__ __forceinline__ void init(const void* stream, char* lds, int wave, int lane) {
         wave_off = wave * PW * 1024;
@@ -183,9 +197,15 @@ struct WRing {
     }
     template <int U>
     __device__ __forceinline__ void advance() {
+#ifdef NRN_TIMING
+        const unsigned long long tb0 = NRN_NOW();
+#endif
         wait_ring<(RING - LAG - 1) * PW>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef NRN_TIMING
+        bar_cycles += NRN_NOW() - tb0; ++bar_count;
+#endif
         issue<(U + RING - LAG) % NUP>();
     }
     // fragment GF (index in the whole stream) for this lane; advances the ring when GF opens a new unit
@@ -436,8 +456,12 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         tile_stride = (long long)gridDim.x * WAVES;
     }
 
+#ifdef NRN_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     int iter = 0;
     for (long long tile0 = blk_begin; tile0 < blk_end; tile0 += tile_stride, ++iter) {
+        const unsigned long long t_pass = NRN_NOW();
         const long long blk = tile0 + wave;
         const bool blk_ok = blk < blk_end;
         const long long b = blk_ok ? blk : blk_end - 1;
@@ -465,6 +489,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             a.ex.init_pts[so * 3 + 0] = p[0]; a.ex.init_pts[so * 3 + 1] = p[1]; a.ex.init_pts[so * 3 + 2] = p[2];
         }
 
+        NRN_TACC(1, t_pass);
+        const unsigned long long t_bend = NRN_NOW();
         float rig_mask = 0.0f;
         if constexpr (HAS_BEND) {
             constexpr int NS_BIN = PL::NS_BIN, NS_RIN = PL::NS_RIN;
@@ -562,6 +588,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 #pragma unroll
             for (int c = 0; c < 3; ++c) p[c] = __fadd_rn(p[c], mo[c]);                // rnh:570
         }
+        NRN_TACC(2, t_bend);
+        const unsigned long long t_mid = NRN_NOW();
         if (writer && a.ex.in_pts) {
             a.ex.in_pts[so * 3 + 0] = p[0]; a.ex.in_pts[so * 3 + 1] = p[1]; a.ex.in_pts[so * 3 + 2] = p[2];
         }
@@ -670,6 +698,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             });
         }
 
+        NRN_TACC(3, t_mid);
+        const unsigned long long t_trunk = NRN_NOW();
         // ---- trunk (run_nerf_helpers.py:272-282) and head (:306)
         constexpr int NH = NT_W * SP;
         frag ha[NH], hb[NH];
@@ -721,6 +751,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             if constexpr (LAST_IN_B) head(hb, ha); else head(ha, hb);
         }
 
+        NRN_TACC(4, t_trunk);
+        const unsigned long long t_out = NRN_NOW();
         if (HAS_BEND && a.knobs.detailed && a.knobs.has_removal && rig_mask >= a.knobs.removal)
             raw[3] = raw[3] * 0.0f;                                                  // rnh:308-311
         if (writer) {
@@ -733,8 +765,19 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         }
         // padding units (keep the ring phase identical every pass and prime the next pass' first units)
         static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+        NRN_TACC(5, t_out);
+        NRN_TACC(0, t_pass);
+#ifdef NRN_TIMING
+        tacc[7] += 1;
+#endif
     }
     st.drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released
+#ifdef NRN_TIMING
+    if (blockIdx.x == 0 && lane == 0 && wave < 8) {
+        tacc[6] = st.bar_cycles;
+        for (int i = 0; i < 8; ++i) g_nrn_timing[wave][i] += tacc[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

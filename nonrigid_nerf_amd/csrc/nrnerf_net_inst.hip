@@ -8,3 +8,14 @@ hipError_t NRN_NAME(const NetArgs& a, int num_cus, hipStream_t stream) {
     return launch_one<NRN_POL, ArchById<NRN_ARCH>::type, (NRN_BEND != 0), (NRN_VIEWS != 0), NRN_WAVES>(a, num_cus, stream);
 }
 }  // namespace nrn
+
+#ifdef NRN_TIMING
+#define NRN_CAT2(a, b) a##b
+#define NRN_CAT(a, b) NRN_CAT2(a, b)
+// reads and clears the per-phase cycle counters of this variant: out[8 waves][8 slots]
+extern "C" int NRN_CAT(nrnerf_debug_timing_, NRN_NAME)(unsigned long long* out) {
+    static const unsigned long long zero[64] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nrn::g_nrn_timing), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(nrn::g_nrn_timing), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

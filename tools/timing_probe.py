@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of net_kernel (bf16, bender, no views) from the NRN_TIMING build.
+
+    make -C nonrigid_nerf_amd/csrc -j8 TUNE=-DNRN_TIMING SUFFIX=_timing
+    NRNERF_LIB=$PWD/nonrigid_nerf_amd/lib/libnrnerf_hip_timing.so python tools/timing_probe.py
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nonrigid_nerf_amd import _lib, render as R
+from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
+
+cfg = SceneConfig()
+scene = make_scene(cfg, 0)
+rb, coarse, fine = build_modules(scene, device="cuda:0")
+R.set_precision("bf16")
+rays, lat = make_rays(196608, 1, cfg)
+rays, lat = rays.cuda(), lat.cuda()
+model = R.get_model(coarse, fine)
+lib = _lib.load()
+fn = lib.nrnerf_debug_timing_launch_net_a0_bf16_bend
+fn.argtypes, fn.restype = [C.POINTER(C.c_ulonglong)], C.c_int
+buf = (C.c_ulonglong * 64)()
+names = ["total", "front(z,pts)", "bender+rigidity", "mask,dirs,encoding", "trunk+head", "stores+pad", "ring wait+barrier", "passes"]
+with torch.no_grad():
+    model.render(rays, lat, 64, 128); torch.cuda.synchronize(); fn(buf)          # warm-up, clear
+    for label, I in (("coarse-only launch (64 samples)", 0), ("64 + 128 (coarse + fine launches)", 128)):
+        model.render(rays, lat, 64, I); torch.cuda.synchronize(); fn(buf)
+        print(f"== {label}: cycles per 32-sample block pass, workgroup 0")
+        for w in range(8):
+            row = [buf[w * 8 + i] for i in range(8)]
+            n = max(row[7], 1)
+            print(f"  wave {w}: " + "  ".join(f"{names[i]} {row[i] / n:9.0f}" for i in range(7)) + f"  passes {row[7]}")
