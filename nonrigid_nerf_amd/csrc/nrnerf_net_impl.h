@@ -243,6 +243,22 @@ struct SeqPos {
     static constexpr bool last_of_tile(int q) { return slab(q) == NS - 1; }
 };
 
+// Priority toggling (branch-free wave balancing).  The two waves sharing a SIMD run the same code; the older one wins
+// every arbitration, finishes its unit early and then idles at the ring barrier while its partner runs alone (phase
+// timing: waves 0-3 waited 31 % of the time, waves 4-7 9 %).  Each wave therefore raises its priority for NRN_PRIO_HALF
+// MFMAs and lowers it for the next NRN_PRIO_HALF: whichever wave is ahead soon sits in a low-priority stretch while
+// the laggard is in a high-priority one, so the pair advances in lock-step.  0 disables.
+#ifndef NRN_PRIO_HALF
+#define NRN_PRIO_HALF 0
+#endif
+template <int Q>
+__device__ __forceinline__ void prio_tick() {
+    if constexpr (NRN_PRIO_HALF > 0) {
+        if constexpr (Q % (2 * NRN_PRIO_HALF) == 0) __builtin_amdgcn_s_setprio(1);
+        else if constexpr (Q % (2 * NRN_PRIO_HALF) == NRN_PRIO_HALF) __builtin_amdgcn_s_setprio(0);
+    }
+}
+
 #ifndef NRN_NACC
 #define NRN_NACC 2      // accumulator sets per wave (4: the previous pair's epilogue overlaps the next pair's MFMAs, but the
                         // 32 extra registers spill inside the trunk at 256 VGPRs)
@@ -277,6 +293,7 @@ __device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, cons
     static_for<0, Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int t = SQ::tile(q), s = SQ::slab(q);
+        prio_tick<q>();
         const typename P1::frag cur = a[q % PF];
         if constexpr (q + PF < Q) load(std::integral_constant<int, q + PF>{});
         if constexpr (s < NS0) accs[t % NACC] = P0::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[s], accs[t % NACC]);
