@@ -83,7 +83,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                 // split layers: fragment pair (hi, lo) with lo = f16((w - f16(w)) * 2^11); others: one fragment
                 for (int part = 0; part <= sp.split; ++part) {
                     const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride + part;
-                    if (fi >= (size_t)T.nunits_padded * SH::UNIT_FRAGS) std::abort();     // plan/packer drift
+                    if (fi >= (size_t)T.nfrags) std::abort();                       // plan/packer drift
                     uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
                     const bool as_f16 = (precision == NRNERF_PREC_F16) || frag_is_f16<SH, A>(sp.kind, s);
                     for (int lane = 0; lane < 64; ++lane) {

@@ -153,7 +153,7 @@ __device__ __forceinline__ void wait_ring() {
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class P, int WAVES, int NUP, int PAD>
+template <class P, int WAVES, int NUP>
 struct WRing {
     static constexpr int UNIT = P::UNIT_BYTES;
     // (Tried and rejected on MI355X: letting only 2 or 4 "loader" waves issue the DMA so their SIMD partners keep the
@@ -182,7 +182,6 @@ struct WRing {
     }
     template <int V>
     __device__ __forceinline__ void issue() {
-        if constexpr (V < PAD) return;          // leading padding units carry no data
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             // The offset is a compile-time constant, but hiding it from the optimiser stops LICM from hoisting
@@ -201,10 +200,7 @@ struct WRing {
 #ifdef NRN_TIMING
         const unsigned long long tb0 = NRN_NOW();
 #endif
-        // units U+1 .. U+RING-LAG-1 may still be in flight, minus those that are padding (never issued); a padding
-        // unit itself has nothing to wait for -- its hand-off is only the barrier that frees a slot
-        constexpr int INFLIGHT = ((U + 1) % NUP >= PAD ? 1 : 0) * (RING - LAG - 1 >= 1) + ((RING - LAG - 1 >= 2 && (U + 2) % NUP >= PAD) ? 1 : 0);
-        if constexpr (U >= PAD) wait_ring<INFLIGHT * PW>();
+        wait_ring<(RING - LAG - 1) * PW>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #ifdef NRN_TIMING
@@ -454,7 +450,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
     for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = a.bias[i];
     __syncthreads();
 
-    WRing<P, WAVES, PL::NUP, PL::PAD> st;
+    WRing<P, WAVES, PL::NUP> st;
     st.init(a.wstream, ring, wave, lane);
 
     const int S = a.S;
@@ -501,31 +497,6 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             const float t = lin01(sc, S);
             z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));      // train.py:849
         }
-        // the ray's latent code in B-operand order: element (s, e) of this lane half = latent[(2s+h)*KH + e - 8]
-        constexpr int NLATV = HAS_BEND ? PL::NS_BIN * KH : 1;
-        float latv[NLATV];
-        if constexpr (HAS_BEND) {
-            const float* lat = a.latents + (size_t)ray * a.lat_stride;
-            static_for<0, PL::NS_BIN>([&](auto sc_) {
-                constexpr int s = decltype(sc_)::value;
-                static_for<0, KH>([&](auto ec) {
-                    constexpr int e = decltype(ec)::value;
-                    constexpr int i0 = (2 * s) * KH + e - 8, i1 = (2 * s + 1) * KH + e - 8;      // latent index per half
-                    constexpr bool ok0 = i0 >= 0 && i0 < A::LAT, ok1 = i1 >= 0 && i1 < A::LAT;
-                    if constexpr (ok0 || ok1) {
-                        const int li = h ? (ok1 ? i1 : 0) : (ok0 ? i0 : 0);
-                        const float v = lat[li];
-                        latv[s * KH + e] = (h ? ok1 : ok0) ? v : 0.0f;
-                    } else {
-                        latv[s * KH + e] = 0.0f;
-                    }
-                });
-            });
-        }
-        // hand-offs of the leading padding units: two barriers that free the ring slots of the previous pass' last
-        // units.  Placed here so that they overlap the latency of the loads issued above (rays, depth, latent code).
-        static_for<0, PL::PAD>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
-
         float p[3] = {__fadd_rn(ox, __fmul_rn(dx, z)), __fadd_rn(oy, __fmul_rn(dy, z)),
                       __fadd_rn(oz, __fmul_rn(dz, z))};                                  // train.py:871-873
         const size_t so = (size_t)ray * S + sc;     // flat sample index for per-sample outputs
@@ -542,16 +513,22 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             constexpr int NS_BIN = PL::NS_BIN, NS_RIN = PL::NS_RIN;
             constexpr int NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
             constexpr bool SPLIT = P::SPLIT;
+            const float* lat = a.latents + (size_t)ray * a.lat_stride;
+            auto binval = [&](auto idxc) -> float {
+                constexpr int idx = decltype(idxc)::value;
+                if constexpr (idx < 3) return p[idx];
+                else if constexpr (idx < 8) return 0.0f;
+                else if constexpr (idx - 8 < A::LAT) return lat[idx - 8];
+                else return 0.0f;
+            };
             Act<PE, NS_BIN, SPLIT> bin;
             static_for<0, NS_BIN>([&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
                 static_for<0, KH>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
-                    constexpr int i0 = (2 * s) * KH + e, i1 = (2 * s + 1) * KH + e;       // index into [xyz, 0 x 5, latent]
-                    float v = latv[s * KH + e];
-                    if constexpr (i0 < 3) v = h ? v : p[i0];
-                    if constexpr (i1 < 3) v = h ? p[i1] : v;
-                    bin.template set<s, e>(v);
+                    const float v0 = binval(std::integral_constant<int, (2 * s) * KH + e>{});
+                    const float v1 = binval(std::integral_constant<int, (2 * s + 1) * KH + e>{});
+                    bin.template set<s, e>(h ? v1 : v0);
                 });
             });
             // ---- offset MLP (run_nerf_helpers.py:525-541)
@@ -803,6 +780,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                 if (a.raw_ch > 4) ro[4] = raw[4];
             }
         }
+        // padding units (keep the ring phase identical every pass and prime the next pass' first units)
+        static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
         NRN_TACC(5, t_out);
         NRN_TACC(0, t_pass);
 #ifdef NRN_TIMING

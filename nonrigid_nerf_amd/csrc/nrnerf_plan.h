@@ -152,7 +152,7 @@ constexpr int MAX_TILES = 256;
 struct Tables {
     LayerSpec layers[MAX_LAYERS];
     TileInfo tiles[MAX_TILES];
-    int nlayers, ntiles, nfrags, nunits, nunits_padded, pad_units, mfma_per_block;
+    int nlayers, ntiles, nfrags, nunits, nunits_padded, mfma_per_block;
 };
 
 template <class SH, class A, bool HAS_BEND, bool VIEWS = false>
@@ -212,11 +212,6 @@ constexpr Tables build_tables() {
     T.nfrags = g;
     T.nunits = cdiv(g, SH::UNIT_FRAGS);
     T.nunits_padded = cdiv(T.nunits, RING) * RING;
-    // The padding units (no data, never DMA'd) sit at the FRONT of every pass: their ring hand-offs -- barriers that are
-    // structurally needed to recycle the slots of the previous pass' last units -- then overlap the latency of the
-    // pass' input loads (rays, depths, latent code) instead of being dead time at the end of the pass.
-    T.pad_units = T.nunits_padded - T.nunits;
-    for (int i = 0; i < T.ntiles; ++i) T.tiles[i].gbase += T.pad_units * SH::UNIT_FRAGS;
     T.mfma_per_block = mf;
     return T;
 }
@@ -235,8 +230,7 @@ struct Plan {
     static constexpr int NTILES = TB.ntiles;
     static constexpr int NFRAGS = TB.nfrags;
     static constexpr int NUNITS = TB.nunits;                 // units holding real fragments
-    static constexpr int NUP = TB.nunits_padded;             // ring hand-offs per pass (multiple of RING)
-    static constexpr int PAD = TB.pad_units;                 // leading units without data
+    static constexpr int NUP = TB.nunits_padded;             // units streamed per pass (multiple of RING)
     static constexpr int UF = SH::UNIT_FRAGS;
     static constexpr int MFMA_PER_BLOCK = TB.mfma_per_block;
     static_assert(TB.ntiles <= MAX_TILES && TB.nlayers <= MAX_LAYERS, "plan too large");
