@@ -476,46 +476,6 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 #ifdef NRN_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    // Per-lane inputs of one pass.  They are loaded one pass ahead -- right before the end-of-pass padding hand-offs,
-    // whose barrier waits then overlap the load latency -- instead of stalling the start of every pass.
-    constexpr int NLATV = HAS_BEND ? PL::NS_BIN * KH : 1;
-    struct PassIn { float o[3], d[3], near, far, z, vd[3]; float latv[NLATV]; };
-    auto load_inputs = [&](long long tile0_) {
-        PassIn in;
-        const long long blk_ = tile0_ + wave;
-        const long long b_ = blk_ < blk_end ? blk_ : blk_end - 1;
-        const int ray_ = (int)(b_ / bpr);
-        const int sidx_ = (int)(b_ % bpr) * 32 + j;
-        const int sc_i = sidx_ < S ? sidx_ : S - 1;
-        const float* rp = a.rays + (size_t)ray_ * a.ray_stride;
-        in.o[0] = rp[0]; in.o[1] = rp[1]; in.o[2] = rp[2]; in.d[0] = rp[3]; in.d[1] = rp[4]; in.d[2] = rp[5];
-        in.near = rp[6]; in.far = rp[7];
-        in.z = a.z ? a.z[(size_t)ray_ * S + sc_i] : 0.0f;
-        if constexpr (VIEWS && !HAS_BEND) { in.vd[0] = rp[8]; in.vd[1] = rp[9]; in.vd[2] = rp[10]; }
-        else { in.vd[0] = in.vd[1] = in.vd[2] = 0.0f; }
-        if constexpr (HAS_BEND) {
-            // the ray's latent code in B-operand order: element (s, e) of this lane half = latent[(2s+h)*KH + e - 8]
-            const float* lat = a.latents + (size_t)ray_ * a.lat_stride;
-            static_for<0, PL::NS_BIN>([&](auto sc_) {
-                constexpr int s = decltype(sc_)::value;
-                static_for<0, KH>([&](auto ec) {
-                    constexpr int e = decltype(ec)::value;
-                    constexpr int i0 = (2 * s) * KH + e - 8, i1 = (2 * s + 1) * KH + e - 8;
-                    constexpr bool ok0 = i0 >= 0 && i0 < A::LAT, ok1 = i1 >= 0 && i1 < A::LAT;
-                    if constexpr (ok0 || ok1) {
-                        const float v = lat[h ? (ok1 ? i1 : 0) : (ok0 ? i0 : 0)];
-                        in.latv[s * KH + e] = (h ? ok1 : ok0) ? v : 0.0f;
-                    } else {
-                        in.latv[s * KH + e] = 0.0f;
-                    }
-                });
-            });
-        } else {
-            in.latv[0] = 0.0f;
-        }
-        return in;
-    };
-    PassIn cur = load_inputs(blk_begin < blk_end ? blk_begin : 0);
     int iter = 0;
     for (long long tile0 = blk_begin; tile0 < blk_end; tile0 += tile_stride, ++iter) {
         const unsigned long long t_pass = NRN_NOW();
@@ -527,11 +487,15 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         const bool ok = blk_ok && sidx < S;
         const int sc = sidx < S ? sidx : S - 1;
 
-        const float ox = cur.o[0], oy = cur.o[1], oz = cur.o[2], dx = cur.d[0], dy = cur.d[1], dz = cur.d[2];
-        float z = cur.z;
-        if (!a.z) {
+        const float* rp = a.rays + (size_t)ray * a.ray_stride;
+        const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+        float z;
+        if (a.z) {
+            z = a.z[(size_t)ray * S + sc];
+        } else {
+            const float near = rp[6], far = rp[7];
             const float t = lin01(sc, S);
-            z = __fadd_rn(__fmul_rn(cur.near, __fsub_rn(1.0f, t)), __fmul_rn(cur.far, t));      // train.py:849
+            z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));      // train.py:849
         }
         float p[3] = {__fadd_rn(ox, __fmul_rn(dx, z)), __fadd_rn(oy, __fmul_rn(dy, z)),
                       __fadd_rn(oz, __fmul_rn(dz, z))};                                  // train.py:871-873
@@ -549,16 +513,22 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             constexpr int NS_BIN = PL::NS_BIN, NS_RIN = PL::NS_RIN;
             constexpr int NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
             constexpr bool SPLIT = P::SPLIT;
+            const float* lat = a.latents + (size_t)ray * a.lat_stride;
+            auto binval = [&](auto idxc) -> float {
+                constexpr int idx = decltype(idxc)::value;
+                if constexpr (idx < 3) return p[idx];
+                else if constexpr (idx < 8) return 0.0f;
+                else if constexpr (idx - 8 < A::LAT) return lat[idx - 8];
+                else return 0.0f;
+            };
             Act<PE, NS_BIN, SPLIT> bin;
             static_for<0, NS_BIN>([&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
                 static_for<0, KH>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
-                    constexpr int i0 = (2 * s) * KH + e, i1 = (2 * s + 1) * KH + e;       // index into [xyz, 0 x 5, latent]
-                    float v = cur.latv[s * KH + e];
-                    if constexpr (i0 < 3) v = h ? v : p[i0];
-                    if constexpr (i1 < 3) v = h ? p[i1] : v;
-                    bin.template set<s, e>(v);
+                    const float v0 = binval(std::integral_constant<int, (2 * s) * KH + e>{});
+                    const float v1 = binval(std::integral_constant<int, (2 * s + 1) * KH + e>{});
+                    bin.template set<s, e>(h ? v1 : v0);
                 });
             });
             // ---- offset MLP (run_nerf_helpers.py:525-541)
@@ -673,7 +643,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 #pragma unroll
                 for (int c = 0; c < 3; ++c) dirv[c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f));
             } else {
-                dirv[0] = cur.vd[0]; dirv[1] = cur.vd[1]; dirv[2] = cur.vd[2];
+                dirv[0] = rp[8]; dirv[1] = rp[9]; dirv[2] = rp[10];
             }
             constexpr int F0V = enc_F0(A::LV);
             constexpr int NSLOTV = NS_ENCV * KH;
@@ -810,9 +780,6 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                 if (a.raw_ch > 4) ro[4] = raw[4];
             }
         }
-        // next pass' inputs, requested before the padding hand-offs so their latency hides behind those barriers
-        // (clamped to the last block when there is no next pass)
-        cur = load_inputs(tile0 + tile_stride);
         // padding units (keep the ring phase identical every pass and prime the next pass' first units)
         static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
         NRN_TACC(5, t_out);
