@@ -10,6 +10,14 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
+    # The CPU tier runs in a small VM whose vCPUs can be descheduled by the host: an 8-thread OpenMP team then spins at
+    # every barrier and the suite goes from 10 s to 8 min.  The cases are sized for 1-2 threads (about 30 s).
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            torch.set_num_threads(2)
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
