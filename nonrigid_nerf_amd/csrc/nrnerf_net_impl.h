@@ -168,6 +168,7 @@ struct WRing {
     char* ring;            // LDS ring base
     int wave_off;          // this wave's piece offset inside a unit (wave-uniform)
     int lane_off;          // lane * (FRAG_BYTES / 64)
+    unsigned lane_addr;    // LDS byte address of this lane's part of fragment 0 of slot 0
 #ifdef NRN_TIMING
     unsigned long long bar_cycles = 0, bar_count = 0;
 #endif
@@ -178,6 +179,7 @@ struct WRing {
         lane16 = (unsigned)lane * 16u;
         ring = lds;
         lane_off = lane * (P::FRAG_BYTES / 64);
+        lane_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (unsigned)lane_off;
         static_for<0, RING - LAG>([&](auto uc) { issue<decltype(uc)::value>(); });
     }
     template <int V>
@@ -208,14 +210,42 @@ struct WRing {
 #endif
         issue<(U + RING - LAG) % NUP>();
     }
-    // fragment GF (index in the whole stream) for this lane; advances the ring when GF opens a new unit
+    // fragment GF (index in the whole stream) for this lane; advances the ring when GF opens a new unit.
+    //
+    // 16-byte fragments are read with an explicit `ds_read_b128 vdst, vaddr offset:imm` and consumed after an explicit
+    // counted `s_waitcnt lgkmcnt(N)` (ready<N>): left to itself hipcc re-sinks the prefetched reads next to their MFMA
+    // and drains the queue with lgkmcnt(0) -- which schedule it picks flips with unrelated changes of register pressure.
+    // LDS operations retire in order, so at the consumer "at most N younger LDS operations outstanding" implies this
+    // read is done; LDS traffic the compiler adds on its own (bias table, mailbox) only makes the wait stricter, and its
+    // own waits (computed without knowing about these reads) can only be stricter than needed.  No scalar memory load
+    // may be in flight across a counted wait (SMEM returns out of order): the kernel reads its arguments before the
+    // persistent loop, and tools/check_isa.py asserts there is no s_load inside the loop.
+    static constexpr bool ASM_FRAGS = (P::FRAG_BYTES == 1024);
     template <class PX, int GF>
     __device__ __forceinline__ typename PX::frag frag() {
         static_assert(PX::FRAG_BYTES == P::FRAG_BYTES, "mixed policies must share the fragment size");
         constexpr int UF = P::UNIT_FRAGS;
         if constexpr (GF % UF == 0) advance<GF / UF>();
-        const char* p = ring + ((GF / UF) % RING) * UNIT + (GF % UF) * P::FRAG_BYTES + lane_off;
-        return *(const typename PX::frag*)p;
+        constexpr int OFF = ((GF / UF) % RING) * UNIT + (GF % UF) * P::FRAG_BYTES;
+        if constexpr (ASM_FRAGS) {
+            static_assert(OFF + 16 <= 65536, "ring must stay within the immediate ds_read offset");
+            u32x4 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lane_addr), "n"(OFF));
+            return __builtin_bit_cast(typename PX::frag, v);
+        } else {
+            const char* p = ring + OFF + lane_off;
+            return *(const typename PX::frag*)p;
+        }
+    }
+    // the fragment read N LDS operations before the most recent one has landed
+    template <int N, class F>
+    __device__ __forceinline__ void ready(F& f) {
+        if constexpr (ASM_FRAGS) {
+            static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+            u32x4 v = __builtin_bit_cast(u32x4, f);
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+            f = __builtin_bit_cast(F, v);
+        }
     }
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -226,8 +256,18 @@ struct WRing {
 // in1 (NS1, policy P1): the skip layer mixes f16 encoding slabs with bf16 hidden slabs in one
 // fp32 accumulator.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x16 load_bias(const float* bias_lds, int tile, int h) {
-    const f32x4* bp = (const f32x4*)(bias_lds + tile * 32 + h * 16);
+// `bias_lane` is the per-lane LDS address (table + 64 * (lane >> 5)), made opaque once in the kernel prologue
+// (BiasPtr): the table sits above the 64 KiB ring, so with a visible base hipcc materialises one VGPR per tile
+// address and hoists all ~70 of them out of the persistent loop (64 VGPRs + 12 scratch slots, each reload draining
+// the DMA queue with a vmcnt(0)); from an opaque base every tile is an immediate ds_read offset.
+typedef const __attribute__((address_space(3))) f32x4* BiasPtr;
+__device__ __forceinline__ BiasPtr bias_lane_ptr(const float* bias_lds, int h) {
+    BiasPtr p = (BiasPtr)(bias_lds + h * 16);
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ f32x16 load_bias(BiasPtr bias_lane, int tile) {
+    BiasPtr bp = bias_lane + tile * 8;
     const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
     return f32x16{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3],
                   b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
@@ -269,7 +309,7 @@ __device__ __forceinline__ void prio_tick() {
 // with NACC = 4 the chains of pair p+1 start in fresh accumulator sets while pair p's epilogue (convert, relu) is
 // issued DLY steps later, so the VALU work overlaps the matrix pipe.
 template <class P0, class P1, class PL, int LI, int NS0, int NS1, class ST, class IN0, class IN1, class EPI>
-__device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, const IN0& in0, const IN1& in1, EPI&& epi) {
+__device__ __forceinline__ void dense(ST& st, BiasPtr bias_lane, const IN0& in0, const IN1& in1, EPI&& epi) {
     constexpr LayerSpec spec = PL::TB.layers[LI];
     static_assert(spec.ns == NS0 + NS1 && spec.split == 0, "slab count mismatch between kernel and plan");
     constexpr int NS = NS0 + NS1, NT = spec.nt, Q = NT * NS, PF = P1::PF;
@@ -288,12 +328,13 @@ __device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, cons
     f32x16 accs[NACC];
     static_for<0, (NACC < NT ? NACC : NT)>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        if constexpr (NACC == 4 || t < 2) accs[t % NACC] = load_bias(bias_lds, spec.tile0 + t, h);
+        if constexpr (NACC == 4 || t < 2) accs[t % NACC] = load_bias(bias_lane, spec.tile0 + t);
     });
     static_for<0, Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int t = SQ::tile(q), s = SQ::slab(q);
         prio_tick<q>();
+        st.template ready<(Q - 1 - q < PF - 1) ? Q - 1 - q : PF - 1>(a[q % PF]);     // reads q+1 .. q+PF-1 may be in flight
         const typename P1::frag cur = a[q % PF];
         if constexpr (q + PF < Q) load(std::integral_constant<int, q + PF>{});
         if constexpr (s < NS0) accs[t % NACC] = P0::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[s], accs[t % NACC]);
@@ -304,8 +345,8 @@ __device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, cons
                 constexpr int tp = (t & ~1) - 2;
                 epi(std::integral_constant<int, tp>{}, accs[tp % NACC]);
                 epi(std::integral_constant<int, tp + 1>{}, accs[(tp + 1) % NACC]);
-                if constexpr (tp + 4 < NT) accs[(tp + 4) % NACC] = load_bias(bias_lds, spec.tile0 + tp + 4, h);
-                if constexpr (tp + 5 < NT) accs[(tp + 5) % NACC] = load_bias(bias_lds, spec.tile0 + tp + 5, h);
+                if constexpr (tp + 4 < NT) accs[(tp + 4) % NACC] = load_bias(bias_lane, spec.tile0 + tp + 4);
+                if constexpr (tp + 5 < NT) accs[(tp + 5) % NACC] = load_bias(bias_lane, spec.tile0 + tp + 5);
             }
             if constexpr (q == Q - 1) {     // drain: the last pair (or the odd tile, plus the pair before it)
                 constexpr int first = (NT & 1) ? (NT >= 3 ? NT - 3 : NT - 1) : NT - 2;
@@ -316,8 +357,8 @@ __device__ __forceinline__ void dense(ST& st, const float* bias_lds, int h, cons
                 // pair finished: epilogue of its tile(s), then the next pair's biases
                 if constexpr ((t & 1) == 1) epi(std::integral_constant<int, t - 1>{}, accs[(t - 1) % NACC]);
                 epi(std::integral_constant<int, t>{}, accs[t % NACC]);
-                if constexpr (t + 1 < NT) accs[(t + 1) % NACC] = load_bias(bias_lds, spec.tile0 + t + 1, h);
-                if constexpr (t + 2 < NT) accs[(t + 2) % NACC] = load_bias(bias_lds, spec.tile0 + t + 2, h);
+                if constexpr (t + 1 < NT) accs[(t + 1) % NACC] = load_bias(bias_lane, spec.tile0 + t + 1);
+                if constexpr (t + 2 < NT) accs[(t + 2) % NACC] = load_bias(bias_lane, spec.tile0 + t + 2);
             }
         }
     });
@@ -333,43 +374,82 @@ struct Act {
         PE::template set<E>(hi[S], v);
         if constexpr (SPLIT) PE::template set<E>(lo[S], (v - PE::round(v)) * PE::LO_SCALE);
     }
+    // slab S := relu(accumulator registers 8U..8U+7), 16-bit policies.  Per pair of values: 2 x v_max_i32 (relu),
+    // v_cvt_pk_f16_f32 (hi), v_pk_mul_f32 (x * 2^11) and 2 x v_fma_mix{lo,hi}_f16 computing f16(x * 2^11 - hi * 2^11)
+    // straight from the packed hi halves -- 6 VALU instead of the 10-12 of the element-wise form (convert back,
+    // subtract, scale, convert).  Same value: x - hi is exact in fp32.
+    template <int S, int U>
+    __device__ __forceinline__ void set_slab_relu(const f32x16& c) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        u32x4 wh, wl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2 t = {relu_bits(c[8 * U + 2 * k]), relu_bits(c[8 * U + 2 * k + 1])};
+            const h2 hh = __builtin_convertvector(t, h2);
+            wh[k] = __builtin_bit_cast(unsigned, hh);
+            if constexpr (SPLIT) {
+                // hipcc does not select the mixed-precision fma here (it converts hi back with v_cvt_f32_f16 + sdwa)
+                f32x2 ts;
+                const f32x2 sc = {PE::LO_SCALE, -PE::LO_SCALE};
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ts) : "v"(t), "s"(sc));
+                unsigned w;      // mixlo leaves the upper half alone; mixhi then defines it
+                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]"
+                    : "=v"(w) : "v"(wh[k]), "s"(sc[1]), "v"(ts[0]));
+                asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                    : "+v"(w) : "v"(wh[k]), "s"(sc[1]), "v"(ts[1]));
+                wl[k] = w;
+            }
+        }
+        hi[S] = __builtin_bit_cast(typename PE::frag, wh);
+        if constexpr (SPLIT) lo[S] = __builtin_bit_cast(typename PE::frag, wl);
+    }
 };
 
 // dense layer of the bender: 3-term split product  Whi*xhi + 2^-11 (Whi*xlo + Wlo*xhi)  when SPLIT.  The two tiles of
 // a pair advance together, so no accumulator is written by two consecutive MFMAs.
 template <class PE, bool SPLIT, class PL, int LI, int NS, class ST, class ACT, class EPI>
-__device__ __forceinline__ void dense_b(ST& st, const float* bias_lds, int h, const ACT& in, EPI&& epi) {
+__device__ __forceinline__ void dense_b(ST& st, BiasPtr bias_lane, const ACT& in, EPI&& epi) {
     constexpr LayerSpec spec = PL::TB.layers[LI];
     static_assert(spec.ns == NS && spec.split == (SPLIT ? 1 : 0), "bender layer mismatch between kernel and plan");
     constexpr int NT = spec.nt;
+    constexpr int FP = SPLIT ? 2 : 1;                     // fragments per (tile, slab): hi [, lo]
     static_for<0, (NT + 1) / 2>([&](auto pc) {
         constexpr int t0 = 2 * decltype(pc)::value;
         constexpr int W = (t0 + 1 < NT) ? 2 : 1;          // tiles in this group
+        // the group's fragments are consecutive in the stream (slab-major, then tile, then hi/lo): step s is read
+        // into w[s & 1] while the MFMAs of step s - 1 run (the layers are too short to hide an LDS round trip per step)
+        typename PE::frag w[2][W * FP];
+        auto load = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            static_for<0, W>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t0 + u];
+                static_for<0, FP>([&](auto fc) {
+                    constexpr int f = decltype(fc)::value;
+                    w[s & 1][u * FP + f] = st.template frag<PE, ti.gbase + s * ti.gstride + f>();
+                });
+            });
+        };
+        load(std::integral_constant<int, 0>{});
         f32x16 acc[W], corr[W];
         static_for<0, W>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
-            acc[u] = load_bias(bias_lds, spec.tile0 + t0 + u, h);
+            acc[u] = load_bias(bias_lane, spec.tile0 + t0 + u);
             corr[u] = f32x16{};
         });
         static_for<0, NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
+            // start step s + 1, then wait for step s (the W * FP younger reads may stay in flight)
+            if constexpr (s + 1 < NS) load(std::integral_constant<int, s + 1>{});
+            static_for<0, W * FP>([&](auto fc) {
+                st.template ready<(s + 1 < NS) ? W * FP : 0>(w[s & 1][decltype(fc)::value]);
+            });
             if constexpr (SPLIT) {
-                typename PE::frag whi[W], wlo[W];
-                static_for<0, W>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t0 + u];
-                    whi[u] = st.template frag<PE, ti.gbase + s * ti.gstride>();
-                    wlo[u] = st.template frag<PE, ti.gbase + s * ti.gstride + 1>();
-                });
-                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; corr[u] = PE::mfma(wlo[u], in.hi[s], corr[u]); });
-                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; acc[u] = PE::mfma(whi[u], in.hi[s], acc[u]); });
-                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; corr[u] = PE::mfma(whi[u], in.lo[s], corr[u]); });
+                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; corr[u] = PE::mfma(w[s & 1][2 * u + 1], in.hi[s], corr[u]); });
+                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; acc[u] = PE::mfma(w[s & 1][2 * u], in.hi[s], acc[u]); });
+                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; corr[u] = PE::mfma(w[s & 1][2 * u], in.lo[s], corr[u]); });
             } else {
-                static_for<0, W>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    constexpr TileInfo ti = PL::TB.tiles[spec.tile0 + t0 + u];
-                    acc[u] = PE::mfma(st.template frag<PE, ti.gbase + s * ti.gstride>(), in.hi[s], acc[u]);
-                });
+                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; acc[u] = PE::mfma(w[s & 1][u], in.hi[s], acc[u]); });
             }
         });
         static_for<0, W>([&](auto uc) {
@@ -392,10 +472,14 @@ template <class PE, int T, class ACT>
 __device__ __forceinline__ void pack_act(const f32x16& acc, ACT& out) {
     static_for<0, PE::SP>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        static_for<0, PE::KH>([&](auto ec) {
-            constexpr int e = decltype(ec)::value;
-            out.template set<T * PE::SP + u, e>(relu_bits(acc[u * PE::KH + e]));
-        });
+        if constexpr (PE::KH == 8) {
+            out.template set_slab_relu<T * PE::SP + u, u>(acc);
+        } else {
+            static_for<0, PE::KH>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                out.template set<T * PE::SP + u, e>(relu_bits(acc[u * PE::KH + e]));
+            });
+        }
     });
 }
 
@@ -449,6 +533,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 
     for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = a.bias[i];
     __syncthreads();
+
+    const BiasPtr bias_lane = bias_lane_ptr(bias_lds, h);
 
     WRing<P, WAVES, PL::NUP> st;
     st.init(a.wstream, ring, wave, lane);
@@ -533,25 +619,25 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             });
             // ---- offset MLP (run_nerf_helpers.py:525-541)
             Act<PE, NB, SPLIT> ba, bb;
-            dense_b<PE, SPLIT, PL, PL::L_BEND0, NS_BIN>(st, bias_lds, h, bin, [&](auto tc, const f32x16& acc) {
+            dense_b<PE, SPLIT, PL, PL::L_BEND0, NS_BIN>(st, bias_lane, bin, [&](auto tc, const f32x16& acc) {
                 pack_act<PE, decltype(tc)::value>(acc, ba);
             });
             static_for<1, A::BD - 1>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i % 2 == 1) {
-                    dense_b<PE, SPLIT, PL, PL::L_BEND0 + i, NB>(st, bias_lds, h, ba, [&](auto tc, const f32x16& acc) {
+                    dense_b<PE, SPLIT, PL, PL::L_BEND0 + i, NB>(st, bias_lane, ba, [&](auto tc, const f32x16& acc) {
                         pack_act<PE, decltype(tc)::value>(acc, bb);
                     });
                 } else {
-                    dense_b<PE, SPLIT, PL, PL::L_BEND0 + i, NB>(st, bias_lds, h, bb, [&](auto tc, const f32x16& acc) {
+                    dense_b<PE, SPLIT, PL, PL::L_BEND0 + i, NB>(st, bias_lane, bb, [&](auto tc, const f32x16& acc) {
                         pack_act<PE, decltype(tc)::value>(acc, ba);
                     });
                 }
             });
             float off[3];
             auto take_off = [&](auto, const f32x16& acc) { off[0] = acc[0]; off[1] = acc[1]; off[2] = acc[2]; };
-            if constexpr ((A::BD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lds, h, bb, take_off);
-            else dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lds, h, ba, take_off);
+            if constexpr ((A::BD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, bb, take_off);
+            else dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, ba, take_off);
             // ---- rigidity MLP (run_nerf_helpers.py:545-561); input = xyz only
             Act<PE, NS_RIN, SPLIT> rin;
             auto rinval = [&](auto idxc) -> float {
@@ -569,25 +655,25 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                 });
             });
             Act<PE, NR, SPLIT> ra, rb;
-            dense_b<PE, SPLIT, PL, PL::L_RIG0, NS_RIN>(st, bias_lds, h, rin, [&](auto tc, const f32x16& acc) {
+            dense_b<PE, SPLIT, PL, PL::L_RIG0, NS_RIN>(st, bias_lane, rin, [&](auto tc, const f32x16& acc) {
                 pack_act<PE, decltype(tc)::value>(acc, ra);
             });
             static_for<1, A::RD - 1>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i % 2 == 1) {
-                    dense_b<PE, SPLIT, PL, PL::L_RIG0 + i, NR>(st, bias_lds, h, ra, [&](auto tc, const f32x16& acc) {
+                    dense_b<PE, SPLIT, PL, PL::L_RIG0 + i, NR>(st, bias_lane, ra, [&](auto tc, const f32x16& acc) {
                         pack_act<PE, decltype(tc)::value>(acc, rb);
                     });
                 } else {
-                    dense_b<PE, SPLIT, PL, PL::L_RIG0 + i, NR>(st, bias_lds, h, rb, [&](auto tc, const f32x16& acc) {
+                    dense_b<PE, SPLIT, PL, PL::L_RIG0 + i, NR>(st, bias_lane, rb, [&](auto tc, const f32x16& acc) {
                         pack_act<PE, decltype(tc)::value>(acc, ra);
                     });
                 }
             });
             float logit;
             auto take_logit = [&](auto, const f32x16& acc) { logit = acc[0]; };
-            if constexpr ((A::RD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lds, h, rb, take_logit);
-            else dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lds, h, ra, take_logit);
+            if constexpr ((A::RD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, rb, take_logit);
+            else dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, ra, take_logit);
 
             rig_mask = (tanhf(logit) + 1.0f) / 2.0f;                                  // rnh:559-561
             if (a.knobs.has_cutoff && rig_mask <= a.knobs.cutoff) rig_mask = 0.0f;    // rnh:563-564
@@ -721,7 +807,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         constexpr int NH = NT_W * SP;
         frag ha[NH], hb[NH];
         Empty none;
-        dense<PE, P, PL, PL::L_TRUNK0, NS_ENC, 0>(st, bias_lds, h, enc, none, [&](auto tc, const f32x16& acc) {
+        dense<PE, P, PL, PL::L_TRUNK0, NS_ENC, 0>(st, bias_lane, enc, none, [&](auto tc, const f32x16& acc) {
             pack_tile<P, true, decltype(tc)::value>(acc, ha);
         });
         static_for<1, A::D>([&](auto ic) {
@@ -729,17 +815,17 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             constexpr bool skip = (i - 1 == A::SKIP);
             if constexpr (i % 2 == 1) {
                 if constexpr (skip)
-                    dense<PE, P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lds, h, enc, ha, [&](auto tc, const f32x16& acc) {
+                    dense<PE, P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lane, enc, ha, [&](auto tc, const f32x16& acc) {
                         pack_tile<P, true, decltype(tc)::value>(acc, hb); });
                 else
-                    dense<P, P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lds, h, ha, none, [&](auto tc, const f32x16& acc) {
+                    dense<P, P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lane, ha, none, [&](auto tc, const f32x16& acc) {
                         pack_tile<P, true, decltype(tc)::value>(acc, hb); });
             } else {
                 if constexpr (skip)
-                    dense<PE, P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lds, h, enc, hb, [&](auto tc, const f32x16& acc) {
+                    dense<PE, P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lane, enc, hb, [&](auto tc, const f32x16& acc) {
                         pack_tile<P, true, decltype(tc)::value>(acc, ha); });
                 else
-                    dense<P, P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lds, h, hb, none, [&](auto tc, const f32x16& acc) {
+                    dense<P, P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lane, hb, none, [&](auto tc, const f32x16& acc) {
                         pack_tile<P, true, decltype(tc)::value>(acc, ha); });
             }
         });
@@ -749,20 +835,20 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             auto take_raw = [&](auto, const f32x16& acc) {
                 raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; raw[3] = acc[3]; raw[4] = acc[4];
             };
-            if constexpr (LAST_IN_B) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, hb, none, take_raw);
-            else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lds, h, ha, none, take_raw);
+            if constexpr (LAST_IN_B) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, hb, none, take_raw);
+            else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, ha, none, take_raw);
         } else {
             // view-dependent head (run_nerf_helpers.py:284-304): alpha and feature from the trunk output, then
             // relu(views_linear([feature, enc(dir)])) and rgb_linear; output = [rgb, alpha]
             auto head = [&](auto& hx, auto& hy) {
-                dense<P, P, PL, PL::L_ALPHA, NH, 0>(st, bias_lds, h, hx, none, [&](auto, const f32x16& acc) { raw[3] = acc[0]; });
-                dense<P, P, PL, PL::L_FEAT, NH, 0>(st, bias_lds, h, hx, none, [&](auto tc, const f32x16& acc) {
+                dense<P, P, PL, PL::L_ALPHA, NH, 0>(st, bias_lane, hx, none, [&](auto, const f32x16& acc) { raw[3] = acc[0]; });
+                dense<P, P, PL, PL::L_FEAT, NH, 0>(st, bias_lane, hx, none, [&](auto tc, const f32x16& acc) {
                     pack_tile<P, false, decltype(tc)::value>(acc, hy); });
                 constexpr int NV = (NT_W / 2) * SP;
                 frag hv[NV];
-                dense<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH>(st, bias_lds, h, encv, hy, [&](auto tc, const f32x16& acc) {
+                dense<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH>(st, bias_lane, encv, hy, [&](auto tc, const f32x16& acc) {
                     pack_tile<P, true, decltype(tc)::value>(acc, hv); });
-                dense<P, P, PL, PL::L_RGB, NV, 0>(st, bias_lds, h, hv, none, [&](auto, const f32x16& acc) {
+                dense<P, P, PL, PL::L_RGB, NV, 0>(st, bias_lane, hv, none, [&](auto, const f32x16& acc) {
                     raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; });
             };
             if constexpr (LAST_IN_B) head(hb, ha); else head(ha, hb);

@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Static checks on the compiled network kernels (gfx950 ISA of nonrigid_nerf_amd/csrc/build*/net_*.o).
+
+  python tools/check_isa.py [build_dir]          -> one line per kernel, exit 1 on a violated invariant
+
+Invariants the hand-placed waits of nrnerf_net_impl.h rely on (16-bit kernels, WRing::frag / ready):
+  * no scalar memory load (s_load / s_buffer_load) after the first MFMA of a kernel: SMEM returns out of order, so a
+    counted `s_waitcnt lgkmcnt(N > 0)` is only meaningful while none is in flight;
+  * no scratch traffic: every scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the LDS-DMA queue;
+  * at most 256 VGPRs (two waves per SIMD) for the 16-bit kernels.
+Also reported: MFMA count, VALU count, counted vs draining LDS waits.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def device_code_object(obj: str, tmp: str) -> str | None:
+    local = os.path.join(tmp, os.path.basename(obj))
+    shutil.copy(obj, local)
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", local], check=True, capture_output=True)
+    hits = glob.glob(local + ".*gfx950*")
+    return hits[0] if hits else None
+
+
+def analyse(co: str) -> dict:
+    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    meta = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", notes)}
+    dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    ins = [l.split()[0] for l in dis.splitlines() if re.match(r"^\s+[a-z]+_", l)]
+    mfma = [i for i, x in enumerate(ins) if "mfma" in x]
+    first = mfma[0] if mfma else len(ins)
+    waits = [l.split("//")[0].strip() for l in dis.splitlines() if "s_waitcnt" in l]
+    lg = [int(m.group(1)) for w in waits for m in [re.search(r"lgkmcnt\((\d+)\)", w)] if m]
+    return dict(meta, mfma=len(mfma), valu=sum(x.startswith("v_") and "mfma" not in x for x in ins),
+                smem_after_first_mfma=sum(x.startswith(("s_load", "s_buffer_load")) for x in ins[first:]),
+                scratch=sum(x.startswith("scratch_") for x in ins),
+                lgkm_counted=sum(n > 0 for n in lg), lgkm_drain=sum(n == 0 for n in lg))
+
+
+def check(build_dir: str) -> list[str]:
+    errors = []
+    objs = sorted(glob.glob(os.path.join(build_dir, "net_*.o")))
+    if not objs:
+        raise FileNotFoundError(f"no net_*.o under {build_dir} (run make first)")
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj in objs:
+            co = device_code_object(obj, tmp)
+            name = os.path.basename(obj)[4:-2]
+            if co is None:
+                errors.append(f"{name}: no gfx950 code object")
+                continue
+            r = analyse(co)
+            print(f"{name:24s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} scratch {r['scratch']:3d} "
+                  f"mfma {r['mfma']:5d} valu {r['valu']:5d} lgkm counted/drain {r['lgkm_counted']:4d}/{r['lgkm_drain']:3d} "
+                  f"smem-after-mfma {r['smem_after_first_mfma']}")
+            sixteen = "_f32_" not in "_" + name + "_"
+            if sixteen:
+                if r["smem_after_first_mfma"]:
+                    errors.append(f"{name}: {r['smem_after_first_mfma']} scalar memory load(s) after the first MFMA")
+                if r["scratch"] or r.get("vgpr_spill_count", 0):
+                    errors.append(f"{name}: scratch traffic ({r['scratch']} instructions)")
+                if r.get("vgpr_count", 0) > 256:
+                    errors.append(f"{name}: {r['vgpr_count']} VGPRs > 256")
+    return errors
+
+
+if __name__ == "__main__":
+    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "nonrigid_nerf_amd", "csrc", "build")
+    errs = check(d)
+    for e in errs:
+        print("VIOLATION:", e)
+    sys.exit(1 if errs else 0)
