@@ -113,7 +113,10 @@ def main():
                     "issued_mfma_tflops": round(k["mfma_flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else 0.0,
                     "traffic": pmc_traffic(args),
                     "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_summary.txt); algorithmic 7.86e8",
-                    "other_kernels_ms_per_step": {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()}}
+                    "other_kernels_ms_per_step": {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()},
+                    # context, not the peak: what a plain hipBLASLt GEMM sustains on this box right now (the chip
+                    # clocks down under MFMA load)
+                    "library_gemm_tflops_same_box": library_gemm_tflops(dev, args.precision)}
         res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -132,6 +135,25 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def library_gemm_tflops(dev, precision):
+    """8192^3 GEMM through torch (hipBLASLt) in the kernel's input type, ~30 ms; None if it cannot run."""
+    try:
+        dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[precision]
+        n = 8192 if precision != "f32" else 4096
+        a = torch.randn(n, n, device=dev, dtype=dt)
+        b = torch.randn(n, n, device=dev, dtype=dt)
+        for _ in range(3):
+            a @ b
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            a @ b
+        torch.cuda.synchronize()
+        return round(2.0 * n ** 3 * 20 / (time.perf_counter() - t0) / 1e12, 1)
+    except Exception:
+        return None
 
 
 def pmc_traffic(args):
