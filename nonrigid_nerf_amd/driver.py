@@ -10,7 +10,9 @@ What changes relative to the reference loop:
 * frame f+1 is enqueued while frame f's pixels travel to pinned host memory on a side stream (the reference
   blocks on ``.cpu().numpy()`` for every output key of every frame, train.py:481-497).
 
-Image writing (``savedir``) is not reproduced: it is host-side I/O that needs imageio (train.py:506-545).
+Image writing (``savedir``) is not reproduced: it is host-side I/O that needs imageio (train.py:506-545); with
+``rgb_dtype="uint8"`` the frames come back already converted the way the reference converts them for writing
+(``to8b``, run_nerf_helpers.py:19), 3 bytes per pixel over PCIe instead of 12.
 """
 from __future__ import annotations
 
@@ -45,7 +47,8 @@ def generate_rays(c2w, intrin: dict, near: float, far: float, use_viewdirs: bool
 
 
 def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_latents, gt_imgs=None, savedir=None,
-                render_factor=0, detailed_output=False, parallelized_render_function=None, surface_outputs=False):
+                render_factor=0, detailed_output=False, parallelized_render_function=None, surface_outputs=False,
+                rgb_dtype="float32", device=None):
     """Signature and return value of reference ``render_path`` (train.py:419-431, 547-553).
 
     ``render_kwargs`` is the dict ``create_nerf`` builds (train.py:698-719) plus ``near`` / ``far``; the networks
@@ -55,7 +58,13 @@ def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_late
     ``surface_outputs=True`` (extension) additionally returns, per frame, ``{"surface_pts" [H,W,3], "surface_rigidity"
     [H,W], "median_index" [H,W]}`` -- the reduction free_viewpoint_rendering.py:621-658 computes from the detailed
     outputs -- without moving the per-sample tensors to the host.
+
+    ``rgb_dtype="uint8"`` (extension): ``rgbs`` is ``to8b`` of the render (run_nerf_helpers.py:19), converted on the
+    device.  ``device`` (extension): where to render when the networks are host-resident weight holders
+    (``checkpoint.load_checkpoint``); default: the networks' device if that is a GPU, else the current GPU.
     """
+    if rgb_dtype not in ("float32", "uint8"):
+        raise ValueError("rgb_dtype must be 'float32' or 'uint8'")
     if savedir is not None:
         raise NotImplementedError("image writing is host-side I/O outside the accelerated path (train.py:506-545)")
     if render_factor != 0:                                           # train.py:434-446
@@ -73,7 +82,9 @@ def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_late
     for k in ("ndc", "c2w_staticcam"):
         kw.pop(k, None)
     net = kw["network_fn"]
-    dev = next(net.parameters()).device
+    dev = torch.device(device) if device is not None else next(net.parameters()).device
+    if dev.type != "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
     copy_stream = torch.cuda.Stream(device=dev)
     pending = []          # (pinned rgb, pinned disp, event, H, W, details)
     with torch.no_grad():
@@ -87,9 +98,12 @@ def render_path(render_poses, intrinsics, chunk, render_kwargs, ray_bending_late
             done.record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(done)
-                rgb_h = torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True)
+                rgb_d = out["rgb_map"]
+                if rgb_dtype == "uint8":
+                    rgb_d = (255 * rgb_d.clamp(0, 1)).to(torch.uint8)          # to8b: clip, scale, truncate
+                rgb_h = torch.empty((H, W, 3), dtype=rgb_d.dtype, pin_memory=True)
                 disp_h = torch.empty((H, W), dtype=torch.float32, pin_memory=True)
-                rgb_h.copy_(out["rgb_map"].view(H, W, 3), non_blocking=True)
+                rgb_h.copy_(rgb_d.view(H, W, 3), non_blocking=True)
                 disp_h.copy_(out["disp_map"].view(H, W), non_blocking=True)
                 details = None
                 if detailed_output or surface_outputs:

@@ -160,9 +160,34 @@ def run_raygen(H_ref):
     return arrays
 
 
+CHECKPOINT_CONFIGS = {           # = tests/test_checkpoint.py::CONFIGS
+    "default":          dict(),
+    "coarse_only":      dict(N_importance=0),
+    "viewdirs":         dict(N_importance=64, use_viewdirs=True),
+    "no_bender":        dict(N_importance=64, ray_bending=False),
+    "time_conditioned": dict(N_importance=64, ray_bending=False, time_conditioned_baseline=True),
+    "deep_bender":      dict(N_importance=64, use_viewdirs=True, bend_depth=7),
+}
+
+
+def run_checkpoint_layout(H, T):
+    """Keys and shapes of what train.py:1680-1698 stores, read off the reference's own modules' state_dict()."""
+    layout = {}
+    for name, cfg_kw in CHECKPOINT_CONFIGS.items():
+        scene = make_scene(SceneConfig(**cfg_kw), 0)
+        kw, rb, coarse, fine = reference_kwargs(H, T, scene)
+        shapes = lambda m: None if m is None else {k: list(v.shape) for k, v in m.state_dict().items()}
+        layout[name] = {"network_fn": shapes(coarse), "network_fine": shapes(fine), "ray_bender": shapes(rb)}
+    return layout
+
+
 def main():
     H, T = import_reference()
     os.makedirs(os.path.join(REPO, "tests", "golden"), exist_ok=True)
+    with open(os.path.join(REPO, "tests", "golden", "checkpoint_layout.json"), "w") as f:
+        __import__("json").dump(run_checkpoint_layout(H, T), f, indent=0, sort_keys=True)
+    if "--only-layout" in sys.argv:
+        return
     np.savez_compressed(os.path.join(REPO, "tests", "golden", "raygen.npz"), **run_raygen(H))
     for name in CASES:
         arrays, out = run_case(H, T, name)
