@@ -116,7 +116,7 @@ def main():
                     "other_kernels_ms_per_step": {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()},
                     # context, not the peak: what a plain hipBLASLt GEMM sustains on this box right now (the chip
                     # clocks down under MFMA load)
-                    "library_gemm_tflops_same_box": library_gemm_tflops(dev, args.precision)}
+                    "library_gemm_tflops_same_box": library_gemm_tflops(dev, args.precision) if world == 1 else None}
         res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",

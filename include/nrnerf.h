@@ -149,6 +149,9 @@ typedef struct nrnerf_render_args {
     /* scratch */
     void* workspace;            /* >= nrnerf_workspace_bytes(), 256-byte aligned */
     size_t workspace_bytes;
+    /* render_rays' remaining deterministic flags (create_nerf passes False for both, train.py:707,715) */
+    int32_t lindisp;            /* coarse depths linear in inverse depth            train.py:850-852 */
+    int32_t white_bkgd;         /* rgb_map (and rgb0) += 1 - acc_map                train.py:786-787 */
 } nrnerf_render_args;
 
 /* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */

@@ -64,7 +64,8 @@ class RenderArgs(C.Structure):
                 ("z_vals", C.c_void_p),
                 ("surface_pts", C.c_void_p), ("surface_rigidity", C.c_void_p), ("median_index", C.c_void_p),
                 ("coarse", SampleOutputs), ("fine", SampleOutputs),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("lindisp", C.c_int32), ("white_bkgd", C.c_int32)]
 
 
 class Profile(C.Structure):

@@ -427,7 +427,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     NetArgs na{};
     na.rays = a->rays; na.ray_stride = a->ray_stride;
     na.latents = a->latents; na.lat_stride = a->latent_stride;
-    na.z = nullptr; na.n_rays = N; na.S = S;
+    na.z = nullptr; na.lindisp = a->lindisp; na.n_rays = N; na.S = S;
     na.wstream = m->coarse.stream; na.bias = m->coarse.bias;
     na.raw4 = raw_c;
     na.raw_out = (I == 0) ? a->raw : nullptr;
@@ -443,6 +443,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     CompositeArgs ca{};
     ca.rays = a->rays; ca.ray_stride = a->ray_stride;
     ca.raw4 = raw_c; ca.z = nullptr; ca.n_rays = N; ca.S = S; ca.n_importance = I;
+    ca.lindisp = a->lindisp; ca.white_bkgd = a->white_bkgd;
     if (I > 0) {
         // rgb0/disp0/acc0 are optional for the caller but the kernel always writes them: park them in raw_f
         // (not yet written) when the caller passed NULL.
@@ -475,6 +476,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     CompositeArgs cf{};
     cf.rays = a->rays; cf.ray_stride = a->ray_stride;
     cf.raw4 = raw_f; cf.z = z_fine; cf.n_rays = N; cf.S = SF; cf.n_importance = 0;
+    cf.white_bkgd = a->white_bkgd;
     cf.rgb = a->rgb_map; cf.disp = a->disp_map; cf.acc = a->acc_map;
     cf.z_std = nullptr; cf.z_out = nullptr; cf.z_user = a->z_vals;
     cf.vis = a->fine.visibility_weights; cf.alpha = a->fine.opacity_alpha;

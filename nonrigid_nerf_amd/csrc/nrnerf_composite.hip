@@ -68,7 +68,11 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
         if (a.z) z[k] = a.z[(size_t)ray * S + ic];
         else {
             const float t = c_lin01(ic, S);
-            z[k] = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));   // train.py:849
+            if (a.lindisp)                                                               // train.py:850-852
+                z[k] = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)),
+                                                 __fmul_rn(__fdiv_rn(1.0f, far), t)));
+            else
+                z[k] = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));   // train.py:849
         }
         const f32x4 r = *(const f32x4*)(a.raw4 + ((size_t)ray * S + ic) * 4);
         col[k][0] = r[0]; col[k][1] = r[1]; col[k][2] = r[2]; sig[k] = r[3];
@@ -110,6 +114,10 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
     }
     sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sdepth = wave_sum(sdepth); sacc = wave_sum(sacc);
     if (ray_ok && lane == 0) {
+        if (a.white_bkgd) {                                                                                   // :786-787
+            const float bg = __fsub_rn(1.0f, sacc);
+            sr = __fadd_rn(sr, bg); sg = __fadd_rn(sg, bg); sb = __fadd_rn(sb, bg);
+        }
         a.rgb[(size_t)ray * 3 + 0] = sr; a.rgb[(size_t)ray * 3 + 1] = sg; a.rgb[(size_t)ray * 3 + 2] = sb;   // :776
         a.acc[ray] = sacc;                                                                                    // :779
         const float q = sdepth / sacc;                               // 0/0 = NaN when acc == 0 ...

@@ -28,6 +28,7 @@ struct NetArgs {
     const float* rays;   int ray_stride;
     const float* latents; int lat_stride;
     const float* z;          // [N,S] sample depths, or nullptr: coarse linspace between near and far
+    int lindisp;             // coarse spacing linear in inverse depth (train.py:850-852); only read when z == nullptr
     int n_rays, S;
     const void* wstream;     // packed fragment stream of this pass (whole 16 KiB units, nrnerf_plan.h)
     const float* bias;       // [NTILES*32]
@@ -43,6 +44,8 @@ struct CompositeArgs {
     const float* rays;   int ray_stride;
     const float* raw4;       // [N,S,4]
     const float* z;          // [N,S] or nullptr: coarse linspace
+    int lindisp;             // as NetArgs::lindisp
+    int white_bkgd;          // rgb += 1 - acc (train.py:786-787)
     int n_rays, S;
     int n_importance;        // I: > 0 -> also run sample_pdf + merge and write z_out [N,S+I], z_std
     float* rgb; float* disp; float* acc;     // [N,3],[N],[N]

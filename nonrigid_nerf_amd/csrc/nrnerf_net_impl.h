@@ -581,7 +581,11 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         } else {
             const float near = rp[6], far = rp[7];
             const float t = lin01(sc, S);
-            z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));      // train.py:849
+            if (a.lindisp)                                                               // train.py:850-852
+                z = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)),
+                                              __fmul_rn(__fdiv_rn(1.0f, far), t)));
+            else
+                z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));  // train.py:849
         }
         float p[3] = {__fadd_rn(ox, __fmul_rn(dx, z)), __fadd_rn(oy, __fmul_rn(dy, z)),
                       __fadd_rn(oz, __fmul_rn(dz, z))};                                  // train.py:871-873

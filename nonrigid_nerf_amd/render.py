@@ -202,7 +202,8 @@ class Model:
 
     def render(self, rays: torch.Tensor, latents: torch.Tensor | None, N_samples: int, N_importance: int = 0,
                retraw: bool = False, detailed_output: bool = False, rigidity_cutoff=None, test_time_scaling=None,
-               removal_threshold=None, want_z_vals: bool = False, surface: bool = False) -> dict:
+               removal_threshold=None, want_z_vals: bool = False, surface: bool = False, lindisp: bool = False,
+               white_bkgd: bool = False) -> dict:
         """One ``render_rays`` worth of work on ``rays [N, 8|11]``; returns the reference's output dict."""
         N = int(rays.shape[0])
         S, I = int(N_samples), int(N_importance)
@@ -213,6 +214,7 @@ class Model:
         a = _lib.RenderArgs()
         a.struct_size = C.sizeof(_lib.RenderArgs)
         a.n_rays, a.n_samples, a.n_importance = N, S, I
+        a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
         a.rays, a.ray_stride = rays.data_ptr(), rays.shape[1]
         if self.needs_latents:
             if latents is None:
@@ -307,8 +309,8 @@ def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importanc
         return "perturb > 0 (stratified sampling draws from torch's RNG)"
     if raw_noise_std and raw_noise_std > 0.0:
         return "raw_noise_std > 0"
-    if lindisp or white_bkgd or pytest:
-        return "lindisp / white_bkgd / pytest flags"
+    if pytest:
+        return "pytest flag (numpy-seeded random numbers, train.py:863-867)"
     if ray_batch.device.type != "cuda":
         return "rays are not on a ROCm device"
     if getattr(network_fn, "use_viewdirs", False):
@@ -361,7 +363,8 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
         rigidity_cutoff=getattr(rb, "rigidity_test_time_cutoff", None) if rb is not None else None,
         test_time_scaling=getattr(rb, "test_time_scaling", None) if rb is not None else None,
         removal_threshold=getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None),
-        want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)), surface=bool(dummy_kwargs.get("_surface", False)))
+        want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)), surface=bool(dummy_kwargs.get("_surface", False)),
+        lindisp=lindisp, white_bkgd=white_bkgd)
 
 
 def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, detailed_output=False, **kwargs):

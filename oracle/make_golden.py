@@ -104,6 +104,9 @@ CASES = {
     "no_bender_64_64":  (dict(N_importance=64, ray_bending=False), 48, 32768, False, False, {}),
     "time_conditioned_64_64": (dict(N_importance=64, ray_bending=False, time_conditioned_baseline=True), 48, 32768, False, True, {}),
     "config4_deep_bender_viewdirs": (dict(N_importance=64, use_viewdirs=True, bend_depth=7), 40, 32768, True, True, {}),
+    # the two render_rays flags create_nerf always passes as False (train.py:707,715); knobs starting with "render_" are
+    # keyword overrides of the reference render() call, not module attributes
+    "lindisp_white_bkgd_64_64": (dict(N_importance=64), 48, 32768, False, True, dict(render_lindisp=True, render_white_bkgd=True)),
 }
 
 
@@ -113,6 +116,7 @@ def run_case(H, T, name, seed=0):
     scene = make_scene(cfg, seed)
     rays, latents = make_rays(n, seed, cfg)
     kw, rb, coarse, fine = reference_kwargs(H, T, scene)
+    kw.update({k[len("render_"):]: v for k, v in knobs.items() if k.startswith("render_")})
     if rb is not None:
         rb.rigidity_test_time_cutoff = knobs.get("rigidity_test_time_cutoff")
         rb.test_time_scaling = knobs.get("test_time_scaling")
@@ -188,8 +192,10 @@ def main():
         __import__("json").dump(run_checkpoint_layout(H, T), f, indent=0, sort_keys=True)
     if "--only-layout" in sys.argv:
         return
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "raygen.npz"), **run_raygen(H))
-    for name in CASES:
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--case=")]
+    if not only:
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "raygen.npz"), **run_raygen(H))
+    for name in (only or CASES):
         arrays, out = run_case(H, T, name)
         path = os.path.join(REPO, "tests", "golden", name + ".npz")
         np.savez_compressed(path, **arrays)

@@ -39,6 +39,13 @@ def load_golden(name):
     return meta, cfg, scene, rays, latents, ref
 
 
+def split_knobs(knobs: dict):
+    """meta["knobs"] of a golden case -> (module editing knobs, render_rays flag overrides such as lindisp / white_bkgd)."""
+    mod = {k: v for k, v in knobs.items() if not k.startswith("render_")}
+    flags = {k[len("render_"):]: v for k, v in knobs.items() if k.startswith("render_")}
+    return mod, flags
+
+
 # fp32-mode tolerances (SURVEY.md section 8c): absolute for bounded maps, relative for disparity.
 TOL = {
     "rgb_map": dict(atol=1e-4, rtol=0), "rgb0": dict(atol=1e-4, rtol=0),

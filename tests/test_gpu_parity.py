@@ -17,14 +17,14 @@ import torch
 from nonrigid_nerf_amd import render as R
 from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
 from oracle import nrnerf_oracle as O
-from tests.helpers import compare_dict, load_golden, psnr
+from tests.helpers import compare_dict, load_golden, psnr, split_knobs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
 def hip_render(scene, rays, latents, precision, chunk=1 << 20, retraw=False, detailed=False, knobs=None,
-               want_z=True, use_batchify=True):
+               want_z=True, use_batchify=True, flags=None):
     cfg = scene.cfg
     rb, coarse, fine = build_modules(scene, device=DEV)
     knobs = knobs or {}
@@ -38,6 +38,7 @@ def hip_render(scene, rays, latents, precision, chunk=1 << 20, retraw=False, det
     kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples,
               N_importance=cfg.N_importance, perturb=0.0, raw_noise_std=0.0, white_bkgd=False, lindisp=False,
               retraw=retraw, ray_bender=rb, _want_z_vals=want_z)
+    kw.update(flags or {})                              # render_rays flags: lindisp, white_bkgd
     api = {"ray_bending_latents": latents.to(DEV)}
     with torch.no_grad():
         if use_batchify:
@@ -48,7 +49,7 @@ def hip_render(scene, rays, latents, precision, chunk=1 << 20, retraw=False, det
     return {k: v.cpu() for k, v in out.items()}
 
 
-def oracle_fine_given_z(scene, rays, latents, z_vals, knobs=None, detailed=False):
+def oracle_fine_given_z(scene, rays, latents, z_vals, knobs=None, detailed=False, white_bkgd=False):
     """The oracle's fine pass evaluated at given merged depths (train.py:921-950)."""
     cfg = scene.cfg
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
@@ -57,7 +58,7 @@ def oracle_fine_given_z(scene, rays, latents, z_vals, knobs=None, detailed=False
     viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
     out = O.query_network(pts, viewdirs, latents, net, scene.bender, cfg, knobs, detailed)
     raw, det = out if detailed else (out, {})
-    rgb, disp, acc, alpha, w, _ = O.composite(raw, z_vals, rays_d)
+    rgb, disp, acc, alpha, w, _ = O.composite(raw, z_vals, rays_d, white_bkgd)
     res = dict(rgb_map=rgb, disp_map=disp, acc_map=acc, raw=raw)
     if detailed:
         res.update(fine_visibility_weights=w, fine_opacity_alpha=alpha, **{"fine_" + k: v for k, v in det.items()})
@@ -76,11 +77,12 @@ COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "
 
 @pytest.mark.parametrize("name", ["coarse_only_1k", "headline_64_128", "detailed_64_128", "ragged_chunks",
                                   "knobs_64_64", "no_bender_64_64", "viewdirs_64_64", "config4_deep_bender_viewdirs",
-                                  "time_conditioned_64_64"])
+                                  "time_conditioned_64_64", "lindisp_white_bkgd_64_64"])
 def test_fp32_mode_matches_reference_golden(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
+    meta["knobs"], flags = split_knobs(meta["knobs"])
     got = hip_render(scene, rays, latents, "f32", chunk=meta["chunk"], retraw=bool(meta["retraw"]),
-                     detailed=bool(meta["detailed"]), knobs=meta["knobs"])
+                     detailed=bool(meta["detailed"]), knobs=meta["knobs"], flags=flags)
     assert set(k for k in got if not k.startswith("_")) == set(ref.keys()), \
         (sorted(set(got) ^ set(ref.keys())))
     for k in ref:
@@ -93,22 +95,28 @@ def test_fp32_mode_matches_reference_golden(name):
         fails += compare_dict(got, ref, keys=[k for k in COARSE_KEYS if k in ref])
         # 2. merged depths: identical up to rounding for almost every sample
         zo = O.batchify_rays(rays, latents, scene, chunk=meta["chunk"], knobs=O.Knobs(**meta["knobs"]),
-                             detailed_output=bool(meta["detailed"]))["_z_vals"]   # the removal knob only acts when detailed
+                             detailed_output=bool(meta["detailed"]), **flags)["_z_vals"]   # the removal knob only acts when detailed
         zg = got["_z_vals"]
         assert (zg[:, 1:] >= zg[:, :-1]).all(), "merged depths are not sorted"
         moved = ((zg - zo).abs() > 2e-5).float().mean().item()
         assert moved < 0.01, f"{moved:.4f} of merged depths differ from the oracle"
-        assert float((zg - zo).abs().max()) < 1.1 / (cfg.N_samples - 1), "a depth moved by more than one coarse bin"
-        fails += compare_dict(got, ref, keys=["z_std"], frac_ok=0.1, outlier_atol=1e-2)
+        widest_bin = (cfg.far - cfg.near) if flags.get("lindisp") else 1.1 / (cfg.N_samples - 1)   # inverse-depth bins are uneven
+        assert float((zg - zo).abs().max()) < widest_bin, "a depth moved by more than one coarse bin"
+        # inverse-depth spacing makes the far bins up to 0.9 wide, so the same few branch decisions of sample_pdf move
+        # a sample -- and the ray's colour -- much further (the reference's own fp32 vs an fp64 evaluation of this
+        # case: 2 of 48 rays differ, by up to 0.098): wider end-to-end allowance there, steps 1-3 stay tight
+        loose = dict(frac_ok=0.25, outlier_atol=0.25) if flags.get("lindisp") else dict(frac_ok=0.10, outlier_atol=2e-2)
+        fails += compare_dict(got, ref, keys=["z_std"], frac_ok=loose["frac_ok"], outlier_atol=1e-2)
         # 3. fine pass at the depths the GPU chose: tight
-        fine = oracle_fine_given_z(scene, rays, latents, zg, O.Knobs(**meta["knobs"]), bool(meta["detailed"]))
+        fine = oracle_fine_given_z(scene, rays, latents, zg, O.Knobs(**meta["knobs"]), bool(meta["detailed"]),
+                                   white_bkgd=bool(flags.get("white_bkgd", False)))
         if cfg.use_viewdirs and cfg.ray_bending:
             fails += compare_dict(got, fine, keys=[k for k in fine if k in got and k != "raw"])
             fails += compare_dict(got, fine, keys=["raw"], **FD_DIRS_RAW)
         else:
             fails += compare_dict(got, fine, keys=[k for k in fine if k in got])
         # 4. end to end against the reference outputs, allowing the few rays whose sample moved
-        fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], frac_ok=0.10, outlier_atol=2e-2)
+        fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], **loose)
     assert not fails, "\n".join(fails)
 
 

@@ -8,15 +8,15 @@ import pytest
 import torch
 
 from oracle import nrnerf_oracle as O
-from tests.helpers import GOLDEN_CASES, compare_dict, load_golden
+from tests.helpers import GOLDEN_CASES, compare_dict, load_golden, split_knobs
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_oracle_matches_reference_fp32(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
-    knobs = O.Knobs(**meta["knobs"])
+    mod, flags = split_knobs(meta["knobs"])
     got = O.batchify_rays(rays, latents, scene, chunk=meta["chunk"], retraw=bool(meta["retraw"]),
-                          detailed_output=bool(meta["detailed"]), knobs=knobs)
+                          detailed_output=bool(meta["detailed"]), knobs=O.Knobs(**mod), **flags)
     assert set(k for k in got if not k.startswith("_")) == set(ref.keys())
     fails = compare_dict(got, ref, tol_scale=0.02)      # 50x tighter than the GPU fp32 tolerance
     assert not fails, "\n".join(fails)
