@@ -176,7 +176,8 @@ class Model:
         handle = C.c_void_p()
         _lib.check(self.lib.nrnerf_model_create(C.byref(desc), C.byref(handle)), "nrnerf_model_create")
         self.handle = handle
-        self._ws = None
+        self._ws = {}            # stream -> workspace: concurrent renders on different streams never share scratch
+        self._ws_lock = threading.Lock()
         del keep
 
     def close(self):
@@ -186,10 +187,15 @@ class Model:
 
     __del__ = close
 
-    def _workspace(self, nbytes: int) -> torch.Tensor:
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
-        return self._ws
+    def _workspace(self, nbytes: int, stream: int) -> torch.Tensor:
+        """Scratch of the launch sequence, cached per stream (allocated while that stream is current, so the caching
+        allocator's stream-ordered reuse rule covers a later, larger re-allocation)."""
+        with self._ws_lock:
+            ws = self._ws.get(stream)
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+                self._ws[stream] = ws
+            return ws
 
     def profile_begin(self):
         _lib.check(self.lib.nrnerf_profile_begin(self.handle), "nrnerf_profile_begin")
@@ -265,11 +271,11 @@ class Model:
         if removal_threshold is not None:
             a.has_removal_threshold, a.removal_threshold = 1, float(removal_threshold)
         nbytes = self.lib.nrnerf_workspace_bytes(self.handle, N, S, I)
-        ws = self._workspace(nbytes + 256)
-        base = (ws.data_ptr() + 255) // 256 * 256
-        a.workspace, a.workspace_bytes = base, nbytes
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
+            ws = self._workspace(nbytes + 256, stream)
+            base = (ws.data_ptr() + 255) // 256 * 256
+            a.workspace, a.workspace_bytes = base, nbytes
             _lib.check(self.lib.nrnerf_render(self.handle, C.byref(a), C.c_void_p(stream)), "nrnerf_render")
         return out
 

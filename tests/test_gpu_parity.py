@@ -436,3 +436,39 @@ def test_surface_reduction_matches_host_side_reduction():
     ref0 = O.render_rays(rays[:100], latents[:100], scene0, retraw=True)
     w0 = O.composite(ref0["raw"], ref0["_z_vals"], rays[:100, 3:6])[4]
     assert (o0["median_index"].cpu().long() == O.surface_from_details(w0, torch.zeros(100, 64, 3))[0]).float().mean() > 0.97
+
+
+def test_concurrent_renders_from_two_threads_on_two_streams():
+    """SURVEY.md section 8b (threading / streams): the handle is immutable during render and the call is asynchronous on
+    the caller's current stream, so two host threads may render through the same handle on their own streams (the
+    DataParallel wrapper, train.py:310-323, runs one thread per replica).  Scratch is kept per stream."""
+    import threading
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    R.set_precision("bf16")
+    model = R.get_model(coarse, fine)
+    batches = [tuple(t.to(DEV) for t in make_rays(20000 + 7 * k, 40 + k, cfg)) for k in range(2)]
+    with torch.no_grad():
+        want = [model.render(r, l, 64, 64) for r, l in batches]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(k):
+        try:
+            s = torch.cuda.Stream(device=DEV)
+            with torch.no_grad(), torch.cuda.stream(s):
+                for _ in range(3):                       # overlapping launch sequences on both streams
+                    out = model.render(*batches[k], 64, 64)
+            s.synchronize()
+            got[k] = out
+        except Exception as e:                           # surfaced in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for k in range(2):
+        for key in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
+            assert torch.equal(torch.nan_to_num(got[k][key]), torch.nan_to_num(want[k][key])), (k, key)
