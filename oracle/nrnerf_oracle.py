@@ -55,9 +55,9 @@ def posenc(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
 
 
 def _lin(arrs, name, x, dtype):
-    w = arrs[name + ".weight"].to(dtype)
+    w = arrs[name + ".weight"].to(device=x.device, dtype=dtype)
     b = arrs.get(name + ".bias")
-    return F.linear(x, w, None if b is None else b.to(dtype))
+    return F.linear(x, w, None if b is None else b.to(device=x.device, dtype=dtype))
 
 
 def bend_points(pts, latents, bender, knobs: Knobs | None = None):
@@ -183,7 +183,7 @@ def sample_pdf_det(bins, weights, n_samples: int):
     pdf = weights / torch.sum(weights, -1, keepdim=True)                           # :655
     cdf = torch.cumsum(pdf, -1)                                                    # :656
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)                     # :657-659
-    u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=torch.float32).to(cdf.dtype)   # :663
+    u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=torch.float32).to(cdf)   # :663
     u = u.expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()                  # :664, 680
     inds = torch.searchsorted(cdf, u, right=False)                                 # :681
     below = torch.clamp(inds - 1, min=0)                                           # :683
@@ -213,7 +213,7 @@ def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=Fals
     rays_o, rays_d = rb[:, 0:3], rb[:, 3:6]                                        # :842
     viewdirs = rb[:, -3:] if rb.shape[-1] > 8 else None                            # :843
     near, far = rb[:, 6:7], rb[:, 7:8]                                             # :844-845
-    t_vals = torch.linspace(0.0, 1.0, steps=S, dtype=torch.float32).to(dtype)      # :847
+    t_vals = torch.linspace(0.0, 1.0, steps=S, dtype=torch.float32).to(device=rb.device, dtype=dtype)      # :847
     if not lindisp:
         z_vals = near * (1.0 - t_vals) + far * t_vals                              # :849
     else:
@@ -253,6 +253,17 @@ def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=Fals
     # internal extra (not a reference key): the merged sample depths, handy for stage-wise parity
     ret["_z_vals"] = z_vals
     return ret
+
+
+def scene_on(scene, device):
+    """A shallow copy of ``scene`` with the weight arrays on ``device`` (the oracle is device-agnostic torch code: on a
+    ROCm device it is "the reference's eager ops on the GPU", a second baseline; never the product path)."""
+    import copy
+    out = copy.copy(scene)
+    for name in ("bender", "coarse", "fine"):
+        d = getattr(scene, name)
+        setattr(out, name, None if d is None else {k: v.to(device) for k, v in d.items()})
+    return out
 
 
 def batchify_rays(rays_flat, latents, scene, chunk=1024 * 32, **kw):
