@@ -168,6 +168,11 @@ int nrnerf_abi_version(void);
 const char* nrnerf_strerror(int status);
 
 int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out);
+/* Re-pack new weights of the SAME architecture / precision / device into an existing handle (e.g. after an optimiser
+ * step or load_state_dict, train.py:666-682): no allocation; ordered after work already queued on hip_stream, complete
+ * on return.  NRNERF_ERR_INVALID if the description is a different model (create a new handle then).  Must not run
+ * concurrently with nrnerf_render on the same handle from another stream. */
+int nrnerf_model_update(nrnerf_model* model, const nrnerf_model_desc* desc, void* hip_stream);
 void nrnerf_model_destroy(nrnerf_model* model);
 
 size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples,

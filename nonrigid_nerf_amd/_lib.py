@@ -87,6 +87,7 @@ EXPORTS = {
     "nrnerf_abi_version": (C.c_int, []),
     "nrnerf_strerror": (C.c_char_p, [C.c_int]),
     "nrnerf_model_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    "nrnerf_model_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrnerf_model_destroy": (None, [C.c_void_p]),
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),

@@ -226,6 +226,7 @@ double algo_macs(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
 struct PassDev {
     void* stream = nullptr;
     float* bias = nullptr;
+    size_t stream_bytes = 0, bias_floats = 0;
     double algo_flops_per_sample = 0;      // 2 * MAC
     double mfma_flops_per_sample = 0;      // issued, incl. padding
     int output_ch = 4;
@@ -249,10 +250,19 @@ struct nrnerf_model {
 namespace {
 
 int upload_pass(const PackedPass& pk, PassDev& dev) {
+    dev.stream_bytes = pk.stream.size();
+    dev.bias_floats = pk.bias.size();
     if (hipMalloc(&dev.stream, pk.stream.size()) != hipSuccess) return NRNERF_ERR_NOMEM;
     if (hipMalloc((void**)&dev.bias, pk.bias.size() * 4) != hipSuccess) return NRNERF_ERR_NOMEM;
     if (hipMemcpy(dev.stream, pk.stream.data(), pk.stream.size(), hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
     if (hipMemcpy(dev.bias, pk.bias.data(), pk.bias.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
+    return NRNERF_OK;
+}
+// new weights of the same architecture into the buffers the kernels already read (stream-ordered)
+int refresh_pass(const PackedPass& pk, PassDev& dev, hipStream_t stream) {
+    if (pk.stream.size() != dev.stream_bytes || pk.bias.size() != dev.bias_floats) return NRNERF_ERR_INVALID;
+    if (hipMemcpyAsync(dev.stream, pk.stream.data(), pk.stream.size(), hipMemcpyHostToDevice, stream) != hipSuccess) return NRNERF_ERR_HIP;
+    if (hipMemcpyAsync(dev.bias, pk.bias.data(), pk.bias.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess) return NRNERF_ERR_HIP;
     return NRNERF_OK;
 }
 void free_pass(PassDev& dev) {
@@ -350,6 +360,31 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     if (rc != NRNERF_OK) { nrnerf_model_destroy(m); return rc; }
     *out = m;
     return NRNERF_OK;
+}
+
+int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hip_stream) {
+    if (!m || !desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
+    if (desc->device != m->device || desc->precision != m->precision || (desc->bender != nullptr) != (m->has_bend != 0) ||
+        (desc->coarse->use_viewdirs != 0) != (m->views != 0) || (desc->fine != nullptr) == m->fine_is_coarse)
+        return NRNERF_ERR_INVALID;                     // a different model: create a new handle instead
+    PackedPass pc, pf;
+    int arch_id = 0, arch_f = 0;
+    int rc = pack_dispatch(*desc, *desc->coarse, pc, &arch_id);
+    if (rc != NRNERF_OK) return rc;
+    if (desc->fine) {
+        rc = pack_dispatch(*desc, *desc->fine, pf, &arch_f);
+        if (rc != NRNERF_OK) return rc;
+    }
+    if (arch_id != m->arch_id || (desc->fine && arch_f != m->arch_id)) return NRNERF_ERR_INVALID;
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(m->device) != hipSuccess) return NRNERF_ERR_HIP;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    rc = refresh_pass(pc, m->coarse, stream);
+    if (rc == NRNERF_OK && desc->fine) rc = refresh_pass(pf, m->fine, stream);
+    // the packed host images die with this call: wait until the copies have consumed them
+    if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;
+    (void)hipSetDevice(prev);
+    return rc;
 }
 
 void nrnerf_model_destroy(nrnerf_model* m) {

@@ -180,6 +180,20 @@ class Model:
         self._ws_lock = threading.Lock()
         del keep
 
+    def update(self, network_fn, network_fine=None) -> bool:
+        """Re-pack changed weights of the same architecture into this handle (``nrnerf_model_update``: no allocation,
+        ordered after the work queued on the current stream).  Returns False when the modules describe a different
+        model (the caller then builds a new handle)."""
+        desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.nrnerf_model_update(self.handle, C.byref(desc), C.c_void_p(stream))
+        del keep
+        if rc == _lib.ERR_INVALID:
+            return False
+        _lib.check(rc, "nrnerf_model_update")
+        return True
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.nrnerf_model_destroy(self.handle)
@@ -297,6 +311,9 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
         per = _cache.setdefault(network_fn, {})
         hit = per.get(key)
         if hit is not None and hit[0] == fp:
+            return hit[1]
+        if hit is not None and hit[1].update(network_fn, network_fine):       # weights changed (optimiser step,
+            per[key] = (fp, hit[1])                                            # load_state_dict): refresh in place
             return hit[1]
         model = Model(network_fn, network_fine, precision, dev)
         per[key] = (fp, model)

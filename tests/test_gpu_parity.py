@@ -472,3 +472,30 @@ def test_concurrent_renders_from_two_threads_on_two_streams():
     for k in range(2):
         for key in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
             assert torch.equal(torch.nan_to_num(got[k][key]), torch.nan_to_num(want[k][key])), (k, key)
+
+
+def test_changed_weights_are_repacked_into_the_same_handle():
+    """Weights mutated in place (optimiser step, load_state_dict: train.py:666-682) bump the parameters' version; the
+    next call must render with the new weights, through nrnerf_model_update on the existing handle."""
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    rays, latents = make_rays(512, 5, cfg)
+    rays, latents = rays.to(DEV), latents.to(DEV)
+    R.set_precision("f32")
+    kw = dict(network_fn=coarse, network_fine=fine, N_samples=64, N_importance=64,
+              additional_pixel_information={"ray_bending_latents": latents})
+    with torch.no_grad():
+        m0 = R.get_model(coarse, fine, device=DEV)
+        before = R.render_rays(rays, **kw)["rgb_map"].clone()
+        coarse.pts_linears[3].weight.mul_(1.05)
+        fine.output_linear.bias.add_(0.25)
+        rb.network[1].weight.mul_(0.9)
+        m1 = R.get_model(coarse, fine, device=DEV)
+        after = R.render_rays(rays, **kw)["rgb_map"].clone()
+        fresh = R.Model(coarse, fine, "f32", DEV)                       # packed from scratch from the modified modules
+        want = fresh.render(rays, latents, 64, 64)["rgb_map"]
+    torch.cuda.synchronize()
+    assert m1 is m0, "same architecture: the handle must be refreshed, not replaced"
+    assert (after - before).abs().max() > 1e-3, "the render did not pick up the new weights"
+    assert torch.equal(after, want)
