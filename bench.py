@@ -50,11 +50,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # NRNERF_BENCH_ONE_GPU=1 (testing aid for a 1-GPU box): every rank renders on cuda:0 and the pixels are gathered over
+    # gloo, so the multi-process path of this script can be exercised without a multi-GPU node.  Never a benchmark.
+    one_gpu = os.environ.get("NRNERF_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -76,6 +84,8 @@ def main():
     def step():
         out = R.batchify_rays(rays, api, chunk=1024 * 32, **kw)
         packed = torch.cat([out["rgb_map"], out["disp_map"][:, None], out["acc_map"][:, None]], -1)
+        if world > 1 and one_gpu:
+            return gather_pixels(packed.cpu())          # gloo has no all_gather for device tensors
         return gather_pixels(packed) if world > 1 else packed
 
     def barrier():
@@ -122,7 +132,7 @@ def main():
         res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (NOT A BENCHMARK: all ranks on one GPU, gloo)" if one_gpu else ""),
                "config": {"workload": "BASELINE config 2: example_sequence-shaped frame (512x384 = 196608 rays/GPU/step), "
                                       "64 coarse + 128 importance samples, netwidth 256, ray bender on, latent 32",
                           "rays_per_gpu_per_step": args.rays, "N_samples": 64, "N_importance": 128,
