@@ -1,7 +1,12 @@
 // Can a single wave keep the matrix pipe busy while it also issues VALU work?  (MI355X, gfx950)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/coissue_probe.hip -o /tmp/coissue_probe && /tmp/coissue_probe
-// One workgroup of 4 waves (one per SIMD) runs a loop of 4 independent v_mfma_f32_32x32x16_bf16 (8 passes = 32 cycles
-// each); K VALU instructions of one kind follow every MFMA.  Reports cycles per MFMA (s_memtime) for K = 0..8.
+// One workgroup of 4 waves (one per SIMD) or 8 waves (two per SIMD) runs a loop of 4 independent
+// v_mfma_f32_32x32x16_bf16; K instructions of one kind follow every MFMA.  Reports s_memtime ticks of SIMD time per MFMA.
+// The tick is NOT a shader cycle here (tick_rate(): the counter ran at 1447 MHz while 20 ticks = 13.8 ns = one MFMA at
+// full rate), so read the table as ratios: 20 = the matrix pipe saturated.
+// Measured: two waves per SIMD hide up to 4 VALU instructions (or 2 LDS reads + waits) per MFMA completely (20.0 ticks),
+// 6-8 cost ~50 %; a lone wave reaches 57 % of the pipe rate with bare MFMAs (35 ticks), 50 % with 4 VALU in between (40),
+// 36 % with 8 (55).  Whole chip, bare loop with constant operands: 2.38-2.40 PFLOP/s by wall clock (95 % of peak).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -19,9 +24,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                  "v_mfma_f32_32x32x16_bf16 %3, %4, %5, %3\n" VALU                            \
                  : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "a"(g0));
 
-template <int MODE, int K>
-__global__ void __launch_bounds__(256, 1) probe(unsigned long long* out, int iters) {
-    __shared__ u32x4 lds[256];
+template <int MODE, int K, int THREADS>
+__global__ void __launch_bounds__(THREADS, 1) probe(unsigned long long* out, int iters) {
+    __shared__ u32x4 lds[512];
     lds[threadIdx.x] = u32x4{1, 2, 3, 4};
     __syncthreads();
     f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
@@ -70,15 +75,50 @@ __global__ void __launch_bounds__(256, 1) probe(unsigned long long* out, int ite
 
 template <int MODE, int K> void run(unsigned long long* d, const char* name) {
     const int iters = 20000;
-    hipLaunchKernelGGL((probe<MODE, K>), dim3(1), dim3(256), 0, 0, d, iters);
-    hipLaunchKernelGGL((probe<MODE, K>), dim3(1), dim3(256), 0, 0, d, iters);
-    hipDeviceSynchronize();
-    unsigned long long h = 0;
-    hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
-    printf("%-20s K=%d VALU per MFMA: %6.1f cycles per MFMA\n", name, K, (double)h / (4.0 * iters));
+    double c[2];
+    for (int two = 0; two < 2; ++two) {          // one wave per SIMD, then two waves per SIMD running the same loop
+        if (two) { hipLaunchKernelGGL((probe<MODE, K, 512>), dim3(1), dim3(512), 0, 0, d, iters); hipLaunchKernelGGL((probe<MODE, K, 512>), dim3(1), dim3(512), 0, 0, d, iters); }
+        else { hipLaunchKernelGGL((probe<MODE, K, 256>), dim3(1), dim3(256), 0, 0, d, iters); hipLaunchKernelGGL((probe<MODE, K, 256>), dim3(1), dim3(256), 0, 0, d, iters); }
+        hipDeviceSynchronize();
+        unsigned long long h = 0;
+        hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+        c[two] = (double)h / (4.0 * iters * (two ? 2 : 1));
+    }
+    printf("%-20s K=%d per MFMA: %6.1f ticks of SIMD time per MFMA with 1 wave/SIMD, %6.1f with 2 waves/SIMD\n", name, K, c[0], c[1]);
+}
+// whole-chip rate of the bare MFMA loop by wall clock (hipEvents): 1024 workgroups of 8 waves
+static void chip_rate(unsigned long long* d) {
+    const int iters = 20000, wgs = 1024;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe<0, 0, 512>), dim3(wgs), dim3(512), 0, 0, d, iters);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((probe<0, 0, 512>), dim3(wgs), dim3(512), 0, 0, d, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)wgs * 8 * iters * 4 * 32768.0;
+    unsigned long long h = 0; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    printf("whole chip, bare MFMA loop, 2 waves/SIMD: %.1f TFLOP/s by wall clock (%.2f ms); s_memtime says %.1f ticks per MFMA of SIMD time\n",
+           flop / (ms * 1e-3) / 1e12, ms, (double)h / (4.0 * iters * 2));
+}
+// frequency of the s_memtime counter: one workgroup, long loop, ticks vs hipEvent wall time
+static void tick_rate(unsigned long long* d) {
+    const int iters = 400000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe<0, 0, 512>), dim3(1), dim3(512), 0, 0, d, 1000);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((probe<0, 0, 512>), dim3(1), dim3(512), 0, 0, d, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h = 0; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    printf("one workgroup, 2 waves/SIMD, %d iterations: %.3f ms wall, %llu s_memtime ticks -> counter runs at %.1f MHz; %.1f ns per MFMA of SIMD time\n",
+           iters, ms, h, (double)h / (ms * 1e3), ms * 1e6 / (4.0 * iters * 2));
 }
 int main() {
     unsigned long long* d; hipMalloc(&d, 64);
+    tick_rate(d);
+    chip_rate(d);
     run<0, 0>(d, "mfma only");
     run<0, 2>(d, "v_pk_max_i16"); run<0, 4>(d, "v_pk_max_i16"); run<0, 6>(d, "v_pk_max_i16"); run<0, 8>(d, "v_pk_max_i16");
     run<1, 2>(d, "v_cvt_pk_bf16_f32"); run<1, 4>(d, "v_cvt_pk_bf16_f32"); run<1, 6>(d, "v_cvt_pk_bf16_f32"); run<1, 8>(d, "v_cvt_pk_bf16_f32");
