@@ -43,8 +43,6 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gpu-eager-rays", type=int, default=0,
-                    help="also time the oracle's eager PyTorch ops ON THE GPU for this many rays (context, off by default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,8 +140,6 @@ def main():
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(scene, cfg, args.cpu_rays)
-        if world == 1 and args.gpu_eager_rays > 0:
-            res["gpu_eager_baseline"] = gpu_eager_baseline(scene, cfg, args.gpu_eager_rays, dev)
         print(json.dumps(res), flush=True)
 
     if world > 1:
@@ -182,25 +178,6 @@ def pmc_traffic(args):
             return float(json.load(f)["fine"]["hbm_bytes_per_launch"])
     except Exception:
         return None
-
-
-def gpu_eager_baseline(scene, cfg, n, dev):
-    """The oracle's PyTorch ops executed eagerly on the MI355X (what running the reference through PyTorch-ROCm amounts
-    to, minus its netchunk loop and host syncs): fp32, one chunk of ``n`` rays, weights resident on the device."""
-    from nonrigid_nerf_amd.synthetic import make_rays
-    from oracle import nrnerf_oracle as O
-    rays, latents = make_rays(n, seed=100, cfg=cfg)
-    rays, latents, sc = rays.to(dev), latents.to(dev), O.scene_on(scene, dev)
-    with torch.no_grad():
-        O.batchify_rays(rays, latents, sc, chunk=n)                    # warm-up
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            O.batchify_rays(rays, latents, sc, chunk=n)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-    return {"value": round(n / dt, 1), "unit": "rays/s", "kind": "port", "dtype": "f32",
-            "sample": f"{n} rays in one chunk, torch {torch.__version__} eager ops on the same GPU, {dt * 1e3:.1f} ms"}
 
 
 def cpu_baseline(scene, cfg, n):

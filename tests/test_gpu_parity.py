@@ -499,3 +499,39 @@ def test_changed_weights_are_repacked_into_the_same_handle():
     assert m1 is m0, "same architecture: the handle must be refreshed, not replaced"
     assert (after - before).abs().max() > 1e-3, "the render did not pick up the new weights"
     assert torch.equal(after, want)
+
+
+def test_report_eager_pytorch_on_the_same_gpu():
+    """Context number ("also report the reference eager path on the MI355X"): the oracle's PyTorch
+    ops executed eagerly on the GPU -- what running the reference through PyTorch-ROCm amounts to, minus its netchunk
+    loop and host syncs -- against the HIP path on the same rays.  Printed with `pytest -s`; the assertion only guards
+    the ordering."""
+    import time
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 0)
+    n = 32768
+    rays, latents = make_rays(n, 100, cfg)
+    rays, latents = rays.to(DEV), latents.to(DEV)
+    sc = O.scene_on(scene, DEV)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    kw = dict(network_fn=coarse, network_fine=fine, N_samples=64, N_importance=128)
+    api = {"ray_bending_latents": latents}
+
+    def rate(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return n * reps / (time.perf_counter() - t0)
+
+    with torch.no_grad():
+        eager = rate(lambda: O.batchify_rays(rays, latents, sc, chunk=n))
+        R.set_precision("f32")
+        ours32 = rate(lambda: R.batchify_rays(rays, api, **kw))
+        R.set_precision("bf16")
+        ours16 = rate(lambda: R.batchify_rays(rays, api, **kw), reps=10)
+    print(f"\n[eager torch fp32 on the GPU] {eager / 1e6:.3f} M rays/s; HIP path: f32 mode {ours32 / 1e6:.3f} M rays/s "
+          f"({ours32 / eager:.1f}x), bf16 mode {ours16 / 1e6:.3f} M rays/s ({ours16 / eager:.1f}x)")
+    assert ours32 > eager and ours16 > 5 * eager
