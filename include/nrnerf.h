@@ -152,6 +152,13 @@ typedef struct nrnerf_render_args {
     /* render_rays' remaining deterministic flags (create_nerf passes False for both, train.py:707,715) */
     int32_t lindisp;            /* coarse depths linear in inverse depth            train.py:850-852 */
     int32_t white_bkgd;         /* rgb_map (and rgb0) += 1 - acc_map                train.py:786-787 */
+    /* The stochastic branches of render_rays (perturb > 0, raw_noise_std > 0), made deterministic: the caller draws
+     * the random numbers -- in the reference's order: t_rand (train.py:860), coarse noise (:753), u (rnh:665), fine
+     * noise (:753) -- and passes them in; NULL = the deterministic branch.  All device pointers. */
+    const float* u_coarse;      /* [N, S]   uniforms in [0,1): stratified jitter of the coarse depths  train.py:855-868 */
+    const float* noise_coarse;  /* [N, S]   raw_noise_std * randn, added to sigma before the relu       train.py:753,761 */
+    const float* u_fine;        /* [N, I]   uniforms for sample_pdf instead of linspace(0,1,I)          rnh:663-665 */
+    const float* noise_fine;    /* [N, S']  as noise_coarse, fine pass */
 } nrnerf_render_args;
 
 /* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */

@@ -65,7 +65,8 @@ class RenderArgs(C.Structure):
                 ("surface_pts", C.c_void_p), ("surface_rigidity", C.c_void_p), ("median_index", C.c_void_p),
                 ("coarse", SampleOutputs), ("fine", SampleOutputs),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("lindisp", C.c_int32), ("white_bkgd", C.c_int32)]
+                ("lindisp", C.c_int32), ("white_bkgd", C.c_int32),
+                ("u_coarse", C.c_void_p), ("noise_coarse", C.c_void_p), ("u_fine", C.c_void_p), ("noise_fine", C.c_void_p)]
 
 
 class Profile(C.Structure):

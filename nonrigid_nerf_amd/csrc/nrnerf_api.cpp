@@ -406,6 +406,7 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
     size_t b = align_up(N * S * 4 * sizeof(float), 256);
     if (n_importance > 0) b += align_up(N * SF * sizeof(float), 256) + align_up(N * SF * 4 * sizeof(float), 256);
     b += align_up(N * SF * 4 * sizeof(float), 256);      // bent point + rigidity of the final pass (surface reduction)
+    b += align_up(N * S * sizeof(float), 256);           // jittered coarse depths (perturb > 0)
     return b;
 }
 
@@ -431,7 +432,11 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         raw_f = (float*)ws; ws += align_up((size_t)N * SF * 4 * sizeof(float), 256);
     }
     const bool surface = a->surface_pts || a->surface_rigidity || a->median_index;
-    float* bent4 = surface ? (float*)ws : nullptr;
+    float* bent4 = (float*)ws;
+    ws += align_up((size_t)N * SF * 4 * sizeof(float), 256);
+    float* z_coarse = (float*)ws;
+    if (!surface) bent4 = nullptr;
+    if ((a->u_fine || a->noise_fine) && I == 0) return NRNERF_ERR_INVALID;
 
     Knobs kn{};
     kn.has_cutoff = a->has_rigidity_cutoff; kn.cutoff = a->rigidity_cutoff;
@@ -458,11 +463,19 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                          o.masked_offsets, o.input_pts, o.rigidity_mask};
     };
 
+    // ---- stratified jitter of the coarse depths (perturb > 0): both coarse kernels then read explicit depths
+    const float* zc = nullptr;
+    if (a->u_coarse) {
+        JitterArgs ja{a->rays, a->ray_stride, a->u_coarse, N, S, a->lindisp, z_coarse};
+        if (launch_zjitter(ja, stream) != hipSuccess) return NRNERF_ERR_HIP;
+        zc = z_coarse;
+    }
+
     // ---- K0: coarse network
     NetArgs na{};
     na.rays = a->rays; na.ray_stride = a->ray_stride;
     na.latents = a->latents; na.lat_stride = a->latent_stride;
-    na.z = nullptr; na.lindisp = a->lindisp; na.n_rays = N; na.S = S;
+    na.z = zc; na.lindisp = a->lindisp; na.n_rays = N; na.S = S;
     na.wstream = m->coarse.stream; na.bias = m->coarse.bias;
     na.raw4 = raw_c;
     na.raw_out = (I == 0) ? a->raw : nullptr;
@@ -477,8 +490,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // ---- K1: coarse composite (+ sampling)
     CompositeArgs ca{};
     ca.rays = a->rays; ca.ray_stride = a->ray_stride;
-    ca.raw4 = raw_c; ca.z = nullptr; ca.n_rays = N; ca.S = S; ca.n_importance = I;
+    ca.raw4 = raw_c; ca.z = zc; ca.n_rays = N; ca.S = S; ca.n_importance = I;
     ca.lindisp = a->lindisp; ca.white_bkgd = a->white_bkgd;
+    ca.noise = a->noise_coarse; ca.u = a->u_fine;
     if (I > 0) {
         // rgb0/disp0/acc0 are optional for the caller but the kernel always writes them: park them in raw_f
         // (not yet written) when the caller passed NULL.
@@ -511,7 +525,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     CompositeArgs cf{};
     cf.rays = a->rays; cf.ray_stride = a->ray_stride;
     cf.raw4 = raw_f; cf.z = z_fine; cf.n_rays = N; cf.S = SF; cf.n_importance = 0;
-    cf.white_bkgd = a->white_bkgd;
+    cf.white_bkgd = a->white_bkgd; cf.noise = a->noise_fine;
     cf.rgb = a->rgb_map; cf.disp = a->disp_map; cf.acc = a->acc_map;
     cf.z_std = nullptr; cf.z_out = nullptr; cf.z_user = a->z_vals;
     cf.vis = a->fine.visibility_weights; cf.alpha = a->fine.opacity_alpha;

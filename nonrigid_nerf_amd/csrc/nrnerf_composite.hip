@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
         }
         const f32x4 r = *(const f32x4*)(a.raw4 + ((size_t)ray * S + ic) * 4);
         col[k][0] = r[0]; col[k][1] = r[1]; col[k][2] = r[2]; sig[k] = r[3];
+        if (a.noise) sig[k] = __fadd_rn(sig[k], a.noise[(size_t)ray * S + ic]);                // train.py:761
     }
     z[EPL] = __shfl_down(z[0], 1);     // first depth of the next lane
 
@@ -188,10 +189,10 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
             if (i < S) s_z[wave][i] = z[k];
         }
         __syncthreads();
-        // ---- inverse CDF at u = linspace(0,1,I) (det=True), rnh:663-696
+        // ---- inverse CDF at u = linspace(0,1,I) (det=True) or at the caller's uniforms (det=False), rnh:663-696
         float zsum = 0.f;
         for (int k = lane; k < I; k += 64) {
-            const float u = c_lin01(k, I);
+            const float u = a.u ? a.u[(size_t)ray * I + k] : c_lin01(k, I);                   // rnh:663-665
             int lo = 0, hi = nb;       // lower_bound: first idx with cdf[idx] >= u  (searchsorted right=False)
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cdf[wave][mid] < u) lo = mid + 1; else hi = mid; }
             const int below = lo - 1 > 0 ? lo - 1 : 0;                                         // :683
@@ -260,6 +261,31 @@ static hipError_t launch_epl(const CompositeArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((composite_kernel<EPL, true>), dim3(grid), dim3(RAYS_PER_WG * 64), 0, stream, a);
     else
         hipLaunchKernelGGL((composite_kernel<EPL, false>), dim3(grid), dim3(RAYS_PER_WG * 64), 0, stream, a);
+    return hipGetLastError();
+}
+
+// train.py:855-868: one thread per sample
+__global__ void __launch_bounds__(256) zjitter_kernel(const JitterArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.n_rays * a.S) return;
+    const int ray = (int)(idx / a.S), i = (int)(idx % a.S), S = a.S;
+    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    const float near = rp[6], far = rp[7];
+    auto zat = [&](int k) {
+        const float t = c_lin01(k, S);
+        if (a.lindisp)
+            return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, far), t)));
+        return __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));
+    };
+    const float zi = zat(i);
+    const float upper = (i < S - 1) ? __fmul_rn(0.5f, __fadd_rn(zat(i + 1), zi)) : zi;         // :857-858
+    const float lower = (i > 0) ? __fmul_rn(0.5f, __fadd_rn(zi, zat(i - 1))) : zi;             // :859
+    a.z_out[idx] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), a.u[idx]));              // :868
+}
+hipError_t launch_zjitter(const JitterArgs& a, hipStream_t stream) {
+    const long long n = (long long)a.n_rays * a.S;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zjitter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -46,6 +46,8 @@ struct CompositeArgs {
     const float* z;          // [N,S] or nullptr: coarse linspace
     int lindisp;             // as NetArgs::lindisp
     int white_bkgd;          // rgb += 1 - acc (train.py:786-787)
+    const float* noise;      // [N,S] added to sigma before the relu (raw_noise_std * randn, train.py:753,761) or nullptr
+    const float* u;          // [N,I] uniforms for sample_pdf (perturb > 0, run_nerf_helpers.py:665) or nullptr: linspace
     int n_rays, S;
     int n_importance;        // I: > 0 -> also run sample_pdf + merge and write z_out [N,S+I], z_std
     float* rgb; float* disp; float* acc;     // [N,3],[N],[N]
@@ -59,6 +61,15 @@ struct CompositeArgs {
     float* surf_rig;             // [N]   rigidity mask at that sample
     int* med_idx;                // [N]   its index
 };
+
+// stratified jitter of the coarse depths (train.py:855-868): z = lower + (upper - lower) * u between the mid-points
+struct JitterArgs {
+    const float* rays;   int ray_stride;
+    const float* u;          // [N,S] uniforms in [0,1)
+    int n_rays, S, lindisp;
+    float* z_out;            // [N,S]
+};
+hipError_t launch_zjitter(const JitterArgs& a, hipStream_t stream);
 
 struct RayGenArgs {
     float c2w[12];            // camera-to-world [3,4], row-major

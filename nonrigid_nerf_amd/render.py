@@ -15,7 +15,7 @@ Call contract mirrored:
   allocated on the rays' device.
 
 Everything is computed by ``libnrnerf_hip.so``.  Configurations the library has no kernel for
-(autograd, stochastic sampling, exact non-rigid view directions, ...) are handed back to the
+(autograd, exact non-rigid view directions, other widths, ...) are handed back to the
 *reference's own* function when one was saved by ``install``; otherwise they raise.  There is
 no CPU or PyTorch re-implementation in this package.
 """
@@ -223,7 +223,7 @@ class Model:
     def render(self, rays: torch.Tensor, latents: torch.Tensor | None, N_samples: int, N_importance: int = 0,
                retraw: bool = False, detailed_output: bool = False, rigidity_cutoff=None, test_time_scaling=None,
                removal_threshold=None, want_z_vals: bool = False, surface: bool = False, lindisp: bool = False,
-               white_bkgd: bool = False) -> dict:
+               white_bkgd: bool = False, randoms: dict | None = None) -> dict:
         """One ``render_rays`` worth of work on ``rays [N, 8|11]``; returns the reference's output dict."""
         N = int(rays.shape[0])
         S, I = int(N_samples), int(N_importance)
@@ -235,6 +235,15 @@ class Model:
         a.struct_size = C.sizeof(_lib.RenderArgs)
         a.n_rays, a.n_samples, a.n_importance = N, S, I
         a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
+        keep_alive = []
+        for key, shape in (("u_coarse", (N, S)), ("noise_coarse", (N, S)), ("u_fine", (N, I)), ("noise_fine", (N, SF))):
+            t = (randoms or {}).get(key)
+            if t is not None:
+                t = t.to(**f32).contiguous()
+                if tuple(t.shape) != shape:
+                    raise ValueError(f"{key} must have shape {shape}, got {tuple(t.shape)}")
+                keep_alive.append(t)
+                setattr(a, key, t.data_ptr())
         a.rays, a.ray_stride = rays.data_ptr(), rays.shape[1]
         if self.needs_latents:
             if latents is None:
@@ -328,10 +337,6 @@ def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importanc
     if torch.is_grad_enabled() and (ray_batch.requires_grad or (latents is not None and latents.requires_grad)
                                     or any(p.requires_grad for p in network_fn.parameters())):
         return "autograd is enabled (training path)"
-    if perturb and perturb > 0.0:
-        return "perturb > 0 (stratified sampling draws from torch's RNG)"
-    if raw_noise_std and raw_noise_std > 0.0:
-        return "raw_noise_std > 0"
     if pytest:
         return "pytest flag (numpy-seeded random numbers, train.py:863-867)"
     if ray_batch.device.type != "cuda":
@@ -381,13 +386,37 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
                    raw_noise_std=raw_noise_std, additional_pixel_information=additional_pixel_information,
                    detailed_output=detailed_output, verbose=verbose, pytest=pytest, **dummy_kwargs)
     rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
+    randoms = _draw_randoms(ray_batch, N_samples, N_importance, perturb, raw_noise_std)
     return model.render(
         ray_batch, latents, N_samples, N_importance, retraw=retraw, detailed_output=detailed_output,
         rigidity_cutoff=getattr(rb, "rigidity_test_time_cutoff", None) if rb is not None else None,
         test_time_scaling=getattr(rb, "test_time_scaling", None) if rb is not None else None,
         removal_threshold=getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None),
         want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)), surface=bool(dummy_kwargs.get("_surface", False)),
-        lindisp=lindisp, white_bkgd=white_bkgd)
+        lindisp=lindisp, white_bkgd=white_bkgd, randoms=randoms)
+
+
+def _draw_randoms(ray_batch, N_samples, N_importance, perturb, raw_noise_std):
+    """The random numbers of render_rays' stochastic branches, drawn with the reference's own calls in the reference's
+    order on the rays' device -- ``t_rand = torch.rand(z_vals.shape)`` (train.py:860), coarse ``torch.randn(raw[..., 3].shape)
+    * raw_noise_std`` (:753), ``u = torch.rand(list(cdf.shape[:-1]) + [N_importance])`` (run_nerf_helpers.py:665), fine
+    noise (:753) -- so a seeded call consumes torch's generator exactly like the reference and renders the same image."""
+    stochastic_z = bool(perturb) and perturb > 0.0
+    noisy = bool(raw_noise_std) and raw_noise_std > 0.0
+    if not (stochastic_z or noisy):
+        return None
+    n, dev = ray_batch.shape[0], ray_batch.device
+    out = {}
+    if stochastic_z:
+        out["u_coarse"] = torch.rand([n, N_samples], device=dev)
+    if noisy:
+        out["noise_coarse"] = torch.randn([n, N_samples], device=dev) * raw_noise_std
+    if N_importance > 0:
+        if stochastic_z:
+            out["u_fine"] = torch.rand([n, N_importance], device=dev)
+        if noisy:
+            out["noise_fine"] = torch.randn([n, N_samples + N_importance], device=dev) * raw_noise_std
+    return out
 
 
 def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, detailed_output=False, **kwargs):
@@ -399,6 +428,8 @@ def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, deta
     """
     n = rays_flat.shape[0]
     step = max(int(chunk), _MAX_RAYS_PER_LAUNCH)
+    if (kwargs.get("perturb") or 0) > 0 or (kwargs.get("raw_noise_std") or 0) > 0:
+        step = int(chunk)        # the chunk shapes decide which random numbers each ray gets: keep the reference's
     lat = additional_pixel_information["ray_bending_latents"] if additional_pixel_information else None
     pieces = {}
     for i in range(0, n, step):
@@ -414,7 +445,7 @@ def install(train_module, precision: str | None = None):
     """Rebind ``train_module.render_rays`` / ``.batchify_rays`` to the HIP path.
 
     The originals are kept and used only for calls the library has no kernel for (training with
-    autograd, stochastic sampling, ...).  Returns a callable that undoes the patch.
+    autograd, exact view directions, ...).  Returns a callable that undoes the patch.
     """
     _lib.load()      # fail now, loudly, if the library is missing
     if precision is not None:

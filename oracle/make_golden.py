@@ -107,6 +107,9 @@ CASES = {
     # the two render_rays flags create_nerf always passes as False (train.py:707,715); knobs starting with "render_" are
     # keyword overrides of the reference render() call, not module attributes
     "lindisp_white_bkgd_64_64": (dict(N_importance=64), 48, 32768, False, True, dict(render_lindisp=True, render_white_bkgd=True)),
+    # the stochastic branches, seeded: torch.manual_seed(render_seed) right before the reference's render() call;
+    # chunk 16 of 40 rays, so the random draws interleave across chunks exactly as in batchify_rays
+    "stochastic_64_64": (dict(N_importance=64), 40, 16, False, True, dict(render_perturb=1.0, render_raw_noise_std=0.7, render_seed=1234)),
 }
 
 
@@ -116,7 +119,9 @@ def run_case(H, T, name, seed=0):
     scene = make_scene(cfg, seed)
     rays, latents = make_rays(n, seed, cfg)
     kw, rb, coarse, fine = reference_kwargs(H, T, scene)
-    kw.update({k[len("render_"):]: v for k, v in knobs.items() if k.startswith("render_")})
+    kw.update({k[len("render_"):]: v for k, v in knobs.items() if k.startswith("render_") and k != "render_seed"})
+    if "render_seed" in knobs:
+        torch.manual_seed(knobs["render_seed"])
     if rb is not None:
         rb.rigidity_test_time_cutoff = knobs.get("rigidity_test_time_cutoff")
         rb.test_time_scaling = knobs.get("test_time_scaling")

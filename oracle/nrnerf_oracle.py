@@ -158,13 +158,16 @@ def query_network(pts, viewdirs, latents, net, bender, cfg, knobs=None, detailed
     return raw
 
 
-def composite(raw, z_vals, rays_d, white_bkgd=False):
-    """raw2outputs (raw_noise_std=0), train.py:724-789."""
+def composite(raw, z_vals, rays_d, white_bkgd=False, raw_noise_std=0.0):
+    """raw2outputs, train.py:724-789."""
     dists = z_vals[..., 1:] - z_vals[..., :-1]                                     # :743
     dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)          # :744-746
     dists = dists * torch.norm(rays_d[..., None, :], dim=-1)                       # :748
     rgb = torch.sigmoid(raw[..., :3])                                              # :750
-    alpha = 1.0 - torch.exp(-F.relu(raw[..., 3]) * dists)                          # :740-741, 761
+    noise = 0.0
+    if raw_noise_std > 0.0:
+        noise = torch.randn(raw[..., 3].shape, device=raw.device).to(raw.dtype) * raw_noise_std   # :753
+    alpha = 1.0 - torch.exp(-F.relu(raw[..., 3] + noise) * dists)                  # :740-741, 761
     trans = torch.cumprod(
         torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]   # :763-775
     weights = alpha * trans
@@ -177,14 +180,17 @@ def composite(raw, z_vals, rays_d, white_bkgd=False):
     return rgb_map, disp_map, acc_map, alpha, weights, depth_map
 
 
-def sample_pdf_det(bins, weights, n_samples: int):
-    """sample_pdf with det=True (test time), run_nerf_helpers.py:651-698."""
+def sample_pdf_det(bins, weights, n_samples: int, det: bool = True):
+    """sample_pdf, run_nerf_helpers.py:651-698 (det=True at test time: perturb == 0)."""
     weights = weights + 1e-5                                                       # :654
     pdf = weights / torch.sum(weights, -1, keepdim=True)                           # :655
     cdf = torch.cumsum(pdf, -1)                                                    # :656
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)                     # :657-659
-    u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=torch.float32).to(cdf)   # :663
-    u = u.expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()                  # :664, 680
+    if det:
+        u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=torch.float32).to(cdf)   # :663
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()              # :664, 680
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [n_samples], device=cdf.device).to(cdf.dtype)   # :665
     inds = torch.searchsorted(cdf, u, right=False)                                 # :681
     below = torch.clamp(inds - 1, min=0)                                           # :683
     above = torch.clamp(inds, max=cdf.shape[-1] - 1)                               # :684
@@ -197,8 +203,9 @@ def sample_pdf_det(bins, weights, n_samples: int):
 
 
 def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=False,
-                knobs: Knobs | None = None, dtype=torch.float32, lindisp=False, white_bkgd=False):
-    """render_rays with perturb=0, raw_noise_std=0 (train.py:792-980).
+                knobs: Knobs | None = None, dtype=torch.float32, lindisp=False, white_bkgd=False,
+                perturb=0.0, raw_noise_std=0.0):
+    """render_rays (train.py:792-980); the stochastic branches draw from torch's generator in the reference's order.
 
     ``scene`` is a ``nonrigid_nerf_amd.synthetic.Scene`` (or anything with
     ``cfg``, ``bender``, ``coarse``, ``fine``).  Output dict: same keys/shapes
@@ -219,22 +226,28 @@ def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=Fals
     else:
         z_vals = 1.0 / (1.0 / near * (1.0 - t_vals) + 1.0 / far * t_vals)          # :851
     z_vals = z_vals.expand(rb.shape[0], S)                                         # :853
+    if perturb > 0.0:
+        mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])                          # :857
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)                            # :858
+        lower = torch.cat([z_vals[..., :1], mids], -1)                             # :859
+        t_rand = torch.rand(z_vals.shape, device=z_vals.device).to(dtype)          # :860
+        z_vals = lower + (upper - lower) * t_rand                                  # :868
     pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]             # :871-873
     lat = latents.to(dtype)
     out = query_network(pts, viewdirs, lat, scene.coarse, scene.bender, cfg, knobs, detailed_output)
     raw, details = out if detailed_output else (out, None)
-    rgb_map, disp_map, acc_map, alpha, weights, _ = composite(raw, z_vals, rays_d, white_bkgd)  # :898
+    rgb_map, disp_map, acc_map, alpha, weights, _ = composite(raw, z_vals, rays_d, white_bkgd, raw_noise_std)  # :898
     ret = {}
     if I > 0:
         rgb0, disp0, acc0, alpha0, weights0 = rgb_map, disp_map, acc_map, alpha, weights   # :902-908
         z_mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])                         # :910
-        z_samples = sample_pdf_det(z_mid, weights[..., 1:-1], I)                   # :911-918
+        z_samples = sample_pdf_det(z_mid, weights[..., 1:-1], I, det=(perturb == 0.0))   # :911-918
         z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)             # :920
         pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]         # :921-923
         net = scene.fine if scene.fine is not None else scene.coarse               # :925
         out = query_network(pts, viewdirs, lat, net, scene.bender, cfg, knobs, detailed_output)
         raw, fine_details = out if detailed_output else (out, None)
-        rgb_map, disp_map, acc_map, alpha, weights, _ = composite(raw, z_vals, rays_d, white_bkgd)   # :943-950
+        rgb_map, disp_map, acc_map, alpha, weights, _ = composite(raw, z_vals, rays_d, white_bkgd, raw_noise_std)   # :943-950
     ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)                # :952
     if retraw:
         ret["raw"] = raw                                                           # :953-954

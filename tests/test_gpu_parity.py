@@ -345,7 +345,7 @@ def test_boundary_contract_errors_and_fallback():
         api = {"ray_bending_latents": lat0.to(DEV)}
         with torch.no_grad():
             out = FakeTrain.batchify_rays(rays0.to(DEV), api, network_fn=coarse, network_query_fn=None, N_samples=64,
-                                          perturb=1.0)          # stochastic sampling -> reference
+                                          pytest=True)          # numpy-seeded debug randoms (train.py:863-867) -> reference
             assert FakeTrain.calls == ["render_rays"] and out["rgb_map"].shape == (8, 3)
             out = FakeTrain.batchify_rays(rays0.to(DEV), api, network_fn=coarse, network_query_fn=None, N_samples=64,
                                           perturb=0.0)          # supported -> HIP
@@ -606,3 +606,37 @@ def test_maximum_sample_counts_vs_oracle():
             fine = oracle_fine_given_z(scene, rays, latents, got["_z_vals"])
             fails += compare_dict(got, fine, keys=["rgb_map", "disp_map", "acc_map", "raw"])
         assert not fails, (cfg_kw, "\n".join(fails))
+
+
+@pytest.mark.parametrize("perturb,noise", [(1.0, 0.0), (0.0, 0.7), (1.0, 0.7)])
+def test_stochastic_branches_consume_the_generator_like_the_reference(perturb, noise):
+    """perturb > 0 (stratified coarse depths, random sample_pdf uniforms) and raw_noise_std > 0: the boundary draws
+    the random numbers with the reference's own torch calls in the reference's order (train.py:860, 753; rnh:665), so
+    after the same manual_seed the HIP path and the oracle -- whose draw order is pinned against the seeded reference
+    golden on CPU -- see the same numbers on this device.  Chunked (3 chunks) so the interleaving is checked too."""
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(80, 9, cfg)
+    sc = O.scene_on(scene, DEV)
+    torch.manual_seed(77)
+    ref = O.batchify_rays(rays.to(DEV), latents.to(DEV), sc, chunk=32, retraw=True, perturb=perturb, raw_noise_std=noise)
+    ref = {k: v.cpu() for k, v in ref.items()}
+    torch.manual_seed(77)
+    got = hip_render(scene, rays, latents, "f32", chunk=32, retraw=True, flags=dict(perturb=perturb, raw_noise_std=noise))
+    if perturb > 0:
+        assert (got["_z_vals"][:, 1:] >= got["_z_vals"][:, :-1]).all()
+        det = hip_render(scene, rays, latents, "f32", chunk=32)
+        assert (det["_z_vals"] - got["_z_vals"]).abs().max() > 1e-4, "depths were not jittered"
+    fails = compare_dict(got, ref, keys=["rgb0", "disp0", "acc0"])
+    moved = ((got["_z_vals"] - ref["_z_vals"]).abs() > 2e-5).float().mean().item()
+    assert moved < 0.02, f"{moved:.4f} of merged depths differ from the oracle"
+    fails += compare_dict(got, ref, keys=["rgb_map", "acc_map", "z_std"], frac_ok=0.10, outlier_atol=5e-2)
+    assert not fails, "\n".join(fails)
+    # after both runs the generator must be in the same state: nothing drawn in a different amount
+    torch.manual_seed(77)
+    O.batchify_rays(rays.to(DEV), latents.to(DEV), sc, chunk=32, perturb=perturb, raw_noise_std=noise)
+    a = torch.rand(4, device=DEV)
+    torch.manual_seed(77)
+    hip_render(scene, rays, latents, "f32", chunk=32, flags=dict(perturb=perturb, raw_noise_std=noise))
+    b = torch.rand(4, device=DEV)
+    assert torch.equal(a, b)

@@ -15,6 +15,8 @@ from tests.helpers import GOLDEN_CASES, compare_dict, load_golden, split_knobs
 def test_oracle_matches_reference_fp32(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
     mod, flags = split_knobs(meta["knobs"])
+    if "seed" in flags:                      # stochastic case: the reference was seeded right before its render() call
+        torch.manual_seed(flags.pop("seed"))
     got = O.batchify_rays(rays, latents, scene, chunk=meta["chunk"], retraw=bool(meta["retraw"]),
                           detailed_output=bool(meta["detailed"]), knobs=O.Knobs(**mod), **flags)
     assert set(k for k in got if not k.startswith("_")) == set(ref.keys())
