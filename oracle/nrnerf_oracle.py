@@ -21,7 +21,9 @@ reference itself, generated in the build container by ``oracle/make_golden.py``
 them bit-for-bit-tolerance on every run.
 
 Inputs are plain tensors and ``{state_dict key: tensor}`` dicts (see
-``nonrigid_nerf_amd.synthetic``), not modules.
+``nonrigid_nerf_amd.synthetic``), not modules.  The code is device-agnostic: two GPU tests also run it on the ROCm
+device (``scene_on``) -- as the eager-PyTorch context number and to give the stochastic branches the device's own
+random stream -- still only as the checker.
 """
 from __future__ import annotations
 
