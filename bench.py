@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --rays per GPU; strong: --rays in total, sharded contiguously over the ranks "
+                         "(BASELINE config 3: one frame over 8 GPUs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,6 +71,8 @@ def main():
     from nonrigid_nerf_amd.distributed import gather_pixels
     from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
 
+    if args.scaling == "strong":                          # one frame for the whole job: ceil(n / G) rays per rank
+        args.rays = (args.rays + world - 1) // world
     cfg = SceneConfig()                                   # 64 + 128, W = 256, bender on, latent 32
     scene = make_scene(cfg, 0)
     rb, coarse, fine = build_modules(scene, device=dev)
@@ -129,7 +134,7 @@ def main():
                     "library_gemm_tflops_same_box": library_gemm_tflops(dev, args.precision) if world == 1 else None}
         res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (NOT A BENCHMARK: all ranks on one GPU, gloo)" if one_gpu else ""),
                "config": {"workload": "BASELINE config 2: example_sequence-shaped frame (512x384 = 196608 rays/GPU/step), "
                                       "64 coarse + 128 importance samples, netwidth 256, ray bender on, latent 32",
