@@ -12,12 +12,13 @@ PMC="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 timeout 250 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmcA -o a -- $PMC > $OUT/pmcA.log 2>&1
 timeout 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcB -o b -- $PMC > $OUT/pmcB.log 2>&1
 timeout 250 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA --output-format csv -d $OUT/pmcC -o c -- $PMC > $OUT/pmcC.log 2>&1
+timeout 250 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmcD -o d -- $PMC > $OUT/pmcD.log 2>&1
 grep -h '"metric"' $OUT/stats.log | cut -c1-160
 ls $OUT
 # summaries (the sqlite database itself is large and stays on the box)
 cd $R
 DB=$(find $OUT/stats -name "*.db" | head -1)
 python tools/rocprof_summary.py "$DB" > gpurun_out/${TAG}_kernel_stats.txt 2>&1
-python tools/pmc_summary.py $OUT/pmcA $OUT/pmcB $OUT/pmcC > gpurun_out/${TAG}_pmc_summary.txt 2>&1
+python tools/pmc_summary.py $OUT/pmcA $OUT/pmcB $OUT/pmcC $OUT/pmcD > gpurun_out/${TAG}_pmc_summary.txt 2>&1
 cp profiles/r01_pmc_fine.json gpurun_out/${TAG}_pmc_fine.json    # pmc_summary.py writes it in place
 find $OUT -name "*.db" -delete

@@ -53,6 +53,10 @@ def main(dirs):
             rd, wr = 2 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
             print(f"  -> HBM traffic per launch: read {rd / 1e6:.1f} MB (2 x FETCH_SIZE), write {wr / 1e6:.1f} MB, total {(rd + wr) / 1e9:.3f} GB")
             out[label]["hbm_bytes_per_launch"] = rd + wr
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+            tot = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
+            print(f"  -> L2 hit rate                       {c['TCC_HIT_sum'] / max(tot, 1):.4f}  ({tot:.4g} requests: the weight stream is "
+                  f"re-read from L2 by every workgroup pass, the rays / depths / outputs stream through once)")
     json.dump(out, open("profiles/r01_pmc_fine.json", "w"), indent=1)
 
 
