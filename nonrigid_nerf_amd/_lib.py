@@ -42,7 +42,8 @@ class BenderDesc(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("precision", C.c_int32), ("multires", C.c_int32),
                 ("multires_views", C.c_int32), ("device", C.c_int32),
-                ("bender", C.POINTER(BenderDesc)), ("coarse", C.POINTER(MlpDesc)), ("fine", C.POINTER(MlpDesc))]
+                ("bender", C.POINTER(BenderDesc)), ("coarse", C.POINTER(MlpDesc)), ("fine", C.POINTER(MlpDesc)),
+                ("exact_viewdirs", C.c_int32)]
 
 
 class SampleOutputs(C.Structure):

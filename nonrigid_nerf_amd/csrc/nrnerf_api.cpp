@@ -237,7 +237,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 struct nrnerf_model {
-    int device = 0, precision = 0, has_bend = 0, views = 0, arch_id = 0, needs_latents = 0, num_cus = 0, latent_size = 0;
+    int device = 0, precision = 0, has_bend = 0, views = 0, arch_id = 0, needs_latents = 0, num_cus = 0, latent_size = 0, exact = 0;
     PassDev coarse, fine;
     bool fine_is_coarse = false;
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
@@ -337,6 +337,8 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     m->has_bend = desc->bender != nullptr;
     m->views = desc->coarse->use_viewdirs != 0;
     m->arch_id = arch_id;
+    m->exact = desc->exact_viewdirs != 0 && m->has_bend && m->views;     // only meaningful with bender + view-dependent head
+    if (m->exact && arch_id != 0) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_UNSUPPORTED; }
     m->needs_latents = m->has_bend || desc->coarse->time_conditioned;
     m->latent_size = desc->bender ? desc->bender->latent_size : 0;
     hipDeviceProp_t prop;
@@ -365,7 +367,8 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
 int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hip_stream) {
     if (!m || !desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
     if (desc->device != m->device || desc->precision != m->precision || (desc->bender != nullptr) != (m->has_bend != 0) ||
-        (desc->coarse->use_viewdirs != 0) != (m->views != 0) || (desc->fine != nullptr) == m->fine_is_coarse)
+        (desc->coarse->use_viewdirs != 0) != (m->views != 0) || (desc->fine != nullptr) == m->fine_is_coarse ||
+        ((desc->exact_viewdirs != 0 && m->has_bend && m->views) != (m->exact != 0)))
         return NRNERF_ERR_INVALID;                     // a different model: create a new handle instead
     PackedPass pc, pf;
     int arch_id = 0, arch_f = 0;
@@ -417,7 +420,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     if (a->n_rays == 0) return NRNERF_OK;
     if (!a->rays || a->ray_stride < 8 || !a->rgb_map || !a->disp_map || !a->acc_map) return NRNERF_ERR_INVALID;
     if (m->needs_latents && (!a->latents || a->latent_stride < 0)) return NRNERF_ERR_INVALID;
-    if (m->views && !m->has_bend && a->ray_stride < 11) return NRNERF_ERR_INVALID;   // needs the unit view directions
+    if (m->views && (!m->has_bend || m->exact) && a->ray_stride < 11) return NRNERF_ERR_INVALID;   // needs the unit view directions
     const size_t need = nrnerf_workspace_bytes(m, a->n_rays, a->n_samples, a->n_importance);
     if (!a->workspace || a->workspace_bytes < need || ((uintptr_t)a->workspace & 255)) return NRNERF_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -484,7 +487,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.ex = sample_out(a->coarse);
     na.knobs = kn;
     hipError_t e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
-                         [&] { return launch_net(m->precision, m->has_bend, m->views, m->arch_id, na, m->num_cus, stream); });
+                         [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 : m->arch_id, na, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K1: coarse composite (+ sampling)
@@ -518,7 +521,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.ex = sample_out(a->fine);
     nf.bent4 = bent4;
     e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
-              [&] { return launch_net(m->precision, m->has_bend, m->views, m->arch_id, nf, m->num_cus, stream); });
+              [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 : m->arch_id, nf, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K3: fine composite

@@ -407,8 +407,20 @@ struct Act {
 
 // dense layer of the bender: 3-term split product  Whi*xhi + 2^-11 (Whi*xlo + Wlo*xhi)  when SPLIT.  The two tiles of
 // a pair advance together, so no accumulator is written by two consecutive MFMAs.
-template <class PE, bool SPLIT, class PL, int LI, int NS, class ST, class ACT, class EPI>
-__device__ __forceinline__ void dense_b(ST& st, BiasPtr bias_lane, const ACT& in, EPI&& epi) {
+// Optional tangent operand (exact non-rigid view directions, run_nerf_helpers.py:358-385): `tin` holds d(layer input)/dt
+// for ONE direction t (forward-mode differentiation; only J . d is needed, not J).  The tangent of W x is W (dx/dt): one
+// more MFMA per (tile, slab) with the hi weight fragment (directions tolerate the f16 rounding of the weights), into its
+// own accumulator; `epi` then receives (tile, value, tangent) and applies the relu mask of the value to the tangent.
+struct NoTan {};
+template <class PE, int N>
+struct Tan {
+    typename PE::frag t[N];
+    template <int S, int E>
+    __device__ __forceinline__ void set(float v) { PE::template set<E>(t[S], v); }
+};
+template <class PE, bool SPLIT, class PL, int LI, int NS, class ST, class ACT, class EPI, class TIN = NoTan>
+__device__ __forceinline__ void dense_b(ST& st, BiasPtr bias_lane, const ACT& in, EPI&& epi, const TIN& tin = TIN{}) {
+    constexpr bool TANG = !std::is_same_v<TIN, NoTan>;
     constexpr LayerSpec spec = PL::TB.layers[LI];
     static_assert(spec.ns == NS && spec.split == (SPLIT ? 1 : 0), "bender layer mismatch between kernel and plan");
     constexpr int NT = spec.nt;
@@ -431,11 +443,12 @@ __device__ __forceinline__ void dense_b(ST& st, BiasPtr bias_lane, const ACT& in
             });
         };
         load(std::integral_constant<int, 0>{});
-        f32x16 acc[W], corr[W];
+        f32x16 acc[W], corr[W], tacc[TANG ? W : 1];
         static_for<0, W>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             acc[u] = load_bias(bias_lane, spec.tile0 + t0 + u);
             corr[u] = f32x16{};
+            if constexpr (TANG) tacc[u] = f32x16{};
         });
         static_for<0, NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -451,11 +464,14 @@ __device__ __forceinline__ void dense_b(ST& st, BiasPtr bias_lane, const ACT& in
             } else {
                 static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; acc[u] = PE::mfma(w[s & 1][u], in.hi[s], acc[u]); });
             }
+            if constexpr (TANG)
+                static_for<0, W>([&](auto uc) { constexpr int u = decltype(uc)::value; tacc[u] = PE::mfma(w[s & 1][FP * u], tin.t[s], tacc[u]); });
         });
         static_for<0, W>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             if constexpr (SPLIT) acc[u] += corr[u] * (1.0f / PE::LO_SCALE);
-            epi(std::integral_constant<int, t0 + u>{}, acc[u]);
+            if constexpr (TANG) epi(std::integral_constant<int, t0 + u>{}, acc[u], tacc[u]);
+            else epi(std::integral_constant<int, t0 + u>{}, acc[u]);
         });
     });
 }
@@ -466,6 +482,17 @@ __device__ __forceinline__ void pack_tile(const f32x16& acc, OUT& out) {
     static_for<0, P::SP>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         out[T * P::SP + u] = P::template from_acc<u, RELU>(acc);
+    });
+}
+// tangent through the relu: d relu(v)/dt = (v > 0) dv/dt
+template <class PE, int T, class TAN>
+__device__ __forceinline__ void pack_tan(const f32x16& acc, const f32x16& tacc, TAN& out) {
+    static_for<0, PE::SP>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        static_for<0, PE::KH>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            out.template set<T * PE::SP + u, e>(acc[u * PE::KH + e] > 0.0f ? tacc[u * PE::KH + e] : 0.0f);
+        });
     });
 }
 template <class PE, int T, class ACT>
@@ -510,8 +537,12 @@ struct Empty {
     template <class T> __device__ __forceinline__ float operator[](T) const { return 0.f; }
 };
 
-template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES>
+// EXACT (only with VIEWS && HAS_BEND): view directions = normalised J . d, J = d(bent point)/d(point), d = the ray's unit
+// direction (exact_nonrigid_viewdirs, run_nerf_helpers.py:358-385), by forward-mode differentiation through the bender
+// and rigidity MLPs inside this kernel; otherwise the finite-difference directions of the default configuration.
+template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES, bool EXACT = false>
 __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(const NetArgs a) {
+    static_assert(!EXACT || (VIEWS && HAS_BEND), "exact directions differentiate the bender");
     using PL = Plan<P, A, HAS_BEND, VIEWS>;
     using frag = typename P::frag;                                                   // hidden activations
     using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;                      // encodings, bender (nrnerf_plan.h frag_is_f16)
@@ -599,6 +630,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         NRN_TACC(1, t_pass);
         const unsigned long long t_bend = NRN_NOW();
         float rig_mask = 0.0f;
+        float jd[3] = {0.f, 0.f, 0.f};             // EXACT: J . d
         if constexpr (HAS_BEND) {
             constexpr int NS_BIN = PL::NS_BIN, NS_RIN = PL::NS_RIN;
             constexpr int NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
@@ -623,6 +655,50 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             });
             // ---- offset MLP (run_nerf_helpers.py:525-541)
             Act<PE, NB, SPLIT> ba, bb;
+            float off[3], doff[3] = {0.f, 0.f, 0.f}, dlogit = 0.0f;
+            float dvec[3] = {0.f, 0.f, 0.f};
+            if constexpr (EXACT) { dvec[0] = rp[8]; dvec[1] = rp[9]; dvec[2] = rp[10]; }      // unbent unit direction (train.py:380, 397)
+            auto tangent_in = [&](auto& tin, auto nslab) {      // d(input)/dt: t = d in the xyz slots, 0 elsewhere
+                static_for<0, decltype(nslab)::value>([&](auto sc_) {
+                    constexpr int s = decltype(sc_)::value;
+                    static_for<0, KH>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        constexpr int i0 = (2 * s) * KH + e, i1 = (2 * s + 1) * KH + e;
+                        const float v0 = (i0 < 3) ? dvec[i0 < 3 ? i0 : 0] : 0.0f;
+                        const float v1 = (i1 < 3) ? dvec[i1 < 3 ? i1 : 0] : 0.0f;
+                        tin.template set<s, e>(h ? v1 : v0);
+                    });
+                });
+            };
+            if constexpr (EXACT) {
+                Tan<PE, NS_BIN> tin;
+                tangent_in(tin, std::integral_constant<int, NS_BIN>{});
+                Tan<PE, NB> ta, tb;
+                dense_b<PE, SPLIT, PL, PL::L_BEND0, NS_BIN>(st, bias_lane, bin, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                    pack_act<PE, decltype(tc)::value>(acc, ba);
+                    pack_tan<PE, decltype(tc)::value>(acc, tacc, ta);
+                }, tin);
+                static_for<1, A::BD - 1>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i % 2 == 1) {
+                        dense_b<PE, SPLIT, PL, PL::L_BEND0 + i, NB>(st, bias_lane, ba, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                            pack_act<PE, decltype(tc)::value>(acc, bb);
+                            pack_tan<PE, decltype(tc)::value>(acc, tacc, tb);
+                        }, ta);
+                    } else {
+                        dense_b<PE, SPLIT, PL, PL::L_BEND0 + i, NB>(st, bias_lane, bb, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                            pack_act<PE, decltype(tc)::value>(acc, ba);
+                            pack_tan<PE, decltype(tc)::value>(acc, tacc, ta);
+                        }, tb);
+                    }
+                });
+                auto take_off_t = [&](auto, const f32x16& acc, const f32x16& tacc) {
+                    off[0] = acc[0]; off[1] = acc[1]; off[2] = acc[2];
+                    doff[0] = tacc[0]; doff[1] = tacc[1]; doff[2] = tacc[2];
+                };
+                if constexpr ((A::BD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, bb, take_off_t, tb);
+                else dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, ba, take_off_t, ta);
+            } else {
             dense_b<PE, SPLIT, PL, PL::L_BEND0, NS_BIN>(st, bias_lane, bin, [&](auto tc, const f32x16& acc) {
                 pack_act<PE, decltype(tc)::value>(acc, ba);
             });
@@ -638,10 +714,10 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                     });
                 }
             });
-            float off[3];
             auto take_off = [&](auto, const f32x16& acc) { off[0] = acc[0]; off[1] = acc[1]; off[2] = acc[2]; };
             if constexpr ((A::BD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, bb, take_off);
             else dense_b<PE, SPLIT, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, ba, take_off);
+            }
             // ---- rigidity MLP (run_nerf_helpers.py:545-561); input = xyz only
             Act<PE, NS_RIN, SPLIT> rin;
             auto rinval = [&](auto idxc) -> float {
@@ -659,6 +735,33 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                 });
             });
             Act<PE, NR, SPLIT> ra, rb;
+            float logit;
+            if constexpr (EXACT) {
+                Tan<PE, NS_RIN> trin;
+                tangent_in(trin, std::integral_constant<int, NS_RIN>{});
+                Tan<PE, NR> tra, trb;
+                dense_b<PE, SPLIT, PL, PL::L_RIG0, NS_RIN>(st, bias_lane, rin, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                    pack_act<PE, decltype(tc)::value>(acc, ra);
+                    pack_tan<PE, decltype(tc)::value>(acc, tacc, tra);
+                }, trin);
+                static_for<1, A::RD - 1>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i % 2 == 1) {
+                        dense_b<PE, SPLIT, PL, PL::L_RIG0 + i, NR>(st, bias_lane, ra, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                            pack_act<PE, decltype(tc)::value>(acc, rb);
+                            pack_tan<PE, decltype(tc)::value>(acc, tacc, trb);
+                        }, tra);
+                    } else {
+                        dense_b<PE, SPLIT, PL, PL::L_RIG0 + i, NR>(st, bias_lane, rb, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                            pack_act<PE, decltype(tc)::value>(acc, ra);
+                            pack_tan<PE, decltype(tc)::value>(acc, tacc, tra);
+                        }, trb);
+                    }
+                });
+                auto take_logit_t = [&](auto, const f32x16& acc, const f32x16& tacc) { logit = acc[0]; dlogit = tacc[0]; };
+                if constexpr ((A::RD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, rb, take_logit_t, trb);
+                else dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, ra, take_logit_t, tra);
+            } else {
             dense_b<PE, SPLIT, PL, PL::L_RIG0, NS_RIN>(st, bias_lane, rin, [&](auto tc, const f32x16& acc) {
                 pack_act<PE, decltype(tc)::value>(acc, ra);
             });
@@ -674,13 +777,21 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                     });
                 }
             });
-            float logit;
             auto take_logit = [&](auto, const f32x16& acc) { logit = acc[0]; };
             if constexpr ((A::RD - 2) % 2 == 1) dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, rb, take_logit);
             else dense_b<PE, SPLIT, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, ra, take_logit);
+            }
 
-            rig_mask = (tanhf(logit) + 1.0f) / 2.0f;                                  // rnh:559-561
-            if (a.knobs.has_cutoff && rig_mask <= a.knobs.cutoff) rig_mask = 0.0f;    // rnh:563-564
+            const float th = tanhf(logit);
+            rig_mask = (th + 1.0f) / 2.0f;                                            // rnh:559-561
+            float dmask = EXACT ? (1.0f - th * th) * 0.5f * dlogit : 0.0f;           // d mask / dt
+            if (a.knobs.has_cutoff && rig_mask <= a.knobs.cutoff) { rig_mask = 0.0f; dmask = 0.0f; }   // rnh:563-564 (assignment: no gradient)
+            if constexpr (EXACT) {
+                // bent = p + s * mask * off  =>  J . d = d + s * (dmask * off + mask * doff)        (rnh:567-570)
+                const float sc_ = a.knobs.has_scaling ? a.knobs.scaling : 1.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) jd[c] = dvec[c] + sc_ * (dmask * off[c] + rig_mask * doff[c]);
+            }
             float mo[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -708,7 +819,11 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         efrag encv[VIEWS ? NS_ENCV : 1];
         if constexpr (VIEWS) {
             float dirv[3];
-            if constexpr (HAS_BEND) {
+            if constexpr (EXACT) {
+                const float nrm = sqrtf(jd[0] * jd[0] + jd[1] * jd[1] + jd[2] * jd[2]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dirv[c] = __fadd_rn(__fdiv_rn(jd[c], nrm), 0.000001f);   // rnh:374-378: eps outside the division
+            } else if constexpr (HAS_BEND) {
                 if (j == 31 && h == 0) {
                     float* mb = mailbox + ((iter & 1) * WAVES + wave) * 4;
                     mb[0] = p[0]; mb[1] = p[1]; mb[2] = p[2];
@@ -890,11 +1005,11 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 // ------------------------------------------------------------------------------------------
 // launch (one explicit instantiation per translation unit, see nrnerf_net_inst.hip)
 // ------------------------------------------------------------------------------------------
-template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES>
+template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES, bool EXACT = false>
 static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) {
     using PL = Plan<P, A, HAS_BEND, VIEWS>;
     const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * 4 * sizeof(float);
-    auto kern = net_kernel<P, A, HAS_BEND, VIEWS, WAVES>;
+    auto kern = net_kernel<P, A, HAS_BEND, VIEWS, WAVES, EXACT>;
     static bool attr_set = false;    // idempotent; racing threads set the same value
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -144,6 +144,9 @@ def build_model_desc(network_fn, network_fine, precision: str, device_index: int
         bd = _bender_desc(rb, keep)
         keep.objs.append(bd)
         desc.bender = C.pointer(bd)
+    # exact (Jacobian) view directions when the module asks for them (NeRF.approx_nonrigid_viewdirs, rnh:289-294)
+    desc.exact_viewdirs = int(rb is not None and bool(getattr(network_fn, "use_viewdirs", False))
+                              and not getattr(network_fn, "approx_nonrigid_viewdirs", True))
     return desc, keep
 
 
@@ -314,7 +317,8 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
     precision = precision or _DEFAULT_PRECISION
     rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
     dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
-    key = (id(network_fine) if network_fine is not None else None, id(rb) if rb is not None else None, precision, str(dev))
+    key = (id(network_fine) if network_fine is not None else None, id(rb) if rb is not None else None, precision, str(dev),
+           bool(getattr(network_fn, "approx_nonrigid_viewdirs", True)))
     fp = _fingerprint([network_fn, network_fine, rb])
     with _cache_lock:
         per = _cache.setdefault(network_fn, {})
@@ -343,10 +347,11 @@ def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importanc
         return "rays are not on a ROCm device"
     if getattr(network_fn, "use_viewdirs", False):
         has_bender = bool(getattr(network_fn, "ray_bender", None)) and network_fn.ray_bender[0] is not None
-        if has_bender and not getattr(network_fn, "approx_nonrigid_viewdirs", True):
-            return "exact non-rigid view directions (autograd Jacobian, run_nerf_helpers.py:358-385)"
-        if not has_bender and ray_batch.shape[-1] < 11:
+        exact = has_bender and not getattr(network_fn, "approx_nonrigid_viewdirs", True)
+        if (not has_bender or exact) and ray_batch.shape[-1] < 11:
             return "use_viewdirs without view directions in the ray batch"
+        if network_fine is not None and getattr(network_fine, "approx_nonrigid_viewdirs", True) == exact:
+            return "coarse and fine networks disagree about approx_nonrigid_viewdirs"
     if N_samples < 2 or N_samples + N_importance > 256:
         return "more than 256 samples per ray"
     a = getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None)

@@ -41,6 +41,7 @@ class SceneConfig:
     skips: tuple = (4,)
     ray_bending: bool = True
     time_conditioned_baseline: bool = False
+    approx_nonrigid_viewdirs: bool = True     # False: directions = normalised J(bent wrt xyz) . d   (rnh:358-385)
     near: float = NEAR
     far: float = FAR
 
@@ -187,6 +188,7 @@ def build_modules(scene: Scene, device="cpu", dtype=torch.float32):
                         input_ch_views=cfg.input_ch_views, output_ch=cfg.output_ch,
                         skips=cfg.skips, use_viewdirs=cfg.use_viewdirs, ray_bender=None,
                         ray_bending_latent_size=cfg.latent_size, num_ray_samples=ns,
+                        approx_nonrigid_viewdirs=cfg.approx_nonrigid_viewdirs,
                         time_conditioned_baseline=cfg.time_conditioned_baseline)
         load_named_arrays(m, arrays)
         m = m.to(device=device, dtype=dtype)

@@ -72,7 +72,7 @@ def reference_kwargs(H, T, scene):
         m = H.NeRF(D=cfg.netdepth, W=cfg.netwidth, input_ch=input_ch, output_ch=cfg.output_ch,
                    skips=list(cfg.skips), input_ch_views=input_ch_views, use_viewdirs=cfg.use_viewdirs,
                    ray_bender=rb, ray_bending_latent_size=cfg.latent_size, embeddirs_fn=embeddirs_fn,
-                   num_ray_samples=ns, approx_nonrigid_viewdirs=True,
+                   num_ray_samples=ns, approx_nonrigid_viewdirs=cfg.approx_nonrigid_viewdirs,
                    time_conditioned_baseline=cfg.time_conditioned_baseline)
         m.load_state_dict({k: v.clone() for k, v in arrays.items()}, strict=True)
         return m
@@ -109,6 +109,9 @@ CASES = {
     "lindisp_white_bkgd_64_64": (dict(N_importance=64), 48, 32768, False, True, dict(render_lindisp=True, render_white_bkgd=True)),
     # the stochastic branches, seeded: torch.manual_seed(render_seed) right before the reference's render() call;
     # chunk 16 of 40 rays, so the random draws interleave across chunks exactly as in batchify_rays
+    "exact_viewdirs_64_64": (dict(N_importance=64, use_viewdirs=True, approx_nonrigid_viewdirs=False), 40, 32768, False, True, {}),
+    "exact_viewdirs_knobs": (dict(N_importance=64, use_viewdirs=True, approx_nonrigid_viewdirs=False), 24, 32768, True, False,
+                             dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5)),
     "stochastic_64_64": (dict(N_importance=64), 40, 16, False, True, dict(render_perturb=1.0, render_raw_noise_std=0.7, render_seed=1234)),
 }
 

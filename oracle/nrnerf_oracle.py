@@ -101,6 +101,16 @@ def finite_difference_dirs(bent, samples_per_ray: int):
     return torch.cat([diff[:, :1], diff], 1).reshape(-1, 3)
 
 
+def exact_dirs(flat, lat, bender, knobs, unbent_dirs):
+    """NeRF.exact_nonrigid_viewdirs, run_nerf_helpers.py:358-385: the bent point's Jacobian wrt the straight point,
+    applied to the ray's unit direction.  Only J . d is needed, so one forward-mode product replaces the reference's
+    three reverse passes (_get_minibatch_jacobian, :81-104); same value up to fp32 rounding."""
+    with torch.enable_grad():
+        _, jd = torch.autograd.functional.jvp(lambda x: bend_points(x, lat, bender, knobs)[0], (flat,), (unbent_dirs,))
+    jd = jd.detach()
+    return jd / torch.norm(jd, dim=-1, keepdim=True) + 0.000001        # :374-378 (eps lands outside the division)
+
+
 def canonical_mlp(enc, net, cfg, enc_dirs=None, latents=None):
     """NeRF.forward after bending, run_nerf_helpers.py:272-306."""
     dt = enc.dtype
@@ -143,7 +153,10 @@ def query_network(pts, viewdirs, latents, net, bender, cfg, knobs=None, detailed
     enc = posenc(bent, cfg.multires)                               # rnh:582-584
     enc_dirs = None
     if cfg.use_viewdirs:
-        if bender is not None:
+        if bender is not None and not getattr(cfg, "approx_nonrigid_viewdirs", True):
+            d = viewdirs[:, None, :].expand(N, S, 3).reshape(-1, 3).to(dt)
+            dirs = exact_dirs(flat, lat, bender, knobs, d)         # rnh:291-294
+        elif bender is not None:
             dirs = finite_difference_dirs(bent, S)                 # rnh:288-290
         else:
             dirs = viewdirs[:, None, :].expand(N, S, 3).reshape(-1, 3).to(dt)   # train.py:73-76

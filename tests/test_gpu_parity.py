@@ -77,7 +77,8 @@ COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "
 
 @pytest.mark.parametrize("name", ["coarse_only_1k", "headline_64_128", "detailed_64_128", "ragged_chunks",
                                   "knobs_64_64", "no_bender_64_64", "viewdirs_64_64", "config4_deep_bender_viewdirs",
-                                  "time_conditioned_64_64", "lindisp_white_bkgd_64_64"])
+                                  "time_conditioned_64_64", "lindisp_white_bkgd_64_64", "exact_viewdirs_64_64",
+                                  "exact_viewdirs_knobs"])
 def test_fp32_mode_matches_reference_golden(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
     meta["knobs"], flags = split_knobs(meta["knobs"])
@@ -110,7 +111,7 @@ def test_fp32_mode_matches_reference_golden(name):
         # 3. fine pass at the depths the GPU chose: tight
         fine = oracle_fine_given_z(scene, rays, latents, zg, O.Knobs(**meta["knobs"]), bool(meta["detailed"]),
                                    white_bkgd=bool(flags.get("white_bkgd", False)))
-        if cfg.use_viewdirs and cfg.ray_bending:
+        if cfg.use_viewdirs and cfg.ray_bending and cfg.approx_nonrigid_viewdirs:
             fails += compare_dict(got, fine, keys=[k for k in fine if k in got and k != "raw"])
             fails += compare_dict(got, fine, keys=["raw"], **FD_DIRS_RAW)
         else:
@@ -545,6 +546,7 @@ VARIANT_CFGS = {
     "deep_bender_viewdirs": dict(N_importance=0, bend_depth=7, use_viewdirs=True),
     "time_conditioned":     dict(N_importance=0, ray_bending=False, time_conditioned_baseline=True),
     "time_conditioned_viewdirs": dict(N_importance=0, ray_bending=False, time_conditioned_baseline=True, use_viewdirs=True),
+    "exact_viewdirs":       dict(N_importance=0, use_viewdirs=True, approx_nonrigid_viewdirs=False),
 }
 
 
