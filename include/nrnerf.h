@@ -98,7 +98,7 @@ typedef struct nrnerf_model_desc {
     const nrnerf_mlp_desc* fine;        /* network_fine; NULL: reuse coarse (train.py:925) */
     int32_t exact_viewdirs;   /* with bender + view-dependent head: 0 = finite-difference directions (the configs' default,
                                  approx_nonrigid_viewdirs=True, rnh:316-356); 1 = normalised J . d from the bender's
-                                 Jacobian (exact_nonrigid_viewdirs, rnh:358-385), default architecture only */
+                                 Jacobian (exact_nonrigid_viewdirs, rnh:358-385) */
 } nrnerf_model_desc;
 
 typedef struct nrnerf_model nrnerf_model;   /* opaque: packed weights resident in HBM */

@@ -338,7 +338,7 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     m->views = desc->coarse->use_viewdirs != 0;
     m->arch_id = arch_id;
     m->exact = desc->exact_viewdirs != 0 && m->has_bend && m->views;     // only meaningful with bender + view-dependent head
-    if (m->exact && arch_id != 0) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_UNSUPPORTED; }
+    if (m->exact && arch_id > 1) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_UNSUPPORTED; }
     m->needs_latents = m->has_bend || desc->coarse->time_conditioned;
     m->latent_size = desc->bender ? desc->bender->latent_size : 0;
     hipDeviceProp_t prop;
@@ -487,7 +487,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.ex = sample_out(a->coarse);
     na.knobs = kn;
     hipError_t e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
-                         [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 : m->arch_id, na, m->num_cus, stream); });
+                         [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K1: coarse composite (+ sampling)
@@ -521,7 +521,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.ex = sample_out(a->fine);
     nf.bent4 = bent4;
     e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
-              [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 : m->arch_id, nf, m->num_cus, stream); });
+              [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, nf, m->num_cus, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K3: fine composite

@@ -78,7 +78,7 @@ COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "
 @pytest.mark.parametrize("name", ["coarse_only_1k", "headline_64_128", "detailed_64_128", "ragged_chunks",
                                   "knobs_64_64", "no_bender_64_64", "viewdirs_64_64", "config4_deep_bender_viewdirs",
                                   "time_conditioned_64_64", "lindisp_white_bkgd_64_64", "exact_viewdirs_64_64",
-                                  "exact_viewdirs_knobs"])
+                                  "exact_viewdirs_knobs", "config4_exact_viewdirs"])
 def test_fp32_mode_matches_reference_golden(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
     meta["knobs"], flags = split_knobs(meta["knobs"])
@@ -547,6 +547,7 @@ VARIANT_CFGS = {
     "time_conditioned":     dict(N_importance=0, ray_bending=False, time_conditioned_baseline=True),
     "time_conditioned_viewdirs": dict(N_importance=0, ray_bending=False, time_conditioned_baseline=True, use_viewdirs=True),
     "exact_viewdirs":       dict(N_importance=0, use_viewdirs=True, approx_nonrigid_viewdirs=False),
+    "deep_bender_exact_viewdirs": dict(N_importance=0, use_viewdirs=True, bend_depth=7, approx_nonrigid_viewdirs=False),
 }
 
 
