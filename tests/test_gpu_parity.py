@@ -643,3 +643,25 @@ def test_stochastic_branches_consume_the_generator_like_the_reference(perturb, n
     hip_render(scene, rays, latents, "f32", chunk=32, flags=dict(perturb=perturb, raw_noise_std=noise))
     b = torch.rand(4, device=DEV)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cfg_kw", [dict(), dict(use_viewdirs=True, N_importance=64),
+                                    dict(use_viewdirs=True, N_importance=64, approx_nonrigid_viewdirs=False)],
+                         ids=["default", "viewdirs", "viewdirs_exact"])
+def test_repeated_launches_are_bit_identical(cfg_kw):
+    """Race detector: the LDS ring hand-offs, the counted waits and the view-direction mailbox use no atomics, so the
+    same launch must reproduce itself bit for bit; a race would show up as a run-to-run difference
+    (tools/soak_determinism.py is the long version over every variant and precision)."""
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    rays, lat = make_rays(30011, 5, cfg)
+    rays, lat = rays.to(DEV), lat.to(DEV)
+    R.set_precision("bf16")
+    model = R.get_model(coarse, fine)
+    with torch.no_grad():
+        first = model.render(rays, lat, cfg.N_samples, cfg.N_importance, retraw=True)
+        for _ in range(12):
+            out = model.render(rays, lat, cfg.N_samples, cfg.N_importance, retraw=True)
+            for k in first:
+                assert torch.equal(torch.nan_to_num(out[k]), torch.nan_to_num(first[k])), k

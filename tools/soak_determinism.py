@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Race detector for the hand-synchronised kernels: the same launch repeated many times must give bit-identical
+outputs (the LDS ring hand-offs, counted waits and the view-direction mailbox have no atomics; any race shows up as a
+run-to-run difference).  python tools/soak_determinism.py [repeats]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nonrigid_nerf_amd import render as R
+from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+CASES = {
+    "default 64+128":        dict(),
+    "no bender":             dict(ray_bending=False, N_importance=64),
+    "viewdirs (finite diff)": dict(use_viewdirs=True, N_importance=64),
+    "viewdirs (exact)":      dict(use_viewdirs=True, N_importance=64, approx_nonrigid_viewdirs=False),
+    "deep bender + viewdirs": dict(use_viewdirs=True, N_importance=64, bend_depth=7),
+    "time-conditioned":      dict(ray_bending=False, time_conditioned_baseline=True, N_importance=64),
+}
+bad = 0
+for name, kw in CASES.items():
+    cfg = SceneConfig(**kw)
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = build_modules(scene, device="cuda:0")
+    for n in (50000, 3333):
+        rays, lat = make_rays(n, 5, cfg)
+        rays, lat = rays.cuda(), lat.cuda()
+        for prec in ("bf16", "f16", "f32"):
+            R.set_precision(prec)
+            model = R.get_model(coarse, fine)
+            with torch.no_grad():
+                first = model.render(rays, lat, cfg.N_samples, cfg.N_importance, retraw=True)
+                diffs = 0
+                for _ in range(reps if prec != "f32" else max(reps // 8, 2)):
+                    out = model.render(rays, lat, cfg.N_samples, cfg.N_importance, retraw=True)
+                    diffs += sum(int(not torch.equal(torch.nan_to_num(out[k]), torch.nan_to_num(first[k]))) for k in first)
+            torch.cuda.synchronize()
+            bad += diffs
+            print(f"{name:24s} n={n:6d} {prec}: {'identical' if diffs == 0 else str(diffs) + ' DIFFERENCES'}", flush=True)
+print("TOTAL differing tensors:", bad)
+sys.exit(1 if bad else 0)
