@@ -4,8 +4,9 @@
   python tools/check_isa.py [build_dir]          -> one line per kernel, exit 1 on a violated invariant
 
 Invariants the hand-placed waits of nrnerf_net_impl.h rely on (16-bit kernels, WRing::frag / ready):
-  * no scalar memory load (s_load / s_buffer_load) after the first MFMA of a kernel: SMEM returns out of order, so a
-    counted `s_waitcnt lgkmcnt(N > 0)` is only meaningful while none is in flight;
+  * no scalar memory load (s_load / s_buffer_load) after the first MFMA of a kernel or anywhere inside the persistent
+    loop (addresses at or above the target of the widest backward branch): SMEM returns out of order, so a counted
+    `s_waitcnt lgkmcnt(N > 0)` is only meaningful while none is in flight;
   * no scratch traffic: every scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the LDS-DMA queue;
   * at most 256 VGPRs (two waves per SIMD) for the 16-bit kernels.
 Also reported: MFMA count, VALU count, counted vs draining LDS waits.
@@ -39,10 +40,32 @@ def analyse(co: str) -> dict:
     ins = [l.split()[0] for l in dis.splitlines() if re.match(r"^\s+[a-z]+_", l)]
     mfma = [i for i, x in enumerate(ins) if "mfma" in x]
     first = mfma[0] if mfma else len(ins)
+    # scalar memory loads must all sit before the persistent loop
+    base = None
+    addr_of, smem_addrs, back_targets = {}, [], []
+    for l in dis.splitlines():
+        m = re.match(r"^([0-9a-f]{16}) <", l)
+        if m:
+            base = int(m.group(1), 16)
+            continue
+        m = re.search(r"//\s*([0-9A-F]{12}):", l)
+        if not m or base is None:
+            continue
+        addr = int(m.group(1), 16)
+        op = l.split()[0]
+        if op.startswith(("s_load", "s_buffer_load")):
+            smem_addrs.append(addr)
+        t = re.search(r"<[^>]*\+0x([0-9a-f]+)>", l)
+        if op.startswith(("s_cbranch", "s_branch")) and t and base + int(t.group(1), 16) <= addr:
+            back_targets.append((addr - (base + int(t.group(1), 16)), base + int(t.group(1), 16)))
+    # the persistent loop is the backward branch with the largest span (small loops before it, e.g. the bias-table
+    # copy, end in an lgkmcnt(0) long before the first counted wait)
+    loop_start = max(back_targets)[1] if back_targets else None
+    smem_in_loop = sum(a >= loop_start for a in smem_addrs) if loop_start is not None else 0
     waits = [l.split("//")[0].strip() for l in dis.splitlines() if "s_waitcnt" in l]
     lg = [int(m.group(1)) for w in waits for m in [re.search(r"lgkmcnt\((\d+)\)", w)] if m]
     return dict(meta, mfma=len(mfma), valu=sum(x.startswith("v_") and "mfma" not in x for x in ins),
-                smem_after_first_mfma=sum(x.startswith(("s_load", "s_buffer_load")) for x in ins[first:]),
+                smem_after_first_mfma=sum(x.startswith(("s_load", "s_buffer_load")) for x in ins[first:]) + smem_in_loop,
                 scratch=sum(x.startswith("scratch_") for x in ins),
                 lgkm_counted=sum(n > 0 for n in lg), lgkm_drain=sum(n == 0 for n in lg))
 
