@@ -21,12 +21,13 @@ def shard_bounds(n: int, world: int, rank: int):
     return lo, min(lo + per, n), per
 
 
-def render_sharded(render_fn, rays: torch.Tensor, latents: torch.Tensor | None, group=None):
+def render_sharded(render_fn, rays: torch.Tensor, latents: torch.Tensor | None, group=None, force_collective: bool = False):
     """Render ``rays`` cooperatively; every rank returns the full ``[n, 5]`` = (rgb, disp, acc) image.
 
     ``render_fn(rays_shard, latents_shard) -> dict`` with ``rgb_map [m,3]``, ``disp_map [m]``,
     ``acc_map [m]`` (e.g. a closure over ``nonrigid_nerf_amd.render.batchify_rays``).  Every rank
-    must pass the same ``rays`` / ``latents`` (as DataParallel's caller does on GPU0).
+    must pass the same ``rays`` / ``latents`` (as DataParallel's caller does on GPU0).  ``force_collective`` runs the
+    all-gather even in a one-rank group (exercises the RCCL path on a single-GPU box).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -38,7 +39,7 @@ def render_sharded(render_fn, rays: torch.Tensor, latents: torch.Tensor | None, 
         packed[:hi - lo, 0:3] = out["rgb_map"]
         packed[:hi - lo, 3] = out["disp_map"]
         packed[:hi - lo, 4] = out["acc_map"]
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return packed[:n]
     full = torch.empty(world * per, 5, dtype=torch.float32, device=rays.device)
     dist.all_gather_into_tensor(full, packed, group=group)

@@ -67,3 +67,46 @@ def test_shard_bounds_cover_everything_once():
                 assert hi - lo <= per
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+
+
+def _rccl_worker(port, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from nonrigid_nerf_amd import render as R
+    from nonrigid_nerf_amd.synthetic import build_modules
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = build_modules(scene, device="cuda:0")
+    rays, lat = make_rays(1000, 4, cfg)
+    rays, lat = rays.cuda(), lat.cuda()
+    R.set_precision("bf16")
+    kw = dict(network_fn=coarse, network_fine=fine, N_samples=64, N_importance=64)
+
+    def render_fn(r, l):
+        return R.batchify_rays(r, {"ray_bending_latents": l}, **kw)
+
+    with torch.no_grad():
+        img = render_sharded(render_fn, rays, lat, force_collective=True)         # all_gather_into_tensor over RCCL
+        direct = render_fn(rays, lat)
+    dist.barrier()
+    want = torch.cat([direct["rgb_map"], direct["disp_map"][:, None], direct["acc_map"][:, None]], -1)
+    ok = torch.equal(torch.nan_to_num(img), torch.nan_to_num(want))
+    torch.save({"ok": ok, "backend": dist.get_backend()}, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_path_with_one_rank_on_the_gpu(tmp_path):
+    """The collective of the multi-GPU path over the real backend (torch "nccl" = RCCL on ROCm) with a one-rank group:
+    what a 1-GPU box can exercise of SURVEY.md section 8e (the 2/4/8-GPU points are the driver's to measure)."""
+    out = os.path.join(str(tmp_path), "r.pt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    res = torch.load(out)
+    assert res["ok"] and res["backend"] == "nccl"
