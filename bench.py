@@ -66,6 +66,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:       # N processes building their synthetic scene on the host at once: do not oversubscribe the cores
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // (2 * world))))
 
     from nonrigid_nerf_amd import render as R
     from nonrigid_nerf_amd.distributed import gather_pixels
