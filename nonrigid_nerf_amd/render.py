@@ -32,6 +32,7 @@ import torch
 from . import _lib
 
 _DEFAULT_PRECISION = os.environ.get("NRNERF_PRECISION", "bf16")
+_SCAN_OUTPUTS = os.environ.get("NRNERF_SCAN_OUTPUTS") == "1"
 _fallbacks = {}          # {"render_rays": fn, "batchify_rays": fn} saved by install()
 _MAX_RAYS_PER_LAUNCH = 1 << 20
 
@@ -392,13 +393,20 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
                    detailed_output=detailed_output, verbose=verbose, pytest=pytest, **dummy_kwargs)
     rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
     randoms = _draw_randoms(ray_batch, N_samples, N_importance, perturb, raw_noise_std)
-    return model.render(
+    ret = model.render(
         ray_batch, latents, N_samples, N_importance, retraw=retraw, detailed_output=detailed_output,
         rigidity_cutoff=getattr(rb, "rigidity_test_time_cutoff", None) if rb is not None else None,
         test_time_scaling=getattr(rb, "test_time_scaling", None) if rb is not None else None,
         removal_threshold=getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None),
         want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)), surface=bool(dummy_kwargs.get("_surface", False)),
         lindisp=lindisp, white_bkgd=white_bkgd, randoms=randoms)
+    if _SCAN_OUTPUTS:
+        # the reference's per-key scan (train.py:974-978, on whenever its DEBUG global is True): one reduction and one
+        # host sync per output key per call, hence opt-in here (NRNERF_SCAN_OUTPUTS=1)
+        for k, v in ret.items():
+            if torch.isnan(v).any() or torch.isinf(v).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
 
 
 def _draw_randoms(ray_batch, N_samples, N_importance, perturb, raw_noise_std):
