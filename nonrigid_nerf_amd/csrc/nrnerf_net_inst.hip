@@ -1,14 +1,26 @@
 // nrnerf_net_inst.hip -- one instantiation of the network kernel per translation unit, so the variants
 // (precision x bender x view-dependent head) compile in parallel.  Build with
 //   -DNRN_POL=PolBF16 -DNRN_BEND=1 -DNRN_VIEWS=0 -DNRN_WAVES=8 -DNRN_ARCH=0 -DNRN_NAME=launch_net_a0_bf16_bend
+#ifndef NRN_MB
+#define NRN_MB 1
+#endif
+#if NRN_MB > 1
+#include "nrnerf_net_mb.h"
+#else
 #include "nrnerf_net_impl.h"
+#endif
 #ifndef NRN_EXACT
 #define NRN_EXACT 0
 #endif
 
 namespace nrn {
 hipError_t NRN_NAME(const NetArgs& a, int num_cus, hipStream_t stream) {
+#if NRN_MB > 1
+    static_assert(NRN_VIEWS == 0 && NRN_EXACT == 0, "two blocks per wave: no view-dependent head");
+    return launch_one_mb<NRN_POL, ArchById<NRN_ARCH>::type, (NRN_BEND != 0), NRN_WAVES, NRN_MB>(a, num_cus, stream);
+#else
     return launch_one<NRN_POL, ArchById<NRN_ARCH>::type, (NRN_BEND != 0), (NRN_VIEWS != 0), NRN_WAVES, (NRN_EXACT != 0)>(a, num_cus, stream);
+#endif
 }
 }  // namespace nrn
 

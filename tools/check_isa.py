@@ -8,7 +8,9 @@ Invariants the hand-placed waits of nrnerf_net_impl.h rely on (16-bit kernels, W
     loop (addresses at or above the target of the widest backward branch): SMEM returns out of order, so a counted
     `s_waitcnt lgkmcnt(N > 0)` is only meaningful while none is in flight;
   * no scratch traffic: every scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the LDS-DMA queue;
-  * at most 256 VGPRs (two waves per SIMD) for the 16-bit kernels.
+  * at most 256 VGPRs (two waves per SIMD) for the 16-bit kernels of nrnerf_net_impl.h; the two-blocks-per-wave kernels
+    of nrnerf_net_mb.h run one wave per SIMD: at most 512 registers, and at most one v_accvgpr copy per 3 MFMAs (more
+    means the accumulators went to AccVGPRs: the build lost -mllvm -amdgpu-mfma-vgpr-form).
 Also reported: MFMA count, VALU count, counted vs draining LDS waits.
 """
 from __future__ import annotations
@@ -65,6 +67,7 @@ def analyse(co: str) -> dict:
     waits = [l.split("//")[0].strip() for l in dis.splitlines() if "s_waitcnt" in l]
     lg = [int(m.group(1)) for w in waits for m in [re.search(r"lgkmcnt\((\d+)\)", w)] if m]
     return dict(meta, mfma=len(mfma), valu=sum(x.startswith("v_") and "mfma" not in x for x in ins),
+                mb="net_kernel_mb" in dis, accvgpr=sum("accvgpr" in x for x in ins),
                 smem_after_first_mfma=sum(x.startswith(("s_load", "s_buffer_load")) for x in ins[first:]) + smem_in_loop,
                 scratch=sum(x.startswith("scratch_") for x in ins),
                 lgkm_counted=sum(n > 0 for n in lg), lgkm_drain=sum(n == 0 for n in lg))
@@ -85,15 +88,18 @@ def check(build_dir: str) -> list[str]:
             r = analyse(co)
             print(f"{name:24s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} scratch {r['scratch']:3d} "
                   f"mfma {r['mfma']:5d} valu {r['valu']:5d} lgkm counted/drain {r['lgkm_counted']:4d}/{r['lgkm_drain']:3d} "
-                  f"smem-after-mfma {r['smem_after_first_mfma']}")
+                  f"smem-after-mfma {r['smem_after_first_mfma']}" + (f"  [2 blocks/wave, accvgpr {r['accvgpr']}]" if r["mb"] else ""))
             sixteen = "_f32_" not in "_" + name + "_"
             if sixteen:
                 if r["smem_after_first_mfma"]:
                     errors.append(f"{name}: {r['smem_after_first_mfma']} scalar memory load(s) after the first MFMA")
                 if r["scratch"] or r.get("vgpr_spill_count", 0):
                     errors.append(f"{name}: scratch traffic ({r['scratch']} instructions)")
-                if r.get("vgpr_count", 0) > 256:
-                    errors.append(f"{name}: {r['vgpr_count']} VGPRs > 256")
+                limit = 512 if r["mb"] else 256
+                if r.get("vgpr_count", 0) > limit:
+                    errors.append(f"{name}: {r['vgpr_count']} VGPRs > {limit}")
+                if r["mb"] and 3 * r["accvgpr"] > r["mfma"]:
+                    errors.append(f"{name}: {r['accvgpr']} AccVGPR copies for {r['mfma']} MFMAs (accumulators not in VGPRs?)")
     return errors
 
 
