@@ -184,18 +184,18 @@ struct WRing {
     }
     template <int V>
     __device__ __forceinline__ void issue() {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            // The offset is a compile-time constant, but hiding it from the optimiser stops LICM from hoisting
-            // one 64-bit per-lane address per (unit, piece) out of the persistent loop (134 spilled VGPR pairs,
-            // and every scratch reload drains the DMA queue with a vmcnt(0)).  Cost: s_mov + s_add/s_addc.
-            unsigned off = (unsigned)(V * UNIT + i * 1024);
-            asm volatile("" : "+s"(off));
-            const char* src = (ubase + off) + lane16;
-            char* dst = ring + (V % RING) * UNIT + wave_off + i * 1024;
+        // One address per unit: the offset is a compile-time constant, but hiding it from the optimiser stops LICM from
+        // hoisting one 64-bit per-lane address per unit out of the persistent loop (spilled VGPR pairs, and every scratch
+        // reload drains the DMA queue with a vmcnt(0)).  The pieces of a wave are 1 KiB apart in the stream and in the
+        // slot, which is what the instruction's immediate offset (added to the global and to the LDS address) expresses.
+        unsigned off = (unsigned)(V * UNIT);
+        asm volatile("" : "+s"(off));
+        const char* src = (ubase + off) + lane16;
+        char* dst = ring + (V % RING) * UNIT + wave_off;
+        static_for<0, PW>([&](auto ic) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)dst, 16, decltype(ic)::value * 1024, 0);
+        });
     }
     template <int U>
     __device__ __forceinline__ void advance() {

@@ -93,8 +93,9 @@ def check(build_dir: str) -> list[str]:
             if sixteen:
                 if r["smem_after_first_mfma"]:
                     errors.append(f"{name}: {r['smem_after_first_mfma']} scalar memory load(s) after the first MFMA")
-                if r["scratch"] or r.get("vgpr_spill_count", 0):
-                    errors.append(f"{name}: scratch traffic ({r['scratch']} instructions)")
+                # (a non-zero vgpr_spill_count with no scratch segment is a VGPR parked in a free AccVGPR: no memory traffic)
+                if r["scratch"] or r.get("private_segment_fixed_size", 0):
+                    errors.append(f"{name}: scratch traffic ({r['scratch']} instructions, {r.get('private_segment_fixed_size', 0)} B per lane)")
                 limit = 512 if r["mb"] else 256
                 if r.get("vgpr_count", 0) > limit:
                     errors.append(f"{name}: {r['vgpr_count']} VGPRs > {limit}")
