@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--use-viewdirs", action="store_true", help="BASELINE config 4: view-dependent head (not the headline config)")
+    ap.add_argument("--bend-depth", type=int, default=5, help="BASELINE config 4: deeper ray-bending MLP (5 or 7)")
+    ap.add_argument("--exact-viewdirs", action="store_true", help="with --use-viewdirs: Jacobian instead of finite-difference directions")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --rays per GPU; strong: --rays in total, sharded contiguously over the ranks "
                          "(BASELINE config 3: one frame over 8 GPUs)")
@@ -75,7 +78,8 @@ def main():
 
     if args.scaling == "strong":                          # one frame for the whole job: ceil(n / G) rays per rank
         args.rays = (args.rays + world - 1) // world
-    cfg = SceneConfig()                                   # 64 + 128, W = 256, bender on, latent 32
+    cfg = SceneConfig(use_viewdirs=args.use_viewdirs, bend_depth=args.bend_depth,      # default: 64 + 128, W = 256, bender on, latent 32
+                      approx_nonrigid_viewdirs=not args.exact_viewdirs)
     scene = make_scene(cfg, 0)
     rb, coarse, fine = build_modules(scene, device=dev)
     R.set_precision(args.precision)
@@ -139,11 +143,13 @@ def main():
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (NOT A BENCHMARK: all ranks on one GPU, gloo)" if one_gpu else ""),
                "config": {"workload": "BASELINE config 2: example_sequence-shaped frame (512x384 = 196608 rays/GPU/step), "
-                                      "64 coarse + 128 importance samples, netwidth 256, ray bender on, latent 32",
+                                      "64 coarse + 128 importance samples, netwidth 256, ray bender on, latent 32"
+                                      + (f"; NON-HEADLINE VARIANT: use_viewdirs={args.use_viewdirs}, bend_depth={args.bend_depth}, "
+                                         f"exact_viewdirs={args.exact_viewdirs}" if (args.use_viewdirs or args.bend_depth != 5) else ""),
                           "rays_per_gpu_per_step": args.rays, "N_samples": 64, "N_importance": 128,
                           "parallelism": f"rays sharded over {world} rank(s)" + (", all-gather of [rgb,disp,acc] over RCCL" if world > 1 else "")},
-               "mflop_per_ray_algorithmic": ALGO_MFLOP_PER_RAY,
-               "end_to_end_tflops": round(value * ALGO_MFLOP_PER_RAY * 1e6 / 1e12, 2),
+               "mflop_per_ray_algorithmic": round(sum(v["flops"] for v in prof.values()) / max(args.rays * args.steps, 1) / 1e6, 2),
+               "end_to_end_tflops": round(value * sum(v["flops"] for v in prof.values()) / max(args.rays * args.steps, 1) / 1e12, 2),
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(scene, cfg, args.cpu_rays)
