@@ -16,8 +16,8 @@
 namespace nrn {
 hipError_t NRN_NAME(const NetArgs& a, int num_cus, hipStream_t stream) {
 #if NRN_MB > 1
-    static_assert(NRN_VIEWS == 0 && NRN_EXACT == 0, "two blocks per wave: no view-dependent head");
-    return launch_one_mb<NRN_POL, ArchById<NRN_ARCH>::type, (NRN_BEND != 0), NRN_WAVES, NRN_MB>(a, num_cus, stream);
+    static_assert(NRN_EXACT == 0, "two blocks per wave: exact view directions stay on the one-block kernel");
+    return launch_one_mb<NRN_POL, ArchById<NRN_ARCH>::type, (NRN_BEND != 0), (NRN_VIEWS != 0), NRN_WAVES, NRN_MB>(a, num_cus, stream);
 #else
     return launch_one<NRN_POL, ArchById<NRN_ARCH>::type, (NRN_BEND != 0), (NRN_VIEWS != 0), NRN_WAVES, (NRN_EXACT != 0)>(a, num_cus, stream);
 #endif

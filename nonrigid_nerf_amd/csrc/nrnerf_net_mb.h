@@ -7,8 +7,10 @@
 //   * dense_mb: four accumulator sets per block; the epilogue of tile pair p is issued in chunks among the MFMAs of pair
 //     p+1, the last pair of a layer is finished inside the next layer, and the fragment prefetch queue runs across layers;
 //   * dense_b2: the two blocks run the bender half a layer apart, so one block's hi/lo packing overlaps the other's MFMAs.
-// No view-dependent head here (its finite-difference mailbox assumes one block per wave): those variants stay on
-// nrnerf_net_impl.h.  Same packed weight stream, same results bit for bit.
+// The view-dependent head is supported with finite-difference or ray directions (the mailbox of nrnerf_net_impl.h,
+// indexed by the block's position in the tile); the exact-direction (Jacobian) variants stay on nrnerf_net_impl.h.
+// Same packed weight stream; same results bit for bit (with finite-difference directions: up to one-ulp flips of an
+// f16-rounded direction encoding on 0.05 % of the samples).
 #pragma once
 #include "nrnerf_net_impl.h"
 
@@ -213,9 +215,8 @@ __device__ __forceinline__ void bend_drain(BendPend& pend, PEPI&& prev_epi) {
 
 #define NRN_FORB(b) static_for<0, MB>([&](auto bc_) { constexpr int b = decltype(bc_)::value;
 #define NRN_ENDB });
-template <class P, class A, bool HAS_BEND, int WAVES, int MB>
+template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES, int MB>
 __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) {
-    constexpr bool VIEWS = false;
     static_assert(MB == 2 && P::KH == 8, "two blocks per wave, 16-bit policies");
     using PL = Plan<P, A, HAS_BEND, VIEWS>;
     using frag = typename P::frag;                                                   // hidden activations
@@ -229,6 +230,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
     char* ring = smem;
     float* bias_lds = (float*)(smem + RING * P::UNIT_BYTES);
 
+    float* mailbox = bias_lds + PL::NTILES * 32;      // [2][WAVES * MB][4]: last bent point of each block (VIEWS only)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform (SGPR)
@@ -248,9 +250,19 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
     const long long nblocks = (long long)a.n_rays * bpr;
     // Block -> workgroup assignment: tiles of WAVES * MB consecutive blocks, strided over the grid; wave w of a tile owns
     // blocks w and WAVES + w of it.
-    const long long blk_begin = (long long)blockIdx.x * (WAVES * MB);
-    const long long blk_end = nblocks;
-    const long long tile_stride = (long long)gridDim.x * (WAVES * MB);
+    long long blk_begin, blk_end, tile_stride;
+    if constexpr (VIEWS) {      // contiguous whole rays per workgroup: a sample's direction needs its predecessor's bent point
+        const long long rays_per_wg = (a.n_rays + gridDim.x - 1) / gridDim.x;
+        blk_begin = (long long)blockIdx.x * rays_per_wg * bpr;
+        blk_end = blk_begin + rays_per_wg * bpr;
+        if (blk_end > nblocks) blk_end = nblocks;
+        if (blk_begin > nblocks) blk_begin = nblocks;
+        tile_stride = WAVES * MB;
+    } else {
+        blk_begin = (long long)blockIdx.x * (WAVES * MB);
+        blk_end = nblocks;
+        tile_stride = (long long)gridDim.x * (WAVES * MB);
+    }
 
 #ifdef NRN_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -404,6 +416,74 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
             if (writer[b] && a.bent4) *(f32x4*)(a.bent4 + so[b] * 4) = f32x4{p[b][0], p[b][1], p[b][2], rig_mask[b]};
         NRN_ENDB
 
+        // ---- view direction of the sample (VIEWS): finite difference of the bent points along the ray, or the ray's own
+        //      unit direction without a bender (run_nerf_helpers.py:288-290, 339-351; train.py:73-76).  Block (b, wave) is
+        //      block b * WAVES + wave of the tile, so its predecessor's mailbox slot is that index minus one.
+        constexpr int NS_ENCV = PL::NS_ENCV;
+        efrag encv[MB][VIEWS ? NS_ENCV : 1];
+        if constexpr (VIEWS) {
+            float dirv[MB][3];
+            if constexpr (HAS_BEND) {
+                NRN_FORB(b)
+                    if (j == 31 && h == 0) {
+                        float* mb = mailbox + ((iter & 1) * (WAVES * MB) + b * WAVES + wave) * 4;
+                        mb[0] = p[b][0]; mb[1] = p[b][1]; mb[2] = p[b][2];
+                    }
+                NRN_ENDB
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                NRN_FORB(b)
+                    float prev[3], next[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { prev[c] = __shfl_up(p[b][c], 1); next[c] = __shfl_down(p[b][c], 1); }
+                    const bool first_in_ray = (sidx[b] == 0);
+                    if (j == 0 && !first_in_ray) {
+                        constexpr int NV_ = WAVES * MB;
+                        const int v = b * WAVES + wave;
+                        const float* mb = (v > 0) ? mailbox + ((iter & 1) * NV_ + v - 1) * 4
+                                                  : mailbox + (((iter + 1) & 1) * NV_ + NV_ - 1) * 4;
+                        prev[0] = mb[0]; prev[1] = mb[1]; prev[2] = mb[2];
+                    }
+                    float dd[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dd[c] = first_in_ray ? __fsub_rn(next[c], p[b][c]) : __fsub_rn(p[b][c], prev[c]);
+                    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dd[0], dd[0]), __fmul_rn(dd[1], dd[1])), __fmul_rn(dd[2], dd[2])));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dirv[b][c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f));
+                NRN_ENDB
+            } else {
+                NRN_FORB(b) dirv[b][0] = rp[b][8]; dirv[b][1] = rp[b][9]; dirv[b][2] = rp[b][10]; NRN_ENDB
+            }
+            constexpr int F0V = enc_F0(A::LV);
+            constexpr int NSLOTV = NS_ENCV * KH;
+            NRN_FORB(b)
+                float evv[NSLOTV];
+#pragma unroll
+                for (int q = 0; q < NSLOTV; ++q) evv[q] = 0.0f;
+                evv[0] = h ? dirv[b][2] : dirv[b][0];
+                evv[1] = h ? 0.0f : dirv[b][1];
+                const float vscale = h ? (float)(1 << F0V) : 1.0f;
+                const float drev[3] = {dirv[b][0] * 0.15915494309189535f, dirv[b][1] * 0.15915494309189535f, dirv[b][2] * 0.15915494309189535f};
+                static_for<0, F0V>([&](auto fc) {
+                    constexpr int fl = decltype(fc)::value;
+                    static_for<0, 3>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        float sv, cv;
+                        enc_sincos<KH == 1>(dirv[b][c], drev[c], vscale * (float)(1 << fl), &sv, &cv);
+                        evv[2 + 2 * (3 * fl + c)] = sv;
+                        evv[2 + 2 * (3 * fl + c) + 1] = cv;
+                    });
+                });
+                static_for<0, NS_ENCV>([&](auto sc_) {
+                    constexpr int s = decltype(sc_)::value;
+                    static_for<0, KH>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        PE::template set<e>(encv[b][s], evv[s * KH + e]);
+                    });
+                });
+            NRN_ENDB
+        }
+
         // ---- positional encoding of the (bent) point, directly in B-operand order
         constexpr int F0 = enc_F0(A::L);
         constexpr int NSLOT = PL::NS_ENC_XYZ * KH;
@@ -473,12 +553,34 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
         float raw[MB][5];
         NRN_FORB(b) raw[b][0] = raw[b][1] = raw[b][2] = raw[b][3] = raw[b][4] = 0.f; NRN_ENDB
         constexpr bool LAST_IN_B = ((A::D - 1) % 2 == 1);       // buffer holding the trunk output
-        auto take_raw = [&](auto bc, auto, const f32x16& acc) {
-            constexpr int b = decltype(bc)::value;
-            raw[b][0] = acc[0]; raw[b][1] = acc[1]; raw[b][2] = acc[2]; raw[b][3] = acc[3]; raw[b][4] = acc[4];
-        };
-        if constexpr (LAST_IN_B) dense_mb<P, P, PL, PL::L_HEAD, NH, 0, MB, NT_W, false, true, false>(st, bias_lane, ms, hb, none, take_raw, to_hb);
-        else dense_mb<P, P, PL, PL::L_HEAD, NH, 0, MB, NT_W, false, true, false>(st, bias_lane, ms, ha, none, take_raw, to_ha);
+        if constexpr (!VIEWS) {
+            auto take_raw = [&](auto bc, auto, const f32x16& acc) {
+                constexpr int b = decltype(bc)::value;
+                raw[b][0] = acc[0]; raw[b][1] = acc[1]; raw[b][2] = acc[2]; raw[b][3] = acc[3]; raw[b][4] = acc[4];
+            };
+            if constexpr (LAST_IN_B) dense_mb<P, P, PL, PL::L_HEAD, NH, 0, MB, NT_W, false, true, false>(st, bias_lane, ms, hb, none, take_raw, to_hb);
+            else dense_mb<P, P, PL, PL::L_HEAD, NH, 0, MB, NT_W, false, true, false>(st, bias_lane, ms, ha, none, take_raw, to_ha);
+        } else {
+            // view-dependent head (run_nerf_helpers.py:284-304): alpha and feature from the trunk output, then
+            // relu(views_linear([feature, enc(dir)])) and rgb_linear; output = [rgb, alpha].  hx = trunk output, hy = free buffer.
+            auto head = [&](auto& hx, auto& hy, auto&& to_hx) {
+                auto take_alpha = [&](auto bc, auto, const f32x16& acc) { raw[decltype(bc)::value][3] = acc[0]; };
+                auto to_hy_lin = [&](auto bc, auto tc, const f32x16& acc) { pack_tile<P, false, decltype(tc)::value>(acc, hy[decltype(bc)::value]); };
+                // alpha finishes the trunk's deferred pair in its shadow and drains itself (one tile)
+                dense_mb<P, P, PL, PL::L_ALPHA, NH, 0, MB, NT_W, false, true, true>(st, bias_lane, ms, hx, none, take_alpha, to_hx);
+                dense_mb<P, P, PL, PL::L_FEAT, NH, 0, MB, 0, true, true, true>(st, bias_lane, ms, hx, none, to_hy_lin, NoEpi{});
+                constexpr int NV = (NT_W / 2) * SP;
+                frag hv[MB][NV];
+                auto to_hv = [&](auto bc, auto tc, const f32x16& acc) { pack_tile<P, true, decltype(tc)::value>(acc, hv[decltype(bc)::value]); };
+                dense_mb<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH, MB, NT_W, false, true, true>(st, bias_lane, ms, encv, hy, to_hv, to_hy_lin);
+                auto take_rgb = [&](auto bc, auto, const f32x16& acc) {
+                    constexpr int b = decltype(bc)::value;
+                    raw[b][0] = acc[0]; raw[b][1] = acc[1]; raw[b][2] = acc[2];
+                };
+                dense_mb<P, P, PL, PL::L_RGB, NV, 0, MB, 0, false, true, false>(st, bias_lane, ms, hv, none, take_rgb, NoEpi{});
+            };
+            if constexpr (LAST_IN_B) head(hb, ha, to_hb); else head(ha, hb, to_ha);
+        }
 
         NRN_TACC(4, t_trunk);
         const unsigned long long t_out = NRN_NOW();
@@ -512,11 +614,11 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
 }
 
 
-template <class P, class A, bool HAS_BEND, int WAVES, int MB>
+template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES, int MB>
 static hipError_t launch_one_mb(const NetArgs& a, int num_cus, hipStream_t stream) {
-    using PL = Plan<P, A, HAS_BEND, false>;
-    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * 4 * sizeof(float);
-    auto kern = net_kernel_mb<P, A, HAS_BEND, WAVES, MB>;
+    using PL = Plan<P, A, HAS_BEND, VIEWS>;
+    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * MB * 4 * sizeof(float);
+    auto kern = net_kernel_mb<P, A, HAS_BEND, VIEWS, WAVES, MB>;
     static bool attr_set = false;    // idempotent; racing threads set the same value
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -525,9 +627,13 @@ static hipError_t launch_one_mb(const NetArgs& a, int num_cus, hipStream_t strea
     }
     const int bpr = (a.S + 31) / 32;
     const long long nblocks = (long long)a.n_rays * bpr;
-    const long long ntiles = (nblocks + WAVES * MB - 1) / (WAVES * MB);
-    if (ntiles <= 0) return hipSuccess;
-    const int grid = (int)(ntiles < num_cus ? ntiles : num_cus);       // persistent: one 4-wave workgroup per CU
+    long long want = (nblocks + WAVES * MB - 1) / (WAVES * MB);
+    if (want <= 0) return hipSuccess;
+    if (VIEWS) {    // contiguous whole-ray ranges: no more workgroups than ray groups that fill a tile
+        const long long rays_per_tile = (WAVES * MB + bpr - 1) / bpr;
+        want = ((long long)a.n_rays + rays_per_tile - 1) / rays_per_tile;
+    }
+    const int grid = (int)(want < num_cus ? (want > 0 ? want : 1) : num_cus);       // persistent: one 4-wave workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }
