@@ -194,6 +194,31 @@ def run_checkpoint_layout(H, T):
     return layout
 
 
+GRAD_PARAMS = {"bender": ["network.4.weight", "network.0.bias", "rigidity_network.2.weight"],
+               "coarse": ["pts_linears.0.bias", "output_linear.weight"],
+               "fine": ["pts_linears.7.bias", "output_linear.weight"]}
+
+
+def run_gradients(H, T, seed=0):
+    """Reference autograd through render() (the training data term, train.py:1560-1580 restricted to rgb): gradients of
+    sum(rgb_map) + sum(rgb0) wrt a few small parameters and the latent codes -- the yardstick for a future backward pass."""
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, seed)
+    rays, latents = make_rays(16, seed, cfg)
+    kw, rb, coarse, fine = reference_kwargs(H, T, scene)
+    latents = latents.clone().requires_grad_(True)
+    rgb, disp, acc, extras = T.render(rays[:, 0:3], rays[:, 3:6], chunk=32768,
+                                      additional_pixel_information={"ray_bending_latents": latents}, **kw)
+    loss = rgb.sum() + extras["rgb0"].sum()
+    loss.backward()
+    out = {"loss": loss.detach().numpy().astype(np.float64), "grad__latents": latents.grad.numpy()}
+    for part, mod in (("bender", rb), ("coarse", coarse), ("fine", fine)):
+        params = dict(mod.named_parameters())
+        for name in GRAD_PARAMS[part]:
+            out[f"grad__{part}__{name}"] = params[name].grad.numpy()
+    return out
+
+
 def main():
     H, T = import_reference()
     os.makedirs(os.path.join(REPO, "tests", "golden"), exist_ok=True)
@@ -201,6 +226,10 @@ def main():
         __import__("json").dump(run_checkpoint_layout(H, T), f, indent=0, sort_keys=True)
     if "--only-layout" in sys.argv:
         return
+    if "--only-grads" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_64_64.npz"), **run_gradients(H, T))
+        if "--only-grads" in sys.argv:
+            return
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--case=")]
     if not only:
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "raygen.npz"), **run_raygen(H))

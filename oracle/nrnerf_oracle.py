@@ -256,7 +256,7 @@ def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=Fals
     if I > 0:
         rgb0, disp0, acc0, alpha0, weights0 = rgb_map, disp_map, acc_map, alpha, weights   # :902-908
         z_mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])                         # :910
-        z_samples = sample_pdf_det(z_mid, weights[..., 1:-1], I, det=(perturb == 0.0))   # :911-918
+        z_samples = sample_pdf_det(z_mid, weights[..., 1:-1], I, det=(perturb == 0.0)).detach()   # :911-918 (no gradient through the sample positions)
         z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)             # :920
         pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]         # :921-923
         net = scene.fine if scene.fine is not None else scene.coarse               # :925

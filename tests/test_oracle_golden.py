@@ -72,3 +72,38 @@ def test_oracle_get_rays_matches_reference():
         ro, rd = O.get_rays(c2w, intrin)
         assert torch.equal(ro, torch.from_numpy(z[f"out__rays_o_{k}"]))
         assert torch.allclose(rd, torch.from_numpy(z[f"out__rays_d_{k}"]), rtol=0, atol=1e-7)
+
+
+def test_oracle_gradients_match_reference_autograd():
+    """Groundwork for the backward pass: the oracle is differentiable torch code, and its
+    gradients of sum(rgb_map) + sum(rgb0) wrt a few parameters and the latent codes equal what the reference's own
+    autograd produced (tests/golden/gradients_64_64.npz, oracle/make_golden.py::run_gradients)."""
+    import os
+    import numpy as np
+    from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
+    from tests.helpers import GOLDEN_DIR
+    ref = np.load(os.path.join(GOLDEN_DIR, "gradients_64_64.npz"))
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(16, 0, cfg)
+    latents = latents.clone().requires_grad_(True)
+    leaves = {}
+    for part in ("bender", "coarse", "fine"):
+        d = getattr(scene, part)
+        for k in d:
+            d[k] = d[k].clone().requires_grad_(True)
+            leaves[(part, k)] = d[k]
+    out = O.render_rays(rays, latents, scene)
+    loss = out["rgb_map"].sum() + out["rgb0"].sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref["loss"])) < 1e-4 * abs(float(ref["loss"]))
+    checks = {"grad__latents": latents.grad}
+    for key in ref.files:
+        if key.startswith("grad__") and key != "grad__latents":
+            _, part, name = key.split("__", 2)
+            checks[key] = leaves[(part, name)].grad
+    for key, g in checks.items():
+        want = torch.from_numpy(ref[key])
+        scale = float(want.abs().max()) + 1e-12
+        assert g.shape == want.shape, key
+        assert float((g - want).abs().max()) <= 2e-3 * scale, (key, float((g - want).abs().max()), scale)
