@@ -188,7 +188,8 @@ void nrnerf_model_destroy(nrnerf_model* model);
 size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples,
                               int32_t n_importance);
 
-/* hip_stream: a hipStream_t (NULL = the null stream).  Asynchronous. */
+/* hip_stream: a hipStream_t of the model's device (NULL = its null stream).  Asynchronous.  The calling thread's
+ * current device may be any: the launches are issued on the model's device and the previous one is restored. */
 int nrnerf_render(const nrnerf_model* model, const nrnerf_render_args* args, void* hip_stream);
 
 /* Camera rays of one frame, generated on the device: reference get_rays (run_nerf_helpers.py:588-605) followed by

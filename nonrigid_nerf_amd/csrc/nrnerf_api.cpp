@@ -425,6 +425,18 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     if (!a->workspace || a->workspace_bytes < need || ((uintptr_t)a->workspace & 255)) return NRNERF_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const int N = a->n_rays, S = a->n_samples, I = a->n_importance, SF = S + I;
+    // launches go to the model's device whatever the calling thread's current device is (restored on every exit path)
+    struct DeviceGuard {
+        int prev = -1;
+        bool ok = true;
+        explicit DeviceGuard(int want) {
+            if (hipGetDevice(&prev) != hipSuccess) { ok = false; prev = -1; return; }
+            if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
+            if (prev == want) prev = -1;
+        }
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
 
     char* ws = (char*)a->workspace;
     float* raw_c = (float*)ws;

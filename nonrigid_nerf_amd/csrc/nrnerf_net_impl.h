@@ -1010,11 +1010,14 @@ static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) 
     using PL = Plan<P, A, HAS_BEND, VIEWS>;
     const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * 4 * sizeof(float);
     auto kern = net_kernel<P, A, HAS_BEND, VIEWS, WAVES, EXACT>;
-    static bool attr_set = false;    // idempotent; racing threads set the same value
-    if (!attr_set) {
+    // function attributes are per device: one flag per ordinal (idempotent; racing threads set the same value)
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int bpr = (a.S + 31) / 32;
     const long long nblocks = (long long)a.n_rays * bpr;
