@@ -195,7 +195,8 @@ int nrnerf_render(const nrnerf_model* model, const nrnerf_render_args* args, voi
 /* Camera rays of one frame, generated on the device: reference get_rays (run_nerf_helpers.py:588-605) followed by
  * the packing of render() (train.py:380-399).  rays_out [H*W, ray_stride] (device), row j*W+i =
  * [origin3, direction3, near, far (, unit direction3 when ray_stride == 11)].  c2w: host pointer to the 3x4
- * camera-to-world matrix, row-major. */
+ * camera-to-world matrix, row-major.  The kernel runs on the device that owns rays_out (hip_stream must belong to
+ * it); the calling thread's current device may be any and is restored. */
 typedef struct nrnerf_camera {
     float c2w[12];
     float focal_x, focal_y, center_x, center_y;

@@ -234,6 +234,18 @@ struct PassDev {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// makes `want` the calling thread's current device for the lifetime of the guard (restored on every exit path)
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int want) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; prev = -1; return; }
+        if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
+        if (prev == want) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 }  // namespace
 
 struct nrnerf_model {
@@ -426,16 +438,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     hipStream_t stream = (hipStream_t)hip_stream;
     const int N = a->n_rays, S = a->n_samples, I = a->n_importance, SF = S + I;
     // launches go to the model's device whatever the calling thread's current device is (restored on every exit path)
-    struct DeviceGuard {
-        int prev = -1;
-        bool ok = true;
-        explicit DeviceGuard(int want) {
-            if (hipGetDevice(&prev) != hipSuccess) { ok = false; prev = -1; return; }
-            if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
-            if (prev == want) prev = -1;
-        }
-        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-    } guard(m->device);
+    DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
 
     char* ws = (char*)a->workspace;
@@ -559,6 +562,12 @@ int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_p
     a.fx = cam->focal_x; a.fy = cam->focal_y; a.cx = cam->center_x; a.cy = cam->center_y;
     a.H = cam->height; a.W = cam->width; a.near = near_plane; a.far = far_plane;
     a.rays = rays_out; a.ray_stride = ray_stride;
+    // the launch goes to the device that owns rays_out, whatever the calling thread's current device is (as nrnerf_render)
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, rays_out) != hipSuccess) { (void)hipGetLastError(); return NRNERF_ERR_INVALID; }
+    if (attr.type != hipMemoryTypeDevice) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(attr.device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
     return launch_raygen(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 

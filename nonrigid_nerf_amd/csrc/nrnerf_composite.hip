@@ -139,8 +139,10 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
             if (lane == l) base = carry;
             carry = __shfl(e, l);
         }
+        // NaN weights (a diverged checkpoint, an overflowed f16 sigma) compare false everywhere: start from this lane's
+        // first valid sample so the index is always in range, like the host argmin the reference uses (fvr:626-628)
         float best = 3.0e38f, run_c = base;
-        int bidx = 0x7fffffff;
+        int bidx = (lane * EPL < S) ? lane * EPL : S - 1;
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
             const int i = lane * EPL + k;
@@ -155,6 +157,7 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
             if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
         }
         if (ray_ok && lane == 0) {
+            bidx = bidx < 0 ? 0 : (bidx > S - 1 ? S - 1 : bidx);
             const f32x4 b = *(const f32x4*)(a.bent4 + ((size_t)ray * S + bidx) * 4);
             if (a.surf_pts) { a.surf_pts[(size_t)ray * 3] = b[0]; a.surf_pts[(size_t)ray * 3 + 1] = b[1]; a.surf_pts[(size_t)ray * 3 + 2] = b[2]; }
             if (a.surf_rig) a.surf_rig[ray] = b[3];

@@ -174,7 +174,8 @@ class Model:
         desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
         self.has_bender = bool(desc.bender)
         self.needs_latents = self.has_bender or bool(desc.coarse.contents.time_conditioned)
-        self.latent_size = desc.bender.contents.latent_size if self.has_bender else 0
+        self.latent_size = desc.bender.contents.latent_size if self.has_bender else \
+            (int(getattr(network_fn, "ray_bending_latent_size", 0)) if self.needs_latents else 0)
         self.output_ch = desc.fine.contents.output_ch if desc.fine else desc.coarse.contents.output_ch
         self.coarse_output_ch = desc.coarse.contents.output_ch
         handle = C.c_void_p()
@@ -190,6 +191,9 @@ class Model:
         model (the caller then builds a new handle)."""
         desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
         with torch.cuda.device(self.device):
+            # renders queued on OTHER streams from this cached handle may still be reading the weight buffers: wait for
+            # the whole device before overwriting them (updates are rare: an optimiser step or a load_state_dict)
+            torch.cuda.synchronize(self.device)
             stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = self.lib.nrnerf_model_update(self.handle, C.byref(desc), C.c_void_p(stream))
         del keep
@@ -252,6 +256,10 @@ class Model:
         if self.needs_latents:
             if latents is None:
                 raise ValueError("ray_bending_latents are required (ray bender or time-conditioned baseline)")
+            # the kernel reads latent_size floats per ray: a wrong shape would be a silent out-of-bounds read where the
+            # reference raises in expand / split (train.py:82-87, run_nerf_helpers.py:246)
+            if latents.dim() != 2 or latents.shape[0] != N or latents.shape[1] != self.latent_size:
+                raise ValueError(f"ray_bending_latents must have shape ({N}, {self.latent_size}), got {tuple(latents.shape)}")
             if latents.dim() == 2 and latents.shape[0] == N and latents.stride(0) == 0 and latents.stride(1) == 1 \
                     and latents.dtype == torch.float32 and latents.device == dev:
                 a.latents, a.latent_stride = latents.data_ptr(), 0          # frame code expanded per ray (train.py:465)
@@ -310,44 +318,97 @@ class Model:
 # --------------------------------------------------------------------------------------------
 # model cache (weights are packed once per (modules, version) -- no per-call broadcast as in DataParallel)
 # --------------------------------------------------------------------------------------------
-_cache = weakref.WeakKeyDictionary()
+_cache = weakref.WeakKeyDictionary()       # network_fn -> {key: (fingerprint, Model | Unsupported)}
 _cache_lock = threading.Lock()
 
 
+def _bender_of(network_fn):
+    rb = getattr(network_fn, "ray_bender", None)
+    return rb[0] if rb else None
+
+
+def _wref(obj):
+    """Weak reference usable in a cache key: equal while both referents are the same live object, never equal to a new
+    object that happens to reuse a dead one's address (``id()`` can)."""
+    return None if obj is None else weakref.ref(obj)
+
+
 def get_model(network_fn, network_fine=None, precision: str | None = None, device=None) -> Model:
+    """The packed-weight handle for these modules on ``device`` (created, refreshed in place, or served from the cache).
+
+    Staleness is detected from ``(data_ptr, _version)`` of every parameter: optimiser steps, ``load_state_dict``,
+    ``copy_`` and friends bump ``_version``.  In-place edits made through ``param.data`` do NOT (PyTorch does not
+    version them): call ``invalidate(network_fn)`` after such an edit.  Architectures the library has no kernel for
+    raise ``Unsupported``; that verdict is cached as well, so a fallback caller does not re-copy the weights to the
+    host on every call."""
     precision = precision or _DEFAULT_PRECISION
-    rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
+    rb = _bender_of(network_fn)
     dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
-    key = (id(network_fine) if network_fine is not None else None, id(rb) if rb is not None else None, precision, str(dev),
-           bool(getattr(network_fn, "approx_nonrigid_viewdirs", True)))
+    key = (_wref(network_fine), _wref(rb), precision, str(dev), bool(getattr(network_fn, "approx_nonrigid_viewdirs", True)))
     fp = _fingerprint([network_fn, network_fine, rb])
     with _cache_lock:
         per = _cache.setdefault(network_fn, {})
+        for k in [k for k in per if any(r is not None and r() is None for r in k[:2])]:
+            del per[k]                                                         # entries of collected fine nets / benders
         hit = per.get(key)
         if hit is not None and hit[0] == fp:
+            if isinstance(hit[1], Exception):
+                raise hit[1]
             return hit[1]
-        if hit is not None and hit[1].update(network_fn, network_fine):       # weights changed (optimiser step,
-            per[key] = (fp, hit[1])                                            # load_state_dict): refresh in place
+        if hit is not None and isinstance(hit[1], Model) and hit[1].update(network_fn, network_fine):
+            per[key] = (fp, hit[1])                                            # weights changed: refreshed in place
             return hit[1]
-        model = Model(network_fn, network_fine, precision, dev)
+        try:
+            model = Model(network_fn, network_fine, precision, dev)
+        except Unsupported as e:
+            per[key] = (fp, e)
+            raise
+        except _lib.NrnerfError as e:
+            if e.status != _lib.ERR_UNSUPPORTED:
+                raise
+            err = Unsupported(str(e))
+            per[key] = (fp, err)
+            raise err from e
         per[key] = (fp, model)
         return model
+
+
+def invalidate(network_fn=None):
+    """Forget the packed weights of ``network_fn`` (all models when None): the next call re-packs from the modules.
+    Needed only after edits the version counters cannot see (``param.data.copy_(...)``, ``param.data *= ...``)."""
+    with _cache_lock:
+        if network_fn is None:
+            _cache.clear()
+        else:
+            _cache.pop(network_fn, None)
 
 
 # --------------------------------------------------------------------------------------------
 # eligibility + the two drop-in entry points
 # --------------------------------------------------------------------------------------------
+def _trains(network_fn, network_fine, ray_batch, latents):
+    """Is this a call autograd has to see?  (The bender is deliberately not a submodule of the NeRF modules --
+    run_nerf_helpers.py:213-215 -- so its parameters are checked explicitly, like the fine network's.)"""
+    if not torch.is_grad_enabled():
+        return False
+    if ray_batch.requires_grad or (latents is not None and latents.requires_grad):
+        return True
+    for m in (network_fn, network_fine, _bender_of(network_fn)):
+        if m is not None and any(p.requires_grad for p in m.parameters()):
+            return True
+    return False
+
+
 def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importance, lindisp, perturb, white_bkgd,
                      raw_noise_std, pytest, latents):
-    if torch.is_grad_enabled() and (ray_batch.requires_grad or (latents is not None and latents.requires_grad)
-                                    or any(p.requires_grad for p in network_fn.parameters())):
+    if _trains(network_fn, network_fine if N_importance > 0 else None, ray_batch, latents):
         return "autograd is enabled (training path)"
     if pytest:
         return "pytest flag (numpy-seeded random numbers, train.py:863-867)"
     if ray_batch.device.type != "cuda":
         return "rays are not on a ROCm device"
     if getattr(network_fn, "use_viewdirs", False):
-        has_bender = bool(getattr(network_fn, "ray_bender", None)) and network_fn.ray_bender[0] is not None
+        has_bender = _bender_of(network_fn) is not None
         exact = has_bender and not getattr(network_fn, "approx_nonrigid_viewdirs", True)
         if (not has_bender or exact) and ray_batch.shape[-1] < 11:
             return "use_viewdirs without view directions in the ray batch"
@@ -362,6 +423,19 @@ def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importanc
     return None
 
 
+def _eligible(ray_batch, latents, network_fn, network_fine=None, N_samples=64, N_importance=0, lindisp=False,
+              perturb=0.0, white_bkgd=False, raw_noise_std=0.0, pytest=False, **_):
+    """(model, None) when the HIP path takes this call, (None, reason) otherwise.  Decided once per ``batchify_rays``."""
+    why = _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importance, lindisp, perturb,
+                           white_bkgd, raw_noise_std, pytest, latents)
+    if why is not None:
+        return None, why
+    try:
+        return get_model(network_fn, network_fine if N_importance > 0 else None, device=ray_batch.device), None
+    except Unsupported as e:
+        return None, str(e)
+
+
 def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retraw=False, lindisp=False, perturb=0.0,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.0,
                 additional_pixel_information=None, detailed_output=False, verbose=False, pytest=False,
@@ -370,19 +444,15 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
     latents = None
     if additional_pixel_information is not None:
         latents = additional_pixel_information.get("ray_bending_latents")
-    why = _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importance, lindisp, perturb,
-                           white_bkgd, raw_noise_std, pytest, latents)
+    model = dummy_kwargs.pop("_model", None)           # batchify_rays already decided
+    why = None
+    if model is None:
+        model, why = _eligible(ray_batch, latents, network_fn, network_fine, N_samples, N_importance, lindisp, perturb,
+                               white_bkgd, raw_noise_std, pytest)
     if why is None and N_importance == 0 and detailed_output:
         # the reference raises UnboundLocalError here (train.py:900-908 vs 967-970); keep that contract
         raise UnboundLocalError("local variable 'visibility_weights_0' referenced before assignment "
                                 "(reference render_rays cannot do detailed_output with N_importance == 0)")
-    if why is None:
-        try:
-            model = get_model(network_fn, network_fine if N_importance > 0 else None, device=ray_batch.device)
-        except (Unsupported, _lib.NrnerfError) as e:
-            if isinstance(e, _lib.NrnerfError) and e.status != _lib.ERR_UNSUPPORTED:
-                raise
-            why = str(e)
     if why is not None:
         ref = _fallbacks.get("render_rays")
         if ref is None:
@@ -391,7 +461,7 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
                    perturb=perturb, N_importance=N_importance, network_fine=network_fine, white_bkgd=white_bkgd,
                    raw_noise_std=raw_noise_std, additional_pixel_information=additional_pixel_information,
                    detailed_output=detailed_output, verbose=verbose, pytest=pytest, **dummy_kwargs)
-    rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
+    rb = _bender_of(network_fn)
     randoms = _draw_randoms(ray_batch, N_samples, N_importance, perturb, raw_noise_std)
     ret = model.render(
         ray_batch, latents, N_samples, N_importance, retraw=retraw, detailed_output=detailed_output,
@@ -437,18 +507,26 @@ def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, deta
 
     ``chunk`` exists in the reference to bound memory and "does not affect final results"
     (train.py:344-345).  The fused kernels need ~5 KB of scratch per ray instead of the reference's
-    ~70 KB, so rays are processed in launches of up to 2^20 rays (or ``chunk`` if larger).
+    ~70 KB, so on the HIP path rays are processed in launches of up to 2^20 rays (or ``chunk`` if larger).
+    Whether the HIP path takes the call is decided ONCE, here: a call it cannot take goes to the reference's own
+    ``batchify_rays`` with the caller's ``chunk`` (its memory bound must hold for the reference's ~70 KB per ray).
     """
+    lat = additional_pixel_information["ray_bending_latents"] if additional_pixel_information else None
+    model, why = _eligible(rays_flat, lat, **kwargs)
+    if model is None:
+        ref = _fallbacks.get("batchify_rays")
+        if ref is None:
+            raise Unsupported(f"no HIP kernel for this call ({why}) and no reference function installed to defer to")
+        return ref(rays_flat, additional_pixel_information, chunk=chunk, detailed_output=detailed_output, **kwargs)
     n = rays_flat.shape[0]
     step = max(int(chunk), _MAX_RAYS_PER_LAUNCH)
     if (kwargs.get("perturb") or 0) > 0 or (kwargs.get("raw_noise_std") or 0) > 0:
         step = int(chunk)        # the chunk shapes decide which random numbers each ray gets: keep the reference's
-    lat = additional_pixel_information["ray_bending_latents"] if additional_pixel_information else None
     pieces = {}
     for i in range(0, n, step):
         api = {"ray_bending_latents": lat[i:i + step, :]} if lat is not None else None    # train.py:119-123
         ret = render_rays(rays_flat[i:i + step], additional_pixel_information=api,
-                          detailed_output=detailed_output, **kwargs)
+                          detailed_output=detailed_output, _model=model, **kwargs)
         for k, v in ret.items():
             pieces.setdefault(k, []).append(v)
     return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in pieces.items()}

@@ -1,0 +1,168 @@
+"""Fit NR-NeRF to the example-sequence fixture with the differentiable oracle.  TEST INFRASTRUCTURE ONLY.
+
+The reference ships no trained checkpoint, and seeded random weights are a stress scene, not
+what the renderer sees in production.  This script produces a checkpoint with *trained-like* weight statistics in
+the reference's ``latest.tar`` layout (train.py:1680-1698) so that the accuracy tests (PSNR of the 16-bit modes
+against the fp32 reference render, and of both against ground truth) run on a realistic model:
+
+    python oracle/fit_checkpoint.py --iters 6000 --out gpurun_out/fitted_latest.tar     # on a GPU box: ~2-3 minutes
+    cp gpurun_out/fitted_latest.tar tests/golden/fitted_latest.tar                      # commit the result
+
+It is a restatement of the reference's training loop on top of ``oracle/nrnerf_oracle.py`` (whose gradients are
+pinned against the reference's own autograd, tests/golden/gradients_64_64.npz):
+  * model construction / initialisation      create_nerf train.py:556-721; ray_bending.__init__ rnh:388-505 (kaiming
+    hidden layers, zero biases, zero last layers: rays start straight, rigidity starts at 0.5)
+  * ray batches over all images               train.py:1543-1560 (random image, x, y)
+  * forward                                   training_wrapper_class.forward train.py:152-287: render with perturb = 1,
+    raw_noise_std, detailed outputs; data term on rgb_map and rgb0 (:207-217); offsets + rigidity regulariser (:219-242)
+    with the increasing schedule.  The divergence regulariser (:244-287) is left out (it only shapes the deformation
+    field further; irrelevant for weight statistics).
+  * test frames only optimise their latent    train.py:1584-1610
+  * Adam(5e-4), warm-up, exponential decay    train.py:655-658, 1630-1642
+Runs on whatever device torch offers (the oracle is device-agnostic eager PyTorch); never part of the product path.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from nonrigid_nerf_amd.modules import NeRFWeights, RayBenderWeights  # noqa: E402  (parameter holders only)
+from nonrigid_nerf_amd.synthetic import Scene, SceneConfig  # noqa: E402
+from oracle import nrnerf_oracle as O  # noqa: E402
+
+FIXTURE = os.path.join(REPO, "tests", "golden", "example_sequence_96x72.npz")
+
+
+def load_fixture(path=FIXTURE):
+    z = np.load(path)
+    H, W, focal = (float(v) for v in z["hwf"])
+    intrin = dict(height=int(H), width=int(W), focal_x=focal, focal_y=focal, center_x=W / 2, center_y=H / 2,
+                  ray_bending_latent_size=32)                                   # train.py:1304-1366
+    near, far = float(z["bds"].min()) * 0.9, float(z["bds"].max())            # train.py:1418-1419
+    return dict(images=torch.from_numpy(z["images"]).float() / 255.0, poses=torch.from_numpy(z["poses"]),
+                intrin=intrin, near=near, far=far, i_test=int(z["i_test"]), frame_ids=z["frame_ids"],
+                render_poses=torch.from_numpy(z["render_poses"]))
+
+
+def init_bender_like_reference(rb: RayBenderWeights):
+    """ray_bending.__init__, run_nerf_helpers.py:436-455, 487-505."""
+    with torch.no_grad():
+        for net in (rb.network, rb.rigidity_network):
+            for layer in list(net)[:-1]:
+                torch.nn.init.kaiming_uniform_(layer.weight, a=0, mode="fan_in", nonlinearity="relu")
+                torch.nn.init.zeros_(layer.bias)
+            net[-1].weight.mul_(0.0)
+            if net[-1].bias is not None:
+                net[-1].bias.mul_(0.0)
+
+
+def frame_rays(pose, intrin, near, far):
+    ro, rd = O.get_rays(pose[:3, :4], intrin)
+    return O.pack_rays(ro, rd, near, far, use_viewdirs=False)                   # [H*W, 8]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=6000)
+    ap.add_argument("--minutes", type=float, default=6.0, help="stop early after this much wall time")
+    ap.add_argument("--n-rand", type=int, default=2048)
+    ap.add_argument("--n-importance", type=int, default=128)
+    ap.add_argument("--raw-noise-std", type=float, default=1.0)
+    ap.add_argument("--offsets-loss-weight", type=float, default=60.0)
+    ap.add_argument("--rigidity-loss-weight", type=float, default=0.0005)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "fitted_latest.tar"))
+    args = ap.parse_args()
+
+    dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    torch.manual_seed(args.seed)
+    rng = np.random.RandomState(args.seed)
+    fx = load_fixture()
+    F_, H, W = fx["images"].shape[:3]
+    cfg = SceneConfig(N_samples=64, N_importance=args.n_importance, near=fx["near"], far=fx["far"])
+    rb = RayBenderWeights()
+    init_bender_like_reference(rb)
+    coarse = NeRFWeights(output_ch=5, num_ray_samples=cfg.N_samples)
+    fine = NeRFWeights(output_ch=5, num_ray_samples=cfg.N_samples + cfg.N_importance)
+    for m in (rb, coarse, fine):
+        m.to(dev)
+    latents = torch.zeros(F_, 32, device=dev, requires_grad=True)              # train.py:1443-1448
+    scene = Scene(cfg, dict(rb.named_parameters()), dict(coarse.named_parameters()), dict(fine.named_parameters()))
+    net_params = list(coarse.parameters()) + list(fine.parameters()) + list(rb.parameters())
+    opt = torch.optim.Adam(net_params + [latents], lr=5e-4, betas=(0.9, 0.999))  # train.py:655-658
+
+    rays_all = torch.stack([frame_rays(fx["poses"][f], fx["intrin"], fx["near"], fx["far"]) for f in range(F_)], 0).to(dev)
+    target_all = fx["images"].reshape(F_, H * W, 3).to(dev)
+    is_test = torch.zeros(F_, dtype=torch.bool, device=dev)
+    is_test[fx["i_test"]] = True
+
+    t0 = time.time()
+    step = 0
+    for step in range(args.iters):
+        img = torch.from_numpy(rng.randint(F_, size=args.n_rand)).to(dev)       # train.py:1546-1548
+        pix = torch.from_numpy(rng.randint(H * W, size=args.n_rand)).to(dev)
+        rays, target = rays_all[img, pix], target_all[img, pix]
+        lat = latents[img]
+        out = O.render_rays(rays, lat, scene, retraw=True, detailed_output=True, perturb=1.0,
+                            raw_noise_std=args.raw_noise_std)
+        loss = ((out["rgb_map"] - target) ** 2).mean(-1) + ((out["rgb0"] - target) ** 2).mean(-1)   # :207-217 (img2mse per ray)
+        w = out["visibility_weights"].detach()
+        off = torch.norm(out["unmasked_offsets"], dim=-1)
+        rig = out["rigidity_mask"][..., 0]
+        offsets_loss = (w * torch.pow(off + 1e-12, 2.0 - rig)).mean(-1) + args.rigidity_loss_weight * (w * rig).mean(-1)   # :219-236
+        sched = (1.0 / 100.0) ** (1 - step / args.iters)                        # :237-242 increasing schedule
+        loss = loss + args.offsets_loss_weight * sched * offsets_loss
+        test_ray = is_test[img]
+        opt.zero_grad(set_to_none=True)
+        g_test = None
+        if bool(test_ray.any()):                                                # :1584-1601: test frames -> latents only
+            (g_test,) = torch.autograd.grad((loss * test_ray).mean(), latents, retain_graph=True)
+        (loss * ~test_ray).mean().backward()
+        if g_test is not None:
+            latents.grad = g_test if latents.grad is None else latents.grad + g_test
+        opt.step()
+        lr = 5e-4 * (0.1 ** (step / 250000))                                    # :1630-1642
+        if step < 1000:
+            lr /= 20.0 * (-(step - 1000) / 1000) + 1.0
+        for g in opt.param_groups:
+            g["lr"] = lr
+        if step % 250 == 0 or step == args.iters - 1:
+            mse = float(((out["rgb_map"].detach() - target) ** 2).mean())
+            print(f"step {step:5d}  loss {float(loss.detach().mean()):.5f}  psnr {-10 * np.log10(mse):.2f} dB  "
+                  f"acc {float(out['acc_map'].detach().mean()):.3f}  |offset| {float(off.detach().mean()):.2e}  rigidity {float(rig.detach().mean()):.3f}  "
+                  f"{time.time() - t0:.0f} s", flush=True)
+        if time.time() - t0 > args.minutes * 60:
+            print(f"time budget reached at step {step}")
+            break
+
+    # held-out frame: PSNR of the fp32 oracle render against the ground-truth image (free_viewpoint_rendering.py:821-828)
+    with torch.no_grad():
+        f = fx["i_test"]
+        o = O.batchify_rays(rays_all[f], latents[f:f + 1].expand(H * W, -1), scene, chunk=4096)
+        mse = float(((o["rgb_map"] - target_all[f]) ** 2).mean())
+        print(f"held-out frame {f}: PSNR(oracle fp32, GT) = {-10 * np.log10(mse):.2f} dB, acc mean {float(o['acc_map'].mean()):.3f}, "
+              f"acc<0.99 on {float((o['acc_map'] < 0.99).float().mean()):.3f} of the rays")
+
+    cpu = lambda m: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    intrinsics = {v: dict(fx["intrin"]) for v in range(F_)}
+    ck = {"global_step": step + 1, "network_fn_state_dict": cpu(coarse), "network_fine_state_dict": cpu(fine),
+          "ray_bender_state_dict": cpu(rb), "optimizer_state_dict": None,
+          "ray_bending_latent_codes": latents.detach().cpu().clone(), "intrinsics": intrinsics,
+          "scripts_dict": {"near": fx["near"], "far": fx["far"], "image_folder": "images"},
+          "dataset_extras": {"imageid_to_timestepid": list(range(F_)), "raw_timesteps": list(range(F_)),
+                             "fixture": os.path.basename(FIXTURE), "fit": vars(args)}}
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    torch.save(ck, args.out)
+    print(f"wrote {args.out} ({os.path.getsize(args.out) / 1e6:.1f} MB) after {step + 1} iterations, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
