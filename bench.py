@@ -1,27 +1,39 @@
 #!/usr/bin/env python
 """Headline benchmark: rendered rays/s of the NR-NeRF per-ray hot path at 64+128 samples/ray.
 
-  python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py                                   # 1 GPU
+  python bench.py --gpus 8 --steps 20 --warmup 5    # spawns 8 ranks itself (torch.distributed.run, RCCL)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W     # or under an external launcher (RANK / WORLD_SIZE in the env)
 
-A "step" is one ``batchify_rays`` pass (reference train.py:108-137) over one 512x384 frame worth of
-synthetic rays per GPU (196 608 rays = the reference's 6 chunks of 32 768; BASELINE.json config 2:
-64 coarse + 128 importance samples, 8x256 canonical MLPs + ray bender, bf16 contractions with fp32
-accumulation) with inputs already resident in HBM, plus -- for N > 1 -- the all-gather of the rendered
-pixels over RCCL/xGMI (config 3).  Weak scaling: every rank renders its own frame-sized shard.
+A "step" is one ``batchify_rays`` pass (reference train.py:108-137) over one 512x384 frame worth of rays per GPU
+(196 608 rays = the reference's 6 chunks of 32 768; BASELINE.json config 2: 64 coarse + 128 importance samples,
+8x256 canonical MLPs + ray bender, bf16 contractions with fp32 accumulation) with inputs already resident in HBM,
+plus -- for N > 1 -- the all-gather of the rendered pixels over RCCL/xGMI (config 3), issued on a side stream so
+that frame f's gather overlaps frame f+1's render.  Weak scaling: every rank renders its own frame-sized shard
+(``--scaling strong``: one frame sharded contiguously over the ranks).
+
+``--scene synthetic`` (default): seeded random weights + random rays (nonrigid_nerf_amd/synthetic.py).
+``--scene fitted``: the weights of tests/golden/fitted_latest.tar (NR-NeRF fitted to the down-sampled example
+sequence by oracle/fit_checkpoint.py) and real camera rays of the example sequence at 512x384, one latent code per
+frame -- the reference's free-viewpoint render of that sequence.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  "roofline":     the dominant kernel (fine-pass network kernel) against the dense bf16 MFMA peak, from
-                  HIP events recorded around that kernel on the render stream during the timed steps;
-  "cpu_baseline": the CPU oracle (a PyTorch-CPU port of the reference path, oracle/nrnerf_oracle.py)
-                  timed on this box's host cores on a bounded sample of the same workload.
+  "roofline":          the dominant kernel (fine-pass network kernel) against the dense MFMA peak of the dtype, from HIP
+                       events recorded around that kernel on the render stream during the timed steps;
+  "psnr_vs_oracle_db": PSNR (free_viewpoint_rendering.py:821-828) of this run's precision against the fp32 oracle
+                       render of the same rays and weights (all rays, no exclusions), checker use of oracle/ only;
+  "cpu_baseline":      the CPU oracle (a PyTorch-CPU port of the reference path, oracle/nrnerf_oracle.py) timed on this
+                       box's host cores on a bounded sample of the same workload (after the GPU section).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,25 +43,94 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}       # dense MFMA, MI355X_MICROARCH.md
-ALGO_MFLOP_PER_RAY = 260.18                                        # SURVEY.md section 8d (64 + 192 evaluations)
+FITTED = os.path.join(REPO, "tests", "golden", "fitted_latest.tar")
+FIXTURE = os.path.join(REPO, "tests", "golden", "example_sequence_96x72.npz")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=196608, help="rays per GPU per step (default: one 512x384 frame)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--scene", default="synthetic", choices=["synthetic", "fitted"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--psnr-rays", type=int, default=32768)
+    ap.add_argument("--min-gpu-seconds", type=float, default=6.0,
+                    help="keep the GPU busy at least this long in total (untimed extra frames after the timed region) so "
+                         "that an external utilisation sampler sees the run")
     ap.add_argument("--use-viewdirs", action="store_true", help="BASELINE config 4: view-dependent head (not the headline config)")
     ap.add_argument("--bend-depth", type=int, default=5, help="BASELINE config 4: deeper ray-bending MLP (5 or 7)")
     ap.add_argument("--exact-viewdirs", action="store_true", help="with --use-viewdirs: Jacobian instead of finite-difference directions")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --rays per GPU; strong: --rays in total, sharded contiguously over the ranks "
                          "(BASELINE config 3: one frame over 8 GPUs)")
-    args = ap.parse_args()
+    ap.add_argument("--train-step", action="store_true", help="additionally time the native training step (forward + backward, 1024 rays)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """``--gpus N`` without a launcher: re-exec this script under torch.distributed.run, one rank per GPU."""
+    one_gpu = os.environ.get("NRNERF_BENCH_ONE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if not one_gpu and have < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (NRNERF_BENCH_ONE_GPU=1 runs all ranks on "
+                 f"GPU 0 over gloo, as a functional test only)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // (2 * args.gpus)))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def build_workload(args, rank, world, dev):
+    """(scene, cfg, modules, rays, latents-as-passed, description).  Inputs resident in HBM on return."""
+    from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
+    n = args.rays
+    if args.scene == "fitted":
+        import numpy as np
+        from nonrigid_nerf_amd.checkpoint import load_checkpoint
+        from nonrigid_nerf_amd.driver import generate_rays
+        from nonrigid_nerf_amd.synthetic import Scene
+        ck = load_checkpoint(FITTED, N_samples=64, N_importance=128)
+        z = np.load(FIXTURE)
+        near, far = float(z["bds"].min()) * 0.9, float(z["bds"].max())
+        cfg = SceneConfig(near=near, far=far)
+        sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+        scene = Scene(cfg, sd(ck.ray_bender), sd(ck.network_fn), sd(ck.network_fine))
+        rb, coarse, fine = ck.ray_bender, ck.network_fn, ck.network_fine
+        # one full-resolution frame of the sequence per rank (512x384; the fixture's intrinsics are 96x72)
+        frame = (3 + rank) % int(z["poses"].shape[0])
+        s = 512.0 / float(z["hwf"][1])
+        intrin = dict(height=384, width=512, focal_x=float(z["hwf"][2]) * s, focal_y=float(z["hwf"][2]) * s,
+                      center_x=256.0, center_y=192.0)
+        rays = generate_rays(torch.from_numpy(z["poses"][frame]), intrin, near, far, False, dev)
+        reps = (n + rays.shape[0] - 1) // rays.shape[0]
+        rays = rays.repeat(reps, 1)[:n].contiguous()
+        code = ck.latents[frame].to(dev).reshape(1, -1)
+        latents = code.expand(n, -1)                     # stride-0 view, as render_path passes it (train.py:464-466)
+        desc = (f"example_sequence frame {int(z['frame_ids'][frame])} camera rays at 512x384, weights fitted to the "
+                f"down-sampled sequence ({ck.global_step} oracle iterations, tests/golden/fitted_latest.tar), one latent per frame")
+        return scene, cfg, (rb, coarse, fine), rays, latents, desc
+    cfg = SceneConfig(use_viewdirs=args.use_viewdirs, bend_depth=args.bend_depth,      # default: 64 + 128, W = 256, bender on, latent 32
+                      approx_nonrigid_viewdirs=not args.exact_viewdirs)
+    scene = make_scene(cfg, 0)
+    mods = build_modules(scene, device=dev)
+    rays, latents = make_rays(n, seed=100 + rank, cfg=cfg)
+    return scene, cfg, mods, rays.to(dev), latents.to(dev), "seeded random weights and rays (nonrigid_nerf_amd/synthetic.py)"
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -59,10 +140,12 @@ def main():
     one_gpu = os.environ.get("NRNERF_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
+        backend = "gloo" if one_gpu else "nccl"
         if one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -73,91 +156,176 @@ def main():
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // (2 * world))))
 
     from nonrigid_nerf_amd import render as R
-    from nonrigid_nerf_amd.distributed import gather_pixels
-    from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
 
     if args.scaling == "strong":                          # one frame for the whole job: ceil(n / G) rays per rank
         args.rays = (args.rays + world - 1) // world
-    cfg = SceneConfig(use_viewdirs=args.use_viewdirs, bend_depth=args.bend_depth,      # default: 64 + 128, W = 256, bender on, latent 32
-                      approx_nonrigid_viewdirs=not args.exact_viewdirs)
-    scene = make_scene(cfg, 0)
-    rb, coarse, fine = build_modules(scene, device=dev)
+    scene, cfg, (rb, coarse, fine), rays, latents, data_desc = build_workload(args, rank, world, dev)
     R.set_precision(args.precision)
-    rays, latents = make_rays(args.rays, seed=100 + rank, cfg=cfg)
-    rays, latents = rays.to(dev), latents.to(dev)
     api = {"ray_bending_latents": latents}
     kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples,
               N_importance=cfg.N_importance, perturb=0.0, raw_noise_std=0.0)
     model = R.get_model(coarse, fine, device=dev)          # weights packed once, outside the timed region
 
-    def step():
+    # ---- multi-GPU: double-buffered pixel blocks, all-gather on a side stream (frame f's gather overlaps frame f+1's render)
+    n = args.rays
+    main_stream = torch.cuda.current_stream(dev)
+    if world > 1:
+        import torch.distributed as dist
+        side = torch.cuda.Stream(device=dev)
+        packed = [torch.empty(n, 5, device=dev) for _ in range(2)]
+        full = [torch.empty(world * n, 5, device=("cpu" if one_gpu else dev)) for _ in range(2)]
+        pending = [None, None]
+
+    def step(i):
         out = R.batchify_rays(rays, api, chunk=1024 * 32, **kw)
-        packed = torch.cat([out["rgb_map"], out["disp_map"][:, None], out["acc_map"][:, None]], -1)
-        if world > 1 and one_gpu:
-            return gather_pixels(packed.cpu())          # gloo has no all_gather for device tensors
-        return gather_pixels(packed) if world > 1 else packed
+        if world == 1:
+            return out
+        b = i & 1
+        if pending[b] is not None:                        # buffer pair b was handed to gather i-2: finished long ago
+            pending[b].wait()
+        buf = packed[b]
+        buf[:, 0:3] = out["rgb_map"]; buf[:, 3] = out["disp_map"]; buf[:, 4] = out["acc_map"]
+        if one_gpu:                                       # gloo has no all_gather for device tensors
+            dist.all_gather_into_tensor(full[b], buf.cpu())
+            return full[b]
+        ready = torch.cuda.Event()
+        ready.record(main_stream)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            pending[b] = dist.all_gather_into_tensor(full[b], buf, async_op=True)
+        return full[b]
+
+    def drain():
+        if world > 1:
+            for b in range(2):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+            main_stream.wait_stream(side) if not one_gpu else None
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_gpu0 = time.perf_counter()
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
+        for i in range(args.warmup):
+            step(i)
+        drain()
         barrier()
         model.profile_begin()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            img = step()
+        for i in range(args.steps):
+            img = step(i)
+        drain()
         barrier()
         dt = time.perf_counter() - t0
         prof = model.profile_end()
-    assert img.shape == (world * args.rays, 5)
-
     if world > 1:
-        import torch.distributed as dist
+        assert img.shape == (world * n, 5)
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if one_gpu:
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_rays = world * args.rays * args.steps
+    total_rays = world * n * args.steps
     value = total_rays / dt
 
+    extra = {}
     if rank == 0:
+        with torch.no_grad():
+            if not args.no_psnr:
+                extra["psnr_vs_oracle_db"] = psnr_vs_oracle(args, scene, cfg, rays, latents, api, kw, dev)
+            if args.train_step:
+                extra["train_step"] = train_step_leg(args, scene, cfg, dev)
+            gemm = library_gemm_tflops(dev, args.precision) if world == 1 else None
+            # keep the device visibly busy for an external sampler (the timed region alone is < 1 s)
+            extra_frames = 0
+            while world == 1 and time.perf_counter() - t_gpu0 < args.min_gpu_seconds:
+                step(0)
+                torch.cuda.synchronize()
+                extra_frames += 1
+
         k = prof["net_fine"]
-        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
+
+        def roof(kk):
+            ach = kk["flops"] / (kk["ms"] * 1e-3) / 1e12 if kk["ms"] > 0 else 0.0
+            return {"achieved": round(ach, 2), "frac": round(ach / peak, 4),
+                    "avg_launch_ms": round(kk["ms"] / max(kk["launches"], 1), 4),
+                    "issued_mfma_tflops": round(kk["mfma_flops"] / (kk["ms"] * 1e-3) / 1e12, 2) if kk["ms"] > 0 else 0.0}
+        rf = roof(k)
+        traffic, traffic_note = pmc_traffic(args)
         roofline = {"bound": "mfma", "kernel": "net_kernel (fine pass, 192 samples/ray)",
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
-                    "issued_mfma_tflops": round(k["mfma_flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else 0.0,
-                    "traffic": pmc_traffic(args),
-                    "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_summary.txt); algorithmic 7.86e8",
-                    "other_kernels_ms_per_step": {n: round(v["ms"] / args.steps, 4) for n, v in prof.items()},
+                    "achieved": rf["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": rf["frac"],
+                    "avg_launch_ms": rf["avg_launch_ms"], "issued_mfma_tflops": rf["issued_mfma_tflops"],
+                    "traffic": traffic, "traffic_unit": traffic_note,
+                    "coarse_pass": roof(prof["net_coarse"]),
+                    "kernels_ms_per_step": {nm: round(v["ms"] / args.steps, 4) for nm, v in prof.items() if v["launches"]},
                     # context, not the peak: what a plain hipBLASLt GEMM sustains on this box right now (the chip
                     # clocks down under MFMA load)
-                    "library_gemm_tflops_same_box": library_gemm_tflops(dev, args.precision) if world == 1 else None}
+                    "library_gemm_tflops_same_box": gemm}
+        flops_per_ray = sum(v["flops"] for v in prof.values()) / max(n * args.steps, 1)
         res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
-               "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (NOT A BENCHMARK: all ranks on one GPU, gloo)" if one_gpu else ""),
+               "vs_baseline": None, "dtype": args.precision,
+               "data": ("synthetic: " if args.scene == "synthetic" else "example_sequence: ") + data_desc
+                       + (" (NOT A BENCHMARK: all ranks on one GPU, gloo)" if one_gpu else ""),
                "config": {"workload": "BASELINE config 2: example_sequence-shaped frame (512x384 = 196608 rays/GPU/step), "
                                       "64 coarse + 128 importance samples, netwidth 256, ray bender on, latent 32"
                                       + (f"; NON-HEADLINE VARIANT: use_viewdirs={args.use_viewdirs}, bend_depth={args.bend_depth}, "
                                          f"exact_viewdirs={args.exact_viewdirs}" if (args.use_viewdirs or args.bend_depth != 5) else ""),
-                          "rays_per_gpu_per_step": args.rays, "N_samples": 64, "N_importance": 128,
-                          "parallelism": f"rays sharded over {world} rank(s)" + (", all-gather of [rgb,disp,acc] over RCCL" if world > 1 else "")},
-               "mflop_per_ray_algorithmic": round(sum(v["flops"] for v in prof.values()) / max(args.rays * args.steps, 1) / 1e6, 2),
-               "end_to_end_tflops": round(value * sum(v["flops"] for v in prof.values()) / max(args.rays * args.steps, 1) / 1e12, 2),
+                          "scene": args.scene, "rays_per_gpu_per_step": n, "N_samples": 64, "N_importance": 128,
+                          "parallelism": f"rays sharded over {world} rank(s)"
+                                         + (", all-gather of [rgb,disp,acc] on a side stream, overlapped with the next frame" if world > 1 else "")},
+               "rccl_ranks": world if world > 1 else 1, "backend": backend,
+               "mflop_per_ray_algorithmic": round(flops_per_ray / 1e6, 2),
+               "end_to_end_tflops": round(value * flops_per_ray / 1e12, 2),
+               "untimed_extra_frames": extra_frames,
                "roofline": roofline}
+        res.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(scene, cfg, args.cpu_rays)
+            res["cpu_baseline"] = cpu_baseline(scene, cfg, args, rays, latents)
         print(json.dumps(res), flush=True)
 
     if world > 1:
-        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def psnr_vs_oracle(args, scene, cfg, rays, latents, api, kw, dev):
+    """PSNR of this run's precision (and of the other precisions, for context) against the fp32 oracle on the first
+    ``--psnr-rays`` rays of the benchmark workload.  All rays count.  The oracle runs on the GPU (device-agnostic eager
+    PyTorch, the reference's own ops): checker use only."""
+    import math
+
+    from nonrigid_nerf_amd import render as R
+    from oracle import nrnerf_oracle as O
+    m = min(args.psnr_rays, rays.shape[0])
+    r, lat = rays[:m], latents[:m]
+    ref = O.batchify_rays(r, lat.contiguous(), O.scene_on(scene, dev), chunk=8192)
+    out = {}
+    for prec in ("f32", "bf16", "f16"):
+        R.set_precision(prec)
+        got = R.batchify_rays(r, {"ray_bending_latents": lat}, **kw)
+        res = {}
+        for key in ("rgb_map", "rgb0"):
+            mse = float(((got[key].double() - ref[key].double()) ** 2).mean())
+            res[key] = round(-10.0 * math.log10(max(mse, 1e-30)), 2)
+        out[prec] = res
+    R.set_precision(args.precision)
+    return {"dtype": args.precision, "rgb_map": out[args.precision]["rgb_map"], "rgb0": out[args.precision]["rgb0"],
+            "rays": m, "all_precisions": out, "reference": "fp32 oracle (eager PyTorch ops of the reference) on the same rays and weights"}
+
+
+def train_step_leg(args, scene, cfg, dev):
+    try:
+        from nonrigid_nerf_amd import training
+    except Exception as e:                                    # not built yet
+        return {"error": f"{type(e).__name__}: {e}"}
+    return training.bench_train_step(scene, cfg, dev, precision=args.precision)
 
 
 def library_gemm_tflops(dev, precision):
@@ -179,25 +347,36 @@ def library_gemm_tflops(dev, precision):
         return None
 
 
+def lib_sha16():
+    from nonrigid_nerf_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def pmc_traffic(args):
-    """HBM bytes per launch of the fine-pass network kernel for THIS workload, from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_summary.py; counters cannot be read from inside the process).  None when
-    the run does not match the profiled configuration."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_fine.json")
-    if args.rays != 196608 or args.precision != "bf16" or not os.path.exists(path):
-        return None
+    """HBM bytes per launch of the fine-pass network kernel.  Hardware counters cannot be read from inside the process:
+    they come from separate ``rocprofv3 --pmc`` passes of this very command (tools/collect_profiles.sh), stored with the
+    hash of the library they profiled.  Reported only when that hash matches the library loaded now and the workload is
+    the profiled one; otherwise null (a stale number is worse than none)."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_fine.json")
+    if args.rays != 196608 or args.precision != "bf16" or args.scene != "synthetic" or not os.path.exists(path):
+        return None, "null: no rocprofv3 --pmc pass of this build and workload on file (profiles/r02_pmc_fine.json)"
     try:
         with open(path) as f:
-            return float(json.load(f)["fine"]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+            j = json.load(f)
+        if j.get("lib_sha16") != lib_sha16():
+            return None, "null: profiles/r02_pmc_fine.json was collected from a different build of libnrnerf_hip.so"
+        return float(j["fine"]["hbm_bytes_per_launch"]), ("bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from rocprofv3 --pmc passes "
+                                                          "of this build (profiles/r02_pmc_summary.txt); algorithmic 7.86e8")
+    except Exception as e:
+        return None, f"null: {type(e).__name__}"
 
 
-def cpu_baseline(scene, cfg, n):
+def cpu_baseline(scene, cfg, args, rays_dev, latents_dev):
     """The CPU oracle (PyTorch-CPU port of reference render_rays/batchify_rays) on ``n`` rays of the same workload."""
-    from nonrigid_nerf_amd.synthetic import make_rays
     from oracle import nrnerf_oracle as O
-    rays, latents = make_rays(n, seed=100, cfg=cfg)
+    n = min(args.cpu_rays, rays_dev.shape[0])
+    rays, latents = rays_dev[:n].cpu(), latents_dev[:n].cpu().contiguous()
     # torch's default (one thread per logical core) oversubscribes a 256-thread host badly (measured 277 rays/s
     # at 128 threads vs ~1300 at 8); probe a few thread counts on a small sample and report the best.
     best_t, best_r = torch.get_num_threads(), 0.0
@@ -217,7 +396,10 @@ def cpu_baseline(scene, cfg, n):
         dt = time.perf_counter() - t0
     return {"value": round(n / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{n} rays of the same 64+128 workload, chunk 1024, torch {torch.__version__} CPU, "
-                      f"{threads} threads of {os.cpu_count()} host cores, {dt:.1f} s"}
+                      f"{threads} threads of {os.cpu_count()} host cores, {dt:.1f} s",
+            "port_vs_reference": "oracle/nrnerf_oracle.py restates the reference with the same torch ops; the unmodified "
+                                 "reference (train.render) and the port were timed side by side on the build container "
+                                 "(BASELINE.md section 2): ratio 0.97-1.03"}
 
 
 if __name__ == "__main__":

@@ -219,6 +219,37 @@ def run_gradients(H, T, seed=0):
     return out
 
 
+def run_render_path(H, T, seed=0):
+    """Reference ``train.render_path`` (train.py:419-553) on two tiny frames with detailed outputs, and the per-pixel
+    surface reduction free_viewpoint_rendering.py:621-658 performs on those outputs (the same torch ops, lifted: the
+    script itself needs a checkpoint directory and a GPU).  Pins ``O.render_path`` and ``O.surface_from_details``."""
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, seed)
+    kw, rb, coarse, fine = reference_kwargs(H, T, scene)
+    cams = [synthetic_camera(k, H=8, W=12) for k in range(2)]
+    poses, intrins = [c for c, _ in cams], [i for _, i in cams]
+    codes = torch.randn(2, cfg.latent_size, generator=torch.Generator().manual_seed(3)) * 0.1
+    with torch.no_grad():
+        rgbs, disps, details = T.render_path(poses, intrins, 32768, kw, codes, detailed_output=True)
+    out = {"out__rgbs": rgbs.astype(np.float32), "out__disps": disps.astype(np.float32), "in__codes": codes.numpy(),
+           "in__poses": np.stack([p.numpy() for p in poses], 0)}
+    for i, image_details in enumerate(details):
+        accumulated_visibility = torch.cumsum(torch.Tensor(image_details["fine_visibility_weights"]), dim=-1)      # fvr:623-625
+        median_indices = torch.min(torch.abs(accumulated_visibility - 0.5), dim=-1)[1]                               # fvr:626-628
+        height, width = median_indices.shape
+        surface_pixels = image_details["fine_input_pts"].reshape(height * width, -1, 3)[
+            np.arange(height * width), median_indices.cpu().reshape(-1), :].reshape(height, width, 3)               # fvr:631-637
+        rigidity = image_details["fine_rigidity_mask"].reshape(height * width, -1)[
+            np.arange(height * width), median_indices.cpu().reshape(-1)].reshape(height, width)                     # fvr:648-654
+        out[f"out__median_indices_{i}"] = median_indices.numpy().astype(np.int32)
+        out[f"out__surface_pixels_{i}"] = surface_pixels.astype(np.float32)
+        out[f"out__rigidity_{i}"] = rigidity.astype(np.float32)
+        if i == 0:       # the reference's own detail tensors of one frame, so the reduction can be checked on identical inputs
+            for k in ("fine_visibility_weights", "fine_input_pts", "fine_rigidity_mask"):
+                out["out__" + k + "_0"] = image_details[k].astype(np.float32)
+    return out
+
+
 def main():
     H, T = import_reference()
     os.makedirs(os.path.join(REPO, "tests", "golden"), exist_ok=True)
@@ -226,6 +257,10 @@ def main():
         __import__("json").dump(run_checkpoint_layout(H, T), f, indent=0, sort_keys=True)
     if "--only-layout" in sys.argv:
         return
+    if "--only-render-path" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "render_path_2frames.npz"), **run_render_path(H, T))
+        if "--only-render-path" in sys.argv:
+            return
     if "--only-grads" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_64_64.npz"), **run_gradients(H, T))
         if "--only-grads" in sys.argv:

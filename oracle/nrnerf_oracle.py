@@ -331,19 +331,25 @@ def pack_rays(rays_o, rays_d, near, far, use_viewdirs):
     return torch.cat(cols, -1)
 
 
-def render_path(render_poses, intrinsics, scene, ray_bending_latents, chunk=1024 * 32, **kw):
+def render_path(render_poses, intrinsics, scene, ray_bending_latents, chunk=1024 * 32, detailed_output=False, **kw):
     """render_path, train.py:419-553 (no image writing): per frame get_rays, one latent code expanded to every
-    pixel (:464-466), render, reshape to [H, W, ...].  Returns rgbs [F,H,W,3], disps [F,H,W] as float32 tensors."""
+    pixel (:464-466), render, reshape to [H, W, ...].  Returns rgbs [F,H,W,3], disps [F,H,W] as float32 tensors, plus
+    -- with ``detailed_output`` -- the list of per-frame dicts of the remaining keys reshaped [H, W, ...] (:487-497)."""
     cfg = scene.cfg
-    rgbs, disps = [], []
+    rgbs, disps, details = [], [], []
     for c2w, intrin, code in zip(render_poses, intrinsics, ray_bending_latents):
         ro, rd = get_rays(torch.as_tensor(c2w)[:3, :4], intrin)
         H, W = ro.shape[:2]
         rays = pack_rays(ro, rd, cfg.near, cfg.far, cfg.use_viewdirs)
         lat = torch.as_tensor(code).reshape(1, -1).expand(H * W, -1)
-        out = batchify_rays(rays, lat, scene, chunk=chunk, **kw)
+        out = batchify_rays(rays, lat, scene, chunk=chunk, detailed_output=detailed_output, **kw)
         rgbs.append(out["rgb_map"].reshape(H, W, 3))
         disps.append(out["disp_map"].reshape(H, W))
+        if detailed_output:
+            details.append({k: v.reshape((H, W) + tuple(v.shape[1:])) for k, v in out.items()
+                            if k not in ("rgb_map", "disp_map", "acc_map") and not k.startswith("_")})
+    if detailed_output:
+        return torch.stack(rgbs, 0), torch.stack(disps, 0), details
     return torch.stack(rgbs, 0), torch.stack(disps, 0)
 
 

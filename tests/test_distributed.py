@@ -110,3 +110,25 @@ def test_rccl_path_with_one_rank_on_the_gpu(tmp_path):
     assert p.exitcode == 0
     res = torch.load(out)
     assert res["ok"] and res["backend"] == "nccl"
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher must start two ranks by itself (torch.distributed.run) and report
+    them.  On a 1-GPU box NRNERF_BENCH_ONE_GPU=1 puts both ranks on GPU 0 and gathers over gloo (functional test of the
+    script's N > 1 path, not a measurement)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NRNERF_BENCH_ONE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rays", "8192", "--no-cpu-baseline", "--no-psnr"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["backend"] == "gloo"
+    assert res["steps"] == 3 and res["value"] > 0
