@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NRNERF_ABI_VERSION 1
+#define NRNERF_ABI_VERSION 2
 
 typedef enum nrnerf_status {
     NRNERF_OK = 0,
@@ -165,9 +165,11 @@ typedef struct nrnerf_render_args {
 } nrnerf_render_args;
 
 /* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */
-#define NRNERF_NUM_KERNELS 4
+#define NRNERF_NUM_KERNELS 5
 typedef struct nrnerf_profile {
-    /* 0: coarse network, 1: coarse composite+sample_pdf+merge, 2: fine network, 3: fine composite */
+    /* 0: coarse network, 1: coarse composite+sample_pdf+merge, 2: fine network, 3: fine composite,
+     * 4: stand-alone bender over the importance samples (split-bender path: the fine network kernel then runs without
+     *    bender layers on ready-made points; see nrnerf_render) */
     double ms[NRNERF_NUM_KERNELS];
     int64_t launches[NRNERF_NUM_KERNELS];
     double flops[NRNERF_NUM_KERNELS];        /* algorithmic 2*MAC, unpadded */
@@ -189,7 +191,14 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
                               int32_t n_importance);
 
 /* hip_stream: a hipStream_t of the model's device (NULL = its null stream).  Asynchronous.  The calling thread's
- * current device may be any: the launches are issued on the model's device and the previous one is restored. */
+ * current device may be any: the launches are issued on the model's device and the previous one is restored.
+ *
+ * Kernel sequence.  Default: coarse network -> composite + sample_pdf + merge -> fine network -> composite.  With a ray
+ * bender, no view-dependent head, n_importance > 0 and no per-sample detail outputs requested, the fine pass is split
+ * (same results): the coarse samples keep the bent points of the coarse launch (the bender is shared by both networks,
+ * run_nerf_helpers.py:213-215, and the coarse depths are a subset of the merged depths, train.py:920), a stand-alone
+ * bender kernel handles the n_importance new samples, and the fine network kernel runs its trunk on those points.  The
+ * environment variable NRNERF_FUSED_FINE_BENDER=1 (read once) keeps the fused fine pass. */
 int nrnerf_render(const nrnerf_model* model, const nrnerf_render_args* args, void* hip_stream);
 
 /* Camera rays of one frame, generated on the device: reference get_rays (run_nerf_helpers.py:588-605) followed by
@@ -210,7 +219,8 @@ int nrnerf_profile_begin(nrnerf_model* model);
 int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchronises the recorded events */
 
 /* Host-only packing (no device needed): writes the MFMA-fragment weight stream + unit table + bias
- * table of one pass exactly as nrnerf_model_create uploads them.  which: 0 = coarse, 1 = fine.
+ * table of one pass exactly as nrnerf_model_create uploads them.  which: 0 = coarse, 1 = fine, 2 = fine without the
+ * bender layers, 3 = bender + rigidity layers alone (2, 3: the split-bender path; need a bender and no view-dependent head).
  * Any output pointer may be NULL to query sizes only.  Used by the CPU-side packing tests. */
 typedef struct nrnerf_packed_info {
     uint64_t stream_bytes;     /* fragment stream */

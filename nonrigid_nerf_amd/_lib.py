@@ -12,11 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRNERF_LIB selects an alternative build of the same library (tuning experiments, see csrc/Makefile)
 LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
-NUM_KERNELS = 4
-KERNEL_NAMES = ("net_coarse", "composite_sample_coarse", "net_fine", "composite_fine")
+NUM_KERNELS = 5
+KERNEL_NAMES = ("net_coarse", "composite_sample_coarse", "net_fine", "composite_fine", "bend_fine")
 
 _fp = C.POINTER(C.c_float)
 

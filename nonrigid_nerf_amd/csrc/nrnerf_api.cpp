@@ -62,9 +62,9 @@ const nrnerf_linear* layer_source(const nrnerf_model_desc& d, const nrnerf_mlp_d
     return nullptr;
 }
 
-template <class SH, class A, bool HAS_BEND, bool VIEWS>
+template <class SH, class A, bool HAS_BEND, bool VIEWS, bool TRUNK = true>
 void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out) {
-    using PL = Plan<SH, A, HAS_BEND, VIEWS>;
+    using PL = Plan<SH, A, HAS_BEND, VIEWS, TRUNK>;
     constexpr int KH = SH::KH;
     const Tables& T = PL::TB;
     out.ntiles = T.ntiles; out.nunits = T.nunits_padded;
@@ -164,11 +164,12 @@ int check_arch_t(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
 }
 
 template <class A>
-void pack_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out) {
+void pack_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, bool bender_only = false) {
     const bool bend = d.bender != nullptr, views = m.use_viewdirs != 0;
     auto go = [&](auto sh) {
         using SH = decltype(sh);
-        if (bend && views) pack_pass<SH, A, true, true>(d, m, d.precision, out);
+        if (bender_only) pack_pass<SH, A, true, false, false>(d, m, d.precision, out);       // nrnerf_bend.h
+        else if (bend && views) pack_pass<SH, A, true, true>(d, m, d.precision, out);
         else if (bend) pack_pass<SH, A, true, false>(d, m, d.precision, out);
         else if (views) pack_pass<SH, A, false, true>(d, m, d.precision, out);
         else pack_pass<SH, A, false, false>(d, m, d.precision, out);
@@ -177,10 +178,11 @@ void pack_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass&
 }
 
 // picks the compiled architecture (nrnerf_plan.h ArchById) the description matches; *arch_id receives its id
-int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, int* arch_id = nullptr) {
+int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, int* arch_id = nullptr,
+                  bool bender_only = false) {
     int rc = check_arch_t<ArchDefault>(d, m);
     if (rc == NRNERF_OK) {
-        pack_arch<ArchDefault>(d, m, out);
+        pack_arch<ArchDefault>(d, m, out, bender_only);
         if (arch_id) *arch_id = 0;
         return NRNERF_OK;
     }
@@ -196,7 +198,7 @@ int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPa
     if (rc == NRNERF_ERR_UNSUPPORTED && d.bender) {     // arch 1 is a bender variant: only compiled with a bender
         const int rc1 = check_arch_t<ArchDeepBend>(d, m);
         if (rc1 == NRNERF_OK) {
-            pack_arch<ArchDeepBend>(d, m, out);
+            pack_arch<ArchDeepBend>(d, m, out, bender_only);
             if (arch_id) *arch_id = 1;
             return NRNERF_OK;
         }
@@ -252,6 +254,10 @@ struct nrnerf_model {
     int device = 0, precision = 0, has_bend = 0, views = 0, arch_id = 0, needs_latents = 0, num_cus = 0, latent_size = 0, exact = 0;
     PassDev coarse, fine;
     bool fine_is_coarse = false;
+    // split-bender path (bender, no view-dependent head): the fine network WITHOUT the bender layers (its input points
+    // come from the stand-alone bender kernel) and the bender + rigidity layers alone
+    PassDev fine_trunk, bend_only;
+    bool split_ok = false;
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
     mutable std::mutex prof_mu;
     mutable bool prof_on = false;
@@ -283,6 +289,17 @@ void free_pass(PassDev& dev) {
     dev = PassDev{};
 }
 
+// The two extra weight images of the split-bender path: the fine network without its bender layers (same trunk for the
+// 5- and the 7-layer bender: compiled architecture 0 without bender) and the bender + rigidity layers alone.
+int pack_split(const nrnerf_model_desc& d, PackedPass& trunk, PackedPass& bend) {
+    const nrnerf_mlp_desc& fm = d.fine ? *d.fine : *d.coarse;
+    nrnerf_model_desc d2 = d;
+    d2.bender = nullptr;
+    int rc = pack_dispatch(d2, fm, trunk);
+    if (rc != NRNERF_OK) return rc;
+    return pack_dispatch(d, fm, bend, nullptr, /*bender_only=*/true);
+}
+
 }  // namespace
 
 extern "C" {
@@ -306,7 +323,14 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
     if (!desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
     const nrnerf_mlp_desc* m = (which == 1 && desc->fine) ? desc->fine : desc->coarse;
     PackedPass pk;
-    int rc = pack_dispatch(*desc, *m, pk);
+    int rc;
+    if (which == 2 || which == 3) {
+        if (!desc->bender || desc->coarse->use_viewdirs) return NRNERF_ERR_UNSUPPORTED;
+        PackedPass other;
+        rc = (which == 2) ? pack_split(*desc, pk, other) : pack_split(*desc, other, pk);
+    } else {
+        rc = pack_dispatch(*desc, *m, pk);
+    }
     if (rc != NRNERF_OK) return rc;
     if (info) {
         info->stream_bytes = pk.stream.size();
@@ -370,6 +394,21 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
         m->fine = m->coarse;
         m->fine_is_coarse = true;
     }
+    if (rc == NRNERF_OK && m->has_bend && !m->views) {
+        PackedPass pt, pb;
+        if (pack_split(*desc, pt, pb) == NRNERF_OK) {
+            rc = upload_pass(pt, m->fine_trunk);
+            if (rc == NRNERF_OK) rc = upload_pass(pb, m->bend_only);
+            nrnerf_model_desc d2 = *desc;
+            d2.bender = nullptr;
+            m->fine_trunk.algo_flops_per_sample = 2.0 * algo_macs(d2, desc->fine ? *desc->fine : *desc->coarse);
+            m->fine_trunk.mfma_flops_per_sample = pt.mfma_per_block * mfma_flop / 32.0;
+            m->fine_trunk.output_ch = m->fine.output_ch;
+            m->bend_only.algo_flops_per_sample = m->fine.algo_flops_per_sample - m->fine_trunk.algo_flops_per_sample;
+            m->bend_only.mfma_flops_per_sample = pb.mfma_per_block * mfma_flop / 32.0;
+            m->split_ok = (rc == NRNERF_OK);
+        }
+    }
     (void)hipSetDevice(prev);
     if (rc != NRNERF_OK) { nrnerf_model_destroy(m); return rc; }
     *out = m;
@@ -396,6 +435,12 @@ int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hi
     hipStream_t stream = (hipStream_t)hip_stream;
     rc = refresh_pass(pc, m->coarse, stream);
     if (rc == NRNERF_OK && desc->fine) rc = refresh_pass(pf, m->fine, stream);
+    PackedPass pt, pb;
+    if (rc == NRNERF_OK && m->split_ok) {
+        rc = pack_split(*desc, pt, pb);
+        if (rc == NRNERF_OK) rc = refresh_pass(pt, m->fine_trunk, stream);
+        if (rc == NRNERF_OK) rc = refresh_pass(pb, m->bend_only, stream);
+    }
     // the packed host images die with this call: wait until the copies have consumed them
     if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;
     (void)hipSetDevice(prev);
@@ -410,6 +455,8 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     for (auto& e : m->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (!m->fine_is_coarse) free_pass(m->fine);
     free_pass(m->coarse);
+    free_pass(m->fine_trunk);
+    free_pass(m->bend_only);
     (void)hipSetDevice(prev);
     delete m;
 }
@@ -420,8 +467,12 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
     const size_t N = (size_t)n_rays, S = (size_t)n_samples, SF = S + (size_t)n_importance;
     size_t b = align_up(N * S * 4 * sizeof(float), 256);
     if (n_importance > 0) b += align_up(N * SF * sizeof(float), 256) + align_up(N * SF * 4 * sizeof(float), 256);
-    b += align_up(N * SF * 4 * sizeof(float), 256);      // bent point + rigidity of the final pass (surface reduction)
+    b += align_up(N * SF * 4 * sizeof(float), 256);      // bent point + rigidity of the final pass (surface reduction, split-bender path)
     b += align_up(N * S * sizeof(float), 256);           // jittered coarse depths (perturb > 0)
+    if (n_importance > 0) {                              // split-bender path: coarse bent points, depths + rows of the new samples
+        b += align_up(N * S * 4 * sizeof(float), 256);
+        b += align_up(N * (SF - S) * sizeof(float), 256) + align_up(N * (SF - S), 256);
+    }
     return b;
 }
 
@@ -453,7 +504,22 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     float* bent4 = (float*)ws;
     ws += align_up((size_t)N * SF * 4 * sizeof(float), 256);
     float* z_coarse = (float*)ws;
-    if (!surface) bent4 = nullptr;
+    ws += align_up((size_t)N * S * sizeof(float), 256);
+    // Split-bender path: bender, no view-dependent head, a fine pass, no per-sample detail outputs (those are written by
+    // the fused kernels).  NRNERF_FUSED_FINE_BENDER=1 keeps the fused fine pass (A/B and bit-identity tests).
+    auto any_detail = [](const nrnerf_sample_outputs& o) {
+        return o.visibility_weights || o.opacity_alpha || o.initial_input_pts || o.unmasked_offsets || o.masked_offsets ||
+               o.input_pts || o.rigidity_mask;
+    };
+    static const bool force_fused = [] { const char* e = std::getenv("NRNERF_FUSED_FINE_BENDER"); return e && e[0] == '1'; }();
+    const bool split = m->split_ok && I > 0 && !a->detailed_output && !any_detail(a->coarse) && !any_detail(a->fine) && !force_fused;
+    float* bent_c = nullptr; float* z_new = nullptr; uint8_t* rank_new = nullptr;
+    if (I > 0) {
+        bent_c = (float*)ws; ws += align_up((size_t)N * S * 4 * sizeof(float), 256);
+        z_new = (float*)ws; ws += align_up((size_t)N * I * sizeof(float), 256);
+        rank_new = (uint8_t*)ws;
+    }
+    if (!surface && !split) bent4 = nullptr;
     if ((a->u_fine || a->noise_fine) && I == 0) return NRNERF_ERR_INVALID;
 
     Knobs kn{};
@@ -498,7 +564,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.raw4 = raw_c;
     na.raw_out = (I == 0) ? a->raw : nullptr;
     na.raw_ch = m->coarse.output_ch;
-    na.bent4 = (I == 0) ? bent4 : nullptr;
+    na.bent4 = (I == 0) ? bent4 : (split ? bent_c : nullptr);
     na.ex = sample_out(a->coarse);
     na.knobs = kn;
     hipError_t e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
@@ -518,6 +584,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         ca.disp = a->disp0 ? a->disp0 : raw_f + (size_t)N * 3;
         ca.acc = a->acc0 ? a->acc0 : raw_f + (size_t)N * 4;
         ca.z_std = a->z_std; ca.z_out = z_fine; ca.z_user = nullptr;
+        if (split) { ca.split_bent_in = bent_c; ca.split_bent_out = bent4; ca.z_new = z_new; ca.rank_new = rank_new; }
     } else {
         ca.rgb = a->rgb_map; ca.disp = a->disp_map; ca.acc = a->acc_map;
         ca.z_std = nullptr; ca.z_out = nullptr; ca.z_user = a->z_vals;
@@ -531,12 +598,30 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // ---- K2: fine network on the merged depths
     NetArgs nf = na;
     nf.z = z_fine; nf.S = SF;
-    nf.wstream = m->fine.stream; nf.bias = m->fine.bias;
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
-    nf.bent4 = bent4;
-    e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
-              [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, nf, m->num_cus, stream); });
+    if (split) {
+        // KB: only the I importance samples go through the bender; the coarse samples' bent points are already in place
+        BendArgs ba{};
+        ba.rays = a->rays; ba.ray_stride = a->ray_stride;
+        ba.latents = a->latents; ba.lat_stride = a->latent_stride;
+        ba.z = z_new; ba.rank = rank_new; ba.n_rays = N; ba.n_per_ray = I; ba.out_stride = SF;
+        ba.wstream = m->bend_only.stream; ba.bias = m->bend_only.bias;
+        ba.bent4 = bent4; ba.knobs = kn;
+        e = timed(4, (double)N * I * m->bend_only.algo_flops_per_sample, (double)N * I * m->bend_only.mfma_flops_per_sample,
+                  [&] { return launch_bend(m->precision, m->arch_id, ba, m->num_cus, stream); });
+        if (e != hipSuccess) return NRNERF_ERR_HIP;
+        // K2: trunk + head on ready-made points (compiled architecture 0 without bender)
+        nf.pts4 = bent4; nf.bent4 = nullptr;
+        nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
+        e = timed(2, (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,
+                  [&] { return launch_net(m->precision, false, false, 0, nf, m->num_cus, stream); });
+    } else {
+        nf.wstream = m->fine.stream; nf.bias = m->fine.bias;
+        nf.bent4 = bent4;
+        e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
+                  [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, nf, m->num_cus, stream); });
+    }
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K3: fine composite

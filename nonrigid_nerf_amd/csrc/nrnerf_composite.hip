@@ -223,6 +223,17 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
         //   rank(coarse i) = i + #{samples <  z_i}          (stable: ties keep the concatenation order, coarse first)
         //   rank(sample k) = k + #{coarse  <= s_k}
         // Otherwise fall back to counting against all n elements (correct for any input order).
+        // split-bender path: coarse sample i keeps its bent point, moved to its row among the merged depths; importance
+        // sample k is listed (depth, row) for the stand-alone bender kernel
+        auto split_out = [&](int idx, int rank, float depth) {
+            if (!a.rank_new) return;
+            if (idx < S) {
+                *(f32x4*)(a.split_bent_out + ((size_t)ray * n + rank) * 4) = *(const f32x4*)(a.split_bent_in + ((size_t)ray * S + idx) * 4);
+            } else {
+                a.rank_new[(size_t)ray * I + (idx - S)] = (uint8_t)rank;
+                a.z_new[(size_t)ray * I + (idx - S)] = depth;
+            }
+        };
         bool mono = true;
         for (int k = lane; k < I; k += 64)
             if (k > 0 && s_z[wave][S + k] < s_z[wave][S + k - 1]) mono = false;
@@ -240,7 +251,7 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
                     while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[wave][mid] <= mine) lo = mid + 1; else hi = mid; }
                     rank = (idx - S) + lo;
                 }
-                if (ray_ok) a.z_out[(size_t)ray * n + rank] = mine;
+                if (ray_ok) { a.z_out[(size_t)ray * n + rank] = mine; split_out(idx, rank, mine); }
             }
         } else {
             for (int idx = lane; idx < n; idx += 64) {
@@ -250,7 +261,7 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
                     const float o = s_z[wave][jj];
                     rank += (o < mine || (o == mine && jj < idx)) ? 1 : 0;
                 }
-                if (ray_ok) a.z_out[(size_t)ray * n + rank] = mine;
+                if (ray_ok) { a.z_out[(size_t)ray * n + rank] = mine; split_out(idx, rank, mine); }
             }
         }
     }

@@ -29,6 +29,8 @@ struct NetArgs {
     const float* latents; int lat_stride;
     const float* z;          // [N,S] sample depths, or nullptr: coarse linspace between near and far
     int lindisp;             // coarse spacing linear in inverse depth (train.py:850-852); only read when z == nullptr
+    const float* pts4;       // [N,S,4] ready-made network input points (xyz, w unused) instead of o + d z -- the bent points
+                             // of the stand-alone bender kernel; only read by the variants without a fused bender; or nullptr
     int n_rays, S;
     const void* wstream;     // packed fragment stream of this pass (whole 16 KiB units, nrnerf_plan.h)
     const float* bias;       // [NTILES*32]
@@ -60,7 +62,28 @@ struct CompositeArgs {
     float* surf_pts;             // [N,3] bent point at that sample
     float* surf_rig;             // [N]   rigidity mask at that sample
     int* med_idx;                // [N]   its index
+    // split-bender path (I > 0): the coarse depths are a subset of the merged depths and the bender is shared by both
+    // networks (run_nerf_helpers.py:213-215), so the fine pass re-uses the coarse pass' bent points and only the I new
+    // samples go through the bender again.  All nullptr = off.
+    const float* split_bent_in;  // [N,S,4]   bent point + rigidity of the coarse samples (written by the coarse network kernel)
+    float* split_bent_out;       // [N,S+I,4] the same rows moved to their position among the merged depths
+    float* z_new;                // [N,I]     depths of the importance samples, in sample order
+    uint8_t* rank_new;           // [N,I]     position of each importance sample among the merged depths (S + I <= 256)
 };
+
+// Stand-alone bender (ray_bending.forward, run_nerf_helpers.py:507-577) over n_per_ray samples of every ray.
+struct BendArgs {
+    const float* rays;   int ray_stride;
+    const float* latents; int lat_stride;
+    const float* z;          // [N, n_per_ray] sample depths
+    const uint8_t* rank;     // [N, n_per_ray] row of each sample among the out_stride rows of its ray, or nullptr: identity
+    int n_rays, n_per_ray, out_stride;
+    const void* wstream;     // packed bender + rigidity fragments (Plan<..., TRUNK = false>)
+    const float* bias;
+    float* bent4;            // [N, out_stride, 4] bent point xyz + rigidity mask
+    Knobs knobs;
+};
+hipError_t launch_bend(int precision, int arch_id, const BendArgs& a, int num_cus, hipStream_t stream);
 
 // stratified jitter of the coarse depths (train.py:855-868): z = lower + (upper - lower) * u between the mid-points
 struct JitterArgs {

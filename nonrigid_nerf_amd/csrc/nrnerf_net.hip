@@ -28,6 +28,20 @@ static const launch_fn TABLE[5][3][2][2] = {
     {NRN_ROW4(f32), NRN_ROW4(bf16), NRN_ROW4(f16)},
 };
 
+// stand-alone bender kernels: [arch 0 = 5-layer, 1 = 7-layer offset MLP][precision]
+typedef hipError_t (*bend_fn)(const BendArgs&, int, hipStream_t);
+#define NRN_BDECL(n) hipError_t launch_bend_##n(const BendArgs&, int, hipStream_t);
+NRN_BDECL(a0_f32) NRN_BDECL(a0_bf16) NRN_BDECL(a0_f16) NRN_BDECL(a1_f32) NRN_BDECL(a1_bf16) NRN_BDECL(a1_f16)
+#undef NRN_BDECL
+static const bend_fn BEND_TABLE[2][3] = {
+    {launch_bend_a0_f32, launch_bend_a0_bf16, launch_bend_a0_f16},
+    {launch_bend_a1_f32, launch_bend_a1_bf16, launch_bend_a1_f16},
+};
+hipError_t launch_bend(int precision, int arch_id, const BendArgs& a, int num_cus, hipStream_t stream) {
+    if (arch_id < 0 || arch_id > 1 || precision < 0 || precision > 2) return hipErrorInvalidValue;
+    return BEND_TABLE[arch_id][precision](a, num_cus, stream);
+}
+
 hipError_t launch_net(int precision, bool has_bend, bool views, int arch_id, const NetArgs& a, int num_cus, hipStream_t stream) {
     if (arch_id < 0 || arch_id > 4 || precision < 0 || precision > 2) return hipErrorInvalidValue;
     const launch_fn f = TABLE[arch_id][precision][has_bend ? 1 : 0][views ? 1 : 0];

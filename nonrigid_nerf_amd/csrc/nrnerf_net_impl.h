@@ -622,6 +622,12 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                       __fadd_rn(oz, __fmul_rn(dz, z))};                                  // train.py:871-873
         const size_t so = (size_t)ray * S + sc;     // flat sample index for per-sample outputs
         const bool writer = ok && h == 0;
+        if constexpr (!HAS_BEND) {
+            if (a.pts4) {       // points bent by the stand-alone bender kernel (nrnerf_bend.h)
+                const f32x4 q = *(const f32x4*)(a.pts4 + so * 4);
+                p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+            }
+        }
 
         if (writer && a.ex.init_pts) {
             a.ex.init_pts[so * 3 + 0] = p[0]; a.ex.init_pts[so * 3 + 1] = p[1]; a.ex.init_pts[so * 3 + 2] = p[2];

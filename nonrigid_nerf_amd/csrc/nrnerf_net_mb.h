@@ -301,6 +301,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
             p[b][2] = __fadd_rn(oz, __fmul_rn(dz, z));                                       // train.py:871-873
             so[b] = (size_t)ray[b] * S + sc[b];
             writer[b] = ok[b] && h == 0;
+            if constexpr (!HAS_BEND) {
+                if (a.pts4) {       // points bent by the stand-alone bender kernel (nrnerf_bend.h)
+                    const f32x4 q = *(const f32x4*)(a.pts4 + so[b] * 4);
+                    p[b][0] = q[0]; p[b][1] = q[1]; p[b][2] = q[2];
+                }
+            }
             if (writer[b] && a.ex.init_pts) {
                 a.ex.init_pts[so[b] * 3 + 0] = p[b][0]; a.ex.init_pts[so[b] * 3 + 1] = p[b][1]; a.ex.init_pts[so[b] * 3 + 2] = p[b][2];
             }

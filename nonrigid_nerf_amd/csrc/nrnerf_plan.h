@@ -155,7 +155,8 @@ struct Tables {
     int nlayers, ntiles, nfrags, nunits, nunits_padded, mfma_per_block;
 };
 
-template <class SH, class A, bool HAS_BEND, bool VIEWS = false>
+// TRUNK = false: only the bender / rigidity layers (the stand-alone bender kernel, nrnerf_bend.h; needs HAS_BEND)
+template <class SH, class A, bool HAS_BEND, bool VIEWS = false, bool TRUNK = true>
 constexpr Tables build_tables() {
     constexpr int KH = SH::KH, SP = SH::SP;
     constexpr int NS_ENC = ns_trunk_in<SH, A>();
@@ -179,18 +180,20 @@ constexpr Tables build_tables() {
         for (int i = 1; i < A::RD - 1; ++i) add(LK_RIG_HID, i, NT_RW * SP, NT_RW);
         add(LK_RIG_OUT, A::RD - 1, NT_RW * SP, 1);
     }
-    add(LK_TR_IN, 0, NS_ENC, NT_W);
-    for (int i = 1; i < A::D; ++i) {
-        if (i - 1 == A::SKIP) add(LK_TR_SKIP, i, NS_ENC + NT_W * SP, NT_W);
-        else add(LK_TR_HID, i, NT_W * SP, NT_W);
-    }
-    if (VIEWS) {
-        add(LK_ALPHA, 0, NT_W * SP, 1);
-        add(LK_FEAT, 0, NT_W * SP, NT_W);
-        add(LK_VIEWS, 0, NS_ENCV + NT_W * SP, NT_W / 2);
-        add(LK_RGB, 0, (NT_W / 2) * SP, 1);
-    } else {
-        add(LK_HEAD, 0, NT_W * SP, 1);
+    if (TRUNK) {
+        add(LK_TR_IN, 0, NS_ENC, NT_W);
+        for (int i = 1; i < A::D; ++i) {
+            if (i - 1 == A::SKIP) add(LK_TR_SKIP, i, NS_ENC + NT_W * SP, NT_W);
+            else add(LK_TR_HID, i, NT_W * SP, NT_W);
+        }
+        if (VIEWS) {
+            add(LK_ALPHA, 0, NT_W * SP, 1);
+            add(LK_FEAT, 0, NT_W * SP, NT_W);
+            add(LK_VIEWS, 0, NS_ENCV + NT_W * SP, NT_W / 2);
+            add(LK_RGB, 0, (NT_W / 2) * SP, 1);
+        } else {
+            add(LK_HEAD, 0, NT_W * SP, 1);
+        }
     }
     T.nlayers = nl;
     T.ntiles = tile0;
@@ -216,8 +219,9 @@ constexpr Tables build_tables() {
     return T;
 }
 
-template <class SH, class A, bool HAS_BEND, bool VIEWS = false>
+template <class SH, class A, bool HAS_BEND, bool VIEWS = false, bool TRUNK = true>
 struct Plan {
+    static_assert(TRUNK || (HAS_BEND && !VIEWS), "a plan without trunk is the bender alone");
     static constexpr int KH = SH::KH, SP = SH::SP;
     static constexpr int NS_ENC = ns_trunk_in<SH, A>();          // xyz encoding slabs (+ latent slabs when A::TCB)
     static constexpr int NS_ENC_XYZ = ns_enc_xyz<SH, A>();
@@ -225,7 +229,7 @@ struct Plan {
     static constexpr int NS_BIN = cdiv(bin_len(A::LAT), 2 * KH);
     static constexpr int NS_RIN = cdiv(rin_len(), 2 * KH);
     static constexpr int NT_W = A::W / 32, NT_BW = A::BW / 32, NT_RW = A::RW / 32;
-    static constexpr Tables TB = build_tables<SH, A, HAS_BEND, VIEWS>();
+    static constexpr Tables TB = build_tables<SH, A, HAS_BEND, VIEWS, TRUNK>();
     static constexpr int NLAYERS = TB.nlayers;
     static constexpr int NTILES = TB.ntiles;
     static constexpr int NFRAGS = TB.nfrags;

@@ -88,7 +88,10 @@ def test_full_frame_psnr_vs_oracle_all_rays():
         for p, r in res.items()))
     assert res["f32"]["rgb0"] >= 80.0 and res["f32"]["rgb_map"] >= 55.0, res["f32"]     # fine pass: a few moved samples (rnh:694)
     for prec in ("bf16", "f16"):
-        assert res[prec]["rgb_map"] >= 40.0 and res[prec]["rgb0"] >= 40.0, (prec, res[prec])
+        assert res[prec]["rgb_map"] >= 40.0 and res[prec]["rgb0"] >= 40.0, (prec, res[prec])     # the stated bar
+    # regression guards at the measured level (round 2: bf16 65.8 / 70.7 dB, f16 74.0 / 85.3 dB)
+    assert res["bf16"]["rgb_map"] >= 58.0 and res["bf16"]["rgb0"] >= 62.0, res["bf16"]
+    assert res["f16"]["rgb_map"] >= 66.0 and res["f16"]["rgb0"] >= 75.0, res["f16"]
 
 
 @pytest.mark.gpu
