@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NRNERF_ABI_VERSION 2
+#define NRNERF_ABI_VERSION 3
 
 typedef enum nrnerf_status {
     NRNERF_OK = 0,
@@ -165,11 +165,11 @@ typedef struct nrnerf_render_args {
 } nrnerf_render_args;
 
 /* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */
-#define NRNERF_NUM_KERNELS 5
+#define NRNERF_NUM_KERNELS 6
 typedef struct nrnerf_profile {
     /* 0: coarse network, 1: coarse composite+sample_pdf+merge, 2: fine network, 3: fine composite,
-     * 4: stand-alone bender over the importance samples (split-bender path: the fine network kernel then runs without
-     *    bender layers on ready-made points; see nrnerf_render) */
+     * 4: stand-alone bender over the importance samples, 5: stand-alone bender over the coarse samples (split-bender
+     *    path: the network kernels then run without bender layers on ready-made points; see nrnerf_render) */
     double ms[NRNERF_NUM_KERNELS];
     int64_t launches[NRNERF_NUM_KERNELS];
     double flops[NRNERF_NUM_KERNELS];        /* algorithmic 2*MAC, unpadded */
@@ -185,6 +185,14 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out);
  * on return.  NRNERF_ERR_INVALID if the description is a different model (create a new handle then).  Must not run
  * concurrently with nrnerf_render on the same handle from another stream. */
 int nrnerf_model_update(nrnerf_model* model, const nrnerf_model_desc* desc, void* hip_stream);
+/* The same refresh from DEVICE memory, without a host round trip (one gather/convert kernel per packed image; what a
+ * training loop calls after every optimiser step).  flat_params: device pointer to all parameters as one fp32 vector --
+ * every nn.Linear as weight [out, in] row-major followed by its bias [out] (if it has one), in the order
+ * bender.network[0..], bender.rigidity_network[0..], then network_fn: pts_linears[0..], output_linear (or alpha_linear,
+ * feature_linear, views_linears[0], rgb_linear); then network_fine likewise.  n_floats must equal
+ * nrnerf_model_flat_size().  Asynchronous on hip_stream; same concurrency rule as nrnerf_model_update. */
+int64_t nrnerf_model_flat_size(const nrnerf_model* model);
+int nrnerf_model_update_device(nrnerf_model* model, const float* flat_params, int64_t n_floats, void* hip_stream);
 void nrnerf_model_destroy(nrnerf_model* model);
 
 size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples,
@@ -195,10 +203,11 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
  *
  * Kernel sequence.  Default: coarse network -> composite + sample_pdf + merge -> fine network -> composite.  With a ray
  * bender, no view-dependent head, n_importance > 0 and no per-sample detail outputs requested, the fine pass is split
- * (same results): the coarse samples keep the bent points of the coarse launch (the bender is shared by both networks,
- * run_nerf_helpers.py:213-215, and the coarse depths are a subset of the merged depths, train.py:920), a stand-alone
- * bender kernel handles the n_importance new samples, and the fine network kernel runs its trunk on those points.  The
- * environment variable NRNERF_FUSED_FINE_BENDER=1 (read once) keeps the fused fine pass. */
+ * (same results): every sample is bent exactly once by a stand-alone bender kernel -- the coarse samples before the
+ * coarse network, the n_importance new samples before the fine network; the coarse samples keep their bent points in
+ * the fine pass (the bender is shared by both networks, run_nerf_helpers.py:213-215, and the coarse depths are a subset
+ * of the merged depths, train.py:920) -- and the network kernels run their trunks on those points.  Environment
+ * variables (read once): NRNERF_FUSED_FINE_BENDER=1 keeps both passes fused, NRNERF_SPLIT_COARSE=0 only the coarse one. */
 int nrnerf_render(const nrnerf_model* model, const nrnerf_render_args* args, void* hip_stream);
 
 /* Camera rays of one frame, generated on the device: reference get_rays (run_nerf_helpers.py:588-605) followed by
@@ -214,13 +223,64 @@ typedef struct nrnerf_camera {
 int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_plane, float* rays_out,
                          int32_t ray_stride, void* hip_stream);
 
+/* ---- training support ------------------------------------------------------------------------------------------
+ * The reference trains through autograd (training_wrapper_class.forward, train.py:152-287; backward + optimiser step,
+ * train.py:1594-1610).  These entry points are the pieces a torch.autograd.Function needs (nonrigid_nerf_amd/training.py
+ * is the binding): the canonical network's trunk forward with saved activations and its backward-data pass, and the
+ * compositing forward / backward.  The deformation MLPs stay with the caller's autograd (their regularisers need double
+ * backward, run_nerf_helpers.py:22-116): the trunk takes ready-made (bent) points and returns the gradient wrt them.
+ * Weight gradients are plain GEMMs over two arrays these calls fill: dW_i = d_pre[i]^T x_i with x_0 = encoding,
+ * x_i = acts[i-1] (x_{skip+1} = [encoding, acts[skip]]), db_i = column sums of d_pre[i]; d W_out = d_raw^T acts[D-1].
+ * Available (else NRNERF_ERR_UNSUPPORTED) for the default architecture without view-dependent head, fp32 or bf16. */
+typedef struct nrnerf_trunk_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_trunk_args) */
+    int32_t which;              /* 0 = network_fn (coarse), 1 = network_fine */
+    int32_t n_rays, n_samples;  /* M = n_rays * n_samples points, sample-major per ray */
+    const float* pts4;          /* [M,4] network input points: xyz + one pad float */
+    void* acts;                 /* [depth][M][width] relu(W_i x_i + b_i): float (fp32 mode) / bf16 (bf16 mode); forward
+                                   writes, backward reads */
+    /* forward */
+    float* raw4;                /* out [M,4]  rgb + sigma logits (what nrnerf_composite_* consume) */
+    float* raw;                 /* out [M,raw_ch] all output channels ("raw" of render_rays), or NULL */
+    int32_t raw_ch;             /* 4 or 5 */
+    /* backward */
+    const float* d_raw4;        /* [M,4] gradient wrt raw4 */
+    void* d_pre;                /* out [depth][M][width] gradient wrt every layer's pre-activation, type of acts */
+    float* d_pts4;              /* out [M,4] gradient wrt the input points (xyz, 0) */
+} nrnerf_trunk_args;
+int nrnerf_trunk_forward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);
+int nrnerf_trunk_backward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);
+
+/* raw2outputs (train.py:724-789) of one pass, optionally followed by sample_pdf + merge (run_nerf_helpers.py:651-698,
+ * train.py:910-920), and its backward.  Runs on the device that owns raw4. */
+typedef struct nrnerf_composite_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_composite_args) */
+    int32_t n_rays, n_samples, n_importance;   /* n_importance > 0 (forward only): also draw and merge the new depths */
+    const float* rays; int32_t ray_stride;     /* as nrnerf_render_args */
+    const float* raw4;          /* [N,S,4] */
+    const float* z;             /* [N,S] depths of this pass, or NULL: linspace(near, far) (lindisp honoured) */
+    int32_t lindisp, white_bkgd;
+    const float* noise;         /* [N,S] added to sigma before the relu, or NULL */
+    const float* u;             /* [N,I] uniforms for sample_pdf, or NULL: linspace(0,1,I) */
+    /* forward outputs */
+    float* rgb; float* disp; float* acc;       /* [N,3], [N], [N] */
+    float* weights; float* alpha;              /* [N,S] visibility weights / opacities, or NULL */
+    float* z_std; float* z_merged;             /* [N], [N,S+I] (n_importance > 0) */
+    /* backward: gradients of the forward outputs (NULL = zero), gradient wrt raw4 */
+    const float* g_rgb; const float* g_disp; const float* g_acc; const float* g_weights;
+    float* d_raw4;              /* out [N,S,4] */
+} nrnerf_composite_args;
+int nrnerf_composite_forward(const nrnerf_composite_args* args, void* hip_stream);
+int nrnerf_composite_backward(const nrnerf_composite_args* args, void* hip_stream);
+
 /* profiling: records hipEvents around each kernel of subsequent nrnerf_render calls on this model */
 int nrnerf_profile_begin(nrnerf_model* model);
 int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchronises the recorded events */
 
 /* Host-only packing (no device needed): writes the MFMA-fragment weight stream + unit table + bias
  * table of one pass exactly as nrnerf_model_create uploads them.  which: 0 = coarse, 1 = fine, 2 = fine without the
- * bender layers, 3 = bender + rigidity layers alone (2, 3: the split-bender path; need a bender and no view-dependent head).
+ * bender layers, 3 = bender + rigidity layers alone (2, 3: the split-bender path; need a bender and no view-dependent head),
+ * 4 / 5 = transposed trunk weights of the coarse / fine network for the backward-data kernel (training).
  * Any output pointer may be NULL to query sizes only.  Used by the CPU-side packing tests. */
 typedef struct nrnerf_packed_info {
     uint64_t stream_bytes;     /* fragment stream */

@@ -12,11 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRNERF_LIB selects an alternative build of the same library (tuning experiments, see csrc/Makefile)
 LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
-NUM_KERNELS = 5
-KERNEL_NAMES = ("net_coarse", "composite_sample_coarse", "net_fine", "composite_fine", "bend_fine")
+NUM_KERNELS = 6
+KERNEL_NAMES = ("net_coarse", "composite_sample_coarse", "net_fine", "composite_fine", "bend_fine", "bend_coarse")
 
 _fp = C.POINTER(C.c_float)
 
@@ -85,15 +85,39 @@ class Camera(C.Structure):
                 ("center_y", C.c_float), ("height", C.c_int32), ("width", C.c_int32)]
 
 
+class TrunkArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("which", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+                ("pts4", C.c_void_p), ("acts", C.c_void_p),
+                ("raw4", C.c_void_p), ("raw", C.c_void_p), ("raw_ch", C.c_int32),
+                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p)]
+
+
+class CompositeArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("n_importance", C.c_int32),
+                ("rays", C.c_void_p), ("ray_stride", C.c_int32),
+                ("raw4", C.c_void_p), ("z", C.c_void_p), ("lindisp", C.c_int32), ("white_bkgd", C.c_int32),
+                ("noise", C.c_void_p), ("u", C.c_void_p),
+                ("rgb", C.c_void_p), ("disp", C.c_void_p), ("acc", C.c_void_p), ("weights", C.c_void_p), ("alpha", C.c_void_p),
+                ("z_std", C.c_void_p), ("z_merged", C.c_void_p),
+                ("g_rgb", C.c_void_p), ("g_disp", C.c_void_p), ("g_acc", C.c_void_p), ("g_weights", C.c_void_p),
+                ("d_raw4", C.c_void_p)]
+
+
 EXPORTS = {
     "nrnerf_abi_version": (C.c_int, []),
     "nrnerf_strerror": (C.c_char_p, [C.c_int]),
     "nrnerf_model_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "nrnerf_model_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrnerf_model_flat_size": (C.c_int64, [C.c_void_p]),
+    "nrnerf_model_update_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "nrnerf_model_destroy": (None, [C.c_void_p]),
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
+    "nrnerf_trunk_forward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
+    "nrnerf_trunk_backward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
+    "nrnerf_composite_forward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),
+    "nrnerf_composite_backward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),
     "nrnerf_profile_begin": (C.c_int, [C.c_void_p]),
     "nrnerf_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "nrnerf_pack_host": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(PackedInfo), C.c_void_p, C.c_size_t,

@@ -46,7 +46,43 @@ struct PackedPass {
     std::vector<uint32_t> unit_off;   // nunits + 1, in 16-byte words
     std::vector<float> bias;          // ntiles * 32
     int ntiles = 0, nunits = 0, frag_bytes = 0, slot_bytes = 0, mfma_per_block = 0;
+    // where every stream element / bias entry comes from in the flat parameter vector (nrnerf_model_update_device):
+    // index (-1 = constant zero) and target format (RepackFmt); filled when a FlatLayout is given to the packer
+    std::vector<int32_t> src, bias_src;
+    std::vector<uint8_t> fmt;
 };
+
+// Flat parameter vector of a model (documented in nrnerf.h at nrnerf_model_update_device): every nn.Linear as weight
+// [out, in] row-major then bias [out] (if it has one), in the order bender.network[0..], bender.rigidity_network[0..],
+// coarse (pts_linears[0..], then output_linear | alpha, feature, views, rgb), fine likewise.
+struct FlatLayout {
+    std::vector<std::pair<const float*, int64_t>> base;      // host weight / bias pointer of the description -> offset
+    int64_t total = 0;
+    void add(const nrnerf_linear& l) {
+        if (!l.weight) return;
+        base.push_back({l.weight, total}); total += (int64_t)l.out_features * l.in_features;
+        if (l.bias) { base.push_back({l.bias, total}); total += l.out_features; }
+    }
+    int64_t of(const float* p) const {
+        for (auto& b : base) if (b.first == p) return b.second;
+        return -1;
+    }
+};
+void add_mlp(FlatLayout& f, const nrnerf_mlp_desc& m) {
+    for (int i = 0; i < m.depth; ++i) f.add(m.pts_linears[i]);
+    if (m.use_viewdirs) { f.add(m.alpha_linear); f.add(m.feature_linear); f.add(m.views_linear); f.add(m.rgb_linear); }
+    else f.add(m.output_linear);
+}
+FlatLayout flat_layout(const nrnerf_model_desc& d) {
+    FlatLayout f;
+    if (d.bender) {
+        for (int i = 0; i < d.bender->depth; ++i) f.add(d.bender->network[i]);
+        for (int i = 0; i < d.bender->rigidity_depth; ++i) f.add(d.bender->rigidity_network[i]);
+    }
+    add_mlp(f, *d.coarse);
+    if (d.fine) add_mlp(f, *d.fine);
+    return f;
+}
 
 const nrnerf_linear* layer_source(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, const LayerSpec& sp) {
     switch (sp.kind) {
@@ -63,7 +99,7 @@ const nrnerf_linear* layer_source(const nrnerf_model_desc& d, const nrnerf_mlp_d
 }
 
 template <class SH, class A, bool HAS_BEND, bool VIEWS, bool TRUNK = true>
-void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out) {
+void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr) {
     using PL = Plan<SH, A, HAS_BEND, VIEWS, TRUNK>;
     constexpr int KH = SH::KH;
     const Tables& T = PL::TB;
@@ -73,10 +109,16 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
     out.unit_off.assign(T.nunits_padded + 1, 0);
     for (int u = 0; u <= T.nunits_padded; ++u) out.unit_off[u] = (uint32_t)((size_t)u * SH::UNIT_BYTES / 16);
     out.bias.assign((size_t)T.ntiles * 32, 0.0f);
+    if (lay) {
+        out.src.assign(out.stream.size() / SH::ELEM_BYTES, -1);
+        out.fmt.assign(out.stream.size() / SH::ELEM_BYTES, KH == 1 ? 0 : 1);
+        out.bias_src.assign(out.bias.size(), -1);
+    }
     size_t written = 0;
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
         const nrnerf_linear* lin = layer_source(d, mlp, sp);
+        const int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
         for (int t = 0; t < sp.nt; ++t) {
             const TileInfo& ti = T.tiles[sp.tile0 + t];
             for (int s = 0; s < sp.ns; ++s) {
@@ -92,6 +134,11 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                         for (int e = 0; e < KH; ++e) {
                             const int col = in_col<SH, A>(sp.kind, s, h, e, lin->in_features);
                             const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
+                            if (lay) {
+                                const size_t el = fi * (SH::FRAG_BYTES / SH::ELEM_BYTES) + (size_t)lane * KH + e;
+                                out.src[el] = (row < 0 || col < 0 || wbase < 0) ? -1 : (int32_t)(wbase + (int64_t)row * lin->in_features + col);
+                                out.fmt[el] = (KH == 1) ? 0 : (part == 1 ? 3 : (as_f16 ? 2 : 1));
+                            }
                             if (KH == 1) {
                                 std::memcpy(fr + lane * 4, &w, 4);
                             } else {
@@ -109,7 +156,60 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                 for (int r = 0; r < 16; ++r) {
                     const int row = out_row<A>(sp.kind, t, tile_row(r, h), lin->out_features);
                     out.bias[(size_t)(sp.tile0 + t) * 32 + h * 16 + r] = (row >= 0 && lin->bias) ? lin->bias[row] : 0.0f;
+                    if (lay && row >= 0 && bbase >= 0) out.bias_src[(size_t)(sp.tile0 + t) * 32 + h * 16 + r] = (int32_t)(bbase + row);
                 }
+        }
+    }
+    if (written != (size_t)T.nfrags) std::abort();
+}
+
+// Transposed weights for the backward-data kernel (nrnerf_train.h): PlanB's layer list, fragment element
+// (tile t, row i, slab s, half h, element e) = W[y][x] with (y, x) from bwd_y / bwd_x.  No biases.
+template <class SH, class A>
+void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr) {
+    using PL = PlanB<SH, A>;
+    constexpr int KH = SH::KH;
+    const Tables& T = PL::TB;
+    out.ntiles = T.ntiles; out.nunits = T.nunits_padded;
+    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES; out.mfma_per_block = T.mfma_per_block;
+    out.stream.assign((size_t)T.nunits_padded * SH::UNIT_BYTES, 0);
+    out.unit_off.assign(T.nunits_padded + 1, 0);
+    for (int u = 0; u <= T.nunits_padded; ++u) out.unit_off[u] = (uint32_t)((size_t)u * SH::UNIT_BYTES / 16);
+    out.bias.assign((size_t)T.ntiles * 32, 0.0f);
+    if (lay) {
+        out.src.assign(out.stream.size() / SH::ELEM_BYTES, -1);
+        out.fmt.assign(out.stream.size() / SH::ELEM_BYTES, KH == 1 ? 0 : (precision == NRNERF_PREC_F16 ? 2 : 1));
+        out.bias_src.assign(out.bias.size(), -1);
+    }
+    size_t written = 0;
+    for (int l = 0; l < T.nlayers; ++l) {
+        const LayerSpec& sp = T.layers[l];
+        const nrnerf_linear* lin = (sp.kind == LK_B_HEAD) ? &mlp.output_linear : &mlp.pts_linears[sp.index];
+        const int64_t wbase = lay ? lay->of(lin->weight) : -1;
+        for (int t = 0; t < sp.nt; ++t) {
+            const TileInfo& ti = T.tiles[sp.tile0 + t];
+            for (int s = 0; s < sp.ns; ++s) {
+                const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride;
+                if (fi >= (size_t)T.nfrags) std::abort();
+                uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    const int x = bwd_x<SH, A>(sp.kind, t, i, lin->in_features);
+                    for (int e = 0; e < KH; ++e) {
+                        const int y = bwd_y<SH, A>(sp.kind, s, h, e, lin->out_features);
+                        const float w = (x < 0 || y < 0) ? 0.0f : lin->weight[(size_t)y * lin->in_features + x];
+                        if (lay && x >= 0 && y >= 0 && wbase >= 0)
+                            out.src[fi * (SH::FRAG_BYTES / SH::ELEM_BYTES) + (size_t)lane * KH + e] = (int32_t)(wbase + (int64_t)y * lin->in_features + x);
+                        if (KH == 1) {
+                            std::memcpy(fr + lane * 4, &w, 4);
+                        } else {
+                            const uint16_t q = (precision == NRNERF_PREC_F16) ? f32_to_f16(w) : f32_to_bf16(w);
+                            std::memcpy(fr + (lane * KH + e) * 2, &q, 2);
+                        }
+                    }
+                }
+                ++written;
+            }
         }
     }
     if (written != (size_t)T.nfrags) std::abort();
@@ -164,32 +264,33 @@ int check_arch_t(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
 }
 
 template <class A>
-void pack_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, bool bender_only = false) {
+void pack_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, bool bender_only = false,
+               const FlatLayout* lay = nullptr) {
     const bool bend = d.bender != nullptr, views = m.use_viewdirs != 0;
     auto go = [&](auto sh) {
         using SH = decltype(sh);
-        if (bender_only) pack_pass<SH, A, true, false, false>(d, m, d.precision, out);       // nrnerf_bend.h
-        else if (bend && views) pack_pass<SH, A, true, true>(d, m, d.precision, out);
-        else if (bend) pack_pass<SH, A, true, false>(d, m, d.precision, out);
-        else if (views) pack_pass<SH, A, false, true>(d, m, d.precision, out);
-        else pack_pass<SH, A, false, false>(d, m, d.precision, out);
+        if (bender_only) pack_pass<SH, A, true, false, false>(d, m, d.precision, out, lay);       // nrnerf_bend.h
+        else if (bend && views) pack_pass<SH, A, true, true>(d, m, d.precision, out, lay);
+        else if (bend) pack_pass<SH, A, true, false>(d, m, d.precision, out, lay);
+        else if (views) pack_pass<SH, A, false, true>(d, m, d.precision, out, lay);
+        else pack_pass<SH, A, false, false>(d, m, d.precision, out, lay);
     };
     if (d.precision == NRNERF_PREC_F32) go(ShapeF32{}); else go(Shape16{});
 }
 
 // picks the compiled architecture (nrnerf_plan.h ArchById) the description matches; *arch_id receives its id
 int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, int* arch_id = nullptr,
-                  bool bender_only = false) {
+                  bool bender_only = false, const FlatLayout* lay = nullptr) {
     int rc = check_arch_t<ArchDefault>(d, m);
     if (rc == NRNERF_OK) {
-        pack_arch<ArchDefault>(d, m, out, bender_only);
+        pack_arch<ArchDefault>(d, m, out, bender_only, lay);
         if (arch_id) *arch_id = 0;
         return NRNERF_OK;
     }
     if (rc == NRNERF_ERR_UNSUPPORTED && !d.bender && m.time_conditioned) {
         const int rc2 = check_arch_t<ArchTimeCond>(d, m);
         if (rc2 == NRNERF_OK) {
-            pack_arch<ArchTimeCond>(d, m, out);
+            pack_arch<ArchTimeCond>(d, m, out, false, lay);
             if (arch_id) *arch_id = 2;
             return NRNERF_OK;
         }
@@ -198,7 +299,7 @@ int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPa
     if (rc == NRNERF_ERR_UNSUPPORTED && d.bender) {     // arch 1 is a bender variant: only compiled with a bender
         const int rc1 = check_arch_t<ArchDeepBend>(d, m);
         if (rc1 == NRNERF_OK) {
-            pack_arch<ArchDeepBend>(d, m, out, bender_only);
+            pack_arch<ArchDeepBend>(d, m, out, bender_only, lay);
             if (arch_id) *arch_id = 1;
             return NRNERF_OK;
         }
@@ -232,6 +333,9 @@ struct PassDev {
     double algo_flops_per_sample = 0;      // 2 * MAC
     double mfma_flops_per_sample = 0;      // issued, incl. padding
     int output_ch = 4;
+    // device copies of the packer's source maps (nrnerf_model_update_device); null when not recorded
+    int32_t* src = nullptr; int32_t* bias_src = nullptr; uint8_t* fmt = nullptr;
+    size_t n_elems = 0;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -256,8 +360,13 @@ struct nrnerf_model {
     bool fine_is_coarse = false;
     // split-bender path (bender, no view-dependent head): the fine network WITHOUT the bender layers (its input points
     // come from the stand-alone bender kernel) and the bender + rigidity layers alone
-    PassDev fine_trunk, bend_only;
+    PassDev fine_trunk, coarse_trunk, bend_only;
     bool split_ok = false;
+    // training (nrnerf_train.h): transposed trunk weights of both networks; train_ok: default architecture without
+    // view-dependent head / time conditioning, fp32 or bf16
+    PassDev coarse_bwd, fine_bwd;
+    bool train_ok = false;
+    int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
     mutable std::mutex prof_mu;
     mutable bool prof_on = false;
@@ -274,6 +383,14 @@ int upload_pass(const PackedPass& pk, PassDev& dev) {
     if (hipMalloc((void**)&dev.bias, pk.bias.size() * 4) != hipSuccess) return NRNERF_ERR_NOMEM;
     if (hipMemcpy(dev.stream, pk.stream.data(), pk.stream.size(), hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
     if (hipMemcpy(dev.bias, pk.bias.data(), pk.bias.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
+    if (!pk.src.empty()) {
+        dev.n_elems = pk.src.size();
+        if (hipMalloc((void**)&dev.src, pk.src.size() * 4) != hipSuccess || hipMalloc((void**)&dev.fmt, pk.fmt.size()) != hipSuccess ||
+            hipMalloc((void**)&dev.bias_src, pk.bias_src.size() * 4) != hipSuccess) return NRNERF_ERR_NOMEM;
+        if (hipMemcpy(dev.src, pk.src.data(), pk.src.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dev.fmt, pk.fmt.data(), pk.fmt.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dev.bias_src, pk.bias_src.data(), pk.bias_src.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return NRNERF_ERR_HIP;
+    }
     return NRNERF_OK;
 }
 // new weights of the same architecture into the buffers the kernels already read (stream-ordered)
@@ -286,18 +403,52 @@ int refresh_pass(const PackedPass& pk, PassDev& dev, hipStream_t stream) {
 void free_pass(PassDev& dev) {
     if (dev.stream) (void)hipFree(dev.stream);
     if (dev.bias) (void)hipFree(dev.bias);
+    if (dev.src) (void)hipFree(dev.src);
+    if (dev.fmt) (void)hipFree(dev.fmt);
+    if (dev.bias_src) (void)hipFree(dev.bias_src);
     dev = PassDev{};
 }
 
 // The two extra weight images of the split-bender path: the fine network without its bender layers (same trunk for the
 // 5- and the 7-layer bender: compiled architecture 0 without bender) and the bender + rigidity layers alone.
-int pack_split(const nrnerf_model_desc& d, PackedPass& trunk, PackedPass& bend) {
+int pack_split(const nrnerf_model_desc& d, PackedPass& trunk, PackedPass& bend, PackedPass* coarse_trunk = nullptr,
+               const FlatLayout* lay = nullptr) {
     const nrnerf_mlp_desc& fm = d.fine ? *d.fine : *d.coarse;
     nrnerf_model_desc d2 = d;
     d2.bender = nullptr;
-    int rc = pack_dispatch(d2, fm, trunk);
+    int rc = pack_dispatch(d2, fm, trunk, nullptr, false, lay);
     if (rc != NRNERF_OK) return rc;
-    return pack_dispatch(d, fm, bend, nullptr, /*bender_only=*/true);
+    if (coarse_trunk) {
+        rc = pack_dispatch(d2, *d.coarse, *coarse_trunk, nullptr, false, lay);
+        if (rc != NRNERF_OK) return rc;
+    }
+    return pack_dispatch(d, fm, bend, nullptr, /*bender_only=*/true, lay);
+}
+
+// transposed trunk weights for the backward-data kernel; eligible models only (see nrnerf_model::train_ok)
+bool training_eligible(const nrnerf_model_desc& d, const nrnerf_model* m) {
+    return !m->views && m->arch_id <= 1 && !d.coarse->time_conditioned && d.precision != NRNERF_PREC_F16;
+}
+void pack_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPass& out, const FlatLayout* lay = nullptr) {
+    if (d.precision == NRNERF_PREC_F32) pack_pass_bwd<ShapeF32, ArchDefault>(mlp, d.precision, out, lay);
+    else pack_pass_bwd<Shape16, ArchDefault>(mlp, d.precision, out, lay);
+}
+int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t refresh_stream = nullptr, bool refresh = false,
+                    const FlatLayout* lay = nullptr) {
+    if (!training_eligible(d, m)) return NRNERF_OK;
+    PackedPass bc, bf;
+    pack_bwd(d, *d.coarse, bc, lay);
+    int rc = refresh ? refresh_pass(bc, m->coarse_bwd, refresh_stream) : upload_pass(bc, m->coarse_bwd);
+    if (rc == NRNERF_OK && d.fine) {
+        pack_bwd(d, *d.fine, bf, lay);
+        rc = refresh ? refresh_pass(bf, m->fine_bwd, refresh_stream) : upload_pass(bf, m->fine_bwd);
+    }
+    if (refresh && rc == NRNERF_OK && hipStreamSynchronize(refresh_stream) != hipSuccess) rc = NRNERF_ERR_HIP;   // host images die here
+    const double mfma_flop = 2.0 * 32 * 32 * (d.precision == NRNERF_PREC_F32 ? 2 : 16);
+    m->coarse_bwd.mfma_flops_per_sample = bc.mfma_per_block * mfma_flop / 32.0;
+    m->fine_bwd.mfma_flops_per_sample = (d.fine ? bf.mfma_per_block : bc.mfma_per_block) * mfma_flop / 32.0;
+    m->train_ok = (rc == NRNERF_OK);
+    return rc;
 }
 
 }  // namespace
@@ -328,6 +479,14 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
         if (!desc->bender || desc->coarse->use_viewdirs) return NRNERF_ERR_UNSUPPORTED;
         PackedPass other;
         rc = (which == 2) ? pack_split(*desc, pk, other) : pack_split(*desc, other, pk);
+    } else if (which == 4 || which == 5) {       // transposed trunk weights of the backward-data kernel (training)
+        if (desc->coarse->use_viewdirs || desc->coarse->time_conditioned || desc->precision == NRNERF_PREC_F16) return NRNERF_ERR_UNSUPPORTED;
+        PackedPass fwd;
+        nrnerf_model_desc d2 = *desc;
+        d2.bender = nullptr;
+        const nrnerf_mlp_desc* mm = (which == 5 && desc->fine) ? desc->fine : desc->coarse;
+        rc = pack_dispatch(d2, *mm, fwd);            // validates the architecture
+        if (rc == NRNERF_OK) pack_bwd(*desc, *mm, pk);
     } else {
         rc = pack_dispatch(*desc, *m, pk);
     }
@@ -355,11 +514,12 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     if (!desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
     PackedPass pc, pf;
     int arch_id = 0, arch_f = 0;
-    int rc = pack_dispatch(*desc, *desc->coarse, pc, &arch_id);
+    const FlatLayout lay = flat_layout(*desc);
+    int rc = pack_dispatch(*desc, *desc->coarse, pc, &arch_id, false, &lay);
     if (rc != NRNERF_OK) return rc;
     if (desc->fine) {
         if ((desc->fine->use_viewdirs != 0) != (desc->coarse->use_viewdirs != 0)) return NRNERF_ERR_INVALID;
-        rc = pack_dispatch(*desc, *desc->fine, pf, &arch_f);
+        rc = pack_dispatch(*desc, *desc->fine, pf, &arch_f, false, &lay);
         if (rc != NRNERF_OK) return rc;
         if (arch_f != arch_id) return NRNERF_ERR_INVALID;
     }
@@ -380,6 +540,7 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, desc->device) != hipSuccess) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_HIP; }
     m->num_cus = prop.multiProcessorCount;
+    m->flat_floats = lay.total;
     const double mfma_flop = 2.0 * 32 * 32 * (desc->precision == NRNERF_PREC_F32 ? 2 : 16);
     rc = upload_pass(pc, m->coarse);
     m->coarse.algo_flops_per_sample = 2.0 * algo_macs(*desc, *desc->coarse);
@@ -395,20 +556,25 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
         m->fine_is_coarse = true;
     }
     if (rc == NRNERF_OK && m->has_bend && !m->views) {
-        PackedPass pt, pb;
-        if (pack_split(*desc, pt, pb) == NRNERF_OK) {
+        PackedPass pt, pb, pct;
+        if (pack_split(*desc, pt, pb, &pct, &lay) == NRNERF_OK) {
             rc = upload_pass(pt, m->fine_trunk);
             if (rc == NRNERF_OK) rc = upload_pass(pb, m->bend_only);
+            if (rc == NRNERF_OK) rc = upload_pass(pct, m->coarse_trunk);
+            m->coarse_trunk.mfma_flops_per_sample = pct.mfma_per_block * mfma_flop / 32.0;
+            m->coarse_trunk.output_ch = m->coarse.output_ch;
             nrnerf_model_desc d2 = *desc;
             d2.bender = nullptr;
             m->fine_trunk.algo_flops_per_sample = 2.0 * algo_macs(d2, desc->fine ? *desc->fine : *desc->coarse);
             m->fine_trunk.mfma_flops_per_sample = pt.mfma_per_block * mfma_flop / 32.0;
             m->fine_trunk.output_ch = m->fine.output_ch;
+            m->coarse_trunk.algo_flops_per_sample = 2.0 * algo_macs(d2, *desc->coarse);
             m->bend_only.algo_flops_per_sample = m->fine.algo_flops_per_sample - m->fine_trunk.algo_flops_per_sample;
             m->bend_only.mfma_flops_per_sample = pb.mfma_per_block * mfma_flop / 32.0;
             m->split_ok = (rc == NRNERF_OK);
         }
     }
+    if (rc == NRNERF_OK) rc = upload_training(*desc, m, nullptr, false, &lay);
     (void)hipSetDevice(prev);
     if (rc != NRNERF_OK) { nrnerf_model_destroy(m); return rc; }
     *out = m;
@@ -435,16 +601,38 @@ int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hi
     hipStream_t stream = (hipStream_t)hip_stream;
     rc = refresh_pass(pc, m->coarse, stream);
     if (rc == NRNERF_OK && desc->fine) rc = refresh_pass(pf, m->fine, stream);
-    PackedPass pt, pb;
+    PackedPass pt, pb, pct;
     if (rc == NRNERF_OK && m->split_ok) {
-        rc = pack_split(*desc, pt, pb);
+        rc = pack_split(*desc, pt, pb, &pct);
         if (rc == NRNERF_OK) rc = refresh_pass(pt, m->fine_trunk, stream);
         if (rc == NRNERF_OK) rc = refresh_pass(pb, m->bend_only, stream);
+        if (rc == NRNERF_OK) rc = refresh_pass(pct, m->coarse_trunk, stream);
     }
     // the packed host images die with this call: wait until the copies have consumed them
     if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;
+    if (rc == NRNERF_OK && m->train_ok) rc = upload_training(*desc, m, stream, /*refresh=*/true);
     (void)hipSetDevice(prev);
     return rc;
+}
+
+int64_t nrnerf_model_flat_size(const nrnerf_model* m) { return m ? m->flat_floats : -1; }
+
+int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_t n_floats, void* hip_stream) {
+    if (!m || !flat_params || n_floats != m->flat_floats) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only,
+                         &m->coarse_bwd, &m->fine_bwd};
+    for (PassDev* p : passes) {
+        if (!p || !p->stream) continue;
+        if (!p->src) return NRNERF_ERR_UNSUPPORTED;
+        RepackArgs r{flat_params, p->src, p->fmt, p->stream, (long long)p->n_elems};
+        if (launch_repack(r, stream) != hipSuccess) return NRNERF_ERR_HIP;
+        RepackArgs b{flat_params, p->bias_src, nullptr, p->bias, (long long)p->bias_floats};
+        if (launch_repack(b, stream) != hipSuccess) return NRNERF_ERR_HIP;
+    }
+    return NRNERF_OK;
 }
 
 void nrnerf_model_destroy(nrnerf_model* m) {
@@ -456,7 +644,10 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     if (!m->fine_is_coarse) free_pass(m->fine);
     free_pass(m->coarse);
     free_pass(m->fine_trunk);
+    free_pass(m->coarse_trunk);
     free_pass(m->bend_only);
+    free_pass(m->coarse_bwd);
+    free_pass(m->fine_bwd);
     (void)hipSetDevice(prev);
     delete m;
 }
@@ -567,8 +758,29 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.bent4 = (I == 0) ? bent4 : (split ? bent_c : nullptr);
     na.ex = sample_out(a->coarse);
     na.knobs = kn;
-    hipError_t e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
-                         [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
+    // NRNERF_SPLIT_COARSE=0 keeps the fused coarse kernel while the fine pass is split (A/B)
+    static const bool split_coarse_on = [] { const char* e = std::getenv("NRNERF_SPLIT_COARSE"); return !(e && e[0] == '0'); }();
+    const bool split_coarse = split && split_coarse_on;
+    hipError_t e;
+    if (split_coarse) {
+        // KBc: stand-alone bender over the S coarse samples, then the coarse trunk on the bent points
+        BendArgs bc{};
+        bc.rays = a->rays; bc.ray_stride = a->ray_stride;
+        bc.latents = a->latents; bc.lat_stride = a->latent_stride;
+        bc.z = zc; bc.lindisp = a->lindisp; bc.rank = nullptr; bc.n_rays = N; bc.n_per_ray = S; bc.out_stride = S;
+        bc.wstream = m->bend_only.stream; bc.bias = m->bend_only.bias;
+        bc.bent4 = bent_c; bc.knobs = kn;
+        e = timed(5, (double)N * S * m->bend_only.algo_flops_per_sample, (double)N * S * m->bend_only.mfma_flops_per_sample,
+                  [&] { return launch_bend(m->precision, m->arch_id, bc, m->num_cus, stream); });
+        if (e != hipSuccess) return NRNERF_ERR_HIP;
+        na.pts4 = bent_c; na.bent4 = nullptr;
+        na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
+        e = timed(0, (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
+                  [&] { return launch_net(m->precision, false, false, 0, na, m->num_cus, stream); });
+    } else {
+        e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
+                  [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
+    }
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
     // ---- K1: coarse composite (+ sampling)
@@ -597,6 +809,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
 
     // ---- K2: fine network on the merged depths
     NetArgs nf = na;
+    nf.pts4 = nullptr;
     nf.z = z_fine; nf.S = SF;
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
@@ -654,6 +867,98 @@ int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_p
     DeviceGuard guard(attr.device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     return launch_raygen(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
+// ---- training entry points (nrnerf_train.h, composite_bwd_kernel) -------------------------------------------------
+namespace {
+int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, TrunkArgs& t) {
+    if (!m || !a || a->struct_size != sizeof(nrnerf_trunk_args)) return NRNERF_ERR_INVALID;
+    if (!m->train_ok) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || (a->which != 0 && a->which != 1)) return NRNERF_ERR_INVALID;
+    if (!a->pts4 || !a->acts) return NRNERF_ERR_INVALID;
+    if (!bwd && (!a->raw4 || (a->raw && a->raw_ch != 4 && a->raw_ch != 5))) return NRNERF_ERR_INVALID;
+    if (bwd && (!a->d_raw4 || !a->d_pre || !a->d_pts4)) return NRNERF_ERR_INVALID;
+    const bool fine = a->which == 1;
+    const PassDev& fwd = m->has_bend ? (fine ? m->fine_trunk : m->coarse_trunk) : (fine ? m->fine : m->coarse);
+    const PassDev& bw = (fine && !m->fine_is_coarse) ? m->fine_bwd : m->coarse_bwd;
+    t = TrunkArgs{};
+    t.pts4 = a->pts4; t.n_rays = a->n_rays; t.S = a->n_samples;
+    t.wstream = bwd ? bw.stream : fwd.stream; t.bias = fwd.bias;
+    t.raw4 = a->raw4; t.raw_out = a->raw; t.raw_ch = a->raw_ch;
+    t.acts = a->acts; t.d_raw4 = a->d_raw4; t.d_pre = a->d_pre; t.d_pts4 = a->d_pts4;
+    return NRNERF_OK;
+}
+}  // namespace
+
+int nrnerf_trunk_forward(const nrnerf_model* m, const nrnerf_trunk_args* a, void* hip_stream) {
+    TrunkArgs t;
+    const int rc = trunk_common(m, a, false, t);
+    if (rc != NRNERF_OK) return rc;
+    if (a->n_rays == 0) return NRNERF_OK;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    const hipError_t e = (m->precision == NRNERF_PREC_F32) ? launch_trunk_fwd_train_f32(t, m->num_cus, (hipStream_t)hip_stream)
+                                                           : launch_trunk_fwd_train_bf16(t, m->num_cus, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
+int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, void* hip_stream) {
+    TrunkArgs t;
+    const int rc = trunk_common(m, a, true, t);
+    if (rc != NRNERF_OK) return rc;
+    if (a->n_rays == 0) return NRNERF_OK;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    const hipError_t e = (m->precision == NRNERF_PREC_F32) ? launch_trunk_bwd_f32(t, m->num_cus, (hipStream_t)hip_stream)
+                                                           : launch_trunk_bwd_bf16(t, m->num_cus, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
+namespace {
+int composite_device(const nrnerf_composite_args* a, int* dev) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, a->raw4) != hipSuccess) { (void)hipGetLastError(); return NRNERF_ERR_INVALID; }
+    if (attr.type != hipMemoryTypeDevice) return NRNERF_ERR_INVALID;
+    *dev = attr.device;
+    return NRNERF_OK;
+}
+}  // namespace
+
+int nrnerf_composite_forward(const nrnerf_composite_args* a, void* hip_stream) {
+    if (!a || a->struct_size != sizeof(nrnerf_composite_args)) return NRNERF_ERR_INVALID;
+    if (a->n_rays < 0 || a->n_samples < 2 || a->n_importance < 0) return NRNERF_ERR_INVALID;
+    if (a->n_samples > 256 || a->n_samples + a->n_importance > 256) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_rays == 0) return NRNERF_OK;
+    if (!a->rays || a->ray_stride < 8 || !a->raw4 || !a->rgb || !a->disp || !a->acc) return NRNERF_ERR_INVALID;
+    if (a->n_importance > 0 && !a->z_merged) return NRNERF_ERR_INVALID;
+    int dev = 0;
+    int rc = composite_device(a, &dev);
+    if (rc != NRNERF_OK) return rc;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    CompositeArgs c{};
+    c.rays = a->rays; c.ray_stride = a->ray_stride; c.raw4 = a->raw4; c.z = a->z; c.lindisp = a->lindisp;
+    c.white_bkgd = a->white_bkgd; c.noise = a->noise; c.u = a->u; c.n_rays = a->n_rays; c.S = a->n_samples;
+    c.n_importance = a->n_importance; c.rgb = a->rgb; c.disp = a->disp; c.acc = a->acc; c.z_std = a->z_std;
+    c.z_out = a->z_merged; c.vis = a->weights; c.alpha = a->alpha;
+    return launch_composite(c, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
+int nrnerf_composite_backward(const nrnerf_composite_args* a, void* hip_stream) {
+    if (!a || a->struct_size != sizeof(nrnerf_composite_args)) return NRNERF_ERR_INVALID;
+    if (a->n_rays < 0 || a->n_samples < 2 || a->n_samples > 256) return NRNERF_ERR_INVALID;
+    if (a->n_rays == 0) return NRNERF_OK;
+    if (!a->rays || a->ray_stride < 8 || !a->raw4 || !a->g_rgb || !a->d_raw4) return NRNERF_ERR_INVALID;
+    int dev = 0;
+    int rc = composite_device(a, &dev);
+    if (rc != NRNERF_OK) return rc;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    CompositeBwdArgs c{};
+    c.rays = a->rays; c.ray_stride = a->ray_stride; c.raw4 = a->raw4; c.z = a->z; c.lindisp = a->lindisp;
+    c.white_bkgd = a->white_bkgd; c.noise = a->noise; c.n_rays = a->n_rays; c.S = a->n_samples;
+    c.g_rgb = a->g_rgb; c.g_disp = a->g_disp; c.g_acc = a->g_acc; c.g_w = a->g_weights; c.d_raw4 = a->d_raw4;
+    return launch_composite_bwd(c, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 
 int nrnerf_profile_begin(nrnerf_model* m) {

@@ -87,19 +87,52 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) bend_kernel(
 
     const int n = a.n_per_ray;
     const int bpr = (n + 31) >> 5;                 // 32-sample blocks per ray
-    const long long nblocks = (long long)a.n_rays * bpr;
+    const int nblocks = a.n_rays * bpr;            // n_rays <= 2^20 per launch, bpr <= 8
+    // Inputs of a block.  A block is 32 samples of ONE ray, so the ray record and its latent code are wave-uniform: read
+    // through the constant address space they become scalar loads (38 SGPRs instead of 38 per-lane VMEM loads); the
+    // per-sample depth and output row are the only vector loads.  The next block's inputs are requested before the
+    // current block's MLPs run: with two waves per SIMD nothing else would hide that latency.
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    struct In {
+        float o[3], d[3], lat[A::LAT];
+        float z;
+        int row, ray;
+        bool ok;
+    };
+    auto load_inputs = [&](int blk, In& in) {
+        const int ray = __builtin_amdgcn_readfirstlane(blk / bpr);
+        const int k = (blk - ray * bpr) * 32 + j;
+        in.ok = k < n;
+        const int kc = in.ok ? k : n - 1;
+        in.ray = ray;
+        cfloat_p rp = (cfloat_p)(a.rays + (size_t)ray * a.ray_stride);
+        cfloat_p lp = (cfloat_p)(a.latents + (size_t)ray * a.lat_stride);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { in.o[c] = rp[c]; in.d[c] = rp[3 + c]; }
+#pragma unroll
+        for (int c = 0; c < A::LAT; ++c) in.lat[c] = lp[c];
+        if (a.z) {
+            in.z = a.z[(size_t)ray * n + kc];
+        } else {                                   // coarse depths (train.py:847-852), as in the fused kernels
+            const float near = rp[6], far = rp[7];
+            const float t = lin01(kc, n);
+            if (a.lindisp)
+                in.z = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, far), t)));
+            else
+                in.z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));
+        }
+        in.row = a.rank ? (int)a.rank[(size_t)ray * n + kc] : kc;
+    };
+    const int blk0 = (int)blockIdx.x * WAVES + wave, blk_step = (int)gridDim.x * WAVES;
+    In cur;
+    if (blk0 < nblocks) load_inputs(blk0, cur);
     // no barrier below: every wave strides over the blocks on its own
-    for (long long blk = (long long)blockIdx.x * WAVES + wave; blk < nblocks; blk += (long long)gridDim.x * WAVES) {
-        const int ray = (int)(blk / bpr);
-        const int k = (int)(blk % bpr) * 32 + j;
-        const bool ok = k < n;
-        const int kc = ok ? k : n - 1;
-        const float* rp = a.rays + (size_t)ray * a.ray_stride;
-        const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
-        const float z = a.z[(size_t)ray * n + kc];
-        float p[3] = {__fadd_rn(ox, __fmul_rn(dx, z)), __fadd_rn(oy, __fmul_rn(dy, z)),
-                      __fadd_rn(oz, __fmul_rn(dz, z))};                                  // train.py:921-923
-        const float* lat = a.latents + (size_t)ray * a.lat_stride;
+    for (int blk = blk0; blk < nblocks; blk += blk_step) {
+        const bool ok = cur.ok;
+        const int out_ray = cur.ray, out_row = cur.row;
+        float p[3] = {__fadd_rn(cur.o[0], __fmul_rn(cur.d[0], cur.z)), __fadd_rn(cur.o[1], __fmul_rn(cur.d[1], cur.z)),
+                      __fadd_rn(cur.o[2], __fmul_rn(cur.d[2], cur.z))};                  // train.py:921-923
+        const float* lat = cur.lat;
         auto binval = [&](auto idxc) -> float {
             constexpr int idx = decltype(idxc)::value;
             if constexpr (idx < 3) return p[idx];
@@ -117,6 +150,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) bend_kernel(
                 bin.template set<s, e>(h ? v1 : v0);
             });
         });
+        // `cur` is consumed (point and first-layer operand built): request the next block's inputs into the same registers
+        if (blk + blk_step < nblocks) load_inputs(blk + blk_step, cur);
         // ---- offset MLP (run_nerf_helpers.py:525-541)
         Act<PE, NB, SPLIT> ba, bb;
         float off[3];
@@ -183,10 +218,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) bend_kernel(
             if (a.knobs.has_scaling) mo = __fmul_rn(mo, a.knobs.scaling);                    // rnh:568-569
             p[c] = __fadd_rn(p[c], mo);                                                      // rnh:570
         }
-        if (ok && h == 0) {
-            const int row = a.rank ? (int)a.rank[(size_t)ray * n + kc] : kc;
-            *(f32x4*)(a.bent4 + ((size_t)ray * a.out_stride + row) * 4) = f32x4{p[0], p[1], p[2], rig_mask};
-        }
+        if (ok && h == 0)
+            *(f32x4*)(a.bent4 + ((size_t)out_ray * a.out_stride + out_row) * 4) = f32x4{p[0], p[1], p[2], rig_mask};
     }
 }
 
@@ -204,6 +237,7 @@ static hipError_t launch_bend_one(const BendArgs& a, int num_cus, hipStream_t st
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const long long nblocks = (long long)a.n_rays * ((a.n_per_ray + 31) / 32);
+    if (nblocks >= (1ll << 31)) return hipErrorInvalidValue;
     const long long want = (nblocks + WAVES - 1) / WAVES;
     if (want <= 0) return hipSuccess;
     const int grid = (int)(want < num_cus ? want : num_cus);        // persistent: one workgroup per CU

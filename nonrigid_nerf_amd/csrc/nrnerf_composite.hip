@@ -267,6 +267,134 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
     }
 }
 
+// Backward of the compositing (training).  Same decomposition as the forward kernel: one wave per ray, lane l owns EPL
+// consecutive samples.  With  t_i = 1 - alpha_i + 1e-10,  T_i = prod_{j<i} t_j,  w_i = alpha_i T_i  and
+// G_i = dL/dw_i = g_rgb . c_i + g_acc + g_depth z_i + g_w_i:
+//     dL/dalpha_i = G_i T_i - (sum_{k>i} G_k w_k) / t_i          (every later T_k carries the factor t_i)
+//     dL/dsigma_i = dL/dalpha_i * dist_i * exp(-relu(sigma_i + noise_i) dist_i) * [sigma_i + noise_i > 0]
+//     dL/drgb_i   = w_i * g_rgb * c_i (1 - c_i)                  (c = sigmoid)
+// which is what autograd derives from train.py:740-784 (cumprod backward = reverse cumsum of grad * output / input).
+template <int EPL>
+__global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_bwd_kernel(const CompositeBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray_raw = blockIdx.x * RAYS_PER_WG + wave;
+    const bool ray_ok = ray_raw < a.n_rays;
+    const int ray = ray_ok ? ray_raw : a.n_rays - 1;
+    const int S = a.S;
+    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    const float dx = rp[3], dy = rp[4], dz = rp[5];
+    const float near = rp[6], far = rp[7];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+
+    float z[EPL + 1], sig[EPL], col[EPL][3];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        const int ic = i < S ? i : S - 1;
+        if (a.z) z[k] = a.z[(size_t)ray * S + ic];
+        else {
+            const float t = c_lin01(ic, S);
+            if (a.lindisp)
+                z[k] = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, far), t)));
+            else
+                z[k] = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));
+        }
+        const f32x4 r = *(const f32x4*)(a.raw4 + ((size_t)ray * S + ic) * 4);
+        col[k][0] = r[0]; col[k][1] = r[1]; col[k][2] = r[2]; sig[k] = r[3];
+        if (a.noise) sig[k] = __fadd_rn(sig[k], a.noise[(size_t)ray * S + ic]);
+    }
+    z[EPL] = __shfl_down(z[0], 1);
+
+    // forward quantities, recomputed exactly as composite_kernel does
+    float alpha[EPL], ex[EPL], dist[EPL], tfac[EPL], texcl[EPL], w[EPL];
+    float run = 1.0f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        float d = (i == S - 1) ? 1e10f : __fsub_rn(z[k + 1], z[k]);
+        d = __fmul_rn(d, dnorm);
+        dist[k] = d;
+        const float s = fmaxf(sig[k], 0.0f);
+        ex[k] = (i < S) ? expf(-__fmul_rn(s, d)) : 1.0f;
+        alpha[k] = (i < S) ? __fsub_rn(1.0f, ex[k]) : 0.0f;
+        tfac[k] = (i < S) ? __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f) : 1.0f;
+        texcl[k] = run;
+        run = __fmul_rn(run, tfac[k]);
+    }
+    const float incl = wave_scan_mul(run, lane);
+    float before = __shfl_up(incl, 1);
+    if (lane == 0) before = 1.0f;
+    float c[EPL][3], sdepth = 0.f, sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        texcl[k] = __fmul_rn(before, texcl[k]);                   // T_i
+        w[k] = (i < S) ? __fmul_rn(alpha[k], texcl[k]) : 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) c[k][ch] = 1.0f / (1.0f + expf(-col[k][ch]));
+        sdepth += w[k] * z[k]; sacc += w[k];
+    }
+    sdepth = wave_sum(sdepth); sacc = wave_sum(sacc);
+
+    // gradients of the per-ray maps
+    float gr[3] = {a.g_rgb[(size_t)ray * 3], a.g_rgb[(size_t)ray * 3 + 1], a.g_rgb[(size_t)ray * 3 + 2]};
+    float g_acc = a.g_acc ? a.g_acc[ray] : 0.0f;
+    float g_depth = 0.0f;
+    if (a.white_bkgd) g_acc -= gr[0] + gr[1] + gr[2];             // rgb_map += 1 - acc (train.py:786-787)
+    if (a.g_disp) {                                               // disp = 1 / max(1e-10, depth / acc) (train.py:781-784)
+        const float q = sdepth / sacc;
+        if (q > 1e-10f) {
+            const float gd = a.g_disp[ray];
+            g_depth = -gd * sacc / (sdepth * sdepth);
+            g_acc += gd / sdepth;
+        }
+    }
+    float G[EPL], gw_sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        G[k] = gr[0] * c[k][0] + gr[1] * c[k][1] + gr[2] * c[k][2] + g_acc + g_depth * z[k];
+        if (a.g_w && i < S) G[k] += a.g_w[(size_t)ray * S + i];
+        gw_sum += G[k] * w[k];
+    }
+    // exclusive suffix sum of G_k w_k over the lanes, then inside the lane from its last sample down
+    float suf = gw_sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_down(suf, o); if (lane + o < 64) suf += t; }
+    float after = suf - gw_sum;
+#pragma unroll
+    for (int k = EPL - 1; k >= 0; --k) {
+        const int i = lane * EPL + k;
+        const float dalpha = G[k] * texcl[k] - after / tfac[k];
+        after += G[k] * w[k];
+        const float dsig = (sig[k] > 0.0f) ? dalpha * dist[k] * ex[k] : 0.0f;
+        if (ray_ok && i < S) {
+            const float s0 = w[k] * gr[0] * c[k][0] * (1.0f - c[k][0]);
+            const float s1 = w[k] * gr[1] * c[k][1] * (1.0f - c[k][1]);
+            const float s2 = w[k] * gr[2] * c[k][2] * (1.0f - c[k][2]);
+            *(f32x4*)(a.d_raw4 + ((size_t)ray * S + i) * 4) = f32x4{s0, s1, s2, dsig};
+        }
+    }
+}
+
+template <int EPL>
+static hipError_t launch_bwd_epl(const CompositeBwdArgs& a, hipStream_t stream) {
+    const int grid = (a.n_rays + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL((composite_bwd_kernel<EPL>), dim3(grid), dim3(RAYS_PER_WG * 64), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t stream) {
+    if (a.S < 2 || a.S > MAXS) return hipErrorInvalidValue;
+    switch ((a.S + 63) / 64) {
+        case 1: return launch_bwd_epl<1>(a, stream);
+        case 2: return launch_bwd_epl<2>(a, stream);
+        case 3: return launch_bwd_epl<3>(a, stream);
+        case 4: return launch_bwd_epl<4>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int EPL>
 static hipError_t launch_epl(const CompositeArgs& a, hipStream_t stream) {
     const int grid = (a.n_rays + RAYS_PER_WG - 1) / RAYS_PER_WG;

@@ -75,7 +75,8 @@ struct CompositeArgs {
 struct BendArgs {
     const float* rays;   int ray_stride;
     const float* latents; int lat_stride;
-    const float* z;          // [N, n_per_ray] sample depths
+    const float* z;          // [N, n_per_ray] sample depths, or nullptr: coarse linspace between near and far
+    int lindisp;             // as NetArgs::lindisp; only read when z == nullptr
     const uint8_t* rank;     // [N, n_per_ray] row of each sample among the out_stride rows of its ray, or nullptr: identity
     int n_rays, n_per_ray, out_stride;
     const void* wstream;     // packed bender + rigidity fragments (Plan<..., TRUNK = false>)
@@ -84,6 +85,54 @@ struct BendArgs {
     Knobs knobs;
 };
 hipError_t launch_bend(int precision, int arch_id, const BendArgs& a, int num_cus, hipStream_t stream);
+
+// backward of raw2outputs (train.py:724-789) for one pass: gradients wrt raw4 from the gradients of the per-ray maps
+struct CompositeBwdArgs {
+    const float* rays;   int ray_stride;
+    const float* raw4;       // [N,S,4]
+    const float* z;          // [N,S] or nullptr: coarse linspace
+    int lindisp, white_bkgd;
+    const float* noise;      // [N,S] or nullptr
+    int n_rays, S;
+    const float* g_rgb;      // [N,3]
+    const float* g_disp;     // [N] or nullptr
+    const float* g_acc;      // [N] or nullptr
+    const float* g_w;        // [N,S] gradient wrt the visibility weights, or nullptr
+    float* d_raw4;           // [N,S,4]
+};
+hipError_t launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t stream);
+
+// training kernels of the trunk (nrnerf_train.h): forward with saved activations, backward-data
+struct TrunkArgs {
+    const float* pts4;       // [M,4] input points (xyz, pad), M = n_rays * S
+    int n_rays, S;
+    const void* wstream;     // forward: trunk-only stream (Plan<.., false, false>); backward: PlanB stream
+    const float* bias;
+    float* raw4;             // forward out [M,4]
+    float* raw_out;          // forward out [M,raw_ch] or nullptr
+    int raw_ch;
+    void* acts;              // [D][M][W] hidden activations (float or bf16): forward writes, backward reads
+    const float* d_raw4;     // backward in  [M,4]   (gradient wrt raw4; the 5th raw channel never reaches the loss)
+    void* d_pre;             // backward out [D][M][W] gradient wrt the pre-activations (float or bf16)
+    float* d_pts4;           // backward out [M,4]
+};
+
+hipError_t launch_trunk_fwd_train_f32(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_fwd_train_bf16(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_bwd_f32(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_bwd_bf16(const TrunkArgs&, int num_cus, hipStream_t);
+
+// Re-pack weights on the device (nrnerf_model_update_device): dst[i] = convert(flat[src[i]]) (0 where src[i] < 0).
+// fmt[i]: 0 = fp32, 1 = bf16, 2 = f16, 3 = f16((w - f16(w)) * 2^11), the lo part of the bender's split product;
+// fmt == nullptr: all fp32 (bias tables).
+struct RepackArgs {
+    const float* flat;
+    const int32_t* src;
+    const uint8_t* fmt;
+    void* dst;
+    long long n;
+};
+hipError_t launch_repack(const RepackArgs& a, hipStream_t stream);
 
 // stratified jitter of the coarse depths (train.py:855-868): z = lower + (upper - lower) * u between the mid-points
 struct JitterArgs {

@@ -116,7 +116,12 @@ enum LayerKind : int {
     LK_ALPHA,    // alpha_linear:   trunk output -> 1   (rows duplicated for both lane halves)
     LK_FEAT,     // feature_linear: trunk output -> W   (no activation)
     LK_VIEWS,    // views_linears[0]: [feature W, direction encoding] -> W/2, relu; slabs: direction encoding first
-    LK_RGB       // rgb_linear: W/2 -> 3
+    LK_RGB,      // rgb_linear: W/2 -> 3
+    // backward-data layers of the trunk (training, nrnerf_train.h): dX = W^T dY, the A operand holds W^T
+    LK_B_HEAD,   // output_linear^T:   d raw (C channels) -> d h_{D-1}
+    LK_B_HID,    // pts_linears[i]^T:  W -> W
+    LK_B_SKIP,   // pts_linears[SKIP+1]^T: W -> [encoding slots (2 tiles), W]
+    LK_B_IN      // pts_linears[0]^T:  W -> encoding slots (2 tiles)
 };
 
 struct LayerSpec {
@@ -154,6 +159,30 @@ struct Tables {
     TileInfo tiles[MAX_TILES];
     int nlayers, ntiles, nfrags, nunits, nunits_padded, mfma_per_block;
 };
+
+// stream positions of every tile's fragments (pairs of tiles with interleaved slabs, see TileInfo) and the totals
+template <class SH>
+constexpr void place_fragments(Tables& T) {
+    int g = 0, mf = 0;
+    for (int l = 0; l < T.nlayers; ++l) {
+        const int fps = 1 + T.layers[l].split;          // fragments per (tile, slab)
+        const int ns = T.layers[l].ns, nt = T.layers[l].nt, t0 = T.layers[l].tile0;
+        for (int p = 0; p + 1 < nt; p += 2) {
+            T.tiles[t0 + p] = TileInfo{l, p, g, 2 * fps};
+            T.tiles[t0 + p + 1] = TileInfo{l, p + 1, g + fps, 2 * fps};
+            g += 2 * ns * fps;
+        }
+        if (nt & 1) {
+            T.tiles[t0 + nt - 1] = TileInfo{l, nt - 1, g, fps};
+            g += ns * fps;
+        }
+        mf += nt * ns * (T.layers[l].split ? 3 : 1);
+    }
+    T.nfrags = g;
+    T.nunits = cdiv(g, SH::UNIT_FRAGS);
+    T.nunits_padded = cdiv(T.nunits, RING) * RING;
+    T.mfma_per_block = mf;
+}
 
 // TRUNK = false: only the bender / rigidity layers (the stand-alone bender kernel, nrnerf_bend.h; needs HAS_BEND)
 template <class SH, class A, bool HAS_BEND, bool VIEWS = false, bool TRUNK = true>
@@ -197,26 +226,82 @@ constexpr Tables build_tables() {
     }
     T.nlayers = nl;
     T.ntiles = tile0;
-    int g = 0, mf = 0;
-    for (int l = 0; l < nl; ++l) {
-        const int fps = 1 + T.layers[l].split;          // fragments per (tile, slab)
-        const int ns = T.layers[l].ns, nt = T.layers[l].nt, t0 = T.layers[l].tile0;
-        for (int p = 0; p + 1 < nt; p += 2) {
-            T.tiles[t0 + p] = TileInfo{l, p, g, 2 * fps};
-            T.tiles[t0 + p + 1] = TileInfo{l, p + 1, g + fps, 2 * fps};
-            g += 2 * ns * fps;
-        }
-        if (nt & 1) {
-            T.tiles[t0 + nt - 1] = TileInfo{l, nt - 1, g, fps};
-            g += ns * fps;
-        }
-        mf += nt * ns * (T.layers[l].split ? 3 : 1);
-    }
-    T.nfrags = g;
-    T.nunits = cdiv(g, SH::UNIT_FRAGS);
-    T.nunits_padded = cdiv(T.nunits, RING) * RING;
-    T.mfma_per_block = mf;
+    place_fragments<SH>(T);
     return T;
+}
+
+// Backward-data plan of the trunk (no bender, no view-dependent head, no time conditioning): the layers of the forward
+// pass in reverse order with transposed weights.  Activations flow exactly as in the forward pass (D tile -> B slabs
+// of the next layer), so `in_col`'s hidden() map describes the k index here too.  The encoding part of the gradient
+// comes out in ENCODING-SLOT order: tile te, accumulator register r of lane half h = slot te*16 + r of that half
+// (enc_col), which is how the forward kernel builds the encoding, so each lane ends up holding the gradient of its own
+// sin/cos values.
+constexpr NRN_HD int enc_tiles(int L) { return cdiv(enc_slots(L), 16); }
+constexpr int DRAW_LEN = 8;                         // d raw: C <= 5 channels, padded
+template <class SH, class A>
+constexpr Tables build_tables_bwd() {
+    constexpr int KH = SH::KH, SP = SH::SP;
+    constexpr int NT_W = A::W / 32, NT_E = enc_tiles(A::L);
+    constexpr int NS_DR = cdiv(DRAW_LEN, 2 * KH);
+    Tables T{};
+    int nl = 0, tile0 = 0;
+    auto add = [&](int kind, int index, int ns, int nt) {
+        T.layers[nl] = LayerSpec{kind, index, ns, nt, tile0, 0};
+        tile0 += nt;
+        ++nl;
+    };
+    add(LK_B_HEAD, 0, NS_DR, NT_W);
+    for (int i = A::D - 1; i >= 1; --i) {
+        if (i - 1 == A::SKIP) add(LK_B_SKIP, i, NT_W * SP, NT_E + NT_W);
+        else add(LK_B_HID, i, NT_W * SP, NT_W);
+    }
+    add(LK_B_IN, 0, NT_W * SP, NT_E);
+    T.nlayers = nl;
+    T.ntiles = tile0;
+    place_fragments<SH>(T);
+    return T;
+}
+
+template <class SH, class A>
+struct PlanB {
+    static_assert(!A::TCB, "no training support for the time-conditioned baseline");
+    static constexpr int KH = SH::KH, SP = SH::SP;
+    static constexpr int NT_W = A::W / 32, NT_E = enc_tiles(A::L);
+    static constexpr int NS_DR = cdiv(DRAW_LEN, 2 * KH);
+    static constexpr Tables TB = build_tables_bwd<SH, A>();
+    static constexpr int NLAYERS = TB.nlayers, NTILES = TB.ntiles, NFRAGS = TB.nfrags;
+    static constexpr int NUNITS = TB.nunits, NUP = TB.nunits_padded, UF = SH::UNIT_FRAGS;
+    static constexpr int MFMA_PER_BLOCK = TB.mfma_per_block;
+    static_assert(TB.ntiles <= MAX_TILES && TB.nlayers <= MAX_LAYERS, "plan too large");
+    // layers[0] = head^T; layers[1 + (D-1-i)] = pts_linears[i]^T for i = D-1 .. 1; layers[D] = pts_linears[0]^T
+    static constexpr int layer_of(int i) { return i == 0 ? A::D : 1 + (A::D - 1 - i); }
+};
+
+// Which element W[y][x] of the reference weight the A-fragment element (tile t, row i, slab s, half h, element e) of a
+// backward layer holds (A = W^T: row <-> input feature x of W, k <-> output feature y of W); -1 = zero.
+template <class SH, class A>
+constexpr NRN_HD int bwd_y(int kind, int s, int h, int e, int out_features) {
+    constexpr int KH = SH::KH, SP = SH::SP;
+    if (kind == LK_B_HEAD) {
+        const int ch = (2 * s + h) * KH + e;
+        return ch < out_features ? ch : -1;
+    }
+    const int tp = s / SP, u = s % SP, r = u * KH + e;
+    const int y = 32 * tp + tile_row(r, h);
+    return y < out_features ? y : -1;
+}
+template <class SH, class A>
+constexpr NRN_HD int bwd_x(int kind, int t, int i, int in_features) {
+    constexpr int NT_E = enc_tiles(A::L), IN_CH = 3 + 6 * A::L;
+    auto slot = [&](int te) {
+        const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);     // inverse of tile_row
+        const int q = te * 16 + r;
+        return q < enc_slots(A::L) ? enc_col(A::L, hh, q) : -1;
+    };
+    if (kind == LK_B_IN) return slot(t);
+    if (kind == LK_B_SKIP) return t < NT_E ? slot(t) : IN_CH + 32 * (t - NT_E) + i;
+    const int x = 32 * t + i;
+    return x < in_features ? x : -1;
 }
 
 template <class SH, class A, bool HAS_BEND, bool VIEWS = false, bool TRUNK = true>

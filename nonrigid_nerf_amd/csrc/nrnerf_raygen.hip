@@ -40,4 +40,22 @@ hipError_t launch_raygen(const RayGenArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// weight re-packing on the device (see RepackArgs); conversions round to nearest even like the host packer
+__global__ void __launch_bounds__(256) repack_kernel(const RepackArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int s = a.src[i];
+    const float w = s >= 0 ? a.flat[s] : 0.0f;
+    const int f = a.fmt ? a.fmt[i] : 0;
+    if (f == 0) ((float*)a.dst)[i] = w;
+    else if (f == 1) ((__bf16*)a.dst)[i] = (__bf16)w;
+    else if (f == 2) ((_Float16*)a.dst)[i] = (_Float16)w;
+    else ((_Float16*)a.dst)[i] = (_Float16)((w - (float)(_Float16)w) * 2048.0f);
+}
+hipError_t launch_repack(const RepackArgs& a, hipStream_t stream) {
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 }  // namespace nrn

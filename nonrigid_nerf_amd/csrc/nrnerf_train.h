@@ -1,0 +1,313 @@
+// nrnerf_train.h -- training support for the canonical NeRF trunk (reference NeRF.forward run_nerf_helpers.py:272-306 under
+// autograd; the training step is training_wrapper_class.forward + backward, train.py:152-287, 1594-1610).
+//
+// Two kernels, both built from the forward kernel's parts (weight ring, dense layer, in-register activation hand-off):
+//
+//   trunk_fwd_train   positional encoding + 8x256 trunk + head on ready-made points (the bent points: the deformation
+//                     MLPs stay in PyTorch autograd, their regularisers need double backward, run_nerf_helpers.py:22-116),
+//                     like the inference kernel, but every hidden activation h_i = relu(W_i x_i + b_i) is also written
+//                     to HBM, [layer][sample][256] in TRUE feature order: the D tile holds features 32t+8q+4h .. +3 of a
+//                     sample in four consecutive accumulator registers, i.e. 16 (fp32) or 8 (bf16) contiguous bytes.
+//   trunk_bwd         backward-data: the same dataflow with the layers reversed and the weights transposed (PlanB,
+//                     nrnerf_plan.h): d h_{D-1} = W_out^T d raw, then for i = D-1 .. 1:  d z_i = d h_i * [h_i > 0]
+//                     (stored for the weight gradients),  d x_i = W_i^T d z_i  (x_5 = [encoding, h_4]: its first two tiles
+//                     are the encoding's gradient), finally d enc += W_0^T d z_0 and, through the derivative of the
+//                     encoding, the gradient wrt the input point.  The weight gradients  dW_i = d z_i^T x_i  are plain
+//                     [256 x K_samples] x [K_samples x 256] GEMMs over the two stored arrays and are left to the library
+//                     (hipBLASLt via torch.matmul in nonrigid_nerf_amd/training.py).
+// fp32 mode (exact, the gradient-parity mode) and bf16 mode (bf16 operands incl. the stored activations and d z).
+#pragma once
+#include "nrnerf_net_impl.h"
+
+namespace nrn {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// four consecutive features of one sample, stored / loaded in the array's element type
+template <class P>
+__device__ __forceinline__ void store4(void* base, size_t elem_index, float a, float b, float c, float d) {
+    if constexpr (P::KH == 1) {
+        *(f32x4*)((float*)base + elem_index) = f32x4{a, b, c, d};
+    } else {
+        const bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+        *(bf16x4*)((__bf16*)base + elem_index) = v;
+    }
+}
+template <class P>
+__device__ __forceinline__ f32x4 load4(const void* base, size_t elem_index) {
+    if constexpr (P::KH == 1) {
+        return *(const f32x4*)((const float*)base + elem_index);
+    } else {
+        const bf16x4 v = *(const bf16x4*)((const __bf16*)base + elem_index);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward with saved activations
+// ------------------------------------------------------------------------------------------
+template <class P, class A, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_fwd_train(const TrunkArgs a) {
+    using PL = Plan<P, A, false, false>;
+    using frag = typename P::frag;
+    using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;
+    using efrag = typename PE::frag;
+    constexpr int KH = P::KH, SP = P::SP, NS_ENC = PL::NS_ENC, NT_W = PL::NT_W;
+    static_assert(!A::TCB, "no training support for the time-conditioned baseline");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    float* bias_lds = (float*)(smem + RING * P::UNIT_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = a.bias[i];
+    __syncthreads();
+    const BiasPtr bias_lane = bias_lane_ptr(bias_lds, h);
+    WRing<P, WAVES, PL::NUP> st;
+    st.init(a.wstream, ring, wave, lane);
+
+    const int S = a.S;
+    const int bpr = (S + 31) >> 5;
+    const long long nblocks = (long long)a.n_rays * bpr;
+    const size_t M = (size_t)a.n_rays * S;
+    for (long long tile0 = (long long)blockIdx.x * WAVES; tile0 < nblocks; tile0 += (long long)gridDim.x * WAVES) {
+        const long long blk = tile0 + wave;
+        const bool blk_ok = blk < nblocks;
+        const long long b = blk_ok ? blk : nblocks - 1;
+        const int ray = (int)(b / bpr);
+        const int sidx = (int)(b % bpr) * 32 + j;
+        const bool ok = blk_ok && sidx < S;
+        const size_t so = (size_t)ray * S + (sidx < S ? sidx : S - 1);
+        const f32x4 q4 = *(const f32x4*)(a.pts4 + so * 4);
+        const float p[3] = {q4[0], q4[1], q4[2]};
+
+        // positional encoding in B-operand order (as the inference kernel)
+        constexpr int F0 = enc_F0(A::L);
+        constexpr int NSLOT = PL::NS_ENC_XYZ * KH;
+        float ev[NSLOT];
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) ev[q] = 0.0f;
+        ev[0] = h ? p[2] : p[0];
+        ev[1] = h ? 0.0f : p[1];
+        const float fscale = h ? (float)(1 << F0) : 1.0f;
+        const float prev_[3] = {p[0] * 0.15915494309189535f, p[1] * 0.15915494309189535f, p[2] * 0.15915494309189535f};
+        static_for<0, F0>([&](auto fc) {
+            constexpr int fl = decltype(fc)::value;
+            static_for<0, 3>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                float sv, cv;
+                enc_sincos<KH == 1>(p[c], prev_[c], fscale * (float)(1 << fl), &sv, &cv);
+                ev[2 + 2 * (3 * fl + c)] = sv;
+                ev[2 + 2 * (3 * fl + c) + 1] = cv;
+            });
+        });
+        efrag enc[NS_ENC];
+        static_for<0, NS_ENC>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            static_for<0, KH>([&](auto ec) { constexpr int e = decltype(ec)::value; PE::template set<e>(enc[s], ev[s * KH + e]); });
+        });
+
+        constexpr int NH = NT_W * SP;
+        frag ha[NH], hb[NH];
+        Empty none;
+        // epilogue of hidden layer LAYER: relu, keep for the backward pass, hand to the next layer
+        auto keep = [&](auto lc, auto tc, const f32x16& acc, auto& out) {
+            constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
+            if (ok) {
+                const size_t row = ((size_t)layer * M + so) * A::W + 32 * t + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store4<P>(a.acts, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]),
+                              relu_bits(acc[4 * q + 3]));
+            }
+            pack_tile<P, true, t>(acc, out);
+        };
+        dense<PE, P, PL, PL::L_TRUNK0, NS_ENC, 0>(st, bias_lane, enc, none, [&](auto tc, const f32x16& acc) {
+            keep(std::integral_constant<int, 0>{}, tc, acc, ha); });
+        static_for<1, A::D>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr bool skip = (i - 1 == A::SKIP);
+            if constexpr (i % 2 == 1) {
+                if constexpr (skip)
+                    dense<PE, P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lane, enc, ha, [&](auto tc, const f32x16& acc) { keep(ic, tc, acc, hb); });
+                else
+                    dense<P, P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lane, ha, none, [&](auto tc, const f32x16& acc) { keep(ic, tc, acc, hb); });
+            } else {
+                if constexpr (skip)
+                    dense<PE, P, PL, PL::L_TRUNK0 + i, NS_ENC, NH>(st, bias_lane, enc, hb, [&](auto tc, const f32x16& acc) { keep(ic, tc, acc, ha); });
+                else
+                    dense<P, P, PL, PL::L_TRUNK0 + i, NH, 0>(st, bias_lane, hb, none, [&](auto tc, const f32x16& acc) { keep(ic, tc, acc, ha); });
+            }
+        });
+        float raw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        auto take_raw = [&](auto, const f32x16& acc) { raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; raw[3] = acc[3]; raw[4] = acc[4]; };
+        if constexpr ((A::D - 1) % 2 == 1) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, hb, none, take_raw);
+        else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, ha, none, take_raw);
+        if (ok && h == 0) {
+            *(f32x4*)(a.raw4 + so * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+            if (a.raw_out) {
+                float* ro = a.raw_out + so * a.raw_ch;
+                ro[0] = raw[0]; ro[1] = raw[1]; ro[2] = raw[2]; ro[3] = raw[3];
+                if (a.raw_ch > 4) ro[4] = raw[4];
+            }
+        }
+        static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+    }
+    st.drain();
+}
+
+// ------------------------------------------------------------------------------------------
+// backward-data
+// ------------------------------------------------------------------------------------------
+template <class P, class A, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(const TrunkArgs a) {
+    using PL = PlanB<P, A>;
+    using frag = typename P::frag;
+    constexpr int KH = P::KH, SP = P::SP, NT_W = PL::NT_W, NT_E = PL::NT_E, NS_DR = PL::NS_DR;
+    static_assert(NT_E == 2, "the encoding gradient is kept in two accumulator tiles");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    float* bias_lds = (float*)(smem + RING * P::UNIT_BYTES);           // all zero: backward layers have no bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = 0.0f;
+    __syncthreads();
+    const BiasPtr bias_lane = bias_lane_ptr(bias_lds, h);
+    WRing<P, WAVES, PL::NUP> st;
+    st.init(a.wstream, ring, wave, lane);
+
+    const int S = a.S;
+    const int bpr = (S + 31) >> 5;
+    const long long nblocks = (long long)a.n_rays * bpr;
+    const size_t M = (size_t)a.n_rays * S;
+    for (long long tile0 = (long long)blockIdx.x * WAVES; tile0 < nblocks; tile0 += (long long)gridDim.x * WAVES) {
+        const long long blk = tile0 + wave;
+        const bool blk_ok = blk < nblocks;
+        const long long b = blk_ok ? blk : nblocks - 1;
+        const int ray = (int)(b / bpr);
+        const int sidx = (int)(b % bpr) * 32 + j;
+        const bool ok = blk_ok && sidx < S;
+        const size_t so = (size_t)ray * S + (sidx < S ? sidx : S - 1);
+
+        // d raw as the B operand of the head^T layer: logical vector v[ch], element (s, h, e) = v[(2s + h) KH + e]
+        const f32x4 g4 = *(const f32x4*)(a.d_raw4 + so * 4);
+        frag dr[NS_DR];
+        static_for<0, NS_DR>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            static_for<0, KH>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                constexpr int i0 = (2 * s) * KH + e, i1 = (2 * s + 1) * KH + e;
+                const float v0 = (i0 < 4) ? g4[i0 < 4 ? i0 : 0] : 0.0f;
+                const float v1 = (i1 < 4) ? g4[i1 < 4 ? i1 : 0] : 0.0f;
+                P::template set<e>(dr[s], ok ? (h ? v1 : v0) : 0.0f);
+            });
+        });
+
+        constexpr int NH = NT_W * SP;
+        frag ha[NH], hb[NH];
+        Empty none;
+        // epilogue producing d z_LAYER from tile t of d h_LAYER: mask with the saved activation, store, hand on
+        auto mask_store = [&](auto lc, auto tc, const f32x16& acc, auto& out) {
+            constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
+            const size_t row = ((size_t)layer * M + so) * A::W + 32 * t + 4 * h;
+            f32x16 g = acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 hv = load4<P>(a.acts, row + 8 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[4 * q + k] = (hv[k] > 0.0f) ? acc[4 * q + k] : 0.0f;
+                if (ok) store4<P>(a.d_pre, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+            }
+            pack_tile<P, false, t>(g, out);
+        };
+        // head^T: d h_{D-1}
+        dense<P, P, PL, 0, NS_DR, 0>(st, bias_lane, dr, none, [&](auto tc, const f32x16& acc) {
+            mask_store(std::integral_constant<int, A::D - 1>{}, tc, acc, ha); });
+        f32x16 denc[NT_E];
+        // layers D-1 .. 1 (transposed): input d z_i in the buffer the previous step filled, output d h_{i-1}
+        static_for<0, A::D - 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;          // 0 .. D-2
+            constexpr int i = A::D - 1 - k;                 // forward layer whose transpose runs now
+            constexpr int LI = PL::layer_of(i);
+            constexpr bool skip = (i - 1 == A::SKIP);
+            auto run = [&](auto& src, auto& dst) {
+                if constexpr (skip) {
+                    dense<P, P, PL, LI, NH, 0>(st, bias_lane, src, none, [&](auto tc, const f32x16& acc) {
+                        constexpr int t = decltype(tc)::value;
+                        if constexpr (t < NT_E) denc[t] = acc;
+                        else mask_store(std::integral_constant<int, i - 1>{}, std::integral_constant<int, t - NT_E>{}, acc, dst);
+                    });
+                } else {
+                    dense<P, P, PL, LI, NH, 0>(st, bias_lane, src, none, [&](auto tc, const f32x16& acc) {
+                        mask_store(std::integral_constant<int, i - 1>{}, tc, acc, dst); });
+                }
+            };
+            if constexpr (k % 2 == 0) run(ha, hb); else run(hb, ha);
+        });
+        // layer 0^T: the rest of the encoding's gradient
+        constexpr bool LAST_IN_B = ((A::D - 1) % 2 == 1);
+        auto add_enc = [&](auto tc, const f32x16& acc) { denc[decltype(tc)::value] += acc; };
+        if constexpr (LAST_IN_B) dense<P, P, PL, PL::layer_of(0), NH, 0>(st, bias_lane, hb, none, add_enc);
+        else dense<P, P, PL, PL::layer_of(0), NH, 0>(st, bias_lane, ha, none, add_enc);
+
+        // through the encoding (Embedder, run_nerf_helpers.py:120-150): slot q of this lane half holds d/d(value q);
+        // d p_c = d id_c + sum_f 2^f (cos(2^f p_c) d sin - sin(2^f p_c) d cos)
+        const f32x4 q4 = *(const f32x4*)(a.pts4 + so * 4);
+        const float p[3] = {q4[0], q4[1], q4[2]};
+        constexpr int F0 = enc_F0(A::L);
+        float dp[3] = {0.f, 0.f, 0.f};
+        auto dslot = [&](auto qc) -> float { constexpr int q = decltype(qc)::value; return denc[q / 16][q % 16]; };
+        dp[0] = h ? 0.0f : dslot(std::integral_constant<int, 0>{});
+        dp[1] = h ? 0.0f : dslot(std::integral_constant<int, 1>{});
+        dp[2] = h ? dslot(std::integral_constant<int, 0>{}) : 0.0f;
+        const float fscale = h ? (float)(1 << F0) : 1.0f;
+        const float prev_[3] = {p[0] * 0.15915494309189535f, p[1] * 0.15915494309189535f, p[2] * 0.15915494309189535f};
+        static_for<0, F0>([&](auto fc) {
+            constexpr int fl = decltype(fc)::value;
+            static_for<0, 3>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if (h * F0 + fl < A::L) {       // a frequency that exists (odd L: the upper half has one fewer)
+                    const float scale = fscale * (float)(1 << fl);
+                    float sv, cv;
+                    enc_sincos<KH == 1>(p[c], prev_[c], scale, &sv, &cv);
+                    const float ds = dslot(std::integral_constant<int, 2 + 2 * (3 * fl + c)>{});
+                    const float dc = dslot(std::integral_constant<int, 2 + 2 * (3 * fl + c) + 1>{});
+                    dp[c] += scale * (cv * ds - sv * dc);
+                }
+            });
+        });
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dp[c] += __shfl_xor(dp[c], 32);          // the two halves hold different frequencies
+        if (ok && h == 0) *(f32x4*)(a.d_pts4 + so * 4) = f32x4{dp[0], dp[1], dp[2], 0.0f};
+        static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+    }
+    st.drain();
+}
+
+template <class P, class A, int WAVES, bool BWD>
+static hipError_t launch_trunk_train(const TrunkArgs& a, int num_cus, hipStream_t stream) {
+    constexpr int NTILES = BWD ? PlanB<P, A>::NTILES : Plan<P, A, false, false>::NTILES;
+    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)NTILES * 32 * sizeof(float);
+    void (*kern)(const TrunkArgs) = nullptr;
+    if constexpr (BWD) kern = trunk_bwd<P, A, WAVES>; else kern = trunk_fwd_train<P, A, WAVES>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const long long nblocks = (long long)a.n_rays * ((a.S + 31) / 32);
+    const long long ntiles = (nblocks + WAVES - 1) / WAVES;
+    if (ntiles <= 0) return hipSuccess;
+    const long long resident = (long long)num_cus * ((P::KH == 1) ? 1 : 8 / WAVES);
+    const int grid = (int)(ntiles < resident ? ntiles : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace nrn

@@ -151,6 +151,35 @@ def build_model_desc(network_fn, network_fine, precision: str, device_index: int
     return desc, keep
 
 
+def _linears_in_canonical_order(network_fn, network_fine):
+    """nn.Linear modules in the order of the library's flat parameter vector (include/nrnerf.h,
+    nrnerf_model_update_device): bender offset MLP, rigidity MLP, coarse network, fine network."""
+    rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
+    mods = []
+    if rb is not None:
+        mods += list(rb.network) + list(rb.rigidity_network)
+    for net in (network_fn, network_fine):
+        if net is None:
+            continue
+        mods += list(net.pts_linears)
+        if net.use_viewdirs:
+            mods += [net.alpha_linear, net.feature_linear, net.views_linears[0], net.rgb_linear]
+        else:
+            mods.append(net.output_linear)
+    return mods
+
+
+def _flat_params(network_fn, network_fine):
+    parts = []
+    for lin in _linears_in_canonical_order(network_fn, network_fine):
+        parts.append(lin.weight.detach().reshape(-1))
+        if getattr(lin, "bias", None) is not None:
+            parts.append(lin.bias.detach().reshape(-1))
+    if not parts or any(p.device != parts[0].device for p in parts) or parts[0].device.type != "cuda":
+        return None
+    return torch.cat([p.to(torch.float32) for p in parts])
+
+
 def _fingerprint(mods):
     fp = []
     for m in mods:
@@ -200,6 +229,24 @@ class Model:
         if rc == _lib.ERR_INVALID:
             return False
         _lib.check(rc, "nrnerf_model_update")
+        return True
+
+    def update_from_device(self, network_fn, network_fine=None) -> bool:
+        """The same refresh without a host round trip (``nrnerf_model_update_device``): the parameters -- resident on this
+        model's device -- are concatenated into one fp32 vector in the library's canonical order and re-packed by a
+        gather kernel per image, asynchronously on the current stream.  What every training step does after
+        ``optimizer.step()``.  Returns False when the modules are not on this device or describe a different model."""
+        flat = _flat_params(network_fn, network_fine)
+        if flat is None or flat.device != self.device or int(self.lib.nrnerf_model_flat_size(self.handle)) != flat.numel():
+            return False
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)          # see update(): other streams may still read the old weights
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.nrnerf_model_update_device(self.handle, C.c_void_p(flat.data_ptr()), flat.numel(), C.c_void_p(stream))
+        if rc in (_lib.ERR_INVALID, _lib.ERR_UNSUPPORTED):
+            return False
+        _lib.check(rc, "nrnerf_model_update_device")
+        self._flat_keepalive = flat                       # until the next refresh: the kernels read it asynchronously
         return True
 
     def close(self):
@@ -355,7 +402,8 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
             if isinstance(hit[1], Exception):
                 raise hit[1]
             return hit[1]
-        if hit is not None and isinstance(hit[1], Model) and hit[1].update(network_fn, network_fine):
+        if hit is not None and isinstance(hit[1], Model) and (hit[1].update_from_device(network_fn, network_fine)
+                                                               or hit[1].update(network_fn, network_fine)):
             per[key] = (fp, hit[1])                                            # weights changed: refreshed in place
             return hit[1]
         try:
@@ -446,7 +494,21 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
         latents = additional_pixel_information.get("ray_bending_latents")
     model = dummy_kwargs.pop("_model", None)           # batchify_rays already decided
     why = None
-    if model is None:
+    if model is None and _trains(network_fn, network_fine if N_importance > 0 else None, ray_batch, latents):
+        # training call (train.py:152-287): the native autograd path (nonrigid_nerf_amd/training.py) when it has kernels
+        from . import training
+        why = training.why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp, pytest, ray_batch)
+        if why is None:
+            try:
+                return training.render_rays_train(
+                    ray_batch, network_fn, N_samples, retraw=retraw, perturb=perturb, N_importance=N_importance,
+                    network_fine=network_fine, white_bkgd=white_bkgd, raw_noise_std=raw_noise_std,
+                    additional_pixel_information=additional_pixel_information, detailed_output=detailed_output)
+            except (Unsupported, _lib.NrnerfError) as e:
+                if isinstance(e, _lib.NrnerfError) and e.status != _lib.ERR_UNSUPPORTED:
+                    raise
+                why = str(e)
+    elif model is None:
         model, why = _eligible(ray_batch, latents, network_fn, network_fine, N_samples, N_importance, lindisp, perturb,
                                white_bkgd, raw_noise_std, pytest)
     if why is None and N_importance == 0 and detailed_output:
@@ -513,6 +575,20 @@ def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, deta
     """
     lat = additional_pixel_information["ray_bending_latents"] if additional_pixel_information else None
     model, why = _eligible(rays_flat, lat, **kwargs)
+    if model is None and _trains(kwargs.get("network_fn"), kwargs.get("network_fine"), rays_flat, lat):
+        from . import training
+        if training.why_not_trainable(kwargs.get("network_fn"), kwargs.get("network_fine"), kwargs.get("N_samples", 64),
+                                      kwargs.get("N_importance", 0), kwargs.get("lindisp", False), kwargs.get("pytest", False),
+                                      rays_flat) is None:
+            # native training path: the chunk loop of the reference (train.py:115-137), chunk = the caller's (the random
+            # numbers are drawn per chunk; activations are kept for the backward pass, so memory scales with chunk)
+            pieces = {}
+            for i in range(0, rays_flat.shape[0], int(chunk)):
+                api = {"ray_bending_latents": lat[i:i + chunk, :]} if lat is not None else None
+                ret = render_rays(rays_flat[i:i + chunk], additional_pixel_information=api, detailed_output=detailed_output, **kwargs)
+                for k, v in ret.items():
+                    pieces.setdefault(k, []).append(v)
+            return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in pieces.items()}
     if model is None:
         ref = _fallbacks.get("batchify_rays")
         if ref is None:

@@ -1,0 +1,360 @@
+"""Training path of ``render_rays``: the reference trains through autograd (training_wrapper_class.forward,
+train.py:152-287; backward + optimiser step, train.py:1594-1610); here the same call runs on the HIP library under
+``torch.autograd``.
+
+What is native (C ABI ``nrnerf_trunk_forward / _backward``, ``nrnerf_composite_forward / _backward``, include/nrnerf.h):
+  * the canonical network -- positional encoding, 8x256 trunk, head -- forward with saved activations and the fused
+    backward-data pass on MFMA (csrc/nrnerf_train.h), fp32 or bf16;
+  * compositing forward (raw2outputs, train.py:724-789), hierarchical sampling + merge (run_nerf_helpers.py:651-698,
+    train.py:910-920, no gradient: the reference detaches the sample positions) and the compositing backward.
+What is left to libraries, as plumbing:
+  * the weight gradients ``dW_i = dz_i^T x_i``: plain [256 x K] x [K x 256] GEMMs over the two arrays the kernels fill
+    (``torch.matmul`` = hipBLASLt), and the bias gradients (column sums);
+  * the ray-bending and rigidity MLPs (35->64->64->64->64->3 and 3->32->32->1, 3 % of the flops) run as ``F.linear`` on
+    the modules' own parameters under PyTorch autograd: their regularisers (offsets, divergence:
+    run_nerf_helpers.py:22-116) need double backward through exactly these layers, which autograd provides.  The
+    trunk takes the bent points and returns the gradient with respect to them.
+Eligible: the default architecture without view-dependent head / time conditioning, precision fp32 or bf16
+(``render.set_precision``; "f16" trains in bf16: unscaled f16 gradients underflow).  Anything else is handed to the
+reference by ``render.render_rays`` as before.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from . import render as R
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def posenc(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
+    """Embedder.embed (run_nerf_helpers.py:120-150) -- only used to materialise the first operand of the weight-gradient
+    GEMMs of layers 0 and skip+1 (the kernels compute the encoding in registers and never write it)."""
+    cols = [x]
+    for k in range(n_freqs):
+        xs = x * float(2 ** k)
+        cols += [torch.sin(xs), torch.cos(xs)]
+    return torch.cat(cols, -1)
+
+
+class _Trunk(torch.autograd.Function):
+    """raw4 [N,S,4] (differentiable), raw [N,S,C] (the reference's "raw" key; no gradient) = NeRF trunk(points)."""
+
+    @staticmethod
+    def forward(ctx, pts, model, net, which, *params):
+        N, S = int(pts.shape[0]), int(pts.shape[1])
+        M, dev = N * S, pts.device
+        D, W = int(net.D), int(net.W)
+        act_dtype = torch.float32 if model.precision == "f32" else torch.bfloat16
+        pts4 = torch.zeros(M, 4, dtype=torch.float32, device=dev)
+        pts4[:, :3] = pts.detach().reshape(M, 3)
+        acts = torch.empty(D, M, W, dtype=act_dtype, device=dev)
+        raw4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        C_out = int(net.output_linear.weight.shape[0])
+        raw = torch.empty(M, C_out, dtype=torch.float32, device=dev)
+        a = _lib.TrunkArgs()
+        a.struct_size = C.sizeof(_lib.TrunkArgs)
+        a.which, a.n_rays, a.n_samples = int(which), N, S
+        a.pts4, a.acts, a.raw4, a.raw, a.raw_ch = pts4.data_ptr(), acts.data_ptr(), raw4.data_ptr(), raw.data_ptr(), C_out
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_trunk_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_forward")
+        ctx.model, ctx.net, ctx.which, ctx.dims = model, net, int(which), (N, S, D, W, C_out)
+        ctx.save_for_backward(pts4, acts)
+        ctx.mark_non_differentiable(raw)
+        return raw4.view(N, S, 4), raw.view(N, S, C_out)
+
+    @staticmethod
+    def backward(ctx, g_raw4, _g_raw):
+        pts4, acts = ctx.saved_tensors
+        model, net = ctx.model, ctx.net
+        N, S, D, W, C_out = ctx.dims
+        M, dev = N * S, pts4.device
+        g = g_raw4.contiguous().reshape(M, 4).float()
+        d_pre = torch.empty_like(acts)
+        d_pts4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        a = _lib.TrunkArgs()
+        a.struct_size = C.sizeof(_lib.TrunkArgs)
+        a.which, a.n_rays, a.n_samples = ctx.which, N, S
+        a.pts4, a.acts, a.d_raw4, a.d_pre, a.d_pts4 = pts4.data_ptr(), acts.data_ptr(), g.data_ptr(), d_pre.data_ptr(), d_pts4.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_trunk_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_backward")
+        # weight gradients: library GEMMs over the stored activations x_i and pre-activation gradients dz_i
+        adt = acts.dtype
+        L = (int(net.input_ch) - 3) // 6
+        enc = posenc(pts4[:, :3], L).to(adt)                               # x_0, and the first columns of x_{skip+1}
+        skips = set(int(s) for s in net.skips)
+        grads = []
+        for i in range(D):
+            dz = d_pre[i]
+            if i == 0:
+                dw = (dz.t() @ enc).float()
+            elif (i - 1) in skips:
+                dw = torch.cat([(dz.t() @ enc).float(), (dz.t() @ acts[i - 1]).float()], 1)   # x = [encoding, h] (rnh:278-282)
+            else:
+                dw = (dz.t() @ acts[i - 1]).float()
+            grads += [dw, dz.float().sum(0)]
+        g_out = torch.zeros(M, C_out, dtype=torch.float32, device=dev)
+        g_out[:, :4] = g
+        grads += [(g_out.to(adt).t() @ acts[D - 1]).float(), g_out.sum(0)]
+        return (d_pts4[:, :3].reshape(N, S, 3), None, None, None, *grads)
+
+
+def _trunk_params(net):
+    ps = []
+    for lin in net.pts_linears:
+        ps += [lin.weight, lin.bias]
+    return ps + [net.output_linear.weight, net.output_linear.bias]
+
+
+class _Composite(torch.autograd.Function):
+    """raw2outputs (train.py:724-789) of one pass, plus -- ``n_importance > 0`` -- the hierarchical sampling and merge
+    (run_nerf_helpers.py:651-698, train.py:910-920) in the same launch.  Differentiable outputs: rgb_map, disp_map,
+    acc_map, weights; alpha, the merged depths and z_std carry no gradient (the reference detaches the samples)."""
+
+    @staticmethod
+    def forward(ctx, raw4, rays, z, noise, white_bkgd, n_importance, u):
+        N, S, I = int(raw4.shape[0]), int(raw4.shape[1]), int(n_importance)
+        dev = raw4.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        raw4 = raw4.detach().contiguous()
+        rgb, disp, acc = torch.empty(N, 3, **f32), torch.empty(N, **f32), torch.empty(N, **f32)
+        weights, alpha = torch.empty(N, S, **f32), torch.empty(N, S, **f32)
+        z_std, z_merged = torch.empty(N if I > 0 else 0, **f32), torch.empty(N if I > 0 else 0, S + I, **f32)
+        a = _lib.CompositeArgs()
+        a.struct_size = C.sizeof(_lib.CompositeArgs)
+        a.n_rays, a.n_samples, a.n_importance = N, S, I
+        a.rays, a.ray_stride, a.raw4, a.z = rays.data_ptr(), int(rays.shape[1]), raw4.data_ptr(), z.data_ptr()
+        a.white_bkgd = int(bool(white_bkgd))
+        if noise is not None:
+            a.noise = noise.data_ptr()
+        if u is not None:
+            a.u = u.data_ptr()
+        a.rgb, a.disp, a.acc, a.weights, a.alpha = rgb.data_ptr(), disp.data_ptr(), acc.data_ptr(), weights.data_ptr(), alpha.data_ptr()
+        if I > 0:
+            a.z_std, a.z_merged = z_std.data_ptr(), z_merged.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nrnerf_composite_forward(C.byref(a), _stream(dev)), "nrnerf_composite_forward")
+        ctx.white_bkgd = bool(white_bkgd)
+        ctx.noise = noise
+        ctx.save_for_backward(raw4, rays, z)
+        ctx.mark_non_differentiable(alpha, z_std, z_merged)
+        return rgb, disp, acc, weights, alpha, z_merged, z_std
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, _g_alpha, _g_zm, _g_zs):
+        raw4, rays, z = ctx.saved_tensors
+        N, S = int(raw4.shape[0]), int(raw4.shape[1])
+        dev = raw4.device
+        d_raw4 = torch.empty(N, S, 4, dtype=torch.float32, device=dev)
+        keep = [t.contiguous().float() if t is not None else None for t in (g_rgb, g_disp, g_acc, g_w)]
+        if keep[0] is None:
+            keep[0] = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        a = _lib.CompositeArgs()
+        a.struct_size = C.sizeof(_lib.CompositeArgs)
+        a.n_rays, a.n_samples, a.n_importance = N, S, 0
+        a.rays, a.ray_stride, a.raw4, a.z = rays.data_ptr(), int(rays.shape[1]), raw4.data_ptr(), z.data_ptr()
+        a.white_bkgd = int(ctx.white_bkgd)
+        if ctx.noise is not None:
+            a.noise = ctx.noise.data_ptr()
+        a.g_rgb = keep[0].data_ptr()
+        for name, t in (("g_disp", keep[1]), ("g_acc", keep[2]), ("g_weights", keep[3])):
+            if t is not None:
+                setattr(a, name, t.data_ptr())
+        a.d_raw4 = d_raw4.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nrnerf_composite_backward(C.byref(a), _stream(dev)), "nrnerf_composite_backward")
+        return d_raw4, None, None, None, None, None, None
+
+
+def bend(rb, pts, latents):
+    """ray_bending.forward (run_nerf_helpers.py:507-577) as F.linear on the module's own parameters, under autograd.
+    pts [M,3], latents [M,L] -> bent points [M,3], dict(unmasked_offsets, rigidity_mask, masked_offsets)."""
+    h = torch.cat([pts, latents], -1)                                  # :525
+    n = len(rb.network)
+    for i, lin in enumerate(rb.network):
+        h = F.linear(h, lin.weight, lin.bias)                          # :527
+        if i != n - 1:
+            h = F.relu(h)                                              # :533-536
+    unmasked = h
+    r = pts                                                            # :546
+    n = len(rb.rigidity_network)
+    for i, lin in enumerate(rb.rigidity_network):
+        r = F.linear(r, lin.weight, lin.bias)
+        if i != n - 1:
+            r = F.relu(r)
+    mask = (torch.tanh(r) + 1) / 2                                     # :559-561
+    cutoff = getattr(rb, "rigidity_test_time_cutoff", None)
+    if cutoff is not None:
+        mask = torch.where(mask <= cutoff, torch.zeros_like(mask), mask)   # :563-564
+    masked = mask * unmasked                                           # :567
+    scaling = getattr(rb, "test_time_scaling", None)
+    if scaling is not None:
+        masked = masked * scaling                                      # :568-569
+    return pts + masked, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
+
+
+def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp, pytest, ray_batch):
+    """None when the native training path takes this call."""
+    if pytest:
+        return "pytest flag (numpy-seeded random numbers)"
+    if ray_batch.device.type != "cuda":
+        return "rays are not on a ROCm device"
+    if lindisp:
+        return "lindisp under autograd"
+    for net in (network_fn, network_fine if N_importance > 0 else None):
+        if net is None:
+            continue
+        if getattr(net, "use_viewdirs", False) or getattr(net, "time_conditioned_baseline", False):
+            return "view-dependent head / time-conditioned baseline under autograd"
+        if int(net.D) != 8 or int(net.W) != 256 or list(net.skips) != [4] or int(net.input_ch) != 63:
+            return "non-default trunk under autograd"
+    if N_samples < 2 or N_samples + N_importance > 256:
+        return "more than 256 samples per ray"
+    if R.get_precision() == "f16":
+        return None            # trains in bf16 (see module docstring)
+    return None
+
+
+def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.0, N_importance=0, network_fine=None,
+                      white_bkgd=False, raw_noise_std=0.0, additional_pixel_information=None, detailed_output=False):
+    """reference render_rays (train.py:792-980) with autograd: same output dict, attached to the graph of the networks',
+    the bender's and the latent codes' parameters."""
+    dev = ray_batch.device
+    precision = "bf16" if R.get_precision() == "f16" else R.get_precision()
+    rb = R._bender_of(network_fn)
+    latents = additional_pixel_information.get("ray_bending_latents") if additional_pixel_information else None
+    model = R.get_model(network_fn, network_fine if N_importance > 0 else None, precision=precision, device=dev)
+    rays = ray_batch.detach().to(torch.float32).contiguous()
+    N, S, I = int(rays.shape[0]), int(N_samples), int(N_importance)
+    rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    if I == 0 and detailed_output:
+        raise UnboundLocalError("local variable 'visibility_weights_0' referenced before assignment "
+                                "(reference render_rays cannot do detailed_output with N_importance == 0)")
+    # random numbers in the reference's order (train.py:860, 753; run_nerf_helpers.py:665; 753)
+    rnd = R._draw_randoms(rays, S, I, perturb, raw_noise_std) or {}
+    t_vals = torch.linspace(0.0, 1.0, steps=S, device=dev)                                   # :847
+    z_vals = (near * (1.0 - t_vals) + far * t_vals).expand(N, S)                             # :849, 853
+    if "u_coarse" in rnd:
+        mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])                                    # :857
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        z_vals = lower + (upper - lower) * rnd["u_coarse"]                                   # :868
+    z_vals = z_vals.contiguous()
+
+    def query(z, net, which):
+        pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]                        # :871-873 / 921-923
+        ns = int(z.shape[1])
+        details = {}
+        if detailed_output:
+            details["initial_input_pts"] = pts                                               # rnh:250-252
+        if rb is not None:
+            if latents is None:
+                raise ValueError("ray_bending_latents are required with a ray bender")
+            lat = latents[:, None, :].expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)   # train.py:79-87
+            bent, bd = bend(rb, pts.reshape(-1, 3), lat.to(torch.float32))
+            bent = bent.reshape(N, ns, 3)
+            if detailed_output:
+                details.update({k: v.reshape(N, ns, -1) for k, v in bd.items()})
+        else:
+            bent = pts
+        if detailed_output:
+            details["input_pts"] = bent                                                      # rnh:270
+        raw4, raw = _Trunk.apply(bent, model, net, which, *_trunk_params(net))
+        return raw4, raw, details
+
+    raw4, raw, details = query(z_vals, network_fn, 0)
+    noise_c = rnd.get("noise_coarse")
+    # :898, and -- same launch -- sample_pdf + merge (:910-920; no gradient: the reference detaches the samples)
+    rgb_map, disp_map, acc_map, weights, alpha, z_merged, z_std = _Composite.apply(raw4, rays, z_vals, noise_c, white_bkgd, I,
+                                                                                   rnd.get("u_fine"))
+    ret = {}
+    if I > 0:
+        rgb0, disp0, acc0, weights0, alpha0 = rgb_map, disp_map, acc_map, weights, alpha     # :902-908
+        net_f = network_fine if network_fine is not None else network_fn                     # :925
+        raw4, raw, fine_details = query(z_merged, net_f, 1 if network_fine is not None else 0)
+        rgb_map, disp_map, acc_map, weights, alpha, _, _ = _Composite.apply(raw4, rays, z_merged, rnd.get("noise_fine"),
+                                                                            white_bkgd, 0, None)                # :943-950
+    ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)                          # :952
+    if retraw:
+        ret["raw"] = raw                                                                     # :953-954
+    if I > 0:
+        ret.update(rgb0=rgb0, disp0=disp0, acc0=acc0, z_std=z_std)                           # :955-959
+        if detailed_output:
+            ret["fine_visibility_weights"] = weights                                         # :962
+            ret["fine_opacity_alpha"] = alpha                                                # :964
+            for k, v in fine_details.items():
+                ret["fine_" + k] = v                                                         # :965-966
+    if detailed_output:
+        ret["visibility_weights"] = weights0                                                 # :969
+        ret["opacity_alpha"] = alpha0                                                        # :970
+        ret.update(details)                                                                  # :971-972
+    return ret
+
+
+def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=1024, steps=30, warmup=5):
+    """bench.py's ``train_step`` leg: the reference's training iteration (train.py:1543-1642) at its batch size -- 1024
+    rays, 64 + N_importance samples, perturb = 1, raw_noise_std = 1 -- forward + backward + Adam step (+ the device-side
+    weight refresh the next forward needs) through the drop-in boundary.  Returns rays/s and the share of the step spent
+    in the native kernels."""
+    import time
+
+    from .synthetic import build_modules, make_rays
+    rb, coarse, fine = build_modules(scene, device=dev)
+    params = []
+    for m in (rb, coarse, fine):
+        if m is not None:
+            m.requires_grad_(True)
+            params += list(m.parameters())
+    codes = torch.zeros(8, cfg.latent_size, device=dev, requires_grad=True)
+    opt = torch.optim.Adam(params + [codes], lr=5e-4, betas=(0.9, 0.999))                 # train.py:655-658
+    rays, _ = make_rays(n_rays, 5, cfg)
+    rays = rays.to(dev)
+    frame = torch.randint(0, 8, (n_rays,), device=dev)
+    target = torch.rand(n_rays, 3, device=dev)
+    prev = R.get_precision()
+    R.set_precision(precision)
+    kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples, N_importance=cfg.N_importance,
+              perturb=1.0, raw_noise_std=1.0, retraw=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = R.batchify_rays(rays, {"ray_bending_latents": codes[frame]}, chunk=32768, **kw)
+        loss = ((out["rgb_map"] - target) ** 2).mean() + ((out["rgb0"] - target) ** 2).mean()   # train.py:207-217
+        loss.backward()
+        opt.step()
+        return loss
+
+    try:
+        with torch.enable_grad():
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / steps
+    finally:
+        R.set_precision(prev)
+    samples = n_rays * (2 * cfg.N_samples + cfg.N_importance)              # coarse pass + fine pass network evaluations
+    trunk_macs = 63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256 + 256 * cfg.output_ch
+    flops = 3.0 * 2.0 * trunk_macs * samples                                # forward + backward-data + backward-weights
+    peak = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}[precision]
+    return {"rays_per_s": round(n_rays / dt, 1), "ms_per_step": round(dt * 1e3, 3), "rays_per_step": n_rays,
+            "samples_per_ray": f"{cfg.N_samples}+{cfg.N_importance}", "dtype": precision, "final_loss": round(float(loss.detach()), 5),
+            "what": "forward + backward + Adam step + device-side weight re-pack, through render.batchify_rays under autograd",
+            "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(flops / dt / 1e12 / peak, 4),
+                         "note": "algorithmic trunk flops (3 x forward: fwd, backward-data, weight gradients) over the whole step's "
+                                 "wall time, incl. the PyTorch-autograd bender, optimiser and launch overheads at this batch size"}}

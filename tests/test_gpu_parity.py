@@ -376,7 +376,14 @@ def test_boundary_contract_errors_and_fallback():
         # submodule of the NeRF modules, run_nerf_helpers.py:213-215)
         for p_ in list(coarse.parameters()) + list(fine.parameters() if fine is not None else []):
             p_.requires_grad_(False)
+        # ... and is taken by the native training path (nonrigid_nerf_amd/training.py), not handed to the reference
         out = FakeTrain.batchify_rays(rays0.to(DEV), api, network_fn=coarse, network_query_fn=None, N_samples=64)
+        assert FakeTrain.calls == [] and out["rgb_map"].requires_grad
+        # a training call the native path has no kernels for (view-dependent head) still goes to the reference
+        cfgv = SceneConfig(N_importance=0, use_viewdirs=True)
+        rbv, cv, _ = build_modules(make_scene(cfgv, 0), device=DEV)
+        rv, lv = make_rays(8, 0, cfgv)
+        out = FakeTrain.batchify_rays(rv.to(DEV), {"ray_bending_latents": lv.to(DEV)}, network_fn=cv, network_query_fn=None, N_samples=64)
         assert FakeTrain.calls and FakeTrain.calls[0][0] == "batchify_rays"
         # wrong latent shape: the reference raises in expand/split; here a ValueError, never an out-of-bounds read
         with torch.no_grad(), pytest.raises(ValueError):
@@ -734,3 +741,44 @@ def test_render_path_and_surface_reduction_match_reference_golden():
         assert same.float().mean() >= 0.95, float(same.float().mean())
         assert torch.allclose(torch.from_numpy(extra[f]["surface_pts"])[same], torch.from_numpy(z[f"out__surface_pixels_{f}"])[same], atol=1e-4)
         assert torch.allclose(torch.from_numpy(extra[f]["surface_rigidity"])[same], torch.from_numpy(z[f"out__rigidity_{f}"])[same], atol=1e-4)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("cfg_kw,knobs,flags", [
+    (dict(), {}, {}),
+    (dict(N_importance=64, bend_depth=7), {}, {}),
+    (dict(N_samples=48, N_importance=37), dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5), {}),
+    (dict(N_importance=64), {}, dict(perturb=1.0, raw_noise_std=0.5)),
+    (dict(N_samples=128, N_importance=128), {}, dict(lindisp=True, white_bkgd=True)),
+], ids=["headline", "deep_bender", "ragged_knobs", "stochastic", "max_samples_flags"])
+def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg_kw, knobs, flags):
+    """nrnerf_render's split-bender path (coarse bent points carried over, stand-alone bender kernel for the importance
+    samples, trunk-only fine kernel; nrnerf_bend.h) against the fused fine pass, which a request for per-sample detail
+    outputs selects: same arithmetic, so every common output must be bit-identical -- maps, raw logits, merged depths
+    and the surface reduction."""
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 2)
+    rays, latents = make_rays(3001, 23, cfg)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    rb.rigidity_test_time_cutoff = knobs.get("rigidity_test_time_cutoff")
+    rb.test_time_scaling = knobs.get("test_time_scaling")
+    R.set_precision(precision)
+    model = R.get_model(coarse, fine)
+    r, l = rays.to(DEV), latents.to(DEV)
+    lind, wb = bool(flags.get("lindisp")), bool(flags.get("white_bkgd"))
+    outs = []
+    for detailed in (False, True):
+        torch.manual_seed(5)
+        randoms = R._draw_randoms(r, cfg.N_samples, cfg.N_importance, flags.get("perturb", 0.0), flags.get("raw_noise_std", 0.0))
+        with torch.no_grad():
+            outs.append(model.render(r, l, cfg.N_samples, cfg.N_importance, retraw=True, detailed_output=detailed,
+                                     rigidity_cutoff=rb.rigidity_test_time_cutoff, test_time_scaling=rb.test_time_scaling,
+                                     want_z_vals=True, surface=True, lindisp=lind, white_bkgd=wb, randoms=randoms))
+    torch.cuda.synchronize()
+    split, fused = outs
+    assert "fine_input_pts" in fused and "fine_input_pts" not in split
+    for k in split:
+        assert torch.equal(torch.nan_to_num(split[k].float()), torch.nan_to_num(fused[k].float())), k
+    # and the carried-over / separately bent points are the fused kernel's: the surface point is one of them
+    idx = split["median_index"].long()
+    assert torch.equal(split["surface_pts"], fused["fine_input_pts"][torch.arange(3001, device=DEV), idx])

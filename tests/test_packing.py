@@ -320,3 +320,108 @@ def test_unsupported_architectures_are_rejected():
     assert lib.nrnerf_pack_host(C.byref(bad), 0, None, None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_INVALID
     out = C.c_void_p()
     assert lib.nrnerf_model_create(None, C.byref(out)) == _lib.ERR_INVALID
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("bend_depth", [5, 7])
+def test_split_bender_images_are_the_two_halves_of_the_fused_stream(precision, bend_depth):
+    """Split-bender path (nrnerf_bend.h): the stand-alone bender kernel and the trunk-only fine pass must use exactly the
+    weights of the fused fine pass.  The fused stream is [bender + rigidity fragments | trunk + head fragments] with the
+    tile pairing restarting at every layer, so the two extra images (nrnerf_pack_host which = 3 / 2) are its two halves,
+    byte for byte, and so are the bias tables."""
+    cfg = SceneConfig(N_importance=128, bend_depth=bend_depth)
+    _, _, info_f, stream_f, _, bias_f = _pack(cfg, precision, which=1)
+    _, _, info_t, stream_t, _, bias_t = _pack(cfg, precision, which=2)
+    _, _, info_b, stream_b, _, bias_b = _pack(cfg, precision, which=3)
+    fb = info_f.frag_bytes
+    assert info_t.frag_bytes == fb and info_b.frag_bytes == fb
+    nb_tiles = info_b.n_bias_tiles
+    assert nb_tiles + info_t.n_bias_tiles == info_f.n_bias_tiles
+    assert np.array_equal(bias_f[:nb_tiles * 32], bias_b) and np.array_equal(bias_f[nb_tiles * 32:], bias_t)
+    assert info_b.mfma_per_block + info_t.mfma_per_block == info_f.mfma_per_block
+    # fragment counts: bender layers stream 2 fragments per 3 MFMAs in the split-product (16-bit) modes
+    nfrag_b = info_b.mfma_per_block * 2 // 3 if precision != "f32" else info_b.mfma_per_block
+    nfrag_t = info_t.mfma_per_block
+    assert np.array_equal(stream_f[:nfrag_b * fb], stream_b[:nfrag_b * fb]) and not stream_b[nfrag_b * fb:].any()
+    assert np.array_equal(stream_f[nfrag_b * fb:(nfrag_b + nfrag_t) * fb], stream_t[:nfrag_t * fb]) and not stream_t[nfrag_t * fb:].any()
+    # without a bender (or with the view-dependent head) there is nothing to split
+    scene = make_scene(SceneConfig(ray_bending=False), 0)
+    rb, coarse, fine = build_modules(scene)
+    desc, keep = build_model_desc(coarse, fine, precision, 0)
+    info = _lib.PackedInfo()
+    lib = _lib.load()
+    assert lib.nrnerf_pack_host(C.byref(desc), 3, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_backward_stream_reproduces_autograd_of_the_trunk(precision):
+    """Training (csrc/nrnerf_train.h): the backward-data kernel streams TRANSPOSED weights in PlanB's order (head^T, then
+    pts_linears[7..1]^T, then pts_linears[0]^T; nrnerf_pack_host which = 5).  Emulating its register dataflow in numpy --
+    d raw as the first B operand, relu masks from the forward activations, the skip layer's first two tiles and the last
+    layer's two tiles being the encoding's gradient in encoding-SLOT order -- must reproduce torch.autograd's gradient
+    wrt the encoded input."""
+    cfg = SceneConfig(N_importance=128)
+    scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=5)
+    assert not bias.any(), "backward layers have no bias"
+    KH = 1 if precision == "f32" else 8
+    rnd = rounder(precision)
+    fr = FragReader(stream, precision, info.frag_bytes)
+    gen = torch.Generator().manual_seed(11)
+    ns_ = 32
+    x = (torch.randn(ns_, 63, generator=gen) * 0.5).double().requires_grad_(True)
+    d_raw = torch.randn(ns_, 5, generator=gen).double()
+    d_raw[:, 4] = 0.0
+    # forward in fp64 torch, keeping the activations
+    hs, h = [], x
+    for i, l in enumerate(fine.pts_linears):
+        h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
+        hs.append(h)
+        if i == 4:
+            h = torch.cat([x, h], -1)
+    raw = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double())
+    (g_x,) = torch.autograd.grad(raw, x, d_raw)
+    hs = [t.detach().numpy() for t in hs]
+
+    def mask_tiles(tiles, layer):          # d h_layer tiles [32, ns] -> d z_layer (rows = features 32 t + i)
+        return [np.where(hs[layer][:, 32 * t:32 * t + 32].T > 0, D, 0.0) for t, D in enumerate(tiles)]
+
+    v = np.zeros((8, ns_))
+    v[:5] = d_raw.numpy().T
+    slabs = vec_slabs(v, KH, rnd)
+    tile0, mfma = 0, 0
+    tiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs); mfma += len(slabs) * 8; tile0 += 8          # head^T -> d h_7
+    denc = None
+    for i in range(7, 0, -1):
+        slabs = repack(mask_tiles(tiles, i), KH, False, rnd)
+        nt = 10 if i == 5 else 8
+        out = dense_emul(fr, bias, tile0, len(slabs), nt, slabs); mfma += len(slabs) * nt; tile0 += nt
+        if i == 5:
+            denc, tiles = out[:2], out[2:]
+        else:
+            tiles = out
+    slabs = repack(mask_tiles(tiles, 0), KH, False, rnd)
+    out = dense_emul(fr, bias, tile0, len(slabs), 2, slabs); mfma += len(slabs) * 2; tile0 += 2             # pts_linears[0]^T
+    denc = [denc[0] + out[0], denc[1] + out[1]]
+    assert tile0 == info.n_bias_tiles and mfma == info.mfma_per_block
+    used = fr.pos * info.frag_bytes
+    assert used <= info.stream_bytes and not stream[used:].any()
+    # encoding-slot order -> reference columns (nrnerf_plan.h enc_col): half hh, slot q = te * 16 + r, row = tile_row(r, hh)
+    got = np.zeros((ns_, 63))
+    F0 = 5
+    for te in range(2):
+        for hh in range(2):
+            for r in range(16):
+                q = te * 16 + r
+                if q == 0:
+                    col = 2 if hh else 0
+                elif q == 1:
+                    col = -1 if hh else 1
+                else:
+                    pi, fn = (q - 2) // 2, (q - 2) % 2
+                    fl, c = pi // 3, pi % 3
+                    col = 3 + 6 * (hh * F0 + fl) + 3 * fn + c
+                if col >= 0:
+                    got[:, col] = denc[te][tile_row(r, hh)]
+    tol = 1e-9 if precision == "f32" else 6e-2
+    err = np.abs(got - g_x.numpy()).max()
+    assert err <= tol * np.abs(g_x.numpy()).max(), (err, np.abs(g_x.numpy()).max())

@@ -3,20 +3,32 @@
 under profiles/.  FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads
 on gfx950; FETCH_SIZE / WRITE_SIZE are in KiB.
 
-    python tools/pmc_summary.py gpurun_out/pmcA gpurun_out/pmcB ... > profiles/r01_pmc_summary.txt
+    python tools/pmc_summary.py gpurun_out/pmcA gpurun_out/pmcB ... > profiles/r02_pmc_summary.txt
+
+Also writes profiles/r02_pmc_fine.json (per-pass medians + the hash of the library that was profiled + the bench scene):
+bench.py reports roofline.traffic from it only while that hash matches the library it loaded.
 """
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main(dirs):
     per = collections.defaultdict(dict)       # (pass, dispatch) -> counters
+    bend = collections.defaultdict(dict)      # the stand-alone bender kernel (split-bender path)
     for d in dirs:
         for f in glob.glob(d + "/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
+                if "bend_kernel" in r["Kernel_Name"]:
+                    kb = (d, int(r["Dispatch_Id"]))
+                    bend[kb][r["Counter_Name"]] = float(r["Counter_Value"])
+                    bend[kb]["_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
                 if "net_kernel" not in r["Kernel_Name"]:
                     continue
                 k = (d, int(r["Dispatch_Id"]))
@@ -33,8 +45,14 @@ def main(dirs):
                     for c, v in per[(d, i)].items():
                         agg[c].append(v)
         out[label] = {c: sorted(v)[len(v) // 2] for c, v in agg.items()}
-    print("# rocprofv3 --pmc summary, net_kernel (median over launches), bench.py workload (196608 rays, 64+128)")
-    for label in ("coarse", "fine"):
+    agg = collections.defaultdict(list)
+    for kb, cs in bend.items():
+        for c, v in cs.items():
+            agg[c].append(v)
+    if agg:
+        out["bend"] = {c: sorted(v)[len(v) // 2] for c, v in agg.items()}
+    print("# rocprofv3 --pmc summary, net_kernel / bend_kernel (median over launches), bench.py workload (196608 rays, 64+128)")
+    for label in [l for l in ("coarse", "fine", "bend") if l in out]:
         c = out[label]
         print(f"\n[{label} pass]  duration {c.get('_us', 0):.1f} us")
         for k in sorted(c):
@@ -57,8 +75,13 @@ def main(dirs):
             tot = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
             print(f"  -> L2 hit rate                       {c['TCC_HIT_sum'] / max(tot, 1):.4f}  ({tot:.4g} requests: the weight stream is "
                   f"re-read from L2 by every workgroup pass, the rays / depths / outputs stream through once)")
-    json.dump(out, open("profiles/r01_pmc_fine.json", "w"), indent=1)
+    from nonrigid_nerf_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        out["lib_sha16"] = hashlib.sha256(f.read()).hexdigest()[:16]
+    out["scene"] = os.environ.get("NRNERF_PROFILE_SCENE", "fitted")
+    json.dump(out, open(os.path.join(REPO, "profiles", "r02_pmc_fine.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
+    sys.path.insert(0, REPO)
     main(sys.argv[1:])
