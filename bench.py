@@ -169,48 +169,31 @@ def main():
               N_importance=cfg.N_importance, perturb=0.0, raw_noise_std=0.0)
     model = R.get_model(coarse, fine, device=dev)          # weights packed once, outside the timed region
 
-    # ---- multi-GPU: double-buffered pixel blocks, all-gather on a side stream (frame f's gather overlaps frame f+1's render)
+    # ---- multi-GPU: frame f's all-gather runs on a side stream while frame f+1 renders (distributed.OverlappedGather)
     n = args.rays
-    main_stream = torch.cuda.current_stream(dev)
     if world > 1:
         import torch.distributed as dist
-        side = torch.cuda.Stream(device=dev)
-        packed = [torch.empty(n, 5, device=dev) for _ in range(2)]
-        full = [torch.empty(world * n, 5, device=("cpu" if one_gpu else dev)) for _ in range(2)]
-        pending = [None, None]
+        from nonrigid_nerf_amd.distributed import OverlappedGather
+        gather = OverlappedGather(n, "cpu" if one_gpu else dev)      # gloo (the one-GPU functional mode) gathers host tensors
 
     def step(i):
         out = R.batchify_rays(rays, api, chunk=1024 * 32, **kw)
         if world == 1:
             return out
-        b = i & 1
-        if pending[b] is not None:                        # buffer pair b was handed to gather i-2: finished long ago
-            pending[b].wait()
-        buf = packed[b]
-        buf[:, 0:3] = out["rgb_map"]; buf[:, 3] = out["disp_map"]; buf[:, 4] = out["acc_map"]
-        if one_gpu:                                       # gloo has no all_gather for device tensors
-            dist.all_gather_into_tensor(full[b], buf.cpu())
-            return full[b]
-        ready = torch.cuda.Event()
-        ready.record(main_stream)
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            pending[b] = dist.all_gather_into_tensor(full[b], buf, async_op=True)
-        return full[b]
+        if one_gpu:
+            out = {k: out[k].cpu() for k in ("rgb_map", "disp_map", "acc_map")}
+        return gather.submit(i, out)
 
     def drain():
         if world > 1:
-            for b in range(2):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
-            main_stream.wait_stream(side) if not one_gpu else None
+            gather.drain()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    main_stream = torch.cuda.current_stream(dev)
     t_gpu0 = time.perf_counter()
     with torch.no_grad():
         for i in range(args.warmup):

@@ -203,11 +203,12 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
  *
  * Kernel sequence.  Default: coarse network -> composite + sample_pdf + merge -> fine network -> composite.  With a ray
  * bender, no view-dependent head, n_importance > 0 and no per-sample detail outputs requested, the fine pass is split
- * (same results): every sample is bent exactly once by a stand-alone bender kernel -- the coarse samples before the
- * coarse network, the n_importance new samples before the fine network; the coarse samples keep their bent points in
+ * (same results, bit for bit): the coarse network kernel also writes its bent points; the coarse samples keep them in
  * the fine pass (the bender is shared by both networks, run_nerf_helpers.py:213-215, and the coarse depths are a subset
- * of the merged depths, train.py:920) -- and the network kernels run their trunks on those points.  Environment
- * variables (read once): NRNERF_FUSED_FINE_BENDER=1 keeps both passes fused, NRNERF_SPLIT_COARSE=0 only the coarse one. */
+ * of the merged depths, train.py:920); a stand-alone bender kernel handles the n_importance new samples; the fine
+ * network kernel runs its trunk on those points.  Environment variables (read once): NRNERF_FUSED_FINE_BENDER=1 keeps
+ * the fused fine pass, NRNERF_SPLIT_COARSE=1 also splits the coarse pass (bender kernel + trunk-only kernel; measured
+ * no faster than the fused coarse kernel). */
 int nrnerf_render(const nrnerf_model* model, const nrnerf_render_args* args, void* hip_stream);
 
 /* Camera rays of one frame, generated on the device: reference get_rays (run_nerf_helpers.py:588-605) followed by

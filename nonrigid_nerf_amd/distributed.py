@@ -55,3 +55,59 @@ def gather_pixels(packed_local: torch.Tensor, group=None) -> torch.Tensor:
                        device=packed_local.device)
     dist.all_gather_into_tensor(full, packed_local.contiguous(), group=group)
     return full
+
+
+class OverlappedGather:
+    """Frame f's all-gather overlapped with frame f+1's render (per frame the collective moves
+    20 B/ray and is latency-, not bandwidth-bound, so it is hidden behind the next frame's kernels instead of being
+    waited for).
+
+    Two pixel blocks and two result buffers are used alternately.  ``submit(i, out)`` packs frame i's ``[rgb, disp,
+    acc]`` into block ``i & 1`` on the render stream and issues ``all_gather_into_tensor`` asynchronously from a side
+    stream that waits for the packing; the block pair is reused two frames later, after ``wait()`` on its previous
+    collective (long finished by then).  ``drain()`` joins everything (end of a sequence / before reading a result).
+    With CPU tensors (gloo, the CPU test tier) there are no streams: the collectives are still issued asynchronously
+    and joined the same way.
+    """
+
+    def __init__(self, rows_per_rank: int, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.packed = [torch.empty(rows_per_rank, 5, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.full = [torch.empty(self.world * rows_per_rank, 5, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.pending = [None, None]
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+    def submit(self, i: int, out: dict) -> torch.Tensor:
+        """Returns the buffer that will hold all ranks' pixels of frame i once its collective has completed."""
+        b = i & 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        buf = self.packed[b]
+        buf[:, 0:3] = out["rgb_map"]
+        buf[:, 3] = out["disp_map"]
+        buf[:, 4] = out["acc_map"]
+        if self.world == 1:
+            self.full[b].copy_(buf)
+            return self.full[b]
+        if self.cuda:
+            main = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                self.pending[b] = dist.all_gather_into_tensor(self.full[b], buf, group=self.group, async_op=True)
+        else:
+            self.pending[b] = dist.all_gather_into_tensor(self.full[b], buf, group=self.group, async_op=True)
+        return self.full[b]
+
+    def drain(self):
+        for b in range(2):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)

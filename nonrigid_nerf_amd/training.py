@@ -33,10 +33,6 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
-
-
 def posenc(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
     """Embedder.embed (run_nerf_helpers.py:120-150) -- only used to materialise the first operand of the weight-gradient
     GEMMs of layers 0 and skip+1 (the kernels compute the encoding in registers and never write it)."""
@@ -45,6 +41,28 @@ def posenc(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
         xs = x * float(2 ** k)
         cols += [torch.sin(xs), torch.cos(xs)]
     return torch.cat(cols, -1)
+
+
+def _chunks(m: int, target: int = 4096) -> int:
+    """Number of equal row blocks to cut an [m, .] operand into: the largest divisor of m that keeps blocks >= target rows."""
+    if m < 2 * target:
+        return 1
+    b = m // target
+    while b > 1 and m % b:
+        b -= 1
+    return b
+
+
+def _wgrad(dz: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dz^T x for dz [M, O], x [M, K] -> [O, K] fp32.  A [O x M] x [M x K] GEMM with M in the hundreds of thousands and
+    O, K <= 320 gives a library GEMM two output tiles to parallelise over; cut along M into a batch of partial products
+    (one batched GEMM over ~50-100 blocks fills the chip) and add the partials."""
+    M = dz.shape[0]
+    B = _chunks(M)
+    if B == 1:
+        return (dz.t() @ x).float()
+    part = torch.bmm(dz.view(B, M // B, -1).transpose(1, 2), x.view(B, M // B, -1))      # [B, O, K]
+    return part.sum(0, dtype=torch.float32)
 
 
 class _Trunk(torch.autograd.Function):
@@ -93,19 +111,25 @@ class _Trunk(torch.autograd.Function):
         L = (int(net.input_ch) - 3) // 6
         enc = posenc(pts4[:, :3], L).to(adt)                               # x_0, and the first columns of x_{skip+1}
         skips = set(int(s) for s in net.skips)
+        # hidden-to-hidden layers 1 .. D-1 (x_i = h_{i-1}; for the skip layer this is the h part of [encoding, h]): ONE batched
+        # GEMM over (layer, row block), partial products added per layer; biases: one reduction over the whole d_pre array
+        Bc = _chunks(M)
+        c = M // Bc
+        part = torch.bmm(d_pre[1:D].reshape((D - 1) * Bc, c, W).transpose(1, 2), acts[0:D - 1].reshape((D - 1) * Bc, c, W))
+        dwh = part.view(D - 1, Bc, W, W).sum(1, dtype=torch.float32)               # [D-1, W, W]
+        db = d_pre.sum(1, dtype=torch.float32)                                     # [D, W]
         grads = []
         for i in range(D):
-            dz = d_pre[i]
             if i == 0:
-                dw = (dz.t() @ enc).float()
+                dw = _wgrad(d_pre[0], enc)
             elif (i - 1) in skips:
-                dw = torch.cat([(dz.t() @ enc).float(), (dz.t() @ acts[i - 1]).float()], 1)   # x = [encoding, h] (rnh:278-282)
+                dw = torch.cat([_wgrad(d_pre[i], enc), dwh[i - 1]], 1)             # x = [encoding, h] (rnh:278-282)
             else:
-                dw = (dz.t() @ acts[i - 1]).float()
-            grads += [dw, dz.float().sum(0)]
+                dw = dwh[i - 1]
+            grads += [dw, db[i]]
         g_out = torch.zeros(M, C_out, dtype=torch.float32, device=dev)
         g_out[:, :4] = g
-        grads += [(g_out.to(adt).t() @ acts[D - 1]).float(), g_out.sum(0)]
+        grads += [_wgrad(g_out.to(adt), acts[D - 1]), g_out.sum(0)]
         return (d_pts4[:, :3].reshape(N, S, 3), None, None, None, *grads)
 
 
@@ -176,20 +200,39 @@ class _Composite(torch.autograd.Function):
         return d_raw4, None, None, None, None, None, None
 
 
+# False: the bender's layers run as plain F.linear (bit-identical bent points to the reference's ops; used by the gradient
+# parity tests, because gradients through the 2^9 encoding frequency move by 1e-2 of their scale under a 1-ulp change of
+# the bent points).  True: batched GEMMs over row blocks (see _linear_rows), 4 ms less per 1024-ray step.
+BATCHED_BENDER = True
+
+
+def _linear_rows(x, lin, B):
+    """F.linear(x, W, b) for x [M, in] with M huge and in / out <= 64.  Written as a batched GEMM over B row blocks
+    against the (stride-0) expanded weight: autograd then forms the weight gradient per block with one batched GEMM and
+    adds the blocks (expand's backward), instead of one [out x M] x [M x in] GEMM that has a single output tile to work
+    on.  Pure torch ops, so double backward (divergence regulariser) still works."""
+    if B == 1:
+        return F.linear(x, lin.weight, lin.bias)
+    M = x.shape[0]
+    y = torch.bmm(x.view(B, M // B, -1), lin.weight.t().unsqueeze(0).expand(B, -1, -1)).reshape(M, -1)
+    return y if lin.bias is None else y + lin.bias
+
+
 def bend(rb, pts, latents):
-    """ray_bending.forward (run_nerf_helpers.py:507-577) as F.linear on the module's own parameters, under autograd.
+    """ray_bending.forward (run_nerf_helpers.py:507-577) on the module's own parameters, under autograd.
     pts [M,3], latents [M,L] -> bent points [M,3], dict(unmasked_offsets, rigidity_mask, masked_offsets)."""
+    B = _chunks(pts.shape[0], 2048) if BATCHED_BENDER else 1
     h = torch.cat([pts, latents], -1)                                  # :525
     n = len(rb.network)
     for i, lin in enumerate(rb.network):
-        h = F.linear(h, lin.weight, lin.bias)                          # :527
+        h = _linear_rows(h, lin, B)                                    # :527
         if i != n - 1:
             h = F.relu(h)                                              # :533-536
     unmasked = h
     r = pts                                                            # :546
     n = len(rb.rigidity_network)
     for i, lin in enumerate(rb.rigidity_network):
-        r = F.linear(r, lin.weight, lin.bias)
+        r = _linear_rows(r, lin, B)
         if i != n - 1:
             r = F.relu(r)
     mask = (torch.tanh(r) + 1) / 2                                     # :559-561
@@ -226,7 +269,8 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
 
 
 def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.0, N_importance=0, network_fine=None,
-                      white_bkgd=False, raw_noise_std=0.0, additional_pixel_information=None, detailed_output=False):
+                      white_bkgd=False, raw_noise_std=0.0, additional_pixel_information=None, detailed_output=False,
+                      want_z_vals=False):
     """reference render_rays (train.py:792-980) with autograd: same output dict, attached to the graph of the networks',
     the bender's and the latent codes' parameters."""
     dev = ray_batch.device
@@ -299,6 +343,8 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         ret["visibility_weights"] = weights0                                                 # :969
         ret["opacity_alpha"] = alpha0                                                        # :970
         ret.update(details)                                                                  # :971-972
+    if want_z_vals:
+        ret["_z_vals"] = z_merged if I > 0 else z_vals          # not a reference key: the depths of the final pass
     return ret
 
 
@@ -309,19 +355,41 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=1024, steps=30, w
     in the native kernels."""
     import time
 
-    from .synthetic import build_modules, make_rays
-    rb, coarse, fine = build_modules(scene, device=dev)
+    from .modules import NeRFWeights, RayBenderWeights
+    from .synthetic import make_rays
+    # a model at the reference's initialisation (create_nerf train.py:595-630; ray_bending.__init__ rnh:436-455, 487-505:
+    # kaiming hidden layers, zero biases, zero last layers) -- the synthetic stress weights of the inference benchmark
+    # would die (sigma < 0 everywhere, zero gradients) after one Adam step
+    rb = RayBenderWeights(cfg.latent_size, cfg.bend_hidden, cfg.bend_depth, cfg.rigidity_hidden, cfg.rigidity_depth) if cfg.ray_bending else None
+    if rb is not None:
+        with torch.no_grad():
+            for net in (rb.network, rb.rigidity_network):
+                for layer in list(net)[:-1]:
+                    torch.nn.init.kaiming_uniform_(layer.weight, a=0, mode="fan_in", nonlinearity="relu")
+                    torch.nn.init.zeros_(layer.bias)
+                net[-1].weight.zero_()
+                if net[-1].bias is not None:
+                    net[-1].bias.zero_()
+    mk = lambda ns: NeRFWeights(D=cfg.netdepth, W=cfg.netwidth, input_ch=cfg.input_ch, output_ch=cfg.output_ch, skips=cfg.skips,
+                                ray_bending_latent_size=cfg.latent_size, num_ray_samples=ns)
+    coarse, fine = mk(cfg.N_samples), (mk(cfg.N_samples + cfg.N_importance) if cfg.N_importance > 0 else None)
+    for m in (rb, coarse, fine):
+        if m is not None:
+            m.to(dev)
+    coarse.ray_bender = (rb,)
+    if fine is not None:
+        fine.ray_bender = (rb,)
     params = []
     for m in (rb, coarse, fine):
         if m is not None:
             m.requires_grad_(True)
             params += list(m.parameters())
     codes = torch.zeros(8, cfg.latent_size, device=dev, requires_grad=True)
-    opt = torch.optim.Adam(params + [codes], lr=5e-4, betas=(0.9, 0.999))                 # train.py:655-658
+    opt = torch.optim.Adam(params + [codes], lr=5e-4, betas=(0.9, 0.999), fused=True)     # train.py:655-658 (one fused update kernel)
     rays, _ = make_rays(n_rays, 5, cfg)
     rays = rays.to(dev)
     frame = torch.randint(0, 8, (n_rays,), device=dev)
-    target = torch.rand(n_rays, 3, device=dev)
+    target = 0.5 + 0.4 * torch.sin(3.0 * rays[:, 3:6])                     # a smooth colour field of the ray direction
     prev = R.get_precision()
     R.set_precision(precision)
     kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples, N_importance=cfg.N_importance,

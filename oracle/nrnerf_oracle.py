@@ -219,7 +219,7 @@ def sample_pdf_det(bins, weights, n_samples: int, det: bool = True):
 
 def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=False,
                 knobs: Knobs | None = None, dtype=torch.float32, lindisp=False, white_bkgd=False,
-                perturb=0.0, raw_noise_std=0.0):
+                perturb=0.0, raw_noise_std=0.0, z_fine_override=None):
     """render_rays (train.py:792-980); the stochastic branches draw from torch's generator in the reference's order.
 
     ``scene`` is a ``nonrigid_nerf_amd.synthetic.Scene`` (or anything with
@@ -258,6 +258,10 @@ def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=Fals
         z_mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])                         # :910
         z_samples = sample_pdf_det(z_mid, weights[..., 1:-1], I, det=(perturb == 0.0)).detach()   # :911-918 (no gradient through the sample positions)
         z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)             # :920
+        if z_fine_override is not None:
+            # test hook (not in the reference): evaluate the fine pass at given merged depths, so that a checked
+            # implementation whose sample_pdf branch (rnh:694) fell the other way on a few rays can be compared tightly
+            z_vals = z_fine_override.to(z_vals)
         pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]         # :921-923
         net = scene.fine if scene.fine is not None else scene.coarse               # :925
         out = query_network(pts, viewdirs, lat, net, scene.bender, cfg, knobs, detailed_output)

@@ -132,3 +132,40 @@ def test_bench_spawns_its_own_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["backend"] == "gloo"
     assert res["steps"] == 3 and res["value"] > 0
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nonrigid_nerf_amd.distributed import OverlappedGather
+    n = 11
+    g = OverlappedGather(n, "cpu")
+    results = []
+    for i in range(5):                                   # five "frames": buffers are reused from frame 2 on
+        base = 100.0 * i + 10.0 * rank
+        out = {"rgb_map": torch.full((n, 3), base), "disp_map": torch.full((n,), base + 1), "acc_map": torch.full((n,), base + 2)}
+        full = g.submit(i, out)
+        if i >= 1:                                       # frame i-1 may be read after its collective has been joined
+            g.pending[(i - 1) & 1].wait()
+            results.append(g.full[(i - 1) & 1].clone())
+    g.drain()
+    results.append(full.clone())
+    torch.save(results, os.path.join(out_dir, f"ov{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_double_buffering_world_size_2(tmp_path):
+    """The N > 1 path of bench.py (asynchronous all-gather of frame f while frame f+1 is produced, two buffer pairs) on
+    CPU with gloo: every rank must see every rank's pixels of every frame, in rank order."""
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"ov{r}.pt"))
+        assert len(res) == 5
+        for i, full in enumerate(res):
+            assert full.shape == (22, 5)
+            for src in range(world):
+                blk = full[11 * src:11 * (src + 1)]
+                base = 100.0 * i + 10.0 * src
+                assert torch.equal(blk[:, 0:3], torch.full((11, 3), base)) and torch.equal(blk[:, 3], torch.full((11,), base + 1)) \
+                    and torch.equal(blk[:, 4], torch.full((11,), base + 2)), (r, i, src)
