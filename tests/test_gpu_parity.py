@@ -207,6 +207,18 @@ def test_fp32_mode_vs_oracle_4k_rays():
     assert not fails, "\n".join(fails)
 
 
+def test_split_bender_path_at_full_chunk_size_equals_the_fused_pass():
+    """One reference chunk (32 768 rays, 64+128, bf16): the split-bender path a plain render takes against the fused fine
+    pass a detailed render takes -- every common output bit-identical at BASELINE config 2's size as well."""
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(32768, 3, cfg)
+    a = hip_render(scene, rays, latents, "bf16", retraw=True)                    # split-bender path
+    b = hip_render(scene, rays, latents, "bf16", retraw=True, detailed=True)     # fused fine pass
+    for k in a:
+        assert torch.equal(torch.nan_to_num(a[k]), torch.nan_to_num(b[k])), k
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_full_size_properties(precision):
     """BASELINE config 2 size (32768-ray chunk, 64+128): properties that need no oracle."""
@@ -782,3 +794,48 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
     # and the carried-over / separately bent points are the fused kernel's: the surface point is one of them
     idx = split["median_index"].long()
     assert torch.equal(split["surface_pts"], fused["fine_input_pts"][torch.arange(3001, device=DEV), idx])
+
+
+@pytest.mark.parametrize("cfg_kw", [dict(N_importance=64, use_viewdirs=True), dict(N_importance=64, bend_depth=7),
+                                    dict(N_importance=64, ray_bending=False, time_conditioned_baseline=True),
+                                    dict(N_importance=0, ray_bending=False), dict(N_importance=64, use_viewdirs=True, approx_nonrigid_viewdirs=False)],
+                         ids=["viewdirs", "deep_bender", "time_conditioned", "coarse_only_no_bender", "exact_viewdirs"])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_device_side_weight_refresh_equals_a_fresh_pack(cfg_kw, precision):
+    """nrnerf_model_update_device on every architecture family: after in-place weight changes the cached handle -- refreshed
+    on the device from the flat parameter vector, in the library's canonical order -- must render exactly what a handle
+    packed on the host from the modified modules renders (every packed image: fused passes, split-bender images, heads)."""
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    rays, latents = make_rays(700, 5, cfg)
+    rays, latents = rays.to(DEV), latents.to(DEV)
+    R.set_precision(precision)
+    I = cfg.N_importance
+    with torch.no_grad():
+        m0 = R.get_model(coarse, fine if I > 0 else None, device=DEV)
+        before = m0.render(rays, latents, 64, I, retraw=True)["rgb_map"].clone()
+        for mod in (rb, coarse, fine):
+            if mod is not None:
+                for p_ in mod.parameters():
+                    p_.mul_(1.03).add_(0.001)
+        used = {"dev": 0}
+        orig = R.Model.update_from_device
+
+        def counting(self, *a, **k):
+            ok = orig(self, *a, **k)
+            used["dev"] += int(ok)
+            return ok
+
+        R.Model.update_from_device = counting
+        try:
+            m1 = R.get_model(coarse, fine if I > 0 else None, device=DEV)
+        finally:
+            R.Model.update_from_device = orig
+        after = m1.render(rays, latents, 64, I, retraw=True)
+        fresh = R.Model(coarse, fine if I > 0 else None, precision, DEV).render(rays, latents, 64, I, retraw=True)
+    torch.cuda.synchronize()
+    assert m1 is m0 and used["dev"] == 1, "the handle must be refreshed in place, on the device"
+    assert (after["rgb_map"] - before).abs().max() > 1e-4
+    for k in fresh:
+        assert torch.equal(torch.nan_to_num(after[k]), torch.nan_to_num(fresh[k])), k

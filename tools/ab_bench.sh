@@ -4,5 +4,5 @@
 cd "$(dirname "$0")/.."
 for v in "$@"; do
   NRNERF_LIB=$PWD/nonrigid_nerf_amd/lib/libnrnerf_hip$v.so timeout 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 |
-    python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('variant [$v]', d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['other_kernels_ms_per_step'])" || echo "variant [$v] FAILED"
+    python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('variant [$v]', d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['kernels_ms_per_step'])" || echo "variant [$v] FAILED"
 done

@@ -75,13 +75,15 @@ def analyse(co: str) -> dict:
 
 def check(build_dir: str) -> list[str]:
     errors = []
-    objs = sorted(glob.glob(os.path.join(build_dir, "net_*.o")))
+    objs = sorted(glob.glob(os.path.join(build_dir, "net_*.o")) + glob.glob(os.path.join(build_dir, "bend_*.o")) +
+                  glob.glob(os.path.join(build_dir, "train_*.o")))
     if not objs:
         raise FileNotFoundError(f"no net_*.o under {build_dir} (run make first)")
     with tempfile.TemporaryDirectory() as tmp:
         for obj in objs:
             co = device_code_object(obj, tmp)
-            name = os.path.basename(obj)[4:-2]
+            base = os.path.basename(obj)[:-2]
+            name = base[4:] if base.startswith("net_") else base
             if co is None:
                 errors.append(f"{name}: no gfx950 code object")
                 continue
@@ -91,7 +93,11 @@ def check(build_dir: str) -> list[str]:
                   f"smem-after-mfma {r['smem_after_first_mfma']}" + (f"  [2 blocks/wave, accvgpr {r['accvgpr']}]" if r["mb"] else ""))
             sixteen = "_f32_" not in "_" + name + "_"
             if sixteen:
-                if r["smem_after_first_mfma"]:
+                # (reported, not enforced, for the stand-alone bender -- which reads its per-block inputs with scalar loads on
+                #  purpose -- and the training kernels: a counted LDS wait is conservative with SMEM in flight, at most N
+                #  operations outstanding still means at most N LDS reads; the cost is an occasional lgkmcnt(0) the compiler
+                #  adds for the scalar result, which drains the fragment prefetch queue.  Enforced for the inference kernels.)
+                if r["smem_after_first_mfma"] and not base.startswith(("bend_", "train_")):
                     errors.append(f"{name}: {r['smem_after_first_mfma']} scalar memory load(s) after the first MFMA")
                 # (a non-zero vgpr_spill_count with no scratch segment is a VGPR parked in a free AccVGPR: no memory traffic)
                 if r["scratch"] or r.get("private_segment_fixed_size", 0):
