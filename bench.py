@@ -24,6 +24,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                        events recorded around that kernel on the render stream during the timed steps;
   "psnr_vs_oracle_db": PSNR (free_viewpoint_rendering.py:821-828) of this run's precision against the fp32 oracle
                        render of the same rays and weights (all rays, no exclusions), checker use of oracle/ only;
+  "train_step":        the reference's training iteration at its batch size (1024 rays, perturb + raw noise, forward +
+                       backward + Adam step + device-side weight refresh) through the same boundary under autograd, with its
+                       own roofline entry; not part of the timed region;
   "cpu_baseline":      the CPU oracle (a PyTorch-CPU port of the reference path, oracle/nrnerf_oracle.py) timed on this
                        box's host cores on a bounded sample of the same workload (after the GPU section).
 """
@@ -69,7 +72,8 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --rays per GPU; strong: --rays in total, sharded contiguously over the ranks "
                          "(BASELINE config 3: one frame over 8 GPUs)")
-    ap.add_argument("--train-step", action="store_true", help="additionally time the native training step (forward + backward, 1024 rays)")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the train_step leg (the native training iteration: 1024 rays forward + backward + Adam, untimed part of the run)")
     return ap.parse_args()
 
 
@@ -223,8 +227,9 @@ def main():
         with torch.no_grad():
             if not args.no_psnr:
                 extra["psnr_vs_oracle_db"] = psnr_vs_oracle(args, scene, cfg, rays, latents, api, kw, dev)
-            if args.train_step:
-                extra["train_step"] = train_step_leg(args, scene, cfg, dev)
+        if not args.no_train_step and args.precision != "f16" and not (args.use_viewdirs or args.exact_viewdirs):
+            extra["train_step"] = train_step_leg(args, scene, cfg, dev)          # needs autograd: outside the no_grad block
+        with torch.no_grad():
             gemm = library_gemm_tflops(dev, args.precision) if world == 1 else None
             # keep the device visibly busy for an external sampler (the timed region alone is < 1 s)
             extra_frames = 0
@@ -333,17 +338,23 @@ def library_gemm_tflops(dev, precision):
         return None
 
 
-def lib_sha16():
-    from nonrigid_nerf_amd import _lib
-    with open(_lib.LIB_PATH, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+def kernel_source_sha16():
+    """Hash of everything the library is built from (csrc sources, Makefile, the public header): identifies the kernels
+    independently of the build (a rebuilt .so need not be byte-identical)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "nonrigid_nerf_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip", ".cpp")) or f == "Makefile")
+    for path in files + [os.path.join(REPO, "include", "nrnerf.h")]:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(args):
     """HBM bytes per launch of the fine-pass network kernel.  Hardware counters cannot be read from inside the process:
     they come from separate ``rocprofv3 --pmc`` passes of this very command (tools/collect_profiles.sh), stored with the
-    hash of the library they profiled.  Reported only when that hash matches the library loaded now and the workload is
-    the profiled one; otherwise null (a stale number is worse than none)."""
+    hash of the kernel sources they profiled.  Reported only when that hash matches the sources of this checkout and the
+    workload is the profiled one; otherwise null (a stale number is worse than none)."""
     path = os.path.join(REPO, "profiles", "r02_pmc_fine.json")
     if args.rays != 196608 or args.precision != "bf16" or not os.path.exists(path):
         return None, "null: no rocprofv3 --pmc pass of this build and workload on file (profiles/r02_pmc_fine.json)"
@@ -352,10 +363,10 @@ def pmc_traffic(args):
             j = json.load(f)
         if j.get("scene") != args.scene:
             return None, f"null: profiles/r02_pmc_fine.json was collected on the {j.get('scene')} scene"
-        if j.get("lib_sha16") != lib_sha16():
-            return None, "null: profiles/r02_pmc_fine.json was collected from a different build of libnrnerf_hip.so"
+        if j.get("kernel_source_sha16") != kernel_source_sha16():
+            return None, "null: profiles/r02_pmc_fine.json was collected from different kernel sources"
         return float(j["fine"]["hbm_bytes_per_launch"]), ("bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from rocprofv3 --pmc passes "
-                                                          "of this build (profiles/r02_pmc_summary.txt); algorithmic 7.86e8")
+                                                          "of these kernel sources (profiles/r02_pmc_summary.txt); by design 1.21e9 (16 B/sample in + 16 B/sample out)")
     except Exception as e:
         return None, f"null: {type(e).__name__}"
 

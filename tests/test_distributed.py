@@ -125,7 +125,7 @@ def test_bench_spawns_its_own_ranks():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--rays", "8192", "--no-cpu-baseline", "--no-psnr"], env=env, capture_output=True, text=True, timeout=600)
+                        "--rays", "8192", "--no-cpu-baseline", "--no-psnr", "--no-train-step"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -6,9 +6,9 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-psnr --min-gpu-seconds 0"
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-psnr --no-train-step --min-gpu-seconds 0"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- $CMD > $OUT/stats.log 2>&1
-PMC="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-psnr --min-gpu-seconds 0"
+PMC="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-psnr --no-train-step --min-gpu-seconds 0"
 timeout 250 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmcA -o a -- $PMC > $OUT/pmcA.log 2>&1
 timeout 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcB -o b -- $PMC > $OUT/pmcB.log 2>&1
 timeout 250 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA --output-format csv -d $OUT/pmcC -o c -- $PMC > $OUT/pmcC.log 2>&1

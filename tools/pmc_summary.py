@@ -5,8 +5,8 @@ on gfx950; FETCH_SIZE / WRITE_SIZE are in KiB.
 
     python tools/pmc_summary.py gpurun_out/pmcA gpurun_out/pmcB ... > profiles/r02_pmc_summary.txt
 
-Also writes profiles/r02_pmc_fine.json (per-pass medians + the hash of the library that was profiled + the bench scene):
-bench.py reports roofline.traffic from it only while that hash matches the library it loaded.
+Also writes profiles/r02_pmc_fine.json (per-pass medians + the hash of the kernel sources that were profiled + the bench
+scene): bench.py reports roofline.traffic from it only while that hash matches the sources of the checkout it runs from.
 """
 import collections
 import csv
@@ -75,9 +75,8 @@ def main(dirs):
             tot = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
             print(f"  -> L2 hit rate                       {c['TCC_HIT_sum'] / max(tot, 1):.4f}  ({tot:.4g} requests: the weight stream is "
                   f"re-read from L2 by every workgroup pass, the rays / depths / outputs stream through once)")
-    from nonrigid_nerf_amd import _lib
-    with open(_lib.LIB_PATH, "rb") as f:
-        out["lib_sha16"] = hashlib.sha256(f.read()).hexdigest()[:16]
+    import bench
+    out["kernel_source_sha16"] = bench.kernel_source_sha16()
     out["scene"] = os.environ.get("NRNERF_PROFILE_SCENE", "fitted")
     json.dump(out, open(os.path.join(REPO, "profiles", "r02_pmc_fine.json"), "w"), indent=1)
 

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "split_bender or golden or tiny_and_ragged or surface or stochastic or full_size" > gpurun_out/c2_split_tests.log 2>&1
 tail -4 gpurun_out/c2_split_tests.log
-B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-psnr --min-gpu-seconds 0"
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-psnr --no-train-step --min-gpu-seconds 0"
 for i in 1 2; do
 NRNERF_FUSED_FINE_BENDER=1 timeout 200 $B 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('fused', d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['kernels_ms_per_step'])"
 timeout 200 $B 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('split', d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['kernels_ms_per_step'])"
