@@ -275,7 +275,9 @@ void pack_arch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass&
         else if (views) pack_pass<SH, A, false, true>(d, m, d.precision, out, lay);
         else pack_pass<SH, A, false, false>(d, m, d.precision, out, lay);
     };
-    if (d.precision == NRNERF_PREC_F32) go(ShapeF32{}); else go(Shape16{});
+    if (d.precision == NRNERF_PREC_F32) go(ShapeF32{});
+    else if (d.precision == NRNERF_PREC_BF16) go(Shape16Fast{});      // single-product bender (nrnerf_plan.h Shape::SPLIT)
+    else go(Shape16{});
 }
 
 // picks the compiled architecture (nrnerf_plan.h ArchById) the description matches; *arch_id receives its id

@@ -8,7 +8,8 @@
 // of the fine pass removes a third of that phase and lets the rest run in a kernel shaped for it:
 //   * the whole bender + rigidity weight stream (78 fragments = 78 KiB in the 16-bit modes) is RESIDENT in LDS for the
 //     lifetime of the workgroup: no ring, no DMA and no barrier inside the loop, waves are fully independent;
-//   * eight waves per CU, two per SIMD, so one wave's packing VALU overlaps the other's MFMAs.
+//   * eight waves per CU, two per SIMD, so one wave's packing VALU overlaps the other's MFMAs (sixteen / four in the
+//     "bf16" mode, whose single-product bender needs half the LDS and registers).
 // Arithmetic (MFMA order, split product, tanh, masking) is the fused kernels' own -- dense_b / Act / pack_act of
 // nrnerf_net_impl.h -- so a bent point computed here equals the fused kernel's bit for bit.
 #pragma once
@@ -240,7 +241,11 @@ static hipError_t launch_bend_one(const BendArgs& a, int num_cus, hipStream_t st
     if (nblocks >= (1ll << 31)) return hipErrorInvalidValue;
     const long long want = (nblocks + WAVES - 1) / WAVES;
     if (want <= 0) return hipSuccess;
-    const int grid = (int)(want < num_cus ? want : num_cus);        // persistent: one workgroup per CU
+    // persistent: one workgroup per CU; two for the single-product 16-bit variant (39 KiB of resident weights and < 128
+    // VGPRs per lane: sixteen waves per CU fit, four per SIMD to hide the VALU-heavy packing behind each other's MFMAs)
+    const long long per_cu = (P::KH != 1 && !P::SPLIT) ? 2 : 1;
+    const long long resident = per_cu * num_cus;
+    const int grid = (int)(want < resident ? want : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }

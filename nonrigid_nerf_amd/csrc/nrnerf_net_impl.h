@@ -89,7 +89,7 @@ __device__ __forceinline__ F8 pack16(const f32x16& c) {
 __device__ __forceinline__ float relu_bits(float x) {
     return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0));
 }
-struct PolBF16 : Shape<8> {
+struct PolBF16 : Shape<8, false> {       // bf16 trunk, single-product f16 bender (nrnerf_plan.h Shape::SPLIT)
     typedef __bf16 frag __attribute__((ext_vector_type(8)));
     static constexpr int PF = NRN_PF16;      // A-fragment software prefetch depth (4 VGPRs each)
     typedef __bf16 frag2 __attribute__((ext_vector_type(2)));
@@ -102,7 +102,7 @@ struct PolBF16 : Shape<8> {
     static __device__ __forceinline__ void set(frag& f, float v) { f[E] = (__bf16)v; }
     static __device__ __forceinline__ float round(float v) { return (float)(__bf16)v; }
 };
-struct PolF16 : Shape<8> {
+struct PolF16 : Shape<8, true> {         // f16 trunk, fp32-equivalent split-product bender
     typedef _Float16 frag __attribute__((ext_vector_type(8)));
     static constexpr int PF = NRN_PF16;
     typedef _Float16 frag2 __attribute__((ext_vector_type(2)));

@@ -39,21 +39,26 @@ constexpr NRN_HD int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 
 // Operand shape of one precision policy.  KH = k elements per lane per MFMA.
 //   bf16/f16: 32x32x16, a lane holds 8 consecutive k (KH = 8), lanes 32..63 hold k 8..15
 //   f32     : 32x32x2,  a lane holds 1 k         (KH = 1), lanes 32..63 hold k = 1
-template <int KH_>
+template <int KH_, bool SPLIT_ = (KH_ != 1)>
 struct Shape {
     static constexpr int KH = KH_;
     static constexpr int KS = 2 * KH_;             // k per MFMA
     static constexpr int SP = 16 / KH_;            // B-operand slabs produced by one 32-feature D tile
     static constexpr int ELEM_BYTES = (KH_ == 1) ? 4 : 2;
     static constexpr int FRAG_BYTES = 64 * KH_ * ELEM_BYTES;   // one A fragment: 1024 (16-bit) / 256 (f32)
-    // 16-bit modes evaluate the bender / rigidity MLPs with a 3-term split product
+    // SPLIT: the bender / rigidity MLPs are evaluated with a 3-term split product on the f16 matrix pipe
     //   W x ~= Whi xhi + 2^-11 (Whi xlo + Wlo xhi)     hi = f16(v), lo = f16((v - hi) * 2^11)
-    // which is fp32-equivalent for this purpose: the offsets feed a 2^9-frequency encoding, so plain
-    // 16-bit offsets cost 10+ dB of PSNR.  The lo parts are kept pre-scaled by
-    // 2^11 (exact) and accumulated separately: unscaled they are f16 subnormals (w*2^-12 < 6.1e-5),
-    // which the matrix pipe does not keep (measured: the Wlo term vanished).  Split layers stream two
-    // A fragments (hi, lo) per (tile, slab) and issue three MFMAs.
-    static constexpr bool SPLIT = (KH_ != 1);
+    // which is fp32-equivalent (bent-point rmse 2e-8): the offsets feed a 2^9-frequency encoding.  The lo parts are kept
+    // pre-scaled by 2^11 (exact) and accumulated separately: unscaled they are f16 subnormals (w*2^-12 < 6.1e-5), which
+    // the matrix pipe does not keep (measured: the Wlo term vanished).  Split layers stream two A fragments (hi, lo) per
+    // (tile, slab) and issue three MFMAs, and packing every activation into hi + lo is VALU-heavy (8.8 VALU per MFMA in
+    // the stand-alone bender kernel).  The precision ladder of the library:
+    //   "f32"   exact fp32 everywhere;
+    //   "f16"   f16 trunk + SPLIT bender: the accurate 16-bit mode (74 dB vs the fp32 render on the fitted model);
+    //   "bf16"  bf16 trunk + SINGLE-product f16 bender (SPLIT = false): a third of the bender's MFMAs and less than half
+    //           of its VALU work; measured cost on the fitted model: the bender's own error floor is 71-74 dB, below the
+    //           bf16 trunk's 66 dB (tools/experiments/bender_precision_probe.py; with 5x larger offsets 60-67 dB).
+    static constexpr bool SPLIT = SPLIT_;
     static constexpr float LO_SCALE = 2048.0f;
     static constexpr int UNIT_BYTES = NRN_UNIT_BYTES;             // staging granularity of the LDS ring
     static constexpr int UNIT_FRAGS = UNIT_BYTES / FRAG_BYTES;    // 16 (16-bit) / 64 (f32) fragments per unit
@@ -401,6 +406,7 @@ template <int ID> struct ArchById { using type = ArchDefault; };
 template <> struct ArchById<1> { using type = ArchDeepBend; };
 template <> struct ArchById<2> { using type = ArchTimeCond; };
 using ShapeF32 = Shape<1>;
-using Shape16 = Shape<8>;
+using Shape16 = Shape<8, true>;        // "f16" mode: split-product bender
+using Shape16Fast = Shape<8, false>;   // "bf16" mode: single-product f16 bender
 
 }  // namespace nrn

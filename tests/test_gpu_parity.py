@@ -131,8 +131,13 @@ def _last_sample_flips(raw_got, raw_ref):
     return (raw_got[:, -1, 3] > 0) != (raw_ref[:, -1, 3] > 0)
 
 
-# thresholds: (network-output SNR dB, PSNR dB over rays whose background decision did not flip, max flipped fraction)
-PRECISION_BARS = {"bf16": (34.0, 40.0, 0.02), "f16": (50.0, 52.0, 0.004)}
+# thresholds on the synthetic STRESS scene (regression guards at the measured level, not the acceptance bar -- that is
+# enforced on the fitted checkpoint, tests/test_fitted_checkpoint.py): (network-output SNR dB, PSNR dB over rays whose
+# background decision did not flip, max flipped fraction).  "bf16" is the fastest mode (bf16 trunk, single-product f16
+# bender); "f16" the accurate 16-bit mode (f16 trunk, fp32-equivalent split-product bender).  The stress scene's
+# deformation field is violent (last bender layer ~ N(0, 0.15^2): offsets up to 0.3 of the scene) and its density random,
+# which is what makes the single-product bender visible here (-4 dB) and invisible on a fitted model.
+PRECISION_BARS = {"bf16": (32.0, 40.0, 0.02), "f16": (50.0, 52.0, 0.004)}
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
@@ -177,8 +182,13 @@ def test_16bit_modes_psnr_full_pipeline(precision):
     ref = O.batchify_rays(rays, latents, scene, chunk=1024, retraw=True, detailed_output=True)
     got = hip_render(scene, rays, latents, precision, retraw=True, detailed=True)
     rms = lambda k: float((got[k] - ref[k]).pow(2).mean().sqrt())
-    # the deformation is evaluated with the fp32-equivalent split product: bent points agree to fp32 rounding
-    assert rms("input_pts") < 2e-6 and rms("unmasked_offsets") < 2e-6 and rms("rigidity_mask") < 2e-5
+    # "f16": the deformation is evaluated with the fp32-equivalent split product, bent points agree to fp32 rounding;
+    # "bf16": single f16 product, relative error ~1e-3 of the offsets
+    print(f"[{precision}] rmse bent pts {rms('input_pts'):.2e}, offsets {rms('unmasked_offsets'):.2e}, rigidity {rms('rigidity_mask'):.2e}")
+    if precision == "f16":
+        assert rms("input_pts") < 2e-6 and rms("unmasked_offsets") < 2e-6 and rms("rigidity_mask") < 2e-5
+    else:
+        assert rms("input_pts") < 1e-4 and rms("unmasked_offsets") < 2e-4 and rms("rigidity_mask") < 2e-3
     flips = _last_sample_flips(got["raw"], ref["raw"])      # last merged depth is always `far`: same point in both
     keep = ~flips
     p_all, p_keep = psnr(got["rgb_map"], ref["rgb_map"]), psnr(got["rgb_map"][keep], ref["rgb_map"][keep])
@@ -189,8 +199,8 @@ def test_16bit_modes_psnr_full_pipeline(precision):
     assert flips.float().mean().item() <= flip_bar
     # rays whose COARSE last sample flipped are still in `keep` (the coarse raw is not an output when I > 0); they get
     # differently placed fine samples, which costs a few dB here relative to the coarse-only test
-    assert p_keep >= {"bf16": 38.0, "f16": 44.0}[precision], p_keep
-    assert p_all >= 30.0, p_all                    # regression guard on the raw number
+    assert p_keep >= {"bf16": 36.0, "f16": 44.0}[precision], p_keep
+    assert p_all >= 32.0, p_all                    # regression guard on the raw number
 
 
 def test_fp32_mode_vs_oracle_4k_rays():
@@ -208,15 +218,20 @@ def test_fp32_mode_vs_oracle_4k_rays():
 
 
 def test_split_bender_path_at_full_chunk_size_equals_the_fused_pass():
-    """One reference chunk (32 768 rays, 64+128, bf16): the split-bender path a plain render takes against the fused fine
-    pass a detailed render takes -- every common output bit-identical at BASELINE config 2's size as well."""
+    """One reference chunk (32 768 rays, 64+128): the split-bender path a plain render takes against the fused fine pass a
+    detailed render takes -- every common output bit-identical at BASELINE config 2's size as well (f16 mode; bf16 mode
+    up to the conversion ties described in _assert_split_equals_fused_up_to_conversion_ties)."""
     cfg = SceneConfig()
     scene = make_scene(cfg, 0)
     rays, latents = make_rays(32768, 3, cfg)
-    a = hip_render(scene, rays, latents, "bf16", retraw=True)                    # split-bender path
-    b = hip_render(scene, rays, latents, "bf16", retraw=True, detailed=True)     # fused fine pass
+    a = hip_render(scene, rays, latents, "f16", retraw=True)                     # split-bender path
+    b = hip_render(scene, rays, latents, "f16", retraw=True, detailed=True)      # fused fine pass
     for k in a:
         assert torch.equal(torch.nan_to_num(a[k]), torch.nan_to_num(b[k])), k
+    a = hip_render(scene, rays, latents, "bf16", retraw=True)
+    b = hip_render(scene, rays, latents, "bf16", retraw=True, detailed=True)
+    assert torch.equal(a["rgb0"], b["rgb0"]) and torch.equal(a["_z_vals"], b["_z_vals"])
+    assert (a["raw"] != b["raw"]).any(-1).float().mean().item() < 5e-4 and (a["rgb_map"] - b["rgb_map"]).abs().max().item() < 2e-3
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
@@ -231,12 +246,15 @@ def test_full_size_properties(precision):
     rb, coarse, fine = build_modules(scene, device=DEV)
     R.set_precision(precision)
     model = R.get_model(coarse, fine)
-    parts = [model.render(rays[i:i + 5000].to(DEV), latents[i:i + 5000].to(DEV), 64, 128, want_z_vals=True)
-             for i in range(0, n, 5000)]
-    torch.cuda.synchronize()
-    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std", "_z_vals"):
-        cat = torch.cat([p[k] for p in parts], 0).cpu()
-        assert torch.equal(torch.nan_to_num(cat), torch.nan_to_num(a[k])), f"{k} depends on the launch split"
+    # (detailed renders take the fused fine pass, plain ones the split-bender path: each compared with its own kind)
+    whole_plain = hip_render(scene, rays, latents, precision)
+    for detailed, whole in ((True, a), (False, whole_plain)):
+        parts = [model.render(rays[i:i + 5000].to(DEV), latents[i:i + 5000].to(DEV), 64, 128, want_z_vals=True, detailed_output=detailed)
+                 for i in range(0, n, 5000)]
+        torch.cuda.synchronize()
+        for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std", "_z_vals"):
+            cat = torch.cat([p[k] for p in parts], 0).cpu()
+            assert torch.equal(torch.nan_to_num(cat), torch.nan_to_num(whole[k])), f"{k} depends on the launch split (detailed={detailed})"
     # compositing identities
     w = a["fine_visibility_weights"]
     assert torch.allclose(w.sum(-1), a["acc_map"], atol=2e-5)
@@ -789,11 +807,33 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
     torch.cuda.synchronize()
     split, fused = outs
     assert "fine_input_pts" in fused and "fine_input_pts" not in split
+    if precision == "bf16":
+        _assert_split_equals_fused_up_to_conversion_ties(split, fused)
+        return
     for k in split:
         assert torch.equal(torch.nan_to_num(split[k].float()), torch.nan_to_num(fused[k].float())), k
     # and the carried-over / separately bent points are the fused kernel's: the surface point is one of them
     idx = split["median_index"].long()
     assert torch.equal(split["surface_pts"], fused["fine_input_pts"][torch.arange(3001, device=DEV), idx])
+
+
+def _assert_split_equals_fused_up_to_conversion_ties(split, fused):
+    """bf16 mode (single-product f16 bender): the stand-alone bender kernel and the fused kernel are the same arithmetic,
+    but hipcc pairs the f32 -> f16 conversions of the first-layer inputs differently in the two kernels
+    (v_cvt_pk_f16_f32 vs v_cvt_f16_f32), and the two instructions disagree on rare inputs -- measured: 21 of 384 126 new
+    samples (5e-5, the rate of round-to-nearest ties) get a bent point that differs by <= 5e-6 (tools/debug_split_vs_fused.py).
+    Everything that does not pass through a new sample's bender is still bit-identical."""
+    for k in ("rgb0", "disp0", "acc0", "z_std", "_z_vals"):
+        assert torch.equal(torch.nan_to_num(split[k]), torch.nan_to_num(fused[k])), k
+    differs = (split["raw"] != fused["raw"]).any(-1)
+    assert differs.float().mean().item() < 5e-4, differs.float().mean().item()
+    assert (split["rgb_map"] - fused["rgb_map"]).abs().max().item() < 2e-3
+    assert (split["rgb_map"] != fused["rgb_map"]).any(-1).float().mean().item() < 0.05
+    same_idx = split["median_index"] == fused["median_index"]
+    assert same_idx.float().mean().item() > 0.99
+    n = split["surface_pts"].shape[0]
+    ref = fused["fine_input_pts"][torch.arange(n, device=split["surface_pts"].device), split["median_index"].long()]
+    assert (split["surface_pts"] - ref).abs().max().item() < 1e-4
 
 
 @pytest.mark.parametrize("cfg_kw", [dict(N_importance=64, use_viewdirs=True), dict(N_importance=64, bend_depth=7),

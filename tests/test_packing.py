@@ -185,8 +185,8 @@ def test_packed_stream_reproduces_the_network(precision, bend, views, tcb):
     KH = 1 if precision == "f32" else 8
     SP = 16 // KH
     rnd = rounder(precision)
-    split = precision != "f32"                 # bender layers use the 3-term split product in 16-bit modes
-    rnd_b = (lambda x: x)                      # hi + lo carries ~22 bits: emulate as exact
+    split = precision == "f16"                 # "f16" mode: 3-term split product in the bender; "bf16": single f16 product
+    rnd_b = (lambda x: x) if precision != "bf16" else rounder("f16")   # hi + lo carries ~22 bits: emulate as exact
     rnd_e = rounder("f16") if split else rnd   # encoding slabs are f16 in both 16-bit modes
     fr = FragReader(stream, precision, info.frag_bytes)
     gen = torch.Generator().manual_seed(5)
@@ -231,7 +231,7 @@ def test_packed_stream_reproduces_the_network(precision, bend, views, tcb):
                 r = F.linear(r, l.weight.double(), l.bias.double())
                 if i != len(rb.rigidity_network) - 1:
                     r = F.relu(r)
-        tol = 1e-9 if precision == "f32" else 2e-6     # split product: weights carry hi + lo (~22 bits)
+        tol = {"f32": 1e-9, "f16": 2e-6, "bf16": 4e-3}[precision]     # split product: hi + lo (~22 bits); single f16 product
         scale = float(h.abs().max())
         assert np.abs(off.T - h.numpy()).max() <= tol * max(scale, 1e-3) + 1e-12, "bender offsets"
         assert np.abs(logit - r.numpy()[:, 0]).max() <= tol * max(float(r.abs().max()), 1.0), "rigidity logit"
@@ -312,10 +312,11 @@ def test_unsupported_architectures_are_rejected():
     # the deeper-bender architecture of BASELINE config 4 IS compiled (arch id 1)
     scene = make_scene(SceneConfig(bend_depth=7, use_viewdirs=True), 0)
     rb, coarse, fine = build_modules(scene)
-    desc, keep = build_model_desc(coarse, fine, "bf16", 0)
-    info = _lib.PackedInfo()
-    assert lib.nrnerf_pack_host(C.byref(desc), 1, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == 0
-    assert info.mfma_per_block == 976 - 16 + 16 + 128 + 72 + 8 + 3 * (6 + 5 * 8 + 4) + 15
+    for prec, bender_mfmas in (("f16", 3 * (6 + 5 * 8 + 4) + 15), ("bf16", (6 + 5 * 8 + 4) + 5)):     # split product: 3 MFMAs per slab
+        desc, keep = build_model_desc(coarse, fine, prec, 0)
+        info = _lib.PackedInfo()
+        assert lib.nrnerf_pack_host(C.byref(desc), 1, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == 0
+        assert info.mfma_per_block == 976 - 16 + 16 + 128 + 72 + 8 + bender_mfmas, prec
     bad = _lib.ModelDesc()
     assert lib.nrnerf_pack_host(C.byref(bad), 0, None, None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_INVALID
     out = C.c_void_p()
@@ -339,8 +340,8 @@ def test_split_bender_images_are_the_two_halves_of_the_fused_stream(precision, b
     assert nb_tiles + info_t.n_bias_tiles == info_f.n_bias_tiles
     assert np.array_equal(bias_f[:nb_tiles * 32], bias_b) and np.array_equal(bias_f[nb_tiles * 32:], bias_t)
     assert info_b.mfma_per_block + info_t.mfma_per_block == info_f.mfma_per_block
-    # fragment counts: bender layers stream 2 fragments per 3 MFMAs in the split-product (16-bit) modes
-    nfrag_b = info_b.mfma_per_block * 2 // 3 if precision != "f32" else info_b.mfma_per_block
+    # fragment counts: bender layers stream 2 fragments per 3 MFMAs in the split-product ("f16") mode
+    nfrag_b = info_b.mfma_per_block * 2 // 3 if precision == "f16" else info_b.mfma_per_block
     nfrag_t = info_t.mfma_per_block
     assert np.array_equal(stream_f[:nfrag_b * fb], stream_b[:nfrag_b * fb]) and not stream_b[nfrag_b * fb:].any()
     assert np.array_equal(stream_f[nfrag_b * fb:(nfrag_b + nfrag_t) * fb], stream_t[:nfrag_t * fb]) and not stream_t[nfrag_t * fb:].any()

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""GPU box: where do the split-bender path and the fused fine pass differ (bf16)?"""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from nonrigid_nerf_amd import render as R  # noqa: E402
+from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene  # noqa: E402
+
+DEV = "cuda:0"
+cfg = SceneConfig()
+scene = make_scene(cfg, 2)
+rays, latents = make_rays(3001, 23, cfg)
+rb, coarse, fine = build_modules(scene, device=DEV)
+for prec in ("bf16", "f16"):
+    R.set_precision(prec)
+    model = R.get_model(coarse, fine)
+    r, l = rays.to(DEV), latents.to(DEV)
+    with torch.no_grad():
+        split = model.render(r, l, 64, 128, retraw=True, want_z_vals=True, surface=True)
+        fused = model.render(r, l, 64, 128, retraw=True, detailed_output=True, want_z_vals=True, surface=True)
+    torch.cuda.synchronize()
+    idx = split["median_index"].long()
+    ar = torch.arange(3001, device=DEV)
+    same_idx = (split["median_index"] == fused["median_index"]).float().mean().item()
+    d_pts = (split["surface_pts"] - fused["fine_input_pts"][ar, idx]).abs().max(-1)[0]
+    z = split["_z_vals"]
+    t = torch.linspace(0, 1, 64, device=DEV)
+    zc = cfg.near * (1 - t) + cfg.far * t
+    is_coarse = torch.isclose(z[ar, idx][:, None], zc[None, :], atol=1e-7, rtol=0).any(1)
+    print(f"[{prec}] z equal {torch.equal(split['_z_vals'], fused['_z_vals'])}; rgb0 equal {torch.equal(split['rgb0'], fused['rgb0'])}; "
+          f"median idx equal on {same_idx:.4f}; bent point at the median sample: max |diff| {float(d_pts.max()):.3e}, "
+          f"differing rays {int((d_pts > 0).sum())} (of which the sample is a coarse depth: {int(((d_pts > 0) & is_coarse).sum())}, new: {int(((d_pts > 0) & ~is_coarse).sum())}); "
+          f"raw max |diff| {float((split['raw'] - fused['raw']).abs().max()):.3e}; rgb_map max |diff| {float((split['rgb_map'] - fused['rgb_map']).abs().max()):.3e}")
+    dr = (split["raw"] - fused["raw"]).abs().amax(-1)          # [N, 192]
+    bad = dr > 0
+    isc = torch.isclose(z[:, :, None], zc[None, None, :], atol=1e-7, rtol=0).any(-1)
+    print(f"      samples whose raw differs: {int(bad.sum())} of {bad.numel()}; among coarse-depth samples {int((bad & isc).sum())} of {int(isc.sum())}, among new samples {int((bad & ~isc).sum())} of {int((~isc).sum())}")
+
+# ---- bent points of the split path, read straight out of the workspace (layout of nrnerf_render: raw_c | z_fine | raw_f | bent4 ...)
+def align(v, a=256):
+    return (v + a - 1) // a * a
+
+R.set_precision("bf16")
+model = R.get_model(coarse, fine)
+N, S, SF = 3001, 64, 192
+with torch.no_grad():
+    split = model.render(r, l, 64, 128, retraw=True, want_z_vals=True)
+    torch.cuda.synchronize()
+    ws = list(model._ws.values())[0]
+    base = (ws.data_ptr() + 255) // 256 * 256 - ws.data_ptr()
+    off = base + align(N * S * 16) + align(N * SF * 4) + align(N * SF * 16)
+    bent4 = ws[off:off + N * SF * 16].view(torch.float32).view(N, SF, 4).clone()
+    fused = model.render(r, l, 64, 128, retraw=True, detailed_output=True, want_z_vals=True)
+    torch.cuda.synchronize()
+dp = (bent4[..., :3] - fused["fine_input_pts"]).abs().amax(-1)
+dm = (bent4[..., 3] - fused["fine_rigidity_mask"][..., 0]).abs()
+print(f"bent points differing: {int((dp > 0).sum())} samples, max |diff| {float(dp.max()):.3e}; rigidity differing {int((dm > 0).sum())}, max {float(dm.max()):.3e}")
+bad = (dp > 0).nonzero()[:6]
+for n_, s_ in bad.tolist():
+    print(f"   ray {n_} sample {s_} (lane {s_ % 32}): split {bent4[n_, s_].tolist()}  fused {fused['fine_input_pts'][n_, s_].tolist()} {float(fused['fine_rigidity_mask'][n_, s_, 0])} "
+          f"unbent {fused['fine_initial_input_pts'][n_, s_].tolist()} off {fused['fine_unmasked_offsets'][n_, s_].tolist()}")
