@@ -339,14 +339,13 @@ def library_gemm_tflops(dev, precision):
 
 
 def kernel_source_sha16():
-    """Hash of everything the library is built from (csrc sources, Makefile, the public header): identifies the kernels
-    independently of the build (a rebuilt .so need not be byte-identical)."""
+    """Hash of the device code the library is built from (csrc/*.h, *.hip: plans, kernels, launchers): identifies the
+    kernels independently of the build (a rebuilt .so need not be byte-identical) and of host-only edits (nrnerf_api.cpp)."""
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "nonrigid_nerf_amd", "csrc")
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip", ".cpp")) or f == "Makefile")
-    for path in files + [os.path.join(REPO, "include", "nrnerf.h")]:
-        with open(path, "rb") as f:
-            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hip"))):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 

@@ -705,7 +705,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                o.input_pts || o.rigidity_mask;
     };
     static const bool force_fused = [] { const char* e = std::getenv("NRNERF_FUSED_FINE_BENDER"); return e && e[0] == '1'; }();
-    const bool split = m->split_ok && I > 0 && !a->detailed_output && !any_detail(a->coarse) && !any_detail(a->fine) && !force_fused;
+    // (the stand-alone bender kernel indexes its 32-sample blocks with 32 bits: beyond 2^31 blocks stay on the fused kernels)
+    const bool split = m->split_ok && I > 0 && !a->detailed_output && !any_detail(a->coarse) && !any_detail(a->fine) && !force_fused &&
+                       (long long)N * ((imax(S, I) + 31) / 32) < (1ll << 31);
     float* bent_c = nullptr; float* z_new = nullptr; uint8_t* rank_new = nullptr;
     if (I > 0) {
         bent_c = (float*)ws; ws += align_up((size_t)N * S * 4 * sizeof(float), 256);

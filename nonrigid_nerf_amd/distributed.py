@@ -70,8 +70,9 @@ class OverlappedGather:
     and joined the same way.
     """
 
-    def __init__(self, rows_per_rank: int, device, group=None):
+    def __init__(self, rows_per_rank: int, device, group=None, force_collective: bool = False):
         self.group = group
+        self.force_collective = force_collective      # run the collective even in a one-rank group (1-GPU test of the RCCL path)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -90,7 +91,7 @@ class OverlappedGather:
         buf[:, 0:3] = out["rgb_map"]
         buf[:, 3] = out["disp_map"]
         buf[:, 4] = out["acc_map"]
-        if self.world == 1:
+        if self.world == 1 and not (self.force_collective and dist.is_initialized()):
             self.full[b].copy_(buf)
             return self.full[b]
         if self.cuda:
@@ -109,5 +110,5 @@ class OverlappedGather:
             if self.pending[b] is not None:
                 self.pending[b].wait()
                 self.pending[b] = None
-        if self.cuda and self.world > 1:
+        if self.cuda and (self.world > 1 or self.force_collective):
             torch.cuda.current_stream(self.device).wait_stream(self.side)

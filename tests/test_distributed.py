@@ -94,7 +94,19 @@ def _rccl_worker(port, out_path):
     dist.barrier()
     want = torch.cat([direct["rgb_map"], direct["disp_map"][:, None], direct["acc_map"][:, None]], -1)
     ok = torch.equal(torch.nan_to_num(img), torch.nan_to_num(want))
-    torch.save({"ok": ok, "backend": dist.get_backend()}, out_path)
+    # the overlapped form bench.py uses: asynchronous all_gather_into_tensor over RCCL from a side stream, two buffer pairs
+    from nonrigid_nerf_amd.distributed import OverlappedGather
+    g = OverlappedGather(1000, torch.device("cuda", 0), force_collective=True)
+    frames = []
+    with torch.no_grad():
+        for i in range(4):
+            out = render_fn(rays + 0.001 * i, lat)
+            full = g.submit(i, out)
+            frames.append((full, torch.cat([out["rgb_map"], out["disp_map"][:, None], out["acc_map"][:, None]], -1).clone()))
+        g.drain()       # (a buffer pair is reused two frames later: after the loop the pairs hold frames 2 and 3)
+    torch.cuda.synchronize()
+    ok_overlap = all(torch.equal(torch.nan_to_num(frames[i][0]), torch.nan_to_num(frames[i][1])) for i in (2, 3))   # the two live pairs
+    torch.save({"ok": ok, "ok_overlap": ok_overlap, "backend": dist.get_backend()}, out_path)
     dist.destroy_process_group()
 
 
@@ -109,7 +121,7 @@ def test_rccl_path_with_one_rank_on_the_gpu(tmp_path):
     p.join(300)
     assert p.exitcode == 0
     res = torch.load(out)
-    assert res["ok"] and res["backend"] == "nccl"
+    assert res["ok"] and res["ok_overlap"] and res["backend"] == "nccl"
 
 
 @pytest.mark.gpu
