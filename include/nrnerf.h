@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NRNERF_ABI_VERSION 3
+#define NRNERF_ABI_VERSION 4
 
 typedef enum nrnerf_status {
     NRNERF_OK = 0,
@@ -228,8 +228,8 @@ int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_p
  * The reference trains through autograd (training_wrapper_class.forward, train.py:152-287; backward + optimiser step,
  * train.py:1594-1610).  These entry points are the pieces a torch.autograd.Function needs (nonrigid_nerf_amd/training.py
  * is the binding): the canonical network's trunk forward with saved activations and its backward-data pass, and the
- * compositing forward / backward.  The deformation MLPs stay with the caller's autograd (their regularisers need double
- * backward, run_nerf_helpers.py:22-116): the trunk takes ready-made (bent) points and returns the gradient wrt them.
+ * compositing forward / backward, and the ray bender's forward / backward (nrnerf_bender_*, below).  The trunk takes
+ * ready-made (bent) points and returns the gradient wrt them.
  * Weight gradients are plain GEMMs over two arrays these calls fill: dW_i = d_pre[i]^T x_i with x_0 = encoding,
  * x_i = acts[i-1] (x_{skip+1} = [encoding, acts[skip]]), db_i = column sums of d_pre[i]; d W_out = d_raw^T acts[D-1].
  * Available (else NRNERF_ERR_UNSUPPORTED) for the default architecture without view-dependent head, fp32 or bf16. */
@@ -251,6 +251,42 @@ typedef struct nrnerf_trunk_args {
 } nrnerf_trunk_args;
 int nrnerf_trunk_forward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);
 int nrnerf_trunk_backward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);
+
+/* ray_bending.forward (run_nerf_helpers.py:507-577) under autograd, for a model with a bender: the sample points
+ * p = origin + direction * z of n_rays x n_samples samples go through the offset and rigidity MLPs in exact fp32 (whatever
+ * the model's precision).  Differentiable outputs: the bent point p + mask * offsets (* scaling), the unmasked offsets and
+ * the rigidity mask; the masked offsets are mask * offsets (* scaling) of those.  Inputs that receive a gradient: the
+ * latent codes (d_latents holds one row per SAMPLE; the caller sums the n_samples rows of a ray) and the layers' weights:
+ *   offset MLP       dW_i = dz_i^T x_i,  x_0 = [p, latent], x_i = acts_offsets[i-1], dz_i = dz_offsets[i] for the hidden
+ *                    layers and dz_out4[:, 0:3] for the last one (which has no bias); db_i = column sums of dz_i;
+ *   rigidity MLP     likewise with x_0 = p, acts_rigidity, dz_rigidity and dz_out4[:, 3].
+ * The sample positions carry no gradient (the reference detaches z_samples; rays are data).  First order only: the
+ * divergence regulariser differentiates the reference module's own forward a second time (run_nerf_helpers.py:41-58) and
+ * never passes through here.  NRNERF_ERR_UNSUPPORTED unless the trunk entry points are available and the model has a bender. */
+typedef struct nrnerf_bender_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_bender_args) */
+    int32_t n_rays, n_samples;  /* M = n_rays * n_samples, sample-major per ray */
+    const float* rays; int32_t ray_stride;          /* [N, ray_stride >= 6]: origin3, direction3 */
+    const float* latents; int32_t latent_stride;    /* [N, latent_stride >= latent_size] */
+    const float* z;             /* [N, n_samples] sample depths */
+    int32_t has_rigidity_cutoff;   float rigidity_cutoff;     /* as nrnerf_render_args */
+    int32_t has_test_time_scaling; float test_time_scaling;
+    /* forward writes, backward reads */
+    float* bent4;               /* [M,4] bent point + rigidity mask (what nrnerf_trunk_args.pts4 takes; w ignored there) */
+    float* off4;                /* [M,4] unmasked offsets + tanh of the rigidity logit */
+    float* acts_offsets;        /* [bender depth - 1][M][bender hidden] */
+    float* acts_rigidity;       /* [rigidity depth - 1][M][rigidity hidden] */
+    /* backward */
+    const float* g_bent4;       /* [M,4] gradient wrt the bent point (w ignored) */
+    const float* g_unmasked_offsets;   /* [M,3] or NULL */
+    const float* g_rigidity_mask;      /* [M] or NULL */
+    float* dz_offsets;          /* out, shape of acts_offsets: gradient wrt the hidden pre-activations */
+    float* dz_rigidity;         /* out, shape of acts_rigidity */
+    float* dz_out4;             /* out [M,4] gradient wrt the offsets (xyz) and the rigidity logit (w) */
+    float* d_latents;           /* out [M, latent_size] gradient wrt each sample's latent inputs */
+} nrnerf_bender_args;
+int nrnerf_bender_forward(const nrnerf_model* model, const nrnerf_bender_args* args, void* hip_stream);
+int nrnerf_bender_backward(const nrnerf_model* model, const nrnerf_bender_args* args, void* hip_stream);
 
 /* raw2outputs (train.py:724-789) of one pass, optionally followed by sample_pdf + merge (run_nerf_helpers.py:651-698,
  * train.py:910-920), and its backward.  Runs on the device that owns raw4. */
@@ -281,7 +317,8 @@ int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchroni
 /* Host-only packing (no device needed): writes the MFMA-fragment weight stream + unit table + bias
  * table of one pass exactly as nrnerf_model_create uploads them.  which: 0 = coarse, 1 = fine, 2 = fine without the
  * bender layers, 3 = bender + rigidity layers alone (2, 3: the split-bender path; need a bender and no view-dependent head),
- * 4 / 5 = transposed trunk weights of the coarse / fine network for the backward-data kernel (training).
+ * 4 / 5 = transposed trunk weights of the coarse / fine network for the backward-data kernel (training),
+ * 6 = transposed bender + rigidity weights for nrnerf_bender_backward (always fp32).
  * Any output pointer may be NULL to query sizes only.  Used by the CPU-side packing tests. */
 typedef struct nrnerf_packed_info {
     uint64_t stream_bytes;     /* fragment stream */

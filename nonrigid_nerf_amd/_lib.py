@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRNERF_LIB selects an alternative build of the same library (tuning experiments, see csrc/Makefile)
 LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
 NUM_KERNELS = 6
@@ -92,6 +92,18 @@ class TrunkArgs(C.Structure):
                 ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p)]
 
 
+class BenderArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+                ("rays", C.c_void_p), ("ray_stride", C.c_int32),
+                ("latents", C.c_void_p), ("latent_stride", C.c_int32),
+                ("z", C.c_void_p),
+                ("has_rigidity_cutoff", C.c_int32), ("rigidity_cutoff", C.c_float),
+                ("has_test_time_scaling", C.c_int32), ("test_time_scaling", C.c_float),
+                ("bent4", C.c_void_p), ("off4", C.c_void_p), ("acts_offsets", C.c_void_p), ("acts_rigidity", C.c_void_p),
+                ("g_bent4", C.c_void_p), ("g_unmasked_offsets", C.c_void_p), ("g_rigidity_mask", C.c_void_p),
+                ("dz_offsets", C.c_void_p), ("dz_rigidity", C.c_void_p), ("dz_out4", C.c_void_p), ("d_latents", C.c_void_p)]
+
+
 class CompositeArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("n_importance", C.c_int32),
                 ("rays", C.c_void_p), ("ray_stride", C.c_int32),
@@ -116,6 +128,8 @@ EXPORTS = {
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "nrnerf_trunk_forward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
     "nrnerf_trunk_backward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
+    "nrnerf_bender_forward": (C.c_int, [C.c_void_p, C.POINTER(BenderArgs), C.c_void_p]),
+    "nrnerf_bender_backward": (C.c_int, [C.c_void_p, C.POINTER(BenderArgs), C.c_void_p]),
     "nrnerf_composite_forward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),
     "nrnerf_composite_backward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),
     "nrnerf_profile_begin": (C.c_int, [C.c_void_p]),

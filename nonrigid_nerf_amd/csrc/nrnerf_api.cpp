@@ -215,6 +215,52 @@ void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
     if (written != (size_t)T.nfrags) std::abort();
 }
 
+// Transposed weights of the bender / rigidity MLPs for their backward-data kernel (nrnerf_train_bend.h): PlanBB's layer
+// list, always fp32.  Same element rule as pack_pass_bwd.
+template <class A>
+void pack_pass_bwd_bender(const nrnerf_bender_desc& b, PackedPass& out, const FlatLayout* lay = nullptr) {
+    using SH = ShapeF32;
+    using PL = PlanBB<SH, A>;
+    const Tables& T = PL::TB;
+    out.ntiles = T.ntiles; out.nunits = T.nunits_padded;
+    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES; out.mfma_per_block = T.mfma_per_block;
+    out.stream.assign((size_t)T.nunits_padded * SH::UNIT_BYTES, 0);
+    out.unit_off.assign(T.nunits_padded + 1, 0);
+    for (int u = 0; u <= T.nunits_padded; ++u) out.unit_off[u] = (uint32_t)((size_t)u * SH::UNIT_BYTES / 16);
+    out.bias.assign((size_t)T.ntiles * 32, 0.0f);
+    if (lay) {
+        out.src.assign(out.stream.size() / SH::ELEM_BYTES, -1);
+        out.fmt.assign(out.stream.size() / SH::ELEM_BYTES, 0);
+        out.bias_src.assign(out.bias.size(), -1);
+    }
+    size_t written = 0;
+    for (int l = 0; l < T.nlayers; ++l) {
+        const LayerSpec& sp = T.layers[l];
+        const bool rig = sp.kind == LK_BR_OUT || sp.kind == LK_BR_HID;
+        const nrnerf_linear* lin = rig ? &b.rigidity_network[sp.index] : &b.network[sp.index];
+        const int64_t wbase = lay ? lay->of(lin->weight) : -1;
+        for (int t = 0; t < sp.nt; ++t) {
+            const TileInfo& ti = T.tiles[sp.tile0 + t];
+            for (int s = 0; s < sp.ns; ++s) {
+                const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride;
+                if (fi >= (size_t)T.nfrags) std::abort();
+                uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    const int x = bwd_x<SH, A>(sp.kind, t, i, lin->in_features);
+                    const int y = bwd_y<SH, A>(sp.kind, s, h, 0, lin->out_features);
+                    const float w = (x < 0 || y < 0) ? 0.0f : lin->weight[(size_t)y * lin->in_features + x];
+                    if (lay && x >= 0 && y >= 0 && wbase >= 0)
+                        out.src[fi * (SH::FRAG_BYTES / SH::ELEM_BYTES) + (size_t)lane] = (int32_t)(wbase + (int64_t)y * lin->in_features + x);
+                    std::memcpy(fr + lane * 4, &w, 4);
+                }
+                ++written;
+            }
+        }
+    }
+    if (written != (size_t)T.nfrags) std::abort();
+}
+
 bool linear_is(const nrnerf_linear& l, int out_f, int in_f, bool need_bias) {
     return l.weight && l.out_features == out_f && l.in_features == in_f && (!need_bias || l.bias);
 }
@@ -368,6 +414,10 @@ struct nrnerf_model {
     // view-dependent head / time conditioning, fp32 or bf16
     PassDev coarse_bwd, fine_bwd;
     bool train_ok = false;
+    // training of the ray bender (nrnerf_train_bend.h): its layers alone in fp32 (whatever the model's precision) and
+    // their transposes; bend_train_ok: train_ok and a bender
+    PassDev bend_train_fwd, bend_train_bwd;
+    bool bend_train_ok = false;
     int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
     mutable std::mutex prof_mu;
@@ -450,6 +500,22 @@ int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t ref
     m->coarse_bwd.mfma_flops_per_sample = bc.mfma_per_block * mfma_flop / 32.0;
     m->fine_bwd.mfma_flops_per_sample = (d.fine ? bf.mfma_per_block : bc.mfma_per_block) * mfma_flop / 32.0;
     m->train_ok = (rc == NRNERF_OK);
+    if (rc == NRNERF_OK && d.bender) {
+        PackedPass bfw, bbw;
+        nrnerf_model_desc d32 = d;
+        d32.precision = NRNERF_PREC_F32;
+        if (m->arch_id == 0) {
+            pack_pass<ShapeF32, ArchDefault, true, false, false>(d32, *d.coarse, NRNERF_PREC_F32, bfw, lay);
+            pack_pass_bwd_bender<ArchDefault>(*d.bender, bbw, lay);
+        } else {
+            pack_pass<ShapeF32, ArchDeepBend, true, false, false>(d32, *d.coarse, NRNERF_PREC_F32, bfw, lay);
+            pack_pass_bwd_bender<ArchDeepBend>(*d.bender, bbw, lay);
+        }
+        rc = refresh ? refresh_pass(bfw, m->bend_train_fwd, refresh_stream) : upload_pass(bfw, m->bend_train_fwd);
+        if (rc == NRNERF_OK) rc = refresh ? refresh_pass(bbw, m->bend_train_bwd, refresh_stream) : upload_pass(bbw, m->bend_train_bwd);
+        if (refresh && rc == NRNERF_OK && hipStreamSynchronize(refresh_stream) != hipSuccess) rc = NRNERF_ERR_HIP;
+        m->bend_train_ok = (rc == NRNERF_OK);
+    }
     return rc;
 }
 
@@ -489,6 +555,16 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
         const nrnerf_mlp_desc* mm = (which == 5 && desc->fine) ? desc->fine : desc->coarse;
         rc = pack_dispatch(d2, *mm, fwd);            // validates the architecture
         if (rc == NRNERF_OK) pack_bwd(*desc, *mm, pk);
+    } else if (which == 6) {                     // transposed bender / rigidity weights of its backward-data kernel (fp32)
+        if (!desc->bender) return NRNERF_ERR_UNSUPPORTED;
+        PackedPass fwd;
+        int arch_id = 0;
+        rc = pack_dispatch(*desc, *desc->coarse, fwd, &arch_id);
+        if (rc == NRNERF_OK && arch_id > 1) rc = NRNERF_ERR_UNSUPPORTED;
+        if (rc == NRNERF_OK) {
+            if (arch_id == 0) pack_pass_bwd_bender<ArchDefault>(*desc->bender, pk);
+            else pack_pass_bwd_bender<ArchDeepBend>(*desc->bender, pk);
+        }
     } else {
         rc = pack_dispatch(*desc, *m, pk);
     }
@@ -625,7 +701,7 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     if (!guard.ok) return NRNERF_ERR_HIP;
     hipStream_t stream = (hipStream_t)hip_stream;
     PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only,
-                         &m->coarse_bwd, &m->fine_bwd};
+                         &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd};
     for (PassDev* p : passes) {
         if (!p || !p->stream) continue;
         if (!p->src) return NRNERF_ERR_UNSUPPORTED;
@@ -650,6 +726,8 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->bend_only);
     free_pass(m->coarse_bwd);
     free_pass(m->fine_bwd);
+    free_pass(m->bend_train_fwd);
+    free_pass(m->bend_train_bwd);
     (void)hipSetDevice(prev);
     delete m;
 }
@@ -917,6 +995,52 @@ int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, voi
     if (!guard.ok) return NRNERF_ERR_HIP;
     const hipError_t e = (m->precision == NRNERF_PREC_F32) ? launch_trunk_bwd_f32(t, m->num_cus, (hipStream_t)hip_stream)
                                                            : launch_trunk_bwd_bf16(t, m->num_cus, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
+namespace {
+int bender_common(const nrnerf_model* m, const nrnerf_bender_args* a, bool bwd, BendTrainArgs& t) {
+    if (!m || !a || a->struct_size != sizeof(nrnerf_bender_args)) return NRNERF_ERR_INVALID;
+    if (!m->bend_train_ok) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256) return NRNERF_ERR_INVALID;
+    if (!a->rays || a->ray_stride < 6 || !a->latents || a->latent_stride < m->latent_size || !a->z) return NRNERF_ERR_INVALID;
+    if (!a->bent4 || !a->off4 || !a->acts_offsets || !a->acts_rigidity) return NRNERF_ERR_INVALID;
+    if (bwd && (!a->g_bent4 || !a->dz_offsets || !a->dz_rigidity || !a->dz_out4 || !a->d_latents)) return NRNERF_ERR_INVALID;
+    t = BendTrainArgs{};
+    t.rays = a->rays; t.ray_stride = a->ray_stride; t.latents = a->latents; t.lat_stride = a->latent_stride; t.z = a->z;
+    t.n_rays = a->n_rays; t.S = a->n_samples;
+    const PassDev& p = bwd ? m->bend_train_bwd : m->bend_train_fwd;
+    t.wstream = p.stream; t.bias = p.bias;
+    t.knobs.has_cutoff = a->has_rigidity_cutoff; t.knobs.cutoff = a->rigidity_cutoff;
+    t.knobs.has_scaling = a->has_test_time_scaling; t.knobs.scaling = a->test_time_scaling;
+    t.bent4 = a->bent4; t.off4 = a->off4; t.acts_b = a->acts_offsets; t.acts_r = a->acts_rigidity;
+    t.g_bent4 = a->g_bent4; t.g_unmasked = a->g_unmasked_offsets; t.g_mask = a->g_rigidity_mask;
+    t.dz_b = a->dz_offsets; t.dz_r = a->dz_rigidity; t.dz_out4 = a->dz_out4; t.d_lat = a->d_latents;
+    return NRNERF_OK;
+}
+}  // namespace
+
+int nrnerf_bender_forward(const nrnerf_model* m, const nrnerf_bender_args* a, void* hip_stream) {
+    BendTrainArgs t;
+    const int rc = bender_common(m, a, false, t);
+    if (rc != NRNERF_OK) return rc;
+    if (a->n_rays == 0) return NRNERF_OK;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    const hipError_t e = (m->arch_id == 0) ? launch_bend_fwd_train_a0(t, m->num_cus, (hipStream_t)hip_stream)
+                                           : launch_bend_fwd_train_a1(t, m->num_cus, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
+int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, void* hip_stream) {
+    BendTrainArgs t;
+    const int rc = bender_common(m, a, true, t);
+    if (rc != NRNERF_OK) return rc;
+    if (a->n_rays == 0) return NRNERF_OK;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    const hipError_t e = (m->arch_id == 0) ? launch_bend_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
+                                           : launch_bend_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 

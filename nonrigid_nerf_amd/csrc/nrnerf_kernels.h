@@ -122,6 +122,32 @@ hipError_t launch_trunk_fwd_train_bf16(const TrunkArgs&, int num_cus, hipStream_
 hipError_t launch_trunk_bwd_f32(const TrunkArgs&, int num_cus, hipStream_t);
 hipError_t launch_trunk_bwd_bf16(const TrunkArgs&, int num_cus, hipStream_t);
 
+// training kernels of the ray bender (nrnerf_train_bend.h): forward with saved activations, backward-data; always fp32
+struct BendTrainArgs {
+    const float* rays;   int ray_stride;
+    const float* latents; int lat_stride;
+    const float* z;          // [N,S] sample depths
+    int n_rays, S;
+    const void* wstream;     // forward: bender + rigidity stream (Plan<ShapeF32, A, true, false, false>); backward: PlanBB stream
+    const float* bias;       // forward only
+    Knobs knobs;
+    float* bent4;            // [M,4] bent point xyz + rigidity mask (after the cutoff knob): forward writes, backward reads
+    float* off4;             // [M,4] unmasked offsets xyz + tanh(rigidity logit):            forward writes, backward reads
+    float* acts_b;           // [BD-1][M][BW] hidden activations of the offset MLP
+    float* acts_r;           // [RD-1][M][RW] hidden activations of the rigidity MLP
+    const float* g_bent4;    // backward in  [M,4] gradient wrt the bent point (w ignored)
+    const float* g_unmasked; // backward in  [M,3] gradient wrt the unmasked offsets, or nullptr
+    const float* g_mask;     // backward in  [M]   gradient wrt the rigidity mask, or nullptr
+    float* dz_b;             // backward out [BD-1][M][BW] gradient wrt the hidden pre-activations of the offset MLP
+    float* dz_r;             // backward out [RD-1][M][RW] ... of the rigidity MLP
+    float* dz_out4;          // backward out [M,4] gradient wrt the offsets (xyz) and the rigidity logit (w)
+    float* d_lat;            // backward out [M,LAT] gradient wrt each sample's latent inputs
+};
+hipError_t launch_bend_fwd_train_a0(const BendTrainArgs&, int num_cus, hipStream_t);
+hipError_t launch_bend_fwd_train_a1(const BendTrainArgs&, int num_cus, hipStream_t);
+hipError_t launch_bend_bwd_a0(const BendTrainArgs&, int num_cus, hipStream_t);
+hipError_t launch_bend_bwd_a1(const BendTrainArgs&, int num_cus, hipStream_t);
+
 // Re-pack weights on the device (nrnerf_model_update_device): dst[i] = convert(flat[src[i]]) (0 where src[i] < 0).
 // fmt[i]: 0 = fp32, 1 = bf16, 2 = f16, 3 = f16((w - f16(w)) * 2^11), the lo part of the bender's split product;
 // fmt == nullptr: all fp32 (bias tables).

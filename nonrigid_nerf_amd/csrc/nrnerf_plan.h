@@ -126,7 +126,13 @@ enum LayerKind : int {
     LK_B_HEAD,   // output_linear^T:   d raw (C channels) -> d h_{D-1}
     LK_B_HID,    // pts_linears[i]^T:  W -> W
     LK_B_SKIP,   // pts_linears[SKIP+1]^T: W -> [encoding slots (2 tiles), W]
-    LK_B_IN      // pts_linears[0]^T:  W -> encoding slots (2 tiles)
+    LK_B_IN,     // pts_linears[0]^T:  W -> encoding slots (2 tiles)
+    // backward-data layers of the bender / rigidity MLPs (training, nrnerf_train_bend.h)
+    LK_BB_OUT,   // network[BD-1]^T:          d offsets (3) -> BW
+    LK_BB_HID,   // network[i]^T:             BW -> BW
+    LK_BB_IN,    // network[0]^T:             BW -> the LAT latent inputs (the xyz inputs carry no gradient)
+    LK_BR_OUT,   // rigidity_network[RD-1]^T: d logit (1) -> RW
+    LK_BR_HID    // rigidity_network[i]^T:    RW -> RW   (rigidity_network[0]^T is not needed: its input is xyz)
 };
 
 struct LayerSpec {
@@ -282,12 +288,48 @@ struct PlanB {
     static constexpr int layer_of(int i) { return i == 0 ? A::D : 1 + (A::D - 1 - i); }
 };
 
+// Backward-data plan of the bender and rigidity MLPs: network[BD-1..0]^T, then rigidity_network[RD-1..1]^T.
+template <class SH, class A>
+constexpr Tables build_tables_bwd_bender() {
+    constexpr int KH = SH::KH, SP = SH::SP;
+    constexpr int NT_BW = A::BW / 32, NT_RW = A::RW / 32, NT_LAT = cdiv(A::LAT, 32);
+    constexpr int NS_DR = cdiv(DRAW_LEN, 2 * KH);
+    Tables T{};
+    int nl = 0, tile0 = 0;
+    auto add = [&](int kind, int index, int ns, int nt) {
+        T.layers[nl] = LayerSpec{kind, index, ns, nt, tile0, 0};
+        tile0 += nt;
+        ++nl;
+    };
+    add(LK_BB_OUT, A::BD - 1, NS_DR, NT_BW);
+    for (int i = A::BD - 2; i >= 1; --i) add(LK_BB_HID, i, NT_BW * SP, NT_BW);
+    add(LK_BB_IN, 0, NT_BW * SP, NT_LAT);
+    add(LK_BR_OUT, A::RD - 1, NS_DR, NT_RW);
+    for (int i = A::RD - 2; i >= 1; --i) add(LK_BR_HID, i, NT_RW * SP, NT_RW);
+    T.nlayers = nl;
+    T.ntiles = tile0;
+    place_fragments<SH>(T);
+    return T;
+}
+template <class SH, class A>
+struct PlanBB {
+    static constexpr int KH = SH::KH, SP = SH::SP;
+    static constexpr int NT_BW = A::BW / 32, NT_RW = A::RW / 32, NT_LAT = cdiv(A::LAT, 32);
+    static constexpr int NS_DR = cdiv(DRAW_LEN, 2 * KH);
+    static constexpr Tables TB = build_tables_bwd_bender<SH, A>();
+    static constexpr int NLAYERS = TB.nlayers, NTILES = TB.ntiles, NFRAGS = TB.nfrags;
+    static_assert(TB.ntiles <= MAX_TILES && TB.nlayers <= MAX_LAYERS, "plan too large");
+    // layers[0] = network[BD-1]^T, layers[k] = network[BD-1-k]^T (k <= BD-1), then rigidity_network[RD-1]^T, ...
+    static constexpr int L_BEND(int i) { return A::BD - 1 - i; }            // network[i]^T
+    static constexpr int L_RIG(int i) { return A::BD + (A::RD - 1 - i); }   // rigidity_network[i]^T, i >= 1
+};
+
 // Which element W[y][x] of the reference weight the A-fragment element (tile t, row i, slab s, half h, element e) of a
 // backward layer holds (A = W^T: row <-> input feature x of W, k <-> output feature y of W); -1 = zero.
 template <class SH, class A>
 constexpr NRN_HD int bwd_y(int kind, int s, int h, int e, int out_features) {
     constexpr int KH = SH::KH, SP = SH::SP;
-    if (kind == LK_B_HEAD) {
+    if (kind == LK_B_HEAD || kind == LK_BB_OUT || kind == LK_BR_OUT) {
         const int ch = (2 * s + h) * KH + e;
         return ch < out_features ? ch : -1;
     }
@@ -305,6 +347,7 @@ constexpr NRN_HD int bwd_x(int kind, int t, int i, int in_features) {
     };
     if (kind == LK_B_IN) return slot(t);
     if (kind == LK_B_SKIP) return t < NT_E ? slot(t) : IN_CH + 32 * (t - NT_E) + i;
+    if (kind == LK_BB_IN) return (32 * t + i < A::LAT) ? 3 + 32 * t + i : -1;       // bender input [xyz, latent]: latent columns only
     const int x = 32 * t + i;
     return x < in_features ? x : -1;
 }

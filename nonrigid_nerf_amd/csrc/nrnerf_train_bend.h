@@ -1,0 +1,274 @@
+// nrnerf_train_bend.h -- the ray bender for TRAINING (reference ray_bending.forward, run_nerf_helpers.py:507-577, under
+// autograd): forward with saved activations and backward-data, both in exact fp32 on v_mfma_f32_32x32x2_f32.
+//
+// The deformation MLPs are 3 % of the model's flops, but as eager PyTorch ops their autograd graph streams
+// [samples x 64] floats through ~100 elementwise / GEMM launches per step and bounds the training step at scale
+// (DESIGN.md section 3.5).  Here they are two kernels built from the stand-alone bender's parts (weights resident in LDS,
+// `dense_b`, in-register hand-off):
+//   bend_fwd_train   bent point, rigidity mask, unmasked offsets; every hidden activation written to HBM in true feature
+//                    order (as nrnerf_train.h does for the trunk);
+//   bend_bwd         from the gradients of (bent point, unmasked offsets, rigidity mask): the gradient wrt every layer's
+//                    pre-activation (stored for the library weight-gradient GEMMs) and wrt each sample's latent inputs
+//                    (summed per ray by the caller); second plan PlanBB = the layers reversed with transposed weights;
+//                    rigidity_network[0]^T and the xyz rows of network[0]^T are never formed (the sample positions carry
+//                    no gradient: the reference detaches z_samples and the rays are data).
+// Always fp32, whatever the trunk's precision: offsets feed a 2^9-frequency encoding.  First-order only -- the divergence
+// regulariser differentiates the REFERENCE MODULE's own forward a second time (run_nerf_helpers.py:41-58), not this path.
+#pragma once
+#include "nrnerf_bend.h"
+#include "nrnerf_train.h"
+
+namespace nrn {
+
+template <class PE, int T, class ACT>
+__device__ __forceinline__ void pack_lin(const f32x16& acc, ACT& out) {      // D tile -> next B operand, no activation
+    static_for<0, PE::SP>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        static_for<0, PE::KH>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            out.template set<T * PE::SP + u, e>(acc[u * PE::KH + e]);
+        });
+    });
+}
+
+template <class A>
+__global__ void __launch_bounds__(256, 1) bend_fwd_train(const BendTrainArgs a) {
+    using P = PolF32;
+    using PL = Plan<P, A, true, false, false>;
+    constexpr int KH = P::KH, SP = P::SP, WAVES = 4;
+    constexpr int NS_BIN = PL::NS_BIN, NS_RIN = PL::NS_RIN;
+    constexpr int NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
+    using ST = WResident<P, PL::NFRAGS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = (float*)(smem + ST::BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    ST st;
+    st.init(a.wstream, smem, tid, WAVES * 64, lane);
+    for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = a.bias[i];
+    __syncthreads();
+    const BiasPtr bias_lane = bias_lane_ptr(bias_lds, h);
+
+    const int S = a.S;
+    const int bpr = (S + 31) >> 5;
+    const int nblocks = a.n_rays * bpr;
+    const size_t M = (size_t)a.n_rays * S;
+    for (int blk = (int)blockIdx.x * WAVES + wave; blk < nblocks; blk += (int)gridDim.x * WAVES) {
+        const int ray = blk / bpr;
+        const int sidx = (blk - ray * bpr) * 32 + j;
+        const bool ok = sidx < S;
+        const size_t so = (size_t)ray * S + (ok ? sidx : S - 1);
+        const float* rp = a.rays + (size_t)ray * a.ray_stride;
+        const float z = a.z[so];
+        float p[3] = {__fadd_rn(rp[0], __fmul_rn(rp[3], z)), __fadd_rn(rp[1], __fmul_rn(rp[4], z)), __fadd_rn(rp[2], __fmul_rn(rp[5], z))};
+        const float* lat = a.latents + (size_t)ray * a.lat_stride;
+        auto binval = [&](auto idxc) -> float {
+            constexpr int idx = decltype(idxc)::value;
+            if constexpr (idx < 3) return p[idx];
+            else if constexpr (idx < 8) return 0.0f;
+            else if constexpr (idx - 8 < A::LAT) return lat[idx - 8];
+            else return 0.0f;
+        };
+        Act<P, NS_BIN, false> bin;
+        static_for<0, NS_BIN>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            const float v0 = binval(std::integral_constant<int, 2 * s>{}), v1 = binval(std::integral_constant<int, 2 * s + 1>{});
+            bin.template set<s, 0>(h ? v1 : v0);
+        });
+        // hidden activation of layer `layer`: keep (true feature order) and hand on
+        auto keep = [&](float* base, int width, auto lc, auto tc, const f32x16& acc, auto& out) {
+            constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
+            if (ok) {
+                const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store4<P>(base, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]), relu_bits(acc[4 * q + 3]));
+            }
+            pack_act<P, t>(acc, out);
+        };
+        Act<P, NB, false> ba, bb;
+        float off[3];
+        dense_b<P, false, PL, PL::L_BEND0, NS_BIN>(st, bias_lane, bin, [&](auto tc, const f32x16& acc) {
+            keep(a.acts_b, A::BW, std::integral_constant<int, 0>{}, tc, acc, ba); });
+        static_for<1, A::BD - 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i % 2 == 1) dense_b<P, false, PL, PL::L_BEND0 + i, NB>(st, bias_lane, ba, [&](auto tc, const f32x16& acc) { keep(a.acts_b, A::BW, ic, tc, acc, bb); });
+            else dense_b<P, false, PL, PL::L_BEND0 + i, NB>(st, bias_lane, bb, [&](auto tc, const f32x16& acc) { keep(a.acts_b, A::BW, ic, tc, acc, ba); });
+        });
+        auto take_off = [&](auto, const f32x16& acc) { off[0] = acc[0]; off[1] = acc[1]; off[2] = acc[2]; };
+        if constexpr ((A::BD - 2) % 2 == 1) dense_b<P, false, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, bb, take_off);
+        else dense_b<P, false, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, ba, take_off);
+        // rigidity MLP (input = xyz only)
+        Act<P, NS_RIN, false> rin;
+        static_for<0, NS_RIN>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            const float v0 = (2 * s < 3) ? p[2 * s < 3 ? 2 * s : 0] : 0.0f, v1 = (2 * s + 1 < 3) ? p[2 * s + 1 < 3 ? 2 * s + 1 : 0] : 0.0f;
+            rin.template set<s, 0>(h ? v1 : v0);
+        });
+        Act<P, NR, false> ra, rb;
+        float logit;
+        dense_b<P, false, PL, PL::L_RIG0, NS_RIN>(st, bias_lane, rin, [&](auto tc, const f32x16& acc) {
+            keep(a.acts_r, A::RW, std::integral_constant<int, 0>{}, tc, acc, ra); });
+        static_for<1, A::RD - 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i % 2 == 1) dense_b<P, false, PL, PL::L_RIG0 + i, NR>(st, bias_lane, ra, [&](auto tc, const f32x16& acc) { keep(a.acts_r, A::RW, ic, tc, acc, rb); });
+            else dense_b<P, false, PL, PL::L_RIG0 + i, NR>(st, bias_lane, rb, [&](auto tc, const f32x16& acc) { keep(a.acts_r, A::RW, ic, tc, acc, ra); });
+        });
+        auto take_logit = [&](auto, const f32x16& acc) { logit = acc[0]; };
+        if constexpr ((A::RD - 2) % 2 == 1) dense_b<P, false, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, rb, take_logit);
+        else dense_b<P, false, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, ra, take_logit);
+
+        const float th = tanhf(logit);
+        float mask = (th + 1.0f) / 2.0f;                                                   // rnh:559-561
+        if (a.knobs.has_cutoff && mask <= a.knobs.cutoff) mask = 0.0f;                     // rnh:563-564
+        float bent[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float mo = __fmul_rn(mask, off[c]);                                            // rnh:567
+            if (a.knobs.has_scaling) mo = __fmul_rn(mo, a.knobs.scaling);                  // rnh:568-569
+            bent[c] = __fadd_rn(p[c], mo);                                                 // rnh:570
+        }
+        if (ok && h == 0) {
+            *(f32x4*)(a.bent4 + so * 4) = f32x4{bent[0], bent[1], bent[2], mask};
+            *(f32x4*)(a.off4 + so * 4) = f32x4{off[0], off[1], off[2], th};
+        }
+    }
+}
+
+template <class A>
+__global__ void __launch_bounds__(256, 1) bend_bwd(const BendTrainArgs a) {
+    using P = PolF32;
+    using PL = PlanBB<P, A>;
+    constexpr int KH = P::KH, SP = P::SP, WAVES = 4;
+    constexpr int NS_DR = PL::NS_DR, NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
+    using ST = WResident<P, PL::NFRAGS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = (float*)(smem + ST::BYTES);          // zero: backward layers have no bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    ST st;
+    st.init(a.wstream, smem, tid, WAVES * 64, lane);
+    for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = 0.0f;
+    __syncthreads();
+    const BiasPtr bias_lane = bias_lane_ptr(bias_lds, h);
+
+    const int S = a.S;
+    const int bpr = (S + 31) >> 5;
+    const int nblocks = a.n_rays * bpr;
+    const size_t M = (size_t)a.n_rays * S;
+    for (int blk = (int)blockIdx.x * WAVES + wave; blk < nblocks; blk += (int)gridDim.x * WAVES) {
+        const int ray = blk / bpr;
+        const int sidx = (blk - ray * bpr) * 32 + j;
+        const bool ok = sidx < S;
+        const size_t so = (size_t)ray * S + (ok ? sidx : S - 1);
+        // bent = p + s * mask * off (rnh:567-570): gradients of its three differentiable outputs -> d off, d logit
+        const f32x4 gb = *(const f32x4*)(a.g_bent4 + so * 4);
+        const f32x4 bm = *(const f32x4*)(a.bent4 + so * 4);        // .w = mask after the cutoff knob
+        const f32x4 ot = *(const f32x4*)(a.off4 + so * 4);         // offsets xyz, tanh(logit)
+        const float sc = a.knobs.has_scaling ? a.knobs.scaling : 1.0f;
+        const float mask = bm[3], th = ot[3];
+        float g_off[3], g_mask = a.g_mask ? a.g_mask[so] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g_off[c] = gb[c] * mask * sc + (a.g_unmasked ? a.g_unmasked[so * 3 + c] : 0.0f);
+            g_mask += gb[c] * ot[c] * sc;
+        }
+        const bool cut = a.knobs.has_cutoff && (th + 1.0f) / 2.0f <= a.knobs.cutoff;       // the assignment mask[...] = 0 has no gradient
+        float g_logit = cut ? 0.0f : g_mask * 0.5f * (1.0f - th * th);
+        if (!ok) { g_off[0] = g_off[1] = g_off[2] = 0.0f; g_logit = 0.0f; }
+        if (ok && h == 0) *(f32x4*)(a.dz_out4 + so * 4) = f32x4{g_off[0], g_off[1], g_off[2], g_logit};
+
+        // d h_layer tile t -> d z_layer (mask with the saved activation), stored for the weight gradients, handed on
+        auto mask_store = [&](const float* acts, float* dz, int width, auto lc, auto tc, const f32x16& acc, auto& out) {
+            constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
+            const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
+            f32x16 g = acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 hv = load4<P>(acts, row + 8 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[4 * q + k] = (hv[k] > 0.0f) ? acc[4 * q + k] : 0.0f;
+                if (ok) store4<P>(dz, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+            }
+            pack_lin<P, t>(g, out);
+        };
+        // ---- offset MLP: network[BD-1]^T .. network[0]^T
+        Act<P, NS_DR, false> dr;
+        static_for<0, NS_DR>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            const float v0 = (2 * s < 3) ? g_off[2 * s < 3 ? 2 * s : 0] : 0.0f, v1 = (2 * s + 1 < 3) ? g_off[2 * s + 1 < 3 ? 2 * s + 1 : 0] : 0.0f;
+            dr.template set<s, 0>(h ? v1 : v0);
+        });
+        Act<P, NB, false> ba, bb;
+        dense_b<P, false, PL, PL::L_BEND(A::BD - 1), NS_DR>(st, bias_lane, dr, [&](auto tc, const f32x16& acc) {
+            mask_store(a.acts_b, a.dz_b, A::BW, std::integral_constant<int, A::BD - 2>{}, tc, acc, ba); });
+        static_for<0, A::BD - 2>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;             // 0 .. BD-3
+            constexpr int i = A::BD - 2 - k;                   // network[i]^T: d z_i -> d h_{i-1}
+            auto run = [&](auto& src, auto& dst) {
+                dense_b<P, false, PL, PL::L_BEND(i), NB>(st, bias_lane, src, [&](auto tc, const f32x16& acc) {
+                    mask_store(a.acts_b, a.dz_b, A::BW, std::integral_constant<int, i - 1>{}, tc, acc, dst); });
+            };
+            if constexpr (k % 2 == 0) run(ba, bb); else run(bb, ba);
+        });
+        // network[0]^T, latent rows only: gradient wrt this sample's latent inputs
+        auto take_lat = [&](auto tc, const f32x16& acc) {
+            constexpr int t = decltype(tc)::value;
+            if (ok) {
+                const size_t row = so * A::LAT + 32 * t + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (32 * t + 8 * q + 4 * h + 3 < A::LAT) store4<P>(a.d_lat, row + 8 * q, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        };
+        if constexpr ((A::BD - 2) % 2 == 0) dense_b<P, false, PL, PL::L_BEND(0), NB>(st, bias_lane, ba, take_lat);
+        else dense_b<P, false, PL, PL::L_BEND(0), NB>(st, bias_lane, bb, take_lat);
+        // ---- rigidity MLP: rigidity_network[RD-1]^T .. rigidity_network[1]^T
+        Act<P, NS_DR, false> drr;
+        static_for<0, NS_DR>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            drr.template set<s, 0>((s == 0 && h == 0) ? g_logit : 0.0f);
+        });
+        Act<P, NR, false> ra, rb;
+        dense_b<P, false, PL, PL::L_RIG(A::RD - 1), NS_DR>(st, bias_lane, drr, [&](auto tc, const f32x16& acc) {
+            mask_store(a.acts_r, a.dz_r, A::RW, std::integral_constant<int, A::RD - 2>{}, tc, acc, ra); });
+        static_for<0, A::RD - 2>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int i = A::RD - 2 - k;                   // rigidity_network[i]^T, i >= 1
+            auto run = [&](auto& src, auto& dst) {
+                dense_b<P, false, PL, PL::L_RIG(i), NR>(st, bias_lane, src, [&](auto tc, const f32x16& acc) {
+                    mask_store(a.acts_r, a.dz_r, A::RW, std::integral_constant<int, i - 1>{}, tc, acc, dst); });
+            };
+            if constexpr (k % 2 == 0) run(ra, rb); else run(rb, ra);
+        });
+    }
+}
+
+template <class A, bool BWD>
+static hipError_t launch_bend_train(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
+    using P = PolF32;
+    constexpr int NFRAGS = BWD ? PlanBB<P, A>::NFRAGS : Plan<P, A, true, false, false>::NFRAGS;
+    constexpr int NTILES = BWD ? PlanBB<P, A>::NTILES : Plan<P, A, true, false, false>::NTILES;
+    const size_t lds = (size_t)NFRAGS * P::FRAG_BYTES + (size_t)NTILES * 32 * sizeof(float);
+    void (*kern)(const BendTrainArgs) = nullptr;
+    if constexpr (BWD) kern = bend_bwd<A>; else kern = bend_fwd_train<A>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const long long nblocks = (long long)a.n_rays * ((a.S + 31) / 32);
+    if (nblocks >= (1ll << 31)) return hipErrorInvalidValue;
+    const long long want = (nblocks + 3) / 4;
+    if (want <= 0) return hipSuccess;
+    const int grid = (int)(want < num_cus ? want : num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace nrn

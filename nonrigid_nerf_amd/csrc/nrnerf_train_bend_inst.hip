@@ -1,0 +1,14 @@
+// nrnerf_train_bend_inst.hip -- the two training kernels of the ray bender (nrnerf_train_bend.h) for one compiled bender
+// architecture.  Build with -DNRN_ARCH=0 (reference default) or 1 (deeper offset MLP).
+#include "nrnerf_train_bend.h"
+
+#define NRN_CAT2(a, b) a##b
+#define NRN_CAT(a, b) NRN_CAT2(a, b)
+namespace nrn {
+hipError_t NRN_CAT(launch_bend_fwd_train_a, NRN_ARCH)(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
+    return launch_bend_train<ArchById<NRN_ARCH>::type, false>(a, num_cus, stream);
+}
+hipError_t NRN_CAT(launch_bend_bwd_a, NRN_ARCH)(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
+    return launch_bend_train<ArchById<NRN_ARCH>::type, true>(a, num_cus, stream);
+}
+}  // namespace nrn

@@ -7,13 +7,16 @@ What is native (C ABI ``nrnerf_trunk_forward / _backward``, ``nrnerf_composite_f
     backward-data pass on MFMA (csrc/nrnerf_train.h), fp32 or bf16;
   * compositing forward (raw2outputs, train.py:724-789), hierarchical sampling + merge (run_nerf_helpers.py:651-698,
     train.py:910-920, no gradient: the reference detaches the sample positions) and the compositing backward.
+  * the ray-bending and rigidity MLPs (35->64->64->64->64->3 and 3->32->32->1; ``nrnerf_bender_forward / _backward``,
+    csrc/nrnerf_train_bend.h), always in exact fp32: forward with saved activations and backward-data down to the latent
+    codes.  First order only: the divergence regulariser (run_nerf_helpers.py:22-116) differentiates the reference
+    MODULE's own forward a second time (it is handed the module, not this path), the offsets regulariser only needs the
+    first-order outputs ``unmasked_offsets`` / ``rigidity_mask``.  ``NATIVE_BENDER = False`` runs these MLPs as torch ops on
+    the modules' parameters instead (double-differentiable; the gradient-parity tests use it because it reproduces the
+    reference's bent points bit for bit).
 What is left to libraries, as plumbing:
-  * the weight gradients ``dW_i = dz_i^T x_i``: plain [256 x K] x [K x 256] GEMMs over the two arrays the kernels fill
-    (``torch.matmul`` = hipBLASLt), and the bias gradients (column sums);
-  * the ray-bending and rigidity MLPs (35->64->64->64->64->3 and 3->32->32->1, 3 % of the flops) run as ``F.linear`` on
-    the modules' own parameters under PyTorch autograd: their regularisers (offsets, divergence:
-    run_nerf_helpers.py:22-116) need double backward through exactly these layers, which autograd provides.  The
-    trunk takes the bent points and returns the gradient with respect to them.
+  * the weight gradients ``dW_i = dz_i^T x_i``: plain [out x K] x [K x in] GEMMs over the two arrays the kernels fill
+    (``torch.bmm`` = hipBLASLt), and the bias gradients (column sums).
 Eligible: the default architecture without view-dependent head / time conditioning, precision fp32 or bf16
 (``render.set_precision``; "f16" trains in bf16: unscaled f16 gradients underflow).  Anything else is handed to the
 reference by ``render.render_rays`` as before.
@@ -44,7 +47,9 @@ def posenc(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
 
 
 def _chunks(m: int, target: int = 4096) -> int:
-    """Number of equal row blocks to cut an [m, .] operand into: the largest divisor of m that keeps blocks >= target rows."""
+    """Number of equal row blocks to cut an [m, .] operand into: the largest divisor of m that keeps blocks >= target rows
+    (and at most ~256 blocks: enough to fill the chip, and the fp32 partial products that are added afterwards stay small)."""
+    target = max(target, m // 256)
     if m < 2 * target:
         return 1
     b = m // target
@@ -65,6 +70,18 @@ def _wgrad(dz: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return part.sum(0, dtype=torch.float32)
 
 
+def _rows4(x: torch.Tensor, M: int) -> torch.Tensor:
+    """[.., 3] float32 -> the [M,4] rows (xyz + one float the kernels ignore) the C ABI takes.  A tensor that already is the
+    xyz part of such rows (what _Bender returns and _Trunk.backward hands back) is re-viewed, anything else copied."""
+    n = x.shape[-2] if x.dim() == 3 else 1
+    if x.dtype == torch.float32 and x.dim() == 3 and x.stride() == (n * 4, 4, 1) and x.untyped_storage().nbytes() >= (x.storage_offset() + M * 4) * 4 \
+            and x.storage_offset() % 4 == 0:
+        return x.as_strided((M, 4), (4, 1), x.storage_offset())
+    rows = torch.zeros(M, 4, dtype=torch.float32, device=x.device)
+    rows[:, :3] = x.reshape(M, 3)
+    return rows
+
+
 class _Trunk(torch.autograd.Function):
     """raw4 [N,S,4] (differentiable), raw [N,S,C] (the reference's "raw" key; no gradient) = NeRF trunk(points)."""
 
@@ -74,8 +91,7 @@ class _Trunk(torch.autograd.Function):
         M, dev = N * S, pts.device
         D, W = int(net.D), int(net.W)
         act_dtype = torch.float32 if model.precision == "f32" else torch.bfloat16
-        pts4 = torch.zeros(M, 4, dtype=torch.float32, device=dev)
-        pts4[:, :3] = pts.detach().reshape(M, 3)
+        pts4 = _rows4(pts.detach(), M)               # the bender's own [M,4] rows when the points come from _Bender
         acts = torch.empty(D, M, W, dtype=act_dtype, device=dev)
         raw4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         C_out = int(net.output_linear.weight.shape[0])
@@ -130,7 +146,7 @@ class _Trunk(torch.autograd.Function):
         g_out = torch.zeros(M, C_out, dtype=torch.float32, device=dev)
         g_out[:, :4] = g
         grads += [_wgrad(g_out.to(adt), acts[D - 1]), g_out.sum(0)]
-        return (d_pts4[:, :3].reshape(N, S, 3), None, None, None, *grads)
+        return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *grads)
 
 
 def _trunk_params(net):
@@ -199,6 +215,115 @@ class _Composite(torch.autograd.Function):
             _lib.check(_lib.load().nrnerf_composite_backward(C.byref(a), _stream(dev)), "nrnerf_composite_backward")
         return d_raw4, None, None, None, None, None, None
 
+
+class _Bender(torch.autograd.Function):
+    """bent points [N,S,3], unmasked offsets [N,S,3], rigidity mask [N,S,1] = ray_bending(o + d z, latents)
+    (run_nerf_helpers.py:507-577) on the HIP library, fp32.  Gradients: latents and the bender's parameters."""
+
+    @staticmethod
+    def forward(ctx, latents, model, rb, rays, z, *params):
+        N, S = int(z.shape[0]), int(z.shape[1])
+        M, dev = N * S, z.device
+        BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
+        RD, RW = len(rb.rigidity_network), int(rb.rigidity_network[0].weight.shape[0])
+        lat = latents.detach().to(torch.float32).contiguous()
+        z = z.detach().contiguous()
+        bent4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        off4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        acts_b = torch.empty(BD - 1, M, BW, dtype=torch.float32, device=dev)
+        acts_r = torch.empty(RD - 1, M, RW, dtype=torch.float32, device=dev)
+        a = _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r)
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_bender_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_forward")
+        ctx.model, ctx.rb, ctx.dims = model, rb, (N, S, BD, BW, RD, RW)
+        ctx.save_for_backward(rays, lat, z, bent4, off4, acts_b, acts_r)
+        ctx.set_materialize_grads(False)
+        b = bent4.view(N, S, 4)
+        return b[..., :3], off4.view(N, S, 4)[..., :3], b[..., 3:4]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_bent, g_unmasked, g_mask):
+        rays, lat, z, bent4, off4, acts_b, acts_r = ctx.saved_tensors
+        model, rb = ctx.model, ctx.rb
+        N, S, BD, BW, RD, RW = ctx.dims
+        M, dev, LAT = N * S, z.device, int(lat.shape[1])
+        g4 = _rows4(g_bent, M) if g_bent is not None else torch.zeros(M, 4, dtype=torch.float32, device=dev)
+        gu = g_unmasked.reshape(M, 3).float().contiguous() if g_unmasked is not None else None
+        gm = g_mask.reshape(M).float().contiguous() if g_mask is not None else None
+        dz_b, dz_r = torch.empty_like(acts_b), torch.empty_like(acts_r)
+        dz_out4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        d_lat = torch.empty(M, LAT, dtype=torch.float32, device=dev)
+        a = _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r)
+        a.g_bent4 = g4.data_ptr()
+        a.g_unmasked_offsets = gu.data_ptr() if gu is not None else None
+        a.g_rigidity_mask = gm.data_ptr() if gm is not None else None
+        a.dz_offsets, a.dz_rigidity, a.dz_out4, a.d_latents = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), d_lat.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_bender_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_backward")
+        # weight gradients dW_i = dz_i^T x_i over the stored arrays (batched library GEMMs, see _wgrad).  x_0 = [p, latent]:
+        # the latent columns are constant along a ray, so their part is (per-ray sums of dz_0)^T latents.
+        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(M, 3)
+        dw0 = torch.cat([_wgrad(dz_b[0], pts), dz_b[0].view(N, S, BW).sum(1).t() @ lat], 1)
+        db_b = dz_b.sum(1)                                                                     # [BD-1, BW]
+        grads = [dw0, db_b[0]]
+        if BD > 2:
+            Bc = _chunks(M)
+            c = M // Bc
+            part = torch.bmm(dz_b[1:BD - 1].reshape((BD - 2) * Bc, c, BW).transpose(1, 2), acts_b[0:BD - 2].reshape((BD - 2) * Bc, c, BW))
+            dwh = part.view(BD - 2, Bc, BW, BW).sum(1)
+            for i in range(1, BD - 1):
+                grads += [dwh[i - 1], db_b[i]]
+        grads.append(_wgrad(dz_out4, acts_b[BD - 2])[0:3])                                     # network[-1]: 3 x BW
+        if rb.network[BD - 1].bias is not None:
+            grads.append(dz_out4[:, 0:3].sum(0))
+        db_r = dz_r.sum(1)
+        grads += [_wgrad(dz_r[0], pts), db_r[0]]
+        for i in range(1, RD - 1):
+            grads += [_wgrad(dz_r[i], acts_r[i - 1]), db_r[i]]
+        grads += [_wgrad(dz_out4, acts_r[RD - 2])[3:4], dz_out4[:, 3].sum(0, keepdim=True)]
+        return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, *grads)
+
+
+def _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r):
+    a = _lib.BenderArgs()
+    a.struct_size = C.sizeof(_lib.BenderArgs)
+    a.n_rays, a.n_samples = N, S
+    a.rays, a.ray_stride = rays.data_ptr(), int(rays.stride(0))
+    a.latents, a.latent_stride = lat.data_ptr(), int(lat.stride(0))
+    a.z = z.data_ptr()
+    cutoff, scaling = getattr(rb, "rigidity_test_time_cutoff", None), getattr(rb, "test_time_scaling", None)
+    if cutoff is not None:
+        a.has_rigidity_cutoff, a.rigidity_cutoff = 1, float(cutoff)
+    if scaling is not None:
+        a.has_test_time_scaling, a.test_time_scaling = 1, float(scaling)
+    a.bent4, a.off4, a.acts_offsets, a.acts_rigidity = bent4.data_ptr(), off4.data_ptr(), acts_b.data_ptr(), acts_r.data_ptr()
+    return a
+
+
+def _bender_params(rb):
+    ps = []
+    for lin in list(rb.network) + list(rb.rigidity_network):
+        ps.append(lin.weight)
+        if lin.bias is not None:
+            ps.append(lin.bias)
+    return ps
+
+
+def bend_native(model, rb, rays, z, latents, details=True):
+    """As `bend`, on the HIP library: rays [N,>=6], z [N,S], latents [N,L] -> bent [N,S,3], dict of [N,S,.] tensors."""
+    bent, unmasked, mask = _Bender.apply(latents, model, rb, rays, z, *_bender_params(rb))
+    if not details:
+        return bent, {}
+    masked = mask * unmasked                                           # rnh:567
+    scaling = getattr(rb, "test_time_scaling", None)
+    if scaling is not None:
+        masked = masked * scaling                                      # rnh:568-569
+    return bent, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
+
+
+# True: the ray bender runs on the HIP library (_Bender).  False: as torch ops on the module's parameters (`bend`).
+NATIVE_BENDER = True
 
 # False: the bender's layers run as plain F.linear (bit-identical bent points to the reference's ops; used by the gradient
 # parity tests, because gradients through the 2^9 encoding frequency move by 1e-2 of their scale under a 1-ulp change of
@@ -297,17 +422,22 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     z_vals = z_vals.contiguous()
 
     def query(z, net, which):
-        pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]                        # :871-873 / 921-923
+        native = rb is not None and NATIVE_BENDER
         ns = int(z.shape[1])
         details = {}
+        if detailed_output or not native:
+            pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]                    # :871-873 / 921-923
         if detailed_output:
             details["initial_input_pts"] = pts                                               # rnh:250-252
         if rb is not None:
             if latents is None:
                 raise ValueError("ray_bending_latents are required with a ray bender")
-            lat = latents[:, None, :].expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)   # train.py:79-87
-            bent, bd = bend(rb, pts.reshape(-1, 3), lat.to(torch.float32))
-            bent = bent.reshape(N, ns, 3)
+            if native:
+                bent, bd = bend_native(model, rb, rays, z, latents, details=detailed_output)
+            else:
+                lat = latents[:, None, :].expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)   # train.py:79-87
+                bent, bd = bend(rb, pts.reshape(-1, 3), lat.to(torch.float32))
+                bent = bent.reshape(N, ns, 3)
             if detailed_output:
                 details.update({k: v.reshape(N, ns, -1) for k, v in bd.items()})
         else:

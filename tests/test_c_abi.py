@@ -29,6 +29,8 @@ def test_header_compiles_as_c99_and_matches_the_ctypes_mirror(tmp_path):
                      'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nrnerf_trunk_args), sizeof(nrnerf_composite_args), sizeof(nrnerf_profile),\n'
                      '       offsetof(nrnerf_trunk_args, d_pts4), offsetof(nrnerf_trunk_args, raw_ch), offsetof(nrnerf_composite_args, d_raw4),\n'
                      '       offsetof(nrnerf_composite_args, z_merged));\n'
+                     'printf("%zu %zu %zu %zu\\n", sizeof(nrnerf_bender_args), offsetof(nrnerf_bender_args, z), offsetof(nrnerf_bender_args, bent4),\n'
+                     '       offsetof(nrnerf_bender_args, d_latents));\n'
                      'return 0; }\n')
     exe = tmp_path / "probe"
     subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(REPO, "include"), str(probe), "-o", str(exe)], check=True)
@@ -36,7 +38,8 @@ def test_header_compiles_as_c99_and_matches_the_ctypes_mirror(tmp_path):
     want = [C.sizeof(_lib.RenderArgs), C.sizeof(_lib.ModelDesc), C.sizeof(_lib.MlpDesc), _lib.RenderArgs.workspace.offset,
             _lib.RenderArgs.u_coarse.offset, _lib.RenderArgs.coarse.offset,
             C.sizeof(_lib.TrunkArgs), C.sizeof(_lib.CompositeArgs), C.sizeof(_lib.Profile), _lib.TrunkArgs.d_pts4.offset,
-            _lib.TrunkArgs.raw_ch.offset, _lib.CompositeArgs.d_raw4.offset, _lib.CompositeArgs.z_merged.offset]
+            _lib.TrunkArgs.raw_ch.offset, _lib.CompositeArgs.d_raw4.offset, _lib.CompositeArgs.z_merged.offset,
+            C.sizeof(_lib.BenderArgs), _lib.BenderArgs.z.offset, _lib.BenderArgs.bent4.offset, _lib.BenderArgs.d_latents.offset]
     assert got == want, (got, want)
 
 

@@ -426,3 +426,69 @@ def test_backward_stream_reproduces_autograd_of_the_trunk(precision):
     tol = 1e-9 if precision == "f32" else 6e-2
     err = np.abs(got - g_x.numpy()).max()
     assert err <= tol * np.abs(g_x.numpy()).max(), (err, np.abs(g_x.numpy()).max())
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_bender_backward_stream_reproduces_autograd_of_the_bender(precision):
+    """Training of the ray bender (csrc/nrnerf_train_bend.h): nrnerf_pack_host which = 6 is the fp32 stream of PlanBB --
+    network[4]^T .. network[1]^T, the latent rows of network[0]^T, then rigidity_network[2]^T, rigidity_network[1]^T --
+    whatever the model's precision.  Emulating the kernel's dataflow (gradient of the offsets / of the logit as first B
+    operand, relu masks from the forward activations) must reproduce torch.autograd's gradients wrt the latent inputs and
+    wrt every layer's pre-activation."""
+    cfg = SceneConfig(N_importance=128)
+    scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=6)
+    assert info.frag_bytes == 256 and not bias.any()
+    fr = FragReader(stream, "f32", info.frag_bytes)
+    ident = lambda x: x
+    gen = torch.Generator().manual_seed(5)
+    ns_ = 32
+    x = (torch.randn(ns_, 35, generator=gen) * 0.5).double().requires_grad_(True)
+    g_off = torch.randn(ns_, 3, generator=gen).double()
+    g_logit = torch.randn(ns_, 1, generator=gen).double()
+    zs, hs, h = [], [], x
+    for i, l in enumerate(rb.network):
+        z = F.linear(h, l.weight.double(), None if l.bias is None else l.bias.double())
+        z.retain_grad()
+        zs.append(z)
+        h = F.relu(z) if i != len(rb.network) - 1 else z
+        hs.append(h)
+    off = h
+    rzs, rhs, r = [], [], x[:, :3]
+    for i, l in enumerate(rb.rigidity_network):
+        z = F.linear(r, l.weight.double(), l.bias.double())
+        z.retain_grad()
+        rzs.append(z)
+        r = F.relu(z) if i != len(rb.rigidity_network) - 1 else z
+        rhs.append(r)
+    ((off * g_off).sum() + (r * g_logit).sum()).backward()
+    BD, RD = len(rb.network), len(rb.rigidity_network)
+
+    def masked(tiles, acts):
+        return [np.where(acts[:, 32 * t:32 * t + 32].T > 0, D, 0.0) for t, D in enumerate(tiles)]
+
+    def as_rows(tiles):
+        return np.concatenate(tiles, 0).T          # [nsamp, 32 * nt]
+
+    tile0 = mfma = 0
+    v = np.zeros((8, ns_)); v[:3] = g_off.numpy().T
+    slabs = vec_slabs(v, 1, ident)
+    tiles = dense_emul(fr, bias, tile0, len(slabs), 2, slabs); mfma += len(slabs) * 2; tile0 += 2          # network[4]^T
+    for i in range(BD - 2, -1, -1):                # tiles = d h_i
+        dz = masked(tiles, hs[i].detach().numpy())
+        np.testing.assert_allclose(as_rows(dz), zs[i].grad.numpy(), rtol=1e-9, atol=1e-12)
+        slabs = repack(dz, 1, False)
+        nt = 2 if i > 0 else 1
+        tiles = dense_emul(fr, bias, tile0, len(slabs), nt, slabs); mfma += len(slabs) * nt; tile0 += nt   # network[i]^T
+    np.testing.assert_allclose(as_rows(tiles), x.grad.numpy()[:, 3:35], rtol=1e-9, atol=1e-12)             # latent columns
+    v = np.zeros((8, ns_)); v[0] = g_logit.numpy()[:, 0]
+    slabs = vec_slabs(v, 1, ident)
+    tiles = dense_emul(fr, bias, tile0, len(slabs), 1, slabs); mfma += len(slabs); tile0 += 1              # rigidity_network[2]^T
+    for i in range(RD - 2, -1, -1):
+        dz = masked(tiles, rhs[i].detach().numpy())
+        np.testing.assert_allclose(as_rows(dz), rzs[i].grad.numpy(), rtol=1e-9, atol=1e-12)
+        if i > 0:
+            slabs = repack(dz, 1, False)
+            tiles = dense_emul(fr, bias, tile0, len(slabs), 1, slabs); mfma += len(slabs); tile0 += 1      # rigidity_network[i]^T
+    assert tile0 == info.n_bias_tiles and mfma == info.mfma_per_block
+    used = fr.pos * info.frag_bytes
+    assert used <= info.stream_bytes and not stream[used:].any()

@@ -91,7 +91,7 @@ def check(build_dir: str) -> list[str]:
             print(f"{name:24s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} scratch {r['scratch']:3d} "
                   f"mfma {r['mfma']:5d} valu {r['valu']:5d} lgkm counted/drain {r['lgkm_counted']:4d}/{r['lgkm_drain']:3d} "
                   f"smem-after-mfma {r['smem_after_first_mfma']}" + (f"  [2 blocks/wave, accvgpr {r['accvgpr']}]" if r["mb"] else ""))
-            sixteen = "_f32_" not in "_" + name + "_"
+            sixteen = "_f32_" not in "_" + name + "_" and not name.startswith("train_bend_")      # the training bender is fp32 only
             if sixteen:
                 # (reported, not enforced, for the stand-alone bender -- which reads its per-block inputs with scalar loads on
                 #  purpose -- and the training kernels: a counted LDS wait is conservative with SMEM in flight, at most N

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""GPU box: where a native training step (1024 rays, 64+128, bf16) spends its time -- wall time per phase with a device
+"""GPU box: where a native training step (argv: precision, rays per step; default bf16, 1024; 64+128 samples) spends its time -- wall time per phase with a device
 synchronisation after each (so launch overheads of the eager pieces are included), plus the top GPU kernels by time."""
 import os
 import sys
@@ -17,6 +17,7 @@ DEV = torch.device("cuda:0")
 
 def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    NR = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     cfg = SceneConfig()
     scene = make_scene(cfg, 0)
     rb, coarse, fine = build_modules(scene, device=DEV)
@@ -26,10 +27,10 @@ def main():
         params += list(m.parameters())
     codes = torch.zeros(8, 32, device=DEV, requires_grad=True)
     opt = torch.optim.Adam(params + [codes], lr=5e-4)
-    rays, _ = make_rays(1024, 5, cfg)
+    rays, _ = make_rays(NR, 5, cfg)
     rays = rays.to(DEV)
-    frame = torch.randint(0, 8, (1024,), device=DEV)
-    target = torch.rand(1024, 3, device=DEV)
+    frame = torch.randint(0, 8, (NR,), device=DEV)
+    target = torch.rand(NR, 3, device=DEV)
     R.set_precision(prec)
     kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=64, N_importance=128, perturb=1.0,
               raw_noise_std=1.0, retraw=True)
