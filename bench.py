@@ -68,6 +68,7 @@ def parse_args():
                          "that an external utilisation sampler sees the run")
     ap.add_argument("--use-viewdirs", action="store_true", help="BASELINE config 4: view-dependent head (not the headline config)")
     ap.add_argument("--bend-depth", type=int, default=5, help="BASELINE config 4: deeper ray-bending MLP (5 or 7)")
+    ap.add_argument("--netwidth", type=int, default=256, help="trunk width of both networks (256 = headline; 128 is the other compiled width)")
     ap.add_argument("--exact-viewdirs", action="store_true", help="with --use-viewdirs: Jacobian instead of finite-difference directions")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --rays per GPU; strong: --rays in total, sharded contiguously over the ranks "
@@ -125,7 +126,7 @@ def build_workload(args, rank, world, dev):
                 f"down-sampled sequence ({ck.global_step} oracle iterations, tests/golden/fitted_latest.tar), one latent per frame")
         return scene, cfg, (rb, coarse, fine), rays, latents, desc
     cfg = SceneConfig(use_viewdirs=args.use_viewdirs, bend_depth=args.bend_depth,      # default: 64 + 128, W = 256, bender on, latent 32
-                      approx_nonrigid_viewdirs=not args.exact_viewdirs)
+                      approx_nonrigid_viewdirs=not args.exact_viewdirs, netwidth=args.netwidth)
     scene = make_scene(cfg, 0)
     mods = build_modules(scene, device=dev)
     rays, latents = make_rays(n, seed=100 + rank, cfg=cfg)
@@ -134,7 +135,7 @@ def build_workload(args, rank, world, dev):
 
 def main():
     args = parse_args()
-    if args.use_viewdirs or args.bend_depth != 5 or args.exact_viewdirs:
+    if args.use_viewdirs or args.bend_depth != 5 or args.exact_viewdirs or args.netwidth != 256:
         args.scene = "synthetic"          # the fitted checkpoint is the default architecture only
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
@@ -227,7 +228,7 @@ def main():
         with torch.no_grad():
             if not args.no_psnr:
                 extra["psnr_vs_oracle_db"] = psnr_vs_oracle(args, scene, cfg, rays, latents, api, kw, dev)
-        if not args.no_train_step and args.precision != "f16" and not (args.use_viewdirs or args.exact_viewdirs):
+        if not args.no_train_step and args.precision != "f16" and not (args.use_viewdirs or args.exact_viewdirs or args.netwidth != 256):
             extra["train_step"] = train_step_leg(args, scene, cfg, dev)          # needs autograd: outside the no_grad block
         with torch.no_grad():
             gemm = library_gemm_tflops(dev, args.precision) if world == 1 else None
@@ -267,7 +268,8 @@ def main():
                "config": {"workload": "BASELINE config 2: example_sequence-shaped frame (512x384 = 196608 rays/GPU/step), "
                                       "64 coarse + 128 importance samples, netwidth 256, ray bender on, latent 32"
                                       + (f"; NON-HEADLINE VARIANT: use_viewdirs={args.use_viewdirs}, bend_depth={args.bend_depth}, "
-                                         f"exact_viewdirs={args.exact_viewdirs}" if (args.use_viewdirs or args.bend_depth != 5) else ""),
+                                         f"exact_viewdirs={args.exact_viewdirs}, netwidth={args.netwidth}"
+                                         if (args.use_viewdirs or args.bend_depth != 5 or args.netwidth != 256) else ""),
                           "scene": args.scene, "rays_per_gpu_per_step": n, "N_samples": 64, "N_importance": 128,
                           "parallelism": f"rays sharded over {world} rank(s)"
                                          + (", all-gather of [rgb,disp,acc] on a side stream, overlapped with the next frame" if world > 1 else "")},

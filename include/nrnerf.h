@@ -179,6 +179,12 @@ typedef struct nrnerf_profile {
 int nrnerf_abi_version(void);
 const char* nrnerf_strerror(int status);
 
+/* Compiled architectures (anything else: NRNERF_ERR_UNSUPPORTED, the Python boundary then defers to the reference):
+ * depth 8, skip after layer 4, 10 encoding frequencies, latent size 32, rigidity MLP 3 x 32, and
+ *   width 256, ray bender 5 x 64 or 7 x 64 or none, optional view-dependent head (finite-difference or exact directions);
+ *   width 256, time-conditioned baseline (no bender), optional view-dependent head;
+ *   width 128 (--netwidth 128 --netwidth_fine 128, train.py:1004-1010), ray bender 5 x 64 or none, no view-dependent head.
+ * Coarse and fine network must have the same shape. */
 int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out);
 /* Re-pack new weights of the SAME architecture / precision / device into an existing handle (e.g. after an optimiser
  * step or load_state_dict, train.py:666-682): no allocation; ordered after work already queued on hip_stream, complete

@@ -353,8 +353,21 @@ int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPa
         }
         if (rc1 != NRNERF_ERR_UNSUPPORTED) return rc1;
     }
+    if (rc == NRNERF_ERR_UNSUPPORTED && !m.time_conditioned && !m.use_viewdirs) {      // arch 5: netwidth 128, no view-dependent head
+        const int rc5 = check_arch_t<ArchNarrow>(d, m);
+        if (rc5 == NRNERF_OK) {
+            pack_arch<ArchNarrow>(d, m, out, bender_only, lay);
+            if (arch_id) *arch_id = 5;
+            return NRNERF_OK;
+        }
+        if (rc5 != NRNERF_ERR_UNSUPPORTED) return rc5;
+    }
     return rc;
 }
+// the trunk-only / bender-only kernels of the split-bender path: the trunk is the architecture's without bender (the 5- and
+// the 7-layer bender share architecture 0's), the bender kernel is compiled per bender shape (narrow trunk: the 5-layer one)
+int trunk_arch(int arch_id) { return arch_id == 5 ? 5 : 0; }
+int bender_arch(int arch_id) { return arch_id == 5 ? 0 : arch_id; }
 
 // algorithmic MACs per sample, unpadded
 double algo_macs(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
@@ -553,7 +566,9 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
         nrnerf_model_desc d2 = *desc;
         d2.bender = nullptr;
         const nrnerf_mlp_desc* mm = (which == 5 && desc->fine) ? desc->fine : desc->coarse;
-        rc = pack_dispatch(d2, *mm, fwd);            // validates the architecture
+        int arch_id = 0;
+        rc = pack_dispatch(d2, *mm, fwd, &arch_id);   // validates the architecture
+        if (rc == NRNERF_OK && arch_id != 0) rc = NRNERF_ERR_UNSUPPORTED;      // training kernels: the default trunk only
         if (rc == NRNERF_OK) pack_bwd(*desc, *mm, pk);
     } else if (which == 6) {                     // transposed bender / rigidity weights of its backward-data kernel (fp32)
         if (!desc->bender) return NRNERF_ERR_UNSUPPORTED;
@@ -855,12 +870,12 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         bc.wstream = m->bend_only.stream; bc.bias = m->bend_only.bias;
         bc.bent4 = bent_c; bc.knobs = kn;
         e = timed(5, (double)N * S * m->bend_only.algo_flops_per_sample, (double)N * S * m->bend_only.mfma_flops_per_sample,
-                  [&] { return launch_bend(m->precision, m->arch_id, bc, m->num_cus, stream); });
+                  [&] { return launch_bend(m->precision, bender_arch(m->arch_id), bc, m->num_cus, stream); });
         if (e != hipSuccess) return NRNERF_ERR_HIP;
         na.pts4 = bent_c; na.bent4 = nullptr;
         na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
         e = timed(0, (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
-                  [&] { return launch_net(m->precision, false, false, 0, na, m->num_cus, stream); });
+                  [&] { return launch_net(m->precision, false, false, trunk_arch(m->arch_id), na, m->num_cus, stream); });
     } else {
         e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
                   [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
@@ -906,13 +921,13 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         ba.wstream = m->bend_only.stream; ba.bias = m->bend_only.bias;
         ba.bent4 = bent4; ba.knobs = kn;
         e = timed(4, (double)N * I * m->bend_only.algo_flops_per_sample, (double)N * I * m->bend_only.mfma_flops_per_sample,
-                  [&] { return launch_bend(m->precision, m->arch_id, ba, m->num_cus, stream); });
+                  [&] { return launch_bend(m->precision, bender_arch(m->arch_id), ba, m->num_cus, stream); });
         if (e != hipSuccess) return NRNERF_ERR_HIP;
         // K2: trunk + head on ready-made points (compiled architecture 0 without bender)
         nf.pts4 = bent4; nf.bent4 = nullptr;
         nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
         e = timed(2, (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,
-                  [&] { return launch_net(m->precision, false, false, 0, nf, m->num_cus, stream); });
+                  [&] { return launch_net(m->precision, false, false, trunk_arch(m->arch_id), nf, m->num_cus, stream); });
     } else {
         nf.wstream = m->fine.stream; nf.bias = m->fine.bias;
         nf.bent4 = bent4;

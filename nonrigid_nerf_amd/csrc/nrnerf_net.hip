@@ -10,6 +10,8 @@ typedef hipError_t (*launch_fn)(const NetArgs&, int, hipStream_t);
 #define NRN_ARCH2(p) NRN_DECL(a2_##p##_nobend) NRN_DECL(a2_##p##_nobend_views)
 #define NRN_ARCH3(p) NRN_DECL(a3_##p##_bend_views) NRN_DECL(a4_##p##_bend_views)
 NRN_ARCH3(f32) NRN_ARCH3(bf16) NRN_ARCH3(f16)
+#define NRN_ARCH5(p) NRN_DECL(a5_##p##_bend) NRN_DECL(a5_##p##_nobend)
+NRN_ARCH5(f32) NRN_ARCH5(bf16) NRN_ARCH5(f16)
 NRN_ARCH0(f32) NRN_ARCH0(bf16) NRN_ARCH0(f16) NRN_ARCH1(f32) NRN_ARCH1(bf16) NRN_ARCH1(f16) NRN_ARCH2(f32) NRN_ARCH2(bf16) NRN_ARCH2(f16)
 #undef NRN_DECL
 
@@ -20,12 +22,15 @@ NRN_ARCH0(f32) NRN_ARCH0(bf16) NRN_ARCH0(f16) NRN_ARCH1(f32) NRN_ARCH1(bf16) NRN
 // rows 3, 4: architectures 0, 1 with exact (Jacobian) view directions -- same packed weights as rows 0, 1
 #define NRN_ROW3(p) {{nullptr, nullptr}, {nullptr, launch_net_a3_##p##_bend_views}}
 #define NRN_ROW4(p) {{nullptr, nullptr}, {nullptr, launch_net_a4_##p##_bend_views}}
-static const launch_fn TABLE[5][3][2][2] = {
+// row 5: architecture 5 (trunk width 128), no view-dependent head
+#define NRN_ROW5(p) {{launch_net_a5_##p##_nobend, nullptr}, {launch_net_a5_##p##_bend, nullptr}}
+static const launch_fn TABLE[6][3][2][2] = {
     {NRN_ROW0(f32), NRN_ROW0(bf16), NRN_ROW0(f16)},
     {NRN_ROW1(f32), NRN_ROW1(bf16), NRN_ROW1(f16)},
     {NRN_ROW2(f32), NRN_ROW2(bf16), NRN_ROW2(f16)},
     {NRN_ROW3(f32), NRN_ROW3(bf16), NRN_ROW3(f16)},
     {NRN_ROW4(f32), NRN_ROW4(bf16), NRN_ROW4(f16)},
+    {NRN_ROW5(f32), NRN_ROW5(bf16), NRN_ROW5(f16)},
 };
 
 // stand-alone bender kernels: [arch 0 = 5-layer, 1 = 7-layer offset MLP][precision]
@@ -43,7 +48,7 @@ hipError_t launch_bend(int precision, int arch_id, const BendArgs& a, int num_cu
 }
 
 hipError_t launch_net(int precision, bool has_bend, bool views, int arch_id, const NetArgs& a, int num_cus, hipStream_t stream) {
-    if (arch_id < 0 || arch_id > 4 || precision < 0 || precision > 2) return hipErrorInvalidValue;
+    if (arch_id < 0 || arch_id > 5 || precision < 0 || precision > 2) return hipErrorInvalidValue;
     const launch_fn f = TABLE[arch_id][precision][has_bend ? 1 : 0][views ? 1 : 0];
     return f ? f(a, num_cus, stream) : hipErrorInvalidValue;
 }

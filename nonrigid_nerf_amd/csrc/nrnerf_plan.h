@@ -444,10 +444,14 @@ constexpr NRN_HD int out_row(int kind, int t, int i, int out_features) {
 using ArchDefault = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32>;      // arch id 0: the reference's shipped configuration
 using ArchDeepBend = ArchT<256, 8, 4, 10, 64, 7, 32, 3, 32>;     // arch id 1: deeper ray-bending MLP (BASELINE config 4)
 using ArchTimeCond = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32, 4, 1>;  // arch id 2: time-conditioned baseline (no bender)
-constexpr int NUM_ARCHS = 3;
+// arch id 5: --netwidth 128 --netwidth_fine 128 (train.py:1004-1010), with the 5-layer bender or without one, no
+// view-dependent head (ids 3 and 4 are the dispatch rows of architectures 0 and 1 with exact view directions)
+using ArchNarrow = ArchT<128, 8, 4, 10, 64, 5, 32, 3, 32>;
+constexpr int NUM_ARCHS = 4;
 template <int ID> struct ArchById { using type = ArchDefault; };
 template <> struct ArchById<1> { using type = ArchDeepBend; };
 template <> struct ArchById<2> { using type = ArchTimeCond; };
+template <> struct ArchById<5> { using type = ArchNarrow; };
 using ShapeF32 = Shape<1>;
 using Shape16 = Shape<8, true>;        // "f16" mode: split-product bender
 using Shape16Fast = Shape<8, false>;   // "bf16" mode: single-product f16 bender

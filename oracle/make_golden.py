@@ -113,6 +113,9 @@ CASES = {
     "exact_viewdirs_knobs": (dict(N_importance=64, use_viewdirs=True, approx_nonrigid_viewdirs=False), 24, 32768, True, False,
                              dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5)),
     "config4_exact_viewdirs": (dict(N_importance=64, use_viewdirs=True, bend_depth=7, approx_nonrigid_viewdirs=False), 32, 32768, False, True, {}),
+    # --netwidth 128 --netwidth_fine 128 (train.py:1004-1010): compiled architecture 5
+    "narrow_128_64_64": (dict(N_importance=64, netwidth=128), 48, 32768, True, True, {}),
+    "narrow_128_no_bender": (dict(N_importance=64, netwidth=128, ray_bending=False), 37, 16, False, True, {}),
     "stochastic_64_64": (dict(N_importance=64), 40, 16, False, True, dict(render_perturb=1.0, render_raw_noise_std=0.7, render_seed=1234)),
 }
 

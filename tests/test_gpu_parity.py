@@ -80,7 +80,7 @@ COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "
 @pytest.mark.parametrize("name", ["coarse_only_1k", "headline_64_128", "detailed_64_128", "ragged_chunks",
                                   "knobs_64_64", "no_bender_64_64", "viewdirs_64_64", "config4_deep_bender_viewdirs",
                                   "time_conditioned_64_64", "lindisp_white_bkgd_64_64", "exact_viewdirs_64_64",
-                                  "exact_viewdirs_knobs", "config4_exact_viewdirs"])
+                                  "exact_viewdirs_knobs", "config4_exact_viewdirs", "narrow_128_64_64", "narrow_128_no_bender"])
 def test_fp32_mode_matches_reference_golden(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
     meta["knobs"], flags = split_knobs(meta["knobs"])
@@ -614,6 +614,8 @@ VARIANT_CFGS = {
     "time_conditioned_viewdirs": dict(N_importance=0, ray_bending=False, time_conditioned_baseline=True, use_viewdirs=True),
     "exact_viewdirs":       dict(N_importance=0, use_viewdirs=True, approx_nonrigid_viewdirs=False),
     "deep_bender_exact_viewdirs": dict(N_importance=0, use_viewdirs=True, bend_depth=7, approx_nonrigid_viewdirs=False),
+    "narrow_128":           dict(N_importance=0, netwidth=128),
+    "narrow_128_no_bender": dict(N_importance=0, netwidth=128, ray_bending=False),
 }
 
 
@@ -780,7 +782,8 @@ def test_render_path_and_surface_reduction_match_reference_golden():
     (dict(N_samples=48, N_importance=37), dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5), {}),
     (dict(N_importance=64), {}, dict(perturb=1.0, raw_noise_std=0.5)),
     (dict(N_samples=128, N_importance=128), {}, dict(lindisp=True, white_bkgd=True)),
-], ids=["headline", "deep_bender", "ragged_knobs", "stochastic", "max_samples_flags"])
+    (dict(N_importance=64, netwidth=128), {}, {}),
+], ids=["headline", "deep_bender", "ragged_knobs", "stochastic", "max_samples_flags", "narrow_128"])
 def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg_kw, knobs, flags):
     """nrnerf_render's split-bender path (coarse bent points carried over, stand-alone bender kernel for the importance
     samples, trunk-only fine kernel; nrnerf_bend.h) against the fused fine pass, which a request for per-sample detail

@@ -177,10 +177,12 @@ def rounder(precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("bend,views,tcb", [(True, False, False), (False, False, False), (True, True, False),
-                                            (False, True, False), (False, False, True)])
-def test_packed_stream_reproduces_the_network(precision, bend, views, tcb):
-    cfg = SceneConfig(N_importance=128, ray_bending=bend, use_viewdirs=views, time_conditioned_baseline=tcb)
+@pytest.mark.parametrize("bend,views,tcb,width", [(True, False, False, 256), (False, False, False, 256), (True, True, False, 256),
+                                                  (False, True, False, 256), (False, False, True, 256),
+                                                  (True, False, False, 128), (False, False, False, 128)])
+def test_packed_stream_reproduces_the_network(precision, bend, views, tcb, width):
+    cfg = SceneConfig(N_importance=128, ray_bending=bend, use_viewdirs=views, time_conditioned_baseline=tcb, netwidth=width)
+    NT = width // 32
     scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=1)
     KH = 1 if precision == "f32" else 8
     SP = 16 // KH
@@ -239,14 +241,14 @@ def test_packed_stream_reproduces_the_network(precision, bend, views, tcb):
     slabs_enc = enc_slabs(p, 10, KH, rnd_e)
     if tcb:        # time-conditioned baseline: latent slabs follow the encoding (element (s,h,e) = latent[(2s+h)*KH+e])
         slabs_enc = slabs_enc + vec_slabs(lat.T, KH, rnd_e)
-    tiles = dense_emul(fr, bias, tile0, len(slabs_enc), 8, slabs_enc, f16_slabs=-1); mfma += len(slabs_enc) * 8; tile0 += 8
+    tiles = dense_emul(fr, bias, tile0, len(slabs_enc), NT, slabs_enc, f16_slabs=-1); mfma += len(slabs_enc) * NT; tile0 += NT
     for i in range(1, 8):
         slabs = repack(tiles, KH, True, rnd)
         n16 = 0
         if i - 1 == 4:
             slabs = slabs_enc + slabs
             n16 = len(slabs_enc)
-        tiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs, f16_slabs=n16); mfma += len(slabs) * 8; tile0 += 8
+        tiles = dense_emul(fr, bias, tile0, len(slabs), NT, slabs, f16_slabs=n16); mfma += len(slabs) * NT; tile0 += NT
     slabs = repack(tiles, KH, True, rnd)
     dirs = (torch.randn(ns_, 3, generator=gen)).double()
     dirs = (dirs / dirs.norm(dim=-1, keepdim=True)).numpy()
@@ -301,7 +303,7 @@ def test_packed_stream_reproduces_the_network(precision, bend, views, tcb):
 
 def test_unsupported_architectures_are_rejected():
     lib = _lib.load()
-    for kw in (dict(netwidth=128), dict(netdepth=6), dict(multires=8), dict(bend_hidden=32), dict(latent_size=16),
+    for kw in (dict(netwidth=192), dict(netwidth=128, use_viewdirs=True), dict(netwidth=128, bend_depth=7), dict(netdepth=6), dict(multires=8), dict(bend_hidden=32), dict(latent_size=16),
                dict(bend_depth=6), dict(bend_depth=7, ray_bending=True, rigidity_depth=4)):
         scene = make_scene(SceneConfig(**kw), 0)
         rb, coarse, fine = build_modules(scene)
