@@ -112,3 +112,124 @@ class OverlappedGather:
                 self.pending[b] = None
         if self.cuda and (self.world > 1 or self.force_collective):
             torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
+class GradientBuckets:
+    """Data-parallel TRAINING: every rank renders its slice of the ray batch, gradients are averaged over ranks.
+
+    Replaces ``nn.DataParallel(training_wrapper_class)`` (train.py:300-323, 1562-1573: per step the parameters are
+    re-broadcast from GPU0, the ray batch scattered, the per-GPU losses gathered and averaged on GPU0, and backward runs
+    through the replicas into GPU0's parameters).  Here every process owns a replica; the only exchange of a step is one
+    all-reduce per bucket of gradients (RCCL over xGMI; a ring all-reduce of B bytes moves 2 B (G-1)/G per link, so the
+    4.8 MB of this model's gradients are latency-bound -- few buckets, each overlapped with the part of backward still
+    running):
+
+      * ``buckets`` is a list of parameter lists in the order their gradients become ready in backward (for
+        ``render_rays``: fine network, coarse network, ray bender + latent codes).  Each bucket owns ONE flat fp32
+        buffer; the parameters' ``.grad`` are views into it, so there is no flatten / unflatten copy around the
+        collective and zeroing the gradients is one fill per bucket (``zero_grad``; do NOT call
+        ``optimizer.zero_grad(set_to_none=True)``, it would detach the views -- ``set_to_none=False`` is fine).
+      * a post-accumulate hook per parameter counts arrivals; when a bucket is complete its all-reduce is issued
+        asynchronously from a side stream that waits for the producing kernels, while autograd goes on with the next
+        bucket's backward on the main stream;
+      * ``finish()`` (after ``loss.backward()``, before ``optimizer.step()``) joins the collectives and divides by the
+        world size (sum -> mean, matching the reference's ``loss.mean()`` over equally sized per-GPU slices).
+    A bucket with parameters that never receive a gradient is reduced in ``finish()`` the first time and from then on as
+    soon as the parameters that do have arrived.  Parameters that take part in no bucket are left alone.  With CPU tensors (gloo; the CPU test tier) there are no
+    streams and the collectives are joined the same way.  ``force_collective``: run the collectives in a one-rank group
+    too (single-GPU test of the RCCL path).
+    """
+
+    def __init__(self, buckets, group=None, force_collective: bool = False):
+        self.group = group
+        self.force_collective = force_collective
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or force_collective)
+        self.flat, self.params, self.pending, self._arrived, self._expected, self._hooks = [], [], [], [], [], []
+        for plist in buckets:
+            plist = [p for p in plist if p.requires_grad]
+            if not plist:
+                continue
+            dev = plist[0].device
+            if any(p.device != dev or p.dtype != torch.float32 for p in plist):
+                raise ValueError("a bucket holds fp32 parameters of one device")
+            flat = torch.zeros(sum(p.numel() for p in plist), dtype=torch.float32, device=dev)
+            off = 0
+            for p in plist:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            bi = len(self.flat)
+            self.flat.append(flat)
+            self.params.append(plist)
+            self.pending.append(None)
+            self._arrived.append(0)
+            self._expected.append(len(plist))
+            for p in plist:
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._on_grad(bi)))
+        self.device = self.flat[0].device if self.flat else torch.device("cpu")
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if (self.cuda and self.active) else None
+
+    def zero_grad(self):
+        for bi, flat in enumerate(self.flat):
+            flat.zero_()
+            self._arrived[bi] = 0
+            for p in self.params[bi]:          # re-attach a view someone replaced (e.g. zero_grad(set_to_none=True))
+                if p.grad is None or p.grad.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
+                    raise RuntimeError("a parameter's .grad no longer lives in its bucket (optimizer.zero_grad(set_to_none=True)?)")
+
+    def _on_grad(self, bi: int):
+        self._arrived[bi] += 1
+        if self._arrived[bi] == self._expected[bi] and self.active and self.pending[bi] is None:
+            self._reduce(bi)
+
+    def _reduce(self, bi: int):
+        flat = self.flat[bi]
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                self.pending[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.pending[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Join the step's collectives; afterwards every ``.grad`` holds the mean over ranks."""
+        if not self.active:
+            return
+        for bi in range(len(self.flat)):
+            if self.pending[bi] is None:
+                # some of the bucket's parameters received no gradient (e.g. NeRF.views_linears without use_viewdirs,
+                # rnh:196-199): reduce now, and from the next step on launch as soon as the ones that do have arrived
+                if 0 < self._arrived[bi] < self._expected[bi]:
+                    self._expected[bi] = self._arrived[bi]
+                self._reduce(bi)
+        for bi in range(len(self.flat)):
+            self.pending[bi].wait()
+            self.pending[bi] = None
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        if self.world > 1:
+            for flat in self.flat:
+                flat.div_(self.world)
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def render_buckets(network_fn, network_fine, ray_bender, latents=None):
+    """Bucket lists for ``GradientBuckets`` in the order backward produces them for ``render_rays``: fine network first,
+    then the coarse network, then the ray bender together with the latent codes (both passes contribute to those)."""
+    out = []
+    if network_fine is not None:
+        out.append(list(network_fine.parameters()))
+    out.append(list(network_fn.parameters()))
+    last = list(ray_bender.parameters()) if ray_bender is not None else []
+    if latents is not None:
+        last += list(latents) if isinstance(latents, (list, tuple)) else [latents]
+    if last:
+        out.append(last)
+    return out

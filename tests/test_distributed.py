@@ -181,3 +181,151 @@ def test_overlapped_gather_double_buffering_world_size_2(tmp_path):
                 base = 100.0 * i + 10.0 * src
                 assert torch.equal(blk[:, 0:3], torch.full((11, 3), base)) and torch.equal(blk[:, 3], torch.full((11,), base + 1)) \
                     and torch.equal(blk[:, 4], torch.full((11,), base + 2)), (r, i, src)
+
+
+def _train_setup(n):
+    """A tiny differentiable render on the CPU (the oracle, test infrastructure) with its parameters as leaves, bucketed in
+    the order backward produces them."""
+    from oracle import nrnerf_oracle as O
+    from nonrigid_nerf_amd.distributed import GradientBuckets  # noqa: F401
+    cfg = SceneConfig(N_samples=16, N_importance=8)
+    scene = make_scene(cfg, 0)
+    rays, lat = make_rays(n, 4, cfg)
+    sc = O.scene_on(scene, "cpu")
+    leaves = {}
+    for part in ("fine", "coarse", "bender"):
+        d = getattr(sc, part)
+        for k in d:
+            d[k] = d[k].clone().requires_grad_(True)
+            leaves[(part, k)] = d[k]
+    lat = lat.clone().requires_grad_(True)
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(3))
+
+    def loss_of(lo, hi):
+        out = O.render_rays(rays[lo:hi], lat[lo:hi], sc)
+        return ((out["rgb_map"] - target[lo:hi]) ** 2).mean() + ((out["rgb0"] - target[lo:hi]) ** 2).mean()
+
+    loss_of(0, 2).backward()                    # which tensors of the scene take part at all (no view-dependent head here)
+    leaves = {k: v for k, v in leaves.items() if v.grad is not None}
+    for v in list(leaves.values()) + [lat]:
+        v.grad = None
+    buckets = [[v for (p, _), v in leaves.items() if p == "fine"], [v for (p, _), v in leaves.items() if p == "coarse"],
+               [v for (p, _), v in leaves.items() if p == "bender"] + [lat]]
+    return leaves, lat, buckets, loss_of
+
+
+def _train_worker(rank, world, port, n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from nonrigid_nerf_amd.distributed import GradientBuckets
+    leaves, lat, buckets, loss_of = _train_setup(n)
+    gb = GradientBuckets(buckets)
+    lo, hi, _ = shard_bounds(n, world, rank)
+    snaps = []
+    for step in range(2):                       # two steps: the buffers are reused, zeroing must not detach the views
+        gb.zero_grad()
+        loss_of(lo, hi).backward()
+        assert all(p is not None for p in gb.pending), "every bucket's all-reduce was issued from inside backward"
+        gb.finish()
+        snaps.append({k: v.grad.clone() for k, v in leaves.items()} | {("latents", ""): lat.grad.clone()})
+    gb.close()
+    torch.save(snaps, os.path.join(out_dir, f"grads{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_gradients_world_size_2(tmp_path):
+    """GradientBuckets (the replacement of nn.DataParallel over training_wrapper_class, train.py:300-323): two gloo ranks
+    render half of the ray batch each; after finish() both hold the gradient of the full-batch mean loss, in both of two
+    consecutive steps, and the collectives were launched from inside backward (one per bucket)."""
+    world, n = 2, 16
+    mp.spawn(_train_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    leaves, lat, _, loss_of = _train_setup(n)
+    (0.5 * (loss_of(0, n // 2) + loss_of(n // 2, n))).backward()
+    want = {k: v.grad for k, v in leaves.items()} | {("latents", ""): lat.grad}
+    for r in range(world):
+        snaps = torch.load(os.path.join(str(tmp_path), f"grads{r}.pt"))
+        assert len(snaps) == 2
+        for got in snaps:
+            assert set(got) == set(want)
+            for k, g in want.items():
+                if k == ("latents", ""):
+                    # each rank only back-propagates into its own rays' codes; the mean over ranks halves them
+                    assert torch.allclose(got[k], g, rtol=1e-4, atol=1e-7 * float(g.abs().max()) + 1e-12), k
+                else:
+                    assert torch.allclose(got[k], g, rtol=1e-4, atol=1e-5 * float(g.abs().max()) + 1e-12), k
+
+
+def _native_train_grads(lo, hi, n, gb_factory=None):
+    """One native training step's gradients (HIP path, fp32 mode) on rays [lo, hi) of a fixed n-ray batch."""
+    from nonrigid_nerf_amd import render as R
+    from nonrigid_nerf_amd.synthetic import build_modules
+    dev = torch.device("cuda:0")
+    cfg = SceneConfig(N_importance=32)
+    scene = make_scene(cfg, 1)
+    rays, latents = make_rays(n, 9, cfg)
+    rb, coarse, fine = build_modules(scene, device=dev)
+    for m in (rb, coarse, fine):
+        m.requires_grad_(True)
+    lat = latents.to(dev).clone().requires_grad_(True)
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    R.set_precision("f32")
+    gb = gb_factory(coarse, fine, rb, lat) if gb_factory else None
+    issued = None
+    for step in range(2 if gb else 1):           # second step: the buckets know which parameters never get a gradient
+        if gb:
+            gb.zero_grad()
+        out = R.render_rays(rays[lo:hi].to(dev), coarse, None, cfg.N_samples, N_importance=cfg.N_importance, network_fine=fine,
+                            additional_pixel_information={"ray_bending_latents": lat[lo:hi]})
+        loss = ((out["rgb_map"] - target[lo:hi]) ** 2).mean() + ((out["rgb0"] - target[lo:hi]) ** 2).mean()
+        loss.backward()
+        if gb:
+            issued = all(p is not None for p in gb.pending)
+            gb.finish()
+    grads = {"latents": lat.grad.detach().cpu().clone()}
+    for part, mod in (("bender", rb), ("coarse", coarse), ("fine", fine)):
+        grads.update({f"{part}.{k}": p.grad.detach().cpu().clone() for k, p in mod.named_parameters() if p.grad is not None})
+    torch.cuda.synchronize()
+    return grads, issued
+
+
+def _native_dp_worker(rank, world, port, backend, n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from nonrigid_nerf_amd.distributed import GradientBuckets, render_buckets
+    lo, hi, _ = shard_bounds(n, world, rank)
+    grads, issued = _native_train_grads(lo, hi, n, lambda c, f, rb, lat: GradientBuckets(render_buckets(c, f, rb, lat), force_collective=True))
+    torch.save({"grads": grads, "issued": issued, "backend": dist.get_backend()}, os.path.join(out_dir, f"dp{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")], ids=["two_ranks_one_gpu_gloo", "one_rank_rccl"])
+def test_data_parallel_native_training_step(tmp_path, world, backend):
+    """GradientBuckets around the NATIVE training step: (a) two ranks on GPU 0 over gloo (what a 1-GPU box can run of the
+    N > 1 training path) render half of a 64-ray batch each -- both end up with the gradient of the full-batch mean loss;
+    (b) the same code over the real backend (torch "nccl" = RCCL) with a one-rank group, collectives forced.  Every
+    bucket's all-reduce must have been issued from inside backward (overlap with the rest of backward)."""
+    n = 64
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_native_dp_worker, args=(r, world, port, backend, n, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    want = {}
+    for r in range(world):                         # single process, same kernels: mean over the shards' gradients
+        lo, hi, _ = shard_bounds(n, world, r)
+        g, _ = _native_train_grads(lo, hi, n)
+        for k, v in g.items():
+            want[k] = want.get(k, 0) + v / world
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"dp{r}.pt"))
+        assert res["issued"] and res["backend"] == backend
+        extra = set(res["grads"]) - set(want)            # parameters render_rays never touches (views_linears): zero, not None
+        assert set(want) <= set(res["grads"]) and all(not res["grads"][k].any() for k in extra), extra
+        for k, g in want.items():
+            assert torch.allclose(res["grads"][k], g, rtol=1e-5, atol=1e-6 * float(g.abs().max()) + 1e-12), (r, k)
