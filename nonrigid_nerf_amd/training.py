@@ -555,4 +555,4 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=1024, steps=30, w
             "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(flops / dt / 1e12 / peak, 4),
                          "note": "algorithmic trunk flops (3 x forward: fwd, backward-data, weight gradients) over the whole step's "
-                                 "wall time, incl. the PyTorch-autograd bender, optimiser and launch overheads at this batch size"}}
+                                 "wall time, incl. the bender's own kernels, the library GEMMs / reductions, optimiser and launch overheads at this batch size"}}
