@@ -492,11 +492,17 @@ int pack_split(const nrnerf_model_desc& d, PackedPass& trunk, PackedPass& bend, 
 
 // transposed trunk weights for the backward-data kernel; eligible models only (see nrnerf_model::train_ok)
 bool training_eligible(const nrnerf_model_desc& d, const nrnerf_model* m) {
-    return !m->views && m->arch_id <= 1 && !d.coarse->time_conditioned && d.precision != NRNERF_PREC_F16;
+    return !m->views && (m->arch_id <= 1 || m->arch_id == 5) && !d.coarse->time_conditioned && d.precision != NRNERF_PREC_F16;
 }
 void pack_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPass& out, const FlatLayout* lay = nullptr) {
-    if (d.precision == NRNERF_PREC_F32) pack_pass_bwd<ShapeF32, ArchDefault>(mlp, d.precision, out, lay);
-    else pack_pass_bwd<Shape16, ArchDefault>(mlp, d.precision, out, lay);
+    const bool narrow = mlp.width == ArchNarrow::W;
+    if (d.precision == NRNERF_PREC_F32) {
+        if (narrow) pack_pass_bwd<ShapeF32, ArchNarrow>(mlp, d.precision, out, lay);
+        else pack_pass_bwd<ShapeF32, ArchDefault>(mlp, d.precision, out, lay);
+    } else {
+        if (narrow) pack_pass_bwd<Shape16, ArchNarrow>(mlp, d.precision, out, lay);
+        else pack_pass_bwd<Shape16, ArchDefault>(mlp, d.precision, out, lay);
+    }
 }
 int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t refresh_stream = nullptr, bool refresh = false,
                     const FlatLayout* lay = nullptr) {
@@ -517,7 +523,7 @@ int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t ref
         PackedPass bfw, bbw;
         nrnerf_model_desc d32 = d;
         d32.precision = NRNERF_PREC_F32;
-        if (m->arch_id == 0) {
+        if (bender_arch(m->arch_id) == 0) {       // the bender-only plan does not depend on the trunk's width
             pack_pass<ShapeF32, ArchDefault, true, false, false>(d32, *d.coarse, NRNERF_PREC_F32, bfw, lay);
             pack_pass_bwd_bender<ArchDefault>(*d.bender, bbw, lay);
         } else {
@@ -568,16 +574,16 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
         const nrnerf_mlp_desc* mm = (which == 5 && desc->fine) ? desc->fine : desc->coarse;
         int arch_id = 0;
         rc = pack_dispatch(d2, *mm, fwd, &arch_id);   // validates the architecture
-        if (rc == NRNERF_OK && arch_id != 0) rc = NRNERF_ERR_UNSUPPORTED;      // training kernels: the default trunk only
+        if (rc == NRNERF_OK && arch_id != 0 && arch_id != 5) rc = NRNERF_ERR_UNSUPPORTED;      // training kernels: trunks of width 256 / 128
         if (rc == NRNERF_OK) pack_bwd(*desc, *mm, pk);
     } else if (which == 6) {                     // transposed bender / rigidity weights of its backward-data kernel (fp32)
         if (!desc->bender) return NRNERF_ERR_UNSUPPORTED;
         PackedPass fwd;
         int arch_id = 0;
         rc = pack_dispatch(*desc, *desc->coarse, fwd, &arch_id);
-        if (rc == NRNERF_OK && arch_id > 1) rc = NRNERF_ERR_UNSUPPORTED;
+        if (rc == NRNERF_OK && arch_id > 1 && arch_id != 5) rc = NRNERF_ERR_UNSUPPORTED;
         if (rc == NRNERF_OK) {
-            if (arch_id == 0) pack_pass_bwd_bender<ArchDefault>(*desc->bender, pk);
+            if (bender_arch(arch_id) == 0) pack_pass_bwd_bender<ArchDefault>(*desc->bender, pk);
             else pack_pass_bwd_bender<ArchDeepBend>(*desc->bender, pk);
         }
     } else {
@@ -996,8 +1002,10 @@ int nrnerf_trunk_forward(const nrnerf_model* m, const nrnerf_trunk_args* a, void
     if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    const hipError_t e = (m->precision == NRNERF_PREC_F32) ? launch_trunk_fwd_train_f32(t, m->num_cus, (hipStream_t)hip_stream)
-                                                           : launch_trunk_fwd_train_bf16(t, m->num_cus, (hipStream_t)hip_stream);
+    const bool f32 = m->precision == NRNERF_PREC_F32;
+    const hipStream_t s = (hipStream_t)hip_stream;
+    const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_fwd_train_f32_a5(t, m->num_cus, s) : launch_trunk_fwd_train_bf16_a5(t, m->num_cus, s))
+                                           : (f32 ? launch_trunk_fwd_train_f32(t, m->num_cus, s) : launch_trunk_fwd_train_bf16(t, m->num_cus, s));
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 
@@ -1008,8 +1016,10 @@ int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, voi
     if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    const hipError_t e = (m->precision == NRNERF_PREC_F32) ? launch_trunk_bwd_f32(t, m->num_cus, (hipStream_t)hip_stream)
-                                                           : launch_trunk_bwd_bf16(t, m->num_cus, (hipStream_t)hip_stream);
+    const bool f32 = m->precision == NRNERF_PREC_F32;
+    const hipStream_t s = (hipStream_t)hip_stream;
+    const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_bwd_f32_a5(t, m->num_cus, s) : launch_trunk_bwd_bf16_a5(t, m->num_cus, s))
+                                           : (f32 ? launch_trunk_bwd_f32(t, m->num_cus, s) : launch_trunk_bwd_bf16(t, m->num_cus, s));
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 
@@ -1042,7 +1052,7 @@ int nrnerf_bender_forward(const nrnerf_model* m, const nrnerf_bender_args* a, vo
     if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    const hipError_t e = (m->arch_id == 0) ? launch_bend_fwd_train_a0(t, m->num_cus, (hipStream_t)hip_stream)
+    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_fwd_train_a0(t, m->num_cus, (hipStream_t)hip_stream)
                                            : launch_bend_fwd_train_a1(t, m->num_cus, (hipStream_t)hip_stream);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
@@ -1054,7 +1064,7 @@ int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, v
     if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    const hipError_t e = (m->arch_id == 0) ? launch_bend_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
+    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
                                            : launch_bend_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }

@@ -121,6 +121,10 @@ hipError_t launch_trunk_fwd_train_f32(const TrunkArgs&, int num_cus, hipStream_t
 hipError_t launch_trunk_fwd_train_bf16(const TrunkArgs&, int num_cus, hipStream_t);
 hipError_t launch_trunk_bwd_f32(const TrunkArgs&, int num_cus, hipStream_t);
 hipError_t launch_trunk_bwd_bf16(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_fwd_train_f32_a5(const TrunkArgs&, int num_cus, hipStream_t);      // architecture 5: trunk width 128
+hipError_t launch_trunk_fwd_train_bf16_a5(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_bwd_f32_a5(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_bwd_bf16_a5(const TrunkArgs&, int num_cus, hipStream_t);
 
 // training kernels of the ray bender (nrnerf_train_bend.h): forward with saved activations, backward-data; always fp32
 struct BendTrainArgs {

@@ -17,7 +17,7 @@ What is native (C ABI ``nrnerf_trunk_forward / _backward``, ``nrnerf_composite_f
 What is left to libraries, as plumbing:
   * the weight gradients ``dW_i = dz_i^T x_i``: plain [out x K] x [K x in] GEMMs over the two arrays the kernels fill
     (``torch.bmm`` = hipBLASLt), and the bias gradients (column sums).
-Eligible: the default architecture without view-dependent head / time conditioning, precision fp32 or bf16
+Eligible: the default architecture (trunk width 256 or 128) without view-dependent head / time conditioning, precision fp32 or bf16
 (``render.set_precision``; "f16" trains in bf16: unscaled f16 gradients underflow).  Anything else is handed to the
 reference by ``render.render_rays`` as before.
 """
@@ -384,7 +384,7 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
             continue
         if getattr(net, "use_viewdirs", False) or getattr(net, "time_conditioned_baseline", False):
             return "view-dependent head / time-conditioned baseline under autograd"
-        if int(net.D) != 8 or int(net.W) != 256 or list(net.skips) != [4] or int(net.input_ch) != 63:
+        if int(net.D) != 8 or int(net.W) not in (256, 128) or list(net.skips) != [4] or int(net.input_ch) != 63:
             return "non-default trunk under autograd"
     if N_samples < 2 or N_samples + N_importance > 256:
         return "more than 256 samples per ray"

@@ -356,14 +356,16 @@ def test_split_bender_images_are_the_two_halves_of_the_fused_stream(precision, b
     assert lib.nrnerf_pack_host(C.byref(desc), 3, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("width", [256, 128])
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_backward_stream_reproduces_autograd_of_the_trunk(precision):
+def test_backward_stream_reproduces_autograd_of_the_trunk(precision, width):
     """Training (csrc/nrnerf_train.h): the backward-data kernel streams TRANSPOSED weights in PlanB's order (head^T, then
     pts_linears[7..1]^T, then pts_linears[0]^T; nrnerf_pack_host which = 5).  Emulating its register dataflow in numpy --
     d raw as the first B operand, relu masks from the forward activations, the skip layer's first two tiles and the last
     layer's two tiles being the encoding's gradient in encoding-SLOT order -- must reproduce torch.autograd's gradient
     wrt the encoded input."""
-    cfg = SceneConfig(N_importance=128)
+    cfg = SceneConfig(N_importance=128, netwidth=width)
+    NT = width // 32
     scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=5)
     assert not bias.any(), "backward layers have no bias"
     KH = 1 if precision == "f32" else 8
@@ -392,11 +394,11 @@ def test_backward_stream_reproduces_autograd_of_the_trunk(precision):
     v[:5] = d_raw.numpy().T
     slabs = vec_slabs(v, KH, rnd)
     tile0, mfma = 0, 0
-    tiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs); mfma += len(slabs) * 8; tile0 += 8          # head^T -> d h_7
+    tiles = dense_emul(fr, bias, tile0, len(slabs), NT, slabs); mfma += len(slabs) * NT; tile0 += NT       # head^T -> d h_7
     denc = None
     for i in range(7, 0, -1):
         slabs = repack(mask_tiles(tiles, i), KH, False, rnd)
-        nt = 10 if i == 5 else 8
+        nt = NT + 2 if i == 5 else NT
         out = dense_emul(fr, bias, tile0, len(slabs), nt, slabs); mfma += len(slabs) * nt; tile0 += nt
         if i == 5:
             denc, tiles = out[:2], out[2:]

@@ -151,8 +151,9 @@ def _loss(out, detailed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("perturb,noise,detailed,cfg_kw", [(0.0, 0.0, False, dict(N_importance=64)),
                                                            (1.0, 1.0, True, dict(N_samples=48, N_importance=37)),
-                                                           (1.0, 0.5, False, dict(N_importance=128, ray_bending=False))],
-                         ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128"])
+                                                           (1.0, 0.5, False, dict(N_importance=128, ray_bending=False)),
+                                                           (1.0, 0.0, False, dict(N_importance=64, netwidth=128))],
+                         ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128"])
 @pytest.mark.parametrize("bender", ["torch_ops", "native"])
 def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, bender):
     """Every parameter of every network + the latent codes, fp32 mode, against the oracle's autograd (eager torch on the
@@ -316,15 +317,16 @@ def test_native_training_fits_the_example_sequence_and_refreshes_weights_on_the_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", [dict(), dict(rigidity_test_time_cutoff=0.58, test_time_scaling=0.7)], ids=["plain", "cutoff_scaling"])
+@pytest.mark.parametrize("knobs,bend_depth", [(dict(), 5), (dict(rigidity_test_time_cutoff=0.58, test_time_scaling=0.7), 5), (dict(), 7)],
+                         ids=["plain", "cutoff_scaling", "deep_bender"])
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_native_bender_forward_and_gradients_vs_torch_autograd(precision, knobs):
+def test_native_bender_forward_and_gradients_vs_torch_autograd(precision, knobs, bend_depth):
     """nrnerf_bender_forward / _backward (csrc/nrnerf_train_bend.h, always fp32) against torch.autograd over the same
     layers written as torch ops (training.bend), on the bender ALONE -- without the 2^9-frequency encoding behind it the
-    comparison is well conditioned: outputs within 2e-6, every gradient (latent codes, all 15 parameter tensors) within
+    comparison is well conditioned: outputs within 2e-6, every gradient (latent codes, all 15 / 19 parameter tensors) within
     1e-4 of its scale, for random upstream gradients of all three differentiable outputs; ragged sample count."""
     from nonrigid_nerf_amd import training
-    cfg = SceneConfig(N_importance=64)
+    cfg = SceneConfig(N_importance=64, bend_depth=bend_depth)
     scene = make_scene(cfg, 2)
     N, S = 77, 83
     rays, latents = make_rays(N, 5, cfg)
@@ -367,7 +369,7 @@ def test_native_bender_forward_and_gradients_vs_torch_autograd(precision, knobs)
         assert float((d_n[k] - d_t[k]).abs().max()) <= 2e-6, k
     if knobs:
         assert float((d_t["rigidity_mask"] == 0).float().mean()) > 0.02, "the cutoff should bite on this scene"
-    assert set(g_n) == set(g_t) and len(g_t) == 16
+    assert set(g_n) == set(g_t) and len(g_t) == 2 * bend_depth + 6
     worst = 0.0
     for k, want in g_t.items():
         scale = float(want.abs().max()) + 1e-12

@@ -75,4 +75,7 @@ def test_eligibility_of_training_calls():
     assert T.why_not_trainable(coarse, fine, 64, 64, False, False, OnGpu) is None
     cfgw = SceneConfig(N_importance=64, netwidth=128)
     _, cw, fw = build_modules(make_scene(cfgw, 0))
+    assert T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu) is None      # the second compiled trunk width
+    cfgw = SceneConfig(N_importance=64, netwidth=192)
+    _, cw, fw = build_modules(make_scene(cfgw, 0))
     assert "non-default trunk" in T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu)
