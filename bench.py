@@ -341,11 +341,12 @@ def library_gemm_tflops(dev, precision):
 
 
 def kernel_source_sha16():
-    """Hash of the device code the library is built from (csrc/*.h, *.hip: plans, kernels, launchers): identifies the
-    kernels independently of the build (a rebuilt .so need not be byte-identical) and of host-only edits (nrnerf_api.cpp)."""
+    """Hash of the device code the rendering kernels are built from (csrc/*.h, *.hip: plans, kernels, launchers; the
+    training-only kernels nrnerf_train* excluded): identifies the profiled kernels independently of the build (a rebuilt
+    .so need not be byte-identical) and of host-only edits (nrnerf_api.cpp)."""
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "nonrigid_nerf_amd", "csrc")
-    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hip"))):
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hip")) and not f.startswith("nrnerf_train")):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -377,8 +377,6 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
         return "pytest flag (numpy-seeded random numbers)"
     if ray_batch.device.type != "cuda":
         return "rays are not on a ROCm device"
-    if lindisp:
-        return "lindisp under autograd"
     for net in (network_fn, network_fine if N_importance > 0 else None):
         if net is None:
             continue
@@ -395,7 +393,7 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
 
 def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.0, N_importance=0, network_fine=None,
                       white_bkgd=False, raw_noise_std=0.0, additional_pixel_information=None, detailed_output=False,
-                      want_z_vals=False):
+                      want_z_vals=False, lindisp=False):
     """reference render_rays (train.py:792-980) with autograd: same output dict, attached to the graph of the networks',
     the bender's and the latent codes' parameters."""
     dev = ray_batch.device
@@ -413,7 +411,10 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     # random numbers in the reference's order (train.py:860, 753; run_nerf_helpers.py:665; 753)
     rnd = R._draw_randoms(rays, S, I, perturb, raw_noise_std) or {}
     t_vals = torch.linspace(0.0, 1.0, steps=S, device=dev)                                   # :847
-    z_vals = (near * (1.0 - t_vals) + far * t_vals).expand(N, S)                             # :849, 853
+    if not lindisp:
+        z_vals = (near * (1.0 - t_vals) + far * t_vals).expand(N, S)                         # :849, 853
+    else:
+        z_vals = (1.0 / (1.0 / near * (1.0 - t_vals) + 1.0 / far * t_vals)).expand(N, S)     # :851
     if "u_coarse" in rnd:
         mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])                                    # :857
         upper = torch.cat([mids, z_vals[..., -1:]], -1)

@@ -115,7 +115,7 @@ def test_gradients_match_reference_autograd_golden(torch_ops_bender):
           "(ours | the oracle on this device): " + "; ".join(f"{k[6:]} {e:.1e} | {d:.1e}" for k, e, d in report))
 
 
-def _oracle_grads(scene, rays, latents, seed, perturb, noise, detailed_loss, z_override=None):
+def _oracle_grads(scene, rays, latents, seed, perturb, noise, detailed_loss, z_override=None, **flags):
     from oracle import nrnerf_oracle as O
     sc = O.scene_on(scene, DEV)
     leaves = {}
@@ -129,7 +129,7 @@ def _oracle_grads(scene, rays, latents, seed, perturb, noise, detailed_loss, z_o
     lat = latents.to(DEV).clone().requires_grad_(True)
     torch.manual_seed(seed)
     out = O.render_rays(rays.to(DEV), lat, sc, retraw=True, detailed_output=detailed_loss, perturb=perturb, raw_noise_std=noise,
-                        z_fine_override=z_override)
+                        z_fine_override=z_override, **flags)
     loss = _loss(out, detailed_loss)
     loss.backward()
     return float(loss.detach()), lat.grad, {k: v.grad for k, v in leaves.items()}, out
@@ -138,7 +138,10 @@ def _oracle_grads(scene, rays, latents, seed, perturb, noise, detailed_loss, z_o
 def _loss(out, detailed):
     target = torch.linspace(0.1, 0.9, 3, device=out["rgb_map"].device)
     loss = ((out["rgb_map"] - target) ** 2).mean() + ((out["rgb0"] - target) ** 2).mean() + 0.1 * out["acc_map"].mean()
-    loss = loss + 0.05 * (out["disp_map"].clamp(max=50.0)).mean() * 1e-2
+    if not bool(torch.isnan(out["disp_map"]).any()):
+        # (a ray without any opacity has disp = 1 / max(1e-10, 0 / 0) = NaN, train.py:781, and autograd then turns every
+        #  gradient into NaN even under a mask -- in the reference too, whose training loss never touches disp_map)
+        loss = loss + 0.05 * (out["disp_map"].clamp(max=50.0)).mean() * 1e-2
     if detailed:        # the offsets regulariser's shape (train.py:219-236): detached weights x offset norms, plus the rigidity term
         w = out["visibility_weights"].detach()
         off = torch.norm(out["unmasked_offsets"], dim=-1)
@@ -152,8 +155,9 @@ def _loss(out, detailed):
 @pytest.mark.parametrize("perturb,noise,detailed,cfg_kw", [(0.0, 0.0, False, dict(N_importance=64)),
                                                            (1.0, 1.0, True, dict(N_samples=48, N_importance=37)),
                                                            (1.0, 0.5, False, dict(N_importance=128, ray_bending=False)),
-                                                           (1.0, 0.0, False, dict(N_importance=64, netwidth=128))],
-                         ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128"])
+                                                           (1.0, 0.0, False, dict(N_importance=64, netwidth=128)),
+                                                           (0.0, 0.0, False, dict(N_importance=64, _lindisp=True, _white_bkgd=True))],
+                         ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128", "lindisp_white_bkgd"])
 @pytest.mark.parametrize("bender", ["torch_ops", "native"])
 def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, bender):
     """Every parameter of every network + the latent codes, fp32 mode, against the oracle's autograd (eager torch on the
@@ -167,6 +171,8 @@ def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, ben
     a 5e-2 bar here and their tight check in test_native_bender_forward_and_gradients_vs_torch_autograd (1e-4, bender
     alone); the trunk / head tensors keep the 2e-3 bar."""
     from nonrigid_nerf_amd import training
+    flags = {k[1:]: v for k, v in cfg_kw.items() if k.startswith("_")}      # render_rays flags (train.py:799, 802), not scene settings
+    cfg_kw = {k: v for k, v in cfg_kw.items() if not k.startswith("_")}
     if bender == "native" and not SceneConfig(**cfg_kw).ray_bending:
         pytest.skip("no bender in this case")
     loose = 5e-2 if bender == "native" else 2e-3
@@ -181,12 +187,12 @@ def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, ben
     training.NATIVE_BENDER, training.BATCHED_BENDER = bender == "native", False      # torch_ops: the oracle's bent points, bit for bit
     out = R.render_rays(rays.to(DEV), coarse, None, cfg.N_samples, retraw=True, perturb=perturb, N_importance=cfg.N_importance,
                         network_fine=fine, raw_noise_std=noise, additional_pixel_information={"ray_bending_latents": lat},
-                        detailed_output=detailed, _want_z_vals=True)
+                        detailed_output=detailed, _want_z_vals=True, **flags)
     training.NATIVE_BENDER, training.BATCHED_BENDER = saved
     z_ours = out.pop("_z_vals").detach()
     loss = _loss(out, detailed)
     loss.backward()
-    l_ref, glat_ref, g_ref, out_ref = _oracle_grads(scene, rays, latents, 99, perturb, noise, detailed, z_override=z_ours)
+    l_ref, glat_ref, g_ref, out_ref = _oracle_grads(scene, rays, latents, 99, perturb, noise, detailed, z_override=z_ours, **flags)
     assert set(out) == set(k for k in out_ref if not k.startswith("_"))
     for k in ("rgb_map", "rgb0", "acc_map"):
         assert torch.allclose(out[k], out_ref[k].detach(), atol=1e-4), k
@@ -211,16 +217,16 @@ def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, ben
     assert not fails, fails
     # free-running (the oracle draws its own importance samples): the sample_pdf branch may move a sample on a few rays
     torch.manual_seed(99)
-    free = O_render_free(scene, rays, latents, perturb, noise, detailed)
+    free = O_render_free(scene, rays, latents, perturb, noise, detailed, **flags)
     moved = ((z_ours - free).abs() > 2e-5).float().mean().item()
     assert moved < 0.02, moved
 
 
-def O_render_free(scene, rays, latents, perturb, noise, detailed):
+def O_render_free(scene, rays, latents, perturb, noise, detailed, **flags):
     from oracle import nrnerf_oracle as O
     with torch.no_grad():
         return O.render_rays(rays.to(DEV), latents.to(DEV), O.scene_on(scene, DEV), detailed_output=detailed, perturb=perturb,
-                             raw_noise_std=noise)["_z_vals"]
+                             raw_noise_std=noise, **flags)["_z_vals"]
 
 
 @pytest.mark.gpu

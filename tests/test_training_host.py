@@ -69,7 +69,7 @@ def test_eligibility_of_training_calls():
         device = torch.device("cuda", 0)
 
     assert "view-dependent" in T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu)
-    assert T.why_not_trainable(coarse, fine, 64, 64, True, False, OnGpu) == "lindisp under autograd"
+    assert T.why_not_trainable(coarse, fine, 64, 64, True, False, OnGpu) is None                  # lindisp trains natively
     assert T.why_not_trainable(coarse, fine, 64, 64, False, True, OnGpu).startswith("pytest flag")
     assert T.why_not_trainable(coarse, fine, 200, 100, False, False, OnGpu) == "more than 256 samples per ray"
     assert T.why_not_trainable(coarse, fine, 64, 64, False, False, OnGpu) is None
