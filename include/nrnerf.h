@@ -208,11 +208,12 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
  * current device may be any: the launches are issued on the model's device and the previous one is restored.
  *
  * Kernel sequence.  Default: coarse network -> composite + sample_pdf + merge -> fine network -> composite.  With a ray
- * bender, no view-dependent head, n_importance > 0 and no per-sample detail outputs requested, the fine pass is split
- * (same results, bit for bit): the coarse network kernel also writes its bent points; the coarse samples keep them in
+ * bender (view directions, if any, by finite differences), n_importance > 0 and no per-sample detail outputs requested,
+ * the fine pass is split (same results, bit for bit): the coarse network kernel also writes its bent points; the coarse samples keep them in
  * the fine pass (the bender is shared by both networks, run_nerf_helpers.py:213-215, and the coarse depths are a subset
  * of the merged depths, train.py:920); a stand-alone bender kernel handles the n_importance new samples; the fine
- * network kernel runs its trunk on those points.  Environment variables (read once): NRNERF_FUSED_FINE_BENDER=1 keeps
+ * network kernel runs its trunk on those points (and takes a sample's view direction from the differences of
+ * neighbouring points of that array).  Environment variables (read once): NRNERF_FUSED_FINE_BENDER=1 keeps
  * the fused fine pass, NRNERF_SPLIT_COARSE=1 also splits the coarse pass (bender kernel + trunk-only kernel; measured
  * no faster than the fused coarse kernel). */
 int nrnerf_render(const nrnerf_model* model, const nrnerf_render_args* args, void* hip_stream);
@@ -322,7 +323,7 @@ int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchroni
 
 /* Host-only packing (no device needed): writes the MFMA-fragment weight stream + unit table + bias
  * table of one pass exactly as nrnerf_model_create uploads them.  which: 0 = coarse, 1 = fine, 2 = fine without the
- * bender layers, 3 = bender + rigidity layers alone (2, 3: the split-bender path; need a bender and no view-dependent head),
+ * bender layers, 3 = bender + rigidity layers alone (2, 3: the split-bender path; need a bender and not the exact view directions),
  * 4 / 5 = transposed trunk weights of the coarse / fine network for the backward-data kernel (training),
  * 6 = transposed bender + rigidity weights for nrnerf_bender_backward (always fp32).
  * Any output pointer may be NULL to query sizes only.  Used by the CPU-side packing tests. */

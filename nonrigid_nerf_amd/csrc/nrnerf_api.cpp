@@ -419,7 +419,7 @@ struct nrnerf_model {
     int device = 0, precision = 0, has_bend = 0, views = 0, arch_id = 0, needs_latents = 0, num_cus = 0, latent_size = 0, exact = 0;
     PassDev coarse, fine;
     bool fine_is_coarse = false;
-    // split-bender path (bender, no view-dependent head): the fine network WITHOUT the bender layers (its input points
+    // split-bender path (bender; finite-difference view directions if any): the fine network WITHOUT the bender layers (its input points
     // come from the stand-alone bender kernel) and the bender + rigidity layers alone
     PassDev fine_trunk, coarse_trunk, bend_only;
     bool split_ok = false;
@@ -563,7 +563,7 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
     PackedPass pk;
     int rc;
     if (which == 2 || which == 3) {
-        if (!desc->bender || desc->coarse->use_viewdirs) return NRNERF_ERR_UNSUPPORTED;
+        if (!desc->bender || (desc->coarse->use_viewdirs && desc->exact_viewdirs)) return NRNERF_ERR_UNSUPPORTED;
         PackedPass other;
         rc = (which == 2) ? pack_split(*desc, pk, other) : pack_split(*desc, other, pk);
     } else if (which == 4 || which == 5) {       // transposed trunk weights of the backward-data kernel (training)
@@ -654,7 +654,7 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
         m->fine = m->coarse;
         m->fine_is_coarse = true;
     }
-    if (rc == NRNERF_OK && m->has_bend && !m->views) {
+    if (rc == NRNERF_OK && m->has_bend && !m->exact) {       // (exact view directions need the bender's Jacobian: fused only)
         PackedPass pt, pb, pct;
         if (pack_split(*desc, pt, pb, &pct, &lay) == NRNERF_OK) {
             rc = upload_pass(pt, m->fine_trunk);
@@ -881,7 +881,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         na.pts4 = bent_c; na.bent4 = nullptr;
         na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
         e = timed(0, (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
-                  [&] { return launch_net(m->precision, false, false, trunk_arch(m->arch_id), na, m->num_cus, stream); });
+                  [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), na, m->num_cus, stream); });
     } else {
         e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
                   [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
@@ -933,7 +933,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         nf.pts4 = bent4; nf.bent4 = nullptr;
         nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
         e = timed(2, (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,
-                  [&] { return launch_net(m->precision, false, false, trunk_arch(m->arch_id), nf, m->num_cus, stream); });
+                  [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), nf, m->num_cus, stream); });
     } else {
         nf.wstream = m->fine.stream; nf.bias = m->fine.bias;
         nf.bent4 = bent4;

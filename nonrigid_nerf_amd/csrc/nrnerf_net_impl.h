@@ -853,6 +853,16 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
                 const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dd[0], dd[0]), __fmul_rn(dd[1], dd[1])), __fmul_rn(dd[2], dd[2])));
 #pragma unroll
                 for (int c = 0; c < 3; ++c) dirv[c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f));
+            } else if (a.pts4) {
+                // split-bender path: the points are the bent points of nrnerf_bend.h, so the direction is their finite
+                // difference along the ray exactly as in the fused kernel, the neighbour read from the same array
+                const f32x4 nb = *(const f32x4*)(a.pts4 + (sidx == 0 ? so + 1 : so - 1) * 4);
+                float dd[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dd[c] = (sidx == 0) ? __fsub_rn(nb[c], p[c]) : __fsub_rn(p[c], nb[c]);
+                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dd[0], dd[0]), __fmul_rn(dd[1], dd[1])), __fmul_rn(dd[2], dd[2])));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dirv[c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f));
             } else {
                 dirv[0] = rp[8]; dirv[1] = rp[9]; dirv[2] = rp[10];
             }

@@ -457,6 +457,19 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
 #pragma unroll
                     for (int c = 0; c < 3; ++c) dirv[b][c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f));
                 NRN_ENDB
+            } else if (a.pts4) {
+                // split-bender path: the points are the bent points of nrnerf_bend.h, so the direction is their finite
+                // difference along the ray exactly as in the fused kernel, the neighbour read from the same array
+                NRN_FORB(b)
+                    const bool first_in_ray = (sidx[b] == 0);
+                    const f32x4 nb = *(const f32x4*)(a.pts4 + (first_in_ray ? so[b] + 1 : so[b] - 1) * 4);
+                    float dd[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dd[c] = first_in_ray ? __fsub_rn(nb[c], p[b][c]) : __fsub_rn(p[b][c], nb[c]);
+                    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dd[0], dd[0]), __fmul_rn(dd[1], dd[1])), __fmul_rn(dd[2], dd[2])));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dirv[b][c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f));
+                NRN_ENDB
             } else {
                 NRN_FORB(b) dirv[b][0] = rp[b][8]; dirv[b][1] = rp[b][9]; dirv[b][2] = rp[b][10]; NRN_ENDB
             }

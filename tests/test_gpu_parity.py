@@ -353,7 +353,7 @@ def test_million_ray_launch_bf16():
 
 
 def test_boundary_contract_errors_and_fallback():
-    cfg = SceneConfig(netwidth=128, N_importance=64)        # no kernel compiled for W = 128
+    cfg = SceneConfig(netwidth=192, N_importance=64)        # no kernel compiled for W = 192 (256 and 128 are)
     scene = make_scene(cfg, 0)
     rays, latents = make_rays(8, 0, cfg)
     with pytest.raises(R.Unsupported):
@@ -783,7 +783,9 @@ def test_render_path_and_surface_reduction_match_reference_golden():
     (dict(N_importance=64), {}, dict(perturb=1.0, raw_noise_std=0.5)),
     (dict(N_samples=128, N_importance=128), {}, dict(lindisp=True, white_bkgd=True)),
     (dict(N_importance=64, netwidth=128), {}, {}),
-], ids=["headline", "deep_bender", "ragged_knobs", "stochastic", "max_samples_flags", "narrow_128"])
+    (dict(N_importance=64, use_viewdirs=True), {}, {}),
+    (dict(N_samples=48, N_importance=37, use_viewdirs=True, bend_depth=7), dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5), {}),
+], ids=["headline", "deep_bender", "ragged_knobs", "stochastic", "max_samples_flags", "narrow_128", "viewdirs", "config4_ragged_knobs"])
 def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg_kw, knobs, flags):
     """nrnerf_render's split-bender path (coarse bent points carried over, stand-alone bender kernel for the importance
     samples, trunk-only fine kernel; nrnerf_bend.h) against the fused fine pass, which a request for per-sample detail
@@ -812,6 +814,21 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
     assert "fine_input_pts" in fused and "fine_input_pts" not in split
     if precision == "bf16":
         _assert_split_equals_fused_up_to_conversion_ties(split, fused)
+        return
+    if cfg.use_viewdirs:
+        # View-dependent head: the trunk-only kernel takes a sample's direction from the same bent points (read back from
+        # the array instead of shuffled between lanes), but it is another template instantiation and hipcc rounds the
+        # direction encoding's fp32 arithmetic differently in the two (the same effect as between the one- and the
+        # two-blocks-per-wave kernels): sigma, depths and the coarse maps stay bit-identical, colour
+        # logits differ by an ulp on a few per cent of the samples (measured, tools/debug_split_views.py: f32 1.7 % of the
+        # samples by <= 2.4e-7, rgb_map <= 6e-8; f16 0.1 % by <= 1.1e-4, rgb_map <= 1.2e-6).
+        for k in ("rgb0", "disp0", "acc0", "z_std", "_z_vals", "disp_map", "acc_map", "median_index", "surface_pts", "surface_rigidity"):
+            assert torch.equal(torch.nan_to_num(split[k].float()), torch.nan_to_num(fused[k].float())), k
+        assert torch.equal(split["raw"][..., 3], fused["raw"][..., 3])
+        d = (split["raw"][..., :3] - fused["raw"][..., :3]).abs()
+        tol, frac = (1e-6, 0.04) if precision == "f32" else (5e-4, 0.01)
+        assert d.max().item() <= tol and (d.amax(-1) > 0).float().mean().item() <= frac, (d.max().item(), (d.amax(-1) > 0).float().mean().item())
+        assert (split["rgb_map"] - fused["rgb_map"]).abs().max().item() <= tol
         return
     for k in split:
         assert torch.equal(torch.nan_to_num(split[k].float()), torch.nan_to_num(fused[k].float())), k
