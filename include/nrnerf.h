@@ -245,15 +245,21 @@ typedef struct nrnerf_trunk_args {
     int32_t which;              /* 0 = network_fn (coarse), 1 = network_fine */
     int32_t n_rays, n_samples;  /* M = n_rays * n_samples points, sample-major per ray */
     const float* pts4;          /* [M,4] network input points: xyz + one pad float */
-    void* acts;                 /* [depth][M][width] relu(W_i x_i + b_i): float (fp32 mode) / bf16 (bf16 mode); forward
-                                   writes, backward reads */
+    void* acts;                 /* relu(W_i x_i + b_i) of every hidden layer, forward writes.  fp32 mode: float
+                                   [depth][M][width] (backward reads it).  bf16 mode: bf16 [depth][B][width][32], B =
+                                   n_rays * ceil(n_samples / 32) blocks of 32 consecutive samples of a ray, the samples
+                                   contiguous (columns beyond the ray's end: finite padding) -- the operand layout of
+                                   nrnerf_trunk_wgrad */
+    void* relu_mask;            /* bf16 mode only: uint16 [depth][B][width/32][64], which values passed the relu; forward
+                                   writes, backward reads (instead of acts) */
     /* forward */
     float* raw4;                /* out [M,4]  rgb + sigma logits (what nrnerf_composite_* consume) */
     float* raw;                 /* out [M,raw_ch] all output channels ("raw" of render_rays), or NULL */
     int32_t raw_ch;             /* 4 or 5 */
     /* backward */
     const float* d_raw4;        /* [M,4] gradient wrt raw4 */
-    void* d_pre;                /* out [depth][M][width] gradient wrt every layer's pre-activation, type of acts */
+    void* d_pre;                /* out: gradient wrt every layer's pre-activation, type and layout of acts (zero in the
+                                   padded columns) */
     float* d_pts4;              /* out [M,4] gradient wrt the input points (xyz, 0) */
 } nrnerf_trunk_args;
 int nrnerf_trunk_forward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);
@@ -294,6 +300,29 @@ typedef struct nrnerf_bender_args {
 } nrnerf_bender_args;
 int nrnerf_bender_forward(const nrnerf_model* model, const nrnerf_bender_args* args, void* hip_stream);
 int nrnerf_bender_backward(const nrnerf_model* model, const nrnerf_bender_args* args, void* hip_stream);
+
+/* bf16 mode: the weight and bias gradients of the trunk from the two arrays nrnerf_trunk_forward / _backward filled, in
+ * one launch over their [block][feature][32 samples] layout (the contraction runs over samples; no transposes):
+ *   dw_hidden[i-1] = d_pre[i]^T acts[i-1]  (i = 1 .. depth-1; the skip layer's columns for its encoding input are in dw_enc)
+ *   dw_enc[0] = d_pre[0]^T enc,  dw_enc[1] = d_pre[skip+1]^T enc     (64 columns: the 63 encoding columns + one of padding)
+ *   dw_head^T = acts[depth-1]^T g                                    (64 columns: the output channels, zero padded)
+ *   db[i] = row sums of d_pre[i]
+ * each as n_partials partial sums (one per workgroup) the caller adds up.  enc / g: the encoding of the input points and
+ * the gradient wrt the head's outputs in the same block layout, bf16 [B][64][32] (built by the caller: they are small).
+ * NRNERF_ERR_UNSUPPORTED in fp32 mode (the fp32 arrays are row-major for the library GEMMs). */
+typedef struct nrnerf_wgrad_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_wgrad_args) */
+    int32_t n_rays, n_samples;
+    const void* acts; const void* d_pre;       /* as nrnerf_trunk_args, bf16 mode */
+    const void* enc;            /* bf16 [B][64][32] */
+    const void* g_head;         /* bf16 [B][64][32] */
+    int32_t n_partials;         /* 1 .. 4096; (depth - 1) * n_partials workgroups carry the bulk of the work */
+    float* dw_hidden;           /* out [depth-1][n_partials][width][width] */
+    float* dw_enc;              /* out [2][n_partials][width][64] */
+    float* dw_head_t;           /* out [n_partials][width][64] */
+    float* db;                  /* out [depth+1][n_partials][width]; row `depth` is scratch */
+} nrnerf_wgrad_args;
+int nrnerf_trunk_wgrad(const nrnerf_model* model, const nrnerf_wgrad_args* args, void* hip_stream);
 
 /* raw2outputs (train.py:724-789) of one pass, optionally followed by sample_pdf + merge (run_nerf_helpers.py:651-698,
  * train.py:910-920), and its backward.  Runs on the device that owns raw4. */

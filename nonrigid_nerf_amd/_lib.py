@@ -87,9 +87,16 @@ class Camera(C.Structure):
 
 class TrunkArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("which", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
-                ("pts4", C.c_void_p), ("acts", C.c_void_p),
+                ("pts4", C.c_void_p), ("acts", C.c_void_p), ("relu_mask", C.c_void_p),
                 ("raw4", C.c_void_p), ("raw", C.c_void_p), ("raw_ch", C.c_int32),
                 ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+                ("acts", C.c_void_p), ("d_pre", C.c_void_p), ("enc", C.c_void_p), ("g_head", C.c_void_p),
+                ("n_partials", C.c_int32),
+                ("dw_hidden", C.c_void_p), ("dw_enc", C.c_void_p), ("dw_head_t", C.c_void_p), ("db", C.c_void_p)]
 
 
 class BenderArgs(C.Structure):
@@ -128,6 +135,7 @@ EXPORTS = {
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "nrnerf_trunk_forward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
     "nrnerf_trunk_backward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
+    "nrnerf_trunk_wgrad": (C.c_int, [C.c_void_p, C.POINTER(WgradArgs), C.c_void_p]),
     "nrnerf_bender_forward": (C.c_int, [C.c_void_p, C.POINTER(BenderArgs), C.c_void_p]),
     "nrnerf_bender_backward": (C.c_int, [C.c_void_p, C.POINTER(BenderArgs), C.c_void_p]),
     "nrnerf_composite_forward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),

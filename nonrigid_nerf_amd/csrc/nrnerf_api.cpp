@@ -991,6 +991,8 @@ int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, Tr
     t.wstream = bwd ? bw.stream : fwd.stream; t.bias = fwd.bias;
     t.raw4 = a->raw4; t.raw_out = a->raw; t.raw_ch = a->raw_ch;
     t.acts = a->acts; t.d_raw4 = a->d_raw4; t.d_pre = a->d_pre; t.d_pts4 = a->d_pts4;
+    t.mask = (unsigned short*)a->relu_mask;
+    if (m->precision != NRNERF_PREC_F32 && !t.mask) return NRNERF_ERR_INVALID;
     return NRNERF_OK;
 }
 }  // namespace
@@ -1020,6 +1022,33 @@ int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, voi
     const hipStream_t s = (hipStream_t)hip_stream;
     const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_bwd_f32_a5(t, m->num_cus, s) : launch_trunk_bwd_bf16_a5(t, m->num_cus, s))
                                            : (f32 ? launch_trunk_bwd_f32(t, m->num_cus, s) : launch_trunk_bwd_bf16(t, m->num_cus, s));
+    return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
+int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* hip_stream) {
+    if (!m || !a || a->struct_size != sizeof(nrnerf_wgrad_args)) return NRNERF_ERR_INVALID;
+    if (!m->train_ok || m->precision == NRNERF_PREC_F32) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 1 || a->n_partials > 4096) return NRNERF_ERR_INVALID;
+    if (!a->acts || !a->d_pre || !a->enc || !a->g_head || !a->dw_hidden || !a->dw_enc || !a->dw_head_t || !a->db) return NRNERF_ERR_INVALID;
+    if (a->n_rays == 0) return NRNERF_OK;
+    const int W = (m->arch_id == 5) ? ArchNarrow::W : ArchDefault::W, D = ArchDefault::D, SKIP = ArchDefault::SKIP;
+    const long long nblocks = (long long)a->n_rays * ((a->n_samples + 31) / 32);
+    const size_t layer = (size_t)nblocks * W * 32;                  // elements of one layer of acts / d_pre
+    const size_t kch = (size_t)a->n_partials;
+    const __bf16* acts = (const __bf16*)a->acts;
+    const __bf16* dpre = (const __bf16*)a->d_pre;
+    WgradArgs w{};
+    w.kch = a->n_partials; w.nblocks = nblocks;
+    int n = 0;
+    for (int i = 1; i < D; ++i)                                     // hidden-to-hidden layers: the bulk, first in the grid
+        w.job[n++] = WgradJob{dpre + i * layer, acts + (i - 1) * layer, W, a->dw_hidden + (size_t)(i - 1) * kch * W * W, a->db + (size_t)i * kch * W};
+    w.job[n++] = WgradJob{dpre, a->enc, 64, a->dw_enc, a->db};
+    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer, a->enc, 64, a->dw_enc + kch * W * 64, a->db + (size_t)D * kch * W};
+    w.job[n++] = WgradJob{acts + (D - 1) * layer, a->g_head, 64, a->dw_head_t, a->db + (size_t)D * kch * W};
+    w.njobs = n;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    const hipError_t e = (m->arch_id == 5) ? launch_trunk_wgrad_bf16_a5(w, (hipStream_t)hip_stream) : launch_trunk_wgrad_bf16(w, (hipStream_t)hip_stream);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 

@@ -111,7 +111,8 @@ struct TrunkArgs {
     float* raw4;             // forward out [M,4]
     float* raw_out;          // forward out [M,raw_ch] or nullptr
     int raw_ch;
-    void* acts;              // [D][M][W] hidden activations (float or bf16): forward writes, backward reads
+    void* acts;              // hidden activations: fp32 mode [D][M][W] float; bf16 mode [D][nblocks][W][32] bf16 (nrnerf_train.h)
+    unsigned short* mask;    // bf16 mode: [D][nblocks][W/32][64] relu masks (forward writes, backward reads); fp32 mode: unused
     const float* d_raw4;     // backward in  [M,4]   (gradient wrt raw4; the 5th raw channel never reaches the loss)
     void* d_pre;             // backward out [D][M][W] gradient wrt the pre-activations (float or bf16)
     float* d_pts4;           // backward out [M,4]
@@ -151,6 +152,23 @@ hipError_t launch_bend_fwd_train_a0(const BendTrainArgs&, int num_cus, hipStream
 hipError_t launch_bend_fwd_train_a1(const BendTrainArgs&, int num_cus, hipStream_t);
 hipError_t launch_bend_bwd_a0(const BendTrainArgs&, int num_cus, hipStream_t);
 hipError_t launch_bend_bwd_a1(const BendTrainArgs&, int num_cus, hipStream_t);
+
+// weight gradients of the trunk, bf16 mode (trunk_wgrad, nrnerf_train.h): a list of products  dz^T x  over the samples
+struct WgradJob {
+    const void* dz;          // [nblocks][W][32] bf16: gradient wrt a layer's pre-activations
+    const void* x;           // [nblocks][xw][32] bf16: that layer's input (previous activations, or the encoding)
+    int xw;                  // 256-wide trunk: W or 64 (encoding, zero padded); a multiple of 64
+    float* dw;               // out [kch][W][xw] fp32: one partial product per workgroup of the job (the caller adds them)
+    float* db;               // out [kch][W]     fp32: partial row sums of dz = bias gradient
+};
+constexpr int WGRAD_MAX_JOBS = 12;
+struct WgradArgs {
+    WgradJob job[WGRAD_MAX_JOBS];
+    int njobs, kch;          // grid = (kch, njobs)
+    long long nblocks;
+};
+hipError_t launch_trunk_wgrad_bf16(const WgradArgs&, hipStream_t);
+hipError_t launch_trunk_wgrad_bf16_a5(const WgradArgs&, hipStream_t);
 
 // Re-pack weights on the device (nrnerf_model_update_device): dst[i] = convert(flat[src[i]]) (0 where src[i] < 0).
 // fmt[i]: 0 = fp32, 1 = bf16, 2 = f16, 3 = f16((w - f16(w)) * 2^11), the lo part of the bender's split product;

@@ -16,6 +16,16 @@
 //                     [256 x K_samples] x [K_samples x 256] GEMMs over the two stored arrays and are left to the library
 //                     (hipBLASLt via torch.matmul in nonrigid_nerf_amd/training.py).
 // fp32 mode (exact, the gradient-parity mode) and bf16 mode (bf16 operands incl. the stored activations and d z).
+//
+// Layout of the stored arrays.  fp32 mode: [layer][sample][256], true feature order (the library GEMMs want rows of
+// features).  bf16 mode: [layer][block][feature][32 samples] -- one 256 x 32 tile per 32-sample block with the SAMPLES
+// contiguous: register r of a D tile holds one feature for the 32 samples of the block in the 32 lanes of a wave half, so a
+// store instruction writes two whole 64-byte rows; and it is the layout the weight-gradient kernel (trunk_wgrad, below)
+// wants, whose contraction runs over samples: a lane's 8 consecutive k of an MFMA operand are 8 consecutive samples of
+// one feature = one 16-byte load, no transpose anywhere.  Lanes of samples beyond the ray's end hold finite activations
+// (those of the clamped sample) and zero gradients, so the padded columns contribute nothing.  The backward kernel does not
+// read the activations at all in this mode: the forward kernel also writes which values passed the relu, 16 bits per lane
+// and tile ([layer][block][tile][64 lanes] u16, 1/16 of the activations' bytes).
 #pragma once
 #include "nrnerf_net_impl.h"
 
@@ -41,6 +51,25 @@ __device__ __forceinline__ f32x4 load4(const void* base, size_t elem_index) {
         const bf16x4 v = *(const bf16x4*)((const __bf16*)base + elem_index);
         return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     }
+}
+
+// bf16 mode: the 16 values of a D tile this lane holds, written into the [feature][32 samples] tile of its block straight
+// from the two B-operand fragments pack_tile has just produced (word k of fragment u = registers 8u + 2k, 8u + 2k + 1 as
+// bf16): 16 two-byte stores, no second conversion, no temporaries.  `dst` points at (feature 32 t + 4 h, sample j).
+template <int R>
+__device__ __forceinline__ void store_half_bf16(__bf16* dst, unsigned word) {
+    constexpr int off = ((R & 3) + 8 * (R >> 2)) * 32 * 2;              // bytes: feature row of register R, 64 bytes per row
+    if constexpr (R & 1) asm volatile("global_store_short_d16_hi %0, %1, off offset:%2" ::"v"(dst), "v"(word), "n"(off) : "memory");
+    else asm volatile("global_store_short %0, %1, off offset:%2" ::"v"(dst), "v"(word), "n"(off) : "memory");
+}
+template <class FRAG, int... R>
+__device__ __forceinline__ void store_tile_bf16_impl(__bf16* dst, const FRAG& f0, const FRAG& f1, std::integer_sequence<int, R...>) {
+    const u32x4 w0 = __builtin_bit_cast(u32x4, f0), w1 = __builtin_bit_cast(u32x4, f1);
+    (store_half_bf16<R>(dst, (R < 8 ? w0 : w1)[(R & 7) >> 1]), ...);
+}
+template <class FRAG>
+__device__ __forceinline__ void store_tile_bf16(__bf16* dst, const FRAG& f0, const FRAG& f1) {
+    store_tile_bf16_impl(dst, f0, f1, std::make_integer_sequence<int, 16>{});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -114,14 +143,26 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_fwd_tr
         // epilogue of hidden layer LAYER: relu, keep for the backward pass, hand to the next layer
         auto keep = [&](auto lc, auto tc, const f32x16& acc, auto& out) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
-            if (ok) {
-                const size_t row = ((size_t)layer * M + so) * A::W + 32 * t + 4 * h;
+            if constexpr (KH == 1) {
+                if (ok) {
+                    const size_t row = ((size_t)layer * M + so) * A::W + 32 * t + 4 * h;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    store4<P>(a.acts, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]),
-                              relu_bits(acc[4 * q + 3]));
+                    for (int q = 0; q < 4; ++q)
+                        store4<P>(a.acts, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]),
+                                  relu_bits(acc[4 * q + 3]));
+                }
             }
             pack_tile<P, true, t>(acc, out);
+            if constexpr (KH != 1) {
+                if (blk_ok) {
+                    store_tile_bf16((__bf16*)a.acts + (((size_t)layer * nblocks + b) * A::W + 32 * t + 4 * h) * 32 + j, out[t * SP], out[t * SP + 1]);
+                    unsigned m = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m |= (acc[r] > 0.0f ? 1u : 0u) << r;
+                    // which of this lane's 16 values passed the relu: all the backward kernel needs of the activations
+                    a.mask[(((size_t)layer * nblocks + b) * NT_W + t) * 64 + lane] = (unsigned short)m;
+                }
+            }
         };
         dense<PE, P, PL, PL::L_TRUNK0, NS_ENC, 0>(st, bias_lane, enc, none, [&](auto tc, const f32x16& acc) {
             keep(std::integral_constant<int, 0>{}, tc, acc, ha); });
@@ -212,16 +253,33 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
         // epilogue producing d z_LAYER from tile t of d h_LAYER: mask with the saved activation, store, hand on
         auto mask_store = [&](auto lc, auto tc, const f32x16& acc, auto& out) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
-            const size_t row = ((size_t)layer * M + so) * A::W + 32 * t + 4 * h;
             f32x16 g = acc;
+            if constexpr (KH == 1) {
+                const size_t row = ((size_t)layer * M + so) * A::W + 32 * t + 4 * h;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 hv = load4<P>(a.acts, row + 8 * q);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 hv = load4<P>(a.acts, row + 8 * q);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) g[4 * q + k] = (hv[k] > 0.0f) ? acc[4 * q + k] : 0.0f;
-                if (ok) store4<P>(a.d_pre, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+                    for (int k = 0; k < 4; ++k) g[4 * q + k] = (hv[k] > 0.0f) ? acc[4 * q + k] : 0.0f;
+                    if (ok) store4<P>(a.d_pre, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+                }
+            } else {
+                // sign-extended so that bit r of the mask becomes "all ones or all zeros" with one shift: g = acc & that
+                const unsigned m = a.mask[(((size_t)layer * nblocks + b) * NT_W + t) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // bit r of the mask sign-extended to all ones / all zeros, ANDed in: two VALU per value and no condition
+                    // registers (the select form spilled two registers into scratch at the 256-register budget).  The
+                    // scalar copy matters: __builtin_bit_cast applied to a vector ELEMENT reads element 0 (hipcc 7.2).
+                    const float v = acc[r];
+                    g[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & ((int)(m << (31 - r)) >> 31));
+                }
             }
             pack_tile<P, false, t>(g, out);
+            if constexpr (KH != 1) {
+                if (blk_ok)
+                    store_tile_bf16((__bf16*)a.d_pre + (((size_t)layer * nblocks + b) * A::W + 32 * t + 4 * h) * 32 + j, out[t * SP], out[t * SP + 1]);
+            }
         };
         // head^T: d h_{D-1}
         dense<P, P, PL, 0, NS_DR, 0>(st, bias_lane, dr, none, [&](auto tc, const f32x16& acc) {
@@ -285,6 +343,109 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
         static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
     }
     st.drain();
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradients (bf16 mode)
+// ------------------------------------------------------------------------------------------
+// dW = dz^T x summed over the samples, for a list of (dz, x) pairs -- the seven hidden-to-hidden layers (x = the previous
+// layer's activations) and the two layers that see the encoding (x = the encoding, 64 columns) -- straight from the
+// [block][feature][32 samples] arrays the two kernels above fill: the contraction index of the MFMA is the sample, a lane's
+// operand is 8 consecutive samples of one feature (one 16-byte global load), so there is no LDS, no transpose and no
+// barrier.  grid = (kch, jobs): workgroup (c, j) accumulates job j over blocks c, c + kch, ... in registers and writes one
+// fp32 partial [W][xw]; the caller adds the kch partials.  4 waves (one per SIMD, up to 256 accumulator registers): wave
+// (wr, wc) owns tile rows wr * NTR/2 .. and tile columns wc * NTC/2 ..; next block's 16 fragments are requested before the
+// current block's MFMAs.  Measured 3.2 TB/s of unique HBM traffic at 16 384 rays; 8 waves with half the tiles each (more
+// loads in flight, but every fragment requested by more waves) were 10 % slower.  The bias gradient comes along: the waves of column 0 add up the dz fragments they hold (eight
+// conversions + adds per fragment on the VALU, one register per row tile).
+template <class A>
+__global__ void __launch_bounds__(256, 1) trunk_wgrad(const WgradArgs a) {
+    using P = PolBF16;
+    typedef typename P::frag frag;
+    constexpr int NTR = A::W / 32;                  // row tiles of dz^T (features of this layer)
+    constexpr int TR = NTR / 2;                     // per wave
+    static_assert(NTR % 2 == 0, "two wave rows");
+    const WgradJob jb = a.job[blockIdx.y];
+    const int ntc = jb.xw / 32, tcw = ntc / 2;      // column tiles of x per wave: 4 (hidden) or 1 (encoding)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int h = lane >> 5, i = lane & 31;
+    const __bf16* dz = (const __bf16*)jb.dz;
+    const __bf16* x = (const __bf16*)jb.x;
+    constexpr int TCMAX = NTR / 2;
+    f32x16 acc[TR][TCMAX];
+    float bsum[TR];          // bias gradient: this lane's share of the row sums of dz (its 8 samples of feature i per fragment)
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+        bsum[u] = 0.0f;
+#pragma unroll
+        for (int v = 0; v < TCMAX; ++v) acc[u][v] = f32x16{};
+    }
+    auto load = [&](long long blk, frag (&fa)[TR][2], frag (&fb)[TCMAX][2]) {
+#pragma unroll
+        for (int u = 0; u < TR; ++u)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fa[u][ks] = *(const frag*)(dz + ((size_t)blk * A::W + 32 * (wr * TR + u) + i) * 32 + ks * 16 + 8 * h);
+#pragma unroll
+        for (int v = 0; v < TCMAX; ++v)
+            if (v < tcw)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    fb[v][ks] = *(const frag*)(x + ((size_t)blk * jb.xw + 32 * (wc * tcw + v) + i) * 32 + ks * 16 + 8 * h);
+    };
+    auto step = [&](const frag (&fa)[TR][2], const frag (&fb)[TCMAX][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int u = 0; u < TR; ++u) {
+                if (wc == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[u] += (float)fa[u][ks][e];
+                }
+#pragma unroll
+                for (int v = 0; v < TCMAX; ++v)
+                    if (v < tcw) acc[u][v] = P::mfma(fa[u][ks], fb[v][ks], acc[u][v]);
+            }
+        }
+    };
+    frag fa0[TR][2], fb0[TCMAX][2], fa1[TR][2], fb1[TCMAX][2];
+    long long blk = blockIdx.x;
+    if (blk < a.nblocks) load(blk, fa0, fb0);
+    while (blk < a.nblocks) {
+        const long long n1 = blk + a.kch;
+        if (n1 < a.nblocks) load(n1, fa1, fb1);
+        step(fa0, fb0);
+        if (n1 >= a.nblocks) break;
+        const long long n2 = n1 + a.kch;
+        if (n2 < a.nblocks) load(n2, fa0, fb0);
+        step(fa1, fb1);
+        blk = n2;
+    }
+    // D tile: lane (h, j) holds rows tile_row(r, h), column j
+    float* dw = jb.dw + (size_t)blockIdx.x * A::W * jb.xw;
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+#pragma unroll
+        for (int v = 0; v < TCMAX; ++v)
+            if (v < tcw) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dw[(size_t)(32 * (wr * TR + u) + tile_row(r, h)) * jb.xw + 32 * (wc * tcw + v) + i] = acc[u][v][r];
+            }
+        const float rowsum = bsum[u] + __shfl_xor(bsum[u], 32);        // the two lane halves hold samples 8h .. 8h + 7 of each k-step
+        if (wc == 0 && h == 0) jb.db[(size_t)blockIdx.x * A::W + 32 * (wr * TR + u) + i] = rowsum;
+    }
+}
+
+template <class A>
+static hipError_t launch_trunk_wgrad(const WgradArgs& a, hipStream_t stream) {
+    if (a.njobs <= 0 || a.kch <= 0 || a.nblocks <= 0) return hipSuccess;
+    for (int j = 0; j < a.njobs; ++j)
+        if (a.job[j].xw % 64 != 0 || a.job[j].xw > A::W) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(trunk_wgrad<A>, dim3(a.kch, a.njobs), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 template <class P, class A, int WAVES, bool BWD>

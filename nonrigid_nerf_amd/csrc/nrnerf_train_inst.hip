@@ -15,4 +15,9 @@ hipError_t NRN_CAT(launch_trunk_fwd_train_, NRN_TAG)(const TrunkArgs& a, int num
 hipError_t NRN_CAT(launch_trunk_bwd_, NRN_TAG)(const TrunkArgs& a, int num_cus, hipStream_t stream) {
     return launch_trunk_train<NRN_POL, ArchById<NRN_ARCH>::type, (NRN_POL::KH == 1) ? 4 : 8, true>(a, num_cus, stream);
 }
+#ifdef NRN_WGRAD      // bf16 units only: the weight-gradient kernel of that trunk width
+hipError_t NRN_CAT(launch_trunk_wgrad_, NRN_TAG)(const WgradArgs& a, hipStream_t stream) {
+    return launch_trunk_wgrad<ArchById<NRN_ARCH>::type>(a, stream);
+}
+#endif
 }  // namespace nrn

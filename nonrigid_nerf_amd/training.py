@@ -90,9 +90,13 @@ class _Trunk(torch.autograd.Function):
         N, S = int(pts.shape[0]), int(pts.shape[1])
         M, dev = N * S, pts.device
         D, W = int(net.D), int(net.W)
-        act_dtype = torch.float32 if model.precision == "f32" else torch.bfloat16
+        f32 = model.precision == "f32"
         pts4 = _rows4(pts.detach(), M)               # the bender's own [M,4] rows when the points come from _Bender
-        acts = torch.empty(D, M, W, dtype=act_dtype, device=dev)
+        # saved activations.  fp32 mode: [layer][sample][width] for the library GEMMs; bf16 mode: [layer][block][width][32
+        # samples] for nrnerf_trunk_wgrad (blocks of 32 consecutive samples of a ray) + 16 relu bits per lane and tile
+        nblk = N * ((S + 31) // 32)
+        acts = torch.empty(D, M, W, dtype=torch.float32, device=dev) if f32 else torch.empty(D, nblk, W, 32, dtype=torch.bfloat16, device=dev)
+        mask = None if f32 else torch.empty(D, nblk, W // 32, 64, dtype=torch.int16, device=dev)
         raw4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         C_out = int(net.output_linear.weight.shape[0])
         raw = torch.empty(M, C_out, dtype=torch.float32, device=dev)
@@ -100,17 +104,19 @@ class _Trunk(torch.autograd.Function):
         a.struct_size = C.sizeof(_lib.TrunkArgs)
         a.which, a.n_rays, a.n_samples = int(which), N, S
         a.pts4, a.acts, a.raw4, a.raw, a.raw_ch = pts4.data_ptr(), acts.data_ptr(), raw4.data_ptr(), raw.data_ptr(), C_out
+        a.relu_mask = None if f32 else mask.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_forward")
         ctx.model, ctx.net, ctx.which, ctx.dims = model, net, int(which), (N, S, D, W, C_out)
-        ctx.save_for_backward(pts4, acts)
+        ctx.save_for_backward(*((pts4, acts) if f32 else (pts4, acts, mask)))
         ctx.mark_non_differentiable(raw)
         return raw4.view(N, S, 4), raw.view(N, S, C_out)
 
     @staticmethod
     def backward(ctx, g_raw4, _g_raw):
-        pts4, acts = ctx.saved_tensors
         model, net = ctx.model, ctx.net
+        f32 = model.precision == "f32"
+        pts4, acts = ctx.saved_tensors[:2]
         N, S, D, W, C_out = ctx.dims
         M, dev = N * S, pts4.device
         g = g_raw4.contiguous().reshape(M, 4).float()
@@ -120,8 +126,11 @@ class _Trunk(torch.autograd.Function):
         a.struct_size = C.sizeof(_lib.TrunkArgs)
         a.which, a.n_rays, a.n_samples = ctx.which, N, S
         a.pts4, a.acts, a.d_raw4, a.d_pre, a.d_pts4 = pts4.data_ptr(), acts.data_ptr(), g.data_ptr(), d_pre.data_ptr(), d_pts4.data_ptr()
+        a.relu_mask = None if f32 else ctx.saved_tensors[2].data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_backward")
+        if not f32:
+            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *_Trunk._weight_grads_bf16(model, net, ctx.dims, pts4, acts, d_pre, g))
         # weight gradients: library GEMMs over the stored activations x_i and pre-activation gradients dz_i
         adt = acts.dtype
         L = (int(net.input_ch) - 3) // 6
@@ -147,6 +156,68 @@ class _Trunk(torch.autograd.Function):
         g_out[:, :4] = g
         grads += [_wgrad(g_out.to(adt), acts[D - 1]), g_out.sum(0)]
         return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *grads)
+
+
+    @staticmethod
+    def _weight_grads_bf16(model, net, dims, pts4, acts, d_pre, g):
+        """bf16 mode: every weight and bias gradient of the trunk from one launch of nrnerf_trunk_wgrad over the two
+        [block][feature][32 samples] arrays (reads each once; the library route read them twice and reduced d_pre a third
+        time).  The two small operands it needs in the same layout -- the encoding of the input points and the gradient
+        wrt the head's outputs -- are built here."""
+        N, S, D, W, C_out = dims
+        dev = acts.device
+        L = (int(net.input_ch) - 3) // 6
+        enc_t = _block_tiles(posenc(pts4[:, :3], L), N, S)                                   # [B, 64, 32]
+        g_t = _block_tiles(g, N, S)                                                          # channels 0..3; the 5th never reaches the loss
+        kch = max(1, min(int(acts.shape[1]), _num_cus(dev) // (D - 1)))
+        dwh = torch.empty(D - 1, kch, W, W, dtype=torch.float32, device=dev)
+        dwe = torch.empty(2, kch, W, 64, dtype=torch.float32, device=dev)
+        dwo = torch.empty(kch, W, 64, dtype=torch.float32, device=dev)
+        db = torch.empty(D + 1, kch, W, dtype=torch.float32, device=dev)
+        a = _lib.WgradArgs()
+        a.struct_size = C.sizeof(_lib.WgradArgs)
+        a.n_rays, a.n_samples, a.n_partials = N, S, kch
+        a.acts, a.d_pre, a.enc, a.g_head = acts.data_ptr(), d_pre.data_ptr(), enc_t.data_ptr(), g_t.data_ptr()
+        a.dw_hidden, a.dw_enc, a.dw_head_t, a.db = dwh.data_ptr(), dwe.data_ptr(), dwo.data_ptr(), db.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_wgrad")
+        dwh, dwe, dwo, db = dwh.sum(1), dwe.sum(1), dwo.sum(0), db.sum(1)
+        n_enc = 3 + 6 * L
+        skips = set(int(s) for s in net.skips)
+        grads = []
+        for i in range(D):
+            if i == 0:
+                dw = dwe[0][:, :n_enc]
+            elif (i - 1) in skips:
+                dw = torch.cat([dwe[1][:, :n_enc], dwh[i - 1]], 1)                           # x = [encoding, h] (rnh:278-282)
+            else:
+                dw = dwh[i - 1]
+            grads += [dw, db[i]]
+        g_out = torch.zeros(C_out, dtype=torch.float32, device=dev)
+        g_out[:4] = g.sum(0)
+        dw_out = torch.zeros(C_out, W, dtype=torch.float32, device=dev)
+        dw_out[:4] = dwo[:, :4].t()
+        return grads + [dw_out, g_out]
+
+
+_NUM_CUS = {}
+
+
+def _num_cus(dev) -> int:
+    k = torch.device(dev).index or 0
+    if k not in _NUM_CUS:
+        _NUM_CUS[k] = int(torch.cuda.get_device_properties(k).multi_processor_count)
+    return _NUM_CUS[k]
+
+
+def _block_tiles(x: torch.Tensor, N: int, S: int) -> torch.Tensor:
+    """[N*S, c <= 64] -> bf16 [B, 64, 32]: per block of 32 consecutive samples of a ray a [64 x 32] tile with the samples
+    contiguous, rows >= c and the columns beyond a ray's end zero -- the operand layout of nrnerf_trunk_wgrad."""
+    c = int(x.shape[1])
+    bpr = (S + 31) // 32
+    t = torch.zeros(N, bpr * 32, 64, dtype=torch.bfloat16, device=x.device)
+    t[:, :S, :c] = x.view(N, S, c)
+    return t.view(N * bpr, 32, 64).transpose(1, 2).contiguous()
 
 
 def _trunk_params(net):

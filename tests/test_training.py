@@ -383,3 +383,50 @@ def test_native_bender_forward_and_gradients_vs_torch_autograd(precision, knobs,
         worst = max(worst, err)
         assert err <= 1e-4, (k, err)
     print(f"\n[native bender vs torch autograd, {precision} model] worst gradient error / scale {worst:.1e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,n_rays,S", [(256, 37, 192), (256, 5, 85), (128, 64, 64)], ids=["w256", "w256_ragged", "w128"])
+def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S):
+    """nrnerf_trunk_wgrad (bf16 mode: all weight / bias gradients of the trunk in one launch over the [block][feature][32
+    samples] arrays) on random bf16 arrays against fp32 einsums over the same values: hidden layers, the two encoding
+    products, the head, the bias sums; ragged block counts; both compiled trunk widths.  fp32 accumulation on both sides,
+    so 1e-4 of scale."""
+    import ctypes as C
+    from nonrigid_nerf_amd import _lib
+    cfg = SceneConfig(N_importance=64, netwidth=width)
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = _modules(scene, requires_grad=False)
+    R.set_precision("bf16")
+    model = R.get_model(coarse, fine, precision="bf16", device=torch.device(DEV))
+    D, W = 8, width
+    nblk = n_rays * ((S + 31) // 32)
+    gen = torch.Generator().manual_seed(4)
+    mk = lambda *shape: (torch.randn(*shape, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
+    acts, d_pre = mk(D, nblk, W, 32).abs(), mk(D, nblk, W, 32)
+    enc_t, g_t = mk(nblk, 64, 32), mk(nblk, 64, 32)
+    kch = 7
+    dwh = torch.full((D - 1, kch, W, W), float("nan"), device=DEV)
+    dwe = torch.full((2, kch, W, 64), float("nan"), device=DEV)
+    dwo = torch.full((kch, W, 64), float("nan"), device=DEV)
+    db = torch.full((D + 1, kch, W), float("nan"), device=DEV)
+    a = _lib.WgradArgs()
+    a.struct_size = C.sizeof(_lib.WgradArgs)
+    a.n_rays, a.n_samples, a.n_partials = n_rays, S, kch
+    a.acts, a.d_pre, a.enc, a.g_head = acts.data_ptr(), d_pre.data_ptr(), enc_t.data_ptr(), g_t.data_ptr()
+    a.dw_hidden, a.dw_enc, a.dw_head_t, a.db = dwh.data_ptr(), dwe.data_ptr(), dwo.data_ptr(), db.data_ptr()
+    _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nrnerf_trunk_wgrad")
+    torch.cuda.synchronize()
+    A, Z = acts.float(), d_pre.float()
+
+    def close(got, want, what):
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 1e-4 * scale, (what, float((got - want).abs().max()), scale)
+
+    for i in range(1, D):
+        close(dwh[i - 1].sum(0), torch.einsum("bfs,bgs->fg", Z[i], A[i - 1]), f"hidden {i}")
+        close(db[i].sum(0), Z[i].sum((0, 2)), f"bias {i}")
+    close(db[0].sum(0), Z[0].sum((0, 2)), "bias 0")
+    close(dwe[0].sum(0), torch.einsum("bfs,bgs->fg", Z[0], enc_t.float()), "encoding, layer 0")
+    close(dwe[1].sum(0), torch.einsum("bfs,bgs->fg", Z[5], enc_t.float()), "encoding, skip layer")
+    close(dwo.sum(0), torch.einsum("bfs,bgs->fg", A[D - 1], g_t.float()), "head")

@@ -37,8 +37,17 @@ def device_code_object(obj: str, tmp: str) -> str | None:
 
 def analyse(co: str) -> dict:
     notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
-    meta = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", notes)}
+    # per kernel; the rules apply to the kernels that stream weights through the LDS ring, i.e. not to trunk_wgrad (a
+    # ring-less one-wave-per-SIMD kernel with 256 accumulator registers that shares an object with the training kernels)
+    meta = {}
+    for blk in re.split(r"\n\s*- \.agpr_count", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if name and "trunk_wgrad" in name.group(1):
+            continue
+        for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", blk):
+            meta[k] = max(meta.get(k, 0), int(v))
     dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    dis = re.sub(r"(?ms)^[0-9a-f]{16} <[^>]*trunk_wgrad[^>]*>:.*?(?=^[0-9a-f]{16} <|\Z)", "", dis)
     ins = [l.split()[0] for l in dis.splitlines() if re.match(r"^\s+[a-z]+_", l)]
     mfma = [i for i, x in enumerate(ins) if "mfma" in x]
     first = mfma[0] if mfma else len(ins)
