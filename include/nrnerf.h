@@ -301,6 +301,23 @@ typedef struct nrnerf_bender_args {
 int nrnerf_bender_forward(const nrnerf_model* model, const nrnerf_bender_args* args, void* hip_stream);
 int nrnerf_bender_backward(const nrnerf_model* model, const nrnerf_bender_args* args, void* hip_stream);
 
+/* The weight and bias gradients of the bender's two MLPs from the arrays nrnerf_bender_forward / _backward filled, in one
+ * launch: job j = layer j in the order network[0 .. depth-1], rigidity_network[0 .. rigidity_depth-1]; every job yields
+ * n_partials partial sums (one per wave; the caller adds them) of  dW [64][64] (rows = the layer's outputs, columns = its
+ * inputs; only [out_features][in_features] is meaningful) followed by db [64].  x0 [M, 3 + latent_size]: the offset MLP's
+ * input rows (point, latent code), built by the caller. */
+#define NRNERF_BENDER_WGRAD_SLOT (64 * 64 + 64)
+typedef struct nrnerf_bender_wgrad_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_bender_wgrad_args) */
+    int32_t n_rays, n_samples;
+    const float* x0;
+    const float* acts_offsets; const float* acts_rigidity;                       /* as nrnerf_bender_args */
+    const float* dz_offsets; const float* dz_rigidity; const float* dz_out4;     /* as nrnerf_bender_args */
+    int32_t n_partials;         /* a multiple of 4, <= 4096 */
+    float* partials;            /* out [n_partials][depth + rigidity_depth][NRNERF_BENDER_WGRAD_SLOT] */
+} nrnerf_bender_wgrad_args;
+int nrnerf_bender_wgrad(const nrnerf_model* model, const nrnerf_bender_wgrad_args* args, void* hip_stream);
+
 /* bf16 mode: the weight and bias gradients of the trunk from the two arrays nrnerf_trunk_forward / _backward filled, in
  * one launch over their [block][feature][32 samples] layout (the contraction runs over samples; no transposes):
  *   dw_hidden[i-1] = d_pre[i]^T acts[i-1]  (i = 1 .. depth-1; the skip layer's columns for its encoding input are in dw_enc)

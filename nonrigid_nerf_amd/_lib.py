@@ -111,6 +111,16 @@ class BenderArgs(C.Structure):
                 ("dz_offsets", C.c_void_p), ("dz_rigidity", C.c_void_p), ("dz_out4", C.c_void_p), ("d_latents", C.c_void_p)]
 
 
+class BenderWgradArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+                ("x0", C.c_void_p), ("acts_offsets", C.c_void_p), ("acts_rigidity", C.c_void_p),
+                ("dz_offsets", C.c_void_p), ("dz_rigidity", C.c_void_p), ("dz_out4", C.c_void_p),
+                ("n_partials", C.c_int32), ("partials", C.c_void_p)]
+
+
+BENDER_WGRAD_SLOT = 64 * 64 + 64
+
+
 class CompositeArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("n_importance", C.c_int32),
                 ("rays", C.c_void_p), ("ray_stride", C.c_int32),
@@ -138,6 +148,7 @@ EXPORTS = {
     "nrnerf_trunk_wgrad": (C.c_int, [C.c_void_p, C.POINTER(WgradArgs), C.c_void_p]),
     "nrnerf_bender_forward": (C.c_int, [C.c_void_p, C.POINTER(BenderArgs), C.c_void_p]),
     "nrnerf_bender_backward": (C.c_int, [C.c_void_p, C.POINTER(BenderArgs), C.c_void_p]),
+    "nrnerf_bender_wgrad": (C.c_int, [C.c_void_p, C.POINTER(BenderWgradArgs), C.c_void_p]),
     "nrnerf_composite_forward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),
     "nrnerf_composite_backward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),
     "nrnerf_profile_begin": (C.c_int, [C.c_void_p]),

@@ -1098,6 +1098,31 @@ int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, v
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 
+int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a, void* hip_stream) {
+    if (!m || !a || a->struct_size != sizeof(nrnerf_bender_wgrad_args)) return NRNERF_ERR_INVALID;
+    if (!m->bend_train_ok) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 4 || a->n_partials > 4096 || a->n_partials % 4) return NRNERF_ERR_INVALID;
+    if (!a->x0 || !a->acts_offsets || !a->acts_rigidity || !a->dz_offsets || !a->dz_rigidity || !a->dz_out4 || !a->partials) return NRNERF_ERR_INVALID;
+    if (a->n_rays == 0) return NRNERF_OK;
+    const int BD = (bender_arch(m->arch_id) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
+    const int BW = ArchDefault::BW, RD = ArchDefault::RD, RW = ArchDefault::RW, X0 = 3 + ArchDefault::LAT;
+    const size_t M = (size_t)a->n_rays * a->n_samples;
+    BendWgradArgs w{};
+    int n = 0;
+    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, a->x0, X0, X0};                                         // network[0]
+    for (int i = 1; i <= BD - 2; ++i)
+        w.job[n++] = BendWgradJob{a->dz_offsets + (size_t)i * M * BW, BW, BW, a->acts_offsets + (size_t)(i - 1) * M * BW, BW, BW};
+    w.job[n++] = BendWgradJob{a->dz_out4, 4, 3, a->acts_offsets + (size_t)(BD - 2) * M * BW, BW, BW};        // network[BD-1]: 3 x BW
+    w.job[n++] = BendWgradJob{a->dz_rigidity, RW, RW, a->x0, X0, 3};                                         // rigidity_network[0]: input = the point
+    for (int i = 1; i <= RD - 2; ++i)
+        w.job[n++] = BendWgradJob{a->dz_rigidity + (size_t)i * M * RW, RW, RW, a->acts_rigidity + (size_t)(i - 1) * M * RW, RW, RW};
+    w.job[n++] = BendWgradJob{a->dz_out4 + 3, 4, 1, a->acts_rigidity + (size_t)(RD - 2) * M * RW, RW, RW};   // the logit's layer: 1 x RW
+    w.njobs = n; w.nparts = a->n_partials; w.m = (long long)M; w.out = a->partials;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    return launch_bend_wgrad(w, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+
 namespace {
 int composite_device(const nrnerf_composite_args* a, int* dev) {
     hipPointerAttribute_t attr;

@@ -153,6 +153,22 @@ hipError_t launch_bend_fwd_train_a1(const BendTrainArgs&, int num_cus, hipStream
 hipError_t launch_bend_bwd_a0(const BendTrainArgs&, int num_cus, hipStream_t);
 hipError_t launch_bend_bwd_a1(const BendTrainArgs&, int num_cus, hipStream_t);
 
+// weight gradients of the bender / rigidity MLPs (bend_wgrad, nrnerf_train_bend.h): products dz^T x over the samples of
+// row-major fp32 arrays, at most 64 x 64 each
+struct BendWgradJob {
+    const float* dz; int ldz, f;      // [M][ldz], the first f <= 64 columns: gradient wrt a layer's pre-activations
+    const float* x;  int ldx, g;      // [M][ldx], the first g <= 64 columns: that layer's input
+};
+constexpr int BEND_WGRAD_MAX_JOBS = 12;
+constexpr int BEND_WGRAD_SLOT = 64 * 64 + 64;       // floats per (partial, job): dW [64][64] then db [64]
+struct BendWgradArgs {
+    BendWgradJob job[BEND_WGRAD_MAX_JOBS];
+    int njobs, nparts;                // grid = (nparts / 4, njobs), 4 waves per workgroup, one partial per wave
+    long long m;
+    float* out;                       // [nparts][njobs][BEND_WGRAD_SLOT]
+};
+hipError_t launch_bend_wgrad(const BendWgradArgs&, hipStream_t);
+
 // weight gradients of the trunk, bf16 mode (trunk_wgrad, nrnerf_train.h): a list of products  dz^T x  over the samples
 struct WgradJob {
     const void* dz;          // [nblocks][W][32] bf16: gradient wrt a layer's pre-activations

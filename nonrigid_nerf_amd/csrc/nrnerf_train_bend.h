@@ -246,6 +246,61 @@ __global__ void __launch_bounds__(256, 1) bend_bwd(const BendTrainArgs a) {
     }
 }
 
+// Weight and bias gradients of both MLPs in one launch: dW = dz^T x over the samples for a list of (dz, x) pairs of
+// row-major fp32 arrays (at most 64 x 64 each), on v_mfma_f32_32x32x2_f32 with the SAMPLE as contraction index: the A
+// operand of a k-step is dz[sample s + h][32 tr + i], the B operand x[sample s + h][32 tc + j] -- one coalesced 128-byte
+// row segment per lane half, no transposes.  Every wave owns a contiguous range of samples and writes one fp32 partial
+// (dW [64][64] and the row sums of dz = db [64]) per job; the caller adds the partials.
+template <int U>        // k-steps per batch of loads (a template only so that the header can be included by several units)
+__global__ void __launch_bounds__(256) bend_wgrad(const BendWgradArgs a) {
+    const BendWgradJob jb = a.job[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    const int part = (int)blockIdx.x * 4 + wave;
+    const long long pairs = (a.m + 1) / 2;
+    const long long per = (pairs + a.nparts - 1) / a.nparts;
+    const long long p0 = (long long)part * per, p1 = (p0 + per < pairs) ? p0 + per : pairs;
+    const bool f1 = jb.f > 32, g1 = jb.g > 32;           // second row / column tile in use (wave-uniform)
+    const bool fa0 = i < jb.f, fa1 = 32 + i < jb.f, gb0 = i < jb.g, gb1 = 32 + i < jb.g;
+    f32x16 acc[2][2] = {{f32x16{}, f32x16{}}, {f32x16{}, f32x16{}}};
+    float bsum[2] = {0.0f, 0.0f};
+    for (long long p = p0; p < p1; p += U) {
+        float av[U][2], bv[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long s = 2 * (p + u) + h;
+            const bool ok = (p + u < p1) && s < a.m;
+            const float* dr = jb.dz + (size_t)s * jb.ldz + i;
+            const float* xr = jb.x + (size_t)s * jb.ldx + i;
+            av[u][0] = (ok && fa0) ? dr[0] : 0.0f;
+            av[u][1] = (ok && fa1) ? dr[32] : 0.0f;
+            bv[u][0] = (ok && gb0) ? xr[0] : 0.0f;
+            bv[u][1] = (ok && gb1) ? xr[32] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bsum[0] += av[u][0];
+            bsum[1] += av[u][1];
+            acc[0][0] = PolF32::mfma(av[u][0], bv[u][0], acc[0][0]);
+            if (g1) acc[0][1] = PolF32::mfma(av[u][0], bv[u][1], acc[0][1]);
+            if (f1) {
+                acc[1][0] = PolF32::mfma(av[u][1], bv[u][0], acc[1][0]);
+                if (g1) acc[1][1] = PolF32::mfma(av[u][1], bv[u][1], acc[1][1]);
+            }
+        }
+    }
+    float* out = a.out + ((size_t)part * a.njobs + blockIdx.y) * BEND_WGRAD_SLOT;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(32 * u + tile_row(r, h)) * 64 + 32 * v + i] = acc[u][v][r];
+        const float rs = bsum[u] + __shfl_xor(bsum[u], 32);
+        if (h == 0) out[64 * 64 + 32 * u + i] = rs;
+    }
+}
+
 template <class A, bool BWD>
 static hipError_t launch_bend_train(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
     using P = PolF32;

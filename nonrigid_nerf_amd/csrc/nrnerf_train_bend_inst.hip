@@ -11,4 +11,11 @@ hipError_t NRN_CAT(launch_bend_fwd_train_a, NRN_ARCH)(const BendTrainArgs& a, in
 hipError_t NRN_CAT(launch_bend_bwd_a, NRN_ARCH)(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
     return launch_bend_train<ArchById<NRN_ARCH>::type, true>(a, num_cus, stream);
 }
+#if NRN_ARCH == 0     // the weight-gradient kernel does not depend on the bender's depth: one copy
+hipError_t launch_bend_wgrad(const BendWgradArgs& a, hipStream_t stream) {
+    if (a.njobs <= 0 || a.nparts < 4 || a.nparts % 4 != 0 || a.m <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bend_wgrad<8>, dim3(a.nparts / 4, a.njobs), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+#endif
 }  // namespace nrn

@@ -332,9 +332,31 @@ class _Bender(torch.autograd.Function):
         a.dz_offsets, a.dz_rigidity, a.dz_out4, a.d_latents = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), d_lat.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_backward")
-        # weight gradients dW_i = dz_i^T x_i over the stored arrays (batched library GEMMs, see _wgrad).  x_0 = [p, latent]:
-        # the latent columns are constant along a ray, so their part is (per-ray sums of dz_0)^T latents.
         pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(M, 3)
+        if NATIVE_BENDER_WGRAD:
+            # every weight / bias gradient of both MLPs in one launch (nrnerf_bender_wgrad): partial sums per wave, added here
+            x0 = torch.cat([pts, lat[:, None, :].expand(N, S, LAT).reshape(M, LAT)], 1)
+            nparts = 4 * max(1, min(_num_cus(dev), (M + 1023) // 1024))
+            nj = BD + RD
+            parts = torch.empty(nparts, nj, _lib.BENDER_WGRAD_SLOT, dtype=torch.float32, device=dev)
+            w = _lib.BenderWgradArgs()
+            w.struct_size = C.sizeof(_lib.BenderWgradArgs)
+            w.n_rays, w.n_samples, w.n_partials = N, S, nparts
+            w.x0, w.acts_offsets, w.acts_rigidity = x0.data_ptr(), acts_b.data_ptr(), acts_r.data_ptr()
+            w.dz_offsets, w.dz_rigidity, w.dz_out4, w.partials = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), parts.data_ptr()
+            with torch.cuda.device(dev):
+                _lib.check(model.lib.nrnerf_bender_wgrad(model.handle, C.byref(w), _stream(dev)), "nrnerf_bender_wgrad")
+            tot = parts.sum(0)                                                               # [jobs, 64*64 + 64]
+            dW, dB = tot[:, :4096].view(nj, 64, 64), tot[:, 4096:]
+            grads = []
+            for k, lin in enumerate(list(rb.network) + list(rb.rigidity_network)):
+                o, i_ = int(lin.weight.shape[0]), int(lin.weight.shape[1])
+                grads.append(dW[k, :o, :i_])
+                if lin.bias is not None:
+                    grads.append(dB[k, :o])
+            return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, *grads)
+        # library route.  weight gradients dW_i = dz_i^T x_i over the stored arrays (batched library GEMMs, see _wgrad).
+        # x_0 = [p, latent]: the latent columns are constant along a ray, so their part is (per-ray sums of dz_0)^T latents.
         dw0 = torch.cat([_wgrad(dz_b[0], pts), dz_b[0].view(N, S, BW).sum(1).t() @ lat], 1)
         db_b = dz_b.sum(1)                                                                     # [BD-1, BW]
         grads = [dw0, db_b[0]]
@@ -392,6 +414,9 @@ def bend_native(model, rb, rays, z, latents, details=True):
         masked = masked * scaling                                      # rnh:568-569
     return bent, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
 
+
+# True: the bender's weight gradients come from nrnerf_bender_wgrad (one launch); False: from batched library GEMMs.
+NATIVE_BENDER_WGRAD = True
 
 # True: the ray bender runs on the HIP library (_Bender).  False: as torch ops on the module's parameters (`bend`).
 NATIVE_BENDER = True
