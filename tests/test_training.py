@@ -230,9 +230,11 @@ def O_render_free(scene, rays, latents, perturb, noise, detailed, **flags):
 
 
 @pytest.mark.gpu
-def test_bf16_gradients_point_the_same_way():
-    """bf16 training mode (bf16 activations, d z and weight-gradient GEMMs): gradient direction and size against fp32."""
-    cfg = SceneConfig(N_importance=64)
+@pytest.mark.parametrize("width", [256, 128])
+def test_bf16_gradients_point_the_same_way(width):
+    """bf16 training mode (bf16 activations and d z in block-tile layout, relu bit masks, trunk_wgrad): gradient direction and
+    size against fp32 mode (row-major arrays, library weight-gradient GEMMs), both compiled trunk widths."""
+    cfg = SceneConfig(N_importance=64, netwidth=width)
     scene = make_scene(cfg, 1)
     rays, latents = make_rays(512, 3, cfg)
     grads = {}
