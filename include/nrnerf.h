@@ -304,13 +304,15 @@ int nrnerf_bender_backward(const nrnerf_model* model, const nrnerf_bender_args* 
 /* The weight and bias gradients of the bender's two MLPs from the arrays nrnerf_bender_forward / _backward filled, in one
  * launch: job j = layer j in the order network[0 .. depth-1], rigidity_network[0 .. rigidity_depth-1]; every job yields
  * n_partials partial sums (one per wave; the caller adds them) of  dW [64][64] (rows = the layer's outputs, columns = its
- * inputs; only [out_features][in_features] is meaningful) followed by db [64].  x0 [M, 3 + latent_size]: the offset MLP's
- * input rows (point, latent code), built by the caller. */
+ * inputs; only [out_features][in_features] is meaningful) followed by db [64].  The first layers' input rows (point =
+ * origin + direction * z, latent code) are formed from rays / latents / z as in nrnerf_bender_args. */
 #define NRNERF_BENDER_WGRAD_SLOT (64 * 64 + 64)
 typedef struct nrnerf_bender_wgrad_args {
     uint32_t struct_size;       /* sizeof(nrnerf_bender_wgrad_args) */
     int32_t n_rays, n_samples;
-    const float* x0;
+    const float* rays; int32_t ray_stride;                                       /* as nrnerf_bender_args */
+    const float* latents; int32_t latent_stride;
+    const float* z;
     const float* acts_offsets; const float* acts_rigidity;                       /* as nrnerf_bender_args */
     const float* dz_offsets; const float* dz_rigidity; const float* dz_out4;     /* as nrnerf_bender_args */
     int32_t n_partials;         /* a multiple of 4, <= 4096 */
@@ -324,21 +326,23 @@ int nrnerf_bender_wgrad(const nrnerf_model* model, const nrnerf_bender_wgrad_arg
  *   dw_enc[0] = d_pre[0]^T enc,  dw_enc[1] = d_pre[skip+1]^T enc     (64 columns: the 63 encoding columns + one of padding)
  *   dw_head^T = acts[depth-1]^T g                                    (64 columns: the output channels, zero padded)
  *   db[i] = row sums of d_pre[i]
- * each as n_partials partial sums (one per workgroup) the caller adds up.  enc / g: the encoding of the input points and
- * the gradient wrt the head's outputs in the same block layout, bf16 [B][64][32] (built by the caller: they are small).
+ * each as n_partials partial sums (one per workgroup) the caller adds up: partials[c] is one record of
+ * NRNERF_WGRAD_STRIDE(depth, width) floats = dw_hidden [depth-1][width][width], dw_enc [2][width][64], dw_head^T [width][64],
+ * db [depth+1][width] (row `depth` is scratch), so one sum over the first axis yields them all.  enc / g: the encoding of the input points and
+ * the gradient wrt the head's outputs in the same block layout, bf16 [B][64][32]: scratch the caller allocates, filled by
+ * this call from pts4 and d_raw4 (the arrays given to nrnerf_trunk_backward).
  * NRNERF_ERR_UNSUPPORTED in fp32 mode (the fp32 arrays are row-major for the library GEMMs). */
 typedef struct nrnerf_wgrad_args {
     uint32_t struct_size;       /* sizeof(nrnerf_wgrad_args) */
     int32_t n_rays, n_samples;
     const void* acts; const void* d_pre;       /* as nrnerf_trunk_args, bf16 mode */
-    const void* enc;            /* bf16 [B][64][32] */
-    const void* g_head;         /* bf16 [B][64][32] */
+    const float* pts4; const float* d_raw4;    /* [M,4] each, as nrnerf_trunk_args */
+    void* enc;                  /* scratch, bf16 [B][64][32] */
+    void* g_head;               /* scratch, bf16 [B][64][32] */
     int32_t n_partials;         /* 1 .. 4096; (depth - 1) * n_partials workgroups carry the bulk of the work */
-    float* dw_hidden;           /* out [depth-1][n_partials][width][width] */
-    float* dw_enc;              /* out [2][n_partials][width][64] */
-    float* dw_head_t;           /* out [n_partials][width][64] */
-    float* db;                  /* out [depth+1][n_partials][width]; row `depth` is scratch */
+    float* partials;            /* out [n_partials][NRNERF_WGRAD_STRIDE(depth, width)] */
 } nrnerf_wgrad_args;
+#define NRNERF_WGRAD_STRIDE(depth, width) (((depth) - 1) * (width) * (width) + 3 * (width) * 64 + ((depth) + 1) * (width))
 int nrnerf_trunk_wgrad(const nrnerf_model* model, const nrnerf_wgrad_args* args, void* hip_stream);
 
 /* raw2outputs (train.py:724-789) of one pass, optionally followed by sample_pdf + merge (run_nerf_helpers.py:651-698,

@@ -94,9 +94,14 @@ class TrunkArgs(C.Structure):
 
 class WgradArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
-                ("acts", C.c_void_p), ("d_pre", C.c_void_p), ("enc", C.c_void_p), ("g_head", C.c_void_p),
-                ("n_partials", C.c_int32),
-                ("dw_hidden", C.c_void_p), ("dw_enc", C.c_void_p), ("dw_head_t", C.c_void_p), ("db", C.c_void_p)]
+                ("acts", C.c_void_p), ("d_pre", C.c_void_p), ("pts4", C.c_void_p), ("d_raw4", C.c_void_p),
+                ("enc", C.c_void_p), ("g_head", C.c_void_p),
+                ("n_partials", C.c_int32), ("partials", C.c_void_p)]
+
+
+def wgrad_stride(depth: int, width: int) -> int:
+    """NRNERF_WGRAD_STRIDE of include/nrnerf.h"""
+    return (depth - 1) * width * width + 3 * width * 64 + (depth + 1) * width
 
 
 class BenderArgs(C.Structure):
@@ -113,7 +118,8 @@ class BenderArgs(C.Structure):
 
 class BenderWgradArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
-                ("x0", C.c_void_p), ("acts_offsets", C.c_void_p), ("acts_rigidity", C.c_void_p),
+                ("rays", C.c_void_p), ("ray_stride", C.c_int32), ("latents", C.c_void_p), ("latent_stride", C.c_int32), ("z", C.c_void_p),
+                ("acts_offsets", C.c_void_p), ("acts_rigidity", C.c_void_p),
                 ("dz_offsets", C.c_void_p), ("dz_rigidity", C.c_void_p), ("dz_out4", C.c_void_p),
                 ("n_partials", C.c_int32), ("partials", C.c_void_p)]
 

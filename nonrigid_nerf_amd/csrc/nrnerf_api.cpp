@@ -1029,25 +1029,30 @@ int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* 
     if (!m || !a || a->struct_size != sizeof(nrnerf_wgrad_args)) return NRNERF_ERR_INVALID;
     if (!m->train_ok || m->precision == NRNERF_PREC_F32) return NRNERF_ERR_UNSUPPORTED;
     if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 1 || a->n_partials > 4096) return NRNERF_ERR_INVALID;
-    if (!a->acts || !a->d_pre || !a->enc || !a->g_head || !a->dw_hidden || !a->dw_enc || !a->dw_head_t || !a->db) return NRNERF_ERR_INVALID;
+    if (!a->acts || !a->d_pre || !a->pts4 || !a->d_raw4 || !a->enc || !a->g_head || !a->partials) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
     const int W = (m->arch_id == 5) ? ArchNarrow::W : ArchDefault::W, D = ArchDefault::D, SKIP = ArchDefault::SKIP;
     const long long nblocks = (long long)a->n_rays * ((a->n_samples + 31) / 32);
     const size_t layer = (size_t)nblocks * W * 32;                  // elements of one layer of acts / d_pre
-    const size_t kch = (size_t)a->n_partials;
+    float* const dwh = a->partials;                                 // record layout: NRNERF_WGRAD_STRIDE
+    float* const dwe = dwh + (size_t)(D - 1) * W * W;
+    float* const dwo = dwe + (size_t)2 * W * 64;
+    float* const db = dwo + (size_t)W * 64;
     const __bf16* acts = (const __bf16*)a->acts;
     const __bf16* dpre = (const __bf16*)a->d_pre;
     WgradArgs w{};
-    w.kch = a->n_partials; w.nblocks = nblocks;
+    w.kch = a->n_partials; w.nblocks = nblocks; w.pstride = NRNERF_WGRAD_STRIDE(D, W);
     int n = 0;
     for (int i = 1; i < D; ++i)                                     // hidden-to-hidden layers: the bulk, first in the grid
-        w.job[n++] = WgradJob{dpre + i * layer, acts + (i - 1) * layer, W, a->dw_hidden + (size_t)(i - 1) * kch * W * W, a->db + (size_t)i * kch * W};
-    w.job[n++] = WgradJob{dpre, a->enc, 64, a->dw_enc, a->db};
-    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer, a->enc, 64, a->dw_enc + kch * W * 64, a->db + (size_t)D * kch * W};
-    w.job[n++] = WgradJob{acts + (D - 1) * layer, a->g_head, 64, a->dw_head_t, a->db + (size_t)D * kch * W};
+        w.job[n++] = WgradJob{dpre + i * layer, acts + (i - 1) * layer, W, dwh + (size_t)(i - 1) * W * W, db + (size_t)i * W};
+    w.job[n++] = WgradJob{dpre, a->enc, 64, dwe, db};
+    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer, a->enc, 64, dwe + (size_t)W * 64, db + (size_t)D * W};
+    w.job[n++] = WgradJob{acts + (D - 1) * layer, a->g_head, 64, dwo, db + (size_t)D * W};
     w.njobs = n;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
+    const WgradOperandArgs ops{a->pts4, a->d_raw4, a->n_rays, a->n_samples, ArchDefault::L, a->enc, a->g_head};
+    if (launch_wgrad_operands(ops, (hipStream_t)hip_stream) != hipSuccess) return NRNERF_ERR_HIP;
     const hipError_t e = (m->arch_id == 5) ? launch_trunk_wgrad_bf16_a5(w, (hipStream_t)hip_stream) : launch_trunk_wgrad_bf16(w, (hipStream_t)hip_stream);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
@@ -1102,22 +1107,25 @@ int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a
     if (!m || !a || a->struct_size != sizeof(nrnerf_bender_wgrad_args)) return NRNERF_ERR_INVALID;
     if (!m->bend_train_ok) return NRNERF_ERR_UNSUPPORTED;
     if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 4 || a->n_partials > 4096 || a->n_partials % 4) return NRNERF_ERR_INVALID;
-    if (!a->x0 || !a->acts_offsets || !a->acts_rigidity || !a->dz_offsets || !a->dz_rigidity || !a->dz_out4 || !a->partials) return NRNERF_ERR_INVALID;
+    if (!a->rays || a->ray_stride < 6 || !a->latents || a->latent_stride < m->latent_size || !a->z) return NRNERF_ERR_INVALID;
+    if (!a->acts_offsets || !a->acts_rigidity || !a->dz_offsets || !a->dz_rigidity || !a->dz_out4 || !a->partials) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
     const int BD = (bender_arch(m->arch_id) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
     const int BW = ArchDefault::BW, RD = ArchDefault::RD, RW = ArchDefault::RW, X0 = 3 + ArchDefault::LAT;
     const size_t M = (size_t)a->n_rays * a->n_samples;
     BendWgradArgs w{};
     int n = 0;
-    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, a->x0, X0, X0};                                         // network[0]
+    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, nullptr, X0, X0};                                       // network[0]: input = [point, latent]
     for (int i = 1; i <= BD - 2; ++i)
         w.job[n++] = BendWgradJob{a->dz_offsets + (size_t)i * M * BW, BW, BW, a->acts_offsets + (size_t)(i - 1) * M * BW, BW, BW};
     w.job[n++] = BendWgradJob{a->dz_out4, 4, 3, a->acts_offsets + (size_t)(BD - 2) * M * BW, BW, BW};        // network[BD-1]: 3 x BW
-    w.job[n++] = BendWgradJob{a->dz_rigidity, RW, RW, a->x0, X0, 3};                                         // rigidity_network[0]: input = the point
+    w.job[n++] = BendWgradJob{a->dz_rigidity, RW, RW, nullptr, X0, 3};                                       // rigidity_network[0]: input = the point
     for (int i = 1; i <= RD - 2; ++i)
         w.job[n++] = BendWgradJob{a->dz_rigidity + (size_t)i * M * RW, RW, RW, a->acts_rigidity + (size_t)(i - 1) * M * RW, RW, RW};
     w.job[n++] = BendWgradJob{a->dz_out4 + 3, 4, 1, a->acts_rigidity + (size_t)(RD - 2) * M * RW, RW, RW};   // the logit's layer: 1 x RW
     w.njobs = n; w.nparts = a->n_partials; w.m = (long long)M; w.out = a->partials;
+    w.rays = a->rays; w.ray_stride = a->ray_stride; w.latents = a->latents; w.lat_stride = a->latent_stride; w.lat = m->latent_size;
+    w.z = a->z; w.S = a->n_samples;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     return launch_bend_wgrad(w, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;

@@ -157,7 +157,8 @@ hipError_t launch_bend_bwd_a1(const BendTrainArgs&, int num_cus, hipStream_t);
 // row-major fp32 arrays, at most 64 x 64 each
 struct BendWgradJob {
     const float* dz; int ldz, f;      // [M][ldz], the first f <= 64 columns: gradient wrt a layer's pre-activations
-    const float* x;  int ldx, g;      // [M][ldx], the first g <= 64 columns: that layer's input
+    const float* x;  int ldx, g;      // [M][ldx], the first g <= 64 columns: that layer's input; nullptr: the offset MLP's input
+                                      // row [point, latent code], formed on the fly from the ray records (BendWgradArgs)
 };
 constexpr int BEND_WGRAD_MAX_JOBS = 12;
 constexpr int BEND_WGRAD_SLOT = 64 * 64 + 64;       // floats per (partial, job): dW [64][64] then db [64]
@@ -166,6 +167,10 @@ struct BendWgradArgs {
     int njobs, nparts;                // grid = (nparts / 4, njobs), 4 waves per workgroup, one partial per wave
     long long m;
     float* out;                       // [nparts][njobs][BEND_WGRAD_SLOT]
+    // for jobs with x == nullptr: point = origin + direction * z, then the ray's latent code
+    const float* rays; int ray_stride;
+    const float* latents; int lat_stride, lat;
+    const float* z; int S;
 };
 hipError_t launch_bend_wgrad(const BendWgradArgs&, hipStream_t);
 
@@ -174,15 +179,27 @@ struct WgradJob {
     const void* dz;          // [nblocks][W][32] bf16: gradient wrt a layer's pre-activations
     const void* x;           // [nblocks][xw][32] bf16: that layer's input (previous activations, or the encoding)
     int xw;                  // 256-wide trunk: W or 64 (encoding, zero padded); a multiple of 64
-    float* dw;               // out [kch][W][xw] fp32: one partial product per workgroup of the job (the caller adds them)
-    float* db;               // out [kch][W]     fp32: partial row sums of dz = bias gradient
+    float* dw;               // out [W][xw] fp32 of partial 0; partial c (one per workgroup of the job) at + c * pstride
+    float* db;               // out [W] fp32 of partial 0: row sums of dz = bias gradient
 };
 constexpr int WGRAD_MAX_JOBS = 12;
 struct WgradArgs {
     WgradJob job[WGRAD_MAX_JOBS];
     int njobs, kch;          // grid = (kch, njobs)
     long long nblocks;
+    long long pstride;       // floats between consecutive partials (the caller adds the kch partials)
 };
+// the two small operands of trunk_wgrad in its layout, from the arrays the other kernels already have: the positional
+// encoding of the input points and the gradient wrt the head's outputs, bf16 [nblocks][64][32] each (row 63 / rows >= 4 and
+// the columns beyond a ray's end zero)
+struct WgradOperandArgs {
+    const float* pts4;       // [M,4]
+    const float* d_raw4;     // [M,4]
+    int n_rays, S, L;        // L encoding frequencies (3 + 6 L <= 63)
+    void* enc;               // out bf16 [nblocks][64][32]
+    void* g_head;            // out bf16 [nblocks][64][32]
+};
+hipError_t launch_wgrad_operands(const WgradOperandArgs&, hipStream_t);
 hipError_t launch_trunk_wgrad_bf16(const WgradArgs&, hipStream_t);
 hipError_t launch_trunk_wgrad_bf16_a5(const WgradArgs&, hipStream_t);
 

@@ -52,6 +52,38 @@ __global__ void __launch_bounds__(256) repack_kernel(const RepackArgs a) {
     else if (f == 2) ((_Float16*)a.dst)[i] = (_Float16)w;
     else ((_Float16*)a.dst)[i] = (_Float16)((w - (float)(_Float16)w) * 2048.0f);
 }
+// operands of trunk_wgrad (nrnerf_train.h) that no kernel has written yet: Embedder.embed (run_nerf_helpers.py:120-150) of the
+// trunk's input points and the gradient wrt the head's outputs, as [block][row][32 samples] bf16 tiles
+__global__ void __launch_bounds__(256) wgrad_operands_kernel(const WgradOperandArgs a) {
+    const int bpr = (a.S + 31) >> 5;
+    const long long nblocks = (long long)a.n_rays * bpr;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per (block, row, sample)
+    if (t >= nblocks * 64 * 32) return;
+    const int j = (int)(t & 31), r = (int)((t >> 5) & 63);
+    const long long blk = t >> 11;
+    const int ray = (int)(blk / bpr), sidx = (int)(blk % bpr) * 32 + j;
+    float e = 0.0f, g = 0.0f;
+    if (sidx < a.S) {
+        const size_t so = (size_t)ray * a.S + sidx;
+        if (r < 3) {
+            e = a.pts4[so * 4 + r];
+        } else if (r < 3 + 6 * a.L) {
+            const int k = (r - 3) / 6, w = (r - 3) % 6;
+            const float x = a.pts4[so * 4 + (w % 3)] * (float)(1 << k);
+            e = (w < 3) ? sinf(x) : cosf(x);
+        }
+        if (r < 4) g = a.d_raw4[so * 4 + r];
+    }
+    ((__bf16*)a.enc)[t] = (__bf16)e;
+    ((__bf16*)a.g_head)[t] = (__bf16)g;
+}
+hipError_t launch_wgrad_operands(const WgradOperandArgs& a, hipStream_t stream) {
+    const long long total = (long long)a.n_rays * ((a.S + 31) / 32) * 64 * 32;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(wgrad_operands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_repack(const RepackArgs& a, hipStream_t stream) {
     if (a.n <= 0) return hipSuccess;
     hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256, 1) trunk_wgrad(const WgradArgs a) {
         blk = n2;
     }
     // D tile: lane (h, j) holds rows tile_row(r, h), column j
-    float* dw = jb.dw + (size_t)blockIdx.x * A::W * jb.xw;
+    float* dw = jb.dw + (size_t)blockIdx.x * a.pstride;
 #pragma unroll
     for (int u = 0; u < TR; ++u) {
 #pragma unroll
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256, 1) trunk_wgrad(const WgradArgs a) {
                     dw[(size_t)(32 * (wr * TR + u) + tile_row(r, h)) * jb.xw + 32 * (wc * tcw + v) + i] = acc[u][v][r];
             }
         const float rowsum = bsum[u] + __shfl_xor(bsum[u], 32);        // the two lane halves hold samples 8h .. 8h + 7 of each k-step
-        if (wc == 0 && h == 0) jb.db[(size_t)blockIdx.x * A::W + 32 * (wr * TR + u) + i] = rowsum;
+        if (wc == 0 && h == 0) jb.db[(size_t)blockIdx.x * a.pstride + 32 * (wr * TR + u) + i] = rowsum;
     }
 }
 

@@ -271,11 +271,22 @@ __global__ void __launch_bounds__(256) bend_wgrad(const BendWgradArgs a) {
             const long long s = 2 * (p + u) + h;
             const bool ok = (p + u < p1) && s < a.m;
             const float* dr = jb.dz + (size_t)s * jb.ldz + i;
-            const float* xr = jb.x + (size_t)s * jb.ldx + i;
             av[u][0] = (ok && fa0) ? dr[0] : 0.0f;
             av[u][1] = (ok && fa1) ? dr[32] : 0.0f;
-            bv[u][0] = (ok && gb0) ? xr[0] : 0.0f;
-            bv[u][1] = (ok && gb1) ? xr[32] : 0.0f;
+            if (jb.x) {
+                const float* xr = jb.x + (size_t)s * jb.ldx + i;
+                bv[u][0] = (ok && gb0) ? xr[0] : 0.0f;
+                bv[u][1] = (ok && gb1) ? xr[32] : 0.0f;
+            } else {                            // column c of [point (3), latent code]: c = i (first tile), 32 + i (second)
+                const long long ray = ok ? s / a.S : 0;
+                const float* rp = a.rays + (size_t)ray * a.ray_stride;
+                const float* lp = a.latents + (size_t)ray * a.lat_stride;
+                float v0 = 0.0f, v1 = 0.0f;
+                if (ok && gb0) v0 = (i < 3) ? __fadd_rn(rp[i], __fmul_rn(rp[3 + i], a.z[s])) : lp[i - 3];
+                if (ok && gb1) v1 = lp[29 + i];
+                bv[u][0] = v0;
+                bv[u][1] = v1;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

@@ -160,28 +160,29 @@ class _Trunk(torch.autograd.Function):
 
     @staticmethod
     def _weight_grads_bf16(model, net, dims, pts4, acts, d_pre, g):
-        """bf16 mode: every weight and bias gradient of the trunk from one launch of nrnerf_trunk_wgrad over the two
+        """bf16 mode: every weight and bias gradient of the trunk from one call of nrnerf_trunk_wgrad over the two
         [block][feature][32 samples] arrays (reads each once; the library route read them twice and reduced d_pre a third
-        time).  The two small operands it needs in the same layout -- the encoding of the input points and the gradient
-        wrt the head's outputs -- are built here."""
+        time).  One record of partial sums per workgroup, added here with one reduction."""
         N, S, D, W, C_out = dims
         dev = acts.device
         L = (int(net.input_ch) - 3) // 6
-        enc_t = _block_tiles(posenc(pts4[:, :3], L), N, S)                                   # [B, 64, 32]
-        g_t = _block_tiles(g, N, S)                                                          # channels 0..3; the 5th never reaches the loss
-        kch = max(1, min(int(acts.shape[1]), _num_cus(dev) // (D - 1)))
-        dwh = torch.empty(D - 1, kch, W, W, dtype=torch.float32, device=dev)
-        dwe = torch.empty(2, kch, W, 64, dtype=torch.float32, device=dev)
-        dwo = torch.empty(kch, W, 64, dtype=torch.float32, device=dev)
-        db = torch.empty(D + 1, kch, W, dtype=torch.float32, device=dev)
+        nblk = int(acts.shape[1])
+        scratch = torch.empty(2, nblk, 64, 32, dtype=torch.bfloat16, device=dev)             # encoding / head-gradient tiles
+        kch = max(1, min(nblk, _num_cus(dev) // (D - 1)))
+        parts = torch.empty(kch, _lib.wgrad_stride(D, W), dtype=torch.float32, device=dev)
         a = _lib.WgradArgs()
         a.struct_size = C.sizeof(_lib.WgradArgs)
         a.n_rays, a.n_samples, a.n_partials = N, S, kch
-        a.acts, a.d_pre, a.enc, a.g_head = acts.data_ptr(), d_pre.data_ptr(), enc_t.data_ptr(), g_t.data_ptr()
-        a.dw_hidden, a.dw_enc, a.dw_head_t, a.db = dwh.data_ptr(), dwe.data_ptr(), dwo.data_ptr(), db.data_ptr()
+        a.acts, a.d_pre, a.pts4, a.d_raw4 = acts.data_ptr(), d_pre.data_ptr(), pts4.data_ptr(), g.data_ptr()
+        a.enc, a.g_head, a.partials = scratch[0].data_ptr(), scratch[1].data_ptr(), parts.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_wgrad")
-        dwh, dwe, dwo, db = dwh.sum(1), dwe.sum(1), dwo.sum(0), db.sum(1)
+        tot = parts.sum(0)
+        o = 0
+        dwh = tot[o:o + (D - 1) * W * W].view(D - 1, W, W); o += (D - 1) * W * W
+        dwe = tot[o:o + 2 * W * 64].view(2, W, 64); o += 2 * W * 64
+        dwo = tot[o:o + W * 64].view(W, 64); o += W * 64
+        db = tot[o:o + (D + 1) * W].view(D + 1, W)
         n_enc = 3 + 6 * L
         skips = set(int(s) for s in net.skips)
         grads = []
@@ -193,10 +194,8 @@ class _Trunk(torch.autograd.Function):
             else:
                 dw = dwh[i - 1]
             grads += [dw, db[i]]
-        g_out = torch.zeros(C_out, dtype=torch.float32, device=dev)
-        g_out[:4] = g.sum(0)
-        dw_out = torch.zeros(C_out, W, dtype=torch.float32, device=dev)
-        dw_out[:4] = dwo[:, :4].t()
+        dw_out = F.pad(dwo[:, :4].t(), (0, 0, 0, C_out - 4))                                 # the 5th channel never reaches the loss
+        g_out = F.pad(g.sum(0), (0, C_out - 4))
         return grads + [dw_out, g_out]
 
 
@@ -208,16 +207,6 @@ def _num_cus(dev) -> int:
     if k not in _NUM_CUS:
         _NUM_CUS[k] = int(torch.cuda.get_device_properties(k).multi_processor_count)
     return _NUM_CUS[k]
-
-
-def _block_tiles(x: torch.Tensor, N: int, S: int) -> torch.Tensor:
-    """[N*S, c <= 64] -> bf16 [B, 64, 32]: per block of 32 consecutive samples of a ray a [64 x 32] tile with the samples
-    contiguous, rows >= c and the columns beyond a ray's end zero -- the operand layout of nrnerf_trunk_wgrad."""
-    c = int(x.shape[1])
-    bpr = (S + 31) // 32
-    t = torch.zeros(N, bpr * 32, 64, dtype=torch.bfloat16, device=x.device)
-    t[:, :S, :c] = x.view(N, S, c)
-    return t.view(N * bpr, 32, 64).transpose(1, 2).contiguous()
 
 
 def _trunk_params(net):
@@ -332,17 +321,16 @@ class _Bender(torch.autograd.Function):
         a.dz_offsets, a.dz_rigidity, a.dz_out4, a.d_latents = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), d_lat.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_backward")
-        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(M, 3)
         if NATIVE_BENDER_WGRAD:
             # every weight / bias gradient of both MLPs in one launch (nrnerf_bender_wgrad): partial sums per wave, added here
-            x0 = torch.cat([pts, lat[:, None, :].expand(N, S, LAT).reshape(M, LAT)], 1)
             nparts = 4 * max(1, min(_num_cus(dev), (M + 1023) // 1024))
             nj = BD + RD
             parts = torch.empty(nparts, nj, _lib.BENDER_WGRAD_SLOT, dtype=torch.float32, device=dev)
             w = _lib.BenderWgradArgs()
             w.struct_size = C.sizeof(_lib.BenderWgradArgs)
             w.n_rays, w.n_samples, w.n_partials = N, S, nparts
-            w.x0, w.acts_offsets, w.acts_rigidity = x0.data_ptr(), acts_b.data_ptr(), acts_r.data_ptr()
+            w.rays, w.ray_stride, w.latents, w.latent_stride, w.z = rays.data_ptr(), int(rays.stride(0)), lat.data_ptr(), int(lat.stride(0)), z.data_ptr()
+            w.acts_offsets, w.acts_rigidity = acts_b.data_ptr(), acts_r.data_ptr()
             w.dz_offsets, w.dz_rigidity, w.dz_out4, w.partials = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), parts.data_ptr()
             with torch.cuda.device(dev):
                 _lib.check(model.lib.nrnerf_bender_wgrad(model.handle, C.byref(w), _stream(dev)), "nrnerf_bender_wgrad")
@@ -356,6 +344,7 @@ class _Bender(torch.autograd.Function):
                     grads.append(dB[k, :o])
             return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, *grads)
         # library route.  weight gradients dW_i = dz_i^T x_i over the stored arrays (batched library GEMMs, see _wgrad).
+        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(M, 3)
         # x_0 = [p, latent]: the latent columns are constant along a ray, so their part is (per-ray sums of dz_0)^T latents.
         dw0 = torch.cat([_wgrad(dz_b[0], pts), dz_b[0].view(N, S, BW).sum(1).t() @ lat], 1)
         db_b = dz_b.sum(1)                                                                     # [BD-1, BW]

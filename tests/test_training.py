@@ -392,38 +392,58 @@ def test_native_bender_forward_and_gradients_vs_torch_autograd(precision, wgrad,
     print(f"\n[native bender vs torch autograd, {precision} model, weight gradients: {wgrad}] worst gradient error / scale {worst:.1e}")
 
 
+def _block_tiles(x, N, S):
+    """[N*S, c <= 64] -> bf16 [B, 64, 32]: per block of 32 consecutive samples of a ray a [64 x 32] tile with the samples
+    contiguous, rows >= c and the columns beyond a ray's end zero -- the operand layout of nrnerf_trunk_wgrad."""
+    c, bpr = int(x.shape[1]), (S + 31) // 32
+    t = torch.zeros(N, bpr * 32, 64, dtype=torch.bfloat16, device=x.device)
+    t[:, :S, :c] = x.view(N, S, c)
+    return t.view(N * bpr, 32, 64).transpose(1, 2).contiguous()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("width,n_rays,S", [(256, 37, 192), (256, 5, 85), (128, 64, 64)], ids=["w256", "w256_ragged", "w128"])
 def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S):
-    """nrnerf_trunk_wgrad (bf16 mode: all weight / bias gradients of the trunk in one launch over the [block][feature][32
+    """nrnerf_trunk_wgrad (bf16 mode: all weight / bias gradients of the trunk in one call over the [block][feature][32
     samples] arrays) on random bf16 arrays against fp32 einsums over the same values: hidden layers, the two encoding
     products, the head, the bias sums; ragged block counts; both compiled trunk widths.  fp32 accumulation on both sides,
-    so 1e-4 of scale."""
+    so 1e-4 of scale.  The two operands the call builds itself -- encoding of the points, head gradient, in block tiles --
+    against torch (one bf16 ulp: sin / cos implementations differ in the last fp32 bit)."""
     import ctypes as C
-    from nonrigid_nerf_amd import _lib
+    from nonrigid_nerf_amd import _lib, training
     cfg = SceneConfig(N_importance=64, netwidth=width)
     scene = make_scene(cfg, 0)
     rb, coarse, fine = _modules(scene, requires_grad=False)
     R.set_precision("bf16")
     model = R.get_model(coarse, fine, precision="bf16", device=torch.device(DEV))
-    D, W = 8, width
+    D, W, M = 8, width, n_rays * S
     nblk = n_rays * ((S + 31) // 32)
     gen = torch.Generator().manual_seed(4)
     mk = lambda *shape: (torch.randn(*shape, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
     acts, d_pre = mk(D, nblk, W, 32).abs(), mk(D, nblk, W, 32)
-    enc_t, g_t = mk(nblk, 64, 32), mk(nblk, 64, 32)
+    pts4 = (torch.randn(M, 4, generator=gen) * 0.4).to(DEV)
+    g4 = torch.randn(M, 4, generator=gen).to(DEV)
+    scratch = torch.full((2, nblk, 64, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
     kch = 7
-    dwh = torch.full((D - 1, kch, W, W), float("nan"), device=DEV)
-    dwe = torch.full((2, kch, W, 64), float("nan"), device=DEV)
-    dwo = torch.full((kch, W, 64), float("nan"), device=DEV)
-    db = torch.full((D + 1, kch, W), float("nan"), device=DEV)
+    stride = _lib.wgrad_stride(D, W)
+    parts = torch.full((kch, stride), float("nan"), device=DEV)
     a = _lib.WgradArgs()
     a.struct_size = C.sizeof(_lib.WgradArgs)
     a.n_rays, a.n_samples, a.n_partials = n_rays, S, kch
-    a.acts, a.d_pre, a.enc, a.g_head = acts.data_ptr(), d_pre.data_ptr(), enc_t.data_ptr(), g_t.data_ptr()
-    a.dw_hidden, a.dw_enc, a.dw_head_t, a.db = dwh.data_ptr(), dwe.data_ptr(), dwo.data_ptr(), db.data_ptr()
+    a.acts, a.d_pre, a.pts4, a.d_raw4 = acts.data_ptr(), d_pre.data_ptr(), pts4.data_ptr(), g4.data_ptr()
+    a.enc, a.g_head, a.partials = scratch[0].data_ptr(), scratch[1].data_ptr(), parts.data_ptr()
     _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nrnerf_trunk_wgrad")
     torch.cuda.synchronize()
+    enc_t, g_t = scratch[0], scratch[1]
+    want_enc = _block_tiles(training.posenc(pts4[:, :3], 10), n_rays, S).float()
+    assert float((enc_t.float() - want_enc).abs().max()) <= 2.0 ** -7 and bool((enc_t[:, 63] == 0).all())
+    assert torch.equal(g_t, _block_tiles(g4, n_rays, S))
+    tot = parts.sum(0)
+    o = 0
+    dwh = tot[o:o + (D - 1) * W * W].view(D - 1, W, W); o += (D - 1) * W * W
+    dwe = tot[o:o + 2 * W * 64].view(2, W, 64); o += 2 * W * 64
+    dwo = tot[o:o + W * 64].view(W, 64); o += W * 64
+    db = tot[o:o + (D + 1) * W].view(D + 1, W)
     A, Z = acts.float(), d_pre.float()
 
     def close(got, want, what):
@@ -431,9 +451,9 @@ def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S):
         assert float((got - want).abs().max()) <= 1e-4 * scale, (what, float((got - want).abs().max()), scale)
 
     for i in range(1, D):
-        close(dwh[i - 1].sum(0), torch.einsum("bfs,bgs->fg", Z[i], A[i - 1]), f"hidden {i}")
-        close(db[i].sum(0), Z[i].sum((0, 2)), f"bias {i}")
-    close(db[0].sum(0), Z[0].sum((0, 2)), "bias 0")
-    close(dwe[0].sum(0), torch.einsum("bfs,bgs->fg", Z[0], enc_t.float()), "encoding, layer 0")
-    close(dwe[1].sum(0), torch.einsum("bfs,bgs->fg", Z[5], enc_t.float()), "encoding, skip layer")
-    close(dwo.sum(0), torch.einsum("bfs,bgs->fg", A[D - 1], g_t.float()), "head")
+        close(dwh[i - 1], torch.einsum("bfs,bgs->fg", Z[i], A[i - 1]), f"hidden {i}")
+        close(db[i], Z[i].sum((0, 2)), f"bias {i}")
+    close(db[0], Z[0].sum((0, 2)), "bias 0")
+    close(dwe[0], torch.einsum("bfs,bgs->fg", Z[0], enc_t.float()), "encoding, layer 0")
+    close(dwe[1], torch.einsum("bfs,bgs->fg", Z[5], enc_t.float()), "encoding, skip layer")
+    close(dwo, torch.einsum("bfs,bgs->fg", A[D - 1], g_t.float()), "head")
