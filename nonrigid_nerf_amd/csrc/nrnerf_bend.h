@@ -21,6 +21,10 @@ namespace nrn {
 template <class P, int NFRAGS>
 struct WResident {
     static constexpr bool ASM_FRAGS = (P::FRAG_BYTES == 1024);
+    // fp32 fragments (one dword per lane): explicit ds_read_b32 + counted waits as well -- with plain loads hipcc hoists
+    // dozens of the loop-invariant fragment reads out of the persistent loop and spills them (80-150 registers of scratch in
+    // the fp32 bender kernels)
+    static constexpr bool ASM_FRAGS32 = (P::FRAG_BYTES == 256);
     static constexpr int BYTES = NFRAGS * P::FRAG_BYTES;
     char* base;
     int lane_off;
@@ -45,6 +49,11 @@ struct WResident {
             if constexpr (OFF + 16 <= 65536) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lane_addr), "n"(OFF));
             else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lane_addr_hi), "n"(OFF - 65536));
             return __builtin_bit_cast(typename PX::frag, v);
+        } else if constexpr (ASM_FRAGS32) {
+            unsigned v;
+            if constexpr (OFF + 4 <= 65536) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(lane_addr), "n"(OFF));
+            else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(lane_addr_hi), "n"(OFF - 65536));
+            return __builtin_bit_cast(typename PX::frag, v);
         } else {
             return *(const typename PX::frag*)(base + OFF + lane_off);
         }
@@ -56,13 +65,18 @@ struct WResident {
             u32x4 v = __builtin_bit_cast(u32x4, f);
             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
             f = __builtin_bit_cast(F, v);
+        } else if constexpr (ASM_FRAGS32) {
+            static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+            unsigned v = __builtin_bit_cast(unsigned, f);
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+            f = __builtin_bit_cast(F, v);
         }
     }
 };
 
 template <class P, class A, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) bend_kernel(const BendArgs a) {
-    static_assert(P::KH == 1 ? WAVES == 4 : WAVES == 8, "fp32 mode: one wave per SIMD (512 registers); 16-bit modes: two");
+__global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 4 : 2) bend_kernel(const BendArgs a) {
+    static_assert(P::KH == 1 ? WAVES == 4 : WAVES == 8, "fp32 mode: workgroups of four waves, four of them per CU; 16-bit modes: eight waves");
     using PL = Plan<P, A, true, false, false>;                  // bender + rigidity layers only
     using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;  // as in the fused kernels (nrnerf_plan.h frag_is_f16)
     constexpr int KH = P::KH, SP = P::SP;
@@ -243,7 +257,8 @@ static hipError_t launch_bend_one(const BendArgs& a, int num_cus, hipStream_t st
     if (want <= 0) return hipSuccess;
     // persistent: one workgroup per CU; two for the single-product 16-bit variant (39 KiB of resident weights and < 128
     // VGPRs per lane: sixteen waves per CU fit, four per SIMD to hide the VALU-heavy packing behind each other's MFMAs)
-    const long long per_cu = (P::KH != 1 && !P::SPLIT) ? 2 : 1;
+    // fp32: 20 KiB of resident weights and ~100 VGPRs per lane (explicit ds_read_b32 fragment reads): four workgroups per CU
+    const long long per_cu = (P::KH == 1) ? 4 : ((!P::SPLIT) ? 2 : 1);
     const long long resident = per_cu * num_cus;
     const int grid = (int)(want < resident ? want : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);

@@ -32,7 +32,7 @@ __device__ __forceinline__ void pack_lin(const f32x16& acc, ACT& out) {      // 
 }
 
 template <class A>
-__global__ void __launch_bounds__(256, 1) bend_fwd_train(const BendTrainArgs a) {
+__global__ void __launch_bounds__(256, 2) bend_fwd_train(const BendTrainArgs a) {
     using P = PolF32;
     using PL = Plan<P, A, true, false, false>;
     constexpr int KH = P::KH, SP = P::SP, WAVES = 4;
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256, 1) bend_fwd_train(const BendTrainArgs a) 
 }
 
 template <class A>
-__global__ void __launch_bounds__(256, 1) bend_bwd(const BendTrainArgs a) {
+__global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
     using P = PolF32;
     using PL = PlanBB<P, A>;
     constexpr int KH = P::KH, SP = P::SP, WAVES = 4;
@@ -332,7 +332,9 @@ static hipError_t launch_bend_train(const BendTrainArgs& a, int num_cus, hipStre
     if (nblocks >= (1ll << 31)) return hipErrorInvalidValue;
     const long long want = (nblocks + 3) / 4;
     if (want <= 0) return hipSuccess;
-    const int grid = (int)(want < num_cus ? want : num_cus);
+    // two workgroups per CU when their resident weights fit twice (forward 20 / 28 KiB, backward 65 / 97 KiB of 160)
+    const long long resident = (long long)num_cus * ((2 * lds <= 160 * 1024) ? 2 : 1);
+    const int grid = (int)(want < resident ? want : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
