@@ -230,8 +230,8 @@ def O_render_free(scene, rays, latents, perturb, noise, detailed, **flags):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("width", [256, 128])
-def test_bf16_gradients_point_the_same_way(width):
+@pytest.mark.parametrize("width,detailed", [(256, False), (128, False), (256, True)], ids=["w256", "w128", "w256_detailed_loss"])
+def test_bf16_gradients_point_the_same_way(width, detailed):
     """bf16 training mode (bf16 activations and d z in block-tile layout, relu bit masks, trunk_wgrad): gradient direction and
     size against fp32 mode (row-major arrays, library weight-gradient GEMMs), both compiled trunk widths."""
     cfg = SceneConfig(N_importance=64, netwidth=width)
@@ -243,8 +243,8 @@ def test_bf16_gradients_point_the_same_way(width):
         lat = latents.to(DEV).requires_grad_(True)
         R.set_precision(prec)
         out = R.render_rays(rays.to(DEV), coarse, None, 64, N_importance=64, network_fine=fine,
-                            additional_pixel_information={"ray_bending_latents": lat})
-        _loss(out, False).backward()
+                            additional_pixel_information={"ray_bending_latents": lat}, detailed_output=detailed)
+        _loss(out, detailed).backward()             # detailed: + the offsets / rigidity regulariser terms and a weights term
         g = {k: p.grad.flatten().float() for k, p in _named(rb, coarse, fine).items() if p.grad is not None}
         g[("latents", "")] = lat.grad.flatten()
         grads[prec] = g
