@@ -19,6 +19,7 @@ CASES = {
     "viewdirs (exact)":      dict(use_viewdirs=True, N_importance=64, approx_nonrigid_viewdirs=False),
     "deep bender + viewdirs": dict(use_viewdirs=True, N_importance=64, bend_depth=7),
     "time-conditioned":      dict(ray_bending=False, time_conditioned_baseline=True, N_importance=64),
+    "width 128":             dict(netwidth=128, N_importance=64),
 }
 bad = 0
 for name, kw in CASES.items():
