@@ -328,7 +328,9 @@ int nrnerf_bender_wgrad(const nrnerf_model* model, const nrnerf_bender_wgrad_arg
  *   db[i] = row sums of d_pre[i]
  * each as n_partials partial sums (one per workgroup) the caller adds up: partials[c] is one record of
  * NRNERF_WGRAD_STRIDE(depth, width) floats = dw_hidden [depth-1][width][width], dw_enc [2][width][64], dw_head^T [width][64],
- * db [depth+1][width] (row `depth` is scratch), so one sum over the first axis yields them all.  enc / g: the encoding of the input points and
+ * db [depth+1][width] (row `depth` is scratch), so one sum over the first axis yields them all.  The 64-column products
+ * (dw_enc, dw_head^T, db[0]) are cut into fewer, longer partial sums (they cost less per block: all workgroups of the
+ * launch then finish together) and only fill the first records: the caller ZERO-FILLS `partials` before the call.  enc / g: the encoding of the input points and
  * the gradient wrt the head's outputs in the same block layout, bf16 [B][64][32]: scratch the caller allocates, filled by
  * this call from pts4 and d_raw4 (the arrays given to nrnerf_trunk_backward).
  * NRNERF_ERR_UNSUPPORTED in fp32 mode (the fp32 arrays are row-major for the library GEMMs). */
@@ -339,7 +341,8 @@ typedef struct nrnerf_wgrad_args {
     const float* pts4; const float* d_raw4;    /* [M,4] each, as nrnerf_trunk_args */
     void* enc;                  /* scratch, bf16 [B][64][32] */
     void* g_head;               /* scratch, bf16 [B][64][32] */
-    int32_t n_partials;         /* 1 .. 4096; (depth - 1) * n_partials workgroups carry the bulk of the work */
+    int32_t n_partials;         /* 1 .. 4096 records; the launch has about 8.9 * n_partials workgroups (width 256): 28 fills an
+                                   MI355X with one workgroup per CU */
     float* partials;            /* out [n_partials][NRNERF_WGRAD_STRIDE(depth, width)] */
 } nrnerf_wgrad_args;
 #define NRNERF_WGRAD_STRIDE(depth, width) (((depth) - 1) * (width) * (width) + 3 * (width) * 64 + ((depth) + 1) * (width))

@@ -1041,14 +1041,20 @@ int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* 
     const __bf16* acts = (const __bf16*)a->acts;
     const __bf16* dpre = (const __bf16*)a->d_pre;
     WgradArgs w{};
-    w.kch = a->n_partials; w.nblocks = nblocks; w.pstride = NRNERF_WGRAD_STRIDE(D, W);
+    w.nblocks = nblocks; w.pstride = NRNERF_WGRAD_STRIDE(D, W);
+    // a 64-column job (encoding, head) loads 2 TR + 2 fragments per block and wave, a hidden-to-hidden one 2 TR + 2 TCW:
+    // give it that share of the workgroups, so that all workgroups of the launch finish together
+    const int kh = a->n_partials, TRw = W / 64;
+    int kl = (kh * (2 * TRw + 2) + (2 * TRw + W / 32) / 2) / (2 * TRw + W / 32);
+    kl = kl < 1 ? 1 : (kl > kh ? kh : kl);
     int n = 0;
     for (int i = 1; i < D; ++i)                                     // hidden-to-hidden layers: the bulk, first in the grid
-        w.job[n++] = WgradJob{dpre + i * layer, acts + (i - 1) * layer, W, dwh + (size_t)(i - 1) * W * W, db + (size_t)i * W};
-    w.job[n++] = WgradJob{dpre, a->enc, 64, dwe, db};
-    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer, a->enc, 64, dwe + (size_t)W * 64, db + (size_t)D * W};
-    w.job[n++] = WgradJob{acts + (D - 1) * layer, a->g_head, 64, dwo, db + (size_t)D * W};
+        w.job[n++] = WgradJob{dpre + i * layer, acts + (i - 1) * layer, W, dwh + (size_t)(i - 1) * W * W, db + (size_t)i * W, kh, 0};
+    w.job[n++] = WgradJob{dpre, a->enc, 64, dwe, db, kl, 0};
+    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer, a->enc, 64, dwe + (size_t)W * 64, db + (size_t)D * W, kl, 0};
+    w.job[n++] = WgradJob{acts + (D - 1) * layer, a->g_head, 64, dwo, db + (size_t)D * W, kl, 0};
     w.njobs = n;
+    for (int j = 0, wg = 0; j < n; ++j) { w.job[j].wg0 = wg; wg += w.job[j].kch; w.nwg = wg; }
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     const WgradOperandArgs ops{a->pts4, a->d_raw4, a->n_rays, a->n_samples, ArchDefault::L, a->enc, a->g_head};

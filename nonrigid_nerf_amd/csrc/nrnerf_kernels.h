@@ -181,11 +181,14 @@ struct WgradJob {
     int xw;                  // 256-wide trunk: W or 64 (encoding, zero padded); a multiple of 64
     float* dw;               // out [W][xw] fp32 of partial 0; partial c (one per workgroup of the job) at + c * pstride
     float* db;               // out [W] fp32 of partial 0: row sums of dz = bias gradient
+    int kch;                 // workgroups (= partial sums) of this job: chosen so that every workgroup of the launch has about
+                             // the same work and all of them are resident at once
+    int wg0;                 // index of the job's first workgroup in the 1-D grid
 };
 constexpr int WGRAD_MAX_JOBS = 12;
 struct WgradArgs {
     WgradJob job[WGRAD_MAX_JOBS];
-    int njobs, kch;          // grid = (kch, njobs)
+    int njobs, nwg;          // grid = nwg = sum of the jobs' kch
     long long nblocks;
     long long pstride;       // floats between consecutive partials (the caller adds the kch partials)
 };

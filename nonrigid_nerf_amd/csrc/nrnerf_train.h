@@ -352,50 +352,47 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
 // layer's activations) and the two layers that see the encoding (x = the encoding, 64 columns) -- straight from the
 // [block][feature][32 samples] arrays the two kernels above fill: the contraction index of the MFMA is the sample, a lane's
 // operand is 8 consecutive samples of one feature (one 16-byte global load), so there is no LDS, no transpose and no
-// barrier.  grid = (kch, jobs): workgroup (c, j) accumulates job j over blocks c, c + kch, ... in registers and writes one
-// fp32 partial [W][xw]; the caller adds the kch partials.  4 waves (one per SIMD, up to 256 accumulator registers): wave
+// barrier.  Workgroup c of job j accumulates the job over blocks c, c + kch_j, ... in registers and writes one fp32 partial
+// [W][xw]; the caller adds the partials.  The jobs have their own kch: a 64-column job costs 5/16 of a hidden-to-hidden one
+// per block, so it gets 5/16 of the workgroups and all workgroups of the launch (<= one per CU) finish together.  4 waves (one per SIMD, up to 256 accumulator registers): wave
 // (wr, wc) owns tile rows wr * NTR/2 .. and tile columns wc * NTC/2 ..; next block's 16 fragments are requested before the
 // current block's MFMAs.  Measured 3.2 TB/s of unique HBM traffic at 16 384 rays; 8 waves with half the tiles each (more
 // loads in flight, but every fragment requested by more waves) were 10 % slower.  The bias gradient comes along: the waves of column 0 add up the dz fragments they hold (eight
 // conversions + adds per fragment on the VALU, one register per row tile).
-template <class A>
-__global__ void __launch_bounds__(256, 1) trunk_wgrad(const WgradArgs a) {
+template <class A, int TCW>      // TCW: column tiles of x per wave, compile-time so that the MFMAs issue back to back
+__device__ __forceinline__ void trunk_wgrad_job(const WgradArgs& a, const WgradJob& jb, int c) {
     using P = PolBF16;
     typedef typename P::frag frag;
     constexpr int NTR = A::W / 32;                  // row tiles of dz^T (features of this layer)
     constexpr int TR = NTR / 2;                     // per wave
     static_assert(NTR % 2 == 0, "two wave rows");
-    const WgradJob jb = a.job[blockIdx.y];
-    const int ntc = jb.xw / 32, tcw = ntc / 2;      // column tiles of x per wave: 4 (hidden) or 1 (encoding)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int h = lane >> 5, i = lane & 31;
     const __bf16* dz = (const __bf16*)jb.dz;
     const __bf16* x = (const __bf16*)jb.x;
-    constexpr int TCMAX = NTR / 2;
-    f32x16 acc[TR][TCMAX];
+    f32x16 acc[TR][TCW];
     float bsum[TR];          // bias gradient: this lane's share of the row sums of dz (its 8 samples of feature i per fragment)
 #pragma unroll
     for (int u = 0; u < TR; ++u) {
         bsum[u] = 0.0f;
 #pragma unroll
-        for (int v = 0; v < TCMAX; ++v) acc[u][v] = f32x16{};
+        for (int v = 0; v < TCW; ++v) acc[u][v] = f32x16{};
     }
-    auto load = [&](long long blk, frag (&fa)[TR][2], frag (&fb)[TCMAX][2]) {
+    auto load = [&](long long blk, frag (&fa)[TR][2], frag (&fb)[TCW][2]) {
 #pragma unroll
         for (int u = 0; u < TR; ++u)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 fa[u][ks] = *(const frag*)(dz + ((size_t)blk * A::W + 32 * (wr * TR + u) + i) * 32 + ks * 16 + 8 * h);
 #pragma unroll
-        for (int v = 0; v < TCMAX; ++v)
-            if (v < tcw)
+        for (int v = 0; v < TCW; ++v)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    fb[v][ks] = *(const frag*)(x + ((size_t)blk * jb.xw + 32 * (wc * tcw + v) + i) * 32 + ks * 16 + 8 * h);
+            for (int ks = 0; ks < 2; ++ks)
+                fb[v][ks] = *(const frag*)(x + ((size_t)blk * jb.xw + 32 * (wc * TCW + v) + i) * 32 + ks * 16 + 8 * h);
     };
-    auto step = [&](const frag (&fa)[TR][2], const frag (&fb)[TCMAX][2]) {
+    auto step = [&](const frag (&fa)[TR][2], const frag (&fb)[TCW][2]) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -405,46 +402,60 @@ __global__ void __launch_bounds__(256, 1) trunk_wgrad(const WgradArgs a) {
                     for (int e = 0; e < 8; ++e) bsum[u] += (float)fa[u][ks][e];
                 }
 #pragma unroll
-                for (int v = 0; v < TCMAX; ++v)
-                    if (v < tcw) acc[u][v] = P::mfma(fa[u][ks], fb[v][ks], acc[u][v]);
+                for (int v = 0; v < TCW; ++v) acc[u][v] = P::mfma(fa[u][ks], fb[v][ks], acc[u][v]);
             }
         }
     };
-    frag fa0[TR][2], fb0[TCMAX][2], fa1[TR][2], fb1[TCMAX][2];
-    long long blk = blockIdx.x;
+    frag fa0[TR][2], fb0[TCW][2], fa1[TR][2], fb1[TCW][2];
+    long long blk = c;
     if (blk < a.nblocks) load(blk, fa0, fb0);
     while (blk < a.nblocks) {
-        const long long n1 = blk + a.kch;
+        // (scheduling fences: left alone, hipcc interleaves the two halves of the loop and spills 250 registers)
+        const long long n1 = blk + jb.kch;
         if (n1 < a.nblocks) load(n1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
         step(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
         if (n1 >= a.nblocks) break;
-        const long long n2 = n1 + a.kch;
+        const long long n2 = n1 + jb.kch;
         if (n2 < a.nblocks) load(n2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
         step(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
         blk = n2;
     }
     // D tile: lane (h, j) holds rows tile_row(r, h), column j
-    float* dw = jb.dw + (size_t)blockIdx.x * a.pstride;
+    float* dw = jb.dw + (size_t)c * a.pstride;
 #pragma unroll
     for (int u = 0; u < TR; ++u) {
 #pragma unroll
-        for (int v = 0; v < TCMAX; ++v)
-            if (v < tcw) {
+        for (int v = 0; v < TCW; ++v) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dw[(size_t)(32 * (wr * TR + u) + tile_row(r, h)) * jb.xw + 32 * (wc * tcw + v) + i] = acc[u][v][r];
-            }
+            for (int r = 0; r < 16; ++r)
+                dw[(size_t)(32 * (wr * TR + u) + tile_row(r, h)) * jb.xw + 32 * (wc * TCW + v) + i] = acc[u][v][r];
+        }
         const float rowsum = bsum[u] + __shfl_xor(bsum[u], 32);        // the two lane halves hold samples 8h .. 8h + 7 of each k-step
-        if (wc == 0 && h == 0) jb.db[(size_t)blockIdx.x * a.pstride + 32 * (wr * TR + u) + i] = rowsum;
+        if (wc == 0 && h == 0) jb.db[(size_t)c * a.pstride + 32 * (wr * TR + u) + i] = rowsum;
     }
 }
 
 template <class A>
+__global__ void __launch_bounds__(256, 1) trunk_wgrad(const WgradArgs a) {
+    int j = 0;
+    for (int k = 1; k < a.njobs; ++k)
+        if ((int)blockIdx.x >= a.job[k].wg0) j = k;           // jobs are listed in grid order
+    const WgradJob jb = a.job[j];
+    const int c = (int)blockIdx.x - jb.wg0;
+    if (jb.xw == A::W) trunk_wgrad_job<A, A::W / 64>(a, jb, c);          // hidden-to-hidden layer
+    else trunk_wgrad_job<A, 1>(a, jb, c);                                 // 64 columns: encoding / head
+}
+
+template <class A>
 static hipError_t launch_trunk_wgrad(const WgradArgs& a, hipStream_t stream) {
-    if (a.njobs <= 0 || a.kch <= 0 || a.nblocks <= 0) return hipSuccess;
+    if (a.njobs <= 0 || a.nwg <= 0 || a.nblocks <= 0) return hipSuccess;
     for (int j = 0; j < a.njobs; ++j)
-        if (a.job[j].xw % 64 != 0 || a.job[j].xw > A::W) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(trunk_wgrad<A>, dim3(a.kch, a.njobs), dim3(256), 0, stream, a);
+        if ((a.job[j].xw != 64 && a.job[j].xw != A::W) || a.job[j].kch < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(trunk_wgrad<A>, dim3(a.nwg), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -168,8 +168,9 @@ class _Trunk(torch.autograd.Function):
         L = (int(net.input_ch) - 3) // 6
         nblk = int(acts.shape[1])
         scratch = torch.empty(2, nblk, 64, 32, dtype=torch.bfloat16, device=dev)             # encoding / head-gradient tiles
-        kch = max(1, min(nblk, _num_cus(dev) // (D - 1)))
-        parts = torch.empty(kch, _lib.wgrad_stride(D, W), dtype=torch.float32, device=dev)
+        # records of partial sums; the launch has (D - 1) * kch + 3 * (10/16 or 12/16) kch workgroups: one per CU at most
+        kch = max(1, min(nblk, (_num_cus(dev) * 16) // ((D - 1) * 16 + 3 * (10 if W == 256 else 12))))
+        parts = torch.zeros(kch, _lib.wgrad_stride(D, W), dtype=torch.float32, device=dev)
         a = _lib.WgradArgs()
         a.struct_size = C.sizeof(_lib.WgradArgs)
         a.n_rays, a.n_samples, a.n_partials = N, S, kch
