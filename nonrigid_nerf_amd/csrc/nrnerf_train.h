@@ -410,7 +410,9 @@ __device__ __forceinline__ void trunk_wgrad_job(const WgradArgs& a, const WgradJ
     long long blk = c;
     if (blk < a.nblocks) load(blk, fa0, fb0);
     while (blk < a.nblocks) {
-        // (scheduling fences: left alone, hipcc interleaves the two halves of the loop and spills 250 registers)
+        // (scheduling fences keep the two halves of the loop apart: request block n + 1, then the 32 MFMAs of block n.
+        //  Free-running on purpose: a workgroup barrier every 2 / 4 / 8 blocks removes the redundant HBM reads -- the waves
+        //  that share fragments stay in step -- but costs 15-45 %: tools/experiments/README.md)
         const long long n1 = blk + jb.kch;
         if (n1 < a.nblocks) load(n1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
