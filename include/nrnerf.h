@@ -237,9 +237,12 @@ int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_p
  * is the binding): the canonical network's trunk forward with saved activations and its backward-data pass, and the
  * compositing forward / backward, and the ray bender's forward / backward (nrnerf_bender_*, below).  The trunk takes
  * ready-made (bent) points and returns the gradient wrt them.
- * Weight gradients are plain GEMMs over two arrays these calls fill: dW_i = d_pre[i]^T x_i with x_0 = encoding,
+ * Weight gradients are products over two arrays these calls fill: dW_i = d_pre[i]^T x_i with x_0 = encoding,
  * x_i = acts[i-1] (x_{skip+1} = [encoding, acts[skip]]), db_i = column sums of d_pre[i]; d W_out = d_raw^T acts[D-1].
- * Available (else NRNERF_ERR_UNSUPPORTED) for the default architecture without view-dependent head, fp32 or bf16. */
+ * fp32 mode: row-major arrays, the products are left to the caller's GEMM library; bf16 mode: nrnerf_trunk_wgrad, below.
+ * Available (else NRNERF_ERR_UNSUPPORTED) for the trunks of width 256 and 128 without view-dependent head / time
+ * conditioning, fp32 or bf16 (a model created with NRNERF_PREC_F16 has no training kernels: unscaled f16 gradients
+ * underflow; nonrigid_nerf_amd/training.py trains such a model through a bf16 handle). */
 typedef struct nrnerf_trunk_args {
     uint32_t struct_size;       /* sizeof(nrnerf_trunk_args) */
     int32_t which;              /* 0 = network_fn (coarse), 1 = network_fine */
@@ -330,9 +333,10 @@ int nrnerf_bender_wgrad(const nrnerf_model* model, const nrnerf_bender_wgrad_arg
  * NRNERF_WGRAD_STRIDE(depth, width) floats = dw_hidden [depth-1][width][width], dw_enc [2][width][64], dw_head^T [width][64],
  * db [depth+1][width] (row `depth` is scratch), so one sum over the first axis yields them all.  The 64-column products
  * (dw_enc, dw_head^T, db[0]) are cut into fewer, longer partial sums (they cost less per block: all workgroups of the
- * launch then finish together) and only fill the first records: the caller ZERO-FILLS `partials` before the call.  enc / g: the encoding of the input points and
- * the gradient wrt the head's outputs in the same block layout, bf16 [B][64][32]: scratch the caller allocates, filled by
- * this call from pts4 and d_raw4 (the arrays given to nrnerf_trunk_backward).
+ * launch then finish together) and only fill the first records: the caller ZERO-FILLS `partials` before the call.
+ * enc / g_head: the encoding of the input points and the gradient wrt the head's outputs in the same block layout, bf16
+ * [B][64][32]: scratch the caller allocates, filled by this call from pts4 and d_raw4 (the arrays given to
+ * nrnerf_trunk_backward).
  * NRNERF_ERR_UNSUPPORTED in fp32 mode (the fp32 arrays are row-major for the library GEMMs). */
 typedef struct nrnerf_wgrad_args {
     uint32_t struct_size;       /* sizeof(nrnerf_wgrad_args) */
