@@ -820,7 +820,7 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
         # the array instead of shuffled between lanes), but it is another template instantiation and hipcc rounds the
         # direction encoding's fp32 arithmetic differently in the two (the same effect as between the one- and the
         # two-blocks-per-wave kernels): sigma, depths and the coarse maps stay bit-identical, colour
-        # logits differ by an ulp on a few per cent of the samples (measured, tools/debug_split_views.py: f32 1.7 % of the
+        # logits differ by an ulp on a few per cent of the samples (measured, tools/experiments/debug_split_views.py: f32 1.7 % of the
         # samples by <= 2.4e-7, rgb_map <= 6e-8; f16 0.1 % by <= 1.1e-4, rgb_map <= 1.2e-6).
         for k in ("rgb0", "disp0", "acc0", "z_std", "_z_vals", "disp_map", "acc_map", "median_index", "surface_pts", "surface_rigidity"):
             assert torch.equal(torch.nan_to_num(split[k].float()), torch.nan_to_num(fused[k].float())), k
@@ -841,7 +841,7 @@ def _assert_split_equals_fused_up_to_conversion_ties(split, fused):
     """bf16 mode (single-product f16 bender): the stand-alone bender kernel and the fused kernel are the same arithmetic,
     but hipcc pairs the f32 -> f16 conversions of the first-layer inputs differently in the two kernels
     (v_cvt_pk_f16_f32 vs v_cvt_f16_f32), and the two instructions disagree on rare inputs -- measured: 21 of 384 126 new
-    samples (5e-5, the rate of round-to-nearest ties) get a bent point that differs by <= 5e-6 (tools/debug_split_vs_fused.py).
+    samples (5e-5, the rate of round-to-nearest ties) get a bent point that differs by <= 5e-6 (tools/experiments/debug_split_vs_fused.py).
     Everything that does not pass through a new sample's bender is still bit-identical."""
     for k in ("rgb0", "disp0", "acc0", "z_std", "_z_vals"):
         assert torch.equal(torch.nan_to_num(split[k]), torch.nan_to_num(fused[k])), k

@@ -49,7 +49,7 @@ def test_gradients_match_reference_autograd_golden(torch_ops_bender):
     """fp32 mode: d(sum rgb_map + sum rgb0) wrt the latent codes and a few parameters of every network, against what the
     reference's own autograd produced on the CPU (train.render under grad, z_samples detached).
 
-    Two facts bound what "equal" can mean here, both measured (tools/debug_grads.py, profiles/r02_gradient_parity.txt):
+    Two facts bound what "equal" can mean here, both measured (tools/experiments/debug_grads.py, profiles/r02_gradient_parity.txt):
     the reference's arithmetic evaluated on THIS device (the oracle, eager fp32 torch) lands up to 1 % of scale away
     from its own CPU result for the bender / latent gradients -- sample_pdf's `denom < 1e-5` branch (rnh:694) falls the
     other way on 3 of the 16 rays, and those gradients pass through the 2^9 encoding frequency (fp32 vs fp64 of the same
