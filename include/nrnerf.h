@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NRNERF_ABI_VERSION 4
+#define NRNERF_ABI_VERSION 5
 
 typedef enum nrnerf_status {
     NRNERF_OK = 0,
@@ -41,7 +41,8 @@ typedef enum nrnerf_status {
     NRNERF_ERR_UNSUPPORTED = -2,  /* architecture / flag combination this build has no kernel for */
     NRNERF_ERR_HIP = -3,          /* a HIP runtime call failed (no device, launch failure, ...) */
     NRNERF_ERR_WORKSPACE = -4,    /* workspace smaller than nrnerf_workspace_bytes() */
-    NRNERF_ERR_NOMEM = -5
+    NRNERF_ERR_NOMEM = -5,        /* device memory, or host memory while packing weights */
+    NRNERF_ERR_INTERNAL = -6      /* an internal consistency check failed (a C++ exception was caught at the boundary) */
 } nrnerf_status;
 
 /* arithmetic type of the MLP contractions (accumulation is always fp32; positional encoding,
@@ -200,6 +201,9 @@ int nrnerf_model_update(nrnerf_model* model, const nrnerf_model_desc* desc, void
 int64_t nrnerf_model_flat_size(const nrnerf_model* model);
 int nrnerf_model_update_device(nrnerf_model* model, const float* flat_params, int64_t n_floats, void* hip_stream);
 void nrnerf_model_destroy(nrnerf_model* model);
+/* the nrnerf_precision the handle was created with (decides the layout of nrnerf_trunk_args.acts / d_pre), or
+ * NRNERF_ERR_INVALID for NULL */
+int nrnerf_model_precision(const nrnerf_model* model);
 
 size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples,
                               int32_t n_importance);
@@ -277,8 +281,8 @@ int nrnerf_trunk_backward(const nrnerf_model* model, const nrnerf_trunk_args* ar
  *                    layers and dz_out4[:, 0:3] for the last one (which has no bias); db_i = column sums of dz_i;
  *   rigidity MLP     likewise with x_0 = p, acts_rigidity, dz_rigidity and dz_out4[:, 3].
  * The sample positions carry no gradient (the reference detaches z_samples; rays are data).  First order only: the
- * divergence regulariser differentiates the reference module's own forward a second time (run_nerf_helpers.py:41-58) and
- * never passes through here.  NRNERF_ERR_UNSUPPORTED unless the trunk entry points are available and the model has a bender. */
+ * divergence regulariser (second order in autograd's terms) has its own entry points, nrnerf_bender_divergence_*, below.
+ * NRNERF_ERR_UNSUPPORTED unless the trunk entry points are available and the model has a bender. */
 typedef struct nrnerf_bender_args {
     uint32_t struct_size;       /* sizeof(nrnerf_bender_args) */
     int32_t n_rays, n_samples;  /* M = n_rays * n_samples, sample-major per ray */
@@ -322,6 +326,50 @@ typedef struct nrnerf_bender_wgrad_args {
     float* partials;            /* out [n_partials][depth + rigidity_depth][NRNERF_BENDER_WGRAD_SLOT] */
 } nrnerf_bender_wgrad_args;
 int nrnerf_bender_wgrad(const nrnerf_model* model, const nrnerf_bender_wgrad_args* args, void* hip_stream);
+
+/* The divergence regulariser of the ray bender -- reference compute_divergence_loss / divergence_approx / divergence_exact
+ * (run_nerf_helpers.py:22-116), called from training_wrapper_class.forward (train.py:244-287) -- for n_points independent
+ * points: divergence[k] = e_k^T J_k e_k, J = d(masked offsets)/d(point) of ray_bending.forward with
+ * special_loss_return (run_nerf_helpers.py:507-577), e = probe.  The reference forms J^T e by a vector-Jacobian product
+ * with create_graph=True and back-propagates through that graph; here the value is one forward-mode tangent through the
+ * offset and rigidity MLPs and the backward pass runs the value chain and the tangent chain together (exact fp32 whatever
+ * the model's precision).  With the three unit vectors as probes and the three results added it is the exact divergence
+ * (divergence_exact).  The editing knobs act as in nrnerf_bender_args: the cutoff assignment has no derivative, scaling scales.
+ * Forward writes `divergence` and the saved arrays; backward reads them and g_divergence and writes the dz / dtz arrays,
+ * d_latents (one row per point: the caller reduces rows that share a code) and, in the same call, the weight and bias
+ * gradients as n_partials partial sums (one per wave; the caller adds them) of NRNERF_BENDER_WGRAD_SLOT floats per job
+ * (dW [64][64], rows = the layer's outputs, then db [64]), jobs in the order
+ *   0                 network[0], columns of the point       (dW[:, 0:3])
+ *   1                 network[0], columns of the latent code (dW[:, 0:latent_size]  ->  weight[:, 3:]); its db is network[0]'s too
+ *   2 .. depth        network[1 .. depth-1]
+ *   depth+1 ..        rigidity_network[0 .. rigidity_depth-1]
+ * The points themselves receive no gradient (the reference makes them a leaf that nobody reads).
+ * NRNERF_ERR_UNSUPPORTED unless nrnerf_bender_forward is available for the model. */
+typedef struct nrnerf_divergence_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_divergence_args) */
+    int64_t n_points;           /* M */
+    const float* points;        /* [M,3]  input_points (initial_input_pts of the coarse pass, train.py:248-250) */
+    const float* latents; int32_t latent_stride;   /* one row per point, latent_stride >= latent_size floats apart; 0 = one code */
+    const float* probe;         /* [M,3]  e (torch.randn_like(offsets), run_nerf_helpers.py:106) */
+    int32_t has_rigidity_cutoff;   float rigidity_cutoff;     /* as nrnerf_render_args */
+    int32_t has_test_time_scaling; float test_time_scaling;
+    /* forward writes, backward reads */
+    float* divergence;          /* [M] */
+    float* off4;                /* [M,4] unmasked offsets + tanh of the rigidity logit */
+    float* toff4;               /* [M,4] their tangents (w: tangent of the logit) */
+    float* acts_offsets;  float* tacts_offsets;     /* [bender depth - 1][M][bender hidden]: activations / tangents */
+    float* acts_rigidity; float* tacts_rigidity;    /* [rigidity depth - 1][M][rigidity hidden] */
+    /* backward */
+    const float* g_divergence;  /* [M] */
+    float* dz_offsets;  float* dtz_offsets;         /* out, shapes of acts_offsets */
+    float* dz_rigidity; float* dtz_rigidity;        /* out, shapes of acts_rigidity */
+    float* dz_out4;  float* dtz_out4;               /* out [M,4] each */
+    float* d_latents;           /* out [M, latent_size] */
+    int32_t n_partials;         /* a multiple of 4, <= 4096 */
+    float* partials;            /* out [n_partials][depth + rigidity_depth + 1][NRNERF_BENDER_WGRAD_SLOT] */
+} nrnerf_divergence_args;
+int nrnerf_bender_divergence_forward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);
+int nrnerf_bender_divergence_backward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);
 
 /* bf16 mode: the weight and bias gradients of the trunk from the two arrays nrnerf_trunk_forward / _backward filled, in
  * one launch over their [block][feature][32 samples] layout (the contraction runs over samples; no transposes):

@@ -12,9 +12,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRNERF_LIB selects an alternative build of the same library (tuning experiments, see csrc/Makefile)
 LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
-ABI_VERSION = 4
-OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
+ABI_VERSION = 5
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
+_CANONICAL = {0: "f32", 1: "bf16", 2: "f16"}
+
+
+def canonical_precision(p: str) -> str:
+    """"fp32" / "float32" -> "f32", "bfloat16" -> "bf16", "fp16" / "float16" -> "f16": the three names the rest of the
+    package compares against (the aliases are accepted at every entry point and normalised there, once)."""
+    try:
+        return _CANONICAL[PRECISIONS[p]]
+    except KeyError:
+        raise ValueError(f"unknown precision {p!r} (one of {sorted(PRECISIONS)})") from None
 NUM_KERNELS = 6
 KERNEL_NAMES = ("net_coarse", "composite_sample_coarse", "net_fine", "composite_fine", "bend_fine", "bend_coarse")
 
@@ -127,6 +137,19 @@ class BenderWgradArgs(C.Structure):
 BENDER_WGRAD_SLOT = 64 * 64 + 64
 
 
+class DivergenceArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_points", C.c_int64),
+                ("points", C.c_void_p), ("latents", C.c_void_p), ("latent_stride", C.c_int32), ("probe", C.c_void_p),
+                ("has_rigidity_cutoff", C.c_int32), ("rigidity_cutoff", C.c_float),
+                ("has_test_time_scaling", C.c_int32), ("test_time_scaling", C.c_float),
+                ("divergence", C.c_void_p), ("off4", C.c_void_p), ("toff4", C.c_void_p),
+                ("acts_offsets", C.c_void_p), ("tacts_offsets", C.c_void_p), ("acts_rigidity", C.c_void_p), ("tacts_rigidity", C.c_void_p),
+                ("g_divergence", C.c_void_p),
+                ("dz_offsets", C.c_void_p), ("dtz_offsets", C.c_void_p), ("dz_rigidity", C.c_void_p), ("dtz_rigidity", C.c_void_p),
+                ("dz_out4", C.c_void_p), ("dtz_out4", C.c_void_p), ("d_latents", C.c_void_p),
+                ("n_partials", C.c_int32), ("partials", C.c_void_p)]
+
+
 class CompositeArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("n_importance", C.c_int32),
                 ("rays", C.c_void_p), ("ray_stride", C.c_int32),
@@ -146,6 +169,7 @@ EXPORTS = {
     "nrnerf_model_flat_size": (C.c_int64, [C.c_void_p]),
     "nrnerf_model_update_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "nrnerf_model_destroy": (None, [C.c_void_p]),
+    "nrnerf_model_precision": (C.c_int, [C.c_void_p]),
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -155,6 +179,8 @@ EXPORTS = {
     "nrnerf_bender_forward": (C.c_int, [C.c_void_p, C.POINTER(BenderArgs), C.c_void_p]),
     "nrnerf_bender_backward": (C.c_int, [C.c_void_p, C.POINTER(BenderArgs), C.c_void_p]),
     "nrnerf_bender_wgrad": (C.c_int, [C.c_void_p, C.POINTER(BenderWgradArgs), C.c_void_p]),
+    "nrnerf_bender_divergence_forward": (C.c_int, [C.c_void_p, C.POINTER(DivergenceArgs), C.c_void_p]),
+    "nrnerf_bender_divergence_backward": (C.c_int, [C.c_void_p, C.POINTER(DivergenceArgs), C.c_void_p]),
     "nrnerf_composite_forward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),
     "nrnerf_composite_backward": (C.c_int, [C.POINTER(CompositeArgs), C.c_void_p]),
     "nrnerf_profile_begin": (C.c_int, [C.c_void_p]),

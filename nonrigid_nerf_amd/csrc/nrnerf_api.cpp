@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <vector>
 
 #include "nrnerf.h"
@@ -21,6 +22,11 @@
 #include "nrnerf_plan.h"
 
 using namespace nrn;
+
+// Nothing throws across the C ABI (include/nrnerf.h): every extern "C" body is a function-try-block that turns
+// std::bad_alloc (the packer's std::vector growth) into NRNERF_ERR_NOMEM and anything else -- the packer's
+// plan-consistency checks throw std::logic_error -- into NRNERF_ERR_INTERNAL.
+#define NRN_CATCH catch (const std::bad_alloc&) { return NRNERF_ERR_NOMEM; } catch (...) { return NRNERF_ERR_INTERNAL; }
 
 namespace {
 
@@ -125,7 +131,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                 // split layers: fragment pair (hi, lo) with lo = f16((w - f16(w)) * 2^11); others: one fragment
                 for (int part = 0; part <= sp.split; ++part) {
                     const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride + part;
-                    if (fi >= (size_t)T.nfrags) std::abort();                       // plan/packer drift
+                    if (fi >= (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
                     uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
                     const bool as_f16 = (precision == NRNERF_PREC_F16) || frag_is_f16<SH, A>(sp.kind, s);
                     for (int lane = 0; lane < 64; ++lane) {
@@ -160,7 +166,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                 }
         }
     }
-    if (written != (size_t)T.nfrags) std::abort();
+    if (written != (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
 }
 
 // Transposed weights for the backward-data kernel (nrnerf_train.h): PlanB's layer list, fragment element
@@ -190,7 +196,7 @@ void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
             const TileInfo& ti = T.tiles[sp.tile0 + t];
             for (int s = 0; s < sp.ns; ++s) {
                 const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride;
-                if (fi >= (size_t)T.nfrags) std::abort();
+                if (fi >= (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
                 uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 31, h = lane >> 5;
@@ -212,7 +218,7 @@ void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
             }
         }
     }
-    if (written != (size_t)T.nfrags) std::abort();
+    if (written != (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
 }
 
 // Transposed weights of the bender / rigidity MLPs for their backward-data kernel (nrnerf_train_bend.h): PlanBB's layer
@@ -243,7 +249,7 @@ void pack_pass_bwd_bender(const nrnerf_bender_desc& b, PackedPass& out, const Fl
             const TileInfo& ti = T.tiles[sp.tile0 + t];
             for (int s = 0; s < sp.ns; ++s) {
                 const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride;
-                if (fi >= (size_t)T.nfrags) std::abort();
+                if (fi >= (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
                 uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 31, h = lane >> 5;
@@ -258,7 +264,7 @@ void pack_pass_bwd_bender(const nrnerf_bender_desc& b, PackedPass& out, const Fl
             }
         }
     }
-    if (written != (size_t)T.nfrags) std::abort();
+    if (written != (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
 }
 
 bool linear_is(const nrnerf_linear& l, int out_f, int in_f, bool need_bias) {
@@ -551,13 +557,14 @@ const char* nrnerf_strerror(int status) {
         case NRNERF_ERR_UNSUPPORTED: return "unsupported architecture or flag combination (no kernel compiled for it)";
         case NRNERF_ERR_HIP: return "HIP runtime error (no device, or a launch/copy failed)";
         case NRNERF_ERR_WORKSPACE: return "workspace too small or misaligned";
-        case NRNERF_ERR_NOMEM: return "out of device memory";
+        case NRNERF_ERR_NOMEM: return "out of memory (device, or host while packing weights)";
+        case NRNERF_ERR_INTERNAL: return "internal error (an exception was caught at the C ABI)";
     }
     return "unknown status";
 }
 
 int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_info* info, void* stream_out,
-                     size_t stream_cap, uint32_t* unit_table_out, float* bias_table_out) {
+                     size_t stream_cap, uint32_t* unit_table_out, float* bias_table_out) try {
     if (!desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
     const nrnerf_mlp_desc* m = (which == 1 && desc->fine) ? desc->fine : desc->coarse;
     PackedPass pk;
@@ -605,9 +612,9 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
     if (unit_table_out) std::memcpy(unit_table_out, pk.unit_off.data(), pk.unit_off.size() * 4);
     if (bias_table_out) std::memcpy(bias_table_out, pk.bias.data(), pk.bias.size() * 4);
     return NRNERF_OK;
-}
+} NRN_CATCH
 
-int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
+int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) try {
     if (!out) return NRNERF_ERR_INVALID;
     *out = nullptr;
     if (!desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
@@ -622,22 +629,27 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
         if (rc != NRNERF_OK) return rc;
         if (arch_f != arch_id) return NRNERF_ERR_INVALID;
     }
-    int prev = 0;
-    if (hipGetDevice(&prev) != hipSuccess) return NRNERF_ERR_HIP;
-    if (hipSetDevice(desc->device) != hipSuccess) return NRNERF_ERR_HIP;
-    nrnerf_model* m = new (std::nothrow) nrnerf_model();
-    if (!m) { (void)hipSetDevice(prev); return NRNERF_ERR_NOMEM; }
+    DeviceGuard guard(desc->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    // owns the handle until it is handed to the caller: every early return (and an exception caught by NRN_CATCH) frees
+    // what was uploaded so far
+    struct Owner {
+        nrnerf_model* m;
+        ~Owner() { if (m) nrnerf_model_destroy(m); }
+    } own{new (std::nothrow) nrnerf_model()};
+    nrnerf_model* m = own.m;
+    if (!m) return NRNERF_ERR_NOMEM;
     m->device = desc->device;
     m->precision = desc->precision;
     m->has_bend = desc->bender != nullptr;
     m->views = desc->coarse->use_viewdirs != 0;
     m->arch_id = arch_id;
     m->exact = desc->exact_viewdirs != 0 && m->has_bend && m->views;     // only meaningful with bender + view-dependent head
-    if (m->exact && arch_id > 1) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_UNSUPPORTED; }
+    if (m->exact && arch_id > 1) return NRNERF_ERR_UNSUPPORTED;
     m->needs_latents = m->has_bend || desc->coarse->time_conditioned;
     m->latent_size = desc->bender ? desc->bender->latent_size : 0;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, desc->device) != hipSuccess) { delete m; (void)hipSetDevice(prev); return NRNERF_ERR_HIP; }
+    if (hipGetDeviceProperties(&prop, desc->device) != hipSuccess) return NRNERF_ERR_HIP;
     m->num_cus = prop.multiProcessorCount;
     m->flat_floats = lay.total;
     const double mfma_flop = 2.0 * 32 * 32 * (desc->precision == NRNERF_PREC_F32 ? 2 : 16);
@@ -674,13 +686,13 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) {
         }
     }
     if (rc == NRNERF_OK) rc = upload_training(*desc, m, nullptr, false, &lay);
-    (void)hipSetDevice(prev);
-    if (rc != NRNERF_OK) { nrnerf_model_destroy(m); return rc; }
+    if (rc != NRNERF_OK) return rc;
+    own.m = nullptr;
     *out = m;
     return NRNERF_OK;
-}
+} NRN_CATCH
 
-int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hip_stream) {
+int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hip_stream) try {
     if (!m || !desc || desc->struct_size != sizeof(nrnerf_model_desc) || !desc->coarse) return NRNERF_ERR_INVALID;
     if (desc->device != m->device || desc->precision != m->precision || (desc->bender != nullptr) != (m->has_bend != 0) ||
         (desc->coarse->use_viewdirs != 0) != (m->views != 0) || (desc->fine != nullptr) == m->fine_is_coarse ||
@@ -695,8 +707,8 @@ int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hi
         if (rc != NRNERF_OK) return rc;
     }
     if (arch_id != m->arch_id || (desc->fine && arch_f != m->arch_id)) return NRNERF_ERR_INVALID;
-    int prev = 0;
-    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(m->device) != hipSuccess) return NRNERF_ERR_HIP;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
     hipStream_t stream = (hipStream_t)hip_stream;
     rc = refresh_pass(pc, m->coarse, stream);
     if (rc == NRNERF_OK && desc->fine) rc = refresh_pass(pf, m->fine, stream);
@@ -710,13 +722,14 @@ int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hi
     // the packed host images die with this call: wait until the copies have consumed them
     if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;
     if (rc == NRNERF_OK && m->train_ok) rc = upload_training(*desc, m, stream, /*refresh=*/true);
-    (void)hipSetDevice(prev);
     return rc;
-}
+} NRN_CATCH
 
 int64_t nrnerf_model_flat_size(const nrnerf_model* m) { return m ? m->flat_floats : -1; }
 
-int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_t n_floats, void* hip_stream) {
+int nrnerf_model_precision(const nrnerf_model* m) { return m ? m->precision : NRNERF_ERR_INVALID; }
+
+int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_t n_floats, void* hip_stream) try {
     if (!m || !flat_params || n_floats != m->flat_floats) return NRNERF_ERR_INVALID;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
@@ -732,7 +745,7 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
         if (launch_repack(b, stream) != hipSuccess) return NRNERF_ERR_HIP;
     }
     return NRNERF_OK;
-}
+} NRN_CATCH
 
 void nrnerf_model_destroy(nrnerf_model* m) {
     if (!m) return;
@@ -768,7 +781,7 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
     return b;
 }
 
-int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_stream) {
+int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_stream) try {
     if (!m || !a || a->struct_size != sizeof(nrnerf_render_args)) return NRNERF_ERR_INVALID;
     if (a->n_rays < 0 || a->n_samples < 2 || a->n_importance < 0) return NRNERF_ERR_INVALID;
     if (a->n_samples > 256 || a->n_samples + a->n_importance > 256) return NRNERF_ERR_UNSUPPORTED;
@@ -954,10 +967,10 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     e = timed(3, 0, 0, [&] { return launch_composite(cf, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
     return NRNERF_OK;
-}
+} NRN_CATCH
 
 int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_plane, float* rays_out,
-                         int32_t ray_stride, void* hip_stream) {
+                         int32_t ray_stride, void* hip_stream) try {
     if (!cam || !rays_out || (ray_stride != 8 && ray_stride != 11)) return NRNERF_ERR_INVALID;
     if (cam->height <= 0 || cam->width <= 0 || cam->focal_x == 0.0f || cam->focal_y == 0.0f) return NRNERF_ERR_INVALID;
     RayGenArgs a{};
@@ -972,7 +985,7 @@ int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_p
     DeviceGuard guard(attr.device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     return launch_raygen(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
-}
+} NRN_CATCH
 
 // ---- training entry points (nrnerf_train.h, composite_bwd_kernel) -------------------------------------------------
 namespace {
@@ -997,7 +1010,7 @@ int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, Tr
 }
 }  // namespace
 
-int nrnerf_trunk_forward(const nrnerf_model* m, const nrnerf_trunk_args* a, void* hip_stream) {
+int nrnerf_trunk_forward(const nrnerf_model* m, const nrnerf_trunk_args* a, void* hip_stream) try {
     TrunkArgs t;
     const int rc = trunk_common(m, a, false, t);
     if (rc != NRNERF_OK) return rc;
@@ -1009,9 +1022,9 @@ int nrnerf_trunk_forward(const nrnerf_model* m, const nrnerf_trunk_args* a, void
     const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_fwd_train_f32_a5(t, m->num_cus, s) : launch_trunk_fwd_train_bf16_a5(t, m->num_cus, s))
                                            : (f32 ? launch_trunk_fwd_train_f32(t, m->num_cus, s) : launch_trunk_fwd_train_bf16(t, m->num_cus, s));
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
-}
+} NRN_CATCH
 
-int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, void* hip_stream) {
+int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, void* hip_stream) try {
     TrunkArgs t;
     const int rc = trunk_common(m, a, true, t);
     if (rc != NRNERF_OK) return rc;
@@ -1023,9 +1036,9 @@ int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, voi
     const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_bwd_f32_a5(t, m->num_cus, s) : launch_trunk_bwd_bf16_a5(t, m->num_cus, s))
                                            : (f32 ? launch_trunk_bwd_f32(t, m->num_cus, s) : launch_trunk_bwd_bf16(t, m->num_cus, s));
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
-}
+} NRN_CATCH
 
-int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* hip_stream) {
+int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* hip_stream) try {
     if (!m || !a || a->struct_size != sizeof(nrnerf_wgrad_args)) return NRNERF_ERR_INVALID;
     if (!m->train_ok || m->precision == NRNERF_PREC_F32) return NRNERF_ERR_UNSUPPORTED;
     if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 1 || a->n_partials > 4096) return NRNERF_ERR_INVALID;
@@ -1061,7 +1074,7 @@ int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* 
     if (launch_wgrad_operands(ops, (hipStream_t)hip_stream) != hipSuccess) return NRNERF_ERR_HIP;
     const hipError_t e = (m->arch_id == 5) ? launch_trunk_wgrad_bf16_a5(w, (hipStream_t)hip_stream) : launch_trunk_wgrad_bf16(w, (hipStream_t)hip_stream);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
-}
+} NRN_CATCH
 
 namespace {
 int bender_common(const nrnerf_model* m, const nrnerf_bender_args* a, bool bwd, BendTrainArgs& t) {
@@ -1085,7 +1098,7 @@ int bender_common(const nrnerf_model* m, const nrnerf_bender_args* a, bool bwd, 
 }
 }  // namespace
 
-int nrnerf_bender_forward(const nrnerf_model* m, const nrnerf_bender_args* a, void* hip_stream) {
+int nrnerf_bender_forward(const nrnerf_model* m, const nrnerf_bender_args* a, void* hip_stream) try {
     BendTrainArgs t;
     const int rc = bender_common(m, a, false, t);
     if (rc != NRNERF_OK) return rc;
@@ -1095,9 +1108,9 @@ int nrnerf_bender_forward(const nrnerf_model* m, const nrnerf_bender_args* a, vo
     const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_fwd_train_a0(t, m->num_cus, (hipStream_t)hip_stream)
                                            : launch_bend_fwd_train_a1(t, m->num_cus, (hipStream_t)hip_stream);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
-}
+} NRN_CATCH
 
-int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, void* hip_stream) {
+int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, void* hip_stream) try {
     BendTrainArgs t;
     const int rc = bender_common(m, a, true, t);
     if (rc != NRNERF_OK) return rc;
@@ -1107,9 +1120,9 @@ int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, v
     const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
                                            : launch_bend_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
-}
+} NRN_CATCH
 
-int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a, void* hip_stream) {
+int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a, void* hip_stream) try {
     if (!m || !a || a->struct_size != sizeof(nrnerf_bender_wgrad_args)) return NRNERF_ERR_INVALID;
     if (!m->bend_train_ok) return NRNERF_ERR_UNSUPPORTED;
     if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 4 || a->n_partials > 4096 || a->n_partials % 4) return NRNERF_ERR_INVALID;
@@ -1135,7 +1148,79 @@ int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     return launch_bend_wgrad(w, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
+namespace {
+int divergence_common(const nrnerf_model* m, const nrnerf_divergence_args* a, bool bwd, BendDivArgs& t) {
+    if (!m || !a || a->struct_size != sizeof(nrnerf_divergence_args)) return NRNERF_ERR_INVALID;
+    if (!m->bend_train_ok) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_points < 0 || a->n_points >= (1ll << 36)) return NRNERF_ERR_INVALID;
+    if (!a->points || !a->probe || !a->latents || (a->latent_stride != 0 && a->latent_stride < m->latent_size)) return NRNERF_ERR_INVALID;
+    if (!a->divergence || !a->off4 || !a->toff4 || !a->acts_offsets || !a->tacts_offsets || !a->acts_rigidity || !a->tacts_rigidity)
+        return NRNERF_ERR_INVALID;
+    if (bwd && (!a->g_divergence || !a->dz_offsets || !a->dtz_offsets || !a->dz_rigidity || !a->dtz_rigidity || !a->dz_out4 ||
+                !a->dtz_out4 || !a->d_latents || !a->partials || a->n_partials < 4 || a->n_partials > 4096 || a->n_partials % 4))
+        return NRNERF_ERR_INVALID;
+    t = BendDivArgs{};
+    t.pts = a->points; t.latents = a->latents; t.lat_stride = a->latent_stride; t.e = a->probe; t.m = a->n_points;
+    const PassDev& p = bwd ? m->bend_train_bwd : m->bend_train_fwd;
+    t.wstream = p.stream; t.bias = p.bias;
+    t.knobs.has_cutoff = a->has_rigidity_cutoff; t.knobs.cutoff = a->rigidity_cutoff;
+    t.knobs.has_scaling = a->has_test_time_scaling; t.knobs.scaling = a->test_time_scaling;
+    t.div = a->divergence; t.off4 = a->off4; t.toff4 = a->toff4;
+    t.acts_b = a->acts_offsets; t.tacts_b = a->tacts_offsets; t.acts_r = a->acts_rigidity; t.tacts_r = a->tacts_rigidity;
+    t.g_div = a->g_divergence; t.dz_b = a->dz_offsets; t.dtz_b = a->dtz_offsets; t.dz_r = a->dz_rigidity; t.dtz_r = a->dtz_rigidity;
+    t.dz_out4 = a->dz_out4; t.dtz_out4 = a->dtz_out4; t.d_lat = a->d_latents;
+    return NRNERF_OK;
 }
+}  // namespace
+
+int nrnerf_bender_divergence_forward(const nrnerf_model* m, const nrnerf_divergence_args* a, void* hip_stream) try {
+    BendDivArgs t;
+    const int rc = divergence_common(m, a, false, t);
+    if (rc != NRNERF_OK) return rc;
+    if (a->n_points == 0) return NRNERF_OK;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_fwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
+                                                        : launch_bend_div_fwd_a1(t, m->num_cus, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
+int nrnerf_bender_divergence_backward(const nrnerf_model* m, const nrnerf_divergence_args* a, void* hip_stream) try {
+    BendDivArgs t;
+    const int rc = divergence_common(m, a, true, t);
+    if (rc != NRNERF_OK) return rc;
+    if (a->n_points == 0) return NRNERF_OK;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
+                                                  : launch_bend_div_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return NRNERF_ERR_HIP;
+    // weight / bias gradients: dW_i = dz_i^T h_{i-1} + dtz_i^T th_{i-1} (two products per job), db_i = column sums of dz_i
+    const int BD = (bender_arch(m->arch_id) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
+    const int BW = ArchDefault::BW, RD = ArchDefault::RD, RW = ArchDefault::RW, LAT = m->latent_size;
+    const size_t M = (size_t)a->n_points;
+    BendWgradArgs w{};
+    int n = 0;
+    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, a->points, 3, 3, a->dtz_offsets, a->probe};             // network[0][:, 0:3]: th_0 = e
+    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, a->latents, a->latent_stride, LAT, nullptr, nullptr};    // network[0][:, 3:]
+    for (int i = 1; i <= BD - 2; ++i)
+        w.job[n++] = BendWgradJob{a->dz_offsets + (size_t)i * M * BW, BW, BW, a->acts_offsets + (size_t)(i - 1) * M * BW, BW, BW,
+                                  a->dtz_offsets + (size_t)i * M * BW, a->tacts_offsets + (size_t)(i - 1) * M * BW};
+    w.job[n++] = BendWgradJob{a->dz_out4, 4, 3, a->acts_offsets + (size_t)(BD - 2) * M * BW, BW, BW,
+                              a->dtz_out4, a->tacts_offsets + (size_t)(BD - 2) * M * BW};
+    w.job[n++] = BendWgradJob{a->dz_rigidity, RW, RW, a->points, 3, 3, a->dtz_rigidity, a->probe};           // rigidity_network[0]
+    for (int i = 1; i <= RD - 2; ++i)
+        w.job[n++] = BendWgradJob{a->dz_rigidity + (size_t)i * M * RW, RW, RW, a->acts_rigidity + (size_t)(i - 1) * M * RW, RW, RW,
+                                  a->dtz_rigidity + (size_t)i * M * RW, a->tacts_rigidity + (size_t)(i - 1) * M * RW};
+    w.job[n++] = BendWgradJob{a->dz_out4 + 3, 4, 1, a->acts_rigidity + (size_t)(RD - 2) * M * RW, RW, RW,
+                              a->dtz_out4 + 3, a->tacts_rigidity + (size_t)(RD - 2) * M * RW};
+    w.njobs = n; w.nparts = a->n_partials; w.m = (long long)M; w.out = a->partials;
+    w.S = 1;
+    e = launch_bend_wgrad(w, (hipStream_t)hip_stream);
+    return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
 
 namespace {
 int composite_device(const nrnerf_composite_args* a, int* dev) {
@@ -1147,7 +1232,7 @@ int composite_device(const nrnerf_composite_args* a, int* dev) {
 }
 }  // namespace
 
-int nrnerf_composite_forward(const nrnerf_composite_args* a, void* hip_stream) {
+int nrnerf_composite_forward(const nrnerf_composite_args* a, void* hip_stream) try {
     if (!a || a->struct_size != sizeof(nrnerf_composite_args)) return NRNERF_ERR_INVALID;
     if (a->n_rays < 0 || a->n_samples < 2 || a->n_importance < 0) return NRNERF_ERR_INVALID;
     if (a->n_samples > 256 || a->n_samples + a->n_importance > 256) return NRNERF_ERR_UNSUPPORTED;
@@ -1165,9 +1250,9 @@ int nrnerf_composite_forward(const nrnerf_composite_args* a, void* hip_stream) {
     c.n_importance = a->n_importance; c.rgb = a->rgb; c.disp = a->disp; c.acc = a->acc; c.z_std = a->z_std;
     c.z_out = a->z_merged; c.vis = a->weights; c.alpha = a->alpha;
     return launch_composite(c, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
-}
+} NRN_CATCH
 
-int nrnerf_composite_backward(const nrnerf_composite_args* a, void* hip_stream) {
+int nrnerf_composite_backward(const nrnerf_composite_args* a, void* hip_stream) try {
     if (!a || a->struct_size != sizeof(nrnerf_composite_args)) return NRNERF_ERR_INVALID;
     if (a->n_rays < 0 || a->n_samples < 2 || a->n_samples > 256) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
@@ -1182,18 +1267,18 @@ int nrnerf_composite_backward(const nrnerf_composite_args* a, void* hip_stream) 
     c.white_bkgd = a->white_bkgd; c.noise = a->noise; c.n_rays = a->n_rays; c.S = a->n_samples;
     c.g_rgb = a->g_rgb; c.g_disp = a->g_disp; c.g_acc = a->g_acc; c.g_w = a->g_weights; c.d_raw4 = a->d_raw4;
     return launch_composite_bwd(c, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
-}
+} NRN_CATCH
 
-int nrnerf_profile_begin(nrnerf_model* m) {
+int nrnerf_profile_begin(nrnerf_model* m) try {
     if (!m) return NRNERF_ERR_INVALID;
     std::lock_guard<std::mutex> g(m->prof_mu);
     for (auto& e : m->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     m->prof_events.clear();
     m->prof_on = true;
     return NRNERF_OK;
-}
+} NRN_CATCH
 
-int nrnerf_profile_end(nrnerf_model* m, nrnerf_profile* out) {
+int nrnerf_profile_end(nrnerf_model* m, nrnerf_profile* out) try {
     if (!m || !out) return NRNERF_ERR_INVALID;
     std::lock_guard<std::mutex> g(m->prof_mu);
     m->prof_on = false;
@@ -1210,6 +1295,6 @@ int nrnerf_profile_end(nrnerf_model* m, nrnerf_profile* out) {
     }
     m->prof_events.clear();
     return rc;
-}
+} NRN_CATCH
 
 }  // extern "C"

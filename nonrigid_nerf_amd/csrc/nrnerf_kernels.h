@@ -159,8 +159,10 @@ struct BendWgradJob {
     const float* dz; int ldz, f;      // [M][ldz], the first f <= 64 columns: gradient wrt a layer's pre-activations
     const float* x;  int ldx, g;      // [M][ldx], the first g <= 64 columns: that layer's input; nullptr: the offset MLP's input
                                       // row [point, latent code], formed on the fly from the ray records (BendWgradArgs)
+    const float* dz2; const float* x2;   // optional second product of the same shapes, added into the same dW (not into db):
+                                      // the tangent chain of the divergence regulariser (bend_div_bwd), or nullptr
 };
-constexpr int BEND_WGRAD_MAX_JOBS = 12;
+constexpr int BEND_WGRAD_MAX_JOBS = 16;
 constexpr int BEND_WGRAD_SLOT = 64 * 64 + 64;       // floats per (partial, job): dW [64][64] then db [64]
 struct BendWgradArgs {
     BendWgradJob job[BEND_WGRAD_MAX_JOBS];
@@ -173,6 +175,35 @@ struct BendWgradArgs {
     const float* z; int S;
 };
 hipError_t launch_bend_wgrad(const BendWgradArgs&, hipStream_t);
+
+// Divergence regulariser of the ray bender (compute_divergence_loss / divergence_approx, run_nerf_helpers.py:22-116):
+// d = e^T J e with J = d(masked offsets)/d(point), by ONE forward-mode tangent through both MLPs (the reference takes a
+// vector-Jacobian product with create_graph=True and differentiates that graph again), and its backward pass: the
+// value chain and the tangent chain share weights and relu masks (bend_div_fwd / bend_div_bwd, nrnerf_train_bend.h).
+struct BendDivArgs {
+    const float* pts;        // [M,3] points
+    const float* latents; int lat_stride;   // one row per POINT, lat_stride floats apart (0: one code for every point)
+    const float* e;          // [M,3] probe vectors
+    long long m;
+    const void* wstream;     // forward: bender + rigidity stream (Plan<ShapeF32, A, true, false, false>); backward: PlanBB stream
+    const float* bias;       // forward only
+    Knobs knobs;
+    float* div;              // forward out [M]
+    float* off4;             // [M,4] unmasked offsets xyz + tanh(rigidity logit):                 forward writes, backward reads
+    float* toff4;            // [M,4] tangent of the offsets xyz + tangent of the rigidity logit:  forward writes, backward reads
+    float* acts_b;  float* tacts_b;   // [BD-1][M][BW] hidden activations / their tangents (after the relu mask)
+    float* acts_r;  float* tacts_r;   // [RD-1][M][RW]
+    const float* g_div;      // backward in [M]
+    float* dz_b;  float* dtz_b;       // backward out [BD-1][M][BW] gradient wrt the hidden pre-activations / their tangents
+    float* dz_r;  float* dtz_r;       // backward out [RD-1][M][RW]
+    float* dz_out4;          // backward out [M,4] gradient wrt the offsets (xyz) and the rigidity logit (w)
+    float* dtz_out4;         // backward out [M,4] ... wrt their tangents
+    float* d_lat;            // backward out [M,LAT] gradient wrt each point's latent inputs
+};
+hipError_t launch_bend_div_fwd_a0(const BendDivArgs&, int num_cus, hipStream_t);
+hipError_t launch_bend_div_fwd_a1(const BendDivArgs&, int num_cus, hipStream_t);
+hipError_t launch_bend_div_bwd_a0(const BendDivArgs&, int num_cus, hipStream_t);
+hipError_t launch_bend_div_bwd_a1(const BendDivArgs&, int num_cus, hipStream_t);
 
 // weight gradients of the trunk, bf16 mode (trunk_wgrad, nrnerf_train.h): a list of products  dz^T x  over the samples
 struct WgradJob {

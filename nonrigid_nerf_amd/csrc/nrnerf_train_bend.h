@@ -246,6 +246,280 @@ __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Divergence regulariser (reference compute_divergence_loss / divergence_approx, run_nerf_helpers.py:22-116;
+// train.py:244-287): per point  d = e^T J e,  J = d(masked offsets)/d(point).  The reference forms  J^T e  by a
+// vector-Jacobian product with create_graph=True and back-propagates through that graph (double backward through both
+// MLPs).  Here d is ONE forward-mode tangent through the MLPs (dense_b's tangent operand, as in the exact-view-direction
+// kernels): with z_i = W_i h_{i-1} + b_i, h_i = relu(z_i),
+//     tz_i = W_i th_{i-1},   th_i = [z_i > 0] tz_i,   th_0 = (e, 0),
+//     m = (tanh(r) + 1)/2,   tm = (1 - tanh(r)^2)/2 * tr,          (0 and 0 below the cutoff knob)
+//     d = s * e . (tm * off + m * toff)
+// and its backward pass is two chains that share weights and relu masks (the derivative of the mask itself is zero, as
+// in autograd's double backward of relu):
+//     g_off = g s tm e,  g_toff = g s m e,  g_m = g s (e . toff),  g_tm = g s (e . off)
+//     g_r = g_m (1 - t^2)/2 - g_tm tr t (1 - t^2),   g_tr = g_tm (1 - t^2)/2          (t = tanh(r))
+//     dz_i = [z_i > 0] W_{i+1}^T dz_{i+1},   dtz_i = [z_i > 0] W_{i+1}^T dtz_{i+1}
+//     dW_i = dz_i^T h_{i-1} + dtz_i^T th_{i-1},   db_i = sum dz_i,   d latent = (latent rows of W_0)^T dz_0
+// Points are independent here (no ray structure): a block is 32 consecutive points, every point has its own latent row.
+// ------------------------------------------------------------------------------------------------------------------
+template <class A>
+__global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
+    using P = PolF32;
+    using PL = Plan<P, A, true, false, false>;
+    constexpr int SP = P::SP, WAVES = 4;
+    constexpr int NS_BIN = PL::NS_BIN, NS_RIN = PL::NS_RIN;
+    constexpr int NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
+    using ST = WResident<P, PL::NFRAGS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = (float*)(smem + ST::BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    ST st;
+    st.init(a.wstream, smem, tid, WAVES * 64, lane);
+    for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = a.bias[i];
+    __syncthreads();
+    const BiasPtr bias_lane = bias_lane_ptr(bias_lds, h);
+
+    const size_t M = (size_t)a.m;
+    const long long nblocks = (a.m + 31) >> 5;
+    for (long long blk = (long long)blockIdx.x * WAVES + wave; blk < nblocks; blk += (long long)gridDim.x * WAVES) {
+        const long long sidx = blk * 32 + j;
+        const bool ok = sidx < a.m;
+        const size_t so = ok ? (size_t)sidx : M - 1;
+        const float p[3] = {a.pts[so * 3], a.pts[so * 3 + 1], a.pts[so * 3 + 2]};
+        const float ev[3] = {a.e[so * 3], a.e[so * 3 + 1], a.e[so * 3 + 2]};
+        const float* lat = a.latents + so * (size_t)a.lat_stride;
+        auto binval = [&](auto idxc) -> float {
+            constexpr int idx = decltype(idxc)::value;
+            if constexpr (idx < 3) return p[idx];
+            else if constexpr (idx < 8) return 0.0f;
+            else if constexpr (idx - 8 < A::LAT) return lat[idx - 8];
+            else return 0.0f;
+        };
+        auto tanval = [&](auto idxc) -> float {            // tangent of the first layers' inputs: (e, 0, ...)
+            constexpr int idx = decltype(idxc)::value;
+            if constexpr (idx < 3) return ev[idx];
+            else return 0.0f;
+        };
+        Act<P, NS_BIN, false> bin;
+        Tan<P, NS_BIN> tbin;
+        static_for<0, NS_BIN>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            const float v0 = binval(std::integral_constant<int, 2 * s>{}), v1 = binval(std::integral_constant<int, 2 * s + 1>{});
+            bin.template set<s, 0>(h ? v1 : v0);
+            const float t0 = tanval(std::integral_constant<int, 2 * s>{}), t1 = tanval(std::integral_constant<int, 2 * s + 1>{});
+            tbin.template set<s, 0>(h ? t1 : t0);
+        });
+        // hidden layer `layer`: keep value and tangent (true feature order) and hand both on
+        auto keep = [&](float* base, float* tbase, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc, auto& out, auto& tout) {
+            constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
+            if (ok) {
+                const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    store4<P>(base, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]), relu_bits(acc[4 * q + 3]));
+                    store4<P>(tbase, row + 8 * q, acc[4 * q] > 0.0f ? tacc[4 * q] : 0.0f, acc[4 * q + 1] > 0.0f ? tacc[4 * q + 1] : 0.0f,
+                              acc[4 * q + 2] > 0.0f ? tacc[4 * q + 2] : 0.0f, acc[4 * q + 3] > 0.0f ? tacc[4 * q + 3] : 0.0f);
+                }
+            }
+            pack_act<P, t>(acc, out);
+            pack_tan<P, t>(acc, tacc, tout);
+        };
+        Act<P, NB, false> ba, bb;
+        Tan<P, NB> ta, tb;
+        float off[3], toff[3];
+        dense_b<P, false, PL, PL::L_BEND0, NS_BIN>(st, bias_lane, bin, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+            keep(a.acts_b, a.tacts_b, A::BW, std::integral_constant<int, 0>{}, tc, acc, tacc, ba, ta); }, tbin);
+        static_for<1, A::BD - 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i % 2 == 1)
+                dense_b<P, false, PL, PL::L_BEND0 + i, NB>(st, bias_lane, ba, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                    keep(a.acts_b, a.tacts_b, A::BW, ic, tc, acc, tacc, bb, tb); }, ta);
+            else
+                dense_b<P, false, PL, PL::L_BEND0 + i, NB>(st, bias_lane, bb, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                    keep(a.acts_b, a.tacts_b, A::BW, ic, tc, acc, tacc, ba, ta); }, tb);
+        });
+        auto take_off = [&](auto, const f32x16& acc, const f32x16& tacc) {
+            off[0] = acc[0]; off[1] = acc[1]; off[2] = acc[2];
+            toff[0] = tacc[0]; toff[1] = tacc[1]; toff[2] = tacc[2];
+        };
+        if constexpr ((A::BD - 2) % 2 == 1) dense_b<P, false, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, bb, take_off, tb);
+        else dense_b<P, false, PL, PL::L_BEND0 + A::BD - 1, NB>(st, bias_lane, ba, take_off, ta);
+        // rigidity MLP (input = xyz only)
+        Act<P, NS_RIN, false> rin;
+        Tan<P, NS_RIN> trin;
+        static_for<0, NS_RIN>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            const float v0 = (2 * s < 3) ? p[2 * s < 3 ? 2 * s : 0] : 0.0f, v1 = (2 * s + 1 < 3) ? p[2 * s + 1 < 3 ? 2 * s + 1 : 0] : 0.0f;
+            rin.template set<s, 0>(h ? v1 : v0);
+            const float t0 = (2 * s < 3) ? ev[2 * s < 3 ? 2 * s : 0] : 0.0f, t1 = (2 * s + 1 < 3) ? ev[2 * s + 1 < 3 ? 2 * s + 1 : 0] : 0.0f;
+            trin.template set<s, 0>(h ? t1 : t0);
+        });
+        Act<P, NR, false> ra, rb;
+        Tan<P, NR> tra, trb;
+        float logit, tlogit;
+        dense_b<P, false, PL, PL::L_RIG0, NS_RIN>(st, bias_lane, rin, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+            keep(a.acts_r, a.tacts_r, A::RW, std::integral_constant<int, 0>{}, tc, acc, tacc, ra, tra); }, trin);
+        static_for<1, A::RD - 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i % 2 == 1)
+                dense_b<P, false, PL, PL::L_RIG0 + i, NR>(st, bias_lane, ra, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                    keep(a.acts_r, a.tacts_r, A::RW, ic, tc, acc, tacc, rb, trb); }, tra);
+            else
+                dense_b<P, false, PL, PL::L_RIG0 + i, NR>(st, bias_lane, rb, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                    keep(a.acts_r, a.tacts_r, A::RW, ic, tc, acc, tacc, ra, tra); }, trb);
+        });
+        auto take_logit = [&](auto, const f32x16& acc, const f32x16& tacc) { logit = acc[0]; tlogit = tacc[0]; };
+        if constexpr ((A::RD - 2) % 2 == 1) dense_b<P, false, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, rb, take_logit, trb);
+        else dense_b<P, false, PL, PL::L_RIG0 + A::RD - 1, NR>(st, bias_lane, ra, take_logit, tra);
+
+        const float th = tanhf(logit);
+        float mask = (th + 1.0f) / 2.0f;                                                   // rnh:559-561
+        float tmask = 0.5f * (1.0f - th * th) * tlogit;
+        if (a.knobs.has_cutoff && mask <= a.knobs.cutoff) { mask = 0.0f; tmask = 0.0f; }   // rnh:563-564: the assignment has no derivative
+        float d = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d += ev[c] * (tmask * off[c] + mask * toff[c]);       // e . d(mask * off)/dt   (rnh:567)
+        if (a.knobs.has_scaling) d *= a.knobs.scaling;                                     // rnh:568-569
+        if (ok && h == 0) {
+            a.div[so] = d;
+            *(f32x4*)(a.off4 + so * 4) = f32x4{off[0], off[1], off[2], th};
+            *(f32x4*)(a.toff4 + so * 4) = f32x4{toff[0], toff[1], toff[2], tlogit};
+        }
+    }
+}
+
+template <class A>
+__global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
+    using P = PolF32;
+    using PL = PlanBB<P, A>;
+    constexpr int SP = P::SP, WAVES = 4;
+    constexpr int NS_DR = PL::NS_DR, NB = PL::NT_BW * SP, NR = PL::NT_RW * SP;
+    using ST = WResident<P, PL::NFRAGS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = (float*)(smem + ST::BYTES);          // zero: backward layers have no bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    ST st;
+    st.init(a.wstream, smem, tid, WAVES * 64, lane);
+    for (int i = tid; i < PL::NTILES * 32; i += WAVES * 64) bias_lds[i] = 0.0f;
+    __syncthreads();
+    const BiasPtr bias_lane = bias_lane_ptr(bias_lds, h);
+
+    const size_t M = (size_t)a.m;
+    const long long nblocks = (a.m + 31) >> 5;
+    for (long long blk = (long long)blockIdx.x * WAVES + wave; blk < nblocks; blk += (long long)gridDim.x * WAVES) {
+        const long long sidx = blk * 32 + j;
+        const bool ok = sidx < a.m;
+        const size_t so = ok ? (size_t)sidx : M - 1;
+        const float ev[3] = {a.e[so * 3], a.e[so * 3 + 1], a.e[so * 3 + 2]};
+        const f32x4 ot = *(const f32x4*)(a.off4 + so * 4);         // offsets xyz, tanh(logit)
+        const f32x4 tt = *(const f32x4*)(a.toff4 + so * 4);        // their tangents; .w = tangent of the logit
+        const float sc = a.knobs.has_scaling ? a.knobs.scaling : 1.0f;
+        const float th = ot[3], tlogit = tt[3];
+        const float s2 = 0.5f * (1.0f - th * th);
+        const bool cut = a.knobs.has_cutoff && (th + 1.0f) / 2.0f <= a.knobs.cutoff;
+        const float mask = cut ? 0.0f : (th + 1.0f) / 2.0f, tmask = cut ? 0.0f : s2 * tlogit;
+        const float g = ok ? a.g_div[so] * sc : 0.0f;
+        float g_off[3], g_toff[3], g_m = 0.0f, g_tm = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g_off[c] = g * ev[c] * tmask;
+            g_toff[c] = g * ev[c] * mask;
+            g_m += g * ev[c] * tt[c];
+            g_tm += g * ev[c] * ot[c];
+        }
+        const float g_logit = cut ? 0.0f : g_m * s2 - g_tm * tlogit * th * (1.0f - th * th);
+        const float g_tlogit = cut ? 0.0f : g_tm * s2;
+        if (ok && h == 0) {
+            *(f32x4*)(a.dz_out4 + so * 4) = f32x4{g_off[0], g_off[1], g_off[2], g_logit};
+            *(f32x4*)(a.dtz_out4 + so * 4) = f32x4{g_toff[0], g_toff[1], g_toff[2], g_tlogit};
+        }
+        // (d h, d th) of a hidden layer's tile -> (d z, d tz): both masked with the saved activation, stored, handed on
+        auto mask_store = [&](const float* acts, float* dz, float* dtz, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc,
+                              auto& out, auto& tout) {
+            constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
+            const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
+            f32x16 gv = acc, gt = tacc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 hv = load4<P>(acts, row + 8 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gv[4 * q + k] = (hv[k] > 0.0f) ? acc[4 * q + k] : 0.0f;
+                    gt[4 * q + k] = (hv[k] > 0.0f) ? tacc[4 * q + k] : 0.0f;
+                }
+                if (ok) {
+                    store4<P>(dz, row + 8 * q, gv[4 * q], gv[4 * q + 1], gv[4 * q + 2], gv[4 * q + 3]);
+                    store4<P>(dtz, row + 8 * q, gt[4 * q], gt[4 * q + 1], gt[4 * q + 2], gt[4 * q + 3]);
+                }
+            }
+            pack_lin<P, t>(gv, out);
+            pack_lin<P, t>(gt, tout);
+        };
+        // ---- offset MLP: network[BD-1]^T .. network[0]^T
+        Act<P, NS_DR, false> dr;
+        Tan<P, NS_DR> tdr;
+        static_for<0, NS_DR>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            const float v0 = (2 * s < 3) ? g_off[2 * s < 3 ? 2 * s : 0] : 0.0f, v1 = (2 * s + 1 < 3) ? g_off[2 * s + 1 < 3 ? 2 * s + 1 : 0] : 0.0f;
+            dr.template set<s, 0>(h ? v1 : v0);
+            const float t0 = (2 * s < 3) ? g_toff[2 * s < 3 ? 2 * s : 0] : 0.0f, t1 = (2 * s + 1 < 3) ? g_toff[2 * s + 1 < 3 ? 2 * s + 1 : 0] : 0.0f;
+            tdr.template set<s, 0>(h ? t1 : t0);
+        });
+        Act<P, NB, false> ba, bb;
+        Tan<P, NB> ta, tb;
+        dense_b<P, false, PL, PL::L_BEND(A::BD - 1), NS_DR>(st, bias_lane, dr, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+            mask_store(a.acts_b, a.dz_b, a.dtz_b, A::BW, std::integral_constant<int, A::BD - 2>{}, tc, acc, tacc, ba, ta); }, tdr);
+        static_for<0, A::BD - 2>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;             // 0 .. BD-3
+            constexpr int i = A::BD - 2 - k;                   // network[i]^T: (d z_i, d tz_i) -> (d h_{i-1}, d th_{i-1})
+            auto run = [&](auto& src, auto& tsrc, auto& dst, auto& tdst) {
+                dense_b<P, false, PL, PL::L_BEND(i), NB>(st, bias_lane, src, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                    mask_store(a.acts_b, a.dz_b, a.dtz_b, A::BW, std::integral_constant<int, i - 1>{}, tc, acc, tacc, dst, tdst); }, tsrc);
+            };
+            if constexpr (k % 2 == 0) run(ba, ta, bb, tb); else run(bb, tb, ba, ta);
+        });
+        // network[0]^T, latent rows, value chain only (the tangent of the latent inputs is zero: they are not differentiated
+        // with respect to position)
+        auto take_lat = [&](auto tc, const f32x16& acc) {
+            constexpr int t = decltype(tc)::value;
+            if (ok) {
+                const size_t row = so * A::LAT + 32 * t + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (32 * t + 8 * q + 4 * h + 3 < A::LAT) store4<P>(a.d_lat, row + 8 * q, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        };
+        if constexpr ((A::BD - 2) % 2 == 0) dense_b<P, false, PL, PL::L_BEND(0), NB>(st, bias_lane, ba, take_lat);
+        else dense_b<P, false, PL, PL::L_BEND(0), NB>(st, bias_lane, bb, take_lat);
+        // ---- rigidity MLP: rigidity_network[RD-1]^T .. rigidity_network[1]^T
+        Act<P, NS_DR, false> drr;
+        Tan<P, NS_DR> tdrr;
+        static_for<0, NS_DR>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            drr.template set<s, 0>((s == 0 && h == 0) ? g_logit : 0.0f);
+            tdrr.template set<s, 0>((s == 0 && h == 0) ? g_tlogit : 0.0f);
+        });
+        Act<P, NR, false> ra, rb;
+        Tan<P, NR> tra, trb;
+        dense_b<P, false, PL, PL::L_RIG(A::RD - 1), NS_DR>(st, bias_lane, drr, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+            mask_store(a.acts_r, a.dz_r, a.dtz_r, A::RW, std::integral_constant<int, A::RD - 2>{}, tc, acc, tacc, ra, tra); }, tdrr);
+        static_for<0, A::RD - 2>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int i = A::RD - 2 - k;                   // rigidity_network[i]^T, i >= 1
+            auto run = [&](auto& src, auto& tsrc, auto& dst, auto& tdst) {
+                dense_b<P, false, PL, PL::L_RIG(i), NR>(st, bias_lane, src, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
+                    mask_store(a.acts_r, a.dz_r, a.dtz_r, A::RW, std::integral_constant<int, i - 1>{}, tc, acc, tacc, dst, tdst); }, tsrc);
+            };
+            if constexpr (k % 2 == 0) run(ra, tra, rb, trb); else run(rb, trb, ra, tra);
+        });
+    }
+}
+
 // Weight and bias gradients of both MLPs in one launch: dW = dz^T x over the samples for a list of (dz, x) pairs of
 // row-major fp32 arrays (at most 64 x 64 each), on v_mfma_f32_32x32x2_f32 with the SAMPLE as contraction index: the A
 // operand of a k-step is dz[sample s + h][32 tr + i], the B operand x[sample s + h][32 tc + j] -- one coalesced 128-byte
@@ -264,39 +538,45 @@ __global__ void __launch_bounds__(256) bend_wgrad(const BendWgradArgs a) {
     const bool fa0 = i < jb.f, fa1 = 32 + i < jb.f, gb0 = i < jb.g, gb1 = 32 + i < jb.g;
     f32x16 acc[2][2] = {{f32x16{}, f32x16{}}, {f32x16{}, f32x16{}}};
     float bsum[2] = {0.0f, 0.0f};
-    for (long long p = p0; p < p1; p += U) {
-        float av[U][2], bv[U][2];
+    for (int pass = 0; pass < (jb.dz2 ? 2 : 1); ++pass) {          // second product (dz2, x2): same shapes, same dW, not in db
+        const float* dzp = pass ? jb.dz2 : jb.dz;
+        const float* xp = pass ? jb.x2 : jb.x;
+        for (long long p = p0; p < p1; p += U) {
+            float av[U][2], bv[U][2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long long s = 2 * (p + u) + h;
-            const bool ok = (p + u < p1) && s < a.m;
-            const float* dr = jb.dz + (size_t)s * jb.ldz + i;
-            av[u][0] = (ok && fa0) ? dr[0] : 0.0f;
-            av[u][1] = (ok && fa1) ? dr[32] : 0.0f;
-            if (jb.x) {
-                const float* xr = jb.x + (size_t)s * jb.ldx + i;
-                bv[u][0] = (ok && gb0) ? xr[0] : 0.0f;
-                bv[u][1] = (ok && gb1) ? xr[32] : 0.0f;
-            } else {                            // column c of [point (3), latent code]: c = i (first tile), 32 + i (second)
-                const long long ray = ok ? s / a.S : 0;
-                const float* rp = a.rays + (size_t)ray * a.ray_stride;
-                const float* lp = a.latents + (size_t)ray * a.lat_stride;
-                float v0 = 0.0f, v1 = 0.0f;
-                if (ok && gb0) v0 = (i < 3) ? __fadd_rn(rp[i], __fmul_rn(rp[3 + i], a.z[s])) : lp[i - 3];
-                if (ok && gb1) v1 = lp[29 + i];
-                bv[u][0] = v0;
-                bv[u][1] = v1;
+            for (int u = 0; u < U; ++u) {
+                const long long s = 2 * (p + u) + h;
+                const bool ok = (p + u < p1) && s < a.m;
+                const float* dr = dzp + (size_t)s * jb.ldz + i;
+                av[u][0] = (ok && fa0) ? dr[0] : 0.0f;
+                av[u][1] = (ok && fa1) ? dr[32] : 0.0f;
+                if (xp) {
+                    const float* xr = xp + (size_t)s * jb.ldx + i;
+                    bv[u][0] = (ok && gb0) ? xr[0] : 0.0f;
+                    bv[u][1] = (ok && gb1) ? xr[32] : 0.0f;
+                } else {                            // column c of [point (3), latent code]: c = i (first tile), 32 + i (second)
+                    const long long ray = ok ? s / a.S : 0;
+                    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+                    const float* lp = a.latents + (size_t)ray * a.lat_stride;
+                    float v0 = 0.0f, v1 = 0.0f;
+                    if (ok && gb0) v0 = (i < 3) ? __fadd_rn(rp[i], __fmul_rn(rp[3 + i], a.z[s])) : lp[i - 3];
+                    if (ok && gb1) v1 = lp[29 + i];
+                    bv[u][0] = v0;
+                    bv[u][1] = v1;
+                }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bsum[0] += av[u][0];
-            bsum[1] += av[u][1];
-            acc[0][0] = PolF32::mfma(av[u][0], bv[u][0], acc[0][0]);
-            if (g1) acc[0][1] = PolF32::mfma(av[u][0], bv[u][1], acc[0][1]);
-            if (f1) {
-                acc[1][0] = PolF32::mfma(av[u][1], bv[u][0], acc[1][0]);
-                if (g1) acc[1][1] = PolF32::mfma(av[u][1], bv[u][1], acc[1][1]);
+            for (int u = 0; u < U; ++u) {
+                if (pass == 0) {
+                    bsum[0] += av[u][0];
+                    bsum[1] += av[u][1];
+                }
+                acc[0][0] = PolF32::mfma(av[u][0], bv[u][0], acc[0][0]);
+                if (g1) acc[0][1] = PolF32::mfma(av[u][0], bv[u][1], acc[0][1]);
+                if (f1) {
+                    acc[1][0] = PolF32::mfma(av[u][1], bv[u][0], acc[1][0]);
+                    if (g1) acc[1][1] = PolF32::mfma(av[u][1], bv[u][1], acc[1][1]);
+                }
             }
         }
     }
@@ -333,6 +613,31 @@ static hipError_t launch_bend_train(const BendTrainArgs& a, int num_cus, hipStre
     const long long want = (nblocks + 3) / 4;
     if (want <= 0) return hipSuccess;
     // two workgroups per CU when their resident weights fit twice (forward 20 / 28 KiB, backward 65 / 97 KiB of 160)
+    const long long resident = (long long)num_cus * ((2 * lds <= 160 * 1024) ? 2 : 1);
+    const int grid = (int)(want < resident ? want : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+
+template <class A, bool BWD>
+static hipError_t launch_bend_div(const BendDivArgs& a, int num_cus, hipStream_t stream) {
+    using P = PolF32;
+    constexpr int NFRAGS = BWD ? PlanBB<P, A>::NFRAGS : Plan<P, A, true, false, false>::NFRAGS;
+    constexpr int NTILES = BWD ? PlanBB<P, A>::NTILES : Plan<P, A, true, false, false>::NTILES;
+    const size_t lds = (size_t)NFRAGS * P::FRAG_BYTES + (size_t)NTILES * 32 * sizeof(float);
+    void (*kern)(const BendDivArgs) = nullptr;
+    if constexpr (BWD) kern = bend_div_bwd<A>; else kern = bend_div_fwd<A>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const long long want = ((a.m + 31) / 32 + 3) / 4;
+    if (want <= 0) return hipSuccess;
     const long long resident = (long long)num_cus * ((2 * lds <= 160 * 1024) ? 2 : 1);
     const int grid = (int)(want < resident ? want : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);

@@ -1,4 +1,4 @@
-// nrnerf_train_bend_inst.hip -- the two training kernels of the ray bender (nrnerf_train_bend.h) for one compiled bender
+// nrnerf_train_bend_inst.hip -- the training kernels of the ray bender (forward, backward, divergence regulariser forward / backward) (nrnerf_train_bend.h) for one compiled bender
 // architecture.  Build with -DNRN_ARCH=0 (reference default) or 1 (deeper offset MLP).
 #include "nrnerf_train_bend.h"
 
@@ -10,6 +10,12 @@ hipError_t NRN_CAT(launch_bend_fwd_train_a, NRN_ARCH)(const BendTrainArgs& a, in
 }
 hipError_t NRN_CAT(launch_bend_bwd_a, NRN_ARCH)(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
     return launch_bend_train<ArchById<NRN_ARCH>::type, true>(a, num_cus, stream);
+}
+hipError_t NRN_CAT(launch_bend_div_fwd_a, NRN_ARCH)(const BendDivArgs& a, int num_cus, hipStream_t stream) {
+    return launch_bend_div<ArchById<NRN_ARCH>::type, false>(a, num_cus, stream);
+}
+hipError_t NRN_CAT(launch_bend_div_bwd_a, NRN_ARCH)(const BendDivArgs& a, int num_cus, hipStream_t stream) {
+    return launch_bend_div<ArchById<NRN_ARCH>::type, true>(a, num_cus, stream);
 }
 #if NRN_ARCH == 0     // the weight-gradient kernel does not depend on the bender's depth: one copy
 hipError_t launch_bend_wgrad(const BendWgradArgs& a, hipStream_t stream) {

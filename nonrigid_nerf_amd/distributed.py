@@ -145,7 +145,7 @@ class GradientBuckets:
         self.force_collective = force_collective
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = dist.is_initialized() and (self.world > 1 or force_collective)
-        self.flat, self.params, self.pending, self._arrived, self._expected, self._hooks = [], [], [], [], [], []
+        self.flat, self.params, self.pending, self._arrived, self._expected, self._hooks, self._late = [], [], [], [], [], [], []
         for plist in buckets:
             plist = [p for p in plist if p.requires_grad]
             if not plist:
@@ -162,10 +162,15 @@ class GradientBuckets:
             self.flat.append(flat)
             self.params.append(plist)
             self.pending.append(None)
-            self._arrived.append(0)
-            self._expected.append(len(plist))
-            for p in plist:
-                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._on_grad(bi)))
+            # which parameters have arrived this step / which ones the bucket waits for before it launches: tracked by
+            # IDENTITY (index in the bucket), not by count -- a step that produces gradients for other parameters than the
+            # previous one (a regulariser switched on, N_importance or the head toggled) must not launch the all-reduce
+            # after "the first k arrivals"
+            self._arrived.append(set())
+            self._expected.append(frozenset(range(len(plist))))
+            self._late.append(None)
+            for pi, p in enumerate(plist):
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi, pi=pi: self._on_grad(bi, pi)))
         self.device = self.flat[0].device if self.flat else torch.device("cpu")
         self.cuda = self.device.type == "cuda"
         self.side = torch.cuda.Stream(device=self.device) if (self.cuda and self.active) else None
@@ -173,15 +178,28 @@ class GradientBuckets:
     def zero_grad(self):
         for bi, flat in enumerate(self.flat):
             flat.zero_()
-            self._arrived[bi] = 0
+            self._arrived[bi] = set()
+            self._late[bi] = None
             for p in self.params[bi]:          # re-attach a view someone replaced (e.g. zero_grad(set_to_none=True))
                 if p.grad is None or p.grad.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
                     raise RuntimeError("a parameter's .grad no longer lives in its bucket (optimizer.zero_grad(set_to_none=True)?)")
 
-    def _on_grad(self, bi: int):
-        self._arrived[bi] += 1
-        if self._arrived[bi] == self._expected[bi] and self.active and self.pending[bi] is None:
+    def _on_grad(self, bi: int, pi: int):
+        if self.pending[bi] is not None:
+            # the bucket's all-reduce is already in flight on the side stream and this gradient was just written into the
+            # buffer it reads: the result is undefined.  Remember it; finish() raises (see expect_all).
+            self._late[bi] = pi
+            return
+        self._arrived[bi].add(pi)
+        if self.active and self._arrived[bi] >= self._expected[bi] and pi in self._expected[bi]:
             self._reduce(bi)
+
+    def expect_all(self):
+        """Forget which parameters the previous steps produced gradients for: the next step's buckets are reduced in
+        ``finish()`` (no overlap for one step) and re-learn the set.  Call it when the loss changes which parameters
+        take part (a regulariser switched on or off, a different head), or after ``finish()`` raised."""
+        for bi, plist in enumerate(self.params):
+            self._expected[bi] = frozenset(range(len(plist)))
 
     def _reduce(self, bi: int):
         flat = self.flat[bi]
@@ -202,14 +220,23 @@ class GradientBuckets:
             if self.pending[bi] is None:
                 # some of the bucket's parameters received no gradient (e.g. NeRF.views_linears without use_viewdirs,
                 # rnh:196-199): reduce now, and from the next step on launch as soon as the ones that do have arrived
-                if 0 < self._arrived[bi] < self._expected[bi]:
-                    self._expected[bi] = self._arrived[bi]
+                if self._arrived[bi] and self._arrived[bi] != self._expected[bi]:
+                    self._expected[bi] = frozenset(self._arrived[bi])
                 self._reduce(bi)
         for bi in range(len(self.flat)):
             self.pending[bi].wait()
             self.pending[bi] = None
         if self.cuda:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
+        late = [(bi, pi) for bi, pi in enumerate(self._late) if pi is not None]
+        if late:
+            self.expect_all()
+            bi, pi = late[0]
+            raise RuntimeError(
+                f"GradientBuckets: a gradient (bucket {bi}, parameter {pi}, shape {tuple(self.params[bi][pi].shape)}) arrived after "
+                "its bucket's all-reduce had been issued -- this step produced gradients for parameters the previous steps did "
+                "not, or backward() ran twice before finish().  The gradients of this step are invalid; the expectations were "
+                "reset (expect_all), zero_grad() and repeat the step.")
         if self.world > 1:
             for flat in self.flat:
                 flat.div_(self.world)

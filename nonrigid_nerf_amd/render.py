@@ -31,7 +31,9 @@ import torch
 
 from . import _lib
 
-_DEFAULT_PRECISION = os.environ.get("NRNERF_PRECISION", "bf16")
+# Arithmetic of direct callers (bench.py, tests, Model(...)) when nothing is said: the headline bf16 mode.  `install()` --
+# the two-line drop-in into an fp32 pipeline -- does NOT inherit this: without an explicit precision it selects "f32".
+_DEFAULT_PRECISION = _lib.canonical_precision(os.environ.get("NRNERF_PRECISION", "bf16"))
 _SCAN_OUTPUTS = os.environ.get("NRNERF_SCAN_OUTPUTS") == "1"
 _fallbacks = {}          # {"render_rays": fn, "batchify_rays": fn} saved by install()
 _MAX_RAYS_PER_LAUNCH = 1 << 20
@@ -40,9 +42,7 @@ _MAX_RAYS_PER_LAUNCH = 1 << 20
 def set_precision(p: str):
     """Arithmetic type of the MLP contractions: "bf16" (default, headline), "f16" or "f32" (exact parity mode)."""
     global _DEFAULT_PRECISION
-    if p not in _lib.PRECISIONS:
-        raise ValueError(f"unknown precision {p!r}")
-    _DEFAULT_PRECISION = p
+    _DEFAULT_PRECISION = _lib.canonical_precision(p)
 
 
 def get_precision() -> str:
@@ -195,13 +195,16 @@ class Model:
 
     def __init__(self, network_fn, network_fine=None, precision: str | None = None, device=None):
         self.lib = _lib.load()
-        self.precision = precision or _DEFAULT_PRECISION
+        self.precision = _lib.canonical_precision(precision or _DEFAULT_PRECISION)
         dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
         if dev.type != "cuda":
             raise RuntimeError("nonrigid_nerf_amd renders on a ROCm device only (got %s)" % dev)
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
         self.has_bender = bool(desc.bender)
+        # nrnerf_bender_* / nrnerf_bender_divergence_* are available (the library's own rule: training_eligible in
+        # csrc/nrnerf_api.cpp): a bender, no view-dependent head / time conditioning, not an f16 handle
+        self.trains_bender = bool(desc.bender) and not desc.coarse.contents.use_viewdirs and self.precision != "f16"
         self.needs_latents = self.has_bender or bool(desc.coarse.contents.time_conditioned)
         self.latent_size = desc.bender.contents.latent_size if self.has_bender else \
             (int(getattr(network_fn, "ray_bending_latent_size", 0)) if self.needs_latents else 0)
@@ -212,6 +215,7 @@ class Model:
         self.handle = handle
         self._ws = {}            # stream -> workspace: concurrent renders on different streams never share scratch
         self._ws_lock = threading.Lock()
+        self._render_events = {} # stream -> event recorded after the last render queued there (see update_from_device)
         del keep
 
     def update(self, network_fn, network_fine=None) -> bool:
@@ -240,8 +244,17 @@ class Model:
         if flat is None or flat.device != self.device or int(self.lib.nrnerf_model_flat_size(self.handle)) != flat.numel():
             return False
         with torch.cuda.device(self.device):
-            torch.cuda.synchronize(self.device)          # see update(): other streams may still read the old weights
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            # Stream-ordered, no host synchronisation: the gather kernels run on the current stream after every render /
+            # training kernel already queued there.  Renders this handle has queued on OTHER streams are ordered by
+            # events (one per stream that rendered since the last refresh), not by draining the device: this runs once
+            # per training step.
+            cur = torch.cuda.current_stream(self.device)
+            with self._ws_lock:
+                pending, self._render_events = self._render_events, {}
+            for sid, ev in pending.items():
+                if sid != cur.cuda_stream:
+                    cur.wait_event(ev)
+            stream = cur.cuda_stream
             rc = self.lib.nrnerf_model_update_device(self.handle, C.c_void_p(flat.data_ptr()), flat.numel(), C.c_void_p(stream))
         if rc in (_lib.ERR_INVALID, _lib.ERR_UNSUPPORTED):
             return False
@@ -359,13 +372,27 @@ class Model:
             base = (ws.data_ptr() + 255) // 256 * 256
             a.workspace, a.workspace_bytes = base, nbytes
             _lib.check(self.lib.nrnerf_render(self.handle, C.byref(a), C.c_void_p(stream)), "nrnerf_render")
+            self.note_use(dev)
         return out
+
+    def note_use(self, dev=None):
+        """Kernels reading this handle's weights were just queued on the current stream: remember an event there, so that
+        a later weight refresh issued from ANOTHER stream can order itself after them (update_from_device).  The
+        training entry points (nonrigid_nerf_amd/training.py) do not record: a training step is single-stream by
+        contract -- forward, backward, optimiser step and the refresh all run on the stream that is current."""
+        cur = torch.cuda.current_stream(dev if dev is not None else self.device)
+        with self._ws_lock:
+            ev = self._render_events.get(cur.cuda_stream)
+            if ev is None:
+                ev = self._render_events[cur.cuda_stream] = torch.cuda.Event()
+        ev.record(cur)
 
 
 # --------------------------------------------------------------------------------------------
 # model cache (weights are packed once per (modules, version) -- no per-call broadcast as in DataParallel)
 # --------------------------------------------------------------------------------------------
 _cache = weakref.WeakKeyDictionary()       # network_fn -> {key: (fingerprint, Model | Unsupported)}
+_by_bender = weakref.WeakKeyDictionary()   # ray bender -> (weakref network_fn, weakref network_fine | None, precision) of its last get_model
 _cache_lock = threading.Lock()
 
 
@@ -388,7 +415,7 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
     version them): call ``invalidate(network_fn)`` after such an edit.  Architectures the library has no kernel for
     raise ``Unsupported``; that verdict is cached as well, so a fallback caller does not re-copy the weights to the
     host on every call."""
-    precision = precision or _DEFAULT_PRECISION
+    precision = _lib.canonical_precision(precision or _DEFAULT_PRECISION)
     rb = _bender_of(network_fn)
     dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
     key = (_wref(network_fine), _wref(rb), precision, str(dev), bool(getattr(network_fn, "approx_nonrigid_viewdirs", True)))
@@ -398,6 +425,8 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
         for k in [k for k in per if any(r is not None and r() is None for r in k[:2])]:
             del per[k]                                                         # entries of collected fine nets / benders
         hit = per.get(key)
+        if rb is not None:
+            _by_bender[rb] = (weakref.ref(network_fn), _wref(network_fine), precision)
         if hit is not None and hit[0] == fp:
             if isinstance(hit[1], Exception):
                 raise hit[1]
@@ -419,6 +448,27 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
             raise err from e
         per[key] = (fp, model)
         return model
+
+
+def model_of_bender(ray_bender, device):
+    """The up-to-date packed model (with training kernels) whose ray bender is this module, on ``device`` -- for callers
+    that are handed the bender alone (``compute_divergence_loss``, run_nerf_helpers.py:22).  The modules that were
+    rendered with this bender last are looked up and their handle refreshed like any ``get_model`` call; None if the
+    bender has not been rendered through the HIP path (or its model has no training kernels)."""
+    with _cache_lock:
+        ent = _by_bender.get(ray_bender)
+    if ent is None:
+        return None
+    nf, nfine, precision = ent[0](), (ent[1]() if ent[1] is not None else None), ent[2]
+    if precision == "f16":
+        precision = "bf16"            # as training.render_rays_train: an f16 handle has no training kernels
+    if nf is None or (ent[1] is not None and nfine is None):
+        return None
+    try:
+        model = get_model(nf, nfine, precision=precision, device=device)
+    except Unsupported:
+        return None
+    return model if model.trains_bender else None
 
 
 def invalidate(network_fn=None):
@@ -612,18 +662,29 @@ def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, deta
 def install(train_module, precision: str | None = None):
     """Rebind ``train_module.render_rays`` / ``.batchify_rays`` to the HIP path.
 
-    The originals are kept and used only for calls the library has no kernel for (training with
-    autograd, exact view directions, ...).  Returns a callable that undoes the patch.
+    ``precision``: "f32" (default: exact fp32 MFMA, the parity mode), "bf16" (the benchmarked throughput mode, 65 dB
+    against the fp32 render on a fitted model) or "f16".  The originals are kept and used only for calls the library
+    has no kernel for.  Returns a callable that undoes the patch.
     """
     _lib.load()      # fail now, loudly, if the library is missing
-    if precision is not None:
-        set_precision(precision)
+    # A drop-in must not silently change an fp32 pipeline's arithmetic: without an explicit request (argument, or the
+    # NRNERF_PRECISION environment variable) the exact fp32 kernels are selected; the 16-bit modes are one keyword away.
+    set_precision(precision if precision is not None else os.environ.get("NRNERF_PRECISION", "f32"))
     orig = (train_module.render_rays, train_module.batchify_rays)
     _fallbacks["render_rays"], _fallbacks["batchify_rays"] = orig
     train_module.render_rays = render_rays
     train_module.batchify_rays = batchify_rays
+    # the divergence regulariser of the training iteration (train.py:266 calls the name it star-imported from
+    # run_nerf_helpers, i.e. a global of the train module): second order through the ray bender, native as well
+    orig_div = getattr(train_module, "compute_divergence_loss", None)
+    if orig_div is not None:
+        from . import training
+        _fallbacks["compute_divergence_loss"] = orig_div
+        train_module.compute_divergence_loss = training.compute_divergence_loss
 
     def uninstall():
         train_module.render_rays, train_module.batchify_rays = orig
+        if orig_div is not None:
+            train_module.compute_divergence_loss = orig_div
         _fallbacks.clear()
     return uninstall

@@ -82,6 +82,12 @@ def _rows4(x: torch.Tensor, M: int) -> torch.Tensor:
     return rows
 
 
+def _is_f32(model) -> bool:
+    """Layout of the saved arrays (row-major fp32 vs bf16 block tiles) as the LIBRARY sees this handle -- asked of the handle,
+    not inferred from a precision string, so an alias can never pair bf16-sized buffers with the fp32 kernels."""
+    return int(model.lib.nrnerf_model_precision(model.handle)) == _lib.PRECISIONS["f32"]
+
+
 class _Trunk(torch.autograd.Function):
     """raw4 [N,S,4] (differentiable), raw [N,S,C] (the reference's "raw" key; no gradient) = NeRF trunk(points)."""
 
@@ -90,7 +96,7 @@ class _Trunk(torch.autograd.Function):
         N, S = int(pts.shape[0]), int(pts.shape[1])
         M, dev = N * S, pts.device
         D, W = int(net.D), int(net.W)
-        f32 = model.precision == "f32"
+        f32 = _is_f32(model)
         pts4 = _rows4(pts.detach(), M)               # the bender's own [M,4] rows when the points come from _Bender
         # saved activations.  fp32 mode: [layer][sample][width] for the library GEMMs; bf16 mode: [layer][block][width][32
         # samples] for nrnerf_trunk_wgrad (blocks of 32 consecutive samples of a ray) + 16 relu bits per lane and tile
@@ -115,7 +121,7 @@ class _Trunk(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_raw4, _g_raw):
         model, net = ctx.model, ctx.net
-        f32 = model.precision == "f32"
+        f32 = _is_f32(model)
         pts4, acts = ctx.saved_tensors[:2]
         N, S, D, W, C_out = ctx.dims
         M, dev = N * S, pts4.device
@@ -457,12 +463,151 @@ def bend(rb, pts, latents):
     return pts + masked, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
 
 
+class _Divergence(torch.autograd.Function):
+    """d [M] = e^T J e,  J = d(masked offsets)/d(point) of the ray bender, on the HIP library (nrnerf_bender_divergence_*):
+    one forward-mode tangent through both MLPs instead of the reference's vector-Jacobian product with create_graph=True,
+    and a backward pass over the value and the tangent chain instead of autograd's double backward.  Gradients: the
+    per-point latent rows and the bender's parameters (the points are a leaf nobody reads in the reference)."""
+
+    @staticmethod
+    def forward(ctx, point_latents, model, rb, pts, e, *params):
+        M, dev = int(pts.shape[0]), pts.device
+        BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
+        RD, RW = len(rb.rigidity_network), int(rb.rigidity_network[0].weight.shape[0])
+        lat = point_latents.detach().to(torch.float32)
+        if lat.stride(-1) != 1 or (lat.stride(0) != 0 and lat.stride(0) < lat.shape[1]):
+            lat = lat.contiguous()
+        pts = pts.detach().to(torch.float32).contiguous()
+        e = e.detach().to(torch.float32).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        div = torch.empty(M, **f32)
+        off4, toff4 = torch.empty(M, 4, **f32), torch.empty(M, 4, **f32)
+        acts_b, tacts_b = torch.empty(BD - 1, M, BW, **f32), torch.empty(BD - 1, M, BW, **f32)
+        acts_r, tacts_r = torch.empty(RD - 1, M, RW, **f32), torch.empty(RD - 1, M, RW, **f32)
+        a = _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_divergence_forward")
+        ctx.model, ctx.rb, ctx.dims = model, rb, (M, BD, BW, RD, RW)
+        ctx.save_for_backward(pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
+        return div
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_div):
+        pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r = ctx.saved_tensors
+        model, rb = ctx.model, ctx.rb
+        M, BD, BW, RD, RW = ctx.dims
+        dev, LAT = pts.device, int(lat.shape[1])
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = g_div.contiguous().float()
+        dz_b, dtz_b, dz_r, dtz_r = torch.empty_like(acts_b), torch.empty_like(acts_b), torch.empty_like(acts_r), torch.empty_like(acts_r)
+        dz_out4, dtz_out4 = torch.empty(M, 4, **f32), torch.empty(M, 4, **f32)
+        d_lat = torch.empty(M, LAT, **f32)
+        nparts = 4 * max(1, min(_num_cus(dev), (M + 1023) // 1024))
+        nj = BD + RD + 1
+        parts = torch.empty(nparts, nj, _lib.BENDER_WGRAD_SLOT, **f32)
+        a = _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
+        a.g_divergence = g.data_ptr()
+        a.dz_offsets, a.dtz_offsets, a.dz_rigidity, a.dtz_rigidity = dz_b.data_ptr(), dtz_b.data_ptr(), dz_r.data_ptr(), dtz_r.data_ptr()
+        a.dz_out4, a.dtz_out4, a.d_latents = dz_out4.data_ptr(), dtz_out4.data_ptr(), d_lat.data_ptr()
+        a.n_partials, a.partials = nparts, parts.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_bender_divergence_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_divergence_backward")
+        tot = parts.sum(0)                                                                   # [jobs, 64*64 + 64]
+        dW, dB = tot[:, :4096].view(nj, 64, 64), tot[:, 4096:]
+        grads = []
+        for k, lin in enumerate(list(rb.network) + list(rb.rigidity_network)):
+            o, i_ = int(lin.weight.shape[0]), int(lin.weight.shape[1])
+            if k == 0:                                  # jobs 0 / 1: the point's and the latent code's columns of network[0]
+                grads.append(torch.cat([dW[0, :o, :3], dW[1, :o, :i_ - 3]], 1))
+                job = 0
+            else:
+                job = k + 1
+                grads.append(dW[job, :o, :i_])
+            if lin.bias is not None:
+                grads.append(dB[job, :o])
+        return (d_lat, None, None, None, None, *grads)
+
+
+def _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r):
+    a = _lib.DivergenceArgs()
+    a.struct_size = C.sizeof(_lib.DivergenceArgs)
+    a.n_points = int(pts.shape[0])
+    a.points, a.latents, a.latent_stride, a.probe = pts.data_ptr(), lat.data_ptr(), int(lat.stride(0)), e.data_ptr()
+    cutoff, scaling = getattr(rb, "rigidity_test_time_cutoff", None), getattr(rb, "test_time_scaling", None)
+    if cutoff is not None:
+        a.has_rigidity_cutoff, a.rigidity_cutoff = 1, float(cutoff)
+    if scaling is not None:
+        a.has_test_time_scaling, a.test_time_scaling = 1, float(scaling)
+    a.divergence, a.off4, a.toff4 = div.data_ptr(), off4.data_ptr(), toff4.data_ptr()
+    a.acts_offsets, a.tacts_offsets, a.acts_rigidity, a.tacts_rigidity = acts_b.data_ptr(), tacts_b.data_ptr(), acts_r.data_ptr(), tacts_r.data_ptr()
+    return a
+
+
+def why_no_native_divergence(ray_bender, input_points, point_latents):
+    """None when compute_divergence_loss runs on the HIP library."""
+    if ray_bender is None:
+        return "no ray bender"
+    if input_points.device.type != "cuda":
+        return "points are not on a ROCm device"
+    if input_points.dim() != 2 or input_points.shape[1] != 3 or point_latents.dim() != 2 or point_latents.shape[0] != input_points.shape[0]:
+        return "unexpected shapes"
+    if input_points.grad_fn is not None:
+        return "the points are part of an autograd graph"          # the reference would raise when it sets requires_grad
+    if R.model_of_bender(ray_bender, input_points.device) is None:
+        return "no packed model with training kernels for this ray bender (render through the HIP path first)"
+    return None
+
+
+def compute_divergence_loss(offsets_of_inputs, input_points, point_latents, ray_bender, exact, chunk, N_rays, weights=None,
+                            backprop_into_weights=True):
+    """Signature and semantics of reference ``compute_divergence_loss`` (run_nerf_helpers.py:22-69), what
+    training_wrapper_class.forward calls for the divergence regulariser (train.py:244-287): per point the (Hutchinson
+    estimate ``e^T J e`` of the, or with ``exact`` the exact) divergence of the masked offsets field, absolute value,
+    squared, weighted, mean per ray -> [N_rays].  ``offsets_of_inputs`` is unused, as in the reference (it re-evaluates the
+    bender on ``input_points``).  The probe vectors are drawn with the reference's own call per ``chunk`` of points
+    (``torch.randn_like`` on a [chunk, 3] tensor, rnh:106), so a seeded step consumes the generator like the reference."""
+    why = why_no_native_divergence(ray_bender, input_points, point_latents)
+    if why is not None:
+        ref = R._fallbacks.get("compute_divergence_loss")
+        if ref is None:
+            raise R.Unsupported(f"no HIP kernel for this divergence call ({why}) and no reference function installed to defer to")
+        return ref(offsets_of_inputs, input_points, point_latents, ray_bender, exact, chunk, N_rays, weights=weights,
+                   backprop_into_weights=backprop_into_weights)
+    input_points.requires_grad = True                                                        # rnh:39 (kept: callers may look at it)
+    model = R.model_of_bender(ray_bender, input_points.device)
+    M = int(input_points.shape[0])
+    pts = input_points.detach()
+    params = _bender_params(ray_bender)
+    if exact:                                            # divergence_exact (rnh:72-77): trace of J = sum_k unit_k^T J unit_k
+        div = None
+        for k in range(3):
+            e = torch.zeros(M, 3, dtype=torch.float32, device=pts.device)
+            e[:, k] = 1.0
+            d = _Divergence.apply(point_latents, model, ray_bender, pts, e, *params)
+            div = d if div is None else div + d
+    else:                                                # divergence_approx (rnh:103-113), one draw per chunk as in rnh:52-59
+        e = torch.cat([torch.randn_like(pts[i:i + chunk, :]) for i in range(0, M, int(chunk))], 0)
+        div = _Divergence.apply(point_latents, model, ray_bender, pts, e, *params)
+    divergence_loss = torch.abs(div)                                                         # rnh:61
+    divergence_loss = divergence_loss ** 2                                                   # rnh:62
+    if weights is not None:
+        if not backprop_into_weights:
+            weights = weights.detach()                                                       # rnh:65-66
+        divergence_loss = weights * divergence_loss                                          # rnh:67
+    return torch.mean(divergence_loss.view(N_rays, -1), dim=-1)                              # rnh:69
+
+
 def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp, pytest, ray_batch):
     """None when the native training path takes this call."""
     if pytest:
         return "pytest flag (numpy-seeded random numbers)"
     if ray_batch.device.type != "cuda":
         return "rays are not on a ROCm device"
+    if ray_batch.requires_grad:
+        # the kernels treat rays as data (sample positions carry no gradient): a caller who differentiates with respect to
+        # the rays (camera refinement) must get the reference's autograd graph, not a silently missing gradient
+        return "the ray batch requires a gradient"
     for net in (network_fn, network_fine if N_importance > 0 else None):
         if net is None:
             continue
@@ -489,6 +634,13 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     model = R.get_model(network_fn, network_fine if N_importance > 0 else None, precision=precision, device=dev)
     rays = ray_batch.detach().to(torch.float32).contiguous()
     N, S, I = int(rays.shape[0]), int(N_samples), int(N_importance)
+    if model.needs_latents:
+        # the kernels read latent_size floats per ray and write a [N * S, latent_size] gradient: a wrong shape would be an
+        # out-of-bounds access where the reference raises in expand / split (train.py:82-87, run_nerf_helpers.py:246)
+        if latents is None:
+            raise ValueError("ray_bending_latents are required with a ray bender")
+        if latents.dim() != 2 or tuple(latents.shape) != (N, model.latent_size):
+            raise ValueError(f"ray_bending_latents must have shape ({N}, {model.latent_size}), got {tuple(latents.shape)}")
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
     near, far = rays[:, 6:7], rays[:, 7:8]
     if I == 0 and detailed_output:
@@ -563,6 +715,47 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     if want_z_vals:
         ret["_z_vals"] = z_merged if I > 0 else z_vals          # not a reference key: the depths of the final pass
     return ret
+
+
+def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, offsets_loss_weight=0.0, divergence_loss_weight=0.0,
+                  rigidity_loss_weight=0.0, global_step=0, N_iters=200000, chunk=1024 * 32):
+    """The loss of one training iteration as ``training_wrapper_class.forward`` builds it (train.py:190-287), on the
+    drop-in entry points: ``batchify_rays`` (``retraw=True``; ``detailed_output`` when a regulariser is on, train.py:193-196),
+    data term on the fine and the coarse image (:207-218), offsets + rigidity regulariser (:221-242) and divergence
+    regulariser (:245-287, ``compute_divergence_loss``) with the increasing schedule.  Returns the per-ray loss [N_rays]
+    (the training loop takes ``loss.mean()``, train.py:1594) and the render outputs.  ``render_kwargs`` = the reference's
+    ``render_kwargs_train`` (network_fn, network_fine, N_samples, N_importance, perturb, raw_noise_std, ...).  A caller of
+    the reference does not need this function -- its own ``training_wrapper_class`` lands on the same entry points through
+    ``install()``; bench.py and the tests use it where the reference is not importable."""
+    N_rays = int(rays_flat.shape[0])
+    ray_bender = R._bender_of(render_kwargs["network_fn"])
+    detailed_output = offsets_loss_weight > 0.0 or divergence_loss_weight > 0.0                  # :193-196
+    kw = {k: v for k, v in render_kwargs.items() if k not in ("retraw", "ray_bender", "near", "far", "ndc", "use_viewdirs")}
+    extras = R.batchify_rays(rays_flat, {"ray_bending_latents": ray_bending_latents}, chunk=chunk, detailed_output=detailed_output,
+                             retraw=True, **kw)
+    img2mse = lambda x, y: torch.mean(((x - y) ** 2).view(N_rays, -1), dim=1)                    # rnh:10-13
+    loss = img2mse(extras["rgb_map"], target_s)                                                  # :207-212
+    if "rgb0" in extras:
+        loss = loss + img2mse(extras["rgb0"], target_s)                                          # :214-218
+    schedule = (1.0 / 100.0) ** (1 - (global_step / N_iters))                                    # :240, 285
+    if ray_bender is not None and offsets_loss_weight > 0.0:                                     # :221-242
+        weights = extras["visibility_weights"].detach().view(-1)
+        offsets_loss = torch.mean((weights * torch.pow(torch.norm(extras["unmasked_offsets"].view(-1, 3), dim=-1),
+                                                       2.0 - extras["rigidity_mask"].view(-1))).view(N_rays, -1), dim=-1)
+        offsets_loss = offsets_loss + rigidity_loss_weight * torch.mean((weights * extras["rigidity_mask"].view(-1)).view(N_rays, -1), dim=-1)
+        loss = loss + offsets_loss_weight * schedule * offsets_loss
+    if ray_bender is not None and divergence_loss_weight > 0.0:                                  # :245-287
+        initial_input_pts = extras["initial_input_pts"].view(-1, 3)
+        offsets = (extras["masked_offsets"] if "masked_offsets" in extras else extras["unmasked_offsets"]).view(-1, 3)
+        weights = extras["opacity_alpha"].view(-1)
+        n_samples = int(extras["initial_input_pts"].shape[1])
+        lat = ray_bending_latents
+        divergence_latents = lat.view(N_rays, 1, -1).expand((N_rays, n_samples, lat.shape[-1])).reshape(-1, lat.shape[-1])   # :256-262
+        weights = 1.0 - torch.exp(-F.relu(weights))                                              # :264
+        divergence_loss = compute_divergence_loss(offsets, initial_input_pts, divergence_latents, ray_bender, exact=False, chunk=chunk,
+                                                  N_rays=N_rays, weights=weights, backprop_into_weights=False)
+        loss = loss + divergence_loss_weight * schedule * divergence_loss
+    return loss, extras
 
 
 def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=1024, steps=30, warmup=5):

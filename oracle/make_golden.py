@@ -222,6 +222,63 @@ def run_gradients(H, T, seed=0):
     return out
 
 
+TRAIN_STEP = dict(n_rays=16, n_frames=4, seed=0, render_seed=4321, global_step=100000,
+                  # configs/example_sequence.txt:14-16, 22, 26-28, 35
+                  offsets_loss_weight=60.0, divergence_loss_weight=3.0, rigidity_loss_weight=0.0005, N_iters=200000,
+                  N_samples=64, N_importance=64, chunk=32768, raw_noise_std=1.0, perturb=1.0)
+# every parameter's gradient NORM is stored; these tensors (all of the bender, the codes, a few of each trunk) in full
+TRAIN_STEP_FULL = {"coarse": ["pts_linears.0.weight", "pts_linears.5.bias", "output_linear.weight"],
+                   "fine": ["pts_linears.7.weight", "pts_linears.0.bias", "output_linear.bias"]}
+
+
+def run_train_step(H, T):
+    """The REFERENCE's training iteration on CPU, unmodified: ``training_wrapper_class.forward`` (train.py:152-287) with
+    the shipped regulariser weights (configs/example_sequence.txt) -- render with detailed outputs, data term on both
+    images, offsets + rigidity regulariser, divergence regulariser (compute_divergence_loss, double backward through the
+    ray bender) -- then ``loss.mean().backward()`` as train.py:1594-1597 does.  Seeded right before the call."""
+    import argparse
+    ts = TRAIN_STEP
+    cfg = SceneConfig(N_importance=ts["N_importance"])
+    scene = make_scene(cfg, ts["seed"])
+    rays, _ = make_rays(ts["n_rays"], ts["seed"], cfg)
+    kw, rb, coarse, fine = reference_kwargs(H, T, scene)
+    kw.update(perturb=ts["perturb"], raw_noise_std=ts["raw_noise_std"])                      # train.py:698-719 (training kwargs)
+    g = torch.Generator().manual_seed(11)
+    codes = [(torch.randn(cfg.latent_size, generator=g) * 0.1).requires_grad_(True) for _ in range(ts["n_frames"])]
+    image_ids = torch.randint(0, ts["n_frames"], (ts["n_rays"],), generator=g)
+    target = torch.rand(ts["n_rays"], 3, generator=g)
+    args = argparse.Namespace(offsets_loss_weight=ts["offsets_loss_weight"], divergence_loss_weight=ts["divergence_loss_weight"],
+                              rigidity_loss_weight=ts["rigidity_loss_weight"], chunk=ts["chunk"], N_iters=ts["N_iters"],
+                              N_samples=ts["N_samples"], ray_bending_latent_size=cfg.latent_size)
+    wrapper = T.training_wrapper_class(coarse, codes, fine_model=fine, ray_bender=rb)
+    batch_pixel_indices = torch.stack([image_ids, torch.zeros_like(image_ids), torch.zeros_like(image_ids)], 1)
+    torch.manual_seed(ts["render_seed"])
+    loss = wrapper(args, rays[:, 0:3], rays[:, 3:6], 100, dict(kw), target, ts["global_step"], 0,
+                   {"imageid_to_timestepid": list(range(ts["n_frames"]))}, batch_pixel_indices)
+    assert tuple(loss.shape) == (ts["n_rays"],)
+    loss.mean().backward()                                                                    # train.py:1594-1597
+    # the same seeded call without the divergence term (its probes are the last random numbers drawn, so everything else
+    # sees the same draws): tells a reader how much of the loss the second-order term is
+    args0 = argparse.Namespace(**{**vars(args), "divergence_loss_weight": 0.0})
+    torch.manual_seed(ts["render_seed"])
+    with torch.no_grad():
+        loss0 = wrapper(args0, rays[:, 0:3], rays[:, 3:6], 100, dict(kw), target, ts["global_step"], 0,
+                        {"imageid_to_timestepid": list(range(ts["n_frames"]))}, batch_pixel_indices)
+    out = {"out__loss_per_ray": loss.detach().numpy().astype(np.float64), "out__loss_per_ray_without_divergence": loss0.numpy().astype(np.float64),
+           "in__rays": rays.numpy(),
+           "in__codes": torch.stack([c.detach() for c in codes]).numpy(), "in__image_ids": image_ids.numpy(), "in__target": target.numpy(),
+           "grad__codes": torch.stack([c.grad if c.grad is not None else torch.zeros_like(c) for c in codes]).numpy()}
+    for part, mod in (("bender", rb), ("coarse", coarse), ("fine", fine)):
+        for name, prm in mod.named_parameters():
+            if prm.grad is None:
+                continue
+            out[f"gradnorm__{part}__{name}"] = np.float64(prm.grad.double().norm())
+            if part == "bender" or name in TRAIN_STEP_FULL[part]:
+                out[f"grad__{part}__{name}"] = prm.grad.numpy()
+    out["meta_json"] = np.frombuffer(__import__("json").dumps(ts).encode(), dtype=np.uint8)
+    return out
+
+
 def run_render_path(H, T, seed=0):
     """Reference ``train.render_path`` (train.py:419-553) on two tiny frames with detailed outputs, and the per-pixel
     surface reduction free_viewpoint_rendering.py:621-658 performs on those outputs (the same torch ops, lifted: the
@@ -267,6 +324,10 @@ def main():
     if "--only-grads" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_64_64.npz"), **run_gradients(H, T))
         if "--only-grads" in sys.argv:
+            return
+    if "--only-train-step" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "train_step_64_64.npz"), **run_train_step(H, T))
+        if "--only-train-step" in sys.argv:
             return
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--case=")]
     if not only:

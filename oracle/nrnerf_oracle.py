@@ -287,6 +287,69 @@ def render_rays(ray_batch, latents, scene, *, retraw=False, detailed_output=Fals
     return ret
 
 
+def compute_divergence_loss(input_points, point_latents, bender, exact, chunk, n_rays, weights=None,
+                            backprop_into_weights=True, knobs: Knobs | None = None):
+    """compute_divergence_loss + divergence_approx / divergence_exact (run_nerf_helpers.py:22-116), through autograd with
+    create_graph=True exactly as the reference: per chunk of points, offsets = masked offsets of the bender evaluated on a
+    leaf copy of the points; approx: e = randn_like(offsets), e . (J^T e); exact: trace of the Jacobian built row by row."""
+    input_points = input_points.detach().requires_grad_(True)                      # :39
+    parts = []
+    for i in range(0, input_points.shape[0], chunk):                               # :52-59
+        sub = input_points[i:i + chunk, :]
+        _, details = bend_points(sub, point_latents[i:i + chunk, :], bender, knobs)    # :42 (special_loss_return)
+        offsets = details["masked_offsets"]                                        # :43-47
+        if exact:
+            rows = []
+            for j in range(offsets.shape[1]):                                      # _get_minibatch_jacobian, :81-104
+                rows.append(torch.autograd.grad(offsets[:, j], sub, torch.ones_like(offsets[:, j]), retain_graph=True,
+                                                create_graph=True)[0].view(sub.shape[0], -1).unsqueeze(1))
+            jac = torch.cat(rows, 1)
+            parts.append(torch.sum(jac.view(jac.shape[0], -1)[:, ::(jac.shape[1] + 1)], 1))    # :72-77
+        else:
+            e = torch.randn_like(offsets)                                          # :106
+            e_dydx = torch.autograd.grad(offsets, sub, e, create_graph=True)[0]    # :107-109
+            parts.append((e_dydx * e).view(offsets.shape[0], -1).sum(dim=1))       # :110-112
+    divergence_loss = torch.cat(parts, 0)
+    divergence_loss = torch.abs(divergence_loss) ** 2                              # :61-62
+    if weights is not None:
+        if not backprop_into_weights:
+            weights = weights.detach()                                             # :65-66
+        divergence_loss = weights * divergence_loss                                # :67
+    return torch.mean(divergence_loss.view(n_rays, -1), dim=-1)                    # :69
+
+
+def training_loss(ray_batch, latents, scene, target_s, *, offsets_loss_weight=0.0, divergence_loss_weight=0.0,
+                  rigidity_loss_weight=0.0, global_step=0, n_iters=200000, chunk=1024 * 32, perturb=1.0, raw_noise_std=1.0,
+                  z_fine_override=None):
+    """training_wrapper_class.forward (train.py:152-287) for one ray batch: render with retraw (and detailed outputs when a
+    regulariser is on), data term on the fine and the coarse image, offsets + rigidity regulariser, divergence regulariser,
+    both with the reference's increasing schedule.  Returns the per-ray loss [N_rays] (the caller takes the mean,
+    train.py:1594) and the render outputs.  Random numbers are drawn in the reference's order: render's, then the probes."""
+    n_rays = ray_batch.shape[0]
+    img2mse = lambda x, y: torch.mean((x - y) ** 2, dim=-1)                        # rnh: img2mse(x, y, N_rays) -> [N_rays]
+    detailed = offsets_loss_weight > 0.0 or divergence_loss_weight > 0.0           # :193-196
+    out = render_rays(ray_batch, latents, scene, retraw=True, detailed_output=detailed, perturb=perturb,
+                      raw_noise_std=raw_noise_std, z_fine_override=z_fine_override)
+    loss = img2mse(out["rgb_map"], target_s)                                       # :210-212
+    if "rgb0" in out:
+        loss = loss + img2mse(out["rgb0"], target_s)                               # :215-218
+    schedule = (1.0 / 100.0) ** (1 - (global_step / n_iters))                      # :240, 285
+    if scene.bender is not None and offsets_loss_weight > 0.0:                     # :221-242
+        weights = out["visibility_weights"].detach().reshape(-1)
+        offsets_loss = torch.mean((weights * torch.pow(torch.norm(out["unmasked_offsets"].reshape(-1, 3), dim=-1),
+                                                       2.0 - out["rigidity_mask"].reshape(-1))).view(n_rays, -1), dim=-1)
+        offsets_loss = offsets_loss + rigidity_loss_weight * torch.mean((weights * out["rigidity_mask"].reshape(-1)).view(n_rays, -1), dim=-1)
+        loss = loss + offsets_loss_weight * schedule * offsets_loss
+    if scene.bender is not None and divergence_loss_weight > 0.0:                  # :245-287
+        pts = out["initial_input_pts"].reshape(-1, 3)
+        weights = 1.0 - torch.exp(-F.relu(out["opacity_alpha"].reshape(-1)))       # :264 (sic: of the alphas)
+        n_samples = out["initial_input_pts"].shape[1]
+        lat = latents.view(n_rays, 1, -1).expand(n_rays, n_samples, latents.shape[-1]).reshape(-1, latents.shape[-1])   # :256-262
+        div = compute_divergence_loss(pts, lat, scene.bender, False, chunk, n_rays, weights=weights, backprop_into_weights=False)
+        loss = loss + divergence_loss_weight * schedule * div
+    return loss, out
+
+
 def scene_on(scene, device):
     """A shallow copy of ``scene`` with the weight arrays on ``device`` (the oracle is device-agnostic torch code: on a
     ROCm device it is "the reference's eager ops on the GPU", a second baseline; never the product path)."""

@@ -256,6 +256,56 @@ def test_data_parallel_training_gradients_world_size_2(tmp_path):
                     assert torch.allclose(got[k], g, rtol=1e-4, atol=1e-5 * float(g.abs().max()) + 1e-12), k
 
 
+def _identity_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nonrigid_nerf_amd.distributed import GradientBuckets
+    a, b, c = (torch.full((3,), float(k + 1), requires_grad=True) for k in range(3))
+    gb = GradientBuckets([[a, b, c]])
+    log = []
+    # steps 1, 2: only a and b take part -> the first step reduces in finish(), the second launches from inside backward
+    for _ in range(2):
+        gb.zero_grad()
+        ((a * (rank + 1)).sum() + (b * 2).sum()).backward()
+        log.append(gb.pending[0] is not None)
+        gb.finish()
+        assert torch.allclose(a.grad, torch.full((3,), 1.5)) and torch.allclose(b.grad, torch.full((3,), 2.0))
+    # step 3: a DIFFERENT pair (a, c) of the same size: counting arrivals would launch after two gradients with b's slot
+    # stale-zero and c's possibly missing; by identity the bucket waits (b never comes) and is reduced in finish()
+    gb.zero_grad()
+    ((a * (rank + 1)).sum() + (c * 4).sum()).backward()
+    log.append(gb.pending[0] is not None)
+    gb.finish()
+    assert torch.allclose(a.grad, torch.full((3,), 1.5)) and torch.allclose(c.grad, torch.full((3,), 4.0)) and float(b.grad.abs().sum()) == 0
+    # step 4: all three, c produced AFTER the expected set {a, c} ... order of arrival is autograd's; a superset never
+    # launches early on a subset it was not told about: expected is now {a, c}, b is extra
+    gb.zero_grad()
+    try:
+        ((a * (rank + 1)).sum() + (c * 4).sum() + (b * 2).sum()).backward()
+        gb.finish()
+        late = False
+    except RuntimeError as e:
+        late = "arrived after" in str(e)
+    if late:                                     # the documented recovery: expectations were reset, repeat the step
+        gb.zero_grad()
+        ((a * (rank + 1)).sum() + (c * 4).sum() + (b * 2).sum()).backward()
+        gb.finish()
+    assert torch.allclose(a.grad, torch.full((3,), 1.5)) and torch.allclose(b.grad, torch.full((3,), 2.0)) and torch.allclose(c.grad, torch.full((3,), 4.0))
+    gb.close()
+    torch.save(log, os.path.join(out_dir, f"log{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_track_parameters_by_identity(tmp_path):
+    """A step that produces gradients for a different set of parameters than the previous one (a regulariser switched
+    on, another head) must not launch a bucket's all-reduce after "the first k arrivals": the bucket waits for the exact
+    parameters it expects, reduces in finish() when they do not all come, and never hands out a silently wrong mean."""
+    mp.spawn(_identity_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        log = torch.load(os.path.join(str(tmp_path), f"log{r}.pt"))
+        assert log == [False, True, False], log
+
+
 def _native_train_grads(lo, hi, n, gb_factory=None):
     """One native training step's gradients (HIP path, fp32 mode) on rays [lo, hi) of a fixed n-ray batch."""
     from nonrigid_nerf_amd import render as R

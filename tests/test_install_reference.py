@@ -113,3 +113,152 @@ def test_real_reference_modules_render_through_the_hip_path_on_a_gpu(reference):
         finally:
             undo()
             T.render_rays = orig_rr
+
+
+def _to_device(H, T, G, scene, dev):
+    kw, rb, coarse, fine = G.reference_kwargs(H, T, scene)
+    for m in (rb, coarse, fine):
+        if m is not None:
+            m.to(dev)
+    return kw, rb, coarse, fine
+
+
+class _Spy:
+    """Counts the calls that reach a saved reference function (what install() keeps as the fallback)."""
+
+    def __init__(self, module, name):
+        self.module, self.name, self.orig, self.calls = module, name, getattr(module, name), 0
+        setattr(module, name, self)
+
+    def __call__(self, *a, **k):
+        self.calls += 1
+        return self.orig(*a, **k)
+
+    def restore(self):
+        setattr(self.module, self.name, self.orig)
+
+
+@pytest.mark.gpu
+def test_reference_render_path_and_dataparallel_wrapper_run_on_the_hip_path(reference):
+    """(a) the reference's own frame driver ``train.render_path`` (train.py:419-553) with ``detailed_output=True`` -- what
+    free_viewpoint_rendering.py runs by default -- and (b) the reference's ``render_wrapper_class`` under
+    ``nn.DataParallel`` (``get_parallelized_render_function``, train.py:300-323: the bender tuple is re-attached inside
+    ``forward``), both after ``install(train)`` with the reference's REAL modules on the GPU.  Every render call must be
+    taken by the HIP path (the saved reference ``render_rays`` is never reached) and reproduce the committed outputs of
+    the reference (tests/golden/render_path_2frames.npz)."""
+    import numpy as np
+    from nonrigid_nerf_amd import render as R
+    from nonrigid_nerf_amd.synthetic import SceneConfig, make_scene
+    from tests.helpers import GOLDEN_DIR, synthetic_camera
+    G, H, T = reference
+    dev = torch.device("cuda:0")
+    T.device = dev
+    z = np.load(os.path.join(GOLDEN_DIR, "render_path_2frames.npz"))
+    scene = make_scene(SceneConfig(N_importance=64), 0)
+    kw, rb, coarse, fine = _to_device(H, T, G, scene, dev)
+    cams = [synthetic_camera(k, H=8, W=12) for k in range(2)]
+    poses, intrins = [c.to(dev) for c, _ in cams], [i for _, i in cams]
+    codes = torch.from_numpy(z["in__codes"]).to(dev)
+    spy = _Spy(T, "render_rays")
+    undo = R.install(T)                                    # no precision given: the drop-in must stay fp32
+    try:
+        assert R.get_precision() == "f32"
+        with torch.no_grad():
+            rgbs, disps, details = T.render_path(poses, intrins, 32768, kw, codes, detailed_output=True)
+            par = T.get_parallelized_render_function(coarse_model=coarse, fine_model=fine, ray_bender=rb)
+            kw_par = {k: v for k, v in kw.items() if k not in ("network_fn", "network_fine", "ray_bender")}
+            rgbs2, disps2, _ = T.render_path(poses, intrins, 32768, kw_par, codes, detailed_output=False, parallelized_render_function=par)
+        assert spy.calls == 0, "a call fell back to the reference's render_rays instead of the HIP path"
+    finally:
+        undo()
+        spy.restore()
+    for got_rgb, got_disp in ((rgbs, disps), (rgbs2, disps2)):
+        assert np.allclose(got_rgb, z["out__rgbs"], atol=1e-4)
+        d, dr = np.asarray(got_disp), z["out__disps"]
+        assert ((np.isnan(d) & np.isnan(dr)) | (np.abs(d - dr) <= 1e-4 + 1e-3 * np.abs(dr))).mean() >= 0.97
+    assert len(details) == 2
+    per_pass = ("visibility_weights", "opacity_alpha", "initial_input_pts", "unmasked_offsets", "masked_offsets", "input_pts", "rigidity_mask")
+    assert set(details[0]) == {"rgb0", "disp0", "acc0", "z_std"} | set(per_pass) | {"fine_" + k for k in per_pass}      # train.py:955-972
+    for k in ("fine_visibility_weights", "fine_input_pts", "fine_rigidity_mask"):
+        want = z["out__" + k + "_0"]
+        got = details[0][k].reshape(want.shape)
+        close = np.isclose(got, want, atol=2e-4, rtol=1e-3)
+        assert close.mean() >= 0.97, (k, close.mean())               # a few rays take the other sample_pdf branch (DESIGN section 2)
+
+
+@pytest.mark.gpu
+def test_reference_training_iteration_runs_natively_after_install(reference, capsys):
+    """(c) one iteration of the reference's ``training_wrapper_class.forward`` + ``backward`` (train.py:152-287, 1594-1597)
+    with the shipped loss weights (configs/example_sequence.txt: offsets 60, divergence 3, rigidity 5e-4, 64 + 64 samples,
+    perturb, raw noise 1), on the reference's REAL modules on the GPU: once eagerly (the unmodified reference on this
+    device) and once after ``install(train, precision="f32")``.  After install no call may reach the reference's
+    ``render_rays`` or ``compute_divergence_loss`` -- the whole iteration, second-order term included, is native -- and
+    with the same seed the loss and every parameter gradient must agree with the eager run."""
+    import argparse
+    from nonrigid_nerf_amd import render as R
+    G, H, T = reference
+    dev = torch.device("cuda:0")
+    T.device = dev
+    ts = G.TRAIN_STEP
+    n_rays = 1024                                             # N_rand of the shipped config
+    from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
+    cfg = SceneConfig(N_importance=ts["N_importance"])
+    scene = make_scene(cfg, ts["seed"])
+    rays, _ = make_rays(n_rays, ts["seed"], cfg)
+    g = torch.Generator().manual_seed(11)
+    codes0 = torch.randn(ts["n_frames"], cfg.latent_size, generator=g) * 0.1
+    image_ids = torch.randint(0, ts["n_frames"], (n_rays,), generator=g)
+    target = torch.rand(n_rays, 3, generator=g).to(dev)
+    args = argparse.Namespace(offsets_loss_weight=ts["offsets_loss_weight"], divergence_loss_weight=ts["divergence_loss_weight"],
+                              rigidity_loss_weight=ts["rigidity_loss_weight"], chunk=ts["chunk"], N_iters=ts["N_iters"],
+                              N_samples=ts["N_samples"], ray_bending_latent_size=cfg.latent_size)
+    bpi = torch.stack([image_ids, torch.zeros_like(image_ids), torch.zeros_like(image_ids)], 1)
+
+    def one_step(installed):
+        kw, rb, coarse, fine = _to_device(H, T, G, scene, dev)
+        kw.update(perturb=ts["perturb"], raw_noise_std=ts["raw_noise_std"])
+        codes = [c.clone().to(dev).requires_grad_(True) for c in codes0]
+        wrapper = T.training_wrapper_class(coarse, codes, fine_model=fine, ray_bender=rb)
+        spies, undo = [], None
+        if installed:
+            spies = [_Spy(T, "render_rays"), _Spy(T, "compute_divergence_loss")]
+            undo = R.install(T, precision="f32")
+            assert T.compute_divergence_loss is not spies[1]
+        try:
+            torch.manual_seed(ts["render_seed"])
+            loss = wrapper(args, rays[:, 0:3].to(dev), rays[:, 3:6].to(dev), 100, dict(kw), target, ts["global_step"], 0,
+                           {"imageid_to_timestepid": list(range(ts["n_frames"]))}, bpi)
+            loss.mean().backward()
+            torch.cuda.synchronize()
+            reached = [s.calls for s in spies]
+        finally:
+            if undo is not None:
+                undo()
+            for s in spies:
+                s.restore()
+        grads = {("codes", str(i)): c.grad for i, c in enumerate(codes)}
+        for part, mod in (("bender", rb), ("coarse", coarse), ("fine", fine)):
+            grads.update({(part, k): p.grad for k, p in mod.named_parameters() if p.grad is not None})
+        return loss.detach(), grads, reached
+
+    l_ref, g_ref, _ = one_step(False)
+    l_hip, g_hip, reached = one_step(True)
+    assert reached == [0, 0], f"calls that reached the reference's render_rays / compute_divergence_loss: {reached}"
+    assert set(g_hip) == set(g_ref), set(g_hip) ^ set(g_ref)
+    # a few rays take the other `denom < 1e-5` branch of sample_pdf (DESIGN section 2): per-ray loss with outliers, mean tight
+    rel = (l_hip - l_ref).abs() / (l_ref.abs() + 1e-6)
+    assert float((rel < 1e-3).float().mean()) >= 0.9, float((rel < 1e-3).float().mean())
+    assert abs(float(l_hip.mean()) - float(l_ref.mean())) <= 2e-3 * abs(float(l_ref.mean()))
+    rows = []
+    for k, gr in g_ref.items():
+        gh = g_hip[k]
+        cos = float((gh * gr).sum() / (gh.norm() * gr.norm() + 1e-30))
+        err = float((gh - gr).abs().max() / (gr.abs().max() + 1e-30))
+        rows.append((err, cos, k))
+        assert cos >= 0.99, (k, cos, err)
+    rows.sort(reverse=True)
+    with capsys.disabled():
+        print(f"\n[reference training iteration, {n_rays} rays, real modules] mean loss eager {float(l_ref.mean()):.6f} vs installed "
+              f"{float(l_hip.mean()):.6f}; per-ray loss within 1e-3: {float((rel < 1e-3).float().mean()):.3f}; calls reaching the reference's "
+              f"render_rays / compute_divergence_loss after install: {reached}; {len(rows)} gradient tensors, min cosine "
+              f"{min(c for _, c, _ in rows):.5f}; largest max-error / scale: " + "; ".join(f"{k[0]}.{k[1]} {e:.1e} (cos {c:.5f})" for e, c, k in rows[:6]))

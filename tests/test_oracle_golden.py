@@ -147,3 +147,74 @@ def test_oracle_render_path_and_surface_reduction_match_the_reference():
         assert same.float().mean() >= 0.97
         assert torch.allclose(pts.reshape(8, 12, 3)[same], torch.from_numpy(z[f"out__surface_pixels_{f}"])[same], atol=1e-5)
         assert torch.allclose(rig.reshape(8, 12)[same], torch.from_numpy(z[f"out__rigidity_{f}"])[same], atol=1e-5)
+
+
+def load_train_step_golden():
+    """tests/golden/train_step_64_64.npz (oracle/make_golden.py::run_train_step: the reference's training_wrapper_class.forward
+    + backward on CPU, shipped regulariser weights) -> (meta, scene, rays, codes, image_ids, target, npz)."""
+    import json
+    import os
+    import numpy as np
+    from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
+    from tests.helpers import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "train_step_64_64.npz"))
+    ts = json.loads(bytes(z["meta_json"]).decode())
+    cfg = SceneConfig(N_importance=ts["N_importance"])
+    scene = make_scene(cfg, ts["seed"])
+    rays, _ = make_rays(ts["n_rays"], ts["seed"], cfg)
+    assert np.array_equal(rays.numpy(), z["in__rays"]), "synthetic ray generator drifted from the golden fixture"
+    return ts, scene, rays, torch.from_numpy(z["in__codes"]), torch.from_numpy(z["in__image_ids"]), torch.from_numpy(z["in__target"]), z
+
+
+def oracle_train_step(ts, scene, rays, codes, image_ids, target, device="cpu", z_fine_override=None, divergence=True):
+    """The oracle's restatement of the reference's training iteration, seeded like the golden: (per-ray loss, gradient
+    dict keyed like the fixture, render outputs)."""
+    sc = O.scene_on(scene, device)
+    leaves = {}
+    for part in ("bender", "coarse", "fine"):
+        d = getattr(sc, part)
+        for k in d:
+            d[k] = d[k].clone().requires_grad_(True)
+            leaves[(part, k)] = d[k]
+    codes = codes.to(device).clone().requires_grad_(True)
+    lat = codes[image_ids.to(device)]                                                # train.py:183-186
+    torch.manual_seed(ts["render_seed"])
+    loss, out = O.training_loss(rays.to(device), lat, sc, target.to(device), offsets_loss_weight=ts["offsets_loss_weight"],
+                                divergence_loss_weight=ts["divergence_loss_weight"] if divergence else 0.0,
+                                rigidity_loss_weight=ts["rigidity_loss_weight"], global_step=ts["global_step"], n_iters=ts["N_iters"],
+                                chunk=ts["chunk"], perturb=ts["perturb"], raw_noise_std=ts["raw_noise_std"], z_fine_override=z_fine_override)
+    loss.mean().backward()
+    grads = {("codes", ""): codes.grad}
+    grads.update({k: v.grad for k, v in leaves.items() if v.grad is not None})
+    return loss.detach(), grads, out
+
+
+def test_oracle_training_iteration_matches_the_reference():
+    """``O.training_loss`` (data term + offsets / rigidity regulariser + divergence regulariser with its double backward,
+    the reference's draw order) against the REFERENCE's ``training_wrapper_class.forward`` + ``backward`` on CPU: per-ray
+    loss, the loss without the divergence term, every stored gradient tensor and every parameter's gradient norm."""
+    ts, scene, rays, codes, image_ids, target, z = load_train_step_golden()
+    loss, grads, _ = oracle_train_step(ts, scene, rays, codes, image_ids, target)
+    want = torch.from_numpy(z["out__loss_per_ray"])
+    assert float((loss.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    loss0, _, _ = oracle_train_step(ts, scene, rays, codes, image_ids, target, divergence=False)
+    want0 = torch.from_numpy(z["out__loss_per_ray_without_divergence"])
+    assert float((loss0.double() - want0).abs().max()) <= 2e-6 * float(want0.abs().max())
+    # the divergence term itself (difference of the two, ~1e-4 of the loss on this scene): relative to its own size
+    dterm, dwant = loss.double() - loss0.double(), want - want0
+    assert float((dterm - dwant).abs().max()) <= 2e-2 * float(dwant.abs().max())
+    n = 0
+    for key in z.files:
+        if key.startswith("grad__"):
+            _, part, *name = key.split("__", 2)
+            g = grads[(part, name[0] if name else "")]
+            w = torch.from_numpy(z[key])
+            scale = float(w.abs().max()) + 1e-12
+            assert g.shape == w.shape, key
+            assert float((g - w).abs().max()) <= 2e-3 * scale, (key, float((g - w).abs().max()), scale)
+            n += 1
+        elif key.startswith("gradnorm__"):
+            _, part, name = key.split("__", 2)
+            assert abs(float(grads[(part, name)].double().norm()) - float(z[key])) <= 2e-3 * float(z[key]) + 1e-12, key
+            n += 1
+    assert n > 60

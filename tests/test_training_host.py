@@ -67,7 +67,14 @@ def test_eligibility_of_training_calls():
     class OnGpu:
         """a stand-in whose .device says cuda: the remaining checks only read module attributes"""
         device = torch.device("cuda", 0)
+        requires_grad = False
 
+    class OnGpuWithGrad(OnGpu):
+        requires_grad = True
+
+    # rays that require a gradient (camera refinement): the kernels treat rays as data, so such a call must reach the
+    # reference's autograd graph instead of coming back with a silently missing gradient
+    assert "requires a gradient" in T.why_not_trainable(coarse, fine, 64, 64, False, False, OnGpuWithGrad)
     assert "view-dependent" in T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu)
     assert T.why_not_trainable(coarse, fine, 64, 64, True, False, OnGpu) is None                  # lindisp trains natively
     assert T.why_not_trainable(coarse, fine, 64, 64, False, True, OnGpu).startswith("pytest flag")
