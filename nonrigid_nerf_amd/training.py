@@ -758,18 +758,16 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     return loss, extras
 
 
-def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=1024, steps=30, warmup=5):
-    """bench.py's ``train_step`` leg: the reference's training iteration (train.py:1543-1642) at its batch size -- 1024
-    rays, 64 + N_importance samples, perturb = 1, raw_noise_std = 1 -- forward + backward + Adam step (+ the device-side
-    weight refresh the next forward needs) through the drop-in boundary.  Returns rays/s and the share of the step spent
-    in the native kernels."""
-    import time
+# configs/example_sequence.txt:14-16, 26-28, 35 -- the recipe the reference ships
+SHIPPED_RECIPE = dict(N_samples=64, N_importance=64, N_rand=1024, perturb=1.0, raw_noise_std=1.0, offsets_loss_weight=60.0,
+                      divergence_loss_weight=3.0, rigidity_loss_weight=0.0005, N_iters=200000, chunk=32768)
 
+
+def _fresh_training_modules(cfg, dev, n_importance):
+    """Modules at the reference's initialisation (create_nerf train.py:595-630; ray_bending.__init__ rnh:436-455, 487-505:
+    kaiming hidden layers, zero biases, zero last layers) -- the synthetic stress weights of the inference benchmark would
+    die (sigma < 0 everywhere, zero gradients) after one Adam step."""
     from .modules import NeRFWeights, RayBenderWeights
-    from .synthetic import make_rays
-    # a model at the reference's initialisation (create_nerf train.py:595-630; ray_bending.__init__ rnh:436-455, 487-505:
-    # kaiming hidden layers, zero biases, zero last layers) -- the synthetic stress weights of the inference benchmark
-    # would die (sigma < 0 everywhere, zero gradients) after one Adam step
     rb = RayBenderWeights(cfg.latent_size, cfg.bend_hidden, cfg.bend_depth, cfg.rigidity_hidden, cfg.rigidity_depth) if cfg.ray_bending else None
     if rb is not None:
         with torch.no_grad():
@@ -780,39 +778,53 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=1024, steps=30, w
                 net[-1].weight.zero_()
                 if net[-1].bias is not None:
                     net[-1].bias.zero_()
-    mk = lambda ns: NeRFWeights(D=cfg.netdepth, W=cfg.netwidth, input_ch=cfg.input_ch, output_ch=cfg.output_ch, skips=cfg.skips,
+    out_ch = 5 if n_importance > 0 else 4                                                   # train.py:593
+    mk = lambda ns: NeRFWeights(D=cfg.netdepth, W=cfg.netwidth, input_ch=cfg.input_ch, output_ch=out_ch, skips=cfg.skips,
                                 ray_bending_latent_size=cfg.latent_size, num_ray_samples=ns)
-    coarse, fine = mk(cfg.N_samples), (mk(cfg.N_samples + cfg.N_importance) if cfg.N_importance > 0 else None)
+    coarse, fine = mk(cfg.N_samples), (mk(cfg.N_samples + n_importance) if n_importance > 0 else None)
     for m in (rb, coarse, fine):
         if m is not None:
             m.to(dev)
     coarse.ray_bender = (rb,)
     if fine is not None:
         fine.ray_bender = (rb,)
+    return rb, coarse, fine
+
+
+def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, regularised, graph=False):
+    import time
+
+    from .synthetic import make_rays
+    rec = SHIPPED_RECIPE
+    rb, coarse, fine = _fresh_training_modules(cfg, dev, n_importance)
     params = []
     for m in (rb, coarse, fine):
         if m is not None:
             m.requires_grad_(True)
             params += list(m.parameters())
     codes = torch.zeros(8, cfg.latent_size, device=dev, requires_grad=True)
-    opt = torch.optim.Adam(params + [codes], lr=5e-4, betas=(0.9, 0.999), fused=True)     # train.py:655-658 (one fused update kernel)
+    opt = torch.optim.Adam(params + [codes], lr=5e-4, betas=(0.9, 0.999), fused=True, capturable=bool(graph))   # train.py:655-658
     rays, _ = make_rays(n_rays, 5, cfg)
     rays = rays.to(dev)
     frame = torch.randint(0, 8, (n_rays,), device=dev)
     target = 0.5 + 0.4 * torch.sin(3.0 * rays[:, 3:6])                     # a smooth colour field of the ray direction
-    prev = R.get_precision()
-    R.set_precision(precision)
-    kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples, N_importance=cfg.N_importance,
-              perturb=1.0, raw_noise_std=1.0, retraw=True)
+    kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples, N_importance=n_importance,
+              perturb=rec["perturb"], raw_noise_std=rec["raw_noise_std"])
+    weights = dict(offsets_loss_weight=rec["offsets_loss_weight"], divergence_loss_weight=rec["divergence_loss_weight"],
+                   rigidity_loss_weight=rec["rigidity_loss_weight"]) if (regularised and rb is not None) else {}
+    state = {"i": 0}
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out = R.batchify_rays(rays, {"ray_bending_latents": codes[frame]}, chunk=32768, **kw)
-        loss = ((out["rgb_map"] - target) ** 2).mean() + ((out["rgb0"] - target) ** 2).mean()   # train.py:207-217
+        loss, _ = training_loss(rays, codes[frame], target, kw, global_step=state["i"], N_iters=rec["N_iters"], chunk=rec["chunk"], **weights)
+        loss = loss.mean()                                                  # train.py:1594
         loss.backward()
         opt.step()
+        state["i"] += 1
         return loss
 
+    prev = R.get_precision()
+    R.set_precision(precision)
     try:
         with torch.enable_grad():
             for _ in range(warmup):
@@ -825,14 +837,50 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=1024, steps=30, w
             dt = (time.perf_counter() - t0) / steps
     finally:
         R.set_precision(prev)
-    samples = n_rays * (2 * cfg.N_samples + cfg.N_importance)              # coarse pass + fine pass network evaluations
-    trunk_macs = 63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256 + 256 * cfg.output_ch
-    flops = 3.0 * 2.0 * trunk_macs * samples                                # forward + backward-data + backward-weights
+    return dt, float(loss.detach())
+
+
+def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=None, steps=30, warmup=5):
+    """bench.py's ``train_step`` leg: the reference's training iteration (train.py:1543-1642) with the recipe it ships
+    (configs/example_sequence.txt): N_rand = 1024 rays, 64 + 64 samples, perturb, raw_noise_std = 1, detailed outputs, loss =
+    data term (fine + coarse) + 60 x offsets / rigidity regulariser + 3 x divergence regulariser (increasing schedule), then
+    backward, Adam step and the device-side weight refresh the next forward needs -- everything through the drop-in entry
+    points (training_loss: batchify_rays under autograd, compute_divergence_loss), no eager reference-module call.
+    ``data_term_only`` is last round's lighter step (64 + 128 samples, data term only) for continuity."""
+    rec = SHIPPED_RECIPE
+    n_rays = n_rays or rec["N_rand"]
+    dt, final = _time_training(cfg, dev, precision, n_rays, rec["N_importance"], steps, warmup, regularised=True)
+    dt0, final0 = _time_training(cfg, dev, precision, n_rays, 128, steps, warmup, regularised=False)
     peak = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}[precision]
+    S, I = cfg.N_samples, rec["N_importance"]
+
+    def roof(dt_, n_imp, with_div):
+        samples = n_rays * (2 * S + n_imp)                                  # coarse pass + fine pass network evaluations
+        trunk_macs = 63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256 + 256 * 5       # SURVEY.md section 8d
+        bend_macs = 15872                                                   # offset + rigidity MLPs, SURVEY.md section 8d
+        flops = 3.0 * 2.0 * (trunk_macs + (bend_macs if cfg.ray_bending else 0)) * samples   # forward + backward-data + backward-weights
+        if with_div and cfg.ray_bending:
+            flops += 2.0 * 3.0 * 2.0 * bend_macs * n_rays * S               # value + tangent chain of the divergence term
+        # HBM bytes the designed dataflow must move per sample: every hidden activation and every pre-activation gradient
+        # written once and read once by the weight-gradient kernels (bf16 mode 2 B, fp32 mode 4 B per value), the bender's
+        # arrays in fp32
+        eb = 4 if precision == "f32" else 2
+        per_sample = 4 * 8 * 256 * eb + (4 * (4 * 64 + 2 * 32) * 4 if cfg.ray_bending else 0)
+        hbm = per_sample * samples
+        return {"mfma": {"achieved": round(flops / dt_ / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / dt_ / 1e12 / peak, 4)},
+                "hbm": {"achieved": round(hbm / dt_ / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm / dt_ / 8e12, 4),
+                        "bytes_per_sample_by_design": per_sample}}
+    r = roof(dt, I, True)
     return {"rays_per_s": round(n_rays / dt, 1), "ms_per_step": round(dt * 1e3, 3), "rays_per_step": n_rays,
-            "samples_per_ray": f"{cfg.N_samples}+{cfg.N_importance}", "dtype": precision, "final_loss": round(float(loss.detach()), 5),
-            "what": "forward + backward + Adam step + device-side weight re-pack, through render.batchify_rays under autograd",
-            "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(flops / dt / 1e12 / peak, 4),
-                         "note": "algorithmic trunk flops (3 x forward: fwd, backward-data, weight gradients) over the whole step's "
-                                 "wall time, incl. the bender's own kernels, the library GEMMs / reductions, optimiser and launch overheads at this batch size"}}
+            "samples_per_ray": f"{S}+{I}", "dtype": precision, "final_loss": round(final, 5),
+            "what": "the reference's training iteration with its shipped recipe (configs/example_sequence.txt): render under autograd with "
+                    "detailed outputs (perturb, raw_noise_std 1), loss = mse(rgb_map) + mse(rgb0) + 60 x (offsets + 5e-4 rigidity) "
+                    "regulariser + 3 x divergence regulariser (native second-order path) with the increasing schedule, backward, fused "
+                    "Adam step, device-side weight re-pack; all through render.batchify_rays / training.compute_divergence_loss",
+            "loss_terms": ["mse(rgb_map)", "mse(rgb0)", "offsets", "rigidity", "divergence"],
+            "roofline": {"bound": "hbm", **r["hbm"], "mfma": r["mfma"],
+                         "note": "algorithmic work (3 x forward flops of trunk + bender, + the divergence chains; saved arrays written "
+                                 "once and read once) over the whole step's wall time, incl. optimiser, small loss ops and launch overheads"},
+            "data_term_only": {"rays_per_s": round(n_rays / dt0, 1), "ms_per_step": round(dt0 * 1e3, 3), "samples_per_ray": f"{S}+128",
+                               "final_loss": round(final0, 5), "what": "round 2's step: mse(rgb_map) + mse(rgb0) only, no detailed outputs",
+                               "roofline": roof(dt0, 128, False)}}

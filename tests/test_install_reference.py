@@ -167,7 +167,7 @@ def test_reference_render_path_and_dataparallel_wrapper_run_on_the_hip_path(refe
             rgbs, disps, details = T.render_path(poses, intrins, 32768, kw, codes, detailed_output=True)
             par = T.get_parallelized_render_function(coarse_model=coarse, fine_model=fine, ray_bender=rb)
             kw_par = {k: v for k, v in kw.items() if k not in ("network_fn", "network_fine", "ray_bender")}
-            rgbs2, disps2, _ = T.render_path(poses, intrins, 32768, kw_par, codes, detailed_output=False, parallelized_render_function=par)
+            rgbs2, disps2 = T.render_path(poses, intrins, 32768, kw_par, codes, detailed_output=False, parallelized_render_function=par)      # train.py:550-553
         assert spy.calls == 0, "a call fell back to the reference's render_rays instead of the HIP path"
     finally:
         undo()

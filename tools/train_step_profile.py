@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""GPU box, under `rocprofv3 --kernel-trace --stats`: native training steps (bf16 mode, 64+128 samples) at one batch size."""
+"""GPU box, under `rocprofv3 --kernel-trace --stats`: native training steps with the reference's shipped recipe
+(configs/example_sequence.txt: 64 + 64 samples, detailed outputs, data + offsets / rigidity + divergence terms; bf16 mode) at
+one batch size.    python tools/train_step_profile.py [rays] [precision] [--table]  (--table: torch profiler's kernel table)"""
 import os
 import sys
 
@@ -10,6 +12,16 @@ sys.path.insert(0, REPO)
 from nonrigid_nerf_amd import training  # noqa: E402
 from nonrigid_nerf_amd.synthetic import SceneConfig  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-r = training.bench_train_step(None, SceneConfig(), torch.device("cuda:0"), precision="bf16", n_rays=n, steps=20, warmup=3)
-print(f"[bf16] {n} rays/step: {r['ms_per_step']:.3f} ms/step under the profiler")
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 1024
+prec = args[1] if len(args) > 1 else "bf16"
+dev = torch.device("cuda:0")
+if "--table" in sys.argv:
+    from torch.profiler import ProfilerActivity, profile
+    training._time_training(SceneConfig(), dev, prec, n, 64, 3, 3, regularised=True)
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        dt, _ = training._time_training(SceneConfig(), dev, prec, n, 64, 10, 2, regularised=True)
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=80))
+else:
+    dt, loss = training._time_training(SceneConfig(), dev, prec, n, 64, 20, 3, regularised=True)
+    print(f"[{prec}] shipped recipe, {n} rays/step: {dt * 1e3:.3f} ms/step (loss {loss:.5f})")
