@@ -73,6 +73,10 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --rays per GPU; strong: --rays in total, sharded contiguously over the ranks "
                          "(BASELINE config 3: one frame over 8 GPUs)")
+    ap.add_argument("--chunk", type=int, default=1024 * 32, help="batchify_rays' chunk argument (the reference's memory bound; the HIP "
+                    "path treats it as a lower bound of its launch size)")
+    ap.add_argument("--max-rays-per-launch", type=int, default=0, help="cap the rays of one nrnerf_render launch sequence (default: 2^20; "
+                    "BASELINE config 5 words its workload as 65 536-ray chunks: --chunk 65536 --max-rays-per-launch 65536)")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the train_step leg (the native training iteration: 1024 rays forward + backward + Adam, untimed part of the run)")
     return ap.parse_args()
@@ -96,10 +100,17 @@ def spawn_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def build_workload(args, rank, world, dev):
-    """(scene, cfg, modules, rays, latents-as-passed, description).  Inputs resident in HBM on return."""
+def build_workload(args, rank, world, dev, frame_rays=None, scaling=None):
+    """(scene, cfg, modules, rays, latents-as-passed, description).  Inputs resident in HBM on return.
+    weak: every rank gets its own frame of ``frame_rays`` rays; strong: ONE frame of ``frame_rays`` rays, rank r gets the
+    contiguous slice [r * ceil(n / G), (r + 1) * ceil(n / G)) of it (DataParallel's scatter rule, distributed.shard_bounds)."""
+    from nonrigid_nerf_amd.distributed import shard_bounds
     from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
-    n = args.rays
+    frame_rays = frame_rays or args.rays
+    scaling = scaling or args.scaling
+    strong = scaling == "strong" and world > 1
+    lo, hi, per = shard_bounds(frame_rays, world, rank) if strong else (0, frame_rays, frame_rays)
+    n = frame_rays
     if args.scene == "fitted":
         import numpy as np
         from nonrigid_nerf_amd.checkpoint import load_checkpoint
@@ -113,15 +124,16 @@ def build_workload(args, rank, world, dev):
         scene = Scene(cfg, sd(ck.ray_bender), sd(ck.network_fn), sd(ck.network_fine))
         rb, coarse, fine = ck.ray_bender, ck.network_fn, ck.network_fine
         # one full-resolution frame of the sequence per rank (512x384; the fixture's intrinsics are 96x72)
-        frame = (3 + rank) % int(z["poses"].shape[0])
+        frame = (3 + (0 if strong else rank)) % int(z["poses"].shape[0])
         s = 512.0 / float(z["hwf"][1])
         intrin = dict(height=384, width=512, focal_x=float(z["hwf"][2]) * s, focal_y=float(z["hwf"][2]) * s,
                       center_x=256.0, center_y=192.0)
         rays = generate_rays(torch.from_numpy(z["poses"][frame]), intrin, near, far, False, dev)
         reps = (n + rays.shape[0] - 1) // rays.shape[0]
-        rays = rays.repeat(reps, 1)[:n].contiguous()
+        rays = rays.repeat(reps, 1)[:n]
+        rays = _pad_rows(rays[lo:hi], per).contiguous()   # strong: this rank's slice (the last rank's padded to equal blocks)
         code = ck.latents[frame].to(dev).reshape(1, -1)
-        latents = code.expand(n, -1)                     # stride-0 view, as render_path passes it (train.py:464-466)
+        latents = code.expand(per, -1)                   # stride-0 view, as render_path passes it (train.py:464-466)
         desc = (f"example_sequence frame {int(z['frame_ids'][frame])} camera rays at 512x384, weights fitted to the "
                 f"down-sampled sequence ({ck.global_step} oracle iterations, tests/golden/fitted_latest.tar), one latent per frame")
         return scene, cfg, (rb, coarse, fine), rays, latents, desc
@@ -129,8 +141,16 @@ def build_workload(args, rank, world, dev):
                       approx_nonrigid_viewdirs=not args.exact_viewdirs, netwidth=args.netwidth)
     scene = make_scene(cfg, 0)
     mods = build_modules(scene, device=dev)
-    rays, latents = make_rays(n, seed=100 + rank, cfg=cfg)
+    rays, latents = make_rays(n, seed=100 + (0 if strong else rank), cfg=cfg)
+    rays, latents = _pad_rows(rays[lo:hi], per), _pad_rows(latents[lo:hi], per)
     return scene, cfg, mods, rays.to(dev), latents.to(dev), "seeded random weights and rays (nonrigid_nerf_amd/synthetic.py)"
+
+
+def _pad_rows(t, rows):
+    """The all-gather moves equal blocks: a short last shard is padded by repeating its last row (rendered, then ignored)."""
+    if t.shape[0] == rows:
+        return t
+    return torch.cat([t, t[-1:].expand(rows - t.shape[0], -1)], 0)
 
 
 def main():
@@ -165,10 +185,12 @@ def main():
 
     from nonrigid_nerf_amd import render as R
 
-    if args.scaling == "strong":                          # one frame for the whole job: ceil(n / G) rays per rank
-        args.rays = (args.rays + world - 1) // world
+    frame_rays = args.rays                                # weak: per rank; strong: for the whole job (ceil(n / G) per rank)
     scene, cfg, (rb, coarse, fine), rays, latents, data_desc = build_workload(args, rank, world, dev)
+    args.rays = int(rays.shape[0])
     R.set_precision(args.precision)
+    if args.max_rays_per_launch > 0:
+        R._MAX_RAYS_PER_LAUNCH = int(args.max_rays_per_launch)
     api = {"ray_bending_latents": latents}
     kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples,
               N_importance=cfg.N_importance, perturb=0.0, raw_noise_std=0.0)
@@ -178,48 +200,74 @@ def main():
     n = args.rays
     if world > 1:
         import torch.distributed as dist
-        from nonrigid_nerf_amd.distributed import OverlappedGather
-        gather = OverlappedGather(n, "cpu" if one_gpu else dev)      # gloo (the one-GPU functional mode) gathers host tensors
-
-    def step(i):
-        out = R.batchify_rays(rays, api, chunk=1024 * 32, **kw)
-        if world == 1:
-            return out
-        if one_gpu:
-            out = {k: out[k].cpu() for k in ("rgb_map", "disp_map", "acc_map")}
-        return gather.submit(i, out)
-
-    def drain():
-        if world > 1:
-            gather.drain()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_region(rays_, api_, n_, profile):
+        """args.warmup untimed + args.steps timed passes over `rays_` (n_ rays on this rank), bracketed by barrier +
+        synchronize; returns (max over ranks of the wall time, this rank's own wall time, kernel profile, last image)."""
+        gather = None
+        if world > 1:
+            from nonrigid_nerf_amd.distributed import OverlappedGather
+            gather = OverlappedGather(n_, "cpu" if one_gpu else dev)      # gloo (the one-GPU functional mode) gathers host tensors
+
+        def step(i):
+            out = R.batchify_rays(rays_, api_, chunk=args.chunk, **kw)
+            if gather is None:
+                return out
+            if one_gpu:
+                out = {k: out[k].cpu() for k in ("rgb_map", "disp_map", "acc_map")}
+            return gather.submit(i, out)
+
+        with torch.no_grad():
+            for i in range(args.warmup):
+                step(i)
+            if gather is not None:
+                gather.drain()
+            barrier()
+            if profile:
+                model.profile_begin()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                img = step(i)
+            if gather is not None:
+                gather.drain()
+            barrier()
+            dt_own = time.perf_counter() - t0
+            prof_ = model.profile_end() if profile else None
+        dt_max, per_rank = dt_own, [dt_own]
+        if world > 1:
+            assert img.shape == (world * n_, 5)
+            t = torch.tensor([dt_own], dtype=torch.float64, device="cpu" if one_gpu else dev)
+            allt = torch.empty(world, dtype=torch.float64, device=t.device)
+            dist.all_gather_into_tensor(allt, t)
+            per_rank = [float(x) for x in allt.cpu()]
+            dt_max = max(per_rank)
+        return dt_max, per_rank, prof_, step
+
     main_stream = torch.cuda.current_stream(dev)
     t_gpu0 = time.perf_counter()
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
-        drain()
-        barrier()
-        model.profile_begin()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            img = step(i)
-        drain()
-        barrier()
-        dt = time.perf_counter() - t0
-        prof = model.profile_end()
+    dt, per_rank_dt, prof, step = timed_region(rays, api, n, profile=True)
+    # the other scaling of the same job, for N > 1 (one JSON line carries both): the primary record is `args.scaling`
+    other = None
     if world > 1:
-        assert img.shape == (world * n, 5)
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if one_gpu:
-            t = t.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        other_scaling = "strong" if args.scaling == "weak" else "weak"
+        _, _, _, rays_o, latents_o, _ = build_workload(args, rank, world, dev, frame_rays=frame_rays, scaling=other_scaling)
+        n_o = int(rays_o.shape[0])
+        dt_o, per_rank_o, _, _ = timed_region(rays_o, {"ray_bending_latents": latents_o}, n_o, profile=False)
+        other = scaling_record(other_scaling, world, n_o, args.steps, dt_o, per_rank_o)
+    else:                # N = 1: one frame on one GPU is both the weak and the strong workload
+        other = dict(scaling_record("strong" if args.scaling == "weak" else "weak", 1, n, args.steps, dt, per_rank_dt),
+                     note="identical to the other scaling at N = 1 (not run twice)")
+    rccl_ranks = 1
+    if world > 1:        # counted by an actual collective on the job's backend, not copied from the environment
+        one = torch.ones(1, device="cpu" if one_gpu else dev)
+        cnt = torch.empty(world, device=one.device)
+        dist.all_gather_into_tensor(cnt, one)
+        rccl_ranks = int(cnt.sum().item())
     total_rays = world * n * args.steps
     value = total_rays / dt
 
@@ -271,9 +319,13 @@ def main():
                                          f"exact_viewdirs={args.exact_viewdirs}, netwidth={args.netwidth}"
                                          if (args.use_viewdirs or args.bend_depth != 5 or args.netwidth != 256) else ""),
                           "scene": args.scene, "rays_per_gpu_per_step": n, "N_samples": 64, "N_importance": 128,
+                          "chunk": args.chunk, "rays_per_launch": min(n, max(args.chunk, R._MAX_RAYS_PER_LAUNCH)),
                           "parallelism": f"rays sharded over {world} rank(s)"
                                          + (", all-gather of [rgb,disp,acc] on a side stream, overlapped with the next frame" if world > 1 else "")},
-               "rccl_ranks": world if world > 1 else 1, "backend": backend,
+               "rccl_ranks": rccl_ranks, "backend": backend,
+               # both scalings of an N-GPU job in the one line: weak = a 512x384 frame per rank per step, strong = BASELINE
+               # config 3, ONE frame sharded contiguously over the ranks (24 576 rays per rank at N = 8), all-gather overlapped
+               **{rec["scaling"]: rec for rec in (scaling_record(args.scaling, world, n, args.steps, dt, per_rank_dt), other) if rec},
                "mflop_per_ray_algorithmic": round(flops_per_ray / 1e6, 2),
                "end_to_end_tflops": round(value * flops_per_ray / 1e12, 2),
                "untimed_extra_frames": extra_frames,
@@ -286,6 +338,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scaling_record(scaling, world, rays_per_rank, steps, dt_max, per_rank_dt):
+    """One scaling's figures of an N-rank job: whole-job rays/s from the slowest rank's wall time, every rank's own
+    ms/step (a straggler shows), and the shard size.  Pure function of the measurements (unit-tested on the CPU tier)."""
+    return {"scaling": scaling, "value": round(world * rays_per_rank * steps / dt_max, 1), "unit": "rays/s",
+            "ms_per_step": round(dt_max / steps * 1e3, 3), "rays_per_rank_per_step": int(rays_per_rank),
+            "rays_per_step_whole_job": int(world * rays_per_rank),
+            "per_rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per_rank_dt],
+            "what": ("a frame of that many rays per rank per step (512x384 at the default size)" if scaling == "weak"
+                     else "BASELINE config 3: ONE frame (512x384 at the default size) sharded contiguously over the ranks, "
+                          "all-gather of the pixels overlapped with the next frame")}
 
 
 def psnr_vs_oracle(args, scene, cfg, rays, latents, api, kw, dev):

@@ -144,6 +144,27 @@ def test_bench_spawns_its_own_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["backend"] == "gloo"
     assert res["steps"] == 3 and res["value"] > 0
+    # both scalings of the job in the one line: weak = --rays per rank, strong = --rays sharded over the ranks
+    assert res["scaling"] == "weak" and res["weak"]["value"] == res["value"] and res["weak"]["rays_per_rank_per_step"] == 8192
+    assert res["strong"]["rays_per_rank_per_step"] == 4096 and res["strong"]["rays_per_step_whole_job"] == 8192
+    assert len(res["strong"]["per_rank_ms_per_step"]) == 2 and res["strong"]["value"] > 0
+
+
+def test_bench_scaling_records_are_whole_job_figures():
+    """bench.py's per-scaling record (pure function of the measurements): whole-job rays/s from the SLOWEST rank's wall
+    time, every rank's own ms/step, shard sizes of BASELINE config 3 (one 512x384 frame over 8 ranks = 24 576 rays each)."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    per_rank = [0.100, 0.104, 0.098, 0.101, 0.100, 0.100, 0.099, 0.102]
+    rec = bench.scaling_record("strong", 8, 24576, 20, max(per_rank), per_rank)
+    assert rec["rays_per_step_whole_job"] == 196608 and rec["rays_per_rank_per_step"] == 24576
+    assert abs(rec["value"] - 8 * 24576 * 20 / 0.104) < 1.0 and rec["ms_per_step"] == 5.2
+    assert rec["per_rank_ms_per_step"] == [5.0, 5.2, 4.9, 5.05, 5.0, 5.0, 4.95, 5.1]
+    weak = bench.scaling_record("weak", 8, 196608, 20, 0.8, [0.8] * 8)
+    assert weak["value"] == 8 * 196608 * 20 / 0.8 and weak["scaling"] == "weak"
 
 
 def _overlap_worker(rank, world, port, out_dir):
