@@ -235,6 +235,15 @@ typedef struct nrnerf_camera {
 int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_plane, float* rays_out,
                          int32_t ray_stride, void* hip_stream);
 
+/* The coarse sample depths of render_rays (train.py:847-868) as an array: z_out [n_rays, n_samples] (device) =
+ * near (1 - t) + far t, t = linspace(0, 1, n_samples) (or linear in inverse depth, `lindisp`), and -- uniforms != NULL --
+ * the stratified jitter z = lower + (upper - lower) * u between the mid-points, u [n_rays, n_samples] drawn by the caller
+ * (torch.rand, train.py:860).  The render path computes these inside its kernels; the training path (which hands depths to
+ * nrnerf_bender_forward / nrnerf_composite_forward) gets them here in one launch instead of a dozen elementwise ones.
+ * Runs on the device that owns z_out. */
+int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uniforms, int32_t n_rays, int32_t n_samples,
+                         int32_t lindisp, float* z_out, void* hip_stream);
+
 /* ---- training support ------------------------------------------------------------------------------------------
  * The reference trains through autograd (training_wrapper_class.forward, train.py:152-287; backward + optimiser step,
  * train.py:1594-1610).  These entry points are the pieces a torch.autograd.Function needs (nonrigid_nerf_amd/training.py

@@ -173,6 +173,7 @@ EXPORTS = {
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
+    "nrnerf_sample_depths": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "nrnerf_trunk_forward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
     "nrnerf_trunk_backward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
     "nrnerf_trunk_wgrad": (C.c_int, [C.c_void_p, C.POINTER(WgradArgs), C.c_void_p]),

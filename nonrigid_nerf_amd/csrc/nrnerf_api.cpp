@@ -987,6 +987,19 @@ int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_p
     return launch_raygen(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
+int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uniforms, int32_t n_rays, int32_t n_samples,
+                         int32_t lindisp, float* z_out, void* hip_stream) try {
+    if (!rays || !z_out || ray_stride < 8 || n_rays < 0 || n_samples < 2 || n_samples > 256) return NRNERF_ERR_INVALID;
+    if (n_rays == 0) return NRNERF_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, z_out) != hipSuccess) { (void)hipGetLastError(); return NRNERF_ERR_INVALID; }
+    if (attr.type != hipMemoryTypeDevice) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(attr.device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    JitterArgs j{rays, ray_stride, uniforms, n_rays, n_samples, lindisp, z_out};
+    return launch_zjitter(j, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
 // ---- training entry points (nrnerf_train.h, composite_bwd_kernel) -------------------------------------------------
 namespace {
 int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, TrunkArgs& t) {

@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) zjitter_kernel(const JitterArgs a) {
     const float zi = zat(i);
     const float upper = (i < S - 1) ? __fmul_rn(0.5f, __fadd_rn(zat(i + 1), zi)) : zi;         // :857-858
     const float lower = (i > 0) ? __fmul_rn(0.5f, __fadd_rn(zi, zat(i - 1))) : zi;             // :859
-    a.z_out[idx] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), a.u[idx]));              // :868
+    a.z_out[idx] = a.u ? __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), a.u[idx])) : zi;   // :868 (no uniforms: the plain spacing)
 }
 hipError_t launch_zjitter(const JitterArgs& a, hipStream_t stream) {
     const long long n = (long long)a.n_rays * a.S;

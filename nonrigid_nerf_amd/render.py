@@ -169,15 +169,31 @@ def _linears_in_canonical_order(network_fn, network_fine):
     return mods
 
 
-def _flat_params(network_fn, network_fine):
+def _flat_params(network_fn, network_fine, into=None):
+    """All parameters as one fp32 vector in the library's canonical order.  ``into``: a (buffer, views) pair from an
+    earlier call for the same parameter shapes -- refilled with one multi-tensor copy (no torch.cat: on ROCm a cat of
+    ~90 tensors stages its argument table through host-to-device copies, every training step).  Returns (flat, state)."""
     parts = []
     for lin in _linears_in_canonical_order(network_fn, network_fine):
-        parts.append(lin.weight.detach().reshape(-1))
+        parts.append(lin.weight.detach())
         if getattr(lin, "bias", None) is not None:
-            parts.append(lin.bias.detach().reshape(-1))
+            parts.append(lin.bias.detach())
     if not parts or any(p.device != parts[0].device for p in parts) or parts[0].device.type != "cuda":
-        return None
-    return torch.cat([p.to(torch.float32) for p in parts])
+        return None, None
+    shapes = tuple(tuple(p.shape) for p in parts)
+    if into is None or into[2] != shapes or into[0].device != parts[0].device:
+        flat = torch.empty(sum(p.numel() for p in parts), dtype=torch.float32, device=parts[0].device)
+        views, o = [], 0
+        for p in parts:
+            views.append(flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        into = (flat, views, shapes)
+    if all(p.dtype == torch.float32 for p in parts):
+        torch._foreach_copy_(into[1], parts)
+    else:
+        for v, p in zip(into[1], parts):
+            v.copy_(p)
+    return into[0], into
 
 
 def _fingerprint(mods):
@@ -240,7 +256,7 @@ class Model:
         model's device -- are concatenated into one fp32 vector in the library's canonical order and re-packed by a
         gather kernel per image, asynchronously on the current stream.  What every training step does after
         ``optimizer.step()``.  Returns False when the modules are not on this device or describe a different model."""
-        flat = _flat_params(network_fn, network_fine)
+        flat, self._flat_state = _flat_params(network_fn, network_fine, getattr(self, "_flat_state", None))
         if flat is None or flat.device != self.device or int(self.lib.nrnerf_model_flat_size(self.handle)) != flat.numel():
             return False
         with torch.cuda.device(self.device):
@@ -259,8 +275,7 @@ class Model:
         if rc in (_lib.ERR_INVALID, _lib.ERR_UNSUPPORTED):
             return False
         _lib.check(rc, "nrnerf_model_update_device")
-        self._flat_keepalive = flat                       # until the next refresh: the kernels read it asynchronously
-        return True
+        return True                                       # (the flat buffer is persistent: self._flat_state)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -469,6 +484,18 @@ def model_of_bender(ray_bender, device):
     except Unsupported:
         return None
     return model if model.trains_bender else None
+
+
+def mark_stale(network_fn):
+    """The packed weights of ``network_fn``'s handles no longer match the parameters although the version counters say
+    they do -- an optimiser step replayed from a HIP graph updates the parameters without touching the counters.  The
+    next ``get_model`` re-packs them IN PLACE (device-side refresh), unlike ``invalidate``, which drops the handles."""
+    with _cache_lock:
+        per = _cache.get(network_fn)
+        if per:
+            for k, (fp, m) in list(per.items()):
+                if isinstance(m, Model):
+                    per[k] = (None, m)
 
 
 def invalidate(network_fn=None):

@@ -196,13 +196,17 @@ class _Trunk(torch.autograd.Function):
         for i in range(D):
             if i == 0:
                 dw = dwe[0][:, :n_enc]
-            elif (i - 1) in skips:
-                dw = torch.cat([dwe[1][:, :n_enc], dwh[i - 1]], 1)                           # x = [encoding, h] (rnh:278-282)
+            elif (i - 1) in skips:                                                           # x = [encoding, h] (rnh:278-282)
+                dw = torch.empty(W, n_enc + W, dtype=torch.float32, device=dev)              # (slice copies, not torch.cat: on
+                dw[:, :n_enc] = dwe[1][:, :n_enc]                                            #  ROCm every cat stages its metadata
+                dw[:, n_enc:] = dwh[i - 1]                                                   #  through a host-to-device copy)
             else:
                 dw = dwh[i - 1]
             grads += [dw, db[i]]
-        dw_out = F.pad(dwo[:, :4].t(), (0, 0, 0, C_out - 4))                                 # the 5th channel never reaches the loss
-        g_out = F.pad(g.sum(0), (0, C_out - 4))
+        dw_out = torch.zeros(C_out, W, dtype=torch.float32, device=dev)                      # the 5th channel never reaches the loss
+        dw_out[:4] = dwo[:, :4].t()
+        g_out = torch.zeros(C_out, dtype=torch.float32, device=dev)
+        g_out[:4] = g.sum(0)
         return grads + [dw_out, g_out]
 
 
@@ -519,7 +523,10 @@ class _Divergence(torch.autograd.Function):
         for k, lin in enumerate(list(rb.network) + list(rb.rigidity_network)):
             o, i_ = int(lin.weight.shape[0]), int(lin.weight.shape[1])
             if k == 0:                                  # jobs 0 / 1: the point's and the latent code's columns of network[0]
-                grads.append(torch.cat([dW[0, :o, :3], dW[1, :o, :i_ - 3]], 1))
+                w0 = torch.empty(o, i_, dtype=torch.float32, device=dev)
+                w0[:, :3] = dW[0, :o, :3]
+                w0[:, 3:] = dW[1, :o, :i_ - 3]
+                grads.append(w0)
                 job = 0
             else:
                 job = k + 1
@@ -587,7 +594,9 @@ def compute_divergence_loss(offsets_of_inputs, input_points, point_latents, ray_
             d = _Divergence.apply(point_latents, model, ray_bender, pts, e, *params)
             div = d if div is None else div + d
     else:                                                # divergence_approx (rnh:103-113), one draw per chunk as in rnh:52-59
-        e = torch.cat([torch.randn_like(pts[i:i + chunk, :]) for i in range(0, M, int(chunk))], 0)
+        e = torch.empty_like(pts)                    # randn_like(offsets) per chunk = empty_like().normal_(): same draws, no cat
+        for i in range(0, M, int(chunk)):
+            e[i:i + chunk, :].normal_()
         div = _Divergence.apply(point_latents, model, ray_bender, pts, e, *params)
     divergence_loss = torch.abs(div)                                                         # rnh:61
     divergence_loss = divergence_loss ** 2                                                   # rnh:62
@@ -642,23 +651,17 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         if latents.dim() != 2 or tuple(latents.shape) != (N, model.latent_size):
             raise ValueError(f"ray_bending_latents must have shape ({N}, {model.latent_size}), got {tuple(latents.shape)}")
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
-    near, far = rays[:, 6:7], rays[:, 7:8]
     if I == 0 and detailed_output:
         raise UnboundLocalError("local variable 'visibility_weights_0' referenced before assignment "
                                 "(reference render_rays cannot do detailed_output with N_importance == 0)")
     # random numbers in the reference's order (train.py:860, 753; run_nerf_helpers.py:665; 753)
     rnd = R._draw_randoms(rays, S, I, perturb, raw_noise_std) or {}
-    t_vals = torch.linspace(0.0, 1.0, steps=S, device=dev)                                   # :847
-    if not lindisp:
-        z_vals = (near * (1.0 - t_vals) + far * t_vals).expand(N, S)                         # :849, 853
-    else:
-        z_vals = (1.0 / (1.0 / near * (1.0 - t_vals) + 1.0 / far * t_vals)).expand(N, S)     # :851
-    if "u_coarse" in rnd:
-        mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])                                    # :857
-        upper = torch.cat([mids, z_vals[..., -1:]], -1)
-        lower = torch.cat([z_vals[..., :1], mids], -1)
-        z_vals = lower + (upper - lower) * rnd["u_coarse"]                                   # :868
-    z_vals = z_vals.contiguous()
+    # coarse depths (:847-868): linspace between near and far (or in inverse depth) and the stratified jitter, one launch
+    z_vals = torch.empty(N, S, dtype=torch.float32, device=dev)
+    u_c = rnd.get("u_coarse")
+    with torch.cuda.device(dev):
+        _lib.check(model.lib.nrnerf_sample_depths(rays.data_ptr(), int(rays.shape[1]), u_c.data_ptr() if u_c is not None else None, N, S,
+                                                  int(bool(lindisp)), z_vals.data_ptr(), _stream(dev)), "nrnerf_sample_depths")
 
     def query(z, net, which):
         native = rb is not None and NATIVE_BENDER
@@ -758,6 +761,61 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     return loss, extras
 
 
+class GraphedStep:
+    """One whole training iteration -- device-side weight re-pack, forward, loss, backward, optimiser step -- captured in
+    a HIP graph and replayed: the ~150 launches of a 1024-ray step (N_rand of the shipped config) cost no host time and no
+    launch gaps.  The iteration the reference runs per step (train.py:1543-1610) is launch-bound at that batch size; its
+    Python loop can adopt this with the changes INTEGRATION.md lists (static input tensors, ``capturable=True`` optimiser).
+
+        graphed = GraphedStep(step_fn, inputs, optimizer, [network_fn])      # step_fn(**inputs) -> scalar loss; it must NOT
+        loss = graphed(rays=..., target=..., ...)                            # call backward / optimizer.step itself
+
+    ``inputs``: dict of example tensors; the same keys are accepted per call and copied into the static buffers
+    (shapes fixed).  Anything that changes per step must be one of them -- e.g. the regularisers' schedule as a 0-dim tensor
+    (``training_loss(global_step=tensor)``).  Random numbers are drawn inside the graph from torch's generator (graph-safe
+    Philox offsets), so a replayed step draws fresh numbers.  ``networks``: the ``network_fn`` modules whose packed weights
+    the step reads: their handles are re-packed from the parameters at the START of every replay (the captured refresh),
+    and ``sync()`` must be called before rendering outside the graph (the replayed optimiser steps do not touch the
+    parameters' version counters, so the boundary cannot see them)."""
+
+    def __init__(self, step_fn, inputs, optimizer, networks, warmup=3):
+        self.networks = list(networks)
+        self.static = {k: v.clone() for k, v in inputs.items()}
+        self.optimizer = optimizer
+        dev = next(iter(self.static.values())).device
+
+        def one():
+            for nf in self.networks:
+                R.mark_stale(nf)                                   # the refresh kernels are part of the captured step
+            loss = step_fn(**self.static)
+            loss.backward()
+            optimizer.step()
+            return loss
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.enable_grad():         # warm-up on a side stream, as torch's graph recipe asks
+            for _ in range(warmup):
+                optimizer.zero_grad(set_to_none=True)
+                one()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)                      # .grad tensors are allocated from the graph's pool
+        with torch.enable_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.loss = one()
+
+    def __call__(self, **inputs):
+        for k, v in inputs.items():
+            self.static[k].copy_(v)
+        self.graph.replay()
+        return self.loss
+
+    def sync(self):
+        for nf in self.networks:
+            R.mark_stale(nf)
+
+
 # configs/example_sequence.txt:14-16, 26-28, 35 -- the recipe the reference ships
 SHIPPED_RECIPE = dict(N_samples=64, N_importance=64, N_rand=1024, perturb=1.0, raw_noise_std=1.0, offsets_loss_weight=60.0,
                       divergence_loss_weight=3.0, rigidity_loss_weight=0.0005, N_iters=200000, chunk=32768)
@@ -814,10 +872,13 @@ def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, reg
                    rigidity_loss_weight=rec["rigidity_loss_weight"]) if (regularised and rb is not None) else {}
     state = {"i": 0}
 
+    def loss_of(rays, target, frame, global_step):
+        loss, _ = training_loss(rays, codes[frame], target, kw, global_step=global_step, N_iters=rec["N_iters"], chunk=rec["chunk"], **weights)
+        return loss.mean()                                                  # train.py:1594
+
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, _ = training_loss(rays, codes[frame], target, kw, global_step=state["i"], N_iters=rec["N_iters"], chunk=rec["chunk"], **weights)
-        loss = loss.mean()                                                  # train.py:1594
+        loss = loss_of(rays, target, frame, state["i"])
         loss.backward()
         opt.step()
         state["i"] += 1
@@ -826,6 +887,15 @@ def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, reg
     prev = R.get_precision()
     R.set_precision(precision)
     try:
+        if graph:
+            gstep = torch.zeros((), device=dev)
+            graphed = GraphedStep(loss_of, dict(rays=rays, target=target, frame=frame, global_step=gstep), opt, [coarse], warmup=max(warmup, 2))
+
+            def step():                                                     # noqa: F811  (the replayed step)
+                state["i"] += 1
+                gstep.fill_(float(state["i"]))
+                return graphed(global_step=gstep)
+            warmup = 2
         with torch.enable_grad():
             for _ in range(warmup):
                 step()
@@ -851,6 +921,12 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=None, steps=30, w
     n_rays = n_rays or rec["N_rand"]
     dt, final = _time_training(cfg, dev, precision, n_rays, rec["N_importance"], steps, warmup, regularised=True)
     dt0, final0 = _time_training(cfg, dev, precision, n_rays, 128, steps, warmup, regularised=False)
+    try:        # the same iteration replayed from a HIP graph (GraphedStep): no host time, no launch gaps
+        dtg, finalg = _time_training(cfg, dev, precision, n_rays, rec["N_importance"], steps, warmup, regularised=True, graph=True)
+        graph = {"rays_per_s": round(n_rays / dtg, 1), "ms_per_step": round(dtg * 1e3, 3), "final_loss": round(finalg, 5),
+                 "what": "the same iteration (weight re-pack, forward, loss, backward, Adam) captured once in a HIP graph and replayed (training.GraphedStep)"}
+    except Exception as e:                                                  # capture is best effort: report, do not fail the bench
+        graph = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     peak = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}[precision]
     S, I = cfg.N_samples, rec["N_importance"]
 
@@ -878,6 +954,7 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=None, steps=30, w
                     "regulariser + 3 x divergence regulariser (native second-order path) with the increasing schedule, backward, fused "
                     "Adam step, device-side weight re-pack; all through render.batchify_rays / training.compute_divergence_loss",
             "loss_terms": ["mse(rgb_map)", "mse(rgb0)", "offsets", "rigidity", "divergence"],
+            "hip_graph": graph,
             "roofline": {"bound": "hbm", **r["hbm"], "mfma": r["mfma"],
                          "note": "algorithmic work (3 x forward flops of trunk + bender, + the divergence chains; saved arrays written "
                                  "once and read once) over the whole step's wall time, incl. optimiser, small loss ops and launch overheads"},

@@ -581,3 +581,49 @@ def test_native_full_training_iteration_vs_oracle_and_reference_golden(native_be
     # every parameter the reference's step gives a gradient to got one here, and nothing else
     ref_keys = {tuple(k.split("__", 2)[1:]) for k in z.files if k.startswith("gradnorm__")}
     assert {k for k in ours if k[0] != "codes"} == ref_keys
+
+
+@pytest.mark.gpu
+def test_training_iteration_replayed_from_a_hip_graph():
+    """training.GraphedStep: the whole iteration (device-side weight re-pack, forward with fresh random numbers, the shipped
+    loss, backward, Adam) captured once and replayed.  The replays must train (loss falls on a fixed batch), must draw new
+    random numbers each time (two replays with frozen parameters give different losses), and after ``sync()`` the packed
+    weights the no-grad render uses are the trained ones (equal to a handle built from scratch)."""
+    from nonrigid_nerf_amd import training
+    cfg = SceneConfig(N_importance=64)
+    rb, coarse, fine = training._fresh_training_modules(cfg, torch.device(DEV), 64)
+    params = []
+    for m in (rb, coarse, fine):
+        m.requires_grad_(True)
+        params += list(m.parameters())
+    codes = torch.zeros(4, cfg.latent_size, device=DEV, requires_grad=True)
+    opt = torch.optim.Adam(params + [codes], lr=5e-4, fused=True, capturable=True)
+    rays, _ = make_rays(256, 5, cfg)
+    rays = rays.to(DEV)
+    frame = torch.randint(0, 4, (256,), device=DEV)
+    target = 0.5 + 0.4 * torch.sin(3.0 * rays[:, 3:6])
+    kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=64, N_importance=64, perturb=1.0, raw_noise_std=1.0)
+    R.set_precision("bf16")
+
+    def loss_of(rays, target, frame, global_step):
+        loss, _ = training.training_loss(rays, codes[frame], target, kw, offsets_loss_weight=60.0, divergence_loss_weight=3.0,
+                                         rigidity_loss_weight=0.0005, global_step=global_step, N_iters=200000, chunk=32768)
+        return loss.mean()
+
+    gstep = torch.zeros((), device=DEV)
+    graphed = training.GraphedStep(loss_of, dict(rays=rays, target=target, frame=frame, global_step=gstep), opt, [coarse])
+    losses = [float(graphed(global_step=gstep.fill_(float(i)))) for i in range(60)]
+    assert all(l == l for l in losses)
+    assert sum(losses[-10:]) / 10 < 0.8 * sum(losses[:5]) / 5, (losses[:5], losses[-10:])
+    # fresh random numbers per replay: freeze the parameters (lr = 0) and compare two replays
+    for gr in opt.param_groups:
+        gr["lr"] = torch.zeros((), device=DEV) if torch.is_tensor(gr["lr"]) else 0.0
+    a, b = float(graphed()), float(graphed())
+    graphed.sync()
+    with torch.no_grad():
+        got = R.batchify_rays(rays, {"ray_bending_latents": codes[frame].detach()}, chunk=32768, **{**kw, "perturb": 0.0, "raw_noise_std": 0.0})
+        R.invalidate(coarse)
+        want = R.batchify_rays(rays, {"ray_bending_latents": codes[frame].detach()}, chunk=32768, **{**kw, "perturb": 0.0, "raw_noise_std": 0.0})
+    assert torch.equal(got["rgb_map"], want["rgb_map"]), "after sync() the packed weights must be the trained parameters"
+    print(f"\n[graphed training step] loss {losses[0]:.4f} -> {losses[-1]:.4f} over 60 replays; two frozen replays: {a:.6f} vs {b:.6f}")
+    assert a != b, "a replay must draw new random numbers"
