@@ -253,8 +253,9 @@ int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uni
  * Weight gradients are products over two arrays these calls fill: dW_i = d_pre[i]^T x_i with x_0 = encoding,
  * x_i = acts[i-1] (x_{skip+1} = [encoding, acts[skip]]), db_i = column sums of d_pre[i]; d W_out = d_raw^T acts[D-1].
  * fp32 mode: row-major arrays, the products are left to the caller's GEMM library; bf16 mode: nrnerf_trunk_wgrad, below.
- * Available (else NRNERF_ERR_UNSUPPORTED) for the trunks of width 256 and 128 without view-dependent head / time
- * conditioning, fp32 or bf16 (a model created with NRNERF_PREC_F16 has no training kernels: unscaled f16 gradients
+ * Available (else NRNERF_ERR_UNSUPPORTED) for the trunks of width 256 and 128 without time conditioning (with the
+ * view-dependent head: the density branch natively, the colour branch through d_hidden_extra; not with exact view
+ * directions), fp32 or bf16 (a model created with NRNERF_PREC_F16 has no training kernels: unscaled f16 gradients
  * underflow; nonrigid_nerf_amd/training.py trains such a model through a bf16 handle). */
 typedef struct nrnerf_trunk_args {
     uint32_t struct_size;       /* sizeof(nrnerf_trunk_args) */
@@ -277,6 +278,13 @@ typedef struct nrnerf_trunk_args {
     void* d_pre;                /* out: gradient wrt every layer's pre-activation, type and layout of acts (zero in the
                                    padded columns) */
     float* d_pts4;              /* out [M,4] gradient wrt the input points (xyz, 0) */
+    const float* d_hidden_extra;   /* [M, width] fp32 row-major or NULL: an extra gradient wrt the LAST hidden activation
+                                   (relu output of pts_linears[depth-1]), added to head^T d_raw4 before the relu mask.  With the
+                                   view-dependent head (run_nerf_helpers.py:284-304) the library's head slot holds alpha_linear:
+                                   raw4[:, 3] is the density logit and raw4[:, 0:3] = 0; the colour branch (feature_linear,
+                                   views_linears[0] on [feature, direction encoding], rgb_linear) is the caller's, on that
+                                   activation (fp32 mode: acts[depth-1] is [M][width]; bf16 mode: the [B][width][32] tiles), and
+                                   its gradient comes back here */
 } nrnerf_trunk_args;
 int nrnerf_trunk_forward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);
 int nrnerf_trunk_backward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);

@@ -104,8 +104,13 @@ const nrnerf_linear* layer_source(const nrnerf_model_desc& d, const nrnerf_mlp_d
     return nullptr;
 }
 
+// alpha_head (training with the view-dependent head, nrnerf_train.h): the plan's output_linear slot (LK_HEAD) is filled
+// with alpha_linear in output row 3, the sigma channel of raw4 -- the native trunk then yields the density logit, its
+// backward-data pass starts from alpha_linear^T d sigma, and the colour branch (feature / views / rgb layers) is added by
+// the caller through nrnerf_trunk_args.d_hidden_extra
 template <class SH, class A, bool HAS_BEND, bool VIEWS, bool TRUNK = true>
-void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr) {
+void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr,
+               bool alpha_head = false) {
     using PL = Plan<SH, A, HAS_BEND, VIEWS, TRUNK>;
     constexpr int KH = SH::KH;
     const Tables& T = PL::TB;
@@ -123,7 +128,9 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
     size_t written = 0;
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
-        const nrnerf_linear* lin = layer_source(d, mlp, sp);
+        const bool ah = alpha_head && sp.kind == LK_HEAD;
+        const nrnerf_linear* lin = ah ? &mlp.alpha_linear : layer_source(d, mlp, sp);
+        auto orow = [&](int t, int i) { return ah ? (i == 3 ? 0 : -1) : out_row<A>(sp.kind, t, i, lin->out_features); };
         const int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
         for (int t = 0; t < sp.nt; ++t) {
             const TileInfo& ti = T.tiles[sp.tile0 + t];
@@ -136,7 +143,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                     const bool as_f16 = (precision == NRNERF_PREC_F16) || frag_is_f16<SH, A>(sp.kind, s);
                     for (int lane = 0; lane < 64; ++lane) {
                         const int i = lane & 31, h = lane >> 5;
-                        const int row = out_row<A>(sp.kind, t, i, lin->out_features);
+                        const int row = orow(t, i);
                         for (int e = 0; e < KH; ++e) {
                             const int col = in_col<SH, A>(sp.kind, s, h, e, lin->in_features);
                             const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
@@ -160,7 +167,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
             }
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r) {
-                    const int row = out_row<A>(sp.kind, t, tile_row(r, h), lin->out_features);
+                    const int row = orow(t, tile_row(r, h));
                     out.bias[(size_t)(sp.tile0 + t) * 32 + h * 16 + r] = (row >= 0 && lin->bias) ? lin->bias[row] : 0.0f;
                     if (lay && row >= 0 && bbase >= 0) out.bias_src[(size_t)(sp.tile0 + t) * 32 + h * 16 + r] = (int32_t)(bbase + row);
                 }
@@ -190,7 +197,9 @@ void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
     size_t written = 0;
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
-        const nrnerf_linear* lin = (sp.kind == LK_B_HEAD) ? &mlp.output_linear : &mlp.pts_linears[sp.index];
+        // view-dependent head: alpha_linear stands in for output_linear, channel 3 (sigma) <-> its only row (see pack_pass)
+        const bool ah = sp.kind == LK_B_HEAD && mlp.use_viewdirs;
+        const nrnerf_linear* lin = (sp.kind == LK_B_HEAD) ? (ah ? &mlp.alpha_linear : &mlp.output_linear) : &mlp.pts_linears[sp.index];
         const int64_t wbase = lay ? lay->of(lin->weight) : -1;
         for (int t = 0; t < sp.nt; ++t) {
             const TileInfo& ti = T.tiles[sp.tile0 + t];
@@ -202,7 +211,7 @@ void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
                     const int i = lane & 31, h = lane >> 5;
                     const int x = bwd_x<SH, A>(sp.kind, t, i, lin->in_features);
                     for (int e = 0; e < KH; ++e) {
-                        const int y = bwd_y<SH, A>(sp.kind, s, h, e, lin->out_features);
+                        const int y = ah ? (((2 * s + h) * KH + e == 3) ? 0 : -1) : bwd_y<SH, A>(sp.kind, s, h, e, lin->out_features);
                         const float w = (x < 0 || y < 0) ? 0.0f : lin->weight[(size_t)y * lin->in_features + x];
                         if (lay && x >= 0 && y >= 0 && wbase >= 0)
                             out.src[fi * (SH::FRAG_BYTES / SH::ELEM_BYTES) + (size_t)lane * KH + e] = (int32_t)(wbase + (int64_t)y * lin->in_features + x);
@@ -433,6 +442,8 @@ struct nrnerf_model {
     // view-dependent head / time conditioning, fp32 or bf16
     PassDev coarse_bwd, fine_bwd;
     bool train_ok = false;
+    // view-dependent head: forward images of the trunk alone with alpha_linear in the head slot (pack_pass, alpha_head)
+    PassDev coarse_train, fine_train;
     // training of the ray bender (nrnerf_train_bend.h): its layers alone in fp32 (whatever the model's precision) and
     // their transposes; bend_train_ok: train_ok and a bender
     PassDev bend_train_fwd, bend_train_bwd;
@@ -498,7 +509,9 @@ int pack_split(const nrnerf_model_desc& d, PackedPass& trunk, PackedPass& bend, 
 
 // transposed trunk weights for the backward-data kernel; eligible models only (see nrnerf_model::train_ok)
 bool training_eligible(const nrnerf_model_desc& d, const nrnerf_model* m) {
-    return !m->views && (m->arch_id <= 1 || m->arch_id == 5) && !d.coarse->time_conditioned && d.precision != NRNERF_PREC_F16;
+    // (with the view-dependent head: finite-difference or ray directions -- the exact-Jacobian directions would need the
+    //  bender differentiated twice inside the colour branch)
+    return !(m->views && m->exact) && (m->arch_id <= 1 || m->arch_id == 5) && !d.coarse->time_conditioned && d.precision != NRNERF_PREC_F16;
 }
 void pack_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPass& out, const FlatLayout* lay = nullptr) {
     const bool narrow = mlp.width == ArchNarrow::W;
@@ -521,6 +534,22 @@ int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t ref
         rc = refresh ? refresh_pass(bf, m->fine_bwd, refresh_stream) : upload_pass(bf, m->fine_bwd);
     }
     if (refresh && rc == NRNERF_OK && hipStreamSynchronize(refresh_stream) != hipSuccess) rc = NRNERF_ERR_HIP;   // host images die here
+    if (rc == NRNERF_OK && m->views) {       // trunk-only forward images with the alpha head
+        auto pack_train = [&](const nrnerf_mlp_desc& mlp, PackedPass& out) {
+            nrnerf_model_desc d2 = d;
+            d2.bender = nullptr;
+            if (d.precision == NRNERF_PREC_F32) pack_pass<ShapeF32, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, true);
+            else pack_pass<Shape16Fast, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, true);
+        };
+        PackedPass tc, tf;
+        pack_train(*d.coarse, tc);
+        rc = refresh ? refresh_pass(tc, m->coarse_train, refresh_stream) : upload_pass(tc, m->coarse_train);
+        if (rc == NRNERF_OK && d.fine) {
+            pack_train(*d.fine, tf);
+            rc = refresh ? refresh_pass(tf, m->fine_train, refresh_stream) : upload_pass(tf, m->fine_train);
+        }
+        if (refresh && rc == NRNERF_OK && hipStreamSynchronize(refresh_stream) != hipSuccess) rc = NRNERF_ERR_HIP;
+    }
     const double mfma_flop = 2.0 * 32 * 32 * (d.precision == NRNERF_PREC_F32 ? 2 : 16);
     m->coarse_bwd.mfma_flops_per_sample = bc.mfma_per_block * mfma_flop / 32.0;
     m->fine_bwd.mfma_flops_per_sample = (d.fine ? bf.mfma_per_block : bc.mfma_per_block) * mfma_flop / 32.0;
@@ -735,7 +764,7 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     if (!guard.ok) return NRNERF_ERR_HIP;
     hipStream_t stream = (hipStream_t)hip_stream;
     PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only,
-                         &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd};
+                         &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train};
     for (PassDev* p : passes) {
         if (!p || !p->stream) continue;
         if (!p->src) return NRNERF_ERR_UNSUPPORTED;
@@ -762,6 +791,8 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->fine_bwd);
     free_pass(m->bend_train_fwd);
     free_pass(m->bend_train_bwd);
+    free_pass(m->coarse_train);
+    free_pass(m->fine_train);
     (void)hipSetDevice(prev);
     delete m;
 }
@@ -1010,13 +1041,14 @@ int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, Tr
     if (!bwd && (!a->raw4 || (a->raw && a->raw_ch != 4 && a->raw_ch != 5))) return NRNERF_ERR_INVALID;
     if (bwd && (!a->d_raw4 || !a->d_pre || !a->d_pts4)) return NRNERF_ERR_INVALID;
     const bool fine = a->which == 1;
-    const PassDev& fwd = m->has_bend ? (fine ? m->fine_trunk : m->coarse_trunk) : (fine ? m->fine : m->coarse);
+    const PassDev& fwd = m->views ? ((fine && !m->fine_is_coarse) ? m->fine_train : m->coarse_train)
+                                  : (m->has_bend ? (fine ? m->fine_trunk : m->coarse_trunk) : (fine ? m->fine : m->coarse));
     const PassDev& bw = (fine && !m->fine_is_coarse) ? m->fine_bwd : m->coarse_bwd;
     t = TrunkArgs{};
     t.pts4 = a->pts4; t.n_rays = a->n_rays; t.S = a->n_samples;
     t.wstream = bwd ? bw.stream : fwd.stream; t.bias = fwd.bias;
     t.raw4 = a->raw4; t.raw_out = a->raw; t.raw_ch = a->raw_ch;
-    t.acts = a->acts; t.d_raw4 = a->d_raw4; t.d_pre = a->d_pre; t.d_pts4 = a->d_pts4;
+    t.acts = a->acts; t.d_raw4 = a->d_raw4; t.d_pre = a->d_pre; t.d_pts4 = a->d_pts4; t.d_h_extra = a->d_hidden_extra;
     t.mask = (unsigned short*)a->relu_mask;
     if (m->precision != NRNERF_PREC_F32 && !t.mask) return NRNERF_ERR_INVALID;
     return NRNERF_OK;

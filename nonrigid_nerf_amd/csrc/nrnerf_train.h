@@ -281,9 +281,20 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
                     store_tile_bf16((__bf16*)a.d_pre + (((size_t)layer * nblocks + b) * A::W + 32 * t + 4 * h) * 32 + j, out[t * SP], out[t * SP + 1]);
             }
         };
-        // head^T: d h_{D-1}
+        // head^T: d h_{D-1}  (+ the caller's extra gradient wrt h_{D-1}: the colour branch of the view-dependent head)
         dense<P, P, PL, 0, NS_DR, 0>(st, bias_lane, dr, none, [&](auto tc, const f32x16& acc) {
-            mask_store(std::integral_constant<int, A::D - 1>{}, tc, acc, ha); });
+            constexpr int t = decltype(tc)::value;
+            f32x16 g = acc;
+            if (a.d_h_extra) {
+                const float* er = a.d_h_extra + so * A::W + 32 * t + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 ex = *(const f32x4*)(er + 8 * q);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[4 * q + k] += ok ? ex[k] : 0.0f;
+                }
+            }
+            mask_store(std::integral_constant<int, A::D - 1>{}, tc, g, ha); });
         f32x16 denc[NT_E];
         // layers D-1 .. 1 (transposed): input d z_i in the buffer the previous step filled, output d h_{i-1}
         static_for<0, A::D - 1>([&](auto kc) {

@@ -104,7 +104,10 @@ class _Trunk(torch.autograd.Function):
         acts = torch.empty(D, M, W, dtype=torch.float32, device=dev) if f32 else torch.empty(D, nblk, W, 32, dtype=torch.bfloat16, device=dev)
         mask = None if f32 else torch.empty(D, nblk, W // 32, 64, dtype=torch.int16, device=dev)
         raw4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
-        C_out = int(net.output_linear.weight.shape[0])
+        views = bool(net.use_viewdirs)
+        # view-dependent head (rnh:284-304): the library's head slot holds alpha_linear (raw4[:, 3] = density logit, the colour
+        # channels 0), the caller evaluates the colour branch on the last hidden activation, returned as a third output
+        C_out = 4 if views else int(net.output_linear.weight.shape[0])
         raw = torch.empty(M, C_out, dtype=torch.float32, device=dev)
         a = _lib.TrunkArgs()
         a.struct_size = C.sizeof(_lib.TrunkArgs)
@@ -113,19 +116,26 @@ class _Trunk(torch.autograd.Function):
         a.relu_mask = None if f32 else mask.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_forward")
-        ctx.model, ctx.net, ctx.which, ctx.dims = model, net, int(which), (N, S, D, W, C_out)
+        ctx.model, ctx.net, ctx.which, ctx.dims, ctx.views = model, net, int(which), (N, S, D, W, C_out), views
         ctx.save_for_backward(*((pts4, acts) if f32 else (pts4, acts, mask)))
         ctx.mark_non_differentiable(raw)
-        return raw4.view(N, S, 4), raw.view(N, S, C_out)
+        if not views:
+            return raw4.view(N, S, 4), raw.view(N, S, C_out)
+        if f32:
+            h_last = acts[D - 1].view(N, S, W)                                               # [M][W] rows, as saved
+        else:                                                                                # [block][feature][32 samples] tiles
+            bpr = (S + 31) // 32
+            h_last = acts[D - 1].view(N, bpr, W, 32).permute(0, 1, 3, 2).reshape(N, bpr * 32, W)[:, :S].float()
+        return raw4.view(N, S, 4), raw.view(N, S, C_out), h_last
 
     @staticmethod
-    def backward(ctx, g_raw4, _g_raw):
+    def backward(ctx, g_raw4, _g_raw, g_h=None):
         model, net = ctx.model, ctx.net
         f32 = _is_f32(model)
         pts4, acts = ctx.saved_tensors[:2]
         N, S, D, W, C_out = ctx.dims
         M, dev = N * S, pts4.device
-        g = g_raw4.contiguous().reshape(M, 4).float()
+        g = g_raw4.contiguous().reshape(M, 4).float() if g_raw4 is not None else torch.zeros(M, 4, dtype=torch.float32, device=dev)
         d_pre = torch.empty_like(acts)
         d_pts4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         a = _lib.TrunkArgs()
@@ -133,10 +143,13 @@ class _Trunk(torch.autograd.Function):
         a.which, a.n_rays, a.n_samples = ctx.which, N, S
         a.pts4, a.acts, a.d_raw4, a.d_pre, a.d_pts4 = pts4.data_ptr(), acts.data_ptr(), g.data_ptr(), d_pre.data_ptr(), d_pts4.data_ptr()
         a.relu_mask = None if f32 else ctx.saved_tensors[2].data_ptr()
+        if g_h is not None:                                    # the colour branch's gradient wrt the last hidden activation
+            g_h = g_h.reshape(M, W).float().contiguous()
+            a.d_hidden_extra = g_h.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_backward")
         if not f32:
-            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *_Trunk._weight_grads_bf16(model, net, ctx.dims, pts4, acts, d_pre, g))
+            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *_Trunk._weight_grads_bf16(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views))
         # weight gradients: library GEMMs over the stored activations x_i and pre-activation gradients dz_i
         adt = acts.dtype
         L = (int(net.input_ch) - 3) // 6
@@ -158,6 +171,9 @@ class _Trunk(torch.autograd.Function):
             else:
                 dw = dwh[i - 1]
             grads += [dw, db[i]]
+        if ctx.views:                                          # head slot = alpha_linear: its gradient is the sigma channel's
+            grads += [_wgrad(g[:, 3:4].to(adt).contiguous(), acts[D - 1]), g[:, 3].sum(0, keepdim=True)]
+            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *grads)
         g_out = torch.zeros(M, C_out, dtype=torch.float32, device=dev)
         g_out[:, :4] = g
         grads += [_wgrad(g_out.to(adt), acts[D - 1]), g_out.sum(0)]
@@ -165,7 +181,7 @@ class _Trunk(torch.autograd.Function):
 
 
     @staticmethod
-    def _weight_grads_bf16(model, net, dims, pts4, acts, d_pre, g):
+    def _weight_grads_bf16(model, net, dims, pts4, acts, d_pre, g, views=False):
         """bf16 mode: every weight and bias gradient of the trunk from one call of nrnerf_trunk_wgrad over the two
         [block][feature][32 samples] arrays (reads each once; the library route read them twice and reduced d_pre a third
         time).  One record of partial sums per workgroup, added here with one reduction."""
@@ -203,6 +219,8 @@ class _Trunk(torch.autograd.Function):
             else:
                 dw = dwh[i - 1]
             grads += [dw, db[i]]
+        if views:                                              # head slot = alpha_linear (1 x W): the sigma channel's column
+            return grads + [dwo[:, 3:4].t().contiguous(), g[:, 3].sum(0, keepdim=True)]
         dw_out = torch.zeros(C_out, W, dtype=torch.float32, device=dev)                      # the 5th channel never reaches the loss
         dw_out[:4] = dwo[:, :4].t()
         g_out = torch.zeros(C_out, dtype=torch.float32, device=dev)
@@ -224,7 +242,29 @@ def _trunk_params(net):
     ps = []
     for lin in net.pts_linears:
         ps += [lin.weight, lin.bias]
-    return ps + [net.output_linear.weight, net.output_linear.bias]
+    head = net.alpha_linear if net.use_viewdirs else net.output_linear       # see _Trunk.forward
+    return ps + [head.weight, head.bias]
+
+
+def finite_difference_dirs(bent: torch.Tensor) -> torch.Tensor:
+    """NeRF.viewdirs_via_finite_differences (run_nerf_helpers.py:316-356, "backward" differences) on bent points [N,S,3],
+    under autograd: normalised p_j - p_{j-1} (eps added to the norm), sample 0 takes sample 1's direction."""
+    diff = bent[:, 1:, :] - bent[:, :-1, :]
+    diff = diff / (torch.norm(diff, dim=-1, keepdim=True) + 0.000001)
+    out = torch.empty_like(bent)
+    out[:, 1:, :] = diff
+    out[:, 0, :] = diff[:, 0, :]
+    return out
+
+
+def colour_branch(net, h_last, dirs):
+    """The colour branch of the view-dependent head (run_nerf_helpers.py:286-303) as library GEMMs on the module's own
+    parameters, under autograd: feature_linear, relu(views_linears[0]([feature, direction encoding])), rgb_linear.
+    h_last [N,S,W], dirs [N,S,3] -> rgb logits [N,S,3].  (The density branch, alpha_linear, is in the native trunk kernel.)"""
+    L = (int(net.input_ch_views) - 3) // 6
+    feature = F.linear(h_last, net.feature_linear.weight, net.feature_linear.bias)               # :286
+    hv = F.relu(F.linear(torch.cat([feature, posenc(dirs, L)], -1), net.views_linears[0].weight, net.views_linears[0].bias))   # :296-301
+    return F.linear(hv, net.rgb_linear.weight, net.rgb_linear.bias)                              # :303
 
 
 class _Composite(torch.autograd.Function):
@@ -620,8 +660,16 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
     for net in (network_fn, network_fine if N_importance > 0 else None):
         if net is None:
             continue
-        if getattr(net, "use_viewdirs", False) or getattr(net, "time_conditioned_baseline", False):
-            return "view-dependent head / time-conditioned baseline under autograd"
+        if getattr(net, "time_conditioned_baseline", False):
+            return "time-conditioned baseline under autograd"
+        if getattr(net, "use_viewdirs", False):
+            has_bender = R._bender_of(network_fn) is not None
+            if has_bender and not getattr(net, "approx_nonrigid_viewdirs", True):
+                return "view-dependent head with exact (Jacobian) view directions under autograd"
+            if int(net.W) != 256 or int(getattr(net, "input_ch_views", 0)) != 27:
+                return "view-dependent head on a non-default trunk under autograd"
+            if not has_bender and ray_batch.shape[-1] < 11:
+                return "use_viewdirs without view directions in the ray batch"
         if int(net.D) != 8 or int(net.W) not in (256, 128) or list(net.skips) != [4] or int(net.input_ch) != 63:
             return "non-default trunk under autograd"
     if N_samples < 2 or N_samples + N_importance > 256:
@@ -686,8 +734,18 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             bent = pts
         if detailed_output:
             details["input_pts"] = bent                                                      # rnh:270
-        raw4, raw = _Trunk.apply(bent, model, net, which, *_trunk_params(net))
-        return raw4, raw, details
+        if not net.use_viewdirs:
+            raw4, raw = _Trunk.apply(bent, model, net, which, *_trunk_params(net))
+            return raw4, raw, details
+        # view-dependent head (rnh:284-304): density natively, colour branch on the last hidden activation
+        sigma4, _, h_last = _Trunk.apply(bent, model, net, which, *_trunk_params(net))
+        if rb is not None:
+            dirs = finite_difference_dirs(bent)                                              # rnh:288-290 (approx_nonrigid_viewdirs)
+        else:
+            dirs = rays[:, None, 8:11].expand(N, ns, 3)                                      # train.py:73-76
+        rgb = colour_branch(net, h_last, dirs)
+        raw4 = sigma4 + F.pad(rgb, (0, 1))                                                   # cat[rgb, alpha] (rnh:304): sigma4[..., :3] == 0
+        return raw4, raw4.detach(), details
 
     raw4, raw, details = query(z_vals, network_fn, 0)
     noise_c = rnd.get("noise_coarse")

@@ -202,22 +202,30 @@ GRAD_PARAMS = {"bender": ["network.4.weight", "network.0.bias", "rigidity_networ
                "fine": ["pts_linears.7.bias", "output_linear.weight"]}
 
 
-def run_gradients(H, T, seed=0):
+GRAD_PARAMS_VIEWS = {"bender": ["network.4.weight", "network.0.bias", "rigidity_network.2.weight"],
+                     "coarse": ["pts_linears.0.bias", "alpha_linear.weight", "feature_linear.bias", "views_linears.0.weight", "rgb_linear.weight"],
+                     "fine": ["pts_linears.7.bias", "alpha_linear.bias", "feature_linear.weight", "views_linears.0.bias", "rgb_linear.bias"]}
+
+
+def run_gradients(H, T, seed=0, cfg_kw=None, grad_params=None):
     """Reference autograd through render() (the training data term, train.py:1560-1580 restricted to rgb): gradients of
-    sum(rgb_map) + sum(rgb0) wrt a few small parameters and the latent codes -- the yardstick for a future backward pass."""
-    cfg = SceneConfig(N_importance=64)
+    sum(rgb_map) + sum(rgb0) wrt a few small parameters and the latent codes -- the yardstick for a future backward pass.
+    ``cfg_kw``: scene settings beyond 64 + 64 samples (e.g. use_viewdirs=True: the view-dependent head with
+    finite-difference directions, whose gradient also reaches the bent points of neighbouring samples)."""
+    cfg = SceneConfig(N_importance=64, **(cfg_kw or {}))
+    grad_params = grad_params or GRAD_PARAMS
     scene = make_scene(cfg, seed)
     rays, latents = make_rays(16, seed, cfg)
     kw, rb, coarse, fine = reference_kwargs(H, T, scene)
     latents = latents.clone().requires_grad_(True)
     rgb, disp, acc, extras = T.render(rays[:, 0:3], rays[:, 3:6], chunk=32768,
-                                      additional_pixel_information={"ray_bending_latents": latents}, **kw)
+                                      additional_pixel_information={"ray_bending_latents": latents}, **kw)     # (viewdirs=None: render() derives them, train.py:377-381)
     loss = rgb.sum() + extras["rgb0"].sum()
     loss.backward()
     out = {"loss": loss.detach().numpy().astype(np.float64), "grad__latents": latents.grad.numpy()}
     for part, mod in (("bender", rb), ("coarse", coarse), ("fine", fine)):
         params = dict(mod.named_parameters())
-        for name in GRAD_PARAMS[part]:
+        for name in grad_params[part]:
             out[f"grad__{part}__{name}"] = params[name].grad.numpy()
     return out
 
@@ -323,6 +331,8 @@ def main():
             return
     if "--only-grads" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_64_64.npz"), **run_gradients(H, T))
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_viewdirs_64_64.npz"),
+                            **run_gradients(H, T, cfg_kw=dict(use_viewdirs=True), grad_params=GRAD_PARAMS_VIEWS))
         if "--only-grads" in sys.argv:
             return
     if "--only-train-step" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:

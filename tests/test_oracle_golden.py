@@ -74,7 +74,9 @@ def test_oracle_get_rays_matches_reference():
         assert torch.allclose(rd, torch.from_numpy(z[f"out__rays_d_{k}"]), rtol=0, atol=1e-7)
 
 
-def test_oracle_gradients_match_reference_autograd():
+@pytest.mark.parametrize("fixture,cfg_kw", [("gradients_64_64", {}), ("gradients_viewdirs_64_64", dict(use_viewdirs=True))],
+                         ids=["default", "viewdirs"])
+def test_oracle_gradients_match_reference_autograd(fixture, cfg_kw):
     """Groundwork for the backward pass: the oracle is differentiable torch code, and its
     gradients of sum(rgb_map) + sum(rgb0) wrt a few parameters and the latent codes equal what the reference's own
     autograd produced (tests/golden/gradients_64_64.npz, oracle/make_golden.py::run_gradients)."""
@@ -82,8 +84,8 @@ def test_oracle_gradients_match_reference_autograd():
     import numpy as np
     from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
     from tests.helpers import GOLDEN_DIR
-    ref = np.load(os.path.join(GOLDEN_DIR, "gradients_64_64.npz"))
-    cfg = SceneConfig(N_importance=64)
+    ref = np.load(os.path.join(GOLDEN_DIR, fixture + ".npz"))
+    cfg = SceneConfig(N_importance=64, **cfg_kw)
     scene = make_scene(cfg, 0)
     rays, latents = make_rays(16, 0, cfg)
     latents = latents.clone().requires_grad_(True)

@@ -45,7 +45,9 @@ def torch_ops_bender():
 
 
 @pytest.mark.gpu
-def test_gradients_match_reference_autograd_golden(torch_ops_bender):
+@pytest.mark.parametrize("fixture,cfg_kw", [("gradients_64_64", {}), ("gradients_viewdirs_64_64", dict(use_viewdirs=True))],
+                         ids=["default", "viewdirs"])
+def test_gradients_match_reference_autograd_golden(torch_ops_bender, fixture, cfg_kw):
     """fp32 mode: d(sum rgb_map + sum rgb0) wrt the latent codes and a few parameters of every network, against what the
     reference's own autograd produced on the CPU (train.render under grad, z_samples detached).
 
@@ -57,8 +59,8 @@ def test_gradients_match_reference_autograd_golden(torch_ops_bender):
     at the depths this path chose, EVERY tensor within 1e-4 of scale (measured 2e-6); (2) against the golden, within
     2e-3 of scale or 1.5 x the distance of the reference's own arithmetic on this device, whichever is larger."""
     from oracle import nrnerf_oracle as O
-    ref = np.load(os.path.join(GOLDEN_DIR, "gradients_64_64.npz"))
-    cfg = SceneConfig(N_importance=64)
+    ref = np.load(os.path.join(GOLDEN_DIR, fixture + ".npz"))
+    cfg = SceneConfig(N_importance=64, **cfg_kw)
     scene = make_scene(cfg, 0)
     rays, latents = make_rays(16, 0, cfg)
     rb, coarse, fine = _modules(scene)
@@ -66,7 +68,9 @@ def test_gradients_match_reference_autograd_golden(torch_ops_bender):
     R.set_precision("f32")
     out = R.batchify_rays(rays.to(DEV), {"ray_bending_latents": lat}, network_fn=coarse, network_fine=fine, network_query_fn=None,
                           N_samples=64, N_importance=64, perturb=0.0, raw_noise_std=0.0, retraw=True, _want_z_vals=True)
-    assert out["rgb_map"].requires_grad and out["rgb0"].requires_grad and out["raw"].shape == (16, 128, 5)
+    # (view-dependent head: the density branch in the native trunk kernel, the colour branch on its last hidden activation;
+    #  finite-difference directions of the bent points, whose gradient reaches the bender through neighbouring samples)
+    assert out["rgb_map"].requires_grad and out["rgb0"].requires_grad and out["raw"].shape == (16, 128, 4 if cfg.use_viewdirs else 5)
     loss = out["rgb_map"].sum() + out["rgb0"].sum()
     loss.backward()
     assert abs(float(loss.detach()) - float(ref["loss"])) < 1e-4 * abs(float(ref["loss"]))
@@ -156,8 +160,12 @@ def _loss(out, detailed):
                                                            (1.0, 1.0, True, dict(N_samples=48, N_importance=37)),
                                                            (1.0, 0.5, False, dict(N_importance=128, ray_bending=False)),
                                                            (1.0, 0.0, False, dict(N_importance=64, netwidth=128)),
-                                                           (0.0, 0.0, False, dict(N_importance=64, _lindisp=True, _white_bkgd=True))],
-                         ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128", "lindisp_white_bkgd"])
+                                                           (0.0, 0.0, False, dict(N_importance=64, _lindisp=True, _white_bkgd=True)),
+                                                           (1.0, 1.0, True, dict(N_samples=48, N_importance=37, use_viewdirs=True)),
+                                                           (0.0, 0.0, False, dict(N_importance=64, use_viewdirs=True, ray_bending=False)),
+                                                           (1.0, 0.5, False, dict(N_importance=64, use_viewdirs=True, bend_depth=7))],
+                         ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128", "lindisp_white_bkgd",
+                              "viewdirs_detailed_ragged", "viewdirs_no_bender", "config4_viewdirs_deep_bender"])
 @pytest.mark.parametrize("bender", ["torch_ops", "native"])
 def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, bender):
     """Every parameter of every network + the latent codes, fp32 mode, against the oracle's autograd (eager torch on the
@@ -230,11 +238,12 @@ def O_render_free(scene, rays, latents, perturb, noise, detailed, **flags):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("width,detailed", [(256, False), (128, False), (256, True)], ids=["w256", "w128", "w256_detailed_loss"])
-def test_bf16_gradients_point_the_same_way(width, detailed):
+@pytest.mark.parametrize("width,detailed,views", [(256, False, False), (128, False, False), (256, True, False), (256, False, True)],
+                         ids=["w256", "w128", "w256_detailed_loss", "w256_viewdirs"])
+def test_bf16_gradients_point_the_same_way(width, detailed, views):
     """bf16 training mode (bf16 activations and d z in block-tile layout, relu bit masks, trunk_wgrad): gradient direction and
     size against fp32 mode (row-major arrays, library weight-gradient GEMMs), both compiled trunk widths."""
-    cfg = SceneConfig(N_importance=64, netwidth=width)
+    cfg = SceneConfig(N_importance=64, netwidth=width, use_viewdirs=views)
     scene = make_scene(cfg, 1)
     rays, latents = make_rays(512, 3, cfg)
     grads = {}

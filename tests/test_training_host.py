@@ -75,7 +75,17 @@ def test_eligibility_of_training_calls():
     # rays that require a gradient (camera refinement): the kernels treat rays as data, so such a call must reach the
     # reference's autograd graph instead of coming back with a silently missing gradient
     assert "requires a gradient" in T.why_not_trainable(coarse, fine, 64, 64, False, False, OnGpuWithGrad)
-    assert "view-dependent" in T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu)
+    # view-dependent head: trains (density natively, colour branch as library GEMMs on the last hidden activation) with
+    # finite-difference directions; the exact-Jacobian directions and a ray batch without directions (no bender) do not
+    assert T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu) is None
+    cv.approx_nonrigid_viewdirs = fv.approx_nonrigid_viewdirs = False
+    assert "exact" in T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu)
+    cv.approx_nonrigid_viewdirs = fv.approx_nonrigid_viewdirs = True
+    _, cn, fn = build_modules(make_scene(SceneConfig(N_importance=64, use_viewdirs=True, ray_bending=False), 0))
+
+    class OnGpu8(OnGpu):
+        shape = (4, 8)
+    assert "without view directions" in T.why_not_trainable(cn, fn, 64, 64, False, False, OnGpu8)
     assert T.why_not_trainable(coarse, fine, 64, 64, True, False, OnGpu) is None                  # lindisp trains natively
     assert T.why_not_trainable(coarse, fine, 64, 64, False, True, OnGpu).startswith("pytest flag")
     assert T.why_not_trainable(coarse, fine, 200, 100, False, False, OnGpu) == "more than 256 samples per ray"
