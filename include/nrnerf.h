@@ -253,8 +253,8 @@ int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uni
  * Weight gradients are products over two arrays these calls fill: dW_i = d_pre[i]^T x_i with x_0 = encoding,
  * x_i = acts[i-1] (x_{skip+1} = [encoding, acts[skip]]), db_i = column sums of d_pre[i]; d W_out = d_raw^T acts[D-1].
  * fp32 mode: row-major arrays, the products are left to the caller's GEMM library; bf16 mode: nrnerf_trunk_wgrad, below.
- * Available (else NRNERF_ERR_UNSUPPORTED) for the trunks of width 256 and 128 without time conditioning (with the
- * view-dependent head: the density branch natively, the colour branch through d_hidden_extra; not with exact view
+ * Available (else NRNERF_ERR_UNSUPPORTED) for the trunks of width 256 and 128 (time-conditioned baseline: through
+ * ray_bias; with the view-dependent head: the density branch natively, the colour branch through d_hidden_extra; not with exact view
  * directions), fp32 or bf16 (a model created with NRNERF_PREC_F16 has no training kernels: unscaled f16 gradients
  * underflow; nonrigid_nerf_amd/training.py trains such a model through a bf16 handle). */
 typedef struct nrnerf_trunk_args {
@@ -278,6 +278,13 @@ typedef struct nrnerf_trunk_args {
     void* d_pre;                /* out: gradient wrt every layer's pre-activation, type and layout of acts (zero in the
                                    padded columns) */
     float* d_pts4;              /* out [M,4] gradient wrt the input points (xyz, 0) */
+    const float* ray_bias;      /* forward: [n_rays, 2, width] fp32 or NULL: per-ray vectors added to the pre-activations of
+                                   pts_linears[0] ([ray][0]) and pts_linears[skip + 1] ([ray][1]) for every sample of the ray.  The
+                                   time-conditioned baseline (run_nerf_helpers.py:207-209, 273-282) concatenates the ray's latent
+                                   code to those two layers' inputs; constant along the ray, that is W[:, latent columns] . latent,
+                                   which the caller forms (and differentiates); the library's images of such a model hold the
+                                   remaining columns.  The gradient wrt ray_bias[r][k] is the sum of d_pre[0 | skip + 1] over the
+                                   ray's samples */
     const float* d_hidden_extra;   /* [M, width] fp32 row-major or NULL: an extra gradient wrt the LAST hidden activation
                                    (relu output of pts_linears[depth-1]), added to head^T d_raw4 before the relu mask.  With the
                                    view-dependent head (run_nerf_helpers.py:284-304) the library's head slot holds alpha_linear:

@@ -99,7 +99,7 @@ class TrunkArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("which", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("pts4", C.c_void_p), ("acts", C.c_void_p), ("relu_mask", C.c_void_p),
                 ("raw4", C.c_void_p), ("raw", C.c_void_p), ("raw_ch", C.c_int32),
-                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p), ("d_hidden_extra", C.c_void_p)]
+                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p), ("ray_bias", C.c_void_p), ("d_hidden_extra", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):

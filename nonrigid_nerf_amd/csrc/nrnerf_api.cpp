@@ -108,9 +108,13 @@ const nrnerf_linear* layer_source(const nrnerf_model_desc& d, const nrnerf_mlp_d
 // with alpha_linear in output row 3, the sigma channel of raw4 -- the native trunk then yields the density logit, its
 // backward-data pass starts from alpha_linear^T d sigma, and the colour branch (feature / views / rgb layers) is added by
 // the caller through nrnerf_trunk_args.d_hidden_extra
+// tcb_shift (training of the time-conditioned baseline with architecture A = the plain trunk): the module's first layer
+// reads [encoding, latent] and its skip layer [encoding, latent, h] (rnh:207-209, 273-282); the latent columns act as a
+// per-ray bias (the latent is constant along a ray) that the caller supplies (nrnerf_trunk_args.ray_bias), so the images
+// hold the encoding and the hidden columns only: hidden column c of the skip layer sits tcb_shift columns further right.
 template <class SH, class A, bool HAS_BEND, bool VIEWS, bool TRUNK = true>
 void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr,
-               bool alpha_head = false) {
+               bool alpha_head = false, int tcb_shift = 0) {
     using PL = Plan<SH, A, HAS_BEND, VIEWS, TRUNK>;
     constexpr int KH = SH::KH;
     const Tables& T = PL::TB;
@@ -145,7 +149,8 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
                         const int i = lane & 31, h = lane >> 5;
                         const int row = orow(t, i);
                         for (int e = 0; e < KH; ++e) {
-                            const int col = in_col<SH, A>(sp.kind, s, h, e, lin->in_features);
+                            int col = in_col<SH, A>(sp.kind, s, h, e, lin->in_features - ((sp.kind == LK_TR_IN || sp.kind == LK_TR_SKIP) ? tcb_shift : 0));
+                            if (tcb_shift && sp.kind == LK_TR_SKIP && col >= 3 + 6 * A::L) col += tcb_shift;
                             const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
                             if (lay) {
                                 const size_t el = fi * (SH::FRAG_BYTES / SH::ELEM_BYTES) + (size_t)lane * KH + e;
@@ -179,7 +184,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
 // Transposed weights for the backward-data kernel (nrnerf_train.h): PlanB's layer list, fragment element
 // (tile t, row i, slab s, half h, element e) = W[y][x] with (y, x) from bwd_y / bwd_x.  No biases.
 template <class SH, class A>
-void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr) {
+void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr, int tcb_shift = 0) {
     using PL = PlanB<SH, A>;
     constexpr int KH = SH::KH;
     const Tables& T = PL::TB;
@@ -209,7 +214,8 @@ void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
                 uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 31, h = lane >> 5;
-                    const int x = bwd_x<SH, A>(sp.kind, t, i, lin->in_features);
+                    int x = bwd_x<SH, A>(sp.kind, t, i, lin->in_features - ((sp.kind == LK_B_IN || sp.kind == LK_B_SKIP) ? tcb_shift : 0));
+                    if (tcb_shift && sp.kind == LK_B_SKIP && x >= 3 + 6 * A::L) x += tcb_shift;      // see pack_pass
                     for (int e = 0; e < KH; ++e) {
                         const int y = ah ? (((2 * s + h) * KH + e == 3) ? 0 : -1) : bwd_y<SH, A>(sp.kind, s, h, e, lin->out_features);
                         const float w = (x < 0 || y < 0) ? 0.0f : lin->weight[(size_t)y * lin->in_features + x];
@@ -511,16 +517,22 @@ int pack_split(const nrnerf_model_desc& d, PackedPass& trunk, PackedPass& bend, 
 bool training_eligible(const nrnerf_model_desc& d, const nrnerf_model* m) {
     // (with the view-dependent head: finite-difference or ray directions -- the exact-Jacobian directions would need the
     //  bender differentiated twice inside the colour branch)
-    return !(m->views && m->exact) && (m->arch_id <= 1 || m->arch_id == 5) && !d.coarse->time_conditioned && d.precision != NRNERF_PREC_F16;
+    // (time-conditioned baseline, architecture 2: trained through the plain trunk's kernels, the latent columns of its two
+    //  input layers as per-ray biases -- pack_pass, tcb_shift)
+    return !(m->views && m->exact) && (m->arch_id <= 2 || m->arch_id == 5) && d.precision != NRNERF_PREC_F16;
+}
+int tcb_shift_of(const nrnerf_mlp_desc& mlp) {      // latent columns of a time-conditioned trunk (0: plain trunk)
+    return mlp.time_conditioned ? mlp.pts_linears[0].in_features - (3 + 6 * ArchDefault::L) : 0;
 }
 void pack_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPass& out, const FlatLayout* lay = nullptr) {
     const bool narrow = mlp.width == ArchNarrow::W;
+    const int ts = tcb_shift_of(mlp);
     if (d.precision == NRNERF_PREC_F32) {
-        if (narrow) pack_pass_bwd<ShapeF32, ArchNarrow>(mlp, d.precision, out, lay);
-        else pack_pass_bwd<ShapeF32, ArchDefault>(mlp, d.precision, out, lay);
+        if (narrow) pack_pass_bwd<ShapeF32, ArchNarrow>(mlp, d.precision, out, lay, ts);
+        else pack_pass_bwd<ShapeF32, ArchDefault>(mlp, d.precision, out, lay, ts);
     } else {
-        if (narrow) pack_pass_bwd<Shape16, ArchNarrow>(mlp, d.precision, out, lay);
-        else pack_pass_bwd<Shape16, ArchDefault>(mlp, d.precision, out, lay);
+        if (narrow) pack_pass_bwd<Shape16, ArchNarrow>(mlp, d.precision, out, lay, ts);
+        else pack_pass_bwd<Shape16, ArchDefault>(mlp, d.precision, out, lay, ts);
     }
 }
 int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t refresh_stream = nullptr, bool refresh = false,
@@ -534,12 +546,13 @@ int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t ref
         rc = refresh ? refresh_pass(bf, m->fine_bwd, refresh_stream) : upload_pass(bf, m->fine_bwd);
     }
     if (refresh && rc == NRNERF_OK && hipStreamSynchronize(refresh_stream) != hipSuccess) rc = NRNERF_ERR_HIP;   // host images die here
-    if (rc == NRNERF_OK && m->views) {       // trunk-only forward images with the alpha head
+    if (rc == NRNERF_OK && (m->views || d.coarse->time_conditioned)) {       // trunk-only forward images: alpha head / without the latent columns
         auto pack_train = [&](const nrnerf_mlp_desc& mlp, PackedPass& out) {
             nrnerf_model_desc d2 = d;
             d2.bender = nullptr;
-            if (d.precision == NRNERF_PREC_F32) pack_pass<ShapeF32, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, true);
-            else pack_pass<Shape16Fast, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, true);
+            const bool ah = mlp.use_viewdirs != 0;
+            if (d.precision == NRNERF_PREC_F32) pack_pass<ShapeF32, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, ah, tcb_shift_of(mlp));
+            else pack_pass<Shape16Fast, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, ah, tcb_shift_of(mlp));
         };
         PackedPass tc, tf;
         pack_train(*d.coarse, tc);
@@ -1041,14 +1054,14 @@ int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, Tr
     if (!bwd && (!a->raw4 || (a->raw && a->raw_ch != 4 && a->raw_ch != 5))) return NRNERF_ERR_INVALID;
     if (bwd && (!a->d_raw4 || !a->d_pre || !a->d_pts4)) return NRNERF_ERR_INVALID;
     const bool fine = a->which == 1;
-    const PassDev& fwd = m->views ? ((fine && !m->fine_is_coarse) ? m->fine_train : m->coarse_train)
+    const PassDev& fwd = m->coarse_train.stream ? ((fine && !m->fine_is_coarse) ? m->fine_train : m->coarse_train)
                                   : (m->has_bend ? (fine ? m->fine_trunk : m->coarse_trunk) : (fine ? m->fine : m->coarse));
     const PassDev& bw = (fine && !m->fine_is_coarse) ? m->fine_bwd : m->coarse_bwd;
     t = TrunkArgs{};
     t.pts4 = a->pts4; t.n_rays = a->n_rays; t.S = a->n_samples;
     t.wstream = bwd ? bw.stream : fwd.stream; t.bias = fwd.bias;
     t.raw4 = a->raw4; t.raw_out = a->raw; t.raw_ch = a->raw_ch;
-    t.acts = a->acts; t.d_raw4 = a->d_raw4; t.d_pre = a->d_pre; t.d_pts4 = a->d_pts4; t.d_h_extra = a->d_hidden_extra;
+    t.acts = a->acts; t.d_raw4 = a->d_raw4; t.d_pre = a->d_pre; t.d_pts4 = a->d_pts4; t.d_h_extra = a->d_hidden_extra; t.ray_bias = a->ray_bias;
     t.mask = (unsigned short*)a->relu_mask;
     if (m->precision != NRNERF_PREC_F32 && !t.mask) return NRNERF_ERR_INVALID;
     return NRNERF_OK;

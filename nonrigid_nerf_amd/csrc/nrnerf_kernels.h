@@ -114,6 +114,8 @@ struct TrunkArgs {
     void* acts;              // hidden activations: fp32 mode [D][M][W] float; bf16 mode [D][nblocks][W][32] bf16 (nrnerf_train.h)
     unsigned short* mask;    // bf16 mode: [D][nblocks][W/32][64] relu masks (forward writes, backward reads); fp32 mode: unused
     const float* d_raw4;     // backward in  [M,4]   (gradient wrt raw4; the 5th raw channel never reaches the loss)
+    const float* ray_bias;   // forward in   [n_rays][2][W] fp32 or nullptr: added to the pre-activations of pts_linears[0] and
+                             // pts_linears[skip + 1] of every sample of the ray (the latent columns of the time-conditioned baseline)
     const float* d_h_extra;  // backward in  [M][W] fp32 row-major or nullptr: added to the gradient wrt the last hidden activation
                              // (the colour branch of the view-dependent head, evaluated by the caller)
     void* d_pre;             // backward out [D][M][W] gradient wrt the pre-activations (float or bf16)

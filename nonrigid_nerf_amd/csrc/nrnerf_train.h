@@ -141,8 +141,20 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_fwd_tr
         frag ha[NH], hb[NH];
         Empty none;
         // epilogue of hidden layer LAYER: relu, keep for the backward pass, hand to the next layer
-        auto keep = [&](auto lc, auto tc, const f32x16& acc, auto& out) {
+        auto keep = [&](auto lc, auto tc, const f32x16& acc_in, auto& out) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
+            f32x16 acc = acc_in;
+            if constexpr (layer == 0 || layer == A::SKIP + 1) {
+                if (a.ray_bias) {       // per-ray bias (time-conditioned baseline): features of this lane's accumulator rows
+                    const float* rb = a.ray_bias + ((size_t)ray * 2 + (layer == 0 ? 0 : 1)) * A::W + 32 * t + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 bv = *(const f32x4*)(rb + 8 * q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[4 * q + k] += bv[k];
+                    }
+                }
+            }
             if constexpr (KH == 1) {
                 if (ok) {
                     const size_t row = ((size_t)layer * M + so) * A::W + 32 * t + 4 * h;

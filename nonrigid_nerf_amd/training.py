@@ -92,7 +92,7 @@ class _Trunk(torch.autograd.Function):
     """raw4 [N,S,4] (differentiable), raw [N,S,C] (the reference's "raw" key; no gradient) = NeRF trunk(points)."""
 
     @staticmethod
-    def forward(ctx, pts, model, net, which, *params):
+    def forward(ctx, pts, model, net, which, ray_bias, *params):
         N, S = int(pts.shape[0]), int(pts.shape[1])
         M, dev = N * S, pts.device
         D, W = int(net.D), int(net.W)
@@ -114,9 +114,13 @@ class _Trunk(torch.autograd.Function):
         a.which, a.n_rays, a.n_samples = int(which), N, S
         a.pts4, a.acts, a.raw4, a.raw, a.raw_ch = pts4.data_ptr(), acts.data_ptr(), raw4.data_ptr(), raw.data_ptr(), C_out
         a.relu_mask = None if f32 else mask.data_ptr()
+        if ray_bias is not None:        # time-conditioned baseline: W[:, latent columns] . latent of the two input layers, per ray
+            rbias = ray_bias.detach().to(torch.float32).contiguous()
+            assert tuple(rbias.shape) == (N, 2, W)
+            a.ray_bias = rbias.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_forward")
-        ctx.model, ctx.net, ctx.which, ctx.dims, ctx.views = model, net, int(which), (N, S, D, W, C_out), views
+        ctx.model, ctx.net, ctx.which, ctx.dims, ctx.views, ctx.tcb = model, net, int(which), (N, S, D, W, C_out), views, ray_bias is not None
         ctx.save_for_backward(*((pts4, acts) if f32 else (pts4, acts, mask)))
         ctx.mark_non_differentiable(raw)
         if not views:
@@ -148,8 +152,31 @@ class _Trunk(torch.autograd.Function):
             a.d_hidden_extra = g_h.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_backward")
+        skip1 = int(list(net.skips)[0]) + 1
+        g_bias = None
+        if ctx.tcb:             # gradient wrt the per-ray biases: d_pre of the two input layers summed over the ray's samples
+            if f32:
+                g_bias = torch.stack([d_pre[0].view(N, S, W).sum(1), d_pre[skip1].view(N, S, W).sum(1)], 1)
+            else:               # [block][feature][32 samples] tiles, zero in the padded columns
+                bpr = (S + 31) // 32
+                g_bias = torch.stack([d_pre[k].view(N, bpr, W, 32).float().sum((1, 3)) for k in (0, skip1)], 1)
+        n_lat = int(net.pts_linears[0].weight.shape[1]) - (3 + 6 * ((int(net.input_ch) - 3) // 6)) if ctx.tcb else 0
+
+        def widen(grads):       # time-conditioned baseline: the latent columns of the two input layers get their gradient through ray_bias
+            if not n_lat:
+                return grads
+            n_enc = int(net.input_ch)
+            for li in (0, skip1):
+                dw = grads[2 * li]
+                full = torch.zeros(dw.shape[0], dw.shape[1] + n_lat, dtype=dw.dtype, device=dw.device)
+                full[:, :n_enc] = dw[:, :n_enc]
+                if dw.shape[1] > n_enc:
+                    full[:, n_enc + n_lat:] = dw[:, n_enc:]
+                grads[2 * li] = full
+            return grads
         if not f32:
-            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *_Trunk._weight_grads_bf16(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views))
+            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias,
+                    *widen(_Trunk._weight_grads_bf16(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views)))
         # weight gradients: library GEMMs over the stored activations x_i and pre-activation gradients dz_i
         adt = acts.dtype
         L = (int(net.input_ch) - 3) // 6
@@ -173,11 +200,11 @@ class _Trunk(torch.autograd.Function):
             grads += [dw, db[i]]
         if ctx.views:                                          # head slot = alpha_linear: its gradient is the sigma channel's
             grads += [_wgrad(g[:, 3:4].to(adt).contiguous(), acts[D - 1]), g[:, 3].sum(0, keepdim=True)]
-            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *grads)
+            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias, *widen(grads))
         g_out = torch.zeros(M, C_out, dtype=torch.float32, device=dev)
         g_out[:, :4] = g
         grads += [_wgrad(g_out.to(adt), acts[D - 1]), g_out.sum(0)]
-        return (d_pts4.view(N, S, 4)[..., :3], None, None, None, *grads)
+        return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias, *widen(grads))
 
 
     @staticmethod
@@ -661,7 +688,8 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
         if net is None:
             continue
         if getattr(net, "time_conditioned_baseline", False):
-            return "time-conditioned baseline under autograd"
+            if R._bender_of(network_fn) is not None or int(net.W) != 256 or int(net.pts_linears[0].weight.shape[1]) != int(net.input_ch) + 32:
+                return "time-conditioned baseline with a bender / a non-default trunk under autograd"
         if getattr(net, "use_viewdirs", False):
             has_bender = R._bender_of(network_fn) is not None
             if has_bender and not getattr(net, "approx_nonrigid_viewdirs", True):
@@ -734,11 +762,20 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             bent = pts
         if detailed_output:
             details["input_pts"] = bent                                                      # rnh:270
+        ray_bias = None
+        if getattr(net, "time_conditioned_baseline", False):
+            # naive baseline (rnh:207-209, 273-282): the latent code is concatenated to the inputs of pts_linears[0] and of the
+            # skip layer; constant along a ray, so its columns act as per-ray biases W[:, latent columns] . latent -- formed here
+            # (library GEMMs under autograd: their backward yields the codes' and those columns' gradients), added in the kernel
+            n_enc, lat = int(net.input_ch), latents.to(torch.float32)
+            sk = int(list(net.skips)[0]) + 1
+            ray_bias = torch.stack([F.linear(lat, net.pts_linears[0].weight[:, n_enc:n_enc + lat.shape[1]]),
+                                    F.linear(lat, net.pts_linears[sk].weight[:, n_enc:n_enc + lat.shape[1]])], 1)
         if not net.use_viewdirs:
-            raw4, raw = _Trunk.apply(bent, model, net, which, *_trunk_params(net))
+            raw4, raw = _Trunk.apply(bent, model, net, which, ray_bias, *_trunk_params(net))
             return raw4, raw, details
         # view-dependent head (rnh:284-304): density natively, colour branch on the last hidden activation
-        sigma4, _, h_last = _Trunk.apply(bent, model, net, which, *_trunk_params(net))
+        sigma4, _, h_last = _Trunk.apply(bent, model, net, which, ray_bias, *_trunk_params(net))
         if rb is not None:
             dirs = finite_difference_dirs(bent)                                              # rnh:288-290 (approx_nonrigid_viewdirs)
         else:

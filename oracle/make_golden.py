@@ -207,6 +207,10 @@ GRAD_PARAMS_VIEWS = {"bender": ["network.4.weight", "network.0.bias", "rigidity_
                      "fine": ["pts_linears.7.bias", "alpha_linear.bias", "feature_linear.weight", "views_linears.0.bias", "rgb_linear.bias"]}
 
 
+GRAD_PARAMS_TCB = {"coarse": ["pts_linears.0.weight", "pts_linears.5.bias", "output_linear.weight"],
+                   "fine": ["pts_linears.5.weight", "pts_linears.0.bias", "output_linear.bias"]}
+
+
 def run_gradients(H, T, seed=0, cfg_kw=None, grad_params=None):
     """Reference autograd through render() (the training data term, train.py:1560-1580 restricted to rgb): gradients of
     sum(rgb_map) + sum(rgb0) wrt a few small parameters and the latent codes -- the yardstick for a future backward pass.
@@ -224,6 +228,8 @@ def run_gradients(H, T, seed=0, cfg_kw=None, grad_params=None):
     loss.backward()
     out = {"loss": loss.detach().numpy().astype(np.float64), "grad__latents": latents.grad.numpy()}
     for part, mod in (("bender", rb), ("coarse", coarse), ("fine", fine)):
+        if mod is None:
+            continue
         params = dict(mod.named_parameters())
         for name in grad_params[part]:
             out[f"grad__{part}__{name}"] = params[name].grad.numpy()
@@ -333,6 +339,8 @@ def main():
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_64_64.npz"), **run_gradients(H, T))
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_viewdirs_64_64.npz"),
                             **run_gradients(H, T, cfg_kw=dict(use_viewdirs=True), grad_params=GRAD_PARAMS_VIEWS))
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_time_conditioned_64_64.npz"),
+                            **run_gradients(H, T, cfg_kw=dict(ray_bending=False, time_conditioned_baseline=True), grad_params=GRAD_PARAMS_TCB))
         if "--only-grads" in sys.argv:
             return
     if "--only-train-step" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:

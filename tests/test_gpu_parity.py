@@ -409,8 +409,8 @@ def test_boundary_contract_errors_and_fallback():
         # ... and is taken by the native training path (nonrigid_nerf_amd/training.py), not handed to the reference
         out = FakeTrain.batchify_rays(rays0.to(DEV), api, network_fn=coarse, network_query_fn=None, N_samples=64)
         assert FakeTrain.calls == [] and out["rgb_map"].requires_grad
-        # a training call the native path has no kernels for (view-dependent head) still goes to the reference
-        cfgv = SceneConfig(N_importance=0, use_viewdirs=True)
+        # a training call the native path has no kernels for (exact Jacobian view directions) still goes to the reference
+        cfgv = SceneConfig(N_importance=0, use_viewdirs=True, approx_nonrigid_viewdirs=False)
         rbv, cv, _ = build_modules(make_scene(cfgv, 0), device=DEV)
         rv, lv = make_rays(8, 0, cfgv)
         out = FakeTrain.batchify_rays(rv.to(DEV), {"ray_bending_latents": lv.to(DEV)}, network_fn=cv, network_query_fn=None, N_samples=64)

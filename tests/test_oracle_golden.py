@@ -74,8 +74,9 @@ def test_oracle_get_rays_matches_reference():
         assert torch.allclose(rd, torch.from_numpy(z[f"out__rays_d_{k}"]), rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("fixture,cfg_kw", [("gradients_64_64", {}), ("gradients_viewdirs_64_64", dict(use_viewdirs=True))],
-                         ids=["default", "viewdirs"])
+@pytest.mark.parametrize("fixture,cfg_kw", [("gradients_64_64", {}), ("gradients_viewdirs_64_64", dict(use_viewdirs=True)),
+                                            ("gradients_time_conditioned_64_64", dict(ray_bending=False, time_conditioned_baseline=True))],
+                         ids=["default", "viewdirs", "time_conditioned"])
 def test_oracle_gradients_match_reference_autograd(fixture, cfg_kw):
     """Groundwork for the backward pass: the oracle is differentiable torch code, and its
     gradients of sum(rgb_map) + sum(rgb0) wrt a few parameters and the latent codes equal what the reference's own
@@ -92,6 +93,8 @@ def test_oracle_gradients_match_reference_autograd(fixture, cfg_kw):
     leaves = {}
     for part in ("bender", "coarse", "fine"):
         d = getattr(scene, part)
+        if d is None:
+            continue
         for k in d:
             d[k] = d[k].clone().requires_grad_(True)
             leaves[(part, k)] = d[k]
