@@ -404,16 +404,24 @@ def library_gemm_tflops(dev, precision):
         return None
 
 
-def kernel_source_sha16():
+def kernel_source_sha16(train=False):
     """Hash of the device code the rendering kernels are built from (csrc/*.h, *.hip: plans, kernels, launchers; the
     training-only kernels nrnerf_train* excluded): identifies the profiled kernels independently of the build (a rebuilt
-    .so need not be byte-identical) and of host-only edits (nrnerf_api.cpp)."""
+    .so need not be byte-identical) and of host-only edits (nrnerf_api.cpp).  ``train=True``: the same over ALL device
+    sources, training kernels included -- what the training profiles (profiles/*_train_*) are stamped with."""
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "nonrigid_nerf_amd", "csrc")
-    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hip")) and not f.startswith("nrnerf_train")):
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hip")) and (train or not f.startswith("nrnerf_train"))):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def _latest_profile(suffix):
+    """profiles/rNN<suffix> of the highest round on file."""
+    prof = os.path.join(REPO, "profiles")
+    names = sorted(n for n in os.listdir(prof) if n.endswith(suffix) and n[0] == "r" and n[1:3].isdigit())
+    return os.path.join(prof, names[-1]) if names else None
 
 
 def pmc_traffic(args):
@@ -421,18 +429,19 @@ def pmc_traffic(args):
     they come from separate ``rocprofv3 --pmc`` passes of this very command (tools/collect_profiles.sh), stored with the
     hash of the kernel sources they profiled.  Reported only when that hash matches the sources of this checkout and the
     workload is the profiled one; otherwise null (a stale number is worse than none)."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_fine.json")
-    if args.rays != 196608 or args.precision != "bf16" or not os.path.exists(path):
-        return None, "null: no rocprofv3 --pmc pass of this build and workload on file (profiles/r02_pmc_fine.json)"
+    path = _latest_profile("_pmc_fine.json")
+    if args.rays != 196608 or args.precision != "bf16" or not path:
+        return None, "null: no rocprofv3 --pmc pass of this build and workload on file (profiles/rNN_pmc_fine.json)"
+    name = os.path.relpath(path, REPO)
     try:
         with open(path) as f:
             j = json.load(f)
         if j.get("scene") != args.scene:
-            return None, f"null: profiles/r02_pmc_fine.json was collected on the {j.get('scene')} scene"
+            return None, f"null: {name} was collected on the {j.get('scene')} scene"
         if j.get("kernel_source_sha16") != kernel_source_sha16():
-            return None, "null: profiles/r02_pmc_fine.json was collected from different kernel sources"
+            return None, f"null: {name} was collected from different kernel sources"
         return float(j["fine"]["hbm_bytes_per_launch"]), ("bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from rocprofv3 --pmc passes "
-                                                          "of these kernel sources (profiles/r02_pmc_summary.txt); by design 1.21e9 (16 B/sample in + 16 B/sample out)")
+                                                          f"of these kernel sources ({name.replace('_pmc_fine.json', '_pmc_summary.txt')}); by design 1.21e9 (16 B/sample in + 16 B/sample out)")
     except Exception as e:
         return None, f"null: {type(e).__name__}"
 
@@ -459,11 +468,47 @@ def cpu_baseline(scene, cfg, args, rays_dev, latents_dev):
         t0 = time.perf_counter()
         O.batchify_rays(rays, latents, scene, chunk=1024)
         dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port",
+    port = {"value": round(n / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{n} rays of the same 64+128 workload, chunk 1024, torch {torch.__version__} CPU, "
                       f"{threads} threads of {os.cpu_count()} host cores, {dt:.1f} s",
             "port_vs_reference": "the unmodified reference (train.render) and this port were timed side by side on the build "
                                  "container (tools/cpu_reference_vs_port.py, BASELINE.md section 2): port/reference = 0.96-0.99"}
+    ref = reference_cpu_baseline(scene, rays, latents, threads)
+    if ref is None:
+        return port
+    ref["port_same_box"] = {"value": port["value"], "port_over_reference": round(port["value"] / ref["value"], 3)}
+    return ref
+
+
+def reference_cpu_baseline(scene, rays, latents, threads):
+    """The UNMODIFIED reference (train.render -> batchify_rays -> render_rays, CPU) on the same rays and weights -- only when
+    the operator points NRNERF_REFERENCE at a checkout of facebookresearch/nonrigid_nerf (the driver's GPU boxes carry none,
+    and nothing is read from a default path: then the port above is the baseline).  tools/with_reference.sh stages one."""
+    ref_dir = os.environ.get("NRNERF_REFERENCE")
+    if not ref_dir or not os.path.isfile(os.path.join(ref_dir, "train.py")):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(REPO, "oracle"))
+        import make_golden as G
+        old_get_device = torch.Tensor.get_device
+        H, T = G.import_reference()
+        try:
+            kw, rb, coarse, fine = G.reference_kwargs(H, T, scene)
+            n = rays.shape[0]
+            with torch.no_grad():
+                run = lambda m: T.render(rays[:m, 0:3], rays[:m, 3:6], chunk=1024, additional_pixel_information={"ray_bending_latents": latents[:m]}, **kw)
+                run(512)
+                t0 = time.perf_counter()
+                run(n)
+                dt = time.perf_counter() - t0
+        finally:
+            torch.Tensor.get_device = old_get_device
+        return {"value": round(n / dt, 1), "unit": "rays/s", "cores": threads, "kind": "reference",
+                "sample": f"{n} rays of the same 64+128 workload through the unmodified reference's train.render (chunk 1024, torch "
+                          f"{torch.__version__} CPU, {threads} threads of {os.cpu_count()} host cores, {dt:.1f} s); checkout at $NRNERF_REFERENCE"}
+    except Exception as e:                                                    # a broken checkout must not take the bench down
+        print(f"[bench] reference CPU baseline unavailable: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
 
 
 if __name__ == "__main__":

@@ -19,6 +19,6 @@ ls $OUT
 cd $R
 DB=$(find $OUT/stats -name "*.db" | head -1)
 python tools/rocprof_summary.py "$DB" > gpurun_out/${TAG}_kernel_stats.txt 2>&1
-python tools/pmc_summary.py $OUT/pmcA $OUT/pmcB $OUT/pmcC $OUT/pmcD > gpurun_out/${TAG}_pmc_summary.txt 2>&1
-cp profiles/r02_pmc_fine.json gpurun_out/${TAG}_pmc_fine.json    # pmc_summary.py writes it in place
+NRNERF_PROFILE_TAG=$TAG python tools/pmc_summary.py $OUT/pmcA $OUT/pmcB $OUT/pmcC $OUT/pmcD > gpurun_out/${TAG}_pmc_summary.txt 2>&1
+cp profiles/${TAG}_pmc_fine.json gpurun_out/${TAG}_pmc_fine.json    # pmc_summary.py writes it in place
 find $OUT -name "*.db" -delete

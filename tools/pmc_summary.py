@@ -5,7 +5,7 @@ on gfx950; FETCH_SIZE / WRITE_SIZE are in KiB.
 
     python tools/pmc_summary.py gpurun_out/pmcA gpurun_out/pmcB ... > profiles/r02_pmc_summary.txt
 
-Also writes profiles/r02_pmc_fine.json (per-pass medians + the hash of the kernel sources that were profiled + the bench
+Also writes profiles/<NRNERF_PROFILE_TAG, default r03>_pmc_fine.json (per-pass medians + the hash of the kernel sources that were profiled + the bench
 scene): bench.py reports roofline.traffic from it only while that hash matches the sources of the checkout it runs from.
 """
 import collections
@@ -78,7 +78,8 @@ def main(dirs):
     import bench
     out["kernel_source_sha16"] = bench.kernel_source_sha16()
     out["scene"] = os.environ.get("NRNERF_PROFILE_SCENE", "fitted")
-    json.dump(out, open(os.path.join(REPO, "profiles", "r02_pmc_fine.json"), "w"), indent=1)
+    tag = os.environ.get("NRNERF_PROFILE_TAG", "r03")
+    json.dump(out, open(os.path.join(REPO, "profiles", f"{tag}_pmc_fine.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

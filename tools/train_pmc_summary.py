@@ -7,7 +7,7 @@ import csv
 import glob
 import sys
 
-KERNELS = ("trunk_fwd_train", "trunk_bwd", "trunk_wgrad", "wgrad_operands", "bend_fwd_train", "bend_bwd", "bend_wgrad", "composite_bwd", "composite_kernel")
+KERNELS = ("trunk_fwd_train", "trunk_bwd", "trunk_wgrad", "wgrad_operands", "bend_fwd_train", "bend_bwd", "bend_div_fwd", "bend_div_bwd", "bend_wgrad", "composite_bwd", "composite_kernel")
 
 
 def collect(d):
@@ -24,8 +24,8 @@ def collect(d):
 
 def main():
     fetch, write, rays = collect(sys.argv[1]), collect(sys.argv[2]), int(sys.argv[3])
-    print(f"# HBM traffic of the training kernels, bf16 mode, {rays} rays x (64 + 128) per step; per launch = mean over the launches of 23 steps")
-    print(f"# (two launches per step of each trunk / bender kernel: coarse pass 64 samples per ray, fine pass 192)")
+    print(f"# HBM traffic of the training kernels, bf16 mode, {rays} rays x (64 + 64) per step, shipped recipe; per launch = mean over the launches of 23 steps")
+    print(f"# (two launches per step of each trunk / bender kernel: coarse pass 64 samples per ray, fine pass 128; bend_wgrad a third time for the divergence term)")
     print(f"{'kernel':18s} {'launches':>8s} {'avg us':>10s} {'read MB':>10s} {'write MB':>10s} {'TB/s':>8s}")
     for k in KERNELS:
         if k not in fetch and k not in write:
