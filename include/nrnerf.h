@@ -405,7 +405,8 @@ int nrnerf_bender_divergence_backward(const nrnerf_model* model, const nrnerf_di
  * NRNERF_WGRAD_STRIDE(depth, width) floats = dw_hidden [depth-1][width][width], dw_enc [2][width][64], dw_head^T [width][64],
  * db [depth+1][width] (row `depth` is scratch), so one sum over the first axis yields them all.  The 64-column products
  * (dw_enc, dw_head^T, db[0]) are cut into fewer, longer partial sums (they cost less per block: all workgroups of the
- * launch then finish together) and only fill the first records: the caller ZERO-FILLS `partials` before the call.
+ * launch then finish together) and only fill the first NRNERF_WGRAD_SHORT_PARTIALS(n_partials, width) records: the caller
+ * zero-fills at least dw_enc, dw_head^T, db[0] and db[depth] of the records beyond that (or simply all of `partials`).
  * enc / g_head: the encoding of the input points and the gradient wrt the head's outputs in the same block layout, bf16
  * [B][64][32]: scratch the caller allocates, filled by this call from pts4 and d_raw4 (the arrays given to
  * nrnerf_trunk_backward).
@@ -421,6 +422,9 @@ typedef struct nrnerf_wgrad_args {
                                    MI355X with one workgroup per CU */
     float* partials;            /* out [n_partials][NRNERF_WGRAD_STRIDE(depth, width)] */
 } nrnerf_wgrad_args;
+#define NRNERF_WGRAD_SHORT_PARTIALS(n_partials, width) \
+    ((((n_partials) * (2 * ((width) / 64) + 2) + (2 * ((width) / 64) + (width) / 32) / 2) / (2 * ((width) / 64) + (width) / 32)) < 1 ? 1 : \
+     (((n_partials) * (2 * ((width) / 64) + 2) + (2 * ((width) / 64) + (width) / 32) / 2) / (2 * ((width) / 64) + (width) / 32)))
 #define NRNERF_WGRAD_STRIDE(depth, width) (((depth) - 1) * (width) * (width) + 3 * (width) * 64 + ((depth) + 1) * (width))
 int nrnerf_trunk_wgrad(const nrnerf_model* model, const nrnerf_wgrad_args* args, void* hip_stream);
 

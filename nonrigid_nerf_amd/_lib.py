@@ -114,6 +114,12 @@ def wgrad_stride(depth: int, width: int) -> int:
     return (depth - 1) * width * width + 3 * width * 64 + (depth + 1) * width
 
 
+def wgrad_short_partials(n_partials: int, width: int) -> int:
+    """NRNERF_WGRAD_SHORT_PARTIALS of include/nrnerf.h"""
+    trw = width // 64
+    return min(n_partials, max(1, (n_partials * (2 * trw + 2) + (2 * trw + width // 32) // 2) // (2 * trw + width // 32)))
+
+
 class BenderArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("rays", C.c_void_p), ("ray_stride", C.c_int32),

@@ -1115,9 +1115,9 @@ int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* 
     w.nblocks = nblocks; w.pstride = NRNERF_WGRAD_STRIDE(D, W);
     // a 64-column job (encoding, head) loads 2 TR + 2 fragments per block and wave, a hidden-to-hidden one 2 TR + 2 TCW:
     // give it that share of the workgroups, so that all workgroups of the launch finish together
-    const int kh = a->n_partials, TRw = W / 64;
-    int kl = (kh * (2 * TRw + 2) + (2 * TRw + W / 32) / 2) / (2 * TRw + W / 32);
-    kl = kl < 1 ? 1 : (kl > kh ? kh : kl);
+    const int kh = a->n_partials;
+    int kl = NRNERF_WGRAD_SHORT_PARTIALS(kh, W);
+    kl = kl > kh ? kh : kl;
     int n = 0;
     for (int i = 1; i < D; ++i)                                     // hidden-to-hidden layers: the bulk, first in the grid
         w.job[n++] = WgradJob{dpre + i * layer, acts + (i - 1) * layer, W, dwh + (size_t)(i - 1) * W * W, db + (size_t)i * W, kh, 0};

@@ -219,7 +219,16 @@ class _Trunk(torch.autograd.Function):
         scratch = torch.empty(2, nblk, 64, 32, dtype=torch.bfloat16, device=dev)             # encoding / head-gradient tiles
         # records of partial sums; the launch has (D - 1) * kch + 3 * (10/16 or 12/16) kch workgroups: one per CU at most
         kch = max(1, min(nblk, (_num_cus(dev) * 16) // ((D - 1) * 16 + 3 * (10 if W == 256 else 12))))
-        parts = torch.zeros(kch, _lib.wgrad_stride(D, W), dtype=torch.float32, device=dev)
+        # only the records the kernel does not write need zeroing: the three 64-column products (and their bias rows) are cut
+        # into NRNERF_WGRAD_SHORT_PARTIALS <= kch partial sums (include/nrnerf.h); zero-filling the whole array was 74 MB per call
+        parts = torch.empty(kch, _lib.wgrad_stride(D, W), dtype=torch.float32, device=dev)
+        kl = _lib.wgrad_short_partials(kch, W)
+        if kl < kch:
+            o64 = (D - 1) * W * W
+            odb = o64 + 3 * W * 64
+            parts[kl:, o64:odb].zero_()
+            parts[kl:, odb:odb + W].zero_()
+            parts[kl:, odb + D * W:odb + (D + 1) * W].zero_()
         a = _lib.WgradArgs()
         a.struct_size = C.sizeof(_lib.WgradArgs)
         a.n_rays, a.n_samples, a.n_partials = N, S, kch

@@ -33,6 +33,7 @@ def test_header_compiles_as_c99_and_matches_the_ctypes_mirror(tmp_path):
                      '       offsetof(nrnerf_bender_args, d_latents));\n'
                      'printf("%zu %zu %zu %d %d %d\\n", sizeof(nrnerf_wgrad_args), sizeof(nrnerf_bender_wgrad_args), offsetof(nrnerf_wgrad_args, partials),\n'
                      '       (int)NRNERF_WGRAD_STRIDE(8, 256), (int)NRNERF_WGRAD_STRIDE(8, 128), (int)NRNERF_BENDER_WGRAD_SLOT);\n'
+                     'printf("%d %d %d\\n", (int)NRNERF_WGRAD_SHORT_PARTIALS(28, 256), (int)NRNERF_WGRAD_SHORT_PARTIALS(1, 256), (int)NRNERF_WGRAD_SHORT_PARTIALS(30, 128));\n'
                      'printf("%zu %zu %zu %zu %zu\\n", sizeof(nrnerf_divergence_args), offsetof(nrnerf_divergence_args, probe),\n'
                      '       offsetof(nrnerf_divergence_args, divergence), offsetof(nrnerf_divergence_args, g_divergence), offsetof(nrnerf_divergence_args, partials));\n'
                      'return 0; }\n')
@@ -46,6 +47,7 @@ def test_header_compiles_as_c99_and_matches_the_ctypes_mirror(tmp_path):
             C.sizeof(_lib.BenderArgs), _lib.BenderArgs.z.offset, _lib.BenderArgs.bent4.offset, _lib.BenderArgs.d_latents.offset,
             C.sizeof(_lib.WgradArgs), C.sizeof(_lib.BenderWgradArgs), _lib.WgradArgs.partials.offset,
             _lib.wgrad_stride(8, 256), _lib.wgrad_stride(8, 128), _lib.BENDER_WGRAD_SLOT,
+            _lib.wgrad_short_partials(28, 256), _lib.wgrad_short_partials(1, 256), _lib.wgrad_short_partials(30, 128),
             C.sizeof(_lib.DivergenceArgs), _lib.DivergenceArgs.probe.offset, _lib.DivergenceArgs.divergence.offset,
             _lib.DivergenceArgs.g_divergence.offset, _lib.DivergenceArgs.partials.offset]
     assert got == want, (got, want)
