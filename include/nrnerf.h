@@ -446,6 +446,12 @@ typedef struct nrnerf_composite_args {
     /* backward: gradients of the forward outputs (NULL = zero), gradient wrt raw4 */
     const float* g_rgb; const float* g_disp; const float* g_acc; const float* g_weights;
     float* d_raw4;              /* out [N,S,4] */
+    /* forward, n_importance > 0, both or neither: the importance samples on their own -- depths in sample order and the row
+     * each takes among the merged depths (the coarse depths keep their order in the remaining rows).  The bender is shared by
+     * both networks and the coarse depths are a subset of the merged ones, so a caller bends only these I samples for the
+     * fine pass and re-uses the coarse pass' bent points (as nrnerf_render's split-bender path does). */
+    float* z_new;               /* out [N,I] or NULL */
+    uint8_t* rank_new;          /* out [N,I] or NULL */
 } nrnerf_composite_args;
 int nrnerf_composite_forward(const nrnerf_composite_args* args, void* hip_stream);
 int nrnerf_composite_backward(const nrnerf_composite_args* args, void* hip_stream);

@@ -164,7 +164,7 @@ class CompositeArgs(C.Structure):
                 ("rgb", C.c_void_p), ("disp", C.c_void_p), ("acc", C.c_void_p), ("weights", C.c_void_p), ("alpha", C.c_void_p),
                 ("z_std", C.c_void_p), ("z_merged", C.c_void_p),
                 ("g_rgb", C.c_void_p), ("g_disp", C.c_void_p), ("g_acc", C.c_void_p), ("g_weights", C.c_void_p),
-                ("d_raw4", C.c_void_p)]
+                ("d_raw4", C.c_void_p), ("z_new", C.c_void_p), ("rank_new", C.c_void_p)]
 
 
 EXPORTS = {

@@ -1297,6 +1297,7 @@ int nrnerf_composite_forward(const nrnerf_composite_args* a, void* hip_stream) t
     if (a->n_rays == 0) return NRNERF_OK;
     if (!a->rays || a->ray_stride < 8 || !a->raw4 || !a->rgb || !a->disp || !a->acc) return NRNERF_ERR_INVALID;
     if (a->n_importance > 0 && !a->z_merged) return NRNERF_ERR_INVALID;
+    if ((a->z_new != nullptr) != (a->rank_new != nullptr)) return NRNERF_ERR_INVALID;
     int dev = 0;
     int rc = composite_device(a, &dev);
     if (rc != NRNERF_OK) return rc;
@@ -1307,6 +1308,7 @@ int nrnerf_composite_forward(const nrnerf_composite_args* a, void* hip_stream) t
     c.white_bkgd = a->white_bkgd; c.noise = a->noise; c.u = a->u; c.n_rays = a->n_rays; c.S = a->n_samples;
     c.n_importance = a->n_importance; c.rgb = a->rgb; c.disp = a->disp; c.acc = a->acc; c.z_std = a->z_std;
     c.z_out = a->z_merged; c.vis = a->weights; c.alpha = a->alpha;
+    if (a->n_importance > 0) { c.z_new = a->z_new; c.rank_new = a->rank_new; }
     return launch_composite(c, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 

@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
         auto split_out = [&](int idx, int rank, float depth) {
             if (!a.rank_new) return;
             if (idx < S) {
-                *(f32x4*)(a.split_bent_out + ((size_t)ray * n + rank) * 4) = *(const f32x4*)(a.split_bent_in + ((size_t)ray * S + idx) * 4);
+                if (a.split_bent_in)      // (training asks for the new samples' list only: nrnerf_composite_args.z_new / rank_new)
+                    *(f32x4*)(a.split_bent_out + ((size_t)ray * n + rank) * 4) = *(const f32x4*)(a.split_bent_in + ((size_t)ray * S + idx) * 4);
             } else {
                 a.rank_new[(size_t)ray * I + (idx - S)] = (uint8_t)rank;
                 a.z_new[(size_t)ray * I + (idx - S)] = depth;

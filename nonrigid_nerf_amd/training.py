@@ -317,6 +317,8 @@ class _Composite(torch.autograd.Function):
         rgb, disp, acc = torch.empty(N, 3, **f32), torch.empty(N, **f32), torch.empty(N, **f32)
         weights, alpha = torch.empty(N, S, **f32), torch.empty(N, S, **f32)
         z_std, z_merged = torch.empty(N if I > 0 else 0, **f32), torch.empty(N if I > 0 else 0, S + I, **f32)
+        z_new = torch.empty(N if I > 0 else 0, I, **f32)
+        rank_new = torch.empty(N if I > 0 else 0, I, dtype=torch.uint8, device=dev)
         a = _lib.CompositeArgs()
         a.struct_size = C.sizeof(_lib.CompositeArgs)
         a.n_rays, a.n_samples, a.n_importance = N, S, I
@@ -329,16 +331,17 @@ class _Composite(torch.autograd.Function):
         a.rgb, a.disp, a.acc, a.weights, a.alpha = rgb.data_ptr(), disp.data_ptr(), acc.data_ptr(), weights.data_ptr(), alpha.data_ptr()
         if I > 0:
             a.z_std, a.z_merged = z_std.data_ptr(), z_merged.data_ptr()
+            a.z_new, a.rank_new = z_new.data_ptr(), rank_new.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(_lib.load().nrnerf_composite_forward(C.byref(a), _stream(dev)), "nrnerf_composite_forward")
         ctx.white_bkgd = bool(white_bkgd)
         ctx.noise = noise
         ctx.save_for_backward(raw4, rays, z)
-        ctx.mark_non_differentiable(alpha, z_std, z_merged)
-        return rgb, disp, acc, weights, alpha, z_merged, z_std
+        ctx.mark_non_differentiable(alpha, z_std, z_merged, z_new, rank_new)
+        return rgb, disp, acc, weights, alpha, z_merged, z_std, z_new, rank_new
 
     @staticmethod
-    def backward(ctx, g_rgb, g_disp, g_acc, g_w, _g_alpha, _g_zm, _g_zs):
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, _g_alpha, _g_zm, _g_zs, _g_zn=None, _g_rn=None):
         raw4, rays, z = ctx.saved_tensors
         N, S = int(raw4.shape[0]), int(raw4.shape[1])
         dev = raw4.device
@@ -489,6 +492,35 @@ def bend_native(model, rb, rays, z, latents, details=True):
     if scaling is not None:
         masked = masked * scaling                                      # rnh:568-569
     return bent, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
+
+
+# True: the fine pass bends only its N_importance new samples and re-uses the coarse pass' bent points (render_rays_train);
+# False: it bends all S + I merged samples again, as the reference's graph does (same values, a third more bender work).
+SPLIT_FINE_BENDER = True
+
+
+def _merge_rows(coarse_parts, new_parts, rank_new, S, I):
+    """Per-sample tensors of the S coarse samples and of the I importance samples -> the same in merged-depth order
+    [N, S + I, .]: importance sample i goes to row rank_new[:, i] (nrnerf_composite_args.rank_new), the coarse samples fill the
+    other rows in order.  Gathers under autograd: each source tensor receives its rows' gradient (scatter-add)."""
+    N, dev = int(rank_new.shape[0]), rank_new.device
+    rk = rank_new.long()
+    is_new = torch.zeros(N, S + I, dtype=torch.bool, device=dev)
+    is_new.scatter_(1, rk, True)
+    idx_new = torch.zeros(N, S + I, dtype=torch.int64, device=dev)
+    idx_new.scatter_(1, rk, torch.arange(I, device=dev).expand(N, I))
+    idx_coarse = (torch.cumsum((~is_new).to(torch.int32), 1) - 1).clamp_(0, S - 1).long()
+
+    def merge(c, n):
+        if c is None:
+            return None
+        k = c.shape[-1]
+        return torch.where(is_new[..., None], n.gather(1, idx_new[..., None].expand(N, S + I, k)),
+                           c.gather(1, idx_coarse[..., None].expand(N, S + I, k)))
+    pts = merge(coarse_parts[0], new_parts[0])
+    bent = merge(coarse_parts[1], new_parts[1])
+    details = {k: merge(coarse_parts[2][k], new_parts[2][k]) for k in coarse_parts[2]}
+    return pts, bent, details
 
 
 # True: the bender's weight gradients come from nrnerf_bender_wgrad (one launch); False: from batched library GEMMs.
@@ -748,28 +780,37 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         _lib.check(model.lib.nrnerf_sample_depths(rays.data_ptr(), int(rays.shape[1]), u_c.data_ptr() if u_c is not None else None, N, S,
                                                   int(bool(lindisp)), z_vals.data_ptr(), _stream(dev)), "nrnerf_sample_depths")
 
-    def query(z, net, which):
+    def bend_samples(z):
+        """(points, bent points, bender details) of the samples at depths z [N, ns]; points only when something needs them."""
         native = rb is not None and NATIVE_BENDER
         ns = int(z.shape[1])
-        details = {}
+        pts, bd = None, {}
         if detailed_output or not native:
             pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]                    # :871-873 / 921-923
+        if rb is None:
+            return pts, pts, bd
+        if latents is None:
+            raise ValueError("ray_bending_latents are required with a ray bender")
+        if native:
+            bent, bd = bend_native(model, rb, rays, z, latents, details=detailed_output)
+        else:
+            lat = latents[:, None, :].expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)   # train.py:79-87
+            bent, bd = bend(rb, pts.reshape(-1, 3), lat.to(torch.float32))
+            bent = bent.reshape(N, ns, 3)
+        if detailed_output:
+            bd = {k: v.reshape(N, ns, -1) for k, v in bd.items()}
+        return pts, bent, bd
+
+    def query(z, net, which, bent_parts=None):
+        ns = int(z.shape[1])
+        details = {}
+        if bent_parts is None:
+            pts, bent, bd = bend_samples(z)
+        else:
+            pts, bent, bd = bent_parts
         if detailed_output:
             details["initial_input_pts"] = pts                                               # rnh:250-252
-        if rb is not None:
-            if latents is None:
-                raise ValueError("ray_bending_latents are required with a ray bender")
-            if native:
-                bent, bd = bend_native(model, rb, rays, z, latents, details=detailed_output)
-            else:
-                lat = latents[:, None, :].expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)   # train.py:79-87
-                bent, bd = bend(rb, pts.reshape(-1, 3), lat.to(torch.float32))
-                bent = bent.reshape(N, ns, 3)
-            if detailed_output:
-                details.update({k: v.reshape(N, ns, -1) for k, v in bd.items()})
-        else:
-            bent = pts
-        if detailed_output:
+            details.update(bd)
             details["input_pts"] = bent                                                      # rnh:270
         ray_bias = None
         if getattr(net, "time_conditioned_baseline", False):
@@ -793,18 +834,27 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         raw4 = sigma4 + F.pad(rgb, (0, 1))                                                   # cat[rgb, alpha] (rnh:304): sigma4[..., :3] == 0
         return raw4, raw4.detach(), details
 
-    raw4, raw, details = query(z_vals, network_fn, 0)
+    coarse_parts = bend_samples(z_vals)
+    raw4, raw, details = query(z_vals, network_fn, 0, coarse_parts)
     noise_c = rnd.get("noise_coarse")
     # :898, and -- same launch -- sample_pdf + merge (:910-920; no gradient: the reference detaches the samples)
-    rgb_map, disp_map, acc_map, weights, alpha, z_merged, z_std = _Composite.apply(raw4, rays, z_vals, noise_c, white_bkgd, I,
-                                                                                   rnd.get("u_fine"))
+    rgb_map, disp_map, acc_map, weights, alpha, z_merged, z_std, z_new, rank_new = _Composite.apply(raw4, rays, z_vals, noise_c, white_bkgd, I,
+                                                                                                    rnd.get("u_fine"))
     ret = {}
     if I > 0:
         rgb0, disp0, acc0, weights0, alpha0 = rgb_map, disp_map, acc_map, weights, alpha     # :902-908
         net_f = network_fine if network_fine is not None else network_fn                     # :925
-        raw4, raw, fine_details = query(z_merged, net_f, 1 if network_fine is not None else 0)
-        rgb_map, disp_map, acc_map, weights, alpha, _, _ = _Composite.apply(raw4, rays, z_merged, rnd.get("noise_fine"),
-                                                                            white_bkgd, 0, None)                # :943-950
+        fine_parts = None
+        if rb is not None and SPLIT_FINE_BENDER:
+            # The bender is shared by both networks (rnh:213-215) and the coarse depths are a subset of the merged depths
+            # (:920): bend only the I new samples and put every sample's point / bent point / details at its row among the
+            # merged depths (as nrnerf_render's split-bender path).  Same values as bending all S + I points again; the
+            # coarse samples' bender evaluation now receives the gradient of both passes in ONE backward call.
+            new_parts = bend_samples(z_new)
+            fine_parts = _merge_rows(coarse_parts, new_parts, rank_new, S, I)
+        raw4, raw, fine_details = query(z_merged, net_f, 1 if network_fine is not None else 0, fine_parts)
+        rgb_map, disp_map, acc_map, weights, alpha, _, _, _, _ = _Composite.apply(raw4, rays, z_merged, rnd.get("noise_fine"),
+                                                                                  white_bkgd, 0, None)          # :943-950
     ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)                          # :952
     if retraw:
         ret["raw"] = raw                                                                     # :953-954
