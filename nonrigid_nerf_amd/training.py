@@ -797,8 +797,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             lat = latents[:, None, :].expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)   # train.py:79-87
             bent, bd = bend(rb, pts.reshape(-1, 3), lat.to(torch.float32))
             bent = bent.reshape(N, ns, 3)
-        if detailed_output:
-            bd = {k: v.reshape(N, ns, -1) for k, v in bd.items()}
+        bd = {k: v.reshape(N, ns, -1) for k, v in bd.items()} if detailed_output else {}
         return pts, bent, bd
 
     def query(z, net, which, bent_parts=None):
