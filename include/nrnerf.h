@@ -336,7 +336,9 @@ int nrnerf_bender_backward(const nrnerf_model* model, const nrnerf_bender_args* 
  * launch: job j = layer j in the order network[0 .. depth-1], rigidity_network[0 .. rigidity_depth-1]; every job yields
  * n_partials partial sums (one per wave; the caller adds them) of  dW [64][64] (rows = the layer's outputs, columns = its
  * inputs; only [out_features][in_features] is meaningful) followed by db [64].  The first layers' input rows (point =
- * origin + direction * z, latent code) are formed from rays / latents / z as in nrnerf_bender_args. */
+ * origin + direction * z, latent code) are formed from rays / latents / z as in nrnerf_bender_args.  Contraction: exact
+ * fp32 for a model created with NRNERF_PREC_F32; otherwise the fp32 rows are rounded to bf16 in registers and contracted on
+ * the bf16 matrix pipe with fp32 accumulation (the gradients entering come out of a bf16 trunk there). */
 #define NRNERF_BENDER_WGRAD_SLOT (64 * 64 + 64)
 typedef struct nrnerf_bender_wgrad_args {
     uint32_t struct_size;       /* sizeof(nrnerf_bender_wgrad_args) */

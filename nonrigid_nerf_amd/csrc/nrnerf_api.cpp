@@ -1205,7 +1205,7 @@ int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a
     w.z = a->z; w.S = a->n_samples;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    return launch_bend_wgrad(w, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+    return launch_bend_wgrad(w, (hipStream_t)hip_stream, m->precision != NRNERF_PREC_F32) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
 namespace {
@@ -1276,7 +1276,7 @@ int nrnerf_bender_divergence_backward(const nrnerf_model* m, const nrnerf_diverg
                               a->dtz_out4 + 3, a->tacts_rigidity + (size_t)(RD - 2) * M * RW};
     w.njobs = n; w.nparts = a->n_partials; w.m = (long long)M; w.out = a->partials;
     w.S = 1;
-    e = launch_bend_wgrad(w, (hipStream_t)hip_stream);
+    e = launch_bend_wgrad(w, (hipStream_t)hip_stream, m->precision != NRNERF_PREC_F32);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 

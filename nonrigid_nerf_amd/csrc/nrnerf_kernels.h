@@ -178,7 +178,8 @@ struct BendWgradArgs {
     const float* latents; int lat_stride, lat;
     const float* z; int S;
 };
-hipError_t launch_bend_wgrad(const BendWgradArgs&, hipStream_t);
+// bf16_operands: round the fp32 rows to bf16 in registers and contract on the bf16 matrix pipe (models in bf16 / f16 mode)
+hipError_t launch_bend_wgrad(const BendWgradArgs&, hipStream_t, bool bf16_operands);
 
 // Divergence regulariser of the ray bender (compute_divergence_loss / divergence_approx, run_nerf_helpers.py:22-116):
 // d = e^T J e with J = d(masked offsets)/d(point), by ONE forward-mode tangent through both MLPs (the reference takes a

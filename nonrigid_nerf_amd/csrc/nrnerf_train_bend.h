@@ -613,6 +613,103 @@ __global__ void __launch_bounds__(256) bend_wgrad(const BendWgradArgs a) {
     }
 }
 
+// bf16 mode: the same products on v_mfma_f32_32x32x16_bf16 -- the fp32 rows are loaded exactly as above (the loads are
+// what the kernel is made of: 32 dwords per lane per 16 samples either way) and rounded to bf16 in registers, fp32
+// accumulation.  The fp32 MFMA form issues 32 MFMAs of 64 cycles per 16 samples and 64 x 64 product and was bound by them
+// (bend_wgrad 1.8 ms per launch at 16 384 rays for 0.9 ms of HBM time); here it is 4 MFMAs of 32 cycles.  Operand k of a
+// lane = 8 consecutive samples of one feature: element e of lane (i, h) of chunk c is sample 16 c + 8 h + e, column i.
+// The gradients entering these products come out of a bf16 trunk in this mode, so the rounding of the operands (2^-9
+// relative per element, averaged over the samples) is below what they carry already; fp32 mode keeps the kernel above.
+template <int UNUSED>
+__global__ void __launch_bounds__(256, 2) bend_wgrad16(const BendWgradArgs a) {
+    typedef PolBF16::frag frag;
+    const BendWgradJob jb = a.job[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    const int part = (int)blockIdx.x * 4 + wave;
+    const long long chunks = (a.m + 15) / 16;
+    const long long per = (chunks + a.nparts - 1) / a.nparts;
+    const long long c0 = (long long)part * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
+    const bool f1 = jb.f > 32, g1 = jb.g > 32;           // second row / column tile in use (wave-uniform)
+    const bool fa0 = i < jb.f, fa1 = 32 + i < jb.f, gb0 = i < jb.g, gb1 = 32 + i < jb.g;
+    f32x16 acc[2][2] = {{f32x16{}, f32x16{}}, {f32x16{}, f32x16{}}};
+    float bsum[2] = {0.0f, 0.0f};
+    for (int pass = 0; pass < (jb.dz2 ? 2 : 1); ++pass) {
+        const float* dzp = pass ? jb.dz2 : jb.dz;
+        const float* xp = pass ? jb.x2 : jb.x;
+        // rows beyond the end are clamped to the last row and zeroed afterwards (no predicated loads: every chunk is 32 plain
+        // dword loads off four row pointers)
+        const long long last = a.m - 1;
+        auto load = [&](long long c, float (&av)[8][2], float (&bv)[8][2]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                long long s = 16 * c + 8 * h + e;
+                const bool ok = s <= last;
+                s = ok ? s : last;
+                const float* dr = dzp + (size_t)s * jb.ldz + i;
+                const float a0 = fa0 ? dr[0] : 0.0f, a1 = fa1 ? dr[32] : 0.0f;
+                float b0, b1;
+                if (xp) {
+                    const float* xr = xp + (size_t)s * jb.ldx + i;
+                    b0 = gb0 ? xr[0] : 0.0f;
+                    b1 = gb1 ? xr[32] : 0.0f;
+                } else {                            // column c of [point (3), latent code]: as in bend_wgrad
+                    const long long ray = s / a.S;
+                    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+                    const float* lp = a.latents + (size_t)ray * a.lat_stride;
+                    b0 = gb0 ? ((i < 3) ? __fadd_rn(rp[i], __fmul_rn(rp[3 + i], a.z[s])) : lp[i - 3]) : 0.0f;
+                    b1 = gb1 ? lp[29 + i] : 0.0f;
+                }
+                av[e][0] = ok ? a0 : 0.0f; av[e][1] = ok ? a1 : 0.0f;
+                bv[e][0] = b0; bv[e][1] = b1;          // (a zero row of dz already removes the product)
+            }
+        };
+        auto compute = [&](const float (&av)[8][2], const float (&bv)[8][2]) {
+            frag fa[2], fb[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (pass == 0) {
+                    bsum[0] += av[e][0];
+                    bsum[1] += av[e][1];
+                }
+                fa[0][e] = (__bf16)av[e][0]; fa[1][e] = (__bf16)av[e][1];
+                fb[0][e] = (__bf16)bv[e][0]; fb[1][e] = (__bf16)bv[e][1];
+            }
+            acc[0][0] = PolBF16::mfma(fa[0], fb[0], acc[0][0]);
+            if (g1) acc[0][1] = PolBF16::mfma(fa[0], fb[1], acc[0][1]);
+            if (f1) {
+                acc[1][0] = PolBF16::mfma(fa[1], fb[0], acc[1][0]);
+                if (g1) acc[1][1] = PolBF16::mfma(fa[1], fb[1], acc[1][1]);
+            }
+        };
+        float av0[8][2], bv0[8][2], av1[8][2], bv1[8][2];
+        long long c = c0;
+        if (c < c1) load(c, av0, bv0);
+        while (c < c1) {
+            if (c + 1 < c1) load(c + 1, av1, bv1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(av0, bv0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 >= c1) break;
+            if (c + 2 < c1) load(c + 2, av0, bv0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(av1, bv1);
+            __builtin_amdgcn_sched_barrier(0);
+            c += 2;
+        }
+    }
+    float* out = a.out + ((size_t)part * a.njobs + blockIdx.y) * BEND_WGRAD_SLOT;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(32 * u + tile_row(r, h)) * 64 + 32 * v + i] = acc[u][v][r];
+        const float rs = bsum[u] + __shfl_xor(bsum[u], 32);
+        if (h == 0) out[64 * 64 + 32 * u + i] = rs;
+    }
+}
+
 template <class A, bool BWD>
 static hipError_t launch_bend_train(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
     using P = PolF32;

@@ -18,9 +18,10 @@ hipError_t NRN_CAT(launch_bend_div_bwd_a, NRN_ARCH)(const BendDivArgs& a, int nu
     return launch_bend_div<ArchById<NRN_ARCH>::type, true>(a, num_cus, stream);
 }
 #if NRN_ARCH == 0     // the weight-gradient kernel does not depend on the bender's depth: one copy
-hipError_t launch_bend_wgrad(const BendWgradArgs& a, hipStream_t stream) {
+hipError_t launch_bend_wgrad(const BendWgradArgs& a, hipStream_t stream, bool bf16_operands) {
     if (a.njobs <= 0 || a.nparts < 4 || a.nparts % 4 != 0 || a.m <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bend_wgrad<8>, dim3(a.nparts / 4, a.njobs), dim3(256), 0, stream, a);
+    if (bf16_operands) hipLaunchKernelGGL(bend_wgrad16<0>, dim3(a.nparts / 4, a.njobs), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(bend_wgrad<8>, dim3(a.nparts / 4, a.njobs), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 #endif
