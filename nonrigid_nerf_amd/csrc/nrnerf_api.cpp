@@ -23,6 +23,14 @@
 
 using namespace nrn;
 
+#ifndef NRN_WGRAD_SYNC_DEFAULT
+// pairs of blocks between workgroup barriers in trunk_wgrad (WgradArgs::sync_every; env NRNERF_WGRAD_SYNC, 0 = never).  Measured
+// at 16 384 rays (tools/experiments/wgrad_sync_sweep.sh): never 3.30 ms per launch, every 2 pairs 2.76, 8: 2.54, 32: 2.55, 128: 2.82,
+// 512: 3.09 -- the waves that share a fragment stay within L2's reach of each other, the barrier itself costs nothing because
+// the loads already requested stay in flight across it.
+#define NRN_WGRAD_SYNC_DEFAULT 16
+#endif
+
 // Nothing throws across the C ABI (include/nrnerf.h): every extern "C" body is a function-try-block that turns
 // std::bad_alloc (the packer's std::vector growth) into NRNERF_ERR_NOMEM and anything else -- the packer's
 // plan-consistency checks throw std::logic_error -- into NRNERF_ERR_INTERNAL.
@@ -1113,6 +1121,8 @@ int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* 
     const __bf16* dpre = (const __bf16*)a->d_pre;
     WgradArgs w{};
     w.nblocks = nblocks; w.pstride = NRNERF_WGRAD_STRIDE(D, W);
+    static const int wgrad_sync = [] { const char* e = std::getenv("NRNERF_WGRAD_SYNC"); return e ? std::atoi(e) : NRN_WGRAD_SYNC_DEFAULT; }();
+    w.sync_every = wgrad_sync;
     // a 64-column job (encoding, head) loads 2 TR + 2 fragments per block and wave, a hidden-to-hidden one 2 TR + 2 TCW:
     // give it that share of the workgroups, so that all workgroups of the launch finish together
     const int kh = a->n_partials;

@@ -225,6 +225,9 @@ constexpr int WGRAD_MAX_JOBS = 12;
 struct WgradArgs {
     WgradJob job[WGRAD_MAX_JOBS];
     int njobs, nwg;          // grid = nwg = sum of the jobs' kch
+    int sync_every;          // > 0: a workgroup barrier every that many pairs of blocks -- the four waves of a workgroup run free
+                             // and the two that share a fragment drift apart until the second request misses L2 (1.58 x the needed
+                             // HBM reads at 16 384 rays); a RARE barrier re-aligns them at next to no cost (one per block cost 15-45 %)
     long long nblocks;
     long long pstride;       // floats between consecutive partials (the caller adds the kch partials)
 };

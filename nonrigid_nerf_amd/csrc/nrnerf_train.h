@@ -432,7 +432,12 @@ __device__ __forceinline__ void trunk_wgrad_job(const WgradArgs& a, const WgradJ
     frag fa0[TR][2], fb0[TCW][2], fa1[TR][2], fb1[TCW][2];
     long long blk = c;
     if (blk < a.nblocks) load(blk, fa0, fb0);
+    int since_sync = 0;
     while (blk < a.nblocks) {
+        if (a.sync_every > 0 && ++since_sync >= a.sync_every) {      // all four waves have the same trip count: uniform
+            since_sync = 0;
+            __builtin_amdgcn_s_barrier();                            // (loads already requested stay in flight across it)
+        }
         // (scheduling fences keep the two halves of the loop apart: request block n + 1, then the 32 MFMAs of block n.
         //  Free-running on purpose: a workgroup barrier every 2 / 4 / 8 blocks removes the redundant HBM reads -- the waves
         //  that share fragments stay in step -- but costs 15-45 %: tools/experiments/README.md)
