@@ -267,7 +267,7 @@ typedef struct nrnerf_trunk_args {
                                    n_rays * ceil(n_samples / 32) blocks of 32 consecutive samples of a ray, the samples
                                    contiguous (columns beyond the ray's end: finite padding) -- the operand layout of
                                    nrnerf_trunk_wgrad */
-    void* relu_mask;            /* bf16 mode only: uint16 [depth][B][width/32][64], which values passed the relu; forward
+    void* relu_mask;            /* bf16 mode only: uint16 [depth][B][64 lanes][width/32], which values passed the relu; forward
                                    writes, backward reads (instead of acts) */
     /* forward */
     float* raw4;                /* out [M,4]  rgb + sigma logits (what nrnerf_composite_* consume) */

@@ -25,7 +25,7 @@
 // one feature = one 16-byte load, no transpose anywhere.  Lanes of samples beyond the ray's end hold finite activations
 // (those of the clamped sample) and zero gradients, so the padded columns contribute nothing.  The backward kernel does not
 // read the activations at all in this mode: the forward kernel also writes which values passed the relu, 16 bits per lane
-// and tile ([layer][block][tile][64 lanes] u16, 1/16 of the activations' bytes).
+// and tile, one record per lane and layer ([layer][block][64 lanes][W/32 tiles] u16, 1/16 of the activations' bytes).
 #pragma once
 #include "nrnerf_net_impl.h"
 
@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_fwd_tr
         constexpr int NH = NT_W * SP;
         frag ha[NH], hb[NH];
         Empty none;
+        unsigned mw = 0;                    // relu masks of the tile pair in flight
         // epilogue of hidden layer LAYER: relu, keep for the backward pass, hand to the next layer
         auto keep = [&](auto lc, auto tc, const f32x16& acc_in, auto& out) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
@@ -166,13 +167,19 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_fwd_tr
             }
             pack_tile<P, true, t>(acc, out);
             if constexpr (KH != 1) {
-                if (blk_ok) {
-                    store_tile_bf16((__bf16*)a.acts + (((size_t)layer * nblocks + b) * A::W + 32 * t + 4 * h) * 32 + j, out[t * SP], out[t * SP + 1]);
-                    unsigned m = 0;
+                if (blk_ok) store_tile_bf16((__bf16*)a.acts + (((size_t)layer * nblocks + b) * A::W + 32 * t + 4 * h) * 32 + j, out[t * SP], out[t * SP + 1]);
+                // which of this lane's 16 values passed the relu: all the backward kernel needs of the activations.  The NT_W
+                // tile masks of a layer form ONE 2 NT_W-byte record per lane and layer ([layer][block][lane][tile] u16), written a
+                // tile pair (one dword) at a time: the backward kernel reads a layer's record with one load -- 64 dependent
+                // two-byte loads per block cost it 0.9 ms per launch at 16 384 rays (probe: profiles/r03_train_store_probe.txt)
+                unsigned m = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m |= (acc[r] > 0.0f ? 1u : 0u) << r;
-                    // which of this lane's 16 values passed the relu: all the backward kernel needs of the activations
-                    a.mask[(((size_t)layer * nblocks + b) * NT_W + t) * 64 + lane] = (unsigned short)m;
+                for (int r = 0; r < 16; ++r) m |= (acc[r] > 0.0f ? 1u : 0u) << r;
+                if constexpr ((t & 1) == 0) {
+                    mw = m;
+                } else {                // tiles come in pairs (t - 1, t): one dword per pair
+                    mw |= m << 16;
+                    if (blk_ok) ((unsigned*)(a.mask + (((size_t)layer * nblocks + b) * 64 + lane) * NT_W))[t / 2] = mw;
                 }
             }
         };
@@ -262,6 +269,25 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
         constexpr int NH = NT_W * SP;
         frag ha[NH], hb[NH];
         Empty none;
+        // bf16 mode: the relu masks, one record of NT_W 16-bit tile masks per lane and layer (trunk_fwd_train), requested
+        // right before the transposed layer whose epilogue applies it: the load's latency hides behind that layer's MFMAs
+        // (in two halves of NT_W / 2 tiles -- the second one requested when the first has been used up, a tile pair's MFMAs
+        //  before it is needed: four registers held across a layer spilled two at this kernel's 128-register budget)
+        constexpr int MH = NT_W / 4;                                   // dwords per half record
+        unsigned mk[MH];
+        auto load_masks = [&](auto lc, auto hc) {
+            constexpr int layer = decltype(lc)::value, half = decltype(hc)::value;
+            if constexpr (KH != 1) {
+                const unsigned* mp = (const unsigned*)(a.mask + (((size_t)layer * nblocks + b) * 64 + lane) * NT_W) + half * MH;
+                if constexpr (MH == 2) {
+                    const unsigned long long v = *(const unsigned long long*)mp;
+                    mk[0] = (unsigned)v; mk[1] = (unsigned)(v >> 32);
+                } else {
+                    static_assert(MH == 1, "trunk widths 256 / 128");
+                    mk[0] = *mp;
+                }
+            }
+        };
         // epilogue producing d z_LAYER from tile t of d h_LAYER: mask with the saved activation, store, hand on
         auto mask_store = [&](auto lc, auto tc, const f32x16& acc, auto& out) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
@@ -276,8 +302,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
                     if (ok) store4<P>(a.d_pre, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
                 }
             } else {
-                // sign-extended so that bit r of the mask becomes "all ones or all zeros" with one shift: g = acc & that
-                const unsigned m = a.mask[(((size_t)layer * nblocks + b) * NT_W + t) * 64 + lane];
+                // this tile's 16 mask bits out of the layer's record (requested a layer ahead, see load_masks)
+                const unsigned m = (mk[(t / 2) % MH] >> (16 * (t & 1))) & 0xffffu;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     // bit r of the mask sign-extended to all ones / all zeros, ANDed in: two VALU per value and no condition
@@ -291,9 +317,11 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
             if constexpr (KH != 1) {
                 if (blk_ok)
                     store_tile_bf16((__bf16*)a.d_pre + (((size_t)layer * nblocks + b) * A::W + 32 * t + 4 * h) * 32 + j, out[t * SP], out[t * SP + 1]);
+                if constexpr (t == NT_W / 2 - 1) load_masks(lc, std::integral_constant<int, 1>{});      // second half of this layer's record
             }
         };
         // head^T: d h_{D-1}  (+ the caller's extra gradient wrt h_{D-1}: the colour branch of the view-dependent head)
+        load_masks(std::integral_constant<int, A::D - 1>{}, std::integral_constant<int, 0>{});
         dense<P, P, PL, 0, NS_DR, 0>(st, bias_lane, dr, none, [&](auto tc, const f32x16& acc) {
             constexpr int t = decltype(tc)::value;
             f32x16 g = acc;
@@ -315,6 +343,7 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
             constexpr int LI = PL::layer_of(i);
             constexpr bool skip = (i - 1 == A::SKIP);
             auto run = [&](auto& src, auto& dst) {
+                load_masks(std::integral_constant<int, i - 1>{}, std::integral_constant<int, 0>{});
                 if constexpr (skip) {
                     dense<P, P, PL, LI, NH, 0>(st, bias_lane, src, none, [&](auto tc, const f32x16& acc) {
                         constexpr int t = decltype(tc)::value;

@@ -99,10 +99,10 @@ class _Trunk(torch.autograd.Function):
         f32 = _is_f32(model)
         pts4 = _rows4(pts.detach(), M)               # the bender's own [M,4] rows when the points come from _Bender
         # saved activations.  fp32 mode: [layer][sample][width] for the library GEMMs; bf16 mode: [layer][block][width][32
-        # samples] for nrnerf_trunk_wgrad (blocks of 32 consecutive samples of a ray) + 16 relu bits per lane and tile
+        # samples] for nrnerf_trunk_wgrad (blocks of 32 consecutive samples of a ray) + 16 relu bits per lane and tile (one record per lane and layer)
         nblk = N * ((S + 31) // 32)
         acts = torch.empty(D, M, W, dtype=torch.float32, device=dev) if f32 else torch.empty(D, nblk, W, 32, dtype=torch.bfloat16, device=dev)
-        mask = None if f32 else torch.empty(D, nblk, W // 32, 64, dtype=torch.int16, device=dev)
+        mask = None if f32 else torch.empty(D, nblk, 64, W // 32, dtype=torch.int16, device=dev)
         raw4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         views = bool(net.use_viewdirs)
         # view-dependent head (rnh:284-304): the library's head slot holds alpha_linear (raw4[:, 3] = density logit, the colour
