@@ -181,15 +181,24 @@ __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
         if (ok && h == 0) *(f32x4*)(a.dz_out4 + so * 4) = f32x4{g_off[0], g_off[1], g_off[2], g_logit};
 
         // d h_layer tile t -> d z_layer (mask with the saved activation), stored for the weight gradients, handed on
-        auto mask_store = [&](const float* acts, float* dz, int width, auto lc, auto tc, const f32x16& acc, auto& out) {
+        // the saved activations of a layer (its relu mask), requested BEFORE the transposed layer whose epilogue applies them:
+        // loaded inside the epilogue, every tile waited a memory latency for them (same finding as trunk_bwd's masks)
+        f32x4 hv[2][4];                                    // [tile][q]: features 32 t + 8 q + 4 h .. + 3 of this lane's sample
+        auto fetch_acts = [&](const float* acts, int width, auto lc, auto ntc) {
+            constexpr int layer = decltype(lc)::value, nt = decltype(ntc)::value;
+#pragma unroll
+            for (int t = 0; t < nt; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[t][q] = load4<P>(acts, ((size_t)layer * M + so) * width + 32 * t + 4 * h + 8 * q);
+        };
+        auto mask_store = [&](const float*, float* dz, int width, auto lc, auto tc, const f32x16& acc, auto& out) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
             const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
             f32x16 g = acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 hv = load4<P>(acts, row + 8 * q);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) g[4 * q + k] = (hv[k] > 0.0f) ? acc[4 * q + k] : 0.0f;
+                for (int k = 0; k < 4; ++k) g[4 * q + k] = (hv[t][q][k] > 0.0f) ? acc[4 * q + k] : 0.0f;
                 if (ok) store4<P>(dz, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
             }
             pack_lin<P, t>(g, out);
@@ -202,12 +211,17 @@ __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
             dr.template set<s, 0>(h ? v1 : v0);
         });
         Act<P, NB, false> ba, bb;
+        constexpr auto NTB = std::integral_constant<int, PL::NT_BW>{};
+        constexpr auto NTR = std::integral_constant<int, PL::NT_RW>{};
+        static_assert(PL::NT_BW <= 2 && PL::NT_RW <= 2, "hv holds two tiles");
+        fetch_acts(a.acts_b, A::BW, std::integral_constant<int, A::BD - 2>{}, NTB);
         dense_b<P, false, PL, PL::L_BEND(A::BD - 1), NS_DR>(st, bias_lane, dr, [&](auto tc, const f32x16& acc) {
             mask_store(a.acts_b, a.dz_b, A::BW, std::integral_constant<int, A::BD - 2>{}, tc, acc, ba); });
         static_for<0, A::BD - 2>([&](auto kc) {
             constexpr int k = decltype(kc)::value;             // 0 .. BD-3
             constexpr int i = A::BD - 2 - k;                   // network[i]^T: d z_i -> d h_{i-1}
             auto run = [&](auto& src, auto& dst) {
+                fetch_acts(a.acts_b, A::BW, std::integral_constant<int, i - 1>{}, NTB);
                 dense_b<P, false, PL, PL::L_BEND(i), NB>(st, bias_lane, src, [&](auto tc, const f32x16& acc) {
                     mask_store(a.acts_b, a.dz_b, A::BW, std::integral_constant<int, i - 1>{}, tc, acc, dst); });
             };
@@ -232,12 +246,14 @@ __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
             drr.template set<s, 0>((s == 0 && h == 0) ? g_logit : 0.0f);
         });
         Act<P, NR, false> ra, rb;
+        fetch_acts(a.acts_r, A::RW, std::integral_constant<int, A::RD - 2>{}, NTR);
         dense_b<P, false, PL, PL::L_RIG(A::RD - 1), NS_DR>(st, bias_lane, drr, [&](auto tc, const f32x16& acc) {
             mask_store(a.acts_r, a.dz_r, A::RW, std::integral_constant<int, A::RD - 2>{}, tc, acc, ra); });
         static_for<0, A::RD - 2>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr int i = A::RD - 2 - k;                   // rigidity_network[i]^T, i >= 1
             auto run = [&](auto& src, auto& dst) {
+                fetch_acts(a.acts_r, A::RW, std::integral_constant<int, i - 1>{}, NTR);
                 dense_b<P, false, PL, PL::L_RIG(i), NR>(st, bias_lane, src, [&](auto tc, const f32x16& acc) {
                     mask_store(a.acts_r, a.dz_r, A::RW, std::integral_constant<int, i - 1>{}, tc, acc, dst); });
             };
@@ -439,18 +455,25 @@ __global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
             *(f32x4*)(a.dtz_out4 + so * 4) = f32x4{g_toff[0], g_toff[1], g_toff[2], g_tlogit};
         }
         // (d h, d th) of a hidden layer's tile -> (d z, d tz): both masked with the saved activation, stored, handed on
-        auto mask_store = [&](const float* acts, float* dz, float* dtz, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc,
+        f32x4 hv[2][4];                                    // the layer's saved activations, requested before its transposed layer (see bend_bwd)
+        auto fetch_acts = [&](const float* acts, int width, auto lc, auto ntc) {
+            constexpr int layer = decltype(lc)::value, nt = decltype(ntc)::value;
+#pragma unroll
+            for (int t = 0; t < nt; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[t][q] = load4<P>(acts, ((size_t)layer * M + so) * width + 32 * t + 4 * h + 8 * q);
+        };
+        auto mask_store = [&](const float*, float* dz, float* dtz, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc,
                               auto& out, auto& tout) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
             const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
             f32x16 gv = acc, gt = tacc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 hv = load4<P>(acts, row + 8 * q);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    gv[4 * q + k] = (hv[k] > 0.0f) ? acc[4 * q + k] : 0.0f;
-                    gt[4 * q + k] = (hv[k] > 0.0f) ? tacc[4 * q + k] : 0.0f;
+                    gv[4 * q + k] = (hv[t][q][k] > 0.0f) ? acc[4 * q + k] : 0.0f;
+                    gt[4 * q + k] = (hv[t][q][k] > 0.0f) ? tacc[4 * q + k] : 0.0f;
                 }
                 if (ok) {
                     store4<P>(dz, row + 8 * q, gv[4 * q], gv[4 * q + 1], gv[4 * q + 2], gv[4 * q + 3]);
@@ -472,12 +495,17 @@ __global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
         });
         Act<P, NB, false> ba, bb;
         Tan<P, NB> ta, tb;
+        constexpr auto NTB = std::integral_constant<int, PL::NT_BW>{};
+        constexpr auto NTR = std::integral_constant<int, PL::NT_RW>{};
+        static_assert(PL::NT_BW <= 2 && PL::NT_RW <= 2, "hv holds two tiles");
+        fetch_acts(a.acts_b, A::BW, std::integral_constant<int, A::BD - 2>{}, NTB);
         dense_b<P, false, PL, PL::L_BEND(A::BD - 1), NS_DR>(st, bias_lane, dr, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
             mask_store(a.acts_b, a.dz_b, a.dtz_b, A::BW, std::integral_constant<int, A::BD - 2>{}, tc, acc, tacc, ba, ta); }, tdr);
         static_for<0, A::BD - 2>([&](auto kc) {
             constexpr int k = decltype(kc)::value;             // 0 .. BD-3
             constexpr int i = A::BD - 2 - k;                   // network[i]^T: (d z_i, d tz_i) -> (d h_{i-1}, d th_{i-1})
             auto run = [&](auto& src, auto& tsrc, auto& dst, auto& tdst) {
+                fetch_acts(a.acts_b, A::BW, std::integral_constant<int, i - 1>{}, NTB);
                 dense_b<P, false, PL, PL::L_BEND(i), NB>(st, bias_lane, src, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
                     mask_store(a.acts_b, a.dz_b, a.dtz_b, A::BW, std::integral_constant<int, i - 1>{}, tc, acc, tacc, dst, tdst); }, tsrc);
             };
@@ -506,12 +534,14 @@ __global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
         });
         Act<P, NR, false> ra, rb;
         Tan<P, NR> tra, trb;
+        fetch_acts(a.acts_r, A::RW, std::integral_constant<int, A::RD - 2>{}, NTR);
         dense_b<P, false, PL, PL::L_RIG(A::RD - 1), NS_DR>(st, bias_lane, drr, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
             mask_store(a.acts_r, a.dz_r, a.dtz_r, A::RW, std::integral_constant<int, A::RD - 2>{}, tc, acc, tacc, ra, tra); }, tdrr);
         static_for<0, A::RD - 2>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr int i = A::RD - 2 - k;                   // rigidity_network[i]^T, i >= 1
             auto run = [&](auto& src, auto& tsrc, auto& dst, auto& tdst) {
+                fetch_acts(a.acts_r, A::RW, std::integral_constant<int, i - 1>{}, NTR);
                 dense_b<P, false, PL, PL::L_RIG(i), NR>(st, bias_lane, src, [&](auto tc, const f32x16& acc, const f32x16& tacc) {
                     mask_store(a.acts_r, a.dz_r, a.dtz_r, A::RW, std::integral_constant<int, i - 1>{}, tc, acc, tacc, dst, tdst); }, tsrc);
             };
