@@ -266,3 +266,31 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
               f"{float(l_hip.mean()):.6f}; per-ray loss within 1e-3: {float((rel < 1e-3).float().mean()):.3f}; calls reaching the reference's "
               f"render_rays / compute_divergence_loss after install: {reached}; {len(rows)} gradient tensors, min cosine "
               f"{min(c for _, c, _ in rows):.5f}; largest max-error / scale: " + "; ".join(f"{k[0]}.{k[1]} {e:.1e} (cos {c:.5f})" for e, c, k in rows[:6]))
+
+
+def test_install_rebinds_compute_divergence_loss_and_falls_back_without_a_gpu(reference):
+    """install() also rebinds ``train.compute_divergence_loss`` (star-imported from run_nerf_helpers, called at
+    train.py:266).  On CPU tensors the native kernels cannot take the call: it must reach the saved reference function with
+    every argument intact and return the reference's result (same seed, same probes)."""
+    from nonrigid_nerf_amd import render as R
+    from nonrigid_nerf_amd.synthetic import SceneConfig, make_scene
+    G, H, T = reference
+    scene = make_scene(SceneConfig(N_importance=64), 0)
+    kw, rb, coarse, fine = G.reference_kwargs(H, T, scene)
+    g = torch.Generator().manual_seed(3)
+    n_rays, S = 5, 7
+    pts = (torch.rand(n_rays * S, 3, generator=g) - 0.5)
+    lat = (torch.randn(n_rays, 32, generator=g) * 0.1).view(n_rays, 1, -1).expand(n_rays, S, 32).reshape(-1, 32)
+    w = torch.rand(n_rays * S, generator=g)
+    orig = T.compute_divergence_loss
+    torch.manual_seed(11)
+    want = orig(None, pts.clone(), lat, rb, False, 16, n_rays, weights=w, backprop_into_weights=False)
+    undo = R.install(T)
+    try:
+        assert T.compute_divergence_loss is not orig
+        torch.manual_seed(11)
+        got = T.compute_divergence_loss(None, pts.clone(), lat, rb, False, 16, n_rays, weights=w, backprop_into_weights=False)
+    finally:
+        undo()
+    assert T.compute_divergence_loss is orig
+    assert got.shape == (n_rays,) and torch.equal(got, want)

@@ -14,5 +14,7 @@ cfg = SceneConfig()
 for prec in ("bf16", "f32"):
     for n in (1024, 4096, 16384):
         r = training.bench_train_step(None, cfg, torch.device("cuda:0"), precision=prec, n_rays=n, steps=10 if n > 4096 else 30, warmup=3)
-        print(f"[{prec}] {n:6d} rays/step: {r['ms_per_step']:8.3f} ms/step, {r['rays_per_s'] / 1e3:8.1f} k rays/s, {r['roofline']['achieved']:7.1f} TFLOP/s "
-              f"({r['roofline']['frac']:.3f} of the {prec} MFMA peak for 3x forward flops)")
+        rf = r["roofline"]
+        print(f"[{prec}] {n:6d} rays/step (shipped recipe): {r['ms_per_step']:8.3f} ms/step, {r['rays_per_s'] / 1e3:8.1f} k rays/s; saved-array traffic "
+              f"{rf['achieved']:7.1f} GB/s ({rf['frac']:.3f} of HBM), {rf['mfma']['achieved']:7.1f} TFLOP/s ({rf['mfma']['frac']:.3f} of the {prec} MFMA peak); "
+              f"HIP graph {r['hip_graph'].get('ms_per_step')} ms; data-term-only step {r['data_term_only']['ms_per_step']} ms")
