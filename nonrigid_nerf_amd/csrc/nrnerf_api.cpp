@@ -452,8 +452,7 @@ struct nrnerf_model {
     // come from the stand-alone bender kernel) and the bender + rigidity layers alone
     PassDev fine_trunk, coarse_trunk, bend_only;
     bool split_ok = false;
-    // training (nrnerf_train.h): transposed trunk weights of both networks; train_ok: default architecture without
-    // view-dependent head / time conditioning, fp32 or bf16
+    // training (nrnerf_train.h): transposed trunk weights of both networks; train_ok: see training_eligible, fp32 or bf16
     PassDev coarse_bwd, fine_bwd;
     bool train_ok = false;
     // view-dependent head: forward images of the trunk alone with alpha_linear in the head slot (pack_pass, alpha_head)

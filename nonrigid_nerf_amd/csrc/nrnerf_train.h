@@ -1,10 +1,10 @@
 // nrnerf_train.h -- training support for the canonical NeRF trunk (reference NeRF.forward run_nerf_helpers.py:272-306 under
 // autograd; the training step is training_wrapper_class.forward + backward, train.py:152-287, 1594-1610).
 //
-// Two kernels, both built from the forward kernel's parts (weight ring, dense layer, in-register activation hand-off):
+// Forward and backward-data are built from the forward kernel's parts (weight ring, dense layer, in-register activation hand-off):
 //
 //   trunk_fwd_train   positional encoding + 8x256 trunk + head on ready-made points (the bent points: the deformation
-//                     MLPs stay in PyTorch autograd, their regularisers need double backward, run_nerf_helpers.py:22-116),
+//                     MLPs have kernels of their own, nrnerf_train_bend.h),
 //                     like the inference kernel, but every hidden activation h_i = relu(W_i x_i + b_i) is also written
 //                     to HBM, [layer][sample][256] in TRUE feature order: the D tile holds features 32t+8q+4h .. +3 of a
 //                     sample in four consecutive accumulator registers, i.e. 16 (fp32) or 8 (bf16) contiguous bytes.
@@ -12,9 +12,9 @@
 //                     nrnerf_plan.h): d h_{D-1} = W_out^T d raw, then for i = D-1 .. 1:  d z_i = d h_i * [h_i > 0]
 //                     (stored for the weight gradients),  d x_i = W_i^T d z_i  (x_5 = [encoding, h_4]: its first two tiles
 //                     are the encoding's gradient), finally d enc += W_0^T d z_0 and, through the derivative of the
-//                     encoding, the gradient wrt the input point.  The weight gradients  dW_i = d z_i^T x_i  are plain
-//                     [256 x K_samples] x [K_samples x 256] GEMMs over the two stored arrays and are left to the library
-//                     (hipBLASLt via torch.matmul in nonrigid_nerf_amd/training.py).
+//                     encoding, the gradient wrt the input point.
+//   trunk_wgrad       bf16 mode: the weight gradients  dW_i = d z_i^T x_i  and bias gradients of a trunk in one launch over
+//                     the two stored arrays (fp32 mode: plain [256 x K_samples] x [K_samples x 256] GEMMs, left to the library).
 // fp32 mode (exact, the gradient-parity mode) and bf16 mode (bf16 operands incl. the stored activations and d z).
 //
 // Layout of the stored arrays.  fp32 mode: [layer][sample][256], true feature order (the library GEMMs want rows of

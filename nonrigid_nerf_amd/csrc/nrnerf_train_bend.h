@@ -12,8 +12,8 @@
 //                    (summed per ray by the caller); second plan PlanBB = the layers reversed with transposed weights;
 //                    rigidity_network[0]^T and the xyz rows of network[0]^T are never formed (the sample positions carry
 //                    no gradient: the reference detaches z_samples and the rays are data).
-// Always fp32, whatever the trunk's precision: offsets feed a 2^9-frequency encoding.  First-order only -- the divergence
-// regulariser differentiates the REFERENCE MODULE's own forward a second time (run_nerf_helpers.py:41-58), not this path.
+// Always fp32, whatever the trunk's precision: offsets feed a 2^9-frequency encoding.  These two are first order; the
+// divergence regulariser (second order in autograd's terms) is bend_div_fwd / bend_div_bwd further down.
 #pragma once
 #include "nrnerf_bend.h"
 #include "nrnerf_train.h"

@@ -2,24 +2,30 @@
 train.py:152-287; backward + optimiser step, train.py:1594-1610); here the same call runs on the HIP library under
 ``torch.autograd``.
 
-What is native (C ABI ``nrnerf_trunk_forward / _backward``, ``nrnerf_composite_forward / _backward``, include/nrnerf.h):
-  * the canonical network -- positional encoding, 8x256 trunk, head -- forward with saved activations and the fused
-    backward-data pass on MFMA (csrc/nrnerf_train.h), fp32 or bf16;
+What is native (C ABI, include/nrnerf.h; kernels in csrc/nrnerf_train.h, csrc/nrnerf_train_bend.h, csrc/nrnerf_composite.hip):
+  * the canonical network -- positional encoding, 8x256 (or 8x128) trunk, head -- forward with saved activations, the fused
+    backward-data pass on MFMA and (bf16 mode) every weight / bias gradient in one launch (``nrnerf_trunk_forward / _backward /
+    _wgrad``), fp32 or bf16;
+  * the ray-bending and rigidity MLPs (35->64->64->64->64->3 and 3->32->32->1; ``nrnerf_bender_forward / _backward / _wgrad``):
+    forward with saved activations and backward-data in exact fp32, down to the latent codes; the fine pass bends only its
+    N_importance new samples and re-uses the coarse pass' bent points (SPLIT_FINE_BENDER);
+  * the divergence regulariser (compute_divergence_loss, run_nerf_helpers.py:22-116; second order in autograd's terms): one
+    forward-mode tangent through the bender and a two-chain backward (``nrnerf_bender_divergence_forward / _backward``);
   * compositing forward (raw2outputs, train.py:724-789), hierarchical sampling + merge (run_nerf_helpers.py:651-698,
-    train.py:910-920, no gradient: the reference detaches the sample positions) and the compositing backward.
-  * the ray-bending and rigidity MLPs (35->64->64->64->64->3 and 3->32->32->1; ``nrnerf_bender_forward / _backward``,
-    csrc/nrnerf_train_bend.h), always in exact fp32: forward with saved activations and backward-data down to the latent
-    codes.  First order only: the divergence regulariser (run_nerf_helpers.py:22-116) differentiates the reference
-    MODULE's own forward a second time (it is handed the module, not this path), the offsets regulariser only needs the
-    first-order outputs ``unmasked_offsets`` / ``rigidity_mask``.  ``NATIVE_BENDER = False`` runs these MLPs as torch ops on
-    the modules' parameters instead (double-differentiable; the gradient-parity tests use it because it reproduces the
-    reference's bent points bit for bit).
+    train.py:910-920, no gradient: the reference detaches the sample positions), the compositing backward, the coarse depths
+    (``nrnerf_composite_forward / _backward``, ``nrnerf_sample_depths``).
 What is left to libraries, as plumbing:
-  * the weight gradients ``dW_i = dz_i^T x_i``: plain [out x K] x [K x in] GEMMs over the two arrays the kernels fill
-    (``torch.bmm`` = hipBLASLt), and the bias gradients (column sums).
-Eligible: the default architecture (trunk width 256 or 128) without view-dependent head / time conditioning, precision fp32 or bf16
-(``render.set_precision``; "f16" trains in bf16: unscaled f16 gradients underflow).  Anything else is handed to the
-reference by ``render.render_rays`` as before.
+  * fp32 mode: the trunk's weight gradients ``dW_i = dz_i^T x_i``, plain [out x K] x [K x in] GEMMs over the two row-major
+    arrays the kernels fill (``torch.bmm`` = hipBLASLt), and the bias gradients (column sums);
+  * the colour branch of the view-dependent head (feature_linear, views_linears[0], rgb_linear) and its finite-difference
+    directions, as torch ops on the native trunk's last activation (``colour_branch``; the density branch is native);
+  * the two small GEMMs that turn a time-conditioned baseline's latent columns into per-ray biases.
+``NATIVE_BENDER = False`` runs the bender's MLPs as torch ops on the modules' parameters instead (the gradient-parity tests use
+it because it reproduces the reference's bent points bit for bit).
+Eligible: the compiled architectures (render.py / README.md) in precision fp32 or bf16 (``render.set_precision``; "f16" trains
+in bf16: unscaled f16 gradients underflow), except exact Jacobian view directions.  Anything else is handed to the reference
+by ``render.render_rays`` as before.  ``training_loss`` is the reference's whole iteration on these entry points,
+``GraphedStep`` the same captured in one HIP graph.
 """
 from __future__ import annotations
 
@@ -539,7 +545,7 @@ def _linear_rows(x, lin, B):
     """F.linear(x, W, b) for x [M, in] with M huge and in / out <= 64.  Written as a batched GEMM over B row blocks
     against the (stride-0) expanded weight: autograd then forms the weight gradient per block with one batched GEMM and
     adds the blocks (expand's backward), instead of one [out x M] x [M x in] GEMM that has a single output tile to work
-    on.  Pure torch ops, so double backward (divergence regulariser) still works."""
+    on.  Pure torch ops (double-differentiable)."""
     if B == 1:
         return F.linear(x, lin.weight, lin.bias)
     M = x.shape[0]
