@@ -318,14 +318,17 @@ typedef struct nrnerf_bender_args {
     /* forward writes, backward reads */
     float* bent4;               /* [M,4] bent point + rigidity mask (what nrnerf_trunk_args.pts4 takes; w ignored there) */
     float* off4;                /* [M,4] unmasked offsets + tanh of the rigidity logit */
-    float* acts_offsets;        /* [bender depth - 1][M][bender hidden] */
-    float* acts_rigidity;       /* [rigidity depth - 1][M][rigidity hidden] */
+    void* acts_offsets;         /* [bender depth - 1][M][bender hidden]; element type of this and the other SAVED arrays below */
+    void* acts_rigidity;        /* [rigidity depth - 1][M][rigidity hidden]  (acts_*, dz_offsets, dz_rigidity): fp32 for a model
+                                   created with NRNERF_PREC_F32, bf16 otherwise -- only nrnerf_bender_wgrad reads their values
+                                   (rounded to bf16 for the matrix pipe in that mode anyway); the backward-data chain runs in
+                                   fp32 registers and takes only the sign of an activation from them */
     /* backward */
     const float* g_bent4;       /* [M,4] gradient wrt the bent point (w ignored) */
     const float* g_unmasked_offsets;   /* [M,3] or NULL */
     const float* g_rigidity_mask;      /* [M] or NULL */
-    float* dz_offsets;          /* out, shape of acts_offsets: gradient wrt the hidden pre-activations */
-    float* dz_rigidity;         /* out, shape of acts_rigidity */
+    void* dz_offsets;           /* out, shape and element type of acts_offsets: gradient wrt the hidden pre-activations */
+    void* dz_rigidity;          /* out, shape and element type of acts_rigidity */
     float* dz_out4;             /* out [M,4] gradient wrt the offsets (xyz) and the rigidity logit (w) */
     float* d_latents;           /* out [M, latent_size] gradient wrt each sample's latent inputs */
 } nrnerf_bender_args;
@@ -346,8 +349,8 @@ typedef struct nrnerf_bender_wgrad_args {
     const float* rays; int32_t ray_stride;                                       /* as nrnerf_bender_args */
     const float* latents; int32_t latent_stride;
     const float* z;
-    const float* acts_offsets; const float* acts_rigidity;                       /* as nrnerf_bender_args */
-    const float* dz_offsets; const float* dz_rigidity; const float* dz_out4;     /* as nrnerf_bender_args */
+    const void* acts_offsets; const void* acts_rigidity;                         /* as nrnerf_bender_args: fp32 or bf16 */
+    const void* dz_offsets; const void* dz_rigidity; const float* dz_out4;       /* as nrnerf_bender_args */
     int32_t n_partials;         /* a multiple of 4, <= 4096 */
     float* partials;            /* out [n_partials][depth + rigidity_depth][NRNERF_BENDER_WGRAD_SLOT] */
 } nrnerf_bender_wgrad_args;
@@ -383,12 +386,13 @@ typedef struct nrnerf_divergence_args {
     float* divergence;          /* [M] */
     float* off4;                /* [M,4] unmasked offsets + tanh of the rigidity logit */
     float* toff4;               /* [M,4] their tangents (w: tangent of the logit) */
-    float* acts_offsets;  float* tacts_offsets;     /* [bender depth - 1][M][bender hidden]: activations / tangents */
-    float* acts_rigidity; float* tacts_rigidity;    /* [rigidity depth - 1][M][rigidity hidden] */
+    void* acts_offsets;  void* tacts_offsets;       /* [bender depth - 1][M][bender hidden]: activations / tangents; these saved */
+    void* acts_rigidity; void* tacts_rigidity;      /* [rigidity depth - 1][M][rigidity hidden]    arrays and dz_* / dtz_* below: fp32
+                                                       or bf16 as in nrnerf_bender_args */
     /* backward */
     const float* g_divergence;  /* [M] */
-    float* dz_offsets;  float* dtz_offsets;         /* out, shapes of acts_offsets */
-    float* dz_rigidity; float* dtz_rigidity;        /* out, shapes of acts_rigidity */
+    void* dz_offsets;  void* dtz_offsets;           /* out, shapes of acts_offsets */
+    void* dz_rigidity; void* dtz_rigidity;          /* out, shapes of acts_rigidity */
     float* dz_out4;  float* dtz_out4;               /* out [M,4] each */
     float* d_latents;           /* out [M, latent_size] */
     int32_t n_partials;         /* a multiple of 4, <= 4096 */

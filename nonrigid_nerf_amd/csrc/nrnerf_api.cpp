@@ -1176,8 +1176,9 @@ int nrnerf_bender_forward(const nrnerf_model* m, const nrnerf_bender_args* a, vo
     if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_fwd_train_a0(t, m->num_cus, (hipStream_t)hip_stream)
-                                           : launch_bend_fwd_train_a1(t, m->num_cus, (hipStream_t)hip_stream);
+    const bool b16 = m->precision != NRNERF_PREC_F32;        // element type of the saved arrays (nrnerf_bender_args)
+    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_fwd_train_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
+                                           : launch_bend_fwd_train_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
@@ -1188,8 +1189,9 @@ int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, v
     if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
-                                           : launch_bend_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream);
+    const bool b16 = m->precision != NRNERF_PREC_F32;
+    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
+                                           : launch_bend_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
@@ -1205,14 +1207,17 @@ int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a
     const size_t M = (size_t)a->n_rays * a->n_samples;
     BendWgradArgs w{};
     int n = 0;
-    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, nullptr, X0, X0};                                       // network[0]: input = [point, latent]
+    const int b16 = m->precision != NRNERF_PREC_F32;        // the saved arrays' element type; dz_out4 is fp32 in every mode
+    const size_t esz = b16 ? 2 : 4;
+    auto at = [&](const void* base, size_t elems) { return (const void*)((const char*)base + elems * esz); };
+    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, nullptr, X0, X0, nullptr, nullptr, b16, 0};            // network[0]: input = [point, latent]
     for (int i = 1; i <= BD - 2; ++i)
-        w.job[n++] = BendWgradJob{a->dz_offsets + (size_t)i * M * BW, BW, BW, a->acts_offsets + (size_t)(i - 1) * M * BW, BW, BW};
-    w.job[n++] = BendWgradJob{a->dz_out4, 4, 3, a->acts_offsets + (size_t)(BD - 2) * M * BW, BW, BW};        // network[BD-1]: 3 x BW
-    w.job[n++] = BendWgradJob{a->dz_rigidity, RW, RW, nullptr, X0, 3};                                       // rigidity_network[0]: input = the point
+        w.job[n++] = BendWgradJob{at(a->dz_offsets, (size_t)i * M * BW), BW, BW, at(a->acts_offsets, (size_t)(i - 1) * M * BW), BW, BW, nullptr, nullptr, b16, b16};
+    w.job[n++] = BendWgradJob{a->dz_out4, 4, 3, at(a->acts_offsets, (size_t)(BD - 2) * M * BW), BW, BW, nullptr, nullptr, 0, b16};   // network[BD-1]: 3 x BW
+    w.job[n++] = BendWgradJob{a->dz_rigidity, RW, RW, nullptr, X0, 3, nullptr, nullptr, b16, 0};             // rigidity_network[0]: input = the point
     for (int i = 1; i <= RD - 2; ++i)
-        w.job[n++] = BendWgradJob{a->dz_rigidity + (size_t)i * M * RW, RW, RW, a->acts_rigidity + (size_t)(i - 1) * M * RW, RW, RW};
-    w.job[n++] = BendWgradJob{a->dz_out4 + 3, 4, 1, a->acts_rigidity + (size_t)(RD - 2) * M * RW, RW, RW};   // the logit's layer: 1 x RW
+        w.job[n++] = BendWgradJob{at(a->dz_rigidity, (size_t)i * M * RW), RW, RW, at(a->acts_rigidity, (size_t)(i - 1) * M * RW), RW, RW, nullptr, nullptr, b16, b16};
+    w.job[n++] = BendWgradJob{a->dz_out4 + 3, 4, 1, at(a->acts_rigidity, (size_t)(RD - 2) * M * RW), RW, RW, nullptr, nullptr, 0, b16};   // the logit's layer: 1 x RW
     w.njobs = n; w.nparts = a->n_partials; w.m = (long long)M; w.out = a->partials;
     w.rays = a->rays; w.ray_stride = a->ray_stride; w.latents = a->latents; w.lat_stride = a->latent_stride; w.lat = m->latent_size;
     w.z = a->z; w.S = a->n_samples;
@@ -1253,8 +1258,9 @@ int nrnerf_bender_divergence_forward(const nrnerf_model* m, const nrnerf_diverge
     if (a->n_points == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_fwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
-                                                        : launch_bend_div_fwd_a1(t, m->num_cus, (hipStream_t)hip_stream);
+    const bool b16 = m->precision != NRNERF_PREC_F32;
+    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_fwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
+                                                        : launch_bend_div_fwd_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
@@ -1265,8 +1271,9 @@ int nrnerf_bender_divergence_backward(const nrnerf_model* m, const nrnerf_diverg
     if (a->n_points == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream)
-                                                  : launch_bend_div_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream);
+    const bool b16 = m->precision != NRNERF_PREC_F32;
+    hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
+                                                  : launch_bend_div_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     if (e != hipSuccess) return NRNERF_ERR_HIP;
     // weight / bias gradients: dW_i = dz_i^T h_{i-1} + dtz_i^T th_{i-1} (two products per job), db_i = column sums of dz_i
     const int BD = (bender_arch(m->arch_id) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
@@ -1274,19 +1281,22 @@ int nrnerf_bender_divergence_backward(const nrnerf_model* m, const nrnerf_diverg
     const size_t M = (size_t)a->n_points;
     BendWgradArgs w{};
     int n = 0;
-    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, a->points, 3, 3, a->dtz_offsets, a->probe};             // network[0][:, 0:3]: th_0 = e
-    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, a->latents, a->latent_stride, LAT, nullptr, nullptr};    // network[0][:, 3:]
+    const int s16 = b16 ? 1 : 0;                             // the saved arrays' element type; points / probes / latents / dz_out4: fp32
+    const size_t esz = b16 ? 2 : 4;
+    auto at = [&](const void* base, size_t elems) { return (const void*)((const char*)base + elems * esz); };
+    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, a->points, 3, 3, a->dtz_offsets, a->probe, s16, 0};                 // network[0][:, 0:3]: th_0 = e
+    w.job[n++] = BendWgradJob{a->dz_offsets, BW, BW, a->latents, a->latent_stride, LAT, nullptr, nullptr, s16, 0};        // network[0][:, 3:]
     for (int i = 1; i <= BD - 2; ++i)
-        w.job[n++] = BendWgradJob{a->dz_offsets + (size_t)i * M * BW, BW, BW, a->acts_offsets + (size_t)(i - 1) * M * BW, BW, BW,
-                                  a->dtz_offsets + (size_t)i * M * BW, a->tacts_offsets + (size_t)(i - 1) * M * BW};
-    w.job[n++] = BendWgradJob{a->dz_out4, 4, 3, a->acts_offsets + (size_t)(BD - 2) * M * BW, BW, BW,
-                              a->dtz_out4, a->tacts_offsets + (size_t)(BD - 2) * M * BW};
-    w.job[n++] = BendWgradJob{a->dz_rigidity, RW, RW, a->points, 3, 3, a->dtz_rigidity, a->probe};           // rigidity_network[0]
+        w.job[n++] = BendWgradJob{at(a->dz_offsets, (size_t)i * M * BW), BW, BW, at(a->acts_offsets, (size_t)(i - 1) * M * BW), BW, BW,
+                                  at(a->dtz_offsets, (size_t)i * M * BW), at(a->tacts_offsets, (size_t)(i - 1) * M * BW), s16, s16};
+    w.job[n++] = BendWgradJob{a->dz_out4, 4, 3, at(a->acts_offsets, (size_t)(BD - 2) * M * BW), BW, BW,
+                              a->dtz_out4, at(a->tacts_offsets, (size_t)(BD - 2) * M * BW), 0, s16};
+    w.job[n++] = BendWgradJob{a->dz_rigidity, RW, RW, a->points, 3, 3, a->dtz_rigidity, a->probe, s16, 0};               // rigidity_network[0]
     for (int i = 1; i <= RD - 2; ++i)
-        w.job[n++] = BendWgradJob{a->dz_rigidity + (size_t)i * M * RW, RW, RW, a->acts_rigidity + (size_t)(i - 1) * M * RW, RW, RW,
-                                  a->dtz_rigidity + (size_t)i * M * RW, a->tacts_rigidity + (size_t)(i - 1) * M * RW};
-    w.job[n++] = BendWgradJob{a->dz_out4 + 3, 4, 1, a->acts_rigidity + (size_t)(RD - 2) * M * RW, RW, RW,
-                              a->dtz_out4 + 3, a->tacts_rigidity + (size_t)(RD - 2) * M * RW};
+        w.job[n++] = BendWgradJob{at(a->dz_rigidity, (size_t)i * M * RW), RW, RW, at(a->acts_rigidity, (size_t)(i - 1) * M * RW), RW, RW,
+                                  at(a->dtz_rigidity, (size_t)i * M * RW), at(a->tacts_rigidity, (size_t)(i - 1) * M * RW), s16, s16};
+    w.job[n++] = BendWgradJob{a->dz_out4 + 3, 4, 1, at(a->acts_rigidity, (size_t)(RD - 2) * M * RW), RW, RW,
+                              a->dtz_out4 + 3, at(a->tacts_rigidity, (size_t)(RD - 2) * M * RW), 0, s16};
     w.njobs = n; w.nparts = a->n_partials; w.m = (long long)M; w.out = a->partials;
     w.S = 1;
     e = launch_bend_wgrad(w, (hipStream_t)hip_stream, m->precision != NRNERF_PREC_F32);

@@ -142,29 +142,33 @@ struct BendTrainArgs {
     Knobs knobs;
     float* bent4;            // [M,4] bent point xyz + rigidity mask (after the cutoff knob): forward writes, backward reads
     float* off4;             // [M,4] unmasked offsets xyz + tanh(rigidity logit):            forward writes, backward reads
-    float* acts_b;           // [BD-1][M][BW] hidden activations of the offset MLP
-    float* acts_r;           // [RD-1][M][RW] hidden activations of the rigidity MLP
+    // the saved arrays below are fp32 for an fp32 model and bf16 otherwise (`bf16_arrays` of the launchers): only the
+    // weight-gradient kernel reads their values (and rounds them to bf16 for the matrix pipe anyway in that mode), the
+    // backward-data chain stays in fp32 registers and takes nothing but the SIGN of an activation from them
+    void* acts_b;            // [BD-1][M][BW] hidden activations of the offset MLP
+    void* acts_r;            // [RD-1][M][RW] hidden activations of the rigidity MLP
     const float* g_bent4;    // backward in  [M,4] gradient wrt the bent point (w ignored)
     const float* g_unmasked; // backward in  [M,3] gradient wrt the unmasked offsets, or nullptr
     const float* g_mask;     // backward in  [M]   gradient wrt the rigidity mask, or nullptr
-    float* dz_b;             // backward out [BD-1][M][BW] gradient wrt the hidden pre-activations of the offset MLP
-    float* dz_r;             // backward out [RD-1][M][RW] ... of the rigidity MLP
+    void* dz_b;              // backward out [BD-1][M][BW] gradient wrt the hidden pre-activations of the offset MLP
+    void* dz_r;              // backward out [RD-1][M][RW] ... of the rigidity MLP
     float* dz_out4;          // backward out [M,4] gradient wrt the offsets (xyz) and the rigidity logit (w)
     float* d_lat;            // backward out [M,LAT] gradient wrt each sample's latent inputs
 };
-hipError_t launch_bend_fwd_train_a0(const BendTrainArgs&, int num_cus, hipStream_t);
-hipError_t launch_bend_fwd_train_a1(const BendTrainArgs&, int num_cus, hipStream_t);
-hipError_t launch_bend_bwd_a0(const BendTrainArgs&, int num_cus, hipStream_t);
-hipError_t launch_bend_bwd_a1(const BendTrainArgs&, int num_cus, hipStream_t);
+hipError_t launch_bend_fwd_train_a0(const BendTrainArgs&, int num_cus, hipStream_t, bool bf16_arrays);
+hipError_t launch_bend_fwd_train_a1(const BendTrainArgs&, int num_cus, hipStream_t, bool bf16_arrays);
+hipError_t launch_bend_bwd_a0(const BendTrainArgs&, int num_cus, hipStream_t, bool bf16_arrays);
+hipError_t launch_bend_bwd_a1(const BendTrainArgs&, int num_cus, hipStream_t, bool bf16_arrays);
 
 // weight gradients of the bender / rigidity MLPs (bend_wgrad, nrnerf_train_bend.h): products dz^T x over the samples of
 // row-major fp32 arrays, at most 64 x 64 each
 struct BendWgradJob {
-    const float* dz; int ldz, f;      // [M][ldz], the first f <= 64 columns: gradient wrt a layer's pre-activations
-    const float* x;  int ldx, g;      // [M][ldx], the first g <= 64 columns: that layer's input; nullptr: the offset MLP's input
+    const void* dz; int ldz, f;       // [M][ldz], the first f <= 64 columns: gradient wrt a layer's pre-activations
+    const void* x;  int ldx, g;       // [M][ldx], the first g <= 64 columns: that layer's input; nullptr: the offset MLP's input
                                       // row [point, latent code], formed on the fly from the ray records (BendWgradArgs)
-    const float* dz2; const float* x2;   // optional second product of the same shapes, added into the same dW (not into db):
-                                      // the tangent chain of the divergence regulariser (bend_div_bwd), or nullptr
+    const void* dz2; const void* x2;  // optional second product of the same shapes and element types, added into the same dW (not
+                                      // into db): the tangent chain of the divergence regulariser (bend_div_bwd), or nullptr
+    int dz16, x16;                    // 1: the array's elements are bf16 (the saved arrays of a bf16 / f16 model), 0: fp32
 };
 constexpr int BEND_WGRAD_MAX_JOBS = 16;
 constexpr int BEND_WGRAD_SLOT = 64 * 64 + 64;       // floats per (partial, job): dW [64][64] then db [64]
@@ -196,19 +200,19 @@ struct BendDivArgs {
     float* div;              // forward out [M]
     float* off4;             // [M,4] unmasked offsets xyz + tanh(rigidity logit):                 forward writes, backward reads
     float* toff4;            // [M,4] tangent of the offsets xyz + tangent of the rigidity logit:  forward writes, backward reads
-    float* acts_b;  float* tacts_b;   // [BD-1][M][BW] hidden activations / their tangents (after the relu mask)
-    float* acts_r;  float* tacts_r;   // [RD-1][M][RW]
+    void* acts_b;  void* tacts_b;     // [BD-1][M][BW] hidden activations / their tangents (after the relu mask); fp32 or bf16 as in
+    void* acts_r;  void* tacts_r;     // [RD-1][M][RW]                                                            BendTrainArgs
     const float* g_div;      // backward in [M]
-    float* dz_b;  float* dtz_b;       // backward out [BD-1][M][BW] gradient wrt the hidden pre-activations / their tangents
-    float* dz_r;  float* dtz_r;       // backward out [RD-1][M][RW]
+    void* dz_b;  void* dtz_b;         // backward out [BD-1][M][BW] gradient wrt the hidden pre-activations / their tangents
+    void* dz_r;  void* dtz_r;         // backward out [RD-1][M][RW]
     float* dz_out4;          // backward out [M,4] gradient wrt the offsets (xyz) and the rigidity logit (w)
     float* dtz_out4;         // backward out [M,4] ... wrt their tangents
     float* d_lat;            // backward out [M,LAT] gradient wrt each point's latent inputs
 };
-hipError_t launch_bend_div_fwd_a0(const BendDivArgs&, int num_cus, hipStream_t);
-hipError_t launch_bend_div_fwd_a1(const BendDivArgs&, int num_cus, hipStream_t);
-hipError_t launch_bend_div_bwd_a0(const BendDivArgs&, int num_cus, hipStream_t);
-hipError_t launch_bend_div_bwd_a1(const BendDivArgs&, int num_cus, hipStream_t);
+hipError_t launch_bend_div_fwd_a0(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);
+hipError_t launch_bend_div_fwd_a1(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);
+hipError_t launch_bend_div_bwd_a0(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);
+hipError_t launch_bend_div_bwd_a1(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);
 
 // weight gradients of the trunk, bf16 mode (trunk_wgrad, nrnerf_train.h): a list of products  dz^T x  over the samples
 struct WgradJob {

@@ -31,7 +31,8 @@ __device__ __forceinline__ void pack_lin(const f32x16& acc, ACT& out) {      // 
     });
 }
 
-template <class A>
+// SA: element type of the saved arrays (PolF32: fp32, exact; PolBF16: bf16 -- see BendTrainArgs)
+template <class A, class SA>
 __global__ void __launch_bounds__(256, 2) bend_fwd_train(const BendTrainArgs a) {
     using P = PolF32;
     using PL = Plan<P, A, true, false, false>;
@@ -77,13 +78,13 @@ __global__ void __launch_bounds__(256, 2) bend_fwd_train(const BendTrainArgs a) 
             bin.template set<s, 0>(h ? v1 : v0);
         });
         // hidden activation of layer `layer`: keep (true feature order) and hand on
-        auto keep = [&](float* base, int width, auto lc, auto tc, const f32x16& acc, auto& out) {
+        auto keep = [&](void* base, int width, auto lc, auto tc, const f32x16& acc, auto& out) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
             if (ok) {
                 const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    store4<P>(base, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]), relu_bits(acc[4 * q + 3]));
+                    store4<SA>(base, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]), relu_bits(acc[4 * q + 3]));
             }
             pack_act<P, t>(acc, out);
         };
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(256, 2) bend_fwd_train(const BendTrainArgs a) 
     }
 }
 
-template <class A>
+template <class A, class SA>
 __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
     using P = PolF32;
     using PL = PlanBB<P, A>;
@@ -184,14 +185,14 @@ __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
         // the saved activations of a layer (its relu mask), requested BEFORE the transposed layer whose epilogue applies them:
         // loaded inside the epilogue, every tile waited a memory latency for them (same finding as trunk_bwd's masks)
         f32x4 hv[2][4];                                    // [tile][q]: features 32 t + 8 q + 4 h .. + 3 of this lane's sample
-        auto fetch_acts = [&](const float* acts, int width, auto lc, auto ntc) {
+        auto fetch_acts = [&](const void* acts, int width, auto lc, auto ntc) {
             constexpr int layer = decltype(lc)::value, nt = decltype(ntc)::value;
 #pragma unroll
             for (int t = 0; t < nt; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hv[t][q] = load4<P>(acts, ((size_t)layer * M + so) * width + 32 * t + 4 * h + 8 * q);
+                for (int q = 0; q < 4; ++q) hv[t][q] = load4<SA>(acts, ((size_t)layer * M + so) * width + 32 * t + 4 * h + 8 * q);
         };
-        auto mask_store = [&](const float*, float* dz, int width, auto lc, auto tc, const f32x16& acc, auto& out) {
+        auto mask_store = [&](const void*, void* dz, int width, auto lc, auto tc, const f32x16& acc, auto& out) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
             const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
             f32x16 g = acc;
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) g[4 * q + k] = (hv[t][q][k] > 0.0f) ? acc[4 * q + k] : 0.0f;
-                if (ok) store4<P>(dz, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+                if (ok) store4<SA>(dz, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
             }
             pack_lin<P, t>(g, out);
         };
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
 //     dW_i = dz_i^T h_{i-1} + dtz_i^T th_{i-1},   db_i = sum dz_i,   d latent = (latent rows of W_0)^T dz_0
 // Points are independent here (no ray structure): a block is 32 consecutive points, every point has its own latent row.
 // ------------------------------------------------------------------------------------------------------------------
-template <class A>
+template <class A, class SA>
 __global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
     using P = PolF32;
     using PL = Plan<P, A, true, false, false>;
@@ -329,14 +330,14 @@ __global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
             tbin.template set<s, 0>(h ? t1 : t0);
         });
         // hidden layer `layer`: keep value and tangent (true feature order) and hand both on
-        auto keep = [&](float* base, float* tbase, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc, auto& out, auto& tout) {
+        auto keep = [&](void* base, void* tbase, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc, auto& out, auto& tout) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
             if (ok) {
                 const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    store4<P>(base, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]), relu_bits(acc[4 * q + 3]));
-                    store4<P>(tbase, row + 8 * q, acc[4 * q] > 0.0f ? tacc[4 * q] : 0.0f, acc[4 * q + 1] > 0.0f ? tacc[4 * q + 1] : 0.0f,
+                    store4<SA>(base, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]), relu_bits(acc[4 * q + 3]));
+                    store4<SA>(tbase, row + 8 * q, acc[4 * q] > 0.0f ? tacc[4 * q] : 0.0f, acc[4 * q + 1] > 0.0f ? tacc[4 * q + 1] : 0.0f,
                               acc[4 * q + 2] > 0.0f ? tacc[4 * q + 2] : 0.0f, acc[4 * q + 3] > 0.0f ? tacc[4 * q + 3] : 0.0f);
                 }
             }
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
     }
 }
 
-template <class A>
+template <class A, class SA>
 __global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
     using P = PolF32;
     using PL = PlanBB<P, A>;
@@ -456,14 +457,14 @@ __global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
         }
         // (d h, d th) of a hidden layer's tile -> (d z, d tz): both masked with the saved activation, stored, handed on
         f32x4 hv[2][4];                                    // the layer's saved activations, requested before its transposed layer (see bend_bwd)
-        auto fetch_acts = [&](const float* acts, int width, auto lc, auto ntc) {
+        auto fetch_acts = [&](const void* acts, int width, auto lc, auto ntc) {
             constexpr int layer = decltype(lc)::value, nt = decltype(ntc)::value;
 #pragma unroll
             for (int t = 0; t < nt; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hv[t][q] = load4<P>(acts, ((size_t)layer * M + so) * width + 32 * t + 4 * h + 8 * q);
+                for (int q = 0; q < 4; ++q) hv[t][q] = load4<SA>(acts, ((size_t)layer * M + so) * width + 32 * t + 4 * h + 8 * q);
         };
-        auto mask_store = [&](const float*, float* dz, float* dtz, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc,
+        auto mask_store = [&](const void*, void* dz, void* dtz, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc,
                               auto& out, auto& tout) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
             const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
@@ -476,8 +477,8 @@ __global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
                     gt[4 * q + k] = (hv[t][q][k] > 0.0f) ? tacc[4 * q + k] : 0.0f;
                 }
                 if (ok) {
-                    store4<P>(dz, row + 8 * q, gv[4 * q], gv[4 * q + 1], gv[4 * q + 2], gv[4 * q + 3]);
-                    store4<P>(dtz, row + 8 * q, gt[4 * q], gt[4 * q + 1], gt[4 * q + 2], gt[4 * q + 3]);
+                    store4<SA>(dz, row + 8 * q, gv[4 * q], gv[4 * q + 1], gv[4 * q + 2], gv[4 * q + 3]);
+                    store4<SA>(dtz, row + 8 * q, gt[4 * q], gt[4 * q + 1], gt[4 * q + 2], gt[4 * q + 3]);
                 }
             }
             pack_lin<P, t>(gv, out);
@@ -569,8 +570,8 @@ __global__ void __launch_bounds__(256) bend_wgrad(const BendWgradArgs a) {
     f32x16 acc[2][2] = {{f32x16{}, f32x16{}}, {f32x16{}, f32x16{}}};
     float bsum[2] = {0.0f, 0.0f};
     for (int pass = 0; pass < (jb.dz2 ? 2 : 1); ++pass) {          // second product (dz2, x2): same shapes, same dW, not in db
-        const float* dzp = pass ? jb.dz2 : jb.dz;
-        const float* xp = pass ? jb.x2 : jb.x;
+        const void* dzp = pass ? jb.dz2 : jb.dz;
+        const void* xp = pass ? jb.x2 : jb.x;
         // a batch = U k-steps (2 U samples): 4 U dword loads per lane, then up to 4 U MFMAs.  Two register sets: the loads of
         // batch n + 1 are in flight while the MFMAs of batch n run (a wave's range is short -- a few dozen batches -- and each
         // load phase used to cost a full memory latency: 145 us per launch at 65 536 samples)
@@ -579,11 +580,11 @@ __global__ void __launch_bounds__(256) bend_wgrad(const BendWgradArgs a) {
             for (int u = 0; u < U; ++u) {
                 const long long s = 2 * (p + u) + h;
                 const bool ok = (p + u < p1) && s < a.m;
-                const float* dr = dzp + (size_t)s * jb.ldz + i;
+                const float* dr = (const float*)dzp + (size_t)s * jb.ldz + i;       // (fp32 kernel: fp32 arrays only)
                 av[u][0] = (ok && fa0) ? dr[0] : 0.0f;
                 av[u][1] = (ok && fa1) ? dr[32] : 0.0f;
                 if (xp) {
-                    const float* xr = xp + (size_t)s * jb.ldx + i;
+                    const float* xr = (const float*)xp + (size_t)s * jb.ldx + i;
                     bv[u][0] = (ok && gb0) ? xr[0] : 0.0f;
                     bv[u][1] = (ok && gb1) ? xr[32] : 0.0f;
                 } else {                            // column c of [point (3), latent code]: c = i (first tile), 32 + i (second)
@@ -665,8 +666,11 @@ __global__ void __launch_bounds__(256, 2) bend_wgrad16(const BendWgradArgs a) {
     f32x16 acc[2][2] = {{f32x16{}, f32x16{}}, {f32x16{}, f32x16{}}};
     float bsum[2] = {0.0f, 0.0f};
     for (int pass = 0; pass < (jb.dz2 ? 2 : 1); ++pass) {
-        const float* dzp = pass ? jb.dz2 : jb.dz;
-        const float* xp = pass ? jb.x2 : jb.x;
+        const void* dzp = pass ? jb.dz2 : jb.dz;
+        const void* xp = pass ? jb.x2 : jb.x;
+        auto elem = [](const void* base, bool is16, size_t idx) -> float {      // is16 is wave-uniform (per job)
+            return is16 ? (float)((const __bf16*)base)[idx] : ((const float*)base)[idx];
+        };
         // rows beyond the end are clamped to the last row and zeroed afterwards (no predicated loads: every chunk is 32 plain
         // dword loads off four row pointers)
         const long long last = a.m - 1;
@@ -676,13 +680,13 @@ __global__ void __launch_bounds__(256, 2) bend_wgrad16(const BendWgradArgs a) {
                 long long s = 16 * c + 8 * h + e;
                 const bool ok = s <= last;
                 s = ok ? s : last;
-                const float* dr = dzp + (size_t)s * jb.ldz + i;
-                const float a0 = fa0 ? dr[0] : 0.0f, a1 = fa1 ? dr[32] : 0.0f;
+                const size_t di = (size_t)s * jb.ldz + i;
+                const float a0 = fa0 ? elem(dzp, jb.dz16, di) : 0.0f, a1 = fa1 ? elem(dzp, jb.dz16, di + 32) : 0.0f;
                 float b0, b1;
                 if (xp) {
-                    const float* xr = xp + (size_t)s * jb.ldx + i;
-                    b0 = gb0 ? xr[0] : 0.0f;
-                    b1 = gb1 ? xr[32] : 0.0f;
+                    const size_t xi = (size_t)s * jb.ldx + i;
+                    b0 = gb0 ? elem(xp, jb.x16, xi) : 0.0f;
+                    b1 = gb1 ? elem(xp, jb.x16, xi + 32) : 0.0f;
                 } else {                            // column c of [point (3), latent code]: as in bend_wgrad
                     const long long ray = s / a.S;
                     const float* rp = a.rays + (size_t)ray * a.ray_stride;
@@ -740,14 +744,14 @@ __global__ void __launch_bounds__(256, 2) bend_wgrad16(const BendWgradArgs a) {
     }
 }
 
-template <class A, bool BWD>
+template <class A, bool BWD, class SA>
 static hipError_t launch_bend_train(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
     using P = PolF32;
     constexpr int NFRAGS = BWD ? PlanBB<P, A>::NFRAGS : Plan<P, A, true, false, false>::NFRAGS;
     constexpr int NTILES = BWD ? PlanBB<P, A>::NTILES : Plan<P, A, true, false, false>::NTILES;
     const size_t lds = (size_t)NFRAGS * P::FRAG_BYTES + (size_t)NTILES * 32 * sizeof(float);
     void (*kern)(const BendTrainArgs) = nullptr;
-    if constexpr (BWD) kern = bend_bwd<A>; else kern = bend_fwd_train<A>;
+    if constexpr (BWD) kern = bend_bwd<A, SA>; else kern = bend_fwd_train<A, SA>;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
@@ -768,14 +772,14 @@ static hipError_t launch_bend_train(const BendTrainArgs& a, int num_cus, hipStre
 }
 
 
-template <class A, bool BWD>
+template <class A, bool BWD, class SA>
 static hipError_t launch_bend_div(const BendDivArgs& a, int num_cus, hipStream_t stream) {
     using P = PolF32;
     constexpr int NFRAGS = BWD ? PlanBB<P, A>::NFRAGS : Plan<P, A, true, false, false>::NFRAGS;
     constexpr int NTILES = BWD ? PlanBB<P, A>::NTILES : Plan<P, A, true, false, false>::NTILES;
     const size_t lds = (size_t)NFRAGS * P::FRAG_BYTES + (size_t)NTILES * 32 * sizeof(float);
     void (*kern)(const BendDivArgs) = nullptr;
-    if constexpr (BWD) kern = bend_div_bwd<A>; else kern = bend_div_fwd<A>;
+    if constexpr (BWD) kern = bend_div_bwd<A, SA>; else kern = bend_div_fwd<A, SA>;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;

@@ -5,17 +5,18 @@
 #define NRN_CAT2(a, b) a##b
 #define NRN_CAT(a, b) NRN_CAT2(a, b)
 namespace nrn {
-hipError_t NRN_CAT(launch_bend_fwd_train_a, NRN_ARCH)(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
-    return launch_bend_train<ArchById<NRN_ARCH>::type, false>(a, num_cus, stream);
+using BendArch = ArchById<NRN_ARCH>::type;
+hipError_t NRN_CAT(launch_bend_fwd_train_a, NRN_ARCH)(const BendTrainArgs& a, int num_cus, hipStream_t stream, bool bf16_arrays) {
+    return bf16_arrays ? launch_bend_train<BendArch, false, PolBF16>(a, num_cus, stream) : launch_bend_train<BendArch, false, PolF32>(a, num_cus, stream);
 }
-hipError_t NRN_CAT(launch_bend_bwd_a, NRN_ARCH)(const BendTrainArgs& a, int num_cus, hipStream_t stream) {
-    return launch_bend_train<ArchById<NRN_ARCH>::type, true>(a, num_cus, stream);
+hipError_t NRN_CAT(launch_bend_bwd_a, NRN_ARCH)(const BendTrainArgs& a, int num_cus, hipStream_t stream, bool bf16_arrays) {
+    return bf16_arrays ? launch_bend_train<BendArch, true, PolBF16>(a, num_cus, stream) : launch_bend_train<BendArch, true, PolF32>(a, num_cus, stream);
 }
-hipError_t NRN_CAT(launch_bend_div_fwd_a, NRN_ARCH)(const BendDivArgs& a, int num_cus, hipStream_t stream) {
-    return launch_bend_div<ArchById<NRN_ARCH>::type, false>(a, num_cus, stream);
+hipError_t NRN_CAT(launch_bend_div_fwd_a, NRN_ARCH)(const BendDivArgs& a, int num_cus, hipStream_t stream, bool bf16_arrays) {
+    return bf16_arrays ? launch_bend_div<BendArch, false, PolBF16>(a, num_cus, stream) : launch_bend_div<BendArch, false, PolF32>(a, num_cus, stream);
 }
-hipError_t NRN_CAT(launch_bend_div_bwd_a, NRN_ARCH)(const BendDivArgs& a, int num_cus, hipStream_t stream) {
-    return launch_bend_div<ArchById<NRN_ARCH>::type, true>(a, num_cus, stream);
+hipError_t NRN_CAT(launch_bend_div_bwd_a, NRN_ARCH)(const BendDivArgs& a, int num_cus, hipStream_t stream, bool bf16_arrays) {
+    return bf16_arrays ? launch_bend_div<BendArch, true, PolBF16>(a, num_cus, stream) : launch_bend_div<BendArch, true, PolF32>(a, num_cus, stream);
 }
 #if NRN_ARCH == 0     // the weight-gradient kernel does not depend on the bender's depth: one copy
 hipError_t launch_bend_wgrad(const BendWgradArgs& a, hipStream_t stream, bool bf16_operands) {

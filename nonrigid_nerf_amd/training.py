@@ -386,8 +386,11 @@ class _Bender(torch.autograd.Function):
         z = z.detach().contiguous()
         bent4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         off4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
-        acts_b = torch.empty(BD - 1, M, BW, dtype=torch.float32, device=dev)
-        acts_r = torch.empty(RD - 1, M, RW, dtype=torch.float32, device=dev)
+        # saved arrays: fp32 for an fp32 model, bf16 otherwise (include/nrnerf.h, nrnerf_bender_args): only the weight-gradient
+        # kernel reads their values, and in that mode it rounds them to bf16 for the matrix pipe anyway
+        sdt = torch.float32 if _is_f32(model) else torch.bfloat16
+        acts_b = torch.empty(BD - 1, M, BW, dtype=sdt, device=dev)
+        acts_r = torch.empty(RD - 1, M, RW, dtype=sdt, device=dev)
         a = _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r)
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_forward")
@@ -440,6 +443,7 @@ class _Bender(torch.autograd.Function):
                     grads.append(dB[k, :o])
             return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, *grads)
         # library route.  weight gradients dW_i = dz_i^T x_i over the stored arrays (batched library GEMMs, see _wgrad).
+        dz_b, dz_r, acts_b, acts_r = dz_b.float(), dz_r.float(), acts_b.float(), acts_r.float()
         pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(M, 3)
         # x_0 = [p, latent]: the latent columns are constant along a ray, so their part is (per-ray sums of dz_0)^T latents.
         dw0 = torch.cat([_wgrad(dz_b[0], pts), dz_b[0].view(N, S, BW).sum(1).t() @ lat], 1)
@@ -600,8 +604,9 @@ class _Divergence(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         div = torch.empty(M, **f32)
         off4, toff4 = torch.empty(M, 4, **f32), torch.empty(M, 4, **f32)
-        acts_b, tacts_b = torch.empty(BD - 1, M, BW, **f32), torch.empty(BD - 1, M, BW, **f32)
-        acts_r, tacts_r = torch.empty(RD - 1, M, RW, **f32), torch.empty(RD - 1, M, RW, **f32)
+        sd = dict(dtype=torch.float32 if _is_f32(model) else torch.bfloat16, device=dev)      # saved arrays, as in _Bender
+        acts_b, tacts_b = torch.empty(BD - 1, M, BW, **sd), torch.empty(BD - 1, M, BW, **sd)
+        acts_r, tacts_r = torch.empty(RD - 1, M, RW, **sd), torch.empty(RD - 1, M, RW, **sd)
         a = _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_divergence_forward")
