@@ -15,6 +15,7 @@
 // Always fp32, whatever the trunk's precision: offsets feed a 2^9-frequency encoding.  These two are first order; the
 // divergence regulariser (second order in autograd's terms) is bend_div_fwd / bend_div_bwd further down.
 #pragma once
+#include <type_traits>
 #include "nrnerf_bend.h"
 #include "nrnerf_train.h"
 
@@ -658,89 +659,142 @@ __global__ void __launch_bounds__(256, 2) bend_wgrad16(const BendWgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, i = lane & 31;
     const int part = (int)blockIdx.x * 4 + wave;
-    const long long chunks = (a.m + 15) / 16;
-    const long long per = (chunks + a.nparts - 1) / a.nparts;
-    const long long c0 = (long long)part * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
-    const bool f1 = jb.f > 32, g1 = jb.g > 32;           // second row / column tile in use (wave-uniform)
-    const bool fa0 = i < jb.f, fa1 = 32 + i < jb.f, gb0 = i < jb.g, gb1 = 32 + i < jb.g;
+    const unsigned chunks = (unsigned)((a.m + 15) / 16);
+    const unsigned per = (chunks + a.nparts - 1) / a.nparts;
+    const unsigned c0 = (unsigned)part * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
+    // Which features a lane holds.  fp32 array: lane i holds features i (tile 0) and 32 + i (tile 1), one dword load each.
+    // bf16 array (the saved arrays): lane i holds features 2 i and 2 i + 1 -- ONE dword load per row gives both, tile 0 = the
+    // even features, tile 1 = the odd ones (two-byte loads, one per tile, moved 128 bytes per instruction and made this
+    // kernel 2.5 x slower than on fp32 arrays); the epilogue writes dW / db rows and columns back in feature order.
+    const bool dz16 = jb.dz16 != 0, x16 = jb.x16 != 0;
+    const int fd0 = dz16 ? 2 * i : i, fd1 = dz16 ? 2 * i + 1 : 32 + i;          // features of this lane's dz elements
+    const int fx0 = x16 ? 2 * i : i, fx1 = x16 ? 2 * i + 1 : 32 + i;            // ... of its x elements
+    const bool fa0 = fd0 < jb.f, fa1 = fd1 < jb.f, gb0 = fx0 < jb.g, gb1 = fx1 < jb.g;
+    // Every array element is fetched by a raw buffer load: a 32-bit byte offset off a base held in scalar registers, which
+    // returns 0 beyond the array's last byte, so rows past the end need no clamping or masking.  A lane without a feature
+    // reads the row's first dword and is zeroed at conversion time; the second dword of a row is only asked for from an
+    // fp32 array (one wave-uniform branch per eight loads).  One loop body serves both element types: nothing but the row
+    // pitch and wave-uniform selects at conversion time depend on it.  (Two earlier forms: a run-time choice of the element
+    // type around each load broke the loop into hundreds of basic blocks that each waited for their own load, 2.4 ms per
+    // launch; the loop compiled once per type combination spilled the accumulators.)
+    const unsigned rbd = (unsigned)jb.ldz * (dz16 ? 2u : 4u), rbx = (unsigned)jb.ldx * (x16 ? 2u : 4u);      // row pitch in bytes
+    const unsigned nd = (unsigned)(((size_t)(a.m - 1) * jb.ldz + jb.f) * (dz16 ? 2 : 4));                    // bytes of the array
+    const unsigned nx = (unsigned)(((size_t)(a.m - 1) * jb.ldx + jb.g) * (x16 ? 2 : 4));
+    const unsigned od0 = fa0 ? 4u * i : 0u, od1 = fa1 ? 4u * i + 128u : 0u;
+    const unsigned ox0 = gb0 ? 4u * i : 0u, ox1 = gb1 ? 4u * i + 128u : 0u;
     f32x16 acc[2][2] = {{f32x16{}, f32x16{}}, {f32x16{}, f32x16{}}};
     float bsum[2] = {0.0f, 0.0f};
-    for (int pass = 0; pass < (jb.dz2 ? 2 : 1); ++pass) {
-        const void* dzp = pass ? jb.dz2 : jb.dz;
-        const void* xp = pass ? jb.x2 : jb.x;
-        auto elem = [](const void* base, bool is16, size_t idx) -> float {      // is16 is wave-uniform (per job)
-            return is16 ? (float)((const __bf16*)base)[idx] : ((const float*)base)[idx];
-        };
-        // rows beyond the end are clamped to the last row and zeroed afterwards (no predicated loads: every chunk is 32 plain
-        // dword loads off four row pointers)
-        const long long last = a.m - 1;
-        auto load = [&](long long c, float (&av)[8][2], float (&bv)[8][2]) {
+    const unsigned last = (unsigned)(a.m - 1);
+    auto run = [&](auto x_generated) {              // the main loop, compiled for x from an array and for x made here
+        constexpr bool GEN = decltype(x_generated)::value;
+        for (int pass = 0; pass < (jb.dz2 ? 2 : 1); ++pass) {          // second product (dz2, x2): same shapes and types, same dW, not in db
+            const void* xp = pass ? jb.x2 : jb.x;
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pass ? jb.dz2 : jb.dz), 0, (int)nd, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(GEN ? jb.dz : xp), 0, GEN ? 0 : (int)nx, 0x00020000);
+            // x made here: the rays, their latent codes and the depths, each behind its own descriptor
+            const unsigned n_rays = (unsigned)((a.m + a.S - 1) / a.S);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.rays), 0, GEN ? (int)(((size_t)(n_rays - 1) * a.ray_stride + 6) * 4) : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.latents), 0, GEN ? (int)(((size_t)(n_rays - 1) * a.lat_stride + jb.g - 3) * 4) : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rzz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z), 0, GEN ? (int)((size_t)a.m * 4) : 0, 0x00020000);
+            const unsigned gi3 = (i < 3) ? i : 0, gil = (i >= 3 && gb0) ? i - 3 : 0, gih = gb1 ? 29 + i : 0;
+            auto load = [&](unsigned c, unsigned (&ra)[8][2], unsigned (&rb)[8][2]) {
+                unsigned row0 = 16u * c + 8u * h;
+                asm volatile("" : "+v"(row0));          // opaque: otherwise 32 offsets become loop induction variables, per register set, and spill
+                const unsigned bd = row0 * rbd, bx = row0 * rbx;
+                if constexpr (GEN) {
+                    // column c of [point (3), latent code], as in bend_wgrad: o + z d for lanes 0..2, the ray's latent code
+                    // beyond.  Buffer loads again (no predication, 0 beyond the arrays); asked for BEFORE dz so that the
+                    // arithmetic below waits for these small, cache-resident loads only
+                    float ro[8], rdv[8], rz[8], l0[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                long long s = 16 * c + 8 * h + e;
-                const bool ok = s <= last;
-                s = ok ? s : last;
-                const size_t di = (size_t)s * jb.ldz + i;
-                const float a0 = fa0 ? elem(dzp, jb.dz16, di) : 0.0f, a1 = fa1 ? elem(dzp, jb.dz16, di + 32) : 0.0f;
-                float b0, b1;
-                if (xp) {
-                    const size_t xi = (size_t)s * jb.ldx + i;
-                    b0 = gb0 ? elem(xp, jb.x16, xi) : 0.0f;
-                    b1 = gb1 ? elem(xp, jb.x16, xi + 32) : 0.0f;
-                } else {                            // column c of [point (3), latent code]: as in bend_wgrad
-                    const long long ray = s / a.S;
-                    const float* rp = a.rays + (size_t)ray * a.ray_stride;
-                    const float* lp = a.latents + (size_t)ray * a.lat_stride;
-                    b0 = gb0 ? ((i < 3) ? __fadd_rn(rp[i], __fmul_rn(rp[3 + i], a.z[s])) : lp[i - 3]) : 0.0f;
-                    b1 = gb1 ? lp[29 + i] : 0.0f;
-                }
-                av[e][0] = ok ? a0 : 0.0f; av[e][1] = ok ? a1 : 0.0f;
-                bv[e][0] = b0; bv[e][1] = b1;          // (a zero row of dz already removes the product)
-            }
-        };
-        auto compute = [&](const float (&av)[8][2], const float (&bv)[8][2]) {
-            frag fa[2], fb[2];
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned s = row0 + e, ray = s / (unsigned)a.S;
+                        const unsigned br = ray * (unsigned)a.ray_stride * 4u, bl = ray * (unsigned)a.lat_stride * 4u;
+                        ro[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, br + 4u * gi3, 0, 0));
+                        rdv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, br + 12u + 4u * gi3, 0, 0));
+                        rz[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rzz, 4u * s, 0, 0));
+                        l0[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, bl + 4u * gil, 0, 0));
+                        rb[e][1] = __builtin_amdgcn_raw_buffer_load_b32(rl, bl + 4u * gih, 0, 0);
+                    }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (pass == 0) {
-                    bsum[0] += av[e][0];
-                    bsum[1] += av[e][1];
+                    for (int e = 0; e < 8; ++e) ra[e][0] = __builtin_amdgcn_raw_buffer_load_b32(rd, bd + od0 + e * rbd, 0, 0);
+                    if (!dz16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ra[e][1] = __builtin_amdgcn_raw_buffer_load_b32(rd, bd + od1 + e * rbd, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rb[e][0] = __builtin_bit_cast(unsigned, (i < 3) ? __fadd_rn(ro[e], __fmul_rn(rdv[e], rz[e])) : l0[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ra[e][0] = __builtin_amdgcn_raw_buffer_load_b32(rd, bd + od0 + e * rbd, 0, 0);
+                    if (!dz16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ra[e][1] = __builtin_amdgcn_raw_buffer_load_b32(rd, bd + od1 + e * rbd, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rb[e][0] = __builtin_amdgcn_raw_buffer_load_b32(rx, bx + ox0 + e * rbx, 0, 0);
+                    if (!x16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rb[e][1] = __builtin_amdgcn_raw_buffer_load_b32(rx, bx + ox1 + e * rbx, 0, 0);
+                    }
                 }
-                fa[0][e] = (__bf16)av[e][0]; fa[1][e] = (__bf16)av[e][1];
-                fb[0][e] = (__bf16)bv[e][0]; fb[1][e] = (__bf16)bv[e][1];
-            }
-            acc[0][0] = PolBF16::mfma(fa[0], fb[0], acc[0][0]);
-            if (g1) acc[0][1] = PolBF16::mfma(fa[0], fb[1], acc[0][1]);
-            if (f1) {
+            };
+            auto compute = [&](const unsigned (&ra)[8][2], const unsigned (&rb)[8][2]) {
+                frag fa[2], fb[2];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned ua1 = dz16 ? ra[e][0] & 0xffff0000u : ra[e][1], ub1 = x16 ? rb[e][0] & 0xffff0000u : rb[e][1];
+                    const float a0 = __builtin_bit_cast(float, fa0 ? (dz16 ? ra[e][0] << 16 : ra[e][0]) : 0u);
+                    const float a1 = __builtin_bit_cast(float, fa1 ? ua1 : 0u);
+                    const float b0 = __builtin_bit_cast(float, gb0 ? (x16 ? rb[e][0] << 16 : rb[e][0]) : 0u);
+                    const float b1 = __builtin_bit_cast(float, gb1 ? ub1 : 0u);
+                    if (pass == 0) {
+                        bsum[0] += a0;
+                        bsum[1] += a1;
+                    }
+                    fa[0][e] = (__bf16)a0; fa[1][e] = (__bf16)a1;
+                    fb[0][e] = (__bf16)b0; fb[1][e] = (__bf16)b1;
+                }
+                // all four tiles, used or not (zero operands where a tile has no features): a wave-uniform skip of the unused
+                // ones made the compiler keep a second copy of the accumulators and move 16 registers per tile per chunk
+                acc[0][0] = PolBF16::mfma(fa[0], fb[0], acc[0][0]);
+                acc[0][1] = PolBF16::mfma(fa[0], fb[1], acc[0][1]);
                 acc[1][0] = PolBF16::mfma(fa[1], fb[0], acc[1][0]);
-                if (g1) acc[1][1] = PolBF16::mfma(fa[1], fb[1], acc[1][1]);
+                acc[1][1] = PolBF16::mfma(fa[1], fb[1], acc[1][1]);
+            };
+            unsigned ra0[8][2], rb0[8][2], ra1[8][2], rb1[8][2];
+            unsigned c = c0;
+            if (c < c1) load(c, ra0, rb0);
+            while (c < c1) {
+                if (c + 1 < c1) load(c + 1, ra1, rb1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(ra0, rb0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 >= c1) break;
+                if (c + 2 < c1) load(c + 2, ra0, rb0);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(ra1, rb1);
+                __builtin_amdgcn_sched_barrier(0);
+                c += 2;
             }
-        };
-        float av0[8][2], bv0[8][2], av1[8][2], bv1[8][2];
-        long long c = c0;
-        if (c < c1) load(c, av0, bv0);
-        while (c < c1) {
-            if (c + 1 < c1) load(c + 1, av1, bv1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(av0, bv0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 >= c1) break;
-            if (c + 2 < c1) load(c + 2, av0, bv0);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(av1, bv1);
-            __builtin_amdgcn_sched_barrier(0);
-            c += 2;
         }
-    }
+    };
+    if (jb.x) run(std::false_type{}); else run(std::true_type{});
+    // D tile (u, v): lane (h, i) holds rows tile_row(r, h), column i of the tile; tile rows / columns -> features as above
     float* out = a.out + ((size_t)part * a.njobs + blockIdx.y) * BEND_WGRAD_SLOT;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < 2; ++v) {
+            const int col = x16 ? 2 * i + v : 32 * v + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[(32 * u + tile_row(r, h)) * 64 + 32 * v + i] = acc[u][v][r];
+            for (int r = 0; r < 16; ++r) {
+                const int row = dz16 ? 2 * tile_row(r, h) + u : 32 * u + tile_row(r, h);
+                out[row * 64 + col] = acc[u][v][r];
+            }
+        }
         const float rs = bsum[u] + __shfl_xor(bsum[u], 32);
-        if (h == 0) out[64 * 64 + 32 * u + i] = rs;
+        if (h == 0) out[64 * 64 + (dz16 ? 2 * i + u : 32 * u + i)] = rs;
     }
 }
 
