@@ -401,6 +401,29 @@ typedef struct nrnerf_divergence_args {
 int nrnerf_bender_divergence_forward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);
 int nrnerf_bender_divergence_backward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);
 
+/* The split fine bender of the training path (the fine pass bends only its n_importance new samples; the bender is shared
+ * by both networks, run_nerf_helpers.py:213-215, and the coarse depths are a subset of the merged depths, train.py:920):
+ * per-sample rows of the n_samples coarse samples [N][n_samples][4] and of the new samples [N][n_importance][4] <-> the same
+ * rows in merged-depth order [N][n_samples + n_importance][4].  New sample i of a ray sits at row rank_new[ray][i]
+ * (nrnerf_composite_args.rank_new), the coarse samples fill the other rows in order.  inverse == 0 writes merged_* from
+ * coarse_* and new_*; inverse != 0 writes coarse_* and new_* from merged_* (a permutation: this is also the gradient of the
+ * forward direction).  Two arrays per call (bent point + rigidity mask rows, offset rows); the *_b pointers may all be NULL.
+ * n_samples + n_importance <= 256.  Runs on the device that owns merged_a. */
+int nrnerf_merge_rows(const uint8_t* rank_new, int32_t n_rays, int32_t n_samples, int32_t n_importance, float* coarse_a, float* coarse_b,
+                      float* new_a, float* new_b, float* merged_a, float* merged_b, int32_t inverse, void* hip_stream);
+
+/* The partial sums the weight-gradient entry points below write, added up INTO THE PARAMETERS' OWN LAYOUTS in one launch:
+ *   out[j] = sum over the first P(j) records p of partials[p * record_stride + (index[j] & (NRNERF_REDUCE_SHORT - 1))]
+ * with P(j) = n_short where index[j] carries the NRNERF_REDUCE_SHORT flag (the 64-column products of nrnerf_trunk_wgrad fill
+ * only NRNERF_WGRAD_SHORT_PARTIALS records -- no zero-filling of the others needed on this route) and n_partials otherwise;
+ * out[j] = 0 where index[j] < 0 (padding the caller wants zeroed, e.g. a parameter row no kernel produces).  `index`
+ * (device, int32 [n_out]) is the caller's map from its flat gradient buffer -- every weight and bias of a network back to
+ * back, each in its own shape -- to positions in one record; records are added in order (deterministic).  Runs on the device
+ * that owns `out`. */
+#define NRNERF_REDUCE_SHORT 0x40000000
+int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
+                           int64_t n_out, float* out, void* hip_stream);
+
 /* bf16 mode: the weight and bias gradients of the trunk from the two arrays nrnerf_trunk_forward / _backward filled, in
  * one launch over their [block][feature][32 samples] layout (the contraction runs over samples; no transposes):
  *   dw_hidden[i-1] = d_pre[i]^T acts[i-1]  (i = 1 .. depth-1; the skip layer's columns for its encoding input are in dw_enc)

@@ -109,6 +109,9 @@ class WgradArgs(C.Structure):
                 ("n_partials", C.c_int32), ("partials", C.c_void_p)]
 
 
+REDUCE_SHORT = 0x40000000        # NRNERF_REDUCE_SHORT of include/nrnerf.h
+
+
 def wgrad_stride(depth: int, width: int) -> int:
     """NRNERF_WGRAD_STRIDE of include/nrnerf.h"""
     return (depth - 1) * width * width + 3 * width * 64 + (depth + 1) * width
@@ -180,6 +183,9 @@ EXPORTS = {
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "nrnerf_sample_depths": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "nrnerf_merge_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_void_p]),
+    "nrnerf_reduce_partials": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nrnerf_trunk_forward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
     "nrnerf_trunk_backward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
     "nrnerf_trunk_wgrad": (C.c_int, [C.c_void_p, C.POINTER(WgradArgs), C.c_void_p]),

@@ -19,6 +19,7 @@
 
 #include "nrnerf.h"
 #include "nrnerf_kernels.h"
+#include "nrnerf_aux.h"
 #include "nrnerf_plan.h"
 
 using namespace nrn;
@@ -1053,6 +1054,43 @@ int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uni
     if (!guard.ok) return NRNERF_ERR_HIP;
     JitterArgs j{rays, ray_stride, uniforms, n_rays, n_samples, lindisp, z_out};
     return launch_zjitter(j, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
+namespace {
+// the device that owns `ptr` (device memory): NRNERF_OK and `dev`, or NRNERF_ERR_INVALID
+int device_of(const void* ptr, int& dev) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) { (void)hipGetLastError(); return NRNERF_ERR_INVALID; }
+    if (attr.type != hipMemoryTypeDevice) return NRNERF_ERR_INVALID;
+    dev = attr.device;
+    return NRNERF_OK;
+}
+}  // namespace
+
+int nrnerf_merge_rows(const uint8_t* rank_new, int32_t n_rays, int32_t n_samples, int32_t n_importance, float* coarse_a, float* coarse_b,
+                      float* new_a, float* new_b, float* merged_a, float* merged_b, int32_t inverse, void* hip_stream) try {
+    if (!rank_new || !coarse_a || !new_a || !merged_a || n_rays < 0 || n_samples < 1 || n_importance < 1 || n_samples + n_importance > 256) return NRNERF_ERR_INVALID;
+    if ((coarse_b != nullptr) != (merged_b != nullptr) || (new_b != nullptr) != (merged_b != nullptr)) return NRNERF_ERR_INVALID;
+    if (n_rays == 0) return NRNERF_OK;
+    int dev = 0;
+    if (device_of(merged_a, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    MergeRowsArgs a{n_rays, n_samples, n_importance, rank_new, coarse_a, coarse_b, new_a, new_b, merged_a, merged_b, inverse ? 1 : 0};
+    return launch_merge_rows(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
+int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
+                           int64_t n_out, float* out, void* hip_stream) try {
+    if (!partials || !index || !out || n_out < 0 || n_partials < 1 || n_short < 0 || n_short > n_partials || record_stride < 1 ||
+        record_stride >= NRNERF_REDUCE_SHORT) return NRNERF_ERR_INVALID;
+    if (n_out == 0) return NRNERF_OK;
+    int dev = 0;
+    if (device_of(out, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    ReducePartialsArgs a{partials, record_stride, n_partials, n_short, index, n_out, out};
+    return launch_reduce_partials(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
 // ---- training entry points (nrnerf_train.h, composite_bwd_kernel) -------------------------------------------------

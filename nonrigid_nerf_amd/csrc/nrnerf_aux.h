@@ -1,0 +1,30 @@
+// Small device-side helpers of the training path that are neither network nor compositing kernels (nrnerf_composite.hip
+// holds them): the row merge of the split fine bender and the reduction of weight-gradient partial sums into the
+// parameters' own layouts.  Only nrnerf_api.cpp and nrnerf_composite.hip see this header.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nrn {
+
+// rows of the S coarse samples and of the I importance samples of a ray <-> the same rows in merged-depth order
+// (importance sample i sits at row rank_new[n][i], the coarse samples fill the other rows in order); two [., 4] arrays at once
+struct MergeRowsArgs {
+    int n_rays, S, I;
+    const unsigned char* rank_new;      // [N][I]
+    const float* c_a; const float* c_b; // forward in / inverse out   [N][S][4]      (b may be null)
+    const float* n_a; const float* n_b; //                            [N][I][4]
+    float* m_a; float* m_b;             // forward out / inverse in   [N][S + I][4]
+    int inverse;                        // 0: (c, n) -> m;  1: m -> (c, n)
+};
+hipError_t launch_merge_rows(const MergeRowsArgs&, hipStream_t);
+
+// out[j] = sum over the first P(j) records p of parts[p * stride + (index[j] & OFFSET)],  P(j) = n_short where index[j] has
+// the SHORT flag, n_partials otherwise; 0 where index[j] < 0.  Records are added in order (deterministic).
+struct ReducePartialsArgs {
+    const float* parts; long long stride; int n_partials, n_short;
+    const int* index; long long n_out; float* out;
+};
+constexpr int REDUCE_SHORT_FLAG = 0x40000000;
+hipError_t launch_reduce_partials(const ReducePartialsArgs&, hipStream_t);
+
+}  // namespace nrn

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "nrnerf_kernels.h"
+#include "nrnerf_aux.h"
 
 namespace nrn {
 
@@ -442,6 +443,63 @@ hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream) {
         case 4: return launch_epl<4>(a, stream);
     }
     return hipErrorInvalidValue;
+}
+
+
+// ---- helpers of the training path (nrnerf_aux.h) -----------------------------------------------------------------------
+// One workgroup per ray, one thread per merged row: the row is importance sample i if rank_new[i] names it, else coarse
+// sample (row - number of importance samples before it).  Pure permutation: the inverse direction copies the other way.
+__global__ void __launch_bounds__(256) merge_rows_kernel(const MergeRowsArgs a) {
+    __shared__ unsigned char rk[256];
+    const int n = blockIdx.x, r = threadIdx.x, T = a.S + a.I;
+    if (r < a.I) rk[r] = a.rank_new[(size_t)n * a.I + r];
+    __syncthreads();
+    if (r >= T) return;
+    int before = 0, mine = -1;
+    for (int i = 0; i < a.I; ++i) {
+        const int k = rk[i];
+        before += k < r;
+        mine = (k == r) ? i : mine;
+    }
+    const size_t mrow = (size_t)n * T + r;
+    const size_t srow = (mine >= 0) ? (size_t)n * a.I + mine : (size_t)n * a.S + (r - before);
+    const f32x4* ca = (const f32x4*)(mine >= 0 ? a.n_a : a.c_a);
+    const f32x4* cb = (const f32x4*)(mine >= 0 ? a.n_b : a.c_b);
+    if (!a.inverse) {
+        ((f32x4*)a.m_a)[mrow] = ca[srow];
+        if (a.m_b) ((f32x4*)a.m_b)[mrow] = cb[srow];
+    } else {
+        ((f32x4*)ca)[srow] = ((const f32x4*)a.m_a)[mrow];
+        if (a.m_b) ((f32x4*)cb)[srow] = ((const f32x4*)a.m_b)[mrow];
+    }
+}
+hipError_t launch_merge_rows(const MergeRowsArgs& a, hipStream_t stream) {
+    if (a.n_rays <= 0 || a.S < 1 || a.I < 1 || a.S + a.I > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_rows_kernel, dim3(a.n_rays), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const ReducePartialsArgs a) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.n_out) return;
+    const int ix = a.index[j];
+    float s = 0.0f;
+    if (ix >= 0) {
+        const int P = (ix & REDUCE_SHORT_FLAG) ? a.n_short : a.n_partials;
+        const float* p = a.parts + (ix & (REDUCE_SHORT_FLAG - 1));
+        int k = 0;
+        for (; k + 4 <= P; k += 4) {            // four loads in flight, added in record order
+            const float v0 = p[(size_t)k * a.stride], v1 = p[(size_t)(k + 1) * a.stride], v2 = p[(size_t)(k + 2) * a.stride], v3 = p[(size_t)(k + 3) * a.stride];
+            s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, v0), v1), v2), v3);
+        }
+        for (; k < P; ++k) s = __fadd_rn(s, p[(size_t)k * a.stride]);
+    }
+    a.out[j] = s;
+}
+hipError_t launch_reduce_partials(const ReducePartialsArgs& a, hipStream_t stream) {
+    if (a.n_out <= 0 || a.n_partials < 1 || a.n_short < 0 || a.n_short > a.n_partials || a.stride < 1 || a.stride >= REDUCE_SHORT_FLAG) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((a.n_out + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 }  // namespace nrn

@@ -94,6 +94,138 @@ def _is_f32(model) -> bool:
     return int(model.lib.nrnerf_model_precision(model.handle)) == _lib.PRECISIONS["f32"]
 
 
+_GRAD_INDEX = {}
+
+
+def _reduce_partials(parts: torch.Tensor, n_short: int, index: torch.Tensor) -> torch.Tensor:
+    """Flat fp32 gradient buffer [len(index)] = the records of partial sums `parts` [P, stride] added up and laid out as the
+    parameters are (nrnerf_reduce_partials: one launch instead of a sum, zero-fills of the unwritten records and a copy per
+    parameter whose gradient is not a contiguous block of the record)."""
+    out = torch.empty(int(index.shape[0]), dtype=torch.float32, device=parts.device)
+    with torch.cuda.device(parts.device):
+        _lib.check(_lib.load().nrnerf_reduce_partials(parts.data_ptr(), int(parts.stride(0)), int(parts.shape[0]), int(n_short), index.data_ptr(),
+                                                      int(index.shape[0]), out.data_ptr(), _stream(parts.device)), "nrnerf_reduce_partials")
+    return out
+
+
+def _split_flat(flat: torch.Tensor, shapes):
+    out, o = [], 0
+    for shp in shapes:
+        n = 1
+        for d in shp:
+            n *= int(d)
+        out.append(flat[o:o + n].view(shp))
+        o += n
+    return out
+
+
+def _trunk_grad_index(net, D, W, C_out, views, n_lat, dev):
+    """(index [n] int32 on dev, parameter shapes, offset of the head's bias) for nrnerf_reduce_partials: position in one record
+    of nrnerf_trunk_wgrad (include/nrnerf.h) of every element of the trunk's weights and biases in _trunk_params order; -1
+    (zero) for what no kernel produces: the latent columns of the time-conditioned baseline's two input layers (their
+    gradient comes through ray_bias), the 5th output channel, and the head's bias (summed from d_raw4 by the caller)."""
+    import numpy as np
+    L = (int(net.input_ch) - 3) // 6
+    n_enc = 3 + 6 * L
+    skips = tuple(sorted(int(k) for k in net.skips))
+    key = ("trunk", D, W, C_out, bool(views), n_enc, n_lat, skips, str(dev))
+    if key in _GRAD_INDEX:
+        return _GRAD_INDEX[key]
+    SH = _lib.REDUCE_SHORT
+    o_h, o_e = 0, (D - 1) * W * W
+    o_o = o_e + 2 * W * 64
+    o_db = o_o + W * 64
+    rows = np.arange(W, dtype=np.int64)[:, None]
+    lat = np.full((W, n_lat), -1, dtype=np.int64)
+    segs, shapes = [], []
+    for i in range(D):
+        if i == 0:
+            w = np.concatenate([(o_e + rows * 64 + np.arange(n_enc)[None]) | SH, lat], 1)
+        elif (i - 1) in skips:                                                               # x = [encoding, (latent,) h] (rnh:278-282)
+            w = np.concatenate([(o_e + W * 64 + rows * 64 + np.arange(n_enc)[None]) | SH, lat, o_h + (i - 1) * W * W + rows * W + np.arange(W)[None]], 1)
+        else:
+            w = o_h + (i - 1) * W * W + rows * W + np.arange(W)[None]
+        b = o_db + i * W + np.arange(W)
+        segs += [w.reshape(-1), (b | SH) if i == 0 else b]
+        shapes += [tuple(w.shape), (W,)]
+    if views:                                                  # head slot = alpha_linear (1 x W): the sigma channel's column of dw_head^T
+        segs += [((o_o + np.arange(W) * 64 + 3) | SH), np.full(1, -1)]
+        shapes += [(1, W), (1,)]
+    else:
+        w = np.full((C_out, W), -1, dtype=np.int64)
+        for ch in range(min(4, C_out)):
+            w[ch] = (o_o + np.arange(W) * 64 + ch) | SH
+        segs += [w.reshape(-1), np.full(C_out, -1)]
+        shapes += [(C_out, W), (C_out,)]
+    flat = np.concatenate(segs).astype(np.int32)
+    head_bias_at = int(flat.shape[0]) - int(shapes[-1][0])
+    _GRAD_INDEX[key] = (torch.from_numpy(flat).to(dev), shapes, head_bias_at)
+    return _GRAD_INDEX[key]
+
+
+def _bender_grad_index(rb, dev, divergence):
+    """As _trunk_grad_index for the ray bender's two MLPs (_bender_params order) over the records of nrnerf_bender_wgrad
+    (one slot per layer) or -- ``divergence`` -- of nrnerf_bender_divergence_backward (network[0] in two slots: the point's
+    columns, the latent code's columns)."""
+    import numpy as np
+    layers = list(rb.network) + list(rb.rigidity_network)
+    key = ("bender", bool(divergence), tuple((tuple(l.weight.shape), l.bias is not None) for l in layers), str(dev))
+    if key in _GRAD_INDEX:
+        return _GRAD_INDEX[key]
+    slot = _lib.BENDER_WGRAD_SLOT
+    segs, shapes = [], []
+    for k, lin in enumerate(layers):
+        o, i_ = int(lin.weight.shape[0]), int(lin.weight.shape[1])
+        rows = np.arange(o, dtype=np.int64)[:, None]
+        if divergence and k == 0:                   # jobs 0 / 1: the point's and the latent code's columns of network[0]
+            w = np.concatenate([rows * 64 + np.arange(3)[None], slot + rows * 64 + np.arange(i_ - 3)[None]], 1)
+            job = 0
+        else:
+            job = k + 1 if divergence else k
+            w = job * slot + rows * 64 + np.arange(i_)[None]
+        segs.append(w.reshape(-1))
+        shapes.append((o, i_))
+        if lin.bias is not None:
+            segs.append(job * slot + 4096 + np.arange(o))
+            shapes.append((o,))
+    _GRAD_INDEX[key] = (torch.from_numpy(np.concatenate(segs).astype(np.int32)).to(dev), shapes)
+    return _GRAD_INDEX[key]
+
+
+class _ParamToken(torch.autograd.Function):
+    """A [total] fp32 tensor that STANDS FOR a list of parameters in the autograd graph (its values are never read: the
+    kernels take the weights from the packed model): a function that would return one gradient per parameter returns ONE
+    flat gradient for the token instead, and this node hands each parameter its slice.  Several uses of the same parameters
+    in an iteration (the bender: coarse samples, new samples, divergence term) share one token, so autograd adds their flat
+    gradients with one launch each instead of one per parameter and use."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.set_materialize_grads(False)
+        return torch.empty(sum(int(p.numel()) for p in params), dtype=torch.float32, device=params[0].device)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * len(ctx.shapes)
+        return tuple(_split_flat(g, ctx.shapes))
+
+
+_TOKENS = {}
+
+
+def _param_token(owner, params):
+    """The token of `params` for this iteration: one per (owner, parameter objects and versions, grad mode)."""
+    key = (tuple((id(p), p._version) for p in params), torch.is_grad_enabled())
+    hit = _TOKENS.get(id(owner))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    tok = _ParamToken.apply(*params)
+    _TOKENS[id(owner)] = (key, tok)
+    return tok
+
+
 class _Trunk(torch.autograd.Function):
     """raw4 [N,S,4] (differentiable), raw [N,S,C] (the reference's "raw" key; no gradient) = NeRF trunk(points)."""
 
@@ -129,6 +261,7 @@ class _Trunk(torch.autograd.Function):
         ctx.model, ctx.net, ctx.which, ctx.dims, ctx.views, ctx.tcb = model, net, int(which), (N, S, D, W, C_out), views, ray_bias is not None
         ctx.save_for_backward(*((pts4, acts) if f32 else (pts4, acts, mask)))
         ctx.mark_non_differentiable(raw)
+        ctx.set_materialize_grads(False)             # an output nobody differentiates arrives as None, not as a zero-filled tensor
         if not views:
             return raw4.view(N, S, 4), raw.view(N, S, C_out)
         if f32:
@@ -145,6 +278,8 @@ class _Trunk(torch.autograd.Function):
         pts4, acts = ctx.saved_tensors[:2]
         N, S, D, W, C_out = ctx.dims
         M, dev = N * S, pts4.device
+        if g_raw4 is None and g_h is None:
+            return (None,) * (5 + 2 * D + 2)
         g = g_raw4.contiguous().reshape(M, 4).float() if g_raw4 is not None else torch.zeros(M, 4, dtype=torch.float32, device=dev)
         d_pre = torch.empty_like(acts)
         d_pts4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
@@ -181,8 +316,9 @@ class _Trunk(torch.autograd.Function):
                 grads[2 * li] = full
             return grads
         if not f32:
+            # (bf16 route: the latent columns are already in the flat buffer's layout, zero)
             return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias,
-                    *widen(_Trunk._weight_grads_bf16(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views)))
+                    *_Trunk._weight_grads_bf16(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views, n_lat))
         # weight gradients: library GEMMs over the stored activations x_i and pre-activation gradients dz_i
         adt = acts.dtype
         L = (int(net.input_ch) - 3) // 6
@@ -214,7 +350,7 @@ class _Trunk(torch.autograd.Function):
 
 
     @staticmethod
-    def _weight_grads_bf16(model, net, dims, pts4, acts, d_pre, g, views=False):
+    def _weight_grads_bf16(model, net, dims, pts4, acts, d_pre, g, views=False, n_lat=0):
         """bf16 mode: every weight and bias gradient of the trunk from one call of nrnerf_trunk_wgrad over the two
         [block][feature][32 samples] arrays (reads each once; the library route read them twice and reduced d_pre a third
         time).  One record of partial sums per workgroup, added here with one reduction."""
@@ -228,13 +364,9 @@ class _Trunk(torch.autograd.Function):
         # only the records the kernel does not write need zeroing: the three 64-column products (and their bias rows) are cut
         # into NRNERF_WGRAD_SHORT_PARTIALS <= kch partial sums (include/nrnerf.h); zero-filling the whole array was 74 MB per call
         parts = torch.empty(kch, _lib.wgrad_stride(D, W), dtype=torch.float32, device=dev)
+        # the three 64-column products (and their bias rows) are cut into NRNERF_WGRAD_SHORT_PARTIALS <= kch partial sums
+        # (include/nrnerf.h); the other records' slots are never read (nrnerf_reduce_partials), so nothing is zero-filled
         kl = _lib.wgrad_short_partials(kch, W)
-        if kl < kch:
-            o64 = (D - 1) * W * W
-            odb = o64 + 3 * W * 64
-            parts[kl:, o64:odb].zero_()
-            parts[kl:, odb:odb + W].zero_()
-            parts[kl:, odb + D * W:odb + (D + 1) * W].zero_()
         a = _lib.WgradArgs()
         a.struct_size = C.sizeof(_lib.WgradArgs)
         a.n_rays, a.n_samples, a.n_partials = N, S, kch
@@ -242,32 +374,14 @@ class _Trunk(torch.autograd.Function):
         a.enc, a.g_head, a.partials = scratch[0].data_ptr(), scratch[1].data_ptr(), parts.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_wgrad")
-        tot = parts.sum(0)
-        o = 0
-        dwh = tot[o:o + (D - 1) * W * W].view(D - 1, W, W); o += (D - 1) * W * W
-        dwe = tot[o:o + 2 * W * 64].view(2, W, 64); o += 2 * W * 64
-        dwo = tot[o:o + W * 64].view(W, 64); o += W * 64
-        db = tot[o:o + (D + 1) * W].view(D + 1, W)
-        n_enc = 3 + 6 * L
-        skips = set(int(s) for s in net.skips)
-        grads = []
-        for i in range(D):
-            if i == 0:
-                dw = dwe[0][:, :n_enc]
-            elif (i - 1) in skips:                                                           # x = [encoding, h] (rnh:278-282)
-                dw = torch.empty(W, n_enc + W, dtype=torch.float32, device=dev)              # (slice copies, not torch.cat: on
-                dw[:, :n_enc] = dwe[1][:, :n_enc]                                            #  ROCm every cat stages its metadata
-                dw[:, n_enc:] = dwh[i - 1]                                                   #  through a host-to-device copy)
-            else:
-                dw = dwh[i - 1]
-            grads += [dw, db[i]]
-        if views:                                              # head slot = alpha_linear (1 x W): the sigma channel's column
-            return grads + [dwo[:, 3:4].t().contiguous(), g[:, 3].sum(0, keepdim=True)]
-        dw_out = torch.zeros(C_out, W, dtype=torch.float32, device=dev)                      # the 5th channel never reaches the loss
-        dw_out[:4] = dwo[:, :4].t()
-        g_out = torch.zeros(C_out, dtype=torch.float32, device=dev)
-        g_out[:4] = g.sum(0)
-        return grads + [dw_out, g_out]
+        # every weight and bias, each in its own shape, back to back in one buffer: one launch
+        index, shapes, hb = _trunk_grad_index(net, D, W, C_out, views, n_lat, dev)
+        flat = _reduce_partials(parts, kl, index)
+        if views:                                              # head bias: the sigma channel's column sum
+            torch.sum(g[:, 3:4], 0, out=flat[hb:hb + 1])
+        else:                                                  # (the 5th channel never reaches the loss: zero)
+            torch.sum(g, 0, out=flat[hb:hb + 4])
+        return _split_flat(flat, shapes)
 
 
 _NUM_CUS = {}
@@ -344,6 +458,7 @@ class _Composite(torch.autograd.Function):
         ctx.noise = noise
         ctx.save_for_backward(raw4, rays, z)
         ctx.mark_non_differentiable(alpha, z_std, z_merged, z_new, rank_new)
+        ctx.set_materialize_grads(False)
         return rgb, disp, acc, weights, alpha, z_merged, z_std, z_new, rank_new
 
     @staticmethod
@@ -351,6 +466,8 @@ class _Composite(torch.autograd.Function):
         raw4, rays, z = ctx.saved_tensors
         N, S = int(raw4.shape[0]), int(raw4.shape[1])
         dev = raw4.device
+        if g_rgb is None and g_disp is None and g_acc is None and g_w is None:
+            return (None,) * 7
         d_raw4 = torch.empty(N, S, 4, dtype=torch.float32, device=dev)
         keep = [t.contiguous().float() if t is not None else None for t in (g_rgb, g_disp, g_acc, g_w)]
         if keep[0] is None:
@@ -377,7 +494,7 @@ class _Bender(torch.autograd.Function):
     (run_nerf_helpers.py:507-577) on the HIP library, fp32.  Gradients: latents and the bender's parameters."""
 
     @staticmethod
-    def forward(ctx, latents, model, rb, rays, z, *params):
+    def forward(ctx, latents, model, rb, rays, z, token):
         N, S = int(z.shape[0]), int(z.shape[1])
         M, dev = N * S, z.device
         BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
@@ -420,6 +537,8 @@ class _Bender(torch.autograd.Function):
         a.dz_offsets, a.dz_rigidity, a.dz_out4, a.d_latents = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), d_lat.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_backward")
+        if not ctx.needs_input_grad[5]:              # frozen bender (e.g. fitting test-time latent codes): no weight gradients
+            return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, None)
         if NATIVE_BENDER_WGRAD:
             # every weight / bias gradient of both MLPs in one launch (nrnerf_bender_wgrad): partial sums per wave, added here
             nparts = 4 * max(1, min(_num_cus(dev), (M + 1023) // 1024))
@@ -433,15 +552,9 @@ class _Bender(torch.autograd.Function):
             w.dz_offsets, w.dz_rigidity, w.dz_out4, w.partials = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), parts.data_ptr()
             with torch.cuda.device(dev):
                 _lib.check(model.lib.nrnerf_bender_wgrad(model.handle, C.byref(w), _stream(dev)), "nrnerf_bender_wgrad")
-            tot = parts.sum(0)                                                               # [jobs, 64*64 + 64]
-            dW, dB = tot[:, :4096].view(nj, 64, 64), tot[:, 4096:]
-            grads = []
-            for k, lin in enumerate(list(rb.network) + list(rb.rigidity_network)):
-                o, i_ = int(lin.weight.shape[0]), int(lin.weight.shape[1])
-                grads.append(dW[k, :o, :i_])
-                if lin.bias is not None:
-                    grads.append(dB[k, :o])
-            return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, *grads)
+            # added up into ONE flat gradient (the parameters' shapes back to back) for the bender's token
+            index, _ = _bender_grad_index(rb, dev, divergence=False)
+            return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index))
         # library route.  weight gradients dW_i = dz_i^T x_i over the stored arrays (batched library GEMMs, see _wgrad).
         dz_b, dz_r, acts_b, acts_r = dz_b.float(), dz_r.float(), acts_b.float(), acts_r.float()
         pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(M, 3)
@@ -464,7 +577,7 @@ class _Bender(torch.autograd.Function):
         for i in range(1, RD - 1):
             grads += [_wgrad(dz_r[i], acts_r[i - 1]), db_r[i]]
         grads += [_wgrad(dz_out4, acts_r[RD - 2])[3:4], dz_out4[:, 3].sum(0, keepdim=True)]
-        return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, *grads)
+        return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, torch.cat([g_.reshape(-1).float() for g_ in grads]))
 
 
 def _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r):
@@ -494,7 +607,7 @@ def _bender_params(rb):
 
 def bend_native(model, rb, rays, z, latents, details=True):
     """As `bend`, on the HIP library: rays [N,>=6], z [N,S], latents [N,L] -> bent [N,S,3], dict of [N,S,.] tensors."""
-    bent, unmasked, mask = _Bender.apply(latents, model, rb, rays, z, *_bender_params(rb))
+    bent, unmasked, mask = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)))
     if not details:
         return bent, {}
     masked = mask * unmasked                                           # rnh:567
@@ -509,28 +622,88 @@ def bend_native(model, rb, rays, z, latents, details=True):
 SPLIT_FINE_BENDER = True
 
 
-def _merge_rows(coarse_parts, new_parts, rank_new, S, I):
-    """Per-sample tensors of the S coarse samples and of the I importance samples -> the same in merged-depth order
-    [N, S + I, .]: importance sample i goes to row rank_new[:, i] (nrnerf_composite_args.rank_new), the coarse samples fill the
-    other rows in order.  Gathers under autograd: each source tensor receives its rows' gradient (scatter-add)."""
-    N, dev = int(rank_new.shape[0]), rank_new.device
-    rk = rank_new.long()
-    is_new = torch.zeros(N, S + I, dtype=torch.bool, device=dev)
-    is_new.scatter_(1, rk, True)
-    idx_new = torch.zeros(N, S + I, dtype=torch.int64, device=dev)
-    idx_new.scatter_(1, rk, torch.arange(I, device=dev).expand(N, I))
-    idx_coarse = (torch.cumsum((~is_new).to(torch.int32), 1) - 1).clamp_(0, S - 1).long()
+def _pack4(xyz: torch.Tensor, w, M: int) -> torch.Tensor:
+    """[M,4] fp32 rows (xyz, w) for nrnerf_merge_rows.  What _Bender hands out -- xyz and w as the two parts of the same
+    [M,4] rows -- is re-viewed; anything else is copied (w None: the 4th float is unspecified)."""
+    n = int(xyz.shape[-2])
+    rows_like = xyz.dtype == torch.float32 and xyz.dim() == 3 and xyz.stride() == (n * 4, 4, 1) and xyz.storage_offset() % 4 == 0 \
+        and xyz.untyped_storage().nbytes() >= (xyz.storage_offset() + M * 4) * 4
+    if rows_like and (w is None or (w.dtype == torch.float32 and w.stride() == (n * 4, 4, 1) and w.storage_offset() == xyz.storage_offset() + 3
+                                    and w.untyped_storage().data_ptr() == xyz.untyped_storage().data_ptr())):
+        return xyz.as_strided((M, 4), (4, 1), xyz.storage_offset())
+    if w is None:
+        return _rows4(xyz, M)
+    return torch.cat([xyz.reshape(M, 3).float(), w.reshape(M, 1).float()], 1)
 
-    def merge(c, n):
-        if c is None:
-            return None
-        k = c.shape[-1]
-        return torch.where(is_new[..., None], n.gather(1, idx_new[..., None].expand(N, S + I, k)),
-                           c.gather(1, idx_coarse[..., None].expand(N, S + I, k)))
-    pts = merge(coarse_parts[0], new_parts[0])
-    bent = merge(coarse_parts[1], new_parts[1])
-    details = {k: merge(coarse_parts[2][k], new_parts[2][k]) for k in coarse_parts[2]}
-    return pts, bent, details
+
+class _MergeRows(torch.autograd.Function):
+    """(bent points, unmasked offsets, rigidity mask) of the S coarse samples and of the I importance samples -> the same in
+    merged-depth order [N, S + I, .]: importance sample i goes to row rank_new[:, i] (nrnerf_composite_args.rank_new), the
+    coarse samples fill the other rows in order.  One launch each way (nrnerf_merge_rows; a permutation, so the gradient is
+    the inverse permutation), where gathers / where under autograd were ~45 launches per iteration."""
+
+    @staticmethod
+    def forward(ctx, bent_c, unm_c, mask_c, bent_n, unm_n, mask_n, rank_new):
+        N, S, I = int(bent_c.shape[0]), int(bent_c.shape[1]), int(bent_n.shape[1])
+        dev = bent_c.device
+        det = unm_c is not None                      # with the bender's details, or (None there) the bent points only
+        ca = _pack4(bent_c.detach(), mask_c.detach() if det else None, N * S)
+        na = _pack4(bent_n.detach(), mask_n.detach() if det else None, N * I)
+        cb, nb = (_pack4(unm_c.detach(), None, N * S), _pack4(unm_n.detach(), None, N * I)) if det else (None, None)
+        ma = torch.empty(N, S + I, 4, dtype=torch.float32, device=dev)
+        mb = torch.empty(N, S + I, 4, dtype=torch.float32, device=dev) if det else None
+        rk = rank_new.contiguous()
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nrnerf_merge_rows(rk.data_ptr(), N, S, I, ca.data_ptr(), ptr(cb), na.data_ptr(), ptr(nb), ma.data_ptr(),
+                                                     ptr(mb), 0, _stream(dev)), "nrnerf_merge_rows")
+        ctx.dims = (N, S, I)
+        ctx.save_for_backward(rk)
+        ctx.set_materialize_grads(False)
+        if not det:
+            return ma[..., :3], None, None
+        return ma[..., :3], mb[..., :3], ma[..., 3:4]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_bent, g_unm, g_mask):
+        (rk,) = ctx.saved_tensors
+        N, S, I = ctx.dims
+        T, dev = S + I, rk.device
+        if g_bent is None and g_unm is None and g_mask is None:
+            return (None,) * 7
+        f32 = dict(dtype=torch.float32, device=dev)
+        if g_mask is None:           # the common case (the trunk's gradient wrt the bent points): its [.,4] rows as they are
+            ga = _rows4(g_bent, N * T) if g_bent is not None else None
+        else:
+            ga = torch.cat([g_bent.reshape(N * T, 3).float() if g_bent is not None else torch.zeros(N * T, 3, **f32), g_mask.reshape(N * T, 1).float()], 1)
+        gb = _rows4(g_unm, N * T) if g_unm is not None else None
+        first, second = (ga, gb) if ga is not None else (gb, None)
+        oc = [torch.empty(N, S, 4, **f32), torch.empty(N, S, 4, **f32) if second is not None else None]
+        on = [torch.empty(N, I, 4, **f32), torch.empty(N, I, 4, **f32) if second is not None else None]
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nrnerf_merge_rows(rk.data_ptr(), N, S, I, ptr(oc[0]), ptr(oc[1]), ptr(on[0]), ptr(on[1]), ptr(first), ptr(second),
+                                                     1, _stream(dev)), "nrnerf_merge_rows")
+        (ca, cb), (na, nb) = ((oc[0], oc[1]), (on[0], on[1])) if ga is not None else ((None, oc[0]), (None, on[0]))
+        part = lambda t, lo, hi: t[..., lo:hi] if t is not None else None
+        return (part(ca, 0, 3) if g_bent is not None else None, part(cb, 0, 3), part(ca, 3, 4) if g_mask is not None else None,
+                part(na, 0, 3) if g_bent is not None else None, part(nb, 0, 3), part(na, 3, 4) if g_mask is not None else None, None)
+
+
+def _merge_rows(coarse_parts, new_parts, rank_new, rays, z_merged, scaling, detailed_output):
+    """(points, bent points, bender details) of the merged samples from those of the coarse and of the new samples."""
+    (_, bent_c, bd_c), (_, bent_n, bd_n) = coarse_parts, new_parts
+    if not bd_c:                                     # no details asked for: the bent points only
+        bent, _, _ = _MergeRows.apply(bent_c, None, None, bent_n, None, None, rank_new)
+        return None, bent, {}
+    bent, unmasked, mask = _MergeRows.apply(bent_c, bd_c["unmasked_offsets"], bd_c["rigidity_mask"], bent_n, bd_n["unmasked_offsets"],
+                                            bd_n["rigidity_mask"], rank_new)
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z_merged[:, :, None]                         # train.py:921-923 (no gradient: rays, depths)
+    masked = mask * unmasked                                                                     # rnh:567
+    if scaling is not None:
+        masked = masked * scaling                                                                # rnh:568-569
+    return pts, bent, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
 
 
 # True: the bender's weight gradients come from nrnerf_bender_wgrad (one launch); False: from batched library GEMMs.
@@ -592,7 +765,7 @@ class _Divergence(torch.autograd.Function):
     per-point latent rows and the bender's parameters (the points are a leaf nobody reads in the reference)."""
 
     @staticmethod
-    def forward(ctx, point_latents, model, rb, pts, e, *params):
+    def forward(ctx, point_latents, model, rb, pts, e, token):
         M, dev = int(pts.shape[0]), pts.device
         BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
         RD, RW = len(rb.rigidity_network), int(rb.rigidity_network[0].weight.shape[0])
@@ -612,11 +785,14 @@ class _Divergence(torch.autograd.Function):
             _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_divergence_forward")
         ctx.model, ctx.rb, ctx.dims = model, rb, (M, BD, BW, RD, RW)
         ctx.save_for_backward(pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
+        ctx.set_materialize_grads(False)
         return div
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_div):
+        if g_div is None:
+            return (None,) * 6
         pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r = ctx.saved_tensors
         model, rb = ctx.model, ctx.rb
         M, BD, BW, RD, RW = ctx.dims
@@ -636,23 +812,8 @@ class _Divergence(torch.autograd.Function):
         a.n_partials, a.partials = nparts, parts.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_divergence_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_divergence_backward")
-        tot = parts.sum(0)                                                                   # [jobs, 64*64 + 64]
-        dW, dB = tot[:, :4096].view(nj, 64, 64), tot[:, 4096:]
-        grads = []
-        for k, lin in enumerate(list(rb.network) + list(rb.rigidity_network)):
-            o, i_ = int(lin.weight.shape[0]), int(lin.weight.shape[1])
-            if k == 0:                                  # jobs 0 / 1: the point's and the latent code's columns of network[0]
-                w0 = torch.empty(o, i_, dtype=torch.float32, device=dev)
-                w0[:, :3] = dW[0, :o, :3]
-                w0[:, 3:] = dW[1, :o, :i_ - 3]
-                grads.append(w0)
-                job = 0
-            else:
-                job = k + 1
-                grads.append(dW[job, :o, :i_])
-            if lin.bias is not None:
-                grads.append(dB[job, :o])
-        return (d_lat, None, None, None, None, *grads)
+        index, _ = _bender_grad_index(rb, dev, divergence=True)
+        return (d_lat, None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index))
 
 
 def _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r):
@@ -704,19 +865,19 @@ def compute_divergence_loss(offsets_of_inputs, input_points, point_latents, ray_
     model = R.model_of_bender(ray_bender, input_points.device)
     M = int(input_points.shape[0])
     pts = input_points.detach()
-    params = _bender_params(ray_bender)
+    token = _param_token(ray_bender, _bender_params(ray_bender))
     if exact:                                            # divergence_exact (rnh:72-77): trace of J = sum_k unit_k^T J unit_k
         div = None
         for k in range(3):
             e = torch.zeros(M, 3, dtype=torch.float32, device=pts.device)
             e[:, k] = 1.0
-            d = _Divergence.apply(point_latents, model, ray_bender, pts, e, *params)
+            d = _Divergence.apply(point_latents, model, ray_bender, pts, e, token)
             div = d if div is None else div + d
     else:                                                # divergence_approx (rnh:103-113), one draw per chunk as in rnh:52-59
         e = torch.empty_like(pts)                    # randn_like(offsets) per chunk = empty_like().normal_(): same draws, no cat
         for i in range(0, M, int(chunk)):
             e[i:i + chunk, :].normal_()
-        div = _Divergence.apply(point_latents, model, ray_bender, pts, e, *params)
+        div = _Divergence.apply(point_latents, model, ray_bender, pts, e, token)
     divergence_loss = torch.abs(div)                                                         # rnh:61
     divergence_loss = divergence_loss ** 2                                                   # rnh:62
     if weights is not None:
@@ -791,11 +952,17 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         _lib.check(model.lib.nrnerf_sample_depths(rays.data_ptr(), int(rays.shape[1]), u_c.data_ptr() if u_c is not None else None, N, S,
                                                   int(bool(lindisp)), z_vals.data_ptr(), _stream(dev)), "nrnerf_sample_depths")
 
-    def bend_samples(z):
-        """(points, bent points, bender details) of the samples at depths z [N, ns]; points only when something needs them."""
+    def bend_samples(z, for_merge=False):
+        """(points, bent points, bender details) of the samples at depths z [N, ns]; points only when something needs them
+        (``for_merge``: the new samples of the split fine bender -- what _merge_rows takes, nothing derived)."""
         native = rb is not None and NATIVE_BENDER
         ns = int(z.shape[1])
         pts, bd = None, {}
+        if for_merge and native:
+            if latents is None:
+                raise ValueError("ray_bending_latents are required with a ray bender")
+            bent, unmasked, mask = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)))
+            return None, bent, (dict(unmasked_offsets=unmasked, rigidity_mask=mask) if detailed_output else {})
         if detailed_output or not native:
             pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]                    # :871-873 / 921-923
         if rb is None:
@@ -860,8 +1027,8 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             # (:920): bend only the I new samples and put every sample's point / bent point / details at its row among the
             # merged depths (as nrnerf_render's split-bender path).  Same values as bending all S + I points again; the
             # coarse samples' bender evaluation now receives the gradient of both passes in ONE backward call.
-            new_parts = bend_samples(z_new)
-            fine_parts = _merge_rows(coarse_parts, new_parts, rank_new, S, I)
+            new_parts = bend_samples(z_new, for_merge=True)
+            fine_parts = _merge_rows(coarse_parts, new_parts, rank_new, rays, z_merged, getattr(rb, "test_time_scaling", None), detailed_output)
         raw4, raw, fine_details = query(z_merged, net_f, 1 if network_fine is not None else 0, fine_parts)
         rgb_map, disp_map, acc_map, weights, alpha, _, _, _, _ = _Composite.apply(raw4, rays, z_merged, rnd.get("noise_fine"),
                                                                                   white_bkgd, 0, None)          # :943-950
@@ -923,6 +1090,32 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
                                                   N_rays=N_rays, weights=weights, backprop_into_weights=False)
         loss = loss + divergence_loss_weight * schedule * divergence_loss
     return loss, extras
+
+
+class _SelectCodes(torch.autograd.Function):
+    """codes[index]: the per-ray latent codes of a batch (training_wrapper_class.forward, train.py:173-188, indexes the stacked
+    per-frame codes by each ray's time step).  Backward as ONE small GEMM, onehot(index)^T g -- deterministic, and 0.9 ms less
+    per 16384-ray step than the sort-based accumulation autograd's indexing backward runs for 16384 rows landing on 8."""
+
+    @staticmethod
+    def forward(ctx, codes, index):
+        ctx.save_for_backward(index)
+        ctx.n = int(codes.shape[0])
+        return codes.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        onehot = torch.zeros(ctx.n, int(index.shape[0]), dtype=g.dtype, device=g.device)
+        onehot.scatter_(0, index[None, :], 1.0)
+        return onehot @ g, None
+
+
+def select_codes(codes: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """codes[index] with the cheap backward above while the one-hot matrix stays small; plain indexing otherwise."""
+    if codes.dim() != 2 or index.dim() != 1 or int(codes.shape[0]) * int(index.shape[0]) > (1 << 26):
+        return codes[index]
+    return _SelectCodes.apply(codes, index)
 
 
 class GraphedStep:
@@ -1037,7 +1230,7 @@ def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, reg
     state = {"i": 0}
 
     def loss_of(rays, target, frame, global_step):
-        loss, _ = training_loss(rays, codes[frame], target, kw, global_step=global_step, N_iters=rec["N_iters"], chunk=rec["chunk"], **weights)
+        loss, _ = training_loss(rays, select_codes(codes, frame), target, kw, global_step=global_step, N_iters=rec["N_iters"], chunk=rec["chunk"], **weights)
         return loss.mean()                                                  # train.py:1594
 
     def step():

@@ -486,6 +486,78 @@ def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S):
     close(dwo, torch.einsum("bfs,bgs->fg", A[D - 1], g_t.float()), "head")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,I,details", [(64, 64, True), (64, 128, True), (37, 11, False), (128, 128, True)])
+def test_merge_rows_kernel_vs_gather_both_directions(S, I, details):
+    """nrnerf_merge_rows (the split fine bender's row merge): forward against a sort of the depths, inverse = the
+    permutation undone, and -- under autograd, through training._MergeRows -- gradients against torch.gather's."""
+    from nonrigid_nerf_amd import training
+    N = 53
+    gen = torch.Generator().manual_seed(S * 131 + I)
+    zc = torch.sort(torch.rand(N, S, generator=gen), 1).values
+    zn = torch.sort(torch.rand(N, I, generator=gen), 1).values
+    zm, order = torch.sort(torch.cat([zc, zn], 1), 1, stable=True)
+    rank_new = torch.argsort(order, 1)[:, S:].to(torch.uint8).to(DEV)        # row of new sample i among the merged depths
+    mk = lambda n, k: torch.randn(N, n, 4, generator=gen).to(DEV)[..., :k].requires_grad_(True)
+    c4, n4 = torch.randn(N, S, 4, generator=gen).to(DEV).requires_grad_(True), torch.randn(N, I, 4, generator=gen).to(DEV).requires_grad_(True)
+    cu, nu = mk(S, 3), mk(I, 3)
+    idx = order.to(DEV)
+
+    def want(c, n):
+        both = torch.cat([c, n], 1)
+        return both.gather(1, idx[..., None].expand(N, S + I, both.shape[-1]))
+
+    if details:
+        bent, unm, mask = training._MergeRows.apply(c4[..., :3], cu, c4[..., 3:4], n4[..., :3], nu, n4[..., 3:4], rank_new)
+        assert torch.equal(bent, want(c4, n4)[..., :3]) and torch.equal(mask, want(c4, n4)[..., 3:4]) and torch.equal(unm, want(cu, nu))
+        w1, w2, w3 = (torch.randn_like(t) for t in (bent, unm, mask))
+        ((bent * w1).sum() + (unm * w2).sum() + (mask * w3).sum()).backward()
+        got = [t.grad.clone() for t in (c4, n4, cu, nu)]
+        for t in (c4, n4, cu, nu):
+            t.grad = None
+        m4, mu = want(c4, n4), want(cu, nu)
+        ((m4[..., :3] * w1).sum() + (mu * w2).sum() + (m4[..., 3:4] * w3).sum()).backward()
+        for g, t in zip(got, (c4, n4, cu, nu)):
+            assert torch.equal(g, t.grad)
+    else:
+        bent, unm, mask = training._MergeRows.apply(c4[..., :3], None, None, n4[..., :3], None, None, rank_new)
+        assert unm is None and mask is None and torch.equal(bent, want(c4, n4)[..., :3])
+        w1 = torch.randn_like(bent)
+        (bent * w1).sum().backward()
+        got = [c4.grad.clone(), n4.grad.clone()]
+        c4.grad = n4.grad = None
+        (want(c4, n4)[..., :3] * w1).sum().backward()
+        assert torch.equal(got[0], c4.grad) and torch.equal(got[1], n4.grad)
+
+
+@pytest.mark.gpu
+def test_reduce_partials_kernel_vs_sum_and_index():
+    """nrnerf_reduce_partials: records added in order into an arbitrary layout; flagged positions stop at the short count
+    (whatever the later records hold -- NaN here -- is never read), negative positions give 0."""
+    from nonrigid_nerf_amd import _lib, training
+    P, stride, n_short = 11, 5000, 4
+    gen = torch.Generator().manual_seed(3)
+    parts = torch.randn(P, stride, generator=gen).to(DEV)
+    short_cols = torch.arange(1000, 1300)
+    parts[n_short:, short_cols.to(DEV)] = float("nan")
+    index = torch.randint(0, stride, (7001,), generator=gen).to(torch.int32)
+    is_short = (index >= 1000) & (index < 1300)
+    pad = torch.rand(index.shape, generator=gen) < 0.1
+    coded = torch.where(is_short, index | _lib.REDUCE_SHORT, index)
+    coded = torch.where(pad, torch.full_like(coded, -1), coded).to(DEV)
+    got = training._reduce_partials(parts, n_short, coded)
+    torch.cuda.synchronize()
+    full = torch.zeros(stride, device=DEV)
+    for p_ in range(P):                                   # the kernel's order of additions
+        full = full + parts[p_].nan_to_num(0.0)
+    short = torch.zeros(stride, device=DEV)
+    for p_ in range(n_short):
+        short = short + parts[p_]
+    want = torch.where(is_short.to(DEV), short[index.long().to(DEV)], full[index.long().to(DEV)])
+    want = torch.where(pad.to(DEV), torch.zeros_like(want), want)
+    assert torch.equal(got, want)
+
+
 def _oracle_leaves(scene):
     from oracle import nrnerf_oracle as O
     sc = O.scene_on(scene, DEV)
