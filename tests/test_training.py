@@ -496,7 +496,7 @@ def test_merge_rows_kernel_vs_gather_both_directions(S, I, details):
     gen = torch.Generator().manual_seed(S * 131 + I)
     zc = torch.sort(torch.rand(N, S, generator=gen), 1).values
     zn = torch.sort(torch.rand(N, I, generator=gen), 1).values
-    zm, order = torch.sort(torch.cat([zc, zn], 1), 1, stable=True)
+    zm, order = torch.sort(torch.cat([zc, zn], 1), dim=1, stable=True)
     rank_new = torch.argsort(order, 1)[:, S:].to(torch.uint8).to(DEV)        # row of new sample i among the merged depths
     mk = lambda n, k: torch.randn(N, n, 4, generator=gen).to(DEV)[..., :k].requires_grad_(True)
     c4, n4 = torch.randn(N, S, 4, generator=gen).to(DEV).requires_grad_(True), torch.randn(N, I, 4, generator=gen).to(DEV).requires_grad_(True)
