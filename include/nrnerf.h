@@ -418,8 +418,8 @@ int nrnerf_merge_rows(const uint8_t* rank_new, int32_t n_rays, int32_t n_samples
  * only NRNERF_WGRAD_SHORT_PARTIALS records -- no zero-filling of the others needed on this route) and n_partials otherwise;
  * out[j] = 0 where index[j] < 0 (padding the caller wants zeroed, e.g. a parameter row no kernel produces).  `index`
  * (device, int32 [n_out]) is the caller's map from its flat gradient buffer -- every weight and bias of a network back to
- * back, each in its own shape -- to positions in one record; records are added in order (deterministic).  Runs on the device
- * that owns `out`. */
+ * back, each in its own shape -- to positions in one record.  Fixed order of additions (deterministic): eight interleaved groups
+ * of records (p = g, g + 8, ...), each added in order, then the eight group sums in order.  Runs on the device that owns `out`. */
 #define NRNERF_REDUCE_SHORT 0x40000000
 int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
                            int64_t n_out, float* out, void* hip_stream);

@@ -19,12 +19,14 @@ struct MergeRowsArgs {
 hipError_t launch_merge_rows(const MergeRowsArgs&, hipStream_t);
 
 // out[j] = sum over the first P(j) records p of parts[p * stride + (index[j] & OFFSET)],  P(j) = n_short where index[j] has
-// the SHORT flag, n_partials otherwise; 0 where index[j] < 0.  Records are added in order (deterministic).
+// the SHORT flag, n_partials otherwise; 0 where index[j] < 0.  Fixed order of additions (deterministic): REDUCE_GROUPS
+// interleaved groups of records, each added in order, then the group sums in order.
 struct ReducePartialsArgs {
     const float* parts; long long stride; int n_partials, n_short;
     const int* index; long long n_out; float* out;
 };
 constexpr int REDUCE_SHORT_FLAG = 0x40000000;
+constexpr int REDUCE_GROUPS = 8;
 hipError_t launch_reduce_partials(const ReducePartialsArgs&, hipStream_t);
 
 }  // namespace nrn

@@ -532,7 +532,7 @@ def test_merge_rows_kernel_vs_gather_both_directions(S, I, details):
 
 @pytest.mark.gpu
 def test_reduce_partials_kernel_vs_sum_and_index():
-    """nrnerf_reduce_partials: records added in order into an arbitrary layout; flagged positions stop at the short count
+    """nrnerf_reduce_partials: records added in the documented fixed order into an arbitrary layout; flagged positions stop at the short count
     (whatever the later records hold -- NaN here -- is never read), negative positions give 0."""
     from nonrigid_nerf_amd import _lib, training
     P, stride, n_short = 11, 5000, 4
@@ -547,12 +547,18 @@ def test_reduce_partials_kernel_vs_sum_and_index():
     coded = torch.where(pad, torch.full_like(coded, -1), coded).to(DEV)
     got = training._reduce_partials(parts, n_short, coded)
     torch.cuda.synchronize()
-    full = torch.zeros(stride, device=DEV)
-    for p_ in range(P):                                   # the kernel's order of additions
-        full = full + parts[p_].nan_to_num(0.0)
-    short = torch.zeros(stride, device=DEV)
-    for p_ in range(n_short):
-        short = short + parts[p_]
+    def in_kernel_order(n_records):                       # eight interleaved groups, each in order, then the groups in order
+        groups = []
+        for g in range(8):
+            acc = torch.zeros(stride, device=DEV)
+            for p_ in range(g, n_records, 8):
+                acc = acc + parts[p_].nan_to_num(0.0)
+            groups.append(acc)
+        tot = groups[0]
+        for g in range(1, 8):
+            tot = tot + groups[g]
+        return tot
+    full, short = in_kernel_order(P), in_kernel_order(n_short)
     want = torch.where(is_short.to(DEV), short[index.long().to(DEV)], full[index.long().to(DEV)])
     want = torch.where(pad.to(DEV), torch.zeros_like(want), want)
     assert torch.equal(got, want)
