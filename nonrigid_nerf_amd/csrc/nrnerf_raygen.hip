@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) wgrad_operands_kernel(const WgradOperandA
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float sn, cs;
-            sincosf(p[c] * sc, &sn, &cs);
+            sincosf(p[c] * sc, &sn, &cs);              // (the hardware sin / cos gains 10 %: the stores bound this kernel)
             v[c] = in ? sn : 0.0f;
             v[3 + c] = in ? cs : 0.0f;
         }
