@@ -196,13 +196,41 @@ def _flat_params(network_fn, network_fine, into=None):
     return into[0], into
 
 
+_SLOTS = weakref.WeakKeyDictionary()
+
+
+def _param_slots(m):
+    """Every parameter slot of module ``m`` as (the owning submodule's ``_parameters`` dict, name).  ``m.parameters()`` walks
+    the module tree through ``named_modules`` with de-duplication sets on every call -- 0.15 ms per network, three networks,
+    three calls per training step; the walk is cached and re-validated by identity: every child still sits where it sat and
+    no ``_modules`` / ``_parameters`` dict has grown or shrunk.  Reading the slot (not a cached tensor) sees a parameter
+    object that was replaced."""
+    ent = _SLOTS.get(m)
+    if ent is not None and all(d.get(n) is c for d, n, c in ent[0]) and all(len(d) == k for d, k in ent[1]):
+        return ent[2]
+    children, sizes, slots, seen, stack = [], [], [], set(), [m]
+    while stack:
+        mod = stack.pop()
+        if id(mod) in seen:
+            continue
+        seen.add(id(mod))
+        sizes += [(mod._modules, len(mod._modules)), (mod._parameters, len(mod._parameters))]
+        slots += [(mod._parameters, n) for n in mod._parameters]
+        for n, c in mod._modules.items():
+            children.append((mod._modules, n, c))
+            if c is not None:
+                stack.append(c)
+    _SLOTS[m] = (children, sizes, slots)
+    return slots
+
+
 def _fingerprint(mods):
     fp = []
     for m in mods:
         if m is None:
             fp.append(None)
             continue
-        fp.append(tuple((p.data_ptr(), p._version) for p in m.parameters()))
+        fp.append(tuple((p.data_ptr(), p._version) for p in (d[n] for d, n in _param_slots(m)) if p is not None))
     return tuple(fp)
 
 

@@ -8,7 +8,9 @@ What is native (C ABI, include/nrnerf.h; kernels in csrc/nrnerf_train.h, csrc/nr
     _wgrad``), fp32 or bf16;
   * the ray-bending and rigidity MLPs (35->64->64->64->64->3 and 3->32->32->1; ``nrnerf_bender_forward / _backward / _wgrad``):
     forward with saved activations and backward-data in exact fp32, down to the latent codes; the fine pass bends only its
-    N_importance new samples and re-uses the coarse pass' bent points (SPLIT_FINE_BENDER);
+    N_importance new samples and re-uses the coarse pass' bent points (SPLIT_FINE_BENDER; ``nrnerf_merge_rows`` puts the rows
+    in merged-depth order and undoes that for the gradient);
+  * the partial sums of every weight-gradient call added up straight into the parameters' layouts (``nrnerf_reduce_partials``);
   * the divergence regulariser (compute_divergence_loss, run_nerf_helpers.py:22-116; second order in autograd's terms): one
     forward-mode tangent through the bender and a two-chain backward (``nrnerf_bender_divergence_forward / _backward``);
   * compositing forward (raw2outputs, train.py:724-789), hierarchical sampling + merge (run_nerf_helpers.py:651-698,
@@ -30,6 +32,7 @@ by ``render.render_rays`` as before.  ``training_loss`` is the reference's whole
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -212,17 +215,19 @@ class _ParamToken(torch.autograd.Function):
         return tuple(_split_flat(g, ctx.shapes))
 
 
-_TOKENS = {}
+_TOKENS = weakref.WeakKeyDictionary()
 
 
 def _param_token(owner, params):
-    """The token of `params` for this iteration: one per (owner, parameter objects and versions, grad mode)."""
+    """The token of `params` for this iteration: one per (owner module, parameter objects and versions, grad mode).  An
+    optimiser step bumps the versions, so the next iteration builds a fresh node; a token that is re-used after a backward
+    pass is harmless (the node saves nothing)."""
     key = (tuple((id(p), p._version) for p in params), torch.is_grad_enabled())
-    hit = _TOKENS.get(id(owner))
+    hit = _TOKENS.get(owner)
     if hit is not None and hit[0] == key:
         return hit[1]
     tok = _ParamToken.apply(*params)
-    _TOKENS[id(owner)] = (key, tok)
+    _TOKENS[owner] = (key, tok)
     return tok
 
 
