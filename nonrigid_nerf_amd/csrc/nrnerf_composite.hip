@@ -462,7 +462,8 @@ __global__ void __launch_bounds__(256) merge_rows_kernel(const MergeRowsArgs a) 
         mine = (k == r) ? i : mine;
     }
     const size_t mrow = (size_t)n * T + r;
-    const size_t srow = (mine >= 0) ? (size_t)n * a.I + mine : (size_t)n * a.S + (r - before);
+    const int crow = (r - before < a.S) ? r - before : a.S - 1;       // (in range whatever rank_new holds: ranks that are not a set of I distinct rows only give wrong values)
+    const size_t srow = (mine >= 0) ? (size_t)n * a.I + mine : (size_t)n * a.S + crow;
     const f32x4* ca = (const f32x4*)(mine >= 0 ? a.n_a : a.c_a);
     const f32x4* cb = (const f32x4*)(mine >= 0 ? a.n_b : a.c_b);
     if (!a.inverse) {
@@ -489,7 +490,7 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const ReducePartia
     float s = 0.0f;
     if (j < a.n_out) {
         const int ix = a.index[j];
-        if (ix >= 0) {
+        if (ix >= 0 && (ix & (REDUCE_SHORT_FLAG - 1)) < a.stride) {          // (a position beyond the record reads nothing)
             const int P = (ix & REDUCE_SHORT_FLAG) ? a.n_short : a.n_partials;
             const float* p = a.parts + (ix & (REDUCE_SHORT_FLAG - 1));
             const size_t G = REDUCE_GROUPS;
