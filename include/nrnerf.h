@@ -340,8 +340,11 @@ int nrnerf_bender_backward(const nrnerf_model* model, const nrnerf_bender_args* 
  * n_partials partial sums (one per wave; the caller adds them) of  dW [64][64] (rows = the layer's outputs, columns = its
  * inputs; only [out_features][in_features] is meaningful) followed by db [64].  The first layers' input rows (point =
  * origin + direction * z, latent code) are formed from rays / latents / z as in nrnerf_bender_args.  Contraction: exact
- * fp32 for a model created with NRNERF_PREC_F32; otherwise the fp32 rows are rounded to bf16 in registers and contracted on
- * the bf16 matrix pipe with fp32 accumulation (the gradients entering come out of a bf16 trunk there). */
+ * fp32 for a model created with NRNERF_PREC_F32 (fp32 saved arrays); otherwise the saved arrays are bf16 and are contracted
+ * on the bf16 matrix pipe with fp32 accumulation, the fp32 rows (dz_out4, points, latent codes) rounded to bf16 in registers
+ * (the gradients entering come out of a bf16 trunk there).  The 16-bit route addresses every array by 32-bit byte offsets:
+ * n_rays * n_samples * 256 bytes must stay below 4 GiB (NRNERF_ERR_INVALID beyond, also from nrnerf_bender_divergence_backward,
+ * which forms its weight gradients the same way). */
 #define NRNERF_BENDER_WGRAD_SLOT (64 * 64 + 64)
 typedef struct nrnerf_bender_wgrad_args {
     uint32_t struct_size;       /* sizeof(nrnerf_bender_wgrad_args) */

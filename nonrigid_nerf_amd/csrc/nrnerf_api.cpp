@@ -1243,6 +1243,7 @@ int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a
     const int BD = (bender_arch(m->arch_id) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
     const int BW = ArchDefault::BW, RD = ArchDefault::RD, RW = ArchDefault::RW, X0 = 3 + ArchDefault::LAT;
     const size_t M = (size_t)a->n_rays * a->n_samples;
+    if (m->precision != NRNERF_PREC_F32 && M * 64 * 4 >= 0xffffff00ull) return NRNERF_ERR_INVALID;      // 32-bit offsets in bend_wgrad16
     BendWgradArgs w{};
     int n = 0;
     const int b16 = m->precision != NRNERF_PREC_F32;        // the saved arrays' element type; dz_out4 is fp32 in every mode
@@ -1307,9 +1308,10 @@ int nrnerf_bender_divergence_backward(const nrnerf_model* m, const nrnerf_diverg
     const int rc = divergence_common(m, a, true, t);
     if (rc != NRNERF_OK) return rc;
     if (a->n_points == 0) return NRNERF_OK;
+    const bool b16 = m->precision != NRNERF_PREC_F32;
+    if (b16 && (size_t)a->n_points * 64 * 4 >= 0xffffff00ull) return NRNERF_ERR_INVALID;      // 32-bit offsets in bend_wgrad16: nothing is launched
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    const bool b16 = m->precision != NRNERF_PREC_F32;
     hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
                                                   : launch_bend_div_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     if (e != hipSuccess) return NRNERF_ERR_HIP;
