@@ -285,7 +285,7 @@ typedef struct nrnerf_trunk_args {
                                    which the caller forms (and differentiates); the library's images of such a model hold the
                                    remaining columns.  The gradient wrt ray_bias[r][k] is the sum of d_pre[0 | skip + 1] over the
                                    ray's samples */
-    const float* d_hidden_extra;   /* [M, width] fp32 row-major or NULL: an extra gradient wrt the LAST hidden activation
+    const void* d_hidden_extra;    /* [M, width] row-major (fp32 for an NRNERF_PREC_F32 model, bf16 otherwise) or NULL: an extra gradient wrt the LAST hidden activation
                                    (relu output of pts_linears[depth-1]), added to head^T d_raw4 before the relu mask.  With the
                                    view-dependent head (run_nerf_helpers.py:284-304) the library's head slot holds alpha_linear:
                                    raw4[:, 3] is the density logit and raw4[:, 0:3] = 0; the colour branch (feature_linear,

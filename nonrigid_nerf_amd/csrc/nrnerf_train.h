@@ -325,11 +325,11 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
         dense<P, P, PL, 0, NS_DR, 0>(st, bias_lane, dr, none, [&](auto tc, const f32x16& acc) {
             constexpr int t = decltype(tc)::value;
             f32x16 g = acc;
-            if (a.d_h_extra) {
-                const float* er = a.d_h_extra + so * A::W + 32 * t + 4 * h;
+            if (a.d_h_extra) {          // rows of the saved arrays' element type: fp32, or (bf16 mode) bf16
+                const size_t er = so * A::W + 32 * t + 4 * h;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 ex = *(const f32x4*)(er + 8 * q);
+                    const f32x4 ex = load4<P>((const void*)a.d_h_extra, er + 8 * q);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g[4 * q + k] += ok ? ex[k] : 0.0f;
                 }

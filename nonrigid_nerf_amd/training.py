@@ -343,8 +343,8 @@ class _Trunk(torch.autograd.Function):
         a.which, a.n_rays, a.n_samples = ctx.which, N, S
         a.pts4, a.acts, a.d_raw4, a.d_pre, a.d_pts4 = pts4.data_ptr(), acts.data_ptr(), g.data_ptr(), d_pre.data_ptr(), d_pts4.data_ptr()
         a.relu_mask = None if f32 else ctx.saved_tensors[2].data_ptr()
-        if g_h is not None:                                    # the colour branch's gradient wrt the last hidden activation
-            g_h = g_h.reshape(M, W).float().contiguous()
+        if g_h is not None:                                    # the colour branch's gradient wrt the last hidden activation,
+            g_h = g_h.reshape(M, W).to(torch.float32 if f32 else torch.bfloat16).contiguous()      # in the saved arrays' element type
             a.d_hidden_extra = g_h.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_backward")
@@ -468,6 +468,38 @@ def finite_difference_dirs(bent: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _RowsLinear2(torch.autograd.Function):
+    """F.linear(cat([x1, x2], -1), W, b) without forming the concatenation (a [M, 283] copy per pass for the view-dependent
+    head's middle layer): two GEMMs on the column blocks of W.  Backward as _RowsLinear."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias):
+        k1 = int(x1.shape[1])
+        w = weight.to(x1.dtype)
+        ctx.save_for_backward(x1, x2, weight)
+        ctx.has_bias = bias is not None
+        y = torch.addmm(bias.to(x1.dtype), x1, w[:, :k1].t()) if bias is not None else x1 @ w[:, :k1].t()
+        return y.addmm_(x2, w[:, k1:].t())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x1, x2, weight = ctx.saved_tensors
+        k1 = int(x1.shape[1])
+        g = g.contiguous()
+        w = weight.to(g.dtype)
+        gx1 = g @ w[:, :k1] if ctx.needs_input_grad[0] else None
+        gx2 = g @ w[:, k1:] if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[2]:
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+            gw[:, :k1] = _wgrad(g, x1)
+            gw[:, k1:] = _wgrad(g, x2)
+            gw = gw.to(weight.dtype)
+        gb = _colsum(g).to(weight.dtype) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        return gx1, gx2, gw, gb
+
+
 def colour_branch(net, h_last, dirs):
     """The colour branch of the view-dependent head (run_nerf_helpers.py:286-303) as library GEMMs on the module's own
     parameters, under autograd: feature_linear, relu(views_linears[0]([feature, direction encoding])), rgb_linear.
@@ -478,7 +510,7 @@ def colour_branch(net, h_last, dirs):
     h2 = h_last.reshape(-1, h_last.shape[-1])
     feature = _RowsLinear.apply(h2, net.feature_linear.weight, net.feature_linear.bias)          # :286
     enc = posenc(dirs, L).reshape(h2.shape[0], -1).to(feature.dtype)
-    hv = F.relu(_RowsLinear.apply(torch.cat([feature, enc], -1), net.views_linears[0].weight, net.views_linears[0].bias))   # :296-301
+    hv = F.relu(_RowsLinear2.apply(feature, enc, net.views_linears[0].weight, net.views_linears[0].bias))   # :296-301
     return _RowsLinear.apply(hv, net.rgb_linear.weight, net.rgb_linear.bias).float().reshape(*lead, 3)   # :303
 
 
