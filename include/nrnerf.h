@@ -427,6 +427,13 @@ int nrnerf_merge_rows(const uint8_t* rank_new, int32_t n_rays, int32_t n_samples
 int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
                            int64_t n_out, float* out, void* hip_stream);
 
+/* Sums over the sample axis of the bf16 block tiles nrnerf_trunk_forward / _backward write ([block][feature][32 samples]):
+ * out[r] = the 32 values of row r added in order in fp32, r < n_rows = blocks * features of the layer(s) handed in.  The
+ * time-conditioned baseline's per-ray bias gradient (nrnerf_trunk_args.ray_bias) is the sum of d_pre over a ray's samples:
+ * these row sums, then the ray's blocks (the library's reduction over both axes took 1.4 ms per layer and pass at 16 384 rays,
+ * this 0.3).  Runs on the device that owns `out`. */
+int nrnerf_tile_row_sums(const void* tiles, int64_t n_rows, float* out, void* hip_stream);
+
 /* bf16 mode: the weight and bias gradients of the trunk from the two arrays nrnerf_trunk_forward / _backward filled, in
  * one launch over their [block][feature][32 samples] layout (the contraction runs over samples; no transposes):
  *   dw_hidden[i-1] = d_pre[i]^T acts[i-1]  (i = 1 .. depth-1; the skip layer's columns for its encoding input are in dw_enc)

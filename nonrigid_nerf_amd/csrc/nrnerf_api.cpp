@@ -1093,6 +1093,16 @@ int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t
     return launch_reduce_partials(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
+int nrnerf_tile_row_sums(const void* tiles, int64_t n_rows, float* out, void* hip_stream) try {
+    if (!tiles || !out || n_rows < 0) return NRNERF_ERR_INVALID;
+    if (n_rows == 0) return NRNERF_OK;
+    int dev = 0;
+    if (device_of(out, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    return launch_tile_row_sums(tiles, n_rows, out, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
 // ---- training entry points (nrnerf_train.h, composite_bwd_kernel) -------------------------------------------------
 namespace {
 int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, TrunkArgs& t) {

@@ -29,4 +29,7 @@ constexpr int REDUCE_SHORT_FLAG = 0x40000000;
 constexpr int REDUCE_GROUPS = 8;
 hipError_t launch_reduce_partials(const ReducePartialsArgs&, hipStream_t);
 
+// out[r] = sum of the 32 bf16 values of row r of a [rows][32] array (the sample axis of the training path's block tiles), fp32
+hipError_t launch_tile_row_sums(const void* tiles, long long n_rows, float* out, hipStream_t);
+
 }  // namespace nrn

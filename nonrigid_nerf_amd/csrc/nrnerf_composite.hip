@@ -517,4 +517,29 @@ hipError_t launch_reduce_partials(const ReducePartialsArgs& a, hipStream_t strea
     return hipGetLastError();
 }
 
+// one thread per row of 32 bf16 (64 bytes, four 16-byte loads), added in order in fp32
+__global__ void __launch_bounds__(256) tile_row_sums_kernel(const void* tiles, long long n_rows, float* out) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* p = (const u32x4*)tiles + r * 4;
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32x4 w = p[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s = __fadd_rn(s, __builtin_bit_cast(float, w[k] << 16));
+            s = __fadd_rn(s, __builtin_bit_cast(float, w[k] & 0xffff0000u));
+        }
+    }
+    out[r] = s;
+}
+hipError_t launch_tile_row_sums(const void* tiles, long long n_rows, float* out, hipStream_t stream) {
+    if (n_rows <= 0) return hipSuccess;
+    if (n_rows >= (1ll << 39)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tile_row_sums_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, tiles, n_rows, out);
+    return hipGetLastError();
+}
+
 }  // namespace nrn

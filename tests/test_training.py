@@ -564,6 +564,20 @@ def test_reduce_partials_kernel_vs_sum_and_index():
     assert torch.equal(got, want)
 
 
+@pytest.mark.gpu
+def test_tile_row_sums_kernel_vs_torch():
+    """nrnerf_tile_row_sums: rows of 32 bf16 added in fp32 (the per-ray bias gradient of the time-conditioned baseline)."""
+    from nonrigid_nerf_amd import _lib
+    gen = torch.Generator().manual_seed(9)
+    for n_rows in (1, 255, 70001):
+        x = torch.randn(n_rows, 32, generator=gen).to(torch.bfloat16).to(DEV)
+        out = torch.full((n_rows,), float("nan"), device=DEV)
+        _lib.check(_lib.load().nrnerf_tile_row_sums(x.data_ptr(), n_rows, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "nrnerf_tile_row_sums")
+        torch.cuda.synchronize()
+        want = x.double().sum(1)
+        assert float((out.double() - want).abs().max()) <= 1e-5
+
+
 def _oracle_leaves(scene):
     from oracle import nrnerf_oracle as O
     sc = O.scene_on(scene, DEV)

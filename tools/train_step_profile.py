@@ -16,7 +16,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 1024
 prec = args[1] if len(args) > 1 else "bf16"
 dev = torch.device("cuda:0")
-CFG = SceneConfig(use_viewdirs=True) if "--views" in sys.argv else SceneConfig()          # --views: the view-dependent head
+CFG = SceneConfig(use_viewdirs=True) if "--views" in sys.argv else (SceneConfig(ray_bending=False, time_conditioned_baseline=True) if "--tcb" in sys.argv else SceneConfig())   # --views: view-dependent head; --tcb: time-conditioned baseline
 _SceneConfig, SceneConfig = SceneConfig, (lambda: CFG)
 if "--table" in sys.argv:
     from torch.profiler import ProfilerActivity, profile
