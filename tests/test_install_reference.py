@@ -268,6 +268,71 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
               f"{min(c for _, c, _ in rows):.5f}; largest max-error / scale: " + "; ".join(f"{k[0]}.{k[1]} {e:.1e} (cos {c:.5f})" for e, c, k in rows[:6]))
 
 
+@pytest.mark.gpu
+def test_reference_training_loop_is_faster_after_install(reference, capsys):
+    """What a user of the reference gains by the two-line drop-in, measured on the reference's REAL modules and its own
+    ``training_wrapper_class`` (train.py:152-287) with the shipped recipe, N_rand = 1024: forward + backward + Adam step
+    (train.py:1594-1610), eagerly on this device (the unmodified reference) and after ``install()`` in "f32" (the default:
+    exact) and "bf16" mode.  Asserts only that the drop-in is not slower; the numbers go to profiles/."""
+    import argparse
+    import time
+    from nonrigid_nerf_amd import render as R
+    G, H, T = reference
+    dev = torch.device("cuda:0")
+    T.device = dev
+    ts = G.TRAIN_STEP
+    n_rays = 1024
+    from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
+    cfg = SceneConfig(N_importance=ts["N_importance"])
+    scene = make_scene(cfg, ts["seed"])
+    rays, _ = make_rays(n_rays, ts["seed"], cfg)
+    g = torch.Generator().manual_seed(11)
+    codes0 = torch.randn(ts["n_frames"], cfg.latent_size, generator=g) * 0.1
+    image_ids = torch.randint(0, ts["n_frames"], (n_rays,), generator=g)
+    target = torch.rand(n_rays, 3, generator=g).to(dev)
+    args = argparse.Namespace(offsets_loss_weight=ts["offsets_loss_weight"], divergence_loss_weight=ts["divergence_loss_weight"],
+                              rigidity_loss_weight=ts["rigidity_loss_weight"], chunk=ts["chunk"], N_iters=ts["N_iters"],
+                              N_samples=ts["N_samples"], ray_bending_latent_size=cfg.latent_size)
+    bpi = torch.stack([image_ids, torch.zeros_like(image_ids), torch.zeros_like(image_ids)], 1)
+    ro, rd = rays[:, 0:3].to(dev), rays[:, 3:6].to(dev)
+
+    def ms_per_iteration(precision, iters):
+        kw, rb, coarse, fine = _to_device(H, T, G, scene, dev)
+        kw.update(perturb=ts["perturb"], raw_noise_std=ts["raw_noise_std"])
+        codes = [c.clone().to(dev).requires_grad_(True) for c in codes0]
+        wrapper = T.training_wrapper_class(coarse, codes, fine_model=fine, ray_bender=rb)
+        params = list(coarse.parameters()) + list(fine.parameters()) + list(rb.parameters()) + codes
+        opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))                    # train.py:655-658
+        undo = R.install(T, precision=precision) if precision else None
+        try:
+            def it(i):
+                opt.zero_grad()
+                loss = wrapper(args, ro, rd, 100, dict(kw), target, ts["global_step"] + i, 0,
+                               {"imageid_to_timestepid": list(range(ts["n_frames"]))}, bpi)
+                loss.mean().backward()
+                opt.step()
+            for i in range(3):
+                it(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(iters):
+                it(3 + i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / iters * 1e3
+        finally:
+            if undo is not None:
+                undo()
+
+    eager = ms_per_iteration(None, 10)
+    f32 = ms_per_iteration("f32", 30)
+    bf16 = ms_per_iteration("bf16", 30)
+    with capsys.disabled():
+        print(f"\n[reference training loop, {n_rays} rays, real modules, shipped recipe, forward + backward + Adam] unmodified reference on this "
+              f"GPU (eager PyTorch-ROCm): {eager:.1f} ms / iteration; after install(): f32 {f32:.2f} ms ({eager / f32:.1f} x), "
+              f"bf16 {bf16:.2f} ms ({eager / bf16:.1f} x)")
+    assert f32 < eager and bf16 < eager
+
+
 def test_install_rebinds_compute_divergence_loss_and_falls_back_without_a_gpu(reference):
     """install() also rebinds ``train.compute_divergence_loss`` (star-imported from run_nerf_helpers, called at
     train.py:266).  On CPU tensors the native kernels cannot take the call: it must reach the saved reference function with

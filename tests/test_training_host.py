@@ -182,3 +182,35 @@ def test_bender_gradient_index_table_matches_the_slots(divergence, depth):
         if lin.bias is not None:
             assert torch.equal(got[k_out], dB[job, :o]), k
             k_out += 1
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2)])
+def test_rows_linear_functions_match_f_linear_autograd(dtype, tol):
+    """training._RowsLinear / _RowsLinear2 (the colour branch's layers: dW as batched partial products, db in two stages, the
+    middle layer without the concatenation) against F.linear under autograd, values and all gradients."""
+    g = torch.Generator().manual_seed(5)
+    M = 16384                                    # four row blocks
+    x1 = torch.randn(M, 256, generator=g).to(dtype).requires_grad_(True)
+    x2 = torch.randn(M, 27, generator=g).to(dtype).requires_grad_(True)
+    w = (torch.randn(128, 283, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(128, generator=g).requires_grad_(True)
+    wt = torch.randn(M, 128, generator=g)
+
+    def grads(y):
+        for t in (x1, x2, w, b):
+            t.grad = None
+        (y.float() * wt).sum().backward()
+        return [t.grad.float().clone() for t in (x1, x2, w, b)]
+
+    y_cat = T._RowsLinear.apply(torch.cat([x1, x2], -1), w, b)
+    g_cat = grads(y_cat)
+    y_two = T._RowsLinear2.apply(x1, x2, w, b)
+    g_two = grads(y_two)
+    y_ref = torch.nn.functional.linear(torch.cat([x1, x2], -1).float(), w, b)
+    g_ref = grads(y_ref)
+    for y in (y_cat, y_two):
+        assert float((y.float() - y_ref).abs().max()) <= tol * float(y_ref.abs().max())
+    for got in (g_cat, g_two):
+        for a, r in zip(got, g_ref):
+            assert float((a - r).abs().max()) <= tol * float(r.abs().max())
+    assert torch.allclose(T._colsum(wt), wt.sum(0), rtol=1e-5, atol=1e-3)
