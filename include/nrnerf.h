@@ -434,6 +434,23 @@ int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t
  * this 0.3).  Runs on the device that owns `out`. */
 int nrnerf_tile_row_sums(const void* tiles, int64_t n_rows, float* out, void* hip_stream);
 
+/* One layer of the bf16 block tiles ([block][feature][32 samples], e.g. the last hidden activation acts[depth - 1]) as
+ * rows [n_rays * n_samples][width] bf16 (only the samples a ray has).  Training with the view-dependent head hands the
+ * last hidden activation to the colour branch's GEMMs this way (a strided library copy took 0.9 ms per pass at 16 384 rays).
+ * Runs on the device that owns `rows`. */
+int nrnerf_tiles_to_rows(const void* tiles, int32_t n_rays, int32_t n_samples, int32_t width, void* rows, void* hip_stream);
+
+/* The view-dependent head's direction input under autograd, for models with a ray bender (run_nerf_helpers.py:288-290,
+ * viewdirs_via_finite_differences :316-356, Embedder :120-150): per sample j of a ray the direction
+ * d_j = (p_j - p_{j-1}) / (|p_j - p_{j-1}| + 1e-6) of the BENT points (d_0 = d_1) and its encoding
+ * [d, sin(2^k d), cos(2^k d)], k < n_freqs -- one row of 3 + 6 n_freqs values, fp32 or bf16 (`enc_is_bf16`).
+ * g_bent4 == NULL: forward, writes `enc` [n_rays * n_samples][3 + 6 n_freqs] from bent4 [n_rays][n_samples][4].
+ * g_bent4 != NULL: backward, reads the gradient wrt those rows from `enc` and writes the gradient wrt the bent points
+ * ([.,4] rows, w = 0): through the encoding, the normalisation and both differences a point takes part in.
+ * n_samples >= 2.  Runs on the device that owns `enc`. */
+int nrnerf_direction_encoding(const float* bent4, int32_t n_rays, int32_t n_samples, int32_t n_freqs, void* enc, int32_t enc_is_bf16,
+                              float* g_bent4, void* hip_stream);
+
 /* bf16 mode: the weight and bias gradients of the trunk from the two arrays nrnerf_trunk_forward / _backward filled, in
  * one launch over their [block][feature][32 samples] layout (the contraction runs over samples; no transposes):
  *   dw_hidden[i-1] = d_pre[i]^T acts[i-1]  (i = 1 .. depth-1; the skip layer's columns for its encoding input are in dw_enc)

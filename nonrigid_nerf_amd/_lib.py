@@ -187,6 +187,8 @@ EXPORTS = {
                                     C.c_int32, C.c_void_p]),
     "nrnerf_reduce_partials": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nrnerf_tile_row_sums": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nrnerf_tiles_to_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "nrnerf_direction_encoding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "nrnerf_trunk_forward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
     "nrnerf_trunk_backward": (C.c_int, [C.c_void_p, C.POINTER(TrunkArgs), C.c_void_p]),
     "nrnerf_trunk_wgrad": (C.c_int, [C.c_void_p, C.POINTER(WgradArgs), C.c_void_p]),

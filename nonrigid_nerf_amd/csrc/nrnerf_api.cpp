@@ -1103,6 +1103,28 @@ int nrnerf_tile_row_sums(const void* tiles, int64_t n_rows, float* out, void* hi
     return launch_tile_row_sums(tiles, n_rows, out, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
+int nrnerf_tiles_to_rows(const void* tiles, int32_t n_rays, int32_t n_samples, int32_t width, void* rows, void* hip_stream) try {
+    if (!tiles || !rows || n_rays < 0 || n_samples < 1 || n_samples > 256 || (width != 256 && width != 128)) return NRNERF_ERR_INVALID;
+    if (n_rays == 0) return NRNERF_OK;
+    int dev = 0;
+    if (device_of(rows, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    return launch_tiles_to_rows(tiles, n_rays, n_samples, width, rows, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
+int nrnerf_direction_encoding(const float* bent4, int32_t n_rays, int32_t n_samples, int32_t n_freqs, void* enc, int32_t enc_is_bf16,
+                              float* g_bent4, void* hip_stream) try {
+    if (!bent4 || !enc || n_rays < 0 || n_samples < 2 || n_samples > 256 || n_freqs < 0 || n_freqs > 10) return NRNERF_ERR_INVALID;
+    if (n_rays == 0) return NRNERF_OK;
+    int dev = 0;
+    if (device_of(enc, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    DirEncodingArgs d{bent4, n_rays, n_samples, n_freqs, enc, enc_is_bf16 ? 1 : 0, g_bent4};
+    return launch_dir_encoding(d, g_bent4 != nullptr, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
 // ---- training entry points (nrnerf_train.h, composite_bwd_kernel) -------------------------------------------------
 namespace {
 int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, TrunkArgs& t) {

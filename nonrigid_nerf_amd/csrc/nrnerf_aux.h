@@ -32,4 +32,19 @@ hipError_t launch_reduce_partials(const ReducePartialsArgs&, hipStream_t);
 // out[r] = sum of the 32 bf16 values of row r of a [rows][32] array (the sample axis of the training path's block tiles), fp32
 hipError_t launch_tile_row_sums(const void* tiles, long long n_rows, float* out, hipStream_t);
 
+// [block][feature][32 samples] bf16 tiles of one layer -> rows [n_rays * S][W] bf16 (the samples a ray really has)
+hipError_t launch_tiles_to_rows(const void* tiles, int n_rays, int S, int W, void* rows, hipStream_t);
+
+// The view-dependent head's input under autograd (run_nerf_helpers.py:288-290, 316-356, 120-150): finite-difference view
+// directions of the bent points, d_j = (p_j - p_{j-1}) / (|p_j - p_{j-1}| + 1e-6), d_0 = d_1, and their positional encoding
+// [d, sin(2^k d), cos(2^k d)] (k < L), one row of 3 + 6 L values per sample; backward: gradient wrt the bent points.
+struct DirEncodingArgs {
+    const float* bent4;      // [N][S][4] (xyz)
+    int n_rays, S, L;
+    void* enc;               // forward out / backward in (the gradient): [N * S][3 + 6 L], fp32 or bf16
+    int enc_bf16;
+    float* g_bent4;          // backward out [N][S][4] (w = 0)
+};
+hipError_t launch_dir_encoding(const DirEncodingArgs&, bool backward, hipStream_t);
+
 }  // namespace nrn

@@ -542,4 +542,143 @@ hipError_t launch_tile_row_sums(const void* tiles, long long n_rows, float* out,
     return hipGetLastError();
 }
 
+// one workgroup per tile: 16-byte loads of the tile into LDS, then per (sample, 8 features) eight 2-byte LDS reads down a
+// column (the 32 lanes of a half wave read 32 consecutive samples: conflict-free) and one 16-byte store into the sample's row
+__global__ void __launch_bounds__(256) tiles_to_rows_kernel(const void* tiles, int n_rays, int S, int W, void* rows) {
+    __shared__ unsigned short t[256 * 32];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int bpr = (S + 31) >> 5;
+    const long long blk = blockIdx.x;
+    const int ray = (int)(blk / bpr), s0 = (int)(blk % bpr) * 32;
+    const u32x4* src = (const u32x4*)tiles + blk * (W * 4);
+    for (int c = threadIdx.x; c < W * 4; c += 256) ((u32x4*)t)[c] = src[c];
+    __syncthreads();
+    const int s = threadIdx.x & 31;
+    if (s0 + s >= S) return;
+    unsigned short* dst = (unsigned short*)rows + ((size_t)ray * S + s0 + s) * W;
+    for (int g = threadIdx.x >> 5; g < W / 8; g += 8) {
+        u32x4 w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = (unsigned)t[(8 * g + 2 * k) * 32 + s] | ((unsigned)t[(8 * g + 2 * k + 1) * 32 + s] << 16);
+        *(u32x4*)(dst + 8 * g) = w;
+    }
+}
+hipError_t launch_tiles_to_rows(const void* tiles, int n_rays, int S, int W, void* rows, hipStream_t stream) {
+    if (n_rays <= 0 || S < 1 || (W != 256 && W != 128)) return hipErrorInvalidValue;
+    const long long nblk = (long long)n_rays * ((S + 31) / 32);
+    if (nblk >= (1ll << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tiles_to_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, tiles, n_rays, S, W, rows);
+    return hipGetLastError();
+}
+
+// finite-difference view directions + their encoding, one thread per sample
+namespace {
+struct Dir { float d[3]; float r, n; };        // direction, |diff|, |diff| + eps
+__device__ __forceinline__ Dir dir_at(const float* bent4, size_t ray0, int m) {      // direction of sample m >= 1 (p_m - p_{m-1})
+    const f32x4 a = *(const f32x4*)(bent4 + (ray0 + m) * 4), b = *(const f32x4*)(bent4 + (ray0 + m - 1) * 4);
+    Dir o;
+    const float x = __fsub_rn(a[0], b[0]), y = __fsub_rn(a[1], b[1]), z = __fsub_rn(a[2], b[2]);
+    o.r = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    o.n = __fadd_rn(o.r, 0.000001f);
+    o.d[0] = __fdiv_rn(x, o.n); o.d[1] = __fdiv_rn(y, o.n); o.d[2] = __fdiv_rn(z, o.n);
+    return o;
+}
+template <bool B16>
+__device__ __forceinline__ float enc_get(const void* p, size_t i) {
+    if constexpr (B16) return __builtin_bit_cast(float, (unsigned)((const unsigned short*)p)[i] << 16);
+    else return ((const float*)p)[i];
+}
+// gradient wrt the direction of row `row` (whose direction is d) from that row's encoding gradient
+template <bool B16>
+__device__ __forceinline__ void dir_grad(const DirEncodingArgs& a, size_t row, const float (&d)[3], float (&g)[3]) {
+    const int C = 3 + 6 * a.L;
+    const size_t o = row * C;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = enc_get<B16>(a.enc, o + c);
+    for (int k = 0; k < a.L; ++k) {
+        const float sc = (float)(1 << k);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sn, cs;
+            sincosf(__fmul_rn(d[c], sc), &sn, &cs);
+            g[c] += sc * (cs * enc_get<B16>(a.enc, o + 3 + 6 * k + c) - sn * enc_get<B16>(a.enc, o + 3 + 6 * k + 3 + c));
+        }
+    }
+}
+// gradient wrt diff_m = p_m - p_{m-1} (m >= 1): row m's direction gradient (+ row 0's for m == 1) through the normalisation
+template <bool B16>
+__device__ __forceinline__ void diff_grad(const DirEncodingArgs& a, size_t ray0, int m, float (&dd)[3]) {
+    const Dir D = dir_at(a.bent4, ray0, m);
+    float G[3];
+    dir_grad<B16>(a, ray0 + m, D.d, G);
+    if (m == 1) {
+        float G0[3];
+        dir_grad<B16>(a, ray0, D.d, G0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) G[c] += G0[c];
+    }
+    const float dot = D.d[0] * G[0] + D.d[1] * G[1] + D.d[2] * G[2];
+    const float k2 = D.r > 0.0f ? dot / D.r : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dd[c] = G[c] / D.n - D.d[c] * k2;
+}
+}  // namespace
+template <bool B16>
+__global__ void __launch_bounds__(256) dir_encoding_fwd_kernel(const DirEncodingArgs a) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)a.n_rays * a.S) return;
+    const int j = (int)(t % a.S);
+    const size_t ray0 = (size_t)(t - j);
+    const Dir D = dir_at(a.bent4, ray0, j > 0 ? j : 1);
+    const int C = 3 + 6 * a.L;
+    auto put = [&](int i, float v) {
+        if constexpr (B16) ((__bf16*)a.enc)[(size_t)t * C + i] = (__bf16)v;
+        else ((float*)a.enc)[(size_t)t * C + i] = v;
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) put(c, D.d[c]);
+    for (int k = 0; k < a.L; ++k) {
+        const float sc = (float)(1 << k);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sn, cs;
+            sincosf(__fmul_rn(D.d[c], sc), &sn, &cs);
+            put(3 + 6 * k + c, sn);
+            put(3 + 6 * k + 3 + c, cs);
+        }
+    }
+}
+template <bool B16>
+__global__ void __launch_bounds__(256) dir_encoding_bwd_kernel(const DirEncodingArgs a) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)a.n_rays * a.S) return;
+    const int j = (int)(t % a.S);
+    const size_t ray0 = (size_t)(t - j);
+    float g[3] = {0.0f, 0.0f, 0.0f}, dd[3];
+    if (j >= 1) {                       // p_j is the minuend of diff_j ...
+        diff_grad<B16>(a, ray0, j, dd);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] += dd[c];
+    }
+    if (j + 1 < a.S) {                  // ... and the subtrahend of diff_{j+1}
+        diff_grad<B16>(a, ray0, j + 1, dd);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] -= dd[c];
+    }
+    *(f32x4*)(a.g_bent4 + (size_t)t * 4) = f32x4{g[0], g[1], g[2], 0.0f};
+}
+hipError_t launch_dir_encoding(const DirEncodingArgs& a, bool backward, hipStream_t stream) {
+    if (a.n_rays <= 0 || a.S < 2 || a.L < 0 || a.L > 10) return hipErrorInvalidValue;
+    const long long total = (long long)a.n_rays * a.S;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (!backward) {
+        if (a.enc_bf16) hipLaunchKernelGGL(dir_encoding_fwd_kernel<true>, grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(dir_encoding_fwd_kernel<false>, grid, dim3(256), 0, stream, a);
+    } else {
+        if (a.enc_bf16) hipLaunchKernelGGL(dir_encoding_bwd_kernel<true>, grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(dir_encoding_bwd_kernel<false>, grid, dim3(256), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace nrn

@@ -323,7 +323,9 @@ class _Trunk(torch.autograd.Function):
             h_last = acts[D - 1].view(N, S, W)                                               # [M][W] rows, as saved
         else:                                                                                # [block][feature][32 samples] tiles
             bpr = (S + 31) // 32
-            h_last = acts[D - 1].view(N, bpr, W, 32).permute(0, 1, 3, 2).reshape(N, bpr * 32, W)[:, :S]    # bf16, as saved: the colour branch's GEMMs run in it
+            h_last = torch.empty(N, S, W, dtype=torch.bfloat16, device=dev)    # bf16, as saved: the colour branch's GEMMs run in it
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().nrnerf_tiles_to_rows(acts[D - 1].data_ptr(), N, S, W, h_last.data_ptr(), _stream(dev)), "nrnerf_tiles_to_rows")
         return raw4.view(N, S, 4), raw.view(N, S, C_out), h_last
 
     @staticmethod
@@ -474,6 +476,43 @@ def finite_difference_dirs(bent: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# True: the finite-difference view directions of the bent points and their encoding come from nrnerf_direction_encoding (one
+# launch each way); False: from torch ops under autograd (finite_difference_dirs, posenc: ~40 launches per pass).
+NATIVE_DIRECTION_ENCODING = True
+
+
+class _DirectionEncoding(torch.autograd.Function):
+    """[N*S, 3 + 6 L] encoding of the finite-difference view directions of bent points [N,S,3] (finite_difference_dirs +
+    posenc: run_nerf_helpers.py:316-356, 120-150) in `dtype`, on the HIP library; gradient: the bent points."""
+
+    @staticmethod
+    def forward(ctx, bent, n_freqs, dtype):
+        N, S = int(bent.shape[0]), int(bent.shape[1])
+        dev = bent.device
+        b4 = _rows4(bent.detach(), N * S)
+        enc = torch.empty(N * S, 3 + 6 * int(n_freqs), dtype=dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nrnerf_direction_encoding(b4.data_ptr(), N, S, int(n_freqs), enc.data_ptr(), int(dtype == torch.bfloat16), None,
+                                                            _stream(dev)), "nrnerf_direction_encoding")
+        ctx.save_for_backward(b4)
+        ctx.dims = (N, S, int(n_freqs))
+        return enc
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (b4,) = ctx.saved_tensors
+        N, S, L = ctx.dims
+        g = g.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        out = torch.empty(N, S, 4, dtype=torch.float32, device=b4.device)
+        with torch.cuda.device(b4.device):
+            _lib.check(_lib.load().nrnerf_direction_encoding(b4.data_ptr(), N, S, L, g.data_ptr(), int(g.dtype == torch.bfloat16), out.data_ptr(),
+                                                            _stream(b4.device)), "nrnerf_direction_encoding")
+        return out[..., :3], None, None
+
+
 class _RowsLinear2(torch.autograd.Function):
     """F.linear(cat([x1, x2], -1), W, b) without forming the concatenation (a [M, 283] copy per pass for the view-dependent
     head's middle layer): two GEMMs on the column blocks of W.  Backward as _RowsLinear."""
@@ -506,16 +545,19 @@ class _RowsLinear2(torch.autograd.Function):
         return gx1, gx2, gw, gb
 
 
-def colour_branch(net, h_last, dirs):
+def colour_branch(net, h_last, dirs=None, enc=None):
     """The colour branch of the view-dependent head (run_nerf_helpers.py:286-303) as library GEMMs on the module's own
     parameters, under autograd: feature_linear, relu(views_linears[0]([feature, direction encoding])), rgb_linear.
-    h_last [N,S,W] (fp32, or bf16 from a bf16 trunk: the GEMMs then run in bf16 with fp32 accumulation), dirs [N,S,3] -> rgb
-    logits [N,S,3] fp32.  (The density branch, alpha_linear, is in the native trunk kernel.)"""
+    h_last [N,S,W] (fp32, or bf16 from a bf16 trunk: the GEMMs then run in bf16 with fp32 accumulation); dirs [N,S,3], or
+    their encoding `enc` [N*S, 3 + 6 L] already -> rgb logits [N,S,3] fp32.  (The density branch, alpha_linear, is in the
+    native trunk kernel.)"""
     L = (int(net.input_ch_views) - 3) // 6
     lead = tuple(h_last.shape[:-1])
     h2 = h_last.reshape(-1, h_last.shape[-1])
     feature = _RowsLinear.apply(h2, net.feature_linear.weight, net.feature_linear.bias)          # :286
-    enc = posenc(dirs, L).reshape(h2.shape[0], -1).to(feature.dtype)
+    if enc is None:
+        enc = posenc(dirs, L).reshape(h2.shape[0], -1)
+    enc = enc.to(feature.dtype)
     hv = F.relu(_RowsLinear2.apply(feature, enc, net.views_linears[0].weight, net.views_linears[0].bias))   # :296-301
     return _RowsLinear.apply(hv, net.rgb_linear.weight, net.rgb_linear.bias).float().reshape(*lead, 3)   # :303
 
@@ -1100,11 +1142,13 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             return raw4, raw, details
         # view-dependent head (rnh:284-304): density natively, colour branch on the last hidden activation
         sigma4, _, h_last = _Trunk.apply(bent, model, net, which, ray_bias, *_trunk_params(net))
-        if rb is not None:
-            dirs = finite_difference_dirs(bent)                                              # rnh:288-290 (approx_nonrigid_viewdirs)
+        Lv = (int(net.input_ch_views) - 3) // 6
+        if rb is not None and NATIVE_DIRECTION_ENCODING and bent.is_cuda and ns >= 2:
+            rgb = colour_branch(net, h_last, enc=_DirectionEncoding.apply(bent, Lv, h_last.dtype))    # rnh:288-290, one launch each way
+        elif rb is not None:
+            rgb = colour_branch(net, h_last, finite_difference_dirs(bent))                   # rnh:288-290 (approx_nonrigid_viewdirs)
         else:
-            dirs = rays[:, None, 8:11].expand(N, ns, 3)                                      # train.py:73-76
-        rgb = colour_branch(net, h_last, dirs)
+            rgb = colour_branch(net, h_last, rays[:, None, 8:11].expand(N, ns, 3))           # train.py:73-76
         raw4 = sigma4 + F.pad(rgb, (0, 1))                                                   # cat[rgb, alpha] (rnh:304): sigma4[..., :3] == 0
         return raw4, raw4.detach(), details
 

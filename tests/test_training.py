@@ -578,6 +578,48 @@ def test_tile_row_sums_kernel_vs_torch():
         assert float((out.double() - want).abs().max()) <= 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,S", [(256, 128), (256, 85), (128, 64)])
+def test_tiles_to_rows_kernel_vs_permute(W, S):
+    """nrnerf_tiles_to_rows: [block][feature][32 samples] bf16 tiles -> [ray][sample][feature] rows, ragged sample counts."""
+    from nonrigid_nerf_amd import _lib
+    N, bpr = 19, (S + 31) // 32
+    gen = torch.Generator().manual_seed(S)
+    tiles = torch.randn(N * bpr, W, 32, generator=gen).to(torch.bfloat16).to(DEV)
+    rows = torch.full((N, S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.load().nrnerf_tiles_to_rows(tiles.data_ptr(), N, S, W, rows.data_ptr(), torch.cuda.current_stream().cuda_stream), "nrnerf_tiles_to_rows")
+    torch.cuda.synchronize()
+    want = tiles.view(N, bpr, W, 32).permute(0, 1, 3, 2).reshape(N, bpr * 32, W)[:, :S]
+    assert torch.equal(rows, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+def test_direction_encoding_kernel_vs_torch_autograd(dtype, tol):
+    """nrnerf_direction_encoding (training._DirectionEncoding) against finite_difference_dirs + posenc under autograd:
+    the encoding rows and the gradient wrt the bent points (through the encoding, the normalisation, both differences a
+    point takes part in, and sample 0 sharing sample 1's direction)."""
+    from nonrigid_nerf_amd import training
+    N, S, L = 37, 53, 4
+    gen = torch.Generator().manual_seed(2)
+    walk = torch.cumsum(torch.rand(N, S, 3, generator=gen) * 0.02 + 0.001, 1) + torch.randn(N, 1, 3, generator=gen)      # points marching along a ray
+    b4 = torch.zeros(N, S, 4)
+    b4[..., :3] = walk
+    b4 = b4.to(DEV).requires_grad_(True)
+    bent = b4[..., :3]
+    enc = training._DirectionEncoding.apply(bent, L, dtype)
+    want = training.posenc(training.finite_difference_dirs(bent), L).reshape(N * S, -1)
+    assert enc.dtype == dtype and float((enc.float() - want).abs().max()) <= tol
+    w = torch.randn(N * S, 3 + 6 * L, generator=gen).to(DEV)
+    (enc.float() * w).sum().backward()
+    got = b4.grad.clone()
+    b4.grad = None
+    (want * w).sum().backward()
+    scale = float(b4.grad.abs().max())
+    assert float((got - b4.grad).abs().max()) <= (2e-5 if dtype == torch.float32 else 2e-2) * scale, (float((got - b4.grad).abs().max()), scale)
+    assert float(got[..., 3].abs().max()) == 0.0
+
+
 def _oracle_leaves(scene):
     from oracle import nrnerf_oracle as O
     sc = O.scene_on(scene, DEV)
