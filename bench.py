@@ -274,9 +274,9 @@ def main():
     extra = {}
     if rank == 0:
         with torch.no_grad():
-            if not args.no_psnr:
-                extra["psnr_vs_oracle_db"] = psnr_vs_oracle(args, scene, cfg, rays, latents, api, kw, dev)
-        if not args.no_train_step and args.precision != "f16" and not (args.use_viewdirs or args.exact_viewdirs or args.netwidth != 256):
+            if not args.no_psnr and world == 1:          # (the accuracy / training / CPU legs belong to the N = 1 line: the other
+                extra["psnr_vs_oracle_db"] = psnr_vs_oracle(args, scene, cfg, rays, latents, api, kw, dev)     # ranks of a multi-GPU run would wait for rank 0)
+        if world == 1 and not args.no_train_step and args.precision != "f16" and not (args.use_viewdirs or args.exact_viewdirs or args.netwidth != 256):
             extra["train_step"] = train_step_leg(args, scene, cfg, dev)          # needs autograd: outside the no_grad block
         with torch.no_grad():
             gemm = library_gemm_tflops(dev, args.precision) if world == 1 else None
