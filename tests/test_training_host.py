@@ -214,3 +214,32 @@ def test_rows_linear_functions_match_f_linear_autograd(dtype, tol):
         for a, r in zip(got, g_ref):
             assert float((a - r).abs().max()) <= tol * float(r.abs().max())
     assert torch.allclose(T._colsum(wt), wt.sum(0), rtol=1e-5, atol=1e-3)
+
+
+def test_folded_feature_linear_equals_the_two_layers():
+    """training.colour_branch with feature_linear folded into views_linears[0] (FOLD_FEATURE_LINEAR, used for large passes)
+    against the layers one by one: rgb logits and the gradients wrt the last hidden activation and every parameter."""
+    cfg = SceneConfig(use_viewdirs=True, N_importance=64)
+    _, net, _ = build_modules(make_scene(cfg, 0))
+    net.requires_grad_(True)
+    g = torch.Generator().manual_seed(0)
+    h = torch.randn(5, 64, 256, generator=g).requires_grad_(True)
+    d = torch.nn.functional.normalize(torch.randn(5, 64, 3, generator=g), dim=-1)
+    w = torch.randn(5, 64, 3, generator=g)
+    names = ["feature_linear.weight", "feature_linear.bias", "views_linears.0.weight", "views_linears.0.bias", "rgb_linear.weight", "rgb_linear.bias"]
+    params = dict(net.named_parameters())
+    outs = {}
+    old = (T.FOLD_FEATURE_LINEAR, T.FOLD_MIN_ROWS)
+    try:
+        for fold in (False, True):
+            T.FOLD_FEATURE_LINEAR, T.FOLD_MIN_ROWS = fold, 0
+            for p in net.parameters():
+                p.grad = None
+            h.grad = None
+            y = T.colour_branch(net, h, d)
+            (y * w).sum().backward()
+            outs[fold] = [y.detach().clone(), h.grad.clone()] + [params[n].grad.clone() for n in names]
+    finally:
+        T.FOLD_FEATURE_LINEAR, T.FOLD_MIN_ROWS = old
+    for a, b in zip(outs[False], outs[True]):
+        assert float((a - b).abs().max()) <= 5e-6 * float(a.abs().max()) + 1e-9
