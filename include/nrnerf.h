@@ -196,8 +196,12 @@ int nrnerf_model_update(nrnerf_model* model, const nrnerf_model_desc* desc, void
  * training loop calls after every optimiser step).  flat_params: device pointer to all parameters as one fp32 vector --
  * every nn.Linear as weight [out, in] row-major followed by its bias [out] (if it has one), in the order
  * bender.network[0..], bender.rigidity_network[0..], then network_fn: pts_linears[0..], output_linear (or alpha_linear,
- * feature_linear, views_linears[0], rgb_linear); then network_fine likewise.  n_floats must equal
- * nrnerf_model_flat_size().  Asynchronous on hip_stream; same concurrency rule as nrnerf_model_update. */
+ * feature_linear, views_linears[0], rgb_linear); then network_fine likewise.  After all of those, per network with the
+ * view-dependent head (coarse, then fine), two DERIVED entries the caller computes: the views layer with feature_linear
+ * folded in (no nonlinearity sits between them, run_nerf_helpers.py:286-301; the kernels evaluate the pair as ONE layer on
+ * the trunk output) -- weight [W/2][W + direction encoding] = [ W_v[:, :W] W_f | W_v[:, W:] ] row-major, then bias [W/2] =
+ * W_v[:, :W] b_f + b_v.  n_floats must equal nrnerf_model_flat_size().  Asynchronous on hip_stream; same concurrency
+ * rule as nrnerf_model_update. */
 int64_t nrnerf_model_flat_size(const nrnerf_model* model);
 int nrnerf_model_update_device(nrnerf_model* model, const float* flat_params, int64_t n_floats, void* hip_stream);
 void nrnerf_model_destroy(nrnerf_model* model);

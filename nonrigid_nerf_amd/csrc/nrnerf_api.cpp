@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -82,6 +83,45 @@ struct FlatLayout {
         for (auto& b : base) if (b.first == p) return b.second;
         return -1;
     }
+    // DERIVED entries, after every real parameter: per network with the view-dependent head (coarse, then fine) the views
+    // layer with feature_linear folded in -- weight [W/2][W + direction encoding] = [W_v[:, :W] W_f | W_v[:, W:]], then bias
+    // [W/2] = W_v[:, :W] b_f + b_v -- keyed by the views weight pointer of the description
+    std::vector<std::pair<const float*, int64_t>> folded;
+    void add_folded(const nrnerf_mlp_desc& m) {
+        if (!m.use_viewdirs || !m.views_linear.weight) return;
+        folded.push_back({m.views_linear.weight, total});
+        total += (int64_t)m.views_linear.out_features * m.views_linear.in_features + m.views_linear.out_features;
+    }
+    int64_t folded_of(const float* views_weight) const {
+        for (auto& b : folded) if (b.first == views_weight) return b.second;
+        return -1;
+    }
+};
+// views_linears[0] o feature_linear as one layer (see LK_VIEWS in nrnerf_plan.h): fp64 products rounded to fp32 once
+struct FoldedViews {
+    std::vector<float> w, b;
+    nrnerf_linear lin{};
+    explicit FoldedViews(const nrnerf_mlp_desc& m) {
+        const nrnerf_linear& v = m.views_linear;
+        const nrnerf_linear& f = m.feature_linear;
+        const int O = v.out_features, K = v.in_features, W = f.out_features, Wi = f.in_features;
+        if (!v.weight || !f.weight || K < W) throw std::logic_error("view-dependent head: views layer narrower than the feature vector");
+        w.assign((size_t)O * (size_t)(K - W + Wi), 0.0f);
+        b.assign((size_t)O, 0.0f);
+        const int Kf = K - W + Wi;                 // (Wi == W for the reference's head: same row length as the views layer)
+        for (int r = 0; r < O; ++r) {
+            for (int c = 0; c < Wi; ++c) {
+                double acc = 0.0;
+                for (int k = 0; k < W; ++k) acc += (double)v.weight[(size_t)r * K + k] * (double)f.weight[(size_t)k * Wi + c];
+                w[(size_t)r * Kf + c] = (float)acc;
+            }
+            for (int c = W; c < K; ++c) w[(size_t)r * Kf + Wi + (c - W)] = v.weight[(size_t)r * K + c];
+            double acc = v.bias ? (double)v.bias[r] : 0.0;
+            if (f.bias) for (int k = 0; k < W; ++k) acc += (double)v.weight[(size_t)r * K + k] * (double)f.bias[k];
+            b[r] = (float)acc;
+        }
+        lin.weight = w.data(); lin.bias = b.data(); lin.out_features = O; lin.in_features = Kf;
+    }
 };
 void add_mlp(FlatLayout& f, const nrnerf_mlp_desc& m) {
     for (int i = 0; i < m.depth; ++i) f.add(m.pts_linears[i]);
@@ -96,6 +136,8 @@ FlatLayout flat_layout(const nrnerf_model_desc& d) {
     }
     add_mlp(f, *d.coarse);
     if (d.fine) add_mlp(f, *d.fine);
+    f.add_folded(*d.coarse);
+    if (d.fine) f.add_folded(*d.fine);
     return f;
 }
 
@@ -139,12 +181,20 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
         out.bias_src.assign(out.bias.size(), -1);
     }
     size_t written = 0;
+    std::unique_ptr<FoldedViews> folded;           // the views layer's weights with feature_linear folded in (VIEWS plans)
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
         const bool ah = alpha_head && sp.kind == LK_HEAD;
         const nrnerf_linear* lin = ah ? &mlp.alpha_linear : layer_source(d, mlp, sp);
+        int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
+        if (sp.kind == LK_VIEWS) {                 // source: the derived entries of the flat vector (FlatLayout::add_folded)
+            folded.reset(new FoldedViews(mlp));
+            const int64_t fb = lay ? lay->folded_of(mlp.views_linear.weight) : -1;
+            lin = &folded->lin;
+            wbase = fb;
+            bbase = fb < 0 ? -1 : fb + (int64_t)lin->out_features * lin->in_features;
+        }
         auto orow = [&](int t, int i) { return ah ? (i == 3 ? 0 : -1) : out_row<A>(sp.kind, t, i, lin->out_features); };
-        const int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
         for (int t = 0; t < sp.nt; ++t) {
             const TileInfo& ti = T.tiles[sp.tile0 + t];
             for (int s = 0; s < sp.ns; ++s) {

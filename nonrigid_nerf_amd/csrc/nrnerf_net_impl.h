@@ -973,20 +973,19 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
             if constexpr (LAST_IN_B) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, hb, none, take_raw);
             else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, ha, none, take_raw);
         } else {
-            // view-dependent head (run_nerf_helpers.py:284-304): alpha and feature from the trunk output, then
-            // relu(views_linear([feature, enc(dir)])) and rgb_linear; output = [rgb, alpha]
-            auto head = [&](auto& hx, auto& hy) {
+            // view-dependent head (run_nerf_helpers.py:284-304): alpha from the trunk output, then
+            // relu(views_linear([feature_linear(trunk output), enc(dir)])) -- one layer, feature_linear folded into its weights by
+            // the packer -- and rgb_linear; output = [rgb, alpha]
+            auto head = [&](auto& hx) {
                 dense<P, P, PL, PL::L_ALPHA, NH, 0>(st, bias_lane, hx, none, [&](auto, const f32x16& acc) { raw[3] = acc[0]; });
-                dense<P, P, PL, PL::L_FEAT, NH, 0>(st, bias_lane, hx, none, [&](auto tc, const f32x16& acc) {
-                    pack_tile<P, false, decltype(tc)::value>(acc, hy); });
                 constexpr int NV = (NT_W / 2) * SP;
                 frag hv[NV];
-                dense<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH>(st, bias_lane, encv, hy, [&](auto tc, const f32x16& acc) {
+                dense<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH>(st, bias_lane, encv, hx, [&](auto tc, const f32x16& acc) {
                     pack_tile<P, true, decltype(tc)::value>(acc, hv); });
                 dense<P, P, PL, PL::L_RGB, NV, 0>(st, bias_lane, hv, none, [&](auto, const f32x16& acc) {
                     raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; });
             };
-            if constexpr (LAST_IN_B) head(hb, ha); else head(ha, hb);
+            if constexpr (LAST_IN_B) head(hb); else head(ha);
         }
 
         NRN_TACC(4, t_trunk);

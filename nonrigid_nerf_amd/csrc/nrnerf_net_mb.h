@@ -580,25 +580,24 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
             if constexpr (LAST_IN_B) dense_mb<P, P, PL, PL::L_HEAD, NH, 0, MB, NT_W, false, true, false>(st, bias_lane, ms, hb, none, take_raw, to_hb);
             else dense_mb<P, P, PL, PL::L_HEAD, NH, 0, MB, NT_W, false, true, false>(st, bias_lane, ms, ha, none, take_raw, to_ha);
         } else {
-            // view-dependent head (run_nerf_helpers.py:284-304): alpha and feature from the trunk output, then
-            // relu(views_linear([feature, enc(dir)])) and rgb_linear; output = [rgb, alpha].  hx = trunk output, hy = free buffer.
-            auto head = [&](auto& hx, auto& hy, auto&& to_hx) {
+            // view-dependent head (run_nerf_helpers.py:284-304): alpha from the trunk output, then
+            // relu(views_linear([feature_linear(trunk output), enc(dir)])) -- ONE layer on the trunk output, feature_linear folded
+            // into its weights by the packer -- and rgb_linear; output = [rgb, alpha].  hx = trunk output.
+            auto head = [&](auto& hx, auto&& to_hx) {
                 auto take_alpha = [&](auto bc, auto, const f32x16& acc) { raw[decltype(bc)::value][3] = acc[0]; };
-                auto to_hy_lin = [&](auto bc, auto tc, const f32x16& acc) { pack_tile<P, false, decltype(tc)::value>(acc, hy[decltype(bc)::value]); };
-                // alpha finishes the trunk's deferred pair in its shadow and drains itself (one tile)
+                // alpha finishes the trunk's deferred pair in its shadow and drains itself (one tile): hx is complete after it
                 dense_mb<P, P, PL, PL::L_ALPHA, NH, 0, MB, NT_W, false, true, true>(st, bias_lane, ms, hx, none, take_alpha, to_hx);
-                dense_mb<P, P, PL, PL::L_FEAT, NH, 0, MB, 0, true, true, true>(st, bias_lane, ms, hx, none, to_hy_lin, NoEpi{});
                 constexpr int NV = (NT_W / 2) * SP;
                 frag hv[MB][NV];
                 auto to_hv = [&](auto bc, auto tc, const f32x16& acc) { pack_tile<P, true, decltype(tc)::value>(acc, hv[decltype(bc)::value]); };
-                dense_mb<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH, MB, NT_W, false, true, true>(st, bias_lane, ms, encv, hy, to_hv, to_hy_lin);
+                dense_mb<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH, MB, 0, false, true, true>(st, bias_lane, ms, encv, hx, to_hv, NoEpi{});
                 auto take_rgb = [&](auto bc, auto, const f32x16& acc) {
                     constexpr int b = decltype(bc)::value;
                     raw[b][0] = acc[0]; raw[b][1] = acc[1]; raw[b][2] = acc[2];
                 };
                 dense_mb<P, P, PL, PL::L_RGB, NV, 0, MB, 0, false, true, false>(st, bias_lane, ms, hv, none, take_rgb, NoEpi{});
             };
-            if constexpr (LAST_IN_B) head(hb, ha, to_hb); else head(ha, hb, to_ha);
+            if constexpr (LAST_IN_B) head(hb, to_hb); else head(ha, to_ha);
         }
 
         NRN_TACC(4, t_trunk);

@@ -119,8 +119,8 @@ enum LayerKind : int {
     LK_TR_IN, LK_TR_HID, LK_TR_SKIP, LK_HEAD,
     // view-dependent head (reference NeRF.forward, run_nerf_helpers.py:284-304)
     LK_ALPHA,    // alpha_linear:   trunk output -> 1   (rows duplicated for both lane halves)
-    LK_FEAT,     // feature_linear: trunk output -> W   (no activation)
-    LK_VIEWS,    // views_linears[0]: [feature W, direction encoding] -> W/2, relu; slabs: direction encoding first
+    LK_FEAT,     // feature_linear: trunk output -> W   (no activation) -- not a layer of any plan any more: folded into LK_VIEWS
+    LK_VIEWS,    // views_linears[0] o feature_linear: [trunk output W, direction encoding] -> W/2, relu; slabs: direction encoding first
     LK_RGB,      // rgb_linear: W/2 -> 3
     // backward-data layers of the trunk (training, nrnerf_train.h): dX = W^T dY, the A operand holds W^T
     LK_B_HEAD,   // output_linear^T:   d raw (C channels) -> d h_{D-1}
@@ -228,7 +228,9 @@ constexpr Tables build_tables() {
         }
         if (VIEWS) {
             add(LK_ALPHA, 0, NT_W * SP, 1);
-            add(LK_FEAT, 0, NT_W * SP, NT_W);
+            // feature_linear has no layer of its own: no nonlinearity sits between it and views_linears[0] (rnh:286-301), so the
+            // packer folds it into that layer's hidden columns, W_v[:, :W] W_f (and W_v[:, :W] b_f into the bias): 65 536 of
+            // the 593 408 MAC per sample less, and the trunk output feeds the views layer directly
             add(LK_VIEWS, 0, NS_ENCV + NT_W * SP, NT_W / 2);
             add(LK_RGB, 0, (NT_W / 2) * SP, 1);
         } else {
@@ -377,7 +379,7 @@ struct Plan {
     static constexpr int L_TRUNK0 = HAS_BEND ? (A::BD + A::RD) : 0;
     static constexpr int L_HEAD = NLAYERS - 1;                 // output_linear (no view dependence)
     static constexpr int L_ALPHA = L_TRUNK0 + A::D;            // view-dependent head: alpha, feature, views, rgb
-    static constexpr int L_FEAT = L_ALPHA + 1, L_VIEWS = L_ALPHA + 2, L_RGB = L_ALPHA + 3;
+    static constexpr int L_VIEWS = L_ALPHA + 1, L_RGB = L_ALPHA + 2;       // (feature_linear is folded into L_VIEWS)
 };
 
 // ---------------------------------------------------------------------------------------

@@ -170,9 +170,11 @@ def _linears_in_canonical_order(network_fn, network_fine):
 
 
 def _flat_params(network_fn, network_fine, into=None):
-    """All parameters as one fp32 vector in the library's canonical order.  ``into``: a (buffer, views) pair from an
-    earlier call for the same parameter shapes -- refilled with one multi-tensor copy (no torch.cat: on ROCm a cat of
-    ~90 tensors stages its argument table through host-to-device copies, every training step).  Returns (flat, state)."""
+    """All parameters as one fp32 vector in the library's canonical order, followed by the derived entries of
+    nrnerf_model_update_device (networks with the view-dependent head: views_linears[0] with feature_linear folded in).
+    ``into``: a (buffer, views) pair from an earlier call for the same parameter shapes -- refilled with one multi-tensor
+    copy (no torch.cat: on ROCm a cat of ~90 tensors stages its argument table through host-to-device copies, every training
+    step).  Returns (flat, state)."""
     parts = []
     for lin in _linears_in_canonical_order(network_fn, network_fine):
         parts.append(lin.weight.detach())
@@ -180,6 +182,15 @@ def _flat_params(network_fn, network_fine, into=None):
             parts.append(lin.bias.detach())
     if not parts or any(p.device != parts[0].device for p in parts) or parts[0].device.type != "cuda":
         return None, None
+    for net in (network_fn, network_fine):        # derived entries: [W_v1 W_f | W_v2], W_v1 b_f + b_v  (fp32 products)
+        if net is not None and net.use_viewdirs:
+            wf, bf = net.feature_linear.weight.detach().float(), net.feature_linear.bias.detach().float()
+            wv, bv = net.views_linears[0].weight.detach().float(), net.views_linears[0].bias.detach().float()
+            k1 = int(wf.shape[0])
+            folded = torch.empty(wv.shape[0], wf.shape[1] + wv.shape[1] - k1, dtype=torch.float32, device=wv.device)
+            folded[:, :wf.shape[1]] = wv[:, :k1] @ wf
+            folded[:, wf.shape[1]:] = wv[:, k1:]
+            parts += [folded, torch.addmv(bv, wv[:, :k1], bf)]
     shapes = tuple(tuple(p.shape) for p in parts)
     if into is None or into[2] != shapes or into[0].device != parts[0].device:
         flat = torch.empty(sum(p.numel() for p in parts), dtype=torch.float32, device=parts[0].device)

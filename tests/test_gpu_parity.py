@@ -813,7 +813,7 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
     split, fused = outs
     assert "fine_input_pts" in fused and "fine_input_pts" not in split
     if precision == "bf16":
-        _assert_split_equals_fused_up_to_conversion_ties(split, fused)
+        _assert_split_equals_fused_up_to_conversion_ties(split, fused, views=cfg.use_viewdirs)
         return
     if cfg.use_viewdirs:
         # View-dependent head: the trunk-only kernel takes a sample's direction from the same bent points (read back from
@@ -837,7 +837,7 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
     assert torch.equal(split["surface_pts"], fused["fine_input_pts"][torch.arange(3001, device=DEV), idx])
 
 
-def _assert_split_equals_fused_up_to_conversion_ties(split, fused):
+def _assert_split_equals_fused_up_to_conversion_ties(split, fused, views=False):
     """bf16 mode (single-product f16 bender): the stand-alone bender kernel and the fused kernel are the same arithmetic,
     but hipcc pairs the f32 -> f16 conversions of the first-layer inputs differently in the two kernels
     (v_cvt_pk_f16_f32 vs v_cvt_f16_f32), and the two instructions disagree on rare inputs -- measured: 21 of 384 126 new
@@ -846,7 +846,10 @@ def _assert_split_equals_fused_up_to_conversion_ties(split, fused):
     for k in ("rgb0", "disp0", "acc0", "z_std", "_z_vals"):
         assert torch.equal(torch.nan_to_num(split[k]), torch.nan_to_num(fused[k])), k
     differs = (split["raw"] != fused["raw"]).any(-1)
-    assert differs.float().mean().item() < 5e-4, differs.float().mean().item()
+    # (view-dependent head: on top of that, the one-ulp flips of the f16-rounded direction encoding between the two template
+    #  instantiations -- 0.1 % of the samples in f16 mode, see the f16 / f32 branch of the caller -- now reach the views layer's
+    #  pre-activation directly, feature_linear being folded into it: 5.6e-4 of the samples measured)
+    assert differs.float().mean().item() < (2e-3 if views else 5e-4), differs.float().mean().item()
     assert (split["rgb_map"] - fused["rgb_map"]).abs().max().item() < 2e-3
     assert (split["rgb_map"] != fused["rgb_map"]).any(-1).float().mean().item() < 0.05
     same_idx = split["median_index"] == fused["median_index"]
@@ -898,4 +901,12 @@ def test_device_side_weight_refresh_equals_a_fresh_pack(cfg_kw, precision):
     assert m1 is m0 and used["dev"] == 1, "the handle must be refreshed in place, on the device"
     assert (after["rgb_map"] - before).abs().max() > 1e-4
     for k in fresh:
-        assert torch.equal(torch.nan_to_num(after[k]), torch.nan_to_num(fresh[k])), k
+        a_, f_ = torch.nan_to_num(after[k]).float(), torch.nan_to_num(fresh[k]).float()
+        if cfg.use_viewdirs:
+            # view-dependent head: the views layer is packed with feature_linear folded in (nrnerf_plan.h); the host packer forms
+            # W_v1 W_f in fp64 and rounds once, the device-side refresh takes it from an fp32 GEMM -- the same weights to an ulp
+            # (bf16 mode: a packed weight can land on the other side of a rounding boundary), not bit for bit
+            tol = 2e-5 if precision == "f32" else 2e-2
+            assert float((a_ - f_).abs().max()) <= tol * max(1.0, float(f_.abs().max())), (k, float((a_ - f_).abs().max()))
+        else:
+            assert torch.equal(a_, f_), k

@@ -256,10 +256,9 @@ def test_packed_stream_reproduces_the_network(precision, bend, views, tcb, width
         D = dense_emul(fr, bias, tile0, len(slabs), 1, slabs)[0]; mfma += len(slabs); tile0 += 1        # alpha_linear
         alpha = D[0]
         assert np.allclose(D[4], alpha)
-        ftiles = dense_emul(fr, bias, tile0, len(slabs), 8, slabs); mfma += len(slabs) * 8; tile0 += 8   # feature_linear
-        fslabs = repack(ftiles, KH, False, rnd)
+        # (feature_linear has no layer of its own: folded into the views layer's hidden columns by the packer, nrnerf_plan.h)
         dslabs = enc_slabs(dirs, 4, KH, rnd_e)
-        vs = dslabs + fslabs
+        vs = dslabs + slabs
         vtiles = dense_emul(fr, bias, tile0, len(vs), 4, vs, f16_slabs=len(dslabs)); mfma += len(vs) * 4; tile0 += 4
         vslabs = repack(vtiles, KH, True, rnd)
         D = dense_emul(fr, bias, tile0, len(vslabs), 1, vslabs)[0]; mfma += len(vslabs); tile0 += 1     # rgb_linear
@@ -293,7 +292,8 @@ def test_packed_stream_reproduces_the_network(precision, bend, views, tcb, width
             ref = torch.cat([lin(fine.rgb_linear, hv), al], -1).numpy()
         else:
             ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
-    tol = 1e-9 if precision == "f32" else (8e-2 if precision == "bf16" else 1e-2)
+    # (f32 with the view-dependent head: the folded weights W_v1 W_f are rounded to fp32 once, 1e-7 of their scale)
+    tol = (1e-6 if views else 1e-9) if precision == "f32" else (8e-2 if precision == "bf16" else 1e-2)
     err = np.abs(raw - ref).max()
     assert err <= tol * np.abs(ref).max(), f"trunk+head mismatch {err} vs scale {np.abs(ref).max()}"
     # unit table: uniform 16 KiB units (offsets in 16-byte words)
@@ -318,7 +318,7 @@ def test_unsupported_architectures_are_rejected():
         desc, keep = build_model_desc(coarse, fine, prec, 0)
         info = _lib.PackedInfo()
         assert lib.nrnerf_pack_host(C.byref(desc), 1, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == 0
-        assert info.mfma_per_block == 976 - 16 + 16 + 128 + 72 + 8 + bender_mfmas, prec
+        assert info.mfma_per_block == 976 - 16 + 16 + 72 + 8 + bender_mfmas, prec       # alpha 16, views (feature_linear folded in) 72, rgb 8
     bad = _lib.ModelDesc()
     assert lib.nrnerf_pack_host(C.byref(bad), 0, None, None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_INVALID
     out = C.c_void_p()
