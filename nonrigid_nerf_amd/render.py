@@ -184,13 +184,14 @@ def _flat_params(network_fn, network_fine, into=None):
         return None, None
     for net in (network_fn, network_fine):        # derived entries: [W_v1 W_f | W_v2], W_v1 b_f + b_v  (fp32 products)
         if net is not None and net.use_viewdirs:
-            wf, bf = net.feature_linear.weight.detach().float(), net.feature_linear.bias.detach().float()
-            wv, bv = net.views_linears[0].weight.detach().float(), net.views_linears[0].bias.detach().float()
+            wf, wv = net.feature_linear.weight.detach().float(), net.views_linears[0].weight.detach().float()
+            bf, bv = net.feature_linear.bias, net.views_linears[0].bias
             k1 = int(wf.shape[0])
             folded = torch.empty(wv.shape[0], wf.shape[1] + wv.shape[1] - k1, dtype=torch.float32, device=wv.device)
             folded[:, :wf.shape[1]] = wv[:, :k1] @ wf
             folded[:, wf.shape[1]:] = wv[:, k1:]
-            parts += [folded, torch.addmv(bv, wv[:, :k1], bf)]
+            fb = bv.detach().float() if bv is not None else torch.zeros(wv.shape[0], dtype=torch.float32, device=wv.device)
+            parts += [folded, torch.addmv(fb, wv[:, :k1], bf.detach().float()) if bf is not None else fb]
     shapes = tuple(tuple(p.shape) for p in parts)
     if into is None or into[2] != shapes or into[0].device != parts[0].device:
         flat = torch.empty(sum(p.numel() for p in parts), dtype=torch.float32, device=parts[0].device)
