@@ -215,10 +215,10 @@ def _param_slots(m):
     """Every parameter slot of module ``m`` as (the owning submodule's ``_parameters`` dict, name).  ``m.parameters()`` walks
     the module tree through ``named_modules`` with de-duplication sets on every call -- 0.15 ms per network, three networks,
     three calls per training step; the walk is cached and re-validated by identity: every child still sits where it sat and
-    no ``_modules`` / ``_parameters`` dict has grown or shrunk.  Reading the slot (not a cached tensor) sees a parameter
+    every ``_modules`` / ``_parameters`` dict still has the same keys in the same order.  Reading the slot (not a cached tensor) sees a parameter
     object that was replaced."""
     ent = _SLOTS.get(m)
-    if ent is not None and all(d.get(n) is c for d, n, c in ent[0]) and all(len(d) == k for d, k in ent[1]):
+    if ent is not None and all(d.get(n) is c for d, n, c in ent[0]) and all(tuple(d) == k for d, k in ent[1]):
         return ent[2]
     children, sizes, slots, seen, stack = [], [], [], set(), [m]
     while stack:
@@ -226,7 +226,8 @@ def _param_slots(m):
         if id(mod) in seen:
             continue
         seen.add(id(mod))
-        sizes += [(mod._modules, len(mod._modules)), (mod._parameters, len(mod._parameters))]
+        sizes += [(mod._modules, tuple(mod._modules)), (mod._parameters, tuple(mod._parameters))]     # the key tuples, not only the lengths:
+        # deleting one parameter and registering another under a different name keeps the length
         slots += [(mod._parameters, n) for n in mod._parameters]
         for n, c in mod._modules.items():
             children.append((mod._modules, n, c))
@@ -296,22 +297,28 @@ class Model:
         model's device -- are concatenated into one fp32 vector in the library's canonical order and re-packed by a
         gather kernel per image, asynchronously on the current stream.  What every training step does after
         ``optimizer.step()``.  Returns False when the modules are not on this device or describe a different model."""
-        flat, self._flat_state = _flat_params(network_fn, network_fine, getattr(self, "_flat_state", None))
-        if flat is None or flat.device != self.device or int(self.lib.nrnerf_model_flat_size(self.handle)) != flat.numel():
-            return False
         with torch.cuda.device(self.device):
             # Stream-ordered, no host synchronisation: the gather kernels run on the current stream after every render /
-            # training kernel already queued there.  Renders this handle has queued on OTHER streams are ordered by
-            # events (one per stream that rendered since the last refresh), not by draining the device: this runs once
-            # per training step.
+            # training kernel already queued there.  Work this handle has queued on OTHER streams -- renders, an earlier
+            # refresh (whose gather kernels read the persistent flat buffer refilled below), training kernels -- is ordered
+            # by events / a stream wait, not by draining the device: this runs once per training step.
             cur = torch.cuda.current_stream(self.device)
             with self._ws_lock:
                 pending, self._render_events = self._render_events, {}
             for sid, ev in pending.items():
                 if sid != cur.cuda_stream:
                     cur.wait_event(ev)
+            ts = getattr(self, "_train_stream", None)       # last stream a training kernel read these weights on (training._mstream)
+            if ts is not None and ts.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(ts)
+            flat, self._flat_state = _flat_params(network_fn, network_fine, getattr(self, "_flat_state", None))
+            if flat is None or flat.device != self.device or int(self.lib.nrnerf_model_flat_size(self.handle)) != flat.numel():
+                return False
             stream = cur.cuda_stream
             rc = self.lib.nrnerf_model_update_device(self.handle, C.c_void_p(flat.data_ptr()), flat.numel(), C.c_void_p(stream))
+            # the gather kernels read the persistent flat buffer: a later refresh from ANOTHER stream must not refill it
+            # under them (and must see these packed images complete), so it waits for this event first -- via note_use's table
+            self.note_use()
         if rc in (_lib.ERR_INVALID, _lib.ERR_UNSUPPORTED):
             return False
         _lib.check(rc, "nrnerf_model_update_device")
@@ -736,6 +743,7 @@ def install(train_module, precision: str | None = None):
     _lib.load()      # fail now, loudly, if the library is missing
     # A drop-in must not silently change an fp32 pipeline's arithmetic: without an explicit request (argument, or the
     # NRNERF_PRECISION environment variable) the exact fp32 kernels are selected; the 16-bit modes are one keyword away.
+    previous_precision = _DEFAULT_PRECISION          # restored by uninstall(): direct callers (Model, get_model, bench.py) keep theirs
     set_precision(precision if precision is not None else os.environ.get("NRNERF_PRECISION", "f32"))
     orig = (train_module.render_rays, train_module.batchify_rays)
     _fallbacks["render_rays"], _fallbacks["batchify_rays"] = orig
@@ -754,4 +762,5 @@ def install(train_module, precision: str | None = None):
         if orig_div is not None:
             train_module.compute_divergence_loss = orig_div
         _fallbacks.clear()
+        set_precision(previous_precision)
     return uninstall

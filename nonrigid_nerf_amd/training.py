@@ -45,6 +45,14 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def _mstream(model, dev):
+    """The current stream for a kernel that READS the packed weights of `model`; the model remembers it, so that a weight
+    refresh issued from another stream orders itself after this work (render.Model.update_from_device)."""
+    cur = torch.cuda.current_stream(dev)
+    model._train_stream = cur
+    return C.c_void_p(cur.cuda_stream)
+
+
 def posenc(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
     """Embedder.embed (run_nerf_helpers.py:120-150) -- only used to materialise the first operand of the weight-gradient
     GEMMs of layers 0 and skip+1 (the kernels compute the encoding in registers and never write it)."""
@@ -272,7 +280,9 @@ def _param_token(owner, params):
     """The token of `params` for this iteration: one per (owner module, parameter objects and versions, grad mode).  An
     optimiser step bumps the versions, so the next iteration builds a fresh node; a token that is re-used after a backward
     pass is harmless (the node saves nothing)."""
-    key = (tuple((id(p), p._version) for p in params), torch.is_grad_enabled())
+    # requires_grad is part of the key: freezing the bender for a while (fitting test-time latent codes) and unfreezing it
+    # bumps no version counter, and a token built while frozen carries no gradient to the parameters
+    key = (tuple((id(p), p._version, bool(p.requires_grad)) for p in params), torch.is_grad_enabled())
     hit = _TOKENS.get(owner)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -312,7 +322,7 @@ class _Trunk(torch.autograd.Function):
             assert tuple(rbias.shape) == (N, 2, W)
             a.ray_bias = rbias.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(model.lib.nrnerf_trunk_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_forward")
+            _lib.check(model.lib.nrnerf_trunk_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_trunk_forward")
         ctx.model, ctx.net, ctx.which, ctx.dims, ctx.views, ctx.tcb = model, net, int(which), (N, S, D, W, C_out), views, ray_bias is not None
         ctx.save_for_backward(*((pts4, acts) if f32 else (pts4, acts, mask)))
         ctx.mark_non_differentiable(raw)
@@ -349,7 +359,7 @@ class _Trunk(torch.autograd.Function):
             g_h = g_h.reshape(M, W).to(torch.float32 if f32 else torch.bfloat16).contiguous()      # in the saved arrays' element type
             a.d_hidden_extra = g_h.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(model.lib.nrnerf_trunk_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_backward")
+            _lib.check(model.lib.nrnerf_trunk_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_trunk_backward")
         skip1 = int(list(net.skips)[0]) + 1
         g_bias = None
         if ctx.tcb:             # gradient wrt the per-ray biases: d_pre of the two input layers summed over the ray's samples
@@ -659,7 +669,7 @@ class _Bender(torch.autograd.Function):
         acts_r = torch.empty(RD - 1, M, RW, dtype=sdt, device=dev)
         a = _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r)
         with torch.cuda.device(dev):
-            _lib.check(model.lib.nrnerf_bender_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_forward")
+            _lib.check(model.lib.nrnerf_bender_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_forward")
         ctx.model, ctx.rb, ctx.dims = model, rb, (N, S, BD, BW, RD, RW)
         ctx.save_for_backward(rays, lat, z, bent4, off4, acts_b, acts_r)
         ctx.set_materialize_grads(False)
@@ -685,7 +695,7 @@ class _Bender(torch.autograd.Function):
         a.g_rigidity_mask = gm.data_ptr() if gm is not None else None
         a.dz_offsets, a.dz_rigidity, a.dz_out4, a.d_latents = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), d_lat.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(model.lib.nrnerf_bender_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_backward")
+            _lib.check(model.lib.nrnerf_bender_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_backward")
         if not ctx.needs_input_grad[5]:              # frozen bender (e.g. fitting test-time latent codes): no weight gradients
             return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, None)
         if NATIVE_BENDER_WGRAD:
@@ -931,7 +941,7 @@ class _Divergence(torch.autograd.Function):
         acts_r, tacts_r = torch.empty(RD - 1, M, RW, **sd), torch.empty(RD - 1, M, RW, **sd)
         a = _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
         with torch.cuda.device(dev):
-            _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_divergence_forward")
+            _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_divergence_forward")
         ctx.model, ctx.rb, ctx.dims = model, rb, (M, BD, BW, RD, RW)
         ctx.save_for_backward(pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
         ctx.set_materialize_grads(False)
@@ -960,7 +970,7 @@ class _Divergence(torch.autograd.Function):
         a.dz_out4, a.dtz_out4, a.d_latents = dz_out4.data_ptr(), dtz_out4.data_ptr(), d_lat.data_ptr()
         a.n_partials, a.partials = nparts, parts.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(model.lib.nrnerf_bender_divergence_backward(model.handle, C.byref(a), _stream(dev)), "nrnerf_bender_divergence_backward")
+            _lib.check(model.lib.nrnerf_bender_divergence_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_divergence_backward")
         index, _ = _bender_grad_index(rb, dev, divergence=True)
         return (d_lat, None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index))
 
@@ -1282,9 +1292,9 @@ class GraphedStep:
     (shapes fixed).  Anything that changes per step must be one of them -- e.g. the regularisers' schedule as a 0-dim tensor
     (``training_loss(global_step=tensor)``).  Random numbers are drawn inside the graph from torch's generator (graph-safe
     Philox offsets), so a replayed step draws fresh numbers.  ``networks``: the ``network_fn`` modules whose packed weights
-    the step reads: their handles are re-packed from the parameters at the START of every replay (the captured refresh),
-    and ``sync()`` must be called before rendering outside the graph (the replayed optimiser steps do not touch the
-    parameters' version counters, so the boundary cannot see them)."""
+    the step reads: their handles are re-packed from the parameters at the START of every replay (the captured refresh);
+    after each replay they are marked stale (the replayed optimiser step does not touch the parameters' version counters),
+    so a render outside the graph re-packs first."""
 
     def __init__(self, step_fn, inputs, optimizer, networks, warmup=3):
         self.networks = list(networks)
@@ -1314,12 +1324,22 @@ class GraphedStep:
             self.loss = one()
 
     def __call__(self, **inputs):
+        """Replays the step on `inputs` (keys and shapes of the example inputs; a key that is left out KEEPS the data of the
+        previous replay -- deliberate: a fixed ray batch is passed once).  Returns the graph's STATIC loss tensor: the next
+        replay overwrites it -- ``.clone()`` it to keep a value across steps."""
+        unknown = inputs.keys() - self.static.keys()
+        if unknown:
+            raise KeyError(f"GraphedStep: unknown inputs {sorted(unknown)}; captured with {sorted(self.static)}")
         for k, v in inputs.items():
+            if tuple(v.shape) != tuple(self.static[k].shape):
+                raise ValueError(f"GraphedStep: input {k!r} has shape {tuple(v.shape)}, captured with {tuple(self.static[k].shape)}")
             self.static[k].copy_(v)
         self.graph.replay()
-        return self.loss
+        self.sync()          # host-only: the replayed optimiser step bumped no version counter, so a render / evaluation
+        return self.loss     # outside the graph would otherwise read the weights packed at the START of this replay
 
     def sync(self):
+        """Mark the networks' packed weights stale (done after every replay; kept as a public no-cost call)."""
         for nf in self.networks:
             R.mark_stale(nf)
 

@@ -7,6 +7,8 @@ against the fp32 reference render, and of both against ground truth) run on a re
 
     python oracle/fit_checkpoint.py --iters 6000 --out gpurun_out/fitted_latest.tar     # on a GPU box: ~2-3 minutes
     cp gpurun_out/fitted_latest.tar tests/golden/fitted_latest.tar                      # commit the result
+    python oracle/fit_checkpoint.py --arch config4 --out gpurun_out/fitted_config4.tar  # view-dependent head + 7-layer bender
+    python oracle/fit_checkpoint.py --arch w128 --out gpurun_out/fitted_w128.tar        # --netwidth 128
 
 It is a restatement of the reference's training loop on top of ``oracle/nrnerf_oracle.py`` (whose gradients are
 pinned against the reference's own autograd, tests/golden/gradients_64_64.npz):
@@ -64,9 +66,20 @@ def init_bender_like_reference(rb: RayBenderWeights):
                 net[-1].bias.mul_(0.0)
 
 
-def frame_rays(pose, intrin, near, far):
+def frame_rays(pose, intrin, near, far, use_viewdirs=False):
     ro, rd = O.get_rays(pose[:3, :4], intrin)
-    return O.pack_rays(ro, rd, near, far, use_viewdirs=False)                   # [H*W, 8]
+    return O.pack_rays(ro, rd, near, far, use_viewdirs=use_viewdirs)            # [H*W, 8 | 11]
+
+
+# The compiled architecture families the accuracy bar is enforced on (tests/test_fitted_checkpoint.py):
+#   default  reference defaults (train.py:1004-1010, rnh:406-407)
+#   config4  BASELINE config 4: --use_viewdirs with finite-difference directions (rnh:316-356) and a 7-layer bender
+#   w128     --netwidth 128 --netwidth_fine 128 (train.py:1004-1010)
+ARCHS = {
+    "default": dict(),
+    "config4": dict(use_viewdirs=True, bend_depth=7),
+    "w128": dict(netwidth=128),
+}
 
 
 def main():
@@ -79,6 +92,7 @@ def main():
     ap.add_argument("--offsets-loss-weight", type=float, default=60.0)
     ap.add_argument("--rigidity-loss-weight", type=float, default=0.0005)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--arch", choices=sorted(ARCHS), default="default", help="architecture family to fit (see ARCHS)")
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "fitted_latest.tar"))
     args = ap.parse_args()
 
@@ -87,11 +101,12 @@ def main():
     rng = np.random.RandomState(args.seed)
     fx = load_fixture()
     F_, H, W = fx["images"].shape[:3]
-    cfg = SceneConfig(N_samples=64, N_importance=args.n_importance, near=fx["near"], far=fx["far"])
-    rb = RayBenderWeights()
+    cfg = SceneConfig(N_samples=64, N_importance=args.n_importance, near=fx["near"], far=fx["far"], **ARCHS[args.arch])
+    rb = RayBenderWeights(depth=cfg.bend_depth)
     init_bender_like_reference(rb)
-    coarse = NeRFWeights(output_ch=5, num_ray_samples=cfg.N_samples)
-    fine = NeRFWeights(output_ch=5, num_ray_samples=cfg.N_samples + cfg.N_importance)
+    mk = lambda ns: NeRFWeights(W=cfg.netwidth, input_ch_views=cfg.input_ch_views, output_ch=cfg.output_ch,
+                                use_viewdirs=cfg.use_viewdirs, num_ray_samples=ns)             # train.py:595-630
+    coarse, fine = mk(cfg.N_samples), mk(cfg.N_samples + cfg.N_importance)
     for m in (rb, coarse, fine):
         m.to(dev)
     latents = torch.zeros(F_, 32, device=dev, requires_grad=True)              # train.py:1443-1448
@@ -99,7 +114,7 @@ def main():
     net_params = list(coarse.parameters()) + list(fine.parameters()) + list(rb.parameters())
     opt = torch.optim.Adam(net_params + [latents], lr=5e-4, betas=(0.9, 0.999))  # train.py:655-658
 
-    rays_all = torch.stack([frame_rays(fx["poses"][f], fx["intrin"], fx["near"], fx["far"]) for f in range(F_)], 0).to(dev)
+    rays_all = torch.stack([frame_rays(fx["poses"][f], fx["intrin"], fx["near"], fx["far"], cfg.use_viewdirs) for f in range(F_)], 0).to(dev)
     target_all = fx["images"].reshape(F_, H * W, 3).to(dev)
     is_test = torch.zeros(F_, dtype=torch.bool, device=dev)
     is_test[fx["i_test"]] = True

@@ -243,3 +243,50 @@ def test_folded_feature_linear_equals_the_two_layers():
         T.FOLD_FEATURE_LINEAR, T.FOLD_MIN_ROWS = old
     for a, b in zip(outs[False], outs[True]):
         assert float((a - b).abs().max()) <= 5e-6 * float(a.abs().max()) + 1e-9
+
+
+def test_param_token_is_rebuilt_when_parameters_are_frozen_and_unfrozen():
+    """freezing the bender (fitting test-time latent codes) and unfreezing it bumps no version counter; a token
+    cached while frozen would carry no gradient to the parameters for ever after."""
+    lin = torch.nn.Linear(4, 3)
+    params = list(lin.parameters())
+    with torch.enable_grad():
+        t0 = T._param_token(lin, params)
+        assert t0.requires_grad and T._param_token(lin, params) is t0            # cached within an iteration
+        lin.requires_grad_(False)
+        t1 = T._param_token(lin, params)
+        assert not t1.requires_grad
+        lin.requires_grad_(True)
+        t2 = T._param_token(lin, params)
+        assert t2 is not t1 and t2.requires_grad
+        (t2 * torch.arange(t2.numel(), dtype=torch.float32)).sum().backward()
+    assert lin.weight.grad is not None and lin.bias.grad is not None
+    assert torch.equal(lin.weight.grad.reshape(-1), torch.arange(12, dtype=torch.float32))
+
+
+def test_param_slot_walk_notices_a_renamed_parameter():
+    """same number of parameters, different names -- the cached walk must be rebuilt, not raise KeyError."""
+    from nonrigid_nerf_amd import render as R
+    m = torch.nn.Linear(4, 3)
+    assert [n for _, n in R._param_slots(m)] == ["weight", "bias"]
+    del m._parameters["bias"]
+    m.register_parameter("scale", torch.nn.Parameter(torch.ones(3)))
+    assert [n for _, n in R._param_slots(m)] == ["weight", "scale"]
+    R._fingerprint([m])
+
+
+def test_install_restores_the_previous_precision_on_uninstall():
+    """install() selects "f32" for the drop-in; uninstall() must give direct callers their precision back."""
+    import types
+    from nonrigid_nerf_amd import render as R
+    before = R.get_precision()
+    try:
+        R.set_precision("bf16")
+        mod = types.SimpleNamespace(render_rays=lambda *a, **k: None, batchify_rays=lambda *a, **k: None)
+        orig = (mod.render_rays, mod.batchify_rays)
+        undo = R.install(mod)
+        assert R.get_precision() == "f32" and mod.render_rays is R.render_rays
+        undo()
+        assert R.get_precision() == "bf16" and (mod.render_rays, mod.batchify_rays) == orig
+    finally:
+        R.set_precision(before)
