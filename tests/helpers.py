@@ -103,3 +103,43 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     """PSNR definition of free_viewpoint_rendering.py:821-828 (peak 1.0)."""
     mse = torch.mean((a.double() - b.double()) ** 2)
     return float(-10.0 * torch.log10(mse.clamp_min(1e-30)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Pinned end-to-end numbers of the fp32 mode (VERDICT r3): the fraction of merged depths that moved and of rays outside
+# the fp32 tolerance against the reference's outputs is MEASURED, printed and held to <= 2 x the committed value
+# (tests/golden/pinned_fp32.json), not to a generous constant.  The committed values come from a run on the MI355X with
+# NRNERF_PIN_RECORD=<file> (one JSON object per line), merged by tools/update_pins.py.
+# ---------------------------------------------------------------------------------------------------------------
+PIN_FILE = os.path.join(GOLDEN_DIR, "pinned_fp32.json")
+
+
+def out_of_tolerance_fraction(got, ref, key):
+    """Fraction of the elements of ``got[key]`` outside the fp32 tolerance of ``key`` (both-NaN counts as equal)."""
+    a, b = got[key].detach().cpu().double(), ref[key].detach().cpu().double()
+    t = TOL.get(key, DEFAULT_TOL)
+    bound = t["atol"] + t["rtol"] * b.abs()
+    if "scale_atol" in t:
+        bound = bound + t["scale_atol"] * float(torch.nan_to_num(b).abs().max())
+    both_nan = torch.isnan(a) & torch.isnan(b)
+    bad = ~both_nan & ~((a - b).abs() <= bound)
+    return float(bad.double().mean())
+
+
+def check_pinned(case: str, measured: dict, counts: dict):
+    """Hold every ``measured[k]`` (a fraction) to max(2 x pinned, pinned + 2 / counts[k]); ``counts[k]`` = number of elements
+    the fraction is over (so a tiny fixture may move by two elements).  With NRNERF_PIN_RECORD set the values are appended
+    to that file instead of (not in addition to) failing on a missing pin."""
+    print(f"[pinned fp32 numbers] {case}: " + ", ".join(f"{k} = {v:.6f}" for k, v in measured.items()))
+    rec = os.environ.get("NRNERF_PIN_RECORD")
+    if rec:
+        with open(rec, "a") as f:
+            f.write(json.dumps({"case": case, "measured": measured}) + "\n")
+    pins = json.load(open(PIN_FILE)) if os.path.exists(PIN_FILE) else {}
+    if case not in pins:
+        assert rec, f"no pinned numbers for {case} in {PIN_FILE}: record them on a GPU box (NRNERF_PIN_RECORD) and commit"
+        return
+    for k, v in measured.items():
+        pinned = float(pins[case][k])
+        bound = max(2.0 * pinned, pinned + 2.0 / max(1, counts[k]))
+        assert v <= bound, f"{case}: {k} = {v:.6f} exceeds 2 x the pinned {pinned:.6f} (bound {bound:.6f})"
