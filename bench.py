@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--rays", type=int, default=196608, help="rays per GPU per step (default: one 512x384 frame)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--scene", default="fitted" if os.path.exists(FITTED) else "synthetic", choices=["synthetic", "fitted"])
-    ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--psnr-rays", type=int, default=32768)
@@ -292,14 +292,18 @@ def main():
 
         def roof(kk):
             ach = kk["flops"] / (kk["ms"] * 1e-3) / 1e12 if kk["ms"] > 0 else 0.0
+            issued = kk["mfma_flops"] / (kk["ms"] * 1e-3) / 1e12 if kk["ms"] > 0 else 0.0
+            # `frac` prices the REFERENCE's flops (2 x MAC, unpadded); `frac_issued_mfma` what the matrix pipe really
+            # executes -- more where K is padded (63 -> 64), LESS where the packer folds layers (view-dependent head: feature_linear
+            # folded into views_linears[0], 11 % fewer flops): there `frac` overstates the pipe's utilisation, read this one
             return {"achieved": round(ach, 2), "frac": round(ach / peak, 4),
                     "avg_launch_ms": round(kk["ms"] / max(kk["launches"], 1), 4),
-                    "issued_mfma_tflops": round(kk["mfma_flops"] / (kk["ms"] * 1e-3) / 1e12, 2) if kk["ms"] > 0 else 0.0}
+                    "issued_mfma_tflops": round(issued, 2), "frac_issued_mfma": round(issued / peak, 4)}
         rf = roof(k)
         traffic, traffic_note = pmc_traffic(args)
         roofline = {"bound": "mfma", "kernel": "net_kernel (fine pass, 192 samples/ray)",
                     "achieved": rf["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": rf["frac"],
-                    "avg_launch_ms": rf["avg_launch_ms"], "issued_mfma_tflops": rf["issued_mfma_tflops"],
+                    "avg_launch_ms": rf["avg_launch_ms"], "issued_mfma_tflops": rf["issued_mfma_tflops"], "frac_issued_mfma": rf["frac_issued_mfma"],
                     "traffic": traffic, "traffic_unit": traffic_note,
                     "coarse_pass": roof(prof["net_coarse"]),
                     "kernels_ms_per_step": {nm: round(v["ms"] / args.steps, 4) for nm, v in prof.items() if v["launches"]},
@@ -451,26 +455,35 @@ def cpu_baseline(scene, cfg, args, rays_dev, latents_dev):
     from oracle import nrnerf_oracle as O
     n = min(args.cpu_rays, rays_dev.shape[0])
     rays, latents = rays_dev[:n].cpu(), latents_dev[:n].cpu().contiguous()
-    # torch's default (one thread per logical core) oversubscribes a 256-thread host badly (measured 277 rays/s
-    # at 128 threads vs ~1300 at 8); probe a few thread counts on a small sample and report the best.
-    best_t, best_r = torch.get_num_threads(), 0.0
+    # Thread sweep, recorded in the line: torch's default (one thread per logical core) oversubscribes a 256-thread host badly --
+    # the oracle's ops are small ([1024 x 64 x 95] rows through 256-wide layers per chunk), so beyond a few dozen threads the
+    # intra-op fork/join and the cross-socket traffic cost more than the extra cores give (measured 277 rays/s at 128 threads
+    # vs ~1300 at 8 on the build container).  Each candidate: warm-up, then best of 3 on 1024 rays; the winner: best of 3 on
+    # the whole sample.
+    sweep = {}
     with torch.no_grad():
-        for t in sorted({8, 16, 32, 64} & set(range(1, (os.cpu_count() or 8) + 1))):
+        for t in sorted({8, 16, 32, 64, 128} & set(range(1, (os.cpu_count() or 8) + 1))):
             torch.set_num_threads(t)
             O.batchify_rays(rays[:512], latents[:512], scene, chunk=512)      # warm-up
+            best = 0.0
+            for _ in range(3):
+                t0 = time.perf_counter()
+                O.batchify_rays(rays[:1024], latents[:1024], scene, chunk=1024)
+                best = max(best, 1024 / (time.perf_counter() - t0))
+            sweep[t] = round(best, 1)
+        threads = max(sweep, key=sweep.get)
+        torch.set_num_threads(threads)
+        times = []
+        for _ in range(3):
             t0 = time.perf_counter()
-            O.batchify_rays(rays[:1024], latents[:1024], scene, chunk=1024)
-            r = 1024 / (time.perf_counter() - t0)
-            if r > best_r:
-                best_t, best_r = t, r
-        torch.set_num_threads(best_t)
-        threads = best_t
-        t0 = time.perf_counter()
-        O.batchify_rays(rays, latents, scene, chunk=1024)
-        dt = time.perf_counter() - t0
+            O.batchify_rays(rays, latents, scene, chunk=1024)
+            times.append(time.perf_counter() - t0)
+        dt = min(times)
     port = {"value": round(n / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{n} rays of the same 64+128 workload, chunk 1024, torch {torch.__version__} CPU, "
-                      f"{threads} threads of {os.cpu_count()} host cores, {dt:.1f} s",
+                      f"{threads} threads of {os.cpu_count()} host cores, best of 3: {dt:.1f} s (all: {', '.join(f'{x:.1f}' for x in times)} s)",
+            "thread_sweep_rays_per_s": {str(k): v for k, v in sweep.items()},
+            "why_not_all_cores": "the oracle's per-chunk ops are too small to amortise a 256-way fork/join: throughput peaks at a few dozen threads (sweep above)",
             "port_vs_reference": "the unmodified reference (train.render) and this port were timed side by side on the build "
                                  "container (tools/cpu_reference_vs_port.py, BASELINE.md section 2): port/reference = 0.96-0.99"}
     ref = reference_cpu_baseline(scene, rays, latents, threads)

@@ -34,6 +34,8 @@ extern "C" {
 #endif
 
 #define NRNERF_ABI_VERSION 5
+/* samples per ray and pass of nrnerf_render (the training entry points stay at 256) */
+#define NRNERF_MAX_SAMPLES 1024
 
 typedef enum nrnerf_status {
     NRNERF_OK = 0,
@@ -118,8 +120,8 @@ typedef struct nrnerf_sample_outputs {
 typedef struct nrnerf_render_args {
     uint32_t struct_size;       /* sizeof(nrnerf_render_args) */
     int32_t n_rays;             /* N (any size; the chunk loop of batchify_rays is not needed) */
-    int32_t n_samples;          /* N_samples  (S, coarse)        <= 256 */
-    int32_t n_importance;       /* N_importance (I); S' = S + I   <= 256 */
+    int32_t n_samples;          /* N_samples  (S, coarse)        <= NRNERF_MAX_SAMPLES */
+    int32_t n_importance;       /* N_importance (I); S' = S + I   <= NRNERF_MAX_SAMPLES (the reference has no cap, train.py:1090-1094) */
     /* inputs */
     const float* rays;          /* [N, ray_stride]: o3, d3, near, far (, unit viewdir3)  train.py:397-399 */
     int32_t ray_stride;         /* floats per row: 8 or 11 */
@@ -180,12 +182,20 @@ typedef struct nrnerf_profile {
 int nrnerf_abi_version(void);
 const char* nrnerf_strerror(int status);
 
-/* Compiled architectures (anything else: NRNERF_ERR_UNSUPPORTED, the Python boundary then defers to the reference):
+/* Architectures.  Replaces create_nerf's module construction for the render path (train.py:564-630).
+ * COMPILED shapes (specialised kernels, activations resident in registers; training entry points available):
  * depth 8, skip after layer 4, 10 encoding frequencies, latent size 32, rigidity MLP 3 x 32, and
  *   width 256, ray bender 5 x 64 or 7 x 64 or none, optional view-dependent head (finite-difference or exact directions);
  *   width 256, time-conditioned baseline (no bender), optional view-dependent head;
- *   width 128 (--netwidth 128 --netwidth_fine 128, train.py:1004-1010), ray bender 5 x 64 or none, no view-dependent head.
- * Coarse and fine network must have the same shape. */
+ *   width 128 (--netwidth 128 --netwidth_fine 128, train.py:1004-1010), ray bender 5 x 64 or none, no view-dependent head;
+ *   coarse and fine network of the same shape.
+ * ANY OTHER shape the reference can build (--netdepth / --netwidth and _fine, --multires / --multires_views,
+ * --ray_bending_latent_size: train.py:1004-1010, 1060, 1133-1139) gets a run-time-parameterised kernel (nrnerf_render only;
+ * the training entry points answer NRNERF_ERR_UNSUPPORTED): depth <= 16, width <= 512 (any value; coarse and fine may differ),
+ * <= 16 encoding frequencies, <= 10 direction frequencies, latent size <= 64, bender / rigidity MLPs of any depth (together
+ * <= 28 layers) and width <= 512.  Beyond that, and for exact (Jacobian) view directions on a non-compiled shape:
+ * NRNERF_ERR_UNSUPPORTED, and the Python boundary defers to the reference.  NRNERF_FORCE_GENERIC=1 in the environment selects
+ * the run-time-parameterised kernel for the compiled shapes as well (tests). */
 int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out);
 /* Re-pack new weights of the SAME architecture / precision / device into an existing handle (e.g. after an optimiser
  * step or load_state_dict, train.py:666-682): no allocation; ordered after work already queued on hip_stream, complete
@@ -524,7 +534,12 @@ int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchroni
  * table of one pass exactly as nrnerf_model_create uploads them.  which: 0 = coarse, 1 = fine, 2 = fine without the
  * bender layers, 3 = bender + rigidity layers alone (2, 3: the split-bender path; need a bender and not the exact view directions),
  * 4 / 5 = transposed trunk weights of the coarse / fine network for the backward-data kernel (training),
- * 6 = transposed bender + rigidity weights for nrnerf_bender_backward (always fp32).
+ * 6 = transposed bender + rigidity weights for nrnerf_bender_backward (always fp32),
+ * 7 / 8 / 9 = the layer PROGRAM of the run-time-parameterised kernel for the coarse / fine network / the ray bender (the
+ *   bender always fp32): fragment (tile t, k-slab s) of a layer at w_frag + t * (ns0 + ns1) + s; the unit table then holds
+ *   n_layers, per layer {w_frag, bias_tile, nt, src0, ns0, src1, ns1, dst, relu, o_col, o_rows} (buffers: 0 = network input,
+ *   1 = hidden, 2 = second input, 3 = head outputs), then the padded widths of the three buffers and the latent size
+ *   (n_units = that many entries minus one).
  * Any output pointer may be NULL to query sizes only.  Used by the CPU-side packing tests. */
 typedef struct nrnerf_packed_info {
     uint64_t stream_bytes;     /* fragment stream */

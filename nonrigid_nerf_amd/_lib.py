@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
 ABI_VERSION = 5
+MAX_SAMPLES = 1024        # NRNERF_MAX_SAMPLES (include/nrnerf.h): per ray and pass of nrnerf_render; training: 256
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
 _CANONICAL = {0: "f32", 1: "bf16", 2: "f16"}

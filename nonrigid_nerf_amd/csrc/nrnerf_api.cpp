@@ -444,6 +444,174 @@ int pack_dispatch(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPa
     }
     return rc;
 }
+// ------------------------------------------------------------------------------------------
+// Any other architecture: the run-time-parameterised kernel of nrnerf_generic.h.  The reference builds NeRF(D, W) for any
+// --netdepth / --netwidth (and _fine), any --multires / --multires_views, a bender for any --ray_bending_latent_size
+// (train.py:1004-1010, 1060, 1133-1139, 564-630); what is not one of the compiled shapes gets a layer PROGRAM here: per layer
+// the fragment offset of its weights, its sources among the LDS buffers E (network input) / H (hidden) / V (second input) and
+// its destination.  Columns keep the reference's order, so a fragment element is W[32 t + i][first column of the source + k].
+// ------------------------------------------------------------------------------------------
+struct GenProgram {
+    GenArgs proto{};          // mode, L, LV, lat, layers, ke / kv / kh filled in; pointers are per launch
+    PackedPass pk;
+};
+int pad16(int v) { return (v + 15) / 16 * 16; }
+struct GenSource { int buf, col0, n; };
+
+// one layer into the program and the packed images.  16-bit precisions: fragments read against E / V are f16, against H the
+// model's type (nrnerf_generic.h).
+void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSource a, GenSource b, int dst, int relu, int o_col, const FlatLayout* lay) {
+    if (g.proto.n_layers >= GEN_MAX_LAYERS) throw std::logic_error("generic program too long");
+    const bool f32 = precision == NRNERF_PREC_F32;
+    const int KH = f32 ? 1 : 8, KS = 2 * KH, FB = f32 ? 256 : 1024, EB = f32 ? 4 : 2;
+    GenLayer& ly = g.proto.layer[g.proto.n_layers++];
+    ly.w_frag = (int)(g.pk.stream.size() / FB);
+    ly.bias_tile = (int)(g.pk.bias.size() / 32);
+    ly.nt = (lin.out_features + 31) / 32;
+    ly.src0 = a.buf; ly.ns0 = (a.n + KS - 1) / KS;
+    ly.src1 = b.buf; ly.ns1 = (b.n + KS - 1) / KS;
+    ly.dst = dst; ly.relu = relu; ly.o_col = o_col; ly.o_rows = lin.out_features;
+    if (ly.nt > GEN_WAVES * GEN_MAXT || a.col0 + a.n > lin.in_features || b.col0 + b.n > lin.in_features) throw std::logic_error("generic layer out of range");
+    const int ns = ly.ns0 + ly.ns1;
+    const size_t f0 = g.pk.stream.size();
+    g.pk.stream.resize(f0 + (size_t)ly.nt * ns * FB, 0);
+    const int64_t wbase = lay ? lay->of(lin.weight) : -1, bbase = (lay && lin.bias) ? lay->of(lin.bias) : -1;
+    if (lay) { g.pk.src.resize(g.pk.stream.size() / EB, -1); g.pk.fmt.resize(g.pk.stream.size() / EB, 0); }
+    for (int t = 0; t < ly.nt; ++t)
+        for (int sl = 0; sl < ns; ++sl) {
+            const GenSource& src = (sl < ly.ns0) ? a : b;
+            const int s = (sl < ly.ns0) ? sl : sl - ly.ns0;
+            const bool as_f16 = precision == NRNERF_PREC_F16 || src.buf != GB_H;
+            uint8_t* fr = g.pk.stream.data() + f0 + ((size_t)t * ns + sl) * FB;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5, row = 32 * t + i;
+                for (int e = 0; e < KH; ++e) {
+                    const int k = s * KS + h * KH + e;
+                    const bool live = row < lin.out_features && k < src.n;
+                    const float w = live ? lin.weight[(size_t)row * lin.in_features + src.col0 + k] : 0.0f;
+                    const size_t el = (f0 + ((size_t)t * ns + sl) * FB) / EB + (size_t)lane * KH + e;
+                    if (lay) {
+                        g.pk.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)row * lin.in_features + src.col0 + k) : -1;
+                        g.pk.fmt[el] = f32 ? 0 : (as_f16 ? 2 : 1);
+                    }
+                    if (f32) std::memcpy(fr + lane * 4, &w, 4);
+                    else { const uint16_t q = as_f16 ? f32_to_f16(w) : f32_to_bf16(w); std::memcpy(fr + (lane * KH + e) * 2, &q, 2); }
+                }
+            }
+        }
+    const size_t b0 = g.pk.bias.size();
+    g.pk.bias.resize(b0 + (size_t)ly.nt * 32, 0.0f);
+    if (lay) g.pk.bias_src.resize(g.pk.bias.size(), -1);
+    for (int t = 0; t < ly.nt; ++t)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * t + tile_row(r, h);
+                if (row < lin.out_features && lin.bias) {
+                    g.pk.bias[b0 + (size_t)t * 32 + h * 16 + r] = lin.bias[row];
+                    if (lay && bbase >= 0) g.pk.bias_src[b0 + (size_t)t * 32 + h * 16 + r] = (int32_t)(bbase + row);
+                }
+            }
+}
+void gen_finish(GenProgram& g, int precision) {
+    const int FB = precision == NRNERF_PREC_F32 ? 256 : 1024;
+    g.pk.frag_bytes = FB; g.pk.slot_bytes = FB;
+    g.pk.ntiles = (int)(g.pk.bias.size() / 32);
+    g.pk.nunits = (int)(g.pk.stream.size() / FB);
+    g.pk.unit_off.assign(1, 0);
+}
+
+int gen_skip(const nrnerf_mlp_desc& m) { return (m.skip >= 0 && m.skip <= m.depth - 2) ? m.skip : -1; }
+// what the generic kernel takes (everything else: NRNERF_ERR_UNSUPPORTED, i.e. the reference's own function)
+int gen_check_mlp(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
+    if (d.precision < 0 || d.precision > 2) return NRNERF_ERR_INVALID;
+    if (!m.pts_linears || m.depth < 1 || m.width < 1) return NRNERF_ERR_INVALID;
+    if (d.multires < 0 || d.multires > 16 || m.width > GEN_MAX_W || m.depth > 16) return NRNERF_ERR_UNSUPPORTED;
+    if (m.time_conditioned && d.bender) return NRNERF_ERR_UNSUPPORTED;                       // train.py:574-576
+    const int enc = 3 + 6 * d.multires;
+    const int lat = m.time_conditioned ? m.pts_linears[0].in_features - enc : 0;
+    if (lat < 0 || lat > 64 || pad16(enc + lat) > GEN_MAX_E) return NRNERF_ERR_UNSUPPORTED;
+    // NeRF.forward concatenates [input, h] after layer `skip` whatever follows (rnh:277-282): after the LAST layer the
+    // reference's own head fails on the wider vector; a skip index beyond the depth never triggers
+    if (m.skip == m.depth - 1) return NRNERF_ERR_UNSUPPORTED;
+    const int skip = gen_skip(m);
+    for (int i = 0; i < m.depth; ++i) {
+        const int in_f = (i == 0) ? enc + lat : ((skip >= 0 && i - 1 == skip) ? m.width + enc + lat : m.width);
+        if (!linear_is(m.pts_linears[i], m.width, in_f, true)) return NRNERF_ERR_INVALID;
+    }
+    if (m.use_viewdirs) {
+        if (d.multires_views < 0 || d.multires_views > 10 || m.output_ch != 4) return NRNERF_ERR_UNSUPPORTED;
+        const int half = m.views_linear.out_features;
+        if (!linear_is(m.alpha_linear, 1, m.width, true) || !linear_is(m.feature_linear, m.width, m.width, true) || half < 1 || half > GEN_MAX_W ||
+            !linear_is(m.views_linear, half, m.width + 3 + 6 * d.multires_views, true) || !linear_is(m.rgb_linear, 3, half, true))
+            return NRNERF_ERR_INVALID;
+    } else {
+        if (m.output_ch < 4 || m.output_ch > 5) return NRNERF_ERR_UNSUPPORTED;
+        if (!linear_is(m.output_linear, m.output_ch, m.width, true)) return NRNERF_ERR_INVALID;
+    }
+    return NRNERF_OK;
+}
+int gen_check_bender(const nrnerf_bender_desc& b) {
+    if (!b.network || !b.rigidity_network || b.depth < 2 || b.rigidity_depth < 2) return NRNERF_ERR_INVALID;
+    if (b.latent_size < 0 || b.latent_size > 64 || b.hidden < 1 || b.hidden > GEN_MAX_W || b.rigidity_hidden < 1 || b.rigidity_hidden > GEN_MAX_W ||
+        b.depth + b.rigidity_depth > GEN_MAX_LAYERS)
+        return NRNERF_ERR_UNSUPPORTED;
+    for (int i = 0; i < b.depth; ++i) {
+        const int in_f = (i == 0) ? 3 + b.latent_size : b.hidden, out_f = (i == b.depth - 1) ? 3 : b.hidden;
+        if (!linear_is(b.network[i], out_f, in_f, i != b.depth - 1)) return NRNERF_ERR_INVALID;
+    }
+    for (int i = 0; i < b.rigidity_depth; ++i) {
+        const int in_f = (i == 0) ? 3 : b.rigidity_hidden, out_f = (i == b.rigidity_depth - 1) ? 1 : b.rigidity_hidden;
+        if (!linear_is(b.rigidity_network[i], out_f, in_f, true)) return NRNERF_ERR_INVALID;
+    }
+    return NRNERF_OK;
+}
+// NeRF.forward (rnh:240-314) as a layer program
+void gen_pack_mlp(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenProgram& g, const FlatLayout* lay) {
+    const int enc = 3 + 6 * d.multires, lat = m.time_conditioned ? m.pts_linears[0].in_features - enc : 0, in_w = enc + lat, W = m.width;
+    g.proto.mode = 1; g.proto.L = d.multires; g.proto.LV = m.use_viewdirs ? d.multires_views : -1; g.proto.lat = lat;
+    g.proto.ke = pad16(in_w);
+    g.proto.kv = m.use_viewdirs ? pad16(3 + 6 * d.multires_views) : 16;
+    int widest = W;
+    const int skip = gen_skip(m);
+    const GenSource none{GB_H, 0, 0};
+    for (int i = 0; i < m.depth; ++i) {
+        if (i == 0) gen_add_layer(g, d.precision, m.pts_linears[0], GenSource{GB_E, 0, in_w}, none, GB_H, 1, 0, lay);
+        else if (skip >= 0 && i - 1 == skip)            // h = cat([input_pts, h]) (rnh:280-282): columns [input | hidden]
+            gen_add_layer(g, d.precision, m.pts_linears[i], GenSource{GB_E, 0, in_w}, GenSource{GB_H, in_w, W}, GB_H, 1, 0, lay);
+        else gen_add_layer(g, d.precision, m.pts_linears[i], GenSource{GB_H, 0, W}, none, GB_H, 1, 0, lay);
+    }
+    if (m.use_viewdirs) {                              // rnh:284-304
+        const int half = m.views_linear.out_features, dv = 3 + 6 * d.multires_views;
+        widest = imax(widest, half);
+        gen_add_layer(g, d.precision, m.alpha_linear, GenSource{GB_H, 0, W}, none, GB_O, 0, 3, lay);
+        gen_add_layer(g, d.precision, m.feature_linear, GenSource{GB_H, 0, W}, none, GB_H, 0, 0, lay);
+        gen_add_layer(g, d.precision, m.views_linear, GenSource{GB_H, 0, W}, GenSource{GB_V, W, dv}, GB_H, 1, 0, lay);   // cat([feature, input_views])
+        gen_add_layer(g, d.precision, m.rgb_linear, GenSource{GB_H, 0, half}, none, GB_O, 0, 0, lay);
+    } else {
+        gen_add_layer(g, d.precision, m.output_linear, GenSource{GB_H, 0, W}, none, GB_O, 0, 0, lay);
+    }
+    g.proto.kh = (widest + 31) / 32 * 32;
+    gen_finish(g, d.precision);
+}
+// ray_bending.forward (rnh:507-577): always packed (and run) in fp32
+void gen_pack_bender(const nrnerf_bender_desc& b, GenProgram& g, const FlatLayout* lay) {
+    g.proto.mode = 0; g.proto.L = 0; g.proto.LV = -1; g.proto.lat = b.latent_size;
+    g.proto.ke = pad16(3 + b.latent_size); g.proto.kv = 16;
+    const GenSource none{GB_H, 0, 0};
+    for (int i = 0; i < b.depth; ++i) {
+        const bool last = i == b.depth - 1;
+        gen_add_layer(g, NRNERF_PREC_F32, b.network[i], i == 0 ? GenSource{GB_E, 0, 3 + b.latent_size} : GenSource{GB_H, 0, b.hidden}, none,
+                      last ? GB_O : GB_H, last ? 0 : 1, 0, lay);
+    }
+    for (int i = 0; i < b.rigidity_depth; ++i) {
+        const bool last = i == b.rigidity_depth - 1;
+        gen_add_layer(g, NRNERF_PREC_F32, b.rigidity_network[i], i == 0 ? GenSource{GB_V, 0, 3} : GenSource{GB_H, 0, b.rigidity_hidden}, none,
+                      last ? GB_O : GB_H, last ? 0 : 1, 3, lay);
+    }
+    g.proto.kh = (imax(b.hidden, b.rigidity_hidden) + 31) / 32 * 32;
+    gen_finish(g, NRNERF_PREC_F32);
+}
+
 // the trunk-only / bender-only kernels of the split-bender path: the trunk is the architecture's without bender (the 5- and
 // the 7-layer bender share architecture 0's), the bender kernel is compiled per bender shape (narrow trunk: the 5-layer one)
 int trunk_arch(int arch_id) { return arch_id == 5 ? 5 : 0; }
@@ -512,6 +680,11 @@ struct nrnerf_model {
     // their transposes; bend_train_ok: train_ok and a bender
     PassDev bend_train_fwd, bend_train_bwd;
     bool bend_train_ok = false;
+    // generic architecture (nrnerf_generic.h): layer programs instead of compiled plans; gen_* hold their packed images
+    bool generic = false;
+    GenArgs gen_bend_prog{}, gen_coarse_prog{}, gen_fine_prog{};
+    PassDev gen_bend, gen_coarse, gen_fine;
+    bool gen_fine_is_coarse = false;
     int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
     mutable std::mutex prof_mu;
@@ -644,6 +817,84 @@ int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t ref
     return rc;
 }
 
+// ---- models of an architecture outside the compiled set (nrnerf_generic.h)
+int gen_pack_all(const nrnerf_model_desc& d, const FlatLayout* lay, GenProgram& gb, GenProgram& gc, GenProgram& gf) {
+    if (d.exact_viewdirs && d.bender && d.coarse->use_viewdirs) return NRNERF_ERR_UNSUPPORTED;      // Jacobian directions: compiled kernels only
+    int rc = gen_check_mlp(d, *d.coarse);
+    if (rc == NRNERF_OK && d.fine) rc = gen_check_mlp(d, *d.fine);
+    if (rc == NRNERF_OK && d.fine && (d.fine->time_conditioned != 0) != (d.coarse->time_conditioned != 0)) rc = NRNERF_ERR_INVALID;
+    if (rc == NRNERF_OK && d.bender) rc = gen_check_bender(*d.bender);
+    if (rc != NRNERF_OK) return rc;
+    if (d.bender) gen_pack_bender(*d.bender, gb, lay);
+    gen_pack_mlp(d, *d.coarse, gc, lay);
+    if (d.fine) gen_pack_mlp(d, *d.fine, gf, lay);
+    return NRNERF_OK;
+}
+int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_model** out) {
+    GenProgram gb, gc, gf;
+    int rc = gen_pack_all(d, &lay, gb, gc, gf);
+    if (rc != NRNERF_OK) return rc;
+    DeviceGuard guard(d.device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    struct Owner {
+        nrnerf_model* m;
+        ~Owner() { if (m) nrnerf_model_destroy(m); }
+    } own{new (std::nothrow) nrnerf_model()};
+    nrnerf_model* m = own.m;
+    if (!m) return NRNERF_ERR_NOMEM;
+    m->generic = true;
+    m->device = d.device; m->precision = d.precision;
+    m->has_bend = d.bender != nullptr;
+    m->views = d.coarse->use_viewdirs != 0;
+    m->arch_id = -1; m->exact = 0;
+    m->needs_latents = m->has_bend || d.coarse->time_conditioned;
+    m->latent_size = d.bender ? d.bender->latent_size : gc.proto.lat;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d.device) != hipSuccess) return NRNERF_ERR_HIP;
+    m->num_cus = prop.multiProcessorCount;
+    m->flat_floats = lay.total;
+    nrnerf_model_desc d2 = d;
+    d2.bender = nullptr;
+    if (d.bender) {
+        rc = upload_pass(gb.pk, m->gen_bend);
+        if (rc != NRNERF_OK) return rc;
+        m->gen_bend_prog = gb.proto;
+        m->gen_bend.algo_flops_per_sample = 2.0 * (algo_macs(d, *d.coarse) - algo_macs(d2, *d.coarse));
+    }
+    rc = upload_pass(gc.pk, m->gen_coarse);
+    if (rc != NRNERF_OK) return rc;
+    m->gen_coarse_prog = gc.proto;
+    m->gen_coarse.algo_flops_per_sample = 2.0 * algo_macs(d2, *d.coarse);
+    m->gen_coarse.output_ch = d.coarse->output_ch;
+    m->coarse.output_ch = d.coarse->output_ch;
+    if (d.fine) {
+        rc = upload_pass(gf.pk, m->gen_fine);
+        if (rc != NRNERF_OK) return rc;
+        m->gen_fine_prog = gf.proto;
+        m->gen_fine.algo_flops_per_sample = 2.0 * algo_macs(d2, *d.fine);
+        m->gen_fine.output_ch = d.fine->output_ch;
+    } else {
+        m->gen_fine = m->gen_coarse; m->gen_fine_prog = m->gen_coarse_prog; m->gen_fine_is_coarse = true;
+    }
+    m->fine.output_ch = m->gen_fine.output_ch;
+    m->fine_is_coarse = !d.fine;
+    own.m = nullptr;
+    *out = m;
+    return NRNERF_OK;
+}
+int update_generic(nrnerf_model* m, const nrnerf_model_desc& d, hipStream_t stream) {
+    GenProgram gb, gc, gf;
+    int rc = gen_pack_all(d, nullptr, gb, gc, gf);
+    if (rc != NRNERF_OK) return rc == NRNERF_ERR_UNSUPPORTED ? NRNERF_ERR_INVALID : rc;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    if (d.bender) rc = refresh_pass(gb.pk, m->gen_bend, stream);         // (sizes differ for another architecture: NRNERF_ERR_INVALID)
+    if (rc == NRNERF_OK) rc = refresh_pass(gc.pk, m->gen_coarse, stream);
+    if (rc == NRNERF_OK && d.fine) rc = refresh_pass(gf.pk, m->gen_fine, stream);
+    if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;      // the packed host images die with this call
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -693,6 +944,22 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
             if (bender_arch(arch_id) == 0) pack_pass_bwd_bender<ArchDefault>(*desc->bender, pk);
             else pack_pass_bwd_bender<ArchDeepBend>(*desc->bender, pk);
         }
+    } else if (which >= 7 && which <= 9) {      // layer programs of the run-time-parameterised kernel: 7 = coarse, 8 = fine, 9 = ray bender
+        GenProgram gb, gc, gf;
+        rc = gen_pack_all(*desc, nullptr, gb, gc, gf);
+        if (rc == NRNERF_OK && ((which == 8 && !desc->fine) || (which == 9 && !desc->bender))) rc = NRNERF_ERR_INVALID;
+        if (rc == NRNERF_OK) {
+            GenProgram& g = which == 7 ? gc : (which == 8 ? gf : gb);
+            pk = g.pk;
+            // the "unit table" of a program: n_layers, then per layer the 11 integers of GenLayer; followed by ke, kv, kh, lat
+            pk.unit_off.assign(1, (uint32_t)g.proto.n_layers);
+            for (int l = 0; l < g.proto.n_layers; ++l) {
+                const GenLayer& y = g.proto.layer[l];
+                for (int v : {y.w_frag, y.bias_tile, y.nt, y.src0, y.ns0, y.src1, y.ns1, y.dst, y.relu, y.o_col, y.o_rows}) pk.unit_off.push_back((uint32_t)v);
+            }
+            for (int v : {g.proto.ke, g.proto.kv, g.proto.kh, g.proto.lat}) pk.unit_off.push_back((uint32_t)v);
+            pk.nunits = (int)pk.unit_off.size() - 1;
+        }
     } else {
         rc = pack_dispatch(*desc, *m, pk);
     }
@@ -721,14 +988,18 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) try {
     PackedPass pc, pf;
     int arch_id = 0, arch_f = 0;
     const FlatLayout lay = flat_layout(*desc);
+    if (desc->fine && (desc->fine->use_viewdirs != 0) != (desc->coarse->use_viewdirs != 0)) return NRNERF_ERR_INVALID;
     int rc = pack_dispatch(*desc, *desc->coarse, pc, &arch_id, false, &lay);
-    if (rc != NRNERF_OK) return rc;
-    if (desc->fine) {
-        if ((desc->fine->use_viewdirs != 0) != (desc->coarse->use_viewdirs != 0)) return NRNERF_ERR_INVALID;
+    if (rc == NRNERF_OK && desc->fine) {
         rc = pack_dispatch(*desc, *desc->fine, pf, &arch_f, false, &lay);
-        if (rc != NRNERF_OK) return rc;
-        if (arch_f != arch_id) return NRNERF_ERR_INVALID;
+        if (rc == NRNERF_OK && arch_f != arch_id) rc = NRNERF_ERR_UNSUPPORTED;      // e.g. --netwidth_fine != --netwidth: generic below
     }
+    // NRNERF_FORCE_GENERIC=1 (read per call): the generic kernel also for the compiled shapes (tests: the two routes against each other)
+    const char* fg_env = std::getenv("NRNERF_FORCE_GENERIC");
+    const bool force_generic = fg_env && fg_env[0] == '1';
+    if (rc == NRNERF_OK && force_generic && !(desc->exact_viewdirs && desc->bender && desc->coarse->use_viewdirs)) rc = NRNERF_ERR_UNSUPPORTED;
+    if (rc == NRNERF_ERR_UNSUPPORTED) return create_generic(*desc, lay, out);
+    if (rc != NRNERF_OK) return rc;
     DeviceGuard guard(desc->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     // owns the handle until it is handed to the caller: every early return (and an exception caught by NRN_CATCH) frees
@@ -798,6 +1069,7 @@ int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hi
         (desc->coarse->use_viewdirs != 0) != (m->views != 0) || (desc->fine != nullptr) == m->fine_is_coarse ||
         ((desc->exact_viewdirs != 0 && m->has_bend && m->views) != (m->exact != 0)))
         return NRNERF_ERR_INVALID;                     // a different model: create a new handle instead
+    if (m->generic) return update_generic(m, *desc, (hipStream_t)hip_stream);
     PackedPass pc, pf;
     int arch_id = 0, arch_f = 0;
     int rc = pack_dispatch(*desc, *desc->coarse, pc, &arch_id);
@@ -835,7 +1107,8 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     if (!guard.ok) return NRNERF_ERR_HIP;
     hipStream_t stream = (hipStream_t)hip_stream;
     PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only,
-                         &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train};
+                         &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
+                         &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine};
     for (PassDev* p : passes) {
         if (!p || !p->stream) continue;
         if (!p->src) return NRNERF_ERR_UNSUPPORTED;
@@ -864,6 +1137,9 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->bend_train_bwd);
     free_pass(m->coarse_train);
     free_pass(m->fine_train);
+    free_pass(m->gen_bend);
+    if (!m->gen_fine_is_coarse) free_pass(m->gen_fine);
+    free_pass(m->gen_coarse);
     (void)hipSetDevice(prev);
     delete m;
 }
@@ -886,7 +1162,7 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
 int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_stream) try {
     if (!m || !a || a->struct_size != sizeof(nrnerf_render_args)) return NRNERF_ERR_INVALID;
     if (a->n_rays < 0 || a->n_samples < 2 || a->n_importance < 0) return NRNERF_ERR_INVALID;
-    if (a->n_samples > 256 || a->n_samples + a->n_importance > 256) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_samples > NRNERF_MAX_SAMPLES || a->n_samples + a->n_importance > NRNERF_MAX_SAMPLES) return NRNERF_ERR_UNSUPPORTED;
     if (a->n_rays == 0) return NRNERF_OK;
     if (!a->rays || a->ray_stride < 8 || !a->rgb_map || !a->disp_map || !a->acc_map) return NRNERF_ERR_INVALID;
     if (m->needs_latents && (!a->latents || a->latent_stride < 0)) return NRNERF_ERR_INVALID;
@@ -909,6 +1185,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     }
     const bool surface = a->surface_pts || a->surface_rigidity || a->median_index;
     float* bent4 = (float*)ws;
+    float* const bent4_ws = bent4;       // (the slot itself: `bent4` is nulled below when the compiled path does not need it)
     ws += align_up((size_t)N * SF * 4 * sizeof(float), 256);
     float* z_coarse = (float*)ws;
     ws += align_up((size_t)N * S * sizeof(float), 256);
@@ -920,8 +1197,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     };
     static const bool force_fused = [] { const char* e = std::getenv("NRNERF_FUSED_FINE_BENDER"); return e && e[0] == '1'; }();
     // (the stand-alone bender kernel indexes its 32-sample blocks with 32 bits: beyond 2^31 blocks stay on the fused kernels)
+    // (8-bit ranks among the merged depths: beyond 256 samples per ray the fused-bender fine pass renders)
     const bool split = m->split_ok && I > 0 && !a->detailed_output && !any_detail(a->coarse) && !any_detail(a->fine) && !force_fused &&
-                       (long long)N * ((imax(S, I) + 31) / 32) < (1ll << 31);
+                       (long long)N * ((imax(S, I) + 31) / 32) < (1ll << 31) && SF <= 256;
     float* bent_c = nullptr; float* z_new = nullptr; uint8_t* rank_new = nullptr;
     if (I > 0) {
         bent_c = (float*)ws; ws += align_up((size_t)N * S * 4 * sizeof(float), 256);
@@ -968,6 +1246,69 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         zc = z_coarse;
     }
 
+    if (m->generic) {
+        // ---- architecture outside the compiled set (nrnerf_generic.h): per pass the bender over all samples of the pass (no
+        //      split-bender trick: the generic path trades speed for generality), the canonical network on the bent points,
+        //      the composite kernel.  Kernel slots of the profile: 5 / 4 = bender of the coarse / fine pass.
+        const bool bend = m->has_bend != 0, views = m->views != 0;
+        auto bender_pass = [&](const float* zv, int nS, float* out4, const nrnerf_sample_outputs& so, int slot) -> hipError_t {
+            GenArgs g = m->gen_bend_prog;
+            g.rays = a->rays; g.ray_stride = a->ray_stride; g.latents = a->latents; g.lat_stride = a->latent_stride;
+            g.z = zv; g.lindisp = a->lindisp; g.n_rays = N; g.S = nS;
+            g.wstream = m->gen_bend.stream; g.bias = m->gen_bend.bias;
+            g.bent4 = out4; g.ex = sample_out(so); g.knobs = kn;
+            return timed(slot, (double)N * nS * m->gen_bend.algo_flops_per_sample, 0, [&] { return launch_generic(m->precision, g, m->num_cus, stream); });
+        };
+        auto network_pass = [&](const GenArgs& prog, const PassDev& pd, const float* zv, int nS, const float* pts, float* raw4, float* raw_user,
+                                float* bent_out, const nrnerf_sample_outputs& so, int slot) -> hipError_t {
+            GenArgs g = prog;
+            g.rays = a->rays; g.ray_stride = a->ray_stride; g.latents = a->latents; g.lat_stride = a->latent_stride;
+            g.z = zv; g.lindisp = a->lindisp; g.n_rays = N; g.S = nS;
+            g.pts4 = pts; g.dirs_from_pts = (pts && views) ? 1 : 0;
+            g.wstream = pd.stream; g.bias = pd.bias;
+            g.raw4 = raw4; g.raw_out = raw_user; g.raw_ch = pd.output_ch;
+            g.bent4 = pts ? const_cast<float*>(pts) : bent_out;          // with a bender: read (removal knob); without: written (points of the pass)
+            g.knobs = kn;
+            if (!pts) g.ex = sample_out(so);                             // without a bender the network kernel reports the points
+            return timed(slot, (double)N * nS * pd.algo_flops_per_sample, 0, [&] { return launch_generic(m->precision, g, m->num_cus, stream); });
+        };
+        float* const bent_final = bent4_ws;                         // points of the final pass [N, S + I | S, 4]
+        float* const bentA = (I > 0) ? bent_c : bent4_ws;           // points of the coarse pass: its own array when a fine pass follows
+        hipError_t ge = hipSuccess;
+        if (bend) ge = bender_pass(zc, S, bentA, a->coarse, 5);
+        if (ge != hipSuccess) return NRNERF_ERR_HIP;
+        ge = network_pass(m->gen_coarse_prog, m->gen_coarse, zc, S, bend ? bentA : nullptr, raw_c, (I == 0) ? a->raw : nullptr,
+                          (I == 0 && surface) ? bent_final : nullptr, a->coarse, 0);
+        if (ge != hipSuccess) return NRNERF_ERR_HIP;
+        CompositeArgs gc{};
+        gc.rays = a->rays; gc.ray_stride = a->ray_stride;
+        gc.raw4 = raw_c; gc.z = zc; gc.n_rays = N; gc.S = S; gc.n_importance = I;
+        gc.lindisp = a->lindisp; gc.white_bkgd = a->white_bkgd; gc.noise = a->noise_coarse; gc.u = a->u_fine;
+        gc.vis = a->coarse.visibility_weights; gc.alpha = a->coarse.opacity_alpha;
+        if (I > 0) {
+            gc.rgb = a->rgb0 ? a->rgb0 : raw_f; gc.disp = a->disp0 ? a->disp0 : raw_f + (size_t)N * 3; gc.acc = a->acc0 ? a->acc0 : raw_f + (size_t)N * 4;
+            gc.z_std = a->z_std; gc.z_out = z_fine;
+        } else {
+            gc.rgb = a->rgb_map; gc.disp = a->disp_map; gc.acc = a->acc_map; gc.z_user = a->z_vals;
+            if (surface) { gc.bent4 = bent_final; gc.surf_pts = a->surface_pts; gc.surf_rig = a->surface_rigidity; gc.med_idx = a->median_index; }
+        }
+        if (timed(1, 0, 0, [&] { return launch_composite(gc, stream); }) != hipSuccess) return NRNERF_ERR_HIP;
+        if (I == 0) return NRNERF_OK;
+        if (bend) ge = bender_pass(z_fine, SF, bent_final, a->fine, 4);
+        if (ge != hipSuccess) return NRNERF_ERR_HIP;
+        ge = network_pass(m->gen_fine_prog, m->gen_fine, z_fine, SF, bend ? bent_final : nullptr, raw_f, a->raw, surface ? bent_final : nullptr, a->fine, 2);
+        if (ge != hipSuccess) return NRNERF_ERR_HIP;
+        CompositeArgs gf{};
+        gf.rays = a->rays; gf.ray_stride = a->ray_stride;
+        gf.raw4 = raw_f; gf.z = z_fine; gf.n_rays = N; gf.S = SF; gf.n_importance = 0;
+        gf.white_bkgd = a->white_bkgd; gf.noise = a->noise_fine;
+        gf.rgb = a->rgb_map; gf.disp = a->disp_map; gf.acc = a->acc_map; gf.z_user = a->z_vals;
+        gf.vis = a->fine.visibility_weights; gf.alpha = a->fine.opacity_alpha;
+        if (surface) { gf.bent4 = bent_final; gf.surf_pts = a->surface_pts; gf.surf_rig = a->surface_rigidity; gf.med_idx = a->median_index; }
+        if (timed(3, 0, 0, [&] { return launch_composite(gf, stream); }) != hipSuccess) return NRNERF_ERR_HIP;
+        return NRNERF_OK;
+    }
+
     // ---- K0: coarse network
     NetArgs na{};
     na.rays = a->rays; na.ray_stride = a->ray_stride;
@@ -985,6 +1326,36 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // the samples skips the bender.  NRNERF_SPLIT_COARSE=1 splits it as well (A/B).
     static const bool split_coarse_on = [] { const char* e = std::getenv("NRNERF_SPLIT_COARSE"); return e && e[0] == '1'; }();
     const bool split_coarse = split && split_coarse_on;
+    // Compositing fused into the FINAL pass' network kernel (north_star: "compositing fused into the ray loop"; the
+    // reference calls raw2outputs inline, train.py:943-950): the kernel variants without a fused bender -- the trunk-only fine
+    // pass of the split-bender path, every pass of a model without bender -- let each wave own whole rays, keep their raw
+    // outputs in LDS and composite them itself (nrnerf_composite_ray.h: the composite kernel's own code, so the same bits).
+    // The pass' raw array (16 B per sample written and read back) never exists and one launch goes.  The coarse pass of a
+    // hierarchical render keeps its composite kernel: sample_pdf and the merge follow it there.
+    // NRNERF_UNFUSED_COMPOSITE=1 keeps the separate launch (A/B and bit-identity tests; read per call so that one process can
+    // render both ways).
+    const char* unfused_env = std::getenv("NRNERF_UNFUSED_COMPOSITE");
+    const bool unfused_composite = unfused_env && unfused_env[0] == '1';
+    auto final_composite = [&](int pass_S, const float* zv, const float* noise, const nrnerf_sample_outputs& so, const float* raw4) {
+        CompositeArgs c{};
+        c.rays = a->rays; c.ray_stride = a->ray_stride;
+        c.raw4 = raw4; c.z = zv; c.n_rays = N; c.S = pass_S; c.n_importance = 0;
+        c.lindisp = a->lindisp; c.white_bkgd = a->white_bkgd; c.noise = noise;
+        c.rgb = a->rgb_map; c.disp = a->disp_map; c.acc = a->acc_map;
+        c.z_std = nullptr; c.z_out = nullptr; c.z_user = a->z_vals;
+        c.vis = so.visibility_weights; c.alpha = so.opacity_alpha;
+        if (surface) { c.bent4 = bent4; c.surf_pts = a->surface_pts; c.surf_rig = a->surface_rigidity; c.med_idx = a->median_index; }
+        return c;
+    };
+    // (small batches keep the separate launch: a fused pass hands out whole GROUPS of rays -- 4 rays = 24 blocks at 192 samples --
+    //  where the plain mapping hands out 8-block tiles, so below one group per CU the plain mapping fills more of the chip)
+    auto enough_rays_to_fuse = [&](int pass_S) {
+        const int bpr = (pass_S + 31) / 32;
+        const long long rays_per_group = (m->precision == NRNERF_PREC_F32) ? 4 : ((bpr & 1) ? 8 : 4);
+        return (long long)N >= rays_per_group * m->num_cus;
+    };
+    const bool fuse_coarse_only = I == 0 && !m->has_bend && !unfused_composite && S <= 256 && enough_rays_to_fuse(S);
+    if (fuse_coarse_only) { na.fuse_on = 1; na.fuse = final_composite(S, zc, a->noise_coarse, a->coarse, nullptr); na.raw4 = nullptr; }
     hipError_t e;
     if (split_coarse) {
         // KBc: stand-alone bender over the S coarse samples, then the coarse trunk on the bent points
@@ -1006,6 +1377,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                   [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
     }
     if (e != hipSuccess) return NRNERF_ERR_HIP;
+    if (fuse_coarse_only) return NRNERF_OK;
 
     // ---- K1: coarse composite (+ sampling)
     CompositeArgs ca{};
@@ -1037,6 +1409,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.z = z_fine; nf.S = SF;
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
+    // K3 inside K2 (see final_composite above) whenever K2 is a kernel without a fused bender
+    const bool fuse_fine = (split || !m->has_bend) && !unfused_composite && SF <= 256 && enough_rays_to_fuse(SF);
+    if (fuse_fine) { nf.fuse_on = 1; nf.fuse = final_composite(SF, z_fine, a->noise_fine, a->fine, nullptr); nf.raw4 = nullptr; }
     if (split) {
         // KB: only the I importance samples go through the bender; the coarse samples' bent points are already in place
         BendArgs ba{};
@@ -1061,15 +1436,10 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     }
     if (e != hipSuccess) return NRNERF_ERR_HIP;
 
+    if (fuse_fine) return NRNERF_OK;
+
     // ---- K3: fine composite
-    CompositeArgs cf{};
-    cf.rays = a->rays; cf.ray_stride = a->ray_stride;
-    cf.raw4 = raw_f; cf.z = z_fine; cf.n_rays = N; cf.S = SF; cf.n_importance = 0;
-    cf.white_bkgd = a->white_bkgd; cf.noise = a->noise_fine;
-    cf.rgb = a->rgb_map; cf.disp = a->disp_map; cf.acc = a->acc_map;
-    cf.z_std = nullptr; cf.z_out = nullptr; cf.z_user = a->z_vals;
-    cf.vis = a->fine.visibility_weights; cf.alpha = a->fine.opacity_alpha;
-    if (surface) { cf.bent4 = bent4; cf.surf_pts = a->surface_pts; cf.surf_rig = a->surface_rigidity; cf.med_idx = a->median_index; }
+    const CompositeArgs cf = final_composite(SF, z_fine, a->noise_fine, a->fine, raw_f);
     e = timed(3, 0, 0, [&] { return launch_composite(cf, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
     return NRNERF_OK;

@@ -12,42 +12,24 @@
 
 #include "nrnerf_kernels.h"
 #include "nrnerf_aux.h"
+#include "nrnerf_composite_ray.h"
 
 namespace nrn {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 static constexpr int RAYS_PER_WG = 4;
-static constexpr int MAXS = 256;        // S and S+I are limited to 256 (4 samples per lane)
-
-__device__ __forceinline__ float c_lin01(int i, int n) {     // torch.linspace(0,1,n)[i], fp32
-    if (n <= 1) return 0.0f;
-    const float step = __fdiv_rn(1.0f, (float)(n - 1));
-    return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-// inclusive prefix scans over the 64 lanes
-__device__ __forceinline__ float wave_scan_add(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v += t; }
-    return v;
-}
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v *= t; }
-    return v;
-}
+// Samples per ray and pass: a lane owns EPL <= 16 consecutive samples, so S and S + I go up to 1024 (the reference has no cap,
+// train.py:1090-1094; its configs use 64 + 64 / 64 + 128).  The training kernels below, the split-bender path (8-bit ranks)
+// and the fused compositing of the network kernels stay at 256 (MAXS_TRAIN): beyond it a render takes the fused-bender
+// fine pass and this kernel, a training call the reference's own function.
+static constexpr int MAXS = 1024;
+static constexpr int MAXS_TRAIN = 256;
 
 template <int EPL, bool SAMPLE>
 __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const CompositeArgs a) {
-    __shared__ float s_cdf[RAYS_PER_WG][MAXS];
-    __shared__ float s_bins[RAYS_PER_WG][MAXS];
-    __shared__ float s_z[RAYS_PER_WG][MAXS + 4];
+    constexpr int NLDS = SAMPLE ? 64 * EPL : 1;                     // cdf / bins of the S coarse samples
+    __shared__ float s_cdf[RAYS_PER_WG][NLDS];
+    __shared__ float s_bins[RAYS_PER_WG][NLDS];
+    __shared__ float s_z[RAYS_PER_WG][SAMPLE ? MAXS + 4 : 1];       // the S + I depths to merge
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray_raw = blockIdx.x * RAYS_PER_WG + wave;
@@ -55,116 +37,9 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
     const int ray = ray_ok ? ray_raw : a.n_rays - 1;
     const int S = a.S;
 
-    const float* rp = a.rays + (size_t)ray * a.ray_stride;
-    const float dx = rp[3], dy = rp[4], dz = rp[5];
-    const float near = rp[6], far = rp[7];
-    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);                 // train.py:748
-
-    // ---- load this lane's samples
-    float z[EPL + 1], sig[EPL], col[EPL][3];
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-        const int i = lane * EPL + k;
-        const int ic = i < S ? i : S - 1;
-        if (a.z) z[k] = a.z[(size_t)ray * S + ic];
-        else {
-            const float t = c_lin01(ic, S);
-            if (a.lindisp)                                                               // train.py:850-852
-                z[k] = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)),
-                                                 __fmul_rn(__fdiv_rn(1.0f, far), t)));
-            else
-                z[k] = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));   // train.py:849
-        }
-        const f32x4 r = *(const f32x4*)(a.raw4 + ((size_t)ray * S + ic) * 4);
-        col[k][0] = r[0]; col[k][1] = r[1]; col[k][2] = r[2]; sig[k] = r[3];
-        if (a.noise) sig[k] = __fadd_rn(sig[k], a.noise[(size_t)ray * S + ic]);                // train.py:761
-    }
-    z[EPL] = __shfl_down(z[0], 1);     // first depth of the next lane
-
-    // ---- alpha, transmittance, weights (train.py:740-775)
-    float alpha[EPL], w[EPL];
-    float run = 1.0f;                  // product of (1 - alpha + 1e-10) over this lane's samples so far
-    float texcl[EPL];
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-        const int i = lane * EPL + k;
-        float dist = (i == S - 1) ? 1e10f : __fsub_rn(z[k + 1], z[k]);      // :743-746
-        dist = __fmul_rn(dist, dnorm);                                      // :748
-        const float s = fmaxf(sig[k], 0.0f);
-        alpha[k] = (i < S) ? __fsub_rn(1.0f, expf(-__fmul_rn(s, dist))) : 0.0f;   // :741
-        texcl[k] = run;
-        run = __fmul_rn(run, (i < S) ? __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f) : 1.0f);
-    }
-    const float incl = wave_scan_mul(run, lane);
-    float before = __shfl_up(incl, 1);
-    if (lane == 0) before = 1.0f;
-    float sr = 0.f, sg = 0.f, sb = 0.f, sdepth = 0.f, sacc = 0.f;
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-        const int i = lane * EPL + k;
-        w[k] = (i < S) ? __fmul_rn(alpha[k], __fmul_rn(before, texcl[k])) : 0.0f;
-        const float r = 1.0f / (1.0f + expf(-col[k][0]));                   // sigmoid, :750
-        const float g = 1.0f / (1.0f + expf(-col[k][1]));
-        const float b = 1.0f / (1.0f + expf(-col[k][2]));
-        sr += w[k] * r; sg += w[k] * g; sb += w[k] * b;
-        sdepth += w[k] * z[k]; sacc += w[k];
-        if (ray_ok && i < S) {
-            if (a.vis) a.vis[(size_t)ray * S + i] = w[k];
-            if (a.alpha) a.alpha[(size_t)ray * S + i] = alpha[k];
-            if (a.z_user) a.z_user[(size_t)ray * S + i] = z[k];
-        }
-    }
-    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sdepth = wave_sum(sdepth); sacc = wave_sum(sacc);
-    if (ray_ok && lane == 0) {
-        if (a.white_bkgd) {                                                                                   // :786-787
-            const float bg = __fsub_rn(1.0f, sacc);
-            sr = __fadd_rn(sr, bg); sg = __fadd_rn(sg, bg); sb = __fadd_rn(sb, bg);
-        }
-        a.rgb[(size_t)ray * 3 + 0] = sr; a.rgb[(size_t)ray * 3 + 1] = sg; a.rgb[(size_t)ray * 3 + 2] = sb;   // :776
-        a.acc[ray] = sacc;                                                                                    // :779
-        const float q = sdepth / sacc;                               // 0/0 = NaN when acc == 0 ...
-        a.disp[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));      // ... which torch.max propagates (:781-784)
-    }
-
-    // ---- surface reduction: index of the sample whose accumulated visibility is closest to 0.5 (first one on ties),
-    //      and the bent point / rigidity there (free_viewpoint_rendering.py:621-648 does this on the host from the
-    //      full per-sample tensors: ~15 KB/ray of D2H traffic instead of 20 B/ray)
-    if (a.bent4) {
-        // cumsum in strictly sequential order (carry handed from lane to lane): zero-weight plateaus then give
-        // bit-identical prefixes, hence exact ties that resolve to the first index, as with torch.cumsum on the host
-        float carry = 0.f, base = 0.f;
-        for (int l = 0; l < 64; ++l) {
-            float e = carry;
-#pragma unroll
-            for (int k = 0; k < EPL; ++k) e = __fadd_rn(e, w[k]);
-            if (lane == l) base = carry;
-            carry = __shfl(e, l);
-        }
-        // NaN weights (a diverged checkpoint, an overflowed f16 sigma) compare false everywhere: start from this lane's
-        // first valid sample so the index is always in range, like the host argmin the reference uses (fvr:626-628)
-        float best = 3.0e38f, run_c = base;
-        int bidx = (lane * EPL < S) ? lane * EPL : S - 1;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            const int i = lane * EPL + k;
-            run_c = __fadd_rn(run_c, w[k]);
-            const float dist = fabsf(__fsub_rn(run_c, 0.5f));
-            if (i < S && dist < best) { best = dist; bidx = i; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bidx, o);
-            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-        }
-        if (ray_ok && lane == 0) {
-            bidx = bidx < 0 ? 0 : (bidx > S - 1 ? S - 1 : bidx);
-            const f32x4 b = *(const f32x4*)(a.bent4 + ((size_t)ray * S + bidx) * 4);
-            if (a.surf_pts) { a.surf_pts[(size_t)ray * 3] = b[0]; a.surf_pts[(size_t)ray * 3 + 1] = b[1]; a.surf_pts[(size_t)ray * 3 + 2] = b[2]; }
-            if (a.surf_rig) a.surf_rig[ray] = b[3];
-            if (a.med_idx) a.med_idx[ray] = bidx;
-        }
-    }
+    // ---- alpha compositing, per-ray maps, detail outputs, surface reduction: shared with the network kernels' fused epilogue
+    float z[EPL + 1], w[EPL];
+    composite_ray<EPL>(a, ray, ray_ok, lane, [&](int ic) { return *(const f32x4*)(a.raw4 + ((size_t)ray * S + ic) * 4); }, z, w);
 
     if constexpr (SAMPLE) {
         const int I = a.n_importance;
@@ -286,7 +161,7 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_bwd_kernel(const C
     const float* rp = a.rays + (size_t)ray * a.ray_stride;
     const float dx = rp[3], dy = rp[4], dz = rp[5];
     const float near = rp[6], far = rp[7];
-    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));      // as composite_ray
 
     float z[EPL + 1], sig[EPL], col[EPL][3];
 #pragma unroll
@@ -387,7 +262,7 @@ static hipError_t launch_bwd_epl(const CompositeBwdArgs& a, hipStream_t stream) 
     return hipGetLastError();
 }
 hipError_t launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t stream) {
-    if (a.S < 2 || a.S > MAXS) return hipErrorInvalidValue;
+    if (a.S < 2 || a.S > MAXS_TRAIN) return hipErrorInvalidValue;
     switch ((a.S + 63) / 64) {
         case 1: return launch_bwd_epl<1>(a, stream);
         case 2: return launch_bwd_epl<2>(a, stream);
@@ -435,14 +310,18 @@ hipError_t launch_zjitter(const JitterArgs& a, hipStream_t stream) {
 
 hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream) {
     if (a.S < 2 || a.S > MAXS || a.S + a.n_importance > MAXS) return hipErrorInvalidValue;
+    if (a.rank_new && a.S + a.n_importance > 256) return hipErrorInvalidValue;      // 8-bit ranks of the split-bender path
     const int epl = (a.S + 63) / 64;
     switch (epl) {
         case 1: return launch_epl<1>(a, stream);
         case 2: return launch_epl<2>(a, stream);
         case 3: return launch_epl<3>(a, stream);
         case 4: return launch_epl<4>(a, stream);
+        case 5: case 6: return launch_epl<6>(a, stream);
+        case 7: case 8: return launch_epl<8>(a, stream);
+        case 9: case 10: case 11: case 12: return launch_epl<12>(a, stream);
+        default: return launch_epl<16>(a, stream);
     }
-    return hipErrorInvalidValue;
 }
 
 

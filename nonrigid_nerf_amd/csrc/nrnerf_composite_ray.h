@@ -1,0 +1,183 @@
+// nrnerf_composite_ray.h -- alpha compositing of ONE ray by ONE wavefront (reference raw2outputs, train.py:724-789) and the
+// per-ray surface reduction (free_viewpoint_rendering.py:621-658), as a device function shared by
+//   * composite_kernel (nrnerf_composite.hip): one wave per ray, raw [N,S,4] read from HBM, followed there by sample_pdf and
+//     the merge when the pass is the coarse one of a hierarchical render;
+//   * the network kernels' fused epilogue (nrnerf_net_mb.h / nrnerf_net_impl.h, variants without a fused bender): a wave owns
+//     whole rays, keeps their raw outputs in LDS and composites them itself -- the final pass' raw array never reaches HBM
+//     ("compositing fused into the ray loop", BASELINE.json north_star; train.py:943-959 calls raw2outputs inline).
+// The SAME code in both places, so the two routes give the same bits (asserted: tests/test_gpu_parity.py).
+//
+// Lane l owns the EPL consecutive samples l*EPL .. l*EPL+EPL-1: the exclusive transmittance product is a short in-lane serial
+// scan followed by one 64-lane prefix scan.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "nrnerf_kernels.h"
+
+namespace nrn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float c_lin01(int i, int n) {     // torch.linspace(0,1,n)[i], fp32
+    if (n <= 1) return 0.0f;
+    const float step = __fdiv_rn(1.0f, (float)(n - 1));
+    return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// inclusive prefix scans over the 64 lanes
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v *= t; }
+    return v;
+}
+
+// what composite_ray reads from HBM before it can start, requested early: out[0..2] = direction, out[3 + k] = depth of sample
+// lane * epl + k (k < epl <= 4; only when the pass has explicit depths)
+__device__ __forceinline__ void composite_prefetch(const CompositeArgs& a, const int ray, const int lane, const int epl, float (&out)[8]) {
+    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    out[0] = rp[3]; out[1] = rp[4]; out[2] = rp[5];
+    if (a.z) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane * epl + k, ic = i < a.S ? i : a.S - 1;
+            if (k < epl) out[3 + k] = a.z[(size_t)ray * a.S + ic];
+        }
+    }
+}
+
+// `raw_at(i)` returns the f32x4 (r, g, b, sigma logits) of sample i of this ray (i < S).  On return z[k] / w[k] hold the
+// depth / visibility weight of sample lane*EPL + k (z[EPL]: the next lane's first depth), which sample_pdf goes on to use.
+// `pre` (optional): values the caller fetched ahead of time -- pre[0..2] = the ray's direction, pre[3 + k] = the depth of
+// sample lane*EPL + k when a.z is given (composite_prefetch below) -- so that a fused epilogue does not wait for HBM.
+template <int EPL, class RAWF>
+__device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int ray, const bool ray_ok, const int lane,
+                                              RAWF&& raw_at, float (&z)[EPL + 1], float (&w)[EPL], const float* pre = nullptr) {
+    const int S = a.S;
+    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    const float dx = pre ? pre[0] : rp[3], dy = pre ? pre[1] : rp[4], dz = pre ? pre[2] : rp[5];
+    float near = 0.0f, far = 0.0f;
+    if (!a.z) { near = rp[6]; far = rp[7]; }
+    // (every sum below is written with explicit rounding: left to -ffp-contract the compiler fuses a multiply into an add only
+    //  when both sit in one basic block, which differs between the instantiations of this function -- measured: an ulp on 1 % of
+    //  the rays between the fused epilogue with prefetched inputs and the composite kernel)
+    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));   // train.py:748
+
+    // ---- load this lane's samples
+    float sig[EPL], col[EPL][3];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        const int ic = i < S ? i : S - 1;
+        if (a.z) z[k] = pre ? pre[3 + k] : a.z[(size_t)ray * S + ic];
+        else {
+            const float t = c_lin01(ic, S);
+            if (a.lindisp)                                                               // train.py:850-852
+                z[k] = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)),
+                                                 __fmul_rn(__fdiv_rn(1.0f, far), t)));
+            else
+                z[k] = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));   // train.py:849
+        }
+        const f32x4 r = raw_at(ic);
+        col[k][0] = r[0]; col[k][1] = r[1]; col[k][2] = r[2]; sig[k] = r[3];
+        if (a.noise) sig[k] = __fadd_rn(sig[k], a.noise[(size_t)ray * S + ic]);                // train.py:761
+    }
+    z[EPL] = __shfl_down(z[0], 1);     // first depth of the next lane
+
+    // ---- alpha, transmittance, weights (train.py:740-775)
+    float alpha[EPL];
+    float run = 1.0f;                  // product of (1 - alpha + 1e-10) over this lane's samples so far
+    float texcl[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        float dist = (i == S - 1) ? 1e10f : __fsub_rn(z[k + 1], z[k]);      // :743-746
+        dist = __fmul_rn(dist, dnorm);                                      // :748
+        const float s = fmaxf(sig[k], 0.0f);
+        alpha[k] = (i < S) ? __fsub_rn(1.0f, expf(-__fmul_rn(s, dist))) : 0.0f;   // :741
+        texcl[k] = run;
+        run = __fmul_rn(run, (i < S) ? __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f) : 1.0f);
+    }
+    const float incl = wave_scan_mul(run, lane);
+    float before = __shfl_up(incl, 1);
+    if (lane == 0) before = 1.0f;
+    float sr = 0.f, sg = 0.f, sb = 0.f, sdepth = 0.f, sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        w[k] = (i < S) ? __fmul_rn(alpha[k], __fmul_rn(before, texcl[k])) : 0.0f;
+        const float r = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-col[k][0])));    // sigmoid, :750
+        const float g = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-col[k][1])));
+        const float b = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-col[k][2])));
+        sr = __fmaf_rn(w[k], r, sr); sg = __fmaf_rn(w[k], g, sg); sb = __fmaf_rn(w[k], b, sb);
+        sdepth = __fmaf_rn(w[k], z[k], sdepth); sacc = __fadd_rn(sacc, w[k]);
+        if (ray_ok && i < S) {
+            if (a.vis) a.vis[(size_t)ray * S + i] = w[k];
+            if (a.alpha) a.alpha[(size_t)ray * S + i] = alpha[k];
+            if (a.z_user) a.z_user[(size_t)ray * S + i] = z[k];
+        }
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sdepth = wave_sum(sdepth); sacc = wave_sum(sacc);
+    if (ray_ok && lane == 0) {
+        if (a.white_bkgd) {                                                                                   // :786-787
+            const float bg = __fsub_rn(1.0f, sacc);
+            sr = __fadd_rn(sr, bg); sg = __fadd_rn(sg, bg); sb = __fadd_rn(sb, bg);
+        }
+        a.rgb[(size_t)ray * 3 + 0] = sr; a.rgb[(size_t)ray * 3 + 1] = sg; a.rgb[(size_t)ray * 3 + 2] = sb;   // :776
+        a.acc[ray] = sacc;                                                                                    // :779
+        const float q = __fdiv_rn(sdepth, sacc);                                  // 0/0 = NaN when acc == 0 ...
+        a.disp[ray] = __fdiv_rn(1.0f, (q != q) ? q : fmaxf(1e-10f, q));           // ... which torch.max propagates (:781-784)
+    }
+
+    // ---- surface reduction: index of the sample whose accumulated visibility is closest to 0.5 (first one on ties),
+    //      and the bent point / rigidity there (free_viewpoint_rendering.py:621-648 does this on the host from the
+    //      full per-sample tensors: ~15 KB/ray of D2H traffic instead of 20 B/ray)
+    if (a.bent4) {
+        // cumsum in strictly sequential order (carry handed from lane to lane): zero-weight plateaus then give
+        // bit-identical prefixes, hence exact ties that resolve to the first index, as with torch.cumsum on the host
+        float carry = 0.f, base = 0.f;
+        for (int l = 0; l < 64; ++l) {
+            float e = carry;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) e = __fadd_rn(e, w[k]);
+            if (lane == l) base = carry;
+            carry = __shfl(e, l);
+        }
+        // NaN weights (a diverged checkpoint, an overflowed f16 sigma) compare false everywhere: start from this lane's
+        // first valid sample so the index is always in range, like the host argmin the reference uses (fvr:626-628)
+        float best = 3.0e38f, run_c = base;
+        int bidx = (lane * EPL < S) ? lane * EPL : S - 1;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int i = lane * EPL + k;
+            run_c = __fadd_rn(run_c, w[k]);
+            const float dist = fabsf(__fsub_rn(run_c, 0.5f));
+            if (i < S && dist < best) { best = dist; bidx = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        }
+        if (ray_ok && lane == 0) {
+            bidx = bidx < 0 ? 0 : (bidx > S - 1 ? S - 1 : bidx);
+            const f32x4 b = *(const f32x4*)(a.bent4 + ((size_t)ray * S + bidx) * 4);
+            if (a.surf_pts) { a.surf_pts[(size_t)ray * 3] = b[0]; a.surf_pts[(size_t)ray * 3 + 1] = b[1]; a.surf_pts[(size_t)ray * 3 + 2] = b[2]; }
+            if (a.surf_rig) a.surf_rig[ray] = b[3];
+            if (a.med_idx) a.med_idx[ray] = bidx;
+        }
+    }
+
+}
+
+}  // namespace nrn

@@ -1,0 +1,301 @@
+// nrnerf_generic.h -- the network kernels for ANY architecture the reference can build.
+//
+// The reference instantiates NeRF(D = --netdepth, W = --netwidth) / (--netdepth_fine, --netwidth_fine) with
+// --multires / --multires_views frequencies and a ray bender fed by --ray_bending_latent_size codes (train.py:1004-1010,
+// 1060, 1133-1139, 564-630).  The kernels of nrnerf_net_impl.h / nrnerf_net_mb.h are compiled per architecture: their
+// activations never leave registers and their weight stream has compile-time addresses, which is what makes them fast and
+// what ties them to a handful of shapes.  This file is the other end of the trade: ONE kernel per precision whose layer
+// list, widths and encodings are run-time data, so every shape outside the compiled set still renders natively (slower
+// -- activations take a round trip through LDS per layer and the weights come from L2 without a ring -- but on the matrix
+// pipe, with the same arithmetic types, behind the same C ABI).
+//
+// Dataflow.  A workgroup (4 waves) owns a tile of NS = 32 * NSB consecutive samples of the flattened [ray, sample] index.
+// Three activation buffers live in LDS, one row per sample:
+//     E  the network input vector (positional encoding of the point [, latent code]; bender: [point, latent code])
+//     V  the second input (direction encoding; bender: the bare point, input of the rigidity network)
+//     H  the hidden activations (in place: a layer's outputs replace its inputs between two barriers)
+// A layer is computed transposed like everywhere in this library, D^T = W . X^T: the weights are the MFMA A operand -- packed
+// on the host in fragment order (tile, k-slab), one coalesced 16-byte (16-bit) / 4-byte (fp32) load per lane and fragment,
+// straight from L2 -- and the activations the B operand, read from LDS (lane = sample, 8 / 1 consecutive k per lane).  A wave
+// owns output tiles wave, wave + 4, ... for all NSB sample blocks (each weight fragment feeds NSB MFMAs); its accumulators
+// hold the complete layer output, so one buffer suffices.  A layer reads up to two sources (the skip layer: [E | H], the
+// view-dependent layer: [H | V]), in the reference's column order: the packer needs no permutation.
+// Heads (<= 8 output rows) land in a small fp32 buffer O; the epilogue turns it into raw logits or the bent point.
+//
+// Precision: "f32" exact fp32 (v_mfma_f32_32x32x2_f32); "bf16" / "f16": H in that type, E and V always f16 (bounded by
+// construction, like nrnerf_plan.h::frag_is_f16); the ray bender ALWAYS runs the fp32 instantiation (its offsets feed a
+// 2^(L-1)-frequency encoding; 3 % of the flops).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "nrnerf_kernels.h"
+#include "nrnerf_net_impl.h"      // precision policies, lin01, static_for
+
+namespace nrn {
+
+template <class P>
+struct GenTypes {
+    using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;      // element type of E and V
+    using elem = std::conditional_t<P::KH == 1, float, unsigned short>;
+    static constexpr int PAD = (P::KH == 1) ? 1 : 8;               // row padding in elements: conflict-free B-operand reads
+};
+
+__device__ __forceinline__ unsigned short gen_to_f16(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+__device__ __forceinline__ unsigned short gen_to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+template <class P> __device__ __forceinline__ typename GenTypes<P>::elem gen_cvt(float v) {
+    if constexpr (P::KH == 1) return v;
+    else if constexpr (std::is_same_v<P, PolBF16>) return gen_to_bf16(v);
+    else return gen_to_f16(v);
+}
+
+// B operand of slab s (KS columns from column s * KS) of `buf` for sample row `n`: 8 consecutive k (16-bit) / 1 k (fp32)
+template <class PX>
+__device__ __forceinline__ typename PX::frag gen_bfrag(const void* buf, int stride, int n, int s, int h) {
+    if constexpr (PX::KH == 1) {
+        return ((const float*)buf)[(size_t)n * stride + 2 * s + h];
+    } else {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ v = *(const u32x4_*)((const unsigned short*)buf + (size_t)n * stride + 16 * s + 8 * h);
+        return __builtin_bit_cast(typename PX::frag, v);
+    }
+}
+
+template <class P, int NSB>
+__global__ void __launch_bounds__(GEN_WAVES * 64, NSB == 1 ? 2 : 1) gen_kernel(const GenArgs a) {
+    using PE = typename GenTypes<P>::PE;
+    using elem = typename GenTypes<P>::elem;
+    constexpr int PAD = GenTypes<P>::PAD;
+    constexpr int NS = 32 * NSB, KS = P::KS, KH = P::KH, FB = P::FRAG_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int se = a.ke + PAD, sv = a.kv + PAD, sh = a.kh + PAD;            // row strides in elements
+    elem* E = (elem*)gsm;
+    elem* V = E + (size_t)NS * se;
+    elem* H = V + (size_t)NS * sv;
+    float* O = (float*)(H + (size_t)NS * sh);                               // [NS][8]
+    float* Pt = O + NS * 8;                                                 // [NS][8]: point xyz, (bender) unit direction / spare
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    const int S = a.S;
+    const long long M = (long long)a.n_rays * S;
+    const long long ntile = (M + NS - 1) / NS;
+
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long long m0 = tile * NS;
+        // ---- points (and view directions) of the tile's samples
+        if (tid < NS) {
+            const long long m = (m0 + tid < M) ? m0 + tid : M - 1;
+            const int ray = (int)(m / S), si = (int)(m % S);
+            const float* rp = a.rays + (size_t)ray * a.ray_stride;
+            float p[3];
+            if (a.mode == 1 && a.pts4) {
+                const f32x4 q = *(const f32x4*)(a.pts4 + (size_t)m * 4);
+                p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+            } else {
+                float z;
+                if (a.z) z = a.z[(size_t)ray * S + si];
+                else {
+                    const float near = rp[6], far = rp[7], t = lin01(si, S);
+                    if (a.lindisp) z = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, far), t)));
+                    else z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));            // train.py:849-852
+                }
+                for (int c = 0; c < 3; ++c) p[c] = __fadd_rn(rp[c], __fmul_rn(rp[3 + c], z));               // train.py:871-873
+            }
+            float d[3] = {0.f, 0.f, 0.f};
+            if (a.mode == 1 && a.LV >= 0) {
+                if (a.dirs_from_pts) {           // rnh:339-351: backward difference of the bent points, sample 0 copies sample 1
+                    const bool first = (si == 0);
+                    const f32x4 nb = *(const f32x4*)(a.pts4 + (size_t)(first ? m + 1 : m - 1) * 4);
+                    float dd[3];
+                    for (int c = 0; c < 3; ++c) dd[c] = first ? __fsub_rn(nb[c], p[c]) : __fsub_rn(p[c], nb[c]);
+                    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dd[0], dd[0]), __fmul_rn(dd[1], dd[1])), __fmul_rn(dd[2], dd[2])));
+                    for (int c = 0; c < 3; ++c) d[c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f));
+                } else {
+                    d[0] = rp[8]; d[1] = rp[9]; d[2] = rp[10];                                               // train.py:73-76
+                }
+            }
+            float* pt = Pt + tid * 8;
+            pt[0] = p[0]; pt[1] = p[1]; pt[2] = p[2]; pt[3] = 0.f; pt[4] = d[0]; pt[5] = d[1]; pt[6] = d[2]; pt[7] = 0.f;
+            if (a.mode == 0 && m0 + tid < M && a.ex.init_pts) {
+                a.ex.init_pts[(size_t)m * 3] = p[0]; a.ex.init_pts[(size_t)m * 3 + 1] = p[1]; a.ex.init_pts[(size_t)m * 3 + 2] = p[2];
+            }
+        }
+        __syncthreads();
+        // ---- E and V rows.  network: E = Embedder(point) [, latent], V = Embedder(direction) (rnh:120-150: [x, sin(2^0 x),
+        //      cos(2^0 x), sin(2^1 x), ...]); bender: E = [point, latent] (rnh:525), V = [point] (rnh:546)
+        const int enc_w = (a.mode == 1) ? 3 + 6 * a.L : 3;
+        for (int idx = tid; idx < NS * a.ke; idx += GEN_WAVES * 64) {
+            const int n = idx / a.ke, c = idx - n * a.ke;
+            const float* pt = Pt + n * 8;
+            float v = 0.f;
+            if (c < 3) v = pt[c];
+            else if (c < enc_w) {
+                const int q = c - 3, f = q / 6, r = q - 6 * f;
+                const float x = pt[r % 3] * (float)(1 << f);                       // power-of-two scaling: exact
+                v = (r < 3) ? sinf(x) : cosf(x);
+            } else if (c < enc_w + a.lat) {
+                const long long m = (m0 + n < M) ? m0 + n : M - 1;
+                v = a.latents[(size_t)(m / S) * a.lat_stride + (c - enc_w)];
+            }
+            E[(size_t)n * se + c] = gen_cvt<PE>(v);
+        }
+        for (int idx = tid; idx < NS * a.kv; idx += GEN_WAVES * 64) {
+            const int n = idx / a.kv, c = idx - n * a.kv;
+            const float* pt = Pt + n * 8 + (a.mode == 1 ? 4 : 0);
+            float v = 0.f;
+            if (c < 3) v = pt[c];
+            else if (a.mode == 1 && c < 3 + 6 * a.LV) {
+                const int q = c - 3, f = q / 6, r = q - 6 * f;
+                const float x = pt[r % 3] * (float)(1 << f);
+                v = (r < 3) ? sinf(x) : cosf(x);
+            }
+            V[(size_t)n * sv + c] = gen_cvt<PE>(v);
+        }
+        __syncthreads();
+
+        // ---- layers
+        for (int li = 0; li < a.n_layers; ++li) {
+            const GenLayer& ly = a.layer[li];
+            const int ns = ly.ns0 + ly.ns1;
+            f32x16 acc[GEN_MAXT][NSB];
+            int ntw = 0;                                   // this wave's tiles: wave, wave + 4, ...
+#pragma unroll
+            for (int i = 0; i < GEN_MAXT; ++i) {
+                const int t = wave + i * GEN_WAVES;
+                if (t < ly.nt) {
+                    ntw = i + 1;
+                    const f32x4* bp = (const f32x4*)(a.bias + ((size_t)(ly.bias_tile + t) * 32 + h * 16));
+                    const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+                    const f32x16 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
+#pragma unroll
+                    for (int sb = 0; sb < NSB; ++sb) acc[i][sb] = bv;
+                }
+            }
+            const char* wbase = (const char*)a.wstream + (size_t)ly.w_frag * FB + (size_t)lane * (FB / 64);
+            auto src_ptr = [&](int b) -> const void* { return b == GB_E ? (const void*)E : (b == GB_V ? (const void*)V : (const void*)H); };
+            auto src_stride = [&](int b) { return b == GB_E ? se : (b == GB_V ? sv : sh); };
+            auto run = [&](auto pxc, const void* buf, int stride, int s_begin, int s_count) {
+                using PX = typename decltype(pxc)::type;
+                // weight fragments of slab s + 1 are requested (from L2) before the MFMAs of slab s: with one or two workgroups
+                // per CU nothing else hides that latency
+                typename PX::frag af[GEN_MAXT], an[GEN_MAXT];
+                auto fetch = [&](typename PX::frag (&dst)[GEN_MAXT], int s) {
+#pragma unroll
+                    for (int i = 0; i < GEN_MAXT; ++i)
+                        if (i < ntw) dst[i] = *(const typename PX::frag*)(wbase + ((size_t)(wave + i * GEN_WAVES) * ns + s_begin + s) * FB);
+                };
+                if (s_count > 0) fetch(af, 0);
+                for (int s = 0; s < s_count; ++s) {
+                    if (s + 1 < s_count) fetch(an, s + 1);
+                    typename PX::frag bf[NSB];
+#pragma unroll
+                    for (int sb = 0; sb < NSB; ++sb) bf[sb] = gen_bfrag<PX>(buf, stride, sb * 32 + j, s, h);
+#pragma unroll
+                    for (int i = 0; i < GEN_MAXT; ++i) {
+                        if (i < ntw) {
+#pragma unroll
+                            for (int sb = 0; sb < NSB; ++sb) acc[i][sb] = PX::mfma(af[i], bf[sb], acc[i][sb]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < GEN_MAXT; ++i) af[i] = an[i];
+                }
+            };
+            struct TagE { using type = PE; };
+            struct TagH { using type = P; };
+            if (ly.src0 == GB_H) run(TagH{}, src_ptr(GB_H), sh, 0, ly.ns0); else run(TagE{}, src_ptr(ly.src0), src_stride(ly.src0), 0, ly.ns0);
+            if (ly.ns1 > 0) {
+                if (ly.src1 == GB_H) run(TagH{}, src_ptr(GB_H), sh, ly.ns0, ly.ns1); else run(TagE{}, src_ptr(ly.src1), src_stride(ly.src1), ly.ns0, ly.ns1);
+            }
+            __syncthreads();                               // every wave has read the layer's inputs: H may be overwritten
+#pragma unroll
+            for (int i = 0; i < GEN_MAXT; ++i) {
+                if (i < ntw) {
+                    const int t = wave + i * GEN_WAVES;
+#pragma unroll
+                    for (int sb = 0; sb < NSB; ++sb) {
+                        const int n = sb * 32 + j;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;      // CDNA4 C/D layout (nrnerf_plan.h::tile_row)
+                            float v = acc[i][sb][r];
+                            if (ly.relu) v = fmaxf(v, 0.0f);
+                            if (ly.dst == GB_H) H[(size_t)n * sh + row] = gen_cvt<P>(v);
+                            else if (row < ly.o_rows) O[n * 8 + ly.o_col + row] = v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue
+        if (tid < NS && m0 + tid < M) {
+            const long long m = m0 + tid;
+            const float* o = O + tid * 8;
+            if (a.mode == 1) {
+                float sigma = o[3];
+                if (a.knobs.detailed && a.knobs.has_removal && a.pts4 && a.bent4 && a.bent4[(size_t)m * 4 + 3] >= a.knobs.removal) sigma = sigma * 0.0f;   // rnh:308-311
+                if (!a.pts4) {       // a model without ray bender: the points of this pass are its own (detail outputs, surface reduction)
+                    const float* pt = Pt + tid * 8;
+                    if (a.bent4) *(f32x4*)(a.bent4 + (size_t)m * 4) = f32x4{pt[0], pt[1], pt[2], 0.0f};
+                    for (int c = 0; c < 3; ++c) {
+                        if (a.ex.init_pts) a.ex.init_pts[(size_t)m * 3 + c] = pt[c];
+                        if (a.ex.in_pts) a.ex.in_pts[(size_t)m * 3 + c] = pt[c];
+                    }
+                }
+                if (a.raw4) *(f32x4*)(a.raw4 + (size_t)m * 4) = f32x4{o[0], o[1], o[2], sigma};
+                if (a.raw_out) {
+                    float* ro = a.raw_out + (size_t)m * a.raw_ch;
+                    ro[0] = o[0]; ro[1] = o[1]; ro[2] = o[2]; ro[3] = sigma;
+                    if (a.raw_ch > 4) ro[4] = o[4];
+                }
+            } else {
+                const float* pt = Pt + tid * 8;
+                float mask = (tanhf(o[3]) + 1.0f) / 2.0f;                                      // rnh:559-561
+                if (a.knobs.has_cutoff && mask <= a.knobs.cutoff) mask = 0.0f;                 // rnh:563-564
+                float mo[3], bent[3];
+                for (int c = 0; c < 3; ++c) {
+                    mo[c] = __fmul_rn(mask, o[c]);                                             // rnh:567
+                    if (a.knobs.has_scaling) mo[c] = __fmul_rn(mo[c], a.knobs.scaling);        // rnh:568-569
+                    bent[c] = __fadd_rn(pt[c], mo[c]);                                         // rnh:570
+                }
+                *(f32x4*)(a.bent4 + (size_t)m * 4) = f32x4{bent[0], bent[1], bent[2], mask};
+                for (int c = 0; c < 3; ++c) {
+                    if (a.ex.unmasked) a.ex.unmasked[(size_t)m * 3 + c] = o[c];
+                    if (a.ex.masked) a.ex.masked[(size_t)m * 3 + c] = mo[c];
+                    if (a.ex.in_pts) a.ex.in_pts[(size_t)m * 3 + c] = bent[c];
+                }
+                if (a.ex.rigidity) a.ex.rigidity[m] = mask;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <class P, int NSB>
+static hipError_t launch_gen(const GenArgs& a, int num_cus, hipStream_t stream) {
+    constexpr int PAD = GenTypes<P>::PAD, NS = 32 * NSB;
+    const size_t es = sizeof(typename GenTypes<P>::elem);
+    if (a.ke % 16 || a.kv % 16 || a.kh % 16 || a.ke > GEN_MAX_E || a.kv > GEN_MAX_V || a.kh > GEN_MAX_W || a.n_layers < 1 ||
+        a.n_layers > GEN_MAX_LAYERS) return hipErrorInvalidValue;
+    const size_t lds = (size_t)NS * ((a.ke + PAD) + (a.kv + PAD) + (a.kh + PAD)) * es + (size_t)NS * 16 * sizeof(float);
+    auto kern = gen_kernel<P, NSB>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        const size_t lds_max = (size_t)NS * ((GEN_MAX_E + PAD) + (GEN_MAX_V + PAD) + (GEN_MAX_W + PAD)) * es + (size_t)NS * 16 * sizeof(float);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const long long M = (long long)a.n_rays * a.S;
+    const long long ntile = (M + NS - 1) / NS;
+    if (ntile <= 0) return hipSuccess;
+    // two workgroups per CU when LDS allows (fp32 instantiation; the 16-bit one holds 2 x 4 output tiles per wave: 512 registers)
+    const long long resident = (long long)num_cus * ((NSB == 1 && 2 * lds + 4096 <= 160 * 1024) ? 2 : 1);
+    const int grid = (int)(ntile < resident ? ntile : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEN_WAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace nrn

@@ -1,0 +1,12 @@
+// nrnerf_generic.hip -- instantiations of the run-time-parameterised network kernel (nrnerf_generic.h): one per precision.
+#include "nrnerf_generic.h"
+
+namespace nrn {
+// precision ids as nrnerf_precision; the ray bender (mode 0) always takes the fp32 instantiation
+hipError_t launch_generic(int precision, const GenArgs& a, int num_cus, hipStream_t stream) {
+    if (a.mode == 0 || precision == PREC_F32) return launch_gen<PolF32, 1>(a, num_cus, stream);
+    if (precision == PREC_BF16) return launch_gen<PolBF16, 2>(a, num_cus, stream);
+    if (precision == PREC_F16) return launch_gen<PolF16, 2>(a, num_cus, stream);
+    return hipErrorInvalidValue;
+}
+}  // namespace nrn

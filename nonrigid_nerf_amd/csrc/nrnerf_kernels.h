@@ -23,25 +23,6 @@ struct Knobs {
     int detailed;
 };
 
-// One pass (coarse or fine) of the per-sample network over n_rays * S samples.
-struct NetArgs {
-    const float* rays;   int ray_stride;
-    const float* latents; int lat_stride;
-    const float* z;          // [N,S] sample depths, or nullptr: coarse linspace between near and far
-    int lindisp;             // coarse spacing linear in inverse depth (train.py:850-852); only read when z == nullptr
-    const float* pts4;       // [N,S,4] ready-made network input points (xyz, w unused) instead of o + d z -- the bent points
-                             // of the stand-alone bender kernel; only read by the variants without a fused bender; or nullptr
-    int n_rays, S;
-    const void* wstream;     // packed fragment stream of this pass (whole 16 KiB units, nrnerf_plan.h)
-    const float* bias;       // [NTILES*32]
-    float* raw4;             // [N,S,4] rgb + sigma workspace consumed by the composite kernel
-    float* raw_out;          // [N,S,raw_ch] user-visible raw ("retraw") or nullptr
-    int raw_ch;
-    float* bent4;            // [N,S,4] bent point xyz + rigidity mask per sample (surface reduction) or nullptr
-    SampleOut ex;
-    Knobs knobs;
-};
-
 struct CompositeArgs {
     const float* rays;   int ray_stride;
     const float* raw4;       // [N,S,4]
@@ -70,6 +51,31 @@ struct CompositeArgs {
     float* z_new;                // [N,I]     depths of the importance samples, in sample order
     uint8_t* rank_new;           // [N,I]     position of each importance sample among the merged depths (S + I <= 256)
 };
+
+// One pass (coarse or fine) of the per-sample network over n_rays * S samples.
+struct NetArgs {
+    const float* rays;   int ray_stride;
+    const float* latents; int lat_stride;
+    const float* z;          // [N,S] sample depths, or nullptr: coarse linspace between near and far
+    int lindisp;             // coarse spacing linear in inverse depth (train.py:850-852); only read when z == nullptr
+    const float* pts4;       // [N,S,4] ready-made network input points (xyz, w unused) instead of o + d z -- the bent points
+                             // of the stand-alone bender kernel; only read by the variants without a fused bender; or nullptr
+    int n_rays, S;
+    const void* wstream;     // packed fragment stream of this pass (whole 16 KiB units, nrnerf_plan.h)
+    const float* bias;       // [NTILES*32]
+    float* raw4;             // [N,S,4] rgb + sigma workspace consumed by the composite kernel
+    float* raw_out;          // [N,S,raw_ch] user-visible raw ("retraw") or nullptr
+    int raw_ch;
+    float* bent4;            // [N,S,4] bent point xyz + rigidity mask per sample (surface reduction) or nullptr
+    SampleOut ex;
+    Knobs knobs;
+    // Fused compositing of this pass (kernel variants WITHOUT a fused bender; S <= 256): fuse_on != 0 -> every wave owns whole
+    // rays, keeps their raw outputs in LDS and composites them itself with `fuse` (nrnerf_composite_ray.h; fuse.raw4 unused,
+    // fuse.n_importance must be 0: no sampling follows a fused pass); raw4 is then neither written nor needed (may be nullptr).
+    int fuse_on;
+    CompositeArgs fuse;
+};
+
 
 // Stand-alone bender (ray_bending.forward, run_nerf_helpers.py:507-577) over n_per_ray samples of every ray.
 struct BendArgs {
@@ -279,6 +285,50 @@ struct RayGenArgs {
     int ray_stride;           // 8, or 11 to append the unit view direction
 };
 hipError_t launch_raygen(const RayGenArgs& a, hipStream_t stream);
+
+// ---- run-time-parameterised network kernel (nrnerf_generic.h): any architecture outside the compiled set
+constexpr int GEN_MAX_LAYERS = 28;
+constexpr int GEN_WAVES = 4;
+constexpr int GEN_MAXT = 4;           // output tiles per wave and layer: widths up to 4 * 4 * 32 = 512
+constexpr int GEN_MAX_W = 512;
+constexpr int GEN_MAX_E = 176;        // padded width of E: 3 + 6 * 16 = 99 encoding columns + 64 latent columns, multiple of 16
+constexpr int GEN_MAX_V = 64;         // padded width of V: 3 + 6 * 10 = 63
+enum GenBuf : int { GB_E = 0, GB_H = 1, GB_V = 2, GB_O = 3 };
+
+struct GenLayer {
+    int w_frag;          // index of fragment (tile 0, slab 0) in the weight stream; fragment (t, s) = w_frag + t * (ns0 + ns1) + s
+    int bias_tile;       // index of tile 0 in the bias table ([tile][lane half][16] floats, as nrnerf_plan.h)
+    int nt;              // output tiles of 32 rows
+    int src0, ns0;       // first source buffer (GenBuf) and its k-slabs (of KS columns: 16 / 2)
+    int src1, ns1;       // second source (ns1 = 0: none)
+    int dst;             // GB_H, or GB_O for a head
+    int relu;
+    int o_col;           // dst == GB_O: output row r of the layer goes to O[sample][o_col + r]  (rows < o_rows)
+    int o_rows;
+};
+
+struct GenArgs {
+    int mode;                    // 0: ray bender (bent4 and detail outputs), 1: canonical network (raw4 / raw_out)
+    const float* rays; int ray_stride;
+    const float* latents; int lat_stride, lat;      // lat: latent columns appended to E (bender: always; network: time-conditioned baseline)
+    const float* z;              // [N,S] sample depths or nullptr: coarse spacing between near and far
+    int lindisp;
+    const float* pts4;           // network: [N,S,4] input points (the bender's output) or nullptr: o + d z
+    int n_rays, S;
+    int L, LV;                   // encoding frequencies of the point / of the view direction (LV < 0: no view-dependent head)
+    int dirs_from_pts;           // view directions: 1 = finite differences of pts4 along the ray (rnh:316-356), 0 = the rays' unit directions
+    const void* wstream; const float* bias;
+    int n_layers;
+    GenLayer layer[GEN_MAX_LAYERS];
+    int ke, kv, kh;              // padded row widths of E, V and H in elements (multiples of 16; kh = the widest hidden layer)
+    // outputs
+    float* raw4; float* raw_out; int raw_ch;        // network
+    float* bent4;                // bender: [N,S,4] bent point + rigidity mask (network: read for the removal knob when detailed)
+    SampleOut ex;
+    Knobs knobs;
+};
+
+hipError_t launch_generic(int precision, const GenArgs& a, int num_cus, hipStream_t stream);
 
 // precision ids match nrnerf_precision
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };

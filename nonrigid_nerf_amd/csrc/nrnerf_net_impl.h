@@ -23,6 +23,7 @@
 
 #include "nrnerf_kernels.h"
 #include "nrnerf_plan.h"
+#include "nrnerf_composite_ray.h"
 
 #ifndef NRN_PF16
 #define NRN_PF16 4
@@ -590,17 +591,54 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         tile_stride = (long long)gridDim.x * WAVES;
     }
 
+    // Fused compositing (variants without a fused bender, NetArgs::fuse_on): a WAVE owns whole rays -- ray grp * WAVES + wave
+    // of group grp, one block per tile, bpr tiles per group, groups strided over the grid; the raw outputs are staged in the
+    // wave's own LDS area and composited by the wave itself after the ray's last block (composite_ray).  See nrnerf_net_mb.h.
+    bool fuse = false;
+    int tg = 0;
+    long long ngroups = 0, grp = blockIdx.x;
+    f32x4* stage_w = nullptr;
+    if constexpr (!HAS_BEND) {
+        fuse = a.fuse_on != 0;
+        ngroups = ((long long)a.n_rays + WAVES - 1) / WAVES;
+        stage_w = (f32x4*)(mailbox + 2 * WAVES * 4) + (size_t)wave * bpr * 32;
+        if (fuse) {          // the compositing arguments live in LDS, not in SGPRs held across the whole tile (nrnerf_net_mb.h)
+            int* dst = (int*)((f32x4*)(mailbox + 2 * WAVES * 4) + (size_t)WAVES * bpr * 32);
+            const int* src = (const int*)&a.fuse;
+            for (int i = tid; i < (int)(sizeof(CompositeArgs) / 4); i += WAVES * 64) dst[i] = src[i];
+            __syncthreads();
+        }
+    }
+
 #ifdef NRN_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     int iter = 0;
-    for (long long tile0 = blk_begin; tile0 < blk_end; tile0 += tile_stride, ++iter) {
+    float cpre[8];              // fused compositing: direction and depths of this wave's ray, requested one tile ahead of their use
+    for (long long tile0 = blk_begin; fuse ? (grp < ngroups) : (tile0 < blk_end); ++iter) {
         const unsigned long long t_pass = NRN_NOW();
-        const long long blk = tile0 + wave;
-        const bool blk_ok = blk < blk_end;
-        const long long b = blk_ok ? blk : blk_end - 1;
-        const int ray = (int)(b / bpr);
-        const int sidx = (int)(b % bpr) * 32 + j;
+        if constexpr (!HAS_BEND) {
+            if (fuse && tg == bpr - 1) {
+                const CompositeArgs& fa = *(const CompositeArgs*)((f32x4*)(mailbox + 2 * WAVES * 4) + (size_t)WAVES * bpr * 32);
+                const long long rr = grp * WAVES + wave;
+                composite_prefetch(fa, (int)(rr < a.n_rays ? rr : a.n_rays - 1), lane, (S + 63) >> 6, cpre);
+            }
+        }
+        bool blk_ok;
+        int ray, bir;               // bir: block within its ray
+        if (fuse) {
+            const long long rr = grp * WAVES + wave;
+            blk_ok = rr < a.n_rays;
+            ray = (int)(blk_ok ? rr : a.n_rays - 1);
+            bir = tg;
+        } else {
+            const long long blk = tile0 + wave;
+            blk_ok = blk < blk_end;
+            const long long b = blk_ok ? blk : blk_end - 1;
+            ray = (int)(b / bpr);
+            bir = (int)(b % bpr);
+        }
+        const int sidx = bir * 32 + j;
         const bool ok = blk_ok && sidx < S;
         const int sc = sidx < S ? sidx : S - 1;
 
@@ -993,15 +1031,41 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
         if (HAS_BEND && a.knobs.detailed && a.knobs.has_removal && rig_mask >= a.knobs.removal)
             raw[3] = raw[3] * 0.0f;                                                  // rnh:308-311
         if (writer) {
-            *(f32x4*)(a.raw4 + so * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+            if (!fuse) *(f32x4*)(a.raw4 + so * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
             if (a.raw_out) {
                 float* ro = a.raw_out + so * a.raw_ch;
                 ro[0] = raw[0]; ro[1] = raw[1]; ro[2] = raw[2]; ro[3] = raw[3];
                 if (a.raw_ch > 4) ro[4] = raw[4];
             }
         }
+        if constexpr (!HAS_BEND) {
+            if (fuse && h == 0) stage_w[tg * 32 + j] = f32x4{raw[0], raw[1], raw[2], raw[3]};
+        }
         // padding units (keep the ring phase identical every pass and prime the next pass' first units)
         static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+        if constexpr (!HAS_BEND) {
+            if (fuse) {
+                if (++tg == bpr) {       // the ray's last block: composite it from this wave's LDS stage (train.py:943-950)
+                    // the surface reduction reads bent4 rows this wave's OTHER lanes have just written (only when this kernel
+                    // writes that array itself: a model without bender): make the stores visible first
+                    const CompositeArgs& fa = *(const CompositeArgs*)((f32x4*)(mailbox + 2 * WAVES * 4) + (size_t)WAVES * bpr * 32);
+                    if (a.bent4 && fa.bent4) __threadfence();
+                    auto raw_at = [&](int ic) { return stage_w[ic]; };
+                    switch ((S + 63) >> 6) {
+                        case 1: { float cz[2], cw[1]; composite_ray<1>(fa, ray, blk_ok, lane, raw_at, cz, cw, cpre); break; }
+                        case 2: { float cz[3], cw[2]; composite_ray<2>(fa, ray, blk_ok, lane, raw_at, cz, cw, cpre); break; }
+                        case 3: { float cz[4], cw[3]; composite_ray<3>(fa, ray, blk_ok, lane, raw_at, cz, cw, cpre); break; }
+                        default: { float cz[5], cw[4]; composite_ray<4>(fa, ray, blk_ok, lane, raw_at, cz, cw, cpre); break; }
+                    }
+                    tg = 0;
+                    grp += gridDim.x;
+                }
+            } else {
+                tile0 += tile_stride;
+            }
+        } else {
+            tile0 += tile_stride;
+        }
         NRN_TACC(5, t_out);
         NRN_TACC(0, t_pass);
 #ifdef NRN_TIMING
@@ -1023,14 +1087,21 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) net_kernel(c
 template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES, bool EXACT = false>
 static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) {
     using PL = Plan<P, A, HAS_BEND, VIEWS>;
-    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * 4 * sizeof(float);
+    const int bpr_l = (a.S + 31) / 32;
+    size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * 4 * sizeof(float);
+    if (a.fuse_on) {     // fused compositing: the waves' raw stages (one ray each)
+        if (HAS_BEND || a.S > 256 || a.fuse.n_importance != 0 || a.fuse.S != a.S) return hipErrorInvalidValue;
+        lds += (size_t)WAVES * bpr_l * 32 * 16 + 256;
+    }
     auto kern = net_kernel<P, A, HAS_BEND, VIEWS, WAVES, EXACT>;
     // function attributes are per device: one flag per ordinal (idempotent; racing threads set the same value)
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * 4 * sizeof(float) +
+                               (HAS_BEND ? 0 : (size_t)WAVES * 8 * 32 * 16 + 256);      // + the fused stages at 256 samples per ray, the compositing arguments
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
@@ -1042,7 +1113,9 @@ static hipError_t launch_one(const NetArgs& a, int num_cus, hipStream_t stream) 
     // its own LDS ring); the fp32 build one 4-wave workgroup (512 registers per wave)
     const long long resident = (long long)num_cus * ((P::KH == 1) ? 1 : 8 / WAVES);
     long long want = ntiles;
-    if (VIEWS) {    // contiguous whole-ray ranges: no more workgroups than ray groups that fill a tile
+    if (a.fuse_on) {        // groups of WAVES whole rays
+        want = ((long long)a.n_rays + WAVES - 1) / WAVES;
+    } else if (VIEWS) {    // contiguous whole-ray ranges: no more workgroups than ray groups that fill a tile
         const long long rays_per_tile = (WAVES + bpr - 1) / bpr;
         want = ((long long)a.n_rays + rays_per_tile - 1) / rays_per_tile;
     }

@@ -13,6 +13,7 @@
 // f16-rounded direction encoding on 0.05 % of the samples).
 #pragma once
 #include "nrnerf_net_impl.h"
+#include "nrnerf_composite_ray.h"
 
 namespace nrn {
 
@@ -264,23 +265,72 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
         tile_stride = (long long)gridDim.x * (WAVES * MB);
     }
 
+    // Fused compositing (variants without a fused bender, NetArgs::fuse_on): a WAVE owns whole rays.  Its blocks come in
+    // groups of RW rays = RW * bpr blocks = TG tiles of the workgroup (RW = 1 when bpr is even, else MB), groups strided over
+    // the grid; the raw outputs of a group's blocks are staged in the wave's own LDS area, and after the group's last tile
+    // the wave composites its RW rays itself (composite_ray): no cross-wave exchange, no barrier, the raw array of the pass
+    // never reaches HBM.  Per sample the arithmetic is that of the unfused mapping (bit-identical raw).
+    bool fuse = false;
+    int RW = 1, TG = 1, tg = 0;
+    long long ngroups = 0, grp = blockIdx.x;
+    f32x4* stage_w = nullptr;
+    if constexpr (!HAS_BEND) {
+        fuse = a.fuse_on != 0;
+        RW = (bpr % MB) ? MB : 1;
+        TG = RW * bpr / MB;
+        ngroups = ((long long)a.n_rays + WAVES * RW - 1) / (WAVES * RW);
+        stage_w = (f32x4*)(mailbox + 2 * WAVES * MB * 4) + (size_t)wave * RW * bpr * 32;
+        // the compositing arguments live in LDS, not in SGPRs: ~40 scalar registers held across the whole tile would be
+        // spilled into vector registers the MFMA section needs (measured: +60 VGPRs, scratch in the TCB variants)
+        if (fuse) {
+            int* dst = (int*)((f32x4*)(mailbox + 2 * WAVES * MB * 4) + (size_t)WAVES * RW * bpr * 32);
+            const int* src = (const int*)&a.fuse;
+            for (int i = tid; i < (int)(sizeof(CompositeArgs) / 4); i += WAVES * 64) dst[i] = src[i];
+            __syncthreads();
+        }
+    }
+
 #ifdef NRN_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     int iter = 0;
-    for (long long tile0 = blk_begin; tile0 < blk_end; tile0 += tile_stride, ++iter) {
+    float cpre[MB][8];          // fused compositing: direction and depths of this wave's rays, requested one tile ahead of their use
+    for (long long tile0 = blk_begin; fuse ? (grp < ngroups) : (tile0 < blk_end); ++iter) {
         const unsigned long long t_pass = NRN_NOW();
+        if constexpr (!HAS_BEND) {
+            if (fuse && tg == TG - 1) {
+                const CompositeArgs& fa = *(const CompositeArgs*)((f32x4*)(mailbox + 2 * WAVES * MB * 4) + (size_t)WAVES * RW * bpr * 32);
+                static_for<0, MB>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if (r < RW) {
+                        const long long rr = (grp * WAVES + wave) * RW + r;
+                        composite_prefetch(fa, (int)(rr < a.n_rays ? rr : a.n_rays - 1), lane, (S + 63) >> 6, cpre[r]);
+                    }
+                });
+            }
+        }
         int ray[MB], sidx[MB], sc[MB];
         bool ok[MB], writer[MB];
         size_t so[MB];              // flat sample index for per-sample outputs
         const float* rp[MB];
         float p[MB][3];
         NRN_FORB(b)
-            const long long blk = tile0 + b * WAVES + wave;
-            const bool blk_ok = blk < blk_end;
-            const long long bb_ = blk_ok ? blk : blk_end - 1;
-            ray[b] = (int)(bb_ / bpr);
-            sidx[b] = (int)(bb_ % bpr) * 32 + j;
+            bool blk_ok;
+            int bir;                // block within its ray
+            if (fuse) {             // block q of this wave's group: ray (grp * WAVES + wave) * RW + q / bpr
+                const int q = tg * MB + b;
+                const long long rr = (grp * WAVES + wave) * RW + q / bpr;
+                blk_ok = rr < a.n_rays;
+                ray[b] = (int)(blk_ok ? rr : a.n_rays - 1);
+                bir = q % bpr;
+            } else {
+                const long long blk = tile0 + b * WAVES + wave;
+                blk_ok = blk < blk_end;
+                const long long bb_ = blk_ok ? blk : blk_end - 1;
+                ray[b] = (int)(bb_ / bpr);
+                bir = (int)(bb_ % bpr);
+            }
+            sidx[b] = bir * 32 + j;
             ok[b] = blk_ok && sidx[b] < S;
             sc[b] = sidx[b] < S ? sidx[b] : S - 1;
             rp[b] = a.rays + (size_t)ray[b] * a.ray_stride;
@@ -606,16 +656,51 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
             if (HAS_BEND && a.knobs.detailed && a.knobs.has_removal && rig_mask[b] >= a.knobs.removal)
                 raw[b][3] = raw[b][3] * 0.0f;                                                  // rnh:308-311
             if (writer[b]) {
-                *(f32x4*)(a.raw4 + so[b] * 4) = f32x4{raw[b][0], raw[b][1], raw[b][2], raw[b][3]};
+                if (!fuse) *(f32x4*)(a.raw4 + so[b] * 4) = f32x4{raw[b][0], raw[b][1], raw[b][2], raw[b][3]};
                 if (a.raw_out) {
                     float* ro = a.raw_out + so[b] * a.raw_ch;
                     ro[0] = raw[b][0]; ro[1] = raw[b][1]; ro[2] = raw[b][2]; ro[3] = raw[b][3];
                     if (a.raw_ch > 4) ro[4] = raw[b][4];
                 }
             }
+            if constexpr (!HAS_BEND) {
+                if (fuse && h == 0) stage_w[(tg * MB + b) * 32 + j] = f32x4{raw[b][0], raw[b][1], raw[b][2], raw[b][3]};
+            }
         NRN_ENDB
         // padding units (keep the ring phase identical every pass and prime the next pass' first units)
         static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+        if constexpr (!HAS_BEND) {
+            if (fuse) {
+                if (++tg == TG) {        // the group's last tile: composite this wave's rays from its LDS stage (train.py:943-950)
+                    // the surface reduction reads bent4 rows this wave's OTHER lanes have just written (only when this kernel
+                    // writes that array itself: a model without bender): make the stores visible first
+                    const CompositeArgs& fa = *(const CompositeArgs*)((f32x4*)(mailbox + 2 * WAVES * MB * 4) + (size_t)WAVES * RW * bpr * 32);
+                    if (a.bent4 && fa.bent4) __threadfence();
+                    static_for<0, MB>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        if (r < RW) {
+                            const long long rr = (grp * WAVES + wave) * RW + r;
+                            const bool ray_ok = rr < a.n_rays;
+                            const int cray = (int)(ray_ok ? rr : a.n_rays - 1);
+                            const f32x4* sw = stage_w + r * bpr * 32;
+                            auto raw_at = [&](int ic) { return sw[ic]; };
+                            switch ((S + 63) >> 6) {
+                                case 1: { float cz[2], cw[1]; composite_ray<1>(fa, cray, ray_ok, lane, raw_at, cz, cw, cpre[r]); break; }
+                                case 2: { float cz[3], cw[2]; composite_ray<2>(fa, cray, ray_ok, lane, raw_at, cz, cw, cpre[r]); break; }
+                                case 3: { float cz[4], cw[3]; composite_ray<3>(fa, cray, ray_ok, lane, raw_at, cz, cw, cpre[r]); break; }
+                                default: { float cz[5], cw[4]; composite_ray<4>(fa, cray, ray_ok, lane, raw_at, cz, cw, cpre[r]); break; }
+                            }
+                        }
+                    });
+                    tg = 0;
+                    grp += gridDim.x;
+                }
+            } else {
+                tile0 += tile_stride;
+            }
+        } else {
+            tile0 += tile_stride;
+        }
         NRN_TACC(5, t_out);
         NRN_TACC(0, t_pass);
 #ifdef NRN_TIMING
@@ -635,22 +720,32 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_mb(const NetArgs a) 
 template <class P, class A, bool HAS_BEND, bool VIEWS, int WAVES, int MB>
 static hipError_t launch_one_mb(const NetArgs& a, int num_cus, hipStream_t stream) {
     using PL = Plan<P, A, HAS_BEND, VIEWS>;
-    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * MB * 4 * sizeof(float);
+    const int bpr = (a.S + 31) / 32;
+    size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * MB * 4 * sizeof(float);
+    const int RW = (bpr % MB) ? MB : 1;      // fused compositing: rays per wave and group (see the kernel)
+    if (a.fuse_on) {
+        if (HAS_BEND || a.S > 256 || a.fuse.n_importance != 0 || a.fuse.S != a.S) return hipErrorInvalidValue;
+        lds += (size_t)WAVES * RW * bpr * 32 * 16 + 256;       // the waves' raw stages + the compositing arguments
+    }
     auto kern = net_kernel_mb<P, A, HAS_BEND, VIEWS, WAVES, MB>;
     // function attributes are per device: one flag per ordinal (idempotent; racing threads set the same value)
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // the largest request any launch of this variant can make: ring + bias + mailbox + the fused stages at bpr = 7 (RW = MB)
+        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 32 * sizeof(float) + 2 * WAVES * MB * 4 * sizeof(float) +
+                               (HAS_BEND ? 0 : (size_t)WAVES * MB * 7 * 32 * 16 + 256);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    const int bpr = (a.S + 31) / 32;
     const long long nblocks = (long long)a.n_rays * bpr;
     long long want = (nblocks + WAVES * MB - 1) / (WAVES * MB);
     if (want <= 0) return hipSuccess;
-    if (VIEWS) {    // contiguous whole-ray ranges: no more workgroups than ray groups that fill a tile
+    if (a.fuse_on) {    // groups of WAVES * RW whole rays
+        want = ((long long)a.n_rays + WAVES * RW - 1) / (WAVES * RW);
+    } else if (VIEWS) {    // contiguous whole-ray ranges: no more workgroups than ray groups that fill a tile
         const long long rays_per_tile = (WAVES * MB + bpr - 1) / bpr;
         want = ((long long)a.n_rays + rays_per_tile - 1) / rays_per_tile;
     }

@@ -586,8 +586,8 @@ def _why_unsupported(ray_batch, network_fn, network_fine, N_samples, N_importanc
             return "use_viewdirs without view directions in the ray batch"
         if network_fine is not None and getattr(network_fine, "approx_nonrigid_viewdirs", True) == exact:
             return "coarse and fine networks disagree about approx_nonrigid_viewdirs"
-    if N_samples < 2 or N_samples + N_importance > 256:
-        return "more than 256 samples per ray"
+    if N_samples < 2 or N_samples + N_importance > _lib.MAX_SAMPLES:
+        return f"more than {_lib.MAX_SAMPLES} samples per ray"
     a = getattr(network_fn, "test_time_nonrigid_object_removal_threshold", None)
     b = getattr(network_fine, "test_time_nonrigid_object_removal_threshold", a) if network_fine is not None else a
     if a != b:

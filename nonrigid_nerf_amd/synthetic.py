@@ -30,6 +30,8 @@ class SceneConfig:
     N_importance: int = 128
     netdepth: int = 8
     netwidth: int = 256
+    netdepth_fine: int | None = None          # --netdepth_fine / --netwidth_fine (train.py:1004-1010); None: as the coarse network
+    netwidth_fine: int | None = None
     multires: int = 10
     multires_views: int = 4
     use_viewdirs: bool = False
@@ -44,6 +46,12 @@ class SceneConfig:
     approx_nonrigid_viewdirs: bool = True     # False: directions = normalised J(bent wrt xyz) . d   (rnh:358-385)
     near: float = NEAR
     far: float = FAR
+
+    def for_fine(self) -> "SceneConfig":
+        """The same settings with the fine network's depth / width in ``netdepth`` / ``netwidth`` (create_nerf, train.py:612-630)."""
+        import dataclasses
+        return dataclasses.replace(self, netdepth=self.netdepth_fine or self.netdepth, netwidth=self.netwidth_fine or self.netwidth,
+                                   netdepth_fine=None, netwidth_fine=None)
 
     @property
     def input_ch(self) -> int:
@@ -169,7 +177,7 @@ def make_scene(cfg: SceneConfig | None = None, seed: int = 0) -> Scene:
     cfg = cfg or SceneConfig()
     bender = bender_arrays(cfg, seed * 7919 + 1) if cfg.ray_bending else None
     coarse = nerf_arrays(cfg, seed * 7919 + 2)
-    fine = nerf_arrays(cfg, seed * 7919 + 3) if cfg.N_importance > 0 else None
+    fine = nerf_arrays(cfg.for_fine(), seed * 7919 + 3) if cfg.N_importance > 0 else None
     return Scene(cfg, bender, coarse, fine)
 
 
@@ -183,7 +191,7 @@ def build_modules(scene: Scene, device="cpu", dtype=torch.float32):
         load_named_arrays(rb, scene.bender)
         rb = rb.to(device=device, dtype=dtype)
 
-    def mk(arrays, ns):
+    def mk(arrays, ns, cfg):
         m = NeRFWeights(D=cfg.netdepth, W=cfg.netwidth, input_ch=cfg.input_ch,
                         input_ch_views=cfg.input_ch_views, output_ch=cfg.output_ch,
                         skips=cfg.skips, use_viewdirs=cfg.use_viewdirs, ray_bender=None,
@@ -195,8 +203,8 @@ def build_modules(scene: Scene, device="cpu", dtype=torch.float32):
         m.ray_bender = (rb,)
         return m
 
-    coarse = mk(scene.coarse, cfg.N_samples)
-    fine = mk(scene.fine, cfg.N_samples + cfg.N_importance) if scene.fine is not None else None
+    coarse = mk(scene.coarse, cfg.N_samples, cfg)
+    fine = mk(scene.fine, cfg.N_samples + cfg.N_importance, cfg.for_fine()) if scene.fine is not None else None
     return rb, coarse, fine
 
 

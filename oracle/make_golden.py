@@ -68,7 +68,7 @@ def reference_kwargs(H, T, scene):
         lcm = S * (S + I) // gcd(S, S + I)
         netchunk = (netchunk // lcm) * lcm                      # train.py:584-592
 
-    def mk(arrays, ns):
+    def mk(arrays, ns, cfg):
         m = H.NeRF(D=cfg.netdepth, W=cfg.netwidth, input_ch=input_ch, output_ch=cfg.output_ch,
                    skips=list(cfg.skips), input_ch_views=input_ch_views, use_viewdirs=cfg.use_viewdirs,
                    ray_bender=rb, ray_bending_latent_size=cfg.latent_size, embeddirs_fn=embeddirs_fn,
@@ -77,8 +77,8 @@ def reference_kwargs(H, T, scene):
         m.load_state_dict({k: v.clone() for k, v in arrays.items()}, strict=True)
         return m
 
-    coarse = mk(scene.coarse, S)
-    fine = mk(scene.fine, S + I) if scene.fine is not None else None
+    coarse = mk(scene.coarse, S, cfg)
+    fine = mk(scene.fine, S + I, cfg.for_fine()) if scene.fine is not None else None      # create_nerf, train.py:612-630
 
     def network_query_fn(inputs, viewdirs, api, network_fn, detailed_output=False):   # train.py:633-649
         return T.run_network(inputs, viewdirs, api, network_fn, embed_fn=embed_fn,
@@ -117,6 +117,16 @@ CASES = {
     "narrow_128_64_64": (dict(N_importance=64, netwidth=128), 48, 32768, True, True, {}),
     "narrow_128_no_bender": (dict(N_importance=64, netwidth=128, ray_bending=False), 37, 16, False, True, {}),
     "stochastic_64_64": (dict(N_importance=64), 40, 16, False, True, dict(render_perturb=1.0, render_raw_noise_std=0.7, render_seed=1234)),
+    # architectures outside the compiled set (the run-time-parameterised kernel, csrc/nrnerf_generic.h): --netdepth 6 --netwidth 192
+    # --netdepth_fine 10 --netwidth_fine 320 --multires 8 --ray_bending_latent_size 16 (train.py:1004-1010, 1060, 1133-1139), with
+    # detailed outputs and the editing knobs; and the view-dependent head at --netwidth 96 / 160, --multires 6, --multires_views 2
+    "generic_192_320_detailed": (dict(N_importance=64, netdepth=6, netwidth=192, netdepth_fine=10, netwidth_fine=320, multires=8, latent_size=16),
+                                 40, 32768, True, True, dict(rigidity_test_time_cutoff=0.45, test_time_scaling=0.5, removal_threshold=0.6)),
+    "generic_viewdirs_96_160": (dict(N_importance=48, N_samples=40, netdepth=7, netwidth=96, netwidth_fine=160, multires=6, multires_views=2,
+                                     use_viewdirs=True), 37, 16, False, True, {}),
+    "generic_shallow_no_bender": (dict(N_importance=64, netdepth=4, netwidth=64, ray_bending=False), 48, 32768, False, True, {}),
+    "generic_time_conditioned_448": (dict(N_importance=32, netdepth=8, netwidth=448, multires=12, latent_size=24, ray_bending=False,
+                                          time_conditioned_baseline=True, use_viewdirs=True, multires_views=6), 24, 32768, False, True, {}),
 }
 
 

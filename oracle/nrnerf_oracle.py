@@ -114,7 +114,7 @@ def exact_dirs(flat, lat, bender, knobs, unbent_dirs):
 def canonical_mlp(enc, net, cfg, enc_dirs=None, latents=None):
     """NeRF.forward after bending, run_nerf_helpers.py:272-306."""
     dt = enc.dtype
-    D = cfg.netdepth
+    D = sum(1 for k in net if k.startswith("pts_linears.") and k.endswith(".weight"))   # (the fine network may be deeper / wider: train.py:1004-1010)
     x_in = enc if not cfg.time_conditioned_baseline else torch.cat([enc, latents.to(dt)], -1)  # :273-274
     h = x_in
     for i in range(D):

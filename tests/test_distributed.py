@@ -125,7 +125,8 @@ def test_rccl_path_with_one_rank_on_the_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_spawns_its_own_ranks():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_spawns_its_own_ranks(scaling):
     """`python bench.py --gpus 2` with no launcher must start two ranks by itself (torch.distributed.run) and report
     them.  On a 1-GPU box NRNERF_BENCH_ONE_GPU=1 puts both ranks on GPU 0 and gathers over gloo (functional test of the
     script's N > 1 path, not a measurement)."""
@@ -137,7 +138,8 @@ def test_bench_spawns_its_own_ranks():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--rays", "8192", "--no-cpu-baseline", "--no-psnr", "--no-train-step"], env=env, capture_output=True, text=True, timeout=600)
+                        "--rays", "8192", "--no-cpu-baseline", "--no-psnr", "--no-train-step", "--scaling", scaling],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -145,7 +147,8 @@ def test_bench_spawns_its_own_ranks():
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["backend"] == "gloo"
     assert res["steps"] == 3 and res["value"] > 0
     # both scalings of the job in the one line: weak = --rays per rank, strong = --rays sharded over the ranks
-    assert res["scaling"] == "weak" and res["weak"]["value"] == res["value"] and res["weak"]["rays_per_rank_per_step"] == 8192
+    # (the record named by --scaling is the line's primary one; BASELINE config 3 -- one frame sharded over the ranks -- is "strong")
+    assert res["scaling"] == scaling and res[scaling]["value"] == res["value"] and res["weak"]["rays_per_rank_per_step"] == 8192
     assert res["strong"]["rays_per_rank_per_step"] == 4096 and res["strong"]["rays_per_step_whole_job"] == 8192
     assert len(res["strong"]["per_rank_ms_per_step"]) == 2 and res["strong"]["value"] > 0
 

@@ -19,7 +19,7 @@ import torch
 from nonrigid_nerf_amd import render as R
 from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
 from oracle import nrnerf_oracle as O
-from tests.helpers import compare_dict, load_golden, psnr, split_knobs
+from tests.helpers import check_pinned, compare_dict, load_golden, out_of_tolerance_fraction, psnr, split_knobs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -80,7 +80,10 @@ COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "
 @pytest.mark.parametrize("name", ["coarse_only_1k", "headline_64_128", "detailed_64_128", "ragged_chunks",
                                   "knobs_64_64", "no_bender_64_64", "viewdirs_64_64", "config4_deep_bender_viewdirs",
                                   "time_conditioned_64_64", "lindisp_white_bkgd_64_64", "exact_viewdirs_64_64",
-                                  "exact_viewdirs_knobs", "config4_exact_viewdirs", "narrow_128_64_64", "narrow_128_no_bender"])
+                                  "exact_viewdirs_knobs", "config4_exact_viewdirs", "narrow_128_64_64", "narrow_128_no_bender",
+                                  # architectures outside the compiled set: the run-time-parameterised kernel (csrc/nrnerf_generic.h)
+                                  "generic_192_320_detailed", "generic_viewdirs_96_160", "generic_shallow_no_bender",
+                                  "generic_time_conditioned_448"])
 def test_fp32_mode_matches_reference_golden(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
     meta["knobs"], flags = split_knobs(meta["knobs"])
@@ -118,8 +121,13 @@ def test_fp32_mode_matches_reference_golden(name):
             fails += compare_dict(got, fine, keys=["raw"], **FD_DIRS_RAW)
         else:
             fails += compare_dict(got, fine, keys=[k for k in fine if k in got])
-        # 4. end to end against the reference outputs, allowing the few rays whose sample moved
+        # 4. end to end against the reference outputs, allowing the few rays whose sample moved ...
         fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], **loose)
+        # ... and the measured fractions pinned at <= 2 x the committed values (not at the allowances above)
+        n = rays.shape[0]
+        check_pinned("golden/" + name, dict(moved_depths=moved, rgb_map=out_of_tolerance_fraction(got, ref, "rgb_map"),
+                                            acc_map=out_of_tolerance_fraction(got, ref, "acc_map")),
+                     dict(moved_depths=zg.numel(), rgb_map=3 * n, acc_map=n))
     assert not fails, "\n".join(fails)
 
 
@@ -214,6 +222,40 @@ def test_fp32_mode_vs_oracle_4k_rays():
     fine = oracle_fine_given_z(scene, rays, latents, got["_z_vals"])
     fails += compare_dict(got, fine, keys=["rgb_map", "disp_map", "acc_map"])
     fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], frac_ok=0.10, outlier_atol=2e-2)
+    moved = ((got["_z_vals"] - ref["_z_vals"]).abs() > 2e-5).float().mean().item()
+    check_pinned("oracle_4k_rays", dict(moved_depths=moved, rgb_map=out_of_tolerance_fraction(got, ref, "rgb_map"),
+                                        acc_map=out_of_tolerance_fraction(got, ref, "acc_map")),
+                 dict(moved_depths=got["_z_vals"].numel(), rgb_map=3 * 4096, acc_map=4096))
+    assert not fails, "\n".join(fails)
+
+
+def test_fp32_mode_full_frame_vs_gpu_eager_oracle():
+    """BASELINE config 2's size in fp32 mode: 196 608 rays (one 512x384 frame), 64+128, against the oracle evaluated as
+    eager fp32 torch ops ON THIS GPU (the reference's own arithmetic on this device: the CPU oracle would need minutes).
+    Coarse maps at the fp32 tolerance on every ray; merged depths, final maps: measured fractions, pinned."""
+    cfg = SceneConfig()
+    scene = make_scene(cfg, 1)
+    n = 196608
+    rays, latents = make_rays(n, 17, cfg)
+    with torch.no_grad():
+        ref = O.batchify_rays(rays.to(DEV), latents.to(DEV), O.scene_on(scene, DEV), chunk=16384)
+    ref = {k: v.cpu() for k, v in ref.items()}
+    got = hip_render(scene, rays, latents, "f32")
+    # the GPU's eager GEMMs and this library's MFMA chains round differently: the coarse maps agree to the fp32 tolerance
+    # on all but a few rays in 10^5 whose sigma sits on the relu kink of a sample with a huge distance
+    fails = compare_dict(got, ref, keys=["rgb0", "disp0", "acc0"], frac_ok=1e-4, outlier_atol=2e-2)
+    # (2e-2 bounds what one moved sample does to a ray on a few thousand rays; the tail of 196 608 rays reaches 3.7e-2)
+    fails += compare_dict(got, ref, keys=["rgb_map", "acc_map"], frac_ok=0.10, outlier_atol=5e-2)
+    zg, zo = got["_z_vals"], ref["_z_vals"]
+    assert (zg[:, 1:] >= zg[:, :-1]).all()
+    moved = ((zg - zo).abs() > 2e-5).float().mean().item()
+    assert float((zg - zo).abs().max()) < 1.1 / (cfg.N_samples - 1), "a depth moved by more than one coarse bin"
+    check_pinned("full_frame_196608", dict(moved_depths=moved, rgb0=out_of_tolerance_fraction(got, ref, "rgb0"),
+                                           rgb_map=out_of_tolerance_fraction(got, ref, "rgb_map"),
+                                           acc_map=out_of_tolerance_fraction(got, ref, "acc_map")),
+                 dict(moved_depths=zg.numel(), rgb0=3 * n, rgb_map=3 * n, acc_map=n))
+    print(f"[fp32, 196 608 rays vs the eager oracle on this GPU] PSNR rgb_map {psnr(got['rgb_map'], ref['rgb_map']):.1f} dB, "
+          f"rgb0 {psnr(got['rgb0'], ref['rgb0']):.1f} dB")
     assert not fails, "\n".join(fails)
 
 
@@ -616,6 +658,10 @@ VARIANT_CFGS = {
     "deep_bender_exact_viewdirs": dict(N_importance=0, use_viewdirs=True, bend_depth=7, approx_nonrigid_viewdirs=False),
     "narrow_128":           dict(N_importance=0, netwidth=128),
     "narrow_128_no_bender": dict(N_importance=0, netwidth=128, ray_bending=False),
+    # outside the compiled set: the run-time-parameterised kernel (hidden activations in the 16-bit type, inputs f16, bender fp32)
+    "generic_192_depth6":   dict(N_importance=0, netdepth=6, netwidth=192, multires=8, latent_size=16),
+    "generic_viewdirs_320": dict(N_importance=0, netwidth=320, use_viewdirs=True, multires_views=2),
+    "generic_512_no_bender": dict(N_importance=0, netwidth=512, netdepth=10, ray_bending=False),
 }
 
 
@@ -647,15 +693,55 @@ def test_16bit_kernels_of_every_compiled_variant_track_the_fp32_kernel(variant, 
     p_keep_o = psnr(got["rgb_map"][keep_o], orc["rgb_map"][keep_o])
     print(f"[{variant} / {precision}] raw SNR {[round(x, 1) for x in snr]} dB (vs oracle {[round(x, 1) for x in snr_o]}), "
           f"flipped {int(flips.sum())}/{flips.numel()}, PSNR non-flipped {p_keep:.1f} dB (vs oracle {p_keep_o:.1f})")
-    # the finite-difference directions of the view-dependent head amplify rounding of the bent points (FD_DIRS_RAW):
-    # colour logits get a few dB less there, sigma (channel 3, no view dependence) keeps the bar
-    slack = 6.0 if (cfg.use_viewdirs and cfg.ray_bending) else 0.0
-    # 1.5 dB under the default family's bar: other seeds / wider inputs (time-conditioned: 95 instead of 63 columns)
-    assert snr[3] >= snr_bar - 1.5 and min(snr[:3]) >= snr_bar - 1.5 - slack, snr
+    # the SAME bars for every family (1.5 dB under the default family's network-output bar: other seeds / wider inputs --
+    # time-conditioned: 95 instead of 63 columns); no extra allowance for the view-dependent head with finite-difference
+    # directions (measured round 3: colour SNR 34.4-38.7 dB, PSNR over non-flipped rays 52-62 dB in bf16 mode)
+    assert min(snr) >= snr_bar - 1.5, snr
     assert flips.float().mean().item() <= flip_bar
-    assert p_keep >= psnr_bar - slack, p_keep
-    assert snr_o[3] >= snr_bar - 1.5 and min(snr_o[:3]) >= snr_bar - 1.5 - slack, snr_o
-    assert (~keep_o).float().mean().item() <= flip_bar and p_keep_o >= psnr_bar - slack, p_keep_o
+    assert p_keep >= psnr_bar, p_keep
+    assert min(snr_o) >= snr_bar - 1.5, snr_o
+    assert (~keep_o).float().mean().item() <= flip_bar and p_keep_o >= psnr_bar, p_keep_o
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg_kw", [dict(N_importance=64), dict(N_importance=64, use_viewdirs=True), dict(N_importance=32, ray_bending=False, time_conditioned_baseline=True),
+                                    dict(N_importance=64, netwidth=128, bend_depth=7)],
+                         ids=["default", "viewdirs", "time_conditioned", "w128_deep_bender"])
+def test_generic_kernel_agrees_with_the_compiled_kernels_on_their_own_architectures(cfg_kw, precision):
+    """NRNERF_FORCE_GENERIC=1 sends a compiled architecture through the run-time-parameterised kernel (csrc/nrnerf_generic.h):
+    the two implementations of the same network must agree -- fp32: to rounding (different summation order of the same
+    products); bf16: both within the 16-bit bars of each other -- with detailed outputs, ragged ray counts and knobs."""
+    import os
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 6)
+    rays, latents = make_rays(777, 41, cfg)
+    knobs = dict(rigidity_test_time_cutoff=0.4, test_time_scaling=0.8) if cfg.ray_bending else {}
+    outs = []
+    old = os.environ.get("NRNERF_FORCE_GENERIC")
+    try:
+        for force in ("0", "1"):
+            os.environ["NRNERF_FORCE_GENERIC"] = force
+            R.invalidate()                       # the handle is per architecture route: build a fresh one
+            outs.append(hip_render(scene, rays, latents, precision, retraw=True, detailed=True, knobs=knobs))
+    finally:
+        R.invalidate()
+        if old is None:
+            os.environ.pop("NRNERF_FORCE_GENERIC", None)
+        else:
+            os.environ["NRNERF_FORCE_GENERIC"] = old
+    compiled, generic = outs
+    assert set(compiled) == set(generic)
+    if precision == "f32":
+        fails = compare_dict(generic, compiled, keys=[k for k in COARSE_KEYS if k in compiled])
+        moved = ((generic["_z_vals"] - compiled["_z_vals"]).abs() > 2e-5).float().mean().item()
+        assert moved < 0.01, moved
+        fails += compare_dict(generic, compiled, keys=["rgb_map", "acc_map"], frac_ok=0.10, outlier_atol=2e-2)
+        assert not fails, "\n".join(fails)
+    else:
+        assert psnr(generic["rgb0"], compiled["rgb0"]) >= 34.0       # two bf16 evaluations of the stress scene against each other
+        for k in ("input_pts", "unmasked_offsets", "rigidity_mask"):
+            if k in compiled:       # generic bender: fp32; compiled bf16 mode: single-product f16 (bars of test_16bit_modes_psnr_full_pipeline)
+                assert float((generic[k] - compiled[k]).pow(2).mean().sqrt()) < 2e-3, k
 
 
 @pytest.mark.parametrize("n", [1, 7, 33, 257])
@@ -673,21 +759,41 @@ def test_tiny_and_ragged_ray_counts_vs_oracle(n):
     assert not fails, "\n".join(fails)
 
 
-def test_maximum_sample_counts_vs_oracle():
-    """The compiled limit: 256 samples per ray in either pass (128 + 128, and 256 coarse-only)."""
-    for cfg_kw in (dict(N_samples=128, N_importance=128), dict(N_samples=256, N_importance=0)):
-        cfg = SceneConfig(**cfg_kw)
-        scene = make_scene(cfg, 0)
-        rays, latents = make_rays(96, 37, cfg)
-        got = hip_render(scene, rays, latents, "f32", retraw=True)
-        ref = O.batchify_rays(rays, latents, scene, retraw=True)
-        if cfg.N_importance == 0:
-            fails = compare_dict(got, ref, keys=["rgb_map", "disp_map", "acc_map", "raw"])
-        else:
-            fails = compare_dict(got, ref, keys=["rgb0", "disp0", "acc0"])
-            fine = oracle_fine_given_z(scene, rays, latents, got["_z_vals"])
-            fails += compare_dict(got, fine, keys=["rgb_map", "disp_map", "acc_map", "raw"])
-        assert not fails, (cfg_kw, "\n".join(fails))
+@pytest.mark.parametrize("cfg_kw", [dict(N_samples=128, N_importance=128), dict(N_samples=256, N_importance=0),
+                                    dict(N_samples=192, N_importance=320), dict(N_samples=64, N_importance=450),
+                                    dict(N_samples=600, N_importance=0), dict(N_samples=512, N_importance=512),
+                                    dict(N_samples=200, N_importance=300, ray_bending=False)],
+                         ids=["128+128", "256+0", "192+320", "64+450", "600+0", "512+512", "200+300_no_bender"])
+def test_large_sample_counts_vs_oracle(cfg_kw):
+    """The reference has no cap on --N_samples / --N_importance (train.py:1090-1094).  Up to 256 samples per ray a render
+    takes the split-bender path and the fused compositing; beyond (up to NRNERF_MAX_SAMPLES = 1024 per pass) the
+    fused-bender fine pass and the composite kernel with up to 16 samples per lane."""
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(96, 37, cfg)
+    got = hip_render(scene, rays, latents, "f32", retraw=True)
+    ref = O.batchify_rays(rays, latents, scene, retraw=True)
+    if cfg.N_importance == 0:
+        fails = compare_dict(got, ref)
+    else:
+        fails = compare_dict(got, ref, keys=["rgb0", "disp0", "acc0"])
+        zg = got["_z_vals"]
+        assert zg.shape == (96, cfg.N_samples + cfg.N_importance) and (zg[:, 1:] >= zg[:, :-1]).all()
+        assert ((zg - ref["_z_vals"]).abs() > 2e-5).float().mean().item() < 0.02
+        fine = oracle_fine_given_z(scene, rays, latents, zg)
+        fails += compare_dict(got, fine, keys=["rgb_map", "disp_map", "acc_map", "raw"])
+    assert not fails, "\n".join(fails)
+
+
+def test_more_samples_than_the_library_takes_are_refused_with_the_documented_status():
+    cfg = SceneConfig(N_samples=1000, N_importance=100)
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(8, 37, cfg)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    R.set_precision("f32")
+    with torch.no_grad(), pytest.raises(R.Unsupported):
+        R.batchify_rays(rays.to(DEV), {"ray_bending_latents": latents.to(DEV)}, network_fn=coarse, network_fine=fine,
+                        N_samples=cfg.N_samples, N_importance=cfg.N_importance)
 
 
 @pytest.mark.parametrize("perturb,noise", [(1.0, 0.0), (0.0, 0.7), (1.0, 0.7)])
@@ -835,6 +941,62 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
     # and the carried-over / separately bent points are the fused kernel's: the surface point is one of them
     idx = split["median_index"].long()
     assert torch.equal(split["surface_pts"], fused["fine_input_pts"][torch.arange(3001, device=DEV), idx])
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("cfg_kw,knobs,flags", [
+    (dict(), {}, {}),                                                                   # headline: 64 + 128, split-bender path
+    (dict(N_samples=48, N_importance=37), dict(rigidity_test_time_cutoff=0.45), {}),    # ragged: 85 samples = 3 blocks per ray (odd)
+    (dict(N_samples=33, N_importance=64), {}, dict(perturb=1.0, raw_noise_std=1.0)),    # 97 samples = 4 blocks, noise on sigma
+    (dict(N_samples=128, N_importance=128), {}, dict(white_bkgd=True)),                 # 256 samples: 8 blocks, 4 samples per lane
+    (dict(N_samples=64, N_importance=96, ray_bending=False), {}, {}),                   # no bender: 160 samples = 5 blocks (odd)
+    (dict(N_importance=0, ray_bending=False), {}, {}),                                  # no bender, coarse only: K1 inside K0
+    (dict(N_importance=64, use_viewdirs=True), {}, {}),                                 # view-dependent head, split path
+    (dict(N_importance=64, use_viewdirs=True, ray_bending=False), {}, {}),              # view-dependent head on ray directions
+    (dict(N_importance=64, netwidth=128), {}, {}),                                      # width 128: one block per wave in every mode
+    (dict(N_importance=32, ray_bending=False, time_conditioned_baseline=True), {}, {}), # time-conditioned baseline
+], ids=["headline", "ragged_knobs", "noise", "max_samples_white", "no_bender_odd", "no_bender_coarse_only", "viewdirs", "viewdirs_no_bender",
+        "narrow_128", "time_conditioned"])
+def test_compositing_fused_into_the_network_kernel_equals_the_composite_kernel_bit_for_bit(precision, cfg_kw, knobs, flags):
+    """north_star: "compositing fused into the ray loop".  The final pass' network kernel (every variant without a fused
+    bender: the trunk-only fine pass of the split-bender path, any pass of a model without bender) keeps each ray's raw
+    outputs in LDS and composites them itself with the composite kernel's own code (nrnerf_composite_ray.h); the route with
+    the separate composite launch (NRNERF_UNFUSED_COMPOSITE=1: raw [N,S,4] through HBM) must give the same bits for every
+    output -- maps, raw logits, depths, surface reduction -- in every precision, for even and odd block counts per ray, a
+    ray count that leaves the last group of rays half empty, noise, white background."""
+    import os
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 4)
+    n = 3001
+    rays, latents = make_rays(n, 29, cfg)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    if rb is not None:
+        rb.rigidity_test_time_cutoff = knobs.get("rigidity_test_time_cutoff")
+    R.set_precision(precision)
+    model = R.get_model(coarse, fine)
+    r, l = rays.to(DEV), latents.to(DEV)
+    outs = []
+    old = os.environ.get("NRNERF_UNFUSED_COMPOSITE")
+    try:
+        for unfused in ("0", "1"):
+            os.environ["NRNERF_UNFUSED_COMPOSITE"] = unfused
+            torch.manual_seed(5)
+            randoms = R._draw_randoms(r, cfg.N_samples, cfg.N_importance, flags.get("perturb", 0.0), flags.get("raw_noise_std", 0.0))
+            with torch.no_grad():
+                outs.append(model.render(r, l, cfg.N_samples, cfg.N_importance, retraw=True, detailed_output=False,
+                                         rigidity_cutoff=knobs.get("rigidity_test_time_cutoff"), test_time_scaling=None,
+                                         want_z_vals=True, surface=True, white_bkgd=bool(flags.get("white_bkgd")), randoms=randoms))
+            torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop("NRNERF_UNFUSED_COMPOSITE", None)
+        else:
+            os.environ["NRNERF_UNFUSED_COMPOSITE"] = old
+    fused, unfused = outs
+    assert set(fused) == set(unfused)
+    for k in fused:
+        assert torch.equal(torch.nan_to_num(fused[k].float()), torch.nan_to_num(unfused[k].float())), k
+    assert torch.isfinite(fused["rgb_map"]).all() and float(fused["acc_map"].max()) > 0.5
 
 
 def _assert_split_equals_fused_up_to_conversion_ties(split, fused, views=False):

@@ -496,3 +496,142 @@ def test_bender_backward_stream_reproduces_autograd_of_the_bender(precision):
     assert tile0 == info.n_bias_tiles and mfma == info.mfma_per_block
     used = fr.pos * info.frag_bytes
     assert used <= info.stream_bytes and not stream[used:].any()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The run-time-parameterised kernel (csrc/nrnerf_generic.h): its layer PROGRAM and packed images (nrnerf_pack_host 7 / 8 / 9),
+# executed in numpy exactly as the kernel walks them -- per layer and output tile the fragments (tile, k-slab) against the
+# buffers E (network input) / H (hidden, overwritten in place) / V (second input), accumulators seeded with the bias table in
+# the D-tile register order -- must reproduce the plain F.linear network of the reference's modules.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _run_generic_program(info, stream, units, bias, precision, E, V):
+    f32 = precision == "f32"
+    KH = 1 if f32 else 8
+    KS, FB = 2 * KH, info.frag_bytes
+    assert FB == (256 if f32 else 1024)
+    u = units.astype(np.int64)
+    n_layers = int(u[0])
+    layers = u[1:1 + 11 * n_layers].reshape(n_layers, 11)
+    ke, kv, kh, lat = (int(x) for x in u[1 + 11 * n_layers:1 + 11 * n_layers + 4])
+    n = E.shape[0]
+    bufs = {0: np.zeros((n, ke)), 2: np.zeros((n, kv)), 1: np.zeros((n, kh)), 3: np.zeros((n, 8))}
+    bufs[0][:, :E.shape[1]] = E
+    bufs[2][:, :V.shape[1]] = V
+    if f32:
+        words = stream.view(np.float32).astype(np.float64)
+    else:
+        raw16 = stream.view(np.uint16)
+    for (w_frag, bias_tile, nt, src0, ns0, src1, ns1, dst, relu, o_col, o_rows) in layers:
+        ns = ns0 + ns1
+        out = np.zeros((n, 32 * nt))
+        for t in range(nt):
+            acc = np.zeros((32, n))                       # D tile: row = feature, column = sample
+            for h in range(2):
+                for r in range(16):
+                    acc[tile_row(r, h)] = bias[(bias_tile + t) * 32 + h * 16 + r]
+            for sl in range(ns):
+                src, s = (src0, sl) if sl < ns0 else (src1, sl - ns0)
+                fi = w_frag + t * ns + sl
+                if f32:
+                    fr = words[fi * 64:(fi + 1) * 64].reshape(64, 1)
+                else:
+                    bits = raw16[fi * 512:(fi + 1) * 512].reshape(64, 8)
+                    as_f16 = precision == "f16" or src != 1          # fragments against E / V are f16 (nrnerf_generic.h)
+                    fr = bits.view(np.float16).astype(np.float64) if as_f16 else (bits.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+                A = np.zeros((32, KS))
+                for lane in range(64):
+                    A[lane & 31, KH * (lane >> 5):KH * (lane >> 5) + KH] = fr[lane]
+                acc += A @ bufs[src][:, s * KS:(s + 1) * KS].T
+            out[:, 32 * t:32 * t + 32] = acc.T
+        if relu:
+            out = np.maximum(out, 0.0)
+        if dst == 1:
+            bufs[1][:, :32 * nt] = out
+        else:
+            bufs[3][:, o_col:o_col + o_rows] = out[:, :o_rows]
+    return bufs[3], (ke, kv, kh, lat)
+
+
+def _posenc(x, L):
+    cols = [x]
+    for k in range(L):
+        cols += [np.sin(x * 2.0 ** k), np.cos(x * 2.0 ** k)]
+    return np.concatenate(cols, -1)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("cfg_kw", [dict(netdepth=6, netwidth=192, netdepth_fine=10, netwidth_fine=320, multires=8, latent_size=16),
+                                    dict(netdepth=7, netwidth=96, netwidth_fine=160, multires=6, multires_views=2, use_viewdirs=True),
+                                    dict(netdepth=4, netwidth=72, ray_bending=False),
+                                    dict(netwidth=448, multires=12, latent_size=24, ray_bending=False, time_conditioned_baseline=True,
+                                         use_viewdirs=True, multires_views=6)],
+                         ids=["192_320_latent16", "viewdirs_96_160", "shallow_72_no_bender", "time_conditioned_448"])
+def test_generic_layer_programs_reproduce_the_networks(cfg_kw, precision):
+    cfg = SceneConfig(N_importance=64, **cfg_kw)
+    scene, (rb, coarse, fine), info_c, st_c, un_c, bi_c = _pack(cfg, precision, 7)
+    _, _, info_f, st_f, un_f, bi_f = _pack(cfg, precision, 8)
+    g = np.random.default_rng(5)
+    n = 40
+    pts = g.normal(size=(n, 3)) * 0.3
+    dirs = g.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    lat = g.normal(size=(n, cfg.latent_size)) * 0.1
+    enc = _posenc(pts, cfg.multires)
+    encd = _posenc(dirs, cfg.multires_views) if cfg.use_viewdirs else np.zeros((n, 3))
+    x_in = np.concatenate([enc, lat], -1) if cfg.time_conditioned_baseline else enc
+    tol = 1e-5 if precision == "f32" else (0.08 if precision == "bf16" else 0.01)
+    for net, info, st, un, bi in ((coarse, info_c, st_c, un_c, bi_c), (fine, info_f, st_f, un_f, bi_f)):
+        O, (ke, kv, kh, latw) = _run_generic_program(info, st, un, bi, precision, x_in, encd)
+        assert ke >= x_in.shape[1] and ke % 16 == 0 and kh >= int(net.W) and latw == (cfg.latent_size if cfg.time_conditioned_baseline else 0)
+        # the same network with torch (float64 weights of the modules)
+        with torch.no_grad():
+            x = torch.from_numpy(x_in)
+            h = x
+            for i, lin in enumerate(net.pts_linears):
+                h = F.relu(F.linear(h, lin.weight.double(), lin.bias.double()))
+                if i in net.skips and i < len(net.pts_linears) - 1:
+                    h = torch.cat([x, h], -1)
+            if net.use_viewdirs:
+                alpha = F.linear(h, net.alpha_linear.weight.double(), net.alpha_linear.bias.double())
+                feat = F.linear(h, net.feature_linear.weight.double(), net.feature_linear.bias.double())
+                hv = F.relu(F.linear(torch.cat([feat, torch.from_numpy(encd)], -1), net.views_linears[0].weight.double(), net.views_linears[0].bias.double()))
+                want = torch.cat([F.linear(hv, net.rgb_linear.weight.double(), net.rgb_linear.bias.double()), alpha], -1).numpy()
+            else:
+                want = F.linear(h, net.output_linear.weight.double(), net.output_linear.bias.double()).numpy()
+        got = O[:, :want.shape[1]]
+        # (16-bit modes: the emulation keeps fp64 activations, only the WEIGHTS carry the 16-bit rounding)
+        assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), (np.abs(got - want).max(), np.abs(want).max())
+    if rb is not None:
+        _, _, info_b, st_b, un_b, bi_b = _pack(cfg, precision, 9)
+        assert info_b.frag_bytes == 256                                        # the bender program is always fp32
+        O, (ke, kv, kh, latw) = _run_generic_program(info_b, st_b, un_b, bi_b, "f32", np.concatenate([pts, lat], -1), pts)
+        assert latw == cfg.latent_size and kv == 16
+        with torch.no_grad():
+            h = torch.from_numpy(np.concatenate([pts, lat], -1))
+            for i, lin in enumerate(rb.network):
+                h = F.linear(h, lin.weight.double(), lin.bias.double() if lin.bias is not None else None)
+                if i < len(rb.network) - 1:
+                    h = F.relu(h)
+            r = torch.from_numpy(pts)
+            for i, lin in enumerate(rb.rigidity_network):
+                r = F.linear(r, lin.weight.double(), lin.bias.double())
+                if i < len(rb.rigidity_network) - 1:
+                    r = F.relu(r)
+        assert np.abs(O[:, :3] - h.numpy()).max() <= 1e-5 and np.abs(O[:, 3:4] - r.numpy()).max() <= 1e-5
+
+
+def test_compiled_shapes_are_not_generic_and_exact_directions_stay_unsupported_there():
+    """nrnerf_pack_host 7 works for any supported shape (also a compiled one); exact Jacobian directions have no generic kernel."""
+    cfg = SceneConfig(N_importance=64, netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False)
+    scene = make_scene(cfg, 3)
+    rb, coarse, fine = build_modules(scene)
+    desc, keep = build_model_desc(coarse, fine, "f32", 0)
+    lib = _lib.load()
+    info = _lib.PackedInfo()
+    rc = lib.nrnerf_pack_host(C.byref(desc), 7, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)())
+    assert rc == _lib.ERR_UNSUPPORTED
+    # a width beyond the generic kernel's limit
+    cfg = SceneConfig(N_importance=64, netwidth=640)
+    rb, coarse, fine = build_modules(make_scene(cfg, 3))
+    desc, keep = build_model_desc(coarse, fine, "f32", 0)
+    assert lib.nrnerf_pack_host(C.byref(desc), 7, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_UNSUPPORTED
