@@ -445,7 +445,8 @@ def pmc_traffic(args):
         if j.get("kernel_source_sha16") != kernel_source_sha16():
             return None, f"null: {name} was collected from different kernel sources"
         return float(j["fine"]["hbm_bytes_per_launch"]), ("bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from rocprofv3 --pmc passes "
-                                                          f"of these kernel sources ({name.replace('_pmc_fine.json', '_pmc_summary.txt')}); by design 1.21e9 (16 B/sample in + 16 B/sample out)")
+                                                          f"of these kernel sources ({name.replace('_pmc_fine.json', '_pmc_summary.txt')}); by design 0.76e9 since the compositing is fused "
+                                                          "into the kernel (16 B/sample of points + 4 B/sample of depths in, 44 B/ray out; was 1.21e9 with raw written out)")
     except Exception as e:
         return None, f"null: {type(e).__name__}"
 

@@ -516,6 +516,7 @@ void gen_finish(GenProgram& g, int precision) {
     const int FB = precision == NRNERF_PREC_F32 ? 256 : 1024;
     g.pk.frag_bytes = FB; g.pk.slot_bytes = FB;
     g.pk.ntiles = (int)(g.pk.bias.size() / 32);
+    g.proto.n_bias_tiles = g.pk.ntiles;
     g.pk.nunits = (int)(g.pk.stream.size() / FB);
     g.pk.unit_off.assign(1, 0);
 }
@@ -682,6 +683,8 @@ struct nrnerf_model {
     bool bend_train_ok = false;
     // generic architecture (nrnerf_generic.h): layer programs instead of compiled plans; gen_* hold their packed images
     bool generic = false;
+    int gen_compiled_bender = -1;   // >= 0: the bender has one of the compiled shapes (0: 5 x 64, 1: 7 x 64; latent 32, rigidity 3 x 32) and the
+                                    // stand-alone bender kernel (nrnerf_bend.h, image `bend_only`) takes the passes without detail outputs
     GenArgs gen_bend_prog{}, gen_coarse_prog{}, gen_fine_prog{};
     PassDev gen_bend, gen_coarse, gen_fine;
     bool gen_fine_is_coarse = false;
@@ -817,6 +820,18 @@ int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t ref
     return rc;
 }
 
+// does the bender have compiled architecture A's bender shape?  (check_arch_t's bender part)
+template <class A>
+bool bender_matches(const nrnerf_bender_desc& b) {
+    if (b.latent_size != A::LAT || b.depth != A::BD || b.hidden != A::BW || b.rigidity_depth != A::RD || b.rigidity_hidden != A::RW) return false;
+    if (!b.network || !b.rigidity_network) return false;
+    for (int i = 0; i < A::BD; ++i)
+        if (!linear_is(b.network[i], (i == A::BD - 1) ? 3 : A::BW, (i == 0) ? 3 + A::LAT : A::BW, i != A::BD - 1)) return false;
+    for (int i = 0; i < A::RD; ++i)
+        if (!linear_is(b.rigidity_network[i], (i == A::RD - 1) ? 1 : A::RW, (i == 0) ? 3 : A::RW, true)) return false;
+    return true;
+}
+
 // ---- models of an architecture outside the compiled set (nrnerf_generic.h)
 int gen_pack_all(const nrnerf_model_desc& d, const FlatLayout* lay, GenProgram& gb, GenProgram& gc, GenProgram& gf) {
     if (d.exact_viewdirs && d.bender && d.coarse->use_viewdirs) return NRNERF_ERR_UNSUPPORTED;      // Jacobian directions: compiled kernels only
@@ -860,6 +875,23 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
         if (rc != NRNERF_OK) return rc;
         m->gen_bend_prog = gb.proto;
         m->gen_bend.algo_flops_per_sample = 2.0 * (algo_macs(d, *d.coarse) - algo_macs(d2, *d.coarse));
+        // the usual case -- an odd TRUNK with the reference's hard-coded bender (rnh:406-407): its compiled stand-alone kernel
+        const int cb = bender_matches<ArchDefault>(*d.bender) ? 0 : (bender_matches<ArchDeepBend>(*d.bender) ? 1 : -1);
+        if (cb >= 0) {
+            PackedPass pb;
+            auto go = [&](auto sh) {
+                using SH = decltype(sh);
+                if (cb == 0) pack_pass<SH, ArchDefault, true, false, false>(d, *d.coarse, d.precision, pb, &lay);
+                else pack_pass<SH, ArchDeepBend, true, false, false>(d, *d.coarse, d.precision, pb, &lay);
+            };
+            if (d.precision == NRNERF_PREC_F32) go(ShapeF32{});
+            else if (d.precision == NRNERF_PREC_BF16) go(Shape16Fast{});
+            else go(Shape16{});
+            rc = upload_pass(pb, m->bend_only);
+            if (rc != NRNERF_OK) return rc;
+            m->bend_only.algo_flops_per_sample = m->gen_bend.algo_flops_per_sample;
+            m->gen_compiled_bender = cb;
+        }
     }
     rc = upload_pass(gc.pk, m->gen_coarse);
     if (rc != NRNERF_OK) return rc;
@@ -888,6 +920,20 @@ int update_generic(nrnerf_model* m, const nrnerf_model_desc& d, hipStream_t stre
     if (rc != NRNERF_OK) return rc == NRNERF_ERR_UNSUPPORTED ? NRNERF_ERR_INVALID : rc;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
+    PackedPass pb;
+    if (d.bender && m->gen_compiled_bender >= 0) {
+        auto go = [&](auto sh) {
+            using SH = decltype(sh);
+            if (m->gen_compiled_bender == 0) pack_pass<SH, ArchDefault, true, false, false>(d, *d.coarse, d.precision, pb, nullptr);
+            else pack_pass<SH, ArchDeepBend, true, false, false>(d, *d.coarse, d.precision, pb, nullptr);
+        };
+        if (!(m->gen_compiled_bender == 0 ? bender_matches<ArchDefault>(*d.bender) : bender_matches<ArchDeepBend>(*d.bender))) return NRNERF_ERR_INVALID;
+        if (d.precision == NRNERF_PREC_F32) go(ShapeF32{});
+        else if (d.precision == NRNERF_PREC_BF16) go(Shape16Fast{});
+        else go(Shape16{});
+        rc = refresh_pass(pb, m->bend_only, stream);
+        if (rc != NRNERF_OK) return rc;
+    }
     if (d.bender) rc = refresh_pass(gb.pk, m->gen_bend, stream);         // (sizes differ for another architecture: NRNERF_ERR_INVALID)
     if (rc == NRNERF_OK) rc = refresh_pass(gc.pk, m->gen_coarse, stream);
     if (rc == NRNERF_OK && d.fine) rc = refresh_pass(gf.pk, m->gen_fine, stream);
@@ -1252,6 +1298,15 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         //      the composite kernel.  Kernel slots of the profile: 5 / 4 = bender of the coarse / fine pass.
         const bool bend = m->has_bend != 0, views = m->views != 0;
         auto bender_pass = [&](const float* zv, int nS, float* out4, const nrnerf_sample_outputs& so, int slot) -> hipError_t {
+            if (m->gen_compiled_bender >= 0 && !any_detail(so) && (long long)N * ((nS + 31) / 32) < (1ll << 31)) {
+                // the reference's own bender shape: the compiled stand-alone kernel (weights resident in LDS), all nS samples of a ray
+                BendArgs b{};
+                b.rays = a->rays; b.ray_stride = a->ray_stride; b.latents = a->latents; b.lat_stride = a->latent_stride;
+                b.z = zv; b.lindisp = a->lindisp; b.rank = nullptr; b.n_rays = N; b.n_per_ray = nS; b.out_stride = nS;
+                b.wstream = m->bend_only.stream; b.bias = m->bend_only.bias; b.bent4 = out4; b.knobs = kn;
+                return timed(slot, (double)N * nS * m->bend_only.algo_flops_per_sample, 0,
+                             [&] { return launch_bend(m->precision, m->gen_compiled_bender, b, m->num_cus, stream); });
+            }
             GenArgs g = m->gen_bend_prog;
             g.rays = a->rays; g.ray_stride = a->ray_stride; g.latents = a->latents; g.lat_stride = a->latent_stride;
             g.z = zv; g.lindisp = a->lindisp; g.n_rays = N; g.S = nS;

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_bwd_kernel(const C
     const float* rp = a.rays + (size_t)ray * a.ray_stride;
     const float dx = rp[3], dy = rp[4], dz = rp[5];
     const float near = rp[6], far = rp[7];
-    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));      // as composite_ray
+    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(rounded(dx * dx), rounded(dy * dy)), rounded(dz * dz)));      // as composite_ray
 
     float z[EPL + 1], sig[EPL], col[EPL][3];
 #pragma unroll

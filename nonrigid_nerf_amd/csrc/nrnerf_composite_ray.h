@@ -14,6 +14,12 @@
 
 #include "nrnerf_kernels.h"
 
+// NRN_FUSE_PREFETCH (build-time, experiments): 0 = the fused epilogue loads its inputs itself, 1 = only the ray direction is
+// requested ahead, 2 = direction and depths (default)
+#ifndef NRN_FUSE_PREFETCH
+#define NRN_FUSE_PREFETCH 2
+#endif
+
 namespace nrn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,6 +29,9 @@ __device__ __forceinline__ float c_lin01(int i, int n) {     // torch.linspace(0
     const float step = __fdiv_rn(1.0f, (float)(n - 1));
     return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
 }
+
+// a value the optimiser cannot look into: whatever produced it is rounded to fp32 here, nothing is fused across it
+__device__ __forceinline__ float rounded(float x) { asm("" : "+v"(x)); return x; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -45,8 +54,9 @@ __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
 // lane * epl + k (k < epl <= 4; only when the pass has explicit depths)
 __device__ __forceinline__ void composite_prefetch(const CompositeArgs& a, const int ray, const int lane, const int epl, float (&out)[8]) {
     const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    if (NRN_FUSE_PREFETCH == 0) return;
     out[0] = rp[3]; out[1] = rp[4]; out[2] = rp[5];
-    if (a.z) {
+    if (a.z && NRN_FUSE_PREFETCH >= 2) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = lane * epl + k, ic = i < a.S ? i : a.S - 1;
@@ -62,15 +72,19 @@ __device__ __forceinline__ void composite_prefetch(const CompositeArgs& a, const
 template <int EPL, class RAWF>
 __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int ray, const bool ray_ok, const int lane,
                                               RAWF&& raw_at, float (&z)[EPL + 1], float (&w)[EPL], const float* pre = nullptr) {
+    // No multiply-add fusion the source does not spell out (__fmaf_rn).  hipcc's `__fmul_rn` / `__fadd_rn` are plain * and +, this
+    // build's -ffp-contract=fast fuses them wherever a product feeds a sum IN ONE BASIC BLOCK (pragmas are not honoured), and
+    // which blocks an instantiation ends up with depends on everything around it: with the ray direction prefetched a tile ahead
+    // the 16-bit network kernels evaluated |d| as fma(dz, dz, dx*dx + dy*dy) where the composite kernel did not -- an ulp of
+    // `dnorm`, hence of every alpha, on 1 % of the rays (tools/experiments/debug_fused_composite.py).  `rounded()` hides a product
+    // from the optimiser, so it is rounded before it is added in every instantiation.
     const int S = a.S;
     const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    if (NRN_FUSE_PREFETCH == 0) pre = nullptr;
     const float dx = pre ? pre[0] : rp[3], dy = pre ? pre[1] : rp[4], dz = pre ? pre[2] : rp[5];
     float near = 0.0f, far = 0.0f;
     if (!a.z) { near = rp[6]; far = rp[7]; }
-    // (every sum below is written with explicit rounding: left to -ffp-contract the compiler fuses a multiply into an add only
-    //  when both sit in one basic block, which differs between the instantiations of this function -- measured: an ulp on 1 % of
-    //  the rays between the fused epilogue with prefetched inputs and the composite kernel)
-    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));   // train.py:748
+    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(rounded(dx * dx), rounded(dy * dy)), rounded(dz * dz)));      // train.py:748
 
     // ---- load this lane's samples
     float sig[EPL], col[EPL][3];
@@ -78,14 +92,14 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int 
     for (int k = 0; k < EPL; ++k) {
         const int i = lane * EPL + k;
         const int ic = i < S ? i : S - 1;
-        if (a.z) z[k] = pre ? pre[3 + k] : a.z[(size_t)ray * S + ic];
+        if (a.z) z[k] = (pre && NRN_FUSE_PREFETCH >= 2) ? pre[3 + k] : a.z[(size_t)ray * S + ic];
         else {
             const float t = c_lin01(ic, S);
             if (a.lindisp)                                                               // train.py:850-852
-                z[k] = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)),
-                                                 __fmul_rn(__fdiv_rn(1.0f, far), t)));
+                z[k] = __fdiv_rn(1.0f, __fadd_rn(rounded(__fdiv_rn(1.0f, near) * __fsub_rn(1.0f, t)),
+                                                 rounded(__fdiv_rn(1.0f, far) * t)));
             else
-                z[k] = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));   // train.py:849
+                z[k] = __fadd_rn(rounded(near * __fsub_rn(1.0f, t)), rounded(far * t));     // train.py:849
         }
         const f32x4 r = raw_at(ic);
         col[k][0] = r[0]; col[k][1] = r[1]; col[k][2] = r[2]; sig[k] = r[3];

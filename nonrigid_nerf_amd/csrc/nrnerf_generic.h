@@ -60,8 +60,10 @@ __device__ __forceinline__ typename PX::frag gen_bfrag(const void* buf, int stri
     }
 }
 
-template <class P, int NSB>
-__global__ void __launch_bounds__(GEN_WAVES * 64, NSB == 1 ? 2 : 1) gen_kernel(const GenArgs a) {
+// MAXT: output tiles per wave and layer the instantiation has accumulators for (2: widths <= 256, half the registers, two
+// workgroups per CU; 4: widths <= 512)
+template <class P, int NSB, int MAXT>
+__global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen_kernel(const GenArgs a) {
     using PE = typename GenTypes<P>::PE;
     using elem = typename GenTypes<P>::elem;
     constexpr int PAD = GenTypes<P>::PAD;
@@ -73,7 +75,14 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, NSB == 1 ? 2 : 1) gen_kernel(c
     elem* H = V + (size_t)NS * sv;
     float* O = (float*)(H + (size_t)NS * sh);                               // [NS][8]
     float* Pt = O + NS * 8;                                                 // [NS][8]: point xyz, (bender) unit direction / spare
+    float* Bt = Pt + NS * 8;                                                // the program's whole bias table (a.bias_in_lds)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    // biases from LDS, not from L2 once per layer and tile: nothing overlaps that latency with one or two workgroups per CU
+    if (a.bias_in_lds) {
+        for (int i = tid; i < a.n_bias_tiles * 32; i += GEN_WAVES * 64) Bt[i] = a.bias[i];
+        __syncthreads();
+    }
+    const float* bias_tab = a.bias_in_lds ? Bt : a.bias;
     const int S = a.S;
     const long long M = (long long)a.n_rays * S;
     const long long ntile = (M + NS - 1) / NS;
@@ -151,18 +160,30 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, NSB == 1 ? 2 : 1) gen_kernel(c
         }
         __syncthreads();
 
-        // ---- layers
+        // ---- layers.  The first weight fragments of layer l + 1 are requested before layer l's outputs are written back (two
+        //      barriers away from their use): per layer only the k-slab pipeline's steady state is left exposed.
+        typedef typename P::frag wfrag;                    // (fragments against E / V are f16, against H the model's type: same size)
+        wfrag nxt[MAXT];
+        auto first_frags = [&](int li) {
+            const GenLayer& ly = a.layer[li];
+            const char* wb = (const char*)a.wstream + (size_t)ly.w_frag * FB + (size_t)lane * (FB / 64);
+            const int ns = ly.ns0 + ly.ns1;
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i)
+                if (wave + i * GEN_WAVES < ly.nt) nxt[i] = *(const wfrag*)(wb + (size_t)(wave + i * GEN_WAVES) * ns * FB);
+        };
+        first_frags(0);
         for (int li = 0; li < a.n_layers; ++li) {
             const GenLayer& ly = a.layer[li];
             const int ns = ly.ns0 + ly.ns1;
-            f32x16 acc[GEN_MAXT][NSB];
+            f32x16 acc[MAXT][NSB];
             int ntw = 0;                                   // this wave's tiles: wave, wave + 4, ...
 #pragma unroll
-            for (int i = 0; i < GEN_MAXT; ++i) {
+            for (int i = 0; i < MAXT; ++i) {
                 const int t = wave + i * GEN_WAVES;
                 if (t < ly.nt) {
                     ntw = i + 1;
-                    const f32x4* bp = (const f32x4*)(a.bias + ((size_t)(ly.bias_tile + t) * 32 + h * 16));
+                    const f32x4* bp = (const f32x4*)(bias_tab + ((size_t)(ly.bias_tile + t) * 32 + h * 16));
                     const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
                     const f32x16 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
 #pragma unroll
@@ -172,54 +193,72 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, NSB == 1 ? 2 : 1) gen_kernel(c
             const char* wbase = (const char*)a.wstream + (size_t)ly.w_frag * FB + (size_t)lane * (FB / 64);
             auto src_ptr = [&](int b) -> const void* { return b == GB_E ? (const void*)E : (b == GB_V ? (const void*)V : (const void*)H); };
             auto src_stride = [&](int b) { return b == GB_E ? se : (b == GB_V ? sv : sh); };
-            auto run = [&](auto pxc, const void* buf, int stride, int s_begin, int s_count) {
+            auto run = [&](auto pxc, const void* buf, int stride, int s_begin, int s_count, bool have_first) {
                 using PX = typename decltype(pxc)::type;
-                // weight fragments of slab s + 1 are requested (from L2) before the MFMAs of slab s: with one or two workgroups
-                // per CU nothing else hides that latency
-                typename PX::frag af[GEN_MAXT], an[GEN_MAXT];
-                auto fetch = [&](typename PX::frag (&dst)[GEN_MAXT], int s) {
+                // weight fragments of slab s + 1 are requested (from L2) before the MFMAs of slab s
+                typename PX::frag af[MAXT], an[MAXT];
+                auto fetch = [&](typename PX::frag (&dst)[MAXT], int s) {
 #pragma unroll
-                    for (int i = 0; i < GEN_MAXT; ++i)
+                    for (int i = 0; i < MAXT; ++i)
                         if (i < ntw) dst[i] = *(const typename PX::frag*)(wbase + ((size_t)(wave + i * GEN_WAVES) * ns + s_begin + s) * FB);
                 };
-                if (s_count > 0) fetch(af, 0);
+                if (have_first) {
+#pragma unroll
+                    for (int i = 0; i < MAXT; ++i) af[i] = __builtin_bit_cast(typename PX::frag, nxt[i]);
+                } else if (s_count > 0) {
+                    fetch(af, 0);
+                }
                 for (int s = 0; s < s_count; ++s) {
                     if (s + 1 < s_count) fetch(an, s + 1);
                     typename PX::frag bf[NSB];
 #pragma unroll
                     for (int sb = 0; sb < NSB; ++sb) bf[sb] = gen_bfrag<PX>(buf, stride, sb * 32 + j, s, h);
 #pragma unroll
-                    for (int i = 0; i < GEN_MAXT; ++i) {
+                    for (int i = 0; i < MAXT; ++i) {
                         if (i < ntw) {
 #pragma unroll
                             for (int sb = 0; sb < NSB; ++sb) acc[i][sb] = PX::mfma(af[i], bf[sb], acc[i][sb]);
                         }
                     }
 #pragma unroll
-                    for (int i = 0; i < GEN_MAXT; ++i) af[i] = an[i];
+                    for (int i = 0; i < MAXT; ++i) af[i] = an[i];
                 }
             };
             struct TagE { using type = PE; };
             struct TagH { using type = P; };
-            if (ly.src0 == GB_H) run(TagH{}, src_ptr(GB_H), sh, 0, ly.ns0); else run(TagE{}, src_ptr(ly.src0), src_stride(ly.src0), 0, ly.ns0);
+            if (ly.src0 == GB_H) run(TagH{}, src_ptr(GB_H), sh, 0, ly.ns0, true); else run(TagE{}, src_ptr(ly.src0), src_stride(ly.src0), 0, ly.ns0, true);
             if (ly.ns1 > 0) {
-                if (ly.src1 == GB_H) run(TagH{}, src_ptr(GB_H), sh, ly.ns0, ly.ns1); else run(TagE{}, src_ptr(ly.src1), src_stride(ly.src1), ly.ns0, ly.ns1);
+                if (ly.src1 == GB_H) run(TagH{}, src_ptr(GB_H), sh, ly.ns0, ly.ns1, false); else run(TagE{}, src_ptr(ly.src1), src_stride(ly.src1), ly.ns0, ly.ns1, false);
             }
+            if (li + 1 < a.n_layers) first_frags(li + 1);
             __syncthreads();                               // every wave has read the layer's inputs: H may be overwritten
 #pragma unroll
-            for (int i = 0; i < GEN_MAXT; ++i) {
+            for (int i = 0; i < MAXT; ++i) {
                 if (i < ntw) {
                     const int t = wave + i * GEN_WAVES;
 #pragma unroll
                     for (int sb = 0; sb < NSB; ++sb) {
                         const int n = sb * 32 + j;
+                        if (ly.dst == GB_H) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;      // CDNA4 C/D layout (nrnerf_plan.h::tile_row)
-                            float v = acc[i][sb][r];
-                            if (ly.relu) v = fmaxf(v, 0.0f);
-                            if (ly.dst == GB_H) H[(size_t)n * sh + row] = gen_cvt<P>(v);
-                            else if (row < ly.o_rows) O[n * 8 + ly.o_col + row] = v;
+                            for (int q = 0; q < 4; ++q) {          // registers 4q .. 4q + 3 = rows 32 t + 8 q + 4 h + (0..3) (nrnerf_plan.h::tile_row)
+                                float v[4];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) v[c] = ly.relu ? fmaxf(acc[i][sb][4 * q + c], 0.0f) : acc[i][sb][4 * q + c];
+                                elem* dstp = H + (size_t)n * sh + 32 * t + 8 * q + 4 * h;
+                                if constexpr (KH == 1) {
+                                    dstp[0] = v[0]; dstp[1] = v[1]; dstp[2] = v[2]; dstp[3] = v[3];
+                                } else {                           // four 16-bit values = one 8-byte LDS store (rows are 8-byte aligned)
+                                    typedef unsigned short u16x4_ __attribute__((ext_vector_type(4)));
+                                    *(u16x4_*)dstp = u16x4_{gen_cvt<P>(v[0]), gen_cvt<P>(v[1]), gen_cvt<P>(v[2]), gen_cvt<P>(v[3])};
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                if (row < ly.o_rows) O[n * 8 + ly.o_col + row] = ly.relu ? fmaxf(acc[i][sb][r], 0.0f) : acc[i][sb][r];
+                            }
                         }
                     }
                 }
@@ -271,31 +310,42 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, NSB == 1 ? 2 : 1) gen_kernel(c
     }
 }
 
-template <class P, int NSB>
-static hipError_t launch_gen(const GenArgs& a, int num_cus, hipStream_t stream) {
+template <class P, int NSB, int MAXT>
+static hipError_t launch_gen_t(const GenArgs& a_in, int num_cus, hipStream_t stream) {
     constexpr int PAD = GenTypes<P>::PAD, NS = 32 * NSB;
     const size_t es = sizeof(typename GenTypes<P>::elem);
-    if (a.ke % 16 || a.kv % 16 || a.kh % 16 || a.ke > GEN_MAX_E || a.kv > GEN_MAX_V || a.kh > GEN_MAX_W || a.n_layers < 1 ||
-        a.n_layers > GEN_MAX_LAYERS) return hipErrorInvalidValue;
-    const size_t lds = (size_t)NS * ((a.ke + PAD) + (a.kv + PAD) + (a.kh + PAD)) * es + (size_t)NS * 16 * sizeof(float);
-    auto kern = gen_kernel<P, NSB>;
+    GenArgs a = a_in;
+    const size_t act = (size_t)NS * ((a.ke + PAD) + (a.kv + PAD) + (a.kh + PAD)) * es + (size_t)NS * 16 * sizeof(float);
+    a.bias_in_lds = (a.n_bias_tiles > 0 && a.n_bias_tiles <= 320) ? 1 : 0;            // <= 40 KB of biases
+    const size_t lds = act + (a.bias_in_lds ? (size_t)a.n_bias_tiles * 128 : 0);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = gen_kernel<P, NSB, MAXT>;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        const size_t lds_max = (size_t)NS * ((GEN_MAX_E + PAD) + (GEN_MAX_V + PAD) + (GEN_MAX_W + PAD)) * es + (size_t)NS * 16 * sizeof(float);
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const long long M = (long long)a.n_rays * a.S;
     const long long ntile = (M + NS - 1) / NS;
     if (ntile <= 0) return hipSuccess;
-    // two workgroups per CU when LDS allows (fp32 instantiation; the 16-bit one holds 2 x 4 output tiles per wave: 512 registers)
-    const long long resident = (long long)num_cus * ((NSB == 1 && 2 * lds + 4096 <= 160 * 1024) ? 2 : 1);
+    // workgroups per CU: by registers (launch bounds: two when NSB * MAXT <= 4) and by LDS
+    const long long by_regs = (NSB * MAXT <= 4) ? 2 : 1, by_lds = (long long)(160 * 1024) / (long long)(lds + 1024);
+    const long long resident = (long long)num_cus * (by_regs < by_lds ? by_regs : (by_lds < 1 ? 1 : by_lds));
     const int grid = (int)(ntile < resident ? ntile : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEN_WAVES * 64), lds, stream, a);
     return hipGetLastError();
+}
+template <class P, int NSB>
+static hipError_t launch_gen(const GenArgs& a, int num_cus, hipStream_t stream) {
+    if (a.ke % 16 || a.kv % 16 || a.kh % 16 || a.ke > GEN_MAX_E || a.kv > GEN_MAX_V || a.kh > GEN_MAX_W || a.n_layers < 1 ||
+        a.n_layers > GEN_MAX_LAYERS) return hipErrorInvalidValue;
+    int widest = 0;
+    for (int l = 0; l < a.n_layers; ++l) widest = a.layer[l].nt > widest ? a.layer[l].nt : widest;
+    if (widest > GEN_WAVES * GEN_MAXT) return hipErrorInvalidValue;
+    return (widest <= GEN_WAVES * 2) ? launch_gen_t<P, NSB, 2>(a, num_cus, stream) : launch_gen_t<P, NSB, 4>(a, num_cus, stream);
 }
 
 }  // namespace nrn

@@ -321,6 +321,8 @@ struct GenArgs {
     int n_layers;
     GenLayer layer[GEN_MAX_LAYERS];
     int ke, kv, kh;              // padded row widths of E, V and H in elements (multiples of 16; kh = the widest hidden layer)
+    int n_bias_tiles;            // tiles of the bias table (all layers)
+    int bias_in_lds;             // set by the launcher: the whole table fits next to the activation buffers
     // outputs
     float* raw4; float* raw_out; int raw_ch;        // network
     float* bent4;                // bender: [N,S,4] bent point + rigidity mask (network: read for the removal knob when detailed)
