@@ -223,6 +223,11 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C nonrigid_nerf_amd/csrc -j8`). nonrigid_nerf_amd has no CPU fallback.")
+        # PyTorch-ROCm first: the wheel ships its own HIP runtime (torch/lib/libamdhip64.so), this library is linked against the
+        # system's.  Loaded after torch, it binds to the runtime already in the process; loaded BEFORE torch, the process ends up
+        # with two runtimes and torch's device memory is foreign to this library's (seen on the MI355X as NRNERF_ERR_HIP from
+        # nrnerf_model_create when __graft_entry__.build() and smoke() ran in one process).
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export what nrnerf.h declares
