@@ -20,6 +20,11 @@ CASES = {
     "deep bender + viewdirs": dict(use_viewdirs=True, N_importance=64, bend_depth=7),
     "time-conditioned":      dict(ray_bending=False, time_conditioned_baseline=True, N_importance=64),
     "width 128":             dict(netwidth=128, N_importance=64),
+    # round 4: the fused compositing epilogue (LDS stages, prefetched inputs) is on every plain render above; odd block counts per ray and
+    # the run-time-parameterised kernel (LDS activation buffers, two barriers per layer) get their own rows
+    "odd blocks 64+96":      dict(N_importance=96),
+    "generic 192/320":       dict(netdepth=6, netwidth=192, netwidth_fine=320, multires=8, latent_size=16, N_importance=64),
+    "generic viewdirs 96":   dict(netwidth=96, use_viewdirs=True, multires_views=2, N_importance=64),
 }
 bad = 0
 for name, kw in CASES.items():
