@@ -14,8 +14,9 @@ Call contract mirrored:
 * output: dict with exactly the reference's keys / shapes / dtypes (train.py:952-972), freshly
   allocated on the rays' device.
 
-Everything is computed by ``libnrnerf_hip.so``.  Configurations the library has no kernel for
-(autograd, exact non-rigid view directions, other widths, ...) are handed back to the
+Everything is computed by ``libnrnerf_hip.so`` -- the compiled architectures on their specialised kernels, any other
+depth / width / encoding / latent size on the run-time-parameterised one.  Calls the library has no kernel for
+(training of a non-compiled architecture, exact non-rigid view directions there or under autograd, ...) are handed back to the
 *reference's own* function when one was saved by ``install``; otherwise they raise.  There is
 no CPU or PyTorch re-implementation in this package.
 """
