@@ -116,10 +116,10 @@ def build_workload(args, rank, world, dev, frame_rays=None, scaling=None):
         from nonrigid_nerf_amd.checkpoint import load_checkpoint
         from nonrigid_nerf_amd.driver import generate_rays
         from nonrigid_nerf_amd.synthetic import Scene
-        ck = load_checkpoint(FITTED, N_samples=64, N_importance=128)
+        ck = load_checkpoint(args.fitted_ckpt, N_samples=64, N_importance=128)
         z = np.load(FIXTURE)
         near, far = float(z["bds"].min()) * 0.9, float(z["bds"].max())
-        cfg = SceneConfig(near=near, far=far)
+        cfg = SceneConfig(near=near, far=far, use_viewdirs=args.use_viewdirs, bend_depth=args.bend_depth, netwidth=args.netwidth)
         sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
         scene = Scene(cfg, sd(ck.ray_bender), sd(ck.network_fn), sd(ck.network_fine))
         rb, coarse, fine = ck.ray_bender, ck.network_fn, ck.network_fine
@@ -128,14 +128,14 @@ def build_workload(args, rank, world, dev, frame_rays=None, scaling=None):
         s = 512.0 / float(z["hwf"][1])
         intrin = dict(height=384, width=512, focal_x=float(z["hwf"][2]) * s, focal_y=float(z["hwf"][2]) * s,
                       center_x=256.0, center_y=192.0)
-        rays = generate_rays(torch.from_numpy(z["poses"][frame]), intrin, near, far, False, dev)
+        rays = generate_rays(torch.from_numpy(z["poses"][frame]), intrin, near, far, bool(args.use_viewdirs), dev)
         reps = (n + rays.shape[0] - 1) // rays.shape[0]
         rays = rays.repeat(reps, 1)[:n]
         rays = _pad_rows(rays[lo:hi], per).contiguous()   # strong: this rank's slice (the last rank's padded to equal blocks)
         code = ck.latents[frame].to(dev).reshape(1, -1)
         latents = code.expand(per, -1)                   # stride-0 view, as render_path passes it (train.py:464-466)
         desc = (f"example_sequence frame {int(z['frame_ids'][frame])} camera rays at 512x384, weights fitted to the "
-                f"down-sampled sequence ({ck.global_step} oracle iterations, tests/golden/fitted_latest.tar), one latent per frame")
+                f"down-sampled sequence ({ck.global_step} oracle iterations, tests/golden/{os.path.basename(args.fitted_ckpt)}), one latent per frame")
         return scene, cfg, (rb, coarse, fine), rays, latents, desc
     cfg = SceneConfig(use_viewdirs=args.use_viewdirs, bend_depth=args.bend_depth,      # default: 64 + 128, W = 256, bender on, latent 32
                       approx_nonrigid_viewdirs=not args.exact_viewdirs, netwidth=args.netwidth)
@@ -153,10 +153,29 @@ def _pad_rows(t, rows):
     return torch.cat([t, t[-1:].expand(rows - t.shape[0], -1)], 0)
 
 
+def fitted_checkpoint_for(args):
+    gold = os.path.join(REPO, "tests", "golden")
+    if args.exact_viewdirs:
+        return None
+    if not args.use_viewdirs and args.bend_depth == 5 and args.netwidth == 256:
+        name = "fitted_latest.tar"
+    elif args.use_viewdirs and args.bend_depth == 7 and args.netwidth == 256:
+        name = "fitted_config4.tar"
+    elif not args.use_viewdirs and args.bend_depth == 5 and args.netwidth == 128:
+        name = "fitted_w128.tar"
+    else:
+        return None
+    path = os.path.join(gold, name)
+    return path if os.path.exists(path) else None
+
+
 def main():
     args = parse_args()
-    if args.use_viewdirs or args.bend_depth != 5 or args.exact_viewdirs or args.netwidth != 256:
-        args.scene = "synthetic"          # the fitted checkpoint is the default architecture only
+    # a fitted checkpoint exists for each compiled architecture FAMILY (oracle/fit_checkpoint.py --arch ...): the default one,
+    # BASELINE config 4 (view-dependent head + 7-layer bender) and width 128; any other variant runs on the synthetic stress scene
+    args.fitted_ckpt = fitted_checkpoint_for(args)
+    if args.fitted_ckpt is None:
+        args.scene = "synthetic"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
 
@@ -434,7 +453,8 @@ def pmc_traffic(args):
     hash of the kernel sources they profiled.  Reported only when that hash matches the sources of this checkout and the
     workload is the profiled one; otherwise null (a stale number is worse than none)."""
     path = _latest_profile("_pmc_fine.json")
-    if args.rays != 196608 or args.precision != "bf16" or not path:
+    default_arch = not (args.use_viewdirs or args.exact_viewdirs or args.bend_depth != 5 or args.netwidth != 256)
+    if args.rays != 196608 or args.precision != "bf16" or not path or not default_arch or os.environ.get("NRNERF_FORCE_GENERIC") == "1":
         return None, "null: no rocprofv3 --pmc pass of this build and workload on file (profiles/rNN_pmc_fine.json)"
     name = os.path.relpath(path, REPO)
     try:

@@ -845,6 +845,12 @@ int gen_pack_all(const nrnerf_model_desc& d, const FlatLayout* lay, GenProgram& 
     if (d.fine) gen_pack_mlp(d, *d.fine, gf, lay);
     return NRNERF_OK;
 }
+// issued MFMA flops per sample of a layer program (padding included): every (tile, k-slab) is one 32 x 32 x KS MFMA per 32 samples
+double gen_mfma_flops_per_sample(const GenArgs& g, bool f32) {
+    double f = 0;
+    for (int l = 0; l < g.n_layers; ++l) f += (double)g.layer[l].nt * (g.layer[l].ns0 + g.layer[l].ns1) * 2.0 * 32 * (f32 ? 2 : 16);
+    return f;
+}
 int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_model** out) {
     GenProgram gb, gc, gf;
     int rc = gen_pack_all(d, &lay, gb, gc, gf);
@@ -898,6 +904,7 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
     m->gen_coarse_prog = gc.proto;
     m->gen_coarse.algo_flops_per_sample = 2.0 * algo_macs(d2, *d.coarse);
     m->gen_coarse.output_ch = d.coarse->output_ch;
+    m->gen_coarse.mfma_flops_per_sample = gen_mfma_flops_per_sample(gc.proto, d.precision == NRNERF_PREC_F32);
     m->coarse.output_ch = d.coarse->output_ch;
     if (d.fine) {
         rc = upload_pass(gf.pk, m->gen_fine);
@@ -905,6 +912,7 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
         m->gen_fine_prog = gf.proto;
         m->gen_fine.algo_flops_per_sample = 2.0 * algo_macs(d2, *d.fine);
         m->gen_fine.output_ch = d.fine->output_ch;
+        m->gen_fine.mfma_flops_per_sample = gen_mfma_flops_per_sample(gf.proto, d.precision == NRNERF_PREC_F32);
     } else {
         m->gen_fine = m->gen_coarse; m->gen_fine_prog = m->gen_coarse_prog; m->gen_fine_is_coarse = true;
     }
@@ -1325,7 +1333,8 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
             g.bent4 = pts ? const_cast<float*>(pts) : bent_out;          // with a bender: read (removal knob); without: written (points of the pass)
             g.knobs = kn;
             if (!pts) g.ex = sample_out(so);                             // without a bender the network kernel reports the points
-            return timed(slot, (double)N * nS * pd.algo_flops_per_sample, 0, [&] { return launch_generic(m->precision, g, m->num_cus, stream); });
+            return timed(slot, (double)N * nS * pd.algo_flops_per_sample, (double)N * nS * pd.mfma_flops_per_sample,
+                         [&] { return launch_generic(m->precision, g, m->num_cus, stream); });
         };
         float* const bent_final = bent4_ws;                         // points of the final pass [N, S + I | S, 4]
         float* const bentA = (I > 0) ? bent_c : bent4_ws;           // points of the coarse pass: its own array when a fine pass follows

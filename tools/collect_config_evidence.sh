@@ -25,6 +25,9 @@ run config5 3 1 --rays 2073600 --precision f16 --chunk 65536 --max-rays-per-laun
 run config5_default_launch 3 1 --rays 2073600 --precision f16 --chunk 65536 --psnr-rays 65536
 run w128 10 3 --netwidth 128
 run strong_shard_24576 20 5 --rays 24576
+# round 4: shapes outside the compiled set (the run-time-parameterised kernel, csrc/nrnerf_generic.h), synthetic weights
+run generic_w192 5 2 --netwidth 192
+run generic_w512 3 1 --netwidth 512
 cd $R
 for f in gpurun_out/${TAG}_*_bench.json; do python - "$f" <<'PY'
 import json, sys
