@@ -1415,7 +1415,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     //  where the plain mapping hands out 8-block tiles, so below one group per CU the plain mapping fills more of the chip)
     auto enough_rays_to_fuse = [&](int pass_S) {
         const int bpr = (pass_S + 31) / 32;
-        const long long rays_per_group = (m->precision == NRNERF_PREC_F32) ? 4 : ((bpr & 1) ? 8 : 4);
+        // rays per group = waves per workgroup x rays per wave: fp32 kernels 4 x 1; 16-bit two-blocks-per-wave kernels 4 x (1 or 2);
+        // 16-bit one-block-per-wave kernels (architecture 5) 8 x 1
+        const long long rays_per_group = (m->precision == NRNERF_PREC_F32) ? 4 : (m->arch_id == 5 ? 8 : ((bpr & 1) ? 8 : 4));
         return (long long)N >= rays_per_group * m->num_cus;
     };
     const bool fuse_coarse_only = I == 0 && !m->has_bend && !unfused_composite && S <= 256 && enough_rays_to_fuse(S);
