@@ -403,3 +403,21 @@ def test_data_parallel_native_training_step(tmp_path, world, backend):
         assert set(want) <= set(res["grads"]) and all(not res["grads"][k].any() for k in extra), extra
         for k, g in want.items():
             assert torch.allclose(res["grads"][k], g, rtol=1e-5, atol=1e-6 * float(g.abs().max()) + 1e-12), (r, k)
+
+
+def test_bench_picks_the_fitted_checkpoint_of_the_requested_architecture_family():
+    """bench.py renders every compiled architecture family on ITS fitted checkpoint (so `psnr_vs_oracle_db` of a non-default
+    line is measured on a realistic model, not on the synthetic stress scene); other variants fall back to synthetic weights."""
+    import argparse
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module2", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ns = lambda **kw: argparse.Namespace(**{**dict(use_viewdirs=False, bend_depth=5, netwidth=256, exact_viewdirs=False), **kw})
+    base = lambda p: os.path.basename(p) if p else None
+    assert base(bench.fitted_checkpoint_for(ns())) == "fitted_latest.tar"
+    assert base(bench.fitted_checkpoint_for(ns(use_viewdirs=True, bend_depth=7))) == "fitted_config4.tar"
+    assert base(bench.fitted_checkpoint_for(ns(netwidth=128))) == "fitted_w128.tar"
+    for other in (ns(netwidth=192), ns(use_viewdirs=True), ns(bend_depth=7), ns(use_viewdirs=True, bend_depth=7, exact_viewdirs=True)):
+        assert bench.fitted_checkpoint_for(other) is None
