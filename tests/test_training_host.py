@@ -290,3 +290,25 @@ def test_install_restores_the_previous_precision_on_uninstall():
         assert R.get_precision() == "bf16" and (mod.render_rays, mod.batchify_rays) == orig
     finally:
         R.set_precision(before)
+
+
+def test_pinned_numbers_are_held_to_twice_the_committed_value(tmp_path, monkeypatch):
+    """tests/helpers.py::check_pinned (the fp32 end-to-end fractions of the GPU tier): <= max(2 x pinned, pinned + 2 elements)
+    passes, more fails, an unpinned case fails unless a recording file is given."""
+    import json
+    from tests import helpers
+    pin = tmp_path / "pins.json"
+    pin.write_text(json.dumps({"case_a": {"moved": 0.010, "rgb": 0.0}}))
+    monkeypatch.setattr(helpers, "PIN_FILE", str(pin))
+    monkeypatch.delenv("NRNERF_PIN_RECORD", raising=False)
+    helpers.check_pinned("case_a", {"moved": 0.019, "rgb": 2.0 / 1000}, {"moved": 10000, "rgb": 1000})      # 2 x, and two elements of 1000
+    with pytest.raises(AssertionError):
+        helpers.check_pinned("case_a", {"moved": 0.021, "rgb": 0.0}, {"moved": 10000, "rgb": 1000})
+    with pytest.raises(AssertionError):
+        helpers.check_pinned("case_a", {"moved": 0.0, "rgb": 3.0 / 1000}, {"moved": 10000, "rgb": 1000})
+    with pytest.raises(AssertionError):
+        helpers.check_pinned("case_unpinned", {"moved": 0.0}, {"moved": 10})
+    rec = tmp_path / "rec.jsonl"
+    monkeypatch.setenv("NRNERF_PIN_RECORD", str(rec))
+    helpers.check_pinned("case_unpinned", {"moved": 0.5}, {"moved": 10})                                     # recording: no pin needed
+    assert json.loads(rec.read_text().splitlines()[-1]) == {"case": "case_unpinned", "measured": {"moved": 0.5}}
