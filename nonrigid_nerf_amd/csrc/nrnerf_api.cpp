@@ -463,7 +463,9 @@ struct GenSource { int buf, col0, n; };
 void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSource a, GenSource b, int dst, int relu, int o_col, const FlatLayout* lay) {
     if (g.proto.n_layers >= GEN_MAX_LAYERS) throw std::logic_error("generic program too long");
     const bool f32 = precision == NRNERF_PREC_F32;
-    const int KH = f32 ? 1 : 8, KS = 2 * KH, FB = f32 ? 256 : 1024, EB = f32 ? 4 : 2;
+    // a fragment = 64 lanes x 16 bytes in every precision: 8 16-bit k per lane (one MFMA), or 4 fp32 k per lane (four 32x32x2 MFMAs:
+    // lane half h holds k = 8 s + 4 h + e), see nrnerf_generic.h::GenTypes
+    const int KH = f32 ? 4 : 8, KS = 2 * KH, FB = 1024, EB = f32 ? 4 : 2;
     GenLayer& ly = g.proto.layer[g.proto.n_layers++];
     ly.w_frag = (int)(g.pk.stream.size() / FB);
     ly.bias_tile = (int)(g.pk.bias.size() / 32);
@@ -494,7 +496,7 @@ void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSo
                         g.pk.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)row * lin.in_features + src.col0 + k) : -1;
                         g.pk.fmt[el] = f32 ? 0 : (as_f16 ? 2 : 1);
                     }
-                    if (f32) std::memcpy(fr + lane * 4, &w, 4);
+                    if (f32) std::memcpy(fr + (lane * KH + e) * 4, &w, 4);
                     else { const uint16_t q = as_f16 ? f32_to_f16(w) : f32_to_bf16(w); std::memcpy(fr + (lane * KH + e) * 2, &q, 2); }
                 }
             }
@@ -513,7 +515,8 @@ void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSo
             }
 }
 void gen_finish(GenProgram& g, int precision) {
-    const int FB = precision == NRNERF_PREC_F32 ? 256 : 1024;
+    (void)precision;
+    const int FB = 1024;
     g.pk.frag_bytes = FB; g.pk.slot_bytes = FB;
     g.pk.ntiles = (int)(g.pk.bias.size() / 32);
     g.proto.n_bias_tiles = g.pk.ntiles;
@@ -848,7 +851,7 @@ int gen_pack_all(const nrnerf_model_desc& d, const FlatLayout* lay, GenProgram& 
 // issued MFMA flops per sample of a layer program (padding included): every (tile, k-slab) is one 32 x 32 x KS MFMA per 32 samples
 double gen_mfma_flops_per_sample(const GenArgs& g, bool f32) {
     double f = 0;
-    for (int l = 0; l < g.n_layers; ++l) f += (double)g.layer[l].nt * (g.layer[l].ns0 + g.layer[l].ns1) * 2.0 * 32 * (f32 ? 2 : 16);
+    for (int l = 0; l < g.n_layers; ++l) f += (double)g.layer[l].nt * (g.layer[l].ns0 + g.layer[l].ns1) * 2.0 * 32 * (f32 ? 8 : 16);
     return f;
 }
 int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_model** out) {

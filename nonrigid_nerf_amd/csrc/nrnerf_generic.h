@@ -33,12 +33,20 @@
 
 namespace nrn {
 
+// A "slab" of the generic kernel is one 16-byte fetch per lane of each operand: 16-bit types 8 k per lane = ONE 32x32x16 MFMA; fp32
+// 4 k per lane = FOUR 32x32x2 MFMAs (lane half h holds k = 8 s + 4 h + j, j = 0..3: MFMA j contracts the pair {8 s + j, 8 s + 4 + j}
+// -- any pairing is a valid order of the sum as long as the packed weights use the same one).  One dword per lane and MFMA, as first
+// built, left the fp32 instantiation waiting for L2 on every 64-cycle MFMA: 0.7 x the eager PyTorch path on a wide network.
 template <class P>
 struct GenTypes {
     using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;      // element type of E and V
     using elem = std::conditional_t<P::KH == 1, float, unsigned short>;
-    static constexpr int PAD = (P::KH == 1) ? 1 : 8;               // row padding in elements: conflict-free B-operand reads
+    using gfrag = std::conditional_t<P::KH == 1, f32x4, typename P::frag>;      // 16 bytes per lane either way
+    static constexpr int KHG = (P::KH == 1) ? 4 : 8;               // k per lane and slab
+    static constexpr int KSG = 2 * KHG;                            // k per slab
+    static constexpr int PAD = (P::KH == 1) ? 4 : 8;               // row padding in elements: rows stay 16-byte aligned, 128-bit reads spread over the banks
 };
+constexpr int GEN_FRAG_BYTES = 1024;                               // 64 lanes x 16 bytes, every precision
 
 __device__ __forceinline__ unsigned short gen_to_f16(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
 __device__ __forceinline__ unsigned short gen_to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
@@ -48,15 +56,26 @@ template <class P> __device__ __forceinline__ typename GenTypes<P>::elem gen_cvt
     else return gen_to_f16(v);
 }
 
-// B operand of slab s (KS columns from column s * KS) of `buf` for sample row `n`: 8 consecutive k (16-bit) / 1 k (fp32)
+// B operand of slab s of `buf` for sample row `n`: 8 (16-bit) / 4 (fp32) consecutive k from column s * KSG + h * KHG, one 128-bit LDS read
 template <class PX>
-__device__ __forceinline__ typename PX::frag gen_bfrag(const void* buf, int stride, int n, int s, int h) {
+__device__ __forceinline__ typename GenTypes<PX>::gfrag gen_bfrag(const void* buf, int stride, int n, int s, int h) {
     if constexpr (PX::KH == 1) {
-        return ((const float*)buf)[(size_t)n * stride + 2 * s + h];
+        return *(const f32x4*)((const float*)buf + (size_t)n * stride + 8 * s + 4 * h);
     } else {
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
         const u32x4_ v = *(const u32x4_*)((const unsigned short*)buf + (size_t)n * stride + 16 * s + 8 * h);
         return __builtin_bit_cast(typename PX::frag, v);
+    }
+}
+// acc += A(slab) . B(slab): one MFMA (16-bit) / four (fp32)
+template <class PX>
+__device__ __forceinline__ f32x16 gen_mfma(const typename GenTypes<PX>::gfrag& a, const typename GenTypes<PX>::gfrag& b, f32x16 acc) {
+    if constexpr (PX::KH == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = PX::mfma(a[j], b[j], acc);
+        return acc;
+    } else {
+        return PX::mfma(a, b, acc);
     }
 }
 
@@ -67,7 +86,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
     using PE = typename GenTypes<P>::PE;
     using elem = typename GenTypes<P>::elem;
     constexpr int PAD = GenTypes<P>::PAD;
-    constexpr int NS = 32 * NSB, KS = P::KS, KH = P::KH, FB = P::FRAG_BYTES;
+    constexpr int NS = 32 * NSB, KH = P::KH, FB = GEN_FRAG_BYTES;
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const int se = a.ke + PAD, sv = a.kv + PAD, sh = a.kh + PAD;            // row strides in elements
     elem* E = (elem*)gsm;
@@ -162,7 +181,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
 
         // ---- layers.  The first weight fragments of layer l + 1 are requested before layer l's outputs are written back (two
         //      barriers away from their use): per layer only the k-slab pipeline's steady state is left exposed.
-        typedef typename P::frag wfrag;                    // (fragments against E / V are f16, against H the model's type: same size)
+        typedef typename GenTypes<P>::gfrag wfrag;         // (fragments against E / V are f16, against H the model's type: same size)
         wfrag nxt[MAXT];
         auto first_frags = [&](int li) {
             const GenLayer& ly = a.layer[li];
@@ -196,28 +215,29 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             auto run = [&](auto pxc, const void* buf, int stride, int s_begin, int s_count, bool have_first) {
                 using PX = typename decltype(pxc)::type;
                 // weight fragments of slab s + 1 are requested (from L2) before the MFMAs of slab s
-                typename PX::frag af[MAXT], an[MAXT];
-                auto fetch = [&](typename PX::frag (&dst)[MAXT], int s) {
+                using GF = typename GenTypes<PX>::gfrag;
+                GF af[MAXT], an[MAXT];
+                auto fetch = [&](GF (&dst)[MAXT], int s) {
 #pragma unroll
                     for (int i = 0; i < MAXT; ++i)
-                        if (i < ntw) dst[i] = *(const typename PX::frag*)(wbase + ((size_t)(wave + i * GEN_WAVES) * ns + s_begin + s) * FB);
+                        if (i < ntw) dst[i] = *(const GF*)(wbase + ((size_t)(wave + i * GEN_WAVES) * ns + s_begin + s) * FB);
                 };
                 if (have_first) {
 #pragma unroll
-                    for (int i = 0; i < MAXT; ++i) af[i] = __builtin_bit_cast(typename PX::frag, nxt[i]);
+                    for (int i = 0; i < MAXT; ++i) af[i] = __builtin_bit_cast(GF, nxt[i]);
                 } else if (s_count > 0) {
                     fetch(af, 0);
                 }
                 for (int s = 0; s < s_count; ++s) {
                     if (s + 1 < s_count) fetch(an, s + 1);
-                    typename PX::frag bf[NSB];
+                    GF bf[NSB];
 #pragma unroll
                     for (int sb = 0; sb < NSB; ++sb) bf[sb] = gen_bfrag<PX>(buf, stride, sb * 32 + j, s, h);
 #pragma unroll
                     for (int i = 0; i < MAXT; ++i) {
                         if (i < ntw) {
 #pragma unroll
-                            for (int sb = 0; sb < NSB; ++sb) acc[i][sb] = PX::mfma(af[i], bf[sb], acc[i][sb]);
+                            for (int sb = 0; sb < NSB; ++sb) acc[i][sb] = gen_mfma<PX>(af[i], bf[sb], acc[i][sb]);
                         }
                     }
 #pragma unroll
@@ -246,8 +266,8 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) v[c] = ly.relu ? fmaxf(acc[i][sb][4 * q + c], 0.0f) : acc[i][sb][4 * q + c];
                                 elem* dstp = H + (size_t)n * sh + 32 * t + 8 * q + 4 * h;
-                                if constexpr (KH == 1) {
-                                    dstp[0] = v[0]; dstp[1] = v[1]; dstp[2] = v[2]; dstp[3] = v[3];
+                                if constexpr (KH == 1) {                 // four floats = one 16-byte LDS store (rows are 16-byte aligned)
+                                    *(f32x4*)dstp = f32x4{v[0], v[1], v[2], v[3]};
                                 } else {                           // four 16-bit values = one 8-byte LDS store (rows are 8-byte aligned)
                                     typedef unsigned short u16x4_ __attribute__((ext_vector_type(4)));
                                     *(u16x4_*)dstp = u16x4_{gen_cvt<P>(v[0]), gen_cvt<P>(v[1]), gen_cvt<P>(v[2]), gen_cvt<P>(v[3])};

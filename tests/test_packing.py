@@ -506,9 +506,9 @@ def test_bender_backward_stream_reproduces_autograd_of_the_bender(precision):
 # ---------------------------------------------------------------------------------------------------------------------------
 def _run_generic_program(info, stream, units, bias, precision, E, V):
     f32 = precision == "f32"
-    KH = 1 if f32 else 8
+    KH = 4 if f32 else 8              # k per lane and fragment: 16 bytes per lane in every precision (fp32: four 32x32x2 MFMAs per fragment)
     KS, FB = 2 * KH, info.frag_bytes
-    assert FB == (256 if f32 else 1024)
+    assert FB == 1024
     u = units.astype(np.int64)
     n_layers = int(u[0])
     layers = u[1:1 + 11 * n_layers].reshape(n_layers, 11)
@@ -533,7 +533,7 @@ def _run_generic_program(info, stream, units, bias, precision, E, V):
                 src, s = (src0, sl) if sl < ns0 else (src1, sl - ns0)
                 fi = w_frag + t * ns + sl
                 if f32:
-                    fr = words[fi * 64:(fi + 1) * 64].reshape(64, 1)
+                    fr = words[fi * 256:(fi + 1) * 256].reshape(64, 4)
                 else:
                     bits = raw16[fi * 512:(fi + 1) * 512].reshape(64, 8)
                     as_f16 = precision == "f16" or src != 1          # fragments against E / V are f16 (nrnerf_generic.h)
@@ -603,7 +603,7 @@ def test_generic_layer_programs_reproduce_the_networks(cfg_kw, precision):
         assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), (np.abs(got - want).max(), np.abs(want).max())
     if rb is not None:
         _, _, info_b, st_b, un_b, bi_b = _pack(cfg, precision, 9)
-        assert info_b.frag_bytes == 256                                        # the bender program is always fp32
+        assert info_b.frag_bytes == 1024 and info_b.stream_bytes % 1024 == 0   # (the bender program is always fp32: 4 k per lane)
         O, (ke, kv, kh, latw) = _run_generic_program(info_b, st_b, un_b, bi_b, "f32", np.concatenate([pts, lat], -1), pts)
         assert latw == cfg.latent_size and kv == 16
         with torch.no_grad():
