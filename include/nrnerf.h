@@ -266,7 +266,7 @@ int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uni
  * ready-made (bent) points and returns the gradient wrt them.
  * Weight gradients are products over two arrays these calls fill: dW_i = d_pre[i]^T x_i with x_0 = encoding,
  * x_i = acts[i-1] (x_{skip+1} = [encoding, acts[skip]]), db_i = column sums of d_pre[i]; d W_out = d_raw^T acts[D-1].
- * fp32 mode: row-major arrays, the products are left to the caller's GEMM library; bf16 mode: nrnerf_trunk_wgrad, below.
+ * Both modes: nrnerf_trunk_wgrad, below (fp32 mode: row-major arrays [layer][sample][width], bf16 mode: block tiles).
  * Available (else NRNERF_ERR_UNSUPPORTED) for the trunks of width 256 and 128 (time-conditioned baseline: through
  * ray_bias; with the view-dependent head: the density branch natively, the colour branch through d_hidden_extra; not with exact view
  * directions), fp32 or bf16 (a model created with NRNERF_PREC_F16 has no training kernels: unscaled f16 gradients
@@ -465,8 +465,9 @@ int nrnerf_tiles_to_rows(const void* tiles, int32_t n_rays, int32_t n_samples, i
 int nrnerf_direction_encoding(const float* bent4, int32_t n_rays, int32_t n_samples, int32_t n_freqs, void* enc, int32_t enc_is_bf16,
                               float* g_bent4, void* hip_stream);
 
-/* bf16 mode: the weight and bias gradients of the trunk from the two arrays nrnerf_trunk_forward / _backward filled, in
- * one launch over their [block][feature][32 samples] layout (the contraction runs over samples; no transposes):
+/* The weight and bias gradients of the trunk from the two arrays nrnerf_trunk_forward / _backward filled, in one launch
+ * (the contraction runs over samples; no transposes).  bf16 mode: over their [block][feature][32 samples] tiles on the bf16
+ * matrix pipe; fp32 mode: over their rows [sample][feature] on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums).
  *   dw_hidden[i-1] = d_pre[i]^T acts[i-1]  (i = 1 .. depth-1; the skip layer's columns for its encoding input are in dw_enc)
  *   dw_enc[0] = d_pre[0]^T enc,  dw_enc[1] = d_pre[skip+1]^T enc     (64 columns: the 63 encoding columns + one of padding)
  *   dw_head^T = acts[depth-1]^T g                                    (64 columns: the output channels, zero padded)
@@ -476,18 +477,18 @@ int nrnerf_direction_encoding(const float* bent4, int32_t n_rays, int32_t n_samp
  * db [depth+1][width] (row `depth` is scratch), so one sum over the first axis yields them all.  The 64-column products
  * (dw_enc, dw_head^T, db[0]) are cut into fewer, longer partial sums (they cost less per block: all workgroups of the
  * launch then finish together) and only fill the first NRNERF_WGRAD_SHORT_PARTIALS(n_partials, width) records: the caller
- * zero-fills at least dw_enc, dw_head^T, db[0] and db[depth] of the records beyond that (or simply all of `partials`).
- * enc / g_head: the encoding of the input points and the gradient wrt the head's outputs in the same block layout, bf16
- * [B][64][32]: scratch the caller allocates, filled by this call from pts4 and d_raw4 (the arrays given to
- * nrnerf_trunk_backward).
- * NRNERF_ERR_UNSUPPORTED in fp32 mode (the fp32 arrays are row-major for the library GEMMs). */
+ * zero-fills at least dw_enc, dw_head^T, db[0] and db[depth] of the records beyond that (or simply all of `partials`), or
+ * adds them up with nrnerf_reduce_partials, which never reads those.
+ * enc / g_head: the encoding of the input points and the gradient wrt the head's outputs in the layout of the mode -- bf16
+ * [B][64][32] tiles, or fp32 rows [M][64]: scratch the caller allocates, filled by this call from pts4 and d_raw4 (the
+ * arrays given to nrnerf_trunk_backward). */
 typedef struct nrnerf_wgrad_args {
     uint32_t struct_size;       /* sizeof(nrnerf_wgrad_args) */
     int32_t n_rays, n_samples;
-    const void* acts; const void* d_pre;       /* as nrnerf_trunk_args, bf16 mode */
+    const void* acts; const void* d_pre;       /* as nrnerf_trunk_args, in the model's mode */
     const float* pts4; const float* d_raw4;    /* [M,4] each, as nrnerf_trunk_args */
-    void* enc;                  /* scratch, bf16 [B][64][32] */
-    void* g_head;               /* scratch, bf16 [B][64][32] */
+    void* enc;                  /* scratch, bf16 [B][64][32] (fp32 mode: float [M][64]) */
+    void* g_head;               /* scratch, bf16 [B][64][32] (fp32 mode: float [M][64]) */
     int32_t n_partials;         /* 1 .. 4096 records; the launch has about 8.9 * n_partials workgroups (width 256): 28 fills an
                                    MI355X with one workgroup per CU */
     float* partials;            /* out [n_partials][NRNERF_WGRAD_STRIDE(depth, width)] */

@@ -1669,41 +1669,49 @@ int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, voi
 
 int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* hip_stream) try {
     if (!m || !a || a->struct_size != sizeof(nrnerf_wgrad_args)) return NRNERF_ERR_INVALID;
-    if (!m->train_ok || m->precision == NRNERF_PREC_F32) return NRNERF_ERR_UNSUPPORTED;
+    if (!m->train_ok) return NRNERF_ERR_UNSUPPORTED;
     if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 1 || a->n_partials > 4096) return NRNERF_ERR_INVALID;
     if (!a->acts || !a->d_pre || !a->pts4 || !a->d_raw4 || !a->enc || !a->g_head || !a->partials) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
+    const bool f32 = m->precision == NRNERF_PREC_F32;
     const int W = (m->arch_id == 5) ? ArchNarrow::W : ArchDefault::W, D = ArchDefault::D, SKIP = ArchDefault::SKIP;
     const long long nblocks = (long long)a->n_rays * ((a->n_samples + 31) / 32);
-    const size_t layer = (size_t)nblocks * W * 32;                  // elements of one layer of acts / d_pre
+    const long long M = (long long)a->n_rays * a->n_samples;
+    // elements of one layer of acts / d_pre: bf16 [block][W][32 samples] tiles, or (fp32 mode) rows [sample][W]
+    const size_t layer = f32 ? (size_t)M * W : (size_t)nblocks * W * 32;
+    const size_t esz = f32 ? 4 : 2;
     float* const dwh = a->partials;                                 // record layout: NRNERF_WGRAD_STRIDE
     float* const dwe = dwh + (size_t)(D - 1) * W * W;
     float* const dwo = dwe + (size_t)2 * W * 64;
     float* const db = dwo + (size_t)W * 64;
-    const __bf16* acts = (const __bf16*)a->acts;
-    const __bf16* dpre = (const __bf16*)a->d_pre;
+    const char* acts = (const char*)a->acts;
+    const char* dpre = (const char*)a->d_pre;
     WgradArgs w{};
-    w.nblocks = nblocks; w.pstride = NRNERF_WGRAD_STRIDE(D, W);
+    w.nblocks = f32 ? M : nblocks; w.pstride = NRNERF_WGRAD_STRIDE(D, W);
     static const int wgrad_sync = [] { const char* e = std::getenv("NRNERF_WGRAD_SYNC"); return e ? std::atoi(e) : NRN_WGRAD_SYNC_DEFAULT; }();
     w.sync_every = wgrad_sync;
     // a 64-column job (encoding, head) loads 2 TR + 2 fragments per block and wave, a hidden-to-hidden one 2 TR + 2 TCW:
     // give it that share of the workgroups, so that all workgroups of the launch finish together
+    // (fp32 mode: the same split; its 64-column jobs issue a quarter / half of a hidden-to-hidden job's MFMAs per sample and
+    //  finish early -- 1.9 of 8.9 n_partials workgroups)
     const int kh = a->n_partials;
     int kl = NRNERF_WGRAD_SHORT_PARTIALS(kh, W);
     kl = kl > kh ? kh : kl;
     int n = 0;
     for (int i = 1; i < D; ++i)                                     // hidden-to-hidden layers: the bulk, first in the grid
-        w.job[n++] = WgradJob{dpre + i * layer, acts + (i - 1) * layer, W, dwh + (size_t)(i - 1) * W * W, db + (size_t)i * W, kh, 0};
+        w.job[n++] = WgradJob{dpre + i * layer * esz, acts + (i - 1) * layer * esz, W, dwh + (size_t)(i - 1) * W * W, db + (size_t)i * W, kh, 0};
     w.job[n++] = WgradJob{dpre, a->enc, 64, dwe, db, kl, 0};
-    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer, a->enc, 64, dwe + (size_t)W * 64, db + (size_t)D * W, kl, 0};
-    w.job[n++] = WgradJob{acts + (D - 1) * layer, a->g_head, 64, dwo, db + (size_t)D * W, kl, 0};
+    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer * esz, a->enc, 64, dwe + (size_t)W * 64, db + (size_t)D * W, kl, 0};
+    w.job[n++] = WgradJob{acts + (D - 1) * layer * esz, a->g_head, 64, dwo, db + (size_t)D * W, kl, 0};
     w.njobs = n;
     for (int j = 0, wg = 0; j < n; ++j) { w.job[j].wg0 = wg; wg += w.job[j].kch; w.nwg = wg; }
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
+    const hipStream_t s = (hipStream_t)hip_stream;
     const WgradOperandArgs ops{a->pts4, a->d_raw4, a->n_rays, a->n_samples, ArchDefault::L, a->enc, a->g_head};
-    if (launch_wgrad_operands(ops, (hipStream_t)hip_stream) != hipSuccess) return NRNERF_ERR_HIP;
-    const hipError_t e = (m->arch_id == 5) ? launch_trunk_wgrad_bf16_a5(w, (hipStream_t)hip_stream) : launch_trunk_wgrad_bf16(w, (hipStream_t)hip_stream);
+    if ((f32 ? launch_wgrad_operands_f32(ops, s) : launch_wgrad_operands(ops, s)) != hipSuccess) return NRNERF_ERR_HIP;
+    const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_wgrad_f32_a5(w, s) : launch_trunk_wgrad_bf16_a5(w, s))
+                                           : (f32 ? launch_trunk_wgrad_f32(w, s) : launch_trunk_wgrad_bf16(w, s));
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 

@@ -252,8 +252,13 @@ struct WgradOperandArgs {
     void* g_head;            // out bf16 [nblocks][64][32]
 };
 hipError_t launch_wgrad_operands(const WgradOperandArgs&, hipStream_t);
+// fp32 mode: the same two operands as rows, fp32 [M][64] each (columns >= 3 + 6 L / >= 4 zero)
+hipError_t launch_wgrad_operands_f32(const WgradOperandArgs&, hipStream_t);
 hipError_t launch_trunk_wgrad_bf16(const WgradArgs&, hipStream_t);
 hipError_t launch_trunk_wgrad_bf16_a5(const WgradArgs&, hipStream_t);
+// fp32 mode (trunk_wgrad_f32): WgradJob::dz / x are fp32 rows [M][W] / [M][xw], WgradArgs::nblocks = M samples
+hipError_t launch_trunk_wgrad_f32(const WgradArgs&, hipStream_t);
+hipError_t launch_trunk_wgrad_f32_a5(const WgradArgs&, hipStream_t);
 
 // Re-pack weights on the device (nrnerf_model_update_device): dst[i] = convert(flat[src[i]]) (0 where src[i] < 0).
 // fmt[i]: 0 = fp32, 1 = bf16, 2 = f16, 3 = f16((w - f16(w)) * 2^11), the lo part of the bender's split product;

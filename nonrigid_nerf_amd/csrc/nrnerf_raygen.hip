@@ -112,6 +112,38 @@ hipError_t launch_wgrad_operands(const WgradOperandArgs& a, hipStream_t stream) 
     return hipGetLastError();
 }
 
+// fp32 mode (trunk_wgrad_f32 reads rows): thread (sample, q) writes columns 4 q .. 4 q + 3 of the sample's encoding row and of
+// its head-gradient row ([M][64] fp32 each), sincosf as in the fp32 forward kernel.
+__global__ void __launch_bounds__(256) wgrad_operands_f32_kernel(const WgradOperandArgs a) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long M = (long long)a.n_rays * a.S;
+    if (t >= M * 16) return;
+    const long long m = t >> 4;
+    const int q = (int)(t & 15);
+    const f32x4 p = *(const f32x4*)(a.pts4 + (size_t)m * 4);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int col = 4 * q + e;
+        if (col < 3) v[e] = p[col];
+        else if (col < 3 + 6 * a.L) {
+            const int kk = col - 3, f = kk / 6, r = kk % 6;
+            float sn, cs;
+            sincosf(p[r % 3] * (float)(1 << f), &sn, &cs);
+            v[e] = r < 3 ? sn : cs;
+        } else v[e] = 0.0f;
+    }
+    *(f32x4*)((float*)a.enc + (size_t)m * 64 + 4 * q) = f32x4{v[0], v[1], v[2], v[3]};
+    const f32x4 g = (q == 0) ? *(const f32x4*)(a.d_raw4 + (size_t)m * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    *(f32x4*)((float*)a.g_head + (size_t)m * 64 + 4 * q) = g;
+}
+hipError_t launch_wgrad_operands_f32(const WgradOperandArgs& a, hipStream_t stream) {
+    const long long total = (long long)a.n_rays * a.S * 16;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(wgrad_operands_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_repack(const RepackArgs& a, hipStream_t stream) {
     if (a.n <= 0) return hipSuccess;
     hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);

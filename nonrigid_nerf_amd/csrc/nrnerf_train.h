@@ -14,11 +14,11 @@
 //                     are the encoding's gradient), finally d enc += W_0^T d z_0 and, through the derivative of the
 //                     encoding, the gradient wrt the input point.
 //   trunk_wgrad       bf16 mode: the weight gradients  dW_i = d z_i^T x_i  and bias gradients of a trunk in one launch over
-//                     the two stored arrays (fp32 mode: plain [256 x K_samples] x [K_samples x 256] GEMMs, left to the library).
+//                     the two stored arrays;  trunk_wgrad_f32: the same on the fp32 mode's row-major arrays.
 // fp32 mode (exact, the gradient-parity mode) and bf16 mode (bf16 operands incl. the stored activations and d z).
 //
-// Layout of the stored arrays.  fp32 mode: [layer][sample][256], true feature order (the library GEMMs want rows of
-// features).  bf16 mode: [layer][block][feature][32 samples] -- one 256 x 32 tile per 32-sample block with the SAMPLES
+// Layout of the stored arrays.  fp32 mode: [layer][sample][256], true feature order (rows of features: trunk_wgrad_f32
+// contracts over samples with one dword per lane and MFMA, so a lane reads along a row).  bf16 mode: [layer][block][feature][32 samples] -- one 256 x 32 tile per 32-sample block with the SAMPLES
 // contiguous: register r of a D tile holds one feature for the 32 samples of the block in the 32 lanes of a wave half, so a
 // store instruction writes two whole 64-byte rows; and it is the layout the weight-gradient kernel (trunk_wgrad, below)
 // wants, whose contraction runs over samples: a lane's 8 consecutive k of an MFMA operand are 8 consecutive samples of
@@ -515,6 +515,149 @@ static hipError_t launch_trunk_wgrad(const WgradArgs& a, hipStream_t stream) {
     for (int j = 0; j < a.njobs; ++j)
         if ((a.job[j].xw != 64 && a.job[j].xw != A::W) || a.job[j].kch < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(trunk_wgrad<A>, dim3(a.nwg), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradients (fp32 mode)
+// ------------------------------------------------------------------------------------------
+// The same jobs on the fp32 mode's row-major arrays ([sample][feature]: what trunk_fwd_train / trunk_bwd write in that mode),
+// v_mfma_f32_32x32x2_f32 with the SAMPLE as the contraction index: lane (i, k = lane >> 5) of an A operand holds dz[m0 + k][row],
+// of a B operand x[m0 + k][col] -- one dword per lane and MFMA.  A lane therefore loads CR consecutive features of dz and CC of x
+// per sample (16 / 8 / 4 bytes: a wave half reads 32 CR consecutive floats of one row) and feeds CR x CC MFMAs from them: MFMA
+// (c, d) contracts rows {CR i + c} with columns {CC i + d} -- any assignment of features to the 32 rows of a tile is as good
+// as any other, the epilogue writes each accumulator where it belongs.  Wave (wr, wc) owns rows wr 32 CR .. and columns wc 32 CC
+// ..: 2 x 2 waves cover a [64 CR] x [64 CC] product (CR = W / 64; CC = W / 64 for a hidden-to-hidden layer, 1 for the 64-column
+// ones).  16 MFMAs of 64 cycles per two samples and wave at W = 256 against 2 KB of loads per workgroup: matrix-pipe-bound (64
+// flop per byte).  Workgroup c of a job takes a contiguous range of samples; the next eight samples' operands are requested
+// before the current eight's MFMAs.  Same record layout of the partial sums as the bf16 kernel.
+template <int N> struct fvec { typedef float type __attribute__((ext_vector_type(N))); };
+template <> struct fvec<1> { typedef float type; };
+template <int N>
+__device__ __forceinline__ float fvec_get(const typename fvec<N>::type& v, int k) {
+    if constexpr (N == 1) return v; else return v[k];
+}
+template <int W, int CR, int CC>
+__device__ __forceinline__ void trunk_wgrad_f32_job(const WgradArgs& a, const WgradJob& jb, int c) {
+    typedef typename fvec<CR>::type vr;
+    typedef typename fvec<CC>::type vc;
+#ifndef NRN_WGF_G
+#define NRN_WGF_G 4
+#endif
+    constexpr int G = NRN_WGF_G;                      // sample pairs per group (loads in flight: two groups)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int k = lane >> 5, i = lane & 31;
+    const long long M = a.nblocks;                    // fp32 mode: samples
+    long long per = (M + jb.kch - 1) / jb.kch;
+    per = (per + 2 * G - 1) / (2 * G) * (2 * G);
+    const long long m_begin = (long long)c * per;
+    const long long m_end = (m_begin + per < M) ? m_begin + per : M;
+    const float* dz = (const float*)jb.dz + wr * 32 * CR + CR * i;
+    const float* x = (const float*)jb.x + wc * 32 * CC + CC * i;
+    const int xw = jb.xw;
+    f32x16 acc[CR][CC];
+    float bsum[CR];
+#pragma unroll
+    for (int u = 0; u < CR; ++u) {
+        bsum[u] = 0.0f;
+#pragma unroll
+        for (int v = 0; v < CC; ++v) acc[u][v] = f32x16{};
+    }
+    auto load = [&](long long m0, vr (&fa)[G], vc (&fb)[G]) {          // a whole group inside the range
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const size_t row = (size_t)(m0 + 2 * g + k);
+            fa[g] = *(const vr*)(dz + row * W);
+            fb[g] = *(const vc*)(x + row * xw);
+        }
+    };
+    // the array's own end inside a group (a workgroup's range is a multiple of 2 G samples, so this is the last group of the last
+    // workgroup only): the row of the last sample is read instead and dz zeroed -- x is finite there, the product and the row sum vanish
+    auto load_tail = [&](long long m0, vr (&fa)[G], vc (&fb)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const long long m = m0 + 2 * g + k;
+            const bool in = m < M;
+            const size_t row = (size_t)(in ? m : M - 1);
+            const vr va = *(const vr*)(dz + row * W);
+            fb[g] = *(const vc*)(x + row * xw);
+            if constexpr (CR == 1) fa[g] = in ? va : 0.0f;
+            else {
+#pragma unroll
+                for (int e = 0; e < CR; ++e) fa[g][e] = in ? va[e] : 0.0f;
+            }
+        }
+    };
+    auto step = [&](const vr (&fa)[G], const vc (&fb)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int u = 0; u < CR; ++u) {
+                if (wc == 0) bsum[u] += fvec_get<CR>(fa[g], u);
+#pragma unroll
+                for (int v = 0; v < CC; ++v) acc[u][v] = PolF32::mfma(fvec_get<CR>(fa[g], u), fvec_get<CC>(fb[g], v), acc[u][v]);
+            }
+        }
+    };
+    // (one loop exit: with the bf16 kernel's two-step loop -- an exit after each half -- hipcc 7.2 keeps a second copy of the 256
+    //  accumulator registers and spills 500 of them)
+    vr fa0[G], fa1[G];
+    vc fb0[G], fb1[G];
+    const long long m_full = m_begin + (m_end > m_begin ? (m_end - m_begin) / (2 * G) * (2 * G) : 0);
+    long long m0 = m_begin;
+    if (m0 < m_full) load(m0, fa0, fb0);
+    // (vmcnt(0) once: otherwise the first group's loads are "pending" on one path into the loop and hipcc makes every iteration's
+    //  first MFMAs wait for the loads issued right in front of them)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (; m0 < m_full; m0 += 4 * G) {
+        const bool more1 = m0 + 2 * G < m_full, more2 = m0 + 4 * G < m_full;
+        if (more1) load(m0 + 2 * G, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) load(m0 + 4 * G, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) step(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (m_full < m_end) {
+        load_tail(m_full, fa0, fb0);
+        step(fa0, fb0);
+    }
+    // D tile of MFMA (u, v): lane (k, i) register r = (row CR tile_row(r, k) + u, column CC i + v) of this wave's block
+    float* dw = jb.dw + (size_t)c * a.pstride;
+#pragma unroll
+    for (int u = 0; u < CR; ++u) {
+#pragma unroll
+        for (int v = 0; v < CC; ++v) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dw[(size_t)(wr * 32 * CR + CR * tile_row(r, k) + u) * xw + wc * 32 * CC + CC * i + v] = acc[u][v][r];
+        }
+        const float rowsum = bsum[u] + __shfl_xor(bsum[u], 32);        // the two lane halves hold the two samples of each pair
+        if (wc == 0 && k == 0) jb.db[(size_t)c * a.pstride + wr * 32 * CR + CR * i + u] = rowsum;
+    }
+}
+
+template <class A>
+__global__ void __launch_bounds__(256, 1) trunk_wgrad_f32(const WgradArgs a) {
+    int j = 0;
+    for (int q = 1; q < a.njobs; ++q)
+        if ((int)blockIdx.x >= a.job[q].wg0) j = q;           // jobs are listed in grid order
+    const WgradJob jb = a.job[j];
+    const int c = (int)blockIdx.x - jb.wg0;
+    if (jb.xw == A::W) trunk_wgrad_f32_job<A::W, A::W / 64, A::W / 64>(a, jb, c);      // hidden-to-hidden layer
+    else trunk_wgrad_f32_job<A::W, A::W / 64, 1>(a, jb, c);                             // 64 columns: encoding / head
+}
+
+template <class A>
+static hipError_t launch_trunk_wgrad_f32(const WgradArgs& a, hipStream_t stream) {
+    if (a.njobs <= 0 || a.nwg <= 0 || a.nblocks <= 0) return hipSuccess;
+    for (int j = 0; j < a.njobs; ++j)
+        if ((a.job[j].xw != 64 && a.job[j].xw != A::W) || a.job[j].kch < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(trunk_wgrad_f32<A>, dim3(a.nwg), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

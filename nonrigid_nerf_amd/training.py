@@ -4,8 +4,8 @@ train.py:152-287; backward + optimiser step, train.py:1594-1610); here the same 
 
 What is native (C ABI, include/nrnerf.h; kernels in csrc/nrnerf_train.h, csrc/nrnerf_train_bend.h, csrc/nrnerf_composite.hip):
   * the canonical network -- positional encoding, 8x256 (or 8x128) trunk, head -- forward with saved activations, the fused
-    backward-data pass on MFMA and (bf16 mode) every weight / bias gradient in one launch (``nrnerf_trunk_forward / _backward /
-    _wgrad``), fp32 or bf16;
+    backward-data pass on MFMA and every weight / bias gradient in one launch (``nrnerf_trunk_forward / _backward / _wgrad``),
+    fp32 (v_mfma_f32_32x32x2_f32 throughout) or bf16;
   * the ray-bending and rigidity MLPs (35->64->64->64->64->3 and 3->32->32->1; ``nrnerf_bender_forward / _backward / _wgrad``):
     forward with saved activations and backward-data in exact fp32, down to the latent codes; the fine pass bends only its
     N_importance new samples and re-uses the coarse pass' bent points (SPLIT_FINE_BENDER; ``nrnerf_merge_rows`` puts the rows
@@ -17,8 +17,6 @@ What is native (C ABI, include/nrnerf.h; kernels in csrc/nrnerf_train.h, csrc/nr
     train.py:910-920, no gradient: the reference detaches the sample positions), the compositing backward, the coarse depths
     (``nrnerf_composite_forward / _backward``, ``nrnerf_sample_depths``).
 What is left to libraries, as plumbing:
-  * fp32 mode: the trunk's weight gradients ``dW_i = dz_i^T x_i``, plain [out x K] x [K x in] GEMMs over the two row-major
-    arrays the kernels fill (``torch.bmm`` = hipBLASLt), and the bias gradients (column sums);
   * the colour branch of the view-dependent head (feature_linear, views_linears[0], rgb_linear) and its finite-difference
     directions, as torch ops on the native trunk's last activation (``colour_branch``; the density branch is native);
   * the two small GEMMs that turn a time-conditioned baseline's latent columns into per-ray biases.
@@ -301,7 +299,7 @@ class _Trunk(torch.autograd.Function):
         D, W = int(net.D), int(net.W)
         f32 = _is_f32(model)
         pts4 = _rows4(pts.detach(), M)               # the bender's own [M,4] rows when the points come from _Bender
-        # saved activations.  fp32 mode: [layer][sample][width] for the library GEMMs; bf16 mode: [layer][block][width][32
+        # saved activations.  fp32 mode: [layer][sample][width] rows; bf16 mode: [layer][block][width][32
         # samples] for nrnerf_trunk_wgrad (blocks of 32 consecutive samples of a ray) + 16 relu bits per lane and tile (one record per lane and layer)
         nblk = N * ((S + 31) // 32)
         acts = torch.empty(D, M, W, dtype=torch.float32, device=dev) if f32 else torch.empty(D, nblk, W, 32, dtype=torch.bfloat16, device=dev)
@@ -376,62 +374,23 @@ class _Trunk(torch.autograd.Function):
                 g_bias = rows.view(2, N, bpr, W).sum(2).permute(1, 0, 2)
         n_lat = int(net.pts_linears[0].weight.shape[1]) - (3 + 6 * ((int(net.input_ch) - 3) // 6)) if ctx.tcb else 0
 
-        def widen(grads):       # time-conditioned baseline: the latent columns of the two input layers get their gradient through ray_bias
-            if not n_lat:
-                return grads
-            n_enc = int(net.input_ch)
-            for li in (0, skip1):
-                dw = grads[2 * li]
-                full = torch.zeros(dw.shape[0], dw.shape[1] + n_lat, dtype=dw.dtype, device=dw.device)
-                full[:, :n_enc] = dw[:, :n_enc]
-                if dw.shape[1] > n_enc:
-                    full[:, n_enc + n_lat:] = dw[:, n_enc:]
-                grads[2 * li] = full
-            return grads
-        if not f32:
-            # (bf16 route: the latent columns are already in the flat buffer's layout, zero)
-            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias,
-                    *_Trunk._weight_grads_bf16(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views, n_lat))
-        # weight gradients: library GEMMs over the stored activations x_i and pre-activation gradients dz_i
-        adt = acts.dtype
-        L = (int(net.input_ch) - 3) // 6
-        enc = posenc(pts4[:, :3], L).to(adt)                               # x_0, and the first columns of x_{skip+1}
-        skips = set(int(s) for s in net.skips)
-        # hidden-to-hidden layers 1 .. D-1 (x_i = h_{i-1}; for the skip layer this is the h part of [encoding, h]): ONE batched
-        # GEMM over (layer, row block), partial products added per layer; biases: one reduction over the whole d_pre array
-        Bc = _chunks(M)
-        c = M // Bc
-        part = torch.bmm(d_pre[1:D].reshape((D - 1) * Bc, c, W).transpose(1, 2), acts[0:D - 1].reshape((D - 1) * Bc, c, W))
-        dwh = part.view(D - 1, Bc, W, W).sum(1, dtype=torch.float32)               # [D-1, W, W]
-        db = d_pre.sum(1, dtype=torch.float32)                                     # [D, W]
-        grads = []
-        for i in range(D):
-            if i == 0:
-                dw = _wgrad(d_pre[0], enc)
-            elif (i - 1) in skips:
-                dw = torch.cat([_wgrad(d_pre[i], enc), dwh[i - 1]], 1)             # x = [encoding, h] (rnh:278-282)
-            else:
-                dw = dwh[i - 1]
-            grads += [dw, db[i]]
-        if ctx.views:                                          # head slot = alpha_linear: its gradient is the sigma channel's
-            grads += [_wgrad(g[:, 3:4].to(adt).contiguous(), acts[D - 1]), g[:, 3].sum(0, keepdim=True)]
-            return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias, *widen(grads))
-        g_out = torch.zeros(M, C_out, dtype=torch.float32, device=dev)
-        g_out[:, :4] = g
-        grads += [_wgrad(g_out.to(adt), acts[D - 1]), g_out.sum(0)]
-        return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias, *widen(grads))
-
+        # every weight and bias gradient from ONE launch over the two saved arrays (nrnerf_trunk_wgrad: bf16 block tiles, or the
+        # fp32 mode's rows); the time-conditioned baseline's latent columns are already in the flat buffer's layout, zero
+        return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias,
+                *_Trunk._weight_grads(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views, n_lat))
 
     @staticmethod
-    def _weight_grads_bf16(model, net, dims, pts4, acts, d_pre, g, views=False, n_lat=0):
-        """bf16 mode: every weight and bias gradient of the trunk from one call of nrnerf_trunk_wgrad over the two
-        [block][feature][32 samples] arrays (reads each once; the library route read them twice and reduced d_pre a third
-        time).  One record of partial sums per workgroup, added here with one reduction."""
+    def _weight_grads(model, net, dims, pts4, acts, d_pre, g, views=False, n_lat=0):
+        """Every weight and bias gradient of the trunk from one call of nrnerf_trunk_wgrad over the two saved arrays (reads
+        each once; a library route read them twice and reduced d_pre a third time): bf16 [block][feature][32 samples] tiles on
+        the bf16 matrix pipe, or (fp32 mode) [sample][feature] rows on v_mfma_f32_32x32x2_f32.  One record of partial sums
+        per workgroup, added here with one reduction."""
         N, S, D, W, C_out = dims
         dev = acts.device
-        L = (int(net.input_ch) - 3) // 6
-        nblk = int(acts.shape[1])
-        scratch = torch.empty(2, nblk, 64, 32, dtype=torch.bfloat16, device=dev)             # encoding / head-gradient tiles
+        f32 = acts.dtype == torch.float32
+        nblk = N * ((S + 31) // 32)
+        # encoding / head-gradient operands the call fills: bf16 tiles, or fp32 rows [M][64]
+        scratch = torch.empty(2, N * S, 64, dtype=torch.float32, device=dev) if f32 else torch.empty(2, nblk, 64, 32, dtype=torch.bfloat16, device=dev)
         # records of partial sums; the launch has (D - 1) * kch + 3 * (10/16 or 12/16) kch workgroups: one per CU at most
         kch = max(1, min(nblk, (_num_cus(dev) * 16) // ((D - 1) * 16 + 3 * (10 if W == 256 else 12))))
         # only the records the kernel does not write need zeroing: the three 64-column products (and their bias rows) are cut

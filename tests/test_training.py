@@ -256,7 +256,7 @@ def O_render_free(scene, rays, latents, perturb, noise, detailed, **flags):
                          ids=["w256", "w128", "w256_detailed_loss", "w256_viewdirs"])
 def test_bf16_gradients_point_the_same_way(width, detailed, views):
     """bf16 training mode (bf16 activations and d z in block-tile layout, relu bit masks, trunk_wgrad): gradient direction and
-    size against fp32 mode (row-major arrays, library weight-gradient GEMMs), both compiled trunk widths."""
+    size against fp32 mode (row-major arrays, trunk_wgrad_f32), both compiled trunk widths."""
     cfg = SceneConfig(N_importance=64, netwidth=width, use_viewdirs=views)
     scene = make_scene(cfg, 1)
     rays, latents = make_rays(512, 3, cfg)
@@ -484,6 +484,62 @@ def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S):
     close(dwe[0], torch.einsum("bfs,bgs->fg", Z[0], enc_t.float()), "encoding, layer 0")
     close(dwe[1], torch.einsum("bfs,bgs->fg", Z[5], enc_t.float()), "encoding, skip layer")
     close(dwo, torch.einsum("bfs,bgs->fg", A[D - 1], g_t.float()), "head")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,n_rays,S,kch", [(256, 37, 192, 7), (256, 5, 85, 3), (256, 1, 3, 4), (128, 64, 64, 28)],
+                         ids=["w256", "w256_ragged", "w256_three_samples", "w128"])
+def test_trunk_wgrad_fp32_kernel_vs_einsum(width, n_rays, S, kch):
+    """nrnerf_trunk_wgrad in fp32 mode (trunk_wgrad_f32: v_mfma_f32_32x32x2_f32 over the row-major arrays the fp32 forward /
+    backward kernels write) on random arrays against float64 einsums over the same values: hidden layers, the two encoding
+    products, the head, the bias sums; sample counts that are no multiple of the kernel's group of eight and fewer samples
+    than workgroups; both compiled trunk widths.  Exact fp32 products, fp32 accumulation in a different order: 2e-6 of
+    scale.  The two operands the call builds itself (encoding rows, head-gradient rows) against torch."""
+    import ctypes as C
+    from nonrigid_nerf_amd import _lib, training
+    cfg = SceneConfig(N_importance=64, netwidth=width)
+    scene = make_scene(cfg, 0)
+    rb, coarse, fine = _modules(scene, requires_grad=False)
+    R.set_precision("f32")
+    model = R.get_model(coarse, fine, precision="f32", device=torch.device(DEV))
+    D, W, M = 8, width, n_rays * S
+    gen = torch.Generator().manual_seed(5)
+    mk = lambda *shape: (torch.randn(*shape, generator=gen) * 0.5).to(DEV)
+    acts, d_pre = mk(D, M, W).abs(), mk(D, M, W)
+    pts4 = (torch.randn(M, 4, generator=gen) * 0.4).to(DEV)
+    g4 = torch.randn(M, 4, generator=gen).to(DEV)
+    scratch = torch.full((2, M, 64), float("nan"), device=DEV)
+    stride = _lib.wgrad_stride(D, W)
+    parts = torch.zeros(kch, stride, device=DEV)          # the 64-column jobs fill fewer records: zero-filled by the caller
+    a = _lib.WgradArgs()
+    a.struct_size = C.sizeof(_lib.WgradArgs)
+    a.n_rays, a.n_samples, a.n_partials = n_rays, S, kch
+    a.acts, a.d_pre, a.pts4, a.d_raw4 = acts.data_ptr(), d_pre.data_ptr(), pts4.data_ptr(), g4.data_ptr()
+    a.enc, a.g_head, a.partials = scratch[0].data_ptr(), scratch[1].data_ptr(), parts.data_ptr()
+    _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nrnerf_trunk_wgrad")
+    torch.cuda.synchronize()
+    enc_r, g_r = scratch[0], scratch[1]
+    assert float((enc_r[:, :63] - training.posenc(pts4[:, :3], 10)).abs().max()) <= 2e-6 and bool((enc_r[:, 63] == 0).all())
+    assert torch.equal(g_r[:, :4], g4) and bool((g_r[:, 4:] == 0).all())
+    tot = parts.double().sum(0)
+    o = 0
+    dwh = tot[o:o + (D - 1) * W * W].view(D - 1, W, W); o += (D - 1) * W * W
+    dwe = tot[o:o + 2 * W * 64].view(2, W, 64); o += 2 * W * 64
+    dwo = tot[o:o + W * 64].view(W, 64); o += W * 64
+    db = tot[o:o + (D + 1) * W].view(D + 1, W)
+    A, Z, E, G = acts.double(), d_pre.double(), enc_r.double(), g_r.double()
+
+    def close(got, want, what):
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 2e-6 * scale, (what, float((got - want).abs().max()), scale)
+
+    for i in range(1, D):
+        close(dwh[i - 1], Z[i].t() @ A[i - 1], f"hidden {i}")
+        close(db[i], Z[i].sum(0), f"bias {i}")
+    close(db[0], Z[0].sum(0), "bias 0")
+    close(dwe[0], Z[0].t() @ E, "encoding, layer 0")
+    close(dwe[1], Z[5].t() @ E, "encoding, skip layer")
+    close(dwo, A[D - 1].t() @ G, "head")
 
 
 @pytest.mark.gpu
