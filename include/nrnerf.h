@@ -268,8 +268,8 @@ int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uni
  * x_i = acts[i-1] (x_{skip+1} = [encoding, acts[skip]]), db_i = column sums of d_pre[i]; d W_out = d_raw^T acts[D-1].
  * Both modes: nrnerf_trunk_wgrad, below (fp32 mode: row-major arrays [layer][sample][width], bf16 mode: block tiles).
  * Available (else NRNERF_ERR_UNSUPPORTED) for the trunks of width 256 and 128 (time-conditioned baseline: through
- * ray_bias; with the view-dependent head: the density branch natively, the colour branch through d_hidden_extra; not with exact view
- * directions), fp32 or bf16 (a model created with NRNERF_PREC_F16 has no training kernels: unscaled f16 gradients
+ * ray_bias; with the view-dependent head -- width 256 -- both branches of the head, on the directions the caller hands
+ * in; not with exact view directions), fp32 or bf16 (a model created with NRNERF_PREC_F16 has no training kernels: unscaled f16 gradients
  * underflow; nonrigid_nerf_amd/training.py trains such a model through a bf16 handle). */
 typedef struct nrnerf_trunk_args {
     uint32_t struct_size;       /* sizeof(nrnerf_trunk_args) */
@@ -305,7 +305,18 @@ typedef struct nrnerf_trunk_args {
                                    raw4[:, 3] is the density logit and raw4[:, 0:3] = 0; the colour branch (feature_linear,
                                    views_linears[0] on [feature, direction encoding], rgb_linear) is the caller's, on that
                                    activation (fp32 mode: acts[depth-1] is [M][width]; bf16 mode: the [B][width][32] tiles), and
-                                   its gradient comes back here */
+                                   its gradient comes back here.  (How round 3 trained the view-dependent head; the library now
+                                   evaluates the colour branch itself, below, and a caller has no reason to pass this) */
+    /* view-dependent head (run_nerf_helpers.py:284-304; models whose networks have use_viewdirs): the colour branch runs
+       behind the trunk in the same kernels -- raw4 = [rgb logits, density logit] -- and these are required */
+    const float* dirs;          /* [M,3] view direction of every sample: the normalised finite differences of the bent points
+                                   (rnh:316-356; nrnerf_direction_encoding with n_freqs = 0 yields them and takes their gradient
+                                   back to the points), or the ray's own direction (train.py:73-76) */
+    void* hv;                   /* relu(views_linears[0]([feature_linear(h), enc(dirs)])), width/2 values per sample, forward
+                                   writes: float [M][width/2] (fp32 mode) or bf16 [B][width/2][32] */
+    void* hv_mask;              /* bf16 mode only: uint16 [B][64 lanes][width/64], relu bits of hv; forward writes, backward reads */
+    void* d_pre_v;              /* backward out: gradient wrt the views layer's pre-activation, type and layout of hv */
+    float* d_dirs;              /* backward out [M,3]: gradient wrt dirs; NULL when nobody differentiates them (no bender) */
 } nrnerf_trunk_args;
 int nrnerf_trunk_forward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);
 int nrnerf_trunk_backward(const nrnerf_model* model, const nrnerf_trunk_args* args, void* hip_stream);
@@ -490,9 +501,22 @@ typedef struct nrnerf_wgrad_args {
     void* enc;                  /* scratch, bf16 [B][64][32] (fp32 mode: float [M][64]) */
     void* g_head;               /* scratch, bf16 [B][64][32] (fp32 mode: float [M][64]) */
     int32_t n_partials;         /* 1 .. 4096 records; the launch has about 8.9 * n_partials workgroups (width 256): 28 fills an
-                                   MI355X with one workgroup per CU */
-    float* partials;            /* out [n_partials][NRNERF_WGRAD_STRIDE(depth, width)] */
+                                   MI355X with one workgroup per CU (view-dependent head: about 11.1 * n_partials, 23) */
+    float* partials;            /* out [n_partials][NRNERF_WGRAD_STRIDE(depth, width)]; view-dependent head:
+                                   [n_partials][NRNERF_WGRAD_STRIDE_VIEWS(depth, width)] */
+    /* view-dependent head: the arrays of nrnerf_trunk_args, and one more scratch operand.  The record then continues with
+         dw_fold [width/2][width]  = d_pre_v^T acts[depth-1]   gradient wrt the FOLDED views layer's hidden columns
+                                                               (views_linears[0].weight[:, :width] . feature_linear.weight)
+         dw_dirs [width/2][64]     = d_pre_v^T enc(dirs)       wrt views_linears[0].weight[:, width:] (27 columns + padding)
+         dw_rgb^T [width/2][64]    = hv^T d_raw4               wrt rgb_linear.weight, transposed (columns 0..2)
+         db_views [width/2]        = row sums of d_pre_v       wrt the folded bias (views . feature bias + views bias)
+       (dw_fold, db_views: n_partials records; dw_dirs, dw_rgb^T: NRNERF_WGRAD_SHORT_PARTIALS), and dw_head^T's column 3 is
+       alpha_linear's gradient.  The chain rule through the fold is the caller's (two small products in parameter space). */
+    const float* dirs;          /* [M,3] */
+    const void* hv; const void* d_pre_v;
+    void* encv;                 /* scratch, layout of enc */
 } nrnerf_wgrad_args;
+#define NRNERF_WGRAD_STRIDE_VIEWS(depth, width) (NRNERF_WGRAD_STRIDE(depth, width) + ((width) / 2) * (width) + 2 * ((width) / 2) * 64 + (width) / 2)
 #define NRNERF_WGRAD_SHORT_PARTIALS(n_partials, width) \
     ((((n_partials) * (2 * ((width) / 64) + 2) + (2 * ((width) / 64) + (width) / 32) / 2) / (2 * ((width) / 64) + (width) / 32)) < 1 ? 1 : \
      (((n_partials) * (2 * ((width) / 64) + 2) + (2 * ((width) / 64) + (width) / 32) / 2) / (2 * ((width) / 64) + (width) / 32)))

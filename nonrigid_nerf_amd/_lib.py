@@ -100,14 +100,16 @@ class TrunkArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("which", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("pts4", C.c_void_p), ("acts", C.c_void_p), ("relu_mask", C.c_void_p),
                 ("raw4", C.c_void_p), ("raw", C.c_void_p), ("raw_ch", C.c_int32),
-                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p), ("ray_bias", C.c_void_p), ("d_hidden_extra", C.c_void_p)]
+                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p), ("ray_bias", C.c_void_p), ("d_hidden_extra", C.c_void_p),
+                ("dirs", C.c_void_p), ("hv", C.c_void_p), ("hv_mask", C.c_void_p), ("d_pre_v", C.c_void_p), ("d_dirs", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("acts", C.c_void_p), ("d_pre", C.c_void_p), ("pts4", C.c_void_p), ("d_raw4", C.c_void_p),
                 ("enc", C.c_void_p), ("g_head", C.c_void_p),
-                ("n_partials", C.c_int32), ("partials", C.c_void_p)]
+                ("n_partials", C.c_int32), ("partials", C.c_void_p),
+                ("dirs", C.c_void_p), ("hv", C.c_void_p), ("d_pre_v", C.c_void_p), ("encv", C.c_void_p)]
 
 
 REDUCE_SHORT = 0x40000000        # NRNERF_REDUCE_SHORT of include/nrnerf.h
@@ -116,6 +118,11 @@ REDUCE_SHORT = 0x40000000        # NRNERF_REDUCE_SHORT of include/nrnerf.h
 def wgrad_stride(depth: int, width: int) -> int:
     """NRNERF_WGRAD_STRIDE of include/nrnerf.h"""
     return (depth - 1) * width * width + 3 * width * 64 + (depth + 1) * width
+
+
+def wgrad_stride_views(depth: int, width: int) -> int:
+    """NRNERF_WGRAD_STRIDE_VIEWS of include/nrnerf.h"""
+    return wgrad_stride(depth, width) + (width // 2) * width + 2 * (width // 2) * 64 + width // 2
 
 
 def wgrad_short_partials(n_partials: int, width: int) -> int:

@@ -155,17 +155,13 @@ const nrnerf_linear* layer_source(const nrnerf_model_desc& d, const nrnerf_mlp_d
     return nullptr;
 }
 
-// alpha_head (training with the view-dependent head, nrnerf_train.h): the plan's output_linear slot (LK_HEAD) is filled
-// with alpha_linear in output row 3, the sigma channel of raw4 -- the native trunk then yields the density logit, its
-// backward-data pass starts from alpha_linear^T d sigma, and the colour branch (feature / views / rgb layers) is added by
-// the caller through nrnerf_trunk_args.d_hidden_extra
 // tcb_shift (training of the time-conditioned baseline with architecture A = the plain trunk): the module's first layer
 // reads [encoding, latent] and its skip layer [encoding, latent, h] (rnh:207-209, 273-282); the latent columns act as a
 // per-ray bias (the latent is constant along a ray) that the caller supplies (nrnerf_trunk_args.ray_bias), so the images
 // hold the encoding and the hidden columns only: hidden column c of the skip layer sits tcb_shift columns further right.
 template <class SH, class A, bool HAS_BEND, bool VIEWS, bool TRUNK = true>
 void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr,
-               bool alpha_head = false, int tcb_shift = 0) {
+               int tcb_shift = 0) {
     using PL = Plan<SH, A, HAS_BEND, VIEWS, TRUNK>;
     constexpr int KH = SH::KH;
     const Tables& T = PL::TB;
@@ -184,8 +180,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
     std::unique_ptr<FoldedViews> folded;           // the views layer's weights with feature_linear folded in (VIEWS plans)
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
-        const bool ah = alpha_head && sp.kind == LK_HEAD;
-        const nrnerf_linear* lin = ah ? &mlp.alpha_linear : layer_source(d, mlp, sp);
+        const nrnerf_linear* lin = layer_source(d, mlp, sp);
         int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
         if (sp.kind == LK_VIEWS) {                 // source: the derived entries of the flat vector (FlatLayout::add_folded)
             folded.reset(new FoldedViews(mlp));
@@ -194,7 +189,7 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
             wbase = fb;
             bbase = fb < 0 ? -1 : fb + (int64_t)lin->out_features * lin->in_features;
         }
-        auto orow = [&](int t, int i) { return ah ? (i == 3 ? 0 : -1) : out_row<A>(sp.kind, t, i, lin->out_features); };
+        auto orow = [&](int t, int i) { return out_row<A>(sp.kind, t, i, lin->out_features); };
         for (int t = 0; t < sp.nt; ++t) {
             const TileInfo& ti = T.tiles[sp.tile0 + t];
             for (int s = 0; s < sp.ns; ++s) {
@@ -242,10 +237,14 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
 
 // Transposed weights for the backward-data kernel (nrnerf_train.h): PlanB's layer list, fragment element
 // (tile t, row i, slab s, half h, element e) = W[y][x] with (y, x) from bwd_y / bwd_x.  No biases.
-template <class SH, class A>
+// VIEWS (view-dependent head, rnh:284-304): rgb_linear^T, then the layer that joins both branches of the head -- its k index
+// runs over [d raw (only channel 3, sigma, is used: alpha_linear), d z_v (W/2)], its rows over [direction-encoding slots (one
+// tile, enc_col order), h_{D-1} (W)]; the weights of the d z_v part are the FOLDED views layer's (FoldedViews: hidden columns
+// first, then the direction encoding's), transposed.
+template <class SH, class A, bool VIEWS = false>
 void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr, int tcb_shift = 0) {
-    using PL = PlanB<SH, A>;
-    constexpr int KH = SH::KH;
+    using PL = PlanB<SH, A, VIEWS>;
+    constexpr int KH = SH::KH, SP = SH::SP;
     const Tables& T = PL::TB;
     out.ntiles = T.ntiles; out.nunits = T.nunits_padded;
     out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES; out.mfma_per_block = T.mfma_per_block;
@@ -258,12 +257,42 @@ void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
         out.fmt.assign(out.stream.size() / SH::ELEM_BYTES, KH == 1 ? 0 : (precision == NRNERF_PREC_F16 ? 2 : 1));
         out.bias_src.assign(out.bias.size(), -1);
     }
+    std::unique_ptr<FoldedViews> folded;
+    if (VIEWS) folded.reset(new FoldedViews(mlp));
+    const int64_t fbase = (VIEWS && lay) ? lay->folded_of(mlp.views_linear.weight) : -1;
+    const int64_t abase = (VIEWS && lay) ? lay->of(mlp.alpha_linear.weight) : -1;
+    // LK_B_VHEAD: value and flat-vector position of element (tile t, row i, slab s, half h, element e)
+    auto vhead = [&](int t, int i, int s, int h, int e, int64_t* src) -> float {
+        constexpr int NT_EV = PL::NT_EV, NS_DR = PL::NS_DR;
+        const int Kf = folded->lin.in_features, Wi = mlp.feature_linear.in_features;
+        *src = -1;
+        int col;                                    // column of the folded layer = output row of its transpose
+        if (t < NT_EV) {
+            const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3), q = t * 16 + r;      // inverse of tile_row
+            const int c = q < enc_slots(A::LV) ? enc_col(A::LV, hh, q) : -1;
+            if (c < 0) return 0.0f;
+            col = Wi + c;
+        } else {
+            col = 32 * (t - NT_EV) + i;
+            if (col >= Wi) return 0.0f;
+        }
+        if (s < NS_DR) {                            // d raw: only sigma (channel 3) enters here, through alpha_linear
+            const int ch = (2 * s + h) * KH + e;
+            if (ch != 3 || t < NT_EV) return 0.0f;
+            if (abase >= 0) *src = abase + col;
+            return mlp.alpha_linear.weight[col];
+        }
+        const int s2 = s - NS_DR, tp = s2 / SP, u = s2 % SP, r = u * KH + e;
+        const int y = 32 * tp + tile_row(r, h);
+        if (y >= folded->lin.out_features) return 0.0f;
+        if (fbase >= 0) *src = fbase + (int64_t)y * Kf + col;
+        return folded->w[(size_t)y * Kf + col];
+    };
     size_t written = 0;
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
-        // view-dependent head: alpha_linear stands in for output_linear, channel 3 (sigma) <-> its only row (see pack_pass)
-        const bool ah = sp.kind == LK_B_HEAD && mlp.use_viewdirs;
-        const nrnerf_linear* lin = (sp.kind == LK_B_HEAD) ? (ah ? &mlp.alpha_linear : &mlp.output_linear) : &mlp.pts_linears[sp.index];
+        const nrnerf_linear* lin = (sp.kind == LK_B_HEAD) ? &mlp.output_linear
+                                 : (sp.kind == LK_B_RGB) ? &mlp.rgb_linear : (sp.kind == LK_B_VHEAD) ? &mlp.alpha_linear : &mlp.pts_linears[sp.index];
         const int64_t wbase = lay ? lay->of(lin->weight) : -1;
         for (int t = 0; t < sp.nt; ++t) {
             const TileInfo& ti = T.tiles[sp.tile0 + t];
@@ -276,10 +305,16 @@ void pack_pass_bwd(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
                     int x = bwd_x<SH, A>(sp.kind, t, i, lin->in_features - ((sp.kind == LK_B_IN || sp.kind == LK_B_SKIP) ? tcb_shift : 0));
                     if (tcb_shift && sp.kind == LK_B_SKIP && x >= 3 + 6 * A::L) x += tcb_shift;      // see pack_pass
                     for (int e = 0; e < KH; ++e) {
-                        const int y = ah ? (((2 * s + h) * KH + e == 3) ? 0 : -1) : bwd_y<SH, A>(sp.kind, s, h, e, lin->out_features);
-                        const float w = (x < 0 || y < 0) ? 0.0f : lin->weight[(size_t)y * lin->in_features + x];
-                        if (lay && x >= 0 && y >= 0 && wbase >= 0)
-                            out.src[fi * (SH::FRAG_BYTES / SH::ELEM_BYTES) + (size_t)lane * KH + e] = (int32_t)(wbase + (int64_t)y * lin->in_features + x);
+                        float w;
+                        int64_t src = -1;
+                        if (sp.kind == LK_B_VHEAD) {
+                            w = vhead(t, i, s, h, e, &src);
+                        } else {
+                            const int y = bwd_y<SH, A>(sp.kind, s, h, e, lin->out_features);
+                            w = (x < 0 || y < 0) ? 0.0f : lin->weight[(size_t)y * lin->in_features + x];
+                            if (x >= 0 && y >= 0 && wbase >= 0) src = wbase + (int64_t)y * lin->in_features + x;
+                        }
+                        if (lay && src >= 0) out.src[fi * (SH::FRAG_BYTES / SH::ELEM_BYTES) + (size_t)lane * KH + e] = (int32_t)src;
                         if (KH == 1) {
                             std::memcpy(fr + lane * 4, &w, 4);
                         } else {
@@ -678,7 +713,8 @@ struct nrnerf_model {
     // training (nrnerf_train.h): transposed trunk weights of both networks; train_ok: see training_eligible, fp32 or bf16
     PassDev coarse_bwd, fine_bwd;
     bool train_ok = false;
-    // view-dependent head: forward images of the trunk alone with alpha_linear in the head slot (pack_pass, alpha_head)
+    // view-dependent head / time-conditioned baseline: bender-less forward images for trunk_fwd_train (with both branches of the head /
+    // without the latent columns)
     PassDev coarse_train, fine_train;
     // training of the ray bender (nrnerf_train_bend.h): its layers alone in fp32 (whatever the model's precision) and
     // their transposes; bend_train_ok: train_ok and a bender
@@ -762,13 +798,15 @@ int tcb_shift_of(const nrnerf_mlp_desc& mlp) {      // latent columns of a time-
     return mlp.time_conditioned ? mlp.pts_linears[0].in_features - (3 + 6 * ArchDefault::L) : 0;
 }
 void pack_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPass& out, const FlatLayout* lay = nullptr) {
-    const bool narrow = mlp.width == ArchNarrow::W;
+    const bool narrow = mlp.width == ArchNarrow::W, views = mlp.use_viewdirs != 0;      // (no view-dependent head at width 128)
     const int ts = tcb_shift_of(mlp);
     if (d.precision == NRNERF_PREC_F32) {
         if (narrow) pack_pass_bwd<ShapeF32, ArchNarrow>(mlp, d.precision, out, lay, ts);
+        else if (views) pack_pass_bwd<ShapeF32, ArchDefault, true>(mlp, d.precision, out, lay, ts);
         else pack_pass_bwd<ShapeF32, ArchDefault>(mlp, d.precision, out, lay, ts);
     } else {
         if (narrow) pack_pass_bwd<Shape16, ArchNarrow>(mlp, d.precision, out, lay, ts);
+        else if (views) pack_pass_bwd<Shape16, ArchDefault, true>(mlp, d.precision, out, lay, ts);
         else pack_pass_bwd<Shape16, ArchDefault>(mlp, d.precision, out, lay, ts);
     }
 }
@@ -783,13 +821,16 @@ int upload_training(const nrnerf_model_desc& d, nrnerf_model* m, hipStream_t ref
         rc = refresh ? refresh_pass(bf, m->fine_bwd, refresh_stream) : upload_pass(bf, m->fine_bwd);
     }
     if (refresh && rc == NRNERF_OK && hipStreamSynchronize(refresh_stream) != hipSuccess) rc = NRNERF_ERR_HIP;   // host images die here
-    if (rc == NRNERF_OK && (m->views || d.coarse->time_conditioned)) {       // trunk-only forward images: alpha head / without the latent columns
+    if (rc == NRNERF_OK && (m->views || d.coarse->time_conditioned)) {       // bender-less forward images: with the view-dependent head / without the latent columns
         auto pack_train = [&](const nrnerf_mlp_desc& mlp, PackedPass& out) {
             nrnerf_model_desc d2 = d;
             d2.bender = nullptr;
-            const bool ah = mlp.use_viewdirs != 0;
-            if (d.precision == NRNERF_PREC_F32) pack_pass<ShapeF32, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, ah, tcb_shift_of(mlp));
-            else pack_pass<Shape16Fast, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, ah, tcb_shift_of(mlp));
+            const int ts = tcb_shift_of(mlp);
+            if (mlp.use_viewdirs) {             // trunk + both branches of the view-dependent head (trunk_fwd_train<.., VIEWS>)
+                if (d.precision == NRNERF_PREC_F32) pack_pass<ShapeF32, ArchDefault, false, true>(d2, mlp, d.precision, out, lay, ts);
+                else pack_pass<Shape16Fast, ArchDefault, false, true>(d2, mlp, d.precision, out, lay, ts);
+            } else if (d.precision == NRNERF_PREC_F32) pack_pass<ShapeF32, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, ts);
+            else pack_pass<Shape16Fast, ArchDefault, false, false>(d2, mlp, d.precision, out, lay, ts);
         };
         PackedPass tc, tf;
         pack_train(*d.coarse, tc);
@@ -982,7 +1023,8 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
         PackedPass other;
         rc = (which == 2) ? pack_split(*desc, pk, other) : pack_split(*desc, other, pk);
     } else if (which == 4 || which == 5) {       // transposed trunk weights of the backward-data kernel (training)
-        if (desc->coarse->use_viewdirs || desc->coarse->time_conditioned || desc->precision == NRNERF_PREC_F16) return NRNERF_ERR_UNSUPPORTED;
+        if (desc->coarse->time_conditioned || desc->precision == NRNERF_PREC_F16) return NRNERF_ERR_UNSUPPORTED;
+        if (desc->coarse->use_viewdirs && desc->exact_viewdirs) return NRNERF_ERR_UNSUPPORTED;
         PackedPass fwd;
         nrnerf_model_desc d2 = *desc;
         d2.bender = nullptr;
@@ -1635,6 +1677,10 @@ int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, Tr
     t.d_h_extra = (const float*)a->d_hidden_extra;      // (its element type follows the model's precision: nrnerf_train.h)
     t.mask = (unsigned short*)a->relu_mask;
     if (m->precision != NRNERF_PREC_F32 && !t.mask) return NRNERF_ERR_INVALID;
+    if (m->views) {             // the colour branch behind the trunk (the *_views kernels)
+        if (!a->dirs || !a->hv || (bwd && !a->d_pre_v) || (m->precision != NRNERF_PREC_F32 && !a->hv_mask)) return NRNERF_ERR_INVALID;
+        t.dirs = a->dirs; t.hv = a->hv; t.hv_mask = (unsigned short*)a->hv_mask; t.d_pre_v = a->d_pre_v; t.d_dirs = a->d_dirs;
+    }
     return NRNERF_OK;
 }
 }  // namespace
@@ -1649,7 +1695,8 @@ int nrnerf_trunk_forward(const nrnerf_model* m, const nrnerf_trunk_args* a, void
     const bool f32 = m->precision == NRNERF_PREC_F32;
     const hipStream_t s = (hipStream_t)hip_stream;
     const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_fwd_train_f32_a5(t, m->num_cus, s) : launch_trunk_fwd_train_bf16_a5(t, m->num_cus, s))
-                                           : (f32 ? launch_trunk_fwd_train_f32(t, m->num_cus, s) : launch_trunk_fwd_train_bf16(t, m->num_cus, s));
+                       : m->views ? (f32 ? launch_trunk_fwd_train_f32_views(t, m->num_cus, s) : launch_trunk_fwd_train_bf16_views(t, m->num_cus, s))
+                                  : (f32 ? launch_trunk_fwd_train_f32(t, m->num_cus, s) : launch_trunk_fwd_train_bf16(t, m->num_cus, s));
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
@@ -1663,7 +1710,8 @@ int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, voi
     const bool f32 = m->precision == NRNERF_PREC_F32;
     const hipStream_t s = (hipStream_t)hip_stream;
     const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_bwd_f32_a5(t, m->num_cus, s) : launch_trunk_bwd_bf16_a5(t, m->num_cus, s))
-                                           : (f32 ? launch_trunk_bwd_f32(t, m->num_cus, s) : launch_trunk_bwd_bf16(t, m->num_cus, s));
+                       : m->views ? (f32 ? launch_trunk_bwd_f32_views(t, m->num_cus, s) : launch_trunk_bwd_bf16_views(t, m->num_cus, s))
+                                  : (f32 ? launch_trunk_bwd_f32(t, m->num_cus, s) : launch_trunk_bwd_bf16(t, m->num_cus, s));
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
@@ -1699,19 +1747,37 @@ int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* 
     kl = kl > kh ? kh : kl;
     int n = 0;
     for (int i = 1; i < D; ++i)                                     // hidden-to-hidden layers: the bulk, first in the grid
-        w.job[n++] = WgradJob{dpre + i * layer * esz, acts + (i - 1) * layer * esz, W, dwh + (size_t)(i - 1) * W * W, db + (size_t)i * W, kh, 0};
-    w.job[n++] = WgradJob{dpre, a->enc, 64, dwe, db, kl, 0};
-    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer * esz, a->enc, 64, dwe + (size_t)W * 64, db + (size_t)D * W, kl, 0};
-    w.job[n++] = WgradJob{acts + (D - 1) * layer * esz, a->g_head, 64, dwo, db + (size_t)D * W, kl, 0};
+        w.job[n++] = WgradJob{dpre + i * layer * esz, acts + (i - 1) * layer * esz, W, dwh + (size_t)(i - 1) * W * W, db + (size_t)i * W, kh, 0, W};
+    const bool views = m->views != 0;
+    float* const dwf = db + (size_t)(D + 1) * W;                     // view-dependent head: NRNERF_WGRAD_STRIDE_VIEWS
+    float* const dwd = dwf + (size_t)(W / 2) * W;
+    float* const dwr = dwd + (size_t)(W / 2) * 64;
+    float* const dbv = dwr + (size_t)(W / 2) * 64;
+    if (views) {
+        if (!a->dirs || !a->hv || !a->d_pre_v || !a->encv) return NRNERF_ERR_INVALID;
+        w.pstride = NRNERF_WGRAD_STRIDE_VIEWS(D, W);
+        // (half the rows of a hidden-to-hidden product per block: its workgroups finish early; kept at kh records so that the
+        //  caller's reduction knows two record counts only)
+        w.job[n++] = WgradJob{a->d_pre_v, acts + (D - 1) * layer * esz, W, dwf, dbv, kh, 0, W / 2};
+    }
+    w.job[n++] = WgradJob{dpre, a->enc, 64, dwe, db, kl, 0, W};
+    w.job[n++] = WgradJob{dpre + (SKIP + 1) * layer * esz, a->enc, 64, dwe + (size_t)W * 64, db + (size_t)D * W, kl, 0, W};
+    w.job[n++] = WgradJob{acts + (D - 1) * layer * esz, a->g_head, 64, dwo, db + (size_t)D * W, kl, 0, W};
+    if (views) {        // (their row sums -- of d_pre_v again, of hv -- land in the scratch row db[depth])
+        w.job[n++] = WgradJob{a->d_pre_v, a->encv, 64, dwd, db + (size_t)D * W, kl, 0, W / 2};
+        w.job[n++] = WgradJob{a->hv, a->g_head, 64, dwr, db + (size_t)D * W, kl, 0, W / 2};
+    }
     w.njobs = n;
     for (int j = 0, wg = 0; j < n; ++j) { w.job[j].wg0 = wg; wg += w.job[j].kch; w.nwg = wg; }
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     const hipStream_t s = (hipStream_t)hip_stream;
-    const WgradOperandArgs ops{a->pts4, a->d_raw4, a->n_rays, a->n_samples, ArchDefault::L, a->enc, a->g_head};
+    const WgradOperandArgs ops{a->pts4, a->d_raw4, a->n_rays, a->n_samples, ArchDefault::L, a->enc, a->g_head,
+                               views ? a->dirs : nullptr, ArchDefault::LV, views ? a->encv : nullptr};
     if ((f32 ? launch_wgrad_operands_f32(ops, s) : launch_wgrad_operands(ops, s)) != hipSuccess) return NRNERF_ERR_HIP;
     const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_wgrad_f32_a5(w, s) : launch_trunk_wgrad_bf16_a5(w, s))
-                                           : (f32 ? launch_trunk_wgrad_f32(w, s) : launch_trunk_wgrad_bf16(w, s));
+                            : views ? (f32 ? launch_trunk_wgrad_f32_views(w, s) : launch_trunk_wgrad_bf16_views(w, s))
+                                    : (f32 ? launch_trunk_wgrad_f32(w, s) : launch_trunk_wgrad_bf16(w, s));
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 

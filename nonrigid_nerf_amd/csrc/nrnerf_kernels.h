@@ -126,12 +126,22 @@ struct TrunkArgs {
                              // (the colour branch of the view-dependent head, evaluated by the caller)
     void* d_pre;             // backward out [D][M][W] gradient wrt the pre-activations (float or bf16)
     float* d_pts4;           // backward out [M,4]
+    // view-dependent head (the *_views kernels): the colour branch behind the trunk
+    const float* dirs;       // [M,3] view direction of every sample
+    void* hv;                // relu(views layer), W / 2 per sample: fp32 mode [M][W/2] float; bf16 mode [nblocks][W/2][32] bf16 (forward writes)
+    unsigned short* hv_mask; // bf16 mode: [nblocks][64 lanes][W/64] relu bits of hv (forward writes, backward reads)
+    void* d_pre_v;           // backward out: gradient wrt the views layer's pre-activation, layout of hv
+    float* d_dirs;           // backward out [M,3] gradient wrt dirs, or nullptr
 };
 
 hipError_t launch_trunk_fwd_train_f32(const TrunkArgs&, int num_cus, hipStream_t);
 hipError_t launch_trunk_fwd_train_bf16(const TrunkArgs&, int num_cus, hipStream_t);
 hipError_t launch_trunk_bwd_f32(const TrunkArgs&, int num_cus, hipStream_t);
 hipError_t launch_trunk_bwd_bf16(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_fwd_train_f32_views(const TrunkArgs&, int num_cus, hipStream_t);   // width 256 + view-dependent head
+hipError_t launch_trunk_fwd_train_bf16_views(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_bwd_f32_views(const TrunkArgs&, int num_cus, hipStream_t);
+hipError_t launch_trunk_bwd_bf16_views(const TrunkArgs&, int num_cus, hipStream_t);
 hipError_t launch_trunk_fwd_train_f32_a5(const TrunkArgs&, int num_cus, hipStream_t);      // architecture 5: trunk width 128
 hipError_t launch_trunk_fwd_train_bf16_a5(const TrunkArgs&, int num_cus, hipStream_t);
 hipError_t launch_trunk_bwd_f32_a5(const TrunkArgs&, int num_cus, hipStream_t);
@@ -230,8 +240,9 @@ struct WgradJob {
     int kch;                 // workgroups (= partial sums) of this job: chosen so that every workgroup of the launch has about
                              // the same work and all of them are resident at once
     int wg0;                 // index of the job's first workgroup in the 1-D grid
+    int rows;                // features of dz = rows of the product: W, or W / 2 (the colour branch's hidden layer)
 };
-constexpr int WGRAD_MAX_JOBS = 12;
+constexpr int WGRAD_MAX_JOBS = 14;
 struct WgradArgs {
     WgradJob job[WGRAD_MAX_JOBS];
     int njobs, nwg;          // grid = nwg = sum of the jobs' kch
@@ -250,15 +261,21 @@ struct WgradOperandArgs {
     int n_rays, S, L;        // L encoding frequencies (3 + 6 L <= 63)
     void* enc;               // out bf16 [nblocks][64][32]
     void* g_head;            // out bf16 [nblocks][64][32]
+    // view-dependent head: the encoding of the samples' view directions (reference column order, zero padded to 64) as a third operand
+    const float* dirs;       // [M,3] or nullptr
+    int LV;
+    void* encv;              // out, layout of enc
 };
 hipError_t launch_wgrad_operands(const WgradOperandArgs&, hipStream_t);
 // fp32 mode: the same two operands as rows, fp32 [M][64] each (columns >= 3 + 6 L / >= 4 zero)
 hipError_t launch_wgrad_operands_f32(const WgradOperandArgs&, hipStream_t);
 hipError_t launch_trunk_wgrad_bf16(const WgradArgs&, hipStream_t);
 hipError_t launch_trunk_wgrad_bf16_a5(const WgradArgs&, hipStream_t);
+hipError_t launch_trunk_wgrad_bf16_views(const WgradArgs&, hipStream_t);       // + the colour branch's three jobs (rows = W / 2)
 // fp32 mode (trunk_wgrad_f32): WgradJob::dz / x are fp32 rows [M][W] / [M][xw], WgradArgs::nblocks = M samples
 hipError_t launch_trunk_wgrad_f32(const WgradArgs&, hipStream_t);
 hipError_t launch_trunk_wgrad_f32_a5(const WgradArgs&, hipStream_t);
+hipError_t launch_trunk_wgrad_f32_views(const WgradArgs&, hipStream_t);
 
 // Re-pack weights on the device (nrnerf_model_update_device): dst[i] = convert(flat[src[i]]) (0 where src[i] < 0).
 // fmt[i]: 0 = fp32, 1 = bf16, 2 = f16, 3 = f16((w - f16(w)) * 2^11), the lo part of the bender's split product;

@@ -132,7 +132,11 @@ enum LayerKind : int {
     LK_BB_HID,   // network[i]^T:             BW -> BW
     LK_BB_IN,    // network[0]^T:             BW -> the LAT latent inputs (the xyz inputs carry no gradient)
     LK_BR_OUT,   // rigidity_network[RD-1]^T: d logit (1) -> RW
-    LK_BR_HID    // rigidity_network[i]^T:    RW -> RW   (rigidity_network[0]^T is not needed: its input is xyz)
+    LK_BR_HID,   // rigidity_network[i]^T:    RW -> RW   (rigidity_network[0]^T is not needed: its input is xyz)
+    // backward-data layers of the view-dependent head (training; they replace LK_B_HEAD at the front of the trunk's plan)
+    LK_B_RGB,    // rgb_linear^T: d raw (channels 0..2) -> d hv (W/2: the hidden layer of the colour branch)
+    LK_B_VHEAD   // [alpha_linear; views_linears[0] o feature_linear]^T: [d raw (channel 3 = sigma), d z_v (W/2)] ->
+                 //   [direction-encoding slots (1 tile), d h_{D-1} (W)]: both branches of the head land in the same accumulators
 };
 
 struct LayerSpec {
@@ -251,10 +255,13 @@ constexpr Tables build_tables() {
 // sin/cos values.
 constexpr NRN_HD int enc_tiles(int L) { return cdiv(enc_slots(L), 16); }
 constexpr int DRAW_LEN = 8;                         // d raw: C <= 5 channels, padded
-template <class SH, class A>
+// VIEWS: the view-dependent head (rnh:284-304) in front -- rgb_linear^T, then ONE layer for alpha_linear^T and the transposed
+// (views_linears[0] o feature_linear) whose first output tile is the gradient of the direction encoding (in encoding-slot
+// order, like the point encoding's) and whose other tiles are d h_{D-1}.
+template <class SH, class A, bool VIEWS = false>
 constexpr Tables build_tables_bwd() {
     constexpr int KH = SH::KH, SP = SH::SP;
-    constexpr int NT_W = A::W / 32, NT_E = enc_tiles(A::L);
+    constexpr int NT_W = A::W / 32, NT_E = enc_tiles(A::L), NT_EV = enc_tiles(A::LV);
     constexpr int NS_DR = cdiv(DRAW_LEN, 2 * KH);
     Tables T{};
     int nl = 0, tile0 = 0;
@@ -263,7 +270,12 @@ constexpr Tables build_tables_bwd() {
         tile0 += nt;
         ++nl;
     };
-    add(LK_B_HEAD, 0, NS_DR, NT_W);
+    if (VIEWS) {
+        add(LK_B_RGB, 0, NS_DR, NT_W / 2);
+        add(LK_B_VHEAD, 0, NS_DR + (NT_W / 2) * SP, NT_EV + NT_W);
+    } else {
+        add(LK_B_HEAD, 0, NS_DR, NT_W);
+    }
     for (int i = A::D - 1; i >= 1; --i) {
         if (i - 1 == A::SKIP) add(LK_B_SKIP, i, NT_W * SP, NT_E + NT_W);
         else add(LK_B_HID, i, NT_W * SP, NT_W);
@@ -275,19 +287,20 @@ constexpr Tables build_tables_bwd() {
     return T;
 }
 
-template <class SH, class A>
+template <class SH, class A, bool VIEWS = false>
 struct PlanB {
     static_assert(!A::TCB, "no training support for the time-conditioned baseline");
     static constexpr int KH = SH::KH, SP = SH::SP;
-    static constexpr int NT_W = A::W / 32, NT_E = enc_tiles(A::L);
+    static constexpr int NT_W = A::W / 32, NT_E = enc_tiles(A::L), NT_EV = enc_tiles(A::LV);
     static constexpr int NS_DR = cdiv(DRAW_LEN, 2 * KH);
-    static constexpr Tables TB = build_tables_bwd<SH, A>();
+    static constexpr Tables TB = build_tables_bwd<SH, A, VIEWS>();
     static constexpr int NLAYERS = TB.nlayers, NTILES = TB.ntiles, NFRAGS = TB.nfrags;
     static constexpr int NUNITS = TB.nunits, NUP = TB.nunits_padded, UF = SH::UNIT_FRAGS;
     static constexpr int MFMA_PER_BLOCK = TB.mfma_per_block;
     static_assert(TB.ntiles <= MAX_TILES && TB.nlayers <= MAX_LAYERS, "plan too large");
-    // layers[0] = head^T; layers[1 + (D-1-i)] = pts_linears[i]^T for i = D-1 .. 1; layers[D] = pts_linears[0]^T
-    static constexpr int layer_of(int i) { return i == 0 ? A::D : 1 + (A::D - 1 - i); }
+    // layers[0] = head^T (VIEWS: rgb_linear^T, [alpha; views o feature]^T); then pts_linears[i]^T for i = D-1 .. 1; last: pts_linears[0]^T
+    static constexpr int H = VIEWS ? 1 : 0;
+    static constexpr int layer_of(int i) { return H + (i == 0 ? A::D : 1 + (A::D - 1 - i)); }
 };
 
 // Backward-data plan of the bender and rigidity MLPs: network[BD-1..0]^T, then rigidity_network[RD-1..1]^T.
@@ -331,7 +344,7 @@ struct PlanBB {
 template <class SH, class A>
 constexpr NRN_HD int bwd_y(int kind, int s, int h, int e, int out_features) {
     constexpr int KH = SH::KH, SP = SH::SP;
-    if (kind == LK_B_HEAD || kind == LK_BB_OUT || kind == LK_BR_OUT) {
+    if (kind == LK_B_HEAD || kind == LK_BB_OUT || kind == LK_BR_OUT || kind == LK_B_RGB) {
         const int ch = (2 * s + h) * KH + e;
         return ch < out_features ? ch : -1;
     }

@@ -105,10 +105,45 @@ __global__ void __launch_bounds__(256) wgrad_operands_kernel(const WgradOperandA
         for (int o = 64 + 4 * j; o < 64 * 16; o += 128) *(u32x4*)(gh + o) = u32x4{0u, 0u, 0u, 0u};      // rows 4 .. 63
     }
 }
+// view-dependent head: Embedder.embed of the samples' view directions as a third operand tile, [block][64 rows][32 samples]
+// bf16, rows in the reference's column order [d, sin(2^f d), cos(2^f d)] (f < LV), the rest zero.  Thread (block, row, sample
+// pair) writes one dword.
+__global__ void __launch_bounds__(256) wgrad_operand_dirs_kernel(const WgradOperandArgs a) {
+    const int bpr = (a.S + 31) >> 5;
+    const long long nblocks = (long long)a.n_rays * bpr;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nblocks * 1024) return;
+    const int jp = (int)(t & 15), row = (int)((t >> 4) & 63);
+    const long long blk = t >> 10;
+    const int ray = (int)(blk / bpr), s0 = (int)(blk % bpr) * 32 + 2 * jp;
+    unsigned w = 0;
+    if (row < 3 + 6 * a.LV) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int sidx = s0 + e;
+            float v = 0.0f;
+            if (sidx < a.S) {
+                const float* d = a.dirs + ((size_t)ray * a.S + sidx) * 3;
+                if (row < 3) v = d[row];
+                else {
+                    const int kk = row - 3, f = kk / 6, r = kk % 6;
+                    const float arg = d[r % 3] * (float)(1 << f);
+                    v = r < 3 ? sinf(arg) : cosf(arg);
+                }
+            }
+            w |= bf16_bits(v) << (16 * e);
+        }
+    }
+    ((unsigned*)a.encv)[(size_t)blk * 1024 + row * 16 + jp] = w;
+}
 hipError_t launch_wgrad_operands(const WgradOperandArgs& a, hipStream_t stream) {
     const long long total = (long long)a.n_rays * ((a.S + 31) / 32) * (a.L + 2) * 32;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(wgrad_operands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    if (a.dirs && a.encv) {
+        const long long tv = (long long)a.n_rays * ((a.S + 31) / 32) * 1024;
+        hipLaunchKernelGGL(wgrad_operand_dirs_kernel, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -136,6 +171,22 @@ __global__ void __launch_bounds__(256) wgrad_operands_f32_kernel(const WgradOper
     *(f32x4*)((float*)a.enc + (size_t)m * 64 + 4 * q) = f32x4{v[0], v[1], v[2], v[3]};
     const f32x4 g = (q == 0) ? *(const f32x4*)(a.d_raw4 + (size_t)m * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     *(f32x4*)((float*)a.g_head + (size_t)m * 64 + 4 * q) = g;
+    if (a.dirs && a.encv) {             // view-dependent head: the direction's encoding as a third row
+        const float* d = a.dirs + (size_t)m * 3;
+        float u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = 4 * q + e;
+            if (col < 3) u[e] = d[col];
+            else if (col < 3 + 6 * a.LV) {
+                const int kk = col - 3, f = kk / 6, r = kk % 6;
+                float sn, cs;
+                sincosf(d[r % 3] * (float)(1 << f), &sn, &cs);
+                u[e] = r < 3 ? sn : cs;
+            } else u[e] = 0.0f;
+        }
+        *(f32x4*)((float*)a.encv + (size_t)m * 64 + 4 * q) = f32x4{u[0], u[1], u[2], u[3]};
+    }
 }
 hipError_t launch_wgrad_operands_f32(const WgradOperandArgs& a, hipStream_t stream) {
     const long long total = (long long)a.n_rays * a.S * 16;

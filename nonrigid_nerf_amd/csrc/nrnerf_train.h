@@ -75,9 +75,14 @@ __device__ __forceinline__ void store_tile_bf16(__bf16* dst, const FRAG& f0, con
 // ------------------------------------------------------------------------------------------
 // forward with saved activations
 // ------------------------------------------------------------------------------------------
-template <class P, class A, int WAVES>
+// VIEWS: the view-dependent head (rnh:284-304) behind the trunk, as in the inference kernel -- alpha_linear, then
+// relu(views_linears[0]([feature_linear(h), enc(direction)])) as ONE layer (feature_linear folded into its weights by the
+// packer), then rgb_linear -- on the per-sample directions the caller hands in (TrunkArgs::dirs: the finite differences of the
+// bent points, or the rays' own).  Saved for the backward pass: the colour branch's hidden activation hv (W / 2 values per
+// sample, layout of `acts`) and, bf16 mode, its relu bits.
+template <class P, class A, int WAVES, bool VIEWS = false>
 __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_fwd_train(const TrunkArgs a) {
-    using PL = Plan<P, A, false, false>;
+    using PL = Plan<P, A, false, VIEWS>;
     using frag = typename P::frag;
     using PE = std::conditional_t<P::KH == 1, PolF32, PolF16>;
     using efrag = typename PE::frag;
@@ -201,9 +206,74 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_fwd_tr
             }
         });
         float raw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        auto take_raw = [&](auto, const f32x16& acc) { raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; raw[3] = acc[3]; raw[4] = acc[4]; };
-        if constexpr ((A::D - 1) % 2 == 1) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, hb, none, take_raw);
-        else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, ha, none, take_raw);
+        if constexpr (!VIEWS) {
+            auto take_raw = [&](auto, const f32x16& acc) { raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; raw[3] = acc[3]; raw[4] = acc[4]; };
+            if constexpr ((A::D - 1) % 2 == 1) dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, hb, none, take_raw);
+            else dense<P, P, PL, PL::L_HEAD, NH, 0>(st, bias_lane, ha, none, take_raw);
+        } else {
+            // encoding of the sample's view direction in B-operand order (Embedder with LV frequencies, as the point's above)
+            constexpr int NS_ENCV = PL::NS_ENCV, F0V = enc_F0(A::LV), NSLOTV = NS_ENCV * KH;
+            const float* dp = a.dirs + so * 3;
+            const float dirv[3] = {dp[0], dp[1], dp[2]};
+            float evv[NSLOTV];
+#pragma unroll
+            for (int q = 0; q < NSLOTV; ++q) evv[q] = 0.0f;
+            evv[0] = h ? dirv[2] : dirv[0];
+            evv[1] = h ? 0.0f : dirv[1];
+            const float vscale = h ? (float)(1 << F0V) : 1.0f;
+            const float drev[3] = {dirv[0] * 0.15915494309189535f, dirv[1] * 0.15915494309189535f, dirv[2] * 0.15915494309189535f};
+            static_for<0, F0V>([&](auto fc) {
+                constexpr int fl = decltype(fc)::value;
+                static_for<0, 3>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    float sv, cv;
+                    enc_sincos<KH == 1>(dirv[c], drev[c], vscale * (float)(1 << fl), &sv, &cv);
+                    evv[2 + 2 * (3 * fl + c)] = sv;
+                    evv[2 + 2 * (3 * fl + c) + 1] = cv;
+                });
+            });
+            efrag encv[NS_ENCV];
+            static_for<0, NS_ENCV>([&](auto sc_) {
+                constexpr int s = decltype(sc_)::value;
+                static_for<0, KH>([&](auto ec) { constexpr int e = decltype(ec)::value; PE::template set<e>(encv[s], evv[s * KH + e]); });
+            });
+            constexpr int NTV = NT_W / 2, NV = NTV * SP;
+            frag hv[NV];
+            unsigned mv = 0;
+            // epilogue of the colour branch's hidden layer: relu, keep (rows [M][W/2] fp32, or bf16 tiles [block][W/2][32] + relu bits
+            // [block][lane][NTV] u16), hand to rgb_linear
+            auto keep_v = [&](auto tc, const f32x16& acc, auto& out) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (KH == 1) {
+                    if (ok) {
+                        const size_t row = so * (A::W / 2) + 32 * t + 4 * h;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            store4<P>(a.hv, row + 8 * q, relu_bits(acc[4 * q]), relu_bits(acc[4 * q + 1]), relu_bits(acc[4 * q + 2]), relu_bits(acc[4 * q + 3]));
+                    }
+                }
+                pack_tile<P, true, t>(acc, out);
+                if constexpr (KH != 1) {
+                    if (blk_ok) store_tile_bf16((__bf16*)a.hv + (((size_t)b) * (A::W / 2) + 32 * t + 4 * h) * 32 + j, out[t * SP], out[t * SP + 1]);
+                    unsigned m = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m |= (acc[r] > 0.0f ? 1u : 0u) << r;
+                    if constexpr ((t & 1) == 0) {
+                        mv = m;
+                    } else {
+                        mv |= m << 16;
+                        if (blk_ok) ((unsigned*)(a.hv_mask + ((size_t)b * 64 + lane) * NTV))[t / 2] = mv;
+                    }
+                }
+            };
+            auto head = [&](auto& hx) {
+                dense<P, P, PL, PL::L_ALPHA, NH, 0>(st, bias_lane, hx, none, [&](auto, const f32x16& acc) { raw[3] = acc[0]; });
+                dense<PE, P, PL, PL::L_VIEWS, NS_ENCV, NH>(st, bias_lane, encv, hx, [&](auto tc, const f32x16& acc) { keep_v(tc, acc, hv); });
+                dense<P, P, PL, PL::L_RGB, NV, 0>(st, bias_lane, hv, none, [&](auto, const f32x16& acc) {
+                    raw[0] = acc[0]; raw[1] = acc[1]; raw[2] = acc[2]; });
+            };
+            if constexpr ((A::D - 1) % 2 == 1) head(hb); else head(ha);
+        }
         if (ok && h == 0) {
             *(f32x4*)(a.raw4 + so * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
             if (a.raw_out) {
@@ -220,12 +290,17 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_fwd_tr
 // ------------------------------------------------------------------------------------------
 // backward-data
 // ------------------------------------------------------------------------------------------
-template <class P, class A, int WAVES>
+// VIEWS: the view-dependent head first -- rgb_linear^T on d raw's colour channels gives d hv, masked with hv's relu bits =
+// d z_v (stored for the weight gradients); then ONE layer takes [d raw (sigma), d z_v] to [gradient of the direction encoding
+// (one tile, encoding-slot order), d h_{D-1}]: alpha_linear^T and the transposed folded views layer share accumulators
+// (PlanB<.., true>).  The direction encoding's gradient goes through the encoding's derivative to TrunkArgs::d_dirs.
+template <class P, class A, int WAVES, bool VIEWS = false>
 __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(const TrunkArgs a) {
-    using PL = PlanB<P, A>;
+    using PL = PlanB<P, A, VIEWS>;
     using frag = typename P::frag;
     constexpr int KH = P::KH, SP = P::SP, NT_W = PL::NT_W, NT_E = PL::NT_E, NS_DR = PL::NS_DR;
     static_assert(NT_E == 2, "the encoding gradient is kept in two accumulator tiles");
+    static_assert(!VIEWS || PL::NT_EV == 1, "the direction encoding's gradient is kept in one accumulator tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
@@ -320,9 +395,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
                 if constexpr (t == NT_W / 2 - 1) load_masks(lc, std::integral_constant<int, 1>{});      // second half of this layer's record
             }
         };
-        // head^T: d h_{D-1}  (+ the caller's extra gradient wrt h_{D-1}: the colour branch of the view-dependent head)
-        load_masks(std::integral_constant<int, A::D - 1>{}, std::integral_constant<int, 0>{});
-        dense<P, P, PL, 0, NS_DR, 0>(st, bias_lane, dr, none, [&](auto tc, const f32x16& acc) {
+        // d h_{D-1} from tile t of head^T's output (+ the caller's extra gradient wrt h_{D-1}, if any), masked and stored
+        auto last_hidden = [&](auto tc, const f32x16& acc) {
             constexpr int t = decltype(tc)::value;
             f32x16 g = acc;
             if (a.d_h_extra) {          // rows of the saved arrays' element type: fp32, or (bf16 mode) bf16
@@ -334,7 +408,83 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
                     for (int k = 0; k < 4; ++k) g[4 * q + k] += ok ? ex[k] : 0.0f;
                 }
             }
-            mask_store(std::integral_constant<int, A::D - 1>{}, tc, g, ha); });
+            mask_store(std::integral_constant<int, A::D - 1>{}, tc, g, ha);
+        };
+        if constexpr (!VIEWS) {
+            // head^T: d h_{D-1}
+            load_masks(std::integral_constant<int, A::D - 1>{}, std::integral_constant<int, 0>{});
+            dense<P, P, PL, 0, NS_DR, 0>(st, bias_lane, dr, none, last_hidden);
+        } else {
+            constexpr int NTV = NT_W / 2, NV = NTV * SP;
+            static_assert(KH == 1 || NTV == 4, "one 8-byte record of relu bits per lane");
+            frag dv[NV];
+            f32x16 dencv;                   // gradient of the direction encoding, slot q of this lane half in register q
+            unsigned long long mvw = 0;
+            if constexpr (KH != 1) mvw = *(const unsigned long long*)(a.hv_mask + ((size_t)b * 64 + lane) * NTV);
+            // rgb_linear^T: d hv, masked with hv > 0 = d z_v, stored (layout of d_pre) and handed on
+            dense<P, P, PL, 0, NS_DR, 0>(st, bias_lane, dr, none, [&](auto tc, const f32x16& acc) {
+                constexpr int t = decltype(tc)::value;
+                f32x16 g = acc;
+                if constexpr (KH == 1) {
+                    const size_t row = so * (A::W / 2) + 32 * t + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 hvv = load4<P>(a.hv, row + 8 * q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) g[4 * q + k] = (hvv[k] > 0.0f) ? acc[4 * q + k] : 0.0f;
+                        if (ok) store4<P>(a.d_pre_v, row + 8 * q, g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+                    }
+                } else {
+                    const unsigned m = (unsigned)(mvw >> (16 * t)) & 0xffffu;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[r];
+                        g[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & ((int)(m << (31 - r)) >> 31));
+                    }
+                }
+                pack_tile<P, false, t>(g, dv);
+                if constexpr (KH != 1) {
+                    if (blk_ok) store_tile_bf16((__bf16*)a.d_pre_v + (((size_t)b) * (A::W / 2) + 32 * t + 4 * h) * 32 + j, dv[t * SP], dv[t * SP + 1]);
+                }
+            });
+            // [alpha_linear; views o feature]^T: tile 0 = the direction encoding's gradient, tiles 1 .. NT_W = d h_{D-1}
+            load_masks(std::integral_constant<int, A::D - 1>{}, std::integral_constant<int, 0>{});
+            dense<P, P, PL, 1, NS_DR, NV>(st, bias_lane, dr, dv, [&](auto tc, const f32x16& acc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t == 0) dencv = acc;
+                else last_hidden(std::integral_constant<int, t - 1>{}, acc);
+            });
+            // (right away: sixteen registers held to the end of the pass spilled two at this kernel's 256-register budget)
+            if (a.d_dirs) {             // through the direction's encoding (LV frequencies), as for the point at the end of the pass
+                const float* dq = a.dirs + so * 3;
+                const float dv3[3] = {dq[0], dq[1], dq[2]};
+                constexpr int F0V = enc_F0(A::LV);
+                float dd[3] = {0.f, 0.f, 0.f};
+                auto vslot = [&](auto qc) -> float { return dencv[decltype(qc)::value]; };
+                dd[0] = h ? 0.0f : vslot(std::integral_constant<int, 0>{});
+                dd[1] = h ? 0.0f : vslot(std::integral_constant<int, 1>{});
+                dd[2] = h ? vslot(std::integral_constant<int, 0>{}) : 0.0f;
+                const float vscale = h ? (float)(1 << F0V) : 1.0f;
+                const float drev[3] = {dv3[0] * 0.15915494309189535f, dv3[1] * 0.15915494309189535f, dv3[2] * 0.15915494309189535f};
+                static_for<0, F0V>([&](auto fc) {
+                    constexpr int fl = decltype(fc)::value;
+                    static_for<0, 3>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if (h * F0V + fl < A::LV) {
+                            const float scale = vscale * (float)(1 << fl);
+                            float sv, cv;
+                            enc_sincos<KH == 1>(dv3[c], drev[c], scale, &sv, &cv);
+                            const float ds = vslot(std::integral_constant<int, 2 + 2 * (3 * fl + c)>{});
+                            const float dc = vslot(std::integral_constant<int, 2 + 2 * (3 * fl + c) + 1>{});
+                            dd[c] += scale * (cv * ds - sv * dc);
+                        }
+                    });
+                });
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dd[c] += __shfl_xor(dd[c], 32);
+                if (ok && h == 0) { float* o = a.d_dirs + so * 3; o[0] = dd[0]; o[1] = dd[1]; o[2] = dd[2]; }
+            }
+        }
         f32x16 denc[NT_E];
         // layers D-1 .. 1 (transposed): input d z_i in the buffer the previous step filled, output d h_{i-1}
         static_for<0, A::D - 1>([&](auto kc) {
@@ -411,11 +561,13 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
 // current block's MFMAs.  Measured 3.2 TB/s of unique HBM traffic at 16 384 rays; 8 waves with half the tiles each (more
 // loads in flight, but every fragment requested by more waves) were 10 % slower.  The bias gradient comes along: the waves of column 0 add up the dz fragments they hold (eight
 // conversions + adds per fragment on the VALU, one register per row tile).
-template <class A, int TCW>      // TCW: column tiles of x per wave, compile-time so that the MFMAs issue back to back
-__device__ __forceinline__ void trunk_wgrad_job(const WgradArgs& a, const WgradJob& jb, int c) {
+// DZW: features of dz (rows of the product: W, or W / 2 for the colour branch's hidden layer); TCW: column tiles of x per wave,
+// compile-time so that the MFMAs issue back to back
+template <int DZW, int TCW>
+__device__ __forceinline__ void trunk_wgrad_job(const WgradJob& jb, const long long nblocks, const long long pstride, const int sync_every, int c) {
     using P = PolBF16;
     typedef typename P::frag frag;
-    constexpr int NTR = A::W / 32;                  // row tiles of dz^T (features of this layer)
+    constexpr int NTR = DZW / 32;                   // row tiles of dz^T (features of this layer)
     constexpr int TR = NTR / 2;                     // per wave
     static_assert(NTR % 2 == 0, "two wave rows");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -437,7 +589,7 @@ __device__ __forceinline__ void trunk_wgrad_job(const WgradArgs& a, const WgradJ
         for (int u = 0; u < TR; ++u)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fa[u][ks] = *(const frag*)(dz + ((size_t)blk * A::W + 32 * (wr * TR + u) + i) * 32 + ks * 16 + 8 * h);
+                fa[u][ks] = *(const frag*)(dz + ((size_t)blk * DZW + 32 * (wr * TR + u) + i) * 32 + ks * 16 + 8 * h);
 #pragma unroll
         for (int v = 0; v < TCW; ++v)
 #pragma unroll
@@ -460,10 +612,10 @@ __device__ __forceinline__ void trunk_wgrad_job(const WgradArgs& a, const WgradJ
     };
     frag fa0[TR][2], fb0[TCW][2], fa1[TR][2], fb1[TCW][2];
     long long blk = c;
-    if (blk < a.nblocks) load(blk, fa0, fb0);
+    if (blk < nblocks) load(blk, fa0, fb0);
     int since_sync = 0;
-    while (blk < a.nblocks) {
-        if (a.sync_every > 0 && ++since_sync >= a.sync_every) {      // all four waves have the same trip count: uniform
+    while (blk < nblocks) {
+        if (sync_every > 0 && ++since_sync >= sync_every) {      // all four waves have the same trip count: uniform
             since_sync = 0;
             __builtin_amdgcn_s_barrier();                            // (loads already requested stay in flight across it)
         }
@@ -471,20 +623,20 @@ __device__ __forceinline__ void trunk_wgrad_job(const WgradArgs& a, const WgradJ
         //  Free-running on purpose: a workgroup barrier every 2 / 4 / 8 blocks removes the redundant HBM reads -- the waves
         //  that share fragments stay in step -- but costs 15-45 %: tools/experiments/README.md)
         const long long n1 = blk + jb.kch;
-        if (n1 < a.nblocks) load(n1, fa1, fb1);
+        if (n1 < nblocks) load(n1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         step(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        if (n1 >= a.nblocks) break;
+        if (n1 >= nblocks) break;
         const long long n2 = n1 + jb.kch;
-        if (n2 < a.nblocks) load(n2, fa0, fb0);
+        if (n2 < nblocks) load(n2, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         step(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         blk = n2;
     }
     // D tile: lane (h, j) holds rows tile_row(r, h), column j
-    float* dw = jb.dw + (size_t)c * a.pstride;
+    float* dw = jb.dw + (size_t)c * pstride;
 #pragma unroll
     for (int u = 0; u < TR; ++u) {
 #pragma unroll
@@ -494,27 +646,42 @@ __device__ __forceinline__ void trunk_wgrad_job(const WgradArgs& a, const WgradJ
                 dw[(size_t)(32 * (wr * TR + u) + tile_row(r, h)) * jb.xw + 32 * (wc * TCW + v) + i] = acc[u][v][r];
         }
         const float rowsum = bsum[u] + __shfl_xor(bsum[u], 32);        // the two lane halves hold samples 8h .. 8h + 7 of each k-step
-        if (wc == 0 && h == 0) jb.db[(size_t)c * a.pstride + 32 * (wr * TR + u) + i] = rowsum;
+        if (wc == 0 && h == 0) jb.db[(size_t)c * pstride + 32 * (wr * TR + u) + i] = rowsum;
     }
 }
 
-template <class A>
+// VIEWS: with the three jobs of the view-dependent head's colour branch (rows = W / 2).  A kernel of its own, its four job
+// shapes as out-of-line functions: inlined side by side, hipcc 7.2 allocates 256 registers + scratch to all of them (the plain
+// kernel's two shapes get 442 and no scratch).
+template <int DZW, int TCW>
+__device__ __attribute__((noinline)) void trunk_wgrad_job_call(const WgradJob jb, const long long nblocks, const long long pstride, const int sync_every, int c) {
+    trunk_wgrad_job<DZW, TCW>(jb, nblocks, pstride, sync_every, c);
+}
+template <class A, bool VIEWS = false>
 __global__ void __launch_bounds__(256, 1) trunk_wgrad(const WgradArgs a) {
     int j = 0;
     for (int k = 1; k < a.njobs; ++k)
         if ((int)blockIdx.x >= a.job[k].wg0) j = k;           // jobs are listed in grid order
     const WgradJob jb = a.job[j];
     const int c = (int)blockIdx.x - jb.wg0;
-    if (jb.xw == A::W) trunk_wgrad_job<A, A::W / 64>(a, jb, c);          // hidden-to-hidden layer
-    else trunk_wgrad_job<A, 1>(a, jb, c);                                 // 64 columns: encoding / head
+    if constexpr (!VIEWS) {
+        if (jb.xw == A::W) trunk_wgrad_job<A::W, A::W / 64>(jb, a.nblocks, a.pstride, a.sync_every, c);          // hidden-to-hidden layer
+        else trunk_wgrad_job<A::W, 1>(jb, a.nblocks, a.pstride, a.sync_every, c);                                 // 64 columns: encoding / head
+    } else if (jb.rows == A::W) {
+        if (jb.xw == A::W) trunk_wgrad_job_call<A::W, A::W / 64>(jb, a.nblocks, a.pstride, a.sync_every, c);
+        else trunk_wgrad_job_call<A::W, 1>(jb, a.nblocks, a.pstride, a.sync_every, c);
+    } else {                                                                     // view-dependent head: rows = W / 2
+        if (jb.xw == A::W) trunk_wgrad_job_call<A::W / 2, A::W / 64>(jb, a.nblocks, a.pstride, a.sync_every, c); // d z_v^T h_{D-1}
+        else trunk_wgrad_job_call<A::W / 2, 1>(jb, a.nblocks, a.pstride, a.sync_every, c);                        // d z_v^T enc(direction), hv^T d raw
+    }
 }
 
-template <class A>
+template <class A, bool VIEWS = false>
 static hipError_t launch_trunk_wgrad(const WgradArgs& a, hipStream_t stream) {
     if (a.njobs <= 0 || a.nwg <= 0 || a.nblocks <= 0) return hipSuccess;
     for (int j = 0; j < a.njobs; ++j)
-        if ((a.job[j].xw != 64 && a.job[j].xw != A::W) || a.job[j].kch < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(trunk_wgrad<A>, dim3(a.nwg), dim3(256), 0, stream, a);
+        if ((a.job[j].xw != 64 && a.job[j].xw != A::W) || (a.job[j].rows != A::W && !(VIEWS && a.job[j].rows == A::W / 2)) || a.job[j].kch < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((trunk_wgrad<A, VIEWS>), dim3(a.nwg), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -537,8 +704,9 @@ template <int N>
 __device__ __forceinline__ float fvec_get(const typename fvec<N>::type& v, int k) {
     if constexpr (N == 1) return v; else return v[k];
 }
-template <int W, int CR, int CC>
+template <int DZW, int CR, int CC>       // DZW: features of dz (its row length); CR = DZW / 64
 __device__ __forceinline__ void trunk_wgrad_f32_job(const WgradArgs& a, const WgradJob& jb, int c) {
+    constexpr int W = DZW;
     typedef typename fvec<CR>::type vr;
     typedef typename fvec<CC>::type vc;
 #ifndef NRN_WGF_G
@@ -641,32 +809,38 @@ __device__ __forceinline__ void trunk_wgrad_f32_job(const WgradArgs& a, const Wg
     }
 }
 
-template <class A>
+template <class A, bool VIEWS = false>
 __global__ void __launch_bounds__(256, 1) trunk_wgrad_f32(const WgradArgs a) {
     int j = 0;
     for (int q = 1; q < a.njobs; ++q)
         if ((int)blockIdx.x >= a.job[q].wg0) j = q;           // jobs are listed in grid order
     const WgradJob jb = a.job[j];
     const int c = (int)blockIdx.x - jb.wg0;
-    if (jb.xw == A::W) trunk_wgrad_f32_job<A::W, A::W / 64, A::W / 64>(a, jb, c);      // hidden-to-hidden layer
-    else trunk_wgrad_f32_job<A::W, A::W / 64, 1>(a, jb, c);                             // 64 columns: encoding / head
+    if (jb.rows == A::W) {
+        if (jb.xw == A::W) trunk_wgrad_f32_job<A::W, A::W / 64, A::W / 64>(a, jb, c);      // hidden-to-hidden layer
+        else trunk_wgrad_f32_job<A::W, A::W / 64, 1>(a, jb, c);                             // 64 columns: encoding / head
+    } else if constexpr (VIEWS) {                                                           // view-dependent head: rows = W / 2
+        if (jb.xw == A::W) trunk_wgrad_f32_job<A::W / 2, A::W / 128, A::W / 64>(a, jb, c);
+        else trunk_wgrad_f32_job<A::W / 2, A::W / 128, 1>(a, jb, c);
+    }
 }
 
-template <class A>
+template <class A, bool VIEWS = false>
 static hipError_t launch_trunk_wgrad_f32(const WgradArgs& a, hipStream_t stream) {
     if (a.njobs <= 0 || a.nwg <= 0 || a.nblocks <= 0) return hipSuccess;
     for (int j = 0; j < a.njobs; ++j)
-        if ((a.job[j].xw != 64 && a.job[j].xw != A::W) || a.job[j].kch < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(trunk_wgrad_f32<A>, dim3(a.nwg), dim3(256), 0, stream, a);
+        if ((a.job[j].xw != 64 && a.job[j].xw != A::W) || (a.job[j].rows != A::W && !(VIEWS && a.job[j].rows == A::W / 2)) || a.job[j].kch < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((trunk_wgrad_f32<A, VIEWS>), dim3(a.nwg), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
-template <class P, class A, int WAVES, bool BWD>
+template <class P, class A, int WAVES, bool BWD, bool VIEWS = false>
 static hipError_t launch_trunk_train(const TrunkArgs& a, int num_cus, hipStream_t stream) {
-    constexpr int NTILES = BWD ? PlanB<P, A>::NTILES : Plan<P, A, false, false>::NTILES;
+    constexpr int NTILES = BWD ? PlanB<P, A, VIEWS>::NTILES : Plan<P, A, false, VIEWS>::NTILES;
     const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)NTILES * 32 * sizeof(float);
     void (*kern)(const TrunkArgs) = nullptr;
-    if constexpr (BWD) kern = trunk_bwd<P, A, WAVES>; else kern = trunk_fwd_train<P, A, WAVES>;
+    if constexpr (BWD) kern = trunk_bwd<P, A, WAVES, VIEWS>; else kern = trunk_fwd_train<P, A, WAVES, VIEWS>;
+    if (VIEWS && (!a.dirs || !a.hv || (BWD && !a.d_pre_v) || (P::KH != 1 && !a.hv_mask))) return hipErrorInvalidValue;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;

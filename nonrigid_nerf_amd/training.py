@@ -3,7 +3,8 @@ train.py:152-287; backward + optimiser step, train.py:1594-1610); here the same 
 ``torch.autograd``.
 
 What is native (C ABI, include/nrnerf.h; kernels in csrc/nrnerf_train.h, csrc/nrnerf_train_bend.h, csrc/nrnerf_composite.hip):
-  * the canonical network -- positional encoding, 8x256 (or 8x128) trunk, head -- forward with saved activations, the fused
+  * the canonical network -- positional encoding, 8x256 (or 8x128) trunk, head (output_linear, or the view-dependent head:
+    alpha_linear + feature_linear / views_linears[0] / rgb_linear on the samples' view directions) -- forward with saved activations, the fused
     backward-data pass on MFMA and every weight / bias gradient in one launch (``nrnerf_trunk_forward / _backward / _wgrad``),
     fp32 (v_mfma_f32_32x32x2_f32 throughout) or bf16;
   * the ray-bending and rigidity MLPs (35->64->64->64->64->3 and 3->32->32->1; ``nrnerf_bender_forward / _backward / _wgrad``):
@@ -17,8 +18,9 @@ What is native (C ABI, include/nrnerf.h; kernels in csrc/nrnerf_train.h, csrc/nr
     train.py:910-920, no gradient: the reference detaches the sample positions), the compositing backward, the coarse depths
     (``nrnerf_composite_forward / _backward``, ``nrnerf_sample_depths``).
 What is left to libraries, as plumbing:
-  * the colour branch of the view-dependent head (feature_linear, views_linears[0], rgb_linear) and its finite-difference
-    directions, as torch ops on the native trunk's last activation (``colour_branch``; the density branch is native);
+  * products in PARAMETER space: feature_linear folded into views_linears[0] for the view-dependent head (``_colour_params``:
+    the kernels evaluate both branches of that head and return the gradient wrt the folded weights; autograd carries it
+    back through the two small products);
   * the two small GEMMs that turn a time-conditioned baseline's latent columns into per-ray biases.
 ``NATIVE_BENDER = False`` runs the bender's MLPs as torch ops on the modules' parameters instead (the gradient-parity tests use
 it because it reproduces the reference's bent points bit for bit).
@@ -111,30 +113,6 @@ def _colsum(g: torch.Tensor) -> torch.Tensor:
     return g.sum(0, dtype=torch.float32) if B == 1 else g.view(B, M // B, -1).sum(1, dtype=torch.float32).sum(0)
 
 
-class _RowsLinear(torch.autograd.Function):
-    """F.linear(x, W, b) for x [M, in] with M in the millions, in x's dtype (fp32 accumulation).  Autograd's own backward of
-    addmm forms dW as ONE [out x M] x [M x in] GEMM (two output tiles to parallelise over) and db as one reduction over M rows:
-    51 + 28 ms of a 116 ms training step at 16 384 rays for the three layers of the view-dependent head's colour branch.
-    Here: dW as a batch of partial products along M (`_wgrad`), db in two stages (`_colsum`).  First order only."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        w = weight.to(x.dtype)
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return torch.addmm(bias.to(x.dtype), x, w.t()) if bias is not None else x @ w.t()
-
-    @staticmethod
-    @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        g = g.contiguous()
-        gx = g @ weight.to(g.dtype) if ctx.needs_input_grad[0] else None
-        gw = _wgrad(g, x).to(weight.dtype) if ctx.needs_input_grad[1] else None
-        gb = _colsum(g).to(weight.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb
-
-
 def _rows4(x: torch.Tensor, M: int) -> torch.Tensor:
     """[.., 3] float32 -> the [M,4] rows (xyz + one float the kernels ignore) the C ABI takes.  A tensor that already is the
     xyz part of such rows (what _Bender returns and _Trunk.backward hands back) is re-viewed, anything else copied."""
@@ -187,7 +165,7 @@ def _trunk_grad_index(net, D, W, C_out, views, n_lat, dev):
     L = (int(net.input_ch) - 3) // 6
     n_enc = 3 + 6 * L
     skips = tuple(sorted(int(k) for k in net.skips))
-    key = ("trunk", D, W, C_out, bool(views), n_enc, n_lat, skips, str(dev))
+    key = ("trunk", D, W, C_out, bool(views), int(getattr(net, "input_ch_views", 0)) if views else 0, n_enc, n_lat, skips, str(dev))
     if key in _GRAD_INDEX:
         return _GRAD_INDEX[key]
     SH = _lib.REDUCE_SHORT
@@ -207,9 +185,23 @@ def _trunk_grad_index(net, D, W, C_out, views, n_lat, dev):
         b = o_db + i * W + np.arange(W)
         segs += [w.reshape(-1), (b | SH) if i == 0 else b]
         shapes += [tuple(w.shape), (W,)]
-    if views:                                                  # head slot = alpha_linear (1 x W): the sigma channel's column of dw_head^T
+    if views:                                                  # alpha_linear (1 x W): the sigma channel's column of dw_head^T
         segs += [((o_o + np.arange(W) * 64 + 3) | SH), np.full(1, -1)]
         shapes += [(1, W), (1,)]
+        head_bias_at = sum(int(x.shape[0]) for x in segs) - 1
+        # the colour branch (_colour_params order): folded views layer's hidden columns [W/2, W] and bias [W/2], its direction
+        # columns [W/2, 3 + 6 LV], rgb_linear [3, W/2] (from dw_rgb^T) and its bias (summed from d_raw4 by the caller)
+        V = W // 2
+        n_dir = int(net.input_ch_views)
+        o_f = o_db + (D + 1) * W
+        o_d = o_f + V * W
+        o_r = o_d + V * 64
+        o_bv = o_r + V * 64
+        vrows = np.arange(V, dtype=np.int64)[:, None]
+        segs += [(o_f + vrows * W + np.arange(W)[None]).reshape(-1), o_bv + np.arange(V),
+                 ((o_d + vrows * 64 + np.arange(n_dir)[None]) | SH).reshape(-1),
+                 ((o_r + np.arange(V)[None] * 64 + np.arange(3)[:, None]) | SH).reshape(-1), np.full(3, -1)]
+        shapes += [(V, W), (V,), (V, n_dir), (3, V), (3,)]
     else:
         w = np.full((C_out, W), -1, dtype=np.int64)
         for ch in range(min(4, C_out)):
@@ -217,7 +209,8 @@ def _trunk_grad_index(net, D, W, C_out, views, n_lat, dev):
         segs += [w.reshape(-1), np.full(C_out, -1)]
         shapes += [(C_out, W), (C_out,)]
     flat = np.concatenate(segs).astype(np.int32)
-    head_bias_at = int(flat.shape[0]) - int(shapes[-1][0])
+    if not views:
+        head_bias_at = int(flat.shape[0]) - int(shapes[-1][0])
     _GRAD_INDEX[key] = (torch.from_numpy(flat).to(dev), shapes, head_bias_at)
     return _GRAD_INDEX[key]
 
@@ -293,7 +286,7 @@ class _Trunk(torch.autograd.Function):
     """raw4 [N,S,4] (differentiable), raw [N,S,C] (the reference's "raw" key; no gradient) = NeRF trunk(points)."""
 
     @staticmethod
-    def forward(ctx, pts, model, net, which, ray_bias, *params):
+    def forward(ctx, pts, model, net, which, ray_bias, dirs, *params):
         N, S = int(pts.shape[0]), int(pts.shape[1])
         M, dev = N * S, pts.device
         D, W = int(net.D), int(net.W)
@@ -306,8 +299,8 @@ class _Trunk(torch.autograd.Function):
         mask = None if f32 else torch.empty(D, nblk, 64, W // 32, dtype=torch.int16, device=dev)
         raw4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         views = bool(net.use_viewdirs)
-        # view-dependent head (rnh:284-304): the library's head slot holds alpha_linear (raw4[:, 3] = density logit, the colour
-        # channels 0), the caller evaluates the colour branch on the last hidden activation, returned as a third output
+        # view-dependent head (rnh:284-304): both branches run behind the trunk in the same kernel, on the directions handed in;
+        # raw4 = [rgb logits, density logit]
         C_out = 4 if views else int(net.output_linear.weight.shape[0])
         raw = torch.empty(M, C_out, dtype=torch.float32, device=dev)
         a = _lib.TrunkArgs()
@@ -315,6 +308,13 @@ class _Trunk(torch.autograd.Function):
         a.which, a.n_rays, a.n_samples = int(which), N, S
         a.pts4, a.acts, a.raw4, a.raw, a.raw_ch = pts4.data_ptr(), acts.data_ptr(), raw4.data_ptr(), raw.data_ptr(), C_out
         a.relu_mask = None if f32 else mask.data_ptr()
+        saved = [pts4, acts] if f32 else [pts4, acts, mask]
+        if views:
+            d3 = dirs.detach().to(torch.float32).reshape(M, 3).contiguous()
+            hv = torch.empty(M, W // 2, dtype=torch.float32, device=dev) if f32 else torch.empty(nblk, W // 2, 32, dtype=torch.bfloat16, device=dev)
+            hvm = None if f32 else torch.empty(nblk, 64, W // 64, dtype=torch.int16, device=dev)
+            a.dirs, a.hv, a.hv_mask = d3.data_ptr(), hv.data_ptr(), (None if f32 else hvm.data_ptr())
+            saved += [d3, hv] if f32 else [d3, hv, hvm]
         if ray_bias is not None:        # time-conditioned baseline: W[:, latent columns] . latent of the two input layers, per ray
             rbias = ray_bias.detach().to(torch.float32).contiguous()
             assert tuple(rbias.shape) == (N, 2, W)
@@ -322,30 +322,22 @@ class _Trunk(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_trunk_forward")
         ctx.model, ctx.net, ctx.which, ctx.dims, ctx.views, ctx.tcb = model, net, int(which), (N, S, D, W, C_out), views, ray_bias is not None
-        ctx.save_for_backward(*((pts4, acts) if f32 else (pts4, acts, mask)))
+        ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(raw)
         ctx.set_materialize_grads(False)             # an output nobody differentiates arrives as None, not as a zero-filled tensor
-        if not views:
-            return raw4.view(N, S, 4), raw.view(N, S, C_out)
-        if f32:
-            h_last = acts[D - 1].view(N, S, W)                                               # [M][W] rows, as saved
-        else:                                                                                # [block][feature][32 samples] tiles
-            bpr = (S + 31) // 32
-            h_last = torch.empty(N, S, W, dtype=torch.bfloat16, device=dev)    # bf16, as saved: the colour branch's GEMMs run in it
-            with torch.cuda.device(dev):
-                _lib.check(_lib.load().nrnerf_tiles_to_rows(acts[D - 1].data_ptr(), N, S, W, h_last.data_ptr(), _stream(dev)), "nrnerf_tiles_to_rows")
-        return raw4.view(N, S, 4), raw.view(N, S, C_out), h_last
+        return raw4.view(N, S, 4), raw.view(N, S, C_out)
 
     @staticmethod
-    def backward(ctx, g_raw4, _g_raw, g_h=None):
+    def backward(ctx, g_raw4, _g_raw):
         model, net = ctx.model, ctx.net
         f32 = _is_f32(model)
         pts4, acts = ctx.saved_tensors[:2]
         N, S, D, W, C_out = ctx.dims
         M, dev = N * S, pts4.device
-        if g_raw4 is None and g_h is None:
-            return (None,) * (5 + 2 * D + 2)
-        g = g_raw4.contiguous().reshape(M, 4).float() if g_raw4 is not None else torch.zeros(M, 4, dtype=torch.float32, device=dev)
+        n_params = 2 * D + 2 + (5 if ctx.views else 0)
+        if g_raw4 is None:
+            return (None,) * (6 + n_params)
+        g = g_raw4.contiguous().reshape(M, 4).float()
         d_pre = torch.empty_like(acts)
         d_pts4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         a = _lib.TrunkArgs()
@@ -353,9 +345,16 @@ class _Trunk(torch.autograd.Function):
         a.which, a.n_rays, a.n_samples = ctx.which, N, S
         a.pts4, a.acts, a.d_raw4, a.d_pre, a.d_pts4 = pts4.data_ptr(), acts.data_ptr(), g.data_ptr(), d_pre.data_ptr(), d_pts4.data_ptr()
         a.relu_mask = None if f32 else ctx.saved_tensors[2].data_ptr()
-        if g_h is not None:                                    # the colour branch's gradient wrt the last hidden activation,
-            g_h = g_h.reshape(M, W).to(torch.float32 if f32 else torch.bfloat16).contiguous()      # in the saved arrays' element type
-            a.d_hidden_extra = g_h.data_ptr()
+        colour, d_dirs = None, None
+        if ctx.views:                   # the colour branch's saved arrays; gradient wrt the directions when somebody wants it
+            d3, hv = ctx.saved_tensors[2 if f32 else 3], ctx.saved_tensors[3 if f32 else 4]
+            d_pre_v = torch.empty_like(hv)
+            a.dirs, a.hv, a.d_pre_v = d3.data_ptr(), hv.data_ptr(), d_pre_v.data_ptr()
+            a.hv_mask = None if f32 else ctx.saved_tensors[5].data_ptr()
+            if ctx.needs_input_grad[5]:
+                d_dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+                a.d_dirs = d_dirs.data_ptr()
+            colour = (d3, hv, d_pre_v)
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_trunk_backward")
         skip1 = int(list(net.skips)[0]) + 1
@@ -376,11 +375,11 @@ class _Trunk(torch.autograd.Function):
 
         # every weight and bias gradient from ONE launch over the two saved arrays (nrnerf_trunk_wgrad: bf16 block tiles, or the
         # fp32 mode's rows); the time-conditioned baseline's latent columns are already in the flat buffer's layout, zero
-        return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias,
-                *_Trunk._weight_grads(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views, n_lat))
+        return (d_pts4.view(N, S, 4)[..., :3], None, None, None, g_bias, (d_dirs.view(N, S, 3) if d_dirs is not None else None),
+                *_Trunk._weight_grads(model, net, ctx.dims, pts4, acts, d_pre, g, ctx.views, n_lat, colour))
 
     @staticmethod
-    def _weight_grads(model, net, dims, pts4, acts, d_pre, g, views=False, n_lat=0):
+    def _weight_grads(model, net, dims, pts4, acts, d_pre, g, views=False, n_lat=0, colour=None):
         """Every weight and bias gradient of the trunk from one call of nrnerf_trunk_wgrad over the two saved arrays (reads
         each once; a library route read them twice and reduced d_pre a third time): bf16 [block][feature][32 samples] tiles on
         the bf16 matrix pipe, or (fp32 mode) [sample][feature] rows on v_mfma_f32_32x32x2_f32.  One record of partial sums
@@ -390,12 +389,15 @@ class _Trunk(torch.autograd.Function):
         f32 = acts.dtype == torch.float32
         nblk = N * ((S + 31) // 32)
         # encoding / head-gradient operands the call fills: bf16 tiles, or fp32 rows [M][64]
-        scratch = torch.empty(2, N * S, 64, dtype=torch.float32, device=dev) if f32 else torch.empty(2, nblk, 64, 32, dtype=torch.bfloat16, device=dev)
+        ns = 3 if views else 2          # (+ the direction encoding with the view-dependent head)
+        scratch = torch.empty(ns, N * S, 64, dtype=torch.float32, device=dev) if f32 else torch.empty(ns, nblk, 64, 32, dtype=torch.bfloat16, device=dev)
         # records of partial sums; the launch has (D - 1) * kch + 3 * (10/16 or 12/16) kch workgroups: one per CU at most
-        kch = max(1, min(nblk, (_num_cus(dev) * 16) // ((D - 1) * 16 + 3 * (10 if W == 256 else 12))))
+        # (view-dependent head: one more job of kch and two more of 10/16 kch workgroups)
+        short = 10 if W == 256 else 12
+        kch = max(1, min(nblk, (_num_cus(dev) * 16) // ((D - (0 if views else 1)) * 16 + (5 if views else 3) * short)))
         # only the records the kernel does not write need zeroing: the three 64-column products (and their bias rows) are cut
         # into NRNERF_WGRAD_SHORT_PARTIALS <= kch partial sums (include/nrnerf.h); zero-filling the whole array was 74 MB per call
-        parts = torch.empty(kch, _lib.wgrad_stride(D, W), dtype=torch.float32, device=dev)
+        parts = torch.empty(kch, _lib.wgrad_stride_views(D, W) if views else _lib.wgrad_stride(D, W), dtype=torch.float32, device=dev)
         # the three 64-column products (and their bias rows) are cut into NRNERF_WGRAD_SHORT_PARTIALS <= kch partial sums
         # (include/nrnerf.h); the other records' slots are never read (nrnerf_reduce_partials), so nothing is zero-filled
         kl = _lib.wgrad_short_partials(kch, W)
@@ -404,13 +406,18 @@ class _Trunk(torch.autograd.Function):
         a.n_rays, a.n_samples, a.n_partials = N, S, kch
         a.acts, a.d_pre, a.pts4, a.d_raw4 = acts.data_ptr(), d_pre.data_ptr(), pts4.data_ptr(), g.data_ptr()
         a.enc, a.g_head, a.partials = scratch[0].data_ptr(), scratch[1].data_ptr(), parts.data_ptr()
+        if views:
+            d3, hv, d_pre_v = colour
+            a.dirs, a.hv, a.d_pre_v, a.encv = d3.data_ptr(), hv.data_ptr(), d_pre_v.data_ptr(), scratch[2].data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_wgrad")
         # every weight and bias, each in its own shape, back to back in one buffer: one launch
         index, shapes, hb = _trunk_grad_index(net, D, W, C_out, views, n_lat, dev)
         flat = _reduce_partials(parts, kl, index)
-        if views:                                              # head bias: the sigma channel's column sum
-            torch.sum(g[:, 3:4], 0, out=flat[hb:hb + 1])
+        if views:                                              # biases of alpha_linear and rgb_linear: column sums of d raw
+            sums = g.sum(0)
+            flat[hb:hb + 1].copy_(sums[3:4])
+            flat[flat.shape[0] - 3:].copy_(sums[0:3])
         else:                                                  # (the 5th channel never reaches the loss: zero)
             torch.sum(g, 0, out=flat[hb:hb + 4])
         return _split_flat(flat, shapes)
@@ -430,8 +437,22 @@ def _trunk_params(net):
     ps = []
     for lin in net.pts_linears:
         ps += [lin.weight, lin.bias]
-    head = net.alpha_linear if net.use_viewdirs else net.output_linear       # see _Trunk.forward
-    return ps + [head.weight, head.bias]
+    if not net.use_viewdirs:
+        return ps + [net.output_linear.weight, net.output_linear.bias]
+    return ps + [net.alpha_linear.weight, net.alpha_linear.bias] + _colour_params(net)
+
+
+def _colour_params(net):
+    """The colour branch of the view-dependent head as the kernels see it (rnh:286-303): no nonlinearity sits between
+    feature_linear and views_linears[0], so they are ONE layer on [h, direction encoding],
+        relu(Wv [Wf h + bf, enc] + bv) = relu((Wv1 Wf) h + Wv2 enc + (Wv1 bf + bv)),   Wv = [Wv1 | Wv2],
+    and the library's weight images hold the folded matrix (the packer, or render._flat_params for the device-side re-pack,
+    forms it).  The same two small products in PARAMETER space here, under autograd: the kernels return the gradient wrt
+    the folded weights, autograd carries it back to Wf, bf, Wv and bv.  -> [Wv1 Wf, Wv1 bf + bv, Wv2, W_rgb, b_rgb]."""
+    wf, bf = net.feature_linear.weight, net.feature_linear.bias
+    wv, bv = net.views_linears[0].weight, net.views_linears[0].bias
+    k1 = int(wf.shape[0])
+    return [wv[:, :k1] @ wf, wv[:, :k1] @ bf + bv, wv[:, k1:], net.rgb_linear.weight, net.rgb_linear.bias]
 
 
 def finite_difference_dirs(bent: torch.Tensor) -> torch.Tensor:
@@ -480,65 +501,6 @@ class _DirectionEncoding(torch.autograd.Function):
             _lib.check(_lib.load().nrnerf_direction_encoding(b4.data_ptr(), N, S, L, g.data_ptr(), int(g.dtype == torch.bfloat16), out.data_ptr(),
                                                             _stream(b4.device)), "nrnerf_direction_encoding")
         return out[..., :3], None, None
-
-
-class _RowsLinear2(torch.autograd.Function):
-    """x1 @ w1^T + x2 @ w2^T + b: a linear layer on the concatenation [x1, x2] without forming it (a [M, 283] copy per pass
-    for the view-dependent head's middle layer), the two column blocks of its weight given separately.  Backward as
-    _RowsLinear."""
-
-    @staticmethod
-    def forward(ctx, x1, x2, w1, w2, bias):
-        ctx.save_for_backward(x1, x2, w1, w2)
-        ctx.has_bias = bias is not None
-        a, b = w1.to(x1.dtype), w2.to(x1.dtype)
-        y = torch.addmm(bias.to(x1.dtype), x1, a.t()) if bias is not None else x1 @ a.t()
-        return y.addmm_(x2, b.t())
-
-    @staticmethod
-    @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
-        x1, x2, w1, w2 = ctx.saved_tensors
-        g = g.contiguous()
-        gx1 = g @ w1.to(g.dtype) if ctx.needs_input_grad[0] else None
-        gx2 = g @ w2.to(g.dtype) if ctx.needs_input_grad[1] else None
-        gw1 = _wgrad(g, x1).to(w1.dtype) if ctx.needs_input_grad[2] else None
-        gw2 = _wgrad(g, x2).to(w2.dtype) if ctx.needs_input_grad[3] else None
-        gb = _colsum(g).to(w1.dtype) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
-        return gx1, gx2, gw1, gw2, gb
-
-
-# True: feature_linear is folded into views_linears[0] (no nonlinearity sits between them, rnh:286-301):
-#   relu(Wv [Wf h + bf, enc] + bv) = relu((Wv1 Wf) h + Wv2 enc + (Wv1 bf + bv)),  Wv = [Wv1 | Wv2]
-# -- the [M, 256] feature array and its gradient never exist, the per-sample work of the two layers drops from 203 to 72 kflop,
-# and autograd carries the gradient of the two small products back to Wf, bf and Wv.  False: the layers one by one.
-# Used from FOLD_MIN_ROWS samples per pass on: 16 384 rays 28.2 -> 26.3 ms per step; at 1024 rays the dozen extra small
-# launches cost more than the saved traffic (4.50 vs 4.41 ms, host-bound).
-FOLD_FEATURE_LINEAR = True
-FOLD_MIN_ROWS = 1 << 18
-
-
-def colour_branch(net, h_last, dirs=None, enc=None):
-    """The colour branch of the view-dependent head (run_nerf_helpers.py:286-303) as library GEMMs on the module's own
-    parameters, under autograd: feature_linear, relu(views_linears[0]([feature, direction encoding])), rgb_linear.
-    h_last [N,S,W] (fp32, or bf16 from a bf16 trunk: the GEMMs then run in bf16 with fp32 accumulation); dirs [N,S,3], or
-    their encoding `enc` [N*S, 3 + 6 L] already -> rgb logits [N,S,3] fp32.  (The density branch, alpha_linear, is in the
-    native trunk kernel.)"""
-    L = (int(net.input_ch_views) - 3) // 6
-    lead = tuple(h_last.shape[:-1])
-    h2 = h_last.reshape(-1, h_last.shape[-1])
-    if enc is None:
-        enc = posenc(dirs, L).reshape(h2.shape[0], -1)
-    enc = enc.to(h2.dtype)
-    wf, bf = net.feature_linear.weight, net.feature_linear.bias
-    wv, bv = net.views_linears[0].weight, net.views_linears[0].bias
-    k1 = int(wf.shape[0])
-    if FOLD_FEATURE_LINEAR and int(h2.shape[0]) >= FOLD_MIN_ROWS:
-        pre = _RowsLinear2.apply(h2, enc, wv[:, :k1] @ wf, wv[:, k1:], wv[:, :k1] @ bf + bv)                # :286, 296-301 in one layer
-    else:
-        feature = _RowsLinear.apply(h2, wf, bf)                                                   # :286
-        pre = _RowsLinear2.apply(feature, enc, wv[:, :k1], wv[:, k1:], bv)                                  # :296-301
-    return _RowsLinear.apply(F.relu(pre), net.rgb_linear.weight, net.rgb_linear.bias).float().reshape(*lead, 3)   # :303
 
 
 class _Composite(torch.autograd.Function):
@@ -1116,20 +1078,19 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             sk = int(list(net.skips)[0]) + 1
             ray_bias = torch.stack([F.linear(lat, net.pts_linears[0].weight[:, n_enc:n_enc + lat.shape[1]]),
                                     F.linear(lat, net.pts_linears[sk].weight[:, n_enc:n_enc + lat.shape[1]])], 1)
-        if not net.use_viewdirs:
-            raw4, raw = _Trunk.apply(bent, model, net, which, ray_bias, *_trunk_params(net))
-            return raw4, raw, details
-        # view-dependent head (rnh:284-304): density natively, colour branch on the last hidden activation
-        sigma4, _, h_last = _Trunk.apply(bent, model, net, which, ray_bias, *_trunk_params(net))
-        Lv = (int(net.input_ch_views) - 3) // 6
-        if rb is not None and NATIVE_DIRECTION_ENCODING and bent.is_cuda and ns >= 2:
-            rgb = colour_branch(net, h_last, enc=_DirectionEncoding.apply(bent, Lv, h_last.dtype))    # rnh:288-290, one launch each way
-        elif rb is not None:
-            rgb = colour_branch(net, h_last, finite_difference_dirs(bent))                   # rnh:288-290 (approx_nonrigid_viewdirs)
-        else:
-            rgb = colour_branch(net, h_last, rays[:, None, 8:11].expand(N, ns, 3))           # train.py:73-76
-        raw4 = sigma4 + F.pad(rgb, (0, 1))                                                   # cat[rgb, alpha] (rnh:304): sigma4[..., :3] == 0
-        return raw4, raw4.detach(), details
+        dirs = None
+        if net.use_viewdirs:
+            # view-dependent head (rnh:284-304): the direction of every sample -- the finite differences of the bent points
+            # (rnh:288-290, approx_nonrigid_viewdirs; one launch each way) or the ray's own (train.py:73-76); the head itself runs
+            # behind the trunk in the same kernels
+            if rb is not None and NATIVE_DIRECTION_ENCODING and bent.is_cuda and ns >= 2:
+                dirs = _DirectionEncoding.apply(bent, 0, torch.float32).view(N, ns, 3)
+            elif rb is not None:
+                dirs = finite_difference_dirs(bent)
+            else:
+                dirs = rays[:, None, 8:11].expand(N, ns, 3)
+        raw4, raw = _Trunk.apply(bent, model, net, which, ray_bias, dirs, *_trunk_params(net))
+        return raw4, raw, details
 
     coarse_parts = bend_samples(z_vals)
     raw4, raw, details = query(z_vals, network_fn, 0, coarse_parts)

@@ -433,6 +433,94 @@ def test_backward_stream_reproduces_autograd_of_the_trunk(precision, width):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_backward_stream_with_the_view_dependent_head_reproduces_autograd(precision):
+    """Training with use_viewdirs (csrc/nrnerf_train.h, trunk_bwd<.., VIEWS>): PlanB<.., true> starts with rgb_linear^T
+    (d raw's colour channels -> d hv) and ONE layer that joins both branches of the head -- k over [d raw (sigma), d z_v], rows
+    over [direction-encoding slots, h_7], weights = alpha_linear^T and the transposed FOLDED views layer (views_linears[0] o
+    feature_linear) -- then the trunk's transposes as before.  Emulated in numpy against torch.autograd of the reference's
+    head (rnh:284-304): gradient wrt the point's encoding and wrt the direction's encoding."""
+    cfg = SceneConfig(N_importance=128, use_viewdirs=True)
+    NT = 8
+    scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=5)
+    assert not bias.any(), "backward layers have no bias"
+    KH = 1 if precision == "f32" else 8
+    rnd = rounder(precision)
+    fr = FragReader(stream, precision, info.frag_bytes)
+    gen = torch.Generator().manual_seed(12)
+    ns_ = 32
+    x = (torch.randn(ns_, 63, generator=gen) * 0.5).double().requires_grad_(True)
+    ev = (torch.randn(ns_, 27, generator=gen) * 0.5).double().requires_grad_(True)
+    d_raw = torch.randn(ns_, 4, generator=gen).double()
+    hs, h = [], x
+    for i, l in enumerate(fine.pts_linears):
+        h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
+        hs.append(h)
+        if i == 4:
+            h = torch.cat([x, h], -1)
+    lin = lambda m, t: F.linear(t, m.weight.double(), m.bias.double())
+    alpha = lin(fine.alpha_linear, h)                                                        # rnh:285
+    hv = F.relu(lin(fine.views_linears[0], torch.cat([lin(fine.feature_linear, h), ev], -1)))  # rnh:286-301
+    raw = torch.cat([lin(fine.rgb_linear, hv), alpha], -1)                                   # rnh:303-304
+    g_x, g_ev = torch.autograd.grad(raw, (x, ev), d_raw)
+    hs = [t.detach().numpy() for t in hs]
+    hvn = hv.detach().numpy()
+
+    def mask_tiles(tiles, act):            # d h tiles [32, ns] -> d z (rows = features 32 t + i)
+        return [np.where(act[:, 32 * t:32 * t + 32].T > 0, D, 0.0) for t, D in enumerate(tiles)]
+
+    v = np.zeros((8, ns_))
+    v[:4] = d_raw.numpy().T
+    dr = vec_slabs(v, KH, rnd)
+    tile0, mfma = 0, 0
+    tiles = dense_emul(fr, bias, tile0, len(dr), NT // 2, dr); mfma += len(dr) * (NT // 2); tile0 += NT // 2          # rgb_linear^T -> d hv
+    dv = repack(mask_tiles(tiles, hvn), KH, False, rnd)
+    slabs = dr + dv
+    out = dense_emul(fr, bias, tile0, len(slabs), 1 + NT, slabs); mfma += len(slabs) * (1 + NT); tile0 += 1 + NT        # the joined head layer
+    dencv, tiles = out[0], out[1:]
+    denc = None
+    for i in range(7, 0, -1):
+        slabs = repack(mask_tiles(tiles, hs[i]), KH, False, rnd)
+        nt = NT + 2 if i == 5 else NT
+        out = dense_emul(fr, bias, tile0, len(slabs), nt, slabs); mfma += len(slabs) * nt; tile0 += nt
+        if i == 5:
+            denc, tiles = out[:2], out[2:]
+        else:
+            tiles = out
+    slabs = repack(mask_tiles(tiles, hs[0]), KH, False, rnd)
+    out = dense_emul(fr, bias, tile0, len(slabs), 2, slabs); mfma += len(slabs) * 2; tile0 += 2
+    denc = [denc[0] + out[0], denc[1] + out[1]]
+    assert tile0 == info.n_bias_tiles and mfma == info.mfma_per_block
+    used = fr.pos * info.frag_bytes
+    assert used <= info.stream_bytes and not stream[used:].any()
+
+    def from_slots(tiles_, L):             # encoding-slot order -> reference columns (nrnerf_plan.h enc_col)
+        F0 = (L + 1) // 2
+        got = np.zeros((ns_, 3 + 6 * L))
+        for te, D in enumerate(tiles_):
+            for hh in range(2):
+                for r in range(16):
+                    q = te * 16 + r
+                    if q == 0:
+                        col = 2 if hh else 0
+                    elif q == 1:
+                        col = -1 if hh else 1
+                    else:
+                        pi, fn = (q - 2) // 2, (q - 2) % 2
+                        fl, c = pi // 3, pi % 3
+                        col = 3 + 6 * (hh * F0 + fl) + 3 * fn + c if (fl < F0 and hh * F0 + fl < L) else -1
+                    if col >= 0:
+                        got[:, col] = D[tile_row(r, hh)]
+                    else:
+                        assert not D[tile_row(r, hh)].any(), "a slot without a column must carry no gradient"
+        return got
+
+    tol = 1e-9 if precision == "f32" else 6e-2
+    for got, want, what in ((from_slots(denc, 10), g_x.numpy(), "point encoding"), (from_slots([dencv], 4), g_ev.numpy(), "direction encoding")):
+        err = np.abs(got - want).max()
+        assert err <= tol * np.abs(want).max(), (what, err, np.abs(want).max())
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_bender_backward_stream_reproduces_autograd_of_the_bender(precision):
     """Training of the ray bender (csrc/nrnerf_train_bend.h): nrnerf_pack_host which = 6 is the fp32 stream of PlanBB --
     network[4]^T .. network[1]^T, the latent rows of network[0]^T, then rigidity_network[2]^T, rigidity_network[1]^T --

@@ -124,8 +124,9 @@ def test_trunk_gradient_index_table_matches_the_record_layout(cfg_kw):
     n_lat = int(coarse.pts_linears[0].weight.shape[1]) - n_enc
     index, shapes, hb = T._trunk_grad_index(coarse, D, W, C_out, views, n_lat, "cpu")
     assert [tuple(p.shape) for p in params] == [tuple(s) for s in shapes]
-    assert int(index.shape[0]) == sum(int(p.numel()) for p in params) and hb == int(index.shape[0]) - (1 if views else C_out)
-    rec = torch.arange(_lib.wgrad_stride(D, W), dtype=torch.float64) + 1.0                  # one record, every slot distinct and non-zero
+    n_colour = sum(int(p.numel()) for p in params[2 * D + 2:]) if views else 0            # the colour branch follows alpha_linear
+    assert int(index.shape[0]) == sum(int(p.numel()) for p in params) and hb == int(index.shape[0]) - n_colour - (1 if views else C_out)
+    rec = torch.arange(_lib.wgrad_stride_views(D, W) if views else _lib.wgrad_stride(D, W), dtype=torch.float64) + 1.0    # one record, every slot distinct and non-zero
     flat = _apply_index(rec, index, torch.tensor(7), torch.tensor(3))
     got = T._split_flat(flat, shapes)
     o = 0
@@ -184,65 +185,66 @@ def test_bender_gradient_index_table_matches_the_slots(divergence, depth):
             k_out += 1
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2)])
-def test_rows_linear_functions_match_f_linear_autograd(dtype, tol):
-    """training._RowsLinear / _RowsLinear2 (the colour branch's layers: dW as batched partial products, db in two stages, the
-    middle layer without the concatenation) against F.linear under autograd, values and all gradients."""
-    g = torch.Generator().manual_seed(5)
-    M = 16384                                    # four row blocks
-    x1 = torch.randn(M, 256, generator=g).to(dtype).requires_grad_(True)
-    x2 = torch.randn(M, 27, generator=g).to(dtype).requires_grad_(True)
-    w = (torch.randn(128, 283, generator=g) * 0.1).requires_grad_(True)
-    b = torch.randn(128, generator=g).requires_grad_(True)
-    wt = torch.randn(M, 128, generator=g)
-
-    def grads(y):
-        for t in (x1, x2, w, b):
-            t.grad = None
-        (y.float() * wt).sum().backward()
-        return [t.grad.float().clone() for t in (x1, x2, w, b)]
-
-    y_cat = T._RowsLinear.apply(torch.cat([x1, x2], -1), w, b)
-    g_cat = grads(y_cat)
-    y_two = T._RowsLinear2.apply(x1, x2, w[:, :256], w[:, 256:], b)
-    g_two = grads(y_two)
-    y_ref = torch.nn.functional.linear(torch.cat([x1, x2], -1).float(), w, b)
-    g_ref = grads(y_ref)
-    for y in (y_cat, y_two):
-        assert float((y.float() - y_ref).abs().max()) <= tol * float(y_ref.abs().max())
-    for got in (g_cat, g_two):
-        for a, r in zip(got, g_ref):
-            assert float((a - r).abs().max()) <= tol * float(r.abs().max())
-    assert torch.allclose(T._colsum(wt), wt.sum(0), rtol=1e-5, atol=1e-3)
-
-
-def test_folded_feature_linear_equals_the_two_layers():
-    """training.colour_branch with feature_linear folded into views_linears[0] (FOLD_FEATURE_LINEAR, used for large passes)
-    against the layers one by one: rgb logits and the gradients wrt the last hidden activation and every parameter."""
+def test_folded_colour_parameters_equal_the_two_layers():
+    """training._colour_params: the colour branch of the view-dependent head as the kernels evaluate it -- feature_linear
+    folded into views_linears[0] (no nonlinearity between them, rnh:286-301) -- against the reference's layers one by one:
+    rgb logits, and the gradients wrt the last hidden activation and every parameter carried back through the fold by
+    autograd (the kernels return the gradient wrt the FOLDED weights; the chain rule through the two small products is
+    torch's, in parameter space)."""
+    import torch.nn.functional as F
     cfg = SceneConfig(use_viewdirs=True, N_importance=64)
     _, net, _ = build_modules(make_scene(cfg, 0))
     net.requires_grad_(True)
     g = torch.Generator().manual_seed(0)
-    h = torch.randn(5, 64, 256, generator=g).requires_grad_(True)
-    d = torch.nn.functional.normalize(torch.randn(5, 64, 3, generator=g), dim=-1)
-    w = torch.randn(5, 64, 3, generator=g)
+    h = torch.randn(320, 256, generator=g).requires_grad_(True)
+    d = F.normalize(torch.randn(320, 3, generator=g), dim=-1)
+    enc = T.posenc(d, 4)
+    w = torch.randn(320, 3, generator=g)
     names = ["feature_linear.weight", "feature_linear.bias", "views_linears.0.weight", "views_linears.0.bias", "rgb_linear.weight", "rgb_linear.bias"]
     params = dict(net.named_parameters())
-    outs = {}
-    old = (T.FOLD_FEATURE_LINEAR, T.FOLD_MIN_ROWS)
-    try:
-        for fold in (False, True):
-            T.FOLD_FEATURE_LINEAR, T.FOLD_MIN_ROWS = fold, 0
-            for p in net.parameters():
-                p.grad = None
-            h.grad = None
-            y = T.colour_branch(net, h, d)
-            (y * w).sum().backward()
-            outs[fold] = [y.detach().clone(), h.grad.clone()] + [params[n].grad.clone() for n in names]
-    finally:
-        T.FOLD_FEATURE_LINEAR, T.FOLD_MIN_ROWS = old
-    for a, b in zip(outs[False], outs[True]):
+
+    def run(folded):
+        for p in net.parameters():
+            p.grad = None
+        h.grad = None
+        if folded:
+            wfold, bfold, wdir, wr, br = T._colour_params(net)
+            assert tuple(wfold.shape) == (128, 256) and tuple(wdir.shape) == (128, 27)
+            hv = F.relu(F.linear(h, wfold) + F.linear(enc, wdir) + bfold)
+            y = F.linear(hv, wr, br)
+        else:
+            feat = net.feature_linear(h)                                                     # rnh:286
+            y = net.rgb_linear(F.relu(net.views_linears[0](torch.cat([feat, enc], -1))))     # rnh:296-303
+        (y * w).sum().backward()
+        return [y.detach().clone(), h.grad.clone()] + [params[n].grad.clone() for n in names]
+
+    for a, b in zip(run(False), run(True)):
         assert float((a - b).abs().max()) <= 5e-6 * float(a.abs().max()) + 1e-9
+
+
+def test_trunk_gradient_index_places_the_colour_branch():
+    """training._trunk_grad_index for a view-dependent head: every parameter of _trunk_params order finds its slot in one
+    record of nrnerf_trunk_wgrad (NRNERF_WGRAD_STRIDE_VIEWS): the folded matrix and its bias after the plain record, the
+    direction columns and rgb_linear (transposed there) in the 64-column products, the biases the caller sums as -1."""
+    from nonrigid_nerf_amd import _lib
+    cfg = SceneConfig(use_viewdirs=True, N_importance=64)
+    _, net, _ = build_modules(make_scene(cfg, 0))
+    D, W = 8, 256
+    index, shapes, hb = T._trunk_grad_index(net, D, W, 4, True, 0, torch.device("cpu"))
+    assert [tuple(p.shape) for p in T._trunk_params(net)] == [tuple(x) for x in shapes]
+    stride, base = _lib.wgrad_stride_views(D, W), _lib.wgrad_stride(D, W)
+    idx = index.numpy().astype("int64")
+    pos = idx & (_lib.REDUCE_SHORT - 1)
+    assert int(pos[idx >= 0].max()) < stride and idx[hb] == -1 and (idx[-3:] == -1).all()
+    o = int(sum(int(torch.tensor(x).prod()) for x in shapes[:-5]))
+    fold = idx[o:o + 128 * 256].reshape(128, 256)
+    assert fold[0, 0] == base and fold[1, 0] == base + 256 and fold[127, 255] == base + 128 * 256 - 1      # n_partials records
+    bias = idx[o + 128 * 256:o + 128 * 256 + 128]
+    assert bias[0] == base + 128 * 256 + 2 * 128 * 64 and bias[127] == stride - 1
+    dirs = idx[o + 128 * 257:o + 128 * 257 + 128 * 27].reshape(128, 27)
+    assert dirs[2, 5] == ((base + 128 * 256 + 2 * 64 + 5) | _lib.REDUCE_SHORT)
+    rgb = idx[o + 128 * 257 + 128 * 27:o + 128 * 257 + 128 * 27 + 3 * 128].reshape(3, 128)
+    assert rgb[1, 7] == ((base + 128 * 256 + 128 * 64 + 7 * 64 + 1) | _lib.REDUCE_SHORT)
 
 
 def test_param_token_is_rebuilt_when_parameters_are_frozen_and_unfrozen():
