@@ -443,6 +443,8 @@ class Model:
         a later weight refresh issued from ANOTHER stream can order itself after them (update_from_device).  The
         training entry points (nonrigid_nerf_amd/training.py) do not record: a training step is single-stream by
         contract -- forward, backward, optimiser step and the refresh all run on the stream that is current."""
+        if torch.cuda.is_current_stream_capturing():
+            return              # (a captured record could never be waited on outside its graph: GraphedRender records after each replay)
         cur = torch.cuda.current_stream(dev if dev is not None else self.device)
         with self._ws_lock:
             ev = self._render_events.get(cur.cuda_stream)
@@ -688,6 +690,71 @@ def _draw_randoms(ray_batch, N_samples, N_importance, perturb, raw_noise_std):
         if noisy:
             out["noise_fine"] = torch.randn([n, N_samples + N_importance], device=dev) * raw_noise_std
     return out
+
+
+class GraphedRender:
+    """``render_rays`` for a FIXED number of rays and fixed keyword arguments, captured once in a HIP graph and replayed.
+
+    A small call -- the 1024-ray batches of a training forward, the ``chunk=128`` probes of
+    ``determine_nerf_volume_extent`` (run_nerf_helpers.py:918-1051) -- is four kernels of 10-150 us: the host side of an eager
+    call (argument struct, output tensors, four launches) costs as much as the kernels when the caller waits for every
+    result, and leaves gaps between them when it does not.  A replay is one launch.
+
+        g = GraphedRender(example_rays, network_fn, N_samples=64, N_importance=128, network_fine=fine, latents=example_codes)
+        out = g(rays, codes)          # the reference's output dict; the SAME tensors every call (copy what must survive)
+
+    Weights: the graph reads the packed handle's buffers, which ``get_model`` refreshes in place when a parameter changed
+    -- checked on every call (``check_weights=False`` skips that for frozen networks); a handle that had to be REBUILT
+    (other architecture) re-captures.  Stochastic calls (``perturb`` / ``raw_noise_std``) draw fresh numbers on every
+    replay through torch's graph-safe generator state.  Only calls the HIP path takes can be captured (``Unsupported``
+    otherwise); inference only (no autograd: ``training.GraphedStep`` is the training twin)."""
+
+    def __init__(self, example_rays, network_fn, latents=None, warmup=2, check_weights=True, **render_kwargs):
+        if "additional_pixel_information" in render_kwargs:
+            raise ValueError("pass the latent codes as `latents`")
+        self.network_fn, self.kwargs, self.check_weights = network_fn, dict(render_kwargs), bool(check_weights)
+        dev = example_rays.device
+        self.rays = example_rays.detach().to(torch.float32).clone().contiguous()
+        self.latents = latents.detach().to(torch.float32).clone().contiguous() if latents is not None else None
+        self._fine = render_kwargs.get("network_fine") if int(render_kwargs.get("N_importance", 0)) > 0 else None
+        with torch.no_grad():
+            self.model, why = _eligible(self.rays, self.latents, network_fn, **render_kwargs)
+            if self.model is None:
+                raise Unsupported(f"this call does not run on the HIP path ({why}): nothing to capture")
+            self.stream = torch.cuda.Stream(dev)
+            self._capture(int(warmup))
+
+    def _api(self):
+        return {"ray_bending_latents": self.latents} if self.latents is not None else None
+
+    def _capture(self, warmup):
+        cur = torch.cuda.current_stream(self.rays.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(1, warmup)):             # (also sizes the handle's workspace for this stream)
+                render_rays(self.rays, self.network_fn, additional_pixel_information=self._api(), _model=self.model, **self.kwargs)
+        cur.wait_stream(self.stream)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.out = render_rays(self.rays, self.network_fn, additional_pixel_information=self._api(), _model=self.model, **self.kwargs)
+
+    @torch.no_grad()
+    def __call__(self, ray_batch, latents=None):
+        if tuple(ray_batch.shape) != tuple(self.rays.shape):
+            raise ValueError(f"captured for rays of shape {tuple(self.rays.shape)}, got {tuple(ray_batch.shape)}")
+        if (latents is None) != (self.latents is None) or (latents is not None and tuple(latents.shape) != tuple(self.latents.shape)):
+            raise ValueError("latent codes differ in presence / shape from the captured call")
+        if self.check_weights:
+            model = get_model(self.network_fn, self._fine, device=self.rays.device)      # refreshes changed weights in place
+            if model is not self.model:
+                self.model = model
+                self._capture(1)
+        self.rays.copy_(ray_batch, non_blocking=True)
+        if latents is not None:
+            self.latents.copy_(latents, non_blocking=True)
+        self.graph.replay()
+        self.model.note_use(self.rays.device)
+        return self.out
 
 
 def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, detailed_output=False, **kwargs):

@@ -1112,3 +1112,54 @@ def test_device_side_weight_refresh_equals_a_fresh_pack(cfg_kw, precision):
             assert float((a_ - f_).abs().max()) <= tol * max(1.0, float(f_.abs().max())), (k, float((a_ - f_).abs().max()))
         else:
             assert torch.equal(a_, f_), k
+
+
+@pytest.mark.parametrize("n_rays,cfg_kw,stochastic", [(1024, {}, False), (128, dict(use_viewdirs=True), False), (777, dict(ray_bending=False), False),
+                                                      (1024, {}, True)],
+                         ids=["1024_default", "128_viewdirs", "777_no_bender", "1024_stochastic"])
+def test_graphed_render_equals_the_eager_call(n_rays, cfg_kw, stochastic):
+    """render.GraphedRender (small batches from a HIP graph): a replay returns what the eager call returns
+    -- bit for bit, every output key -- for new rays and new latent codes copied into its static buffers; after an in-place
+    weight change (an optimiser step bumps the parameters' versions) the next replay renders with the NEW weights (refreshed
+    into the buffers the graph reads); a stochastic call draws fresh numbers on every replay and consumes torch's generator
+    like the eager call; other shapes are refused."""
+    cfg = SceneConfig(N_importance=64, **cfg_kw)
+    scene = make_scene(cfg, 3)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    R.set_precision("bf16")
+    kw = dict(network_fine=fine, N_samples=cfg.N_samples, N_importance=cfg.N_importance, perturb=1.0 if stochastic else 0.0,
+              raw_noise_std=0.5 if stochastic else 0.0, retraw=True)
+    rays0, lat0 = make_rays(n_rays, 1, cfg)
+    rays1, lat1 = make_rays(n_rays, 2, cfg)
+    rays0, lat0, rays1, lat1 = (t.to(DEV) for t in (rays0, lat0, rays1, lat1))
+    needs_lat = cfg.ray_bending or cfg.time_conditioned_baseline
+    g = R.GraphedRender(rays0, coarse, latents=lat0 if needs_lat else None, **kw)
+
+    def eager(rays, lat):
+        with torch.no_grad():
+            out = R.render_rays(rays, coarse, additional_pixel_information={"ray_bending_latents": lat} if needs_lat else None, **kw)
+        return {k: v.clone() for k, v in out.items()}
+
+    def same(a, b):
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+    if stochastic:
+        torch.manual_seed(5)
+        first = {k: v.clone() for k, v in g(rays1, lat1).items()}
+        second = {k: v.clone() for k, v in g(rays1, lat1).items()}
+        assert not torch.equal(first["rgb_map"], second["rgb_map"]), "every replay must draw new random numbers"
+        torch.manual_seed(5)
+        same(first, eager(rays1, lat1))                      # same generator state -> the eager call's numbers
+        return
+    same(g(rays1, lat1 if needs_lat else None), eager(rays1, lat1))
+    same(g(rays0, lat0 if needs_lat else None), eager(rays0, lat0))
+    before = g(rays1, lat1 if needs_lat else None)["rgb_map"].clone()
+    with torch.no_grad():
+        fine.pts_linears[3].weight.mul_(1.1)                 # in-place: bumps _version, as an optimiser step does
+    after = g(rays1, lat1 if needs_lat else None)
+    assert not torch.equal(after["rgb_map"], before)
+    same(after, eager(rays1, lat1))
+    with pytest.raises(ValueError):
+        g(rays1[:-1], lat1[:-1] if needs_lat else None)

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from nonrigid_nerf_amd import render as R
 from nonrigid_nerf_amd.synthetic import SceneConfig, build_modules, make_rays, make_scene
@@ -429,16 +430,19 @@ def _block_tiles(x, N, S):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("width,n_rays,S", [(256, 37, 192), (256, 5, 85), (128, 64, 64)], ids=["w256", "w256_ragged", "w128"])
-def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S):
+@pytest.mark.parametrize("width,n_rays,S,views", [(256, 37, 192, False), (256, 5, 85, False), (128, 64, 64, False), (256, 11, 85, True)],
+                         ids=["w256", "w256_ragged", "w128", "w256_viewdirs"])
+def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S, views):
     """nrnerf_trunk_wgrad (bf16 mode: all weight / bias gradients of the trunk in one call over the [block][feature][32
     samples] arrays) on random bf16 arrays against fp32 einsums over the same values: hidden layers, the two encoding
     products, the head, the bias sums; ragged block counts; both compiled trunk widths.  fp32 accumulation on both sides,
     so 1e-4 of scale.  The two operands the call builds itself -- encoding of the points, head gradient, in block tiles --
-    against torch (one bf16 ulp: sin / cos implementations differ in the last fp32 bit)."""
+    against torch (one bf16 ulp: sin / cos implementations differ in the last fp32 bit).  ``views``: a model with the
+    view-dependent head -- three more products over the colour branch's saved arrays (d z_v^T h_7, d z_v^T enc(direction),
+    hv^T d raw) and d z_v's row sums, and the direction encoding as a third operand."""
     import ctypes as C
     from nonrigid_nerf_amd import _lib, training
-    cfg = SceneConfig(N_importance=64, netwidth=width)
+    cfg = SceneConfig(N_importance=64, netwidth=width, use_viewdirs=views)
     scene = make_scene(cfg, 0)
     rb, coarse, fine = _modules(scene, requires_grad=False)
     R.set_precision("bf16")
@@ -450,15 +454,19 @@ def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S):
     acts, d_pre = mk(D, nblk, W, 32).abs(), mk(D, nblk, W, 32)
     pts4 = (torch.randn(M, 4, generator=gen) * 0.4).to(DEV)
     g4 = torch.randn(M, 4, generator=gen).to(DEV)
-    scratch = torch.full((2, nblk, 64, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+    scratch = torch.full((3, nblk, 64, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
     kch = 7
-    stride = _lib.wgrad_stride(D, W)
+    stride = _lib.wgrad_stride_views(D, W) if views else _lib.wgrad_stride(D, W)
     parts = torch.zeros(kch, stride, device=DEV)          # the 64-column jobs fill fewer records: zero-filled by the caller
     a = _lib.WgradArgs()
     a.struct_size = C.sizeof(_lib.WgradArgs)
     a.n_rays, a.n_samples, a.n_partials = n_rays, S, kch
     a.acts, a.d_pre, a.pts4, a.d_raw4 = acts.data_ptr(), d_pre.data_ptr(), pts4.data_ptr(), g4.data_ptr()
     a.enc, a.g_head, a.partials = scratch[0].data_ptr(), scratch[1].data_ptr(), parts.data_ptr()
+    if views:
+        hv, d_pre_v = mk(nblk, W // 2, 32).abs(), mk(nblk, W // 2, 32)
+        dirs = F.normalize(torch.randn(M, 3, generator=gen), dim=-1).to(DEV)
+        a.dirs, a.hv, a.d_pre_v, a.encv = dirs.data_ptr(), hv.data_ptr(), d_pre_v.data_ptr(), scratch[2].data_ptr()
     _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nrnerf_trunk_wgrad")
     torch.cuda.synchronize()
     enc_t, g_t = scratch[0], scratch[1]
@@ -484,20 +492,38 @@ def test_trunk_wgrad_kernel_vs_einsum(width, n_rays, S):
     close(dwe[0], torch.einsum("bfs,bgs->fg", Z[0], enc_t.float()), "encoding, layer 0")
     close(dwe[1], torch.einsum("bfs,bgs->fg", Z[5], enc_t.float()), "encoding, skip layer")
     close(dwo, torch.einsum("bfs,bgs->fg", A[D - 1], g_t.float()), "head")
+    if views:
+        o += (D + 1) * W
+        V = W // 2
+        dwf = tot[o:o + V * W].view(V, W); o += V * W
+        dwd = tot[o:o + V * 64].view(V, 64); o += V * 64
+        dwr = tot[o:o + V * 64].view(V, 64); o += V * 64
+        dbv = tot[o:o + V]
+        assert o + V == stride
+        encv_t = scratch[2]
+        want_v = _block_tiles(training.posenc(dirs, 4), n_rays, S).float()
+        assert float((encv_t.float() - want_v).abs().max()) <= 2.0 ** -7 and bool((encv_t[:, 27:] == 0).all())
+        Zv, Hv = d_pre_v.float(), hv.float()
+        close(dwf, torch.einsum("bfs,bgs->fg", Zv, A[D - 1]), "folded views layer")
+        close(dbv, Zv.sum((0, 2)), "folded views bias")
+        close(dwd, torch.einsum("bfs,bgs->fg", Zv, encv_t.float()), "direction columns")
+        close(dwr, torch.einsum("bfs,bgs->fg", Hv, g_t.float()), "rgb_linear, transposed")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("width,n_rays,S,kch", [(256, 37, 192, 7), (256, 5, 85, 3), (256, 1, 3, 4), (128, 64, 64, 28)],
-                         ids=["w256", "w256_ragged", "w256_three_samples", "w128"])
-def test_trunk_wgrad_fp32_kernel_vs_einsum(width, n_rays, S, kch):
+@pytest.mark.parametrize("width,n_rays,S,kch,views", [(256, 37, 192, 7, False), (256, 5, 85, 3, False), (256, 1, 3, 4, False), (128, 64, 64, 28, False),
+                                                      (256, 7, 85, 5, True)],
+                         ids=["w256", "w256_ragged", "w256_three_samples", "w128", "w256_viewdirs"])
+def test_trunk_wgrad_fp32_kernel_vs_einsum(width, n_rays, S, kch, views):
     """nrnerf_trunk_wgrad in fp32 mode (trunk_wgrad_f32: v_mfma_f32_32x32x2_f32 over the row-major arrays the fp32 forward /
     backward kernels write) on random arrays against float64 einsums over the same values: hidden layers, the two encoding
     products, the head, the bias sums; sample counts that are no multiple of the kernel's group of eight and fewer samples
     than workgroups; both compiled trunk widths.  Exact fp32 products, fp32 accumulation in a different order: 2e-6 of
-    scale.  The two operands the call builds itself (encoding rows, head-gradient rows) against torch."""
+    scale.  The two operands the call builds itself (encoding rows, head-gradient rows) against torch.  ``views``: with the
+    colour branch's three products (see the bf16 test)."""
     import ctypes as C
     from nonrigid_nerf_amd import _lib, training
-    cfg = SceneConfig(N_importance=64, netwidth=width)
+    cfg = SceneConfig(N_importance=64, netwidth=width, use_viewdirs=views)
     scene = make_scene(cfg, 0)
     rb, coarse, fine = _modules(scene, requires_grad=False)
     R.set_precision("f32")
@@ -508,14 +534,18 @@ def test_trunk_wgrad_fp32_kernel_vs_einsum(width, n_rays, S, kch):
     acts, d_pre = mk(D, M, W).abs(), mk(D, M, W)
     pts4 = (torch.randn(M, 4, generator=gen) * 0.4).to(DEV)
     g4 = torch.randn(M, 4, generator=gen).to(DEV)
-    scratch = torch.full((2, M, 64), float("nan"), device=DEV)
-    stride = _lib.wgrad_stride(D, W)
+    scratch = torch.full((3, M, 64), float("nan"), device=DEV)
+    stride = _lib.wgrad_stride_views(D, W) if views else _lib.wgrad_stride(D, W)
     parts = torch.zeros(kch, stride, device=DEV)          # the 64-column jobs fill fewer records: zero-filled by the caller
     a = _lib.WgradArgs()
     a.struct_size = C.sizeof(_lib.WgradArgs)
     a.n_rays, a.n_samples, a.n_partials = n_rays, S, kch
     a.acts, a.d_pre, a.pts4, a.d_raw4 = acts.data_ptr(), d_pre.data_ptr(), pts4.data_ptr(), g4.data_ptr()
     a.enc, a.g_head, a.partials = scratch[0].data_ptr(), scratch[1].data_ptr(), parts.data_ptr()
+    if views:
+        hv, d_pre_v = mk(M, W // 2).abs(), mk(M, W // 2)
+        dirs = F.normalize(torch.randn(M, 3, generator=gen), dim=-1).to(DEV)
+        a.dirs, a.hv, a.d_pre_v, a.encv = dirs.data_ptr(), hv.data_ptr(), d_pre_v.data_ptr(), scratch[2].data_ptr()
     _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nrnerf_trunk_wgrad")
     torch.cuda.synchronize()
     enc_r, g_r = scratch[0], scratch[1]
@@ -540,6 +570,21 @@ def test_trunk_wgrad_fp32_kernel_vs_einsum(width, n_rays, S, kch):
     close(dwe[0], Z[0].t() @ E, "encoding, layer 0")
     close(dwe[1], Z[5].t() @ E, "encoding, skip layer")
     close(dwo, A[D - 1].t() @ G, "head")
+    if views:
+        o += (D + 1) * W
+        V = W // 2
+        dwf = tot[o:o + V * W].view(V, W); o += V * W
+        dwd = tot[o:o + V * 64].view(V, 64); o += V * 64
+        dwr = tot[o:o + V * 64].view(V, 64); o += V * 64
+        dbv = tot[o:o + V]
+        assert o + V == stride
+        encv_r = scratch[2]
+        assert float((encv_r[:, :27] - training.posenc(dirs, 4)).abs().max()) <= 2e-6 and bool((encv_r[:, 27:] == 0).all())
+        Zv, Hv, Ev = d_pre_v.double(), hv.double(), encv_r.double()
+        close(dwf, Zv.t() @ A[D - 1], "folded views layer")
+        close(dbv, Zv.sum(0), "folded views bias")
+        close(dwd, Zv.t() @ Ev, "direction columns")
+        close(dwr, Hv.t() @ G, "rgb_linear, transposed")
 
 
 @pytest.mark.gpu
