@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NRNERF_ABI_VERSION 5
+#define NRNERF_ABI_VERSION 6
 /* samples per ray and pass of nrnerf_render (the training entry points stay at 256) */
 #define NRNERF_MAX_SAMPLES 1024
 
@@ -299,14 +299,6 @@ typedef struct nrnerf_trunk_args {
                                    which the caller forms (and differentiates); the library's images of such a model hold the
                                    remaining columns.  The gradient wrt ray_bias[r][k] is the sum of d_pre[0 | skip + 1] over the
                                    ray's samples */
-    const void* d_hidden_extra;    /* [M, width] row-major (fp32 for an NRNERF_PREC_F32 model, bf16 otherwise) or NULL: an extra gradient wrt the LAST hidden activation
-                                   (relu output of pts_linears[depth-1]), added to head^T d_raw4 before the relu mask.  With the
-                                   view-dependent head (run_nerf_helpers.py:284-304) the library's head slot holds alpha_linear:
-                                   raw4[:, 3] is the density logit and raw4[:, 0:3] = 0; the colour branch (feature_linear,
-                                   views_linears[0] on [feature, direction encoding], rgb_linear) is the caller's, on that
-                                   activation (fp32 mode: acts[depth-1] is [M][width]; bf16 mode: the [B][width][32] tiles), and
-                                   its gradient comes back here.  (How round 3 trained the view-dependent head; the library now
-                                   evaluates the colour branch itself, below, and a caller has no reason to pass this) */
     /* view-dependent head (run_nerf_helpers.py:284-304; models whose networks have use_viewdirs): the colour branch runs
        behind the trunk in the same kernels -- raw4 = [rgb logits, density logit] -- and these are required */
     const float* dirs;          /* [M,3] view direction of every sample: the normalised finite differences of the bent points

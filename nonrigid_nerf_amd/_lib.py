@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRNERF_LIB selects an alternative build of the same library (tuning experiments, see csrc/Makefile)
 LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_SAMPLES = 1024        # NRNERF_MAX_SAMPLES (include/nrnerf.h): per ray and pass of nrnerf_render; training: 256
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
@@ -100,7 +100,7 @@ class TrunkArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("which", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("pts4", C.c_void_p), ("acts", C.c_void_p), ("relu_mask", C.c_void_p),
                 ("raw4", C.c_void_p), ("raw", C.c_void_p), ("raw_ch", C.c_int32),
-                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p), ("ray_bias", C.c_void_p), ("d_hidden_extra", C.c_void_p),
+                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_pts4", C.c_void_p), ("ray_bias", C.c_void_p),
                 ("dirs", C.c_void_p), ("hv", C.c_void_p), ("hv_mask", C.c_void_p), ("d_pre_v", C.c_void_p), ("d_dirs", C.c_void_p)]
 
 

@@ -1674,7 +1674,6 @@ int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, Tr
     t.wstream = bwd ? bw.stream : fwd.stream; t.bias = fwd.bias;
     t.raw4 = a->raw4; t.raw_out = a->raw; t.raw_ch = a->raw_ch;
     t.acts = a->acts; t.d_raw4 = a->d_raw4; t.d_pre = a->d_pre; t.d_pts4 = a->d_pts4; t.ray_bias = a->ray_bias;
-    t.d_h_extra = (const float*)a->d_hidden_extra;      // (its element type follows the model's precision: nrnerf_train.h)
     t.mask = (unsigned short*)a->relu_mask;
     if (m->precision != NRNERF_PREC_F32 && !t.mask) return NRNERF_ERR_INVALID;
     if (m->views) {             // the colour branch behind the trunk (the *_views kernels)

@@ -122,8 +122,6 @@ struct TrunkArgs {
     const float* d_raw4;     // backward in  [M,4]   (gradient wrt raw4; the 5th raw channel never reaches the loss)
     const float* ray_bias;   // forward in   [n_rays][2][W] fp32 or nullptr: added to the pre-activations of pts_linears[0] and
                              // pts_linears[skip + 1] of every sample of the ray (the latent columns of the time-conditioned baseline)
-    const float* d_h_extra;  // backward in  [M][W] fp32 row-major or nullptr: added to the gradient wrt the last hidden activation
-                             // (the colour branch of the view-dependent head, evaluated by the caller)
     void* d_pre;             // backward out [D][M][W] gradient wrt the pre-activations (float or bf16)
     float* d_pts4;           // backward out [M,4]
     // view-dependent head (the *_views kernels): the colour branch behind the trunk

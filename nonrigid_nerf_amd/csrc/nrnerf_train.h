@@ -395,21 +395,8 @@ __global__ void __launch_bounds__(WAVES * 64, (P::KH == 1) ? 1 : 2) trunk_bwd(co
                 if constexpr (t == NT_W / 2 - 1) load_masks(lc, std::integral_constant<int, 1>{});      // second half of this layer's record
             }
         };
-        // d h_{D-1} from tile t of head^T's output (+ the caller's extra gradient wrt h_{D-1}, if any), masked and stored
-        auto last_hidden = [&](auto tc, const f32x16& acc) {
-            constexpr int t = decltype(tc)::value;
-            f32x16 g = acc;
-            if (a.d_h_extra) {          // rows of the saved arrays' element type: fp32, or (bf16 mode) bf16
-                const size_t er = so * A::W + 32 * t + 4 * h;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 ex = load4<P>((const void*)a.d_h_extra, er + 8 * q);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) g[4 * q + k] += ok ? ex[k] : 0.0f;
-                }
-            }
-            mask_store(std::integral_constant<int, A::D - 1>{}, tc, g, ha);
-        };
+        // d h_{D-1} from tile t of head^T's output, masked and stored
+        auto last_hidden = [&](auto tc, const f32x16& acc) { mask_store(std::integral_constant<int, A::D - 1>{}, tc, acc, ha); };
         if constexpr (!VIEWS) {
             // head^T: d h_{D-1}
             load_masks(std::integral_constant<int, A::D - 1>{}, std::integral_constant<int, 0>{});
