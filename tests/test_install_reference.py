@@ -194,13 +194,17 @@ def test_reference_render_path_and_dataparallel_wrapper_run_on_the_hip_path(refe
 
 
 @pytest.mark.gpu
-def test_reference_training_iteration_runs_natively_after_install(reference, capsys):
+@pytest.mark.parametrize("views", [False, True], ids=["default", "use_viewdirs"])
+def test_reference_training_iteration_runs_natively_after_install(reference, capsys, views):
     """(c) one iteration of the reference's ``training_wrapper_class.forward`` + ``backward`` (train.py:152-287, 1594-1597)
     with the shipped loss weights (configs/example_sequence.txt: offsets 60, divergence 3, rigidity 5e-4, 64 + 64 samples,
     perturb, raw noise 1), on the reference's REAL modules on the GPU: once eagerly (the unmodified reference on this
     device) and once after ``install(train, precision="f32")``.  After install no call may reach the reference's
     ``render_rays`` or ``compute_divergence_loss`` -- the whole iteration, second-order term included, is native -- and
-    with the same seed the loss and every parameter gradient must agree with the eager run."""
+    with the same seed the loss and every parameter gradient must agree with the eager run.  ``use_viewdirs``: the reference's
+    view-dependent head (rnh:284-304) with finite-difference directions -- both of its branches run inside the training
+    kernels (csrc/nrnerf_train.h, VIEWS), so this is the reference's own autograd through alpha / feature / views / rgb layers
+    against theirs."""
     import argparse
     from nonrigid_nerf_amd import render as R
     G, H, T = reference
@@ -209,7 +213,7 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
     ts = G.TRAIN_STEP
     n_rays = 1024                                             # N_rand of the shipped config
     from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
-    cfg = SceneConfig(N_importance=ts["N_importance"])
+    cfg = SceneConfig(N_importance=ts["N_importance"], use_viewdirs=views)
     scene = make_scene(cfg, ts["seed"])
     rays, _ = make_rays(n_rays, ts["seed"], cfg)
     g = torch.Generator().manual_seed(11)
@@ -265,14 +269,15 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
         assert cos >= 0.99, (k, cos, err)
     rows.sort(reverse=True)
     with capsys.disabled():
-        print(f"\n[reference training iteration, {n_rays} rays, real modules] mean loss eager {float(l_ref.mean()):.6f} vs installed "
+        print(f"\n[reference training iteration, {n_rays} rays, real modules{', use_viewdirs' if views else ''}] mean loss eager {float(l_ref.mean()):.6f} vs installed "
               f"{float(l_hip.mean()):.6f}; per-ray loss within 1e-3: {float((rel < 1e-3).float().mean()):.3f}; calls reaching the reference's "
               f"render_rays / compute_divergence_loss after install: {reached}; {len(rows)} gradient tensors, min cosine "
               f"{min(c for _, c, _ in rows):.5f}; largest max-error / scale: " + "; ".join(f"{k[0]}.{k[1]} {e:.1e} (cos {c:.5f})" for e, c, k in rows[:6]))
 
 
 @pytest.mark.gpu
-def test_reference_training_loop_is_faster_after_install(reference, capsys):
+@pytest.mark.parametrize("views", [False, True], ids=["default", "use_viewdirs"])
+def test_reference_training_loop_is_faster_after_install(reference, capsys, views):
     """What a user of the reference gains by the two-line drop-in, measured on the reference's REAL modules and its own
     ``training_wrapper_class`` (train.py:152-287) with the shipped recipe, N_rand = 1024: forward + backward + Adam step
     (train.py:1594-1610), eagerly on this device (the unmodified reference) and after ``install()`` in "f32" (the default:
@@ -286,7 +291,7 @@ def test_reference_training_loop_is_faster_after_install(reference, capsys):
     ts = G.TRAIN_STEP
     n_rays = 1024
     from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
-    cfg = SceneConfig(N_importance=ts["N_importance"])
+    cfg = SceneConfig(N_importance=ts["N_importance"], use_viewdirs=views)
     scene = make_scene(cfg, ts["seed"])
     rays, _ = make_rays(n_rays, ts["seed"], cfg)
     g = torch.Generator().manual_seed(11)
@@ -330,7 +335,7 @@ def test_reference_training_loop_is_faster_after_install(reference, capsys):
     f32 = ms_per_iteration("f32", 30)
     bf16 = ms_per_iteration("bf16", 30)
     with capsys.disabled():
-        print(f"\n[reference training loop, {n_rays} rays, real modules, shipped recipe, forward + backward + Adam] unmodified reference on this "
+        print(f"\n[reference training loop, {n_rays} rays, real modules{', use_viewdirs' if views else ''}, shipped recipe, forward + backward + Adam] unmodified reference on this "
               f"GPU (eager PyTorch-ROCm): {eager:.1f} ms / iteration; after install(): f32 {f32:.2f} ms ({eager / f32:.1f} x), "
               f"bf16 {bf16:.2f} ms ({eager / bf16:.1f} x)")
     assert f32 < eager and bf16 < eager
