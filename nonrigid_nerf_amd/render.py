@@ -238,13 +238,34 @@ def _param_slots(m):
     return slots
 
 
+# Optimiser steps the version counters do not see.  ``torch.optim.Adam(fused=True)`` -- and every other fused optimiser --
+# updates its parameters through one multi-tensor kernel that leaves ``Tensor._version`` alone (measured on torch 2.10:
+# tools/experiments/debug_refresh_path.py), so (data_ptr, _version) alone would keep serving the weights packed BEFORE the step.
+# A global post-step hook on all optimisers counts steps; the count is part of the fingerprint of every model that has a
+# trainable parameter (frozen networks, whatever optimiser steps elsewhere, keep their handle untouched).
+_OPT_STEPS = [0]
+_OPT_HOOK = []
+
+
+def _watch_optimizers():
+    if not _OPT_HOOK:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+
+        def _count(_optimizer, _args, _kwargs):
+            _OPT_STEPS[0] += 1
+        _OPT_HOOK.append(register_optimizer_step_post_hook(_count))
+
+
 def _fingerprint(mods):
-    fp = []
+    fp, trainable = [], False
     for m in mods:
         if m is None:
             fp.append(None)
             continue
-        fp.append(tuple((p.data_ptr(), p._version) for p in (d[n] for d, n in _param_slots(m)) if p is not None))
+        ps = [p for p in (d[n] for d, n in _param_slots(m)) if p is not None]
+        trainable = trainable or any(p.requires_grad for p in ps)
+        fp.append(tuple((p.data_ptr(), p._version) for p in ps))
+    fp.append(_OPT_STEPS[0] if trainable else None)
     return tuple(fp)
 
 
@@ -475,12 +496,16 @@ def _wref(obj):
 def get_model(network_fn, network_fine=None, precision: str | None = None, device=None) -> Model:
     """The packed-weight handle for these modules on ``device`` (created, refreshed in place, or served from the cache).
 
-    Staleness is detected from ``(data_ptr, _version)`` of every parameter: optimiser steps, ``load_state_dict``,
-    ``copy_`` and friends bump ``_version``.  In-place edits made through ``param.data`` do NOT (PyTorch does not
-    version them): call ``invalidate(network_fn)`` after such an edit.  Architectures the library has no kernel for
+    Staleness is detected from ``(data_ptr, _version)`` of every parameter -- ``load_state_dict``, ``copy_``, plain and
+    foreach optimiser steps bump ``_version`` -- and, for networks with a trainable parameter, from a count of ALL optimiser
+    steps taken in the process (fused optimisers update parameters without touching the version counters; a spurious refresh
+    costs a device-side re-pack, a missed one renders with old weights).  In-place edits made through ``param.data`` are seen
+    by neither: call ``invalidate(network_fn)`` (or ``mark_stale``) after such an edit, and after replaying an optimiser step
+    from a HIP graph.  Architectures the library has no kernel for
     raise ``Unsupported``; that verdict is cached as well, so a fallback caller does not re-copy the weights to the
     host on every call."""
     precision = _lib.canonical_precision(precision or _DEFAULT_PRECISION)
+    _watch_optimizers()
     rb = _bender_of(network_fn)
     dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
     key = (_wref(network_fine), _wref(rb), precision, str(dev), bool(getattr(network_fn, "approx_nonrigid_viewdirs", True)))

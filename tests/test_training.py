@@ -972,3 +972,35 @@ def test_training_iteration_replayed_from_a_hip_graph():
         want = R.batchify_rays(rays, {"ray_bending_latents": codes[frame].detach()}, chunk=32768, **{**kw, "perturb": 0.0, "raw_noise_std": 0.0})
     assert torch.equal(got["rgb_map"], want["rgb_map"]), "after sync() the packed weights must be the trained parameters"
     print(f"\n[graphed training step] loss {losses[0]:.4f} -> {losses[-1]:.4f} over 60 replays")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fused", "foreach", "plain"])
+def test_an_optimiser_step_of_any_kind_reaches_the_packed_weights(kind):
+    """torch.optim.Adam(fused=True) leaves Tensor._version alone (torch 2.10), so the handle's staleness check also counts
+    optimiser steps (render._watch_optimizers): after ONE step of a fused / foreach / plain Adam the next render must use
+    the stepped weights -- equal, bit for bit, to a handle packed from scratch (render.invalidate) -- and differ from the
+    render before the step."""
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, 2)
+    rb, coarse, fine = _modules(scene)
+    params = [p for m in (rb, coarse, fine) for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-2, fused=True) if kind == "fused" else torch.optim.Adam(params, lr=1e-2, foreach=(kind == "foreach"))
+    rays, lat = make_rays(64, 1, cfg)
+    rays, lat = rays.to(DEV), lat.to(DEV)
+    R.set_precision("bf16")
+    kw = dict(N_samples=cfg.N_samples, N_importance=cfg.N_importance, network_fine=fine, additional_pixel_information={"ray_bending_latents": lat})
+
+    def render():
+        with torch.no_grad():
+            return R.render_rays(rays, coarse, **kw)["rgb_map"].clone()
+
+    before = render()
+    g = torch.Generator().manual_seed(0)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g).to(DEV)
+    opt.step()
+    after = render()
+    assert not torch.equal(after, before), "the step did not reach the packed weights"
+    R.invalidate(coarse)
+    assert torch.equal(render(), after)

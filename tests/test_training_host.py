@@ -277,6 +277,26 @@ def test_param_slot_walk_notices_a_renamed_parameter():
     R._fingerprint([m])
 
 
+def test_fingerprint_counts_optimiser_steps_for_trainable_networks_only():
+    """Fused optimisers (torch.optim.Adam(fused=True)) update their parameters without bumping Tensor._version (measured on
+    the GPU: tools/experiments/debug_refresh_path.py), so the staleness check of render.get_model also counts optimiser steps
+    -- for networks with a trainable parameter; a frozen network's fingerprint does not move when some optimiser steps."""
+    from nonrigid_nerf_amd import render as R
+    R._watch_optimizers()
+    trainable, frozen, other = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3).requires_grad_(False), torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD(other.parameters(), lr=0.1)
+    fp_t, fp_f = R._fingerprint([trainable, None]), R._fingerprint([frozen])
+    assert R._fingerprint([trainable, None]) == fp_t
+    other.weight.grad, other.bias.grad = torch.ones(2, 2), torch.ones(2)
+    opt.step()                                               # ANY optimiser: which parameters it owns is not looked at
+    assert R._fingerprint([trainable, None]) != fp_t and R._fingerprint([frozen]) == fp_f
+    # the version counters keep working on their own
+    fp_f = R._fingerprint([frozen])
+    with torch.no_grad():
+        frozen.weight.mul_(2.0)
+    assert R._fingerprint([frozen]) != fp_f
+
+
 def test_install_restores_the_previous_precision_on_uninstall():
     """install() selects "f32" for the drop-in; uninstall() must give direct callers their precision back."""
     import types
