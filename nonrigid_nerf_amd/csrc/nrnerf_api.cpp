@@ -1208,15 +1208,28 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only,
                          &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
                          &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine};
+    for (PassDev* p : passes)
+        if (p && p->stream && !p->src) return NRNERF_ERR_UNSUPPORTED;          // (before anything is launched)
+    // every image (weight stream + bias table) as one segment of ONE launch
+    RepackBatchArgs b{};
+    b.flat = flat_params;
+    auto add = [&](const int32_t* src, const uint8_t* fmt, void* dst, long long n) -> bool {
+        if (n <= 0) return true;
+        if (b.n_segments == REPACK_MAX_SEGMENTS) {
+            if (launch_repack_batch(b, stream) != hipSuccess) return false;
+            b.n_segments = 0;
+        }
+        const int k = b.n_segments++;
+        if (k == 0) b.block0[0] = 0;
+        b.src[k] = src; b.fmt[k] = fmt; b.dst[k] = dst; b.n[k] = n;
+        b.block0[k + 1] = b.block0[k] + (unsigned)((n + 255) / 256);
+        return true;
+    };
     for (PassDev* p : passes) {
         if (!p || !p->stream) continue;
-        if (!p->src) return NRNERF_ERR_UNSUPPORTED;
-        RepackArgs r{flat_params, p->src, p->fmt, p->stream, (long long)p->n_elems};
-        if (launch_repack(r, stream) != hipSuccess) return NRNERF_ERR_HIP;
-        RepackArgs b{flat_params, p->bias_src, nullptr, p->bias, (long long)p->bias_floats};
-        if (launch_repack(b, stream) != hipSuccess) return NRNERF_ERR_HIP;
+        if (!add(p->src, p->fmt, p->stream, (long long)p->n_elems) || !add(p->bias_src, nullptr, p->bias, (long long)p->bias_floats)) return NRNERF_ERR_HIP;
     }
-    return NRNERF_OK;
+    return launch_repack_batch(b, stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
 void nrnerf_model_destroy(nrnerf_model* m) {

@@ -278,14 +278,20 @@ hipError_t launch_trunk_wgrad_f32_views(const WgradArgs&, hipStream_t);
 // Re-pack weights on the device (nrnerf_model_update_device): dst[i] = convert(flat[src[i]]) (0 where src[i] < 0).
 // fmt[i]: 0 = fp32, 1 = bf16, 2 = f16, 3 = f16((w - f16(w)) * 2^11), the lo part of the bender's split product;
 // fmt == nullptr: all fp32 (bias tables).
-struct RepackArgs {
+// All images of a handle in ONE launch: a training step refreshes up to nine images (stream + bias table each) -- eighteen
+// launches of a few microseconds, every iteration, when done one by one.  Segment k covers blocks [block0[k], block0[k + 1])
+// of 256 elements.
+constexpr int REPACK_MAX_SEGMENTS = 32;
+struct RepackBatchArgs {
     const float* flat;
-    const int32_t* src;
-    const uint8_t* fmt;
-    void* dst;
-    long long n;
+    const int32_t* src[REPACK_MAX_SEGMENTS];
+    const uint8_t* fmt[REPACK_MAX_SEGMENTS];
+    void* dst[REPACK_MAX_SEGMENTS];
+    long long n[REPACK_MAX_SEGMENTS];
+    unsigned block0[REPACK_MAX_SEGMENTS + 1];
+    int n_segments;
 };
-hipError_t launch_repack(const RepackArgs& a, hipStream_t stream);
+hipError_t launch_repack_batch(const RepackBatchArgs& a, hipStream_t stream);
 
 // stratified jitter of the coarse depths (train.py:855-868): z = lower + (upper - lower) * u between the mid-points
 struct JitterArgs {

@@ -41,17 +41,23 @@ hipError_t launch_raygen(const RayGenArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// weight re-packing on the device (see RepackArgs); conversions round to nearest even like the host packer
-__global__ void __launch_bounds__(256) repack_kernel(const RepackArgs a) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const int s = a.src[i];
-    const float w = s >= 0 ? a.flat[s] : 0.0f;
-    const int f = a.fmt ? a.fmt[i] : 0;
-    if (f == 0) ((float*)a.dst)[i] = w;
-    else if (f == 1) ((__bf16*)a.dst)[i] = (__bf16)w;
-    else if (f == 2) ((_Float16*)a.dst)[i] = (_Float16)w;
-    else ((_Float16*)a.dst)[i] = (_Float16)((w - (float)(_Float16)w) * 2048.0f);
+// weight re-packing on the device (see RepackBatchArgs); conversions round to nearest even like the host packer
+
+__device__ __forceinline__ void repack_one(const float* flat, const int32_t* src, const uint8_t* fmt, void* dst, long long i) {
+    const int s = src[i];
+    const float w = s >= 0 ? flat[s] : 0.0f;
+    const int f = fmt ? fmt[i] : 0;
+    if (f == 0) ((float*)dst)[i] = w;
+    else if (f == 1) ((__bf16*)dst)[i] = (__bf16)w;
+    else if (f == 2) ((_Float16*)dst)[i] = (_Float16)w;
+    else ((_Float16*)dst)[i] = (_Float16)((w - (float)(_Float16)w) * 2048.0f);
+}
+__global__ void __launch_bounds__(256) repack_batch_kernel(const RepackBatchArgs a) {
+    int k = 0;
+    for (int q = 1; q < a.n_segments; ++q)
+        if (blockIdx.x >= a.block0[q]) k = q;               // segments are listed in grid order (uniform per workgroup)
+    const long long i = (long long)(blockIdx.x - a.block0[k]) * 256 + threadIdx.x;
+    if (i < a.n[k]) repack_one(a.flat, a.src[k], a.fmt[k], a.dst[k], i);
 }
 // operands of trunk_wgrad (nrnerf_train.h) that no kernel has written yet: Embedder.embed (run_nerf_helpers.py:120-150) of the
 // trunk's input points and the gradient wrt the head's outputs, as [block][row][32 samples] bf16 tiles.
@@ -195,10 +201,9 @@ hipError_t launch_wgrad_operands_f32(const WgradOperandArgs& a, hipStream_t stre
     return hipGetLastError();
 }
 
-hipError_t launch_repack(const RepackArgs& a, hipStream_t stream) {
-    if (a.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);
+hipError_t launch_repack_batch(const RepackBatchArgs& a, hipStream_t stream) {
+    if (a.n_segments <= 0 || a.n_segments > REPACK_MAX_SEGMENTS || a.block0[a.n_segments] == 0) return a.n_segments == 0 ? hipSuccess : hipErrorInvalidValue;
+    hipLaunchKernelGGL(repack_batch_kernel, dim3(a.block0[a.n_segments]), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
-
 }  // namespace nrn
