@@ -737,6 +737,8 @@ class GraphedRender:
     def __init__(self, example_rays, network_fn, latents=None, warmup=2, check_weights=True, **render_kwargs):
         if "additional_pixel_information" in render_kwargs:
             raise ValueError("pass the latent codes as `latents`")
+        if _SCAN_OUTPUTS:
+            raise Unsupported("NRNERF_SCAN_OUTPUTS synchronises with the host after every call: nothing to capture")
         self.network_fn, self.kwargs, self.check_weights = network_fn, dict(render_kwargs), bool(check_weights)
         dev = example_rays.device
         self.rays = example_rays.detach().to(torch.float32).clone().contiguous()
