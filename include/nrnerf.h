@@ -452,8 +452,9 @@ int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t
 int nrnerf_tile_row_sums(const void* tiles, int64_t n_rows, float* out, void* hip_stream);
 
 /* One layer of the bf16 block tiles ([block][feature][32 samples], e.g. the last hidden activation acts[depth - 1]) as
- * rows [n_rays * n_samples][width] bf16 (only the samples a ray has).  Training with the view-dependent head hands the
- * last hidden activation to the colour branch's GEMMs this way (a strided library copy took 0.9 ms per pass at 16 384 rays).
+ * rows [n_rays * n_samples][width] bf16 (only the samples a ray has): for a caller that wants a saved activation in the
+ * reference's layout (an LDS transpose per tile; a strided library copy took 0.9 ms per pass at 16 384 rays).  Not used by the
+ * library's own training path any more (round 3 handed the last hidden activation to library GEMMs this way).
  * Runs on the device that owns `rows`. */
 int nrnerf_tiles_to_rows(const void* tiles, int32_t n_rays, int32_t n_samples, int32_t width, void* rows, void* hip_stream);
 
