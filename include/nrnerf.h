@@ -417,6 +417,11 @@ typedef struct nrnerf_divergence_args {
     float* d_latents;           /* out [M, latent_size] */
     int32_t n_partials;         /* a multiple of 4, <= 4096 */
     float* partials;            /* out [n_partials][depth + rigidity_depth + 1][NRNERF_BENDER_WGRAD_SLOT] */
+    /* the tangent itself, for callers that need J . e rather than e^T J e -- NeRF.exact_nonrigid_viewdirs
+       (run_nerf_helpers.py:358-385: the bent point's Jacobian applied to the ray direction = probe + tangent) under autograd */
+    float* tangent;             /* forward out [M,3] or NULL: d(masked offsets)/d(point) . probe  (divergence = probe . tangent) */
+    const float* g_tangent;     /* backward in [M,3] or NULL: gradient wrt `tangent`; when given it is used INSTEAD of
+                                   g_divergence (which may then be NULL) */
 } nrnerf_divergence_args;
 int nrnerf_bender_divergence_forward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);
 int nrnerf_bender_divergence_backward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);

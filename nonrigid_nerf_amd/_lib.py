@@ -164,7 +164,8 @@ class DivergenceArgs(C.Structure):
                 ("g_divergence", C.c_void_p),
                 ("dz_offsets", C.c_void_p), ("dtz_offsets", C.c_void_p), ("dz_rigidity", C.c_void_p), ("dtz_rigidity", C.c_void_p),
                 ("dz_out4", C.c_void_p), ("dtz_out4", C.c_void_p), ("d_latents", C.c_void_p),
-                ("n_partials", C.c_int32), ("partials", C.c_void_p)]
+                ("n_partials", C.c_int32), ("partials", C.c_void_p),
+                ("tangent", C.c_void_p), ("g_tangent", C.c_void_p)]
 
 
 class CompositeArgs(C.Structure):

@@ -788,11 +788,11 @@ int pack_split(const nrnerf_model_desc& d, PackedPass& trunk, PackedPass& bend, 
 
 // transposed trunk weights for the backward-data kernel; eligible models only (see nrnerf_model::train_ok)
 bool training_eligible(const nrnerf_model_desc& d, const nrnerf_model* m) {
-    // (with the view-dependent head: finite-difference or ray directions -- the exact-Jacobian directions would need the
-    //  bender differentiated twice inside the colour branch)
+    // (with the view-dependent head: the directions are an input of the trunk's training kernels -- finite differences, the rays' own, or
+    //  the exact Jacobian directions, whose tangent and its gradient come from nrnerf_bender_divergence_* (tangent / g_tangent))
     // (time-conditioned baseline, architecture 2: trained through the plain trunk's kernels, the latent columns of its two
     //  input layers as per-ray biases -- pack_pass, tcb_shift)
-    return !(m->views && m->exact) && (m->arch_id <= 2 || m->arch_id == 5) && d.precision != NRNERF_PREC_F16;
+    return (m->arch_id <= 2 || m->arch_id == 5) && d.precision != NRNERF_PREC_F16;
 }
 int tcb_shift_of(const nrnerf_mlp_desc& mlp) {      // latent columns of a time-conditioned trunk (0: plain trunk)
     return mlp.time_conditioned ? mlp.pts_linears[0].in_features - (3 + 6 * ArchDefault::L) : 0;
@@ -1024,7 +1024,6 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
         rc = (which == 2) ? pack_split(*desc, pk, other) : pack_split(*desc, other, pk);
     } else if (which == 4 || which == 5) {       // transposed trunk weights of the backward-data kernel (training)
         if (desc->coarse->time_conditioned || desc->precision == NRNERF_PREC_F16) return NRNERF_ERR_UNSUPPORTED;
-        if (desc->coarse->use_viewdirs && desc->exact_viewdirs) return NRNERF_ERR_UNSUPPORTED;
         PackedPass fwd;
         nrnerf_model_desc d2 = *desc;
         d2.bender = nullptr;
@@ -1881,7 +1880,7 @@ int divergence_common(const nrnerf_model* m, const nrnerf_divergence_args* a, bo
     if (!a->points || !a->probe || !a->latents || (a->latent_stride != 0 && a->latent_stride < m->latent_size)) return NRNERF_ERR_INVALID;
     if (!a->divergence || !a->off4 || !a->toff4 || !a->acts_offsets || !a->tacts_offsets || !a->acts_rigidity || !a->tacts_rigidity)
         return NRNERF_ERR_INVALID;
-    if (bwd && (!a->g_divergence || !a->dz_offsets || !a->dtz_offsets || !a->dz_rigidity || !a->dtz_rigidity || !a->dz_out4 ||
+    if (bwd && ((!a->g_divergence && !a->g_tangent) || !a->dz_offsets || !a->dtz_offsets || !a->dz_rigidity || !a->dtz_rigidity || !a->dz_out4 ||
                 !a->dtz_out4 || !a->d_latents || !a->partials || a->n_partials < 4 || a->n_partials > 4096 || a->n_partials % 4))
         return NRNERF_ERR_INVALID;
     t = BendDivArgs{};
@@ -1890,7 +1889,7 @@ int divergence_common(const nrnerf_model* m, const nrnerf_divergence_args* a, bo
     t.wstream = p.stream; t.bias = p.bias;
     t.knobs.has_cutoff = a->has_rigidity_cutoff; t.knobs.cutoff = a->rigidity_cutoff;
     t.knobs.has_scaling = a->has_test_time_scaling; t.knobs.scaling = a->test_time_scaling;
-    t.div = a->divergence; t.off4 = a->off4; t.toff4 = a->toff4;
+    t.div = a->divergence; t.off4 = a->off4; t.toff4 = a->toff4; t.tvec = a->tangent; t.g_tvec = a->g_tangent;
     t.acts_b = a->acts_offsets; t.tacts_b = a->tacts_offsets; t.acts_r = a->acts_rigidity; t.tacts_r = a->tacts_rigidity;
     t.g_div = a->g_divergence; t.dz_b = a->dz_offsets; t.dtz_b = a->dtz_offsets; t.dz_r = a->dz_rigidity; t.dtz_r = a->dtz_rigidity;
     t.dz_out4 = a->dz_out4; t.dtz_out4 = a->dtz_out4; t.d_lat = a->d_latents;

@@ -212,6 +212,8 @@ struct BendDivArgs {
     const float* bias;       // forward only
     Knobs knobs;
     float* div;              // forward out [M]
+    float* tvec;             // forward out [M,3] or nullptr: the tangent of the masked offsets along e (div = e . tvec)
+    const float* g_tvec;     // backward in [M,3] or nullptr: gradient wrt tvec, used INSTEAD of g_div e
     float* off4;             // [M,4] unmasked offsets xyz + tanh(rigidity logit):                 forward writes, backward reads
     float* toff4;            // [M,4] tangent of the offsets xyz + tangent of the rigidity logit:  forward writes, backward reads
     void* acts_b;  void* tacts_b;     // [BD-1][M][BW] hidden activations / their tangents (after the relu mask); fp32 or bf16 as in

@@ -402,6 +402,12 @@ __global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
         for (int c = 0; c < 3; ++c) d += ev[c] * (tmask * off[c] + mask * toff[c]);       // e . d(mask * off)/dt   (rnh:567)
         if (a.knobs.has_scaling) d *= a.knobs.scaling;                                     // rnh:568-569
         if (ok && h == 0) {
+            if (a.tvec) {               // the tangent itself: d(masked offsets)/dp . e  (J . e = e + this for the bent point)
+                const float sc = a.knobs.has_scaling ? a.knobs.scaling : 1.0f;
+                float* tv = a.tvec + so * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tv[c] = sc * (tmask * off[c] + mask * toff[c]);
+            }
             a.div[so] = d;
             *(f32x4*)(a.off4 + so * 4) = f32x4{off[0], off[1], off[2], th};
             *(f32x4*)(a.toff4 + so * 4) = f32x4{toff[0], toff[1], toff[2], tlogit};
@@ -441,14 +447,24 @@ __global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
         const float s2 = 0.5f * (1.0f - th * th);
         const bool cut = a.knobs.has_cutoff && (th + 1.0f) / 2.0f <= a.knobs.cutoff;
         const float mask = cut ? 0.0f : (th + 1.0f) / 2.0f, tmask = cut ? 0.0f : s2 * tlogit;
-        const float g = ok ? a.g_div[so] * sc : 0.0f;
+        // cotangent of the masked tangent vector sc (tmask off + mask toff): the divergence e . (that) hands down g_div e; a caller
+        // that consumes the vector itself (exact view directions, rnh:358-385) hands in its own
+        float gv[3];
+        if (a.g_tvec) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gv[c] = ok ? a.g_tvec[so * 3 + c] * sc : 0.0f;
+        } else {
+            const float g = ok ? a.g_div[so] * sc : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gv[c] = g * ev[c];
+        }
         float g_off[3], g_toff[3], g_m = 0.0f, g_tm = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            g_off[c] = g * ev[c] * tmask;
-            g_toff[c] = g * ev[c] * mask;
-            g_m += g * ev[c] * tt[c];
-            g_tm += g * ev[c] * ot[c];
+            g_off[c] = gv[c] * tmask;
+            g_toff[c] = gv[c] * mask;
+            g_m += gv[c] * tt[c];
+            g_tm += gv[c] * ot[c];
         }
         const float g_logit = cut ? 0.0f : g_m * s2 - g_tm * tlogit * th * (1.0f - th * th);
         const float g_tlogit = cut ? 0.0f : g_tm * s2;

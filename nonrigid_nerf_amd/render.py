@@ -282,8 +282,8 @@ class Model:
         desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
         self.has_bender = bool(desc.bender)
         # nrnerf_bender_* / nrnerf_bender_divergence_* are available (the library's own rule: training_eligible in
-        # csrc/nrnerf_api.cpp): a bender, not the exact-Jacobian view directions, not an f16 handle
-        self.trains_bender = bool(desc.bender) and not (desc.coarse.contents.use_viewdirs and desc.exact_viewdirs) and self.precision != "f16"
+        # csrc/nrnerf_api.cpp): a bender, not an f16 handle
+        self.trains_bender = bool(desc.bender) and self.precision != "f16"
         self.needs_latents = self.has_bender or bool(desc.coarse.contents.time_conditioned)
         self.latent_size = desc.bender.contents.latent_size if self.has_bender else \
             (int(getattr(network_fn, "ray_bending_latent_size", 0)) if self.needs_latents else 0)

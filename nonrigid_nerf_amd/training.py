@@ -25,7 +25,8 @@ What is left to libraries, as plumbing:
 ``NATIVE_BENDER = False`` runs the bender's MLPs as torch ops on the modules' parameters instead (the gradient-parity tests use
 it because it reproduces the reference's bent points bit for bit).
 Eligible: the compiled architectures (render.py / README.md) in precision fp32 or bf16 (``render.set_precision``; "f16" trains
-in bf16: unscaled f16 gradients underflow), except exact Jacobian view directions.  Anything else is handed to the reference
+in bf16: unscaled f16 gradients underflow), exact Jacobian view directions included (the tangent J d and its gradient come
+from the divergence regulariser's kernels).  Anything else is handed to the reference
 by ``render.render_rays`` as before.  ``training_loss`` is the reference's whole iteration on these entry points,
 ``GraphedStep`` the same captured in one HIP graph.
 """
@@ -845,7 +846,9 @@ class _Divergence(torch.autograd.Function):
     per-point latent rows and the bender's parameters (the points are a leaf nobody reads in the reference)."""
 
     @staticmethod
-    def forward(ctx, point_latents, model, rb, pts, e, token):
+    def forward(ctx, point_latents, model, rb, pts, e, token, tangent=False):
+        """tangent: return J e itself, [M,3] -- the directional derivative of the masked offsets along e -- instead of e^T J e
+        (exact view directions, rnh:358-385: the bent point's Jacobian applied to the ray direction is e + this)."""
         M, dev = int(pts.shape[0]), pts.device
         BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
         RD, RW = len(rb.rigidity_network), int(rb.rigidity_network[0].weight.shape[0])
@@ -861,18 +864,21 @@ class _Divergence(torch.autograd.Function):
         acts_b, tacts_b = torch.empty(BD - 1, M, BW, **sd), torch.empty(BD - 1, M, BW, **sd)
         acts_r, tacts_r = torch.empty(RD - 1, M, RW, **sd), torch.empty(RD - 1, M, RW, **sd)
         a = _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
+        tvec = torch.empty(M, 3, **f32) if tangent else None
+        if tangent:
+            a.tangent = tvec.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_divergence_forward")
-        ctx.model, ctx.rb, ctx.dims = model, rb, (M, BD, BW, RD, RW)
+        ctx.model, ctx.rb, ctx.dims, ctx.tangent = model, rb, (M, BD, BW, RD, RW), bool(tangent)
         ctx.save_for_backward(pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
         ctx.set_materialize_grads(False)
-        return div
+        return tvec if tangent else div
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_div):
         if g_div is None:
-            return (None,) * 6
+            return (None,) * 7
         pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r = ctx.saved_tensors
         model, rb = ctx.model, ctx.rb
         M, BD, BW, RD, RW = ctx.dims
@@ -886,14 +892,17 @@ class _Divergence(torch.autograd.Function):
         nj = BD + RD + 1
         parts = torch.empty(nparts, nj, _lib.BENDER_WGRAD_SLOT, **f32)
         a = _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
-        a.g_divergence = g.data_ptr()
+        if ctx.tangent:
+            a.g_tangent = g.data_ptr()          # [M,3]: gradient wrt the tangent vector
+        else:
+            a.g_divergence = g.data_ptr()
         a.dz_offsets, a.dtz_offsets, a.dz_rigidity, a.dtz_rigidity = dz_b.data_ptr(), dtz_b.data_ptr(), dz_r.data_ptr(), dtz_r.data_ptr()
         a.dz_out4, a.dtz_out4, a.d_latents = dz_out4.data_ptr(), dtz_out4.data_ptr(), d_lat.data_ptr()
         a.n_partials, a.partials = nparts, parts.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_divergence_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_divergence_backward")
         index, _ = _bender_grad_index(rb, dev, divergence=True)
-        return (d_lat, None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index))
+        return (d_lat, None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index), None)
 
 
 def _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r):
@@ -985,11 +994,10 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
                 return "time-conditioned baseline with a bender / a non-default trunk under autograd"
         if getattr(net, "use_viewdirs", False):
             has_bender = R._bender_of(network_fn) is not None
-            if has_bender and not getattr(net, "approx_nonrigid_viewdirs", True):
-                return "view-dependent head with exact (Jacobian) view directions under autograd"
+            exact = has_bender and not getattr(net, "approx_nonrigid_viewdirs", True)
             if int(net.W) != 256 or int(getattr(net, "input_ch_views", 0)) != 27:
                 return "view-dependent head on a non-default trunk under autograd"
-            if not has_bender and ray_batch.shape[-1] < 11:
+            if (not has_bender or exact) and ray_batch.shape[-1] < 11:
                 return "use_viewdirs without view directions in the ray batch"
         if int(net.D) != 8 or int(net.W) not in (256, 128) or list(net.skips) != [4] or int(net.input_ch) != 63:
             return "non-default trunk under autograd"
@@ -1083,7 +1091,16 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             # view-dependent head (rnh:284-304): the direction of every sample -- the finite differences of the bent points
             # (rnh:288-290, approx_nonrigid_viewdirs; one launch each way) or the ray's own (train.py:73-76); the head itself runs
             # behind the trunk in the same kernels
-            if rb is not None and NATIVE_DIRECTION_ENCODING and bent.is_cuda and ns >= 2:
+            if rb is not None and not getattr(net, "approx_nonrigid_viewdirs", True):
+                # exact directions (rnh:291-294, 358-385): the bent point's Jacobian applied to the ray's unit direction, J d = d +
+                # d(masked offsets)/dp . d -- one forward-mode tangent through the bender (the reference: three reverse passes with
+                # create_graph=True), differentiated by the two-chain backward of the divergence kernels
+                d_unit = rays[:, None, 8:11].expand(N, ns, 3).reshape(N * ns, 3)
+                straight = (rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]).reshape(N * ns, 3)
+                lat_pts = latents.view(N, 1, -1).expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)
+                jd = d_unit + _Divergence.apply(lat_pts, model, rb, straight, d_unit, _param_token(rb, _bender_params(rb)), True)
+                dirs = (jd / torch.norm(jd, dim=-1, keepdim=True) + 0.000001).view(N, ns, 3)        # rnh:371-376: eps outside the division
+            elif rb is not None and NATIVE_DIRECTION_ENCODING and bent.is_cuda and ns >= 2:
                 dirs = _DirectionEncoding.apply(bent, 0, torch.float32).view(N, ns, 3)
             elif rb is not None:
                 dirs = finite_difference_dirs(bent)

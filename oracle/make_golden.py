@@ -349,6 +349,8 @@ def main():
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_64_64.npz"), **run_gradients(H, T))
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_viewdirs_64_64.npz"),
                             **run_gradients(H, T, cfg_kw=dict(use_viewdirs=True), grad_params=GRAD_PARAMS_VIEWS))
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_exact_viewdirs_64_64.npz"),
+                            **run_gradients(H, T, cfg_kw=dict(use_viewdirs=True, approx_nonrigid_viewdirs=False), grad_params=GRAD_PARAMS_VIEWS))
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_time_conditioned_64_64.npz"),
                             **run_gradients(H, T, cfg_kw=dict(ray_bending=False, time_conditioned_baseline=True), grad_params=GRAD_PARAMS_TCB))
         if "--only-grads" in sys.argv:

@@ -103,12 +103,24 @@ def finite_difference_dirs(bent, samples_per_ray: int):
 
 def exact_dirs(flat, lat, bender, knobs, unbent_dirs):
     """NeRF.exact_nonrigid_viewdirs, run_nerf_helpers.py:358-385: the bent point's Jacobian wrt the straight point,
-    applied to the ray's unit direction.  Only J . d is needed, so one forward-mode product replaces the reference's
-    three reverse passes (_get_minibatch_jacobian, :81-104); same value up to fp32 rounding."""
-    with torch.enable_grad():
-        _, jd = torch.autograd.functional.jvp(lambda x: bend_points(x, lat, bender, knobs)[0], (flat,), (unbent_dirs,))
-    jd = jd.detach()
-    return jd / torch.norm(jd, dim=-1, keepdim=True) + 0.000001        # :374-378 (eps lands outside the division)
+    applied to the ray's unit direction.  Inference (nothing requires a gradient): only J . d is needed, so one forward-mode
+    product replaces the reference's three reverse passes (_get_minibatch_jacobian, :81-104); same value up to fp32 rounding.
+    Under autograd (training): the Jacobian row by row with create_graph=True exactly as :81-104 -- the reference's loss
+    differentiates THROUGH the Jacobian (second order in the bender's parameters and the latent codes)."""
+    trains = torch.is_grad_enabled() and (lat.requires_grad or any(v.requires_grad for v in bender.values()))
+    if not trains:
+        with torch.enable_grad():
+            _, jd = torch.autograd.functional.jvp(lambda x: bend_points(x, lat, bender, knobs)[0], (flat,), (unbent_dirs,))
+        jd = jd.detach()
+        return jd / torch.norm(jd, dim=-1, keepdim=True) + 0.000001        # :374-378 (eps lands outside the division)
+    x = flat.detach().requires_grad_(True)                                 # (the reference's points are a leaf here too: train.py:871-873)
+    y = bend_points(x, lat, bender, knobs)[0]
+    rows = []
+    for j in range(3):                                                     # :93-103
+        rows.append(torch.autograd.grad(y[:, j], x, torch.ones_like(y[:, j]), retain_graph=True, create_graph=True)[0].unsqueeze(1))
+    jac = torch.cat(rows, 1)                                               # [M, 3 (outputs), 3 (inputs)]
+    jd = torch.matmul(jac, unbent_dirs.reshape(-1, 3, 1)).view(-1, 3)      # :367-368
+    return jd / torch.norm(jd, dim=-1, keepdim=True) + 0.000001            # :371-376
 
 
 def canonical_mlp(enc, net, cfg, enc_dirs=None, latents=None):

@@ -194,7 +194,7 @@ def test_reference_render_path_and_dataparallel_wrapper_run_on_the_hip_path(refe
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("views", [False, True], ids=["default", "use_viewdirs"])
+@pytest.mark.parametrize("views", [False, True, "exact"], ids=["default", "use_viewdirs", "use_viewdirs_exact"])
 def test_reference_training_iteration_runs_natively_after_install(reference, capsys, views):
     """(c) one iteration of the reference's ``training_wrapper_class.forward`` + ``backward`` (train.py:152-287, 1594-1597)
     with the shipped loss weights (configs/example_sequence.txt: offsets 60, divergence 3, rigidity 5e-4, 64 + 64 samples,
@@ -204,7 +204,8 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
     with the same seed the loss and every parameter gradient must agree with the eager run.  ``use_viewdirs``: the reference's
     view-dependent head (rnh:284-304) with finite-difference directions -- both of its branches run inside the training
     kernels (csrc/nrnerf_train.h, VIEWS), so this is the reference's own autograd through alpha / feature / views / rgb layers
-    against theirs."""
+    against theirs.  ``exact``: exact_nonrigid_viewdirs (rnh:358-385) -- the reference differentiates THROUGH the bender's Jacobian
+    (three reverse passes with create_graph=True); here one forward-mode tangent and the divergence kernels' two-chain backward."""
     import argparse
     from nonrigid_nerf_amd import render as R
     G, H, T = reference
@@ -213,7 +214,7 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
     ts = G.TRAIN_STEP
     n_rays = 1024                                             # N_rand of the shipped config
     from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
-    cfg = SceneConfig(N_importance=ts["N_importance"], use_viewdirs=views)
+    cfg = SceneConfig(N_importance=ts["N_importance"], use_viewdirs=bool(views), approx_nonrigid_viewdirs=(views != "exact"))
     scene = make_scene(cfg, ts["seed"])
     rays, _ = make_rays(n_rays, ts["seed"], cfg)
     g = torch.Generator().manual_seed(11)
@@ -269,7 +270,7 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
         assert cos >= 0.99, (k, cos, err)
     rows.sort(reverse=True)
     with capsys.disabled():
-        print(f"\n[reference training iteration, {n_rays} rays, real modules{', use_viewdirs' if views else ''}] mean loss eager {float(l_ref.mean()):.6f} vs installed "
+        print(f"\n[reference training iteration, {n_rays} rays, real modules{(', use_viewdirs, exact Jacobian directions' if views == 'exact' else ', use_viewdirs') if views else ''}] mean loss eager {float(l_ref.mean()):.6f} vs installed "
               f"{float(l_hip.mean()):.6f}; per-ray loss within 1e-3: {float((rel < 1e-3).float().mean()):.3f}; calls reaching the reference's "
               f"render_rays / compute_divergence_loss after install: {reached}; {len(rows)} gradient tensors, min cosine "
               f"{min(c for _, c, _ in rows):.5f}; largest max-error / scale: " + "; ".join(f"{k[0]}.{k[1]} {e:.1e} (cos {c:.5f})" for e, c, k in rows[:6]))

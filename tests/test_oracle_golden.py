@@ -75,8 +75,9 @@ def test_oracle_get_rays_matches_reference():
 
 
 @pytest.mark.parametrize("fixture,cfg_kw", [("gradients_64_64", {}), ("gradients_viewdirs_64_64", dict(use_viewdirs=True)),
+                                            ("gradients_exact_viewdirs_64_64", dict(use_viewdirs=True, approx_nonrigid_viewdirs=False)),
                                             ("gradients_time_conditioned_64_64", dict(ray_bending=False, time_conditioned_baseline=True))],
-                         ids=["default", "viewdirs", "time_conditioned"])
+                         ids=["default", "viewdirs", "exact_viewdirs", "time_conditioned"])
 def test_oracle_gradients_match_reference_autograd(fixture, cfg_kw):
     """Groundwork for the backward pass: the oracle is differentiable torch code, and its
     gradients of sum(rgb_map) + sum(rgb0) wrt a few parameters and the latent codes equal what the reference's own

@@ -49,8 +49,9 @@ def torch_ops_bender():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture,cfg_kw", [("gradients_64_64", {}), ("gradients_viewdirs_64_64", dict(use_viewdirs=True)),
+                                            ("gradients_exact_viewdirs_64_64", dict(use_viewdirs=True, approx_nonrigid_viewdirs=False)),
                                             ("gradients_time_conditioned_64_64", dict(ray_bending=False, time_conditioned_baseline=True))],
-                         ids=["default", "viewdirs", "time_conditioned"])
+                         ids=["default", "viewdirs", "exact_viewdirs", "time_conditioned"])
 def test_gradients_match_reference_autograd_golden(torch_ops_bender, fixture, cfg_kw):
     """fp32 mode: d(sum rgb_map + sum rgb0) wrt the latent codes and a few parameters of every network, against what the
     reference's own autograd produced on the CPU (train.render under grad, z_samples detached).
@@ -172,10 +173,12 @@ def _loss(out, detailed):
                                                            (1.0, 0.5, False, dict(N_importance=64, use_viewdirs=True, bend_depth=7)),
                                                            (1.0, 1.0, False, dict(N_samples=48, N_importance=37, ray_bending=False, time_conditioned_baseline=True)),
                                                            (1.0, 0.0, False, dict(N_samples=48, N_importance=37, ray_bending=False, time_conditioned_baseline=True,
-                                                                                   use_viewdirs=True))],
+                                                                                   use_viewdirs=True)),
+                                                           (1.0, 1.0, True, dict(N_samples=48, N_importance=37, use_viewdirs=True, approx_nonrigid_viewdirs=False)),
+                                                           (0.0, 0.0, False, dict(N_importance=64, use_viewdirs=True, approx_nonrigid_viewdirs=False, bend_depth=7))],
                          ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128", "lindisp_white_bkgd",
                               "viewdirs_detailed_ragged", "viewdirs_no_bender", "config4_viewdirs_deep_bender", "time_conditioned_ragged",
-                              "time_conditioned_viewdirs"])
+                              "time_conditioned_viewdirs", "exact_viewdirs_detailed_ragged", "exact_viewdirs_deep_bender"])
 @pytest.mark.parametrize("bender", ["torch_ops", "native"])
 def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, bender):
     """Every parameter of every network + the latent codes, fp32 mode, against the oracle's autograd (eager torch on the

@@ -75,16 +75,22 @@ def test_eligibility_of_training_calls():
     # rays that require a gradient (camera refinement): the kernels treat rays as data, so such a call must reach the
     # reference's autograd graph instead of coming back with a silently missing gradient
     assert "requires a gradient" in T.why_not_trainable(coarse, fine, 64, 64, False, False, OnGpuWithGrad)
-    # view-dependent head: trains (density natively, colour branch as library GEMMs on the last hidden activation) with
-    # finite-difference directions; the exact-Jacobian directions and a ray batch without directions (no bender) do not
-    assert T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu) is None
-    cv.approx_nonrigid_viewdirs = fv.approx_nonrigid_viewdirs = False
-    assert "exact" in T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu)
-    cv.approx_nonrigid_viewdirs = fv.approx_nonrigid_viewdirs = True
-    _, cn, fn = build_modules(make_scene(SceneConfig(N_importance=64, use_viewdirs=True, ray_bending=False), 0))
-
     class OnGpu8(OnGpu):
         shape = (4, 8)
+
+    class OnGpu11(OnGpu):
+        shape = (4, 11)
+
+    # view-dependent head: trains natively (both branches in the training kernels) with finite-difference directions -- which
+    # need nothing from the ray batch --, with the exact Jacobian directions and without a bender when the batch carries the
+    # rays' unit directions (columns 8..10, train.py:73-76), not without them
+    assert T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu8) is None
+    cv.approx_nonrigid_viewdirs = fv.approx_nonrigid_viewdirs = False
+    assert T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu11) is None
+    assert "without view directions" in T.why_not_trainable(cv, fv, 64, 64, False, False, OnGpu8)
+    cv.approx_nonrigid_viewdirs = fv.approx_nonrigid_viewdirs = True
+    _, cn, fn = build_modules(make_scene(SceneConfig(N_importance=64, use_viewdirs=True, ray_bending=False), 0))
+    assert T.why_not_trainable(cn, fn, 64, 64, False, False, OnGpu11) is None
     assert "without view directions" in T.why_not_trainable(cn, fn, 64, 64, False, False, OnGpu8)
     assert T.why_not_trainable(coarse, fine, 64, 64, True, False, OnGpu) is None                  # lindisp trains natively
     assert T.why_not_trainable(coarse, fine, 64, 64, False, True, OnGpu).startswith("pytest flag")

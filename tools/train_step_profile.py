@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU box, under `rocprofv3 --kernel-trace --stats`: native training steps with the reference's shipped recipe
 (configs/example_sequence.txt: 64 + 64 samples, detailed outputs, data + offsets / rigidity + divergence terms; bf16 mode) at
-one batch size.    python tools/train_step_profile.py [rays] [precision] [--table] [--views]  (--table: torch profiler's kernel table)"""
+one batch size.    python tools/train_step_profile.py [rays] [precision] [--table] [--views | --exact]  (--table: torch profiler's kernel table)"""
 import os
 import sys
 
@@ -16,7 +16,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 1024
 prec = args[1] if len(args) > 1 else "bf16"
 dev = torch.device("cuda:0")
-CFG = SceneConfig(use_viewdirs=True) if "--views" in sys.argv else (SceneConfig(ray_bending=False, time_conditioned_baseline=True) if "--tcb" in sys.argv else SceneConfig())   # --views: view-dependent head; --tcb: time-conditioned baseline
+CFG = SceneConfig(use_viewdirs=True, approx_nonrigid_viewdirs=False) if "--exact" in sys.argv else SceneConfig(use_viewdirs=True) if "--views" in sys.argv else (SceneConfig(ray_bending=False, time_conditioned_baseline=True) if "--tcb" in sys.argv else SceneConfig())   # --views: view-dependent head; --tcb: time-conditioned baseline
 _SceneConfig, SceneConfig = SceneConfig, (lambda: CFG)
 if "--table" in sys.argv:
     from torch.profiler import ProfilerActivity, profile
