@@ -443,11 +443,18 @@ def test_boundary_contract_errors_and_fallback():
         # ... and is taken by the native training path (nonrigid_nerf_amd/training.py), not handed to the reference
         out = FakeTrain.batchify_rays(rays0.to(DEV), api, network_fn=coarse, network_query_fn=None, N_samples=64)
         assert FakeTrain.calls == [] and out["rgb_map"].requires_grad
-        # a training call the native path has no kernels for (exact Jacobian view directions) still goes to the reference
+        # exact Jacobian view directions under autograd: native since the end of round 4 (the tangent of the divergence kernels)
         cfgv = SceneConfig(N_importance=0, use_viewdirs=True, approx_nonrigid_viewdirs=False)
         rbv, cv, _ = build_modules(make_scene(cfgv, 0), device=DEV)
         rv, lv = make_rays(8, 0, cfgv)
         out = FakeTrain.batchify_rays(rv.to(DEV), {"ray_bending_latents": lv.to(DEV)}, network_fn=cv, network_query_fn=None, N_samples=64)
+        assert FakeTrain.calls == [] and out["rgb_map"].requires_grad
+        # a training call the native path has no kernels for (a trunk width outside the compiled set: rendered by the generic
+        # kernel, but not trained) still goes to the reference
+        cfgw = SceneConfig(N_importance=0, netwidth=192)
+        rbw2, cw2, _ = build_modules(make_scene(cfgw, 0), device=DEV)
+        rw2, lw2 = make_rays(8, 0, cfgw)
+        out = FakeTrain.batchify_rays(rw2.to(DEV), {"ray_bending_latents": lw2.to(DEV)}, network_fn=cw2, network_query_fn=None, N_samples=64)
         assert FakeTrain.calls and FakeTrain.calls[0][0] == "batchify_rays"
         # wrong latent shape: the reference raises in expand/split; here a ValueError, never an out-of-bounds read
         with torch.no_grad(), pytest.raises(ValueError):
