@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define NRNERF_ABI_VERSION 6
-/* samples per ray and pass of nrnerf_render (the training entry points stay at 256) */
+/* samples per ray and pass: nrnerf_render and the training entry points (the split fine bender -- nrnerf_merge_rows,
+ * nrnerf_composite_args.rank_new -- up to 256 merged samples: 8-bit ranks) */
 #define NRNERF_MAX_SAMPLES 1024
 
 typedef enum nrnerf_status {

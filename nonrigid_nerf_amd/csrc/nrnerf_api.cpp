@@ -1588,7 +1588,7 @@ int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_p
 
 int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uniforms, int32_t n_rays, int32_t n_samples,
                          int32_t lindisp, float* z_out, void* hip_stream) try {
-    if (!rays || !z_out || ray_stride < 8 || n_rays < 0 || n_samples < 2 || n_samples > 256) return NRNERF_ERR_INVALID;
+    if (!rays || !z_out || ray_stride < 8 || n_rays < 0 || n_samples < 2 || n_samples > NRNERF_MAX_SAMPLES) return NRNERF_ERR_INVALID;
     if (n_rays == 0) return NRNERF_OK;
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, z_out) != hipSuccess) { (void)hipGetLastError(); return NRNERF_ERR_INVALID; }
@@ -1658,7 +1658,7 @@ int nrnerf_tiles_to_rows(const void* tiles, int32_t n_rays, int32_t n_samples, i
 
 int nrnerf_direction_encoding(const float* bent4, int32_t n_rays, int32_t n_samples, int32_t n_freqs, void* enc, int32_t enc_is_bf16,
                               float* g_bent4, void* hip_stream) try {
-    if (!bent4 || !enc || n_rays < 0 || n_samples < 2 || n_samples > 256 || n_freqs < 0 || n_freqs > 10) return NRNERF_ERR_INVALID;
+    if (!bent4 || !enc || n_rays < 0 || n_samples < 2 || n_samples > NRNERF_MAX_SAMPLES || n_freqs < 0 || n_freqs > 10) return NRNERF_ERR_INVALID;
     if (n_rays == 0) return NRNERF_OK;
     int dev = 0;
     if (device_of(enc, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
@@ -1673,7 +1673,7 @@ namespace {
 int trunk_common(const nrnerf_model* m, const nrnerf_trunk_args* a, bool bwd, TrunkArgs& t) {
     if (!m || !a || a->struct_size != sizeof(nrnerf_trunk_args)) return NRNERF_ERR_INVALID;
     if (!m->train_ok) return NRNERF_ERR_UNSUPPORTED;
-    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || (a->which != 0 && a->which != 1)) return NRNERF_ERR_INVALID;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NRNERF_MAX_SAMPLES || (a->which != 0 && a->which != 1)) return NRNERF_ERR_INVALID;
     if (!a->pts4 || !a->acts) return NRNERF_ERR_INVALID;
     if (!bwd && (!a->raw4 || (a->raw && a->raw_ch != 4 && a->raw_ch != 5))) return NRNERF_ERR_INVALID;
     if (bwd && (!a->d_raw4 || !a->d_pre || !a->d_pts4)) return NRNERF_ERR_INVALID;
@@ -1729,7 +1729,7 @@ int nrnerf_trunk_backward(const nrnerf_model* m, const nrnerf_trunk_args* a, voi
 int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* hip_stream) try {
     if (!m || !a || a->struct_size != sizeof(nrnerf_wgrad_args)) return NRNERF_ERR_INVALID;
     if (!m->train_ok) return NRNERF_ERR_UNSUPPORTED;
-    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 1 || a->n_partials > 4096) return NRNERF_ERR_INVALID;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NRNERF_MAX_SAMPLES || a->n_partials < 1 || a->n_partials > 4096) return NRNERF_ERR_INVALID;
     if (!a->acts || !a->d_pre || !a->pts4 || !a->d_raw4 || !a->enc || !a->g_head || !a->partials) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
     const bool f32 = m->precision == NRNERF_PREC_F32;
@@ -1796,7 +1796,7 @@ namespace {
 int bender_common(const nrnerf_model* m, const nrnerf_bender_args* a, bool bwd, BendTrainArgs& t) {
     if (!m || !a || a->struct_size != sizeof(nrnerf_bender_args)) return NRNERF_ERR_INVALID;
     if (!m->bend_train_ok) return NRNERF_ERR_UNSUPPORTED;
-    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256) return NRNERF_ERR_INVALID;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NRNERF_MAX_SAMPLES) return NRNERF_ERR_INVALID;
     if (!a->rays || a->ray_stride < 6 || !a->latents || a->latent_stride < m->latent_size || !a->z) return NRNERF_ERR_INVALID;
     if (!a->bent4 || !a->off4 || !a->acts_offsets || !a->acts_rigidity) return NRNERF_ERR_INVALID;
     if (bwd && (!a->g_bent4 || !a->dz_offsets || !a->dz_rigidity || !a->dz_out4 || !a->d_latents)) return NRNERF_ERR_INVALID;
@@ -1843,7 +1843,7 @@ int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, v
 int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a, void* hip_stream) try {
     if (!m || !a || a->struct_size != sizeof(nrnerf_bender_wgrad_args)) return NRNERF_ERR_INVALID;
     if (!m->bend_train_ok) return NRNERF_ERR_UNSUPPORTED;
-    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > 256 || a->n_partials < 4 || a->n_partials > 4096 || a->n_partials % 4) return NRNERF_ERR_INVALID;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NRNERF_MAX_SAMPLES || a->n_partials < 4 || a->n_partials > 4096 || a->n_partials % 4) return NRNERF_ERR_INVALID;
     if (!a->rays || a->ray_stride < 6 || !a->latents || a->latent_stride < m->latent_size || !a->z) return NRNERF_ERR_INVALID;
     if (!a->acts_offsets || !a->acts_rigidity || !a->dz_offsets || !a->dz_rigidity || !a->dz_out4 || !a->partials) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
@@ -1963,7 +1963,8 @@ int composite_device(const nrnerf_composite_args* a, int* dev) {
 int nrnerf_composite_forward(const nrnerf_composite_args* a, void* hip_stream) try {
     if (!a || a->struct_size != sizeof(nrnerf_composite_args)) return NRNERF_ERR_INVALID;
     if (a->n_rays < 0 || a->n_samples < 2 || a->n_importance < 0) return NRNERF_ERR_INVALID;
-    if (a->n_samples > 256 || a->n_samples + a->n_importance > 256) return NRNERF_ERR_UNSUPPORTED;
+    if (a->n_samples > NRNERF_MAX_SAMPLES || a->n_samples + a->n_importance > NRNERF_MAX_SAMPLES) return NRNERF_ERR_UNSUPPORTED;
+    if (a->rank_new && a->n_samples + a->n_importance > 256) return NRNERF_ERR_UNSUPPORTED;       // 8-bit ranks (the split fine bender)
     if (a->n_rays == 0) return NRNERF_OK;
     if (!a->rays || a->ray_stride < 8 || !a->raw4 || !a->rgb || !a->disp || !a->acc) return NRNERF_ERR_INVALID;
     if (a->n_importance > 0 && !a->z_merged) return NRNERF_ERR_INVALID;
@@ -1984,7 +1985,7 @@ int nrnerf_composite_forward(const nrnerf_composite_args* a, void* hip_stream) t
 
 int nrnerf_composite_backward(const nrnerf_composite_args* a, void* hip_stream) try {
     if (!a || a->struct_size != sizeof(nrnerf_composite_args)) return NRNERF_ERR_INVALID;
-    if (a->n_rays < 0 || a->n_samples < 2 || a->n_samples > 256) return NRNERF_ERR_INVALID;
+    if (a->n_rays < 0 || a->n_samples < 2 || a->n_samples > NRNERF_MAX_SAMPLES) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
     if (!a->rays || a->ray_stride < 8 || !a->raw4 || !a->g_rgb || !a->d_raw4) return NRNERF_ERR_INVALID;
     int dev = 0;

@@ -18,11 +18,10 @@ namespace nrn {
 
 static constexpr int RAYS_PER_WG = 4;
 // Samples per ray and pass: a lane owns EPL <= 16 consecutive samples, so S and S + I go up to 1024 (the reference has no cap,
-// train.py:1090-1094; its configs use 64 + 64 / 64 + 128).  The training kernels below, the split-bender path (8-bit ranks)
-// and the fused compositing of the network kernels stay at 256 (MAXS_TRAIN): beyond it a render takes the fused-bender
-// fine pass and this kernel, a training call the reference's own function.
+// train.py:1090-1094; its configs use 64 + 64 / 64 + 128), forward and backward.  The split-bender paths (8-bit ranks of the new
+// samples among the merged depths) and the fused compositing of the network kernels stay at 256: beyond it a render takes the
+// fused-bender fine pass and this kernel, a training pass bends all merged samples again.
 static constexpr int MAXS = 1024;
-static constexpr int MAXS_TRAIN = 256;
 
 template <int EPL, bool SAMPLE>
 __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const CompositeArgs a) {
@@ -262,14 +261,17 @@ static hipError_t launch_bwd_epl(const CompositeBwdArgs& a, hipStream_t stream) 
     return hipGetLastError();
 }
 hipError_t launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t stream) {
-    if (a.S < 2 || a.S > MAXS_TRAIN) return hipErrorInvalidValue;
+    if (a.S < 2 || a.S > MAXS) return hipErrorInvalidValue;
     switch ((a.S + 63) / 64) {
         case 1: return launch_bwd_epl<1>(a, stream);
         case 2: return launch_bwd_epl<2>(a, stream);
         case 3: return launch_bwd_epl<3>(a, stream);
         case 4: return launch_bwd_epl<4>(a, stream);
+        case 5: case 6: return launch_bwd_epl<6>(a, stream);
+        case 7: case 8: return launch_bwd_epl<8>(a, stream);
+        case 9: case 10: case 11: case 12: return launch_bwd_epl<12>(a, stream);
+        default: return launch_bwd_epl<16>(a, stream);
     }
-    return hipErrorInvalidValue;
 }
 
 template <int EPL>

@@ -532,7 +532,8 @@ class _Composite(torch.autograd.Function):
         a.rgb, a.disp, a.acc, a.weights, a.alpha = rgb.data_ptr(), disp.data_ptr(), acc.data_ptr(), weights.data_ptr(), alpha.data_ptr()
         if I > 0:
             a.z_std, a.z_merged = z_std.data_ptr(), z_merged.data_ptr()
-            a.z_new, a.rank_new = z_new.data_ptr(), rank_new.data_ptr()
+            if S + I <= SPLIT_MAX_SAMPLES:          # (8-bit ranks: beyond that the fine pass bends all merged samples again)
+                a.z_new, a.rank_new = z_new.data_ptr(), rank_new.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(_lib.load().nrnerf_composite_forward(C.byref(a), _stream(dev)), "nrnerf_composite_forward")
         ctx.white_bkgd = bool(white_bkgd)
@@ -701,6 +702,7 @@ def bend_native(model, rb, rays, z, latents, details=True):
 # True: the fine pass bends only its N_importance new samples and re-uses the coarse pass' bent points (render_rays_train);
 # False: it bends all S + I merged samples again, as the reference's graph does (same values, a third more bender work).
 SPLIT_FINE_BENDER = True
+SPLIT_MAX_SAMPLES = 256         # merged samples per ray up to which it applies (the new samples' ranks are 8-bit: include/nrnerf.h)
 
 
 def _pack4(xyz: torch.Tensor, w, M: int) -> torch.Tensor:
@@ -1001,8 +1003,8 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
                 return "use_viewdirs without view directions in the ray batch"
         if int(net.D) != 8 or int(net.W) not in (256, 128) or list(net.skips) != [4] or int(net.input_ch) != 63:
             return "non-default trunk under autograd"
-    if N_samples < 2 or N_samples + N_importance > 256:
-        return "more than 256 samples per ray"
+    if N_samples < 2 or N_samples + N_importance > _lib.MAX_SAMPLES:
+        return f"more than {_lib.MAX_SAMPLES} samples per ray"
     if R.get_precision() == "f16":
         return None            # trains in bf16 (see module docstring)
     return None
@@ -1120,7 +1122,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         rgb0, disp0, acc0, weights0, alpha0 = rgb_map, disp_map, acc_map, weights, alpha     # :902-908
         net_f = network_fine if network_fine is not None else network_fn                     # :925
         fine_parts = None
-        if rb is not None and SPLIT_FINE_BENDER:
+        if rb is not None and SPLIT_FINE_BENDER and S + I <= SPLIT_MAX_SAMPLES:
             # The bender is shared by both networks (rnh:213-215) and the coarse depths are a subset of the merged depths
             # (:920): bend only the I new samples and put every sample's point / bent point / details at its row among the
             # merged depths (as nrnerf_render's split-bender path).  Same values as bending all S + I points again; the

@@ -175,10 +175,12 @@ def _loss(out, detailed):
                                                            (1.0, 0.0, False, dict(N_samples=48, N_importance=37, ray_bending=False, time_conditioned_baseline=True,
                                                                                    use_viewdirs=True)),
                                                            (1.0, 1.0, True, dict(N_samples=48, N_importance=37, use_viewdirs=True, approx_nonrigid_viewdirs=False)),
-                                                           (0.0, 0.0, False, dict(N_importance=64, use_viewdirs=True, approx_nonrigid_viewdirs=False, bend_depth=7))],
+                                                           (0.0, 0.0, False, dict(N_importance=64, use_viewdirs=True, approx_nonrigid_viewdirs=False, bend_depth=7)),
+                                                           (1.0, 1.0, True, dict(N_samples=200, N_importance=150))],
                          ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128", "lindisp_white_bkgd",
                               "viewdirs_detailed_ragged", "viewdirs_no_bender", "config4_viewdirs_deep_bender", "time_conditioned_ragged",
-                              "time_conditioned_viewdirs", "exact_viewdirs_detailed_ragged", "exact_viewdirs_deep_bender"])
+                              "time_conditioned_viewdirs", "exact_viewdirs_detailed_ragged", "exact_viewdirs_deep_bender",
+                              "350_samples_per_ray"])
 @pytest.mark.parametrize("bender", ["torch_ops", "native"])
 def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, bender):
     """Every parameter of every network + the latent codes, fp32 mode, against the oracle's autograd (eager torch on the

@@ -94,7 +94,8 @@ def test_eligibility_of_training_calls():
     assert "without view directions" in T.why_not_trainable(cn, fn, 64, 64, False, False, OnGpu8)
     assert T.why_not_trainable(coarse, fine, 64, 64, True, False, OnGpu) is None                  # lindisp trains natively
     assert T.why_not_trainable(coarse, fine, 64, 64, False, True, OnGpu).startswith("pytest flag")
-    assert T.why_not_trainable(coarse, fine, 200, 100, False, False, OnGpu) == "more than 256 samples per ray"
+    assert T.why_not_trainable(coarse, fine, 200, 100, False, False, OnGpu) is None               # up to 1024 samples per pass
+    assert T.why_not_trainable(coarse, fine, 600, 500, False, False, OnGpu) == "more than 1024 samples per ray"
     assert T.why_not_trainable(coarse, fine, 64, 64, False, False, OnGpu) is None
     cfgw = SceneConfig(N_importance=64, netwidth=128)
     _, cw, fw = build_modules(make_scene(cfgw, 0))
