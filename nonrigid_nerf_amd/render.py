@@ -37,6 +37,23 @@ from . import _lib
 _DEFAULT_PRECISION = _lib.canonical_precision(os.environ.get("NRNERF_PRECISION", "bf16"))
 _SCAN_OUTPUTS = os.environ.get("NRNERF_SCAN_OUTPUTS") == "1"
 _fallbacks = {}          # {"render_rays": fn, "batchify_rays": fn} saved by install()
+
+
+class FallbackWarning(UserWarning):
+    """A call was handed to the reference's own function saved by install() (it runs, but not on the HIP path)."""
+
+
+_fallback_seen = set()
+
+
+def _note_fallback(entry: str, why: str):
+    """Say ONCE per (entry point, reason) that a call went to the reference -- a training run that silently takes the eager path
+    is ten times slower than it needs to be and nothing else would tell.  NRNERF_QUIET_FALLBACK=1 silences it."""
+    if (entry, why) in _fallback_seen or os.environ.get("NRNERF_QUIET_FALLBACK") == "1":
+        return
+    _fallback_seen.add((entry, why))
+    import warnings
+    warnings.warn(f"nonrigid_nerf_amd: {entry} handed to the reference's own function ({why})", FallbackWarning, stacklevel=3)
 _MAX_RAYS_PER_LAUNCH = 1 << 20
 
 
@@ -672,6 +689,7 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
         ref = _fallbacks.get("render_rays")
         if ref is None:
             raise Unsupported(f"no HIP kernel for this call ({why}) and no reference function installed to defer to")
+        _note_fallback("render_rays", why)
         return ref(ray_batch, network_fn, network_query_fn, N_samples, retraw=retraw, lindisp=lindisp,
                    perturb=perturb, N_importance=N_importance, network_fine=network_fine, white_bkgd=white_bkgd,
                    raw_noise_std=raw_noise_std, additional_pixel_information=additional_pixel_information,
@@ -813,6 +831,7 @@ def batchify_rays(rays_flat, additional_pixel_information, chunk=1024 * 32, deta
         ref = _fallbacks.get("batchify_rays")
         if ref is None:
             raise Unsupported(f"no HIP kernel for this call ({why}) and no reference function installed to defer to")
+        _note_fallback("batchify_rays", why)
         return ref(rays_flat, additional_pixel_information, chunk=chunk, detailed_output=detailed_output, **kwargs)
     n = rays_flat.shape[0]
     step = max(int(chunk), _MAX_RAYS_PER_LAUNCH)

@@ -950,6 +950,7 @@ def compute_divergence_loss(offsets_of_inputs, input_points, point_latents, ray_
         ref = R._fallbacks.get("compute_divergence_loss")
         if ref is None:
             raise R.Unsupported(f"no HIP kernel for this divergence call ({why}) and no reference function installed to defer to")
+        R._note_fallback("compute_divergence_loss", why)
         return ref(offsets_of_inputs, input_points, point_latents, ray_bender, exact, chunk, N_rays, weights=weights,
                    backprop_into_weights=backprop_into_weights)
     input_points.requires_grad = True                                                        # rnh:39 (kept: callers may look at it)

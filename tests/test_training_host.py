@@ -1,5 +1,7 @@
 """Host-side pieces of the training path (nonrigid_nerf_amd/training.py) that need no GPU: eligibility, the row-block
 arithmetic of the batched weight-gradient GEMMs, and the autograd-side bender against the oracle's."""
+import os
+
 import pytest
 import torch
 
@@ -302,6 +304,41 @@ def test_fingerprint_counts_optimiser_steps_for_trainable_networks_only():
     with torch.no_grad():
         frozen.weight.mul_(2.0)
     assert R._fingerprint([frozen]) != fp_f
+
+
+def test_a_fallback_to_the_reference_is_announced_once_per_reason():
+    """A call the HIP path cannot take runs on the reference's own function saved by install() -- and says so ONCE per (entry
+    point, reason) with a FallbackWarning: a training run that silently takes the eager path is ten times slower than it
+    needs to be.  NRNERF_QUIET_FALLBACK=1 silences it."""
+    import types
+    import warnings
+    from nonrigid_nerf_amd import render as R
+    cfg = SceneConfig(N_importance=0)
+    _, coarse, _ = build_modules(make_scene(cfg, 0))
+    rays, lat = make_rays(4, 0, cfg)
+    seen = []
+    mod = types.SimpleNamespace(render_rays=lambda *a, **k: seen.append("rr") or {"rgb_map": torch.zeros(4, 3)},
+                                batchify_rays=lambda *a, **k: seen.append("br") or {"rgb_map": torch.zeros(4, 3)})
+    undo = R.install(mod)
+    R._fallback_seen.clear()
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for _ in range(3):                                   # CPU rays: "rays are not on a ROCm device"
+                with torch.no_grad():
+                    mod.batchify_rays(rays, {"ray_bending_latents": lat}, network_fn=coarse, network_query_fn=None, N_samples=64)
+            notes = [x for x in w if issubclass(x.category, R.FallbackWarning)]
+        assert seen == ["br"] * 3 and len(notes) == 1 and "not on a ROCm device" in str(notes[0].message)
+        os.environ["NRNERF_QUIET_FALLBACK"] = "1"
+        R._fallback_seen.clear()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with torch.no_grad():
+                mod.batchify_rays(rays, {"ray_bending_latents": lat}, network_fn=coarse, network_query_fn=None, N_samples=64)
+            assert not [x for x in w if issubclass(x.category, R.FallbackWarning)]
+    finally:
+        os.environ.pop("NRNERF_QUIET_FALLBACK", None)
+        undo()
 
 
 def test_install_restores_the_previous_precision_on_uninstall():
