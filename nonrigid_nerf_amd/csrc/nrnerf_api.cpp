@@ -235,6 +235,79 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
     if (written != (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
 }
 
+// The trunk-only image of the 16x16x32 kernel (nrnerf_net_x16.h, PlanX16): fragment (tile t, k-step s) holds, for lane (r = lane & 15,
+// g = lane >> 4) and element e < 8,  W[x16_out_row(t, r)][x16_in_col(s, g, e)]; encoding k-steps f16, hidden ones the model's type;
+// bias table [tile][16 rows].
+template <class SH, class A>
+void pack_pass_x16(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr) {
+    using PL = PlanX16<SH, A>;
+    const Tables& T = PL::TB;
+    out.ntiles = T.ntiles; out.nunits = T.nunits_padded;
+    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES; out.mfma_per_block = T.mfma_per_block;
+    out.stream.assign((size_t)T.nunits_padded * SH::UNIT_BYTES, 0);
+    out.unit_off.assign(T.nunits_padded + 1, 0);
+    for (int u = 0; u <= T.nunits_padded; ++u) out.unit_off[u] = (uint32_t)((size_t)u * SH::UNIT_BYTES / 16);
+    out.bias.assign((size_t)T.ntiles * 16, 0.0f);
+    if (lay) {
+        out.src.assign(out.stream.size() / 2, -1);
+        out.fmt.assign(out.stream.size() / 2, 1);
+        out.bias_src.assign(out.bias.size(), -1);
+    }
+    size_t written = 0;
+    for (int l = 0; l < T.nlayers; ++l) {
+        const LayerSpec& sp = T.layers[l];
+        const nrnerf_linear* lin = (sp.kind == LK_HEAD) ? &mlp.output_linear : &mlp.pts_linears[sp.index];
+        const int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
+        for (int t = 0; t < sp.nt; ++t) {
+            const TileInfo& ti = T.tiles[sp.tile0 + t];
+            for (int s = 0; s < sp.ns; ++s) {
+                const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride;
+                if (fi >= (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
+                uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
+                const bool enc_step = (sp.kind == LK_TR_IN || sp.kind == LK_TR_SKIP) && s < PL::NS_E;
+                const bool as_f16 = precision == NRNERF_PREC_F16 || enc_step;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 15, g = lane >> 4;
+                    const int row = x16_out_row<A>(sp.kind, t, r, lin->out_features);
+                    for (int e = 0; e < 8; ++e) {
+                        const int col = x16_in_col<A>(sp.kind, s, g, e, lin->in_features);
+                        const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
+                        const size_t el = fi * (SH::FRAG_BYTES / 2) + (size_t)lane * 8 + e;
+                        if (lay) {
+                            out.src[el] = (row < 0 || col < 0 || wbase < 0) ? -1 : (int32_t)(wbase + (int64_t)row * lin->in_features + col);
+                            out.fmt[el] = as_f16 ? 2 : 1;
+                        }
+                        const uint16_t q = as_f16 ? f32_to_f16(w) : f32_to_bf16(w);
+                        std::memcpy(fr + (lane * 8 + e) * 2, &q, 2);
+                    }
+                }
+                ++written;
+            }
+            for (int r = 0; r < 16; ++r) {
+                const int row = x16_out_row<A>(sp.kind, t, r, lin->out_features);
+                out.bias[(size_t)(sp.tile0 + t) * 16 + r] = (row >= 0 && lin->bias) ? lin->bias[row] : 0.0f;
+                if (lay && row >= 0 && bbase >= 0) out.bias_src[(size_t)(sp.tile0 + t) * 16 + r] = (int32_t)(bbase + row);
+            }
+        }
+    }
+    if (written != (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
+}
+// does the 16x16x32 trunk kernel have this network?  (compiled architecture 0's trunk, output_linear head, 16-bit precision)
+bool x16_eligible(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, bool any_16bit = false) {
+    using A = ArchDefault;
+    // (bf16 mode only for now: "f16" is the mode whose split path is held bit-identical to the fused-bender fine pass -- the same
+    //  32x32x16 products on both sides -- by tests/test_gpu_parity.py; NRNERF_X16_F16=1 lifts that for experiments)
+    static const bool f16_too = [] { const char* e = std::getenv("NRNERF_X16_F16"); return e && std::atoi(e) != 0; }();
+    if (d.precision != NRNERF_PREC_BF16 && !(d.precision == NRNERF_PREC_F16 && (f16_too || any_16bit))) return false;
+    if (m.use_viewdirs || m.time_conditioned || d.multires != A::L || m.depth != A::D || m.width != A::W || m.skip != A::SKIP) return false;
+    if (m.output_ch != 4 && m.output_ch != 5) return false;
+    return true;
+}
+void pack_x16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, const FlatLayout* lay = nullptr) {
+    if (d.precision == NRNERF_PREC_F16) pack_pass_x16<Shape16, ArchDefault>(m, d.precision, out, lay);
+    else pack_pass_x16<Shape16Fast, ArchDefault>(m, d.precision, out, lay);
+}
+
 // Transposed weights for the backward-data kernel (nrnerf_train.h): PlanB's layer list, fragment element
 // (tile t, row i, slab s, half h, element e) = W[y][x] with (y, x) from bwd_y / bwd_x.  No biases.
 // VIEWS (view-dependent head, rnh:284-304): rgb_linear^T, then the layer that joins both branches of the head -- its k index
@@ -710,6 +783,9 @@ struct nrnerf_model {
     // come from the stand-alone bender kernel) and the bender + rigidity layers alone
     PassDev fine_trunk, coarse_trunk, bend_only;
     bool split_ok = false;
+    // the fine network's trunk once more, packed for the 16x16x32 kernel (nrnerf_net_x16.h): what the split-bender path's fine pass
+    // runs when the call asks for no detail outputs
+    PassDev fine_trunk_x16;
     // training (nrnerf_train.h): transposed trunk weights of both networks; train_ok: see training_eligible, fp32 or bf16
     PassDev coarse_bwd, fine_bwd;
     bool train_ok = false;
@@ -1042,6 +1118,11 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
             if (bender_arch(arch_id) == 0) pack_pass_bwd_bender<ArchDefault>(*desc->bender, pk);
             else pack_pass_bwd_bender<ArchDeepBend>(*desc->bender, pk);
         }
+    } else if (which == 10) {                    // the fine network's trunk packed for the 16x16x32 kernel (nrnerf_net_x16.h)
+        const nrnerf_mlp_desc* mm = desc->fine ? desc->fine : desc->coarse;
+        if (!x16_eligible(*desc, *mm, /*any_16bit=*/true)) return NRNERF_ERR_UNSUPPORTED;
+        rc = NRNERF_OK;
+        pack_x16(*desc, *mm, pk);
     } else if (which >= 7 && which <= 9) {      // layer programs of the run-time-parameterised kernel: 7 = coarse, 8 = fine, 9 = ray bender
         GenProgram gb, gc, gf;
         rc = gen_pack_all(*desc, nullptr, gb, gc, gf);
@@ -1152,6 +1233,15 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) try {
             m->bend_only.algo_flops_per_sample = m->fine.algo_flops_per_sample - m->fine_trunk.algo_flops_per_sample;
             m->bend_only.mfma_flops_per_sample = pb.mfma_per_block * mfma_flop / 32.0;
             m->split_ok = (rc == NRNERF_OK);
+            const nrnerf_mlp_desc& fm = desc->fine ? *desc->fine : *desc->coarse;
+            if (rc == NRNERF_OK && x16_eligible(*desc, fm)) {
+                PackedPass px;
+                pack_x16(*desc, fm, px, &lay);
+                rc = upload_pass(px, m->fine_trunk_x16);
+                m->fine_trunk_x16.algo_flops_per_sample = m->fine_trunk.algo_flops_per_sample;
+                m->fine_trunk_x16.mfma_flops_per_sample = px.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
+                m->fine_trunk_x16.output_ch = m->fine.output_ch;
+            }
         }
     }
     if (rc == NRNERF_OK) rc = upload_training(*desc, m, nullptr, false, &lay);
@@ -1189,6 +1279,11 @@ int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hi
         if (rc == NRNERF_OK) rc = refresh_pass(pb, m->bend_only, stream);
         if (rc == NRNERF_OK) rc = refresh_pass(pct, m->coarse_trunk, stream);
     }
+    PackedPass px;
+    if (rc == NRNERF_OK && m->fine_trunk_x16.stream) {
+        pack_x16(*desc, desc->fine ? *desc->fine : *desc->coarse, px);
+        rc = refresh_pass(px, m->fine_trunk_x16, stream);
+    }
     // the packed host images die with this call: wait until the copies have consumed them
     if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;
     if (rc == NRNERF_OK && m->train_ok) rc = upload_training(*desc, m, stream, /*refresh=*/true);
@@ -1204,7 +1299,7 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     hipStream_t stream = (hipStream_t)hip_stream;
-    PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only,
+    PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16,
                          &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
                          &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine};
     for (PassDev* p : passes)
@@ -1240,6 +1335,7 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     if (!m->fine_is_coarse) free_pass(m->fine);
     free_pass(m->coarse);
     free_pass(m->fine_trunk);
+    free_pass(m->fine_trunk_x16);
     free_pass(m->coarse_trunk);
     free_pass(m->bend_only);
     free_pass(m->coarse_bwd);
@@ -1533,7 +1629,11 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
     // K3 inside K2 (see final_composite above) whenever K2 is a kernel without a fused bender
-    const bool fuse_fine = (split || !m->has_bend) && !unfused_composite && SF <= 256 && enough_rays_to_fuse(SF);
+    // the split path's trunk-only pass on the 16x16x32 kernel (nrnerf_net_x16.h) when the call wants no detail outputs; its compositing
+    // is a launch of its own (NRNERF_X16=0: the 32x32x16 kernel with the compositing fused in)
+    static const bool x16_on = [] { const char* e = std::getenv("NRNERF_X16"); return !e || std::atoi(e) != 0; }();
+    const bool x16 = split && x16_on && m->fine_trunk_x16.stream && !a->detailed_output && !kn.detailed;
+    const bool fuse_fine = !x16 && (split || !m->has_bend) && !unfused_composite && SF <= 256 && enough_rays_to_fuse(SF);
     if (fuse_fine) { nf.fuse_on = 1; nf.fuse = final_composite(SF, z_fine, a->noise_fine, a->fine, nullptr); nf.raw4 = nullptr; }
     if (split) {
         // KB: only the I importance samples go through the bender; the coarse samples' bent points are already in place
@@ -1548,9 +1648,15 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         if (e != hipSuccess) return NRNERF_ERR_HIP;
         // K2: trunk + head on ready-made points (compiled architecture 0 without bender)
         nf.pts4 = bent4; nf.bent4 = nullptr;
-        nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
-        e = timed(2, (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,
-                  [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), nf, m->num_cus, stream); });
+        if (x16) {
+            nf.wstream = m->fine_trunk_x16.stream; nf.bias = m->fine_trunk_x16.bias;
+            e = timed(2, (double)N * SF * m->fine_trunk_x16.algo_flops_per_sample, (double)N * SF * m->fine_trunk_x16.mfma_flops_per_sample,
+                      [&] { return launch_net_x16(m->precision, nf, m->num_cus, stream); });
+        } else {
+            nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
+            e = timed(2, (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,
+                      [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), nf, m->num_cus, stream); });
+        }
     } else {
         nf.wstream = m->fine.stream; nf.bias = m->fine.bias;
         nf.bent4 = bent4;

@@ -456,6 +456,84 @@ constexpr NRN_HD int out_row(int kind, int t, int i, int out_features) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The trunk on v_mfma_f32_16x16x32_{bf16,f16} (nrnerf_net_x16.h): 16-row tiles, 32 k per MFMA.
+// ---------------------------------------------------------------------------------------
+// Under the socket's power cap the 16x16x32 shape sustains 10-18 % more flops than 32x32x16 (tools/probes/mfma_shape_power.hip:
+// the accumulator is a quarter the size; per 32 x 32 x 256 of work the register file sees 512 instead of 640 accesses).
+// Dataflow: a wave owns blocks of 16 consecutive samples; lane = (n = lane & 15: sample, g = lane >> 4: k group).  A fragment
+// (tile t, k-step s) holds W[16 t + (lane & 15)][k(s, g, e)], e < 8; the B operand holds act[k(s, g, e)][sample n]; the D tile
+// gives lane (n, g) the four features 16 t + 4 g + i of sample n.  TWO consecutive D tiles (features 32 s .. 32 s + 31) make the
+// B operand of k-step s of the next layer without leaving the lane: element e < 4 = feature 32 s + 4 g + e (tile 2 s), e >= 4 =
+// feature 32 s + 16 + 4 g + (e - 4) (tile 2 s + 1) -- the k order the packer gives the weights.
+// Encoding (K = 64 = two k-steps; Embedder's 3 + 6 L <= 63 columns): slot q = 8 s + e of group g holds, for q < 14 or g < 2,
+// the (sin, cos) pair number m = 4 (q / 2) + g of the list (frequency f = m / 3, coordinate c = m % 3), and the four spare slots
+// (q = 14, 15 of groups 2, 3, when L = 10) the identity columns x, y | z, 0: every group runs the same code.
+constexpr NRN_HD int x16_hidden_feature(int s, int g, int e) { return 32 * s + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4)); }
+constexpr NRN_HD int x16_enc_col(int L, int s, int g, int e) {       // reference column of encoding slot (s, g, e), -1: zero
+    const int q = 8 * s + e, m = 4 * (q / 2) + g;
+    if (m < 3 * L) return 3 + 6 * (m / 3) + 3 * (q & 1) + (m % 3);
+    // spare slots of this group, in order: the identity columns, two per group starting at group 2 (L = 10: exactly q = 14, 15)
+    int spare = 0;
+    for (int qq = 0; qq < q; ++qq) spare += (4 * (qq / 2) + g >= 3 * L) ? 1 : 0;
+    int before = 0;                                                    // spare slots of lower groups
+    for (int gg = 0; gg < g; ++gg)
+        for (int qq = 0; qq < 16; ++qq) before += (4 * (qq / 2) + gg >= 3 * L) ? 1 : 0;
+    const int id = before + spare;
+    return id < 3 ? id : -1;
+}
+template <class SH, class A>
+constexpr Tables build_tables_x16() {
+    static_assert(SH::KH == 8, "16-bit operands");
+    constexpr int NT = A::W / 16, NS_H = A::W / 32, NS_E = 2;
+    static_assert(3 + 6 * A::L <= 64 && A::W % 32 == 0, "the encoding fills two k-steps");
+    Tables T{};
+    int nl = 0, tile0 = 0;
+    auto add = [&](int kind, int index, int ns, int nt) {
+        T.layers[nl] = LayerSpec{kind, index, ns, nt, tile0, 0};
+        tile0 += nt;
+        ++nl;
+    };
+    add(LK_TR_IN, 0, NS_E, NT);
+    for (int i = 1; i < A::D; ++i) {
+        if (i - 1 == A::SKIP) add(LK_TR_SKIP, i, NS_E + NS_H, NT);
+        else add(LK_TR_HID, i, NS_H, NT);
+    }
+    add(LK_HEAD, 0, NS_H, 1);
+    T.nlayers = nl;
+    T.ntiles = tile0;
+    place_fragments<SH>(T);
+    return T;
+}
+template <class SH, class A>
+struct PlanX16 {
+    static constexpr int NT = A::W / 16, NS_H = A::W / 32, NS_E = 2;
+    static constexpr Tables TB = build_tables_x16<SH, A>();
+    static constexpr int NLAYERS = TB.nlayers, NTILES = TB.ntiles, NFRAGS = TB.nfrags;
+    static constexpr int NUNITS = TB.nunits, NUP = TB.nunits_padded, UF = SH::UNIT_FRAGS;
+    static constexpr int MFMA_PER_BLOCK = TB.mfma_per_block;         // per 16-sample block
+    static_assert(TB.ntiles <= MAX_TILES && TB.nlayers <= MAX_LAYERS, "plan too large");
+    static constexpr int L_HEAD = NLAYERS - 1;
+};
+// reference element of fragment (layer kind, tile t, lane row r, k-step s, group g, element e): (row, column), -1 = zero
+template <class A>
+constexpr NRN_HD int x16_out_row(int kind, int t, int r, int out_features) {
+    if (kind == LK_HEAD) return r < out_features ? r : -1;           // channels 0..3 in group 0's four registers, channel 4 in group 1's first
+    return (16 * t + r < out_features) ? 16 * t + r : -1;
+}
+template <class A>
+constexpr NRN_HD int x16_in_col(int kind, int s, int g, int e, int in_features) {
+    constexpr int IN_CH = 3 + 6 * A::L;
+    if (kind == LK_TR_IN) return x16_enc_col(A::L, s, g, e);
+    if (kind == LK_TR_SKIP) {
+        if (s < 2) return x16_enc_col(A::L, s, g, e);
+        const int c = IN_CH + x16_hidden_feature(s - 2, g, e);
+        return c < in_features ? c : -1;
+    }
+    const int c = x16_hidden_feature(s, g, e);
+    return c < in_features ? c : -1;
+}
+
 using ArchDefault = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32>;      // arch id 0: the reference's shipped configuration
 using ArchDeepBend = ArchT<256, 8, 4, 10, 64, 7, 32, 3, 32>;     // arch id 1: deeper ray-bending MLP (BASELINE config 4)
 using ArchTimeCond = ArchT<256, 8, 4, 10, 64, 5, 32, 3, 32, 4, 1>;  // arch id 2: time-conditioned baseline (no bender)

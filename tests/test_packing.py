@@ -301,6 +301,118 @@ def test_packed_stream_reproduces_the_network(precision, bend, views, tcb, width
     assert (np.diff(units.astype(np.int64)) * 16 == info.slot_bytes).all()
 
 
+def _x16_enc_col(L, s, g, e):
+    """nrnerf_plan.h::x16_enc_col, restated: slot (k-step s, lane group g, element e) of the encoding -> reference column."""
+    q = 8 * s + e
+    m = 4 * (q // 2) + g
+    if m < 3 * L:
+        return 3 + 6 * (m // 3) + 3 * (q & 1) + (m % 3)
+    spare = sum(1 for qq in range(q) if 4 * (qq // 2) + g >= 3 * L)
+    before = sum(1 for gg in range(g) for qq in range(16) if 4 * (qq // 2) + gg >= 3 * L)
+    return before + spare if before + spare < 3 else -1
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_x16_stream_reproduces_the_trunk(precision):
+    """The trunk-only image of the 16x16x32 kernel (csrc/nrnerf_net_x16.h, PlanX16; nrnerf_pack_host which = 10), emulated in
+    numpy as the kernel consumes it: a fragment is W[16 rows][32 k] with lane (r, g) holding k positions 8 g .. 8 g + 7; the B
+    operand of k-step s holds, at position 8 g + e, input column x16_in_col(s, g, e) -- for the encoding the slot layout of
+    x16_enc_col (every one of the 63 columns exactly once), for hidden layers features 32 s + 4 g + e (e < 4, D tile 2 s) and
+    32 s + 16 + 4 g + (e - 4) (D tile 2 s + 1): what a lane holds after two consecutive 16-row tiles; tiles in pairs with their
+    k-steps interleaved, the head alone.  Must reproduce the fp64 network up to the operand rounding."""
+    cfg = SceneConfig(N_importance=128)
+    scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=10)
+    assert info.frag_bytes == 1024
+    rnd, rnd_e = rounder(precision), rounder("f16")
+    u16 = stream.view(np.uint16)
+    as_bf16 = (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    as_f16 = stream.view(np.float16).astype(np.float64)
+    pos = [0]
+
+    def next_A(f16):
+        vals = as_f16 if (f16 or precision == "f16") else as_bf16
+        f = vals[pos[0] * 512:(pos[0] + 1) * 512].reshape(64, 8)
+        pos[0] += 1
+        A = np.zeros((16, 32))
+        for lane in range(64):
+            A[lane & 15, 8 * (lane >> 4):8 * (lane >> 4) + 8] = f[lane]
+        return A
+
+    def dense(tile0, ns, nt, B, n_f16):
+        """B: [ns][32 positions][samples] -> nt D tiles [16][samples]"""
+        def bias_of(t):
+            return np.repeat(bias[(tile0 + t) * 16:(tile0 + t) * 16 + 16].astype(np.float64)[:, None], B[0].shape[1], 1)
+        out = [None] * nt
+        for p_ in range(0, nt - 1, 2):
+            D0, D1 = bias_of(p_), bias_of(p_ + 1)
+            for s_ in range(ns):
+                D0 = D0 + next_A(s_ < n_f16) @ B[s_]
+                D1 = D1 + next_A(s_ < n_f16) @ B[s_]
+            out[p_], out[p_ + 1] = D0, D1
+        if nt & 1:
+            D = bias_of(nt - 1)
+            for s_ in range(ns):
+                D = D + next_A(s_ < n_f16) @ B[s_]
+            out[nt - 1] = D
+        return out
+
+    def hand_off(tiles):
+        """16 D tiles -> 8 B operands: position 8 g + e = relu(feature 32 s + 4 g + e | 32 s + 16 + 4 g + e - 4), rounded"""
+        B = []
+        for s_ in range(len(tiles) // 2):
+            b = np.zeros((32, tiles[0].shape[1]))
+            for g in range(4):
+                for e in range(8):
+                    b[8 * g + e] = tiles[2 * s_][4 * g + e] if e < 4 else tiles[2 * s_ + 1][4 * g + e - 4]
+            B.append(rnd(np.maximum(b, 0.0)))
+        return B
+
+    gen = torch.Generator().manual_seed(6)
+    ns_ = 24
+    p = (torch.randn(ns_, 3, generator=gen) * 0.4).double()
+    cols = [p]
+    for k in range(10):
+        cols += [torch.sin(p * 2.0 ** k), torch.cos(p * 2.0 ** k)]
+    x = torch.cat(cols, -1)                                                   # [ns, 63], reference column order
+    xn = x.numpy()
+    seen = sorted(c for s_ in range(2) for g in range(4) for e in range(8) if (c := _x16_enc_col(10, s_, g, e)) >= 0)
+    assert seen == list(range(63)), "every encoding column sits in exactly one slot"
+    Benc = []
+    for s_ in range(2):
+        b = np.zeros((32, ns_))
+        for g in range(4):
+            for e in range(8):
+                c = _x16_enc_col(10, s_, g, e)
+                if c >= 0:
+                    b[8 * g + e] = xn[:, c]
+        Benc.append(rnd_e(b))
+    NT = 16
+    tile0, mfma = 0, 0
+    tiles = dense(tile0, 2, NT, Benc, 2); tile0 += NT; mfma += 2 * NT
+    for i in range(1, 8):
+        B = hand_off(tiles)
+        n16 = 0
+        if i - 1 == 4:
+            B, n16 = Benc + B, 2
+        tiles = dense(tile0, len(B), NT, B, n16); tile0 += NT; mfma += len(B) * NT
+    B = hand_off(tiles)
+    D = dense(tile0, len(B), 1, B, 0)[0]; tile0 += 1; mfma += len(B)
+    raw = D[0:5].T                                                           # channels 0..3: group 0's registers, channel 4: group 1's first
+    assert tile0 == info.n_bias_tiles and mfma == info.mfma_per_block
+    used = pos[0] * 1024
+    assert used <= info.stream_bytes and not stream[used:].any(), "stream fully consumed"
+    with torch.no_grad():
+        h = x
+        for i, l in enumerate(fine.pts_linears):
+            h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
+            if i == 4:
+                h = torch.cat([x, h], -1)
+        ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
+    tol = 8e-2 if precision == "bf16" else 1e-2
+    err = np.abs(raw - ref).max()
+    assert err <= tol * np.abs(ref).max(), f"x16 trunk + head mismatch {err} vs scale {np.abs(ref).max()}"
+
+
 def test_unsupported_architectures_are_rejected():
     lib = _lib.load()
     for kw in (dict(netwidth=192), dict(netwidth=128, use_viewdirs=True), dict(netwidth=128, bend_depth=7), dict(netdepth=6), dict(multires=8), dict(bend_hidden=32), dict(latent_size=16),
