@@ -1629,11 +1629,17 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
     nf.ex = sample_out(a->fine);
     // K3 inside K2 (see final_composite above) whenever K2 is a kernel without a fused bender
-    // the split path's trunk-only pass on the 16x16x32 kernel (nrnerf_net_x16.h) when the call wants no detail outputs; its compositing
-    // is a launch of its own (NRNERF_X16=0: the 32x32x16 kernel with the compositing fused in)
-    static const bool x16_on = [] { const char* e = std::getenv("NRNERF_X16"); return !e || std::atoi(e) != 0; }();
+    // the split path's trunk-only pass on the 16x16x32 kernel (nrnerf_net_x16.h) when the call wants no detail outputs
+    // (NRNERF_X16=0: the 32x32x16 kernel of nrnerf_net_mb.h)
+    // (read per call, like NRNERF_UNFUSED_COMPOSITE: the parity tests run both kernels in one process)
+    const char* x16_env = std::getenv("NRNERF_X16");
+    const bool x16_on = !x16_env || std::atoi(x16_env) != 0;
     const bool x16 = split && x16_on && m->fine_trunk_x16.stream && !a->detailed_output && !kn.detailed;
-    const bool fuse_fine = !x16 && (split || !m->has_bend) && !unfused_composite && SF <= 256 && enough_rays_to_fuse(SF);
+    // (the 16x16x32 kernel's groups: 4 waves x the fewest rays whose 16-sample blocks fill whole iterations of 4 blocks)
+    const int bpr16 = (SF + 15) / 16;
+    const long long x16_group = 4LL * ((bpr16 % 4 == 0) ? 1 : ((bpr16 % 2 == 0) ? 2 : 4));
+    const bool fuse_fine = (split || !m->has_bend) && !unfused_composite && SF <= 256 &&
+                           (x16 ? (long long)N >= x16_group * m->num_cus : enough_rays_to_fuse(SF));
     if (fuse_fine) { nf.fuse_on = 1; nf.fuse = final_composite(SF, z_fine, a->noise_fine, a->fine, nullptr); nf.raw4 = nullptr; }
     if (split) {
         // KB: only the I importance samples go through the bender; the coarse samples' bent points are already in place

@@ -30,6 +30,12 @@ __device__ __forceinline__ float c_lin01(int i, int n) {     // torch.linspace(0
     return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
 }
 
+// The arguments' pointers are device-memory pointers.  Saying so matters where the argument block was copied to LDS (the fused
+// epilogues): read back from there a pointer is generic, its accesses become FLAT instructions -- which count in both memory
+// counters -- and hipcc's waits around them degrade to vmcnt(0), i.e. to waiting out the weight ring's LDS-DMA and earlier stores.
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T* gmem(T* p) { return (__attribute__((address_space(1))) T*)p; }
+
 // a value the optimiser cannot look into: whatever produced it is rounded to fp32 here, nothing is fused across it
 __device__ __forceinline__ float rounded(float x) { asm("" : "+v"(x)); return x; }
 
@@ -53,14 +59,14 @@ __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
 // what composite_ray reads from HBM before it can start, requested early: out[0..2] = direction, out[3 + k] = depth of sample
 // lane * epl + k (k < epl <= 4; only when the pass has explicit depths)
 __device__ __forceinline__ void composite_prefetch(const CompositeArgs& a, const int ray, const int lane, const int epl, float (&out)[8]) {
-    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    const __attribute__((address_space(1))) float* rp = gmem(a.rays) + (size_t)ray * a.ray_stride;
     if (NRN_FUSE_PREFETCH == 0) return;
     out[0] = rp[3]; out[1] = rp[4]; out[2] = rp[5];
     if (a.z && NRN_FUSE_PREFETCH >= 2) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = lane * epl + k, ic = i < a.S ? i : a.S - 1;
-            if (k < epl) out[3 + k] = a.z[(size_t)ray * a.S + ic];
+            if (k < epl) out[3 + k] = gmem(a.z)[(size_t)ray * a.S + ic];
         }
     }
 }
@@ -69,9 +75,13 @@ __device__ __forceinline__ void composite_prefetch(const CompositeArgs& a, const
 // depth / visibility weight of sample lane*EPL + k (z[EPL]: the next lane's first depth), which sample_pdf goes on to use.
 // `pre` (optional): values the caller fetched ahead of time -- pre[0..2] = the ray's direction, pre[3 + k] = the depth of
 // sample lane*EPL + k when a.z is given (composite_prefetch below) -- so that a fused epilogue does not wait for HBM.
-template <int EPL, class RAWF>
+template <int EPL, bool FENCED = false, class RAWF>
 __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int ray, const bool ray_ok, const int lane,
                                               RAWF&& raw_at, float (&z)[EPL + 1], float (&w)[EPL], const float* pre = nullptr) {
+    // FENCED (the 16x16x32 kernel's epilogue, where a lone wave per SIMD runs this code with nothing to overlap it): scheduling fences
+    // between the phases.  Same instructions, same bits; measured with NRN_TIMING, the iteration that composites takes 12 000 cycles
+    // less with them (and with ONE instantiation in the kernel instead of four behind a switch) -- tools/experiments/README.md.
+    auto phase_fence = [] { if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0); };
     // No multiply-add fusion the source does not spell out (__fmaf_rn).  hipcc's `__fmul_rn` / `__fadd_rn` are plain * and +, this
     // build's -ffp-contract=fast fuses them wherever a product feeds a sum IN ONE BASIC BLOCK (pragmas are not honoured), and
     // which blocks an instantiation ends up with depends on everything around it: with the ray direction prefetched a tile ahead
@@ -79,7 +89,7 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int 
     // `dnorm`, hence of every alpha, on 1 % of the rays (tools/experiments/debug_fused_composite.py).  `rounded()` hides a product
     // from the optimiser, so it is rounded before it is added in every instantiation.
     const int S = a.S;
-    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    const __attribute__((address_space(1))) float* rp = gmem(a.rays) + (size_t)ray * a.ray_stride;
     if (NRN_FUSE_PREFETCH == 0) pre = nullptr;
     const float dx = pre ? pre[0] : rp[3], dy = pre ? pre[1] : rp[4], dz = pre ? pre[2] : rp[5];
     float near = 0.0f, far = 0.0f;
@@ -92,7 +102,7 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int 
     for (int k = 0; k < EPL; ++k) {
         const int i = lane * EPL + k;
         const int ic = i < S ? i : S - 1;
-        if (a.z) z[k] = (pre && NRN_FUSE_PREFETCH >= 2) ? pre[3 + k] : a.z[(size_t)ray * S + ic];
+        if (a.z) z[k] = (pre && NRN_FUSE_PREFETCH >= 2) ? pre[3 + k] : gmem(a.z)[(size_t)ray * S + ic];
         else {
             const float t = c_lin01(ic, S);
             if (a.lindisp)                                                               // train.py:850-852
@@ -103,9 +113,10 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int 
         }
         const f32x4 r = raw_at(ic);
         col[k][0] = r[0]; col[k][1] = r[1]; col[k][2] = r[2]; sig[k] = r[3];
-        if (a.noise) sig[k] = __fadd_rn(sig[k], a.noise[(size_t)ray * S + ic]);                // train.py:761
+        if (a.noise) sig[k] = __fadd_rn(sig[k], gmem(a.noise)[(size_t)ray * S + ic]);                // train.py:761
     }
     z[EPL] = __shfl_down(z[0], 1);     // first depth of the next lane
+    phase_fence();
 
     // ---- alpha, transmittance, weights (train.py:740-775)
     float alpha[EPL];
@@ -121,10 +132,12 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int 
         texcl[k] = run;
         run = __fmul_rn(run, (i < S) ? __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f) : 1.0f);
     }
+    phase_fence();
     const float incl = wave_scan_mul(run, lane);
     float before = __shfl_up(incl, 1);
     if (lane == 0) before = 1.0f;
     float sr = 0.f, sg = 0.f, sb = 0.f, sdepth = 0.f, sacc = 0.f;
+    phase_fence();
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
         const int i = lane * EPL + k;
@@ -135,23 +148,25 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int 
         sr = __fmaf_rn(w[k], r, sr); sg = __fmaf_rn(w[k], g, sg); sb = __fmaf_rn(w[k], b, sb);
         sdepth = __fmaf_rn(w[k], z[k], sdepth); sacc = __fadd_rn(sacc, w[k]);
         if (ray_ok && i < S) {
-            if (a.vis) a.vis[(size_t)ray * S + i] = w[k];
-            if (a.alpha) a.alpha[(size_t)ray * S + i] = alpha[k];
-            if (a.z_user) a.z_user[(size_t)ray * S + i] = z[k];
+            if (a.vis) gmem(a.vis)[(size_t)ray * S + i] = w[k];
+            if (a.alpha) gmem(a.alpha)[(size_t)ray * S + i] = alpha[k];
+            if (a.z_user) gmem(a.z_user)[(size_t)ray * S + i] = z[k];
         }
     }
+    phase_fence();
     sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sdepth = wave_sum(sdepth); sacc = wave_sum(sacc);
     if (ray_ok && lane == 0) {
         if (a.white_bkgd) {                                                                                   // :786-787
             const float bg = __fsub_rn(1.0f, sacc);
             sr = __fadd_rn(sr, bg); sg = __fadd_rn(sg, bg); sb = __fadd_rn(sb, bg);
         }
-        a.rgb[(size_t)ray * 3 + 0] = sr; a.rgb[(size_t)ray * 3 + 1] = sg; a.rgb[(size_t)ray * 3 + 2] = sb;   // :776
-        a.acc[ray] = sacc;                                                                                    // :779
+        gmem(a.rgb)[(size_t)ray * 3 + 0] = sr; gmem(a.rgb)[(size_t)ray * 3 + 1] = sg; gmem(a.rgb)[(size_t)ray * 3 + 2] = sb;   // :776
+        gmem(a.acc)[ray] = sacc;                                                                                    // :779
         const float q = __fdiv_rn(sdepth, sacc);                                  // 0/0 = NaN when acc == 0 ...
-        a.disp[ray] = __fdiv_rn(1.0f, (q != q) ? q : fmaxf(1e-10f, q));           // ... which torch.max propagates (:781-784)
+        gmem(a.disp)[ray] = __fdiv_rn(1.0f, (q != q) ? q : fmaxf(1e-10f, q));           // ... which torch.max propagates (:781-784)
     }
 
+    phase_fence();
     // ---- surface reduction: index of the sample whose accumulated visibility is closest to 0.5 (first one on ties),
     //      and the bent point / rigidity there (free_viewpoint_rendering.py:621-648 does this on the host from the
     //      full per-sample tensors: ~15 KB/ray of D2H traffic instead of 20 B/ray)
@@ -185,12 +200,13 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int 
         }
         if (ray_ok && lane == 0) {
             bidx = bidx < 0 ? 0 : (bidx > S - 1 ? S - 1 : bidx);
-            const f32x4 b = *(const f32x4*)(a.bent4 + ((size_t)ray * S + bidx) * 4);
-            if (a.surf_pts) { a.surf_pts[(size_t)ray * 3] = b[0]; a.surf_pts[(size_t)ray * 3 + 1] = b[1]; a.surf_pts[(size_t)ray * 3 + 2] = b[2]; }
-            if (a.surf_rig) a.surf_rig[ray] = b[3];
-            if (a.med_idx) a.med_idx[ray] = bidx;
+            const f32x4 b = *(const __attribute__((address_space(1))) f32x4*)(gmem(a.bent4) + ((size_t)ray * S + bidx) * 4);
+            if (a.surf_pts) { gmem(a.surf_pts)[(size_t)ray * 3] = b[0]; gmem(a.surf_pts)[(size_t)ray * 3 + 1] = b[1]; gmem(a.surf_pts)[(size_t)ray * 3 + 2] = b[2]; }
+            if (a.surf_rig) gmem(a.surf_rig)[ray] = b[3];
+            if (a.med_idx) gmem(a.med_idx)[ray] = bidx;
         }
     }
+    phase_fence();
 
 }
 

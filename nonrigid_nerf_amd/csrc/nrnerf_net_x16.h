@@ -44,6 +44,9 @@ __device__ __forceinline__ typename P::frag x16_pack(const f32x4& d0, const f32x
 #ifndef NRN_X16_NB
 #define NRN_X16_NB 4          // 16-sample blocks per wave
 #endif
+#ifndef NRN_X16_PF
+#define NRN_X16_PF 8          // weight fragments requested from LDS ahead of their MFMAs (4: 24.1 ms per fine pass, 6: 23.7, 8: 23.7)
+#endif
 
 // One dense layer.  Stream order (PlanX16 = place_fragments): tile pairs (2 p, 2 p + 1), their k-steps interleaved; an odd last tile
 // (the head) alone.  Per fragment NB MFMAs (one per block).  Two accumulator sets: pair p runs in set p & 1 while the epilogue of
@@ -54,42 +57,65 @@ __device__ __forceinline__ void dense_x16(ST& st, const __attribute__((address_s
                                           EPI&& epi) {
     constexpr LayerSpec spec = PL::TB.layers[LI];
     static_assert(spec.ns == NS0 + NS1, "k-step count mismatch between kernel and plan");
-    constexpr int NS = NS0 + NS1, NT = spec.nt, Q = NT * NS, PF = P1::PF;
+    constexpr int NS = NS0 + NS1, NT = spec.nt, Q = NT * NS, PF = NRN_X16_PF;
     using SQ = SeqPos<NT, NS>;
     constexpr int G0 = PL::TB.tiles[spec.tile0].gbase;
     typename P1::frag a[PF];
+    f32x4 bias[NT];               // (one name per tile: a bias is requested PF k-steps ahead, across tile pairs in the short layers)
+    const unsigned bias_addr = (unsigned)(size_t)bias_lane;
     auto load = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int s = SQ::slab(q);
+        // A tile's bias ([tile][16 rows]: this lane's rows 4 g .. 4 g + 3) travels in the same queue, right ahead of the tile's
+        // first fragment, and is covered by that fragment's counted wait (LDS operations retire in order).  Read with a plain
+        // load, hipcc -- which cannot see the fragment reads inside the asm statements -- waits for it with lgkmcnt(0) at every
+        // tile pair and drains the prefetch queue there (87 times per pass of the network).
+        if constexpr (s == 0) {
+            u32x4 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bias_addr), "n"((spec.tile0 + SQ::tile(q)) * 64));
+            bias[SQ::tile(q)] = __builtin_bit_cast(f32x4, v);
+        }
         if constexpr (s < NS0) a[q % PF] = __builtin_bit_cast(typename P1::frag, st.template frag<P0, G0 + q>());
         else a[q % PF] = st.template frag<P1, G0 + q>();
     };
+    // fragment q has landed -- and with it everything older in the queue (N: LDS operations younger than fragment q, at most)
+    auto ready = [&](auto qc, auto& f) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int F = (Q - 1 - q < PF - 1) ? Q - 1 - q : PF - 1;          // younger fragments ...
+        constexpr int N = F + [] { int nb = 0; for (int j = q + 1; j <= q + F; ++j) nb += SQ::slab(j) == 0; return nb; }();   // ... and biases
+        static_assert(ST::ASM_FRAGS && N >= 0 && N <= 15, "counted waits need the 16-byte asm fragment reads");
+        u32x4 v = __builtin_bit_cast(u32x4, f);
+        if constexpr (SQ::slab(q) == 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v), "+v"(bias[SQ::tile(q)]) : "n"(N));
+        else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+        f = __builtin_bit_cast(typename P1::frag, v);
+    };
     static_for<0, (PF < Q ? PF : Q)>([&](auto qc) { load(qc); });
     f32x4 acc[2][2][NB];          // [set][tile of the pair][block]
-    f32x4 bias[2];
+    // an accumulator as the epilogue sees it: through a volatile asm, which stays behind the counted LDS wait of the k-step it is
+    // written after -- left alone, hipcc hoists the conversions up to the accumulator's last MFMA and waits out its latency there
+    auto pinned = [](f32x4 v) { asm volatile("" : "+v"(v)); return v; };
     static_for<0, Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int t = SQ::tile(q), s = SQ::slab(q);
         constexpr int p = t >> 1, u = t & 1, set = p & 1;
-        if constexpr (s == 0) bias[u] = bias_lane[(spec.tile0 + t) * 4];         // [tile][16 rows]: this lane's rows 4 g .. 4 g + 3
-        st.template ready<(Q - 1 - q < PF - 1) ? Q - 1 - q : PF - 1>(a[q % PF]);
+        ready(qc, a[q % PF]);
         const typename P1::frag cur = a[q % PF];
         if constexpr (q + PF < Q) load(std::integral_constant<int, q + PF>{});
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            const f32x4 c = (s == 0) ? bias[u] : acc[set][u][b];
+            const f32x4 c = (s == 0) ? bias[t] : acc[set][u][b];
             if constexpr (s < NS0) acc[set][u][b] = X16<P0>::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[b][s], c);
             else acc[set][u][b] = X16<P1>::mfma(cur, in1[b][s - NS0], c);
         });
         // epilogue of the previous pair: block k after the second tile's MFMAs of k-step k
         if constexpr (p > 0 && u == 1 && s < NB) {
-            epi(std::integral_constant<int, p - 1>{}, std::integral_constant<int, s>{}, acc[set ^ 1][0][s], acc[set ^ 1][1][s]);
+            epi(std::integral_constant<int, p - 1>{}, std::integral_constant<int, s>{}, pinned(acc[set ^ 1][0][s]), pinned(acc[set ^ 1][1][s]));
         }
         // a layer with fewer k-steps than blocks (the encoding layer: 2): the rest of that epilogue at its last k-step
         if constexpr (p > 0 && u == 1 && s == NS - 1 && NS < NB) {
             static_for<NS, NB>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                epi(std::integral_constant<int, p - 1>{}, kc, acc[set ^ 1][0][k], acc[set ^ 1][1][k]);
+                epi(std::integral_constant<int, p - 1>{}, kc, pinned(acc[set ^ 1][0][k]), pinned(acc[set ^ 1][1][k]));
             });
         }
         if constexpr (q == Q - 1) {              // the last pair (or the lone head tile)
@@ -102,7 +128,11 @@ __device__ __forceinline__ void dense_x16(ST& st, const __attribute__((address_s
     });
 }
 
-template <class P, class A, int WAVES>
+// EPL: 0 = the raw outputs go to memory (NetArgs::raw4); 1..4 = the compositing is fused in (NetArgs::fuse_on) for passes of up to
+// 64 EPL samples per ray, a lane owning EPL of them (composite_ray<EPL>).  One kernel per case rather than a switch inside one: the loop
+// body is straight-line code several times the instruction cache, and the iteration that composites was measured 12 000 cycles
+// faster with a single compositing instantiation (and scheduling fences in it) than with four.
+template <class P, class A, int WAVES, int EPL>
 __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a) {
     using PL = PlanX16<P, A>;
     using PE = PolF16;                                                // the encoding's operands are f16 in both modes
@@ -128,7 +158,48 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     const int bpr = (S + 15) >> 4;
     const long long nblocks = (long long)a.n_rays * bpr;
     const long long per_wg = (long long)WAVES * NB;
-    for (long long b0 = (long long)blockIdx.x * per_wg; b0 < nblocks; b0 += (long long)gridDim.x * per_wg) {
+    // Fused compositing (NetArgs::fuse_on; as nrnerf_net_mb.h): a WAVE owns whole rays.  Its blocks come in groups of RW rays = RW * bpr
+    // blocks = TG iterations of NB blocks (RW: the fewest rays whose blocks fill whole iterations), groups strided over the grid; the raw
+    // outputs of a group are staged in the wave's own LDS area and after the group's last iteration the wave composites its RW rays
+    // itself (composite_ray): no exchange between waves, no barrier, the pass' raw array never reaches HBM.
+    constexpr bool fuse = EPL > 0;
+    const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
+    const int TG = RW * bpr / NB;
+    const long long ngroups = ((long long)a.n_rays + WAVES * RW - 1) / (WAVES * RW);
+    f32x4* const stage0 = (f32x4*)(bias_lds + PL::NTILES * 16);
+    f32x4* const stage_w = stage0 + (size_t)wave * RW * bpr * 16;
+    const CompositeArgs& fa = *(const CompositeArgs*)(stage0 + (size_t)WAVES * RW * bpr * 16);      // (in LDS: see nrnerf_net_mb.h)
+    if constexpr (fuse) {
+        int* dst = (int*)(stage0 + (size_t)WAVES * RW * bpr * 16);
+        const int* src = (const int*)&a.fuse;
+        for (int i = tid; i < (int)(sizeof(CompositeArgs) / 4); i += WAVES * 64) dst[i] = src[i];
+        __syncthreads();
+    }
+    int tg = 0;
+    long long grp = blockIdx.x;
+    // (opaque: re-derived inside the loop, gridDim.x is a scalar load from the dispatch packet -- ~4000 cycles per iteration
+    //  measured with NRN_TIMING on the path that advances every iteration)
+    unsigned gdim = gridDim.x;
+    asm volatile("" : "+s"(gdim));
+    float cpre[NB][8];          // direction and depths of this wave's rays, requested one iteration ahead of their use
+#ifdef NRN_TIMING
+    // slots: 0 iteration, 1 points + encoding, 2 layers + head, 3 outputs + ring tail, 4 compositing, 5 iteration in 100 MHz ticks,
+    //        6 ring waits + barriers (inside 2), 7 iterations
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (long long b0 = (long long)blockIdx.x * per_wg; fuse ? (grp < ngroups) : (b0 < nblocks); ) {
+#ifdef NRN_TIMING
+        const unsigned long long t_it = NRN_NOW(), r_it = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (fuse && tg == TG - 1) {
+            static_for<0, NB>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if (r < RW) {
+                    const long long rr = (grp * WAVES + wave) * RW + r;
+                    composite_prefetch(fa, (int)(rr < a.n_rays ? rr : a.n_rays - 1), lane, EPL, cpre[r]);
+                }
+            });
+        }
         size_t so[NB];
         bool ok[NB];
         efrag enc[NB][NS_E];
@@ -136,11 +207,22 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         //      (sin, cos) of pair m = 4 i + g (frequency m / 3, coordinate m % 3); groups 2, 3: slots 14, 15 = x, y | z, 0
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            const long long blk_raw = b0 + (long long)wave * NB + b;
-            const bool blk_ok = blk_raw < nblocks;
-            const long long blk = blk_ok ? blk_raw : nblocks - 1;
-            const int ray = (int)(blk / bpr);
-            const int sidx = (int)(blk % bpr) * 16 + n;
+            bool blk_ok;
+            int ray, bir;
+            if (fuse) {                         // block q of this wave's group: ray (grp * WAVES + wave) * RW + q / bpr
+                const int q = tg * NB + b;
+                const long long rr = (grp * WAVES + wave) * RW + q / bpr;
+                blk_ok = rr < a.n_rays;
+                ray = (int)(blk_ok ? rr : a.n_rays - 1);
+                bir = q % bpr;
+            } else {
+                const long long blk_raw = b0 + (long long)wave * NB + b;
+                blk_ok = blk_raw < nblocks;
+                const long long blk = blk_ok ? blk_raw : nblocks - 1;
+                ray = (int)(blk / bpr);
+                bir = (int)(blk % bpr);
+            }
+            const int sidx = bir * 16 + n;
             ok[b] = blk_ok && sidx < S;
             so[b] = (size_t)ray * S + (sidx < S ? sidx : S - 1);
             const f32x4 q4 = *(const f32x4*)(a.pts4 + so[b] * 4);
@@ -165,6 +247,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
                 for (int e = 0; e < 8; ++e) enc[b][s][e] = (_Float16)ev[8 * s + e];
         });
 
+#ifdef NRN_TIMING
+        NRN_TACC(1, t_it);
+        const unsigned long long t_net = NRN_NOW();
+#endif
         frag ha[NB][NS_H], hb[NB][NS_H];
         frag none[NB][1];                   // (the second source of a layer that has one: never indexed)
         auto keep = [&](auto& out) {
@@ -189,41 +275,97 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         auto take = [&](auto, auto kc, const f32x4& d0, const f32x4&) { raw[decltype(kc)::value] = d0; };
         if constexpr ((A::D - 1) % 2 == 1) dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB>(st, bias_lane, hb, none, take);
         else dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB>(st, bias_lane, ha, none, take);
+#ifdef NRN_TIMING
+        NRN_TACC(2, t_net);
+        const unsigned long long t_out = NRN_NOW();
+#endif
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             if (ok[b] && g == 0) {
-                *(f32x4*)(a.raw4 + so[b] * 4) = raw[b];
+                if (!fuse) *(f32x4*)(a.raw4 + so[b] * 4) = raw[b];
                 if (a.raw_out) {
                     float* ro = a.raw_out + so[b] * a.raw_ch;
                     ro[0] = raw[b][0]; ro[1] = raw[b][1]; ro[2] = raw[b][2]; ro[3] = raw[b][3];
                 }
             }
             if (ok[b] && g == 1 && a.raw_out && a.raw_ch > 4) a.raw_out[so[b] * a.raw_ch + 4] = raw[b][0];
+            if (fuse && g == 0) stage_w[(tg * NB + b) * 16 + n] = raw[b];
         });
+#ifdef NRN_TIMING
+        NRN_TACC(3, t_out);
+        const unsigned long long t_comp = NRN_NOW();
+#endif
+        // (hinted: the iteration that does not composite falls through to the back edge)
+        if constexpr (fuse) {
+            if (__builtin_expect(++tg == TG, 0)) {      // the group's last iteration: composite this wave's rays from its LDS stage (train.py:943-950)
+                static_for<0, NB>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if (r < RW) {
+                        const long long rr = (grp * WAVES + wave) * RW + r;
+                        const bool ray_ok = rr < a.n_rays;
+                        const int cray = (int)(ray_ok ? rr : a.n_rays - 1);
+                        const f32x4* sw = stage_w + r * bpr * 16;
+                        auto raw_at = [&](int ic) { return sw[ic]; };
+                        float cz[EPL + 1], cw[EPL];
+                        composite_ray<EPL, true>(fa, cray, ray_ok, lane, raw_at, cz, cw, cpre[r]);
+                    }
+                });
+                tg = 0;
+                grp += gdim;
+            }
+        } else {
+            b0 += (long long)gdim * per_wg;
+        }
+        // the stream's padding units: the ring runs on into the next iteration's first units (after the compositing, so that a wait for
+        // device memory in there never includes these LDS-DMA requests)
         static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+#ifdef NRN_TIMING
+        NRN_TACC(4, t_comp);
+        NRN_TACC(0, t_it);
+        tacc[5] += __builtin_amdgcn_s_memrealtime() - r_it;
+        tacc[7] += 1;
+#endif
     }
     st.drain();
+#ifdef NRN_TIMING
+    if (blockIdx.x == 0 && lane == 0 && wave < 8) {
+        tacc[6] = st.bar_cycles;
+        for (int i = 0; i < 8; ++i) g_nrn_timing[wave][i] += tacc[i];
+    }
+#endif
 }
 
-template <class P, class A>
+template <class P, class A, int EPL>
 static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t stream) {
     constexpr int WAVES = 4;
     using PL = PlanX16<P, A>;
-    if (!a.pts4 || !a.raw4 || a.fuse_on || a.S < 1) return hipErrorInvalidValue;
-    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float);
-    auto kern = net_kernel_x16<P, A, WAVES>;
+    constexpr int NB = NRN_X16_NB;
+    if (!a.pts4 || (!a.raw4 && !a.fuse_on) || a.S < 1) return hipErrorInvalidValue;
+    if ((a.fuse_on != 0) != (EPL > 0) || (EPL > 0 && (a.S + 63) / 64 != EPL)) return hipErrorInvalidValue;      // (the dispatcher's job)
+    const int bpr = (a.S + 15) / 16;
+    const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
+    size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float);
+    if (a.fuse_on) {
+        if (a.S > 256 || a.fuse.n_importance != 0 || a.fuse.S != a.S) return hipErrorInvalidValue;
+        lds += (size_t)WAVES * RW * bpr * 16 * 16 + 256;            // the waves' raw stages + the compositing arguments
+    }
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = net_kernel_x16<P, A, WAVES, EPL>;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // the largest request any launch can make: ring + bias table + the fused stages at bpr = 15 (RW = NB)
+        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + (size_t)WAVES * NB * 15 * 256 + 256;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max < 160 * 1024 ? lds_max : 160 * 1024));
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    const long long nblocks = (long long)a.n_rays * ((a.S + 15) / 16);
-    const long long ntiles = (nblocks + WAVES * NRN_X16_NB - 1) / (WAVES * NRN_X16_NB);
-    if (ntiles <= 0) return hipSuccess;
-    const int grid = (int)(ntiles < num_cus ? ntiles : num_cus);
+    long long want;
+    if (a.fuse_on) want = ((long long)a.n_rays + WAVES * RW - 1) / (WAVES * RW);          // groups of WAVES * RW whole rays
+    else want = ((long long)a.n_rays * bpr + WAVES * NB - 1) / (WAVES * NB);
+    if (want <= 0) return hipSuccess;
+    const int grid = (int)(want < num_cus ? want : num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }

@@ -1,10 +1,44 @@
-// nrnerf_net_x16.hip -- instantiations of the 16x16x32 trunk-only kernel (nrnerf_net_x16.h): compiled architecture 0's trunk, bf16 and f16.
+// nrnerf_net_x16.hip -- instantiations of the 16x16x32 trunk-only kernel (nrnerf_net_x16.h): compiled architecture 0's trunk, bf16 and
+// f16, one object per compositing case (-DNRN_X16_EPL=0..4: raw outputs to memory / compositing fused in for passes of up to 64, 128,
+// 192, 256 samples per ray); the object of case 0 also holds the dispatcher.
 #include "nrnerf_net_x16.h"
 
+#ifndef NRN_X16_EPL
+#error "compile with -DNRN_X16_EPL=0..4 (Makefile)"
+#endif
+#define NRN_CAT2(a, b) a##b
+#define NRN_CAT(a, b) NRN_CAT2(a, b)
+
 namespace nrn {
-hipError_t launch_net_x16(int precision, const NetArgs& a, int num_cus, hipStream_t stream) {
-    if (precision == PREC_BF16) return launch_net_x16_t<PolBF16, ArchDefault>(a, num_cus, stream);
-    if (precision == PREC_F16) return launch_net_x16_t<PolF16, ArchDefault>(a, num_cus, stream);
+hipError_t NRN_CAT(launch_net_x16_e, NRN_X16_EPL)(int precision, const NetArgs& a, int num_cus, hipStream_t stream) {
+    if (precision == PREC_BF16) return launch_net_x16_t<PolBF16, ArchDefault, NRN_X16_EPL>(a, num_cus, stream);
+    if (precision == PREC_F16) return launch_net_x16_t<PolF16, ArchDefault, NRN_X16_EPL>(a, num_cus, stream);
     return hipErrorInvalidValue;
 }
+
+#if NRN_X16_EPL == 0
+hipError_t launch_net_x16_e1(int, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e2(int, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e3(int, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e4(int, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16(int precision, const NetArgs& a, int num_cus, hipStream_t stream) {
+    if (!a.fuse_on) return launch_net_x16_e0(precision, a, num_cus, stream);
+    switch ((a.S + 63) / 64) {
+        case 1: return launch_net_x16_e1(precision, a, num_cus, stream);
+        case 2: return launch_net_x16_e2(precision, a, num_cus, stream);
+        case 3: return launch_net_x16_e3(precision, a, num_cus, stream);
+        case 4: return launch_net_x16_e4(precision, a, num_cus, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+#endif
 }  // namespace nrn
+
+#if defined(NRN_TIMING) && NRN_X16_EPL == 3
+// reads and clears the per-phase cycle counters of the 129..192-sample kernel (tools/timing_probe.py --x16): out[8 waves][8 slots]
+extern "C" int nrnerf_debug_timing_launch_net_x16(unsigned long long* out) {
+    static const unsigned long long zero[64] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nrn::g_nrn_timing), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(nrn::g_nrn_timing), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -12,6 +12,9 @@ The one discrete decision of the algorithm whose outcome legitimately depends on
 fine pass against the oracle evaluated AT THE DEPTHS THE GPU CHOSE (tight), and the depths themselves
 statistically (almost all equal, the rest inside one coarse bin).
 """
+import contextlib
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -23,6 +26,35 @@ from tests.helpers import check_pinned, compare_dict, load_golden, out_of_tolera
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+@contextlib.contextmanager
+def _setenv(name, value):
+    """A library switch that nrnerf_render reads per call (NRNERF_X16, NRNERF_UNFUSED_COMPOSITE, ...) for the duration of a block."""
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+
+
+def _assert_x16_is_an_equally_good_rounding(x16, k32, ref32):
+    """bf16 mode's split-bender path runs its trunk-only fine pass on the 16x16x32 MFMA kernel (nrnerf_net_x16.h) by default
+    and on the 32x32x16 kernel (nrnerf_net_mb.h) with NRNERF_X16=0: the same bf16 products of the same bf16-rounded operands,
+    summed in fp32 in another order (k-slices of 32 instead of 16, another feature permutation) -- so hidden activations round
+    to the neighbouring bf16 value now and then and the two renders are two roundings of one fp32 network, not one bit
+    pattern.  What must hold: everything upstream of the fine network is bit-identical, and against the fp32-MFMA render of
+    the same call the 16x16x32 kernel's error is the 32x32x16 kernel's (mean within 30 %, maximum within 3x)."""
+    for k in ("rgb0", "disp0", "acc0", "z_std", "_z_vals"):
+        assert torch.equal(torch.nan_to_num(x16[k]), torch.nan_to_num(k32[k])), k
+    for k in ("rgb_map", "acc_map"):
+        e16, e32 = (x16[k].float() - ref32[k].float()).abs(), (k32[k].float() - ref32[k].float()).abs()
+        assert e16.mean().item() <= 1.3 * e32.mean().item() + 1e-6, (k, e16.mean().item(), e32.mean().item())
+        assert e16.max().item() <= 3.0 * e32.max().item() + 1e-4, (k, e16.max().item(), e32.max().item())
 
 
 def hip_render(scene, rays, latents, precision, chunk=1 << 20, retraw=False, detailed=False, knobs=None,
@@ -262,7 +294,9 @@ def test_fp32_mode_full_frame_vs_gpu_eager_oracle():
 def test_split_bender_path_at_full_chunk_size_equals_the_fused_pass():
     """One reference chunk (32 768 rays, 64+128): the split-bender path a plain render takes against the fused fine pass a
     detailed render takes -- every common output bit-identical at BASELINE config 2's size as well (f16 mode; bf16 mode
-    up to the conversion ties described in _assert_split_equals_fused_up_to_conversion_ties)."""
+    with the trunk-only pass on the same 32x32x16 tiles, up to the conversion ties described in
+    _assert_split_equals_fused_up_to_conversion_ties; bf16 mode's default 16x16x32 trunk-only kernel as
+    _assert_x16_is_an_equally_good_rounding states)."""
     cfg = SceneConfig()
     scene = make_scene(cfg, 0)
     rays, latents = make_rays(32768, 3, cfg)
@@ -270,10 +304,14 @@ def test_split_bender_path_at_full_chunk_size_equals_the_fused_pass():
     b = hip_render(scene, rays, latents, "f16", retraw=True, detailed=True)      # fused fine pass
     for k in a:
         assert torch.equal(torch.nan_to_num(a[k]), torch.nan_to_num(b[k])), k
-    a = hip_render(scene, rays, latents, "bf16", retraw=True)
+    with _setenv("NRNERF_X16", "0"):                                             # trunk-only pass on the 32x32x16 kernel
+        a = hip_render(scene, rays, latents, "bf16", retraw=True)
     b = hip_render(scene, rays, latents, "bf16", retraw=True, detailed=True)
     assert torch.equal(a["rgb0"], b["rgb0"]) and torch.equal(a["_z_vals"], b["_z_vals"])
     assert (a["raw"] != b["raw"]).any(-1).float().mean().item() < 5e-4 and (a["rgb_map"] - b["rgb_map"]).abs().max().item() < 2e-3
+    # the default trunk-only pass (16x16x32 kernel): another summation order, judged against the fp32-MFMA render
+    x16 = hip_render(scene, rays, latents, "bf16", retraw=True)
+    _assert_x16_is_an_equally_good_rounding(x16, a, hip_render(scene, rays, latents, "f32", retraw=True))
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
@@ -954,19 +992,26 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
     model = R.get_model(coarse, fine)
     r, l = rays.to(DEV), latents.to(DEV)
     lind, wb = bool(flags.get("lindisp")), bool(flags.get("white_bkgd"))
-    outs = []
-    for detailed in (False, True):
+
+    def run(mdl, detailed):
         torch.manual_seed(5)
         randoms = R._draw_randoms(r, cfg.N_samples, cfg.N_importance, flags.get("perturb", 0.0), flags.get("raw_noise_std", 0.0))
         with torch.no_grad():
-            outs.append(model.render(r, l, cfg.N_samples, cfg.N_importance, retraw=True, detailed_output=detailed,
-                                     rigidity_cutoff=rb.rigidity_test_time_cutoff, test_time_scaling=rb.test_time_scaling,
-                                     want_z_vals=True, surface=True, lindisp=lind, white_bkgd=wb, randoms=randoms))
-    torch.cuda.synchronize()
-    split, fused = outs
+            out = mdl.render(r, l, cfg.N_samples, cfg.N_importance, retraw=True, detailed_output=detailed,
+                             rigidity_cutoff=rb.rigidity_test_time_cutoff, test_time_scaling=rb.test_time_scaling,
+                             want_z_vals=True, surface=True, lindisp=lind, white_bkgd=wb, randoms=randoms)
+        torch.cuda.synchronize()
+        return out
+
+    split, fused = run(model, False), run(model, True)
     assert "fine_input_pts" in fused and "fine_input_pts" not in split
     if precision == "bf16":
-        _assert_split_equals_fused_up_to_conversion_ties(split, fused, views=cfg.use_viewdirs)
+        # the trunk-only pass on the fused pass's own 32x32x16 tiles: the same arithmetic up to conversion ties ...
+        with _setenv("NRNERF_X16", "0"):
+            split32 = run(model, False)
+        _assert_split_equals_fused_up_to_conversion_ties(split32, fused, views=cfg.use_viewdirs)
+        # ... and the default 16x16x32 trunk-only kernel (width 256, no view branch): as good a rounding of the fp32 network
+        _assert_x16_is_an_equally_good_rounding(split, split32, run(R.get_model(coarse, fine, precision="f32"), False))
         return
     if cfg.use_viewdirs:
         # View-dependent head: the trunk-only kernel takes a sample's direction from the same bent points (read back from

@@ -10,7 +10,7 @@ Invariants the hand-placed waits of nrnerf_net_impl.h rely on (16-bit kernels, W
     prefetch queue.  Outside the section (tile prologue, the fused compositing epilogue) scalar loads are free;
   * no scratch traffic: every scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the LDS-DMA queue;
   * at most 256 VGPRs (two waves per SIMD) for the 16-bit kernels of nrnerf_net_impl.h; the two-blocks-per-wave kernels
-    of nrnerf_net_mb.h run one wave per SIMD: at most 512 registers, and at most one v_accvgpr copy per 3 MFMAs (more
+    of nrnerf_net_mb.h and the 16x16x32 trunk-only kernel of nrnerf_net_x16.h run one wave per SIMD: at most 512 registers, and at most one v_accvgpr copy per 3 MFMAs (more
     means the accumulators went to AccVGPRs: the build lost -mllvm -amdgpu-mfma-vgpr-form).
 Also reported: MFMA count, VALU count, counted vs draining LDS waits.
 """
@@ -80,10 +80,15 @@ def analyse(co: str) -> dict:
     # the compositing epilogue (nrnerf_composite_ray.h) in their persistent loop, outside that section: it re-reads a few
     # kernel arguments with scalar loads (the compiler's cure for SGPR pressure) and parks values in AccVGPRs -- harmless
     # there (no fragment prefetch queue to drain, once per group of rays); inside the section the rules stay as they were
-    last = mfma[-1] if mfma else len(ins)
-    span = ins[first:last + 1]
+    # (per kernel: an object may hold several -- nrnerf_net_x16.o has one per 16-bit type)
+    span = []
+    for fn in re.split(r"(?m)^[0-9a-f]{16} <[^>]*>:", dis)[1:]:
+        f_ins = [l.split()[0] for l in fn.splitlines() if re.match(r"^\s+[a-z]+_", l)]
+        f_mfma = [i for i, x in enumerate(f_ins) if "mfma" in x]
+        if f_mfma:
+            span += f_ins[f_mfma[0]:f_mfma[-1] + 1]
     return dict(meta, mfma=len(mfma), valu=sum(x.startswith("v_") and "mfma" not in x for x in ins),
-                mb="net_kernel_mb" in dis, accvgpr=sum("accvgpr" in x for x in span), accvgpr_total=sum("accvgpr" in x for x in ins),
+                mb="net_kernel_mb" in dis or "net_kernel_x16" in dis, accvgpr=sum("accvgpr" in x for x in span), accvgpr_total=sum("accvgpr" in x for x in ins),
                 smem_in_mfma_section=sum(x.startswith(("s_load", "s_buffer_load")) for x in span),
                 smem_after_first_mfma=sum(x.startswith(("s_load", "s_buffer_load")) for x in ins[first:]) + smem_in_loop,
                 scratch=sum(x.startswith("scratch_") for x in ins),
@@ -93,21 +98,21 @@ def analyse(co: str) -> dict:
 def check(build_dir: str) -> list[str]:
     errors = []
     objs = sorted(glob.glob(os.path.join(build_dir, "net_*.o")) + glob.glob(os.path.join(build_dir, "bend_*.o")) +
-                  glob.glob(os.path.join(build_dir, "train_*.o")))
+                  glob.glob(os.path.join(build_dir, "train_*.o")) + glob.glob(os.path.join(build_dir, "nrnerf_net_x16_e*.o")))
     if not objs:
         raise FileNotFoundError(f"no net_*.o under {build_dir} (run make first)")
     with tempfile.TemporaryDirectory() as tmp:
         for obj in objs:
             co = device_code_object(obj, tmp)
             base = os.path.basename(obj)[:-2]
-            name = base[4:] if base.startswith("net_") else base
+            name = base[4:] if base.startswith("net_") else base.replace("nrnerf_net_", "")
             if co is None:
                 errors.append(f"{name}: no gfx950 code object")
                 continue
             r = analyse(co)
             print(f"{name:24s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} scratch {r['scratch']:3d} "
                   f"mfma {r['mfma']:5d} valu {r['valu']:5d} lgkm counted/drain {r['lgkm_counted']:4d}/{r['lgkm_drain']:3d} "
-                  f"smem in-section/in-loop {r['smem_in_mfma_section']}/{r['smem_after_first_mfma']}" + (f"  [2 blocks/wave, accvgpr in-section {r['accvgpr']} of {r['accvgpr_total']}]" if r["mb"] else ""))
+                  f"smem in-section/in-loop {r['smem_in_mfma_section']}/{r['smem_after_first_mfma']}" + (f"  [1 wave/SIMD, accvgpr in-section {r['accvgpr']} of {r['accvgpr_total']}]" if r["mb"] else ""))
             sixteen = "_f32_" not in "_" + name + "_" and not name.startswith("train_bend_")      # the training bender is fp32 only
             if sixteen:
                 # (reported, not enforced, for the stand-alone bender -- which reads its per-block inputs with scalar loads on

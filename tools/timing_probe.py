@@ -3,6 +3,9 @@
 
     make -C nonrigid_nerf_amd/csrc -j8 TUNE=-DNRN_TIMING SUFFIX=_timing
     NRNERF_LIB=$PWD/nonrigid_nerf_amd/lib/libnrnerf_hip_timing.so python tools/timing_probe.py
+
+With `--x16`: the 16x16x32 trunk-only kernel (nrnerf_net_x16.h; only nrnerf_net_x16.hip needs -DNRN_TIMING), whose counters also hold
+the iteration time in 100 MHz ticks, i.e. the shader clock the workgroup actually ran at.
 """
 import ctypes as C
 import os
@@ -22,6 +25,27 @@ rays, lat = make_rays(196608, 1, cfg)
 rays, lat = rays.cuda(), lat.cuda()
 model = R.get_model(coarse, fine)
 lib = _lib.load()
+if "--x16" in sys.argv:
+    fn = lib.nrnerf_debug_timing_launch_net_x16
+    fn.argtypes, fn.restype = [C.POINTER(C.c_ulonglong)], C.c_int
+    buf = (C.c_ulonglong * 64)()
+    names = ["iteration", "points+encoding", "layers+head", "outputs+ring tail", "compositing", "100 MHz ticks", "ring wait+barrier", "iterations"]
+    rays, lat = make_rays(262144, 1, cfg)
+    rays, lat = rays.cuda(), lat.cuda()
+    with torch.no_grad():
+        model.render(rays, lat, 64, 128); torch.cuda.synchronize(); fn(buf)
+        for rep in range(2):
+            model.render(rays, lat, 64, 128); torch.cuda.synchronize(); fn(buf)
+            print("== fine pass, 262144 rays x 192 samples: cycles per iteration (4 blocks of 16 samples per wave), workgroup 0")
+            for w in range(4):
+                row = [buf[w * 8 + i] for i in range(8)]
+                n = max(row[7], 1)
+                mhz = 100.0 * row[0] / max(row[5], 1)
+                if "--raw" in sys.argv:
+                    print(f"  wave {w}: slots per iteration " + "  ".join(f"[{i}] {row[i] / n:8.0f}" for i in range(7)) + f"  iterations {row[7]}")
+                    continue
+                print(f"  wave {w}: " + "  ".join(f"{names[i]} {row[i] / n:8.0f}" for i in (0, 1, 2, 3, 4, 6)) + f"  iterations {row[7]}  clock {mhz:6.0f} MHz")
+    sys.exit(0)
 fn = lib.nrnerf_debug_timing_launch_net_a0_bf16_bend
 fn.argtypes, fn.restype = [C.POINTER(C.c_ulonglong)], C.c_int
 buf = (C.c_ulonglong * 64)()
