@@ -79,8 +79,8 @@ template <int EPL, bool FENCED = false, class RAWF>
 __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int ray, const bool ray_ok, const int lane,
                                               RAWF&& raw_at, float (&z)[EPL + 1], float (&w)[EPL], const float* pre = nullptr) {
     // FENCED (the 16x16x32 kernel's epilogue, where a lone wave per SIMD runs this code with nothing to overlap it): scheduling fences
-    // between the phases.  Same instructions, same bits; measured with NRN_TIMING, the iteration that composites takes 12 000 cycles
-    // less with them (and with ONE instantiation in the kernel instead of four behind a switch) -- tools/experiments/README.md.
+    // between the phases.  Same instructions, same bits; measured with NRN_TIMING, together with ONE instantiation in the kernel
+    // instead of four behind a switch: 6 600 -> 6 300 cycles per iteration (tools/experiments/README.md, round 4).
     auto phase_fence = [] { if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0); };
     // No multiply-add fusion the source does not spell out (__fmaf_rn).  hipcc's `__fmul_rn` / `__fadd_rn` are plain * and +, this
     // build's -ffp-contract=fast fuses them wherever a product feeds a sum IN ONE BASIC BLOCK (pragmas are not honoured), and

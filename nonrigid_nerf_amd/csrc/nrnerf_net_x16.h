@@ -130,8 +130,8 @@ __device__ __forceinline__ void dense_x16(ST& st, const __attribute__((address_s
 
 // EPL: 0 = the raw outputs go to memory (NetArgs::raw4); 1..4 = the compositing is fused in (NetArgs::fuse_on) for passes of up to
 // 64 EPL samples per ray, a lane owning EPL of them (composite_ray<EPL>).  One kernel per case rather than a switch inside one: the loop
-// body is straight-line code several times the instruction cache, and the iteration that composites was measured 12 000 cycles
-// faster with a single compositing instantiation (and scheduling fences in it) than with four.
+// body is straight-line code several times the instruction cache (every jump to code that is not next in line costs ~2000 cycles,
+// NRN_TIMING), the flag and the case fold at compile time, and the fine pass measured 0.5-1 % faster (tools/experiments/README.md).
 template <class P, class A, int WAVES, int EPL>
 __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a) {
     using PL = PlanX16<P, A>;
