@@ -320,8 +320,9 @@ def main():
                     "issued_mfma_tflops": round(issued, 2), "frac_issued_mfma": round(issued / peak, 4)}
         rf = roof(k)
         traffic, traffic_note = pmc_traffic(args)
-        # (bf16 with a ray bender and no view branch: the split path's trunk-only pass on 16x16x32 MFMAs, nrnerf_net_x16.h, unless NRNERF_X16=0)
-        x16 = (args.precision == "bf16" and os.environ.get("NRNERF_X16", "1") != "0" and args.netwidth == 256
+        # (16-bit modes with a ray bender and no view branch: the split path's trunk-only pass on 16x16x32 MFMAs, nrnerf_net_x16.h, unless NRNERF_X16=0)
+        x16 = (args.precision in ("bf16", "f16") and os.environ.get("NRNERF_X16", "1") != "0" and args.netwidth == 256
+               and not (args.precision == "f16" and os.environ.get("NRNERF_X16_F16", "1") == "0")
                and not (args.use_viewdirs or args.exact_viewdirs))
         roofline = {"bound": "mfma", "kernel": ("net_kernel_x16" if x16 else "net_kernel") + " (fine pass, 192 samples/ray)",
                     "achieved": rf["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": rf["frac"],

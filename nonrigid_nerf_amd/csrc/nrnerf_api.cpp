@@ -295,9 +295,10 @@ void pack_pass_x16(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
 // does the 16x16x32 trunk kernel have this network?  (compiled architecture 0's trunk, output_linear head, 16-bit precision)
 bool x16_eligible(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, bool any_16bit = false) {
     using A = ArchDefault;
-    // (bf16 mode only for now: "f16" is the mode whose split path is held bit-identical to the fused-bender fine pass -- the same
-    //  32x32x16 products on both sides -- by tests/test_gpu_parity.py; NRNERF_X16_F16=1 lifts that for experiments)
-    static const bool f16_too = [] { const char* e = std::getenv("NRNERF_X16_F16"); return e && std::atoi(e) != 0; }();
+    // (both 16-bit modes; NRNERF_X16_F16=0 at model creation keeps "f16" mode on the 32x32x16 kernels only.  At render time NRNERF_X16=0
+    //  selects the 32x32x16 trunk-only kernel per call: the split path is then bit-identical to the fused-bender fine pass in "f16" mode,
+    //  which tests/test_gpu_parity.py asserts)
+    static const bool f16_too = [] { const char* e = std::getenv("NRNERF_X16_F16"); return !e || std::atoi(e) != 0; }();
     if (d.precision != NRNERF_PREC_BF16 && !(d.precision == NRNERF_PREC_F16 && (f16_too || any_16bit))) return false;
     if (m.use_viewdirs || m.time_conditioned || d.multires != A::L || m.depth != A::D || m.width != A::W || m.skip != A::SKIP) return false;
     if (m.output_ch != 4 && m.output_ch != 5) return false;
