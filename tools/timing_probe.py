@@ -4,8 +4,9 @@
     make -C nonrigid_nerf_amd/csrc -j8 TUNE=-DNRN_TIMING SUFFIX=_timing
     NRNERF_LIB=$PWD/nonrigid_nerf_amd/lib/libnrnerf_hip_timing.so python tools/timing_probe.py
 
-With `--x16`: the 16x16x32 trunk-only kernel (nrnerf_net_x16.h; only nrnerf_net_x16.hip needs -DNRN_TIMING), whose counters also hold
-the iteration time in 100 MHz ticks, i.e. the shader clock the workgroup actually ran at.
+With `--x16`: the 16x16x32 trunk-only kernel (nrnerf_net_x16.h; the object of the 129..192-sample case is enough: nrnerf_net_x16.hip
+with -DNRN_X16_EPL=3 -DNRN_TIMING, linked with the shipped objects), whose counters also hold the iteration time in 100 MHz ticks,
+i.e. the shader clock the workgroup actually ran at.  `--raw`: all eight slots per iteration.
 """
 import ctypes as C
 import os
