@@ -11,7 +11,9 @@ Invariants the hand-placed waits of nrnerf_net_impl.h rely on (16-bit kernels, W
   * no scratch traffic: every scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the LDS-DMA queue;
   * at most 256 VGPRs (two waves per SIMD) for the 16-bit kernels of nrnerf_net_impl.h; the two-blocks-per-wave kernels
     of nrnerf_net_mb.h and the 16x16x32 trunk-only kernel of nrnerf_net_x16.h run one wave per SIMD: at most 512 registers, and at most one v_accvgpr copy per 3 MFMAs (more
-    means the accumulators went to AccVGPRs: the build lost -mllvm -amdgpu-mfma-vgpr-form).
+    means the accumulators went to AccVGPRs: the build lost -mllvm -amdgpu-mfma-vgpr-form);
+  * nrnerf_net_x16.h: no draining `s_waitcnt lgkmcnt(0)` between the first and the last MFMA except at the layer ends (the biases
+    travel in the counted fragment queue).
 Also reported: MFMA count, VALU count, counted vs draining LDS waits.
 """
 from __future__ import annotations
@@ -81,18 +83,22 @@ def analyse(co: str) -> dict:
     # kernel arguments with scalar loads (the compiler's cure for SGPR pressure) and parks values in AccVGPRs -- harmless
     # there (no fragment prefetch queue to drain, once per group of rays); inside the section the rules stay as they were
     # (per kernel: an object may hold several -- nrnerf_net_x16.o has one per 16-bit type)
-    span = []
+    span, drains_in_section, kernels = [], 0, 0
     for fn in re.split(r"(?m)^[0-9a-f]{16} <[^>]*>:", dis)[1:]:
-        f_ins = [l.split()[0] for l in fn.splitlines() if re.match(r"^\s+[a-z]+_", l)]
+        f_lines = [l for l in fn.splitlines() if re.match(r"^\s+[a-z]+_", l)]
+        f_ins = [l.split()[0] for l in f_lines]
         f_mfma = [i for i, x in enumerate(f_ins) if "mfma" in x]
         if f_mfma:
+            kernels += 1
             span += f_ins[f_mfma[0]:f_mfma[-1] + 1]
+            drains_in_section += sum("s_waitcnt" in l and "lgkmcnt(0)" in l for l in f_lines[f_mfma[0]:f_mfma[-1] + 1])
     return dict(meta, mfma=len(mfma), valu=sum(x.startswith("v_") and "mfma" not in x for x in ins),
                 mb="net_kernel_mb" in dis or "net_kernel_x16" in dis, accvgpr=sum("accvgpr" in x for x in span), accvgpr_total=sum("accvgpr" in x for x in ins),
                 smem_in_mfma_section=sum(x.startswith(("s_load", "s_buffer_load")) for x in span),
                 smem_after_first_mfma=sum(x.startswith(("s_load", "s_buffer_load")) for x in ins[first:]) + smem_in_loop,
                 scratch=sum(x.startswith("scratch_") for x in ins),
-                lgkm_counted=sum(n > 0 for n in lg), lgkm_drain=sum(n == 0 for n in lg))
+                lgkm_counted=sum(n > 0 for n in lg), lgkm_drain=sum(n == 0 for n in lg),
+                lgkm_drain_in_section=drains_in_section, kernels=kernels, x16="net_kernel_x16" in dis)
 
 
 def check(build_dir: str) -> list[str]:
@@ -127,6 +133,11 @@ def check(build_dir: str) -> list[str]:
                 limit = 512 if r["mb"] else 256
                 if r.get("vgpr_count", 0) > limit:
                     errors.append(f"{name}: {r['vgpr_count']} VGPRs > {limit}")
+                # the 16x16x32 kernel keeps EVERYTHING it reads from LDS between its first and last MFMA in the counted queue (fragments
+                # and biases): the only lgkmcnt(0) in there are the layer ends, where the queue runs empty (9 layers + head per kernel).
+                # A plain LDS load in the section brings hipcc's own lgkmcnt(0) back (87 per pass with the biases: -2.5 %)
+                if r["x16"] and r["lgkm_drain_in_section"] > 12 * r["kernels"]:
+                    errors.append(f"{name}: {r['lgkm_drain_in_section']} draining LDS waits inside the MFMA sections of {r['kernels']} kernels")
                 if r["mb"] and 3 * r["accvgpr"] > r["mfma"]:
                     errors.append(f"{name}: {r['accvgpr']} AccVGPR copies for {r['mfma']} MFMAs (accumulators not in VGPRs?)")
     return errors
