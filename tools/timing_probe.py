@@ -5,7 +5,7 @@
     NRNERF_LIB=$PWD/nonrigid_nerf_amd/lib/libnrnerf_hip_timing.so python tools/timing_probe.py
 
 With `--x16`: the 16x16x32 trunk-only kernel (nrnerf_net_x16.h; the object of the 129..192-sample case is enough: nrnerf_net_x16.hip
-with -DNRN_X16_EPL=3 -DNRN_TIMING, linked with the shipped objects), whose counters also hold the iteration time in 100 MHz ticks,
+with -DNRN_X16_EPL=3 -DNRN_TIMING, linked with the shipped objects -- tools/build_timing_x16.sh does that), whose counters also hold the iteration time in 100 MHz ticks,
 i.e. the shader clock the workgroup actually ran at.  `--raw`: all eight slots per iteration.
 """
 import ctypes as C
