@@ -182,6 +182,39 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     unsigned gdim = gridDim.x;
     asm volatile("" : "+s"(gdim));
     float cpre[NB][8];          // direction and depths of this wave's rays, requested one iteration ahead of their use
+    // where block b of the iteration (tg_, grp_ | b0_) lies: its sample's row in the [N, S] arrays, and whether the lane has a sample
+    auto locate = [&](int tg_, long long grp_, long long b0_, int b, size_t& so_, bool& ok_) {
+        bool blk_ok;
+        int ray, bir;
+        if constexpr (fuse) {                   // block q of this wave's group: ray (grp * WAVES + wave) * RW + q / bpr
+            const int q = tg_ * NB + b;
+            const long long rr = (grp_ * WAVES + wave) * RW + q / bpr;
+            blk_ok = rr < a.n_rays;
+            ray = (int)(blk_ok ? rr : a.n_rays - 1);
+            bir = q % bpr;
+        } else {
+            const long long blk_raw = b0_ + (long long)wave * NB + b;
+            blk_ok = blk_raw < nblocks;
+            const long long blk = blk_ok ? blk_raw : nblocks - 1;
+            ray = (int)(blk / bpr);
+            bir = (int)(blk % bpr);
+        }
+        const int sidx = bir * 16 + n;
+        ok_ = blk_ok && sidx < S;
+        so_ = (size_t)ray * S + (sidx < S ? sidx : S - 1);
+    };
+    // The points of an iteration are requested during the PREVIOUS one -- right after its last LDS-DMA requests, before its output
+    // stores and its compositing: a lone wave per SIMD has nothing else to put between the request and the use, and the loads'
+    // latency was 4 000 of an iteration's 96 000 cycles (NRN_TIMING).  Not earlier: the vector-memory queue retires in order, and the
+    // ring's counted vmcnt waits would wait for them.
+    size_t so[NB];
+    bool ok[NB];
+    f32x4 q4n[NB];
+    static_for<0, NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        locate(0, grp, (long long)blockIdx.x * per_wg, b, so[b], ok[b]);
+        q4n[b] = *(const f32x4*)(a.pts4 + so[b] * 4);
+    });
 #ifdef NRN_TIMING
     // slots: 0 iteration, 1 points + encoding, 2 layers + head, 3 outputs + ring tail, 4 compositing, 5 iteration in 100 MHz ticks,
     //        6 ring waits + barriers (inside 2), 7 iterations
@@ -200,32 +233,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
                 }
             });
         }
-        size_t so[NB];
-        bool ok[NB];
         efrag enc[NB][NS_E];
-        // ---- points and their positional encoding, in B-operand order (x16_enc_col): slots 2 i, 2 i + 1 of this lane's group =
+        // ---- the points' positional encoding, in B-operand order (x16_enc_col): slots 2 i, 2 i + 1 of this lane's group =
         //      (sin, cos) of pair m = 4 i + g (frequency m / 3, coordinate m % 3); groups 2, 3: slots 14, 15 = x, y | z, 0
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            bool blk_ok;
-            int ray, bir;
-            if (fuse) {                         // block q of this wave's group: ray (grp * WAVES + wave) * RW + q / bpr
-                const int q = tg * NB + b;
-                const long long rr = (grp * WAVES + wave) * RW + q / bpr;
-                blk_ok = rr < a.n_rays;
-                ray = (int)(blk_ok ? rr : a.n_rays - 1);
-                bir = q % bpr;
-            } else {
-                const long long blk_raw = b0 + (long long)wave * NB + b;
-                blk_ok = blk_raw < nblocks;
-                const long long blk = blk_ok ? blk_raw : nblocks - 1;
-                ray = (int)(blk / bpr);
-                bir = (int)(blk % bpr);
-            }
-            const int sidx = bir * 16 + n;
-            ok[b] = blk_ok && sidx < S;
-            so[b] = (size_t)ray * S + (sidx < S ? sidx : S - 1);
-            const f32x4 q4 = *(const f32x4*)(a.pts4 + so[b] * 4);
+            const f32x4 q4 = q4n[b];
             const float prev[3] = {q4[0] * 0.15915494309189535f, q4[1] * 0.15915494309189535f, q4[2] * 0.15915494309189535f};
             float ev[16];
 #pragma unroll
@@ -279,6 +292,23 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         NRN_TACC(2, t_net);
         const unsigned long long t_out = NRN_NOW();
 #endif
+        // the stream's padding units: the ring runs on into the next iteration's first units
+        static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+        // the next iteration's points, requested behind the ring's last LDS-DMA requests and ahead of everything that is left to do here
+        int tg_n = tg;
+        long long grp_n = grp, b0_n = b0;
+        if constexpr (fuse) {
+            if (tg + 1 == TG) { tg_n = 0; grp_n = grp + gdim; } else tg_n = tg + 1;
+        } else {
+            b0_n = b0 + (long long)gdim * per_wg;
+        }
+        size_t so_n[NB];
+        bool ok_n[NB];
+        static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            locate(tg_n, grp_n, b0_n, b, so_n[b], ok_n[b]);
+            q4n[b] = *(const f32x4*)(a.pts4 + so_n[b] * 4);
+        });
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             if (ok[b] && g == 0) {
@@ -297,7 +327,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
 #endif
         // (hinted: the iteration that does not composite falls through to the back edge)
         if constexpr (fuse) {
-            if (__builtin_expect(++tg == TG, 0)) {      // the group's last iteration: composite this wave's rays from its LDS stage (train.py:943-950)
+            if (__builtin_expect(tg + 1 == TG, 0)) {    // the group's last iteration: composite this wave's rays from its LDS stage (train.py:943-950)
                 static_for<0, NB>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     if (r < RW) {
@@ -310,15 +340,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
                         composite_ray<EPL, true>(fa, cray, ray_ok, lane, raw_at, cz, cw, cpre[r]);
                     }
                 });
-                tg = 0;
-                grp += gdim;
             }
-        } else {
-            b0 += (long long)gdim * per_wg;
         }
-        // the stream's padding units: the ring runs on into the next iteration's first units (after the compositing, so that a wait for
-        // device memory in there never includes these LDS-DMA requests)
-        static_for<PL::NUNITS, PL::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+        tg = tg_n; grp = grp_n; b0 = b0_n;
+        static_for<0, NB>([&](auto bc) { so[decltype(bc)::value] = so_n[decltype(bc)::value]; ok[decltype(bc)::value] = ok_n[decltype(bc)::value]; });
 #ifdef NRN_TIMING
         NRN_TACC(4, t_comp);
         NRN_TACC(0, t_it);
