@@ -786,7 +786,7 @@ struct nrnerf_model {
     bool split_ok = false;
     // the fine network's trunk once more, packed for the 16x16x32 kernel (nrnerf_net_x16.h): what the split-bender path's fine pass
     // runs when the call asks for no detail outputs
-    PassDev fine_trunk_x16;
+    PassDev fine_trunk_x16, coarse_trunk_x16;
     // training (nrnerf_train.h): transposed trunk weights of both networks; train_ok: see training_eligible, fp32 or bf16
     PassDev coarse_bwd, fine_bwd;
     bool train_ok = false;
@@ -1243,6 +1243,15 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) try {
                 m->fine_trunk_x16.mfma_flops_per_sample = px.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
                 m->fine_trunk_x16.output_ch = m->fine.output_ch;
             }
+            // the coarse network's trunk in the same packing: the coarse pass of the split path on the 16x16x32 kernel too
+            if (rc == NRNERF_OK && desc->fine && x16_eligible(*desc, *desc->coarse)) {
+                PackedPass pxc;
+                pack_x16(*desc, *desc->coarse, pxc, &lay);
+                rc = upload_pass(pxc, m->coarse_trunk_x16);
+                m->coarse_trunk_x16.algo_flops_per_sample = m->coarse_trunk.algo_flops_per_sample;
+                m->coarse_trunk_x16.mfma_flops_per_sample = pxc.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
+                m->coarse_trunk_x16.output_ch = m->coarse.output_ch;
+            }
         }
     }
     if (rc == NRNERF_OK) rc = upload_training(*desc, m, nullptr, false, &lay);
@@ -1285,6 +1294,11 @@ int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hi
         pack_x16(*desc, desc->fine ? *desc->fine : *desc->coarse, px);
         rc = refresh_pass(px, m->fine_trunk_x16, stream);
     }
+    PackedPass pxc;
+    if (rc == NRNERF_OK && m->coarse_trunk_x16.stream) {
+        pack_x16(*desc, *desc->coarse, pxc);
+        rc = refresh_pass(pxc, m->coarse_trunk_x16, stream);
+    }
     // the packed host images die with this call: wait until the copies have consumed them
     if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;
     if (rc == NRNERF_OK && m->train_ok) rc = upload_training(*desc, m, stream, /*refresh=*/true);
@@ -1300,7 +1314,7 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     hipStream_t stream = (hipStream_t)hip_stream;
-    PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16,
+    PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16, &m->coarse_trunk_x16,
                          &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
                          &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine};
     for (PassDev* p : passes)
@@ -1337,6 +1351,7 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->coarse);
     free_pass(m->fine_trunk);
     free_pass(m->fine_trunk_x16);
+    free_pass(m->coarse_trunk_x16);
     free_pass(m->coarse_trunk);
     free_pass(m->bend_only);
     free_pass(m->coarse_bwd);
@@ -1543,7 +1558,14 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // kernel 8.72 ms = 10.28 ms against 10.22 ms fused -- nothing is saved there, unlike in the fine pass where a third of
     // the samples skips the bender.  NRNERF_SPLIT_COARSE=1 splits it as well (A/B).
     static const bool split_coarse_on = [] { const char* e = std::getenv("NRNERF_SPLIT_COARSE"); return e && e[0] == '1'; }();
-    const bool split_coarse = split && split_coarse_on;
+    // The 16x16x32 trunk-only kernel (nrnerf_net_x16.h) for the passes of the split path when the call wants no detail outputs.
+    // NRNERF_X16 (read per call, like NRNERF_UNFUSED_COMPOSITE: the parity tests run the kernels side by side in one process):
+    // 0 = the 32x32x16 kernels of nrnerf_net_mb.h, 1 = the fine pass only, 2 (default) = the coarse pass too -- stand-alone bender
+    // over the S coarse samples + 16x16x32 trunk instead of the fused-bender 32x32x16 kernel.
+    const char* x16_env = std::getenv("NRNERF_X16");
+    const int x16_mode = x16_env ? std::atoi(x16_env) : 2;
+    const bool x16_coarse = split && x16_mode >= 2 && m->coarse_trunk_x16.stream && !a->detailed_output && !kn.detailed;
+    const bool split_coarse = split && (split_coarse_on || x16_coarse);
     // Compositing fused into the FINAL pass' network kernel (north_star: "compositing fused into the ray loop"; the
     // reference calls raw2outputs inline, train.py:943-950): the kernel variants without a fused bender -- the trunk-only fine
     // pass of the split-bender path, every pass of a model without bender -- let each wave own whole rays, keep their raw
@@ -1589,9 +1611,15 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                   [&] { return launch_bend(m->precision, bender_arch(m->arch_id), bc, m->num_cus, stream); });
         if (e != hipSuccess) return NRNERF_ERR_HIP;
         na.pts4 = bent_c; na.bent4 = nullptr;
-        na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
-        e = timed(0, (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
-                  [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), na, m->num_cus, stream); });
+        if (x16_coarse) {
+            na.wstream = m->coarse_trunk_x16.stream; na.bias = m->coarse_trunk_x16.bias;
+            e = timed(0, (double)N * S * m->coarse_trunk_x16.algo_flops_per_sample, (double)N * S * m->coarse_trunk_x16.mfma_flops_per_sample,
+                      [&] { return launch_net_x16(m->precision, na, m->num_cus, stream); });
+        } else {
+            na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
+            e = timed(0, (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
+                      [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), na, m->num_cus, stream); });
+        }
     } else {
         e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
                   [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
@@ -1633,9 +1661,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // the split path's trunk-only pass on the 16x16x32 kernel (nrnerf_net_x16.h) when the call wants no detail outputs
     // (NRNERF_X16=0: the 32x32x16 kernel of nrnerf_net_mb.h)
     // (read per call, like NRNERF_UNFUSED_COMPOSITE: the parity tests run both kernels in one process)
-    const char* x16_env = std::getenv("NRNERF_X16");
-    const bool x16_on = !x16_env || std::atoi(x16_env) != 0;
-    const bool x16 = split && x16_on && m->fine_trunk_x16.stream && !a->detailed_output && !kn.detailed;
+    const bool x16 = split && x16_mode != 0 && m->fine_trunk_x16.stream && !a->detailed_output && !kn.detailed;
     // (the 16x16x32 kernel's groups: 4 waves x the fewest rays whose 16-sample blocks fill whole iterations of 4 blocks)
     const int bpr16 = (SF + 15) / 16;
     const long long x16_group = 4LL * ((bpr16 % 4 == 0) ? 1 : ((bpr16 % 2 == 0) ? 2 : 4));

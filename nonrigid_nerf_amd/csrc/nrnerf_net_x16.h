@@ -44,6 +44,9 @@ __device__ __forceinline__ typename P::frag x16_pack(const f32x4& d0, const f32x
 #ifndef NRN_X16_NB
 #define NRN_X16_NB 4          // 16-sample blocks per wave
 #endif
+#ifndef NRN_X16_WAVES
+#define NRN_X16_WAVES 4       // waves per workgroup (4: one per SIMD, up to 512 registers; 8: two per SIMD, 256)
+#endif
 #ifndef NRN_X16_PF
 #define NRN_X16_PF 8          // weight fragments requested from LDS ahead of their MFMAs (4: 24.1 ms per fine pass, 6: 23.7, 8: 23.7)
 #endif
@@ -362,7 +365,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
 
 template <class P, class A, int EPL>
 static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t stream) {
-    constexpr int WAVES = 4;
+    constexpr int WAVES = NRN_X16_WAVES;
     using PL = PlanX16<P, A>;
     constexpr int NB = NRN_X16_NB;
     if (!a.pts4 || (!a.raw4 && !a.fuse_on) || a.S < 1) return hipErrorInvalidValue;

@@ -57,6 +57,22 @@ def _assert_x16_is_an_equally_good_rounding(x16, k32, ref32):
         assert e16.max().item() <= 3.0 * e32.max().item() + 1e-4, (k, e16.max().item(), e32.max().item())
 
 
+def _assert_x16_coarse_is_an_equally_good_rounding(x16, k32, ref32):
+    """NRNERF_X16=2 (the default of round 5): the COARSE pass of the split path leaves the fused-bender 32x32x16 kernel too -- stand-alone
+    bender over the coarse samples (the fused kernel's own building blocks) + the 16x16x32 trunk.  The coarse maps are then another
+    rounding of the same fp32 network, and the importance samples follow them: against the fp32-MFMA render the coarse maps' error
+    must be the 32x32x16 kernel's (mean within 30 %, maximum within 3x), no more depths may move than with that kernel (+ 30 %), and
+    the final maps are held to the same bound."""
+    for k in ("rgb0", "acc0", "rgb_map", "acc_map"):
+        e16, e32 = (x16[k].float() - ref32[k].float()).abs(), (k32[k].float() - ref32[k].float()).abs()
+        assert e16.mean().item() <= 1.3 * e32.mean().item() + 1e-6, (k, e16.mean().item(), e32.mean().item())
+        assert e16.max().item() <= 3.0 * e32.max().item() + 1e-4, (k, e16.max().item(), e32.max().item())
+    span = float(ref32["_z_vals"].max() - ref32["_z_vals"].min())
+    m16 = ((x16["_z_vals"] - ref32["_z_vals"]).abs() > 1e-5 * span).float().mean().item()
+    m32 = ((k32["_z_vals"] - ref32["_z_vals"]).abs() > 1e-5 * span).float().mean().item()
+    assert m16 <= 1.3 * m32 + 2e-3, ("moved depths", m16, m32)
+
+
 def hip_render(scene, rays, latents, precision, chunk=1 << 20, retraw=False, detailed=False, knobs=None,
                want_z=True, use_batchify=True, flags=None):
     cfg = scene.cfg
@@ -306,15 +322,20 @@ def test_split_bender_path_at_full_chunk_size_equals_the_fused_pass():
     for k in a:
         assert torch.equal(torch.nan_to_num(a[k]), torch.nan_to_num(b[k])), k
     ref32 = hip_render(scene, rays, latents, "f32", retraw=True)
-    _assert_x16_is_an_equally_good_rounding(hip_render(scene, rays, latents, "f16", retraw=True), a, ref32)
+    with _setenv("NRNERF_X16", "1"):                                             # fine pass on the 16x16x32 kernel, coarse pass as above
+        _assert_x16_is_an_equally_good_rounding(hip_render(scene, rays, latents, "f16", retraw=True), a, ref32)
+    _assert_x16_coarse_is_an_equally_good_rounding(hip_render(scene, rays, latents, "f16", retraw=True), a, ref32)
     with _setenv("NRNERF_X16", "0"):                                             # trunk-only pass on the 32x32x16 kernel
         a = hip_render(scene, rays, latents, "bf16", retraw=True)
     b = hip_render(scene, rays, latents, "bf16", retraw=True, detailed=True)
     assert torch.equal(a["rgb0"], b["rgb0"]) and torch.equal(a["_z_vals"], b["_z_vals"])
     assert (a["raw"] != b["raw"]).any(-1).float().mean().item() < 5e-4 and (a["rgb_map"] - b["rgb_map"]).abs().max().item() < 2e-3
     # the default trunk-only pass (16x16x32 kernel): another summation order, judged against the fp32-MFMA render
-    x16 = hip_render(scene, rays, latents, "bf16", retraw=True)
+    with _setenv("NRNERF_X16", "1"):
+        x16 = hip_render(scene, rays, latents, "bf16", retraw=True)
     _assert_x16_is_an_equally_good_rounding(x16, a, ref32)
+    # the default: the coarse pass on the 16x16x32 kernel as well (stand-alone bender + trunk)
+    _assert_x16_coarse_is_an_equally_good_rounding(hip_render(scene, rays, latents, "bf16", retraw=True), a, ref32)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
@@ -1006,14 +1027,19 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
         torch.cuda.synchronize()
         return out
 
-    split16, fused = run(model, False), run(model, True)
+    with _setenv("NRNERF_X16", "1"):           # (the fine pass on the 16x16x32 kernel; 2, the default, moves the coarse pass there as well)
+        split16 = run(model, False)
+    fused = run(model, True)
     assert "fine_input_pts" in fused and "fine_input_pts" not in split16
     # the trunk-only pass on the fused pass's own 32x32x16 tiles (NRNERF_X16=0) is what the bit-for-bit statement is about; the default
     # trunk-only pass of the 16-bit modes (16x16x32 kernel; width 256, no view branch) is as good a rounding of the fp32 network
     with _setenv("NRNERF_X16", "0"):
         split = run(model, False)
     if precision != "f32":
-        _assert_x16_is_an_equally_good_rounding(split16, split, run(R.get_model(coarse, fine, precision="f32"), False))
+        ref32 = run(R.get_model(coarse, fine, precision="f32"), False)
+        _assert_x16_is_an_equally_good_rounding(split16, split, ref32)
+        if cfg.N_importance > 0:
+            _assert_x16_coarse_is_an_equally_good_rounding(run(model, False), split, ref32)
     if precision == "bf16":
         _assert_split_equals_fused_up_to_conversion_ties(split, fused, views=cfg.use_viewdirs)
         return
