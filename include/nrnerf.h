@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NRNERF_ABI_VERSION 6
+#define NRNERF_ABI_VERSION 7
 /* samples per ray and pass: nrnerf_render and the training entry points (the split fine bender -- nrnerf_merge_rows,
  * nrnerf_composite_args.rank_new -- up to 256 merged samples: 8-bit ranks) */
 #define NRNERF_MAX_SAMPLES 1024
@@ -103,7 +103,15 @@ typedef struct nrnerf_model_desc {
     int32_t exact_viewdirs;   /* with bender + view-dependent head: 0 = finite-difference directions (the configs' default,
                                  approx_nonrigid_viewdirs=True, rnh:316-356); 1 = normalised J . d from the bender's
                                  Jacobian (exact_nonrigid_viewdirs, rnh:358-385) */
+    uint32_t flags;           /* bits of nrnerf_model_flags, since ABI 7; 0 = the defaults */
 } nrnerf_model_desc;
+
+/* Kernel-selection switches of a model handle (ABI 7: fields of the call, not process environment -- the library reads no
+ * environment variable).  They select among kernels that compute the same function; 0 is what a caller wants. */
+typedef enum nrnerf_model_flags {
+    NRNERF_MODEL_FORCE_GENERIC = 1u << 0,  /* the run-time-parameterised kernel also for a compiled shape (tests: one route against the other) */
+    NRNERF_MODEL_NO_X16_F16 = 1u << 1      /* NRNERF_PREC_F16: no 16x16x32 images; the split path then stays bit-identical to the fused pass */
+} nrnerf_model_flags;
 
 typedef struct nrnerf_model nrnerf_model;   /* opaque: packed weights resident in HBM */
 
@@ -166,7 +174,19 @@ typedef struct nrnerf_render_args {
     const float* noise_coarse;  /* [N, S]   raw_noise_std * randn, added to sigma before the relu       train.py:753,761 */
     const float* u_fine;        /* [N, I]   uniforms for sample_pdf instead of linspace(0,1,I)          rnh:663-665 */
     const float* noise_fine;    /* [N, S']  as noise_coarse, fine pass */
+    uint32_t flags;             /* bits of nrnerf_render_flags, since ABI 7; 0 = the defaults */
 } nrnerf_render_args;
+
+/* Kernel-selection switches of one nrnerf_render call (ABI 7; they were environment variables read inside the library up to
+ * ABI 6).  Every combination renders the same function; the parity tests run the routes against each other. */
+typedef enum nrnerf_render_flags {
+    NRNERF_RENDER_FUSED_FINE_BENDER = 1u << 0,  /* no split-bender path: the fine pass bends all S + I samples in the network kernel */
+    NRNERF_RENDER_UNFUSED_COMPOSITE = 1u << 1,  /* the final pass' compositing as a separate launch instead of the network kernel's epilogue */
+    NRNERF_RENDER_SPLIT_COARSE = 1u << 2,       /* split path: stand-alone bender + trunk-only kernel for the coarse pass as well
+                                                   (implied when the coarse pass runs on the 16x16x32 kernel) */
+    NRNERF_RENDER_NO_X16 = 1u << 3,             /* every pass on the 32x32x16 kernels */
+    NRNERF_RENDER_X16_FINE_ONLY = 1u << 4       /* 16x16x32 kernel for the fine pass only (the coarse pass on the fused-bender 32x32x16 kernel) */
+} nrnerf_render_flags;
 
 /* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */
 #define NRNERF_NUM_KERNELS 6

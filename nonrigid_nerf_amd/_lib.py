@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRNERF_LIB selects an alternative build of the same library (tuning experiments, see csrc/Makefile)
 LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_SAMPLES = 1024        # NRNERF_MAX_SAMPLES (include/nrnerf.h): per ray and pass of nrnerf_render; training: 256
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
@@ -54,7 +54,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("precision", C.c_int32), ("multires", C.c_int32),
                 ("multires_views", C.c_int32), ("device", C.c_int32),
                 ("bender", C.POINTER(BenderDesc)), ("coarse", C.POINTER(MlpDesc)), ("fine", C.POINTER(MlpDesc)),
-                ("exact_viewdirs", C.c_int32)]
+                ("exact_viewdirs", C.c_int32), ("flags", C.c_uint32)]
 
 
 class SampleOutputs(C.Structure):
@@ -78,7 +78,40 @@ class RenderArgs(C.Structure):
                 ("coarse", SampleOutputs), ("fine", SampleOutputs),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("lindisp", C.c_int32), ("white_bkgd", C.c_int32),
-                ("u_coarse", C.c_void_p), ("noise_coarse", C.c_void_p), ("u_fine", C.c_void_p), ("noise_fine", C.c_void_p)]
+                ("u_coarse", C.c_void_p), ("noise_coarse", C.c_void_p), ("u_fine", C.c_void_p), ("noise_fine", C.c_void_p),
+                ("flags", C.c_uint32)]
+
+
+# include/nrnerf.h: nrnerf_model_flags / nrnerf_render_flags (ABI 7: kernel-selection switches are fields of the call; the library
+# reads no environment variable).  The test switches NRNERF_* of the environment are mapped to them HERE, on the Python side.
+MODEL_FORCE_GENERIC, MODEL_NO_X16_F16 = 1 << 0, 1 << 1
+RENDER_FUSED_FINE_BENDER, RENDER_UNFUSED_COMPOSITE, RENDER_SPLIT_COARSE, RENDER_NO_X16, RENDER_X16_FINE_ONLY = (1 << i for i in range(5))
+
+
+def model_flags_from_env() -> int:
+    """NRNERF_FORCE_GENERIC=1 / NRNERF_X16_F16=0 -> nrnerf_model_desc.flags (read when a handle is created)."""
+    f = 0
+    if os.environ.get("NRNERF_FORCE_GENERIC") == "1":
+        f |= MODEL_FORCE_GENERIC
+    if os.environ.get("NRNERF_X16_F16", "1") == "0":
+        f |= MODEL_NO_X16_F16
+    return f
+
+
+def render_flags_from_env() -> int:
+    """NRNERF_FUSED_FINE_BENDER=1, NRNERF_UNFUSED_COMPOSITE=1, NRNERF_SPLIT_COARSE=1, NRNERF_X16=0|1|2 -> nrnerf_render_args.flags
+    (read per call: the parity tests render one scene through several kernel routes in one process)."""
+    f = 0
+    if os.environ.get("NRNERF_FUSED_FINE_BENDER") == "1":
+        f |= RENDER_FUSED_FINE_BENDER
+    if os.environ.get("NRNERF_UNFUSED_COMPOSITE") == "1":
+        f |= RENDER_UNFUSED_COMPOSITE
+    if os.environ.get("NRNERF_SPLIT_COARSE") == "1":
+        f |= RENDER_SPLIT_COARSE
+    x16 = os.environ.get("NRNERF_X16")
+    if x16 is not None and x16.strip() != "":
+        f |= {0: RENDER_NO_X16, 1: RENDER_X16_FINE_ONLY}.get(int(x16), 0)
+    return f
 
 
 class Profile(C.Structure):

@@ -295,10 +295,10 @@ void pack_pass_x16(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
 // does the 16x16x32 trunk kernel have this network?  (compiled architecture 0's trunk, output_linear head, 16-bit precision)
 bool x16_eligible(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, bool any_16bit = false) {
     using A = ArchDefault;
-    // (both 16-bit modes; NRNERF_X16_F16=0 at model creation keeps "f16" mode on the 32x32x16 kernels only.  At render time NRNERF_X16=0
-    //  selects the 32x32x16 trunk-only kernel per call: the split path is then bit-identical to the fused-bender fine pass in "f16" mode,
-    //  which tests/test_gpu_parity.py asserts)
-    static const bool f16_too = [] { const char* e = std::getenv("NRNERF_X16_F16"); return !e || std::atoi(e) != 0; }();
+    // (both 16-bit modes; nrnerf_model_desc::flags & NRNERF_MODEL_NO_X16_F16 keeps "f16" mode on the 32x32x16 kernels only.  At render
+    //  time NRNERF_RENDER_NO_X16 selects the 32x32x16 trunk-only kernel per call: the split path is then bit-identical to the
+    //  fused-bender fine pass in "f16" mode, which tests/test_gpu_parity.py asserts)
+    const bool f16_too = !(d.flags & NRNERF_MODEL_NO_X16_F16);
     if (d.precision != NRNERF_PREC_BF16 && !(d.precision == NRNERF_PREC_F16 && (f16_too || any_16bit))) return false;
     if (m.use_viewdirs || m.time_conditioned || d.multires != A::L || m.depth != A::D || m.width != A::W || m.skip != A::SKIP) return false;
     if (m.output_ch != 4 && m.output_ch != 5) return false;
@@ -1174,9 +1174,8 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) try {
         rc = pack_dispatch(*desc, *desc->fine, pf, &arch_f, false, &lay);
         if (rc == NRNERF_OK && arch_f != arch_id) rc = NRNERF_ERR_UNSUPPORTED;      // e.g. --netwidth_fine != --netwidth: generic below
     }
-    // NRNERF_FORCE_GENERIC=1 (read per call): the generic kernel also for the compiled shapes (tests: the two routes against each other)
-    const char* fg_env = std::getenv("NRNERF_FORCE_GENERIC");
-    const bool force_generic = fg_env && fg_env[0] == '1';
+    // NRNERF_MODEL_FORCE_GENERIC: the generic kernel also for the compiled shapes (tests: the two routes against each other)
+    const bool force_generic = (desc->flags & NRNERF_MODEL_FORCE_GENERIC) != 0;
     if (rc == NRNERF_OK && force_generic && !(desc->exact_viewdirs && desc->bender && desc->coarse->use_viewdirs)) rc = NRNERF_ERR_UNSUPPORTED;
     if (rc == NRNERF_ERR_UNSUPPORTED) return create_generic(*desc, lay, out);
     if (rc != NRNERF_OK) return rc;
@@ -1413,12 +1412,12 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     float* z_coarse = (float*)ws;
     ws += align_up((size_t)N * S * sizeof(float), 256);
     // Split-bender path: bender, no view-dependent head, a fine pass, no per-sample detail outputs (those are written by
-    // the fused kernels).  NRNERF_FUSED_FINE_BENDER=1 keeps the fused fine pass (A/B and bit-identity tests).
+    // the fused kernels).  NRNERF_RENDER_FUSED_FINE_BENDER keeps the fused fine pass (A/B and bit-identity tests).
     auto any_detail = [](const nrnerf_sample_outputs& o) {
         return o.visibility_weights || o.opacity_alpha || o.initial_input_pts || o.unmasked_offsets || o.masked_offsets ||
                o.input_pts || o.rigidity_mask;
     };
-    static const bool force_fused = [] { const char* e = std::getenv("NRNERF_FUSED_FINE_BENDER"); return e && e[0] == '1'; }();
+    const bool force_fused = (a->flags & NRNERF_RENDER_FUSED_FINE_BENDER) != 0;
     // (the stand-alone bender kernel indexes its 32-sample blocks with 32 bits: beyond 2^31 blocks stay on the fused kernels)
     // (8-bit ranks among the merged depths: beyond 256 samples per ray the fused-bender fine pass renders)
     const bool split = m->split_ok && I > 0 && !a->detailed_output && !any_detail(a->coarse) && !any_detail(a->fine) && !force_fused &&
@@ -1556,14 +1555,13 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     na.knobs = kn;
     // The coarse pass stays fused by default: measured on MI355X (round 2), bender kernel 1.56 ms + trunk-only coarse
     // kernel 8.72 ms = 10.28 ms against 10.22 ms fused -- nothing is saved there, unlike in the fine pass where a third of
-    // the samples skips the bender.  NRNERF_SPLIT_COARSE=1 splits it as well (A/B).
-    static const bool split_coarse_on = [] { const char* e = std::getenv("NRNERF_SPLIT_COARSE"); return e && e[0] == '1'; }();
+    // the samples skips the bender.  NRNERF_RENDER_SPLIT_COARSE splits it as well (A/B).
+    const bool split_coarse_on = (a->flags & NRNERF_RENDER_SPLIT_COARSE) != 0;
     // The 16x16x32 trunk-only kernel (nrnerf_net_x16.h) for the passes of the split path when the call wants no detail outputs.
-    // NRNERF_X16 (read per call, like NRNERF_UNFUSED_COMPOSITE: the parity tests run the kernels side by side in one process):
-    // 0 = the 32x32x16 kernels of nrnerf_net_mb.h, 1 = the fine pass only, 2 (default) = the coarse pass too -- stand-alone bender
-    // over the S coarse samples + 16x16x32 trunk instead of the fused-bender 32x32x16 kernel.
-    const char* x16_env = std::getenv("NRNERF_X16");
-    const int x16_mode = x16_env ? std::atoi(x16_env) : 2;
+    // Per call (nrnerf_render_args::flags; the parity tests run the kernels side by side in one process): NRNERF_RENDER_NO_X16 = the
+    // 32x32x16 kernels of nrnerf_net_mb.h, NRNERF_RENDER_X16_FINE_ONLY = the fine pass only, default = the coarse pass too --
+    // stand-alone bender over the S coarse samples + 16x16x32 trunk instead of the fused-bender 32x32x16 kernel.
+    const int x16_mode = (a->flags & NRNERF_RENDER_NO_X16) ? 0 : ((a->flags & NRNERF_RENDER_X16_FINE_ONLY) ? 1 : 2);
     const bool x16_coarse = split && x16_mode >= 2 && m->coarse_trunk_x16.stream && !a->detailed_output && !kn.detailed;
     const bool split_coarse = split && (split_coarse_on || x16_coarse);
     // Compositing fused into the FINAL pass' network kernel (north_star: "compositing fused into the ray loop"; the
@@ -1572,10 +1570,8 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // outputs in LDS and composite them itself (nrnerf_composite_ray.h: the composite kernel's own code, so the same bits).
     // The pass' raw array (16 B per sample written and read back) never exists and one launch goes.  The coarse pass of a
     // hierarchical render keeps its composite kernel: sample_pdf and the merge follow it there.
-    // NRNERF_UNFUSED_COMPOSITE=1 keeps the separate launch (A/B and bit-identity tests; read per call so that one process can
-    // render both ways).
-    const char* unfused_env = std::getenv("NRNERF_UNFUSED_COMPOSITE");
-    const bool unfused_composite = unfused_env && unfused_env[0] == '1';
+    // NRNERF_RENDER_UNFUSED_COMPOSITE keeps the separate launch (A/B and bit-identity tests).
+    const bool unfused_composite = (a->flags & NRNERF_RENDER_UNFUSED_COMPOSITE) != 0;
     auto final_composite = [&](int pass_S, const float* zv, const float* noise, const nrnerf_sample_outputs& so, const float* raw4) {
         CompositeArgs c{};
         c.rays = a->rays; c.ray_stride = a->ray_stride;
@@ -1659,12 +1655,10 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     nf.ex = sample_out(a->fine);
     // K3 inside K2 (see final_composite above) whenever K2 is a kernel without a fused bender
     // the split path's trunk-only pass on the 16x16x32 kernel (nrnerf_net_x16.h) when the call wants no detail outputs
-    // (NRNERF_X16=0: the 32x32x16 kernel of nrnerf_net_mb.h)
+    // (NRNERF_RENDER_NO_X16: the 32x32x16 kernel of nrnerf_net_mb.h)
     // (read per call, like NRNERF_UNFUSED_COMPOSITE: the parity tests run both kernels in one process)
     const bool x16 = split && x16_mode != 0 && m->fine_trunk_x16.stream && !a->detailed_output && !kn.detailed;
-    // (the 16x16x32 kernel's groups: 4 waves x the fewest rays whose 16-sample blocks fill whole iterations of 4 blocks)
-    const int bpr16 = (SF + 15) / 16;
-    const long long x16_group = 4LL * ((bpr16 % 4 == 0) ? 1 : ((bpr16 % 2 == 0) ? 2 : 4));
+    const long long x16_group = x16_rays_per_group(SF);          // (nrnerf_net_x16.hip: the kernel's own ray-group size)
     const bool fuse_fine = (split || !m->has_bend) && !unfused_composite && SF <= 256 &&
                            (x16 ? (long long)N >= x16_group * m->num_cus : enough_rays_to_fuse(SF));
     if (fuse_fine) { nf.fuse_on = 1; nf.fuse = final_composite(SF, z_fine, a->noise_fine, a->fine, nullptr); nf.raw4 = nullptr; }
@@ -1886,8 +1880,7 @@ int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* 
     const char* dpre = (const char*)a->d_pre;
     WgradArgs w{};
     w.nblocks = f32 ? M : nblocks; w.pstride = NRNERF_WGRAD_STRIDE(D, W);
-    static const int wgrad_sync = [] { const char* e = std::getenv("NRNERF_WGRAD_SYNC"); return e ? std::atoi(e) : NRN_WGRAD_SYNC_DEFAULT; }();
-    w.sync_every = wgrad_sync;
+    w.sync_every = NRN_WGRAD_SYNC_DEFAULT;       // (swept in round 3, tools/experiments/README.md; a build-time constant: the library reads no environment)
     // a 64-column job (encoding, head) loads 2 TR + 2 fragments per block and wave, a hidden-to-hidden one 2 TR + 2 TCW:
     // give it that share of the workgroups, so that all workgroups of the launch finish together
     // (fp32 mode: the same split; its 64-column jobs issue a quarter / half of a hidden-to-hidden job's MFMAs per sample and

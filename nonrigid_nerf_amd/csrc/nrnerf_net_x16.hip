@@ -17,6 +17,13 @@ hipError_t NRN_CAT(launch_net_x16_e, NRN_X16_EPL)(int precision, const NetArgs& 
 }
 
 #if NRN_X16_EPL == 0
+// rays of one fused-compositing group (one workgroup iteration set): WAVES waves x the fewest rays whose 16-sample blocks fill whole
+// iterations of NB blocks -- the API layer's "enough rays to fuse" threshold asks here instead of restating the kernel's mapping
+long long x16_rays_per_group(int S) {
+    const int bpr = (S + 15) / 16, NB = NRN_X16_NB;
+    const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
+    return (long long)NRN_X16_WAVES * RW;
+}
 hipError_t launch_net_x16_e1(int, const NetArgs&, int, hipStream_t);
 hipError_t launch_net_x16_e2(int, const NetArgs&, int, hipStream_t);
 hipError_t launch_net_x16_e3(int, const NetArgs&, int, hipStream_t);

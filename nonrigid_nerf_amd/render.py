@@ -139,7 +139,7 @@ def _bender_desc(rb, keep: _Keep) -> _lib.BenderDesc:
     return d
 
 
-def build_model_desc(network_fn, network_fine, precision: str, device_index: int):
+def build_model_desc(network_fn, network_fine, precision: str, device_index: int, flags: int = 0):
     """ModelDesc for the C ABI from reference-style modules.  Returns (desc, keepalive)."""
     keep = _Keep()
     rb = network_fn.ray_bender[0] if getattr(network_fn, "ray_bender", None) else None
@@ -152,6 +152,7 @@ def build_model_desc(network_fn, network_fine, precision: str, device_index: int
     icv = int(getattr(network_fn, "input_ch_views", 0))
     desc.multires_views = (icv - 3) // 6 if icv >= 3 else 0
     desc.device = device_index
+    desc.flags = int(flags)
     cm = _mlp_desc(network_fn, keep)
     keep.objs.append(cm)
     desc.coarse = C.pointer(cm)
@@ -289,14 +290,15 @@ def _fingerprint(mods):
 class Model:
     """Owns one ``nrnerf_model`` handle (packed weights resident in HBM on one device)."""
 
-    def __init__(self, network_fn, network_fine=None, precision: str | None = None, device=None):
+    def __init__(self, network_fn, network_fine=None, precision: str | None = None, device=None, flags: int | None = None):
         self.lib = _lib.load()
+        self.flags = _lib.model_flags_from_env() if flags is None else int(flags)          # nrnerf_model_flags
         self.precision = _lib.canonical_precision(precision or _DEFAULT_PRECISION)
         dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
         if dev.type != "cuda":
             raise RuntimeError("nonrigid_nerf_amd renders on a ROCm device only (got %s)" % dev)
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
-        desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
+        desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index, self.flags)
         self.has_bender = bool(desc.bender)
         # nrnerf_bender_* / nrnerf_bender_divergence_* are available (the library's own rule: training_eligible in
         # csrc/nrnerf_api.cpp): a bender, not an f16 handle
@@ -318,7 +320,7 @@ class Model:
         """Re-pack changed weights of the same architecture into this handle (``nrnerf_model_update``: no allocation,
         ordered after the work queued on the current stream).  Returns False when the modules describe a different
         model (the caller then builds a new handle)."""
-        desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index)
+        desc, keep = build_model_desc(network_fn, network_fine, self.precision, self.device.index, self.flags)
         with torch.cuda.device(self.device):
             # renders queued on OTHER streams from this cached handle may still be reading the weight buffers: wait for
             # the whole device before overwriting them (updates are rare: an optimiser step or a load_state_dict)
@@ -460,6 +462,7 @@ class Model:
             if I > 0:
                 fill(a.fine, "fine_", SF)
         a.detailed_output = int(detailed_output)
+        a.flags = _lib.render_flags_from_env()
         if rigidity_cutoff is not None:
             a.has_rigidity_cutoff, a.rigidity_cutoff = 1, float(rigidity_cutoff)
         if test_time_scaling is not None:
@@ -525,7 +528,8 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
     _watch_optimizers()
     rb = _bender_of(network_fn)
     dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
-    key = (_wref(network_fine), _wref(rb), precision, str(dev), bool(getattr(network_fn, "approx_nonrigid_viewdirs", True)))
+    mflags = _lib.model_flags_from_env()
+    key = (_wref(network_fine), _wref(rb), precision, str(dev), bool(getattr(network_fn, "approx_nonrigid_viewdirs", True)), mflags)
     fp = _fingerprint([network_fn, network_fine, rb])
     with _cache_lock:
         per = _cache.setdefault(network_fn, {})
@@ -543,7 +547,7 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
             per[key] = (fp, hit[1])                                            # weights changed: refreshed in place
             return hit[1]
         try:
-            model = Model(network_fn, network_fine, precision, dev)
+            model = Model(network_fn, network_fine, precision, dev, flags=mflags)
         except Unsupported as e:
             per[key] = (fp, e)
             raise

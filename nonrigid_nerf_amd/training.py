@@ -76,44 +76,6 @@ def _chunks(m: int, target: int = 4096) -> int:
     return b
 
 
-_BMM_OUT_F32 = None
-
-
-def _bmm_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """torch.bmm with fp32 results: for 16-bit operands through ``out_dtype`` where this torch has it (the partial products of a
-    weight gradient are then not rounded to 16 bits before they are added)."""
-    global _BMM_OUT_F32
-    if a.dtype == torch.float32:
-        return torch.bmm(a, b)
-    if _BMM_OUT_F32 is None:
-        try:
-            torch.bmm(a[:1, :1, :1], b[:1, :1, :1], out_dtype=torch.float32)
-            _BMM_OUT_F32 = True
-        except (TypeError, RuntimeError):
-            _BMM_OUT_F32 = False
-    return torch.bmm(a, b, out_dtype=torch.float32) if _BMM_OUT_F32 else torch.bmm(a, b)
-
-
-def _wgrad(dz: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dz^T x for dz [M, O], x [M, K] -> [O, K] fp32.  A [O x M] x [M x K] GEMM with M in the hundreds of thousands and
-    O, K <= 320 gives a library GEMM two output tiles to parallelise over; cut along M into a batch of partial products
-    (one batched GEMM over ~50-100 blocks fills the chip) and add the partials."""
-    M = dz.shape[0]
-    B = _chunks(M)
-    if B == 1:
-        return (dz.t() @ x).float()
-    part = _bmm_f32(dz.view(B, M // B, -1).transpose(1, 2), x.view(B, M // B, -1))       # [B, O, K]
-    return part.sum(0, dtype=torch.float32)
-
-
-def _colsum(g: torch.Tensor) -> torch.Tensor:
-    """Column sums of g [M, O] in fp32, in two stages over the row blocks of `_chunks` (one reduction over millions of rows
-    into a few hundred outputs runs at 0.4 TB/s in the library)."""
-    M = g.shape[0]
-    B = _chunks(M)
-    return g.sum(0, dtype=torch.float32) if B == 1 else g.view(B, M // B, -1).sum(1, dtype=torch.float32).sum(0)
-
-
 def _rows4(x: torch.Tensor, M: int) -> torch.Tensor:
     """[.., 3] float32 -> the [M,4] rows (xyz + one float the kernels ignore) the C ABI takes.  A tensor that already is the
     xyz part of such rows (what _Bender returns and _Trunk.backward hands back) is re-viewed, anything else copied."""
@@ -621,45 +583,21 @@ class _Bender(torch.autograd.Function):
             _lib.check(model.lib.nrnerf_bender_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_backward")
         if not ctx.needs_input_grad[5]:              # frozen bender (e.g. fitting test-time latent codes): no weight gradients
             return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, None)
-        if NATIVE_BENDER_WGRAD:
-            # every weight / bias gradient of both MLPs in one launch (nrnerf_bender_wgrad): partial sums per wave, added here
-            nparts = 4 * max(1, min(_num_cus(dev), (M + 1023) // 1024))
-            nj = BD + RD
-            parts = torch.empty(nparts, nj, _lib.BENDER_WGRAD_SLOT, dtype=torch.float32, device=dev)
-            w = _lib.BenderWgradArgs()
-            w.struct_size = C.sizeof(_lib.BenderWgradArgs)
-            w.n_rays, w.n_samples, w.n_partials = N, S, nparts
-            w.rays, w.ray_stride, w.latents, w.latent_stride, w.z = rays.data_ptr(), int(rays.stride(0)), lat.data_ptr(), int(lat.stride(0)), z.data_ptr()
-            w.acts_offsets, w.acts_rigidity = acts_b.data_ptr(), acts_r.data_ptr()
-            w.dz_offsets, w.dz_rigidity, w.dz_out4, w.partials = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), parts.data_ptr()
-            with torch.cuda.device(dev):
-                _lib.check(model.lib.nrnerf_bender_wgrad(model.handle, C.byref(w), _stream(dev)), "nrnerf_bender_wgrad")
-            # added up into ONE flat gradient (the parameters' shapes back to back) for the bender's token
-            index, _ = _bender_grad_index(rb, dev, divergence=False)
-            return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index))
-        # library route.  weight gradients dW_i = dz_i^T x_i over the stored arrays (batched library GEMMs, see _wgrad).
-        dz_b, dz_r, acts_b, acts_r = dz_b.float(), dz_r.float(), acts_b.float(), acts_r.float()
-        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(M, 3)
-        # x_0 = [p, latent]: the latent columns are constant along a ray, so their part is (per-ray sums of dz_0)^T latents.
-        dw0 = torch.cat([_wgrad(dz_b[0], pts), dz_b[0].view(N, S, BW).sum(1).t() @ lat], 1)
-        db_b = dz_b.sum(1)                                                                     # [BD-1, BW]
-        grads = [dw0, db_b[0]]
-        if BD > 2:
-            Bc = _chunks(M)
-            c = M // Bc
-            part = torch.bmm(dz_b[1:BD - 1].reshape((BD - 2) * Bc, c, BW).transpose(1, 2), acts_b[0:BD - 2].reshape((BD - 2) * Bc, c, BW))
-            dwh = part.view(BD - 2, Bc, BW, BW).sum(1)
-            for i in range(1, BD - 1):
-                grads += [dwh[i - 1], db_b[i]]
-        grads.append(_wgrad(dz_out4, acts_b[BD - 2])[0:3])                                     # network[-1]: 3 x BW
-        if rb.network[BD - 1].bias is not None:
-            grads.append(dz_out4[:, 0:3].sum(0))
-        db_r = dz_r.sum(1)
-        grads += [_wgrad(dz_r[0], pts), db_r[0]]
-        for i in range(1, RD - 1):
-            grads += [_wgrad(dz_r[i], acts_r[i - 1]), db_r[i]]
-        grads += [_wgrad(dz_out4, acts_r[RD - 2])[3:4], dz_out4[:, 3].sum(0, keepdim=True)]
-        return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, torch.cat([g_.reshape(-1).float() for g_ in grads]))
+        # every weight / bias gradient of both MLPs in one launch (nrnerf_bender_wgrad): partial sums per wave, added here
+        nparts = 4 * max(1, min(_num_cus(dev), (M + 1023) // 1024))
+        nj = BD + RD
+        parts = torch.empty(nparts, nj, _lib.BENDER_WGRAD_SLOT, dtype=torch.float32, device=dev)
+        w = _lib.BenderWgradArgs()
+        w.struct_size = C.sizeof(_lib.BenderWgradArgs)
+        w.n_rays, w.n_samples, w.n_partials = N, S, nparts
+        w.rays, w.ray_stride, w.latents, w.latent_stride, w.z = rays.data_ptr(), int(rays.stride(0)), lat.data_ptr(), int(lat.stride(0)), z.data_ptr()
+        w.acts_offsets, w.acts_rigidity = acts_b.data_ptr(), acts_r.data_ptr()
+        w.dz_offsets, w.dz_rigidity, w.dz_out4, w.partials = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), parts.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_bender_wgrad(model.handle, C.byref(w), _stream(dev)), "nrnerf_bender_wgrad")
+        # added up into ONE flat gradient (the parameters' shapes back to back) for the bender's token
+        index, _ = _bender_grad_index(rb, dev, divergence=False)
+        return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index))
 
 
 def _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r):
@@ -788,9 +726,6 @@ def _merge_rows(coarse_parts, new_parts, rank_new, rays, z_merged, scaling, deta
         masked = masked * scaling                                                                # rnh:568-569
     return pts, bent, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
 
-
-# True: the bender's weight gradients come from nrnerf_bender_wgrad (one launch); False: from batched library GEMMs.
-NATIVE_BENDER_WGRAD = True
 
 # True: the ray bender runs on the HIP library (_Bender).  False: as torch ops on the module's parameters (`bend`).
 NATIVE_BENDER = True
