@@ -281,6 +281,16 @@ def main():
     else:                # N = 1: one frame on one GPU is both the weak and the strong workload
         other = dict(scaling_record("strong" if args.scaling == "weak" else "weak", 1, n, args.steps, dt, per_rank_dt),
                      note="identical to the other scaling at N = 1 (not run twice)")
+    # every rank's own kernel time per step (HIP events around each launch on its render stream): lets a scaling record separate
+    # kernel time from launch / collective time -- per-rank wall minus this is what the launches and the all-gather cost
+    names = list(prof.keys())
+    kern_own = torch.tensor([prof[k]["ms"] / args.steps for k in names], dtype=torch.float64)
+    per_rank_kernels = [{k: round(float(v), 4) for k, v in zip(names, kern_own) if v > 0}]
+    if world > 1:
+        t = kern_own.to("cpu" if one_gpu else dev)
+        allk = torch.empty(world, len(names), dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allk, t)
+        per_rank_kernels = [{k: round(float(v), 4) for k, v in zip(names, row) if v > 0} for row in allk.cpu()]
     rccl_ranks = 1
     if world > 1:        # counted by an actual collective on the job's backend, not copied from the environment
         one = torch.ones(1, device="cpu" if one_gpu else dev)
@@ -319,16 +329,27 @@ def main():
                     "avg_launch_ms": round(kk["ms"] / max(kk["launches"], 1), 4),
                     "issued_mfma_tflops": round(issued, 2), "frac_issued_mfma": round(issued / peak, 4)}
         rf = roof(k)
-        traffic, traffic_note = pmc_traffic(args)
+        traffic, traffic_note, traffic_source = pmc_traffic(args)
+        # the coarse pass as ONE figure: with the coarse pass on the 16x16x32 kernel it is two launches (stand-alone bender over the
+        # 64 coarse samples + trunk), priced together against the same reference flops as the fused kernel it replaced
+        cp = dict(prof["net_coarse"])
+        if prof.get("bend_coarse", {}).get("launches"):
+            for key in ("ms", "flops", "mfma_flops"):
+                cp[key] = prof["net_coarse"][key] + prof["bend_coarse"][key]
+        coarse_roof = roof(cp)
+        coarse_roof["launches_per_pass"] = 2 if prof.get("bend_coarse", {}).get("launches") else 1
+        coarse_roof["trunk_kernel_alone"] = roof(prof["net_coarse"])
         # (16-bit modes with a ray bender and no view branch: the split path's trunk-only pass on 16x16x32 MFMAs, nrnerf_net_x16.h, unless NRNERF_X16=0)
-        x16 = (args.precision in ("bf16", "f16") and os.environ.get("NRNERF_X16", "1") != "0" and args.netwidth == 256
-               and not (args.precision == "f16" and os.environ.get("NRNERF_X16_F16", "1") == "0")
+        from nonrigid_nerf_amd import _lib
+        x16 = (args.precision in ("bf16", "f16") and not (_lib.render_flags_from_env() & _lib.RENDER_NO_X16) and args.netwidth == 256
+               and not (args.precision == "f16" and (_lib.model_flags_from_env() & _lib.MODEL_NO_X16_F16))
+               and not (_lib.model_flags_from_env() & _lib.MODEL_FORCE_GENERIC)
                and not (args.use_viewdirs or args.exact_viewdirs))
         roofline = {"bound": "mfma", "kernel": ("net_kernel_x16" if x16 else "net_kernel") + " (fine pass, 192 samples/ray)",
                     "achieved": rf["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": rf["frac"],
                     "avg_launch_ms": rf["avg_launch_ms"], "issued_mfma_tflops": rf["issued_mfma_tflops"], "frac_issued_mfma": rf["frac_issued_mfma"],
-                    "traffic": traffic, "traffic_unit": traffic_note,
-                    "coarse_pass": roof(prof["net_coarse"]),
+                    "traffic": traffic, "traffic_unit": traffic_note, "traffic_source": traffic_source,
+                    "coarse_pass": coarse_roof,
                     "kernels_ms_per_step": {nm: round(v["ms"] / args.steps, 4) for nm, v in prof.items() if v["launches"]},
                     # context, not the peak: what a plain hipBLASLt GEMM sustains on this box right now (the chip
                     # clocks down under MFMA load)
@@ -340,12 +361,9 @@ def main():
                "vs_baseline": None, "dtype": args.precision,
                "data": ("synthetic: " if args.scene == "synthetic" else "example_sequence: ") + data_desc
                        + (" (NOT A BENCHMARK: all ranks on one GPU, gloo)" if one_gpu else ""),
-               "config": {"workload": "BASELINE config 2: example_sequence-shaped frame (512x384 = 196608 rays/GPU/step), "
-                                      "64 coarse + 128 importance samples, netwidth 256, ray bender on, latent 32"
-                                      + (f"; NON-HEADLINE VARIANT: use_viewdirs={args.use_viewdirs}, bend_depth={args.bend_depth}, "
-                                         f"exact_viewdirs={args.exact_viewdirs}, netwidth={args.netwidth}"
-                                         if (args.use_viewdirs or args.bend_depth != 5 or args.netwidth != 256) else ""),
-                          "scene": args.scene, "rays_per_gpu_per_step": n, "N_samples": 64, "N_importance": 128,
+               "config": {"workload": workload_label(args, cfg, frame_rays, n, world),
+                          "scene": args.scene, "rays_per_gpu_per_step": n, "N_samples": cfg.N_samples, "N_importance": cfg.N_importance,
+                          "netwidth": args.netwidth, "use_viewdirs": bool(args.use_viewdirs), "bend_depth": args.bend_depth,
                           "chunk": args.chunk, "rays_per_launch": min(n, max(args.chunk, R._MAX_RAYS_PER_LAUNCH)),
                           "parallelism": f"rays sharded over {world} rank(s)"
                                          + (", all-gather of [rgb,disp,acc] on a side stream, overlapped with the next frame" if world > 1 else "")},
@@ -356,6 +374,7 @@ def main():
                "mflop_per_ray_algorithmic": round(flops_per_ray / 1e6, 2),
                "end_to_end_tflops": round(value * flops_per_ray / 1e12, 2),
                "untimed_extra_frames": extra_frames,
+               "per_rank_kernels_ms_per_step": per_rank_kernels,
                "roofline": roofline}
         res.update(extra)
         if world == 1 and not args.no_cpu_baseline:
@@ -365,6 +384,26 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def workload_label(args, cfg, frame_rays, rays_per_rank, world):
+    """config.workload, built from the arguments of THIS run: which BASELINE.json config it is (only when it is one), else what differs."""
+    default_net = not (args.use_viewdirs or args.exact_viewdirs or args.bend_depth != 5 or args.netwidth != 256)
+    shape = (f"{frame_rays} rays per {'frame (sharded over the ranks)' if args.scaling == 'strong' and world > 1 else 'GPU and step'}"
+             + (" (= one 512x384 frame)" if frame_rays == 196608 else " (= one 1920x1080 frame)" if frame_rays == 2073600 else "")
+             + f", {cfg.N_samples} coarse + {cfg.N_importance} importance samples, netwidth {args.netwidth}, "
+             + ("view-dependent head (" + ("exact Jacobian" if args.exact_viewdirs else "finite-difference") + " directions), " if args.use_viewdirs or args.exact_viewdirs else "")
+             + f"ray bender {args.bend_depth} x 64, latent 32, {args.precision}, chunk {args.chunk}"
+             + (f", at most {args.max_rays_per_launch} rays per launch" if args.max_rays_per_launch > 0 else ""))
+    if default_net and frame_rays == 196608 and args.precision == "bf16" and args.max_rays_per_launch == 0:
+        name = "BASELINE config 3 (one frame sharded over the ranks)" if (args.scaling == "strong" and world > 1) else "BASELINE config 2"
+    elif args.use_viewdirs and not args.exact_viewdirs and args.bend_depth == 7 and args.netwidth == 256:
+        name = "BASELINE config 4 (view-dependent head, deeper ray-bending MLP; one latent per frame)"
+    elif default_net and frame_rays == 2073600 and args.precision == "f16" and args.max_rays_per_launch == 65536:
+        name = "BASELINE config 5 (1080p frame in 65 536-ray launches, f16 weights)"
+    else:
+        name = "NOT a BASELINE.json config (variant run)"
+    return f"{name}: {shape}"
 
 
 def scaling_record(scaling, world, rays_per_rank, steps, dt_max, per_rank_dt):
@@ -459,20 +498,22 @@ def pmc_traffic(args):
     path = _latest_profile("_pmc_fine.json")
     default_arch = not (args.use_viewdirs or args.exact_viewdirs or args.bend_depth != 5 or args.netwidth != 256)
     if args.rays != 196608 or args.precision != "bf16" or not path or not default_arch or os.environ.get("NRNERF_FORCE_GENERIC") == "1":
-        return None, "null: no rocprofv3 --pmc pass of this build and workload on file (profiles/rNN_pmc_fine.json)"
+        return None, "null: no rocprofv3 --pmc pass of this build and workload on file (profiles/rNN_pmc_fine.json)", None
     name = os.path.relpath(path, REPO)
     try:
         with open(path) as f:
             j = json.load(f)
         if j.get("scene") != args.scene:
-            return None, f"null: {name} was collected on the {j.get('scene')} scene"
+            return None, f"null: {name} was collected on the {j.get('scene')} scene", None
         if j.get("kernel_source_sha16") != kernel_source_sha16():
-            return None, f"null: {name} was collected from different kernel sources"
+            return None, f"null: {name} was collected from different kernel sources", None
         return float(j["fine"]["hbm_bytes_per_launch"]), ("bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from rocprofv3 --pmc passes "
                                                           f"of these kernel sources ({name.replace('_pmc_fine.json', '_pmc_summary.txt')}); by design 0.76e9 since the compositing is fused "
-                                                          "into the kernel (16 B/sample of points + 4 B/sample of depths in, 44 B/ray out; was 1.21e9 with raw written out)")
+                                                          "into the kernel (16 B/sample of points + 4 B/sample of depths in, 44 B/ray out; was 1.21e9 with raw written out)",
+                f"committed profile {name}: separate rocprofv3 --pmc passes of this command over the same kernel sources (hash-checked), "
+                "NOT measured in this run -- hardware counters cannot be read from inside the process")
     except Exception as e:
-        return None, f"null: {type(e).__name__}"
+        return None, f"null: {type(e).__name__}", None
 
 
 def cpu_baseline(scene, cfg, args, rays_dev, latents_dev):
@@ -509,8 +550,12 @@ def cpu_baseline(scene, cfg, args, rays_dev, latents_dev):
                       f"{threads} threads of {os.cpu_count()} host cores, best of 3: {dt:.1f} s (all: {', '.join(f'{x:.1f}' for x in times)} s)",
             "thread_sweep_rays_per_s": {str(k): v for k, v in sweep.items()},
             "why_not_all_cores": "the oracle's per-chunk ops are too small to amortise a 256-way fork/join: throughput peaks at a few dozen threads (sweep above)",
-            "port_vs_reference": "the unmodified reference (train.render) and this port were timed side by side on the build "
-                                 "container (tools/cpu_reference_vs_port.py, BASELINE.md section 2): port/reference = 0.96-0.99"}
+            "port_vs_reference": {"note": "the unmodified reference (train.render) and this port timed side by side, same rays / weights / "
+                                          "chunk; NOT measured in this run (the GPU box carries no copy of the reference unless "
+                                          "NRNERF_REFERENCE points at one -- then this line has kind 'reference' and port_same_box)",
+                                  "gpu_host_256_core_epyc_32_threads": 1.25, "gpu_host_source": "BASELINE.md section 2, round 3, profiles/r03_bench_bf16.json: reference 675 rays/s, port 845",
+                                  "build_container_8_vcpu": "0.96-0.99", "build_container_source": "BASELINE.md section 2, tools/cpu_reference_vs_port.py",
+                                  "this_host": f"{socket.gethostname()}, {os.cpu_count()} logical cores"}}
     ref = reference_cpu_baseline(scene, rays, latents, threads)
     if ref is None:
         return port

@@ -239,6 +239,10 @@ void nrnerf_model_destroy(nrnerf_model* model);
 /* the nrnerf_precision the handle was created with (decides the layout of nrnerf_trunk_args.acts / d_pre), or
  * NRNERF_ERR_INVALID for NULL */
 int nrnerf_model_precision(const nrnerf_model* model);
+/* 1 when the handle renders on the run-time-parameterised kernel (an architecture outside the compiled set, or
+ * NRNERF_MODEL_FORCE_GENERIC), 0 on the specialised kernels, NRNERF_ERR_INVALID for NULL -- so that a test or a benchmark line can
+ * say which kernels it measured instead of inferring it */
+int nrnerf_model_is_generic(const nrnerf_model* model);
 
 size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples,
                               int32_t n_importance);

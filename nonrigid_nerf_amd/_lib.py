@@ -221,6 +221,7 @@ EXPORTS = {
     "nrnerf_model_update_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "nrnerf_model_destroy": (None, [C.c_void_p]),
     "nrnerf_model_precision": (C.c_int, [C.c_void_p]),
+    "nrnerf_model_is_generic": (C.c_int, [C.c_void_p]),
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),

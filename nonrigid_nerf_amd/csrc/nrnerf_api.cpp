@@ -1308,6 +1308,8 @@ int64_t nrnerf_model_flat_size(const nrnerf_model* m) { return m ? m->flat_float
 
 int nrnerf_model_precision(const nrnerf_model* m) { return m ? m->precision : NRNERF_ERR_INVALID; }
 
+int nrnerf_model_is_generic(const nrnerf_model* m) { return m ? (m->generic ? 1 : 0) : NRNERF_ERR_INVALID; }
+
 int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_t n_floats, void* hip_stream) try {
     if (!m || !flat_params || n_floats != m->flat_floats) return NRNERF_ERR_INVALID;
     DeviceGuard guard(m->device);

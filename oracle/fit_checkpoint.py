@@ -9,6 +9,7 @@ against the fp32 reference render, and of both against ground truth) run on a re
     cp gpurun_out/fitted_latest.tar tests/golden/fitted_latest.tar                      # commit the result
     python oracle/fit_checkpoint.py --arch config4 --out gpurun_out/fitted_config4.tar  # view-dependent head + 7-layer bender
     python oracle/fit_checkpoint.py --arch w128 --out gpurun_out/fitted_w128.tar        # --netwidth 128
+    python oracle/fit_checkpoint.py --arch w192_320 --out gpurun_out/fitted_w192_320.tar   # a NON-compiled shape (generic kernel)
 
 It is a restatement of the reference's training loop on top of ``oracle/nrnerf_oracle.py`` (whose gradients are
 pinned against the reference's own autograd, tests/golden/gradients_64_64.npz):
@@ -75,10 +76,13 @@ def frame_rays(pose, intrin, near, far, use_viewdirs=False):
 #   default  reference defaults (train.py:1004-1010, rnh:406-407)
 #   config4  BASELINE config 4: --use_viewdirs with finite-difference directions (rnh:316-356) and a 7-layer bender
 #   w128     --netwidth 128 --netwidth_fine 128 (train.py:1004-1010)
+#   w192_320 --netwidth 192 --netwidth_fine 320: outside the compiled set (csrc/nrnerf_generic.h renders it)
 ARCHS = {
     "default": dict(),
     "config4": dict(use_viewdirs=True, bend_depth=7),
     "w128": dict(netwidth=128),
+    # NOT a compiled shape: --netwidth 192 --netwidth_fine 320 (coarse != fine) -- the run-time-parameterised kernel's acceptance fixture
+    "w192_320": dict(netwidth=192, netwidth_fine=320),
 }
 
 
@@ -104,9 +108,9 @@ def main():
     cfg = SceneConfig(N_samples=64, N_importance=args.n_importance, near=fx["near"], far=fx["far"], **ARCHS[args.arch])
     rb = RayBenderWeights(depth=cfg.bend_depth)
     init_bender_like_reference(rb)
-    mk = lambda ns: NeRFWeights(W=cfg.netwidth, input_ch_views=cfg.input_ch_views, output_ch=cfg.output_ch,
-                                use_viewdirs=cfg.use_viewdirs, num_ray_samples=ns)             # train.py:595-630
-    coarse, fine = mk(cfg.N_samples), mk(cfg.N_samples + cfg.N_importance)
+    mk = lambda ns, c: NeRFWeights(D=c.netdepth, W=c.netwidth, input_ch_views=c.input_ch_views, output_ch=c.output_ch,
+                                   use_viewdirs=c.use_viewdirs, num_ray_samples=ns)            # train.py:595-630
+    coarse, fine = mk(cfg.N_samples, cfg), mk(cfg.N_samples + cfg.N_importance, cfg.for_fine())
     for m in (rb, coarse, fine):
         m.to(dev)
     latents = torch.zeros(F_, 32, device=dev, requires_grad=True)              # train.py:1443-1448

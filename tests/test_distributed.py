@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size 2, gloo.  Rays sharded by rank + all-gather of the rendered pixels must give
+"""N > 1 path on CPU: world_size 2 and 8, gloo.  Rays sharded by rank + all-gather of the rendered pixels must give
 every rank exactly the single-process image.  The renderer plugged in here is the CPU
 oracle (test infrastructure); on GPUs bench.py plugs in the HIP path and the backend is RCCL."""
 import os
@@ -56,6 +56,77 @@ def test_sharded_render_matches_single_process(tmp_path, n):
         img = torch.load(os.path.join(str(tmp_path), f"img{r}.pt"))
         assert img.shape == (n, 5)
         assert torch.allclose(torch.nan_to_num(img), torch.nan_to_num(full), atol=1e-6), f"rank {r}"
+
+
+def _worker8(rank, world, port, n, out_dir):
+    """One rank of the 8-rank job: `render_sharded` (contiguous ragged shards, some of them EMPTY when n < world) and the
+    overlapped all-gather bench.py uses for a sequence of frames, on one process group."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from nonrigid_nerf_amd.distributed import OverlappedGather
+
+    def render_fn(r, l):           # a closed-form "renderer": every pixel names its own ray, so misplaced shards show
+        return {"rgb_map": r[:, 0:3] * 2.0 + l[:, 0:3], "disp_map": r[:, 3] - l[:, 3], "acc_map": r[:, 4] * l[:, 4]}
+
+    g = torch.Generator().manual_seed(11)
+    rays, lat = torch.randn(n, 8, generator=g), torch.randn(n, 32, generator=g)
+    img = render_sharded(render_fn, rays, lat)
+    lo, hi, per = shard_bounds(n, world, rank)
+    og = OverlappedGather(per, "cpu")
+    frames = []
+    for i in range(4):
+        mine = render_fn(rays[lo:hi] + float(i), lat[lo:hi])
+        pad = {k: torch.cat([v, v.new_zeros((per - (hi - lo),) + v.shape[1:])], 0) for k, v in mine.items()}    # equal blocks: short shards padded
+        frames.append(og.submit(i, pad))
+        if i >= 1:
+            og.pending[(i - 1) & 1].wait()
+            frames[i - 1] = frames[i - 1].clone()
+    og.drain()
+    torch.save({"img": img, "frames": [f.clone() for f in frames]}, os.path.join(out_dir, f"w8_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [5, 61, 200])
+def test_eight_ranks_ragged_shards_and_overlapped_gather(tmp_path, n):
+    """BASELINE config 3's rank count on the CPU tier (gloo, 8 processes): ragged ceil(n / 8) shards -- with n = 5 three ranks own
+    NOTHING, with n = 61 the last rank owns 5 of 8 rows -- through `render_sharded`, and four frames through `OverlappedGather`
+    with double buffering; every rank must end up with every ray's pixels at the ray's own row."""
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(11)
+    rays, lat = torch.randn(n, 8, generator=g), torch.randn(n, 32, generator=g)
+    want = lambda r: torch.cat([r[:, 0:3] * 2.0 + lat[:, 0:3], (r[:, 3] - lat[:, 3])[:, None], (r[:, 4] * lat[:, 4])[:, None]], -1)
+    per = shard_bounds(n, world, 0)[2]
+    for rank in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"w8_{rank}.pt"))
+        assert res["img"].shape == (n, 5) and torch.equal(res["img"], want(rays)), rank
+        for i, full in enumerate(res["frames"]):
+            assert full.shape == (world * per, 5)
+            rows = torch.cat([full[per * r: per * r + (shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0])] for r in range(world)], 0)
+            assert torch.equal(rows, want(rays + float(i))), (rank, i)
+
+
+def test_bench_workload_label_follows_the_arguments():
+    """config.workload of the bench line is built from the run's own arguments: only the headline arguments may call themselves
+    BASELINE config 2, a config-4 / config-5 / variant run says what it is (the config-5 record carried config 2's label)."""
+    import argparse
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module2", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    base = dict(use_viewdirs=False, exact_viewdirs=False, bend_depth=5, netwidth=256, precision="bf16", chunk=32768,
+                max_rays_per_launch=0, scaling="weak")
+    cfg = SceneConfig()
+    lab = lambda frame_rays=196608, world=1, **kw: bench.workload_label(argparse.Namespace(**dict(base, **kw)), cfg, frame_rays, frame_rays, world)
+    assert lab().startswith("BASELINE config 2:") and "196608 rays" in lab()
+    assert lab(world=8, scaling="strong").startswith("BASELINE config 3")
+    assert lab(use_viewdirs=True, bend_depth=7).startswith("BASELINE config 4") and "view-dependent" in lab(use_viewdirs=True, bend_depth=7)
+    l5 = lab(frame_rays=2073600, precision="f16", chunk=65536, max_rays_per_launch=65536)
+    assert l5.startswith("BASELINE config 5") and "2073600" in l5 and "config 2" not in l5
+    for kw in (dict(netwidth=128), dict(precision="f16"), dict(frame_rays=32768), dict(use_viewdirs=True)):
+        assert lab(**kw).startswith("NOT a BASELINE.json config"), kw
 
 
 def test_shard_bounds_cover_everything_once():

@@ -176,11 +176,17 @@ def _loss(out, detailed):
                                                                                    use_viewdirs=True)),
                                                            (1.0, 1.0, True, dict(N_samples=48, N_importance=37, use_viewdirs=True, approx_nonrigid_viewdirs=False)),
                                                            (0.0, 0.0, False, dict(N_importance=64, use_viewdirs=True, approx_nonrigid_viewdirs=False, bend_depth=7)),
-                                                           (1.0, 1.0, True, dict(N_samples=200, N_importance=150))],
+                                                           (1.0, 1.0, True, dict(N_samples=200, N_importance=150)),
+                                                           # the native training cap went from 256 to 1024 samples per pass -- the
+                                                           # composite_bwd instantiations with 6 / 12 / 16 samples per lane, trunk / bender /
+                                                           # wgrad kernels beyond 8 blocks per ray, the non-split fine bender (> 256 merged)
+                                                           (0.0, 0.0, False, dict(N_samples=192, N_importance=128)),
+                                                           (1.0, 1.0, True, dict(N_samples=64, N_importance=450)),
+                                                           (1.0, 0.0, False, dict(N_samples=600, N_importance=300))],
                          ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128", "lindisp_white_bkgd",
                               "viewdirs_detailed_ragged", "viewdirs_no_bender", "config4_viewdirs_deep_bender", "time_conditioned_ragged",
                               "time_conditioned_viewdirs", "exact_viewdirs_detailed_ragged", "exact_viewdirs_deep_bender",
-                              "350_samples_per_ray"])
+                              "350_samples_per_ray", "192_plus_128", "514_samples_detailed", "900_samples"])
 @pytest.mark.parametrize("bender", ["torch_ops", "native"])
 def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, bender):
     """Every parameter of every network + the latent codes, fp32 mode, against the oracle's autograd (eager torch on the
@@ -208,7 +214,7 @@ def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, ben
     if cfg.use_viewdirs and cfg.ray_bending:
         loose = 5e-2
     scene = make_scene(cfg, 1)
-    rays, latents = make_rays(131, 3, cfg)
+    rays, latents = make_rays(131 if cfg.N_samples + cfg.N_importance <= 400 else 37, 3, cfg)
     rb, coarse, fine = _modules(scene)
     lat = latents.to(DEV).requires_grad_(True)
     R.set_precision("f32")
@@ -261,20 +267,26 @@ def O_render_free(scene, rays, latents, perturb, noise, detailed, **flags):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("width,detailed,views", [(256, False, False), (128, False, False), (256, True, False), (256, False, True)],
-                         ids=["w256", "w128", "w256_detailed_loss", "w256_viewdirs"])
-def test_bf16_gradients_point_the_same_way(width, detailed, views):
+@pytest.mark.parametrize("width,detailed,views,S,I", [(256, False, False, 64, 64), (128, False, False, 64, 64), (256, True, False, 64, 64),
+                                                      (256, False, True, 64, 64), (256, False, False, 192, 128), (256, True, False, 300, 400),
+                                                      (128, False, False, 64, 450)],
+                         ids=["w256", "w128", "w256_detailed_loss", "w256_viewdirs", "w256_192_plus_128", "w256_700_samples_detailed", "w128_514_samples"])
+def test_bf16_gradients_point_the_same_way(width, detailed, views, S, I):
     """bf16 training mode (bf16 activations and d z in block-tile layout, relu bit masks, trunk_wgrad): gradient direction and
-    size against fp32 mode (row-major arrays, trunk_wgrad_f32), both compiled trunk widths."""
-    cfg = SceneConfig(N_importance=64, netwidth=width, use_viewdirs=views)
+    size against fp32 mode (row-major arrays, trunk_wgrad_f32), both compiled trunk widths -- and above 256 samples per pass (up to
+    NRNERF_MAX_SAMPLES: more than 8 blocks per ray in every training kernel, composite_bwd with 6 / 12 samples per lane, the fine pass
+    bending all merged samples instead of the split bender)."""
+    cfg = SceneConfig(N_samples=S, N_importance=I, netwidth=width, use_viewdirs=views)
     scene = make_scene(cfg, 1)
+    # (512 rays at every size: the rigidity network's gradients are sums with heavy cancellation -- on 96 rays bf16 and fp32 modes disagree
+    #  about them at 64 + 64 samples as much as at 300 + 400, tools/experiments/debug_bf16_grads_large.py)
     rays, latents = make_rays(512, 3, cfg)
     grads = {}
     for prec in ("f32", "bf16"):
         rb, coarse, fine = _modules(scene)
         lat = latents.to(DEV).requires_grad_(True)
         R.set_precision(prec)
-        out = R.render_rays(rays.to(DEV), coarse, None, 64, N_importance=64, network_fine=fine,
+        out = R.render_rays(rays.to(DEV), coarse, None, S, N_importance=I, network_fine=fine,
                             additional_pixel_information={"ray_bending_latents": lat}, detailed_output=detailed)
         _loss(out, detailed).backward()             # detailed: + the offsets / rigidity regulariser terms and a weights term
         g = {k: p.grad.flatten().float() for k, p in _named(rb, coarse, fine).items() if p.grad is not None}
