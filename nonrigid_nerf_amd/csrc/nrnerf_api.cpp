@@ -21,6 +21,7 @@
 #include "nrnerf.h"
 #include "nrnerf_kernels.h"
 #include "nrnerf_aux.h"
+#include "nrnerf_x16_api.h"
 #include "nrnerf_plan.h"
 
 using namespace nrn;
@@ -295,16 +296,22 @@ void pack_pass_x16(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
 // does the 16x16x32 trunk kernel have this network?  (compiled architecture 0's trunk, output_linear head, 16-bit precision)
 bool x16_eligible(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, bool any_16bit = false) {
     using A = ArchDefault;
+    const bool width_ok = m.width == ArchDefault::W || m.width == ArchNarrow::W;        // the two compiled trunk widths
     // (both 16-bit modes; nrnerf_model_desc::flags & NRNERF_MODEL_NO_X16_F16 keeps "f16" mode on the 32x32x16 kernels only.  At render
     //  time NRNERF_RENDER_NO_X16 selects the 32x32x16 trunk-only kernel per call: the split path is then bit-identical to the
     //  fused-bender fine pass in "f16" mode, which tests/test_gpu_parity.py asserts)
     const bool f16_too = !(d.flags & NRNERF_MODEL_NO_X16_F16);
     if (d.precision != NRNERF_PREC_BF16 && !(d.precision == NRNERF_PREC_F16 && (f16_too || any_16bit))) return false;
-    if (m.use_viewdirs || m.time_conditioned || d.multires != A::L || m.depth != A::D || m.width != A::W || m.skip != A::SKIP) return false;
+    if (m.use_viewdirs || m.time_conditioned || d.multires != A::L || m.depth != A::D || !width_ok || m.skip != A::SKIP) return false;
     if (m.output_ch != 4 && m.output_ch != 5) return false;
     return true;
 }
 void pack_x16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, const FlatLayout* lay = nullptr) {
+    if (m.width == ArchNarrow::W) {
+        if (d.precision == NRNERF_PREC_F16) pack_pass_x16<Shape16, ArchNarrow>(m, d.precision, out, lay);
+        else pack_pass_x16<Shape16Fast, ArchNarrow>(m, d.precision, out, lay);
+        return;
+    }
     if (d.precision == NRNERF_PREC_F16) pack_pass_x16<Shape16, ArchDefault>(m, d.precision, out, lay);
     else pack_pass_x16<Shape16Fast, ArchDefault>(m, d.precision, out, lay);
 }
@@ -1612,7 +1619,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         if (x16_coarse) {
             na.wstream = m->coarse_trunk_x16.stream; na.bias = m->coarse_trunk_x16.bias;
             e = timed(0, (double)N * S * m->coarse_trunk_x16.algo_flops_per_sample, (double)N * S * m->coarse_trunk_x16.mfma_flops_per_sample,
-                      [&] { return launch_net_x16(m->precision, na, m->num_cus, stream); });
+                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), na, m->num_cus, stream); });
         } else {
             na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
             e = timed(0, (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
@@ -1660,7 +1667,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // (NRNERF_RENDER_NO_X16: the 32x32x16 kernel of nrnerf_net_mb.h)
     // (read per call, like NRNERF_UNFUSED_COMPOSITE: the parity tests run both kernels in one process)
     const bool x16 = split && x16_mode != 0 && m->fine_trunk_x16.stream && !a->detailed_output && !kn.detailed;
-    const long long x16_group = x16_rays_per_group(SF);          // (nrnerf_net_x16.hip: the kernel's own ray-group size)
+    const long long x16_group = x16_rays_per_group(trunk_arch(m->arch_id), SF);          // (nrnerf_net_x16.hip: the kernel's own ray-group size)
     const bool fuse_fine = (split || !m->has_bend) && !unfused_composite && SF <= 256 &&
                            (x16 ? (long long)N >= x16_group * m->num_cus : enough_rays_to_fuse(SF));
     if (fuse_fine) { nf.fuse_on = 1; nf.fuse = final_composite(SF, z_fine, a->noise_fine, a->fine, nullptr); nf.raw4 = nullptr; }
@@ -1680,7 +1687,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         if (x16) {
             nf.wstream = m->fine_trunk_x16.stream; nf.bias = m->fine_trunk_x16.bias;
             e = timed(2, (double)N * SF * m->fine_trunk_x16.algo_flops_per_sample, (double)N * SF * m->fine_trunk_x16.mfma_flops_per_sample,
-                      [&] { return launch_net_x16(m->precision, nf, m->num_cus, stream); });
+                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), nf, m->num_cus, stream); });
         } else {
             nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
             e = timed(2, (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,

@@ -77,10 +77,7 @@ struct NetArgs {
 };
 
 
-// The trunk-only pass (ready-made points -> raw) on v_mfma_f32_16x16x32 (nrnerf_net_x16.h): compiled architecture 0's trunk, bf16 / f16,
-// image packed for PlanX16; needs pts4 and raw4, no fused compositing, no detail outputs.
-hipError_t launch_net_x16(int precision, const NetArgs& a, int num_cus, hipStream_t stream);
-long long x16_rays_per_group(int S);          // rays per fused-compositing group of net_kernel_x16 (nrnerf_net_x16.hip)
+// (The trunk-only pass on v_mfma_f32_16x16x32, nrnerf_net_x16.h, is declared in nrnerf_x16_api.h.)
 
 // Stand-alone bender (ray_bending.forward, run_nerf_helpers.py:507-577) over n_per_ray samples of every ray.
 struct BendArgs {

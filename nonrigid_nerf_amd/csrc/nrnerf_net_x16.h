@@ -47,6 +47,15 @@ __device__ __forceinline__ typename P::frag x16_pack(const f32x4& d0, const f32x
 #ifndef NRN_X16_WAVES
 #define NRN_X16_WAVES 4       // waves per workgroup (4: one per SIMD, up to 512 registers; 8: two per SIMD, 256)
 #endif
+// the same two knobs for the 128-wide trunk (ArchNarrow): a quarter of the flops per sample, so the latency-bound ends of an iteration
+// (points, encoding, outputs, compositing) weigh four times as much and a second wave per SIMD pays (measured, profiles/r05_*)
+#ifndef NRN_X16_NB_NARROW
+#define NRN_X16_NB_NARROW 4
+#endif
+#ifndef NRN_X16_WAVES_NARROW
+#define NRN_X16_WAVES_NARROW 8
+#endif
+template <class A> struct X16Cfg { static constexpr int NB = (A::W <= 128) ? NRN_X16_NB_NARROW : NRN_X16_NB, WAVES = (A::W <= 128) ? NRN_X16_WAVES_NARROW : NRN_X16_WAVES; };
 #ifndef NRN_X16_PF
 #define NRN_X16_PF 8          // weight fragments requested from LDS ahead of their MFMAs (4: 24.1 ms per fine pass, 6: 23.7, 8: 23.7)
 #endif
@@ -141,7 +150,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     using PE = PolF16;                                                // the encoding's operands are f16 in both modes
     using frag = typename P::frag;
     using efrag = typename PE::frag;
-    constexpr int NB = NRN_X16_NB, NS_H = PL::NS_H, NS_E = PL::NS_E;
+    constexpr int NB = X16Cfg<A>::NB, NS_H = PL::NS_H, NS_E = PL::NS_E;
+    static_assert(WAVES == X16Cfg<A>::WAVES, "launched with the architecture's own workgroup size");
     static_assert(A::L == 10, "the encoding's slot layout below is spelt out for ten frequencies (x16_enc_col)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -365,9 +375,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
 
 template <class P, class A, int EPL>
 static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t stream) {
-    constexpr int WAVES = NRN_X16_WAVES;
+    constexpr int WAVES = X16Cfg<A>::WAVES;
     using PL = PlanX16<P, A>;
-    constexpr int NB = NRN_X16_NB;
+    constexpr int NB = X16Cfg<A>::NB;
     if (!a.pts4 || (!a.raw4 && !a.fuse_on) || a.S < 1) return hipErrorInvalidValue;
     if ((a.fuse_on != 0) != (EPL > 0) || (EPL > 0 && (a.S + 63) / 64 != EPL)) return hipErrorInvalidValue;      // (the dispatcher's job)
     const int bpr = (a.S + 15) / 16;

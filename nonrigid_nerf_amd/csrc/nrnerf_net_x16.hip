@@ -2,6 +2,7 @@
 // f16, one object per compositing case (-DNRN_X16_EPL=0..4: raw outputs to memory / compositing fused in for passes of up to 64, 128,
 // 192, 256 samples per ray); the object of case 0 also holds the dispatcher.
 #include "nrnerf_net_x16.h"
+#include "nrnerf_x16_api.h"
 
 #ifndef NRN_X16_EPL
 #error "compile with -DNRN_X16_EPL=0..4 (Makefile)"
@@ -10,31 +11,38 @@
 #define NRN_CAT(a, b) NRN_CAT2(a, b)
 
 namespace nrn {
-hipError_t NRN_CAT(launch_net_x16_e, NRN_X16_EPL)(int precision, const NetArgs& a, int num_cus, hipStream_t stream) {
-    if (precision == PREC_BF16) return launch_net_x16_t<PolBF16, ArchDefault, NRN_X16_EPL>(a, num_cus, stream);
-    if (precision == PREC_F16) return launch_net_x16_t<PolF16, ArchDefault, NRN_X16_EPL>(a, num_cus, stream);
+// arch: 0 = the default trunk (8 x 256), 5 = --netwidth 128 (ArchNarrow; the ids of nrnerf_net.hip's dispatch table)
+hipError_t NRN_CAT(launch_net_x16_e, NRN_X16_EPL)(int precision, int arch, const NetArgs& a, int num_cus, hipStream_t stream) {
+    if (arch == 0) {
+        if (precision == PREC_BF16) return launch_net_x16_t<PolBF16, ArchDefault, NRN_X16_EPL>(a, num_cus, stream);
+        if (precision == PREC_F16) return launch_net_x16_t<PolF16, ArchDefault, NRN_X16_EPL>(a, num_cus, stream);
+    } else if (arch == 5) {
+        if (precision == PREC_BF16) return launch_net_x16_t<PolBF16, ArchNarrow, NRN_X16_EPL>(a, num_cus, stream);
+        if (precision == PREC_F16) return launch_net_x16_t<PolF16, ArchNarrow, NRN_X16_EPL>(a, num_cus, stream);
+    }
     return hipErrorInvalidValue;
 }
 
 #if NRN_X16_EPL == 0
 // rays of one fused-compositing group (one workgroup iteration set): WAVES waves x the fewest rays whose 16-sample blocks fill whole
 // iterations of NB blocks -- the API layer's "enough rays to fuse" threshold asks here instead of restating the kernel's mapping
-long long x16_rays_per_group(int S) {
-    const int bpr = (S + 15) / 16, NB = NRN_X16_NB;
+long long x16_rays_per_group(int arch, int S) {
+    const int bpr = (S + 15) / 16;
+    const int NB = (arch == 5) ? X16Cfg<ArchNarrow>::NB : X16Cfg<ArchDefault>::NB, WAVES = (arch == 5) ? X16Cfg<ArchNarrow>::WAVES : X16Cfg<ArchDefault>::WAVES;
     const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
-    return (long long)NRN_X16_WAVES * RW;
+    return (long long)WAVES * RW;
 }
-hipError_t launch_net_x16_e1(int, const NetArgs&, int, hipStream_t);
-hipError_t launch_net_x16_e2(int, const NetArgs&, int, hipStream_t);
-hipError_t launch_net_x16_e3(int, const NetArgs&, int, hipStream_t);
-hipError_t launch_net_x16_e4(int, const NetArgs&, int, hipStream_t);
-hipError_t launch_net_x16(int precision, const NetArgs& a, int num_cus, hipStream_t stream) {
-    if (!a.fuse_on) return launch_net_x16_e0(precision, a, num_cus, stream);
+hipError_t launch_net_x16_e1(int, int, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e2(int, int, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e3(int, int, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e4(int, int, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16(int precision, int arch, const NetArgs& a, int num_cus, hipStream_t stream) {
+    if (!a.fuse_on) return launch_net_x16_e0(precision, arch, a, num_cus, stream);
     switch ((a.S + 63) / 64) {
-        case 1: return launch_net_x16_e1(precision, a, num_cus, stream);
-        case 2: return launch_net_x16_e2(precision, a, num_cus, stream);
-        case 3: return launch_net_x16_e3(precision, a, num_cus, stream);
-        case 4: return launch_net_x16_e4(precision, a, num_cus, stream);
+        case 1: return launch_net_x16_e1(precision, arch, a, num_cus, stream);
+        case 2: return launch_net_x16_e2(precision, arch, a, num_cus, stream);
+        case 3: return launch_net_x16_e3(precision, arch, a, num_cus, stream);
+        case 4: return launch_net_x16_e4(precision, arch, a, num_cus, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,12 @@
+// nrnerf_x16_api.h -- host-side entry points of the 16x16x32 trunk-only kernel (nrnerf_net_x16.h / .hip), seen by the API layer only
+// (kept out of nrnerf_kernels.h: every translation unit depends on that one).
+#pragma once
+#include "nrnerf_kernels.h"
+
+namespace nrn {
+// arch: 0 = the default trunk (8 x 256), 5 = --netwidth 128 (the ids of nrnerf_net.hip's dispatch table)
+hipError_t launch_net_x16(int precision, int arch, const NetArgs& a, int num_cus, hipStream_t stream);
+// rays of one fused-compositing group of that kernel: its waves per workgroup x the fewest rays whose 16-sample blocks fill whole
+// iterations -- the API layer's "enough rays to fuse" threshold asks here instead of restating the kernel's mapping
+long long x16_rays_per_group(int arch, int S);
+}  // namespace nrn
