@@ -239,9 +239,11 @@ void pack_pass(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, int preci
 // The trunk-only image of the 16x16x32 kernel (nrnerf_net_x16.h, PlanX16): fragment (tile t, k-step s) holds, for lane (r = lane & 15,
 // g = lane >> 4) and element e < 8,  W[x16_out_row(t, r)][x16_in_col(s, g, e)]; encoding k-steps f16, hidden ones the model's type;
 // bias table [tile][16 rows].
-template <class SH, class A>
+// VIEWS: the view-dependent head as PlanX16 lays it out -- [views_linears[0] o feature_linear (FoldedViews) | alpha_linear in the last tile],
+// then rgb_linear.
+template <class SH, class A, bool VIEWS = false>
 void pack_pass_x16(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, const FlatLayout* lay = nullptr) {
-    using PL = PlanX16<SH, A>;
+    using PL = PlanX16<SH, A, VIEWS>;
     const Tables& T = PL::TB;
     out.ntiles = T.ntiles; out.nunits = T.nunits_padded;
     out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES; out.mfma_per_block = T.mfma_per_block;
@@ -255,23 +257,37 @@ void pack_pass_x16(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
         out.bias_src.assign(out.bias.size(), -1);
     }
     size_t written = 0;
+    std::unique_ptr<FoldedViews> folded;
     for (int l = 0; l < T.nlayers; ++l) {
         const LayerSpec& sp = T.layers[l];
-        const nrnerf_linear* lin = (sp.kind == LK_HEAD) ? &mlp.output_linear : &mlp.pts_linears[sp.index];
-        const int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
+        const nrnerf_linear* lin0 = (sp.kind == LK_HEAD) ? &mlp.output_linear : (sp.kind == LK_RGB ? &mlp.rgb_linear : &mlp.pts_linears[sp.index]);
+        int64_t wbase0 = lay ? lay->of(lin0->weight) : -1, bbase0 = (lay && lin0->bias) ? lay->of(lin0->bias) : -1;
+        if (sp.kind == LK_VIEWS) {                 // source: the derived entries of the flat vector (FlatLayout::add_folded), as pack_pass
+            folded.reset(new FoldedViews(mlp));
+            lin0 = &folded->lin;
+            wbase0 = lay ? lay->folded_of(mlp.views_linear.weight) : -1;
+            bbase0 = wbase0 < 0 ? -1 : wbase0 + (int64_t)lin0->out_features * lin0->in_features;
+        }
         for (int t = 0; t < sp.nt; ++t) {
+            // the views layer's last tile: alpha_linear (row 0), over the hidden k-steps only
+            const bool alpha_tile = sp.kind == LK_VIEWS && t == sp.nt - 1;
+            const nrnerf_linear* lin = alpha_tile ? &mlp.alpha_linear : lin0;
+            const int64_t wbase = alpha_tile ? (lay ? lay->of(lin->weight) : -1) : wbase0;
+            const int64_t bbase = alpha_tile ? ((lay && lin->bias) ? lay->of(lin->bias) : -1) : bbase0;
             const TileInfo& ti = T.tiles[sp.tile0 + t];
             for (int s = 0; s < sp.ns; ++s) {
                 const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride;
                 if (fi >= (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
                 uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
-                const bool enc_step = (sp.kind == LK_TR_IN || sp.kind == LK_TR_SKIP) && s < PL::NS_E;
+                const bool enc_step = ((sp.kind == LK_TR_IN || sp.kind == LK_TR_SKIP) && s < PL::NS_E) || (sp.kind == LK_VIEWS && s == 0);
                 const bool as_f16 = precision == NRNERF_PREC_F16 || enc_step;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int r = lane & 15, g = lane >> 4;
-                    const int row = x16_out_row<A>(sp.kind, t, r, lin->out_features);
+                    const int row = alpha_tile ? (r == 0 ? 0 : -1) : x16_out_row<A>(sp.kind, t, r, lin->out_features);
                     for (int e = 0; e < 8; ++e) {
-                        const int col = x16_in_col<A>(sp.kind, s, g, e, lin->in_features);
+                        int col;
+                        if (alpha_tile) { col = (s == 0) ? -1 : x16_hidden_feature(s - 1, g, e); if (col >= lin->in_features) col = -1; }
+                        else col = x16_in_col<A>(sp.kind, s, g, e, lin->in_features);
                         const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
                         const size_t el = fi * (SH::FRAG_BYTES / 2) + (size_t)lane * 8 + e;
                         if (lay) {
@@ -285,7 +301,7 @@ void pack_pass_x16(const nrnerf_mlp_desc& mlp, int precision, PackedPass& out, c
                 ++written;
             }
             for (int r = 0; r < 16; ++r) {
-                const int row = x16_out_row<A>(sp.kind, t, r, lin->out_features);
+                const int row = alpha_tile ? (r == 0 ? 0 : -1) : x16_out_row<A>(sp.kind, t, r, lin->out_features);
                 out.bias[(size_t)(sp.tile0 + t) * 16 + r] = (row >= 0 && lin->bias) ? lin->bias[row] : 0.0f;
                 if (lay && row >= 0 && bbase >= 0) out.bias_src[(size_t)(sp.tile0 + t) * 16 + r] = (int32_t)(bbase + row);
             }
@@ -302,11 +318,21 @@ bool x16_eligible(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, bool any
     //  fused-bender fine pass in "f16" mode, which tests/test_gpu_parity.py asserts)
     const bool f16_too = !(d.flags & NRNERF_MODEL_NO_X16_F16);
     if (d.precision != NRNERF_PREC_BF16 && !(d.precision == NRNERF_PREC_F16 && (f16_too || any_16bit))) return false;
-    if (m.use_viewdirs || m.time_conditioned || d.multires != A::L || m.depth != A::D || !width_ok || m.skip != A::SKIP) return false;
+    if (m.time_conditioned || d.multires != A::L || m.depth != A::D || !width_ok || m.skip != A::SKIP) return false;
+    if (m.use_viewdirs) {            // view-dependent head: width 256, 4 direction frequencies, finite-difference (not exact Jacobian) directions
+        if (m.width != A::W || d.multires_views != A::LV || (d.exact_viewdirs && d.bender)) return false;
+        if (m.views_linear.out_features != A::W / 2 || m.feature_linear.out_features != A::W) return false;
+        return true;
+    }
     if (m.output_ch != 4 && m.output_ch != 5) return false;
     return true;
 }
 void pack_x16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& out, const FlatLayout* lay = nullptr) {
+    if (m.use_viewdirs) {
+        if (d.precision == NRNERF_PREC_F16) pack_pass_x16<Shape16, ArchDefault, true>(m, d.precision, out, lay);
+        else pack_pass_x16<Shape16Fast, ArchDefault, true>(m, d.precision, out, lay);
+        return;
+    }
     if (m.width == ArchNarrow::W) {
         if (d.precision == NRNERF_PREC_F16) pack_pass_x16<Shape16, ArchNarrow>(m, d.precision, out, lay);
         else pack_pass_x16<Shape16Fast, ArchNarrow>(m, d.precision, out, lay);
@@ -1619,7 +1645,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         if (x16_coarse) {
             na.wstream = m->coarse_trunk_x16.stream; na.bias = m->coarse_trunk_x16.bias;
             e = timed(0, (double)N * S * m->coarse_trunk_x16.algo_flops_per_sample, (double)N * S * m->coarse_trunk_x16.mfma_flops_per_sample,
-                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), na, m->num_cus, stream); });
+                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, na, m->num_cus, stream); });
         } else {
             na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
             e = timed(0, (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
@@ -1687,7 +1713,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         if (x16) {
             nf.wstream = m->fine_trunk_x16.stream; nf.bias = m->fine_trunk_x16.bias;
             e = timed(2, (double)N * SF * m->fine_trunk_x16.algo_flops_per_sample, (double)N * SF * m->fine_trunk_x16.mfma_flops_per_sample,
-                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), nf, m->num_cus, stream); });
+                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, nf, m->num_cus, stream); });
         } else {
             nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
             e = timed(2, (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,

@@ -119,12 +119,14 @@ __device__ __forceinline__ void dense_x16(ST& st, const __attribute__((address_s
             if constexpr (s < NS0) acc[set][u][b] = X16<P0>::mfma(__builtin_bit_cast(typename P0::frag, cur), in0[b][s], c);
             else acc[set][u][b] = X16<P1>::mfma(cur, in1[b][s - NS0], c);
         });
-        // epilogue of the previous pair: block k after the second tile's MFMAs of k-step k
-        if constexpr (p > 0 && u == 1 && s < NB) {
+        // epilogue of the previous pair: block k after the second tile's MFMAs of k-step k (or after the lone last tile's, when the
+        // layer has an odd tile count > 1: the views layer's alpha tile)
+        constexpr bool host = (u == 1) || (NT % 2 == 1 && t == NT - 1);
+        if constexpr (p > 0 && host && s < NB) {
             epi(std::integral_constant<int, p - 1>{}, std::integral_constant<int, s>{}, pinned(acc[set ^ 1][0][s]), pinned(acc[set ^ 1][1][s]));
         }
         // a layer with fewer k-steps than blocks (the encoding layer: 2): the rest of that epilogue at its last k-step
-        if constexpr (p > 0 && u == 1 && s == NS - 1 && NS < NB) {
+        if constexpr (p > 0 && host && s == NS - 1 && NS < NB) {
             static_for<NS, NB>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 epi(std::integral_constant<int, p - 1>{}, kc, pinned(acc[set ^ 1][0][k]), pinned(acc[set ^ 1][1][k]));
@@ -144,9 +146,12 @@ __device__ __forceinline__ void dense_x16(ST& st, const __attribute__((address_s
 // 64 EPL samples per ray, a lane owning EPL of them (composite_ray<EPL>).  One kernel per case rather than a switch inside one: the loop
 // body is straight-line code several times the instruction cache (every jump to code that is not next in line costs ~2000 cycles,
 // NRN_TIMING), the flag and the case fold at compile time, and the fine pass measured 0.5-1 % faster (tools/experiments/README.md).
-template <class P, class A, int WAVES, int EPL>
+// VIEWS: the view-dependent head (rnh:284-304) behind the trunk -- a sample's direction = the finite difference of the points of
+// NetArgs::pts4 along its ray (rnh:339-351; the neighbour read from the same array, as the 32x32x16 trunk-only kernel does), its
+// encoding one more B operand; [views_linears[0] o feature_linear | alpha_linear] and rgb_linear as two more dense_x16 calls.
+template <class P, class A, int WAVES, int EPL, bool VIEWS = false>
 __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a) {
-    using PL = PlanX16<P, A>;
+    using PL = PlanX16<P, A, VIEWS>;
     using PE = PolF16;                                                // the encoding's operands are f16 in both modes
     using frag = typename P::frag;
     using efrag = typename PE::frag;
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     asm volatile("" : "+s"(gdim));
     float cpre[NB][8];          // direction and depths of this wave's rays, requested one iteration ahead of their use
     // where block b of the iteration (tg_, grp_ | b0_) lies: its sample's row in the [N, S] arrays, and whether the lane has a sample
-    auto locate = [&](int tg_, long long grp_, long long b0_, int b, size_t& so_, bool& ok_) {
+    auto locate = [&](int tg_, long long grp_, long long b0_, int b, size_t& so_, bool& ok_, size_t& nb_, bool& first_) {
         bool blk_ok;
         int ray, bir;
         if constexpr (fuse) {                   // block q of this wave's group: ray (grp * WAVES + wave) * RW + q / bpr
@@ -214,7 +219,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         }
         const int sidx = bir * 16 + n;
         ok_ = blk_ok && sidx < S;
-        so_ = (size_t)ray * S + (sidx < S ? sidx : S - 1);
+        const int sc = sidx < S ? sidx : S - 1;
+        so_ = (size_t)ray * S + sc;
+        first_ = sc == 0;                                          // (VIEWS) sample 0 takes sample 1's direction, rnh:346-348
+        nb_ = (size_t)ray * S + (sc == 0 ? (S > 1 ? 1 : 0) : sc - 1);
     };
     // The points of an iteration are requested during the PREVIOUS one -- right after its last LDS-DMA requests, before its output
     // stores and its compositing: a lone wave per SIMD has nothing else to put between the request and the use, and the loads'
@@ -223,10 +231,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     size_t so[NB];
     bool ok[NB];
     f32x4 q4n[NB];
+    f32x4 q4p[VIEWS ? NB : 1];          // (VIEWS) the neighbouring sample's point
+    bool first[NB];
     static_for<0, NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
-        locate(0, grp, (long long)blockIdx.x * per_wg, b, so[b], ok[b]);
+        size_t nb;
+        locate(0, grp, (long long)blockIdx.x * per_wg, b, so[b], ok[b], nb, first[b]);
         q4n[b] = *(const f32x4*)(a.pts4 + so[b] * 4);
+        if constexpr (VIEWS) q4p[b] = *(const f32x4*)(a.pts4 + nb * 4);
     });
 #ifdef NRN_TIMING
     // slots: 0 iteration, 1 points + encoding, 2 layers + head, 3 outputs + ring tail, 4 compositing, 5 iteration in 100 MHz ticks,
@@ -273,6 +285,37 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
                 for (int e = 0; e < 8; ++e) enc[b][s][e] = (_Float16)ev[8 * s + e];
         });
 
+        // ---- (VIEWS) the samples' directions and their encoding, one k-step in B-operand order (x16_dir_col): slots 2 i, 2 i + 1 (i < 3)
+        //      = (sin, cos) of pair m = 4 i + g; slots 6, 7 of groups 0, 1 = the identity columns x, y | z, 0
+        efrag encv[NB][1];
+        if constexpr (VIEWS) {
+            static_assert(A::LV == 4, "the direction encoding's slot layout is spelt out for four frequencies (x16_dir_col)");
+            static_for<0, NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                const f32x4 q4 = q4n[b], nb4 = q4p[b];
+                float dd[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dd[c] = first[b] ? __fsub_rn(nb4[c], q4[c]) : __fsub_rn(q4[c], nb4[c]);
+                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dd[0], dd[0]), __fmul_rn(dd[1], dd[1])), __fmul_rn(dd[2], dd[2])));
+                float dir[3], drev[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { dir[c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f)); drev[c] = dir[c] * 0.15915494309189535f; }
+                float ev[8];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int m = 4 * i + g;
+                    const int f = m / 3, c = m - 3 * f;
+                    const float xr = c == 0 ? drev[0] : (c == 1 ? drev[1] : drev[2]);
+                    const float r = __builtin_amdgcn_fractf(xr * (float)(1 << f));
+                    ev[2 * i] = __builtin_amdgcn_sinf(r);
+                    ev[2 * i + 1] = __builtin_amdgcn_cosf(r);
+                }
+                ev[6] = (g == 0) ? dir[0] : (g == 1 ? dir[2] : 0.0f);
+                ev[7] = (g == 0) ? dir[1] : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) encv[b][0][e] = (_Float16)ev[e];
+            });
+        }
 #ifdef NRN_TIMING
         NRN_TACC(1, t_it);
         const unsigned long long t_net = NRN_NOW();
@@ -299,8 +342,25 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         // ---- head: one tile; group 0 holds channels 0..3 (rgb, sigma) of its sample, group 1 channel 4 in its first register
         f32x4 raw[NB];
         auto take = [&](auto, auto kc, const f32x4& d0, const f32x4&) { raw[decltype(kc)::value] = d0; };
-        if constexpr ((A::D - 1) % 2 == 1) dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB>(st, bias_lane, hb, none, take);
-        else dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB>(st, bias_lane, ha, none, take);
+        if constexpr (!VIEWS) {
+            if constexpr ((A::D - 1) % 2 == 1) dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB>(st, bias_lane, hb, none, take);
+            else dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB>(st, bias_lane, ha, none, take);
+        } else {
+            // view-dependent head: hv = relu(views o feature ([enc(dir), h])) in tile pairs 0 .. NT_V / 2 - 1, sigma = the lone last tile's
+            // row 0 (group 0's first register, no relu); then rgb = rgb_linear(hv): raw = [rgb, sigma]
+            constexpr int NS_V = PL::NS_V;
+            frag hv[NB][NS_V];
+            float sigma[NB];
+            auto views_epi = [&](auto pc, auto kc, const f32x4& d0, const f32x4& d1) {
+                constexpr int p = decltype(pc)::value, k = decltype(kc)::value;
+                if constexpr (p < NS_V) hv[k][p] = x16_pack<P>(d0, d1);
+                else sigma[k] = d0[0];
+            };
+            if constexpr ((A::D - 1) % 2 == 1) dense_x16<PE, P, PL, PL::L_VIEWS, 1, NS_H, NB>(st, bias_lane, encv, hb, views_epi);
+            else dense_x16<PE, P, PL, PL::L_VIEWS, 1, NS_H, NB>(st, bias_lane, encv, ha, views_epi);
+            dense_x16<P, P, PL, PL::L_HEAD, NS_V, 0, NB>(st, bias_lane, hv, none, take);
+            static_for<0, NB>([&](auto bc) { raw[decltype(bc)::value][3] = sigma[decltype(bc)::value]; });
+        }
 #ifdef NRN_TIMING
         NRN_TACC(2, t_net);
         const unsigned long long t_out = NRN_NOW();
@@ -319,8 +379,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         bool ok_n[NB];
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            locate(tg_n, grp_n, b0_n, b, so_n[b], ok_n[b]);
+            size_t nb;
+            locate(tg_n, grp_n, b0_n, b, so_n[b], ok_n[b], nb, first[b]);
             q4n[b] = *(const f32x4*)(a.pts4 + so_n[b] * 4);
+            if constexpr (VIEWS) q4p[b] = *(const f32x4*)(a.pts4 + nb * 4);
         });
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
@@ -373,10 +435,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
 #endif
 }
 
-template <class P, class A, int EPL>
+template <class P, class A, int EPL, bool VIEWS = false>
 static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t stream) {
     constexpr int WAVES = X16Cfg<A>::WAVES;
-    using PL = PlanX16<P, A>;
+    using PL = PlanX16<P, A, VIEWS>;
     constexpr int NB = X16Cfg<A>::NB;
     if (!a.pts4 || (!a.raw4 && !a.fuse_on) || a.S < 1) return hipErrorInvalidValue;
     if ((a.fuse_on != 0) != (EPL > 0) || (EPL > 0 && (a.S + 63) / 64 != EPL)) return hipErrorInvalidValue;      // (the dispatcher's job)
@@ -388,7 +450,7 @@ static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t st
         lds += (size_t)WAVES * RW * bpr * 16 * 16 + 256;            // the waves' raw stages + the compositing arguments
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = net_kernel_x16<P, A, WAVES, EPL>;
+    auto kern = net_kernel_x16<P, A, WAVES, EPL, VIEWS>;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;

@@ -12,7 +12,13 @@
 
 namespace nrn {
 // arch: 0 = the default trunk (8 x 256), 5 = --netwidth 128 (ArchNarrow; the ids of nrnerf_net.hip's dispatch table)
-hipError_t NRN_CAT(launch_net_x16_e, NRN_X16_EPL)(int precision, int arch, const NetArgs& a, int num_cus, hipStream_t stream) {
+hipError_t NRN_CAT(launch_net_x16_e, NRN_X16_EPL)(int precision, int arch, bool views, const NetArgs& a, int num_cus, hipStream_t stream) {
+    if (views) {
+        if (arch != 0) return hipErrorInvalidValue;
+        if (precision == PREC_BF16) return launch_net_x16_t<PolBF16, ArchDefault, NRN_X16_EPL, true>(a, num_cus, stream);
+        if (precision == PREC_F16) return launch_net_x16_t<PolF16, ArchDefault, NRN_X16_EPL, true>(a, num_cus, stream);
+        return hipErrorInvalidValue;
+    }
     if (arch == 0) {
         if (precision == PREC_BF16) return launch_net_x16_t<PolBF16, ArchDefault, NRN_X16_EPL>(a, num_cus, stream);
         if (precision == PREC_F16) return launch_net_x16_t<PolF16, ArchDefault, NRN_X16_EPL>(a, num_cus, stream);
@@ -32,17 +38,17 @@ long long x16_rays_per_group(int arch, int S) {
     const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
     return (long long)WAVES * RW;
 }
-hipError_t launch_net_x16_e1(int, int, const NetArgs&, int, hipStream_t);
-hipError_t launch_net_x16_e2(int, int, const NetArgs&, int, hipStream_t);
-hipError_t launch_net_x16_e3(int, int, const NetArgs&, int, hipStream_t);
-hipError_t launch_net_x16_e4(int, int, const NetArgs&, int, hipStream_t);
-hipError_t launch_net_x16(int precision, int arch, const NetArgs& a, int num_cus, hipStream_t stream) {
-    if (!a.fuse_on) return launch_net_x16_e0(precision, arch, a, num_cus, stream);
+hipError_t launch_net_x16_e1(int, int, bool, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e2(int, int, bool, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e3(int, int, bool, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16_e4(int, int, bool, const NetArgs&, int, hipStream_t);
+hipError_t launch_net_x16(int precision, int arch, bool views, const NetArgs& a, int num_cus, hipStream_t stream) {
+    if (!a.fuse_on) return launch_net_x16_e0(precision, arch, views, a, num_cus, stream);
     switch ((a.S + 63) / 64) {
-        case 1: return launch_net_x16_e1(precision, arch, a, num_cus, stream);
-        case 2: return launch_net_x16_e2(precision, arch, a, num_cus, stream);
-        case 3: return launch_net_x16_e3(precision, arch, a, num_cus, stream);
-        case 4: return launch_net_x16_e4(precision, arch, a, num_cus, stream);
+        case 1: return launch_net_x16_e1(precision, arch, views, a, num_cus, stream);
+        case 2: return launch_net_x16_e2(precision, arch, views, a, num_cus, stream);
+        case 3: return launch_net_x16_e3(precision, arch, views, a, num_cus, stream);
+        case 4: return launch_net_x16_e4(precision, arch, views, a, num_cus, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -470,23 +470,35 @@ constexpr NRN_HD int out_row(int kind, int t, int i, int out_features) {
 // the (sin, cos) pair number m = 4 (q / 2) + g of the list (frequency f = m / 3, coordinate c = m % 3), and the four spare slots
 // (q = 14, 15 of groups 2, 3, when L = 10) the identity columns x, y | z, 0: every group runs the same code.
 constexpr NRN_HD int x16_hidden_feature(int s, int g, int e) { return 32 * s + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4)); }
-constexpr NRN_HD int x16_enc_col(int L, int s, int g, int e) {       // reference column of encoding slot (s, g, e), -1: zero
+// (NSLOT = 8 x the k-steps the encoding fills: 16 for the points' (L = 10), 8 for the directions' (LV = 4: pairs m = g, 4 + g, 8 + g in
+//  slots 0..5 of every group, the identity columns x, y | z, 0 in slots 6, 7 of groups 0, 1))
+constexpr NRN_HD int x16_enc_col_n(int L, int NSLOT, int s, int g, int e) {       // reference column of encoding slot (s, g, e), -1: zero
     const int q = 8 * s + e, m = 4 * (q / 2) + g;
     if (m < 3 * L) return 3 + 6 * (m / 3) + 3 * (q & 1) + (m % 3);
-    // spare slots of this group, in order: the identity columns, two per group starting at group 2 (L = 10: exactly q = 14, 15)
+    // spare slots of this group, in order: the identity columns, two per group starting at the first group that has spares
+    // (L = 10: exactly q = 14, 15 of groups 2, 3)
     int spare = 0;
     for (int qq = 0; qq < q; ++qq) spare += (4 * (qq / 2) + g >= 3 * L) ? 1 : 0;
     int before = 0;                                                    // spare slots of lower groups
     for (int gg = 0; gg < g; ++gg)
-        for (int qq = 0; qq < 16; ++qq) before += (4 * (qq / 2) + gg >= 3 * L) ? 1 : 0;
+        for (int qq = 0; qq < NSLOT; ++qq) before += (4 * (qq / 2) + gg >= 3 * L) ? 1 : 0;
     const int id = before + spare;
     return id < 3 ? id : -1;
 }
-template <class SH, class A>
+constexpr NRN_HD int x16_enc_col(int L, int s, int g, int e) { return x16_enc_col_n(L, 16, s, g, e); }
+constexpr NRN_HD int x16_dir_col(int LV, int g, int e) { return x16_enc_col_n(LV, 8, 0, g, e); }
+// VIEWS (view-dependent head, rnh:284-304) behind the trunk, two more layers:
+//   LK_VIEWS  k-steps [direction encoding (one: 3 + 6 LV <= 32 columns, x16_dir_col(LV, g, e)), trunk output (W / 32)] ->
+//             W / 32 tiles of relu(views_linears[0] o feature_linear) (feature_linear folded into the weights by the packer, as
+//             in the 32x32x16 plans) + ONE last tile whose row 0 is alpha_linear (zero weights in the direction k-step; no relu:
+//             the kernel takes it from the accumulator) -- an odd tile count: the alpha tile runs alone, like the plain head;
+//   LK_RGB    W / 64 k-steps -> one tile, rows 0..2 = rgb_linear.
+template <class SH, class A, bool VIEWS = false>
 constexpr Tables build_tables_x16() {
     static_assert(SH::KH == 8, "16-bit operands");
     constexpr int NT = A::W / 16, NS_H = A::W / 32, NS_E = 2;
     static_assert(3 + 6 * A::L <= 64 && A::W % 32 == 0, "the encoding fills two k-steps");
+    static_assert(!VIEWS || (3 + 6 * A::LV <= 32 && A::W % 64 == 0), "the direction encoding fills one k-step");
     Tables T{};
     int nl = 0, tile0 = 0;
     auto add = [&](int kind, int index, int ns, int nt) {
@@ -499,32 +511,48 @@ constexpr Tables build_tables_x16() {
         if (i - 1 == A::SKIP) add(LK_TR_SKIP, i, NS_E + NS_H, NT);
         else add(LK_TR_HID, i, NS_H, NT);
     }
-    add(LK_HEAD, 0, NS_H, 1);
+    if (VIEWS) {
+        add(LK_VIEWS, 0, 1 + NS_H, NT / 2 + 1);
+        add(LK_RGB, 0, NS_H / 2, 1);
+    } else {
+        add(LK_HEAD, 0, NS_H, 1);
+    }
     T.nlayers = nl;
     T.ntiles = tile0;
     place_fragments<SH>(T);
     return T;
 }
-template <class SH, class A>
+template <class SH, class A, bool VIEWS = false>
 struct PlanX16 {
     static constexpr int NT = A::W / 16, NS_H = A::W / 32, NS_E = 2;
-    static constexpr Tables TB = build_tables_x16<SH, A>();
+    static constexpr int NT_V = NT / 2, NS_V = NS_H / 2;       // VIEWS: feature tiles of the views layer (+ 1 alpha tile), k-steps of rgb_linear
+    static constexpr Tables TB = build_tables_x16<SH, A, VIEWS>();
     static constexpr int NLAYERS = TB.nlayers, NTILES = TB.ntiles, NFRAGS = TB.nfrags;
     static constexpr int NUNITS = TB.nunits, NUP = TB.nunits_padded, UF = SH::UNIT_FRAGS;
     static constexpr int MFMA_PER_BLOCK = TB.mfma_per_block;         // per 16-sample block
     static_assert(TB.ntiles <= MAX_TILES && TB.nlayers <= MAX_LAYERS, "plan too large");
-    static constexpr int L_HEAD = NLAYERS - 1;
+    static constexpr int L_HEAD = NLAYERS - 1;                 // output_linear, or (VIEWS) rgb_linear
+    static constexpr int L_VIEWS = NLAYERS - 2;                // (VIEWS) [views_linears[0] o feature_linear; alpha_linear]
 };
 // reference element of fragment (layer kind, tile t, lane row r, k-step s, group g, element e): (row, column), -1 = zero
+// (LK_VIEWS: rows / columns of the FOLDED layer -- hidden columns first, then the direction encoding's; its last tile, the alpha
+//  row, is the packer's business: another nn.Linear)
 template <class A>
 constexpr NRN_HD int x16_out_row(int kind, int t, int r, int out_features) {
     if (kind == LK_HEAD) return r < out_features ? r : -1;           // channels 0..3 in group 0's four registers, channel 4 in group 1's first
+    if (kind == LK_RGB) return r < 3 ? r : -1;
     return (16 * t + r < out_features) ? 16 * t + r : -1;
 }
 template <class A>
 constexpr NRN_HD int x16_in_col(int kind, int s, int g, int e, int in_features) {
     constexpr int IN_CH = 3 + 6 * A::L;
     if (kind == LK_TR_IN) return x16_enc_col(A::L, s, g, e);
+    if (kind == LK_VIEWS) {                                          // in_features = hidden width + direction-encoding columns
+        constexpr int EV = 3 + 6 * A::LV;
+        if (s == 0) { const int c = x16_dir_col(A::LV, g, e); return c < 0 ? -1 : (in_features - EV) + c; }
+        const int c = x16_hidden_feature(s - 1, g, e);
+        return c < in_features - EV ? c : -1;
+    }
     if (kind == LK_TR_SKIP) {
         if (s < 2) return x16_enc_col(A::L, s, g, e);
         const int c = IN_CH + x16_hidden_feature(s - 2, g, e);

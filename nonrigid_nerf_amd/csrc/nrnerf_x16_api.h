@@ -4,8 +4,9 @@
 #include "nrnerf_kernels.h"
 
 namespace nrn {
-// arch: 0 = the default trunk (8 x 256), 5 = --netwidth 128 (the ids of nrnerf_net.hip's dispatch table)
-hipError_t launch_net_x16(int precision, int arch, const NetArgs& a, int num_cus, hipStream_t stream);
+// arch: 0 = the default trunk (8 x 256), 5 = --netwidth 128 (the ids of nrnerf_net.hip's dispatch table); views: the view-dependent head
+// (width 256 only; directions = finite differences of the points of NetArgs::pts4 along the ray, rnh:339-351)
+hipError_t launch_net_x16(int precision, int arch, bool views, const NetArgs& a, int num_cus, hipStream_t stream);
 // rays of one fused-compositing group of that kernel: its waves per workgroup x the fewest rays whose 16-sample blocks fill whole
 // iterations -- the API layer's "enough rays to fuse" threshold asks here instead of restating the kernel's mapping
 long long x16_rays_per_group(int arch, int S);

@@ -312,17 +312,30 @@ def _x16_enc_col(L, s, g, e):
     return before + spare if before + spare < 3 else -1
 
 
+def _x16_dir_col(LV, g, e):
+    """nrnerf_plan.h::x16_dir_col, restated: the direction encoding fills ONE k-step (8 slots per lane group)."""
+    m = 4 * (e // 2) + g
+    if m < 3 * LV:
+        return 3 + 6 * (m // 3) + 3 * (e & 1) + (m % 3)
+    spare = sum(1 for qq in range(e) if 4 * (qq // 2) + g >= 3 * LV)
+    before = sum(1 for gg in range(g) for qq in range(8) if 4 * (qq // 2) + gg >= 3 * LV)
+    return before + spare if before + spare < 3 else -1
+
+
+@pytest.mark.parametrize("cfg_kw", [dict(), dict(netwidth=128), dict(use_viewdirs=True), dict(use_viewdirs=True, bend_depth=7)],
+                         ids=["w256", "w128", "w256_viewdirs", "config4"])
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
-def test_x16_stream_reproduces_the_trunk(precision):
+def test_x16_stream_reproduces_the_trunk(precision, cfg_kw):
     """The trunk-only image of the 16x16x32 kernel (csrc/nrnerf_net_x16.h, PlanX16; nrnerf_pack_host which = 10), emulated in
     numpy as the kernel consumes it: a fragment is W[16 rows][32 k] with lane (r, g) holding k positions 8 g .. 8 g + 7; the B
     operand of k-step s holds, at position 8 g + e, input column x16_in_col(s, g, e) -- for the encoding the slot layout of
     x16_enc_col (every one of the 63 columns exactly once), for hidden layers features 32 s + 4 g + e (e < 4, D tile 2 s) and
     32 s + 16 + 4 g + (e - 4) (D tile 2 s + 1): what a lane holds after two consecutive 16-row tiles; tiles in pairs with their
     k-steps interleaved, the head alone.  Must reproduce the fp64 network up to the operand rounding."""
-    cfg = SceneConfig(N_importance=128)
+    cfg = SceneConfig(N_importance=128, **cfg_kw)
     scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=10)
     assert info.frag_bytes == 1024
+    views, W = cfg.use_viewdirs, cfg.netwidth
     rnd, rnd_e = rounder(precision), rounder("f16")
     u16 = stream.view(np.uint16)
     as_bf16 = (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
@@ -386,7 +399,7 @@ def test_x16_stream_reproduces_the_trunk(precision):
                 if c >= 0:
                     b[8 * g + e] = xn[:, c]
         Benc.append(rnd_e(b))
-    NT = 16
+    NT = W // 16
     tile0, mfma = 0, 0
     tiles = dense(tile0, 2, NT, Benc, 2); tile0 += NT; mfma += 2 * NT
     for i in range(1, 8):
@@ -396,8 +409,33 @@ def test_x16_stream_reproduces_the_trunk(precision):
             B, n16 = Benc + B, 2
         tiles = dense(tile0, len(B), NT, B, n16); tile0 += NT; mfma += len(B) * NT
     B = hand_off(tiles)
-    D = dense(tile0, len(B), 1, B, 0)[0]; tile0 += 1; mfma += len(B)
-    raw = D[0:5].T                                                           # channels 0..3: group 0's registers, channel 4: group 1's first
+    if views:
+        # view-dependent head (PlanX16<.., VIEWS>): k-steps [direction encoding (one, x16_dir_col), trunk output] -> W / 32 feature tiles
+        # of relu(views_linears[0] o feature_linear) + the alpha tile (row 0, no relu, zero weights in the direction k-step); then rgb_linear
+        d = torch.randn(ns_, 3, generator=gen).double()
+        d = d / d.norm(dim=-1, keepdim=True)
+        dcols = [d]
+        for k in range(4):
+            dcols += [torch.sin(d * 2.0 ** k), torch.cos(d * 2.0 ** k)]
+        xd = torch.cat(dcols, -1)                                             # [ns, 27]
+        seen_d = sorted(c for g in range(4) for e in range(8) if (c := _x16_dir_col(4, g, e)) >= 0)
+        assert seen_d == list(range(27)), "every direction-encoding column sits in exactly one slot"
+        bd = np.zeros((32, ns_))
+        for g in range(4):
+            for e in range(8):
+                c = _x16_dir_col(4, g, e)
+                if c >= 0:
+                    bd[8 * g + e] = xd.numpy()[:, c]
+        Bv = [rnd_e(bd)] + B
+        NTV = W // 32
+        vt = dense(tile0, len(Bv), NTV + 1, Bv, 1); tile0 += NTV + 1; mfma += len(Bv) * (NTV + 1)
+        sigma = vt[NTV][0]
+        Bh = hand_off(vt[:NTV])
+        D = dense(tile0, len(Bh), 1, Bh, 0)[0]; tile0 += 1; mfma += len(Bh)
+        raw = np.concatenate([D[0:3].T, sigma[:, None]], 1)                  # [rgb, sigma]
+    else:
+        D = dense(tile0, len(B), 1, B, 0)[0]; tile0 += 1; mfma += len(B)
+        raw = D[0:5].T                                                       # channels 0..3: group 0's registers, channel 4: group 1's first
     assert tile0 == info.n_bias_tiles and mfma == info.mfma_per_block
     used = pos[0] * 1024
     assert used <= info.stream_bytes and not stream[used:].any(), "stream fully consumed"
@@ -407,7 +445,13 @@ def test_x16_stream_reproduces_the_trunk(precision):
             h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
             if i == 4:
                 h = torch.cat([x, h], -1)
-        ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
+        if views:                                                             # rnh:284-304
+            alpha = F.linear(h, fine.alpha_linear.weight.double(), fine.alpha_linear.bias.double())
+            feat = F.linear(h, fine.feature_linear.weight.double(), fine.feature_linear.bias.double())
+            hv = F.relu(F.linear(torch.cat([feat, xd], -1), fine.views_linears[0].weight.double(), fine.views_linears[0].bias.double()))
+            ref = torch.cat([F.linear(hv, fine.rgb_linear.weight.double(), fine.rgb_linear.bias.double()), alpha], -1).numpy()
+        else:
+            ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
     tol = 8e-2 if precision == "bf16" else 1e-2
     err = np.abs(raw - ref).max()
     assert err <= tol * np.abs(ref).max(), f"x16 trunk + head mismatch {err} vs scale {np.abs(ref).max()}"
