@@ -184,8 +184,10 @@ typedef enum nrnerf_render_flags {
     NRNERF_RENDER_UNFUSED_COMPOSITE = 1u << 1,  /* the final pass' compositing as a separate launch instead of the network kernel's epilogue */
     NRNERF_RENDER_SPLIT_COARSE = 1u << 2,       /* split path: stand-alone bender + trunk-only kernel for the coarse pass as well
                                                    (implied when the coarse pass runs on the 16x16x32 kernel) */
-    NRNERF_RENDER_NO_X16 = 1u << 3,             /* every pass on the 32x32x16 kernels */
-    NRNERF_RENDER_X16_FINE_ONLY = 1u << 4       /* 16x16x32 kernel for the fine pass only (the coarse pass on the fused-bender 32x32x16 kernel) */
+    NRNERF_RENDER_NO_X16 = 1u << 3,             /* every pass, and the stand-alone bender, on the 32x32x16 kernels */
+    NRNERF_RENDER_X16_FINE_ONLY = 1u << 4,      /* 16x16x32 kernel for the fine pass only (the coarse pass on the fused-bender 32x32x16 kernel) */
+    NRNERF_RENDER_BENDER_32X32 = 1u << 5        /* split path, bf16 mode: the stand-alone bender on the fused kernels' own 32x32x16 tiles
+                                                   (bent points then equal the fused-bender pass up to conversion ties) instead of 16x16x32 */
 } nrnerf_render_flags;
 
 /* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */

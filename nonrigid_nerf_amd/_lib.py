@@ -85,7 +85,7 @@ class RenderArgs(C.Structure):
 # include/nrnerf.h: nrnerf_model_flags / nrnerf_render_flags (ABI 7: kernel-selection switches are fields of the call; the library
 # reads no environment variable).  The test switches NRNERF_* of the environment are mapped to them HERE, on the Python side.
 MODEL_FORCE_GENERIC, MODEL_NO_X16_F16 = 1 << 0, 1 << 1
-RENDER_FUSED_FINE_BENDER, RENDER_UNFUSED_COMPOSITE, RENDER_SPLIT_COARSE, RENDER_NO_X16, RENDER_X16_FINE_ONLY = (1 << i for i in range(5))
+RENDER_FUSED_FINE_BENDER, RENDER_UNFUSED_COMPOSITE, RENDER_SPLIT_COARSE, RENDER_NO_X16, RENDER_X16_FINE_ONLY, RENDER_BENDER_32X32 = (1 << i for i in range(6))
 
 
 def model_flags_from_env() -> int:
@@ -99,7 +99,7 @@ def model_flags_from_env() -> int:
 
 
 def render_flags_from_env() -> int:
-    """NRNERF_FUSED_FINE_BENDER=1, NRNERF_UNFUSED_COMPOSITE=1, NRNERF_SPLIT_COARSE=1, NRNERF_X16=0|1|2 -> nrnerf_render_args.flags
+    """NRNERF_FUSED_FINE_BENDER=1, NRNERF_UNFUSED_COMPOSITE=1, NRNERF_SPLIT_COARSE=1, NRNERF_X16=0|1|2, NRNERF_X16_BENDER=0 -> nrnerf_render_args.flags
     (read per call: the parity tests render one scene through several kernel routes in one process)."""
     f = 0
     if os.environ.get("NRNERF_FUSED_FINE_BENDER") == "1":
@@ -108,6 +108,8 @@ def render_flags_from_env() -> int:
         f |= RENDER_UNFUSED_COMPOSITE
     if os.environ.get("NRNERF_SPLIT_COARSE") == "1":
         f |= RENDER_SPLIT_COARSE
+    if os.environ.get("NRNERF_X16_BENDER", "1") == "0":
+        f |= RENDER_BENDER_32X32
     x16 = os.environ.get("NRNERF_X16")
     if x16 is not None and x16.strip() != "":
         f |= {0: RENDER_NO_X16, 1: RENDER_X16_FINE_ONLY}.get(int(x16), 0)

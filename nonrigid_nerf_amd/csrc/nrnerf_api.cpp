@@ -22,6 +22,7 @@
 #include "nrnerf_kernels.h"
 #include "nrnerf_aux.h"
 #include "nrnerf_x16_api.h"
+#include "nrnerf_bend_x16_plan.h"
 #include "nrnerf_plan.h"
 
 using namespace nrn;
@@ -340,6 +341,70 @@ void pack_x16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, PackedPass& 
     }
     if (d.precision == NRNERF_PREC_F16) pack_pass_x16<Shape16, ArchDefault>(m, d.precision, out, lay);
     else pack_pass_x16<Shape16Fast, ArchDefault>(m, d.precision, out, lay);
+}
+
+// The bender + rigidity MLPs for the 16x16x32 stand-alone bender (nrnerf_bend_x16.h, PlanX16Bend): f16 fragments of 16 rows x 32 k,
+// element (lane (r, g), e) = W[x16b_out_row(t, r)][x16b_in_col(s, g, e)]; bias table [tile][16 rows].
+template <class A>
+void pack_pass_x16_bend(const nrnerf_bender_desc& bd, PackedPass& out, const FlatLayout* lay = nullptr) {
+    using PL = PlanX16Bend<A>;
+    using SH = Shape16Fast;
+    const Tables& T = PL::TB;
+    out.ntiles = T.ntiles; out.nunits = cdiv(T.nfrags, SH::UNIT_FRAGS);
+    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES; out.mfma_per_block = T.mfma_per_block;
+    out.stream.assign((size_t)T.nfrags * SH::FRAG_BYTES, 0);
+    out.unit_off.assign(1, 0);
+    out.bias.assign((size_t)T.ntiles * 16, 0.0f);
+    if (lay) {
+        out.src.assign(out.stream.size() / 2, -1);
+        out.fmt.assign(out.stream.size() / 2, 2);              // f16
+        out.bias_src.assign(out.bias.size(), -1);
+    }
+    size_t written = 0;
+    for (int l = 0; l < T.nlayers; ++l) {
+        const LayerSpec& sp = T.layers[l];
+        const nrnerf_linear* lin = (sp.kind <= LK_BEND_OUT) ? &bd.network[sp.index] : &bd.rigidity_network[sp.index];
+        const int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
+        for (int t = 0; t < sp.nt; ++t) {
+            const TileInfo& ti = T.tiles[sp.tile0 + t];
+            for (int s = 0; s < sp.ns; ++s) {
+                const size_t fi = (size_t)ti.gbase + (size_t)s * ti.gstride;
+                if (fi >= (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
+                uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 15, g = lane >> 4;
+                    const int row = x16b_out_row(sp.kind, t, r, lin->out_features);
+                    for (int e = 0; e < 8; ++e) {
+                        const int col = x16b_in_col(sp.kind, s, g, e, lin->in_features);
+                        const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
+                        if (lay) out.src[fi * (SH::FRAG_BYTES / 2) + (size_t)lane * 8 + e] =
+                            (row < 0 || col < 0 || wbase < 0) ? -1 : (int32_t)(wbase + (int64_t)row * lin->in_features + col);
+                        const uint16_t q = f32_to_f16(w);
+                        std::memcpy(fr + (lane * 8 + e) * 2, &q, 2);
+                    }
+                }
+                ++written;
+            }
+            for (int r = 0; r < 16; ++r) {
+                const int row = x16b_out_row(sp.kind, t, r, lin->out_features);
+                out.bias[(size_t)(sp.tile0 + t) * 16 + r] = (row >= 0 && lin->bias) ? lin->bias[row] : 0.0f;
+                if (lay && row >= 0 && bbase >= 0) out.bias_src[(size_t)(sp.tile0 + t) * 16 + r] = (int32_t)(bbase + row);
+            }
+        }
+    }
+    if (written != (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
+}
+// does the 16x16x32 bender kernel have this bender?  (one of the two compiled shapes, "bf16" mode: the single-product bender)
+bool bend_x16_eligible(const nrnerf_model_desc& d) {
+    if (!d.bender || d.precision != NRNERF_PREC_BF16) return false;
+    const nrnerf_bender_desc& b = *d.bender;
+    using A = ArchDefault;
+    return b.latent_size == A::LAT && b.hidden == A::BW && (b.depth == ArchDefault::BD || b.depth == ArchDeepBend::BD) &&
+           b.rigidity_hidden == A::RW && b.rigidity_depth == A::RD;
+}
+void pack_bend_x16(const nrnerf_model_desc& d, PackedPass& out, const FlatLayout* lay = nullptr) {
+    if (d.bender->depth == ArchDeepBend::BD) pack_pass_x16_bend<ArchDeepBend>(*d.bender, out, lay);
+    else pack_pass_x16_bend<ArchDefault>(*d.bender, out, lay);
 }
 
 // Transposed weights for the backward-data kernel (nrnerf_train.h): PlanB's layer list, fragment element
@@ -820,6 +885,7 @@ struct nrnerf_model {
     // the fine network's trunk once more, packed for the 16x16x32 kernel (nrnerf_net_x16.h): what the split-bender path's fine pass
     // runs when the call asks for no detail outputs
     PassDev fine_trunk_x16, coarse_trunk_x16;
+    PassDev bend_x16;             // the bender + rigidity MLPs packed for the 16x16x32 stand-alone bender ("bf16" mode)
     // training (nrnerf_train.h): transposed trunk weights of both networks; train_ok: see training_eligible, fp32 or bf16
     PassDev coarse_bwd, fine_bwd;
     bool train_ok = false;
@@ -1275,6 +1341,13 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) try {
                 m->fine_trunk_x16.mfma_flops_per_sample = px.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
                 m->fine_trunk_x16.output_ch = m->fine.output_ch;
             }
+            if (rc == NRNERF_OK && bend_x16_eligible(*desc)) {
+                PackedPass pbx;
+                pack_bend_x16(*desc, pbx, &lay);
+                rc = upload_pass(pbx, m->bend_x16);
+                m->bend_x16.algo_flops_per_sample = m->bend_only.algo_flops_per_sample;
+                m->bend_x16.mfma_flops_per_sample = pbx.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
+            }
             // the coarse network's trunk in the same packing: the coarse pass of the split path on the 16x16x32 kernel too
             if (rc == NRNERF_OK && desc->fine && x16_eligible(*desc, *desc->coarse)) {
                 PackedPass pxc;
@@ -1326,6 +1399,11 @@ int nrnerf_model_update(nrnerf_model* m, const nrnerf_model_desc* desc, void* hi
         pack_x16(*desc, desc->fine ? *desc->fine : *desc->coarse, px);
         rc = refresh_pass(px, m->fine_trunk_x16, stream);
     }
+    PackedPass pbx;
+    if (rc == NRNERF_OK && m->bend_x16.stream) {
+        pack_bend_x16(*desc, pbx);
+        rc = refresh_pass(pbx, m->bend_x16, stream);
+    }
     PackedPass pxc;
     if (rc == NRNERF_OK && m->coarse_trunk_x16.stream) {
         pack_x16(*desc, *desc->coarse, pxc);
@@ -1348,7 +1426,7 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     hipStream_t stream = (hipStream_t)hip_stream;
-    PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16, &m->coarse_trunk_x16,
+    PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16, &m->coarse_trunk_x16, &m->bend_x16,
                          &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
                          &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine};
     for (PassDev* p : passes)
@@ -1386,6 +1464,7 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->fine_trunk);
     free_pass(m->fine_trunk_x16);
     free_pass(m->coarse_trunk_x16);
+    free_pass(m->bend_x16);
     free_pass(m->coarse_trunk);
     free_pass(m->bend_only);
     free_pass(m->coarse_bwd);
@@ -1493,6 +1572,20 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     auto sample_out = [](const nrnerf_sample_outputs& o) {
         return SampleOut{o.visibility_weights, o.opacity_alpha, o.initial_input_pts, o.unmasked_offsets,
                          o.masked_offsets, o.input_pts, o.rigidity_mask};
+    };
+
+    // the stand-alone bender of the split path: the 16x16x32 kernel (nrnerf_bend_x16.h; "bf16" mode's single-product bender) unless the call
+    // asks for the 32x32x16 one (NRNERF_RENDER_BENDER_32X32: the bit-identity tests against the fused-bender kernels)
+    const bool bend_x16 = m->bend_x16.stream && !(a->flags & (NRNERF_RENDER_BENDER_32X32 | NRNERF_RENDER_NO_X16));
+    auto run_bender = [&](BendArgs& b, int slot, int n_samples) -> hipError_t {
+        if (bend_x16) {
+            b.wstream = m->bend_x16.stream; b.bias = m->bend_x16.bias;
+            return timed(slot, (double)N * n_samples * m->bend_x16.algo_flops_per_sample, (double)N * n_samples * m->bend_x16.mfma_flops_per_sample,
+                         [&] { return launch_bend_x16(bender_arch(m->arch_id), b, m->num_cus, stream); });
+        }
+        b.wstream = m->bend_only.stream; b.bias = m->bend_only.bias;
+        return timed(slot, (double)N * n_samples * m->bend_only.algo_flops_per_sample, (double)N * n_samples * m->bend_only.mfma_flops_per_sample,
+                     [&] { return launch_bend(m->precision, bender_arch(m->arch_id), b, m->num_cus, stream); });
     };
 
     // ---- stratified jitter of the coarse depths (perturb > 0): both coarse kernels then read explicit depths
@@ -1636,10 +1729,8 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         bc.rays = a->rays; bc.ray_stride = a->ray_stride;
         bc.latents = a->latents; bc.lat_stride = a->latent_stride;
         bc.z = zc; bc.lindisp = a->lindisp; bc.rank = nullptr; bc.n_rays = N; bc.n_per_ray = S; bc.out_stride = S;
-        bc.wstream = m->bend_only.stream; bc.bias = m->bend_only.bias;
         bc.bent4 = bent_c; bc.knobs = kn;
-        e = timed(5, (double)N * S * m->bend_only.algo_flops_per_sample, (double)N * S * m->bend_only.mfma_flops_per_sample,
-                  [&] { return launch_bend(m->precision, bender_arch(m->arch_id), bc, m->num_cus, stream); });
+        e = run_bender(bc, 5, S);
         if (e != hipSuccess) return NRNERF_ERR_HIP;
         na.pts4 = bent_c; na.bent4 = nullptr;
         if (x16_coarse) {
@@ -1703,10 +1794,8 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         ba.rays = a->rays; ba.ray_stride = a->ray_stride;
         ba.latents = a->latents; ba.lat_stride = a->latent_stride;
         ba.z = z_new; ba.rank = rank_new; ba.n_rays = N; ba.n_per_ray = I; ba.out_stride = SF;
-        ba.wstream = m->bend_only.stream; ba.bias = m->bend_only.bias;
         ba.bent4 = bent4; ba.knobs = kn;
-        e = timed(4, (double)N * I * m->bend_only.algo_flops_per_sample, (double)N * I * m->bend_only.mfma_flops_per_sample,
-                  [&] { return launch_bend(m->precision, bender_arch(m->arch_id), ba, m->num_cus, stream); });
+        e = run_bender(ba, 4, I);
         if (e != hipSuccess) return NRNERF_ERR_HIP;
         // K2: trunk + head on ready-made points (compiled architecture 0 without bender)
         nf.pts4 = bent4; nf.bent4 = nullptr;

@@ -64,12 +64,13 @@ template <class A> struct X16Cfg { static constexpr int NB = (A::W <= 128) ? NRN
 // (the head) alone.  Per fragment NB MFMAs (one per block).  Two accumulator sets: pair p runs in set p & 1 while the epilogue of
 // pair p - 1 (pack -> out[b][p - 1], NB chunks of ~8 VALU) is issued among its first k-steps; the last pair's epilogue follows the
 // layer.  The first MFMA of a chain takes the bias as its C operand (no copies).
-template <class P0, class P1, class PL, int LI, int NS0, int NS1, int NB, class ST, class IN0, class IN1, class EPI>
+// (PF_: fragments requested ahead; the stand-alone bender, nrnerf_bend_x16.h, runs several waves per SIMD and asks for fewer)
+template <class P0, class P1, class PL, int LI, int NS0, int NS1, int NB, int PF_ = NRN_X16_PF, class ST, class IN0, class IN1, class EPI>
 __device__ __forceinline__ void dense_x16(ST& st, const __attribute__((address_space(3))) f32x4* bias_lane, const IN0 (&in0)[NB], const IN1 (&in1)[NB],
                                           EPI&& epi) {
     constexpr LayerSpec spec = PL::TB.layers[LI];
     static_assert(spec.ns == NS0 + NS1, "k-step count mismatch between kernel and plan");
-    constexpr int NS = NS0 + NS1, NT = spec.nt, Q = NT * NS, PF = NRN_X16_PF;
+    constexpr int NS = NS0 + NS1, NT = spec.nt, Q = NT * NS, PF = PF_;
     using SQ = SeqPos<NT, NS>;
     constexpr int G0 = PL::TB.tiles[spec.tile0].gbase;
     typename P1::frag a[PF];

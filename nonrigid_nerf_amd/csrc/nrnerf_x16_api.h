@@ -10,4 +10,7 @@ hipError_t launch_net_x16(int precision, int arch, bool views, const NetArgs& a,
 // rays of one fused-compositing group of that kernel: its waves per workgroup x the fewest rays whose 16-sample blocks fill whole
 // iterations -- the API layer's "enough rays to fuse" threshold asks here instead of restating the kernel's mapping
 long long x16_rays_per_group(int arch, int S);
+// the stand-alone ray bender on 16x16x32 MFMAs (nrnerf_bend_x16.h): arch 0 = the 5 x 64 bender, 1 = 7 x 64; BendArgs::wstream / bias =
+// the image of pack_pass_x16_bend (f16 fragments of PlanX16Bend)
+hipError_t launch_bend_x16(int arch, const BendArgs& a, int num_cus, hipStream_t stream);
 }  // namespace nrn

@@ -882,6 +882,59 @@ def test_large_sample_counts_in_the_16_bit_modes(cfg_kw, precision):
     assert float(got["_z_vals"].min()) >= lo - 1e-6 and float(got["_z_vals"].max()) <= hi + 1e-6
 
 
+@pytest.mark.parametrize("bend_depth", [5, 7])
+def test_x16_bender_is_an_equally_good_rounding_of_the_bender(bend_depth):
+    """bf16 mode's stand-alone bender of the split path runs on 16x16x32 MFMAs (csrc/nrnerf_bend_x16.h) by default and on the fused
+    kernels' own 32x32x16 tiles with NRNERF_X16_BENDER=0: the same f16 products summed in fp32 in another order.  The bender ALONE,
+    through the surface reduction of a plain render (surface_pts = the bent point at the median sample, rigidity = its mask): against
+    the exact-fp32 bender's bent points AT THE SAME DEPTHS (nrnerf_bender_forward on the render's own merged depths) both benders
+    must be equally far (rmse within 30 %, maximum within 3 x), on the rays whose median sample is the same in both renders; and
+    the maps of the whole render are held to the same statement against the fp32-MFMA render."""
+    cfg = SceneConfig(bend_depth=bend_depth)
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(4096, 21, cfg)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    r, l = rays.to(DEV), latents.to(DEV)
+
+    def run(precision, env):
+        model = R.get_model(coarse, fine, precision=precision)
+        with contextlib.ExitStack() as st:
+            for k, v in env.items():
+                st.enter_context(_setenv(k, v))
+            with torch.no_grad():
+                out = model.render(r, l, cfg.N_samples, cfg.N_importance, want_z_vals=True, surface=True)
+        torch.cuda.synchronize()
+        return out
+
+    # (NRNERF_X16=1: the coarse pass on the fused-bender kernel in both, so the importance samples are the same bits and only
+    #  the bender of the new samples and the fine trunk differ)
+    new = run("bf16", {"NRNERF_X16": "1"})
+    old = run("bf16", {"NRNERF_X16": "1", "NRNERF_X16_BENDER": "0"})
+    assert torch.equal(new["_z_vals"], old["_z_vals"]) and torch.equal(new["rgb0"], old["rgb0"])
+    # the reference bent points AT THESE DEPTHS: the exact-fp32 bender (nrnerf_bender_forward, the training entry point) on the merged depths
+    from nonrigid_nerf_amd import training
+    with torch.no_grad():
+        bent_ref, det = training.bend_native(R.get_model(coarse, fine, precision="f32"), rb, r, new["_z_vals"], l)
+    same = new["median_index"] == old["median_index"]
+    assert same.float().mean().item() > 0.9
+    idx = new["median_index"].long()[:, None, None]
+    want = torch.gather(bent_ref, 1, idx.expand(-1, 1, 3))[:, 0]
+    want_rig = torch.gather(det["rigidity_mask"], 1, idx.expand(-1, 1, 1))[:, 0, 0]
+    e_new = (new["surface_pts"] - want)[same].norm(dim=-1)
+    e_old = (old["surface_pts"] - want)[same].norm(dim=-1)
+    print(f"\n[bender {bend_depth} x 64, bf16 mode] |bent point - exact fp32 bender's|: 16x16x32 rmse {e_new.pow(2).mean().sqrt().item():.2e} max {e_new.max().item():.2e}; "
+          f"32x32x16 rmse {e_old.pow(2).mean().sqrt().item():.2e} max {e_old.max().item():.2e}")
+    assert e_new.pow(2).mean().sqrt().item() <= 1.3 * e_old.pow(2).mean().sqrt().item() + 1e-7
+    assert e_new.max().item() <= 3.0 * e_old.max().item() + 1e-6
+    er_new = (new["surface_rigidity"] - want_rig)[same].abs()
+    er_old = (old["surface_rigidity"] - want_rig)[same].abs()
+    assert er_new.mean().item() <= 1.3 * er_old.mean().item() + 1e-6 and er_new.max().item() <= 3.0 * er_old.max().item() + 1e-4
+    ref = run("f32", {})
+    for k in ("rgb_map", "acc_map"):
+        a_, b_ = (new[k] - ref[k]).abs(), (old[k] - ref[k]).abs()
+        assert a_.mean().item() <= 1.3 * b_.mean().item() + 1e-6 and a_.max().item() <= 3.0 * b_.max().item() + 1e-4, k
+
+
 def test_more_samples_than_the_library_takes_are_refused_with_the_documented_status():
     cfg = SceneConfig(N_samples=1000, N_importance=100)
     scene = make_scene(cfg, 0)

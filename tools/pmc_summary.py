@@ -45,14 +45,26 @@ def main(dirs):
                     for c, v in per[(d, i)].items():
                         agg[c].append(v)
         out[label] = {c: sorted(v)[len(v) // 2] for c, v in agg.items()}
-    agg = collections.defaultdict(list)
-    for kb, cs in bend.items():
-        for c, v in cs.items():
-            agg[c].append(v)
-    if agg:
-        out["bend"] = {c: sorted(v)[len(v) // 2] for c, v in agg.items()}
+    # the stand-alone bender: one launch per frame (importance samples) up to round 4; two since round 5 (coarse samples, then the
+    # importance samples) -- told apart by their order within a pass when the launch count is even and the durations differ by ~2x
+    for d in dirs:
+        ids = sorted(i for (dd, i) in bend if dd == d)
+        durs = [bend[(d, i)]["_us"] for i in ids]
+        two = len(ids) >= 2 and len(ids) % 2 == 0 and sum(durs[1::2]) > 1.4 * sum(durs[0::2])
+        for n, i in enumerate(ids):
+            bend[(d, i)]["_label"] = ("bend_coarse" if n % 2 == 0 else "bend_fine") if two else "bend"
+    for label in ("bend", "bend_coarse", "bend_fine"):
+        agg = collections.defaultdict(list)
+        for kb, cs in bend.items():
+            if cs.get("_label") != label:
+                continue
+            for c, v in cs.items():
+                if c != "_label":
+                    agg[c].append(v)
+        if agg:
+            out[label] = {c: sorted(v)[len(v) // 2] for c, v in agg.items()}
     print("# rocprofv3 --pmc summary, net_kernel / bend_kernel (median over launches), bench.py workload (196608 rays, 64+128)")
-    for label in [l for l in ("coarse", "fine", "bend") if l in out]:
+    for label in [l for l in ("coarse", "fine", "bend", "bend_coarse", "bend_fine") if l in out]:
         c = out[label]
         print(f"\n[{label} pass]  duration {c.get('_us', 0):.1f} us")
         for k in sorted(c):
