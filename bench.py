@@ -287,10 +287,10 @@ def main():
     kern_own = torch.tensor([prof[k]["ms"] / args.steps for k in names], dtype=torch.float64)
     per_rank_kernels = [{k: round(float(v), 4) for k, v in zip(names, kern_own) if v > 0}]
     if world > 1:
-        t = kern_own.to("cpu" if one_gpu else dev)
-        allk = torch.empty(world, len(names), dtype=torch.float64, device=t.device)
+        t = kern_own.to("cpu" if one_gpu else dev).contiguous()
+        allk = torch.empty(world * len(names), dtype=torch.float64, device=t.device)
         dist.all_gather_into_tensor(allk, t)
-        per_rank_kernels = [{k: round(float(v), 4) for k, v in zip(names, row) if v > 0} for row in allk.cpu()]
+        per_rank_kernels = [{k: round(float(v), 4) for k, v in zip(names, row) if v > 0} for row in allk.cpu().view(world, len(names))]
     rccl_ranks = 1
     if world > 1:        # counted by an actual collective on the job's backend, not copied from the environment
         one = torch.ones(1, device="cpu" if one_gpu else dev)

@@ -548,6 +548,39 @@ typedef struct nrnerf_wgrad_args {
 #define NRNERF_WGRAD_STRIDE(depth, width) (((depth) - 1) * (width) * (width) + 3 * (width) * 64 + ((depth) + 1) * (width))
 int nrnerf_trunk_wgrad(const nrnerf_model* model, const nrnerf_wgrad_args* args, void* hip_stream);
 
+/* The loss of one training iteration over the outputs of render_rays (reference training_wrapper_class.forward, train.py:207-287), per ray:
+ *   loss[r] = mean((rgb_map - target)^2) + [rgb0] mean((rgb0 - target)^2)                                    train.py:207-218, rnh:10-13
+ *           + offsets_weight * ( mean_s( w |off|^(2 - rig) ) + rigidity_weight * mean_s( w rig ) )          train.py:221-242
+ *           + divergence_weight * mean_s( (1 - exp(-relu(alpha))) |div|^2 )                                 train.py:245-287, rnh:61-69
+ * w (visibility weights) and the opacity factor are treated as constants, as the reference detaches them (train.py:223, rnh:65-66); the
+ * increasing schedule (train.py:240, 285) is folded into offsets_weight / divergence_weight by the caller.  One launch forward, one
+ * backward (g_* = gradient of sum_r g_loss[r] loss[r]); all device pointers; runs on the device that owns `loss` / `g_loss`.
+ * Eager torch ops take ~80 launches of 2-5 us for the same on a 1024-ray step. */
+typedef struct nrnerf_loss_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_loss_args) */
+    int32_t n_rays, n_samples;  /* N; S of the per-sample tensors (the coarse pass' detail outputs) */
+    const float* rgb_map;       /* [N,3] */
+    const float* rgb0;          /* [N,3] or NULL */
+    const float* target;        /* [N,3] */
+    const float* weights;       /* [N,S] visibility_weights, or NULL: no offsets / rigidity term */
+    const float* offsets;       /* [N,S,3] unmasked_offsets */
+    const float* rigidity;      /* [N,S] rigidity_mask */
+    const float* alpha;         /* [N,S] opacity_alpha (the divergence term's weights before 1 - exp(-relu(.))) */
+    const float* divergence;    /* [N,S] per-sample divergence, or NULL: no divergence term */
+    float offsets_weight, rigidity_weight, divergence_weight;
+    const float* schedule;      /* device scalar multiplied into offsets_weight and divergence_weight (the increasing schedule of
+                                   train.py:240, 285 as a value a replayed HIP graph can change between steps), or NULL = 1 */
+    float* loss;                /* forward: out [N] */
+    const float* g_loss;        /* backward: in [N] */
+    float* g_rgb_map;           /* backward outs; g_rgb0 / g_offsets + g_rigidity / g_divergence NULL exactly where the input is */
+    float* g_rgb0;
+    float* g_offsets;
+    float* g_rigidity;
+    float* g_divergence;
+} nrnerf_loss_args;
+int nrnerf_loss_forward(const nrnerf_loss_args* args, void* hip_stream);
+int nrnerf_loss_backward(const nrnerf_loss_args* args, void* hip_stream);
+
 /* raw2outputs (train.py:724-789) of one pass, optionally followed by sample_pdf + merge (run_nerf_helpers.py:651-698,
  * train.py:910-920), and its backward.  Runs on the device that owns raw4. */
 typedef struct nrnerf_composite_args {

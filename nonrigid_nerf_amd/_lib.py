@@ -116,6 +116,15 @@ def render_flags_from_env() -> int:
     return f
 
 
+class LossArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+                ("rgb_map", C.c_void_p), ("rgb0", C.c_void_p), ("target", C.c_void_p),
+                ("weights", C.c_void_p), ("offsets", C.c_void_p), ("rigidity", C.c_void_p), ("alpha", C.c_void_p), ("divergence", C.c_void_p),
+                ("offsets_weight", C.c_float), ("rigidity_weight", C.c_float), ("divergence_weight", C.c_float), ("schedule", C.c_void_p),
+                ("loss", C.c_void_p), ("g_loss", C.c_void_p),
+                ("g_rgb_map", C.c_void_p), ("g_rgb0", C.c_void_p), ("g_offsets", C.c_void_p), ("g_rigidity", C.c_void_p), ("g_divergence", C.c_void_p)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * NUM_KERNELS), ("launches", C.c_int64 * NUM_KERNELS),
                 ("flops", C.c_double * NUM_KERNELS), ("mfma_flops", C.c_double * NUM_KERNELS)]
@@ -224,6 +233,8 @@ EXPORTS = {
     "nrnerf_model_destroy": (None, [C.c_void_p]),
     "nrnerf_model_precision": (C.c_int, [C.c_void_p]),
     "nrnerf_model_is_generic": (C.c_int, [C.c_void_p]),
+    "nrnerf_loss_forward": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
+    "nrnerf_loss_backward": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),

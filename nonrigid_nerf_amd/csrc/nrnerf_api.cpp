@@ -23,6 +23,7 @@
 #include "nrnerf_aux.h"
 #include "nrnerf_x16_api.h"
 #include "nrnerf_bend_x16_plan.h"
+#include "nrnerf_loss.h"
 #include "nrnerf_plan.h"
 
 using namespace nrn;
@@ -1866,6 +1867,29 @@ int device_of(const void* ptr, int& dev) {
     return NRNERF_OK;
 }
 }  // namespace
+
+namespace {
+int loss_call(const nrnerf_loss_args* a, bool backward, void* hip_stream) {
+    if (!a || a->struct_size != sizeof(nrnerf_loss_args) || a->n_rays < 0 || a->n_samples < 0 || !a->rgb_map || !a->target) return NRNERF_ERR_INVALID;
+    if (a->weights && (!a->offsets || !a->rigidity)) return NRNERF_ERR_INVALID;
+    if (a->divergence && !a->alpha) return NRNERF_ERR_INVALID;
+    if ((a->weights || a->divergence) && a->n_samples < 1) return NRNERF_ERR_INVALID;
+    if (!backward && !a->loss) return NRNERF_ERR_INVALID;
+    if (backward && (!a->g_loss || !a->g_rgb_map || (a->rgb0 && !a->g_rgb0) || (a->weights && (!a->g_offsets || !a->g_rigidity)) ||
+                     (a->divergence && !a->g_divergence))) return NRNERF_ERR_INVALID;
+    if (a->n_rays == 0) return NRNERF_OK;
+    int dev = 0;
+    if (device_of(backward ? (const void*)a->g_loss : (const void*)a->loss, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    LossArgs l{a->n_rays, a->n_samples, a->rgb_map, a->rgb0, a->target, a->weights, a->offsets, a->rigidity, a->alpha, a->divergence,
+               a->offsets_weight, a->rigidity_weight, a->divergence_weight, a->schedule, a->loss, a->g_loss, a->g_rgb_map, a->g_rgb0, a->g_offsets,
+               a->g_rigidity, a->g_divergence};
+    return launch_loss(l, backward, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+}  // namespace
+int nrnerf_loss_forward(const nrnerf_loss_args* a, void* hip_stream) try { return loss_call(a, false, hip_stream); } NRN_CATCH
+int nrnerf_loss_backward(const nrnerf_loss_args* a, void* hip_stream) try { return loss_call(a, true, hip_stream); } NRN_CATCH
 
 int nrnerf_merge_rows(const uint8_t* rank_new, int32_t n_rays, int32_t n_samples, int32_t n_importance, float* coarse_a, float* coarse_b,
                       float* new_a, float* new_b, float* merged_a, float* merged_b, int32_t inverse, void* hip_stream) try {

@@ -872,6 +872,94 @@ def why_no_native_divergence(ray_bender, input_points, point_latents):
     return None
 
 
+def _divergence_values(input_points, point_latents, ray_bender, exact, chunk):
+    """Per point the (Hutchinson estimate ``e^T J e`` of the, or with ``exact`` the exact) divergence of the masked offsets field, [M], on the
+    native kernels (the caller has checked why_no_native_divergence).  The probe vectors are drawn with the reference's own call per
+    ``chunk`` of points (``torch.randn_like`` on a [chunk, 3] tensor, rnh:106)."""
+    model = R.model_of_bender(ray_bender, input_points.device)
+    M = int(input_points.shape[0])
+    pts = input_points.detach()
+    token = _param_token(ray_bender, _bender_params(ray_bender))
+    if exact:                                            # divergence_exact (rnh:72-77): trace of J = sum_k unit_k^T J unit_k
+        div = None
+        for k in range(3):
+            e = torch.zeros(M, 3, dtype=torch.float32, device=pts.device)
+            e[:, k] = 1.0
+            d = _Divergence.apply(point_latents, model, ray_bender, pts, e, token)
+            div = d if div is None else div + d
+        return div
+    e = torch.empty_like(pts)                        # divergence_approx (rnh:103-113), one draw per chunk as in rnh:52-59:
+    for i in range(0, M, int(chunk)):                # randn_like(offsets) per chunk = empty_like().normal_(): same draws, no cat
+        e[i:i + chunk, :].normal_()
+    return _Divergence.apply(point_latents, model, ray_bender, pts, e, token)
+
+
+class _FusedLoss(torch.autograd.Function):
+    """training_wrapper_class.forward's loss terms (train.py:207-287) over the render outputs as nrnerf_loss_forward / _backward: one
+    launch each instead of ~30 + ~50 eager torch launches of 2-5 us (a third of a graphed 1024-ray step's launches).  Differentiable
+    inputs: rgb_map, rgb0, unmasked offsets, rigidity mask, divergence; the visibility weights and the opacity are constants, as the
+    reference detaches them (train.py:223, rnh:65-66)."""
+
+    @staticmethod
+    def forward(ctx, rgb_map, rgb0, target, weights, offsets, rigidity, alpha, div, offsets_weight, rigidity_weight, divergence_weight, schedule=None):
+        lib = _lib.load()
+        dev = rgb_map.device
+        f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        rgb_map_, rgb0_, target_, weights_, offsets_, rigidity_, alpha_, div_ = map(f32, (rgb_map, rgb0, target, weights, offsets, rigidity, alpha, div))
+        N = int(rgb_map_.shape[0])
+        S = int(weights_.numel() // N) if weights_ is not None else (int(div_.numel() // N) if div_ is not None else 0)
+        loss = torch.empty(N, dtype=torch.float32, device=dev)
+        a = _lib.LossArgs()
+        a.struct_size = C.sizeof(_lib.LossArgs)
+        a.n_rays, a.n_samples = N, S
+        ptr = lambda t: None if t is None else t.data_ptr()
+        a.rgb_map, a.rgb0, a.target = ptr(rgb_map_), ptr(rgb0_), ptr(target_)
+        a.weights, a.offsets, a.rigidity, a.alpha, a.divergence = ptr(weights_), ptr(offsets_), ptr(rigidity_), ptr(alpha_), ptr(div_)
+        a.offsets_weight, a.rigidity_weight, a.divergence_weight = float(offsets_weight), float(rigidity_weight), float(divergence_weight)
+        # the schedule factor as a device scalar when the caller has it as a tensor (GraphedStep: a graph input)
+        sched = None if schedule is None else schedule.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+        a.schedule = ptr(sched)
+        a.loss = loss.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(lib.nrnerf_loss_forward(C.byref(a), _stream(dev)), "nrnerf_loss_forward")
+        ctx.sched = sched
+        ctx.save_for_backward(*[t for t in (rgb_map_, rgb0_, target_, weights_, offsets_, rigidity_, alpha_, div_) if t is not None])
+        ctx.have = [t is not None for t in (rgb_map_, rgb0_, target_, weights_, offsets_, rigidity_, alpha_, div_)]
+        ctx.scal = (N, S, float(offsets_weight), float(rigidity_weight), float(divergence_weight))
+        ctx.shapes = (None if offsets is None else offsets.shape, None if rigidity is None else rigidity.shape, None if div is None else div.shape)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss):
+        lib = _lib.load()
+        it = iter(ctx.saved_tensors)
+        rgb_map, rgb0, target, weights, offsets, rigidity, alpha, div = [next(it) if h else None for h in ctx.have]
+        N, S, ow, rw, dw = ctx.scal
+        dev = rgb_map.device
+        g_loss = g_loss.to(torch.float32).contiguous()
+        new = lambda t: None if t is None else torch.empty_like(t)
+        g_map, g_0, g_off, g_rig, g_div = new(rgb_map), new(rgb0), new(offsets), new(rigidity), new(div)
+        a = _lib.LossArgs()
+        a.struct_size = C.sizeof(_lib.LossArgs)
+        a.n_rays, a.n_samples = N, S
+        ptr = lambda t: None if t is None else t.data_ptr()
+        a.rgb_map, a.rgb0, a.target = ptr(rgb_map), ptr(rgb0), ptr(target)
+        a.weights, a.offsets, a.rigidity, a.alpha, a.divergence = ptr(weights), ptr(offsets), ptr(rigidity), ptr(alpha), ptr(div)
+        a.offsets_weight, a.rigidity_weight, a.divergence_weight = ow, rw, dw
+        a.schedule = ptr(ctx.sched)
+        a.g_loss = g_loss.data_ptr()
+        a.g_rgb_map, a.g_rgb0, a.g_offsets, a.g_rigidity, a.g_divergence = ptr(g_map), ptr(g_0), ptr(g_off), ptr(g_rig), ptr(g_div)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nrnerf_loss_backward(C.byref(a), _stream(dev)), "nrnerf_loss_backward")
+        so, sr, sd = ctx.shapes
+        return (g_map, g_0, None, None, None if g_off is None else g_off.view(so), None if g_rig is None else g_rig.view(sr), None,
+                None if g_div is None else g_div.view(sd), None, None, None, None)
+
+
+FUSED_LOSS = True        # training_loss: the loss terms as nrnerf_loss_forward / _backward (False: eager torch ops, the gradient-parity reference)
+
+
 def compute_divergence_loss(offsets_of_inputs, input_points, point_latents, ray_bender, exact, chunk, N_rays, weights=None,
                             backprop_into_weights=True):
     """Signature and semantics of reference ``compute_divergence_loss`` (run_nerf_helpers.py:22-69), what
@@ -889,22 +977,7 @@ def compute_divergence_loss(offsets_of_inputs, input_points, point_latents, ray_
         return ref(offsets_of_inputs, input_points, point_latents, ray_bender, exact, chunk, N_rays, weights=weights,
                    backprop_into_weights=backprop_into_weights)
     input_points.requires_grad = True                                                        # rnh:39 (kept: callers may look at it)
-    model = R.model_of_bender(ray_bender, input_points.device)
-    M = int(input_points.shape[0])
-    pts = input_points.detach()
-    token = _param_token(ray_bender, _bender_params(ray_bender))
-    if exact:                                            # divergence_exact (rnh:72-77): trace of J = sum_k unit_k^T J unit_k
-        div = None
-        for k in range(3):
-            e = torch.zeros(M, 3, dtype=torch.float32, device=pts.device)
-            e[:, k] = 1.0
-            d = _Divergence.apply(point_latents, model, ray_bender, pts, e, token)
-            div = d if div is None else div + d
-    else:                                                # divergence_approx (rnh:103-113), one draw per chunk as in rnh:52-59
-        e = torch.empty_like(pts)                    # randn_like(offsets) per chunk = empty_like().normal_(): same draws, no cat
-        for i in range(0, M, int(chunk)):
-            e[i:i + chunk, :].normal_()
-        div = _Divergence.apply(point_latents, model, ray_bender, pts, e, token)
+    div = _divergence_values(input_points, point_latents, ray_bender, exact, chunk)
     divergence_loss = torch.abs(div)                                                         # rnh:61
     divergence_loss = divergence_loss ** 2                                                   # rnh:62
     if weights is not None:
@@ -1103,11 +1176,33 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     kw = {k: v for k, v in render_kwargs.items() if k not in ("retraw", "ray_bender", "near", "far", "ndc", "use_viewdirs")}
     extras = R.batchify_rays(rays_flat, {"ray_bending_latents": ray_bending_latents}, chunk=chunk, detailed_output=detailed_output,
                              retraw=True, **kw)
+    schedule = (1.0 / 100.0) ** (1 - (global_step / N_iters))                                    # :240, 285
+    use_off = ray_bender is not None and offsets_loss_weight > 0.0
+    use_div = ray_bender is not None and divergence_loss_weight > 0.0
+    div_pts = div_lat = None
+    if use_div:
+        n_samples = int(extras["initial_input_pts"].shape[1])
+        lat = ray_bending_latents
+        div_lat = lat.view(N_rays, 1, -1).expand((N_rays, n_samples, lat.shape[-1])).reshape(-1, lat.shape[-1])                  # :256-262
+        div_pts = extras["initial_input_pts"].view(-1, 3)
+    if FUSED_LOSS and extras["rgb_map"].is_cuda and (not use_div or why_no_native_divergence(ray_bender, div_pts, div_lat) is None):
+        # the same terms as below, one launch forward and one backward (nrnerf_loss_forward / _backward)
+        div = None
+        if use_div:
+            div_pts.requires_grad = True                                                         # rnh:39
+            div = _divergence_values(div_pts, div_lat, ray_bender, False, chunk)
+        loss = _FusedLoss.apply(extras["rgb_map"], extras.get("rgb0"), target_s,
+                                extras["visibility_weights"] if use_off else None, extras["unmasked_offsets"] if use_off else None,
+                                extras["rigidity_mask"] if use_off else None, extras["opacity_alpha"] if use_div else None, div,
+                                *((offsets_loss_weight if use_off else 0.0, rigidity_loss_weight, divergence_loss_weight if use_div else 0.0, schedule)
+                                  if torch.is_tensor(schedule) else
+                                  (offsets_loss_weight * schedule if use_off else 0.0, rigidity_loss_weight,
+                                   divergence_loss_weight * schedule if use_div else 0.0)))
+        return loss, extras
     img2mse = lambda x, y: torch.mean(((x - y) ** 2).view(N_rays, -1), dim=1)                    # rnh:10-13
     loss = img2mse(extras["rgb_map"], target_s)                                                  # :207-212
     if "rgb0" in extras:
         loss = loss + img2mse(extras["rgb0"], target_s)                                          # :214-218
-    schedule = (1.0 / 100.0) ** (1 - (global_step / N_iters))                                    # :240, 285
     if ray_bender is not None and offsets_loss_weight > 0.0:                                     # :221-242
         weights = extras["visibility_weights"].detach().view(-1)
         offsets_loss = torch.mean((weights * torch.pow(torch.norm(extras["unmasked_offsets"].view(-1, 3), dim=-1),

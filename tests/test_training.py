@@ -432,7 +432,7 @@ def test_native_bender_forward_and_gradients_vs_torch_autograd(precision, knobs,
         worst = max(worst, err)
         bar = 1e-2 if (precision != "f32" and k != "latents") else 1e-4
         assert err <= bar, (k, err, bar)
-    print(f"\n[native bender vs torch autograd, {precision} model, weight gradients: {wgrad}] worst gradient error / scale {worst:.1e}")
+    print(f"\n[native bender vs torch autograd, {precision} model] worst gradient error / scale {worst:.1e}")
 
 
 def _block_tiles(x, N, S):
@@ -1016,3 +1016,99 @@ def test_an_optimiser_step_of_any_kind_reaches_the_packed_weights(kind):
     assert not torch.equal(after, before), "the step did not reach the packed weights"
     R.invalidate(coarse)
     assert torch.equal(render(), after)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_rgb0,with_offsets,with_div,S", [(True, True, True, 64), (False, True, False, 83), (True, False, True, 37), (True, False, False, 64)])
+def test_fused_loss_kernel_vs_torch_autograd(with_rgb0, with_offsets, with_div, S):
+    """nrnerf_loss_forward / _backward (csrc/nrnerf_loss.hip; training._FusedLoss) against the same terms written as the reference writes
+    them (train.py:207-287, rnh:10-13, 61-69) under torch.autograd: per-ray loss and every gradient, incl. torch's conventions at the
+    singular points (a zero offset vector: d|x|/dx = 0, d(n^e)/de = 0)."""
+    from nonrigid_nerf_amd import training
+    g = torch.Generator().manual_seed(S)
+    N = 301
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(DEV)
+    rgb_map, rgb0, target = torch.sigmoid(mk(N, 3)).requires_grad_(True), torch.sigmoid(mk(N, 3)).requires_grad_(True), torch.rand(N, 3, generator=g).to(DEV)
+    w = torch.rand(N, S, generator=g).to(DEV)
+    off = (0.01 * mk(N, S, 3))
+    off[::7, ::5] = 0.0                                   # singular points
+    off = off.requires_grad_(True)
+    rig = torch.rand(N, S, 1, generator=g).to(DEV)
+    rig[::11, ::3] = 1.0
+    rig = rig.requires_grad_(True)
+    alpha = 3.0 * mk(N, S)
+    div = mk(N * S).requires_grad_(True)
+    ow, rw, dw = 60.0 * 0.37, 5e-4, 3.0 * 0.37
+    upstream = torch.rand(N, generator=g).to(DEV)
+
+    def eager():
+        img2mse = lambda x, y: torch.mean(((x - y) ** 2).view(N, -1), dim=1)
+        loss = img2mse(rgb_map, target)
+        if with_rgb0:
+            loss = loss + img2mse(rgb0, target)
+        if with_offsets:
+            wf = w.detach().view(-1)
+            ol = torch.mean((wf * torch.pow(torch.norm(off.view(-1, 3), dim=-1), 2.0 - rig.view(-1))).view(N, -1), dim=-1)
+            ol = ol + rw * torch.mean((wf * rig.view(-1)).view(N, -1), dim=-1)
+            loss = loss + ow * ol
+        if with_div:
+            wd = (1.0 - torch.exp(-torch.relu(alpha.view(-1)))).detach()
+            loss = loss + dw * torch.mean((wd * torch.abs(div) ** 2).view(N, -1), dim=-1)
+        return loss
+
+    def fused():
+        return training._FusedLoss.apply(rgb_map, rgb0 if with_rgb0 else None, target, w if with_offsets else None, off if with_offsets else None,
+                                         rig if with_offsets else None, alpha if with_div else None, div if with_div else None,
+                                         ow if with_offsets else 0.0, rw, dw if with_div else 0.0)
+
+    leaves = [rgb_map, rgb0, off, rig, div]
+    res = {}
+    for name, fn in (("eager", eager), ("fused", fused)):
+        for t in leaves:
+            t.grad = None
+        loss = fn()
+        (loss * upstream).sum().backward()
+        res[name] = (loss.detach().clone(), [None if t.grad is None else t.grad.clone() for t in leaves])
+    le, lf = res["eager"][0], res["fused"][0]
+    assert torch.allclose(le, lf, rtol=2e-5, atol=1e-7), float((le - lf).abs().max())
+    for nm, ge, gf in zip(("rgb_map", "rgb0", "offsets", "rigidity", "divergence"), res["eager"][1], res["fused"][1]):
+        if ge is None:
+            assert gf is None or float(gf.abs().max()) == 0.0, nm
+            continue
+        assert gf is not None and torch.isfinite(gf).all(), nm
+        scale = float(ge.abs().max()) + 1e-20
+        assert float((ge - gf).abs().max()) <= 2e-5 * scale, (nm, float((ge - gf).abs().max()) / scale)
+
+
+@pytest.mark.gpu
+def test_training_loss_with_the_fused_loss_equals_the_eager_terms():
+    """training.training_loss (the shipped recipe: data term + offsets / rigidity + divergence regularisers) with its loss terms on
+    nrnerf_loss_* against the same call with eager torch ops (FUSED_LOSS = False): same random draws, same loss, same gradients."""
+    from nonrigid_nerf_amd import training
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, 1)
+    rays, latents = make_rays(257, 3, cfg)
+    target = torch.rand(257, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+    R.set_precision("f32")
+    out = {}
+    for fused in (False, True):
+        rb, coarse, fine = _modules(scene)
+        lat = latents.to(DEV).requires_grad_(True)
+        kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=64, N_importance=64, perturb=1.0, raw_noise_std=1.0)
+        old, training.FUSED_LOSS = training.FUSED_LOSS, fused
+        try:
+            torch.manual_seed(11)
+            loss, _ = training.training_loss(rays.to(DEV), lat, target, kw, offsets_loss_weight=60.0, divergence_loss_weight=3.0,
+                                             rigidity_loss_weight=5e-4, global_step=120000, N_iters=200000)
+            loss.mean().backward()
+        finally:
+            training.FUSED_LOSS = old
+        grads = {k: p.grad.clone() for k, p in _named(rb, coarse, fine).items() if p.grad is not None}
+        grads[("latents", "")] = lat.grad.clone()
+        out[fused] = (loss.detach().clone(), grads)
+    assert torch.allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-7)
+    assert set(out[True][1]) == set(out[False][1])
+    for k, ge in out[False][1].items():
+        gf = out[True][1][k]
+        scale = float(ge.abs().max()) + 1e-20
+        assert float((ge - gf).abs().max()) <= 1e-4 * scale, (k, float((ge - gf).abs().max()) / scale)
