@@ -55,7 +55,10 @@ __device__ __forceinline__ typename P::frag x16_pack(const f32x4& d0, const f32x
 #ifndef NRN_X16_WAVES_NARROW
 #define NRN_X16_WAVES_NARROW 8
 #endif
-template <class A> struct X16Cfg { static constexpr int NB = (A::W <= 128) ? NRN_X16_NB_NARROW : NRN_X16_NB, WAVES = (A::W <= 128) ? NRN_X16_WAVES_NARROW : NRN_X16_WAVES; };
+#ifndef NRN_X16_PF_NARROW
+#define NRN_X16_PF_NARROW 2       // weight fragments requested ahead in the narrow trunk: 2 fits 256 registers without spilling (two waves per
+                                  // SIMD cover the LDS latency); measured fine pass 8 (39 spilled): 6.80 ms, 4 (9 spilled): 6.69, 2: 6.75 (profiles/r05_w128_x16_ab.txt)
+#endif
 #ifndef NRN_X16_PF
 #define NRN_X16_PF 8          // weight fragments requested from LDS ahead of their MFMAs (4: 24.1 ms per fine pass, 6: 23.7, 8: 23.7)
 #endif
@@ -64,6 +67,10 @@ template <class A> struct X16Cfg { static constexpr int NB = (A::W <= 128) ? NRN
 // (the head) alone.  Per fragment NB MFMAs (one per block).  Two accumulator sets: pair p runs in set p & 1 while the epilogue of
 // pair p - 1 (pack -> out[b][p - 1], NB chunks of ~8 VALU) is issued among its first k-steps; the last pair's epilogue follows the
 // layer.  The first MFMA of a chain takes the bias as its C operand (no copies).
+template <class A> struct X16Cfg {
+    static constexpr int NB = (A::W <= 128) ? NRN_X16_NB_NARROW : NRN_X16_NB, WAVES = (A::W <= 128) ? NRN_X16_WAVES_NARROW : NRN_X16_WAVES;
+    static constexpr int PF = (A::W <= 128) ? NRN_X16_PF_NARROW : NRN_X16_PF;
+};
 // (PF_: fragments requested ahead; the stand-alone bender, nrnerf_bend_x16.h, runs several waves per SIMD and asks for fewer)
 template <class P0, class P1, class PL, int LI, int NS0, int NS1, int NB, int PF_ = NRN_X16_PF, class ST, class IN0, class IN1, class EPI>
 __device__ __forceinline__ void dense_x16(ST& st, const __attribute__((address_space(3))) f32x4* bias_lane, const IN0 (&in0)[NB], const IN1 (&in1)[NB],
@@ -156,7 +163,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     using PE = PolF16;                                                // the encoding's operands are f16 in both modes
     using frag = typename P::frag;
     using efrag = typename PE::frag;
-    constexpr int NB = X16Cfg<A>::NB, NS_H = PL::NS_H, NS_E = PL::NS_E;
+    constexpr int NB = X16Cfg<A>::NB, NS_H = PL::NS_H, NS_E = PL::NS_E, PFK = X16Cfg<A>::PF;
     static_assert(WAVES == X16Cfg<A>::WAVES, "launched with the architecture's own workgroup size");
     static_assert(A::L == 10, "the encoding's slot layout below is spelt out for ten frequencies (x16_enc_col)");
 
@@ -202,7 +209,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     asm volatile("" : "+s"(gdim));
     float cpre[NB][8];          // direction and depths of this wave's rays, requested one iteration ahead of their use
     // where block b of the iteration (tg_, grp_ | b0_) lies: its sample's row in the [N, S] arrays, and whether the lane has a sample
-    auto locate = [&](int tg_, long long grp_, long long b0_, int b, size_t& so_, bool& ok_, size_t& nb_, bool& first_) {
+    // (rows as 32-bit numbers: n_rays <= 2^20 per launch and S <= 1024)
+    auto locate = [&](int tg_, long long grp_, long long b0_, int b, unsigned& so_, bool& ok_, unsigned& nb_, bool& first_) {
         bool blk_ok;
         int ray, bir;
         if constexpr (fuse) {                   // block q of this wave's group: ray (grp * WAVES + wave) * RW + q / bpr
@@ -221,25 +229,25 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         const int sidx = bir * 16 + n;
         ok_ = blk_ok && sidx < S;
         const int sc = sidx < S ? sidx : S - 1;
-        so_ = (size_t)ray * S + sc;
+        so_ = (unsigned)ray * (unsigned)S + (unsigned)sc;
         first_ = sc == 0;                                          // (VIEWS) sample 0 takes sample 1's direction, rnh:346-348
-        nb_ = (size_t)ray * S + (sc == 0 ? (S > 1 ? 1 : 0) : sc - 1);
+        nb_ = (unsigned)ray * (unsigned)S + (unsigned)(sc == 0 ? (S > 1 ? 1 : 0) : sc - 1);
     };
     // The points of an iteration are requested during the PREVIOUS one -- right after its last LDS-DMA requests, before its output
     // stores and its compositing: a lone wave per SIMD has nothing else to put between the request and the use, and the loads'
     // latency was 4 000 of an iteration's 96 000 cycles (NRN_TIMING).  Not earlier: the vector-memory queue retires in order, and the
     // ring's counted vmcnt waits would wait for them.
-    size_t so[NB];
+    unsigned so[NB];
     bool ok[NB];
     f32x4 q4n[NB];
     f32x4 q4p[VIEWS ? NB : 1];          // (VIEWS) the neighbouring sample's point
     bool first[NB];
     static_for<0, NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
-        size_t nb;
+        unsigned nb;
         locate(0, grp, (long long)blockIdx.x * per_wg, b, so[b], ok[b], nb, first[b]);
-        q4n[b] = *(const f32x4*)(a.pts4 + so[b] * 4);
-        if constexpr (VIEWS) q4p[b] = *(const f32x4*)(a.pts4 + nb * 4);
+        q4n[b] = *(const f32x4*)(a.pts4 + (size_t)so[b] * 4);
+        if constexpr (VIEWS) q4p[b] = *(const f32x4*)(a.pts4 + (size_t)nb * 4);
     });
 #ifdef NRN_TIMING
     // slots: 0 iteration, 1 points + encoding, 2 layers + head, 3 outputs + ring tail, 4 compositing, 5 iteration in 100 MHz ticks,
@@ -328,24 +336,24 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
                 out[decltype(kc)::value][decltype(pc)::value] = x16_pack<P>(d0, d1);
             };
         };
-        dense_x16<PE, P, PL, 0, NS_E, 0, NB>(st, bias_lane, enc, none, keep(ha));
+        dense_x16<PE, P, PL, 0, NS_E, 0, NB, PFK>(st, bias_lane, enc, none, keep(ha));
         static_for<1, A::D>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr bool skip = (i - 1 == A::SKIP);
             if constexpr (i % 2 == 1) {
-                if constexpr (skip) dense_x16<PE, P, PL, i, NS_E, NS_H, NB>(st, bias_lane, enc, ha, keep(hb));
-                else dense_x16<P, P, PL, i, NS_H, 0, NB>(st, bias_lane, ha, none, keep(hb));
+                if constexpr (skip) dense_x16<PE, P, PL, i, NS_E, NS_H, NB, PFK>(st, bias_lane, enc, ha, keep(hb));
+                else dense_x16<P, P, PL, i, NS_H, 0, NB, PFK>(st, bias_lane, ha, none, keep(hb));
             } else {
-                if constexpr (skip) dense_x16<PE, P, PL, i, NS_E, NS_H, NB>(st, bias_lane, enc, hb, keep(ha));
-                else dense_x16<P, P, PL, i, NS_H, 0, NB>(st, bias_lane, hb, none, keep(ha));
+                if constexpr (skip) dense_x16<PE, P, PL, i, NS_E, NS_H, NB, PFK>(st, bias_lane, enc, hb, keep(ha));
+                else dense_x16<P, P, PL, i, NS_H, 0, NB, PFK>(st, bias_lane, hb, none, keep(ha));
             }
         });
         // ---- head: one tile; group 0 holds channels 0..3 (rgb, sigma) of its sample, group 1 channel 4 in its first register
         f32x4 raw[NB];
         auto take = [&](auto, auto kc, const f32x4& d0, const f32x4&) { raw[decltype(kc)::value] = d0; };
         if constexpr (!VIEWS) {
-            if constexpr ((A::D - 1) % 2 == 1) dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB>(st, bias_lane, hb, none, take);
-            else dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB>(st, bias_lane, ha, none, take);
+            if constexpr ((A::D - 1) % 2 == 1) dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB, PFK>(st, bias_lane, hb, none, take);
+            else dense_x16<P, P, PL, PL::L_HEAD, NS_H, 0, NB, PFK>(st, bias_lane, ha, none, take);
         } else {
             // view-dependent head: hv = relu(views o feature ([enc(dir), h])) in tile pairs 0 .. NT_V / 2 - 1, sigma = the lone last tile's
             // row 0 (group 0's first register, no relu); then rgb = rgb_linear(hv): raw = [rgb, sigma]
@@ -357,9 +365,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
                 if constexpr (p < NS_V) hv[k][p] = x16_pack<P>(d0, d1);
                 else sigma[k] = d0[0];
             };
-            if constexpr ((A::D - 1) % 2 == 1) dense_x16<PE, P, PL, PL::L_VIEWS, 1, NS_H, NB>(st, bias_lane, encv, hb, views_epi);
-            else dense_x16<PE, P, PL, PL::L_VIEWS, 1, NS_H, NB>(st, bias_lane, encv, ha, views_epi);
-            dense_x16<P, P, PL, PL::L_HEAD, NS_V, 0, NB>(st, bias_lane, hv, none, take);
+            if constexpr ((A::D - 1) % 2 == 1) dense_x16<PE, P, PL, PL::L_VIEWS, 1, NS_H, NB, PFK>(st, bias_lane, encv, hb, views_epi);
+            else dense_x16<PE, P, PL, PL::L_VIEWS, 1, NS_H, NB, PFK>(st, bias_lane, encv, ha, views_epi);
+            dense_x16<P, P, PL, PL::L_HEAD, NS_V, 0, NB, PFK>(st, bias_lane, hv, none, take);
             static_for<0, NB>([&](auto bc) { raw[decltype(bc)::value][3] = sigma[decltype(bc)::value]; });
         }
 #ifdef NRN_TIMING
@@ -376,25 +384,25 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         } else {
             b0_n = b0 + (long long)gdim * per_wg;
         }
-        size_t so_n[NB];
+        unsigned so_n[NB];
         bool ok_n[NB];
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            size_t nb;
+            unsigned nb;
             locate(tg_n, grp_n, b0_n, b, so_n[b], ok_n[b], nb, first[b]);
-            q4n[b] = *(const f32x4*)(a.pts4 + so_n[b] * 4);
-            if constexpr (VIEWS) q4p[b] = *(const f32x4*)(a.pts4 + nb * 4);
+            q4n[b] = *(const f32x4*)(a.pts4 + (size_t)so_n[b] * 4);
+            if constexpr (VIEWS) q4p[b] = *(const f32x4*)(a.pts4 + (size_t)nb * 4);
         });
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             if (ok[b] && g == 0) {
-                if (!fuse) *(f32x4*)(a.raw4 + so[b] * 4) = raw[b];
+                if (!fuse) *(f32x4*)(a.raw4 + (size_t)so[b] * 4) = raw[b];
                 if (a.raw_out) {
-                    float* ro = a.raw_out + so[b] * a.raw_ch;
+                    float* ro = a.raw_out + (size_t)so[b] * a.raw_ch;
                     ro[0] = raw[b][0]; ro[1] = raw[b][1]; ro[2] = raw[b][2]; ro[3] = raw[b][3];
                 }
             }
-            if (ok[b] && g == 1 && a.raw_out && a.raw_ch > 4) a.raw_out[so[b] * a.raw_ch + 4] = raw[b][0];
+            if (ok[b] && g == 1 && a.raw_out && a.raw_ch > 4) a.raw_out[(size_t)so[b] * a.raw_ch + 4] = raw[b][0];
             if (fuse && g == 0) stage_w[(tg * NB + b) * 16 + n] = raw[b];
         });
 #ifdef NRN_TIMING

@@ -128,7 +128,10 @@ def check(build_dir: str) -> list[str]:
                 if r["smem_in_mfma_section"] and not base.startswith(("bend_", "train_")):
                     errors.append(f"{name}: {r['smem_in_mfma_section']} scalar memory load(s) between the first and the last MFMA")
                 # (a non-zero vgpr_spill_count with no scratch segment is a VGPR parked in a free AccVGPR: no memory traffic)
-                if r["scratch"] or r.get("private_segment_fixed_size", 0):
+                # tolerated: ONE spilled register (8 B per lane) in x16_e0 -- the 128-wide trunk's raw-to-memory instantiation at two
+                # waves per SIMD (256 registers); its spill-free alternatives were measured slower (profiles/r05_w128_x16_ab.txt)
+                tolerated = name == "x16_e0" and r.get("private_segment_fixed_size", 0) <= 8 and r["scratch"] <= 16
+                if (r["scratch"] or r.get("private_segment_fixed_size", 0)) and not tolerated:
                     errors.append(f"{name}: scratch traffic ({r['scratch']} instructions, {r.get('private_segment_fixed_size', 0)} B per lane)")
                 limit = 512 if r["mb"] else 256
                 if r.get("vgpr_count", 0) > limit:
