@@ -507,11 +507,12 @@ def pmc_traffic(args):
             return None, f"null: {name} was collected on the {j.get('scene')} scene", None
         if j.get("kernel_source_sha16") != kernel_source_sha16():
             return None, f"null: {name} was collected from different kernel sources", None
-        return float(j["fine"]["hbm_bytes_per_launch"]), ("bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from rocprofv3 --pmc passes "
-                                                          f"of these kernel sources ({name.replace('_pmc_fine.json', '_pmc_summary.txt')}); by design 0.76e9 since the compositing is fused "
-                                                          "into the kernel (16 B/sample of points + 4 B/sample of depths in, 44 B/ray out; was 1.21e9 with raw written out)",
-                f"committed profile {name}: separate rocprofv3 --pmc passes of this command over the same kernel sources (hash-checked), "
-                "NOT measured in this run -- hardware counters cannot be read from inside the process")
+        note = ("bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from rocprofv3 --pmc passes "
+                f"of these kernel sources ({name.replace('_pmc_fine.json', '_pmc_summary.txt')}); by design 0.76e9 since the compositing is fused "
+                "into the kernel (16 B/sample of points + 4 B/sample of depths in, 44 B/ray out; was 1.21e9 with raw written out)")
+        source = (f"committed profile {name}: separate rocprofv3 --pmc passes of this command over the same kernel sources (hash-checked), "
+                  "NOT measured in this run -- hardware counters cannot be read from inside the process")
+        return float(j["fine"]["hbm_bytes_per_launch"]), note, source
     except Exception as e:
         return None, f"null: {type(e).__name__}", None
 

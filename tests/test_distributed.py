@@ -129,6 +129,32 @@ def test_bench_workload_label_follows_the_arguments():
         assert lab(**kw).startswith("NOT a BASELINE.json config"), kw
 
 
+def test_bench_traffic_lookup_returns_value_note_and_source(tmp_path, monkeypatch):
+    """bench.pmc_traffic: (bytes, note, source) on every path -- the committed profile of these kernel sources, a stale one, none."""
+    import argparse
+    import importlib.util
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module3", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = argparse.Namespace(rays=196608, precision="bf16", use_viewdirs=False, exact_viewdirs=False, bend_depth=5, netwidth=256, scene="fitted")
+    prof = tmp_path / "r99_pmc_fine.json"
+    monkeypatch.setattr(bench, "_latest_profile", lambda suffix: str(prof))
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    prof.write_text(json.dumps({"scene": "fitted", "kernel_source_sha16": bench.kernel_source_sha16.__wrapped__() if hasattr(bench.kernel_source_sha16, "__wrapped__") else "x", "fine": {"hbm_bytes_per_launch": 7.7e8}}))
+    monkeypatch.setattr(bench, "kernel_source_sha16", lambda train=False: "x")
+    prof.write_text(json.dumps({"scene": "fitted", "kernel_source_sha16": "x", "fine": {"hbm_bytes_per_launch": 7.7e8}}))
+    v, note, source = bench.pmc_traffic(args)
+    assert v == 7.7e8 and "FETCH_SIZE" in note and "NOT measured in this run" in source
+    prof.write_text(json.dumps({"scene": "fitted", "kernel_source_sha16": "other", "fine": {"hbm_bytes_per_launch": 1.0}}))
+    v, note, source = bench.pmc_traffic(args)
+    assert v is None and "different kernel sources" in note and source is None
+    args.rays = 1000
+    v, note, source = bench.pmc_traffic(args)
+    assert v is None and source is None
+
+
 def test_shard_bounds_cover_everything_once():
     for n in (0, 1, 7, 8, 9, 196608):
         for world in (1, 2, 3, 8):

@@ -304,6 +304,20 @@ def test_fp32_mode_full_frame_vs_gpu_eager_oracle():
                  dict(moved_depths=zg.numel(), rgb0=3 * n, rgb_map=3 * n, acc_map=n))
     print(f"[fp32, 196 608 rays vs the eager oracle on this GPU] PSNR rgb_map {psnr(got['rgb_map'], ref['rgb_map']):.1f} dB, "
           f"rgb0 {psnr(got['rgb0'], ref['rgb0']):.1f} dB")
+    # The yardstick beside the pinned fractions: the reference's OWN arithmetic against itself at another precision -- the
+    # oracle in fp64 (same ops, fp64 weights / rays / latents) against the oracle in fp32 on the same frame.  Its moved depths and
+    # out-of-tolerance values are what sample_pdf's `denom < 1e-5` branch (rnh:694) does to ANY fp32 evaluation, these kernels' included.
+    with torch.no_grad():
+        ref64 = O.batchify_rays(rays.to(DEV), latents.to(DEV), O.scene_on(scene, DEV), chunk=16384, dtype=torch.float64)
+    ref64 = {k: v.float().cpu() for k, v in ref64.items()}
+    moved64 = ((ref["_z_vals"] - ref64["_z_vals"]).abs() > 2e-5).float().mean().item()
+    yard = {k: out_of_tolerance_fraction(ref, ref64, k) for k in ("rgb0", "rgb_map", "acc_map")}
+    print(f"[yardstick: the oracle in fp32 vs the oracle in fp64, same frame] moved depths {moved64:.4%} (HIP fp32 vs oracle fp32: {moved:.4%}); "
+          f"values outside the fp32 tolerance: rgb0 {yard['rgb0']:.4%}, rgb_map {yard['rgb_map']:.4%} (HIP: {out_of_tolerance_fraction(got, ref, 'rgb_map'):.4%}), "
+          f"acc_map {yard['acc_map']:.4%}; PSNR rgb_map {psnr(ref['rgb_map'], ref64['rgb_map']):.1f} dB")
+    # the kernels must not be further from the reference's fp32 arithmetic than that arithmetic is from its own fp64 evaluation, give or take 2x
+    assert moved <= 2.0 * moved64 + 1e-3, (moved, moved64)
+    assert out_of_tolerance_fraction(got, ref, "rgb_map") <= 2.0 * yard["rgb_map"] + 1e-2, (out_of_tolerance_fraction(got, ref, "rgb_map"), yard["rgb_map"])
     assert not fails, "\n".join(fails)
 
 
