@@ -622,7 +622,11 @@ int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchroni
  *   bender always fp32): fragment (tile t, k-slab s) of a layer at w_frag + t * (ns0 + ns1) + s; the unit table then holds
  *   n_layers, per layer {w_frag, bias_tile, nt, src0, ns0, src1, ns1, dst, relu, o_col, o_rows} (buffers: 0 = network input,
  *   1 = hidden, 2 = second input, 3 = head outputs), then the padded widths of the three buffers and the latent size
- *   (n_units = that many entries minus one).
+ *   (n_units = that many entries minus one),
+ * 10 = the fine network's trunk (+ view-dependent head) for the 16x16x32 kernel (fragments of 16 rows x 32 k; bias table [tile][16]),
+ * 11 / 12 = the coarse / fine trunk of ANY plain-headed architecture for the width-class 16x16x32 kernel: the layers' fragment blocks
+ *   back to back (first layer, pts_linears[1 ..], output_linear), each padded to a whole number of 4-unit ring periods, + a copy of the
+ *   first two units behind the last; width padded to a multiple of 64 with zeros.
  * Any output pointer may be NULL to query sizes only.  Used by the CPU-side packing tests. */
 typedef struct nrnerf_packed_info {
     uint64_t stream_bytes;     /* fragment stream */

@@ -24,6 +24,7 @@
 #include "nrnerf_x16_api.h"
 #include "nrnerf_bend_x16_plan.h"
 #include "nrnerf_loss.h"
+#include "nrnerf_gx16_plan.h"
 #include "nrnerf_plan.h"
 
 using namespace nrn;
@@ -903,6 +904,9 @@ struct nrnerf_model {
                                     // stand-alone bender kernel (nrnerf_bend.h, image `bend_only`) takes the passes without detail outputs
     GenArgs gen_bend_prog{}, gen_coarse_prog{}, gen_fine_prog{};
     PassDev gen_bend, gen_coarse, gen_fine;
+    // the trunks of a generic model packed for the width-class 16x16x32 kernel (nrnerf_gx16.h): 16-bit modes, no view-dependent head
+    PassDev gx_coarse, gx_fine;
+    GxMeta gx_meta_coarse, gx_meta_fine;
     bool gen_fine_is_coarse = false;
     int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
@@ -913,6 +917,7 @@ struct nrnerf_model {
 };
 
 namespace {
+constexpr int NRN_RING_LAG_HOST = 2;      // NRN_RING_LAG of nrnerf_net_impl.h (device header): units of DMA lead behind the ring's read position
 
 int upload_pass(const PackedPass& pk, PassDev& dev) {
     dev.stream_bytes = pk.stream.size();
@@ -1053,6 +1058,96 @@ bool bender_matches(const nrnerf_bender_desc& b) {
     return true;
 }
 
+// ---- the width-class trunk kernel for architectures outside the compiled set (nrnerf_gx16.h, nrnerf_gx16_plan.h)
+// does it take this network?  16-bit modes, no view-dependent head, no time conditioning, <= 10 encoding frequencies, 4 / 5 output channels
+bool gx16_eligible(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
+    if (d.precision != NRNERF_PREC_BF16 && d.precision != NRNERF_PREC_F16) return false;
+    if (m.use_viewdirs || m.time_conditioned || d.multires < 0 || d.multires > GX_MAX_L) return false;
+    if (m.width < 1 || m.width > 512 || m.depth < 1 || m.depth > 16) return false;
+    if (m.output_ch != 4 && m.output_ch != 5) return false;
+    return true;
+}
+// The stream: the layers' fragment blocks back to back in evaluation order (IN, then HID / SKIP per pts_linears[i], then HEAD), each
+// padded to gx_layer_units() units, + a copy of the stream's first RING - LAG units behind the last (the ring runs on into the next
+// iteration's first units).  Fragment element (lane (r, g), e) of (tile t, k-step s): W[row][col] with the maps of nrnerf_gx16_plan.h.
+void pack_gx16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPass& out, GxMeta& meta, const FlatLayout* lay = nullptr) {
+    using SH = Shape16Fast;
+    const int wc = gx_width_class(mlp.width), D = mlp.depth, skip = gen_skip(mlp), L = d.multires, enc = 3 + 6 * L, W = mlp.width;
+    std::vector<int> kinds;
+    kinds.push_back(GX_IN);
+    for (int i = 1; i < D; ++i) kinds.push_back((i - 1 == skip) ? GX_SKIP : GX_HID);
+    kinds.push_back(GX_HEAD);
+    int units = 0, tiles = 0, mfma = 0;
+    for (int k : kinds) { units += gx_layer_units(wc, k); tiles += gx_layer_tiles(wc, k); }
+    constexpr int TAIL = RING - NRN_RING_LAG_HOST;
+    out.ntiles = tiles; out.nunits = units + TAIL;
+    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES;
+    out.stream.assign((size_t)(units + TAIL) * SH::UNIT_BYTES, 0);
+    out.unit_off.assign(units + TAIL + 1, 0);
+    for (int u = 0; u <= units + TAIL; ++u) out.unit_off[u] = (uint32_t)((size_t)u * SH::UNIT_BYTES / 16);
+    out.bias.assign((size_t)tiles * 16, 0.0f);
+    if (lay) {
+        out.src.assign(out.stream.size() / 2, -1);
+        out.fmt.assign(out.stream.size() / 2, 1);
+        out.bias_src.assign(out.bias.size(), -1);
+    }
+    size_t unit0 = 0, tile0 = 0;
+    for (size_t li = 0; li < kinds.size(); ++li) {
+        const int kind = kinds[li];
+        const Tables T = build_tables_gx(wc, kind);
+        const LayerSpec& sp = T.layers[0];
+        const nrnerf_linear* lin = (kind == GX_HEAD) ? &mlp.output_linear : &mlp.pts_linears[li];
+        const int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
+        for (int t = 0; t < sp.nt; ++t) {
+            const TileInfo& ti = T.tiles[t];
+            for (int s = 0; s < sp.ns; ++s) {
+                const size_t fi = unit0 * SH::UNIT_FRAGS + (size_t)ti.gbase + (size_t)s * ti.gstride;
+                uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
+                const bool enc_step = (kind == GX_IN || kind == GX_SKIP) && s < GX_NS_E;
+                const bool as_f16 = d.precision == NRNERF_PREC_F16 || enc_step;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 15, g = lane >> 4;
+                    const int row = (kind == GX_HEAD) ? (r < lin->out_features ? r : -1) : ((16 * t + r < lin->out_features) ? 16 * t + r : -1);
+                    for (int e = 0; e < 8; ++e) {
+                        int col;
+                        if (enc_step) col = gx_enc_col(L, s, g, e);
+                        else {
+                            const int c = x16_hidden_feature(kind == GX_SKIP ? s - GX_NS_E : s, g, e);
+                            col = c < W ? (kind == GX_SKIP ? enc + c : c) : -1;
+                        }
+                        if (col >= lin->in_features) col = -1;
+                        const float w = (row < 0 || col < 0) ? 0.0f : lin->weight[(size_t)row * lin->in_features + col];
+                        const size_t el = fi * (SH::FRAG_BYTES / 2) + (size_t)lane * 8 + e;
+                        if (lay) {
+                            out.src[el] = (row < 0 || col < 0 || wbase < 0) ? -1 : (int32_t)(wbase + (int64_t)row * lin->in_features + col);
+                            out.fmt[el] = as_f16 ? 2 : 1;
+                        }
+                        const uint16_t q = as_f16 ? f32_to_f16(w) : f32_to_bf16(w);
+                        std::memcpy(fr + (lane * 8 + e) * 2, &q, 2);
+                    }
+                }
+            }
+            for (int r = 0; r < 16; ++r) {
+                const int row = (kind == GX_HEAD) ? (r < lin->out_features ? r : -1) : ((16 * t + r < lin->out_features) ? 16 * t + r : -1);
+                out.bias[(tile0 + t) * 16 + r] = (row >= 0 && lin->bias) ? lin->bias[row] : 0.0f;
+                if (lay && row >= 0 && bbase >= 0) out.bias_src[(tile0 + t) * 16 + r] = (int32_t)(bbase + row);
+            }
+        }
+        mfma += sp.ns * sp.nt;
+        unit0 += gx_layer_units(wc, kind);
+        tile0 += sp.nt;
+    }
+    // the copy of the first units behind the last layer
+    std::memcpy(out.stream.data() + (size_t)units * SH::UNIT_BYTES, out.stream.data(), (size_t)TAIL * SH::UNIT_BYTES);
+    if (lay) {
+        const size_t n = (size_t)TAIL * SH::UNIT_BYTES / 2, o = (size_t)units * SH::UNIT_BYTES / 2;
+        std::copy(out.src.begin(), out.src.begin() + n, out.src.begin() + o);
+        std::copy(out.fmt.begin(), out.fmt.begin() + n, out.fmt.begin() + o);
+    }
+    out.mfma_per_block = mfma;
+    meta.wc = wc; meta.depth = D; meta.skip = skip; meta.L = L; meta.n_bias_tiles = tiles;
+}
+
 // ---- models of an architecture outside the compiled set (nrnerf_generic.h)
 int gen_pack_all(const nrnerf_model_desc& d, const FlatLayout* lay, GenProgram& gb, GenProgram& gc, GenProgram& gf) {
     if (d.exact_viewdirs && d.bender && d.coarse->use_viewdirs) return NRNERF_ERR_UNSUPPORTED;      // Jacobian directions: compiled kernels only
@@ -1118,6 +1213,14 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
             if (rc != NRNERF_OK) return rc;
             m->bend_only.algo_flops_per_sample = m->gen_bend.algo_flops_per_sample;
             m->gen_compiled_bender = cb;
+            if (bend_x16_eligible(d)) {              // "bf16" mode: the 16x16x32 stand-alone bender (nrnerf_bend_x16.h)
+                PackedPass pbx;
+                pack_bend_x16(d, pbx, &lay);
+                rc = upload_pass(pbx, m->bend_x16);
+                if (rc != NRNERF_OK) return rc;
+                m->bend_x16.algo_flops_per_sample = m->gen_bend.algo_flops_per_sample;
+                m->bend_x16.mfma_flops_per_sample = pbx.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
+            }
         }
     }
     rc = upload_pass(gc.pk, m->gen_coarse);
@@ -1139,6 +1242,24 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
     }
     m->fine.output_ch = m->gen_fine.output_ch;
     m->fine_is_coarse = !d.fine;
+    // with a bender (the passes then run on ready-made points) and a plain head: the trunks also for the width-class x16 kernel
+    if (d.bender && gx16_eligible(d, *d.coarse) && (!d.fine || gx16_eligible(d, *d.fine))) {
+        PackedPass pgc, pgf;
+        pack_gx16(d, *d.coarse, pgc, m->gx_meta_coarse, &lay);
+        rc = upload_pass(pgc, m->gx_coarse);
+        if (rc != NRNERF_OK) return rc;
+        m->gx_coarse.algo_flops_per_sample = m->gen_coarse.algo_flops_per_sample;
+        m->gx_coarse.mfma_flops_per_sample = pgc.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
+        m->gx_coarse.output_ch = d.coarse->output_ch;
+        if (d.fine) {
+            pack_gx16(d, *d.fine, pgf, m->gx_meta_fine, &lay);
+            rc = upload_pass(pgf, m->gx_fine);
+            if (rc != NRNERF_OK) return rc;
+            m->gx_fine.algo_flops_per_sample = m->gen_fine.algo_flops_per_sample;
+            m->gx_fine.mfma_flops_per_sample = pgf.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
+            m->gx_fine.output_ch = d.fine->output_ch;
+        }
+    }
     own.m = nullptr;
     *out = m;
     return NRNERF_OK;
@@ -1163,9 +1284,25 @@ int update_generic(nrnerf_model* m, const nrnerf_model_desc& d, hipStream_t stre
         rc = refresh_pass(pb, m->bend_only, stream);
         if (rc != NRNERF_OK) return rc;
     }
+    PackedPass pbx;
+    if (d.bender && m->bend_x16.stream) {
+        pack_bend_x16(d, pbx);
+        rc = refresh_pass(pbx, m->bend_x16, stream);
+        if (rc != NRNERF_OK) return rc;
+    }
     if (d.bender) rc = refresh_pass(gb.pk, m->gen_bend, stream);         // (sizes differ for another architecture: NRNERF_ERR_INVALID)
     if (rc == NRNERF_OK) rc = refresh_pass(gc.pk, m->gen_coarse, stream);
     if (rc == NRNERF_OK && d.fine) rc = refresh_pass(gf.pk, m->gen_fine, stream);
+    PackedPass pgc, pgf;
+    if (rc == NRNERF_OK && m->gx_coarse.stream) {
+        GxMeta mc, mf;
+        pack_gx16(d, *d.coarse, pgc, mc);
+        rc = refresh_pass(pgc, m->gx_coarse, stream);
+        if (rc == NRNERF_OK && d.fine && m->gx_fine.stream) {
+            pack_gx16(d, *d.fine, pgf, mf);
+            rc = refresh_pass(pgf, m->gx_fine, stream);
+        }
+    }
     if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;      // the packed host images die with this call
     return rc;
 }
@@ -1219,6 +1356,12 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
             if (bender_arch(arch_id) == 0) pack_pass_bwd_bender<ArchDefault>(*desc->bender, pk);
             else pack_pass_bwd_bender<ArchDeepBend>(*desc->bender, pk);
         }
+    } else if (which == 11 || which == 12) {     // the coarse / fine trunk packed for the width-class kernel (nrnerf_gx16.h)
+        const nrnerf_mlp_desc* mm = (which == 12 && desc->fine) ? desc->fine : desc->coarse;
+        if (!gx16_eligible(*desc, *mm)) return NRNERF_ERR_UNSUPPORTED;
+        GxMeta gm;
+        rc = NRNERF_OK;
+        pack_gx16(*desc, *mm, pk, gm);
     } else if (which == 10) {                    // the fine network's trunk packed for the 16x16x32 kernel (nrnerf_net_x16.h)
         const nrnerf_mlp_desc* mm = desc->fine ? desc->fine : desc->coarse;
         if (!x16_eligible(*desc, *mm, /*any_16bit=*/true)) return NRNERF_ERR_UNSUPPORTED;
@@ -1429,7 +1572,7 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     hipStream_t stream = (hipStream_t)hip_stream;
     PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16, &m->coarse_trunk_x16, &m->bend_x16,
                          &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
-                         &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine};
+                         &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine, &m->gx_coarse, &m->gx_fine};
     for (PassDev* p : passes)
         if (p && p->stream && !p->src) return NRNERF_ERR_UNSUPPORTED;          // (before anything is launched)
     // every image (weight stream + bias table) as one segment of ONE launch
@@ -1466,6 +1609,8 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->fine_trunk_x16);
     free_pass(m->coarse_trunk_x16);
     free_pass(m->bend_x16);
+    free_pass(m->gx_coarse);
+    free_pass(m->gx_fine);
     free_pass(m->coarse_trunk);
     free_pass(m->bend_only);
     free_pass(m->coarse_bwd);
@@ -1608,7 +1753,13 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                 BendArgs b{};
                 b.rays = a->rays; b.ray_stride = a->ray_stride; b.latents = a->latents; b.lat_stride = a->latent_stride;
                 b.z = zv; b.lindisp = a->lindisp; b.rank = nullptr; b.n_rays = N; b.n_per_ray = nS; b.out_stride = nS;
-                b.wstream = m->bend_only.stream; b.bias = m->bend_only.bias; b.bent4 = out4; b.knobs = kn;
+                b.bent4 = out4; b.knobs = kn;
+                if (bend_x16) {
+                    b.wstream = m->bend_x16.stream; b.bias = m->bend_x16.bias;
+                    return timed(slot, (double)N * nS * m->bend_x16.algo_flops_per_sample, (double)N * nS * m->bend_x16.mfma_flops_per_sample,
+                                 [&] { return launch_bend_x16(m->gen_compiled_bender, b, m->num_cus, stream); });
+                }
+                b.wstream = m->bend_only.stream; b.bias = m->bend_only.bias;
                 return timed(slot, (double)N * nS * m->bend_only.algo_flops_per_sample, 0,
                              [&] { return launch_bend(m->precision, m->gen_compiled_bender, b, m->num_cus, stream); });
             }
@@ -1621,6 +1772,19 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         };
         auto network_pass = [&](const GenArgs& prog, const PassDev& pd, const float* zv, int nS, const float* pts, float* raw4, float* raw_user,
                                 float* bent_out, const nrnerf_sample_outputs& so, int slot) -> hipError_t {
+            // the trunk on the width-class 16x16x32 kernel (nrnerf_gx16.h) when the pass runs on ready-made points and wants no detail outputs
+            const PassDev& gx = (&pd == &m->gen_coarse) ? m->gx_coarse : m->gx_fine;
+            const GxMeta& gm = (&pd == &m->gen_coarse) ? m->gx_meta_coarse : m->gx_meta_fine;
+            const PassDev& gxu = (m->gen_fine_is_coarse && &pd == &m->gen_fine) ? m->gx_coarse : gx;      // (one network for both passes)
+            const GxMeta& gmu = (m->gen_fine_is_coarse && &pd == &m->gen_fine) ? m->gx_meta_coarse : gm;
+            if (pts && gxu.stream && !(a->flags & NRNERF_RENDER_NO_X16) && !any_detail(so) && !kn.detailed) {
+                GxArgs x{};
+                x.pts4 = pts; x.raw4 = raw4; x.raw_out = raw_user; x.raw_ch = pd.output_ch;
+                x.n_rays = N; x.S = nS; x.wstream = gxu.stream; x.bias = gxu.bias;
+                x.depth = gmu.depth; x.skip = gmu.skip; x.L = gmu.L; x.n_bias_tiles = gmu.n_bias_tiles;
+                return timed(slot, (double)N * nS * gxu.algo_flops_per_sample, (double)N * nS * gxu.mfma_flops_per_sample,
+                             [&] { return launch_gx16(m->precision, gmu.wc, x, m->num_cus, stream); });
+            }
             GenArgs g = prog;
             g.rays = a->rays; g.ray_stride = a->ray_stride; g.latents = a->latents; g.lat_stride = a->latent_stride;
             g.z = zv; g.lindisp = a->lindisp; g.n_rays = N; g.S = nS;

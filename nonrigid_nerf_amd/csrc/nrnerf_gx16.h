@@ -1,0 +1,206 @@
+// nrnerf_gx16.h -- the width-class trunk kernel on v_mfma_f32_16x16x32 for architectures outside the compiled set (see
+// nrnerf_gx16_plan.h for why and for the layer kinds).  Trunk-only, like net_kernel_x16's raw-to-memory case: positional encoding of
+// READY-MADE points (the bender pass' output), pts_linears with any depth / one skip index, output_linear; bf16 or f16.
+// Everything else of such a model (the bender, compositing, sampling) runs on the kernels it already had.
+#pragma once
+#include "nrnerf_gx16_plan.h"
+#include "nrnerf_net_x16.h"
+#include "nrnerf_x16_api.h"
+
+namespace nrn {
+
+// the LDS weight ring with a RUN-TIME source pointer: unit V of the current layer comes from lbase + V * UNIT; slots are compile-time
+// because every layer streams a whole number of ring periods (PlanGX::NUP).  Otherwise WRing (nrnerf_net_impl.h).
+template <class P, int WAVES>
+struct WRingRT {
+    static constexpr int UNIT = P::UNIT_BYTES;
+    static constexpr int PW = UNIT / 1024 / WAVES;
+    static constexpr int LAG = NRN_RING_LAG;
+    static constexpr bool ASM_FRAGS = (P::FRAG_BYTES == 1024);
+    static_assert(ASM_FRAGS && LAG >= 1 && RING - LAG >= 2 && UNIT % (1024 * WAVES) == 0, "16-bit fragments, at least one unit of DMA lead");
+    const char* lbase;     // first unit of the current layer + this wave's piece offset (wave-uniform)
+    unsigned lane16;
+    char* ring;
+    int wave_off;
+    unsigned lane_addr;
+
+    __device__ __forceinline__ void init(const void* stream, char* lds, int wave, int lane) {
+        wave_off = wave * PW * 1024;
+        lbase = (const char*)stream + wave_off;
+        lane16 = (unsigned)lane * 16u;
+        ring = lds;
+        lane_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (unsigned)lane * 16u;
+        static_for<0, RING - LAG>([&](auto uc) { issue<decltype(uc)::value>(); });
+    }
+    template <int V>
+    __device__ __forceinline__ void issue() {
+        unsigned off = (unsigned)(V * UNIT);
+        asm volatile("" : "+s"(off));
+        const char* src = (lbase + off) + lane16;
+        char* dst = ring + (V % RING) * UNIT + wave_off;
+        static_for<0, PW>([&](auto ic) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, decltype(ic)::value * 1024, 0);
+        });
+    }
+    template <int U>
+    __device__ __forceinline__ void advance() {
+        wait_ring<(RING - LAG - 1) * PW>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue<U + RING - LAG>();                       // (beyond the layer's last unit: the next layer's first units, contiguous in the stream)
+    }
+    template <class PX, int GF>
+    __device__ __forceinline__ typename PX::frag frag() {
+        constexpr int UF = P::UNIT_FRAGS;
+        if constexpr (GF % UF == 0) advance<GF / UF>();
+        constexpr int OFF = ((GF / UF) % RING) * UNIT + (GF % UF) * P::FRAG_BYTES;
+        static_assert(OFF + 16 <= 65536, "ring must stay within the immediate ds_read offset");
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lane_addr), "n"(OFF));
+        return __builtin_bit_cast(typename PX::frag, v);
+    }
+    // the layer's padding units, then on to the next layer's block
+    template <class PLK>
+    __device__ __forceinline__ void end_layer() {
+        static_for<PLK::NUNITS, PLK::NUP>([&](auto uc) { advance<decltype(uc)::value>(); });
+        lbase += (size_t)PLK::NUP * UNIT;
+    }
+    __device__ __forceinline__ void rewind(const void* stream) { lbase = (const char*)stream + wave_off; }
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+template <class P, int WC, int NB>
+__global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
+    constexpr int WAVES = 4;
+    using PE = PolF16;                                                // the encoding's operands are f16 in both modes
+    using frag = typename P::frag;
+    using efrag = typename PE::frag;
+    using PIN = PlanGX<WC, GX_IN>;
+    using PHID = PlanGX<WC, GX_HID>;
+    using PSKIP = PlanGX<WC, GX_SKIP>;
+    using PHEAD = PlanGX<WC, GX_HEAD>;
+    constexpr int NS_H = WC / 32, NS_E = GX_NS_E, NT = WC / 16;
+    constexpr int PF = (WC > 256) ? 4 : 8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    float* bias_lds = (float*)(smem + RING * P::UNIT_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    for (int i = tid; i < a.n_bias_tiles * 16; i += WAVES * 64) bias_lds[i] = a.bias[i];
+    __syncthreads();
+    typedef const __attribute__((address_space(3))) f32x4* BP;
+    const BP bias_lane0 = (BP)(bias_lds + 4 * g);
+    WRingRT<P, WAVES> st;
+    st.init(a.wstream, ring, wave, lane);
+
+    const int S = a.S, D = a.depth, skip = a.skip, L = a.L;
+    const int bpr = (S + 15) >> 4;
+    const long long nblocks = (long long)a.n_rays * bpr;
+    const long long per_wg = (long long)WAVES * NB;
+    for (long long b0 = (long long)blockIdx.x * per_wg; b0 < nblocks; b0 += (long long)gridDim.x * per_wg) {
+        unsigned so[NB];
+        bool ok[NB];
+        efrag enc[NB][NS_E];
+        static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const long long blk_raw = b0 + (long long)wave * NB + b;
+            const bool blk_ok = blk_raw < nblocks;
+            const long long blk = blk_ok ? blk_raw : nblocks - 1;
+            const int ray = (int)(blk / bpr), bir = (int)(blk % bpr);
+            const int sidx = bir * 16 + n;
+            ok[b] = blk_ok && sidx < S;
+            so[b] = (unsigned)ray * (unsigned)S + (unsigned)(sidx < S ? sidx : S - 1);
+            const f32x4 q4 = *(const f32x4*)(a.pts4 + (size_t)so[b] * 4);
+            const float prev[3] = {q4[0] * 0.15915494309189535f, q4[1] * 0.15915494309189535f, q4[2] * 0.15915494309189535f};
+#pragma unroll
+            for (int s = 0; s < NS_E; ++s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {          // the lane's 4 (sin, cos) pairs of this k-step: positions 32 s + 8 g + 2 i, + 1
+                    const int p = 32 * s + 8 * g + 2 * i;
+                    const int m = (p - 4) >> 1;        // (p = 0, 2 of lane group 0, k-step 0: the identity columns instead)
+                    const int f = m / 3, c = m - 3 * f;
+                    const float xr = c == 0 ? prev[0] : (c == 1 ? prev[1] : prev[2]);
+                    const float r = __builtin_amdgcn_fractf(xr * __builtin_amdgcn_ldexpf(1.0f, f));
+                    float sv = __builtin_amdgcn_sinf(r), cv = __builtin_amdgcn_cosf(r);
+                    if (p < 4) { sv = (p == 0) ? q4[0] : q4[2]; cv = (p == 0) ? q4[1] : 0.0f; }
+                    else if (m >= 3 * L) { sv = 0.0f; cv = 0.0f; }
+                    enc[b][s][2 * i] = (_Float16)sv;
+                    enc[b][s][2 * i + 1] = (_Float16)cv;
+                }
+            }
+        });
+
+        frag ha[NB][NS_H], hb[NB][NS_H];
+        frag none[NB][1];
+        auto keep = [&](auto& out) {
+            return [&](auto pc, auto kc, const f32x4& d0, const f32x4& d1) {
+                out[decltype(kc)::value][decltype(pc)::value] = x16_pack<P>(d0, d1);
+            };
+        };
+        BP bl = bias_lane0;
+        asm volatile("" : "+v"(bl));
+        dense_x16<PE, P, PIN, 0, NS_E, 0, NB, PF>(st, bl, enc, none, keep(ha));
+        st.template end_layer<PIN>();
+        bl += NT * 4;                                   // (f32x4 units: 16 floats per tile)
+        // the layers two at a time (ha -> hb -> ha: which array holds the activations is then a compile-time fact in every code block;
+        // a run-time flag for it cost 280 spilled registers at width class 256), an odd one last; the head reads whichever is current
+        f32x4 raw[NB];
+        auto take = [&](auto, auto kc, const f32x4& d0, const f32x4&) { raw[decltype(kc)::value] = d0; };
+        auto layer = [&](int l, auto& in, auto& out) __attribute__((always_inline)) {
+            asm volatile("" : "+v"(bl));
+            if (l - 1 == skip) { dense_x16<PE, P, PSKIP, 0, NS_E, NS_H, NB, PF>(st, bl, enc, in, keep(out)); st.template end_layer<PSKIP>(); }
+            else { dense_x16<P, P, PHID, 0, NS_H, 0, NB, PF>(st, bl, in, none, keep(out)); st.template end_layer<PHID>(); }
+            bl += NT * 4;
+        };
+        int l = 1;
+        for (; l + 1 < D; l += 2) {
+            layer(l, ha, hb);
+            layer(l + 1, hb, ha);
+        }
+        if (l < D) {
+            layer(l, ha, hb);
+            asm volatile("" : "+v"(bl));
+            dense_x16<P, P, PHEAD, 0, NS_H, 0, NB, PF>(st, bl, hb, none, take);
+        } else {
+            asm volatile("" : "+v"(bl));
+            dense_x16<P, P, PHEAD, 0, NS_H, 0, NB, PF>(st, bl, ha, none, take);
+        }
+        // the head's padding units run on into the copy of the first layer's first units behind it; then back to the stream's start
+        static_for<PHEAD::NUNITS, PHEAD::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+        st.rewind(a.wstream);
+
+        static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            if (ok[b] && g == 0) {
+                *(f32x4*)(a.raw4 + (size_t)so[b] * 4) = raw[b];
+                if (a.raw_out) {
+                    float* ro = a.raw_out + (size_t)so[b] * a.raw_ch;
+                    ro[0] = raw[b][0]; ro[1] = raw[b][1]; ro[2] = raw[b][2]; ro[3] = raw[b][3];
+                }
+            }
+            if (ok[b] && g == 1 && a.raw_out && a.raw_ch > 4) a.raw_out[(size_t)so[b] * a.raw_ch + 4] = raw[b][0];
+        });
+    }
+    st.drain();
+}
+
+template <class P, int WC>
+static hipError_t launch_gx16_t(const GxArgs& a, int num_cus, hipStream_t stream) {
+    constexpr int WAVES = 4, NB = (WC > 256) ? 2 : 4;
+    if (!a.pts4 || !a.raw4 || a.S < 1 || a.depth < 1 || a.L < 0 || a.L > GX_MAX_L) return hipErrorInvalidValue;
+    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)a.n_bias_tiles * 16 * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = gx16_kernel<P, WC, NB>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipErrorUnknown;
+    const long long bpr = (a.S + 15) / 16;
+    const long long want = ((long long)a.n_rays * bpr + WAVES * NB - 1) / (WAVES * NB);
+    if (want <= 0) return hipSuccess;
+    const int grid = (int)(want < num_cus ? want : num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace nrn

@@ -1,0 +1,67 @@
+// nrnerf_gx16_plan.h -- layer tables of the WIDTH-CLASS trunk kernel for architectures outside the compiled set (nrnerf_gx16.h; packer:
+// nrnerf_api.cpp).
+//
+// The run-time-parameterised kernel of nrnerf_generic.h keeps activations in LDS and lets the waves split the OUTPUT tiles, so every
+// wave pulls its own weights from L2 for 64 samples: 0.17-0.24 of the bf16 peak.  The compiled kernels are 3 x faster because the
+// activations stay in registers and all four waves share one weight stream -- which ties them to compile-time shapes.  Here only the
+// WIDTH CLASS (the trunk width rounded up to a multiple of 64, zero-padded) is compile-time: a layer of a given kind is a compile-time
+// code block (dense_x16 of nrnerf_net_x16.h on a one-layer plan), and the DEPTH, the skip index and the encoding size are run-time:
+// the kernel loops over the layers, the weight stream is the layers' blocks back to back, each padded to a whole number of ring
+// periods so that every layer starts at ring slot 0, and the ring's source pointer advances at run time.
+//   GX_IN    k-steps [encoding (2)]                      -> WC / 16 tiles            pts_linears[0]
+//   GX_HID   k-steps [hidden (WC / 32)]                  -> WC / 16 tiles            pts_linears[i]
+//   GX_SKIP  k-steps [encoding (2), hidden (WC / 32)]    -> WC / 16 tiles            pts_linears[skip + 1]  (reference order [input, h], rnh:277-282)
+//   GX_HEAD  k-steps [hidden (WC / 32)]                  -> one tile                 output_linear (4 / 5 channels)
+// Encoding slots (two k-steps = 64 positions, L <= 10): position p = 32 s + 8 g + e; p < 3: the identity column p; p = 3: zero; p >= 4:
+// pair m = (p - 4) / 2 (frequency m / 3, coordinate m % 3), sin for even p, cos for odd -- a lane's 8 slots hold 4 whole (sin, cos) pairs.
+#pragma once
+#include "nrnerf_plan.h"
+
+namespace nrn {
+
+enum GxKind : int { GX_IN = 0, GX_HID = 1, GX_SKIP = 2, GX_HEAD = 3 };
+constexpr int GX_NS_E = 2;                      // encoding k-steps (3 + 6 L + 1 <= 64: L <= 10)
+constexpr int GX_MAX_L = 10;
+
+constexpr NRN_HD int gx_enc_col(int L, int s, int g, int e) {       // reference column of encoding position (s, g, e), -1: zero
+    const int p = 32 * s + 8 * g + e;
+    if (p < 3) return p;
+    if (p == 3) return -1;
+    const int m = (p - 4) / 2, b = (p - 4) & 1;
+    if (m >= 3 * L) return -1;
+    return 3 + 6 * (m / 3) + 3 * b + (m % 3);
+}
+constexpr NRN_HD int gx_width_class(int W) { return ((W + 63) / 64) * 64; }
+
+// (a plain constexpr function of (width class, kind): the kernel instantiates it per template argument, the packer calls it at run time)
+constexpr Tables build_tables_gx(int wc, int kind) {
+    Tables T{};
+    const int ns = (kind == GX_IN) ? GX_NS_E : (kind == GX_SKIP ? GX_NS_E + wc / 32 : wc / 32);
+    const int nt = (kind == GX_HEAD) ? 1 : wc / 16;
+    T.layers[0] = LayerSpec{kind, 0, ns, nt, 0, 0};
+    T.nlayers = 1;
+    T.ntiles = nt;
+    place_fragments<Shape16Fast>(T);
+    return T;
+}
+template <int WC, int KIND>
+struct PlanGX {
+    static_assert(WC % 64 == 0 && WC >= 64 && WC <= 512, "width classes are multiples of 64 up to 512");
+    static constexpr Tables TB = build_tables_gx(WC, KIND);
+    static constexpr int NT = TB.ntiles, NFRAGS = TB.nfrags;
+    static constexpr int NUNITS = TB.nunits;                     // units holding fragments
+    static constexpr int NUP = TB.nunits_padded;                 // units streamed for this layer: a whole number of ring periods
+    static_assert(NUP % RING == 0, "every layer starts at ring slot 0");
+};
+// units of one layer of kind k at width class wc (host-side mirror for the packer)
+constexpr int gx_layer_units(int wc, int kind) {
+    const int ns = (kind == GX_IN) ? GX_NS_E : (kind == GX_SKIP ? GX_NS_E + wc / 32 : wc / 32);
+    const int nt = (kind == GX_HEAD) ? 1 : wc / 16;
+    const int units = cdiv(ns * nt, Shape16Fast::UNIT_FRAGS);
+    return cdiv(units, RING) * RING;
+}
+constexpr int gx_layer_tiles(int wc, int kind) { return (kind == GX_HEAD) ? 1 : wc / 16; }
+// run-time shape of one packed trunk (the kernel's GxArgs fields the packer decides)
+struct GxMeta { int wc = 0, depth = 0, skip = -1, L = 0, n_bias_tiles = 0; };
+
+}  // namespace nrn

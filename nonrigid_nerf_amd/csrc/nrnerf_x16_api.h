@@ -13,4 +13,17 @@ long long x16_rays_per_group(int arch, int S);
 // the stand-alone ray bender on 16x16x32 MFMAs (nrnerf_bend_x16.h): arch 0 = the 5 x 64 bender, 1 = 7 x 64; BendArgs::wstream / bias =
 // the image of pack_pass_x16_bend (f16 fragments of PlanX16Bend)
 hipError_t launch_bend_x16(int arch, const BendArgs& a, int num_cus, hipStream_t stream);
+// the width-class trunk kernel for architectures outside the compiled set (nrnerf_gx16.h): wc = gx_width_class(trunk width), 64 .. 512
+struct GxArgs {
+    const float* pts4;          // [N, S, 4] points of the pass
+    float* raw4;                // [N, S, 4] rgb, sigma (workspace, for the composite kernel)
+    float* raw_out;             // [N, S, raw_ch] or null (retraw)
+    int raw_ch;
+    int n_rays, S;
+    const void* wstream;        // the layers' fragment blocks back to back (+ a copy of the first two units behind the last)
+    const float* bias;          // [total tiles][16]
+    int depth, skip, L;         // pts_linears count; index after which [input, h] is concatenated (-1: never); encoding frequencies
+    int n_bias_tiles;
+};
+hipError_t launch_gx16(int precision, int wc, const GxArgs& a, int num_cus, hipStream_t stream);
 }  // namespace nrn

@@ -457,6 +457,127 @@ def test_x16_stream_reproduces_the_trunk(precision, cfg_kw):
     assert err <= tol * np.abs(ref).max(), f"x16 trunk + head mismatch {err} vs scale {np.abs(ref).max()}"
 
 
+@pytest.mark.parametrize("cfg_kw", [dict(netwidth=192, netdepth=6, multires=8), dict(netwidth=320, netdepth=10), dict(netwidth=64, netdepth=3, skips=()),
+                                    dict(netwidth=256), dict(netwidth=500, netdepth=5, skips=(1,), multires=4)],
+                         ids=["w192_d6_l8", "w320_d10", "w64_d3_noskip", "w256_default", "w500_d5_skip1_l4"])
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_width_class_stream_reproduces_any_plain_trunk(precision, cfg_kw):
+    """The image of the width-class trunk kernel (csrc/nrnerf_gx16.h; nrnerf_pack_host which = 12), emulated in numpy as the kernel
+    consumes it: the layers' fragment blocks back to back -- first layer (two encoding k-steps, positions p = 32 s + 8 g + e: p < 3 the
+    identity columns, p = 3 zero, then (sin, cos) pairs m = (p - 4) / 2), pts_linears[1 ..] (the one after the skip index with the encoding
+    k-steps first), output_linear -- each padded to a whole number of 4-unit ring periods, the width padded to a multiple of 64 with zero
+    rows / columns; a copy of the first two units behind the last layer.  Any depth, skip index, width <= 512, <= 10 frequencies."""
+    cfg = SceneConfig(N_importance=128, **cfg_kw)
+    scene, (rb, coarse, fine), info, stream, units, bias = _pack(cfg, precision, which=12)
+    assert info.frag_bytes == 1024
+    W, D, L = cfg.netwidth, cfg.netdepth, cfg.multires
+    skip = cfg.skips[0] if cfg.skips else -1
+    WC = (W + 63) // 64 * 64
+    rnd, rnd_e = rounder(precision), rounder("f16")
+    u16 = stream.view(np.uint16)
+    as_bf16 = (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    as_f16 = stream.view(np.float16).astype(np.float64)
+    pos = [0]
+
+    def next_A(f16):
+        vals = as_f16 if (f16 or precision == "f16") else as_bf16
+        f = vals[pos[0] * 512:(pos[0] + 1) * 512].reshape(64, 8)
+        pos[0] += 1
+        A = np.zeros((16, 32))
+        for lane in range(64):
+            A[lane & 15, 8 * (lane >> 4):8 * (lane >> 4) + 8] = f[lane]
+        return A
+
+    tile = [0]
+
+    def dense(ns, nt, B, n_f16):
+        start = pos[0]
+
+        def bias_of(t):
+            return np.repeat(bias[(tile[0] + t) * 16:(tile[0] + t) * 16 + 16].astype(np.float64)[:, None], B[0].shape[1], 1)
+        out = [None] * nt
+        for p_ in range(0, nt - 1, 2):
+            D0, D1 = bias_of(p_), bias_of(p_ + 1)
+            for s_ in range(ns):
+                D0 = D0 + next_A(s_ < n_f16) @ B[s_]
+                D1 = D1 + next_A(s_ < n_f16) @ B[s_]
+            out[p_], out[p_ + 1] = D0, D1
+        if nt & 1:
+            Dl = bias_of(nt - 1)
+            for s_ in range(ns):
+                Dl = Dl + next_A(s_ < n_f16) @ B[s_]
+            out[nt - 1] = Dl
+        tile[0] += nt
+        used_units = -(-(pos[0] - start) // 16)
+        pos[0] = start + (-(-used_units // 4) * 4) * 16           # the layer's padding: on to the next whole ring period
+        return out
+
+    def hand_off(tiles):
+        B = []
+        for s_ in range(len(tiles) // 2):
+            b = np.zeros((32, tiles[0].shape[1]))
+            for g in range(4):
+                for e in range(8):
+                    b[8 * g + e] = tiles[2 * s_][4 * g + e] if e < 4 else tiles[2 * s_ + 1][4 * g + e - 4]
+            B.append(rnd(np.maximum(b, 0.0)))
+        return B
+
+    gen = torch.Generator().manual_seed(6)
+    ns_ = 24
+    p = (torch.randn(ns_, 3, generator=gen) * 0.4).double()
+    cols = [p]
+    for k in range(L):
+        cols += [torch.sin(p * 2.0 ** k), torch.cos(p * 2.0 ** k)]
+    x = torch.cat(cols, -1)                                                   # [ns, 3 + 6 L], reference column order
+    xn = x.numpy()
+
+    def enc_col(s_, g, e):
+        q = 32 * s_ + 8 * g + e
+        if q < 3:
+            return q
+        if q == 3:
+            return -1
+        m, b = (q - 4) // 2, (q - 4) & 1
+        return 3 + 6 * (m // 3) + 3 * b + (m % 3) if m < 3 * L else -1
+    seen = sorted(c for s_ in range(2) for g in range(4) for e in range(8) if (c := enc_col(s_, g, e)) >= 0)
+    assert seen == list(range(3 + 6 * L)), "every encoding column sits in exactly one position"
+    Benc = []
+    for s_ in range(2):
+        b = np.zeros((32, ns_))
+        for g in range(4):
+            for e in range(8):
+                c = enc_col(s_, g, e)
+                if c >= 0:
+                    b[8 * g + e] = xn[:, c]
+        Benc.append(rnd_e(b))
+    NT = WC // 16
+    mfma = 0
+    tiles = dense(2, NT, Benc, 2); mfma += 2 * NT
+    for i in range(1, D):
+        B = hand_off(tiles)
+        n16 = 0
+        if i - 1 == skip:
+            B, n16 = Benc + B, 2
+        tiles = dense(len(B), NT, B, n16); mfma += len(B) * NT
+    B = hand_off(tiles)
+    Dh = dense(len(B), 1, B, 0)[0]; mfma += len(B)
+    raw = Dh[0:5].T
+    assert tile[0] == info.n_bias_tiles and mfma == info.mfma_per_block
+    # behind the last layer: a copy of the stream's first two units, then nothing
+    assert info.stream_bytes == (pos[0] // 16 + 2) * 16384
+    assert (stream[pos[0] * 1024:pos[0] * 1024 + 2 * 16384] == stream[:2 * 16384]).all()
+    with torch.no_grad():
+        h = x
+        for i, l in enumerate(fine.pts_linears):
+            h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
+            if i == skip:
+                h = torch.cat([x, h], -1)
+        ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
+    tol = 8e-2 if precision == "bf16" else 1e-2
+    err = np.abs(raw - ref).max()
+    assert err <= tol * np.abs(ref).max(), f"width-class trunk + head mismatch {err} vs scale {np.abs(ref).max()}"
+
+
 def test_unsupported_architectures_are_rejected():
     lib = _lib.load()
     for kw in (dict(netwidth=192), dict(netwidth=128, use_viewdirs=True), dict(netwidth=128, bend_depth=7), dict(netdepth=6), dict(multires=8), dict(bend_hidden=32), dict(latent_size=16),
