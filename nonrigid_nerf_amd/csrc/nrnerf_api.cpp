@@ -1062,8 +1062,13 @@ bool bender_matches(const nrnerf_bender_desc& b) {
 // does it take this network?  16-bit modes, no view-dependent head, no time conditioning, <= 10 encoding frequencies, 4 / 5 output channels
 bool gx16_eligible(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
     if (d.precision != NRNERF_PREC_BF16 && d.precision != NRNERF_PREC_F16) return false;
-    if (m.use_viewdirs || m.time_conditioned || d.multires < 0 || d.multires > GX_MAX_L) return false;
+    if (m.time_conditioned || d.multires < 0 || d.multires > GX_MAX_L) return false;
     if (m.width < 1 || m.width > 512 || m.depth < 1 || m.depth > 16) return false;
+    if (m.use_viewdirs) {            // view-dependent head: <= 4 direction frequencies, finite-difference directions, views layer <= half the class
+        if (d.multires_views < 0 || d.multires_views > GX_MAX_LV || (d.exact_viewdirs && d.bender)) return false;
+        if (m.views_linear.out_features > gx_width_class(m.width) / 2 || m.feature_linear.out_features != m.width) return false;
+        return true;
+    }
     if (m.output_ch != 4 && m.output_ch != 5) return false;
     return true;
 }
@@ -1076,7 +1081,12 @@ void pack_gx16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPas
     std::vector<int> kinds;
     kinds.push_back(GX_IN);
     for (int i = 1; i < D; ++i) kinds.push_back((i - 1 == skip) ? GX_SKIP : GX_HID);
-    kinds.push_back(GX_HEAD);
+    const bool views = mlp.use_viewdirs != 0;
+    if (views) { kinds.push_back(GX_VIEWS); kinds.push_back(GX_RGB); }
+    else kinds.push_back(GX_HEAD);
+    std::unique_ptr<FoldedViews> folded;
+    if (views) folded.reset(new FoldedViews(mlp));
+    const int EV = 3 + 6 * d.multires_views;
     int units = 0, tiles = 0, mfma = 0;
     for (int k : kinds) { units += gx_layer_units(wc, k); tiles += gx_layer_tiles(wc, k); }
     constexpr int TAIL = RING - NRN_RING_LAG_HOST;
@@ -1096,21 +1106,41 @@ void pack_gx16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPas
         const int kind = kinds[li];
         const Tables T = build_tables_gx(wc, kind);
         const LayerSpec& sp = T.layers[0];
-        const nrnerf_linear* lin = (kind == GX_HEAD) ? &mlp.output_linear : &mlp.pts_linears[li];
-        const int64_t wbase = lay ? lay->of(lin->weight) : -1, bbase = (lay && lin->bias) ? lay->of(lin->bias) : -1;
+        const nrnerf_linear* lin0 = (kind == GX_HEAD) ? &mlp.output_linear : (kind == GX_RGB ? &mlp.rgb_linear : (kind == GX_VIEWS ? &folded->lin : &mlp.pts_linears[li]));
+        int64_t wbase0 = (lay && kind != GX_VIEWS) ? lay->of(lin0->weight) : -1, bbase0 = (lay && kind != GX_VIEWS && lin0->bias) ? lay->of(lin0->bias) : -1;
+        if (kind == GX_VIEWS && lay) {             // the derived entries of the flat vector (FlatLayout::add_folded), as pack_pass
+            wbase0 = lay->folded_of(mlp.views_linear.weight);
+            bbase0 = wbase0 < 0 ? -1 : wbase0 + (int64_t)lin0->out_features * lin0->in_features;
+        }
         for (int t = 0; t < sp.nt; ++t) {
+            const bool alpha_tile = kind == GX_VIEWS && t == sp.nt - 1;          // the views layer's last tile: alpha_linear (row 0)
+            const nrnerf_linear* lin = alpha_tile ? &mlp.alpha_linear : lin0;
+            const int64_t wbase = alpha_tile ? (lay ? lay->of(lin->weight) : -1) : wbase0;
+            const int64_t bbase = alpha_tile ? ((lay && lin->bias) ? lay->of(lin->bias) : -1) : bbase0;
             const TileInfo& ti = T.tiles[t];
+            auto row_of = [&](int r) {
+                if (alpha_tile) return r == 0 ? 0 : -1;
+                if (kind == GX_HEAD) return r < lin->out_features ? r : -1;
+                if (kind == GX_RGB) return r < 3 ? r : -1;
+                return (16 * t + r < lin->out_features) ? 16 * t + r : -1;
+            };
             for (int s = 0; s < sp.ns; ++s) {
                 const size_t fi = unit0 * SH::UNIT_FRAGS + (size_t)ti.gbase + (size_t)s * ti.gstride;
                 uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
-                const bool enc_step = (kind == GX_IN || kind == GX_SKIP) && s < GX_NS_E;
+                const bool enc_step = ((kind == GX_IN || kind == GX_SKIP) && s < GX_NS_E) || (kind == GX_VIEWS && s == 0);
                 const bool as_f16 = d.precision == NRNERF_PREC_F16 || enc_step;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int r = lane & 15, g = lane >> 4;
-                    const int row = (kind == GX_HEAD) ? (r < lin->out_features ? r : -1) : ((16 * t + r < lin->out_features) ? 16 * t + r : -1);
+                    const int row = row_of(r);
                     for (int e = 0; e < 8; ++e) {
                         int col;
-                        if (enc_step) col = gx_enc_col(L, s, g, e);
+                        if (kind == GX_VIEWS) {            // folded columns: hidden (W) first, then the direction encoding's (EV); alpha: hidden only
+                            if (s == 0) { const int c = gx_enc_col(d.multires_views, 0, g, e); col = (c < 0 || alpha_tile) ? -1 : (lin->in_features - EV) + c; }
+                            else { const int c = x16_hidden_feature(s - 1, g, e); col = c < W ? c : -1; }
+                        } else if (kind == GX_RGB) {
+                            const int c = x16_hidden_feature(s, g, e);
+                            col = c < lin->in_features ? c : -1;
+                        } else if (enc_step) col = gx_enc_col(L, s, g, e);
                         else {
                             const int c = x16_hidden_feature(kind == GX_SKIP ? s - GX_NS_E : s, g, e);
                             col = c < W ? (kind == GX_SKIP ? enc + c : c) : -1;
@@ -1128,7 +1158,7 @@ void pack_gx16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPas
                 }
             }
             for (int r = 0; r < 16; ++r) {
-                const int row = (kind == GX_HEAD) ? (r < lin->out_features ? r : -1) : ((16 * t + r < lin->out_features) ? 16 * t + r : -1);
+                const int row = row_of(r);
                 out.bias[(tile0 + t) * 16 + r] = (row >= 0 && lin->bias) ? lin->bias[row] : 0.0f;
                 if (lay && row >= 0 && bbase >= 0) out.bias_src[(tile0 + t) * 16 + r] = (int32_t)(bbase + row);
             }
@@ -1145,7 +1175,7 @@ void pack_gx16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPas
         std::copy(out.fmt.begin(), out.fmt.begin() + n, out.fmt.begin() + o);
     }
     out.mfma_per_block = mfma;
-    meta.wc = wc; meta.depth = D; meta.skip = skip; meta.L = L; meta.n_bias_tiles = tiles;
+    meta.wc = wc; meta.depth = D; meta.skip = skip; meta.L = L; meta.n_bias_tiles = tiles; meta.views = views ? 1 : 0; meta.LV = d.multires_views;
 }
 
 // ---- models of an architecture outside the compiled set (nrnerf_generic.h)
@@ -1781,9 +1811,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                 GxArgs x{};
                 x.pts4 = pts; x.raw4 = raw4; x.raw_out = raw_user; x.raw_ch = pd.output_ch;
                 x.n_rays = N; x.S = nS; x.wstream = gxu.stream; x.bias = gxu.bias;
-                x.depth = gmu.depth; x.skip = gmu.skip; x.L = gmu.L; x.n_bias_tiles = gmu.n_bias_tiles;
+                x.depth = gmu.depth; x.skip = gmu.skip; x.L = gmu.L; x.n_bias_tiles = gmu.n_bias_tiles; x.LV = gmu.LV;
                 return timed(slot, (double)N * nS * gxu.algo_flops_per_sample, (double)N * nS * gxu.mfma_flops_per_sample,
-                             [&] { return launch_gx16(m->precision, gmu.wc, x, m->num_cus, stream); });
+                             [&] { return launch_gx16(m->precision, gmu.wc, gmu.views != 0, x, m->num_cus, stream); });
             }
             GenArgs g = prog;
             g.rays = a->rays; g.ray_stride = a->ray_stride; g.latents = a->latents; g.lat_stride = a->latent_stride;

@@ -70,7 +70,8 @@ struct WRingRT {
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
-template <class P, int WC, int NB>
+// VIEWS: the view-dependent head behind the trunk (directions = finite differences of the points' rows, as net_kernel_x16<VIEWS>)
+template <class P, int WC, int NB, bool VIEWS>
 __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
     constexpr int WAVES = 4;
     using PE = PolF16;                                                // the encoding's operands are f16 in both modes
@@ -80,6 +81,9 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
     using PHID = PlanGX<WC, GX_HID>;
     using PSKIP = PlanGX<WC, GX_SKIP>;
     using PHEAD = PlanGX<WC, GX_HEAD>;
+    using PVIEWS = PlanGX<WC, GX_VIEWS>;
+    using PRGB = PlanGX<WC, GX_RGB>;
+    constexpr int NS_V = WC / 64;
     constexpr int NS_H = WC / 32, NS_E = GX_NS_E, NT = WC / 16;
     constexpr int PF = (WC > 256) ? 4 : 8;
 
@@ -104,6 +108,7 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
         unsigned so[NB];
         bool ok[NB];
         efrag enc[NB][NS_E];
+        efrag encv[NB][1];
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             const long long blk_raw = b0 + (long long)wave * NB + b;
@@ -114,6 +119,33 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
             ok[b] = blk_ok && sidx < S;
             so[b] = (unsigned)ray * (unsigned)S + (unsigned)(sidx < S ? sidx : S - 1);
             const f32x4 q4 = *(const f32x4*)(a.pts4 + (size_t)so[b] * 4);
+            if constexpr (VIEWS) {
+                // the sample's direction: finite difference of the points along the ray, sample 0 takes sample 1's (rnh:339-351)
+                const int sc = sidx < S ? sidx : S - 1;
+                const bool first = sc == 0;
+                const unsigned nbr = (unsigned)ray * (unsigned)S + (unsigned)(first ? (S > 1 ? 1 : 0) : sc - 1);
+                const f32x4 nb4 = *(const f32x4*)(a.pts4 + (size_t)nbr * 4);
+                float dd[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dd[c] = first ? __fsub_rn(nb4[c], q4[c]) : __fsub_rn(q4[c], nb4[c]);
+                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dd[0], dd[0]), __fmul_rn(dd[1], dd[1])), __fmul_rn(dd[2], dd[2])));
+                float dir[3], drev[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { dir[c] = __fdiv_rn(dd[c], __fadd_rn(nrm, 0.000001f)); drev[c] = dir[c] * 0.15915494309189535f; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int p = 8 * g + 2 * i;
+                    const int m = (p - 4) >> 1;
+                    const int f = m / 3, c = m - 3 * f;
+                    const float xr = c == 0 ? drev[0] : (c == 1 ? drev[1] : drev[2]);
+                    const float r = __builtin_amdgcn_fractf(xr * __builtin_amdgcn_ldexpf(1.0f, f));
+                    float sv = __builtin_amdgcn_sinf(r), cv = __builtin_amdgcn_cosf(r);
+                    if (p < 4) { sv = (p == 0) ? dir[0] : dir[2]; cv = (p == 0) ? dir[1] : 0.0f; }
+                    else if (m >= 3 * a.LV) { sv = 0.0f; cv = 0.0f; }
+                    encv[b][0][2 * i] = (_Float16)sv;
+                    encv[b][0][2 * i + 1] = (_Float16)cv;
+                }
+            }
             const float prev[3] = {q4[0] * 0.15915494309189535f, q4[1] * 0.15915494309189535f, q4[2] * 0.15915494309189535f};
 #pragma unroll
             for (int s = 0; s < NS_E; ++s) {
@@ -160,16 +192,36 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
             layer(l, ha, hb);
             layer(l + 1, hb, ha);
         }
+        auto head = [&](auto& hx) __attribute__((always_inline)) {
+            asm volatile("" : "+v"(bl));
+            if constexpr (!VIEWS) {
+                dense_x16<P, P, PHEAD, 0, NS_H, 0, NB, PF>(st, bl, hx, none, take);
+                static_for<PHEAD::NUNITS, PHEAD::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+            } else {
+                // hv = relu(views o feature ([enc(dir), h])) in tile pairs, sigma = the lone last tile's row 0; then rgb = rgb_linear(hv)
+                frag hv[NB][NS_V];
+                float sigma[NB];
+                auto views_epi = [&](auto pc, auto kc, const f32x4& d0, const f32x4& d1) {
+                    constexpr int p = decltype(pc)::value, k = decltype(kc)::value;
+                    if constexpr (p < NS_V) hv[k][p] = x16_pack<P>(d0, d1);
+                    else sigma[k] = d0[0];
+                };
+                dense_x16<PE, P, PVIEWS, 0, 1, NS_H, NB, PF>(st, bl, encv, hx, views_epi);
+                st.template end_layer<PVIEWS>();
+                bl += PVIEWS::NT * 4;
+                asm volatile("" : "+v"(bl));
+                dense_x16<P, P, PRGB, 0, NS_V, 0, NB, PF>(st, bl, hv, none, take);
+                static_for<PRGB::NUNITS, PRGB::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+                static_for<0, NB>([&](auto bc) { raw[decltype(bc)::value][3] = sigma[decltype(bc)::value]; });
+            }
+        };
         if (l < D) {
             layer(l, ha, hb);
-            asm volatile("" : "+v"(bl));
-            dense_x16<P, P, PHEAD, 0, NS_H, 0, NB, PF>(st, bl, hb, none, take);
+            head(hb);
         } else {
-            asm volatile("" : "+v"(bl));
-            dense_x16<P, P, PHEAD, 0, NS_H, 0, NB, PF>(st, bl, ha, none, take);
+            head(ha);
         }
-        // the head's padding units run on into the copy of the first layer's first units behind it; then back to the stream's start
-        static_for<PHEAD::NUNITS, PHEAD::NUP>([&](auto uc) { st.template advance<decltype(uc)::value>(); });
+        // (the last layer's padding units ran on into the copy of the first layer's first units behind it) back to the stream's start
         st.rewind(a.wstream);
 
         static_for<0, NB>([&](auto bc) {
@@ -187,13 +239,14 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
     st.drain();
 }
 
-template <class P, int WC>
+template <class P, int WC, bool VIEWS>
 static hipError_t launch_gx16_t(const GxArgs& a, int num_cus, hipStream_t stream) {
     constexpr int WAVES = 4, NB = (WC > 256) ? 2 : 4;
     if (!a.pts4 || !a.raw4 || a.S < 1 || a.depth < 1 || a.L < 0 || a.L > GX_MAX_L) return hipErrorInvalidValue;
     const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)a.n_bias_tiles * 16 * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = gx16_kernel<P, WC, NB>;
+    if (VIEWS && (a.LV < 0 || a.LV > GX_MAX_LV)) return hipErrorInvalidValue;
+    auto kern = gx16_kernel<P, WC, NB, VIEWS>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipErrorUnknown;
     const long long bpr = (a.S + 15) / 16;
     const long long want = ((long long)a.n_rays * bpr + WAVES * NB - 1) / (WAVES * NB);

@@ -8,9 +8,14 @@
 #define NRN_CAT(a, b) NRN_CAT2(a, b)
 
 namespace nrn {
-hipError_t NRN_CAT(launch_gx16_w, NRN_GX_WC)(int precision, const GxArgs& a, int num_cus, hipStream_t stream) {
-    if (precision == PREC_BF16) return launch_gx16_t<PolBF16, NRN_GX_WC>(a, num_cus, stream);
-    if (precision == PREC_F16) return launch_gx16_t<PolF16, NRN_GX_WC>(a, num_cus, stream);
+hipError_t NRN_CAT(launch_gx16_w, NRN_GX_WC)(int precision, bool views, const GxArgs& a, int num_cus, hipStream_t stream) {
+    if (views) {
+        if (precision == PREC_BF16) return launch_gx16_t<PolBF16, NRN_GX_WC, true>(a, num_cus, stream);
+        if (precision == PREC_F16) return launch_gx16_t<PolF16, NRN_GX_WC, true>(a, num_cus, stream);
+        return hipErrorInvalidValue;
+    }
+    if (precision == PREC_BF16) return launch_gx16_t<PolBF16, NRN_GX_WC, false>(a, num_cus, stream);
+    if (precision == PREC_F16) return launch_gx16_t<PolF16, NRN_GX_WC, false>(a, num_cus, stream);
     return hipErrorInvalidValue;
 }
 }  // namespace nrn

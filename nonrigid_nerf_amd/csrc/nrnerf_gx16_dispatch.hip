@@ -3,18 +3,18 @@
 #include "nrnerf_x16_api.h"
 
 namespace nrn {
-#define NRN_GX_DECL(WC) hipError_t launch_gx16_w##WC(int, const GxArgs&, int, hipStream_t);
+#define NRN_GX_DECL(WC) hipError_t launch_gx16_w##WC(int, bool, const GxArgs&, int, hipStream_t);
 NRN_GX_DECL(64) NRN_GX_DECL(128) NRN_GX_DECL(192) NRN_GX_DECL(256) NRN_GX_DECL(320) NRN_GX_DECL(384) NRN_GX_DECL(448) NRN_GX_DECL(512)
-hipError_t launch_gx16(int precision, int wc, const GxArgs& a, int num_cus, hipStream_t stream) {
+hipError_t launch_gx16(int precision, int wc, bool views, const GxArgs& a, int num_cus, hipStream_t stream) {
     switch (wc) {
-        case 64: return launch_gx16_w64(precision, a, num_cus, stream);
-        case 128: return launch_gx16_w128(precision, a, num_cus, stream);
-        case 192: return launch_gx16_w192(precision, a, num_cus, stream);
-        case 256: return launch_gx16_w256(precision, a, num_cus, stream);
-        case 320: return launch_gx16_w320(precision, a, num_cus, stream);
-        case 384: return launch_gx16_w384(precision, a, num_cus, stream);
-        case 448: return launch_gx16_w448(precision, a, num_cus, stream);
-        case 512: return launch_gx16_w512(precision, a, num_cus, stream);
+        case 64: return launch_gx16_w64(precision, views, a, num_cus, stream);
+        case 128: return launch_gx16_w128(precision, views, a, num_cus, stream);
+        case 192: return launch_gx16_w192(precision, views, a, num_cus, stream);
+        case 256: return launch_gx16_w256(precision, views, a, num_cus, stream);
+        case 320: return launch_gx16_w320(precision, views, a, num_cus, stream);
+        case 384: return launch_gx16_w384(precision, views, a, num_cus, stream);
+        case 448: return launch_gx16_w448(precision, views, a, num_cus, stream);
+        case 512: return launch_gx16_w512(precision, views, a, num_cus, stream);
         default: return hipErrorInvalidValue;
     }
 }

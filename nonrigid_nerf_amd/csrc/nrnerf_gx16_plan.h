@@ -12,6 +12,11 @@
 //   GX_HID   k-steps [hidden (WC / 32)]                  -> WC / 16 tiles            pts_linears[i]
 //   GX_SKIP  k-steps [encoding (2), hidden (WC / 32)]    -> WC / 16 tiles            pts_linears[skip + 1]  (reference order [input, h], rnh:277-282)
 //   GX_HEAD  k-steps [hidden (WC / 32)]                  -> one tile                 output_linear (4 / 5 channels)
+// and for the view-dependent head (rnh:284-304; the views layer is W // 2 wide, padded to WC / 2) instead of GX_HEAD:
+//   GX_VIEWS k-steps [direction encoding (1), hidden (WC / 32)] -> WC / 32 tiles of relu(views_linears[0] o feature_linear) + one last
+//            tile whose row 0 is alpha_linear (no relu; zero weights in the direction k-step)     (as PlanX16<VIEWS>, nrnerf_plan.h)
+//   GX_RGB   k-steps [views hidden (WC / 64)]            -> one tile, rows 0..2               rgb_linear
+// Direction encoding (one k-step, LV <= 4): the same position map as the points' (gx_enc_col(LV, 0, g, e)).
 // Encoding slots (two k-steps = 64 positions, L <= 10): position p = 32 s + 8 g + e; p < 3: the identity column p; p = 3: zero; p >= 4:
 // pair m = (p - 4) / 2 (frequency m / 3, coordinate m % 3), sin for even p, cos for odd -- a lane's 8 slots hold 4 whole (sin, cos) pairs.
 #pragma once
@@ -19,7 +24,7 @@
 
 namespace nrn {
 
-enum GxKind : int { GX_IN = 0, GX_HID = 1, GX_SKIP = 2, GX_HEAD = 3 };
+enum GxKind : int { GX_IN = 0, GX_HID = 1, GX_SKIP = 2, GX_HEAD = 3, GX_VIEWS = 4, GX_RGB = 5 };
 constexpr int GX_NS_E = 2;                      // encoding k-steps (3 + 6 L + 1 <= 64: L <= 10)
 constexpr int GX_MAX_L = 10;
 
@@ -33,11 +38,18 @@ constexpr NRN_HD int gx_enc_col(int L, int s, int g, int e) {       // reference
 }
 constexpr NRN_HD int gx_width_class(int W) { return ((W + 63) / 64) * 64; }
 
+constexpr int GX_MAX_LV = 4;                    // direction frequencies (3 + 6 LV + 1 <= 32)
+constexpr int gx_layer_ns(int wc, int kind) {
+    return (kind == GX_IN) ? GX_NS_E : (kind == GX_SKIP ? GX_NS_E + wc / 32 : (kind == GX_VIEWS ? 1 + wc / 32 : (kind == GX_RGB ? wc / 64 : wc / 32)));
+}
+constexpr int gx_layer_tiles(int wc, int kind) {
+    return (kind == GX_HEAD || kind == GX_RGB) ? 1 : (kind == GX_VIEWS ? wc / 32 + 1 : wc / 16);
+}
 // (a plain constexpr function of (width class, kind): the kernel instantiates it per template argument, the packer calls it at run time)
 constexpr Tables build_tables_gx(int wc, int kind) {
     Tables T{};
-    const int ns = (kind == GX_IN) ? GX_NS_E : (kind == GX_SKIP ? GX_NS_E + wc / 32 : wc / 32);
-    const int nt = (kind == GX_HEAD) ? 1 : wc / 16;
+    const int ns = gx_layer_ns(wc, kind);
+    const int nt = gx_layer_tiles(wc, kind);
     T.layers[0] = LayerSpec{kind, 0, ns, nt, 0, 0};
     T.nlayers = 1;
     T.ntiles = nt;
@@ -55,13 +67,10 @@ struct PlanGX {
 };
 // units of one layer of kind k at width class wc (host-side mirror for the packer)
 constexpr int gx_layer_units(int wc, int kind) {
-    const int ns = (kind == GX_IN) ? GX_NS_E : (kind == GX_SKIP ? GX_NS_E + wc / 32 : wc / 32);
-    const int nt = (kind == GX_HEAD) ? 1 : wc / 16;
-    const int units = cdiv(ns * nt, Shape16Fast::UNIT_FRAGS);
+    const int units = cdiv(gx_layer_ns(wc, kind) * gx_layer_tiles(wc, kind), Shape16Fast::UNIT_FRAGS);
     return cdiv(units, RING) * RING;
 }
-constexpr int gx_layer_tiles(int wc, int kind) { return (kind == GX_HEAD) ? 1 : wc / 16; }
 // run-time shape of one packed trunk (the kernel's GxArgs fields the packer decides)
-struct GxMeta { int wc = 0, depth = 0, skip = -1, L = 0, n_bias_tiles = 0; };
+struct GxMeta { int wc = 0, depth = 0, skip = -1, L = 0, n_bias_tiles = 0, views = 0, LV = 0; };
 
 }  // namespace nrn

@@ -24,6 +24,7 @@ struct GxArgs {
     const float* bias;          // [total tiles][16]
     int depth, skip, L;         // pts_linears count; index after which [input, h] is concatenated (-1: never); encoding frequencies
     int n_bias_tiles;
+    int LV;                     // (view-dependent head) direction-encoding frequencies
 };
-hipError_t launch_gx16(int precision, int wc, const GxArgs& a, int num_cus, hipStream_t stream);
+hipError_t launch_gx16(int precision, int wc, bool views, const GxArgs& a, int num_cus, hipStream_t stream);
 }  // namespace nrn

@@ -458,8 +458,9 @@ def test_x16_stream_reproduces_the_trunk(precision, cfg_kw):
 
 
 @pytest.mark.parametrize("cfg_kw", [dict(netwidth=192, netdepth=6, multires=8), dict(netwidth=320, netdepth=10), dict(netwidth=64, netdepth=3, skips=()),
-                                    dict(netwidth=256), dict(netwidth=500, netdepth=5, skips=(1,), multires=4)],
-                         ids=["w192_d6_l8", "w320_d10", "w64_d3_noskip", "w256_default", "w500_d5_skip1_l4"])
+                                    dict(netwidth=256), dict(netwidth=500, netdepth=5, skips=(1,), multires=4),
+                                    dict(netwidth=192, netdepth=6, use_viewdirs=True), dict(netwidth=96, netdepth=4, skips=(1,), use_viewdirs=True, multires_views=2)],
+                         ids=["w192_d6_l8", "w320_d10", "w64_d3_noskip", "w256_default", "w500_d5_skip1_l4", "w192_viewdirs", "w96_viewdirs_lv2"])
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
 def test_width_class_stream_reproduces_any_plain_trunk(precision, cfg_kw):
     """The image of the width-class trunk kernel (csrc/nrnerf_gx16.h; nrnerf_pack_host which = 12), emulated in numpy as the kernel
@@ -560,8 +561,42 @@ def test_width_class_stream_reproduces_any_plain_trunk(precision, cfg_kw):
             B, n16 = Benc + B, 2
         tiles = dense(len(B), NT, B, n16); mfma += len(B) * NT
     B = hand_off(tiles)
-    Dh = dense(len(B), 1, B, 0)[0]; mfma += len(B)
-    raw = Dh[0:5].T
+    views = cfg.use_viewdirs
+    if views:
+        # GX_VIEWS: k-steps [direction encoding (one; the points' position map with LV), trunk output] -> WC / 32 tiles of
+        # relu(views o feature) + the alpha tile (row 0); GX_RGB: WC / 64 k-steps -> one tile, rows 0..2
+        LV = cfg.multires_views
+        dvec = torch.randn(ns_, 3, generator=gen).double()
+        dvec = dvec / dvec.norm(dim=-1, keepdim=True)
+        dcols = [dvec]
+        for k in range(LV):
+            dcols += [torch.sin(dvec * 2.0 ** k), torch.cos(dvec * 2.0 ** k)]
+        xd = torch.cat(dcols, -1)
+
+        def dir_col(g, e):
+            q = 8 * g + e
+            if q < 3:
+                return q
+            if q == 3:
+                return -1
+            m, b = (q - 4) // 2, (q - 4) & 1
+            return 3 + 6 * (m // 3) + 3 * b + (m % 3) if m < 3 * LV else -1
+        bd = np.zeros((32, ns_))
+        for g in range(4):
+            for e in range(8):
+                c = dir_col(g, e)
+                if c >= 0:
+                    bd[8 * g + e] = xd.numpy()[:, c]
+        Bv = [rnd_e(bd)] + B
+        NTV = WC // 32
+        vt = dense(len(Bv), NTV + 1, Bv, 1); mfma += len(Bv) * (NTV + 1)
+        sigma = vt[NTV][0]
+        Bh = hand_off(vt[:NTV])
+        Dh = dense(len(Bh), 1, Bh, 0)[0]; mfma += len(Bh)
+        raw = np.concatenate([Dh[0:3].T, sigma[:, None]], 1)
+    else:
+        Dh = dense(len(B), 1, B, 0)[0]; mfma += len(B)
+        raw = Dh[0:5].T
     assert tile[0] == info.n_bias_tiles and mfma == info.mfma_per_block
     # behind the last layer: a copy of the stream's first two units, then nothing
     assert info.stream_bytes == (pos[0] // 16 + 2) * 16384
@@ -572,7 +607,13 @@ def test_width_class_stream_reproduces_any_plain_trunk(precision, cfg_kw):
             h = F.relu(F.linear(h, l.weight.double(), l.bias.double()))
             if i == skip:
                 h = torch.cat([x, h], -1)
-        ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
+        if views:
+            alpha = F.linear(h, fine.alpha_linear.weight.double(), fine.alpha_linear.bias.double())
+            feat = F.linear(h, fine.feature_linear.weight.double(), fine.feature_linear.bias.double())
+            hvr = F.relu(F.linear(torch.cat([feat, xd], -1), fine.views_linears[0].weight.double(), fine.views_linears[0].bias.double()))
+            ref = torch.cat([F.linear(hvr, fine.rgb_linear.weight.double(), fine.rgb_linear.bias.double()), alpha], -1).numpy()
+        else:
+            ref = F.linear(h, fine.output_linear.weight.double(), fine.output_linear.bias.double()).numpy()
     tol = 8e-2 if precision == "bf16" else 1e-2
     err = np.abs(raw - ref).max()
     assert err <= tol * np.abs(ref).max(), f"width-class trunk + head mismatch {err} vs scale {np.abs(ref).max()}"
