@@ -831,6 +831,29 @@ def test_generic_kernel_agrees_with_the_compiled_kernels_on_their_own_architectu
                 assert float((generic[k] - compiled[k]).pow(2).mean().sqrt()) < 2e-3, k
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("cfg_kw", [dict(N_importance=64, netdepth=6, netwidth=192, netwidth_fine=320, multires=8),
+                                    dict(N_importance=64, netdepth=5, netwidth=96, skips=(1,), use_viewdirs=True, multires_views=3),
+                                    dict(N_importance=128, netwidth=448, netdepth=3, skips=())],
+                         ids=["w192_w320_l8", "w96_viewdirs_lv3_skip1", "w448_d3_noskip"])
+def test_width_class_kernel_is_an_equally_good_rounding_of_the_generic_kernel(cfg_kw, precision):
+    """Non-compiled architectures in the 16-bit modes: a plain render runs its trunks on the width-class 16x16x32 kernel
+    (csrc/nrnerf_gx16.h) by default and on the run-time-parameterised kernel of nrnerf_generic.h with NRNERF_X16=0.  Two 16-bit
+    evaluations of one network, against the exact-fp32 render of the same call: coarse and final maps' errors alike (mean within
+    30 %, maximum within 3 x), no more moved depths, sorted merged depths; ragged ray count."""
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 4)
+    rays, latents = make_rays(1777, 23, cfg)
+    ref32 = hip_render(scene, rays, latents, "f32", retraw=True)
+    with _setenv("NRNERF_X16", "0"):
+        gen = hip_render(scene, rays, latents, precision, retraw=True)
+    gx = hip_render(scene, rays, latents, precision, retraw=True)
+    assert set(gx) == set(gen) and gx["raw"].shape == gen["raw"].shape
+    assert (gx["_z_vals"][:, 1:] >= gx["_z_vals"][:, :-1]).all() and torch.isfinite(gx["raw"]).all()
+    assert not torch.equal(gx["rgb0"], gen["rgb0"]), "both renders took the same kernel"
+    _assert_x16_coarse_is_an_equally_good_rounding(gx, gen, ref32)
+
+
 @pytest.mark.parametrize("n", [1, 7, 33, 257])
 def test_tiny_and_ragged_ray_counts_vs_oracle(n):
     """Batches smaller than one workgroup tile (8 blocks) and not a multiple of anything, with detailed outputs."""
