@@ -261,7 +261,8 @@ def _param_slots(m):
 # tools/experiments/debug_refresh_path.py), so (data_ptr, _version) alone would keep serving the weights packed BEFORE the step.
 # A global post-step hook on all optimisers counts steps; the count is part of the fingerprint of every model that has a
 # trainable parameter (frozen networks, whatever optimiser steps elsewhere, keep their handle untouched).
-_OPT_STEPS = [0]
+# (round 5, ADVICE r4: counted PER PARAMETER -- the hook bumps a counter on every parameter of the optimiser that stepped -- so a step of an
+#  unrelated optimiser (one that only steps latent codes, or another model's) no longer forces a re-pack of every cached trainable model)
 _OPT_HOOK = []
 
 
@@ -269,21 +270,21 @@ def _watch_optimizers():
     if not _OPT_HOOK:
         from torch.optim.optimizer import register_optimizer_step_post_hook
 
-        def _count(_optimizer, _args, _kwargs):
-            _OPT_STEPS[0] += 1
+        def _count(optimizer, _args, _kwargs):
+            for group in optimizer.param_groups:
+                for p in group["params"]:
+                    p._nrnerf_steps = getattr(p, "_nrnerf_steps", 0) + 1
         _OPT_HOOK.append(register_optimizer_step_post_hook(_count))
 
 
 def _fingerprint(mods):
-    fp, trainable = [], False
+    fp = []
     for m in mods:
         if m is None:
             fp.append(None)
             continue
         ps = [p for p in (d[n] for d, n in _param_slots(m)) if p is not None]
-        trainable = trainable or any(p.requires_grad for p in ps)
-        fp.append(tuple((p.data_ptr(), p._version) for p in ps))
-    fp.append(_OPT_STEPS[0] if trainable else None)
+        fp.append(tuple((p.data_ptr(), p._version, getattr(p, "_nrnerf_steps", 0)) for p in ps))
     return tuple(fp)
 
 
@@ -347,11 +348,15 @@ class Model:
             cur = torch.cuda.current_stream(self.device)
             with self._ws_lock:
                 pending, self._render_events = self._render_events, {}
+            # (while the current stream is being captured -- GraphedStep's captured refresh -- there is nothing to wait for and nothing
+            #  that may be waited for: events recorded outside a capture cannot be joined from inside it; the capture is preceded by a
+            #  device synchronisation, GraphedStep.__init__)
+            capturing = torch.cuda.is_current_stream_capturing()
             for sid, ev in pending.items():
-                if sid != cur.cuda_stream:
+                if sid != cur.cuda_stream and not capturing:
                     cur.wait_event(ev)
             ts = getattr(self, "_train_stream", None)       # last stream a training kernel read these weights on (training._mstream)
-            if ts is not None and ts.cuda_stream != cur.cuda_stream:
+            if ts is not None and ts.cuda_stream != cur.cuda_stream and not capturing:
                 cur.wait_stream(ts)
             flat, self._flat_state = _flat_params(network_fn, network_fine, getattr(self, "_flat_state", None))
             if flat is None or flat.device != self.device or int(self.lib.nrnerf_model_flat_size(self.handle)) != flat.numel():
@@ -583,16 +588,34 @@ def model_of_bender(ray_bender, device):
     return model if model.trains_bender else None
 
 
-def mark_stale(network_fn):
+def mark_stale(network_fn, replay_stream=None):
     """The packed weights of ``network_fn``'s handles no longer match the parameters although the version counters say
     they do -- an optimiser step replayed from a HIP graph updates the parameters without touching the counters.  The
-    next ``get_model`` re-packs them IN PLACE (device-side refresh), unlike ``invalidate``, which drops the handles."""
+    next ``get_model`` re-packs them IN PLACE (device-side refresh), unlike ``invalidate``, which drops the handles.
+    ``replay_stream``: the stream the graph was just replayed on -- the training kernels inside it read the packed weights there,
+    so a refresh issued from another stream has to order itself after it (``Model.update_from_device`` waits on ``_train_stream``;
+    the stream the model remembers from the capture is the capture's, long gone)."""
     with _cache_lock:
         per = _cache.get(network_fn)
         if per:
             for k, (fp, m) in list(per.items()):
                 if isinstance(m, Model):
                     per[k] = (None, m)
+                    if replay_stream is not None:
+                        m._train_stream = replay_stream
+
+
+def forget_streams(network_fn):
+    """After a device synchronisation: drop the recorded render events and the remembered training stream of ``network_fn``'s handles
+    (all that work is complete) -- GraphedStep calls it right before a capture."""
+    with _cache_lock:
+        per = _cache.get(network_fn)
+        if per:
+            for _, m in per.values():
+                if isinstance(m, Model):
+                    with m._ws_lock:
+                        m._render_events = {}
+                    m._train_stream = None
 
 
 def invalidate(network_fn=None):

@@ -1288,6 +1288,8 @@ class GraphedStep:
                 one()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        for nf in networks:                                        # the warm-up's render events / training stream are complete: nothing
+            R.forget_streams(nf)                                   # recorded outside the capture may be waited for inside it
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)                      # .grad tensors are allocated from the graph's pool
         with torch.enable_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -1311,7 +1313,8 @@ class GraphedStep:
     def sync(self):
         """Mark the networks' packed weights stale (done after every replay; kept as a public no-cost call)."""
         for nf in self.networks:
-            R.mark_stale(nf)
+            dev = next(nf.parameters()).device
+            R.mark_stale(nf, torch.cuda.current_stream(dev) if dev.type == "cuda" else None)
 
 
 # configs/example_sequence.txt:14-16, 26-28, 35 -- the recipe the reference ships

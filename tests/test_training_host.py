@@ -276,19 +276,28 @@ def test_param_slot_walk_notices_a_renamed_parameter():
     R._fingerprint([m])
 
 
-def test_fingerprint_counts_optimiser_steps_for_trainable_networks_only():
+def test_fingerprint_counts_the_steps_of_the_optimisers_that_own_a_networks_parameters():
     """Fused optimisers (torch.optim.Adam(fused=True)) update their parameters without bumping Tensor._version (measured on
     the GPU: tools/experiments/debug_refresh_path.py), so the staleness check of render.get_model also counts optimiser steps
-    -- for networks with a trainable parameter; a frozen network's fingerprint does not move when some optimiser steps."""
+    -- PER PARAMETER (round 5): a step of an optimiser that owns none of a network's parameters (one that steps only
+    latent codes, another model's) leaves that network's fingerprint, hence its packed handle, alone."""
     from nonrigid_nerf_amd import render as R
     R._watch_optimizers()
-    trainable, frozen, other = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3).requires_grad_(False), torch.nn.Linear(2, 2)
-    opt = torch.optim.SGD(other.parameters(), lr=0.1)
-    fp_t, fp_f = R._fingerprint([trainable, None]), R._fingerprint([frozen])
-    assert R._fingerprint([trainable, None]) == fp_t
+    mine, frozen, other = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3).requires_grad_(False), torch.nn.Linear(2, 2)
+    opt_other = torch.optim.SGD(other.parameters(), lr=0.1)
+    opt_mine = torch.optim.SGD(mine.parameters(), lr=0.0)          # (lr 0: the values -- and a fused optimiser's version counters -- do not move)
+    fp_m, fp_f, fp_o = R._fingerprint([mine, None]), R._fingerprint([frozen]), R._fingerprint([other])
+    assert R._fingerprint([mine, None]) == fp_m
     other.weight.grad, other.bias.grad = torch.ones(2, 2), torch.ones(2)
-    opt.step()                                               # ANY optimiser: which parameters it owns is not looked at
-    assert R._fingerprint([trainable, None]) != fp_t and R._fingerprint([frozen]) == fp_f
+    opt_other.step()                                         # somebody else's optimiser
+    assert R._fingerprint([mine, None]) == fp_m and R._fingerprint([frozen]) == fp_f and R._fingerprint([other]) != fp_o
+    mine.weight.grad, mine.bias.grad = torch.zeros(3, 4), torch.zeros(3)
+    v = (mine.weight._version, mine.bias._version)
+    opt_mine.step()
+    if (mine.weight._version, mine.bias._version) == v:      # (an optimiser that leaves the version counters alone, like the fused ones)
+        assert R._fingerprint([mine, None]) != fp_m
+    assert getattr(mine.weight, "_nrnerf_steps", 0) == 1 and getattr(frozen.weight, "_nrnerf_steps", 0) == 0
+    assert R._fingerprint([mine, None]) != fp_m
     # the version counters keep working on their own
     fp_f = R._fingerprint([frozen])
     with torch.no_grad():
