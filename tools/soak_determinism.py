@@ -25,6 +25,11 @@ CASES = {
     "odd blocks 64+96":      dict(N_importance=96),
     "generic 192/320":       dict(netdepth=6, netwidth=192, netwidth_fine=320, multires=8, latent_size=16, N_importance=64),
     "generic viewdirs 96":   dict(netwidth=96, use_viewdirs=True, multires_views=2, N_importance=64),
+    # round 5: the 16-bit rows above run on the 16x16x32 kernels (both passes; stand-alone bender on 16x16x32 in bf16 mode), the generic
+    # rows on the width-class kernel (run-time layer loop on a run-time-pointer ring); two more width classes, one of them above 256
+    # (two blocks per wave), one without skip connection and with the reference's bender (the compiled bender kernels)
+    "generic 448 d3 noskip": dict(netwidth=448, netdepth=3, skips=(), N_importance=64),
+    "generic 320 d10":       dict(netwidth=320, netdepth=10, N_importance=32),
 }
 bad = 0
 for name, kw in CASES.items():
