@@ -143,6 +143,22 @@ def check(build_dir: str) -> list[str]:
                     errors.append(f"{name}: {r['lgkm_drain_in_section']} draining LDS waits inside the MFMA sections of {r['kernels']} kernels")
                 if r["mb"] and 3 * r["accvgpr"] > r["mfma"]:
                     errors.append(f"{name}: {r['accvgpr']} AccVGPR copies for {r['mfma']} MFMAs (accumulators not in VGPRs?)")
+        # round 5: the width-class trunk kernel (nrnerf_gx16.h) and the 16x16x32 bender (nrnerf_bend_x16.h) -- same counted LDS queue
+        # (dense_x16), so: no scratch (a reload drains the LDS-DMA queue of the ring), no scalar load between the first and last MFMA
+        for obj in sorted(glob.glob(os.path.join(build_dir, "nrnerf_gx16_w*.o")) + glob.glob(os.path.join(build_dir, "nrnerf_bend_x16.o"))):
+            co = device_code_object(obj, tmp)
+            name = os.path.basename(obj)[:-2].replace("nrnerf_", "")
+            if co is None:
+                errors.append(f"{name}: no gfx950 code object")
+                continue
+            r = analyse(co)
+            print(f"{name:24s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} scratch {r['scratch']:3d} "
+                  f"mfma {r['mfma']:5d} valu {r['valu']:5d} lgkm counted/drain {r['lgkm_counted']:4d}/{r['lgkm_drain']:3d} "
+                  f"smem in-section/in-loop {r['smem_in_mfma_section']}/{r['smem_after_first_mfma']}")
+            if r["scratch"] or r.get("private_segment_fixed_size", 0):
+                errors.append(f"{name}: scratch traffic ({r['scratch']} instructions, {r.get('private_segment_fixed_size', 0)} B per lane)")
+            if r["smem_in_mfma_section"] and name.startswith("gx16"):
+                errors.append(f"{name}: {r['smem_in_mfma_section']} scalar memory load(s) between the first and the last MFMA")
     return errors
 
 
