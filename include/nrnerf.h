@@ -548,6 +548,32 @@ typedef struct nrnerf_wgrad_args {
 #define NRNERF_WGRAD_STRIDE(depth, width) (((depth) - 1) * (width) * (width) + 3 * (width) * 64 + ((depth) + 1) * (width))
 int nrnerf_trunk_wgrad(const nrnerf_model* model, const nrnerf_wgrad_args* args, void* hip_stream);
 
+/* Training of an architecture OUTSIDE the compiled set (round 5; plain output_linear head, fp32 or bf16 handles, width % 4 == 0): the
+ * canonical network on ready-made points with every hidden activation saved, and its backward-data pass -- the run-time-parameterised
+ * kernel's layer programs (forward: NeRF.forward, rnh:240-314; backward: the same layers in reverse with transposed weights).  The weight
+ * gradients are products of the two saved arrays, dW_i = d_pre_i^T x_i (x_0 = the encoding, x_{skip+1} = [encoding, activation], else
+ * the previous activation; db_i = column sums of d_pre_i) and the gradient wrt the points follows from the encoding's: both are left to
+ * the caller (nonrigid_nerf_amd/training.py forms them with library GEMMs -- the one place on the training path where it does).
+ *   acts / d_pre: [depth][n_rays * n_samples][width] in the handle's element type (fp32 for NRNERF_PREC_F32, bf16 for NRNERF_PREC_BF16);
+ *   d_enc0 / d_enc1: [n_rays * n_samples][3 + 6 multires] fp32, the gradient of the encoding through pts_linears[0] and through the layer
+ *   behind the skip connection (d_enc1 may be NULL for a network without one).  nrnerf_model_trains_generic: 1 when the handle has these. */
+typedef struct nrnerf_generic_trunk_args {
+    uint32_t struct_size;       /* sizeof(nrnerf_generic_trunk_args) */
+    int32_t which;              /* 0 = network_fn (coarse), 1 = network_fine */
+    int32_t n_rays, n_samples;
+    const float* pts4;          /* forward in: [N,S,4] points (xyz + one ignored float) */
+    void* acts;                 /* forward out / backward in */
+    float* raw4;                /* forward out: [N,S,4] rgb, sigma */
+    float* raw; int32_t raw_ch; /* forward out (may be NULL): [N,S,raw_ch] the reference's "raw" */
+    const float* d_raw4;        /* backward in: [N,S,4] */
+    void* d_pre;                /* backward out */
+    float* d_enc0;              /* backward out */
+    float* d_enc1;              /* backward out (skip connection) */
+} nrnerf_generic_trunk_args;
+int nrnerf_generic_trunk_forward(const nrnerf_model* model, const nrnerf_generic_trunk_args* args, void* hip_stream);
+int nrnerf_generic_trunk_backward(const nrnerf_model* model, const nrnerf_generic_trunk_args* args, void* hip_stream);
+int nrnerf_model_trains_generic(const nrnerf_model* model);
+
 /* The loss of one training iteration over the outputs of render_rays (reference training_wrapper_class.forward, train.py:207-287), per ray:
  *   loss[r] = mean((rgb_map - target)^2) + [rgb0] mean((rgb0 - target)^2)                                    train.py:207-218, rnh:10-13
  *           + offsets_weight * ( mean_s( w |off|^(2 - rig) ) + rigidity_weight * mean_s( w rig ) )          train.py:221-242

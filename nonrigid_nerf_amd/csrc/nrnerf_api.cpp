@@ -669,7 +669,11 @@ struct GenSource { int buf, col0, n; };
 
 // one layer into the program and the packed images.  16-bit precisions: fragments read against E / V are f16, against H the
 // model's type (nrnerf_generic.h).
-void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSource a, GenSource b, int dst, int relu, int o_col, const FlatLayout* lay) {
+// (t_wbase >= 0: `lin` is a TRANSPOSED copy of rows [t_row0, t_row0 + lin.in_features ... ) -- element (row r, column k) of `lin` is the
+//  original layer's W[k][t_col0 + r], whose flat-vector position is t_wbase + k * t_orig_in + t_col0 + r: the device-side refresh
+//  (nrnerf_model_update_device) then fills the backward-data images of a non-compiled architecture like every other image)
+void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSource a, GenSource b, int dst, int relu, int o_col, const FlatLayout* lay,
+                   int64_t t_wbase = -1, int t_orig_in = 0, int t_col0 = 0) {
     if (g.proto.n_layers >= GEN_MAX_LAYERS) throw std::logic_error("generic program too long");
     const bool f32 = precision == NRNERF_PREC_F32;
     // a fragment = 64 lanes x 16 bytes in every precision: 8 16-bit k per lane (one MFMA), or 4 fp32 k per lane (four 32x32x2 MFMAs:
@@ -682,11 +686,13 @@ void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSo
     ly.src0 = a.buf; ly.ns0 = (a.n + KS - 1) / KS;
     ly.src1 = b.buf; ly.ns1 = (b.n + KS - 1) / KS;
     ly.dst = dst; ly.relu = relu; ly.o_col = o_col; ly.o_rows = lin.out_features;
+    ly.save_idx = -1; ly.mask_idx = -1;
     if (ly.nt > GEN_WAVES * GEN_MAXT || a.col0 + a.n > lin.in_features || b.col0 + b.n > lin.in_features) throw std::logic_error("generic layer out of range");
     const int ns = ly.ns0 + ly.ns1;
     const size_t f0 = g.pk.stream.size();
     g.pk.stream.resize(f0 + (size_t)ly.nt * ns * FB, 0);
-    const int64_t wbase = lay ? lay->of(lin.weight) : -1, bbase = (lay && lin.bias) ? lay->of(lin.bias) : -1;
+    const bool transposed = t_wbase >= 0;
+    const int64_t wbase = transposed ? t_wbase : (lay ? lay->of(lin.weight) : -1), bbase = (lay && lin.bias && !transposed) ? lay->of(lin.bias) : -1;
     if (lay) { g.pk.src.resize(g.pk.stream.size() / EB, -1); g.pk.fmt.resize(g.pk.stream.size() / EB, 0); }
     for (int t = 0; t < ly.nt; ++t)
         for (int sl = 0; sl < ns; ++sl) {
@@ -702,7 +708,8 @@ void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSo
                     const float w = live ? lin.weight[(size_t)row * lin.in_features + src.col0 + k] : 0.0f;
                     const size_t el = (f0 + ((size_t)t * ns + sl) * FB) / EB + (size_t)lane * KH + e;
                     if (lay) {
-                        g.pk.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)row * lin.in_features + src.col0 + k) : -1;
+                        if (transposed) g.pk.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)(src.col0 + k) * t_orig_in + t_col0 + row) : -1;
+                        else g.pk.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)row * lin.in_features + src.col0 + k) : -1;
                         g.pk.fmt[el] = f32 ? 0 : (as_f16 ? 2 : 1);
                     }
                     if (f32) std::memcpy(fr + (lane * KH + e) * 4, &w, 4);
@@ -804,6 +811,50 @@ void gen_pack_mlp(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenProgr
         gen_add_layer(g, d.precision, m.output_linear, GenSource{GB_H, 0, W}, none, GB_O, 0, 0, lay);
     }
     g.proto.kh = (widest + 31) / 32 * 32;
+    for (int i = 0; i < m.depth; ++i) g.proto.layer[i].save_idx = i;        // (training: layer i's activations, only with GenArgs::save set)
+    gen_finish(g, d.precision);
+}
+// Backward-data of a plain-headed NeRF (training of a non-compiled architecture): the forward's layers in reverse order with TRANSPOSED
+// weights, no biases, run by the same kernel (GenArgs::mode 2).  H starts as the rows of d raw; output_linear^T gives d h_{D-1}, masked
+// by the forward activation of layer D - 1 = d pre_{D-1} (saved as index D - 1); pts_linears[i]^T takes d pre_i to d pre_{i-1} (mask:
+// activation i - 1); the layer behind the skip connection has [input | hidden] columns: its input part goes straight to memory
+// (GB_OUT1: the encoding's gradient), its hidden part goes on; pts_linears[0]^T ends in the encoding's gradient (GB_OUT0).
+bool gen_trainable(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
+    return d.precision != NRNERF_PREC_F16 && !m.use_viewdirs && !m.time_conditioned && m.width % 4 == 0 && m.depth >= 1 && m.output_ch >= 4 &&
+           m.output_ch <= 5 && 2 * m.depth + 2 <= GEN_MAX_LAYERS;
+}
+void gen_pack_mlp_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenProgram& g, const FlatLayout* lay) {
+    const int enc = 3 + 6 * d.multires, W = m.width, D = m.depth, skip = gen_skip(m);
+    g.proto.mode = 2; g.proto.L = d.multires; g.proto.LV = -1; g.proto.lat = 0;
+    g.proto.ke = 16; g.proto.kv = 16;
+    const GenSource none{GB_H, 0, 0};
+    std::vector<std::vector<float>> keep;           // transposed copies (alive until the fragments are written: gen_add_layer copies)
+    auto transposed = [&](const nrnerf_linear& lin, int col0, int ncols) {       // rows = the layer's input columns [col0, col0 + ncols), columns = its outputs
+        keep.emplace_back((size_t)ncols * lin.out_features);
+        std::vector<float>& t = keep.back();
+        for (int r = 0; r < ncols; ++r)
+            for (int k = 0; k < lin.out_features; ++k) t[(size_t)r * lin.out_features + k] = lin.weight[(size_t)k * lin.in_features + col0 + r];
+        nrnerf_linear lt{};
+        lt.weight = t.data(); lt.bias = nullptr; lt.out_features = ncols; lt.in_features = lin.out_features;
+        return lt;
+    };
+    auto add = [&](const nrnerf_linear& lin, int col0, int ncols, int k_in, int dst, int mask_idx, int save_idx) {
+        const nrnerf_linear lt = transposed(lin, col0, ncols);
+        gen_add_layer(g, d.precision, lt, GenSource{GB_H, 0, k_in}, none, dst, 0, 0, lay, lay ? lay->of(lin.weight) : -1, lin.in_features, col0);
+        GenLayer& ly = g.proto.layer[g.proto.n_layers - 1];
+        ly.mask_idx = mask_idx; ly.save_idx = save_idx;
+    };
+    add(m.output_linear, 0, W, 4, GB_H, D - 1, D - 1);                                 // d raw (rgb, sigma; a 5th channel never reaches a loss) -> d pre_{D-1}
+    for (int i = D - 1; i >= 1; --i) {
+        if (skip >= 0 && i - 1 == skip) {
+            add(m.pts_linears[i], 0, enc, W, GB_OUT1, -1, -1);                         // input part: gradient of the encoding, to memory
+            add(m.pts_linears[i], enc, W, W, GB_H, i - 1, i - 1);                      // hidden part: d pre_{i-1}
+        } else {
+            add(m.pts_linears[i], 0, W, W, GB_H, i - 1, i - 1);
+        }
+    }
+    add(m.pts_linears[0], 0, enc, W, GB_OUT0, -1, -1);
+    g.proto.kh = (imax(W, 16) + 31) / 32 * 32;
     gen_finish(g, d.precision);
 }
 // ray_bending.forward (rnh:507-577): always packed (and run) in fp32
@@ -907,6 +958,12 @@ struct nrnerf_model {
     // the trunks of a generic model packed for the width-class 16x16x32 kernel (nrnerf_gx16.h): 16-bit modes, no view-dependent head
     PassDev gx_coarse, gx_fine;
     GxMeta gx_meta_coarse, gx_meta_fine;
+    // training of a generic model with a plain head (fp32 / bf16): the backward-data programs (transposed weights); the forward is
+    // gen_coarse / gen_fine run with GenArgs::save set
+    bool gen_train_ok = false;
+    GenArgs gen_coarse_bwd_prog{}, gen_fine_bwd_prog{};
+    PassDev gen_coarse_bwd, gen_fine_bwd;
+    int gen_enc_w = 0, gen_w_coarse = 0, gen_w_fine = 0, gen_d_coarse = 0, gen_d_fine = 0;
     bool gen_fine_is_coarse = false;
     int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
@@ -1272,6 +1329,25 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
     }
     m->fine.output_ch = m->gen_fine.output_ch;
     m->fine_is_coarse = !d.fine;
+    if (gen_trainable(d, *d.coarse) && (!d.fine || gen_trainable(d, *d.fine))) {
+        GenProgram bc, bf;
+        gen_pack_mlp_bwd(d, *d.coarse, bc, &lay);
+        rc = upload_pass(bc.pk, m->gen_coarse_bwd);
+        if (rc != NRNERF_OK) return rc;
+        m->gen_coarse_bwd_prog = bc.proto;
+        m->gen_w_coarse = d.coarse->width; m->gen_d_coarse = d.coarse->depth;
+        if (d.fine) {
+            gen_pack_mlp_bwd(d, *d.fine, bf, &lay);
+            rc = upload_pass(bf.pk, m->gen_fine_bwd);
+            if (rc != NRNERF_OK) return rc;
+            m->gen_fine_bwd_prog = bf.proto;
+            m->gen_w_fine = d.fine->width; m->gen_d_fine = d.fine->depth;
+        } else {
+            m->gen_w_fine = m->gen_w_coarse; m->gen_d_fine = m->gen_d_coarse;
+        }
+        m->gen_enc_w = 3 + 6 * d.multires;
+        m->gen_train_ok = true;
+    }
     // with a bender (the passes then run on ready-made points) and a plain head: the trunks also for the width-class x16 kernel
     if (d.bender && gx16_eligible(d, *d.coarse) && (!d.fine || gx16_eligible(d, *d.fine))) {
         PackedPass pgc, pgf;
@@ -1323,6 +1399,15 @@ int update_generic(nrnerf_model* m, const nrnerf_model_desc& d, hipStream_t stre
     if (d.bender) rc = refresh_pass(gb.pk, m->gen_bend, stream);         // (sizes differ for another architecture: NRNERF_ERR_INVALID)
     if (rc == NRNERF_OK) rc = refresh_pass(gc.pk, m->gen_coarse, stream);
     if (rc == NRNERF_OK && d.fine) rc = refresh_pass(gf.pk, m->gen_fine, stream);
+    GenProgram bwc, bwf;
+    if (rc == NRNERF_OK && m->gen_train_ok) {
+        gen_pack_mlp_bwd(d, *d.coarse, bwc, nullptr);
+        rc = refresh_pass(bwc.pk, m->gen_coarse_bwd, stream);
+        if (rc == NRNERF_OK && d.fine) {
+            gen_pack_mlp_bwd(d, *d.fine, bwf, nullptr);
+            rc = refresh_pass(bwf.pk, m->gen_fine_bwd, stream);
+        }
+    }
     PackedPass pgc, pgf;
     if (rc == NRNERF_OK && m->gx_coarse.stream) {
         GxMeta mc, mf;
@@ -1602,7 +1687,7 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
     hipStream_t stream = (hipStream_t)hip_stream;
     PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16, &m->coarse_trunk_x16, &m->bend_x16,
                          &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
-                         &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine, &m->gx_coarse, &m->gx_fine};
+                         &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine, &m->gx_coarse, &m->gx_fine, &m->gen_coarse_bwd, &m->gen_fine_bwd};
     for (PassDev* p : passes)
         if (p && p->stream && !p->src) return NRNERF_ERR_UNSUPPORTED;          // (before anything is launched)
     // every image (weight stream + bias table) as one segment of ONE launch
@@ -1641,6 +1726,8 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->bend_x16);
     free_pass(m->gx_coarse);
     free_pass(m->gx_fine);
+    free_pass(m->gen_coarse_bwd);
+    free_pass(m->gen_fine_bwd);
     free_pass(m->coarse_trunk);
     free_pass(m->bend_only);
     free_pass(m->coarse_bwd);
@@ -2063,6 +2150,39 @@ int device_of(const void* ptr, int& dev) {
 }  // namespace
 
 namespace {
+int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a, bool backward, void* hip_stream) {
+    if (!m || !a || a->struct_size != sizeof(nrnerf_generic_trunk_args)) return NRNERF_ERR_INVALID;
+    if (!m->generic || !m->gen_train_ok) return NRNERF_ERR_UNSUPPORTED;
+    if (a->which < 0 || a->which > 1 || a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NRNERF_MAX_SAMPLES || !a->acts) return NRNERF_ERR_INVALID;
+    if (!backward && (!a->pts4 || !a->raw4)) return NRNERF_ERR_INVALID;
+    if (backward && (!a->d_raw4 || !a->d_pre || !a->d_enc0)) return NRNERF_ERR_INVALID;
+    if (a->n_rays == 0) return NRNERF_OK;
+    const bool fine = a->which == 1 && !m->gen_fine_is_coarse;
+    const int W = fine ? m->gen_w_fine : m->gen_w_coarse;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    const long long M = (long long)a->n_rays * a->n_samples;
+    GenArgs g = backward ? (fine ? m->gen_fine_bwd_prog : m->gen_coarse_bwd_prog) : (fine ? m->gen_fine_prog : m->gen_coarse_prog);
+    const PassDev& pd = backward ? (fine ? m->gen_fine_bwd : m->gen_coarse_bwd) : (fine ? m->gen_fine : m->gen_coarse);
+    g.wstream = pd.stream; g.bias = pd.bias;
+    g.n_rays = a->n_rays; g.S = a->n_samples;
+    g.save_stride = M * W; g.save_w = W;
+    if (!backward) {
+        g.mode = 1;
+        g.rays = a->pts4; g.ray_stride = 0; g.latents = nullptr; g.lat_stride = 0;      // (points are handed in: the ray record is never read)
+        g.z = nullptr; g.lindisp = 0; g.pts4 = a->pts4; g.dirs_from_pts = 0;
+        g.raw4 = a->raw4; g.raw_out = a->raw; g.raw_ch = a->raw ? a->raw_ch : 4; g.bent4 = nullptr;
+        g.save = a->acts; g.mask = nullptr;
+    } else {
+        if (fine ? (m->gen_fine_bwd_prog.n_layers > m->gen_d_fine + 1 && !a->d_enc1) : (m->gen_coarse_bwd_prog.n_layers > m->gen_d_coarse + 1 && !a->d_enc1)) return NRNERF_ERR_INVALID;
+        g.mode = 2;
+        g.rays = a->d_raw4; g.ray_stride = 0;
+        g.draw = a->d_raw4; g.draw_ch = 4;
+        g.mask = a->acts; g.save = a->d_pre;
+        g.gout[0] = a->d_enc0; g.gout[1] = a->d_enc1; g.gout_w = m->gen_enc_w;
+    }
+    return launch_generic(m->precision, g, m->num_cus, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
 int loss_call(const nrnerf_loss_args* a, bool backward, void* hip_stream) {
     if (!a || a->struct_size != sizeof(nrnerf_loss_args) || a->n_rays < 0 || a->n_samples < 0 || !a->rgb_map || !a->target) return NRNERF_ERR_INVALID;
     if (a->weights && (!a->offsets || !a->rigidity)) return NRNERF_ERR_INVALID;
@@ -2082,6 +2202,9 @@ int loss_call(const nrnerf_loss_args* a, bool backward, void* hip_stream) {
     return launch_loss(l, backward, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 }  // namespace
+int nrnerf_generic_trunk_forward(const nrnerf_model* m, const nrnerf_generic_trunk_args* a, void* hip_stream) try { return generic_trunk_call(m, a, false, hip_stream); } NRN_CATCH
+int nrnerf_generic_trunk_backward(const nrnerf_model* m, const nrnerf_generic_trunk_args* a, void* hip_stream) try { return generic_trunk_call(m, a, true, hip_stream); } NRN_CATCH
+int nrnerf_model_trains_generic(const nrnerf_model* m) { return m ? ((m->generic && m->gen_train_ok) ? 1 : 0) : NRNERF_ERR_INVALID; }
 int nrnerf_loss_forward(const nrnerf_loss_args* a, void* hip_stream) try { return loss_call(a, false, hip_stream); } NRN_CATCH
 int nrnerf_loss_backward(const nrnerf_loss_args* a, void* hip_stream) try { return loss_call(a, true, hip_stream); } NRN_CATCH
 

@@ -108,8 +108,16 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
 
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const long long m0 = tile * NS;
+        if (a.mode == 2) {
+            // ---- backward-data (training): H = the rows of d raw (columns >= draw_ch zero) in the model's type; no points, no E / V
+            for (int idx = tid; idx < NS * 16; idx += GEN_WAVES * 64) {
+                const int n = idx >> 4, c = idx & 15;
+                const float v = (c < a.draw_ch && m0 + n < M) ? a.draw[(size_t)(m0 + n) * a.draw_ch + c] : 0.0f;
+                H[(size_t)n * sh + c] = gen_cvt<P>(v);
+            }
+        }
         // ---- points (and view directions) of the tile's samples
-        if (tid < NS) {
+        if (a.mode != 2 && tid < NS) {
             const long long m = (m0 + tid < M) ? m0 + tid : M - 1;
             const int ray = (int)(m / S), si = (int)(m % S);
             const float* rp = a.rays + (size_t)ray * a.ray_stride;
@@ -150,7 +158,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
         // ---- E and V rows.  network: E = Embedder(point) [, latent], V = Embedder(direction) (rnh:120-150: [x, sin(2^0 x),
         //      cos(2^0 x), sin(2^1 x), ...]); bender: E = [point, latent] (rnh:525), V = [point] (rnh:546)
         const int enc_w = (a.mode == 1) ? 3 + 6 * a.L : 3;
-        for (int idx = tid; idx < NS * a.ke; idx += GEN_WAVES * 64) {
+        for (int idx = tid; a.mode != 2 && idx < NS * a.ke; idx += GEN_WAVES * 64) {
             const int n = idx / a.ke, c = idx - n * a.ke;
             const float* pt = Pt + n * 8;
             float v = 0.f;
@@ -165,7 +173,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             }
             E[(size_t)n * se + c] = gen_cvt<PE>(v);
         }
-        for (int idx = tid; idx < NS * a.kv; idx += GEN_WAVES * 64) {
+        for (int idx = tid; a.mode != 2 && idx < NS * a.kv; idx += GEN_WAVES * 64) {
             const int n = idx / a.kv, c = idx - n * a.kv;
             const float* pt = Pt + n * 8 + (a.mode == 1 ? 4 : 0);
             float v = 0.f;
@@ -259,12 +267,31 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
 #pragma unroll
                     for (int sb = 0; sb < NSB; ++sb) {
                         const int n = sb * 32 + j;
-                        if (ly.dst == GB_H) {
+                        if (ly.dst == GB_OUT0 || ly.dst == GB_OUT1) {          // training, backward-data: the encoding's gradient, straight to memory
+                            float* go = a.gout[ly.dst - GB_OUT0];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                if (row < ly.o_rows && m0 + n < M) go[(size_t)(m0 + n) * a.gout_w + row] = acc[i][sb][r];
+                            }
+                        } else if (ly.dst == GB_H) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {          // registers 4q .. 4q + 3 = rows 32 t + 8 q + 4 h + (0..3) (nrnerf_plan.h::tile_row)
                                 float v[4];
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) v[c] = ly.relu ? fmaxf(acc[i][sb][4 * q + c], 0.0f) : acc[i][sb][4 * q + c];
+                                if (a.mask && ly.mask_idx >= 0) {  // training, backward-data: d pre = d h where the forward activation passed the relu
+                                    const int col = 32 * t + 8 * q + 4 * h;
+                                    const bool live = m0 + n < M && col + 3 < a.save_w;
+                                    const elem* mp = (const elem*)a.mask + (size_t)ly.mask_idx * a.save_stride + (size_t)(live ? m0 + n : 0) * a.save_w + (live ? col : 0);
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) {
+                                        bool pos;
+                                        if constexpr (KH == 1) pos = mp[c] > 0.0f;
+                                        else pos = (mp[c] & 0x7fff) != 0 && !(mp[c] & 0x8000);       // a positive 16-bit float (activations are >= 0)
+                                        v[c] = (live && pos) ? v[c] : 0.0f;
+                                    }
+                                }
                                 elem* dstp = H + (size_t)n * sh + 32 * t + 8 * q + 4 * h;
                                 if constexpr (KH == 1) {                 // four floats = one 16-byte LDS store (rows are 16-byte aligned)
                                     *(f32x4*)dstp = f32x4{v[0], v[1], v[2], v[3]};
@@ -284,10 +311,25 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
                 }
             }
             __syncthreads();
+            if (a.save && ly.save_idx >= 0) {  // training: this layer's H rows (forward: activations; backward: d pre) to memory, 4 elements per lane
+                const int vpr = a.save_w >> 2;           // (save_w % 4 == 0: the launcher checks)
+                elem* sp = (elem*)a.save + (size_t)ly.save_idx * a.save_stride;
+                for (int idx = tid; idx < NS * vpr; idx += GEN_WAVES * 64) {
+                    const int n = idx / vpr, c = (idx - n * vpr) * 4;
+                    if (m0 + n < M) {
+                        if constexpr (KH == 1) *(f32x4*)(sp + (size_t)(m0 + n) * a.save_w + c) = *(const f32x4*)(H + (size_t)n * sh + c);
+                        else {
+                            typedef unsigned short u16x4s_ __attribute__((ext_vector_type(4)));
+                            *(u16x4s_*)(sp + (size_t)(m0 + n) * a.save_w + c) = *(const u16x4s_*)(H + (size_t)n * sh + c);
+                        }
+                    }
+                }
+                // (the next layer's write-back into H is two barriers away: these reads are done by then)
+            }
         }
 
         // ---- epilogue
-        if (tid < NS && m0 + tid < M) {
+        if (a.mode != 2 && tid < NS && m0 + tid < M) {
             const long long m = m0 + tid;
             const float* o = O + tid * 8;
             if (a.mode == 1) {
@@ -362,6 +404,8 @@ template <class P, int NSB>
 static hipError_t launch_gen(const GenArgs& a, int num_cus, hipStream_t stream) {
     if (a.ke % 16 || a.kv % 16 || a.kh % 16 || a.ke > GEN_MAX_E || a.kv > GEN_MAX_V || a.kh > GEN_MAX_W || a.n_layers < 1 ||
         a.n_layers > GEN_MAX_LAYERS) return hipErrorInvalidValue;
+    if ((a.save || a.mask) && (a.save_w % 4 != 0 || a.save_w < 4 || a.save_w > a.kh)) return hipErrorInvalidValue;
+    if (a.mode == 2 && (!a.draw || a.draw_ch < 1 || a.draw_ch > 16)) return hipErrorInvalidValue;
     int widest = 0;
     for (int l = 0; l < a.n_layers; ++l) widest = a.layer[l].nt > widest ? a.layer[l].nt : widest;
     if (widest > GEN_WAVES * GEN_MAXT) return hipErrorInvalidValue;

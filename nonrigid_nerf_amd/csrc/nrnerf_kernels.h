@@ -323,7 +323,7 @@ constexpr int GEN_MAXT = 4;           // output tiles per wave and layer: widths
 constexpr int GEN_MAX_W = 512;
 constexpr int GEN_MAX_E = 176;        // padded width of E: 3 + 6 * 16 = 99 encoding columns + 64 latent columns, multiple of 16
 constexpr int GEN_MAX_V = 64;         // padded width of V: 3 + 6 * 10 = 63
-enum GenBuf : int { GB_E = 0, GB_H = 1, GB_V = 2, GB_O = 3 };
+enum GenBuf : int { GB_E = 0, GB_H = 1, GB_V = 2, GB_O = 3, GB_OUT0 = 4, GB_OUT1 = 5 };     // GB_OUT0 / 1: straight to GenArgs::gout[0 / 1] (training, backward-data)
 
 struct GenLayer {
     int w_frag;          // index of fragment (tile 0, slab 0) in the weight stream; fragment (t, s) = w_frag + t * (ns0 + ns1) + s
@@ -335,10 +335,14 @@ struct GenLayer {
     int relu;
     int o_col;           // dst == GB_O: output row r of the layer goes to O[sample][o_col + r]  (rows < o_rows)
     int o_rows;
+    // training of a non-compiled architecture (round 5): -1 = off
+    int save_idx;        // dst == GB_H: after the write-back the tile's H rows (columns < save_w) are copied to GenArgs::save[save_idx]
+    int mask_idx;        // dst == GB_H: outputs are zeroed where GenArgs::mask[mask_idx][sample][column] <= 0 (the relu's derivative)
 };
 
 struct GenArgs {
-    int mode;                    // 0: ray bender (bent4 and detail outputs), 1: canonical network (raw4 / raw_out)
+    int mode;                    // 0: ray bender (bent4 and detail outputs), 1: canonical network (raw4 / raw_out),
+                                 // 2: backward-data of the canonical network (training): H starts as the rows of `draw`, no E / V
     const float* rays; int ray_stride;
     const float* latents; int lat_stride, lat;      // lat: latent columns appended to E (bender: always; network: time-conditioned baseline)
     const float* z;              // [N,S] sample depths or nullptr: coarse spacing between near and far
@@ -358,6 +362,10 @@ struct GenArgs {
     float* bent4;                // bender: [N,S,4] bent point + rigidity mask (network: read for the removal knob when detailed)
     SampleOut ex;
     Knobs knobs;
+    // training of a non-compiled architecture: saved arrays [index][n_rays * S][save_w] in the model's element type (fp32 / 16-bit)
+    void* save; const void* mask; long long save_stride; int save_w;
+    const float* draw; int draw_ch;      // mode 2: [n_rays * S][draw_ch] gradient of the raw outputs
+    float* gout[2]; int gout_w;          // mode 2: [n_rays * S][gout_w] fp32 outputs of the layers with dst == GB_OUT0 / GB_OUT1
 };
 
 hipError_t launch_generic(int precision, const GenArgs& a, int num_cus, hipStream_t stream);

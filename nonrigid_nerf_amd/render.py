@@ -313,6 +313,9 @@ class Model:
         _lib.check(self.lib.nrnerf_model_create(C.byref(desc), C.byref(handle)), "nrnerf_model_create")
         self.handle = handle
         self.generic = self.lib.nrnerf_model_is_generic(handle) == 1      # the run-time-parameterised kernel (csrc/nrnerf_generic.h)
+        self.trains_generic = self.lib.nrnerf_model_trains_generic(handle) == 1
+        if self.generic:            # the bender's training kernels are compiled per architecture: a generic handle has none
+            self.trains_bender = False
         self._ws = {}            # stream -> workspace: concurrent renders on different streams never share scratch
         self._ws_lock = threading.Lock()
         self._render_events = {} # stream -> event recorded after the last render queued there (see update_from_device)

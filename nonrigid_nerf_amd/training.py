@@ -386,6 +386,104 @@ class _Trunk(torch.autograd.Function):
         return _split_flat(flat, shapes)
 
 
+class _GenericTrunk(torch.autograd.Function):
+    """_Trunk for an architecture outside the compiled set (any depth, width % 4 == 0, at most one skip connection, plain
+    output_linear head; fp32 or bf16): the run-time-parameterised kernel runs the forward with every activation saved and the
+    backward-data pass from transposed weights (nrnerf_generic_trunk_forward / _backward, include/nrnerf.h); the weight gradients
+    dW_i = d_pre_i^T x_i are library GEMMs over the two saved arrays and the points' gradient follows from the encoding's."""
+
+    @staticmethod
+    def forward(ctx, pts, model, net, which, ray_bias, dirs, *params):
+        N, S = int(pts.shape[0]), int(pts.shape[1])
+        M, dev = N * S, pts.device
+        D, W = int(net.D), int(net.W)
+        f32 = _is_f32(model)
+        pts4 = _rows4(pts.detach(), M)
+        acts = torch.empty(D, M, W, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+        C_out = int(net.output_linear.weight.shape[0])
+        raw4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        raw = torch.empty(M, C_out, dtype=torch.float32, device=dev)
+        a = _lib.GenericTrunkArgs()
+        a.struct_size = C.sizeof(_lib.GenericTrunkArgs)
+        a.which, a.n_rays, a.n_samples = int(which), N, S
+        a.pts4, a.acts, a.raw4, a.raw, a.raw_ch = pts4.data_ptr(), acts.data_ptr(), raw4.data_ptr(), raw.data_ptr(), C_out
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_generic_trunk_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_generic_trunk_forward")
+        ctx.model, ctx.net, ctx.which, ctx.dims = model, net, int(which), (N, S, D, W, C_out)
+        ctx.save_for_backward(pts4, acts)
+        ctx.mark_non_differentiable(raw)
+        ctx.set_materialize_grads(False)
+        return raw4.view(N, S, 4), raw.view(N, S, C_out)
+
+    @staticmethod
+    def backward(ctx, g_raw4, _g_raw):
+        model, net = ctx.model, ctx.net
+        pts4, acts = ctx.saved_tensors
+        N, S, D, W, C_out = ctx.dims
+        M, dev = N * S, pts4.device
+        if g_raw4 is None:
+            return (None,) * (6 + 2 * D + 2)
+        n_freqs = (int(net.input_ch) - 3) // 6
+        n_enc = 3 + 6 * n_freqs
+        skips = [int(k) for k in net.skips if 0 <= int(k) <= D - 2]
+        g = g_raw4.contiguous().reshape(M, 4).float()
+        d_pre = torch.empty_like(acts)
+        d_enc = torch.empty(2 if skips else 1, M, n_enc, dtype=torch.float32, device=dev)
+        a = _lib.GenericTrunkArgs()
+        a.struct_size = C.sizeof(_lib.GenericTrunkArgs)
+        a.which, a.n_rays, a.n_samples = ctx.which, N, S
+        a.acts, a.d_raw4, a.d_pre, a.d_enc0 = acts.data_ptr(), g.data_ptr(), d_pre.data_ptr(), d_enc[0].data_ptr()
+        a.d_enc1 = d_enc[1].data_ptr() if skips else None
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_generic_trunk_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_generic_trunk_backward")
+        # the encoding once more, under autograd: its value for dW of the layers that read it, its backward for the points
+        with torch.enable_grad():
+            p = pts4[:, :3].detach().requires_grad_(ctx.needs_input_grad[0])
+            enc = posenc(p, n_freqs)
+        d_pts = None
+        if ctx.needs_input_grad[0]:
+            d_pts, = torch.autograd.grad(enc, p, d_enc.sum(0))
+            d_pts = d_pts.view(N, S, 3)
+        enc = enc.detach()
+        cdt = acts.dtype
+        enc_c = enc.to(cdt)
+
+        def product(dy, x):
+            # dy^T x [out, in] with an fp32 result.  The sum runs over ALL samples and the result is small: as ONE GEMM the library
+            # picks a kernel without a split along k (measured 573 us for 393 216 x 192 x 192 in bf16, 50 TFLOP/s; 10 of the step's 17
+            # ms) -- so: a batched GEMM over chunks of >= 2048 samples, partial results added (<= 64 MB of them)
+            Mx, wo, wi = int(dy.shape[0]), int(dy.shape[1]), int(x.shape[1])
+            B = max(1, min(Mx // 2048, (1 << 24) // max(1, wo * wi)))
+            rows = (Mx // B) * B
+            a3, b3 = dy[:rows].view(B, rows // B, wo).transpose(1, 2), x[:rows].view(B, rows // B, wi)
+            if dy.dtype == torch.float32:
+                out = torch.bmm(a3, b3).sum(0)
+            else:
+                try:
+                    out = torch.bmm(a3, b3, out_dtype=torch.float32).sum(0)
+                except (TypeError, RuntimeError):
+                    out = torch.bmm(a3, b3).sum(0, dtype=torch.float32)
+            if rows < Mx:
+                out = out + dy[rows:].float().t() @ x[rows:].float()
+            return out
+
+        grads = []
+        for i in range(D):              # pts_linears[i]: weight, bias (rnh:253-258: layer skip + 1 reads [encoding, activation])
+            if i == 0:
+                gw = product(d_pre[0], enc_c)
+            elif (i - 1) in skips:
+                gw = torch.cat([product(d_pre[i], enc_c), product(d_pre[i], acts[i - 1])], 1)
+            else:
+                gw = product(d_pre[i], acts[i - 1])
+            grads += [gw, d_pre[i].sum(0, dtype=torch.float32)]
+        gh = torch.zeros(C_out, W, dtype=torch.float32, device=dev)          # output_linear (a 5th channel never reaches a loss)
+        gh[:4] = product(g.to(cdt), acts[D - 1])
+        gb = torch.zeros(C_out, dtype=torch.float32, device=dev)
+        gb[:4] = g.sum(0)
+        grads += [gh, gb]
+        return (d_pts, None, None, None, None, None, *grads)
+
+
 _NUM_CUS = {}
 
 
@@ -1011,7 +1109,14 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
             if (not has_bender or exact) and ray_batch.shape[-1] < 11:
                 return "use_viewdirs without view directions in the ray batch"
         if int(net.D) != 8 or int(net.W) not in (256, 128) or list(net.skips) != [4] or int(net.input_ch) != 63:
-            return "non-default trunk under autograd"
+            # outside the compiled set: the run-time-parameterised kernel trains a plain trunk (_GenericTrunk; the library
+            # decides -- nrnerf_model_trains_generic -- and render_rays_train raises Unsupported when it says no)
+            D, W = int(net.D), int(net.W)
+            skips = [int(k) for k in net.skips if 0 <= int(k) <= D - 2]
+            if (getattr(net, "use_viewdirs", False) or getattr(net, "time_conditioned_baseline", False) or W % 4 or W > 512 or D < 1 or D > 16
+                    or len(skips) > 1 or (int(net.input_ch) - 3) % 6 or int(net.pts_linears[0].weight.shape[1]) != int(net.input_ch)
+                    or int(net.output_linear.weight.shape[0]) not in (4, 5)):
+                return "non-default trunk under autograd"
     if N_samples < 2 or N_samples + N_importance > _lib.MAX_SAMPLES:
         return f"more than {_lib.MAX_SAMPLES} samples per ray"
     if R.get_precision() == "f16":
@@ -1029,6 +1134,9 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     rb = R._bender_of(network_fn)
     latents = additional_pixel_information.get("ray_bending_latents") if additional_pixel_information else None
     model = R.get_model(network_fn, network_fine if N_importance > 0 else None, precision=precision, device=dev)
+    if model.generic and not model.trains_generic:
+        raise R.Unsupported("this architecture has no training kernels (view-dependent head / time-conditioned baseline off the compiled set)")
+    trunk = _GenericTrunk if model.generic else _Trunk
     rays = ray_batch.detach().to(torch.float32).contiguous()
     N, S, I = int(rays.shape[0]), int(N_samples), int(N_importance)
     if model.needs_latents:
@@ -1054,7 +1162,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     def bend_samples(z, for_merge=False):
         """(points, bent points, bender details) of the samples at depths z [N, ns]; points only when something needs them
         (``for_merge``: the new samples of the split fine bender -- what _merge_rows takes, nothing derived)."""
-        native = rb is not None and NATIVE_BENDER
+        native = rb is not None and NATIVE_BENDER and model.trains_bender     # (a generic handle: the bender as library GEMMs, ``bend``)
         ns = int(z.shape[1])
         pts, bd = None, {}
         if for_merge and native:
@@ -1117,7 +1225,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
                 dirs = finite_difference_dirs(bent)
             else:
                 dirs = rays[:, None, 8:11].expand(N, ns, 3)
-        raw4, raw = _Trunk.apply(bent, model, net, which, ray_bias, dirs, *_trunk_params(net))
+        raw4, raw = trunk.apply(bent, model, net, which, ray_bias, dirs, *_trunk_params(net))
         return raw4, raw, details
 
     coarse_parts = bend_samples(z_vals)
@@ -1131,7 +1239,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         rgb0, disp0, acc0, weights0, alpha0 = rgb_map, disp_map, acc_map, weights, alpha     # :902-908
         net_f = network_fine if network_fine is not None else network_fn                     # :925
         fine_parts = None
-        if rb is not None and SPLIT_FINE_BENDER and S + I <= SPLIT_MAX_SAMPLES:
+        if rb is not None and SPLIT_FINE_BENDER and model.trains_bender and S + I <= SPLIT_MAX_SAMPLES:
             # The bender is shared by both networks (rnh:213-215) and the coarse depths are a subset of the merged depths
             # (:920): bend only the I new samples and put every sample's point / bent point / details at its row among the
             # merged depths (as nrnerf_render's split-bender path).  Same values as bending all S + I points again; the

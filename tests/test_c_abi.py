@@ -36,6 +36,8 @@ def test_header_compiles_as_c99_and_matches_the_ctypes_mirror(tmp_path):
                      'printf("%d %d %d\\n", (int)NRNERF_WGRAD_SHORT_PARTIALS(28, 256), (int)NRNERF_WGRAD_SHORT_PARTIALS(1, 256), (int)NRNERF_WGRAD_SHORT_PARTIALS(30, 128));\n'
                      'printf("%zu %zu %zu %zu %zu\\n", sizeof(nrnerf_divergence_args), offsetof(nrnerf_divergence_args, probe),\n'
                      '       offsetof(nrnerf_divergence_args, divergence), offsetof(nrnerf_divergence_args, g_divergence), offsetof(nrnerf_divergence_args, partials));\n'
+                     'printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(nrnerf_loss_args), offsetof(nrnerf_loss_args, schedule), sizeof(nrnerf_generic_trunk_args),\n'
+                     '       offsetof(nrnerf_generic_trunk_args, raw_ch), offsetof(nrnerf_generic_trunk_args, d_raw4), offsetof(nrnerf_generic_trunk_args, d_enc1));\n'
                      'return 0; }\n')
     exe = tmp_path / "probe"
     subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(REPO, "include"), str(probe), "-o", str(exe)], check=True)
@@ -49,7 +51,9 @@ def test_header_compiles_as_c99_and_matches_the_ctypes_mirror(tmp_path):
             _lib.wgrad_stride(8, 256), _lib.wgrad_stride(8, 128), _lib.BENDER_WGRAD_SLOT,
             _lib.wgrad_short_partials(28, 256), _lib.wgrad_short_partials(1, 256), _lib.wgrad_short_partials(30, 128),
             C.sizeof(_lib.DivergenceArgs), _lib.DivergenceArgs.probe.offset, _lib.DivergenceArgs.divergence.offset,
-            _lib.DivergenceArgs.g_divergence.offset, _lib.DivergenceArgs.partials.offset]
+            _lib.DivergenceArgs.g_divergence.offset, _lib.DivergenceArgs.partials.offset,
+            C.sizeof(_lib.LossArgs), _lib.LossArgs.schedule.offset, C.sizeof(_lib.GenericTrunkArgs), _lib.GenericTrunkArgs.raw_ch.offset,
+            _lib.GenericTrunkArgs.d_raw4.offset, _lib.GenericTrunkArgs.d_enc1.offset]
     assert got == want, (got, want)
 
 

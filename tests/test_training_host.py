@@ -94,7 +94,15 @@ def test_eligibility_of_training_calls():
     assert T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu) is None      # the second compiled trunk width
     cfgw = SceneConfig(N_importance=64, netwidth=192)
     _, cw, fw = build_modules(make_scene(cfgw, 0))
-    assert "non-default trunk" in T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu)
+    # round 5: a plain trunk outside the compiled set trains on the run-time-parameterised kernel (training._GenericTrunk) ...
+    assert T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu) is None
+    for kw in (dict(netwidth=320, netdepth=5, skips=(2,), multires=6), dict(netwidth=64, netdepth=3, skips=()), dict(netwidth=512, netdepth=2, skips=(0,))):
+        _, cw, fw = build_modules(make_scene(SceneConfig(N_importance=64, **kw), 0))
+        assert T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu) is None, kw
+    # ... but not with a view-dependent head, a width the kernel's 4-element rows do not divide, or two skip connections
+    for kw in (dict(netwidth=192, use_viewdirs=True), dict(netwidth=190), dict(netwidth=192, skips=(2, 5)), dict(netwidth=640)):
+        _, cw, fw = build_modules(make_scene(SceneConfig(N_importance=64, **kw), 0))
+        assert "non-default trunk" in T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu11), kw
 
 
 def _apply_index(record, index, n_partials_full, n_partials_short):
