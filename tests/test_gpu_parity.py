@@ -525,12 +525,21 @@ def test_boundary_contract_errors_and_fallback():
         rv, lv = make_rays(8, 0, cfgv)
         out = FakeTrain.batchify_rays(rv.to(DEV), {"ray_bending_latents": lv.to(DEV)}, network_fn=cv, network_query_fn=None, N_samples=64)
         assert FakeTrain.calls == [] and out["rgb_map"].requires_grad
-        # a training call the native path has no kernels for (a trunk width outside the compiled set: rendered by the generic
-        # kernel, but not trained) still goes to the reference
+        # a trunk width outside the compiled set with the plain head: trained natively since the end of round 5 (training._GenericTrunk) ...
         cfgw = SceneConfig(N_importance=0, netwidth=192)
         rbw2, cw2, _ = build_modules(make_scene(cfgw, 0), device=DEV)
         rw2, lw2 = make_rays(8, 0, cfgw)
         out = FakeTrain.batchify_rays(rw2.to(DEV), {"ray_bending_latents": lw2.to(DEV)}, network_fn=cw2, network_query_fn=None, N_samples=64)
+        assert FakeTrain.calls == [] and out["rgb_map"].requires_grad
+        out["rgb_map"].sum().backward()
+        assert all(p_.grad is not None and bool(torch.isfinite(p_.grad).all()) and float(p_.grad.abs().max()) > 0
+                   for p_ in list(cw2.pts_linears.parameters()) + list(cw2.output_linear.parameters()))
+        # ... a training call the native path has no kernels for (the same width with a view-dependent head: rendered by the generic
+        # kernel, but not trained) still goes to the reference
+        cfgw = SceneConfig(N_importance=0, netwidth=192, use_viewdirs=True)
+        rbw3, cw3, _ = build_modules(make_scene(cfgw, 0), device=DEV)
+        rw3, lw3 = make_rays(8, 0, cfgw)
+        out = FakeTrain.batchify_rays(rw3.to(DEV), {"ray_bending_latents": lw3.to(DEV)}, network_fn=cw3, network_query_fn=None, N_samples=64)
         assert FakeTrain.calls and FakeTrain.calls[0][0] == "batchify_rays"
         # wrong latent shape: the reference raises in expand/split; here a ValueError, never an out-of-bounds read
         with torch.no_grad(), pytest.raises(ValueError):
