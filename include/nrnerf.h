@@ -548,13 +548,16 @@ typedef struct nrnerf_wgrad_args {
 #define NRNERF_WGRAD_STRIDE(depth, width) (((depth) - 1) * (width) * (width) + 3 * (width) * 64 + ((depth) + 1) * (width))
 int nrnerf_trunk_wgrad(const nrnerf_model* model, const nrnerf_wgrad_args* args, void* hip_stream);
 
-/* Training of an architecture OUTSIDE the compiled set (round 5; plain output_linear head, fp32 or bf16 handles, width % 4 == 0): the
+/* Training of an architecture OUTSIDE the compiled set (round 5; fp32 or bf16 handles, width % 4 == 0, no time-conditioned baseline): the
  * canonical network on ready-made points with every hidden activation saved, and its backward-data pass -- the run-time-parameterised
  * kernel's layer programs (forward: NeRF.forward, rnh:240-314; backward: the same layers in reverse with transposed weights).  The weight
  * gradients are products of the two saved arrays, dW_i = d_pre_i^T x_i (x_0 = the encoding, x_{skip+1} = [encoding, activation], else
  * the previous activation; db_i = column sums of d_pre_i) and the gradient wrt the points follows from the encoding's: both are left to
  * the caller (nonrigid_nerf_amd/training.py forms them with library GEMMs -- the one place on the training path where it does).
- *   acts / d_pre: [depth][n_rays * n_samples][width] in the handle's element type (fp32 for NRNERF_PREC_F32, bf16 for NRNERF_PREC_BF16);
+ *   With the view-dependent head (rnh:284-304; width <= 480) the saved arrays have two more slots: [depth] = feature_linear's outputs
+ *   (forward) / their gradient (backward), [depth + 1] = the colour branch's activations / pre-activation gradients in the first
+ *   views_linears[0].out_features columns (the rest of those rows is scratch); d sigma and d rgb reach h through the kernel.
+ *   acts / d_pre: [depth (+ 2)][n_rays * n_samples][width] in the handle's element type (fp32 for NRNERF_PREC_F32, bf16 for NRNERF_PREC_BF16);
  *   d_enc0 / d_enc1: [n_rays * n_samples][3 + 6 multires] fp32, the gradient of the encoding through pts_linears[0] and through the layer
  *   behind the skip connection (d_enc1 may be NULL for a network without one).  nrnerf_model_trains_generic: 1 when the handle has these. */
 typedef struct nrnerf_generic_trunk_args {
@@ -569,6 +572,8 @@ typedef struct nrnerf_generic_trunk_args {
     void* d_pre;                /* backward out */
     float* d_enc0;              /* backward out */
     float* d_enc1;              /* backward out (skip connection) */
+    const float* dirs;          /* forward in, view-dependent head: [N,S,3] one direction per sample */
+    float* d_encv;              /* backward out, view-dependent head: [N*S][3 + 6 multires_views] gradient of the direction encoding */
 } nrnerf_generic_trunk_args;
 int nrnerf_generic_trunk_forward(const nrnerf_model* model, const nrnerf_generic_trunk_args* args, void* hip_stream);
 int nrnerf_generic_trunk_backward(const nrnerf_model* model, const nrnerf_generic_trunk_args* args, void* hip_stream);

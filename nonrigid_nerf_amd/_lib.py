@@ -119,7 +119,8 @@ def render_flags_from_env() -> int:
 class GenericTrunkArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("which", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("pts4", C.c_void_p), ("acts", C.c_void_p), ("raw4", C.c_void_p), ("raw", C.c_void_p), ("raw_ch", C.c_int32),
-                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_enc0", C.c_void_p), ("d_enc1", C.c_void_p)]
+                ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_enc0", C.c_void_p), ("d_enc1", C.c_void_p),
+                ("dirs", C.c_void_p), ("d_encv", C.c_void_p)]
 
 
 class LossArgs(C.Structure):

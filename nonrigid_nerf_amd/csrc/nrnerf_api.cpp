@@ -672,8 +672,11 @@ struct GenSource { int buf, col0, n; };
 // (t_wbase >= 0: `lin` is a TRANSPOSED copy of rows [t_row0, t_row0 + lin.in_features ... ) -- element (row r, column k) of `lin` is the
 //  original layer's W[k][t_col0 + r], whose flat-vector position is t_wbase + k * t_orig_in + t_col0 + r: the device-side refresh
 //  (nrnerf_model_update_device) then fills the backward-data images of a non-compiled architecture like every other image)
+// (a transposed layer's place in the flat parameter buffer: element (output row r, source column k) of the layer is element
+//  (k - kshift, col0 + r) of the ORIGINAL matrix at wbase, whose rows have orig_in elements; columns k < kshift are constant zeros)
+struct GenTSrc { int64_t wbase = -1; int orig_in = 0, col0 = 0, kshift = 0; };
 void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSource a, GenSource b, int dst, int relu, int o_col, const FlatLayout* lay,
-                   int64_t t_wbase = -1, int t_orig_in = 0, int t_col0 = 0) {
+                   const GenTSrc* ta = nullptr, const GenTSrc* tb = nullptr) {
     if (g.proto.n_layers >= GEN_MAX_LAYERS) throw std::logic_error("generic program too long");
     const bool f32 = precision == NRNERF_PREC_F32;
     // a fragment = 64 lanes x 16 bytes in every precision: 8 16-bit k per lane (one MFMA), or 4 fp32 k per lane (four 32x32x2 MFMAs:
@@ -686,13 +689,13 @@ void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSo
     ly.src0 = a.buf; ly.ns0 = (a.n + KS - 1) / KS;
     ly.src1 = b.buf; ly.ns1 = (b.n + KS - 1) / KS;
     ly.dst = dst; ly.relu = relu; ly.o_col = o_col; ly.o_rows = lin.out_features;
-    ly.save_idx = -1; ly.mask_idx = -1;
+    ly.save_idx = -1; ly.mask_idx = -1; ly.boff0 = 0; ly.boff1 = 0;
     if (ly.nt > GEN_WAVES * GEN_MAXT || a.col0 + a.n > lin.in_features || b.col0 + b.n > lin.in_features) throw std::logic_error("generic layer out of range");
     const int ns = ly.ns0 + ly.ns1;
     const size_t f0 = g.pk.stream.size();
     g.pk.stream.resize(f0 + (size_t)ly.nt * ns * FB, 0);
-    const bool transposed = t_wbase >= 0;
-    const int64_t wbase = transposed ? t_wbase : (lay ? lay->of(lin.weight) : -1), bbase = (lay && lin.bias && !transposed) ? lay->of(lin.bias) : -1;
+    const bool transposed = ta != nullptr;
+    const int64_t wbase = (lay && !transposed) ? lay->of(lin.weight) : -1, bbase = (lay && lin.bias && !transposed) ? lay->of(lin.bias) : -1;
     if (lay) { g.pk.src.resize(g.pk.stream.size() / EB, -1); g.pk.fmt.resize(g.pk.stream.size() / EB, 0); }
     for (int t = 0; t < ly.nt; ++t)
         for (int sl = 0; sl < ns; ++sl) {
@@ -708,8 +711,10 @@ void gen_add_layer(GenProgram& g, int precision, const nrnerf_linear& lin, GenSo
                     const float w = live ? lin.weight[(size_t)row * lin.in_features + src.col0 + k] : 0.0f;
                     const size_t el = (f0 + ((size_t)t * ns + sl) * FB) / EB + (size_t)lane * KH + e;
                     if (lay) {
-                        if (transposed) g.pk.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)(src.col0 + k) * t_orig_in + t_col0 + row) : -1;
-                        else g.pk.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)row * lin.in_features + src.col0 + k) : -1;
+                        if (transposed) {
+                            const GenTSrc* ts = (sl < ly.ns0) ? ta : tb;
+                            g.pk.src[el] = (live && ts && ts->wbase >= 0 && k >= ts->kshift) ? (int32_t)(ts->wbase + (int64_t)(k - ts->kshift) * ts->orig_in + ts->col0 + row) : -1;
+                        } else g.pk.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)row * lin.in_features + src.col0 + k) : -1;
                         g.pk.fmt[el] = f32 ? 0 : (as_f16 ? 2 : 1);
                     }
                     if (f32) std::memcpy(fr + (lane * KH + e) * 4, &w, 4);
@@ -812,6 +817,10 @@ void gen_pack_mlp(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenProgr
     }
     g.proto.kh = (widest + 31) / 32 * 32;
     for (int i = 0; i < m.depth; ++i) g.proto.layer[i].save_idx = i;        // (training: layer i's activations, only with GenArgs::save set)
+    if (m.use_viewdirs) {                                                   // + feature_linear's outputs (slot D) and the colour branch's activations (slot D + 1)
+        g.proto.layer[m.depth + 1].save_idx = m.depth;
+        g.proto.layer[m.depth + 2].save_idx = m.depth + 1;
+    }
     gen_finish(g, d.precision);
 }
 // Backward-data of a plain-headed NeRF (training of a non-compiled architecture): the forward's layers in reverse order with TRANSPOSED
@@ -820,9 +829,14 @@ void gen_pack_mlp(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenProgr
 // activation i - 1); the layer behind the skip connection has [input | hidden] columns: its input part goes straight to memory
 // (GB_OUT1: the encoding's gradient), its hidden part goes on; pts_linears[0]^T ends in the encoding's gradient (GB_OUT0).
 bool gen_trainable(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
-    return d.precision != NRNERF_PREC_F16 && !m.use_viewdirs && !m.time_conditioned && m.width % 4 == 0 && m.depth >= 1 && m.output_ch >= 4 &&
-           m.output_ch <= 5 && 2 * m.depth + 2 <= GEN_MAX_LAYERS;
+    if (d.precision == NRNERF_PREC_F16 || m.time_conditioned || m.width % 4 != 0 || m.depth < 1) return false;
+    if (m.use_viewdirs) return m.feature_linear.out_features == m.width && m.views_linear.in_features == m.width + 3 + 6 * d.multires_views &&
+                               m.views_linear.out_features <= m.width && m.depth + 5 <= GEN_MAX_LAYERS && (m.width + 31) / 32 * 32 + 32 <= GEN_MAX_W;
+    return m.output_ch >= 4 && m.output_ch <= 5 && m.depth + 2 <= GEN_MAX_LAYERS;          // (layers of the backward-data program)
 }
+// column of H where mode 2 parks the rows of d raw (plain head: 0 -- they are the first layer's only input; view-dependent head: behind the
+// activations, because d sigma is needed again when the colour branch's gradient has come down to h_{D-1})
+int gen_draw_col(const nrnerf_mlp_desc& m) { return m.use_viewdirs ? (m.width + 31) / 32 * 32 : 0; }
 void gen_pack_mlp_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenProgram& g, const FlatLayout* lay) {
     const int enc = 3 + 6 * d.multires, W = m.width, D = m.depth, skip = gen_skip(m);
     g.proto.mode = 2; g.proto.L = d.multires; g.proto.LV = -1; g.proto.lat = 0;
@@ -838,13 +852,35 @@ void gen_pack_mlp_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenP
         lt.weight = t.data(); lt.bias = nullptr; lt.out_features = ncols; lt.in_features = lin.out_features;
         return lt;
     };
-    auto add = [&](const nrnerf_linear& lin, int col0, int ncols, int k_in, int dst, int mask_idx, int save_idx) {
+    auto add = [&](const nrnerf_linear& lin, int col0, int ncols, int k_in, int dst, int mask_idx, int save_idx, int boff = 0) {
         const nrnerf_linear lt = transposed(lin, col0, ncols);
-        gen_add_layer(g, d.precision, lt, GenSource{GB_H, 0, k_in}, none, dst, 0, 0, lay, lay ? lay->of(lin.weight) : -1, lin.in_features, col0);
+        const GenTSrc ts{lay ? lay->of(lin.weight) : -1, lin.in_features, col0, 0};
+        gen_add_layer(g, d.precision, lt, GenSource{GB_H, 0, k_in}, none, dst, 0, 0, lay, &ts, nullptr);
         GenLayer& ly = g.proto.layer[g.proto.n_layers - 1];
-        ly.mask_idx = mask_idx; ly.save_idx = save_idx;
+        ly.mask_idx = mask_idx; ly.save_idx = save_idx; ly.boff0 = boff;
     };
-    add(m.output_linear, 0, W, 4, GB_H, D - 1, D - 1);                                 // d raw (rgb, sigma; a 5th channel never reaches a loss) -> d pre_{D-1}
+    if (m.use_viewdirs) {
+        // rgb = rgb_linear(hv), hv = relu(views_linear([feature, enc(dir)])), feature = feature_linear(h), sigma = alpha_linear(h)  (rnh:284-304)
+        const int half = m.views_linear.out_features, dv = 3 + 6 * d.multires_views, dc = gen_draw_col(m);
+        add(m.rgb_linear, 0, half, 3, GB_H, D + 1, D + 1, dc);                        // d rgb (columns dc .. dc + 2) -> d pre of the colour branch (slot D + 1)
+        add(m.views_linear, W, dv, half, GB_OUT2, -1, -1);                            // its direction columns: the direction encoding's gradient, to memory
+        add(m.views_linear, 0, W, half, GB_H, -1, D);                                 // its feature columns: d feature (slot D; feature_linear has no relu)
+        // d h_{D-1} = feature_linear^T d feature + alpha_linear^T d sigma: ONE layer, columns [d feature | the d raw block, only its column 3 live]
+        keep.emplace_back((size_t)W * (W + 4), 0.0f);
+        std::vector<float>& t = keep.back();
+        for (int r = 0; r < W; ++r) {
+            for (int k = 0; k < W; ++k) t[(size_t)r * (W + 4) + k] = m.feature_linear.weight[(size_t)k * W + r];
+            t[(size_t)r * (W + 4) + W + 3] = m.alpha_linear.weight[r];
+        }
+        nrnerf_linear lt{};
+        lt.weight = t.data(); lt.bias = nullptr; lt.out_features = W; lt.in_features = W + 4;
+        const GenTSrc tf{lay ? lay->of(m.feature_linear.weight) : -1, W, 0, 0}, tal{lay ? lay->of(m.alpha_linear.weight) : -1, W, 0, 3};
+        gen_add_layer(g, d.precision, lt, GenSource{GB_H, 0, W}, GenSource{GB_H, W, 4}, GB_H, 0, 0, lay, &tf, &tal);
+        GenLayer& ly = g.proto.layer[g.proto.n_layers - 1];
+        ly.mask_idx = D - 1; ly.save_idx = D - 1; ly.boff1 = dc;
+    } else {
+        add(m.output_linear, 0, W, 4, GB_H, D - 1, D - 1);                             // d raw (rgb, sigma; a 5th channel never reaches a loss) -> d pre_{D-1}
+    }
     for (int i = D - 1; i >= 1; --i) {
         if (skip >= 0 && i - 1 == skip) {
             add(m.pts_linears[i], 0, enc, W, GB_OUT1, -1, -1);                         // input part: gradient of the encoding, to memory
@@ -854,7 +890,7 @@ void gen_pack_mlp_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenP
         }
     }
     add(m.pts_linears[0], 0, enc, W, GB_OUT0, -1, -1);
-    g.proto.kh = (imax(W, 16) + 31) / 32 * 32;
+    g.proto.kh = m.use_viewdirs ? gen_draw_col(m) + 32 : (imax(W, 16) + 31) / 32 * 32;
     gen_finish(g, d.precision);
 }
 // ray_bending.forward (rnh:507-577): always packed (and run) in fp32
@@ -963,7 +999,8 @@ struct nrnerf_model {
     bool gen_train_ok = false;
     GenArgs gen_coarse_bwd_prog{}, gen_fine_bwd_prog{};
     PassDev gen_coarse_bwd, gen_fine_bwd;
-    int gen_enc_w = 0, gen_w_coarse = 0, gen_w_fine = 0, gen_d_coarse = 0, gen_d_fine = 0;
+    struct GenTrainNet { int W = 0, D = 0, dv = 0, draw_col = 0; bool skip = false, views = false; } gen_tn[2];     // [coarse, fine]
+    int gen_enc_w = 0;
     bool gen_fine_is_coarse = false;
     int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
@@ -1335,15 +1372,21 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
         rc = upload_pass(bc.pk, m->gen_coarse_bwd);
         if (rc != NRNERF_OK) return rc;
         m->gen_coarse_bwd_prog = bc.proto;
-        m->gen_w_coarse = d.coarse->width; m->gen_d_coarse = d.coarse->depth;
+        auto describe = [&](const nrnerf_mlp_desc& n) {
+            nrnerf_model::GenTrainNet t;
+            t.W = n.width; t.D = n.depth; t.skip = gen_skip(n) >= 0; t.views = n.use_viewdirs != 0;
+            t.dv = t.views ? 3 + 6 * d.multires_views : 0; t.draw_col = gen_draw_col(n);
+            return t;
+        };
+        m->gen_tn[0] = describe(*d.coarse);
         if (d.fine) {
             gen_pack_mlp_bwd(d, *d.fine, bf, &lay);
             rc = upload_pass(bf.pk, m->gen_fine_bwd);
             if (rc != NRNERF_OK) return rc;
             m->gen_fine_bwd_prog = bf.proto;
-            m->gen_w_fine = d.fine->width; m->gen_d_fine = d.fine->depth;
+            m->gen_tn[1] = describe(*d.fine);
         } else {
-            m->gen_w_fine = m->gen_w_coarse; m->gen_d_fine = m->gen_d_coarse;
+            m->gen_tn[1] = m->gen_tn[0];
         }
         m->gen_enc_w = 3 + 6 * d.multires;
         m->gen_train_ok = true;
@@ -2154,11 +2197,11 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
     if (!m || !a || a->struct_size != sizeof(nrnerf_generic_trunk_args)) return NRNERF_ERR_INVALID;
     if (!m->generic || !m->gen_train_ok) return NRNERF_ERR_UNSUPPORTED;
     if (a->which < 0 || a->which > 1 || a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NRNERF_MAX_SAMPLES || !a->acts) return NRNERF_ERR_INVALID;
-    if (!backward && (!a->pts4 || !a->raw4)) return NRNERF_ERR_INVALID;
-    if (backward && (!a->d_raw4 || !a->d_pre || !a->d_enc0)) return NRNERF_ERR_INVALID;
-    if (a->n_rays == 0) return NRNERF_OK;
     const bool fine = a->which == 1 && !m->gen_fine_is_coarse;
-    const int W = fine ? m->gen_w_fine : m->gen_w_coarse;
+    const nrnerf_model::GenTrainNet& tn = m->gen_tn[fine ? 1 : 0];
+    if (!backward && (!a->pts4 || !a->raw4 || (tn.views && !a->dirs))) return NRNERF_ERR_INVALID;
+    if (backward && (!a->d_raw4 || !a->d_pre || !a->d_enc0 || (tn.skip && !a->d_enc1) || (tn.views && !a->d_encv))) return NRNERF_ERR_INVALID;
+    if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     const long long M = (long long)a->n_rays * a->n_samples;
@@ -2166,20 +2209,19 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
     const PassDev& pd = backward ? (fine ? m->gen_fine_bwd : m->gen_coarse_bwd) : (fine ? m->gen_fine : m->gen_coarse);
     g.wstream = pd.stream; g.bias = pd.bias;
     g.n_rays = a->n_rays; g.S = a->n_samples;
-    g.save_stride = M * W; g.save_w = W;
+    g.save_stride = M * tn.W; g.save_w = tn.W;
     if (!backward) {
         g.mode = 1;
         g.rays = a->pts4; g.ray_stride = 0; g.latents = nullptr; g.lat_stride = 0;      // (points are handed in: the ray record is never read)
-        g.z = nullptr; g.lindisp = 0; g.pts4 = a->pts4; g.dirs_from_pts = 0;
+        g.z = nullptr; g.lindisp = 0; g.pts4 = a->pts4; g.dirs_from_pts = 0; g.dirs = tn.views ? a->dirs : nullptr;
         g.raw4 = a->raw4; g.raw_out = a->raw; g.raw_ch = a->raw ? a->raw_ch : 4; g.bent4 = nullptr;
         g.save = a->acts; g.mask = nullptr;
     } else {
-        if (fine ? (m->gen_fine_bwd_prog.n_layers > m->gen_d_fine + 1 && !a->d_enc1) : (m->gen_coarse_bwd_prog.n_layers > m->gen_d_coarse + 1 && !a->d_enc1)) return NRNERF_ERR_INVALID;
         g.mode = 2;
         g.rays = a->d_raw4; g.ray_stride = 0;
-        g.draw = a->d_raw4; g.draw_ch = 4;
+        g.draw = a->d_raw4; g.draw_ch = 4; g.draw_col = tn.draw_col;
         g.mask = a->acts; g.save = a->d_pre;
-        g.gout[0] = a->d_enc0; g.gout[1] = a->d_enc1; g.gout_w = m->gen_enc_w;
+        g.gout[0] = a->d_enc0; g.gout[1] = a->d_enc1; g.gout[2] = a->d_encv; g.gout_w = m->gen_enc_w; g.gout_w2 = tn.dv;
     }
     return launch_generic(m->precision, g, m->num_cus, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             for (int idx = tid; idx < NS * 16; idx += GEN_WAVES * 64) {
                 const int n = idx >> 4, c = idx & 15;
                 const float v = (c < a.draw_ch && m0 + n < M) ? a.draw[(size_t)(m0 + n) * a.draw_ch + c] : 0.0f;
-                H[(size_t)n * sh + c] = gen_cvt<P>(v);
+                H[(size_t)n * sh + a.draw_col + c] = gen_cvt<P>(v);
             }
         }
         // ---- points (and view directions) of the tile's samples
@@ -137,7 +137,10 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             }
             float d[3] = {0.f, 0.f, 0.f};
             if (a.mode == 1 && a.LV >= 0) {
-                if (a.dirs_from_pts) {           // rnh:339-351: backward difference of the bent points, sample 0 copies sample 1
+                if (a.dirs) {                    // training: the caller's direction of this sample
+                    const float* dp = a.dirs + (size_t)m * 3;
+                    d[0] = dp[0]; d[1] = dp[1]; d[2] = dp[2];
+                } else if (a.dirs_from_pts) {           // rnh:339-351: backward difference of the bent points, sample 0 copies sample 1
                     const bool first = (si == 0);
                     const f32x4 nb = *(const f32x4*)(a.pts4 + (size_t)(first ? m + 1 : m - 1) * 4);
                     float dd[3];
@@ -254,9 +257,9 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             };
             struct TagE { using type = PE; };
             struct TagH { using type = P; };
-            if (ly.src0 == GB_H) run(TagH{}, src_ptr(GB_H), sh, 0, ly.ns0, true); else run(TagE{}, src_ptr(ly.src0), src_stride(ly.src0), 0, ly.ns0, true);
+            if (ly.src0 == GB_H) run(TagH{}, H + ly.boff0, sh, 0, ly.ns0, true); else run(TagE{}, src_ptr(ly.src0), src_stride(ly.src0), 0, ly.ns0, true);
             if (ly.ns1 > 0) {
-                if (ly.src1 == GB_H) run(TagH{}, src_ptr(GB_H), sh, ly.ns0, ly.ns1, false); else run(TagE{}, src_ptr(ly.src1), src_stride(ly.src1), ly.ns0, ly.ns1, false);
+                if (ly.src1 == GB_H) run(TagH{}, H + ly.boff1, sh, ly.ns0, ly.ns1, false); else run(TagE{}, src_ptr(ly.src1), src_stride(ly.src1), ly.ns0, ly.ns1, false);
             }
             if (li + 1 < a.n_layers) first_frags(li + 1);
             __syncthreads();                               // every wave has read the layer's inputs: H may be overwritten
@@ -267,12 +270,13 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
 #pragma unroll
                     for (int sb = 0; sb < NSB; ++sb) {
                         const int n = sb * 32 + j;
-                        if (ly.dst == GB_OUT0 || ly.dst == GB_OUT1) {          // training, backward-data: the encoding's gradient, straight to memory
+                        if (ly.dst >= GB_OUT0) {          // training, backward-data: an encoding's gradient, straight to memory
                             float* go = a.gout[ly.dst - GB_OUT0];
+                            const int gw = ly.dst == GB_OUT2 ? a.gout_w2 : a.gout_w;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                if (row < ly.o_rows && m0 + n < M) go[(size_t)(m0 + n) * a.gout_w + row] = acc[i][sb][r];
+                                if (row < ly.o_rows && m0 + n < M) go[(size_t)(m0 + n) * gw + row] = acc[i][sb][r];
                             }
                         } else if (ly.dst == GB_H) {
 #pragma unroll
@@ -405,7 +409,7 @@ static hipError_t launch_gen(const GenArgs& a, int num_cus, hipStream_t stream) 
     if (a.ke % 16 || a.kv % 16 || a.kh % 16 || a.ke > GEN_MAX_E || a.kv > GEN_MAX_V || a.kh > GEN_MAX_W || a.n_layers < 1 ||
         a.n_layers > GEN_MAX_LAYERS) return hipErrorInvalidValue;
     if ((a.save || a.mask) && (a.save_w % 4 != 0 || a.save_w < 4 || a.save_w > a.kh)) return hipErrorInvalidValue;
-    if (a.mode == 2 && (!a.draw || a.draw_ch < 1 || a.draw_ch > 16)) return hipErrorInvalidValue;
+    if (a.mode == 2 && (!a.draw || a.draw_ch < 1 || a.draw_ch > 16 || a.draw_col % 16 != 0 || a.draw_col < 0 || a.draw_col + 16 > a.kh)) return hipErrorInvalidValue;
     int widest = 0;
     for (int l = 0; l < a.n_layers; ++l) widest = a.layer[l].nt > widest ? a.layer[l].nt : widest;
     if (widest > GEN_WAVES * GEN_MAXT) return hipErrorInvalidValue;

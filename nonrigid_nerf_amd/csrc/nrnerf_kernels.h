@@ -323,7 +323,7 @@ constexpr int GEN_MAXT = 4;           // output tiles per wave and layer: widths
 constexpr int GEN_MAX_W = 512;
 constexpr int GEN_MAX_E = 176;        // padded width of E: 3 + 6 * 16 = 99 encoding columns + 64 latent columns, multiple of 16
 constexpr int GEN_MAX_V = 64;         // padded width of V: 3 + 6 * 10 = 63
-enum GenBuf : int { GB_E = 0, GB_H = 1, GB_V = 2, GB_O = 3, GB_OUT0 = 4, GB_OUT1 = 5 };     // GB_OUT0 / 1: straight to GenArgs::gout[0 / 1] (training, backward-data)
+enum GenBuf : int { GB_E = 0, GB_H = 1, GB_V = 2, GB_O = 3, GB_OUT0 = 4, GB_OUT1 = 5, GB_OUT2 = 6 };     // GB_OUT0 / 1 / 2: straight to GenArgs::gout[.] (training, backward-data)
 
 struct GenLayer {
     int w_frag;          // index of fragment (tile 0, slab 0) in the weight stream; fragment (t, s) = w_frag + t * (ns0 + ns1) + s
@@ -338,6 +338,7 @@ struct GenLayer {
     // training of a non-compiled architecture (round 5): -1 = off
     int save_idx;        // dst == GB_H: after the write-back the tile's H rows (columns < save_w) are copied to GenArgs::save[save_idx]
     int mask_idx;        // dst == GB_H: outputs are zeroed where GenArgs::mask[mask_idx][sample][column] <= 0 (the relu's derivative)
+    int boff0, boff1;    // a source that is GB_H is read from column boff (elements, a multiple of 16) on -- the rows of d raw parked beside the activations
 };
 
 struct GenArgs {
@@ -364,8 +365,10 @@ struct GenArgs {
     Knobs knobs;
     // training of a non-compiled architecture: saved arrays [index][n_rays * S][save_w] in the model's element type (fp32 / 16-bit)
     void* save; const void* mask; long long save_stride; int save_w;
-    const float* draw; int draw_ch;      // mode 2: [n_rays * S][draw_ch] gradient of the raw outputs
-    float* gout[2]; int gout_w;          // mode 2: [n_rays * S][gout_w] fp32 outputs of the layers with dst == GB_OUT0 / GB_OUT1
+    const float* draw; int draw_ch;      // mode 2: [n_rays * S][draw_ch] gradient of the raw outputs, put into H columns [draw_col, draw_col + 16)
+    int draw_col;
+    float* gout[3]; int gout_w, gout_w2; // mode 2: fp32 outputs [n_rays * S][gout_w] of the layers with dst == GB_OUT0 / GB_OUT1, [..][gout_w2] of GB_OUT2
+    const float* dirs;                   // mode 1, LV >= 0: [n_rays * S][3] one view direction per SAMPLE (training), or nullptr
 };
 
 hipError_t launch_generic(int precision, const GenArgs& a, int num_cus, hipStream_t stream);

@@ -388,9 +388,10 @@ class _Trunk(torch.autograd.Function):
 
 class _GenericTrunk(torch.autograd.Function):
     """_Trunk for an architecture outside the compiled set (any depth, width % 4 == 0, at most one skip connection, plain
-    output_linear head; fp32 or bf16): the run-time-parameterised kernel runs the forward with every activation saved and the
-    backward-data pass from transposed weights (nrnerf_generic_trunk_forward / _backward, include/nrnerf.h); the weight gradients
-    dW_i = d_pre_i^T x_i are library GEMMs over the two saved arrays and the points' gradient follows from the encoding's."""
+    output_linear head or the view-dependent one; fp32 or bf16): the run-time-parameterised kernel runs the forward with every
+    activation saved and the backward-data pass from transposed weights (nrnerf_generic_trunk_forward / _backward,
+    include/nrnerf.h); the weight gradients dW_i = d_pre_i^T x_i are library GEMMs over the two saved arrays and the gradients of
+    the points / directions follow from their encodings'.  ``params``: _generic_trunk_params(net)."""
 
     @staticmethod
     def forward(ctx, pts, model, net, which, ray_bias, dirs, *params):
@@ -398,31 +399,38 @@ class _GenericTrunk(torch.autograd.Function):
         M, dev = N * S, pts.device
         D, W = int(net.D), int(net.W)
         f32 = _is_f32(model)
+        views = bool(net.use_viewdirs)
         pts4 = _rows4(pts.detach(), M)
-        acts = torch.empty(D, M, W, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
-        C_out = int(net.output_linear.weight.shape[0])
+        # (view-dependent head: + feature_linear's outputs and the colour branch's activations, include/nrnerf.h)
+        acts = torch.empty(D + (2 if views else 0), M, W, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+        C_out = 4 if views else int(net.output_linear.weight.shape[0])
         raw4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         raw = torch.empty(M, C_out, dtype=torch.float32, device=dev)
         a = _lib.GenericTrunkArgs()
         a.struct_size = C.sizeof(_lib.GenericTrunkArgs)
         a.which, a.n_rays, a.n_samples = int(which), N, S
         a.pts4, a.acts, a.raw4, a.raw, a.raw_ch = pts4.data_ptr(), acts.data_ptr(), raw4.data_ptr(), raw.data_ptr(), C_out
+        saved = [pts4, acts]
+        if views:
+            d3 = dirs.detach().to(torch.float32).reshape(M, 3).contiguous()
+            a.dirs = d3.data_ptr()
+            saved.append(d3)
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_generic_trunk_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_generic_trunk_forward")
-        ctx.model, ctx.net, ctx.which, ctx.dims = model, net, int(which), (N, S, D, W, C_out)
-        ctx.save_for_backward(pts4, acts)
+        ctx.model, ctx.net, ctx.which, ctx.dims, ctx.views = model, net, int(which), (N, S, D, W, C_out), views
+        ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(raw)
         ctx.set_materialize_grads(False)
         return raw4.view(N, S, 4), raw.view(N, S, C_out)
 
     @staticmethod
     def backward(ctx, g_raw4, _g_raw):
-        model, net = ctx.model, ctx.net
-        pts4, acts = ctx.saved_tensors
+        model, net, views = ctx.model, ctx.net, ctx.views
+        pts4, acts = ctx.saved_tensors[:2]
         N, S, D, W, C_out = ctx.dims
         M, dev = N * S, pts4.device
         if g_raw4 is None:
-            return (None,) * (6 + 2 * D + 2)
+            return (None,) * (6 + 2 * D + (8 if views else 2))
         n_freqs = (int(net.input_ch) - 3) // 6
         n_enc = 3 + 6 * n_freqs
         skips = [int(k) for k in net.skips if 0 <= int(k) <= D - 2]
@@ -434,6 +442,10 @@ class _GenericTrunk(torch.autograd.Function):
         a.which, a.n_rays, a.n_samples = ctx.which, N, S
         a.acts, a.d_raw4, a.d_pre, a.d_enc0 = acts.data_ptr(), g.data_ptr(), d_pre.data_ptr(), d_enc[0].data_ptr()
         a.d_enc1 = d_enc[1].data_ptr() if skips else None
+        if views:
+            nv = (int(net.input_ch_views) - 3) // 6
+            d_encv = torch.empty(M, 3 + 6 * nv, dtype=torch.float32, device=dev)
+            a.d_encv = d_encv.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_generic_trunk_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_generic_trunk_backward")
         # the encoding once more, under autograd: its value for dW of the layers that read it, its backward for the points
@@ -455,6 +467,7 @@ class _GenericTrunk(torch.autograd.Function):
             Mx, wo, wi = int(dy.shape[0]), int(dy.shape[1]), int(x.shape[1])
             B = max(1, min(Mx // 2048, (1 << 24) // max(1, wo * wi)))
             rows = (Mx // B) * B
+            dy, x = dy.contiguous(), x.contiguous()
             a3, b3 = dy[:rows].view(B, rows // B, wo).transpose(1, 2), x[:rows].view(B, rows // B, wi)
             if dy.dtype == torch.float32:
                 out = torch.bmm(a3, b3).sum(0)
@@ -476,12 +489,43 @@ class _GenericTrunk(torch.autograd.Function):
             else:
                 gw = product(d_pre[i], acts[i - 1])
             grads += [gw, d_pre[i].sum(0, dtype=torch.float32)]
-        gh = torch.zeros(C_out, W, dtype=torch.float32, device=dev)          # output_linear (a 5th channel never reaches a loss)
-        gh[:4] = product(g.to(cdt), acts[D - 1])
-        gb = torch.zeros(C_out, dtype=torch.float32, device=dev)
-        gb[:4] = g.sum(0)
-        grads += [gh, gb]
-        return (d_pts, None, None, None, None, None, *grads)
+        d_dirs = None
+        if not views:
+            gh = torch.zeros(C_out, W, dtype=torch.float32, device=dev)      # output_linear (a 5th channel never reaches a loss)
+            gh[:4] = product(g.to(cdt), acts[D - 1])
+            gb = torch.zeros(C_out, dtype=torch.float32, device=dev)
+            gb[:4] = g.sum(0)
+            grads += [gh, gb]
+        else:
+            # rnh:284-304: sigma = alpha_linear(h); feature = feature_linear(h); hv = relu(views_linears[0]([feature, enc(dir)])); rgb = rgb_linear(hv)
+            half = int(net.views_linears[0].weight.shape[0])
+            d3 = ctx.saved_tensors[2]
+            with torch.enable_grad():
+                dl = d3.detach().requires_grad_(ctx.needs_input_grad[5])
+                encv = posenc(dl, nv)
+            if ctx.needs_input_grad[5]:
+                d_dirs, = torch.autograd.grad(encv, dl, d_encv)
+                d_dirs = d_dirs.view(N, S, 3)
+            h_last, feature, hv = acts[D - 1], acts[D], acts[D + 1][:, :half]
+            d_feature, d_pre_v = d_pre[D], d_pre[D + 1][:, :half].contiguous()
+            gsum = g.sum(0)
+            grads += [product(g[:, 3:4].to(cdt), h_last), gsum[3:4],                                         # alpha_linear
+                      product(d_feature, h_last), d_feature.sum(0, dtype=torch.float32),                     # feature_linear
+                      torch.cat([product(d_pre_v, feature), product(d_pre_v, encv.detach().to(cdt))], 1),   # views_linears[0] on [feature, enc(dir)]
+                      d_pre_v.sum(0, dtype=torch.float32),
+                      product(g[:, :3].to(cdt), hv), gsum[:3]]                                               # rgb_linear
+        return (d_pts, None, None, None, None, d_dirs, *grads)
+
+
+def _generic_trunk_params(net):
+    """The parameters _GenericTrunk returns gradients for, in its order (the view-dependent head unfolded, unlike _colour_params)."""
+    ps = []
+    for lin in net.pts_linears:
+        ps += [lin.weight, lin.bias]
+    if not net.use_viewdirs:
+        return ps + [net.output_linear.weight, net.output_linear.bias]
+    return ps + [net.alpha_linear.weight, net.alpha_linear.bias, net.feature_linear.weight, net.feature_linear.bias,
+                 net.views_linears[0].weight, net.views_linears[0].bias, net.rgb_linear.weight, net.rgb_linear.bias]
 
 
 _NUM_CUS = {}
@@ -1101,21 +1145,33 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
         if getattr(net, "time_conditioned_baseline", False):
             if R._bender_of(network_fn) is not None or int(net.W) != 256 or int(net.pts_linears[0].weight.shape[1]) != int(net.input_ch) + 32:
                 return "time-conditioned baseline with a bender / a non-default trunk under autograd"
-        if getattr(net, "use_viewdirs", False):
+        views = bool(getattr(net, "use_viewdirs", False))
+        default = int(net.D) == 8 and int(net.W) in (256, 128) and list(net.skips) == [4] and int(net.input_ch) == 63
+        compiled = default and (not views or (int(net.W) == 256 and int(getattr(net, "input_ch_views", 0)) == 27))
+        if views:
             has_bender = R._bender_of(network_fn) is not None
             exact = has_bender and not getattr(net, "approx_nonrigid_viewdirs", True)
-            if int(net.W) != 256 or int(getattr(net, "input_ch_views", 0)) != 27:
-                return "view-dependent head on a non-default trunk under autograd"
+            if exact and not compiled:
+                # (the Jacobian's tangent runs through the bender's compiled training kernels, which a generic handle does not carry)
+                return "exact Jacobian view directions on a non-default trunk under autograd"
             if (not has_bender or exact) and ray_batch.shape[-1] < 11:
                 return "use_viewdirs without view directions in the ray batch"
-        if int(net.D) != 8 or int(net.W) not in (256, 128) or list(net.skips) != [4] or int(net.input_ch) != 63:
-            # outside the compiled set: the run-time-parameterised kernel trains a plain trunk (_GenericTrunk; the library
-            # decides -- nrnerf_model_trains_generic -- and render_rays_train raises Unsupported when it says no)
+        if default and not compiled:
+            # (the 128-wide trunk with the view-dependent head RENDERS on its compiled kernels, so its handle is not a generic one, and
+            #  has no compiled training kernels)
+            return "view-dependent head on a non-default trunk under autograd"
+        if not compiled:
+            # outside the compiled set: the run-time-parameterised kernel trains the trunk, plain or view-dependent head
+            # (_GenericTrunk; the library decides -- nrnerf_model_trains_generic -- and render_rays_train raises Unsupported when it says no)
             D, W = int(net.D), int(net.W)
             skips = [int(k) for k in net.skips if 0 <= int(k) <= D - 2]
-            if (getattr(net, "use_viewdirs", False) or getattr(net, "time_conditioned_baseline", False) or W % 4 or W > 512 or D < 1 or D > 16
-                    or len(skips) > 1 or (int(net.input_ch) - 3) % 6 or int(net.pts_linears[0].weight.shape[1]) != int(net.input_ch)
-                    or int(net.output_linear.weight.shape[0]) not in (4, 5)):
+            if (getattr(net, "time_conditioned_baseline", False) or W % 4 or W > (480 if views else 512) or D < 1 or D > 16
+                    or len(skips) > 1 or (int(net.input_ch) - 3) % 6 or int(net.pts_linears[0].weight.shape[1]) != int(net.input_ch)):
+                return "non-default trunk under autograd"
+            if views and ((int(net.input_ch_views) - 3) % 6 or int(net.views_linears[0].weight.shape[1]) != W + int(net.input_ch_views)
+                          or int(net.views_linears[0].weight.shape[0]) > W or int(net.feature_linear.weight.shape[0]) != W):
+                return "view-dependent head of an unusual shape under autograd"
+            if not views and int(net.output_linear.weight.shape[0]) not in (4, 5):
                 return "non-default trunk under autograd"
     if N_samples < 2 or N_samples + N_importance > _lib.MAX_SAMPLES:
         return f"more than {_lib.MAX_SAMPLES} samples per ray"
@@ -1225,7 +1281,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
                 dirs = finite_difference_dirs(bent)
             else:
                 dirs = rays[:, None, 8:11].expand(N, ns, 3)
-        raw4, raw = trunk.apply(bent, model, net, which, ray_bias, dirs, *_trunk_params(net))
+        raw4, raw = trunk.apply(bent, model, net, which, ray_bias, dirs, *(_generic_trunk_params(net) if model.generic else _trunk_params(net)))
         return raw4, raw, details
 
     coarse_parts = bend_samples(z_vals)

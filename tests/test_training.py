@@ -190,12 +190,17 @@ def _loss(out, detailed):
                                                            (1.0, 1.0, True, dict(N_samples=48, N_importance=37, netwidth=192, netdepth=6)),
                                                            (1.0, 0.5, False, dict(N_importance=64, netwidth=320, netdepth=5, skips=(2,), multires=6, ray_bending=False)),
                                                            (0.0, 0.0, False, dict(N_importance=64, netwidth=64, netdepth=3, skips=(), netwidth_fine=132, netdepth_fine=4)),
-                                                           (1.0, 0.0, False, dict(N_samples=300, N_importance=200, netwidth=512, netdepth=2, skips=(0,), ray_bending=False))],
+                                                           (1.0, 0.0, False, dict(N_samples=300, N_importance=200, netwidth=512, netdepth=2, skips=(0,), ray_bending=False)),
+                                                           # ... with the view-dependent head (the rays' own directions; finite differences of bent points)
+                                                           (1.0, 0.5, False, dict(N_importance=64, netwidth=192, netdepth=6, use_viewdirs=True, ray_bending=False)),
+                                                           (1.0, 1.0, True, dict(N_samples=48, N_importance=37, netwidth=128, netdepth=4, skips=(1,), use_viewdirs=True,
+                                                                                 multires_views=2, netwidth_fine=480, netdepth_fine=3))],
                          ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128", "lindisp_white_bkgd",
                               "viewdirs_detailed_ragged", "viewdirs_no_bender", "config4_viewdirs_deep_bender", "time_conditioned_ragged",
                               "time_conditioned_viewdirs", "exact_viewdirs_detailed_ragged", "exact_viewdirs_deep_bender",
                               "350_samples_per_ray", "192_plus_128", "514_samples_detailed", "900_samples",
-                              "generic_w192_d6_detailed_ragged", "generic_w320_d5_skip2_L6_no_bender", "generic_no_skip_w64_fine_w132", "generic_w512_d2_500_samples"])
+                              "generic_w192_d6_detailed_ragged", "generic_w320_d5_skip2_L6_no_bender", "generic_no_skip_w64_fine_w132", "generic_w512_d2_500_samples",
+                              "generic_viewdirs_w192_d6_no_bender", "generic_viewdirs_w128_d4_fine_w480_detailed_ragged"])
 @pytest.mark.parametrize("bender", ["torch_ops", "native"])
 def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, bender):
     """Every parameter of every network + the latent codes, fp32 mode, against the oracle's autograd (eager torch on the
@@ -278,9 +283,10 @@ def O_render_free(scene, rays, latents, perturb, noise, detailed, **flags):
 @pytest.mark.gpu
 @pytest.mark.parametrize("width,detailed,views,S,I", [(256, False, False, 64, 64), (128, False, False, 64, 64), (256, True, False, 64, 64),
                                                       (256, False, True, 64, 64), (256, False, False, 192, 128), (256, True, False, 300, 400),
-                                                      (128, False, False, 64, 450), (192, True, False, 64, 64), (320, False, False, 64, 300)],
+                                                      (128, False, False, 64, 450), (192, True, False, 64, 64), (320, False, False, 64, 300),
+                                                      (320, False, True, 64, 64)],
                          ids=["w256", "w128", "w256_detailed_loss", "w256_viewdirs", "w256_192_plus_128", "w256_700_samples_detailed", "w128_514_samples",
-                              "generic_w192_detailed_loss", "generic_w320_364_samples"])
+                              "generic_w192_detailed_loss", "generic_w320_364_samples", "generic_w320_viewdirs"])
 def test_bf16_gradients_point_the_same_way(width, detailed, views, S, I):
     """bf16 training mode (bf16 activations and d z in block-tile layout, relu bit masks, trunk_wgrad): gradient direction and
     size against fp32 mode (row-major arrays, trunk_wgrad_f32), both compiled trunk widths -- and above 256 samples per pass (up to
@@ -314,7 +320,10 @@ def test_bf16_gradients_point_the_same_way(width, detailed, views, S, I):
         loose = k[0] in ("bender", "latents")
         # (the rigidity network's: sums with heavy cancellation, see above -- measured norm ratios 0.81 .. 1.42 over these cases, cosine >= 0.94)
         hi = 1.5 if "rigidity_network" in k[1] else 1.4
-        if not (cos > (0.9 if loose else 0.97) and ((0.6 < ratio < hi) if loose else (0.9 < ratio < 1.1))):
+        # (view-dependent head: the bender also receives the gradient of the finite-difference directions, differences of neighbouring bent
+        #  points divided by their ~5e-3 spacing -- measured cosines 0.945 on the compiled 256-wide case, 0.89 on the 320-wide generic one)
+        lo = (0.85 if views else 0.9) if loose else 0.97
+        if not (cos > lo and ((0.6 < ratio < hi) if loose else (0.9 < ratio < 1.1))):
             bad.append((k, round(cos, 4), round(ratio, 4)))
     far = sorted(seen, key=lambda r: -abs(r[2] - 1.0))[:3]
     print(f"\n[bf16 vs fp32 gradients, W{width} {S}+{I}] furthest norm ratios: {far}; lowest cosine {min(r[1] for r in seen)}")
