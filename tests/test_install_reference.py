@@ -194,8 +194,9 @@ def test_reference_render_path_and_dataparallel_wrapper_run_on_the_hip_path(refe
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("views", [False, True, "exact"], ids=["default", "use_viewdirs", "use_viewdirs_exact"])
-def test_reference_training_iteration_runs_natively_after_install(reference, capsys, views):
+@pytest.mark.parametrize("views,width", [(False, 256), (True, 256), ("exact", 256), (False, 192), (True, 192)],
+                         ids=["default", "use_viewdirs", "use_viewdirs_exact", "generic_w192", "generic_w192_use_viewdirs"])
+def test_reference_training_iteration_runs_natively_after_install(reference, capsys, views, width):
     """(c) one iteration of the reference's ``training_wrapper_class.forward`` + ``backward`` (train.py:152-287, 1594-1597)
     with the shipped loss weights (configs/example_sequence.txt: offsets 60, divergence 3, rigidity 5e-4, 64 + 64 samples,
     perturb, raw noise 1), on the reference's REAL modules on the GPU: once eagerly (the unmodified reference on this
@@ -205,7 +206,10 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
     view-dependent head (rnh:284-304) with finite-difference directions -- both of its branches run inside the training
     kernels (csrc/nrnerf_train.h, VIEWS), so this is the reference's own autograd through alpha / feature / views / rgb layers
     against theirs.  ``exact``: exact_nonrigid_viewdirs (rnh:358-385) -- the reference differentiates THROUGH the bender's Jacobian
-    (three reverse passes with create_graph=True); here one forward-mode tangent and the divergence kernels' two-chain backward."""
+    (three reverse passes with create_graph=True); here one forward-mode tangent and the divergence kernels' two-chain backward.
+    ``width`` 192 (round 5): an architecture outside the compiled set -- render_rays trains on the run-time-parameterised kernel
+    (training._GenericTrunk, bender as torch ops); only the divergence regulariser, whose native form needs the bender's compiled training
+    kernels, is the reference's own function there."""
     import argparse
     from nonrigid_nerf_amd import render as R
     G, H, T = reference
@@ -214,7 +218,7 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
     ts = G.TRAIN_STEP
     n_rays = 1024                                             # N_rand of the shipped config
     from nonrigid_nerf_amd.synthetic import SceneConfig, make_rays, make_scene
-    cfg = SceneConfig(N_importance=ts["N_importance"], use_viewdirs=bool(views), approx_nonrigid_viewdirs=(views != "exact"))
+    cfg = SceneConfig(N_importance=ts["N_importance"], use_viewdirs=bool(views), approx_nonrigid_viewdirs=(views != "exact"), netwidth=width)
     scene = make_scene(cfg, ts["seed"])
     rays, _ = make_rays(n_rays, ts["seed"], cfg)
     g = torch.Generator().manual_seed(11)
@@ -255,7 +259,10 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
 
     l_ref, g_ref, _ = one_step(False)
     l_hip, g_hip, reached = one_step(True)
-    assert reached == [0, 0], f"calls that reached the reference's render_rays / compute_divergence_loss: {reached}"
+    if width == 256:
+        assert reached == [0, 0], f"calls that reached the reference's render_rays / compute_divergence_loss: {reached}"
+    else:
+        assert reached[0] == 0, f"calls that reached the reference's render_rays: {reached[0]}"
     assert set(g_hip) == set(g_ref), set(g_hip) ^ set(g_ref)
     # a few rays take the other `denom < 1e-5` branch of sample_pdf: per-ray loss with outliers, mean tight
     rel = (l_hip - l_ref).abs() / (l_ref.abs() + 1e-6)
@@ -270,7 +277,7 @@ def test_reference_training_iteration_runs_natively_after_install(reference, cap
         assert cos >= 0.99, (k, cos, err)
     rows.sort(reverse=True)
     with capsys.disabled():
-        print(f"\n[reference training iteration, {n_rays} rays, real modules{(', use_viewdirs, exact Jacobian directions' if views == 'exact' else ', use_viewdirs') if views else ''}] mean loss eager {float(l_ref.mean()):.6f} vs installed "
+        print(f"\n[reference training iteration, {n_rays} rays, real modules, width {width}{(', use_viewdirs, exact Jacobian directions' if views == 'exact' else ', use_viewdirs') if views else ''}] mean loss eager {float(l_ref.mean()):.6f} vs installed "
               f"{float(l_hip.mean()):.6f}; per-ray loss within 1e-3: {float((rel < 1e-3).float().mean()):.3f}; calls reaching the reference's "
               f"render_rays / compute_divergence_loss after install: {reached}; {len(rows)} gradient tensors, min cosine "
               f"{min(c for _, c, _ in rows):.5f}; largest max-error / scale: " + "; ".join(f"{k[0]}.{k[1]} {e:.1e} (cos {c:.5f})" for e, c, k in rows[:6]))
