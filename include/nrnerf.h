@@ -548,7 +548,7 @@ typedef struct nrnerf_wgrad_args {
 #define NRNERF_WGRAD_STRIDE(depth, width) (((depth) - 1) * (width) * (width) + 3 * (width) * 64 + ((depth) + 1) * (width))
 int nrnerf_trunk_wgrad(const nrnerf_model* model, const nrnerf_wgrad_args* args, void* hip_stream);
 
-/* Training of an architecture OUTSIDE the compiled set (round 5; fp32 or bf16 handles, width % 4 == 0, no time-conditioned baseline): the
+/* Training of an architecture OUTSIDE the compiled set (round 5; fp32 or bf16 handles, width % 4 == 0): the
  * canonical network on ready-made points with every hidden activation saved, and its backward-data pass -- the run-time-parameterised
  * kernel's layer programs (forward: NeRF.forward, rnh:240-314; backward: the same layers in reverse with transposed weights).  The weight
  * gradients are products of the two saved arrays, dW_i = d_pre_i^T x_i (x_0 = the encoding, x_{skip+1} = [encoding, activation], else
@@ -574,10 +574,15 @@ typedef struct nrnerf_generic_trunk_args {
     float* d_enc1;              /* backward out (skip connection) */
     const float* dirs;          /* forward in, view-dependent head: [N,S,3] one direction per sample */
     float* d_encv;              /* backward out, view-dependent head: [N*S][3 + 6 multires_views] gradient of the direction encoding */
+    const float* latents;       /* forward in, time-conditioned baseline (no bender): [N][latent size] one code per ray; d_enc0 / d_enc1 then
+                                 * have 3 + 6 multires + latent size columns, the code's gradient (per sample) in the last ones */
 } nrnerf_generic_trunk_args;
 int nrnerf_generic_trunk_forward(const nrnerf_model* model, const nrnerf_generic_trunk_args* args, void* hip_stream);
 int nrnerf_generic_trunk_backward(const nrnerf_model* model, const nrnerf_generic_trunk_args* args, void* hip_stream);
 int nrnerf_model_trains_generic(const nrnerf_model* model);
+/* 1 when the handle has the ray bender's training kernels (nrnerf_bender_*, nrnerf_divergence_*): a compiled architecture with a bender, or a
+ * generic handle whose BENDER has a compiled shape (5 or 7 x 64 offsets, 3 x 32 rigidity, latent 32) in fp32 / bf16 */
+int nrnerf_model_trains_bender(const nrnerf_model* model);
 
 /* The loss of one training iteration over the outputs of render_rays (reference training_wrapper_class.forward, train.py:207-287), per ray:
  *   loss[r] = mean((rgb_map - target)^2) + [rgb0] mean((rgb0 - target)^2)                                    train.py:207-218, rnh:10-13

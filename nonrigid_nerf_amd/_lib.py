@@ -85,6 +85,9 @@ class RenderArgs(C.Structure):
 # include/nrnerf.h: nrnerf_model_flags / nrnerf_render_flags (ABI 7: kernel-selection switches are fields of the call; the library
 # reads no environment variable).  The test switches NRNERF_* of the environment are mapped to them HERE, on the Python side.
 MODEL_FORCE_GENERIC, MODEL_NO_X16_F16 = 1 << 0, 1 << 1
+# Python-side only (never reaches the library): a handle for the TRAINING entry points, whose callers compute the view directions themselves --
+# described to the library without exact_viewdirs, which the run-time-parameterised RENDER kernel does not do (training.render_rays_train)
+MODEL_PY_TRAINING_HANDLE = 1 << 30
 RENDER_FUSED_FINE_BENDER, RENDER_UNFUSED_COMPOSITE, RENDER_SPLIT_COARSE, RENDER_NO_X16, RENDER_X16_FINE_ONLY, RENDER_BENDER_32X32 = (1 << i for i in range(6))
 
 
@@ -120,7 +123,7 @@ class GenericTrunkArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("which", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("pts4", C.c_void_p), ("acts", C.c_void_p), ("raw4", C.c_void_p), ("raw", C.c_void_p), ("raw_ch", C.c_int32),
                 ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_enc0", C.c_void_p), ("d_enc1", C.c_void_p),
-                ("dirs", C.c_void_p), ("d_encv", C.c_void_p)]
+                ("dirs", C.c_void_p), ("d_encv", C.c_void_p), ("latents", C.c_void_p)]
 
 
 class LossArgs(C.Structure):
@@ -243,6 +246,7 @@ EXPORTS = {
     "nrnerf_generic_trunk_forward": (C.c_int, [C.c_void_p, C.POINTER(GenericTrunkArgs), C.c_void_p]),
     "nrnerf_generic_trunk_backward": (C.c_int, [C.c_void_p, C.POINTER(GenericTrunkArgs), C.c_void_p]),
     "nrnerf_model_trains_generic": (C.c_int, [C.c_void_p]),
+    "nrnerf_model_trains_bender": (C.c_int, [C.c_void_p]),
     "nrnerf_loss_forward": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "nrnerf_loss_backward": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

@@ -829,7 +829,8 @@ void gen_pack_mlp(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenProgr
 // activation i - 1); the layer behind the skip connection has [input | hidden] columns: its input part goes straight to memory
 // (GB_OUT1: the encoding's gradient), its hidden part goes on; pts_linears[0]^T ends in the encoding's gradient (GB_OUT0).
 bool gen_trainable(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
-    if (d.precision == NRNERF_PREC_F16 || m.time_conditioned || m.width % 4 != 0 || m.depth < 1) return false;
+    if (d.precision == NRNERF_PREC_F16 || m.width % 4 != 0 || m.depth < 1) return false;
+    if (m.time_conditioned && (d.bender || m.pts_linears[0].in_features > 512)) return false;
     if (m.use_viewdirs) return m.feature_linear.out_features == m.width && m.views_linear.in_features == m.width + 3 + 6 * d.multires_views &&
                                m.views_linear.out_features <= m.width && m.depth + 5 <= GEN_MAX_LAYERS && (m.width + 31) / 32 * 32 + 32 <= GEN_MAX_W;
     return m.output_ch >= 4 && m.output_ch <= 5 && m.depth + 2 <= GEN_MAX_LAYERS;          // (layers of the backward-data program)
@@ -838,7 +839,9 @@ bool gen_trainable(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
 // activations, because d sigma is needed again when the colour branch's gradient has come down to h_{D-1})
 int gen_draw_col(const nrnerf_mlp_desc& m) { return m.use_viewdirs ? (m.width + 31) / 32 * 32 : 0; }
 void gen_pack_mlp_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m, GenProgram& g, const FlatLayout* lay) {
-    const int enc = 3 + 6 * d.multires, W = m.width, D = m.depth, skip = gen_skip(m);
+    // (time-conditioned baseline, rnh:207-209, 273-282: the latent code's columns follow the encoding's in both layers that read the input,
+    //  and so do their gradients in the two outputs)
+    const int enc = m.time_conditioned ? m.pts_linears[0].in_features : 3 + 6 * d.multires, W = m.width, D = m.depth, skip = gen_skip(m);
     g.proto.mode = 2; g.proto.L = d.multires; g.proto.LV = -1; g.proto.lat = 0;
     g.proto.ke = 16; g.proto.kv = 16;
     const GenSource none{GB_H, 0, 0};
@@ -999,8 +1002,7 @@ struct nrnerf_model {
     bool gen_train_ok = false;
     GenArgs gen_coarse_bwd_prog{}, gen_fine_bwd_prog{};
     PassDev gen_coarse_bwd, gen_fine_bwd;
-    struct GenTrainNet { int W = 0, D = 0, dv = 0, draw_col = 0; bool skip = false, views = false; } gen_tn[2];     // [coarse, fine]
-    int gen_enc_w = 0;
+    struct GenTrainNet { int W = 0, D = 0, dv = 0, draw_col = 0, in_w = 0, lat = 0; bool skip = false, views = false; } gen_tn[2];     // [coarse, fine]
     bool gen_fine_is_coarse = false;
     int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
@@ -1291,6 +1293,18 @@ double gen_mfma_flops_per_sample(const GenArgs& g, bool f32) {
     for (int l = 0; l < g.n_layers; ++l) f += (double)g.layer[l].nt * (g.layer[l].ns0 + g.layer[l].ns1) * 2.0 * 32 * (f32 ? 8 : 16);
     return f;
 }
+// the compiled bender's training images for a generic handle (as pack_training's: the fp32 forward plan and the backward plan)
+void gen_pack_bender_train(const nrnerf_model_desc& d, int cb, PackedPass& bfw, PackedPass& bbw, const FlatLayout* lay) {
+    nrnerf_model_desc d32 = d;
+    d32.precision = NRNERF_PREC_F32;
+    if (cb == 0) {
+        pack_pass<ShapeF32, ArchDefault, true, false, false>(d32, *d.coarse, NRNERF_PREC_F32, bfw, lay);
+        pack_pass_bwd_bender<ArchDefault>(*d.bender, bbw, lay);
+    } else {
+        pack_pass<ShapeF32, ArchDeepBend, true, false, false>(d32, *d.coarse, NRNERF_PREC_F32, bfw, lay);
+        pack_pass_bwd_bender<ArchDeepBend>(*d.bender, bbw, lay);
+    }
+}
 int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_model** out) {
     GenProgram gb, gc, gf;
     int rc = gen_pack_all(d, &lay, gb, gc, gf);
@@ -1337,6 +1351,14 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
             if (rc != NRNERF_OK) return rc;
             m->bend_only.algo_flops_per_sample = m->gen_bend.algo_flops_per_sample;
             m->gen_compiled_bender = cb;
+            if (d.precision != NRNERF_PREC_F16) {    // ... and its training kernels (forward with saved activations, backward, divergence chains)
+                PackedPass bfw, bbw;
+                gen_pack_bender_train(d, cb, bfw, bbw, &lay);
+                rc = upload_pass(bfw, m->bend_train_fwd);
+                if (rc == NRNERF_OK) rc = upload_pass(bbw, m->bend_train_bwd);
+                if (rc != NRNERF_OK) return rc;
+                m->bend_train_ok = true;
+            }
             if (bend_x16_eligible(d)) {              // "bf16" mode: the 16x16x32 stand-alone bender (nrnerf_bend_x16.h)
                 PackedPass pbx;
                 pack_bend_x16(d, pbx, &lay);
@@ -1376,6 +1398,7 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
             nrnerf_model::GenTrainNet t;
             t.W = n.width; t.D = n.depth; t.skip = gen_skip(n) >= 0; t.views = n.use_viewdirs != 0;
             t.dv = t.views ? 3 + 6 * d.multires_views : 0; t.draw_col = gen_draw_col(n);
+            t.in_w = n.time_conditioned ? n.pts_linears[0].in_features : 3 + 6 * d.multires; t.lat = t.in_w - (3 + 6 * d.multires);
             return t;
         };
         m->gen_tn[0] = describe(*d.coarse);
@@ -1388,7 +1411,6 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
         } else {
             m->gen_tn[1] = m->gen_tn[0];
         }
-        m->gen_enc_w = 3 + 6 * d.multires;
         m->gen_train_ok = true;
     }
     // with a bender (the passes then run on ready-made points) and a plain head: the trunks also for the width-class x16 kernel
@@ -1437,6 +1459,13 @@ int update_generic(nrnerf_model* m, const nrnerf_model_desc& d, hipStream_t stre
     if (d.bender && m->bend_x16.stream) {
         pack_bend_x16(d, pbx);
         rc = refresh_pass(pbx, m->bend_x16, stream);
+        if (rc != NRNERF_OK) return rc;
+    }
+    PackedPass tbf, tbb;
+    if (d.bender && m->bend_train_ok) {
+        gen_pack_bender_train(d, m->gen_compiled_bender, tbf, tbb, nullptr);
+        rc = refresh_pass(tbf, m->bend_train_fwd, stream);
+        if (rc == NRNERF_OK) rc = refresh_pass(tbb, m->bend_train_bwd, stream);
         if (rc != NRNERF_OK) return rc;
     }
     if (d.bender) rc = refresh_pass(gb.pk, m->gen_bend, stream);         // (sizes differ for another architecture: NRNERF_ERR_INVALID)
@@ -1721,6 +1750,12 @@ int64_t nrnerf_model_flat_size(const nrnerf_model* m) { return m ? m->flat_float
 
 int nrnerf_model_precision(const nrnerf_model* m) { return m ? m->precision : NRNERF_ERR_INVALID; }
 
+namespace {
+// which compiled bender shape (0: 5 x 64, 1: 7 x 64) the bender's training kernels run: the handle's architecture, or -- a generic handle --
+// the compiled shape its bender happens to have (the reference's hard-coded one next to an odd trunk, rnh:406-407)
+int bender_arch_of(const nrnerf_model* m) { return m->generic ? m->gen_compiled_bender : bender_arch(m->arch_id); }
+}  // namespace
+int nrnerf_model_trains_bender(const nrnerf_model* m) { return m ? (m->bend_train_ok ? 1 : 0) : NRNERF_ERR_INVALID; }
 int nrnerf_model_is_generic(const nrnerf_model* m) { return m ? (m->generic ? 1 : 0) : NRNERF_ERR_INVALID; }
 
 int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_t n_floats, void* hip_stream) try {
@@ -2199,7 +2234,7 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
     if (a->which < 0 || a->which > 1 || a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NRNERF_MAX_SAMPLES || !a->acts) return NRNERF_ERR_INVALID;
     const bool fine = a->which == 1 && !m->gen_fine_is_coarse;
     const nrnerf_model::GenTrainNet& tn = m->gen_tn[fine ? 1 : 0];
-    if (!backward && (!a->pts4 || !a->raw4 || (tn.views && !a->dirs))) return NRNERF_ERR_INVALID;
+    if (!backward && (!a->pts4 || !a->raw4 || (tn.views && !a->dirs) || (tn.lat > 0 && !a->latents))) return NRNERF_ERR_INVALID;
     if (backward && (!a->d_raw4 || !a->d_pre || !a->d_enc0 || (tn.skip && !a->d_enc1) || (tn.views && !a->d_encv))) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
@@ -2212,7 +2247,8 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
     g.save_stride = M * tn.W; g.save_w = tn.W;
     if (!backward) {
         g.mode = 1;
-        g.rays = a->pts4; g.ray_stride = 0; g.latents = nullptr; g.lat_stride = 0;      // (points are handed in: the ray record is never read)
+        g.rays = a->pts4; g.ray_stride = 0;                                              // (points are handed in: the ray record is never read)
+        g.latents = tn.lat > 0 ? a->latents : nullptr; g.lat_stride = tn.lat;
         g.z = nullptr; g.lindisp = 0; g.pts4 = a->pts4; g.dirs_from_pts = 0; g.dirs = tn.views ? a->dirs : nullptr;
         g.raw4 = a->raw4; g.raw_out = a->raw; g.raw_ch = a->raw ? a->raw_ch : 4; g.bent4 = nullptr;
         g.save = a->acts; g.mask = nullptr;
@@ -2221,7 +2257,7 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
         g.rays = a->d_raw4; g.ray_stride = 0;
         g.draw = a->d_raw4; g.draw_ch = 4; g.draw_col = tn.draw_col;
         g.mask = a->acts; g.save = a->d_pre;
-        g.gout[0] = a->d_enc0; g.gout[1] = a->d_enc1; g.gout[2] = a->d_encv; g.gout_w = m->gen_enc_w; g.gout_w2 = tn.dv;
+        g.gout[0] = a->d_enc0; g.gout[1] = a->d_enc1; g.gout[2] = a->d_encv; g.gout_w = tn.in_w; g.gout_w2 = tn.dv;
     }
     return launch_generic(m->precision, g, m->num_cus, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
@@ -2461,7 +2497,7 @@ int nrnerf_bender_forward(const nrnerf_model* m, const nrnerf_bender_args* a, vo
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     const bool b16 = m->precision != NRNERF_PREC_F32;        // element type of the saved arrays (nrnerf_bender_args)
-    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_fwd_train_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
+    const hipError_t e = (bender_arch_of(m) == 0) ? launch_bend_fwd_train_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
                                            : launch_bend_fwd_train_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
@@ -2474,7 +2510,7 @@ int nrnerf_bender_backward(const nrnerf_model* m, const nrnerf_bender_args* a, v
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     const bool b16 = m->precision != NRNERF_PREC_F32;
-    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
+    const hipError_t e = (bender_arch_of(m) == 0) ? launch_bend_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
                                            : launch_bend_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
@@ -2486,7 +2522,7 @@ int nrnerf_bender_wgrad(const nrnerf_model* m, const nrnerf_bender_wgrad_args* a
     if (!a->rays || a->ray_stride < 6 || !a->latents || a->latent_stride < m->latent_size || !a->z) return NRNERF_ERR_INVALID;
     if (!a->acts_offsets || !a->acts_rigidity || !a->dz_offsets || !a->dz_rigidity || !a->dz_out4 || !a->partials) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
-    const int BD = (bender_arch(m->arch_id) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
+    const int BD = (bender_arch_of(m) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
     const int BW = ArchDefault::BW, RD = ArchDefault::RD, RW = ArchDefault::RW, X0 = 3 + ArchDefault::LAT;
     const size_t M = (size_t)a->n_rays * a->n_samples;
     if (m->precision != NRNERF_PREC_F32 && M * 64 * 4 >= 0xffffff00ull) return NRNERF_ERR_INVALID;      // 32-bit offsets in bend_wgrad16
@@ -2544,7 +2580,7 @@ int nrnerf_bender_divergence_forward(const nrnerf_model* m, const nrnerf_diverge
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     const bool b16 = m->precision != NRNERF_PREC_F32;
-    const hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_fwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
+    const hipError_t e = (bender_arch_of(m) == 0) ? launch_bend_div_fwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
                                                         : launch_bend_div_fwd_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     return e == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
@@ -2558,11 +2594,11 @@ int nrnerf_bender_divergence_backward(const nrnerf_model* m, const nrnerf_diverg
     if (b16 && (size_t)a->n_points * 64 * 4 >= 0xffffff00ull) return NRNERF_ERR_INVALID;      // 32-bit offsets in bend_wgrad16: nothing is launched
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    hipError_t e = (bender_arch(m->arch_id) == 0) ? launch_bend_div_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
+    hipError_t e = (bender_arch_of(m) == 0) ? launch_bend_div_bwd_a0(t, m->num_cus, (hipStream_t)hip_stream, b16)
                                                   : launch_bend_div_bwd_a1(t, m->num_cus, (hipStream_t)hip_stream, b16);
     if (e != hipSuccess) return NRNERF_ERR_HIP;
     // weight / bias gradients: dW_i = dz_i^T h_{i-1} + dtz_i^T th_{i-1} (two products per job), db_i = column sums of dz_i
-    const int BD = (bender_arch(m->arch_id) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
+    const int BD = (bender_arch_of(m) == 0) ? ArchDefault::BD : ArchDeepBend::BD;
     const int BW = ArchDefault::BW, RD = ArchDefault::RD, RW = ArchDefault::RW, LAT = m->latent_size;
     const size_t M = (size_t)a->n_points;
     BendWgradArgs w{};

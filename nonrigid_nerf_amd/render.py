@@ -152,7 +152,7 @@ def build_model_desc(network_fn, network_fine, precision: str, device_index: int
     icv = int(getattr(network_fn, "input_ch_views", 0))
     desc.multires_views = (icv - 3) // 6 if icv >= 3 else 0
     desc.device = device_index
-    desc.flags = int(flags)
+    desc.flags = int(flags) & 0xffff            # (higher bits: Python-side markers, _lib.MODEL_PY_*)
     cm = _mlp_desc(network_fn, keep)
     keep.objs.append(cm)
     desc.coarse = C.pointer(cm)
@@ -167,6 +167,8 @@ def build_model_desc(network_fn, network_fine, precision: str, device_index: int
     # exact (Jacobian) view directions when the module asks for them (NeRF.approx_nonrigid_viewdirs, rnh:289-294)
     desc.exact_viewdirs = int(rb is not None and bool(getattr(network_fn, "use_viewdirs", False))
                               and not getattr(network_fn, "approx_nonrigid_viewdirs", True))
+    if int(flags) & _lib.MODEL_PY_TRAINING_HANDLE:      # the caller computes the directions (training.render_rays_train)
+        desc.exact_viewdirs = 0
     return desc, keep
 
 
@@ -314,8 +316,8 @@ class Model:
         self.handle = handle
         self.generic = self.lib.nrnerf_model_is_generic(handle) == 1      # the run-time-parameterised kernel (csrc/nrnerf_generic.h)
         self.trains_generic = self.lib.nrnerf_model_trains_generic(handle) == 1
-        if self.generic:            # the bender's training kernels are compiled per architecture: a generic handle has none
-            self.trains_bender = False
+        if self.generic:            # the bender's training kernels are compiled per BENDER shape: a generic handle has them when its bender has one
+            self.trains_bender = self.lib.nrnerf_model_trains_bender(handle) == 1
         self._ws = {}            # stream -> workspace: concurrent renders on different streams never share scratch
         self._ws_lock = threading.Lock()
         self._render_events = {} # stream -> event recorded after the last render queued there (see update_from_device)
@@ -522,7 +524,7 @@ def _wref(obj):
     return None if obj is None else weakref.ref(obj)
 
 
-def get_model(network_fn, network_fine=None, precision: str | None = None, device=None) -> Model:
+def get_model(network_fn, network_fine=None, precision: str | None = None, device=None, flags: int = 0) -> Model:
     """The packed-weight handle for these modules on ``device`` (created, refreshed in place, or served from the cache).
 
     Staleness is detected from ``(data_ptr, _version)`` of every parameter -- ``load_state_dict``, ``copy_``, plain and
@@ -532,12 +534,12 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
     by neither: call ``invalidate(network_fn)`` (or ``mark_stale``) after such an edit, and after replaying an optimiser step
     from a HIP graph.  Architectures the library has no kernel for
     raise ``Unsupported``; that verdict is cached as well, so a fallback caller does not re-copy the weights to the
-    host on every call."""
+    host on every call.  ``flags``: nrnerf_model_desc.flags to OR in (a handle per flag set), e.g. ``_lib.MODEL_FORCE_GENERIC``."""
     precision = _lib.canonical_precision(precision or _DEFAULT_PRECISION)
     _watch_optimizers()
     rb = _bender_of(network_fn)
     dev = torch.device(device if device is not None else next(network_fn.parameters()).device)
-    mflags = _lib.model_flags_from_env()
+    mflags = _lib.model_flags_from_env() | int(flags)
     key = (_wref(network_fine), _wref(rb), precision, str(dev), bool(getattr(network_fn, "approx_nonrigid_viewdirs", True)), mflags)
     fp = _fingerprint([network_fn, network_fine, rb])
     with _cache_lock:
@@ -546,7 +548,7 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
             del per[k]                                                         # entries of collected fine nets / benders
         hit = per.get(key)
         if rb is not None:
-            _by_bender[rb] = (weakref.ref(network_fn), _wref(network_fine), precision)
+            _by_bender[rb] = (weakref.ref(network_fn), _wref(network_fine), precision, int(flags))
         if hit is not None and hit[0] == fp:
             if isinstance(hit[1], Exception):
                 raise hit[1]
@@ -585,7 +587,7 @@ def model_of_bender(ray_bender, device):
     if nf is None or (ent[1] is not None and nfine is None):
         return None
     try:
-        model = get_model(nf, nfine, precision=precision, device=device)
+        model = get_model(nf, nfine, precision=precision, device=device, flags=ent[3])      # (the handle the last call used: same flags)
     except Unsupported:
         return None
     return model if model.trains_bender else None

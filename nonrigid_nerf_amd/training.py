@@ -415,6 +415,13 @@ class _GenericTrunk(torch.autograd.Function):
             d3 = dirs.detach().to(torch.float32).reshape(M, 3).contiguous()
             a.dirs = d3.data_ptr()
             saved.append(d3)
+        tcb = bool(getattr(net, "time_conditioned_baseline", False))
+        if tcb:         # (``ray_bias`` carries the rays' latent codes [N, latent size] here: they are columns of the two input layers)
+            codes = ray_bias.detach().to(torch.float32).contiguous()
+            assert tuple(codes.shape) == (N, int(net.pts_linears[0].weight.shape[1]) - int(net.input_ch))
+            a.latents = codes.data_ptr()
+            saved.append(codes)
+        ctx.tcb = tcb
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_generic_trunk_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_generic_trunk_forward")
         ctx.model, ctx.net, ctx.which, ctx.dims, ctx.views = model, net, int(which), (N, S, D, W, C_out), views
@@ -433,10 +440,11 @@ class _GenericTrunk(torch.autograd.Function):
             return (None,) * (6 + 2 * D + (8 if views else 2))
         n_freqs = (int(net.input_ch) - 3) // 6
         n_enc = 3 + 6 * n_freqs
+        n_lat = int(net.pts_linears[0].weight.shape[1]) - n_enc if ctx.tcb else 0
         skips = [int(k) for k in net.skips if 0 <= int(k) <= D - 2]
         g = g_raw4.contiguous().reshape(M, 4).float()
         d_pre = torch.empty_like(acts)
-        d_enc = torch.empty(2 if skips else 1, M, n_enc, dtype=torch.float32, device=dev)
+        d_enc = torch.empty(2 if skips else 1, M, n_enc + n_lat, dtype=torch.float32, device=dev)
         a = _lib.GenericTrunkArgs()
         a.struct_size = C.sizeof(_lib.GenericTrunkArgs)
         a.which, a.n_rays, a.n_samples = ctx.which, N, S
@@ -452,13 +460,19 @@ class _GenericTrunk(torch.autograd.Function):
         with torch.enable_grad():
             p = pts4[:, :3].detach().requires_grad_(ctx.needs_input_grad[0])
             enc = posenc(p, n_freqs)
-        d_pts = None
+        d_pts, d_codes = None, None
+        d_in = d_enc.sum(0)                 # gradient of the network's input row [encoding | latent code], both layers that read it
         if ctx.needs_input_grad[0]:
-            d_pts, = torch.autograd.grad(enc, p, d_enc.sum(0))
+            d_pts, = torch.autograd.grad(enc, p, d_in[:, :n_enc])
             d_pts = d_pts.view(N, S, 3)
         enc = enc.detach()
         cdt = acts.dtype
         enc_c = enc.to(cdt)
+        if ctx.tcb:                         # the input rows as the layers saw them; the codes' gradient: their columns summed over the ray's samples
+            codes = ctx.saved_tensors[-1]
+            enc_c = torch.cat([enc_c, codes.to(cdt)[:, None, :].expand(N, S, n_lat).reshape(M, n_lat)], 1)
+            if ctx.needs_input_grad[4]:
+                d_codes = d_in[:, n_enc:].reshape(N, S, n_lat).sum(1)
 
         def product(dy, x):
             # dy^T x [out, in] with an fp32 result.  The sum runs over ALL samples and the result is small: as ONE GEMM the library
@@ -514,7 +528,7 @@ class _GenericTrunk(torch.autograd.Function):
                       torch.cat([product(d_pre_v, feature), product(d_pre_v, encv.detach().to(cdt))], 1),   # views_linears[0] on [feature, enc(dir)]
                       d_pre_v.sum(0, dtype=torch.float32),
                       product(g[:, :3].to(cdt), hv), gsum[:3]]                                               # rgb_linear
-        return (d_pts, None, None, None, None, d_dirs, *grads)
+        return (d_pts, None, None, None, d_codes, d_dirs, *grads)
 
 
 def _generic_trunk_params(net):
@@ -1129,6 +1143,27 @@ def compute_divergence_loss(offsets_of_inputs, input_points, point_latents, ray_
     return torch.mean(divergence_loss.view(N_rays, -1), dim=-1)                              # rnh:69
 
 
+def _trains_on_compiled_kernels(net) -> bool:
+    """Whether the compiled training kernels (csrc/nrnerf_train*.h) cover this network: 8 layers, skip behind layer 4, 10 frequencies,
+    256 or 128 wide -- with the view-dependent head only 256 wide on 4 direction frequencies.  (The 128-wide trunk with that head RENDERS on
+    compiled kernels but trains on the run-time-parameterised one: render_rays_train asks for a generic handle then.)"""
+    views = bool(getattr(net, "use_viewdirs", False))
+    return _is_default_shape(net) and (not views or (int(net.W) == 256 and int(getattr(net, "input_ch_views", 0)) == 27))
+
+
+def _bender_has_compiled_shape(rb) -> bool:
+    """The reference's hard-coded bender (rnh:406-407: 5 -- or 7 -- layers of 64, rigidity 3 x 32, latent 32): the shapes the bender's
+    training kernels are compiled for, whatever the trunk (nrnerf_model_trains_bender)."""
+    lins = [l for l in rb.network if hasattr(l, "weight")]
+    rig = [l for l in rb.rigidity_network if hasattr(l, "weight")]
+    return (len(lins) in (5, 7) and int(lins[0].weight.shape[1]) == 3 + 32 and all(int(l.weight.shape[0]) == 64 for l in lins[:-1])
+            and len(rig) == 3 and int(rig[0].weight.shape[1]) == 3 and all(int(l.weight.shape[0]) == 32 for l in rig[:-1]))
+
+
+def _is_default_shape(net) -> bool:
+    return int(net.D) == 8 and int(net.W) in (256, 128) and list(net.skips) == [4] and int(net.input_ch) == 63
+
+
 def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp, pytest, ray_batch):
     """None when the native training path takes this call."""
     if pytest:
@@ -1142,31 +1177,28 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
     for net in (network_fn, network_fine if N_importance > 0 else None):
         if net is None:
             continue
-        if getattr(net, "time_conditioned_baseline", False):
-            if R._bender_of(network_fn) is not None or int(net.W) != 256 or int(net.pts_linears[0].weight.shape[1]) != int(net.input_ch) + 32:
-                return "time-conditioned baseline with a bender / a non-default trunk under autograd"
+        tcb = bool(getattr(net, "time_conditioned_baseline", False))
+        if tcb and R._bender_of(network_fn) is not None:
+            return "time-conditioned baseline with a bender under autograd"              # (train.py:574-576 rules it out as well)
         views = bool(getattr(net, "use_viewdirs", False))
-        default = int(net.D) == 8 and int(net.W) in (256, 128) and list(net.skips) == [4] and int(net.input_ch) == 63
-        compiled = default and (not views or (int(net.W) == 256 and int(getattr(net, "input_ch_views", 0)) == 27))
+        # (the time-conditioned baseline's compiled training kernels: the 256-wide trunk with a 32-float code)
+        compiled = _trains_on_compiled_kernels(net) and (not tcb or (int(net.W) == 256 and int(net.pts_linears[0].weight.shape[1]) == int(net.input_ch) + 32))
         if views:
             has_bender = R._bender_of(network_fn) is not None
             exact = has_bender and not getattr(net, "approx_nonrigid_viewdirs", True)
-            if exact and not compiled:
-                # (the Jacobian's tangent runs through the bender's compiled training kernels, which a generic handle does not carry)
-                return "exact Jacobian view directions on a non-default trunk under autograd"
+            if exact and not compiled and not _bender_has_compiled_shape(R._bender_of(network_fn)):
+                # (the Jacobian's tangent runs through the bender's compiled training kernels, which a generic handle carries for those shapes only)
+                return "exact Jacobian view directions with a non-default ray bender under autograd"
             if (not has_bender or exact) and ray_batch.shape[-1] < 11:
                 return "use_viewdirs without view directions in the ray batch"
-        if default and not compiled:
-            # (the 128-wide trunk with the view-dependent head RENDERS on its compiled kernels, so its handle is not a generic one, and
-            #  has no compiled training kernels)
-            return "view-dependent head on a non-default trunk under autograd"
         if not compiled:
             # outside the compiled set: the run-time-parameterised kernel trains the trunk, plain or view-dependent head
             # (_GenericTrunk; the library decides -- nrnerf_model_trains_generic -- and render_rays_train raises Unsupported when it says no)
             D, W = int(net.D), int(net.W)
             skips = [int(k) for k in net.skips if 0 <= int(k) <= D - 2]
-            if (getattr(net, "time_conditioned_baseline", False) or W % 4 or W > (480 if views else 512) or D < 1 or D > 16
-                    or len(skips) > 1 or (int(net.input_ch) - 3) % 6 or int(net.pts_linears[0].weight.shape[1]) != int(net.input_ch)):
+            n_in = int(net.pts_linears[0].weight.shape[1])
+            if (W % 4 or W > (480 if views else 512) or D < 1 or D > 16 or len(skips) > 1 or (int(net.input_ch) - 3) % 6
+                    or (n_in != int(net.input_ch) if not tcb else not (int(net.input_ch) < n_in <= int(net.input_ch) + 64))):
                 return "non-default trunk under autograd"
             if views and ((int(net.input_ch_views) - 3) % 6 or int(net.views_linears[0].weight.shape[1]) != W + int(net.input_ch_views)
                           or int(net.views_linears[0].weight.shape[0]) > W or int(net.feature_linear.weight.shape[0]) != W):
@@ -1189,7 +1221,21 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     precision = "bf16" if R.get_precision() == "f16" else R.get_precision()
     rb = R._bender_of(network_fn)
     latents = additional_pixel_information.get("ray_bending_latents") if additional_pixel_information else None
-    model = R.get_model(network_fn, network_fine if N_importance > 0 else None, precision=precision, device=dev)
+    nets = [network_fn] + ([network_fine] if (N_importance > 0 and network_fine is not None) else [])
+    # (a shape that renders on compiled kernels without having compiled TRAINING kernels: a generic handle of its own)
+    def renders_compiled_trains_generic(n):
+        if not _is_default_shape(n):
+            return False
+        if getattr(n, "time_conditioned_baseline", False) and not (int(n.W) == 256 and int(n.pts_linears[0].weight.shape[1]) == int(n.input_ch) + 32):
+            return True
+        return not _trains_on_compiled_kernels(n)
+    forced = _lib.MODEL_FORCE_GENERIC if any(renders_compiled_trains_generic(n) for n in nets) else 0
+    if rb is not None and any(getattr(n, "use_viewdirs", False) and not getattr(n, "approx_nonrigid_viewdirs", True) and not _trains_on_compiled_kernels(n)
+                              for n in nets):
+        # exact Jacobian directions off the compiled set: computed here (the tangent of the divergence kernels); the handle is one for the
+        # training entry points only (the generic RENDER kernel has no Jacobian directions, so the library would refuse the description)
+        forced |= _lib.MODEL_PY_TRAINING_HANDLE
+    model = R.get_model(network_fn, network_fine if N_importance > 0 else None, precision=precision, device=dev, flags=forced)
     if model.generic and not model.trains_generic:
         raise R.Unsupported("this architecture has no training kernels (view-dependent head / time-conditioned baseline off the compiled set)")
     trunk = _GenericTrunk if model.generic else _Trunk
@@ -1258,9 +1304,12 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             # skip layer; constant along a ray, so its columns act as per-ray biases W[:, latent columns] . latent -- formed here
             # (library GEMMs under autograd: their backward yields the codes' and those columns' gradients), added in the kernel
             n_enc, lat = int(net.input_ch), latents.to(torch.float32)
-            sk = int(list(net.skips)[0]) + 1
-            ray_bias = torch.stack([F.linear(lat, net.pts_linears[0].weight[:, n_enc:n_enc + lat.shape[1]]),
-                                    F.linear(lat, net.pts_linears[sk].weight[:, n_enc:n_enc + lat.shape[1]])], 1)
+            if model.generic:               # (_GenericTrunk: the codes themselves, as input columns)
+                ray_bias = lat
+            else:
+                sk = int(list(net.skips)[0]) + 1
+                ray_bias = torch.stack([F.linear(lat, net.pts_linears[0].weight[:, n_enc:n_enc + lat.shape[1]]),
+                                        F.linear(lat, net.pts_linears[sk].weight[:, n_enc:n_enc + lat.shape[1]])], 1)
         dirs = None
         if net.use_viewdirs:
             # view-dependent head (rnh:284-304): the direction of every sample -- the finite differences of the bent points

@@ -534,9 +534,9 @@ def test_boundary_contract_errors_and_fallback():
         out["rgb_map"].sum().backward()
         assert all(p_.grad is not None and bool(torch.isfinite(p_.grad).all()) and float(p_.grad.abs().max()) > 0
                    for p_ in list(cw2.pts_linears.parameters()) + list(cw2.output_linear.parameters()))
-        # ... a training call the native path has no kernels for (the same width with a view-dependent head on exact Jacobian directions:
-        # rendered by the generic kernel, but not trained) still goes to the reference
-        cfgw = SceneConfig(N_importance=0, netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False)
+        # ... a training call the native path has no kernels for (the same width with exact Jacobian directions and a bender of another
+        # shape than the two the bender's training kernels are compiled for: rendered by the generic kernel, but not trained) still goes to the reference
+        cfgw = SceneConfig(N_importance=0, netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False, bend_hidden=96)
         rbw3, cw3, _ = build_modules(make_scene(cfgw, 0), device=DEV)
         rw3, lw3 = make_rays(8, 0, cfgw)
         out = FakeTrain.batchify_rays(rw3.to(DEV), {"ray_bending_latents": lw3.to(DEV)}, network_fn=cw3, network_query_fn=None, N_samples=64)

@@ -194,13 +194,27 @@ def _loss(out, detailed):
                                                            # ... with the view-dependent head (the rays' own directions; finite differences of bent points)
                                                            (1.0, 0.5, False, dict(N_importance=64, netwidth=192, netdepth=6, use_viewdirs=True, ray_bending=False)),
                                                            (1.0, 1.0, True, dict(N_samples=48, N_importance=37, netwidth=128, netdepth=4, skips=(1,), use_viewdirs=True,
-                                                                                 multires_views=2, netwidth_fine=480, netdepth_fine=3))],
+                                                                                 multires_views=2, netwidth_fine=480, netdepth_fine=3)),
+                                                           # the 128-wide trunk with the view-dependent head: rendered by compiled kernels, trained on a
+                                                           # generic handle that render_rays_train asks for (MODEL_FORCE_GENERIC)
+                                                           (1.0, 0.0, False, dict(N_importance=64, netwidth=128, use_viewdirs=True)),
+                                                           # the time-conditioned baseline off the compiled set: the latent code as input columns of the
+                                                           # run-time-parameterised kernel, its gradient from the same two outputs as the encoding's
+                                                           (1.0, 1.0, False, dict(N_samples=48, N_importance=37, ray_bending=False, time_conditioned_baseline=True,
+                                                                                  netwidth=192, netdepth=6)),
+                                                           (1.0, 0.0, False, dict(N_importance=64, ray_bending=False, time_conditioned_baseline=True, use_viewdirs=True,
+                                                                                  netwidth=128, latent_size=16)),
+                                                           # exact Jacobian directions off the compiled set: the tangent through the bender's compiled training
+                                                           # kernels (a generic handle carries them when the bender has the reference's hard-coded shape)
+                                                           (1.0, 1.0, True, dict(N_samples=48, N_importance=37, netwidth=192, netdepth=6, use_viewdirs=True,
+                                                                                 approx_nonrigid_viewdirs=False))],
                          ids=["deterministic", "stochastic_detailed_ragged", "no_bender_64_128", "narrow_128", "lindisp_white_bkgd",
                               "viewdirs_detailed_ragged", "viewdirs_no_bender", "config4_viewdirs_deep_bender", "time_conditioned_ragged",
                               "time_conditioned_viewdirs", "exact_viewdirs_detailed_ragged", "exact_viewdirs_deep_bender",
                               "350_samples_per_ray", "192_plus_128", "514_samples_detailed", "900_samples",
                               "generic_w192_d6_detailed_ragged", "generic_w320_d5_skip2_L6_no_bender", "generic_no_skip_w64_fine_w132", "generic_w512_d2_500_samples",
-                              "generic_viewdirs_w192_d6_no_bender", "generic_viewdirs_w128_d4_fine_w480_detailed_ragged"])
+                              "generic_viewdirs_w192_d6_no_bender", "generic_viewdirs_w128_d4_fine_w480_detailed_ragged", "generic_forced_w128_viewdirs",
+                              "generic_time_conditioned_w192_d6_ragged", "generic_time_conditioned_viewdirs_w128_latent16", "generic_exact_viewdirs_w192_d6_detailed_ragged"])
 @pytest.mark.parametrize("bender", ["torch_ops", "native"])
 def test_fp32_gradients_vs_oracle_autograd(perturb, noise, detailed, cfg_kw, bender):
     """Every parameter of every network + the latent codes, fp32 mode, against the oracle's autograd (eager torch on the
@@ -331,14 +345,18 @@ def test_bf16_gradients_point_the_same_way(width, detailed, views, S, I):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bender", [False, True], ids=["no_bender", "bender"])
+@pytest.mark.parametrize("bender", [False, "torch_ops", "native"], ids=["no_bender", "torch_ops_bender", "native_bender"])
 def test_generic_training_sees_an_optimiser_step_in_forward_and_backward_weights(bender):
     """A non-compiled architecture keeps TWO images of every trunk weight on the device -- the forward program's and the transposed
     one of the backward-data program (csrc/nrnerf_api.cpp::gen_pack_mlp_bwd) -- and an optimiser step must reach both through the
     device-side re-pack (nrnerf_model_update_device: the source maps of the transposed fragments).  Gradients after a large step
     against the oracle's autograd on the stepped weights, fp32 mode, 2e-3 of each tensor's scale as in the test above (stale
-    transposed weights would leave d_pre, hence every gradient but the head's, at the old weights' values)."""
-    cfg = SceneConfig(N_importance=64, netwidth=192, netdepth=6, netwidth_fine=320, netdepth_fine=5, skips=(2,), ray_bending=bender)
+    transposed weights would leave d_pre, hence every gradient but the head's, at the old weights' values).  ``native_bender``: the bender's
+    compiled training kernels on the generic handle (its bender has the reference's hard-coded shape) -- their weight images are re-packed
+    by the same call; bent points then differ from the oracle's by ulps, which the 2^9-frequency encoding turns into 1e-2 of a gradient's
+    scale (the golden test's docstring): 2e-2 / 5e-2 bars there."""
+    from nonrigid_nerf_amd import training
+    cfg = SceneConfig(N_importance=64, netwidth=192, netdepth=6, netwidth_fine=320, netdepth_fine=5, skips=(2,), ray_bending=bool(bender))
     scene = make_scene(cfg, 1)
     rays, latents = make_rays(96, 3, cfg)
     rb, coarse, fine = _modules(scene)
@@ -363,6 +381,8 @@ def test_generic_training_sees_an_optimiser_step_in_forward_and_backward_weights
         return z
 
     R.Model.update_from_device = counting
+    saved = (training.NATIVE_BENDER, training.BATCHED_BENDER, training.SPLIT_FINE_BENDER)
+    training.NATIVE_BENDER, training.BATCHED_BENDER, training.SPLIT_FINE_BENDER = bender == "native", False, bender == "native"
     try:
         ours()
         torch.manual_seed(5)
@@ -372,6 +392,7 @@ def test_generic_training_sees_an_optimiser_step_in_forward_and_backward_weights
         z = ours()
     finally:
         R.Model.update_from_device = orig
+        training.NATIVE_BENDER, training.BATCHED_BENDER, training.SPLIT_FINE_BENDER = saved
     assert calls["dev"] >= 1, "the second call did not take the device-side re-pack"
     _, _, g_ref, _ = _oracle_grads(scene, rays, latents, 0, 0.0, 0.0, False, z_override=z, weights=named)
     fails, worst = [], 0.0
@@ -380,9 +401,9 @@ def test_generic_training_sees_an_optimiser_step_in_forward_and_backward_weights
             continue
         err = float((named[(part, name)].grad - gr).abs().max()) / (float(gr.abs().max()) + 1e-12)
         worst = max(worst, err)
-        if err > (5e-2 if part == "bender" else 2e-3):
+        if err > (5e-2 if part == "bender" else (2e-2 if bender == "native" else 2e-3)):
             fails.append((part, name, err))
-    print(f"\n[generic training after a step, fp32, {'with' if bender else 'no'} bender] worst error / scale {worst:.1e}; device re-packs {calls['dev']}")
+    print(f"\n[generic training after a step, fp32, {bender or 'no'} bender] worst error / scale {worst:.1e}; device re-packs {calls['dev']}")
     assert not fails, fails
 
 

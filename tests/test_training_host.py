@@ -97,17 +97,18 @@ def test_eligibility_of_training_calls():
     # round 5: a plain trunk outside the compiled set trains on the run-time-parameterised kernel (training._GenericTrunk) ...
     assert T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu) is None
     for kw in (dict(netwidth=320, netdepth=5, skips=(2,), multires=6), dict(netwidth=64, netdepth=3, skips=()), dict(netwidth=512, netdepth=2, skips=(0,)),
-               dict(netwidth=192, use_viewdirs=True), dict(netwidth=480, netdepth=3, use_viewdirs=True, multires_views=2)):      # (and with the view-dependent head)
+               dict(netwidth=192, use_viewdirs=True), dict(netwidth=480, netdepth=3, use_viewdirs=True, multires_views=2),      # (and with the view-dependent head)
+               dict(netwidth=128, use_viewdirs=True),      # (renders on compiled kernels, trains on a generic handle of its own: render_rays_train forces one)
+               dict(netwidth=192, ray_bending=False, time_conditioned_baseline=True), dict(ray_bending=False, time_conditioned_baseline=True, latent_size=16),
+               dict(netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False), dict(netwidth=128, use_viewdirs=True, approx_nonrigid_viewdirs=False, bend_depth=7)):
         _, cw, fw = build_modules(make_scene(SceneConfig(N_importance=64, **kw), 0))
         assert T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu11) is None, kw
-    # ... but not with a width the kernel's 4-element rows do not divide, two skip connections, widths beyond the kernel's, the time-conditioned
-    # baseline, exact Jacobian directions (their tangent runs through the bender's compiled training kernels), or the 128-wide trunk with the
-    # view-dependent head (rendered by compiled kernels, so not a generic handle; no compiled training kernels)
+    # ... but not with a width the kernel's 4-element rows do not divide, two skip connections, widths beyond the kernel's,
+    # or exact Jacobian directions with a bender of another shape (their tangent runs through the bender's compiled training kernels)
     for kw, why in ((dict(netwidth=190), "non-default trunk"), (dict(netwidth=192, skips=(2, 5)), "non-default trunk"), (dict(netwidth=640), "non-default trunk"),
                     (dict(netwidth=512, use_viewdirs=True), "non-default trunk"),
-                    (dict(netwidth=192, ray_bending=False, time_conditioned_baseline=True), "time-conditioned baseline"),
-                    (dict(netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False), "exact Jacobian"),
-                    (dict(netwidth=128, use_viewdirs=True), "view-dependent head on a non-default trunk")):
+                    (dict(netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False, bend_hidden=96), "exact Jacobian"),
+                    (dict(netwidth=128, use_viewdirs=True, approx_nonrigid_viewdirs=False, latent_size=16), "exact Jacobian")):
         _, cw, fw = build_modules(make_scene(SceneConfig(N_importance=64, **kw), 0))
         assert why in T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu11), kw
 
