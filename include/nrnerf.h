@@ -663,6 +663,10 @@ int nrnerf_profile_end(nrnerf_model* model, nrnerf_profile* out);   /* synchroni
  * 11 / 12 = the coarse / fine trunk of ANY plain-headed architecture for the width-class 16x16x32 kernel: the layers' fragment blocks
  *   back to back (first layer, pts_linears[1 ..], output_linear), each padded to a whole number of 4-unit ring periods, + a copy of the
  *   first two units behind the last; width padded to a multiple of 64 with zeros.
+ * 13 / 14 = the backward-data PROGRAM of the run-time-parameterised kernel for the coarse / fine network (training of a non-compiled
+ *   architecture, nrnerf_generic_trunk_backward): transposed layers in reverse order; the unit table holds n_layers, per layer the 11
+ *   integers of 7 / 8 plus {save slot, mask slot, column offsets of the two sources in the hidden buffer} (dst 4 / 5 / 6: straight to
+ *   d_enc0 / d_enc1 / d_encv), then the three padded widths, the latent size and the hidden-buffer column where the rows of d raw start.
  * Any output pointer may be NULL to query sizes only.  Used by the CPU-side packing tests. */
 typedef struct nrnerf_packed_info {
     uint64_t stream_bytes;     /* fragment stream */

@@ -1554,6 +1554,26 @@ int nrnerf_pack_host(const nrnerf_model_desc* desc, int which, nrnerf_packed_inf
         if (!x16_eligible(*desc, *mm, /*any_16bit=*/true)) return NRNERF_ERR_UNSUPPORTED;
         rc = NRNERF_OK;
         pack_x16(*desc, *mm, pk);
+    } else if (which == 13 || which == 14) {    // backward-data programs of the run-time-parameterised kernel (training): 13 = coarse, 14 = fine
+        GenProgram gb, gc, gf;
+        rc = gen_pack_all(*desc, nullptr, gb, gc, gf);
+        const nrnerf_mlp_desc* mm = (which == 14) ? desc->fine : desc->coarse;
+        if (rc == NRNERF_OK && !mm) rc = NRNERF_ERR_INVALID;
+        if (rc == NRNERF_OK && !gen_trainable(*desc, *mm)) rc = NRNERF_ERR_UNSUPPORTED;
+        if (rc == NRNERF_OK) {
+            GenProgram g;
+            gen_pack_mlp_bwd(*desc, *mm, g, nullptr);
+            pk = g.pk;
+            // unit table: n_layers, per layer 15 integers (GenLayer incl. save / mask slot and source offsets), then ke, kv, kh, lat, the d raw column
+            pk.unit_off.assign(1, (uint32_t)g.proto.n_layers);
+            for (int l = 0; l < g.proto.n_layers; ++l) {
+                const GenLayer& y = g.proto.layer[l];
+                for (int v : {y.w_frag, y.bias_tile, y.nt, y.src0, y.ns0, y.src1, y.ns1, y.dst, y.relu, y.o_col, y.o_rows, y.save_idx, y.mask_idx, y.boff0, y.boff1})
+                    pk.unit_off.push_back((uint32_t)v);
+            }
+            for (int v : {g.proto.ke, g.proto.kv, g.proto.kh, g.proto.lat, gen_draw_col(*mm)}) pk.unit_off.push_back((uint32_t)v);
+            pk.nunits = (int)pk.unit_off.size() - 1;
+        }
     } else if (which >= 7 && which <= 9) {      // layer programs of the run-time-parameterised kernel: 7 = coarse, 8 = fine, 9 = ray bender
         GenProgram gb, gc, gf;
         rc = gen_pack_all(*desc, nullptr, gb, gc, gf);

@@ -1026,6 +1026,126 @@ def test_generic_layer_programs_reproduce_the_networks(cfg_kw, precision):
         assert np.abs(O[:, :3] - h.numpy()).max() <= 1e-5 and np.abs(O[:, 3:4] - r.numpy()).max() <= 1e-5
 
 
+def _run_generic_bwd_program(info, stream, units, bias, precision, d_raw, acts):
+    """The backward-data program (nrnerf_pack_host 13 / 14) as gen_kernel mode 2 walks it: H starts as zeros with the rows of d raw at the
+    program's d-raw column; every layer = transposed fragments against H (from a column offset per source), outputs masked by the saved
+    activation of slot mask_idx, written back to H and kept as d_pre[save_idx], or (dst 4 / 5 / 6) handed out."""
+    f32 = precision == "f32"
+    KH = 4 if f32 else 8
+    KS = 2 * KH
+    assert info.frag_bytes == 1024
+    u = units.view(np.int32).astype(np.int64)           # (slots of -1 = none)
+    n_layers = int(u[0])
+    layers = u[1:1 + 15 * n_layers].reshape(n_layers, 15)
+    ke, kv, kh, lat, draw_col = (int(x) for x in u[1 + 15 * n_layers:1 + 15 * n_layers + 5])
+    n = d_raw.shape[0]
+    H = np.zeros((n, kh))
+    H[:, draw_col:draw_col + d_raw.shape[1]] = d_raw
+    words = stream.view(np.float32).astype(np.float64) if f32 else None
+    raw16 = None if f32 else stream.view(np.uint16)
+    d_pre, outs = {}, {}
+    for (w_frag, bias_tile, nt, src0, ns0, src1, ns1, dst, relu, o_col, o_rows, save_idx, mask_idx, boff0, boff1) in layers:
+        assert src0 == 1 and (ns1 == 0 or src1 == 1) and relu == 0 and not bias[bias_tile * 32:(bias_tile + nt) * 32].any()
+        ns = ns0 + ns1
+        out = np.zeros((n, 32 * nt))
+        for t in range(nt):
+            acc = np.zeros((32, n))
+            for sl in range(ns):
+                s, boff = (sl, boff0) if sl < ns0 else (sl - ns0, boff1)
+                fi = w_frag + t * ns + sl
+                if f32:
+                    fr = words[fi * 256:(fi + 1) * 256].reshape(64, 4)
+                else:
+                    bits = raw16[fi * 512:(fi + 1) * 512].reshape(64, 8)
+                    fr = bits.view(np.float16).astype(np.float64) if precision == "f16" else (bits.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+                A = np.zeros((32, KS))
+                for lane in range(64):
+                    A[lane & 31, KH * (lane >> 5):KH * (lane >> 5) + KH] = fr[lane]
+                acc += A @ H[:, boff + s * KS:boff + (s + 1) * KS].T
+            out[:, 32 * t:32 * t + 32] = acc.T
+        if dst == 1:
+            if mask_idx >= 0:
+                w = acts[mask_idx].shape[1]
+                out[:, :w] *= acts[mask_idx] > 0
+                out[:, w:] = 0.0
+            H[:, :32 * nt] = out
+            if save_idx >= 0:
+                d_pre[save_idx] = out.copy()
+        else:
+            assert dst in (4, 5, 6)
+            outs[dst] = out[:, :o_rows]
+    return d_pre, outs
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg_kw", [dict(netdepth=6, netwidth=192, netdepth_fine=5, netwidth_fine=320, skips=(2,), multires=8, latent_size=16),
+                                    dict(netdepth=4, netwidth=96, netwidth_fine=160, multires=6, multires_views=2, use_viewdirs=True, skips=(1,)),
+                                    dict(netdepth=3, netwidth=72, skips=(), ray_bending=False),
+                                    dict(netdepth=5, netwidth=132, skips=(2,), multires=5, latent_size=24, ray_bending=False, time_conditioned_baseline=True,
+                                         use_viewdirs=True, multires_views=3)],
+                         ids=["192_320_skip2", "viewdirs_96_160", "no_skip_72", "time_conditioned_viewdirs_132"])
+def test_generic_backward_data_programs_reproduce_autograd(cfg_kw, precision):
+    """Training of a non-compiled architecture (csrc/nrnerf_api.cpp::gen_pack_mlp_bwd, gen_kernel mode 2): the transposed layer program,
+    run in numpy as the kernel walks it on the activations torch saved, must give torch's (float64) gradient of every pre-activation, of the
+    network input [encoding | latent code] (both layers that read it) and of the direction encoding -- plain and view-dependent heads
+    (rnh:284-304: d sigma joins the colour branch's gradient in ONE layer [feature_linear^T | alpha_linear^T]), skip at any layer / none."""
+    cfg = SceneConfig(N_importance=64, **cfg_kw)
+    scene, (rb, coarse, fine), info_c, st_c, un_c, bi_c = _pack(cfg, precision, 13)
+    _, _, info_f, st_f, un_f, bi_f = _pack(cfg, precision, 14)
+    g = np.random.default_rng(7)
+    n = 24
+    pts = g.normal(size=(n, 3)) * 0.3
+    dirs = g.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    lat = g.normal(size=(n, cfg.latent_size)) * 0.1
+    enc = _posenc(pts, cfg.multires)
+    encd = _posenc(dirs, cfg.multires_views) if cfg.use_viewdirs else np.zeros((n, 3))
+    x_in = np.concatenate([enc, lat], -1) if cfg.time_conditioned_baseline else enc
+    d_raw = g.normal(size=(n, 4))
+    tol = 1e-5 if precision == "f32" else 0.06
+    for net, info, st, un, bi in ((coarse, info_c, st_c, un_c, bi_c), (fine, info_f, st_f, un_f, bi_f)):
+        D = len(net.pts_linears)
+        x = torch.from_numpy(x_in).requires_grad_(True)
+        ev = torch.from_numpy(encd).requires_grad_(True)
+        zs, hs, h = [], [], x
+        for i, lin in enumerate(net.pts_linears):
+            z = F.linear(h, lin.weight.double(), lin.bias.double())
+            z.retain_grad()
+            zs.append(z)
+            h = F.relu(z)
+            hs.append(h)
+            if i in net.skips and i < D - 1:
+                h = torch.cat([x, h], -1)
+        if net.use_viewdirs:
+            alpha = F.linear(h, net.alpha_linear.weight.double(), net.alpha_linear.bias.double())
+            feat = F.linear(h, net.feature_linear.weight.double(), net.feature_linear.bias.double())
+            feat.retain_grad()
+            zv = F.linear(torch.cat([feat, ev], -1), net.views_linears[0].weight.double(), net.views_linears[0].bias.double())
+            zv.retain_grad()
+            hv = F.relu(zv)
+            out = torch.cat([F.linear(hv, net.rgb_linear.weight.double(), net.rgb_linear.bias.double()), alpha], -1)
+        else:
+            out = F.linear(h, net.output_linear.weight.double(), net.output_linear.bias.double())[:, :4]
+        (out * torch.from_numpy(d_raw)).sum().backward()
+        acts = {i: hs[i].detach().numpy() for i in range(D)}
+        if net.use_viewdirs:
+            acts[D] = feat.detach().numpy()
+            acts[D + 1] = hv.detach().numpy()
+        d_pre, outs = _run_generic_bwd_program(info, st, un, bi, precision, d_raw, acts)
+
+        def close(got, want, what):
+            assert np.abs(got - want).max() <= tol * max(1e-3, np.abs(want).max()), (what, np.abs(got - want).max(), np.abs(want).max())
+        for i in range(D):
+            close(d_pre[i][:, :zs[i].shape[1]], zs[i].grad.numpy(), f"d_pre[{i}]")
+        d_in = outs[4] + (outs[5] if 5 in outs else 0.0)
+        assert (5 in outs) == any(0 <= int(k) <= D - 2 for k in net.skips)
+        close(d_in, x.grad.numpy(), "d input")
+        if net.use_viewdirs:
+            close(d_pre[D][:, :feat.shape[1]], feat.grad.numpy(), "d feature")
+            close(d_pre[D + 1][:, :zv.shape[1]], zv.grad.numpy(), "d pre of the colour branch")
+            close(outs[6], ev.grad.numpy(), "d direction encoding")
+
+
 def test_compiled_shapes_are_not_generic_and_exact_directions_stay_unsupported_there():
     """nrnerf_pack_host 7 works for any supported shape (also a compiled one); exact Jacobian directions have no generic kernel."""
     cfg = SceneConfig(N_importance=64, netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False)
