@@ -471,13 +471,15 @@ def library_gemm_tflops(dev, precision):
 
 
 def kernel_source_sha16(train=False):
-    """Hash of the device code the rendering kernels are built from (csrc/*.h, *.hip: plans, kernels, launchers; the
-    training-only kernels nrnerf_train* excluded): identifies the profiled kernels independently of the build (a rebuilt
-    .so need not be byte-identical) and of host-only edits (nrnerf_api.cpp).  ``train=True``: the same over ALL device
-    sources, training kernels included -- what the training profiles (profiles/*_train_*) are stamped with."""
+    """Hash of the device code the rendering kernels OF THE COMPILED ARCHITECTURES are built from (csrc/*.h, *.hip: plans, kernels,
+    launchers; excluded: the training-only kernels nrnerf_train* and the run-time-parameterised kernel nrnerf_generic*, which no
+    workload that looks a profile up by this hash launches -- pmc_traffic below answers for the default architecture only):
+    identifies the profiled kernels independently of the build (a rebuilt .so need not be byte-identical) and of host-only edits
+    (nrnerf_api.cpp).  ``train=True``: the same over ALL device sources, training kernels included -- what the training
+    profiles (profiles/*_train_*) are stamped with."""
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "nonrigid_nerf_amd", "csrc")
-    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hip")) and (train or not f.startswith("nrnerf_train"))):
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".hip")) and (train or not f.startswith(("nrnerf_train", "nrnerf_generic")))):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

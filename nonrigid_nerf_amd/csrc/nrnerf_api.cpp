@@ -27,6 +27,8 @@
 #include "nrnerf_gx16_plan.h"
 #include "nrnerf_plan.h"
 
+// the run-time-parameterised kernel's TRAINING instantiations (nrnerf_generic.hip; the rendering ones: launch_generic, nrnerf_kernels.h)
+namespace nrn { hipError_t launch_generic_train(int precision, const GenArgs& a, int num_cus, hipStream_t stream); }
 using namespace nrn;
 
 #ifndef NRN_WGRAD_SYNC_DEFAULT
@@ -2279,7 +2281,7 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
         g.mask = a->acts; g.save = a->d_pre;
         g.gout[0] = a->d_enc0; g.gout[1] = a->d_enc1; g.gout[2] = a->d_encv; g.gout_w = tn.in_w; g.gout_w2 = tn.dv;
     }
-    return launch_generic(m->precision, g, m->num_cus, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+    return launch_generic_train(m->precision, g, m->num_cus, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 int loss_call(const nrnerf_loss_args* a, bool backward, void* hip_stream) {
     if (!a || a->struct_size != sizeof(nrnerf_loss_args) || a->n_rays < 0 || a->n_samples < 0 || !a->rgb_map || !a->target) return NRNERF_ERR_INVALID;

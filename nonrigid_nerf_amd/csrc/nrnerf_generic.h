@@ -80,8 +80,10 @@ __device__ __forceinline__ f32x16 gen_mfma(const typename GenTypes<PX>::gfrag& a
 }
 
 // MAXT: output tiles per wave and layer the instantiation has accumulators for (2: widths <= 256, half the registers, two
-// workgroups per CU; 4: widths <= 512)
-template <class P, int NSB, int MAXT>
+// workgroups per CU; 4: widths <= 512).  TRAIN: the training entry points' instantiations (nrnerf_generic_trunk_forward / _backward:
+// saved activations, relu masks, the backward-data mode, per-sample directions, outputs straight to memory) -- compiled out of the
+// rendering instantiations, whose register allocation they would otherwise cost (35 .. 95 spilled registers, measured on the ISA)
+template <class P, int NSB, int MAXT, bool TRAIN>
 __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen_kernel(const GenArgs a) {
     using PE = typename GenTypes<P>::PE;
     using elem = typename GenTypes<P>::elem;
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
 
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const long long m0 = tile * NS;
-        if (a.mode == 2) {
+        if (TRAIN && a.mode == 2) {
             // ---- backward-data (training): H = the rows of d raw (columns >= draw_ch zero) in the model's type; no points, no E / V
             for (int idx = tid; idx < NS * 16; idx += GEN_WAVES * 64) {
                 const int n = idx >> 4, c = idx & 15;
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             }
         }
         // ---- points (and view directions) of the tile's samples
-        if (a.mode != 2 && tid < NS) {
+        if ((!TRAIN || a.mode != 2) && tid < NS) {
             const long long m = (m0 + tid < M) ? m0 + tid : M - 1;
             const int ray = (int)(m / S), si = (int)(m % S);
             const float* rp = a.rays + (size_t)ray * a.ray_stride;
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             }
             float d[3] = {0.f, 0.f, 0.f};
             if (a.mode == 1 && a.LV >= 0) {
-                if (a.dirs) {                    // training: the caller's direction of this sample
+                if (TRAIN && a.dirs) {           // training: the caller's direction of this sample
                     const float* dp = a.dirs + (size_t)m * 3;
                     d[0] = dp[0]; d[1] = dp[1]; d[2] = dp[2];
                 } else if (a.dirs_from_pts) {           // rnh:339-351: backward difference of the bent points, sample 0 copies sample 1
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
         // ---- E and V rows.  network: E = Embedder(point) [, latent], V = Embedder(direction) (rnh:120-150: [x, sin(2^0 x),
         //      cos(2^0 x), sin(2^1 x), ...]); bender: E = [point, latent] (rnh:525), V = [point] (rnh:546)
         const int enc_w = (a.mode == 1) ? 3 + 6 * a.L : 3;
-        for (int idx = tid; a.mode != 2 && idx < NS * a.ke; idx += GEN_WAVES * 64) {
+        for (int idx = tid; (!TRAIN || a.mode != 2) && idx < NS * a.ke; idx += GEN_WAVES * 64) {
             const int n = idx / a.ke, c = idx - n * a.ke;
             const float* pt = Pt + n * 8;
             float v = 0.f;
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             }
             E[(size_t)n * se + c] = gen_cvt<PE>(v);
         }
-        for (int idx = tid; a.mode != 2 && idx < NS * a.kv; idx += GEN_WAVES * 64) {
+        for (int idx = tid; (!TRAIN || a.mode != 2) && idx < NS * a.kv; idx += GEN_WAVES * 64) {
             const int n = idx / a.kv, c = idx - n * a.kv;
             const float* pt = Pt + n * 8 + (a.mode == 1 ? 4 : 0);
             float v = 0.f;
@@ -257,9 +259,9 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
             };
             struct TagE { using type = PE; };
             struct TagH { using type = P; };
-            if (ly.src0 == GB_H) run(TagH{}, H + ly.boff0, sh, 0, ly.ns0, true); else run(TagE{}, src_ptr(ly.src0), src_stride(ly.src0), 0, ly.ns0, true);
+            if (ly.src0 == GB_H) run(TagH{}, H + (TRAIN ? ly.boff0 : 0), sh, 0, ly.ns0, true); else run(TagE{}, src_ptr(ly.src0), src_stride(ly.src0), 0, ly.ns0, true);
             if (ly.ns1 > 0) {
-                if (ly.src1 == GB_H) run(TagH{}, H + ly.boff1, sh, ly.ns0, ly.ns1, false); else run(TagE{}, src_ptr(ly.src1), src_stride(ly.src1), ly.ns0, ly.ns1, false);
+                if (ly.src1 == GB_H) run(TagH{}, H + (TRAIN ? ly.boff1 : 0), sh, ly.ns0, ly.ns1, false); else run(TagE{}, src_ptr(ly.src1), src_stride(ly.src1), ly.ns0, ly.ns1, false);
             }
             if (li + 1 < a.n_layers) first_frags(li + 1);
             __syncthreads();                               // every wave has read the layer's inputs: H may be overwritten
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
 #pragma unroll
                     for (int sb = 0; sb < NSB; ++sb) {
                         const int n = sb * 32 + j;
-                        if (ly.dst >= GB_OUT0) {          // training, backward-data: an encoding's gradient, straight to memory
+                        if (TRAIN && ly.dst >= GB_OUT0) { // training, backward-data: an encoding's gradient, straight to memory
                             float* go = a.gout[ly.dst - GB_OUT0];
                             const int gw = ly.dst == GB_OUT2 ? a.gout_w2 : a.gout_w;
 #pragma unroll
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
                                 float v[4];
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) v[c] = ly.relu ? fmaxf(acc[i][sb][4 * q + c], 0.0f) : acc[i][sb][4 * q + c];
-                                if (a.mask && ly.mask_idx >= 0) {  // training, backward-data: d pre = d h where the forward activation passed the relu
+                                if (TRAIN && a.mask && ly.mask_idx >= 0) {  // training, backward-data: d pre = d h where the forward activation passed the relu
                                     const int col = 32 * t + 8 * q + 4 * h;
                                     const bool live = m0 + n < M && col + 3 < a.save_w;
                                     const elem* mp = (const elem*)a.mask + (size_t)ly.mask_idx * a.save_stride + (size_t)(live ? m0 + n : 0) * a.save_w + (live ? col : 0);
@@ -315,7 +317,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
                 }
             }
             __syncthreads();
-            if (a.save && ly.save_idx >= 0) {  // training: this layer's H rows (forward: activations; backward: d pre) to memory, 4 elements per lane
+            if (TRAIN && a.save && ly.save_idx >= 0) {  // training: this layer's H rows (forward: activations; backward: d pre) to memory, 4 elements per lane
                 const int vpr = a.save_w >> 2;           // (save_w % 4 == 0: the launcher checks)
                 elem* sp = (elem*)a.save + (size_t)ly.save_idx * a.save_stride;
                 for (int idx = tid; idx < NS * vpr; idx += GEN_WAVES * 64) {
@@ -333,7 +335,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
         }
 
         // ---- epilogue
-        if (a.mode != 2 && tid < NS && m0 + tid < M) {
+        if ((!TRAIN || a.mode != 2) && tid < NS && m0 + tid < M) {
             const long long m = m0 + tid;
             const float* o = O + tid * 8;
             if (a.mode == 1) {
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(GEN_WAVES * 64, (NSB * MAXT <= 4) ? 2 : 1) gen
     }
 }
 
-template <class P, int NSB, int MAXT>
+template <class P, int NSB, int MAXT, bool TRAIN>
 static hipError_t launch_gen_t(const GenArgs& a_in, int num_cus, hipStream_t stream) {
     constexpr int PAD = GenTypes<P>::PAD, NS = 32 * NSB;
     const size_t es = sizeof(typename GenTypes<P>::elem);
@@ -385,7 +387,7 @@ static hipError_t launch_gen_t(const GenArgs& a_in, int num_cus, hipStream_t str
     a.bias_in_lds = (a.n_bias_tiles > 0 && a.n_bias_tiles <= 320) ? 1 : 0;            // <= 40 KB of biases
     const size_t lds = act + (a.bias_in_lds ? (size_t)a.n_bias_tiles * 128 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = gen_kernel<P, NSB, MAXT>;
+    auto kern = gen_kernel<P, NSB, MAXT, TRAIN>;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
@@ -404,16 +406,17 @@ static hipError_t launch_gen_t(const GenArgs& a_in, int num_cus, hipStream_t str
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEN_WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }
-template <class P, int NSB>
+template <class P, int NSB, bool TRAIN>
 static hipError_t launch_gen(const GenArgs& a, int num_cus, hipStream_t stream) {
     if (a.ke % 16 || a.kv % 16 || a.kh % 16 || a.ke > GEN_MAX_E || a.kv > GEN_MAX_V || a.kh > GEN_MAX_W || a.n_layers < 1 ||
         a.n_layers > GEN_MAX_LAYERS) return hipErrorInvalidValue;
+    if (!TRAIN && (a.mode == 2 || a.save || a.mask || a.dirs)) return hipErrorInvalidValue;      // (the training instantiations' business)
     if ((a.save || a.mask) && (a.save_w % 4 != 0 || a.save_w < 4 || a.save_w > a.kh)) return hipErrorInvalidValue;
     if (a.mode == 2 && (!a.draw || a.draw_ch < 1 || a.draw_ch > 16 || a.draw_col % 16 != 0 || a.draw_col < 0 || a.draw_col + 16 > a.kh)) return hipErrorInvalidValue;
     int widest = 0;
     for (int l = 0; l < a.n_layers; ++l) widest = a.layer[l].nt > widest ? a.layer[l].nt : widest;
     if (widest > GEN_WAVES * GEN_MAXT) return hipErrorInvalidValue;
-    return (widest <= GEN_WAVES * 2) ? launch_gen_t<P, NSB, 2>(a, num_cus, stream) : launch_gen_t<P, NSB, 4>(a, num_cus, stream);
+    return (widest <= GEN_WAVES * 2) ? launch_gen_t<P, NSB, 2, TRAIN>(a, num_cus, stream) : launch_gen_t<P, NSB, 4, TRAIN>(a, num_cus, stream);
 }
 
 }  // namespace nrn
