@@ -17,3 +17,34 @@ def test_network_kernels_keep_the_wait_invariants():
     import check_isa
     errors = check_isa.check(BUILD)
     assert not errors, "\n".join(errors)
+
+
+def test_rendering_instantiations_of_the_generic_kernel_do_not_pay_for_its_training_code():
+    """csrc/nrnerf_generic.h: the training entry points' code (saved activations, relu masks, the backward-data mode) is compiled into
+    instantiations of its own (template parameter TRAIN).  In one kernel it cost the RENDERING instantiations 35 - 95 spilled registers
+    although none of it runs in a rendering launch (profiles/r05_generic_kernel_isa_split.txt).  From the code object's metadata: the
+    rendering instantiations spill nothing up to width 256 and what round 4's kernel spilled (17 registers) beyond; both sets exist."""
+    import re
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_isa
+    obj = os.path.join(BUILD, "nrnerf_generic.o")
+    if not os.path.exists(obj):
+        pytest.skip("csrc/build/nrnerf_generic.o not built")
+    with tempfile.TemporaryDirectory() as tmp:
+        co = check_isa.device_code_object(obj, tmp)
+        assert co is not None
+        notes = subprocess.run([f"{check_isa.LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    spills = {}
+    for blk in re.split(r"\n\s*- \.agpr_count", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
+        m = name and re.search(r"gen_kernelINS_(\w+?)ELi(\d)ELi(\d)ELb([01])E", name.group(1))
+        if m and sp:
+            spills[(m.group(1), int(m.group(3)), bool(int(m.group(4))))] = int(sp.group(1))      # (policy, MAXT, TRAIN)
+    render = {k: v for k, v in spills.items() if not k[2]}
+    train = {k: v for k, v in spills.items() if k[2]}
+    assert len(render) == 6 and len(train) == 4, spills
+    for (pol, maxt, _), v in render.items():
+        assert v <= (0 if (maxt == 2 or pol == "6PolF32") else 17), (pol, maxt, v, "the rendering kernel spills: did training code get back in?")
