@@ -1164,6 +1164,25 @@ def _is_default_shape(net) -> bool:
     return int(net.D) == 8 and int(net.W) in (256, 128) and list(net.skips) == [4] and int(net.input_ch) == 63
 
 
+def _training_handle_flags(nets, rb) -> int:
+    """nrnerf_model_desc.flags (+ Python-side markers) of the handle render_rays_train works on, beyond the environment's."""
+    def renders_compiled_trains_generic(n):
+        # a shape that RENDERS on compiled kernels without having compiled TRAINING kernels (the 128-wide trunk with the view-dependent head;
+        # the time-conditioned baseline with another code size than 32 or on the 128-wide trunk): a generic handle of its own
+        if not _is_default_shape(n):
+            return False
+        if getattr(n, "time_conditioned_baseline", False) and not (int(n.W) == 256 and int(n.pts_linears[0].weight.shape[1]) == int(n.input_ch) + 32):
+            return True
+        return not _trains_on_compiled_kernels(n)
+    flags = _lib.MODEL_FORCE_GENERIC if any(renders_compiled_trains_generic(n) for n in nets) else 0
+    if rb is not None and any(getattr(n, "use_viewdirs", False) and not getattr(n, "approx_nonrigid_viewdirs", True) and not _trains_on_compiled_kernels(n)
+                              for n in nets):
+        # exact Jacobian directions off the compiled set: computed by render_rays_train (the tangent of the divergence kernels); the handle is one
+        # for the training entry points only (the generic RENDER kernel has no Jacobian directions, so the library would refuse the description)
+        flags |= _lib.MODEL_PY_TRAINING_HANDLE
+    return flags
+
+
 def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp, pytest, ray_batch):
     """None when the native training path takes this call."""
     if pytest:
@@ -1222,20 +1241,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     rb = R._bender_of(network_fn)
     latents = additional_pixel_information.get("ray_bending_latents") if additional_pixel_information else None
     nets = [network_fn] + ([network_fine] if (N_importance > 0 and network_fine is not None) else [])
-    # (a shape that renders on compiled kernels without having compiled TRAINING kernels: a generic handle of its own)
-    def renders_compiled_trains_generic(n):
-        if not _is_default_shape(n):
-            return False
-        if getattr(n, "time_conditioned_baseline", False) and not (int(n.W) == 256 and int(n.pts_linears[0].weight.shape[1]) == int(n.input_ch) + 32):
-            return True
-        return not _trains_on_compiled_kernels(n)
-    forced = _lib.MODEL_FORCE_GENERIC if any(renders_compiled_trains_generic(n) for n in nets) else 0
-    if rb is not None and any(getattr(n, "use_viewdirs", False) and not getattr(n, "approx_nonrigid_viewdirs", True) and not _trains_on_compiled_kernels(n)
-                              for n in nets):
-        # exact Jacobian directions off the compiled set: computed here (the tangent of the divergence kernels); the handle is one for the
-        # training entry points only (the generic RENDER kernel has no Jacobian directions, so the library would refuse the description)
-        forced |= _lib.MODEL_PY_TRAINING_HANDLE
-    model = R.get_model(network_fn, network_fine if N_importance > 0 else None, precision=precision, device=dev, flags=forced)
+    model = R.get_model(network_fn, network_fine if N_importance > 0 else None, precision=precision, device=dev, flags=_training_handle_flags(nets, rb))
     if model.generic and not model.trains_generic:
         raise R.Unsupported("this architecture has no training kernels (view-dependent head / time-conditioned baseline off the compiled set)")
     trunk = _GenericTrunk if model.generic else _Trunk

@@ -113,6 +113,32 @@ def test_eligibility_of_training_calls():
         assert why in T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu11), kw
 
 
+def test_which_handle_a_training_call_works_on():
+    """training._training_handle_flags: shapes that render on compiled kernels but have no compiled TRAINING kernels get a generic handle
+    of their own (MODEL_FORCE_GENERIC); exact Jacobian directions off the compiled set a handle described without them
+    (MODEL_PY_TRAINING_HANDLE: the training path computes the directions itself); everything else the handle rendering uses."""
+    from nonrigid_nerf_amd import _lib
+    FG, TH = _lib.MODEL_FORCE_GENERIC, _lib.MODEL_PY_TRAINING_HANDLE
+    cases = [(dict(), 0), (dict(netwidth=128), 0), (dict(use_viewdirs=True), 0), (dict(use_viewdirs=True, approx_nonrigid_viewdirs=False), 0),
+             (dict(netwidth=192), 0), (dict(netwidth=192, use_viewdirs=True), 0), (dict(bend_depth=7, use_viewdirs=True), 0),
+             (dict(ray_bending=False, time_conditioned_baseline=True), 0),
+             (dict(netwidth=128, use_viewdirs=True), FG), (dict(netwidth_fine=128, use_viewdirs=True), FG),
+             (dict(ray_bending=False, time_conditioned_baseline=True, latent_size=16), FG), (dict(ray_bending=False, time_conditioned_baseline=True, netwidth=128), FG),
+             (dict(netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False), TH), (dict(netwidth=128, use_viewdirs=True, approx_nonrigid_viewdirs=False), FG | TH),
+             (dict(netwidth=192, ray_bending=False, use_viewdirs=True, approx_nonrigid_viewdirs=False), 0)]       # (no bender: the rays' own directions)
+    for kw, want in cases:
+        rb, c, f = build_modules(make_scene(SceneConfig(N_importance=64, **kw), 0))
+        assert T._training_handle_flags([c, f], rb) == want, (kw, T._training_handle_flags([c, f], rb), want)
+    assert not (TH & 0xffff), "the Python-side marker must not reach nrnerf_model_desc.flags"
+    # ... and what the description handed to the library looks like for such a handle
+    from nonrigid_nerf_amd.render import build_model_desc
+    rb, c, f = build_modules(make_scene(SceneConfig(N_importance=64, netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False), 0))
+    d_render, _k1 = build_model_desc(c, f, "f32", 0, 0)
+    d_train, _k2 = build_model_desc(c, f, "f32", 0, FG | TH)
+    assert d_render.exact_viewdirs == 1 and d_render.flags == 0
+    assert d_train.exact_viewdirs == 0 and d_train.flags == FG
+
+
 def _apply_index(record, index, n_partials_full, n_partials_short):
     """What nrnerf_reduce_partials computes, on the host, for `n` identical records: value x number of records added."""
     from nonrigid_nerf_amd import _lib
