@@ -386,6 +386,28 @@ class _Trunk(torch.autograd.Function):
         return _split_flat(flat, shapes)
 
 
+def _chunked_tn_product(dy, x):
+    """dy^T x [out, in] with an fp32 result (the weight gradients of _GenericTrunk: dy, x = [samples, out], [samples, in]).
+    The sum runs over ALL samples and the result is small: as ONE GEMM the library picks a kernel without a split along k
+    (measured 573 us for 393 216 x 192 x 192 in bf16, 50 TFLOP/s; 10 of the step's 17 ms) -- so: a batched GEMM over chunks of
+    >= 2048 samples, partial results added (<= 64 MB of them)."""
+    Mx, wo, wi = int(dy.shape[0]), int(dy.shape[1]), int(x.shape[1])
+    B = max(1, min(Mx // 2048, (1 << 24) // max(1, wo * wi)))
+    rows = (Mx // B) * B
+    dy, x = dy.contiguous(), x.contiguous()
+    a3, b3 = dy[:rows].view(B, rows // B, wo).transpose(1, 2), x[:rows].view(B, rows // B, wi)
+    if dy.dtype == torch.float32:
+        out = torch.bmm(a3, b3).sum(0)
+    else:
+        try:
+            out = torch.bmm(a3, b3, out_dtype=torch.float32).sum(0)
+        except (TypeError, RuntimeError):
+            out = torch.bmm(a3, b3).sum(0, dtype=torch.float32)
+    if rows < Mx:
+        out = out + dy[rows:].float().t() @ x[rows:].float()
+    return out
+
+
 class _GenericTrunk(torch.autograd.Function):
     """_Trunk for an architecture outside the compiled set (any depth, width % 4 == 0, at most one skip connection, plain
     output_linear head or the view-dependent one; fp32 or bf16): the run-time-parameterised kernel runs the forward with every
@@ -474,25 +496,7 @@ class _GenericTrunk(torch.autograd.Function):
             if ctx.needs_input_grad[4]:
                 d_codes = d_in[:, n_enc:].reshape(N, S, n_lat).sum(1)
 
-        def product(dy, x):
-            # dy^T x [out, in] with an fp32 result.  The sum runs over ALL samples and the result is small: as ONE GEMM the library
-            # picks a kernel without a split along k (measured 573 us for 393 216 x 192 x 192 in bf16, 50 TFLOP/s; 10 of the step's 17
-            # ms) -- so: a batched GEMM over chunks of >= 2048 samples, partial results added (<= 64 MB of them)
-            Mx, wo, wi = int(dy.shape[0]), int(dy.shape[1]), int(x.shape[1])
-            B = max(1, min(Mx // 2048, (1 << 24) // max(1, wo * wi)))
-            rows = (Mx // B) * B
-            dy, x = dy.contiguous(), x.contiguous()
-            a3, b3 = dy[:rows].view(B, rows // B, wo).transpose(1, 2), x[:rows].view(B, rows // B, wi)
-            if dy.dtype == torch.float32:
-                out = torch.bmm(a3, b3).sum(0)
-            else:
-                try:
-                    out = torch.bmm(a3, b3, out_dtype=torch.float32).sum(0)
-                except (TypeError, RuntimeError):
-                    out = torch.bmm(a3, b3).sum(0, dtype=torch.float32)
-            if rows < Mx:
-                out = out + dy[rows:].float().t() @ x[rows:].float()
-            return out
+        product = _chunked_tn_product
 
         grads = []
         for i in range(D):              # pts_linears[i]: weight, bias (rnh:253-258: layer skip + 1 reads [encoding, activation])

@@ -113,6 +113,20 @@ def test_eligibility_of_training_calls():
         assert why in T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu11), kw
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("m,wo,wi", [(5, 4, 3), (2048, 8, 8), (18500, 24, 63), (40000, 192, 4), (9000, 1, 192)])
+def test_chunked_weight_gradient_product(m, wo, wi, dtype, tol):
+    """training._chunked_tn_product (the weight gradients of a non-compiled architecture: dy^T x over all samples as a batched GEMM over
+    chunks, partial results added, + the rows that do not fill a chunk) against the plain product in float64."""
+    g = torch.Generator().manual_seed(m + wo)
+    dy, x = torch.randn(m, wo, generator=g), torch.randn(m, wi, generator=g)
+    got = T._chunked_tn_product(dy.to(dtype), x.to(dtype))
+    want = dy.to(dtype).double().t() @ x.to(dtype).double()
+    assert got.dtype == torch.float32 and tuple(got.shape) == (wo, wi)
+    # (bf16: the chunks' partial results may come back rounded to bf16 where the library has no fp32-output batched GEMM)
+    assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max() + m ** 0.5)
+
+
 def test_which_handle_a_training_call_works_on():
     """training._training_handle_flags: shapes that render on compiled kernels but have no compiled TRAINING kernels get a generic handle
     of their own (MODEL_FORCE_GENERIC); exact Jacobian directions off the compiled set a handle described without them
