@@ -1161,3 +1161,28 @@ def test_compiled_shapes_are_not_generic_and_exact_directions_stay_unsupported_t
     rb, coarse, fine = build_modules(make_scene(cfg, 3))
     desc, keep = build_model_desc(coarse, fine, "f32", 0)
     assert lib.nrnerf_pack_host(C.byref(desc), 7, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()) == _lib.ERR_UNSUPPORTED
+
+
+def test_which_architectures_have_a_backward_data_program():
+    """gen_trainable (csrc/nrnerf_api.cpp) through nrnerf_pack_host 13 / 14: fp32 and bf16 handles of anything the run-time-parameterised kernel
+    renders, the view-dependent head up to width 480 (the rows of d raw sit beside the activations in a 512-column buffer); not f16 handles
+    (they train through a bf16 one), not the time-conditioned baseline next to a bender (train.py:574-576 rules that out anyway), and with the
+    training handle's description (no exact_viewdirs, render_rays_train computes the directions) also the exact-direction models."""
+    lib = _lib.load()
+    info = _lib.PackedInfo()
+
+    def status(cfg_kw, precision, which=13, flags=0):
+        rb, coarse, fine = build_modules(make_scene(SceneConfig(N_importance=64, **cfg_kw), 3))
+        desc, keep = build_model_desc(coarse, fine, precision, 0, flags)
+        return lib.nrnerf_pack_host(C.byref(desc), which, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)())
+
+    for kw in (dict(), dict(netwidth=192), dict(netwidth=512, netdepth=16, skips=(7,)), dict(netwidth=480, use_viewdirs=True),
+               dict(netwidth=132, ray_bending=False, time_conditioned_baseline=True, latent_size=24)):
+        for prec in ("f32", "bf16"):
+            assert status(kw, prec) == 0 and status(kw, prec, 14) == 0, (kw, prec)
+    assert status(dict(netwidth=192), "f16") == _lib.ERR_UNSUPPORTED
+    assert status(dict(netwidth=512, use_viewdirs=True), "bf16") == _lib.ERR_UNSUPPORTED
+    assert status(dict(netwidth=190), "f32") == _lib.ERR_UNSUPPORTED                     # (rows of 4 elements)
+    exact = dict(netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False)
+    assert status(exact, "f32") == _lib.ERR_UNSUPPORTED
+    assert status(exact, "f32", flags=_lib.MODEL_PY_TRAINING_HANDLE) == 0
