@@ -47,6 +47,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}       # dense MFMA, MI355X_MICROARCH.md
+SUSTAINED_MFMA_TFLOPS = {"bf16": (2046.0, 2190.0), "f16": (2046.0, 2190.0)}   # measured: profiles/r04_mfma_shape_power.txt (power-capped clock)
 FITTED = os.path.join(REPO, "tests", "golden", "fitted_latest.tar")
 FIXTURE = os.path.join(REPO, "tests", "golden", "example_sequence_96x72.npz")
 
@@ -77,6 +78,10 @@ def parse_args():
                     "path treats it as a lower bound of its launch size)")
     ap.add_argument("--max-rays-per-launch", type=int, default=0, help="cap the rays of one nrnerf_render launch sequence (default: 2^20; "
                     "BASELINE config 5 words its workload as 65 536-ray chunks: --chunk 65536 --max-rays-per-launch 65536)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frame-sharded sequence mode (NOT the headline line): a step = driver.render_path over F frames of 512x384 "
+                         "(example-sequence poses, one latent code per frame), rank r rendering frames r, r + G, ... with its own packed "
+                         "weights; no collective while rendering, ONE all-gather of the uint8 frames at the end of each step")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the train_step leg (the native training iteration: 1024 rays forward + backward + Adam, untimed part of the run)")
     return ap.parse_args()
@@ -203,6 +208,13 @@ def main():
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // (2 * world))))
 
     from nonrigid_nerf_amd import render as R
+
+    if args.frames > 0:
+        frames_mode(args, rank, world, dev, one_gpu, backend)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     frame_rays = args.rays                                # weak: per rank; strong: for the whole job (ceil(n / G) per rank)
     scene, cfg, (rb, coarse, fine), rays, latents, data_desc = build_workload(args, rank, world, dev)
@@ -339,21 +351,28 @@ def main():
         coarse_roof = roof(cp)
         coarse_roof["launches_per_pass"] = 2 if prof.get("bend_coarse", {}).get("launches") else 1
         coarse_roof["trunk_kernel_alone"] = roof(prof["net_coarse"])
-        # (16-bit modes with a ray bender and no view branch: the split path's trunk-only pass on 16x16x32 MFMAs, nrnerf_net_x16.h, unless NRNERF_X16=0)
-        from nonrigid_nerf_amd import _lib
-        x16 = (args.precision in ("bf16", "f16") and not (_lib.render_flags_from_env() & _lib.RENDER_NO_X16) and args.netwidth == 256
-               and not (args.precision == "f16" and (_lib.model_flags_from_env() & _lib.MODEL_NO_X16_F16))
-               and not (_lib.model_flags_from_env() & _lib.MODEL_FORCE_GENERIC)
-               and not (args.use_viewdirs or args.exact_viewdirs))
-        roofline = {"bound": "mfma", "kernel": ("net_kernel_x16" if x16 else "net_kernel") + " (fine pass, 192 samples/ray)",
+        # which kernel: what nrnerf_render dispatched for the fine pass of the timed steps, as the library recorded it (nrnerf_profile.kernel_name)
+        roofline = {"bound": "mfma", "kernel": f"{k['kernel']} (fine pass, {cfg.N_samples + cfg.N_importance} samples/ray)",
+                    "kernels_launched": {nm: v["kernel"] for nm, v in prof.items() if v["launches"]},
                     "achieved": rf["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": rf["frac"],
                     "avg_launch_ms": rf["avg_launch_ms"], "issued_mfma_tflops": rf["issued_mfma_tflops"], "frac_issued_mfma": rf["frac_issued_mfma"],
                     "traffic": traffic, "traffic_unit": traffic_note, "traffic_source": traffic_source,
-                    "coarse_pass": coarse_roof,
+                    "coarse_pass_incl_bender": coarse_roof,
                     "kernels_ms_per_step": {nm: round(v["ms"] / args.steps, 4) for nm, v in prof.items() if v["launches"]},
                     # context, not the peak: what a plain hipBLASLt GEMM sustains on this box right now (the chip
                     # clocks down under MFMA load)
                     "library_gemm_tflops_same_box": gemm}
+        if traffic is None and "BASELINE config 2" not in workload_label(args, cfg, frame_rays, n, world):
+            # a variant run has no PMC pass of its own on file: no traffic keys at all rather than a null that reads like a measurement
+            for key in ("traffic", "traffic_unit", "traffic_source"):
+                roofline.pop(key)
+        if args.precision in SUSTAINED_MFMA_TFLOPS:
+            # `frac` is against the paper peak (2.4 GHz x 256 CUs).  Under the socket's power cap a register-only stream of the SAME MFMA
+            # (no LDS, no VALU, no memory: tools/probes/mfma_shape_power.hip) sustains less; read `frac` against both.
+            lo, hi = SUSTAINED_MFMA_TFLOPS[args.precision]
+            roofline["sustained_peak"] = {"tflops_range": [lo, hi], "frac_of_sustained": [round(rf["achieved"] / hi, 4), round(rf["achieved"] / lo, 4)],
+                                          "source": "profiles/r04_mfma_shape_power.txt (register-only v_mfma_f32_16x16x32 stream on MI355X under the 1400 W cap), "
+                                                    "profiles/r06_power_trace.txt (socket power and shader clock during this kernel)"}
         flops_per_ray = sum(v["flops"] for v in prof.values()) / max(n * args.steps, 1)
         res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -384,6 +403,81 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def frames_mode(args, rank, world, dev, one_gpu, backend):
+    """``--frames F``: the no-collective half of SURVEY.md section 8(e) -- a free-viewpoint SEQUENCE (what free_viewpoint_rendering.py
+    does with config 3's checkpoint: 120-300 poses through render_path, train.py:419-553) sharded by whole frames.  A step = one
+    ``driver.render_path(..., group=, rgb_dtype="uint8")`` over F frames; rank r renders frames r, r + G, ...; the only collective is the
+    all-gather of the finished uint8 frames at the end of the step (inside the timed region)."""
+    import numpy as np
+    import torch.distributed as dist
+    from nonrigid_nerf_amd import render as R
+    from nonrigid_nerf_amd.driver import frame_shard, render_path
+    scene, cfg, (rb, coarse, fine), _, _, data_desc = build_workload(args, 0, 1, dev, frame_rays=64)
+    R.set_precision(args.precision)
+    z = np.load(FIXTURE)
+    F, nposes = int(args.frames), int(z["poses"].shape[0])
+    s = 512.0 / float(z["hwf"][1])
+    intrin = dict(height=384, width=512, focal_x=float(z["hwf"][2]) * s, focal_y=float(z["hwf"][2]) * s, center_x=256.0, center_y=192.0)
+    poses = [torch.from_numpy(z["poses"][f % nposes]) for f in range(F)]
+    if args.scene == "fitted":
+        from nonrigid_nerf_amd.checkpoint import load_checkpoint
+        codes = load_checkpoint(args.fitted_ckpt, N_samples=64, N_importance=128).latents
+        codes = torch.stack([codes[f % nposes] for f in range(F)], 0)
+    else:
+        codes = 0.1 * torch.randn(F, cfg.latent_size, generator=torch.Generator().manual_seed(5))
+    kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=cfg.N_samples, N_importance=cfg.N_importance,
+              perturb=0.0, raw_noise_std=0.0, near=cfg.near, far=cfg.far, use_viewdirs=bool(args.use_viewdirs))
+    model = R.get_model(coarse, fine, device=dev)
+    grp = True if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return render_path(poses, [intrin] * F, args.chunk, kw, codes, rgb_dtype="uint8", device=dev, group=grp, gather="all")
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    model.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rgbs, disps = step()
+    barrier()
+    dt_own = time.perf_counter() - t0
+    prof = model.profile_end()
+    assert rgbs.shape == (F, 384, 512, 3) and rgbs.dtype == np.uint8
+    kern_ms = sum(v["ms"] for v in prof.values())
+    mine = len(frame_shard(F, world, rank))
+    per_rank = [(dt_own, kern_ms, mine)]
+    if world > 1:
+        t = torch.tensor([dt_own, kern_ms, float(mine)], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        allt = torch.empty(world * 3, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allt, t)
+        per_rank = [tuple(float(x) for x in row) for row in allt.cpu().view(world, 3)]
+    dt = max(r[0] for r in per_rank)
+    if rank != 0:
+        return
+    rays_per_frame = 384 * 512
+    res = {"metric": "rendered rays/sec (64+128 samples/ray)", "value": round(F * rays_per_frame * args.steps / dt, 1), "unit": "rays/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
+           "data": ("synthetic: " if args.scene == "synthetic" else "example_sequence: ") + data_desc
+                   + (" (NOT A BENCHMARK: all ranks on one GPU, gloo)" if one_gpu else ""),
+           "config": {"workload": f"NOT a BASELINE.json config line (variant run): frame-sharded free-viewpoint sequence, {F} frames of 512x384 per step through "
+                                  f"driver.render_path, rank r renders frames r, r + {world}, ...; {cfg.N_samples} + {cfg.N_importance} samples, netwidth {args.netwidth}, "
+                                  f"{args.precision}; ray generation, uint8 conversion, D2H and the final all-gather of the frames inside the timed region",
+                      "frames_per_step": F, "rays_per_frame": rays_per_frame, "scene": args.scene,
+                      "parallelism": f"frames sharded round-robin over {world} rank(s), no collective while rendering, one all-gather of uint8 frames per step"},
+           "backend": backend,
+           "frames_per_s": round(F * args.steps / dt, 3),
+           "per_rank": [{"frames_per_step": int(m), "frames_per_s": round(m * args.steps / t, 3) if t > 0 else None,
+                         "ms_per_step": round(t / args.steps * 1e3, 3), "kernels_ms_per_step": round(k / args.steps, 3)} for t, k, m in per_rank]}
+    print(json.dumps(res), flush=True)
 
 
 def workload_label(args, cfg, frame_rays, rays_per_rank, world):

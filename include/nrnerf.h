@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NRNERF_ABI_VERSION 7
+#define NRNERF_ABI_VERSION 8
 /* samples per ray and pass: nrnerf_render and the training entry points (the split fine bender -- nrnerf_merge_rows,
  * nrnerf_composite_args.rank_new -- up to 256 merged samples: 8-bit ranks) */
 #define NRNERF_MAX_SAMPLES 1024
@@ -186,8 +186,13 @@ typedef enum nrnerf_render_flags {
                                                    (implied when the coarse pass runs on the 16x16x32 kernel) */
     NRNERF_RENDER_NO_X16 = 1u << 3,             /* every pass, and the stand-alone bender, on the 32x32x16 kernels */
     NRNERF_RENDER_X16_FINE_ONLY = 1u << 4,      /* 16x16x32 kernel for the fine pass only (the coarse pass on the fused-bender 32x32x16 kernel) */
-    NRNERF_RENDER_BENDER_32X32 = 1u << 5        /* split path, bf16 mode: the stand-alone bender on the fused kernels' own 32x32x16 tiles
+    NRNERF_RENDER_BENDER_32X32 = 1u << 5,       /* split path, bf16 mode: the stand-alone bender on the fused kernels' own 32x32x16 tiles
                                                    (bent points then equal the fused-bender pass up to conversion ties) instead of 16x16x32 */
+    /* ABI 8: the COARSE pass' compositing + sample_pdf + merge (train.py:889-920) as the epilogue of the coarse trunk kernel (16x16x32
+     * kernels of the split path: a wave owns whole rays, their raw outputs stay in LDS) instead of composite_kernel's own launch: same
+     * bits either way.  Neither bit = the library's default for the call (DESIGN.md section 3.3 says which and why, from an A/B on one box). */
+    NRNERF_RENDER_COARSE_EPILOGUE_ON = 1u << 6,
+    NRNERF_RENDER_COARSE_EPILOGUE_OFF = 1u << 7
 } nrnerf_render_flags;
 
 /* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */
@@ -200,6 +205,8 @@ typedef struct nrnerf_profile {
     int64_t launches[NRNERF_NUM_KERNELS];
     double flops[NRNERF_NUM_KERNELS];        /* algorithmic 2*MAC, unpadded */
     double mfma_flops[NRNERF_NUM_KERNELS];   /* issued MFMA flops incl. padding */
+    char kernel_name[NRNERF_NUM_KERNELS][64]; /* ABI 8: which kernel the slot's LAST launch was (what nrnerf_render actually dispatched:
+                                                 "net_kernel_x16 + fused compositing", "gx16_kernel", "gen_kernel", ...); "" = no launch */
 } nrnerf_profile;
 
 int nrnerf_abi_version(void);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NRNERF_LIB selects an alternative build of the same library (tuning experiments, see csrc/Makefile)
 LIB_PATH = os.environ.get("NRNERF_LIB") or os.path.join(_HERE, "lib", "libnrnerf_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_SAMPLES = 1024        # NRNERF_MAX_SAMPLES (include/nrnerf.h): per ray and pass of nrnerf_render; training: 256
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE, ERR_NOMEM, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
@@ -88,7 +88,8 @@ MODEL_FORCE_GENERIC, MODEL_NO_X16_F16 = 1 << 0, 1 << 1
 # Python-side only (never reaches the library): a handle for the TRAINING entry points, whose callers compute the view directions themselves --
 # described to the library without exact_viewdirs, which the run-time-parameterised RENDER kernel does not do (training.render_rays_train)
 MODEL_PY_TRAINING_HANDLE = 1 << 30
-RENDER_FUSED_FINE_BENDER, RENDER_UNFUSED_COMPOSITE, RENDER_SPLIT_COARSE, RENDER_NO_X16, RENDER_X16_FINE_ONLY, RENDER_BENDER_32X32 = (1 << i for i in range(6))
+RENDER_FUSED_FINE_BENDER, RENDER_UNFUSED_COMPOSITE, RENDER_SPLIT_COARSE, RENDER_NO_X16, RENDER_X16_FINE_ONLY, RENDER_BENDER_32X32, \
+    RENDER_COARSE_EPILOGUE_ON, RENDER_COARSE_EPILOGUE_OFF = (1 << i for i in range(8))
 
 
 def model_flags_from_env() -> int:
@@ -101,21 +102,38 @@ def model_flags_from_env() -> int:
     return f
 
 
+_RENDER_ENV = ("NRNERF_FUSED_FINE_BENDER", "NRNERF_UNFUSED_COMPOSITE", "NRNERF_SPLIT_COARSE", "NRNERF_X16_BENDER", "NRNERF_X16",
+               "NRNERF_FUSED_COARSE_EPILOGUE")
+_render_flags_cache = (None, 0)
+
+
 def render_flags_from_env() -> int:
-    """NRNERF_FUSED_FINE_BENDER=1, NRNERF_UNFUSED_COMPOSITE=1, NRNERF_SPLIT_COARSE=1, NRNERF_X16=0|1|2, NRNERF_X16_BENDER=0 -> nrnerf_render_args.flags
-    (read per call: the parity tests render one scene through several kernel routes in one process)."""
+    """NRNERF_FUSED_FINE_BENDER=1, NRNERF_UNFUSED_COMPOSITE=1, NRNERF_SPLIT_COARSE=1, NRNERF_X16=0|1|2, NRNERF_X16_BENDER=0,
+    NRNERF_FUSED_COARSE_EPILOGUE=0|1 -> nrnerf_render_args.flags (read per call: the parity tests render one scene through several kernel
+    routes in one process; parsed once per distinct set of values -- a small-batch render should not pay for six string comparisons)."""
+    global _render_flags_cache
+    key = tuple(os.environ.get(k) for k in _RENDER_ENV)
+    if _render_flags_cache[0] == key:
+        return _render_flags_cache[1]
     f = 0
-    if os.environ.get("NRNERF_FUSED_FINE_BENDER") == "1":
+    if key[0] == "1":
         f |= RENDER_FUSED_FINE_BENDER
-    if os.environ.get("NRNERF_UNFUSED_COMPOSITE") == "1":
+    if key[1] == "1":
         f |= RENDER_UNFUSED_COMPOSITE
-    if os.environ.get("NRNERF_SPLIT_COARSE") == "1":
+    if key[2] == "1":
         f |= RENDER_SPLIT_COARSE
-    if os.environ.get("NRNERF_X16_BENDER", "1") == "0":
+    if key[3] == "0":
         f |= RENDER_BENDER_32X32
-    x16 = os.environ.get("NRNERF_X16")
+    x16 = key[4]
     if x16 is not None and x16.strip() != "":
+        if x16.strip() not in ("0", "1", "2"):
+            raise ValueError(f"NRNERF_X16={x16!r}: one of 0 (32x32x16 kernels), 1 (16x16x32 fine pass only), 2 (both passes, the default)")
         f |= {0: RENDER_NO_X16, 1: RENDER_X16_FINE_ONLY}.get(int(x16), 0)
+    if key[5] is not None and key[5].strip() != "":
+        if key[5].strip() not in ("0", "1"):
+            raise ValueError(f"NRNERF_FUSED_COARSE_EPILOGUE={key[5]!r}: 0 (composite / sample_pdf / merge as their own launch) or 1 (inside the coarse trunk kernel)")
+        f |= RENDER_COARSE_EPILOGUE_ON if key[5].strip() == "1" else RENDER_COARSE_EPILOGUE_OFF
+    _render_flags_cache = (key, f)
     return f
 
 
@@ -137,7 +155,8 @@ class LossArgs(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * NUM_KERNELS), ("launches", C.c_int64 * NUM_KERNELS),
-                ("flops", C.c_double * NUM_KERNELS), ("mfma_flops", C.c_double * NUM_KERNELS)]
+                ("flops", C.c_double * NUM_KERNELS), ("mfma_flops", C.c_double * NUM_KERNELS),
+                ("kernel_name", (C.c_char * 64) * NUM_KERNELS)]
 
 
 class PackedInfo(C.Structure):

@@ -1010,7 +1010,7 @@ struct nrnerf_model {
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
     mutable std::mutex prof_mu;
     mutable bool prof_on = false;
-    struct Ev { int kernel; hipEvent_t a, b; double flops, mfma; };
+    struct Ev { int kernel; hipEvent_t a, b; double flops, mfma; const char* name; };
     mutable std::vector<Ev> prof_events;
 };
 
@@ -1916,9 +1916,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
 
     bool prof;
     { std::lock_guard<std::mutex> g(m->prof_mu); prof = m->prof_on; }
-    auto timed = [&](int kernel, double flops, double mfma, auto&& launch) -> hipError_t {
+    auto timed = [&](int kernel, const char* name, double flops, double mfma, auto&& launch) -> hipError_t {
         if (!prof) return launch();
-        nrnerf_model::Ev ev{kernel, nullptr, nullptr, flops, mfma};
+        nrnerf_model::Ev ev{kernel, nullptr, nullptr, flops, mfma, name};
         // device-scope events (no system-scope cache write-back with every record).  Measured A/B against default events on
         // one box: no difference (36.00 / 36.04 vs 36.14 / 35.99 ms per step) -- the kernels' event times add up to the step
         // time within 0.05 ms either way, i.e. there are no launch gaps to recover between the five kernels of a render
@@ -1943,11 +1943,11 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     auto run_bender = [&](BendArgs& b, int slot, int n_samples) -> hipError_t {
         if (bend_x16) {
             b.wstream = m->bend_x16.stream; b.bias = m->bend_x16.bias;
-            return timed(slot, (double)N * n_samples * m->bend_x16.algo_flops_per_sample, (double)N * n_samples * m->bend_x16.mfma_flops_per_sample,
+            return timed(slot, "bend_kernel_x16", (double)N * n_samples * m->bend_x16.algo_flops_per_sample, (double)N * n_samples * m->bend_x16.mfma_flops_per_sample,
                          [&] { return launch_bend_x16(bender_arch(m->arch_id), b, m->num_cus, stream); });
         }
         b.wstream = m->bend_only.stream; b.bias = m->bend_only.bias;
-        return timed(slot, (double)N * n_samples * m->bend_only.algo_flops_per_sample, (double)N * n_samples * m->bend_only.mfma_flops_per_sample,
+        return timed(slot, "bend_kernel", (double)N * n_samples * m->bend_only.algo_flops_per_sample, (double)N * n_samples * m->bend_only.mfma_flops_per_sample,
                      [&] { return launch_bend(m->precision, bender_arch(m->arch_id), b, m->num_cus, stream); });
     };
 
@@ -1973,11 +1973,11 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                 b.bent4 = out4; b.knobs = kn;
                 if (bend_x16) {
                     b.wstream = m->bend_x16.stream; b.bias = m->bend_x16.bias;
-                    return timed(slot, (double)N * nS * m->bend_x16.algo_flops_per_sample, (double)N * nS * m->bend_x16.mfma_flops_per_sample,
+                    return timed(slot, "bend_kernel_x16", (double)N * nS * m->bend_x16.algo_flops_per_sample, (double)N * nS * m->bend_x16.mfma_flops_per_sample,
                                  [&] { return launch_bend_x16(m->gen_compiled_bender, b, m->num_cus, stream); });
                 }
                 b.wstream = m->bend_only.stream; b.bias = m->bend_only.bias;
-                return timed(slot, (double)N * nS * m->bend_only.algo_flops_per_sample, 0,
+                return timed(slot, "bend_kernel", (double)N * nS * m->bend_only.algo_flops_per_sample, 0,
                              [&] { return launch_bend(m->precision, m->gen_compiled_bender, b, m->num_cus, stream); });
             }
             GenArgs g = m->gen_bend_prog;
@@ -1985,21 +1985,30 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
             g.z = zv; g.lindisp = a->lindisp; g.n_rays = N; g.S = nS;
             g.wstream = m->gen_bend.stream; g.bias = m->gen_bend.bias;
             g.bent4 = out4; g.ex = sample_out(so); g.knobs = kn;
-            return timed(slot, (double)N * nS * m->gen_bend.algo_flops_per_sample, 0, [&] { return launch_generic(m->precision, g, m->num_cus, stream); });
+            return timed(slot, "gen_kernel (bender program)", (double)N * nS * m->gen_bend.algo_flops_per_sample, 0, [&] { return launch_generic(m->precision, g, m->num_cus, stream); });
         };
+        // `fuse` (a FINAL pass): its compositing arguments -- taken as the kernel's epilogue when the pass runs on the width-class kernel
+        // (then *fused = true and the caller skips the composite launch); NRNERF_RENDER_UNFUSED_COMPOSITE keeps the launch (bit-identity tests)
         auto network_pass = [&](const GenArgs& prog, const PassDev& pd, const float* zv, int nS, const float* pts, float* raw4, float* raw_user,
-                                float* bent_out, const nrnerf_sample_outputs& so, int slot) -> hipError_t {
+                                float* bent_out, const nrnerf_sample_outputs& so, int slot, const CompositeArgs* fuse = nullptr,
+                                bool* fused = nullptr) -> hipError_t {
             // the trunk on the width-class 16x16x32 kernel (nrnerf_gx16.h) when the pass runs on ready-made points and wants no detail outputs
             const PassDev& gx = (&pd == &m->gen_coarse) ? m->gx_coarse : m->gx_fine;
             const GxMeta& gm = (&pd == &m->gen_coarse) ? m->gx_meta_coarse : m->gx_meta_fine;
             const PassDev& gxu = (m->gen_fine_is_coarse && &pd == &m->gen_fine) ? m->gx_coarse : gx;      // (one network for both passes)
             const GxMeta& gmu = (m->gen_fine_is_coarse && &pd == &m->gen_fine) ? m->gx_meta_coarse : gm;
-            if (pts && gxu.stream && !(a->flags & NRNERF_RENDER_NO_X16) && !any_detail(so) && !kn.detailed) {
+            if (pts && gxu.stream && !(a->flags & NRNERF_RENDER_NO_X16) && !any_detail(so) && !kn.detailed &&
+                (long long)N * nS < (1ll << 32)) {      // (the kernel's 32-bit sample rows; beyond: the run-time-parameterised kernel below)
                 GxArgs x{};
                 x.pts4 = pts; x.raw4 = raw4; x.raw_out = raw_user; x.raw_ch = pd.output_ch;
                 x.n_rays = N; x.S = nS; x.wstream = gxu.stream; x.bias = gxu.bias;
                 x.depth = gmu.depth; x.skip = gmu.skip; x.L = gmu.L; x.n_bias_tiles = gmu.n_bias_tiles; x.LV = gmu.LV;
-                return timed(slot, (double)N * nS * gxu.algo_flops_per_sample, (double)N * nS * gxu.mfma_flops_per_sample,
+                if (fuse && !(a->flags & NRNERF_RENDER_UNFUSED_COMPOSITE) && nS <= 256 &&
+                    (long long)N >= gx16_rays_per_group(gmu.wc, nS) * m->num_cus) {
+                    x.fuse_on = 1; x.fuse = *fuse; x.fuse.raw4 = nullptr; x.raw4 = nullptr;
+                    *fused = true;
+                }
+                return timed(slot, (x.fuse_on ? "gx16_kernel + fused compositing" : "gx16_kernel"), (double)N * nS * gxu.algo_flops_per_sample, (double)N * nS * gxu.mfma_flops_per_sample,
                              [&] { return launch_gx16(m->precision, gmu.wc, gmu.views != 0, x, m->num_cus, stream); });
             }
             GenArgs g = prog;
@@ -2011,16 +2020,13 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
             g.bent4 = pts ? const_cast<float*>(pts) : bent_out;          // with a bender: read (removal knob); without: written (points of the pass)
             g.knobs = kn;
             if (!pts) g.ex = sample_out(so);                             // without a bender the network kernel reports the points
-            return timed(slot, (double)N * nS * pd.algo_flops_per_sample, (double)N * nS * pd.mfma_flops_per_sample,
+            return timed(slot, "gen_kernel", (double)N * nS * pd.algo_flops_per_sample, (double)N * nS * pd.mfma_flops_per_sample,
                          [&] { return launch_generic(m->precision, g, m->num_cus, stream); });
         };
         float* const bent_final = bent4_ws;                         // points of the final pass [N, S + I | S, 4]
         float* const bentA = (I > 0) ? bent_c : bent4_ws;           // points of the coarse pass: its own array when a fine pass follows
         hipError_t ge = hipSuccess;
         if (bend) ge = bender_pass(zc, S, bentA, a->coarse, 5);
-        if (ge != hipSuccess) return NRNERF_ERR_HIP;
-        ge = network_pass(m->gen_coarse_prog, m->gen_coarse, zc, S, bend ? bentA : nullptr, raw_c, (I == 0) ? a->raw : nullptr,
-                          (I == 0 && surface) ? bent_final : nullptr, a->coarse, 0);
         if (ge != hipSuccess) return NRNERF_ERR_HIP;
         CompositeArgs gc{};
         gc.rays = a->rays; gc.ray_stride = a->ray_stride;
@@ -2034,11 +2040,13 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
             gc.rgb = a->rgb_map; gc.disp = a->disp_map; gc.acc = a->acc_map; gc.z_user = a->z_vals;
             if (surface) { gc.bent4 = bent_final; gc.surf_pts = a->surface_pts; gc.surf_rig = a->surface_rigidity; gc.med_idx = a->median_index; }
         }
-        if (timed(1, 0, 0, [&] { return launch_composite(gc, stream); }) != hipSuccess) return NRNERF_ERR_HIP;
+        bool fused_c = false, fused_f = false;
+        ge = network_pass(m->gen_coarse_prog, m->gen_coarse, zc, S, bend ? bentA : nullptr, raw_c, (I == 0) ? a->raw : nullptr,
+                          (I == 0 && surface) ? bent_final : nullptr, a->coarse, 0, (I == 0) ? &gc : nullptr, &fused_c);
+        if (ge != hipSuccess) return NRNERF_ERR_HIP;
+        if (!fused_c && timed(1, "composite_kernel", 0, 0, [&] { return launch_composite(gc, stream); }) != hipSuccess) return NRNERF_ERR_HIP;
         if (I == 0) return NRNERF_OK;
         if (bend) ge = bender_pass(z_fine, SF, bent_final, a->fine, 4);
-        if (ge != hipSuccess) return NRNERF_ERR_HIP;
-        ge = network_pass(m->gen_fine_prog, m->gen_fine, z_fine, SF, bend ? bent_final : nullptr, raw_f, a->raw, surface ? bent_final : nullptr, a->fine, 2);
         if (ge != hipSuccess) return NRNERF_ERR_HIP;
         CompositeArgs gf{};
         gf.rays = a->rays; gf.ray_stride = a->ray_stride;
@@ -2047,7 +2055,10 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         gf.rgb = a->rgb_map; gf.disp = a->disp_map; gf.acc = a->acc_map; gf.z_user = a->z_vals;
         gf.vis = a->fine.visibility_weights; gf.alpha = a->fine.opacity_alpha;
         if (surface) { gf.bent4 = bent_final; gf.surf_pts = a->surface_pts; gf.surf_rig = a->surface_rigidity; gf.med_idx = a->median_index; }
-        if (timed(3, 0, 0, [&] { return launch_composite(gf, stream); }) != hipSuccess) return NRNERF_ERR_HIP;
+        ge = network_pass(m->gen_fine_prog, m->gen_fine, z_fine, SF, bend ? bent_final : nullptr, raw_f, a->raw, surface ? bent_final : nullptr, a->fine, 2,
+                          &gf, &fused_f);
+        if (ge != hipSuccess) return NRNERF_ERR_HIP;
+        if (!fused_f && timed(3, "composite_kernel", 0, 0, [&] { return launch_composite(gf, stream); }) != hipSuccess) return NRNERF_ERR_HIP;
         return NRNERF_OK;
     }
 
@@ -2104,34 +2115,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     };
     const bool fuse_coarse_only = I == 0 && !m->has_bend && !unfused_composite && S <= 256 && enough_rays_to_fuse(S);
     if (fuse_coarse_only) { na.fuse_on = 1; na.fuse = final_composite(S, zc, a->noise_coarse, a->coarse, nullptr); na.raw4 = nullptr; }
-    hipError_t e;
-    if (split_coarse) {
-        // KBc: stand-alone bender over the S coarse samples, then the coarse trunk on the bent points
-        BendArgs bc{};
-        bc.rays = a->rays; bc.ray_stride = a->ray_stride;
-        bc.latents = a->latents; bc.lat_stride = a->latent_stride;
-        bc.z = zc; bc.lindisp = a->lindisp; bc.rank = nullptr; bc.n_rays = N; bc.n_per_ray = S; bc.out_stride = S;
-        bc.bent4 = bent_c; bc.knobs = kn;
-        e = run_bender(bc, 5, S);
-        if (e != hipSuccess) return NRNERF_ERR_HIP;
-        na.pts4 = bent_c; na.bent4 = nullptr;
-        if (x16_coarse) {
-            na.wstream = m->coarse_trunk_x16.stream; na.bias = m->coarse_trunk_x16.bias;
-            e = timed(0, (double)N * S * m->coarse_trunk_x16.algo_flops_per_sample, (double)N * S * m->coarse_trunk_x16.mfma_flops_per_sample,
-                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, na, m->num_cus, stream); });
-        } else {
-            na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
-            e = timed(0, (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
-                      [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), na, m->num_cus, stream); });
-        }
-    } else {
-        e = timed(0, (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
-                  [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
-    }
-    if (e != hipSuccess) return NRNERF_ERR_HIP;
-    if (fuse_coarse_only) return NRNERF_OK;
-
-    // ---- K1: coarse composite (+ sampling)
+    // ---- K1's arguments: coarse composite (+ sampling + merge when a fine pass follows)
     CompositeArgs ca{};
     ca.rays = a->rays; ca.ray_stride = a->ray_stride;
     ca.raw4 = raw_c; ca.z = zc; ca.n_rays = N; ca.S = S; ca.n_importance = I;
@@ -2151,12 +2135,54 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     }
     ca.vis = a->coarse.visibility_weights; ca.alpha = a->coarse.opacity_alpha;
     if (I == 0 && surface) { ca.bent4 = bent4; ca.surf_pts = a->surface_pts; ca.surf_rig = a->surface_rigidity; ca.med_idx = a->median_index; }
-    e = timed(1, 0, 0, [&] { return launch_composite(ca, stream); });
+    // K1 inside K0 (north_star: "compositing fused into the ray loop"; train.py:889-920): on the split path's 16x16x32 coarse trunk a wave
+    // owns whole rays, so compositing, sample_pdf and the merge run as its epilogue (net_kernel_x16<.., SAMPLE>: composite_kernel's own
+    // code, same bits) and raw_c never reaches HBM.  NRNERF_RENDER_COARSE_EPILOGUE_ON / _OFF select per call; the default follows the
+    // A/B on one box.
+#ifndef NRN_COARSE_EPILOGUE_DEFAULT
+#define NRN_COARSE_EPILOGUE_DEFAULT 0
+#endif
+    const bool epilogue_wanted = (a->flags & NRNERF_RENDER_COARSE_EPILOGUE_OFF) ? false :
+                                 ((a->flags & NRNERF_RENDER_COARSE_EPILOGUE_ON) ? true : NRN_COARSE_EPILOGUE_DEFAULT != 0);
+    const bool fuse_coarse_epilogue = x16_coarse && epilogue_wanted && !unfused_composite && S <= x16_coarse_epilogue_max_samples() &&
+                                      (long long)N >= x16_rays_per_group(trunk_arch(m->arch_id), S) * m->num_cus;
+    if (fuse_coarse_epilogue) { na.fuse_on = 1; na.fuse = ca; na.fuse.raw4 = nullptr; na.raw4 = nullptr; }
+    hipError_t e;
+    if (split_coarse) {
+        // KBc: stand-alone bender over the S coarse samples, then the coarse trunk on the bent points
+        BendArgs bc{};
+        bc.rays = a->rays; bc.ray_stride = a->ray_stride;
+        bc.latents = a->latents; bc.lat_stride = a->latent_stride;
+        bc.z = zc; bc.lindisp = a->lindisp; bc.rank = nullptr; bc.n_rays = N; bc.n_per_ray = S; bc.out_stride = S;
+        bc.bent4 = bent_c; bc.knobs = kn;
+        e = run_bender(bc, 5, S);
+        if (e != hipSuccess) return NRNERF_ERR_HIP;
+        na.pts4 = bent_c; na.bent4 = nullptr;
+        if (x16_coarse) {
+            na.wstream = m->coarse_trunk_x16.stream; na.bias = m->coarse_trunk_x16.bias;
+            e = timed(0, (fuse_coarse_epilogue ? "net_kernel_x16 + fused compositing, sample_pdf, merge" : "net_kernel_x16"), (double)N * S * m->coarse_trunk_x16.algo_flops_per_sample, (double)N * S * m->coarse_trunk_x16.mfma_flops_per_sample,
+                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, na, m->num_cus, stream); });
+        } else {
+            na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
+            e = timed(0, "net_kernel (trunk only)", (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
+                      [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), na, m->num_cus, stream); });
+        }
+    } else {
+        e = timed(0, (m->has_bend ? "net_kernel (fused bender)" : (fuse_coarse_only ? "net_kernel + fused compositing" : "net_kernel")), (double)N * S * m->coarse.algo_flops_per_sample, (double)N * S * m->coarse.mfma_flops_per_sample,
+                  [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, na, m->num_cus, stream); });
+    }
+    if (e != hipSuccess) return NRNERF_ERR_HIP;
+    if (fuse_coarse_only) return NRNERF_OK;
+
+    // ---- K1: coarse composite (+ sampling), unless it ran as K0's epilogue
+    if (!fuse_coarse_epilogue)
+        e = timed(1, "composite_kernel", 0, 0, [&] { return launch_composite(ca, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
     if (I == 0) return NRNERF_OK;
 
     // ---- K2: fine network on the merged depths
     NetArgs nf = na;
+    nf.fuse_on = 0; nf.fuse = CompositeArgs{};           // (the coarse pass' epilogue, if any, was its own)
     nf.pts4 = nullptr;
     nf.z = z_fine; nf.S = SF;
     nf.raw4 = raw_f; nf.raw_out = a->raw; nf.raw_ch = m->fine.output_ch;
@@ -2183,17 +2209,17 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         nf.pts4 = bent4; nf.bent4 = nullptr;
         if (x16) {
             nf.wstream = m->fine_trunk_x16.stream; nf.bias = m->fine_trunk_x16.bias;
-            e = timed(2, (double)N * SF * m->fine_trunk_x16.algo_flops_per_sample, (double)N * SF * m->fine_trunk_x16.mfma_flops_per_sample,
+            e = timed(2, (fuse_fine ? "net_kernel_x16 + fused compositing" : "net_kernel_x16"), (double)N * SF * m->fine_trunk_x16.algo_flops_per_sample, (double)N * SF * m->fine_trunk_x16.mfma_flops_per_sample,
                       [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, nf, m->num_cus, stream); });
         } else {
             nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
-            e = timed(2, (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,
+            e = timed(2, (fuse_fine ? "net_kernel (trunk only) + fused compositing" : "net_kernel (trunk only)"), (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,
                       [&] { return launch_net(m->precision, false, m->views, trunk_arch(m->arch_id), nf, m->num_cus, stream); });
         }
     } else {
         nf.wstream = m->fine.stream; nf.bias = m->fine.bias;
         nf.bent4 = bent4;
-        e = timed(2, (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
+        e = timed(2, (m->has_bend ? "net_kernel (fused bender)" : (fuse_fine ? "net_kernel + fused compositing" : "net_kernel")), (double)N * SF * m->fine.algo_flops_per_sample, (double)N * SF * m->fine.mfma_flops_per_sample,
                   [&] { return launch_net(m->precision, m->has_bend, m->views, m->exact ? 3 + m->arch_id : m->arch_id, nf, m->num_cus, stream); });
     }
     if (e != hipSuccess) return NRNERF_ERR_HIP;
@@ -2202,7 +2228,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
 
     // ---- K3: fine composite
     const CompositeArgs cf = final_composite(SF, z_fine, a->noise_fine, a->fine, raw_f);
-    e = timed(3, 0, 0, [&] { return launch_composite(cf, stream); });
+    e = timed(3, "composite_kernel", 0, 0, [&] { return launch_composite(cf, stream); });
     if (e != hipSuccess) return NRNERF_ERR_HIP;
     return NRNERF_OK;
 } NRN_CATCH
@@ -2257,6 +2283,8 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
     const bool fine = a->which == 1 && !m->gen_fine_is_coarse;
     const nrnerf_model::GenTrainNet& tn = m->gen_tn[fine ? 1 : 0];
     if (!backward && (!a->pts4 || !a->raw4 || (tn.views && !a->dirs) || (tn.lat > 0 && !a->latents))) return NRNERF_ERR_INVALID;
+    // the epilogue writes channels 0..3 of a row of `raw`, and channel 4 when raw_ch > 4: the row must hold them and the network must have them
+    if (!backward && a->raw && (a->raw_ch < 4 || a->raw_ch > (fine ? m->gen_fine : m->gen_coarse).output_ch)) return NRNERF_ERR_INVALID;
     if (backward && (!a->d_raw4 || !a->d_pre || !a->d_enc0 || (tn.skip && !a->d_enc1) || (tn.views && !a->d_encv))) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
     DeviceGuard guard(m->device);
@@ -2719,6 +2747,7 @@ int nrnerf_profile_end(nrnerf_model* m, nrnerf_profile* out) try {
         out->launches[e.kernel] += 1;
         out->flops[e.kernel] += e.flops;
         out->mfma_flops[e.kernel] += e.mfma;
+        if (e.name) std::snprintf(out->kernel_name[e.kernel], sizeof(out->kernel_name[e.kernel]), "%s", e.name);
         (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
     m->prof_events.clear();

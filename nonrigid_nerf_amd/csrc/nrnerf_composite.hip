@@ -41,105 +41,8 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) composite_kernel(const Compo
     composite_ray<EPL>(a, ray, ray_ok, lane, [&](int ic) { return *(const f32x4*)(a.raw4 + ((size_t)ray * S + ic) * 4); }, z, w);
 
     if constexpr (SAMPLE) {
-        const int I = a.n_importance;
-        const int nb = S - 1;          // bins = mid-points; cdf has nb entries (run_nerf_helpers.py:657-659)
-        // ---- pdf / cdf over weights[1:-1] + 1e-5 (rnh:654-659)
-        float v[EPL], vs = 0.f;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            const int i = lane * EPL + k;
-            v[k] = (i >= 1 && i <= S - 2) ? __fadd_rn(w[k], 1e-5f) : 0.0f;
-            vs += v[k];
-        }
-        const float total = wave_sum(vs);
-        float lrun = 0.f, lpre[EPL];
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) { lrun += __fdiv_rn(v[k], total); lpre[k] = lrun; }      // pdf = w / sum (:655)
-        const float lincl = wave_scan_add(lrun, lane);
-        const float lbase = lincl - lrun;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            const int i = lane * EPL + k;
-            if (i < nb) {
-                s_cdf[wave][i] = (i == 0) ? 0.0f : lbase + lpre[k];                            // cumsum (:656)
-                s_bins[wave][i] = __fmul_rn(0.5f, __fadd_rn(z[k + 1], z[k]));                  // train.py:910
-            }
-            if (i < S) s_z[wave][i] = z[k];
-        }
-        __syncthreads();
-        // ---- inverse CDF at u = linspace(0,1,I) (det=True) or at the caller's uniforms (det=False), rnh:663-696
-        float zsum = 0.f;
-        for (int k = lane; k < I; k += 64) {
-            const float u = a.u ? a.u[(size_t)ray * I + k] : c_lin01(k, I);                   // rnh:663-665
-            int lo = 0, hi = nb;       // lower_bound: first idx with cdf[idx] >= u  (searchsorted right=False)
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cdf[wave][mid] < u) lo = mid + 1; else hi = mid; }
-            const int below = lo - 1 > 0 ? lo - 1 : 0;                                         // :683
-            const int above = lo < nb - 1 ? lo : nb - 1;                                       // :684
-            const float c0 = s_cdf[wave][below], c1 = s_cdf[wave][above];
-            const float b0 = s_bins[wave][below], b1 = s_bins[wave][above];
-            float denom = __fsub_rn(c1, c0);                                                   // :693
-            if (denom < 1e-5f) denom = 1.0f;                                                   // :694
-            const float t = __fdiv_rn(__fsub_rn(u, c0), denom);                                // :695
-            const float zs = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));                   // :696
-            s_z[wave][S + k] = zs;
-            zsum += zs;
-        }
-        __syncthreads();
-        const int n = S + I;
-        // ---- z_std (population std of the importance samples), train.py:959
-        const float mean = wave_sum(zsum) / (float)I;
-        float var = 0.f;
-        for (int k = lane; k < I; k += 64) { const float d = s_z[wave][S + k] - mean; var += d * d; }
-        var = wave_sum(var) / (float)I;
-        if (ray_ok && lane == 0 && a.z_std) a.z_std[ray] = sqrtf(var);
-        // ---- merge (train.py:920): the values torch.sort would return, via the stable rank of every depth.
-        // Coarse depths are strictly increasing.  If the importance samples are non-decreasing too (the inverse CDF is
-        // monotone; rounding can break it by an ulp), ranks follow from one binary search into the other list:
-        //   rank(coarse i) = i + #{samples <  z_i}          (stable: ties keep the concatenation order, coarse first)
-        //   rank(sample k) = k + #{coarse  <= s_k}
-        // Otherwise fall back to counting against all n elements (correct for any input order).
-        // split-bender path: coarse sample i keeps its bent point, moved to its row among the merged depths; importance
-        // sample k is listed (depth, row) for the stand-alone bender kernel
-        auto split_out = [&](int idx, int rank, float depth) {
-            if (!a.rank_new) return;
-            if (idx < S) {
-                if (a.split_bent_in)      // (training asks for the new samples' list only: nrnerf_composite_args.z_new / rank_new)
-                    *(f32x4*)(a.split_bent_out + ((size_t)ray * n + rank) * 4) = *(const f32x4*)(a.split_bent_in + ((size_t)ray * S + idx) * 4);
-            } else {
-                a.rank_new[(size_t)ray * I + (idx - S)] = (uint8_t)rank;
-                a.z_new[(size_t)ray * I + (idx - S)] = depth;
-            }
-        };
-        bool mono = true;
-        for (int k = lane; k < I; k += 64)
-            if (k > 0 && s_z[wave][S + k] < s_z[wave][S + k - 1]) mono = false;
-        mono = __all(mono);
-        if (mono) {
-            for (int idx = lane; idx < n; idx += 64) {
-                const float mine = s_z[wave][idx];
-                int lo, hi, rank;
-                if (idx < S) {      // count samples strictly below
-                    lo = 0; hi = I;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[wave][S + mid] < mine) lo = mid + 1; else hi = mid; }
-                    rank = idx + lo;
-                } else {            // count coarse depths <= mine
-                    lo = 0; hi = S;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[wave][mid] <= mine) lo = mid + 1; else hi = mid; }
-                    rank = (idx - S) + lo;
-                }
-                if (ray_ok) { a.z_out[(size_t)ray * n + rank] = mine; split_out(idx, rank, mine); }
-            }
-        } else {
-            for (int idx = lane; idx < n; idx += 64) {
-                const float mine = s_z[wave][idx];
-                int rank = 0;
-                for (int jj = 0; jj < n; ++jj) {
-                    const float o = s_z[wave][jj];
-                    rank += (o < mine || (o == mine && jj < idx)) ? 1 : 0;
-                }
-                if (ray_ok) { a.z_out[(size_t)ray * n + rank] = mine; split_out(idx, rank, mine); }
-            }
-        }
+        // ---- sample_pdf, z_std, merge: shared with the coarse epilogue of the 16x16x32 trunk kernel (nrnerf_composite_ray.h)
+        sample_merge_ray<EPL, false>(a, ray, ray_ok, lane, z, w, s_cdf[wave], s_bins[wave], s_z[wave]);
     }
 }
 

@@ -210,4 +210,126 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, const int 
 
 }
 
+// ---- the COARSE pass of a hierarchical render, after composite_ray: inverse-CDF sampling of the importance depths (sample_pdf,
+// run_nerf_helpers.py:651-698), z_std (train.py:959) and the sort-merge of coarse and importance depths (train.py:920) of ONE ray by ONE
+// wavefront.  z / w: what composite_ray returned (lane l: samples l * EPL ..).  s_cdf / s_bins [64 * EPL], s_z [S + I]: LDS areas of THIS
+// wave.  Shared by composite_kernel<EPL, true> (one wave per ray) and the coarse epilogue of net_kernel_x16 (a wave owns whole rays and
+// goes on to the next one): the same code, hence the same bits.  WAVE_LOCAL: the areas are private to the wave, so a compiler-level fence
+// orders the phases (LDS operations of one wave execute in order); false: a workgroup barrier, as composite_kernel always had it.
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void ray_phase_sync() {
+    if constexpr (WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int EPL, bool WAVE_LOCAL>
+__device__ __forceinline__ void sample_merge_ray(const CompositeArgs& a, const int ray, const bool ray_ok, const int lane,
+                                                 const float (&z)[EPL + 1], const float (&w)[EPL], float* s_cdf, float* s_bins, float* s_z) {
+    const int S = a.S, I = a.n_importance;
+    const int nb = S - 1;          // bins = mid-points; cdf has nb entries (run_nerf_helpers.py:657-659)
+    // ---- pdf / cdf over weights[1:-1] + 1e-5 (rnh:654-659)
+    float v[EPL], vs = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        v[k] = (i >= 1 && i <= S - 2) ? __fadd_rn(w[k], 1e-5f) : 0.0f;
+        vs += v[k];
+    }
+    const float total = wave_sum(vs);
+    float lrun = 0.f, lpre[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) { lrun += __fdiv_rn(v[k], total); lpre[k] = lrun; }      // pdf = w / sum (:655)
+    const float lincl = wave_scan_add(lrun, lane);
+    const float lbase = lincl - lrun;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = lane * EPL + k;
+        if (i < nb) {
+            s_cdf[i] = (i == 0) ? 0.0f : lbase + lpre[k];                            // cumsum (:656)
+            s_bins[i] = __fmul_rn(0.5f, __fadd_rn(z[k + 1], z[k]));                  // train.py:910
+        }
+        if (i < S) s_z[i] = z[k];
+    }
+    ray_phase_sync<WAVE_LOCAL>();
+    // ---- inverse CDF at u = linspace(0,1,I) (det=True) or at the caller's uniforms (det=False), rnh:663-696
+    float zsum = 0.f;
+    for (int k = lane; k < I; k += 64) {
+        const float u = a.u ? gmem(a.u)[(size_t)ray * I + k] : c_lin01(k, I);             // rnh:663-665
+        int lo = 0, hi = nb;       // lower_bound: first idx with cdf[idx] >= u  (searchsorted right=False)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cdf[mid] < u) lo = mid + 1; else hi = mid; }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;                                         // :683
+        const int above = lo < nb - 1 ? lo : nb - 1;                                       // :684
+        const float c0 = s_cdf[below], c1 = s_cdf[above];
+        const float b0 = s_bins[below], b1 = s_bins[above];
+        float denom = __fsub_rn(c1, c0);                                                   // :693
+        if (denom < 1e-5f) denom = 1.0f;                                                   // :694
+        const float t = __fdiv_rn(__fsub_rn(u, c0), denom);                                // :695
+        const float zs = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));                   // :696
+        s_z[S + k] = zs;
+        zsum += zs;
+    }
+    ray_phase_sync<WAVE_LOCAL>();
+    const int n = S + I;
+    // ---- z_std (population std of the importance samples), train.py:959
+    const float mean = wave_sum(zsum) / (float)I;
+    float var = 0.f;
+    for (int k = lane; k < I; k += 64) { const float d = s_z[S + k] - mean; var += d * d; }
+    var = wave_sum(var) / (float)I;
+    if (ray_ok && lane == 0 && a.z_std) gmem(a.z_std)[ray] = sqrtf(var);
+    // ---- merge (train.py:920): the values torch.sort would return, via the stable rank of every depth.
+    // Coarse depths are strictly increasing.  If the importance samples are non-decreasing too (the inverse CDF is
+    // monotone; rounding can break it by an ulp), ranks follow from one binary search into the other list:
+    //   rank(coarse i) = i + #{samples <  z_i}          (stable: ties keep the concatenation order, coarse first)
+    //   rank(sample k) = k + #{coarse  <= s_k}
+    // Otherwise fall back to counting against all n elements (correct for any input order).
+    // split-bender path: coarse sample i keeps its bent point, moved to its row among the merged depths; importance
+    // sample k is listed (depth, row) for the stand-alone bender kernel
+    auto split_out = [&](int idx, int rank, float depth) {
+        if (!a.rank_new) return;
+        if (idx < S) {
+            if (a.split_bent_in)      // (training asks for the new samples' list only: nrnerf_composite_args.z_new / rank_new)
+                *(__attribute__((address_space(1))) f32x4*)(gmem(a.split_bent_out) + ((size_t)ray * n + rank) * 4) =
+                    *(const __attribute__((address_space(1))) f32x4*)(gmem(a.split_bent_in) + ((size_t)ray * S + idx) * 4);
+        } else {
+            gmem(a.rank_new)[(size_t)ray * I + (idx - S)] = (uint8_t)rank;
+            gmem(a.z_new)[(size_t)ray * I + (idx - S)] = depth;
+        }
+    };
+    bool mono = true;
+    for (int k = lane; k < I; k += 64)
+        if (k > 0 && s_z[S + k] < s_z[S + k - 1]) mono = false;
+    mono = __all(mono);
+    if (mono) {
+        for (int idx = lane; idx < n; idx += 64) {
+            const float mine = s_z[idx];
+            int lo, hi, rank;
+            if (idx < S) {      // count samples strictly below
+                lo = 0; hi = I;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[S + mid] < mine) lo = mid + 1; else hi = mid; }
+                rank = idx + lo;
+            } else {            // count coarse depths <= mine
+                lo = 0; hi = S;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[mid] <= mine) lo = mid + 1; else hi = mid; }
+                rank = (idx - S) + lo;
+            }
+            if (ray_ok) { gmem(a.z_out)[(size_t)ray * n + rank] = mine; split_out(idx, rank, mine); }
+        }
+    } else {
+        for (int idx = lane; idx < n; idx += 64) {
+            const float mine = s_z[idx];
+            int rank = 0;
+            for (int jj = 0; jj < n; ++jj) {
+                const float o = s_z[jj];
+                rank += (o < mine || (o == mine && jj < idx)) ? 1 : 0;
+            }
+            if (ray_ok) { gmem(a.z_out)[(size_t)ray * n + rank] = mine; split_out(idx, rank, mine); }
+        }
+    }
+}
+
 }  // namespace nrn

@@ -71,7 +71,12 @@ struct WRingRT {
 };
 
 // VIEWS: the view-dependent head behind the trunk (directions = finite differences of the points' rows, as net_kernel_x16<VIEWS>)
-template <class P, int WC, int NB, bool VIEWS>
+// FUSE: the pass is a FINAL one and its compositing (raw2outputs, train.py:943-950) runs as the kernel's epilogue, as in net_kernel_x16 --
+// a wave owns whole rays (groups of RW rays = TG iterations of NB blocks, strided over the grid), keeps their raw outputs in its own LDS
+// stage and composites them after the group's last iteration (composite_ray: the composite kernel's own code, same bits); the pass' raw
+// array never reaches HBM and the composite launch goes.  Passes of up to 256 samples (a lane owns 1..4 of them: one code block per
+// case behind a switch -- this kernel is not the one whose last per cent is counted).
+template <class P, int WC, int NB, bool VIEWS, bool FUSE = false>
 __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
     constexpr int WAVES = 4;
     using PE = PolF16;                                                // the encoding's operands are f16 in both modes
@@ -104,17 +109,43 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
     const int bpr = (S + 15) >> 4;
     const long long nblocks = (long long)a.n_rays * bpr;
     const long long per_wg = (long long)WAVES * NB;
-    for (long long b0 = (long long)blockIdx.x * per_wg; b0 < nblocks; b0 += (long long)gridDim.x * per_wg) {
+    // (FUSE) ray groups, as net_kernel_x16: RW = the fewest rays whose blocks fill whole iterations of NB blocks
+    const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
+    const int TG = RW * bpr / NB;
+    const long long ngroups = ((long long)a.n_rays + WAVES * RW - 1) / (WAVES * RW);
+    f32x4* const stage0 = (f32x4*)(bias_lds + a.n_bias_tiles * 16);
+    f32x4* const stage_w = stage0 + (size_t)wave * RW * bpr * 16;
+    const CompositeArgs& fa = *(const CompositeArgs*)(stage0 + (size_t)WAVES * RW * bpr * 16);      // (in LDS: a kernel argument read per use costs scalar loads)
+    if constexpr (FUSE) {
+        static_assert(sizeof(CompositeArgs) <= 256, "the compositing arguments' LDS slot");
+        int* dst = (int*)(stage0 + (size_t)WAVES * RW * bpr * 16);
+        const int* src = (const int*)&a.fuse;
+        for (int i = tid; i < (int)(sizeof(CompositeArgs) / 4); i += WAVES * 64) dst[i] = src[i];
+        __syncthreads();
+    }
+    int tg = 0;
+    long long grp = blockIdx.x;
+    for (long long b0 = (long long)blockIdx.x * per_wg; FUSE ? (grp < ngroups) : (b0 < nblocks); b0 += (long long)gridDim.x * per_wg) {
         unsigned so[NB];
         bool ok[NB];
         efrag enc[NB][NS_E];
         efrag encv[NB][1];
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            const long long blk_raw = b0 + (long long)wave * NB + b;
-            const bool blk_ok = blk_raw < nblocks;
-            const long long blk = blk_ok ? blk_raw : nblocks - 1;
-            const int ray = (int)(blk / bpr), bir = (int)(blk % bpr);
+            bool blk_ok;
+            int ray, bir;
+            if constexpr (FUSE) {                   // block q of this wave's group: ray (grp * WAVES + wave) * RW + q / bpr
+                const int q = tg * NB + b;
+                const long long rr = (grp * WAVES + wave) * RW + q / bpr;
+                blk_ok = rr < a.n_rays;
+                ray = (int)(blk_ok ? rr : a.n_rays - 1);
+                bir = q % bpr;
+            } else {
+                const long long blk_raw = b0 + (long long)wave * NB + b;
+                blk_ok = blk_raw < nblocks;
+                const long long blk = blk_ok ? blk_raw : nblocks - 1;
+                ray = (int)(blk / bpr); bir = (int)(blk % bpr);
+            }
             const int sidx = bir * 16 + n;
             ok[b] = blk_ok && sidx < S;
             so[b] = (unsigned)ray * (unsigned)S + (unsigned)(sidx < S ? sidx : S - 1);
@@ -227,33 +258,79 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             if (ok[b] && g == 0) {
-                *(f32x4*)(a.raw4 + (size_t)so[b] * 4) = raw[b];
+                if constexpr (!FUSE) *(f32x4*)(a.raw4 + (size_t)so[b] * 4) = raw[b];
                 if (a.raw_out) {
                     float* ro = a.raw_out + (size_t)so[b] * a.raw_ch;
                     ro[0] = raw[b][0]; ro[1] = raw[b][1]; ro[2] = raw[b][2]; ro[3] = raw[b][3];
                 }
             }
             if (ok[b] && g == 1 && a.raw_out && a.raw_ch > 4) a.raw_out[(size_t)so[b] * a.raw_ch + 4] = raw[b][0];
+            if (FUSE && g == 0) stage_w[(tg * NB + b) * 16 + n] = raw[b];
         });
+        if constexpr (FUSE) {
+            if (tg + 1 == TG) {       // the group's last iteration: composite this wave's rays from its LDS stage (train.py:943-950)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int r = 0; r < RW; ++r) {
+                    const long long rr = (grp * WAVES + wave) * RW + r;
+                    const bool ray_ok = rr < a.n_rays;
+                    const int cray = (int)(ray_ok ? rr : a.n_rays - 1);
+                    const f32x4* sw = stage_w + r * bpr * 16;
+                    auto raw_at = [&](int ic) { return sw[ic]; };
+                    switch ((S + 63) >> 6) {
+                        case 1: { float cz[2], cw[1]; composite_ray<1, false>(fa, cray, ray_ok, lane, raw_at, cz, cw); break; }
+                        case 2: { float cz[3], cw[2]; composite_ray<2, false>(fa, cray, ray_ok, lane, raw_at, cz, cw); break; }
+                        case 3: { float cz[4], cw[3]; composite_ray<3, false>(fa, cray, ray_ok, lane, raw_at, cz, cw); break; }
+                        default: { float cz[5], cw[4]; composite_ray<4, false>(fa, cray, ray_ok, lane, raw_at, cz, cw); break; }
+                    }
+                }
+                tg = 0; grp += gridDim.x;
+            } else {
+                tg += 1;
+            }
+        }
     }
     st.drain();
 }
 
-template <class P, int WC, bool VIEWS>
-static hipError_t launch_gx16_t(const GxArgs& a, int num_cus, hipStream_t stream) {
+template <class P, int WC, bool VIEWS, bool FUSE>
+static hipError_t launch_gx16_tf(const GxArgs& a, int num_cus, hipStream_t stream) {
     constexpr int WAVES = 4, NB = (WC > 256) ? 2 : 4;
-    if (!a.pts4 || !a.raw4 || a.S < 1 || a.depth < 1 || a.L < 0 || a.L > GX_MAX_L) return hipErrorInvalidValue;
-    const size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)a.n_bias_tiles * 16 * sizeof(float);
+    if (!a.pts4 || (!a.raw4 && !FUSE) || a.S < 1 || a.depth < 1 || a.L < 0 || a.L > GX_MAX_L) return hipErrorInvalidValue;
+    size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)a.n_bias_tiles * 16 * sizeof(float);
+    if (FUSE) {
+        if (a.S > 256 || a.fuse.n_importance != 0 || a.fuse.S != a.S) return hipErrorInvalidValue;
+        const int bpr_ = (a.S + 15) / 16;
+        const int RW = (bpr_ % NB == 0) ? 1 : ((2 * bpr_) % NB == 0 ? 2 : NB);
+        lds += (size_t)WAVES * RW * bpr_ * 16 * 16 + 256;            // the waves' raw stages + the compositing arguments
+    }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (VIEWS && (a.LV < 0 || a.LV > GX_MAX_LV)) return hipErrorInvalidValue;
-    auto kern = gx16_kernel<P, WC, NB, VIEWS>;
+    // sample rows are 32-bit numbers in the kernel (so[], the neighbour's row): refuse what would wrap (launch_bend_x16_t does the same)
+    if ((long long)a.n_rays * a.S >= (1ll << 32) || (long long)a.n_rays * ((a.S + 15) / 16) >= (1ll << 31)) return hipErrorInvalidValue;
+    auto kern = gx16_kernel<P, WC, NB, VIEWS, FUSE>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipErrorUnknown;
     const long long bpr = (a.S + 15) / 16;
-    const long long want = ((long long)a.n_rays * bpr + WAVES * NB - 1) / (WAVES * NB);
+    long long want = ((long long)a.n_rays * bpr + WAVES * NB - 1) / (WAVES * NB);
+    if (FUSE) {
+        const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
+        want = ((long long)a.n_rays + WAVES * RW - 1) / (WAVES * RW);          // groups of WAVES * RW whole rays
+    }
     if (want <= 0) return hipSuccess;
     const int grid = (int)(want < num_cus ? want : num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
+}
+template <class P, int WC, bool VIEWS>
+static hipError_t launch_gx16_t(const GxArgs& a, int num_cus, hipStream_t stream) {
+    return a.fuse_on ? launch_gx16_tf<P, WC, VIEWS, true>(a, num_cus, stream) : launch_gx16_tf<P, WC, VIEWS, false>(a, num_cus, stream);
+}
+// rays of one fused-compositing group of the width-class kernel (the API layer's "enough rays to fuse" threshold)
+static inline long long gx16_rays_per_group_of(int wc, int S) {
+    const int NB = (wc > 256) ? 2 : 4, bpr = (S + 15) / 16;
+    const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
+    return 4ll * RW;
 }
 
 }  // namespace nrn

@@ -18,4 +18,5 @@ hipError_t launch_gx16(int precision, int wc, bool views, const GxArgs& a, int n
         default: return hipErrorInvalidValue;
     }
 }
+long long gx16_rays_per_group(int wc, int S) { return gx16_rays_per_group_of(wc, S); }
 }  // namespace nrn

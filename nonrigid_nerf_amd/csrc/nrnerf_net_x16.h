@@ -157,7 +157,10 @@ __device__ __forceinline__ void dense_x16(ST& st, const __attribute__((address_s
 // VIEWS: the view-dependent head (rnh:284-304) behind the trunk -- a sample's direction = the finite difference of the points of
 // NetArgs::pts4 along its ray (rnh:339-351; the neighbour read from the same array, as the 32x32x16 trunk-only kernel does), its
 // encoding one more B operand; [views_linears[0] o feature_linear | alpha_linear] and rgb_linear as two more dense_x16 calls.
-template <class P, class A, int WAVES, int EPL, bool VIEWS = false>
+// SAMPLE (EPL > 0): the pass is the COARSE one of a hierarchical render -- behind composite_ray the wave also draws its ray's importance
+// depths, z_std and the merge (sample_merge_ray, nrnerf_composite_ray.h: composite_kernel<EPL, true>'s own code) from a private LDS area,
+// i.e. K1 of nrnerf_render's sequence becomes this kernel's epilogue and the coarse raw array never reaches HBM (train.py:889-920).
+template <class P, class A, int WAVES, int EPL, bool VIEWS = false, bool SAMPLE = false>
 __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a) {
     using PL = PlanX16<P, A, VIEWS>;
     using PE = PolF16;                                                // the encoding's operands are f16 in both modes
@@ -195,6 +198,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     f32x4* const stage0 = (f32x4*)(bias_lds + PL::NTILES * 16);
     f32x4* const stage_w = stage0 + (size_t)wave * RW * bpr * 16;
     const CompositeArgs& fa = *(const CompositeArgs*)(stage0 + (size_t)WAVES * RW * bpr * 16);      // (in LDS: see nrnerf_net_mb.h)
+    static_assert(sizeof(CompositeArgs) <= 256, "the compositing arguments' LDS slot");
+    // (SAMPLE) this wave's cdf / bins [64 EPL each] and merge list [S + I <= 256 (+ 4)]
+    constexpr int SCR = SAMPLE ? (2 * 64 * EPL + 260) : 0;
+    float* const scr_w = (float*)((char*)(stage0 + (size_t)WAVES * RW * bpr * 16) + 256) + (size_t)wave * SCR;
     if constexpr (fuse) {
         int* dst = (int*)(stage0 + (size_t)WAVES * RW * bpr * 16);
         const int* src = (const int*)&a.fuse;
@@ -422,6 +429,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
                         auto raw_at = [&](int ic) { return sw[ic]; };
                         float cz[EPL + 1], cw[EPL];
                         composite_ray<EPL, true>(fa, cray, ray_ok, lane, raw_at, cz, cw, cpre[r]);
+                        if constexpr (SAMPLE) sample_merge_ray<EPL, true>(fa, cray, ray_ok, lane, cz, cw, scr_w, scr_w + 64 * EPL, scr_w + 128 * EPL);
                     }
                 });
             }
@@ -444,7 +452,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
 #endif
 }
 
-template <class P, class A, int EPL, bool VIEWS = false>
+template <class P, class A, int EPL, bool VIEWS = false, bool SAMPLE = false>
 static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t stream) {
     constexpr int WAVES = X16Cfg<A>::WAVES;
     using PL = PlanX16<P, A, VIEWS>;
@@ -455,17 +463,22 @@ static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t st
     const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
     size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float);
     if (a.fuse_on) {
-        if (a.S > 256 || a.fuse.n_importance != 0 || a.fuse.S != a.S) return hipErrorInvalidValue;
+        if (a.S > 256 || (a.fuse.n_importance != 0) != SAMPLE || a.fuse.S != a.S) return hipErrorInvalidValue;
         lds += (size_t)WAVES * RW * bpr * 16 * 16 + 256;            // the waves' raw stages + the compositing arguments
+        if (SAMPLE) {
+            if (a.S + a.fuse.n_importance > 256 || !a.fuse.z_out) return hipErrorInvalidValue;
+            lds += (size_t)WAVES * (2 * 64 * EPL + 260) * sizeof(float);
+        }
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = net_kernel_x16<P, A, WAVES, EPL, VIEWS>;
+    auto kern = net_kernel_x16<P, A, WAVES, EPL, VIEWS, SAMPLE>;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         // the largest request any launch can make: ring + bias table + the fused stages at bpr = 15 (RW = NB)
-        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + (size_t)WAVES * NB * 15 * 256 + 256;
+        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + (size_t)WAVES * NB * 15 * 256 + 256 +
+                               (SAMPLE ? (size_t)WAVES * (2 * 64 * EPL + 260) * sizeof(float) : 0);
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max < 160 * 1024 ? lds_max : 160 * 1024));
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;

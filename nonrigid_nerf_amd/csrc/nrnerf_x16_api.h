@@ -10,6 +10,9 @@ hipError_t launch_net_x16(int precision, int arch, bool views, const NetArgs& a,
 // rays of one fused-compositing group of that kernel: its waves per workgroup x the fewest rays whose 16-sample blocks fill whole
 // iterations -- the API layer's "enough rays to fuse" threshold asks here instead of restating the kernel's mapping
 long long x16_rays_per_group(int arch, int S);
+// the largest coarse pass (samples per ray) that has a kernel with the coarse epilogue (NetArgs::fuse with n_importance > 0: compositing +
+// sample_pdf + merge behind the trunk)
+int x16_coarse_epilogue_max_samples();
 // the stand-alone ray bender on 16x16x32 MFMAs (nrnerf_bend_x16.h): arch 0 = the 5 x 64 bender, 1 = 7 x 64; BendArgs::wstream / bias =
 // the image of pack_pass_x16_bend (f16 fragments of PlanX16Bend)
 hipError_t launch_bend_x16(int arch, const BendArgs& a, int num_cus, hipStream_t stream);
@@ -25,6 +28,9 @@ struct GxArgs {
     int depth, skip, L;         // pts_linears count; index after which [input, h] is concatenated (-1: never); encoding frequencies
     int n_bias_tiles;
     int LV;                     // (view-dependent head) direction-encoding frequencies
+    int fuse_on;                // the pass' compositing as the kernel's epilogue (a FINAL pass of <= 256 samples; raw4 may then be null)
+    CompositeArgs fuse;         // its arguments (raw4 unused, n_importance 0)
 };
 hipError_t launch_gx16(int precision, int wc, bool views, const GxArgs& a, int num_cus, hipStream_t stream);
+long long gx16_rays_per_group(int wc, int S);          // rays of one fused-compositing group of that kernel
 }  // namespace nrn

@@ -399,7 +399,7 @@ class Model:
     def profile_end(self) -> dict:
         p = _lib.Profile()
         _lib.check(self.lib.nrnerf_profile_end(self.handle, C.byref(p)), "nrnerf_profile_end")
-        return {name: dict(ms=p.ms[i], launches=p.launches[i], flops=p.flops[i], mfma_flops=p.mfma_flops[i])
+        return {name: dict(ms=p.ms[i], launches=p.launches[i], flops=p.flops[i], mfma_flops=p.mfma_flops[i], kernel=p.kernel_name[i].value.decode())
                 for i, name in enumerate(_lib.KERNEL_NAMES)}
 
     def render(self, rays: torch.Tensor, latents: torch.Tensor | None, N_samples: int, N_importance: int = 0,
@@ -548,7 +548,13 @@ def get_model(network_fn, network_fine=None, precision: str | None = None, devic
             del per[k]                                                         # entries of collected fine nets / benders
         hit = per.get(key)
         if rb is not None:
-            _by_bender[rb] = (weakref.ref(network_fn), _wref(network_fine), precision, int(flags))
+            # which handle a caller that is handed the bender alone gets (model_of_bender): the last call's -- except that a plain
+            # render (flags 0) between a training call and its compute_divergence_loss does not displace the TRAINING handle of the
+            # same networks (flags != 0: a generic / training-only handle; resolved with flags 0 such an architecture has no training
+            # kernels and the divergence would quietly go to the reference)
+            prev = _by_bender.get(rb)
+            if int(flags) or prev is None or prev[3] == 0 or prev[0]() is not network_fn:
+                _by_bender[rb] = (weakref.ref(network_fn), _wref(network_fine), precision, int(flags))
         if hit is not None and hit[0] == fp:
             if isinstance(hit[1], Exception):
                 raise hit[1]

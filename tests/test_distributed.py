@@ -518,3 +518,76 @@ def test_bench_picks_the_fitted_checkpoint_of_the_requested_architecture_family(
     assert base(bench.fitted_checkpoint_for(ns(netwidth=128))) == "fitted_w128.tar"
     for other in (ns(netwidth=192), ns(use_viewdirs=True), ns(bend_depth=7), ns(use_viewdirs=True, bend_depth=7, exact_viewdirs=True)):
         assert bench.fitted_checkpoint_for(other) is None
+
+
+# ---- frame-sharded render_path (the no-collective partitioning; reference train.py:419-553) ---------------------------
+def _closed_form_frame(i, c2w, intrin, code):
+    """A stand-in renderer on the CPU tier: every pixel names its frame, its own index and the frame's latent code, so a frame that lands in the
+    wrong slot (or pixels of another rank's frame) shows.  The HIP path plugs in on the GPU tier (tests/test_gpu_parity.py)."""
+    H, W = int(intrin["height"]), int(intrin["width"])
+    px = torch.arange(H * W, dtype=torch.float32)
+    rgb = torch.stack([(px % 7) / 7.0, torch.full_like(px, (i % 5) / 5.0), torch.full_like(px, float(code[0, 0]))], -1)
+    return {"rgb_map": rgb, "disp_map": px + 1000.0 * i + float(c2w[0, 3]), "acc_map": torch.ones(H * W),
+            "surface_pts": rgb + 1.0, "surface_rigidity": px * 0.0 + i, "median_index": (px % 3).to(torch.int32)}
+
+
+def _frames_job(F):
+    poses = [torch.eye(4)[:3] + 0.01 * f for f in range(F)]
+    intr = [dict(height=3, width=5, focal_x=4.0, focal_y=4.0, center_x=2.5, center_y=1.5) for _ in range(F)]
+    codes = torch.linspace(0.0, 1.0, max(F, 1))[:, None].expand(-1, 4).contiguous()
+    return poses, intr, codes
+
+
+def _worker_frames(rank, world, port, F, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from nonrigid_nerf_amd.driver import frame_shard, render_path
+    poses, intr, codes = _frames_job(F)
+    kw = dict(near=0.1, far=1.0, network_fn=None)
+    calls = []
+
+    def fn(i, c2w, intrin, code):
+        calls.append(i)
+        return _closed_form_frame(i, c2w, intrin, code)
+
+    res = {}
+    for dt in ("float32", "uint8"):
+        calls.clear()
+        res["all_" + dt] = render_path(poses, intr, 1024, kw, codes, rgb_dtype=dt, group=True, gather="all", _frame_fn=fn, surface_outputs=(dt == "uint8"))
+        assert calls == frame_shard(F, world, rank), (calls, rank)         # this rank rendered its own frames and nothing else
+    res["root"] = render_path(poses, intr, 1024, kw, codes, group=True, gather="root", _frame_fn=fn)
+    res["none"] = render_path(poses, intr, 1024, kw, codes, group=True, gather=None, _frame_fn=fn)
+    torch.save(res, os.path.join(out_dir, f"frames_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F", [(2, 5), (2, 1), (8, 3), (8, 19)])
+def test_frame_sharded_render_path_matches_the_single_process_sequence(tmp_path, world, F):
+    """`driver.render_path(..., group=)`: rank r renders frames r, r + G, ... and ONE all-gather at the end gives every rank the sequence the
+    single-process call returns -- ragged frame counts (F = 5 over 2 ranks, 19 over 8), fewer frames than ranks (F = 1 over 2, 3 over 8: five
+    ranks render nothing and still take part in the collective), float and uint8 frames, gather "all" / "root" / None."""
+    import numpy as np
+    from nonrigid_nerf_amd.driver import frame_shard, render_path
+    mp.spawn(_worker_frames, args=(world, _free_port(), F, str(tmp_path)), nprocs=world, join=True)
+    poses, intr, codes = _frames_job(F)
+    kw = dict(near=0.1, far=1.0, network_fn=None)
+    want = {dt: render_path(poses, intr, 1024, kw, codes, rgb_dtype=dt, _frame_fn=_closed_form_frame, surface_outputs=(dt == "uint8")) for dt in ("float32", "uint8")}
+    assert want["uint8"][0].dtype == np.uint8 and want["float32"][0].shape == (F, 3, 5, 3)
+    for rank in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"frames_{rank}.pt"), weights_only=False)
+        mine = frame_shard(F, world, rank)
+        for dt in ("float32", "uint8"):
+            got = res["all_" + dt]
+            assert np.array_equal(got[0], want[dt][0]) and np.array_equal(got[1], want[dt][1]), (rank, dt)
+        det = res["all_uint8"][2]            # surface outputs stay rank-local: an entry per frame, None for the other ranks' frames
+        assert len(det) == F and all((det[f] is not None) == (f in mine) for f in range(F))
+        for f in mine:
+            assert all(np.array_equal(det[f][k], want["uint8"][2][f][k]) for k in ("surface_pts", "surface_rigidity", "median_index"))
+        own_rgb, own_disp = want["float32"][0][mine], want["float32"][1][mine]
+        if rank == 0:
+            assert np.array_equal(res["root"][0], want["float32"][0]) and np.array_equal(res["root"][1], want["float32"][1])
+        else:
+            assert np.array_equal(res["root"][0], own_rgb) and np.array_equal(res["root"][1], own_disp), rank
+        assert res["none"][0].shape[0] == len(mine) and np.array_equal(res["none"][0], own_rgb) and np.array_equal(res["none"][1], own_disp)

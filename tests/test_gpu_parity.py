@@ -1368,3 +1368,89 @@ def test_graphed_render_equals_the_eager_call(n_rays, cfg_kw, stochastic):
     same(after, eager(rays1, lat1))
     with pytest.raises(ValueError):
         g(rays1[:-1], lat1[:-1] if needs_lat else None)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("cfg_kw,flags,n", [
+    (dict(), {}, 3001),                                                                  # headline: 64 + 128; last group of rays half empty
+    (dict(N_samples=48, N_importance=37), {}, 4200),                                     # ragged: 3 blocks per ray -> groups of 4 rays per wave
+    (dict(N_samples=33, N_importance=64), dict(perturb=1.0, raw_noise_std=1.0), 4500),   # stochastic: caller's uniforms + noise on sigma
+    (dict(N_samples=128, N_importance=128), dict(white_bkgd=True), 2200),                # 128 coarse samples: two per lane, 256 merged
+    (dict(N_importance=64, use_viewdirs=True), {}, 2100),                                # view-dependent head behind the coarse trunk
+    (dict(N_importance=64, netwidth=128), {}, 4100),                                     # width 128: eight waves per workgroup
+], ids=["headline", "ragged", "stochastic", "coarse_128_white", "viewdirs", "narrow_128"])
+def test_coarse_epilogue_inside_the_trunk_kernel_equals_the_composite_launch_bit_for_bit(precision, cfg_kw, flags, n):
+    """north_star: "compositing fused into the ray loop" -- the COARSE pass of a hierarchical render (row g1).  With
+    NRNERF_FUSED_COARSE_EPILOGUE=1 (nrnerf_render_args.flags: NRNERF_RENDER_COARSE_EPILOGUE_ON) the coarse trunk kernel of the split path
+    composites each of its rays, draws the importance depths (sample_pdf), computes z_std and merges the depths as its epilogue
+    (train.py:889-920; sample_merge_ray: composite_kernel<EPL, true>'s own code), raw_c never reaching HBM; =0 keeps composite_kernel's own
+    launch.  Every output must have the same bits either way: the coarse maps, z_std, the merged depths, and -- through the new samples'
+    list and the carried-over bent points -- everything the fine pass makes of them."""
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 4)
+    rays, latents = make_rays(n, 31, cfg)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    R.set_precision(precision)
+    model = R.get_model(coarse, fine)
+    r, l = rays.to(DEV), latents.to(DEV)
+    outs, kernels = [], []
+    for on in ("1", "0"):
+        with _setenv("NRNERF_FUSED_COARSE_EPILOGUE", on):
+            torch.manual_seed(5)
+            randoms = R._draw_randoms(r, cfg.N_samples, cfg.N_importance, flags.get("perturb", 0.0), flags.get("raw_noise_std", 0.0))
+            model.profile_begin()
+            with torch.no_grad():
+                outs.append(model.render(r, l, cfg.N_samples, cfg.N_importance, retraw=True, want_z_vals=True, surface=True,
+                                         white_bkgd=bool(flags.get("white_bkgd")), randoms=randoms))
+            torch.cuda.synchronize()
+            kernels.append(model.profile_end())
+    fused, separate = outs
+    # the routes really differ: the fused one launched no coarse composite kernel, and the library says so
+    assert kernels[0]["composite_sample_coarse"]["launches"] == 0 and "sample_pdf" in kernels[0]["net_coarse"]["kernel"], kernels[0]
+    assert kernels[1]["composite_sample_coarse"]["launches"] == 1 and kernels[1]["net_coarse"]["kernel"] == "net_kernel_x16", kernels[1]
+    assert set(fused) == set(separate)
+    for k in fused:
+        assert torch.equal(torch.nan_to_num(fused[k].float()), torch.nan_to_num(separate[k].float())), k
+    assert torch.isfinite(fused["rgb_map"]).all() and float(fused["acc_map"].max()) > 0.5 and float(fused["z_std"].max()) > 0
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("cfg_kw,flags,n", [
+    (dict(N_importance=128, netdepth=6, netwidth=192, netwidth_fine=320, multires=8), {}, 3001),        # 192 merged samples: three per lane
+    (dict(N_samples=48, N_importance=37, netwidth=96), dict(raw_noise_std=1.0), 2049),                  # ragged, noise on sigma
+    (dict(N_samples=128, N_importance=128, netwidth=448), dict(white_bkgd=True), 1100),                 # 256 samples; two blocks per wave (width class 448)
+    (dict(N_importance=0, netwidth=192), {}, 2100),                                                     # coarse only: the coarse pass is the final one
+    (dict(N_importance=64, netwidth=160, use_viewdirs=True), {}, 2100),                                 # view-dependent head
+], ids=["w192_320", "w96_ragged_noise", "w448_256_white", "w192_coarse_only", "w160_viewdirs"])
+def test_width_class_kernel_with_fused_compositing_equals_the_composite_launch_bit_for_bit(precision, cfg_kw, flags, n):
+    """Row g1 for architectures outside the compiled set: the FINAL pass of the width-class trunk kernel (gx16_kernel<.., FUSE>) composites
+    its rays itself (composite_ray, the composite kernel's own code) instead of writing raw [N, S, 4] for a composite_kernel launch
+    (NRNERF_UNFUSED_COMPOSITE=1 keeps that route): same bits for every output, and the library reports which kernels ran."""
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 4)
+    rays, latents = make_rays(n, 37, cfg)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    R.set_precision(precision)
+    model = R.get_model(coarse, fine if cfg.N_importance > 0 else None)
+    assert model.generic
+    r, l = rays.to(DEV), latents.to(DEV)
+    final = "net_fine" if cfg.N_importance > 0 else "net_coarse"
+    final_composite = "composite_fine" if cfg.N_importance > 0 else "composite_sample_coarse"
+    outs, kernels = [], []
+    for unfused in ("0", "1"):
+        with _setenv("NRNERF_UNFUSED_COMPOSITE", unfused):
+            torch.manual_seed(5)
+            randoms = R._draw_randoms(r, cfg.N_samples, cfg.N_importance, 0.0, flags.get("raw_noise_std", 0.0))
+            model.profile_begin()
+            with torch.no_grad():
+                outs.append(model.render(r, l, cfg.N_samples, cfg.N_importance, retraw=True, want_z_vals=True, surface=True,
+                                         white_bkgd=bool(flags.get("white_bkgd")), randoms=randoms))
+            torch.cuda.synchronize()
+            kernels.append(model.profile_end())
+    assert kernels[0][final]["kernel"] == "gx16_kernel + fused compositing" and kernels[0][final_composite]["launches"] == 0, kernels[0]
+    assert kernels[1][final]["kernel"] == "gx16_kernel" and kernels[1][final_composite]["launches"] == 1, kernels[1]
+    fused, separate = outs
+    assert set(fused) == set(separate)
+    for k in fused:
+        assert torch.equal(torch.nan_to_num(fused[k].float()), torch.nan_to_num(separate[k].float())), k
+    assert torch.isfinite(fused["rgb_map"]).all() and float(fused["acc_map"].max()) > 0.5
