@@ -244,6 +244,79 @@ int nrnerf_model_update(nrnerf_model* model, const nrnerf_model_desc* desc, void
  * rule as nrnerf_model_update. */
 int64_t nrnerf_model_flat_size(const nrnerf_model* model);
 int nrnerf_model_update_device(nrnerf_model* model, const float* flat_params, int64_t n_floats, void* hip_stream);
+/* ABI 8: the optimiser step of a training iteration and the re-pack above as ONE call = two launches (reference: torch.optim.Adam over
+ * grad_vars, train.py:655-658, stepped at train.py:1606-1610).  Adam without weight decay / amsgrad, fp32, ONE launch over up to
+ * NRNERF_ADAM_MAX_SEGMENTS contiguous runs (parameter, gradient, exp_avg, exp_avg_sq: device pointers, the same length each) laid end to
+ * end; then, right behind it on the stream, every packed image of `model` is refreshed from `flat_params` exactly as
+ * nrnerf_model_update_device does it (flat_params is normally the storage the segments' `param` pointers point into: training.FusedAdam
+ * keeps the networks' parameters as views of one vector in the canonical order, so nothing is copied).  model == NULL or
+ * flat_params == NULL: the Adam launch alone.  (Both phases in one kernel behind a grid barrier measured slower on this multi-die part:
+ * csrc/nrnerf_optim.hip.)
+ * step: device scalar (float) holding the number of steps taken so far; the launch increments it (a captured step replays correctly).
+ * lr_device (optional): the learning rate as a device scalar -- a schedule inside a captured step; otherwise `lr`.
+ * Asynchronous on hip_stream; same concurrency rule as nrnerf_model_update. */
+#define NRNERF_ADAM_MAX_SEGMENTS 40
+typedef struct nrnerf_adam_segment {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    uint64_t n;
+} nrnerf_adam_segment;
+typedef struct nrnerf_adam_args {
+    uint32_t struct_size;
+    int32_t n_segments;
+    nrnerf_adam_segment segments[NRNERF_ADAM_MAX_SEGMENTS];
+    float lr, beta1, beta2, eps;
+    const float* lr_device;
+    float* step;
+    const float* flat_params;       /* [nrnerf_model_flat_size()] or NULL */
+    int64_t n_floats;
+    uint32_t* barrier;              /* model == NULL only: two zero-initialised words of device memory the launch uses to find its last workgroup (a handle owns its own) */
+} nrnerf_adam_args;
+int nrnerf_adam_step(nrnerf_model* model, const nrnerf_adam_args* args, void* hip_stream);
+
+/* ABI 8: the weight and bias gradients of a NON-COMPILED trunk (any --netdepth / --netwidth, train.py:1004-1010; what autograd derives
+ * from nn.Linear in NeRF.forward, rnh:253-258, 284-306) over the two arrays its training kernels save ROW-MAJOR
+ * (nrnerf_generic_trunk_forward / _backward: acts and d_pre, [sample][feature], bf16 or fp32) -- a list of products
+ *     out[out_offset + o * ldo + k] = sum_m a[m][o] b[m][k]   (o < wo, k < wi),     out[bias_offset + o] = sum_m a[m][o]  (bias_offset >= 0)
+ * as one pass over panels of up to 256 x 256 (bf16: v_mfma_f32_16x16x32_bf16 fed by LDS transpose reads; fp32: v_mfma_f32_16x16x4_f32) and one
+ * deterministic reduction of the partial sums.  a / b: device pointers, 16-byte aligned, lda / ldb in elements with 16-byte aligned rows that are
+ * padded to whole 16-byte pieces (lda >= wo rounded up to 8 bf16 / 4 fp32 values; NRNERF_ERR_INVALID otherwise); `out` [out_floats] is written in full
+ * (positions no job covers: zero).  workspace: nrnerf_tn_workspace_bytes() bytes of device memory.  Replaces round 5's chunked library
+ * GEMMs (training.py::_chunked_tn_product). */
+typedef struct nrnerf_tn_job {
+    const void* a; const void* b;
+    int32_t lda, ldb, wo, wi;
+    int32_t ldo, reserved;
+    int64_t out_offset, bias_offset;
+} nrnerf_tn_job;
+typedef struct nrnerf_tn_args {
+    uint32_t struct_size;
+    int32_t n_jobs, is_bf16, reserved;
+    int64_t n_rows, out_floats;
+    const nrnerf_tn_job* jobs;      /* host array [n_jobs] */
+    float* out;
+    void* workspace; size_t workspace_bytes;
+} nrnerf_tn_args;
+size_t nrnerf_tn_workspace_bytes(const nrnerf_tn_args* args);
+int nrnerf_tn_products(const nrnerf_tn_args* args, void* hip_stream);
+
+/* ABI 8: Embedder.embed (run_nerf_helpers.py:120-150) of 3-vectors as ROWS, and its transposed Jacobian -- the encodings a non-compiled
+ * trunk's weight-gradient products read (nrnerf_tn_products: the layers fed by the encoding) and the gradient wrt the points / view
+ * directions from the encodings' gradients (nrnerf_generic_trunk_backward's d_enc0 / d_enc1 / d_encv).  Columns in the reference's order:
+ * [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], 3 each.
+ *   forward:  enc [n_rows][enc_cols] (fp32 or bf16) = [encoding (3 + 6 L) | codes[row / rows_per_code][0..n_lat) when codes != NULL | zeros]
+ *   backward: d_src [n_rows][d_src_stride] = J^T (d_enc0 [+ d_enc1]) in columns 0..2, zeros behind (fp32 rows of stride d_enc_stride) */
+typedef struct nrnerf_encoding_args {
+    uint32_t struct_size;
+    int32_t n_freqs;
+    int64_t n_rows;
+    const float* src; int32_t src_stride;
+    void* enc; int32_t enc_cols; int32_t enc_is_bf16;
+    const float* codes; int32_t n_lat; int32_t rows_per_code;
+    const float* d_enc0; const float* d_enc1; int32_t d_enc_stride;
+    float* d_src; int32_t d_src_stride;
+} nrnerf_encoding_args;
+int nrnerf_encoding_forward(const nrnerf_encoding_args* args, void* hip_stream);
+int nrnerf_encoding_backward(const nrnerf_encoding_args* args, void* hip_stream);
 void nrnerf_model_destroy(nrnerf_model* model);
 /* the nrnerf_precision the handle was created with (decides the layout of nrnerf_trunk_args.acts / d_pre), or
  * NRNERF_ERR_INVALID for NULL */

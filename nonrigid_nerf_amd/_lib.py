@@ -241,6 +241,39 @@ class DivergenceArgs(C.Structure):
                 ("tangent", C.c_void_p), ("g_tangent", C.c_void_p)]
 
 
+ADAM_MAX_SEGMENTS = 40       # NRNERF_ADAM_MAX_SEGMENTS of include/nrnerf.h
+
+
+class AdamSegment(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_uint64)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_segments", C.c_int32), ("segments", AdamSegment * ADAM_MAX_SEGMENTS),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("lr_device", C.c_void_p), ("step", C.c_void_p), ("flat_params", C.c_void_p), ("n_floats", C.c_int64), ("barrier", C.c_void_p)]
+
+
+class TnJob(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("lda", C.c_int32), ("ldb", C.c_int32), ("wo", C.c_int32), ("wi", C.c_int32),
+                ("ldo", C.c_int32), ("reserved", C.c_int32), ("out_offset", C.c_int64), ("bias_offset", C.c_int64)]
+
+
+class TnArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_jobs", C.c_int32), ("is_bf16", C.c_int32), ("reserved", C.c_int32),
+                ("n_rows", C.c_int64), ("out_floats", C.c_int64), ("jobs", C.POINTER(TnJob)), ("out", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class EncodingArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_freqs", C.c_int32), ("n_rows", C.c_int64),
+                ("src", C.c_void_p), ("src_stride", C.c_int32),
+                ("enc", C.c_void_p), ("enc_cols", C.c_int32), ("enc_is_bf16", C.c_int32),
+                ("codes", C.c_void_p), ("n_lat", C.c_int32), ("rows_per_code", C.c_int32),
+                ("d_enc0", C.c_void_p), ("d_enc1", C.c_void_p), ("d_enc_stride", C.c_int32),
+                ("d_src", C.c_void_p), ("d_src_stride", C.c_int32)]
+
+
 class CompositeArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("n_importance", C.c_int32),
                 ("rays", C.c_void_p), ("ray_stride", C.c_int32),
@@ -259,6 +292,11 @@ EXPORTS = {
     "nrnerf_model_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrnerf_model_flat_size": (C.c_int64, [C.c_void_p]),
     "nrnerf_model_update_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "nrnerf_adam_step": (C.c_int, [C.c_void_p, C.POINTER(AdamArgs), C.c_void_p]),
+    "nrnerf_tn_workspace_bytes": (C.c_size_t, [C.POINTER(TnArgs)]),
+    "nrnerf_tn_products": (C.c_int, [C.POINTER(TnArgs), C.c_void_p]),
+    "nrnerf_encoding_forward": (C.c_int, [C.POINTER(EncodingArgs), C.c_void_p]),
+    "nrnerf_encoding_backward": (C.c_int, [C.POINTER(EncodingArgs), C.c_void_p]),
     "nrnerf_model_destroy": (None, [C.c_void_p]),
     "nrnerf_model_precision": (C.c_int, [C.c_void_p]),
     "nrnerf_model_is_generic": (C.c_int, [C.c_void_p]),

@@ -24,6 +24,8 @@
 #include "nrnerf_x16_api.h"
 #include "nrnerf_bend_x16_plan.h"
 #include "nrnerf_loss.h"
+#include "nrnerf_optim.h"
+#include "nrnerf_gen_train.h"
 #include "nrnerf_gx16_plan.h"
 #include "nrnerf_plan.h"
 
@@ -398,9 +400,14 @@ void pack_pass_x16_bend(const nrnerf_bender_desc& bd, PackedPass& out, const Fla
     }
     if (written != (size_t)T.nfrags) throw std::logic_error("plan / packer drift");
 }
-// does the 16x16x32 bender kernel have this bender?  (one of the two compiled shapes, "bf16" mode: the single-product bender)
+// does the 16x16x32 bender kernel have this bender?  (one of the two compiled shapes; both 16-bit modes: the single-product f16 bender.
+// "f16" mode's fp32-equivalent three-product bender -- 3 x the MFMAs, 11.7 % of a 1080p frame in round 5 -- stays what the FUSED-bender kernels
+// and the 32x32x16 stand-alone bender compute; NRNERF_MODEL_NO_X16_F16 keeps an "f16" handle on those alone.  That the single-product bender
+// meets "f16" mode's stated bar (>= 40 dB vs the fp32 oracle, <= 0.1 dB vs ground truth) on all four fitted checkpoints:
+// tests/test_fitted_checkpoint.py, profiles/r06_fitted_accuracy.txt.)
 bool bend_x16_eligible(const nrnerf_model_desc& d) {
-    if (!d.bender || d.precision != NRNERF_PREC_BF16) return false;
+    if (!d.bender) return false;
+    if (d.precision != NRNERF_PREC_BF16 && !(d.precision == NRNERF_PREC_F16 && !(d.flags & NRNERF_MODEL_NO_X16_F16))) return false;
     const nrnerf_bender_desc& b = *d.bender;
     using A = ArchDefault;
     return b.latent_size == A::LAT && b.hidden == A::BW && (b.depth == ArchDefault::BD || b.depth == ArchDeepBend::BD) &&
@@ -1007,6 +1014,7 @@ struct nrnerf_model {
     struct GenTrainNet { int W = 0, D = 0, dv = 0, draw_col = 0, in_w = 0, lat = 0; bool skip = false, views = false; } gen_tn[2];     // [coarse, fine]
     bool gen_fine_is_coarse = false;
     int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
+    unsigned* adam_barrier = nullptr;   // two words of device memory: the grid barrier of nrnerf_adam_step (nrnerf_optim.hip)
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
     mutable std::mutex prof_mu;
     mutable bool prof_on = false;
@@ -1329,6 +1337,7 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d.device) != hipSuccess) return NRNERF_ERR_HIP;
     m->num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void**)&m->adam_barrier, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(m->adam_barrier, 0, 2 * sizeof(unsigned)) != hipSuccess) return NRNERF_ERR_NOMEM;
     m->flat_floats = lay.total;
     nrnerf_model_desc d2 = d;
     d2.bender = nullptr;
@@ -1653,6 +1662,7 @@ int nrnerf_model_create(const nrnerf_model_desc* desc, nrnerf_model** out) try {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, desc->device) != hipSuccess) return NRNERF_ERR_HIP;
     m->num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void**)&m->adam_barrier, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(m->adam_barrier, 0, 2 * sizeof(unsigned)) != hipSuccess) return NRNERF_ERR_NOMEM;
     m->flat_floats = lay.total;
     const double mfma_flop = 2.0 * 32 * 32 * (desc->precision == NRNERF_PREC_F32 ? 2 : 16);
     rc = upload_pass(pc, m->coarse);
@@ -1780,23 +1790,24 @@ int bender_arch_of(const nrnerf_model* m) { return m->generic ? m->gen_compiled_
 int nrnerf_model_trains_bender(const nrnerf_model* m) { return m ? (m->bend_train_ok ? 1 : 0) : NRNERF_ERR_INVALID; }
 int nrnerf_model_is_generic(const nrnerf_model* m) { return m ? (m->generic ? 1 : 0) : NRNERF_ERR_INVALID; }
 
-int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_t n_floats, void* hip_stream) try {
-    if (!m || !flat_params || n_floats != m->flat_floats) return NRNERF_ERR_INVALID;
-    DeviceGuard guard(m->device);
-    if (!guard.ok) return NRNERF_ERR_HIP;
-    hipStream_t stream = (hipStream_t)hip_stream;
+}  // extern "C"
+namespace {
+int device_of(const void* ptr, int& dev);
+// every packed image of the handle (weight stream + bias table) as segments of repack launches over `flat_params`; `emit(batch, last)` is
+// called per full batch of REPACK_MAX_SEGMENTS and once for the last (possibly empty) one
+template <class EMIT>
+int repack_batches(nrnerf_model* m, const float* flat_params, EMIT&& emit) {
     PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16, &m->coarse_trunk_x16, &m->bend_x16,
                          &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
                          &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine, &m->gx_coarse, &m->gx_fine, &m->gen_coarse_bwd, &m->gen_fine_bwd};
     for (PassDev* p : passes)
         if (p && p->stream && !p->src) return NRNERF_ERR_UNSUPPORTED;          // (before anything is launched)
-    // every image (weight stream + bias table) as one segment of ONE launch
     RepackBatchArgs b{};
     b.flat = flat_params;
     auto add = [&](const int32_t* src, const uint8_t* fmt, void* dst, long long n) -> bool {
         if (n <= 0) return true;
         if (b.n_segments == REPACK_MAX_SEGMENTS) {
-            if (launch_repack_batch(b, stream) != hipSuccess) return false;
+            if (!emit(b, false)) return false;
             b.n_segments = 0;
         }
         const int k = b.n_segments++;
@@ -1809,8 +1820,142 @@ int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_
         if (!p || !p->stream) continue;
         if (!add(p->src, p->fmt, p->stream, (long long)p->n_elems) || !add(p->bias_src, nullptr, p->bias, (long long)p->bias_floats)) return NRNERF_ERR_HIP;
     }
-    return launch_repack_batch(b, stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+    return emit(b, true) ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+}  // namespace
+extern "C" {
+
+int nrnerf_model_update_device(nrnerf_model* m, const float* flat_params, int64_t n_floats, void* hip_stream) try {
+    if (!m || !flat_params || n_floats != m->flat_floats) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    // every image (weight stream + bias table) as one segment of ONE launch
+    return repack_batches(m, flat_params, [&](const RepackBatchArgs& b, bool) { return launch_repack_batch(b, stream) == hipSuccess; });
 } NRN_CATCH
+
+int nrnerf_adam_step(nrnerf_model* m, const nrnerf_adam_args* a, void* hip_stream) try {
+    if (!a || a->struct_size != sizeof(nrnerf_adam_args) || a->n_segments < 0 || a->n_segments > NRNERF_ADAM_MAX_SEGMENTS || !a->step) return NRNERF_ERR_INVALID;
+    if (!(a->beta1 >= 0.0f && a->beta1 < 1.0f && a->beta2 >= 0.0f && a->beta2 < 1.0f && a->eps >= 0.0f)) return NRNERF_ERR_INVALID;
+    const bool repack = m && a->flat_params;
+    if (repack && a->n_floats != m->flat_floats) return NRNERF_ERR_INVALID;
+    if (!m && !a->barrier) return NRNERF_ERR_INVALID;
+    AdamKernelArgs k{};
+    for (int i = 0; i < a->n_segments; ++i) {
+        const nrnerf_adam_segment& s = a->segments[i];
+        if (s.n > 0 && (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq)) return NRNERF_ERR_INVALID;
+        k.seg[i] = AdamSegment{s.param, s.grad, s.exp_avg, s.exp_avg_sq, (unsigned long long)s.n};
+        k.gran0[i + 1] = k.gran0[i] + (long long)((s.n + 3) / 4);
+    }
+    for (int i = a->n_segments; i < ADAM_MAX_SEGMENTS; ++i) k.gran0[i + 1] = k.gran0[i];
+    k.n_segments = a->n_segments;
+    k.lr = a->lr; k.beta1 = a->beta1; k.beta2 = a->beta2; k.eps = a->eps; k.lr_device = a->lr_device; k.step = a->step;
+    int dev = 0, num_cus = 0;
+    if (m) { dev = m->device; num_cus = m->num_cus; k.barrier = m->adam_barrier; }
+    else {
+        if (device_of(a->step, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NRNERF_ERR_HIP;
+        num_cus = prop.multiProcessorCount; k.barrier = a->barrier;
+    }
+    if (!k.barrier) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (launch_adam(k, num_cus, stream) != hipSuccess) return NRNERF_ERR_HIP;
+    if (!repack) return NRNERF_OK;
+    // ... and every packed image from the updated parameters, right behind it on the same stream
+    return repack_batches(m, a->flat_params, [&](const RepackBatchArgs& b, bool) { return launch_repack_batch(b, stream) == hipSuccess; });
+} NRN_CATCH
+
+namespace {
+int cus_of_device(int dev) {
+    static int cache[64] = {};
+    if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) cache[dev] = prop.multiProcessorCount;
+    return prop.multiProcessorCount;
+}
+// panels of all jobs and the number of sample chunks (= records of partial sums) a call is cut into: ~2 workgroups per CU, >= 1024 samples each
+bool tn_plan(const nrnerf_tn_args* a, int num_cus, long long& n_sub, int& kch) {
+    if (!a || a->struct_size != sizeof(nrnerf_tn_args) || a->n_jobs < 1 || !a->jobs || a->n_rows < 1 || a->out_floats < 1) return false;
+    n_sub = 0;
+    for (int j = 0; j < a->n_jobs; ++j) {
+        const nrnerf_tn_job& jb = a->jobs[j];
+        if (!jb.a || !jb.b || jb.wo < 1 || jb.wi < 1 || jb.lda < jb.wo || jb.ldb < jb.wi || jb.ldo < jb.wi || jb.out_offset < 0) return false;
+        if (jb.out_offset + (long long)(jb.wo - 1) * jb.ldo + jb.wi > a->out_floats) return false;
+        if (jb.bias_offset >= 0 && jb.bias_offset + jb.wo > a->out_floats) return false;
+        n_sub += (long long)((jb.wo + 255) / 256) * ((jb.wi + 255) / 256);
+    }
+    long long k = (2ll * (num_cus > 0 ? num_cus : 256) + n_sub - 1) / n_sub;          // (one workgroup per CU at a time: two rounds even out the jobs' sizes)
+    const long long by_rows = a->n_rows / 1024 > 1 ? a->n_rows / 1024 : 1;
+    if (k > by_rows) k = by_rows;
+    if (k > 64) k = 64;
+    if (k < 1) k = 1;
+    kch = (int)k;
+    return true;
+}
+}  // namespace
+
+size_t nrnerf_tn_workspace_bytes(const nrnerf_tn_args* a) {
+    long long n_sub; int kch;
+    int dev = 0;
+    if (!a || !a->out || device_of(a->out, dev) != NRNERF_OK) { (void)hipGetDevice(&dev); }
+    if (!tn_plan(a, cus_of_device(dev), n_sub, kch)) return 0;
+    return (size_t)kch * (size_t)a->out_floats * sizeof(float);
+}
+
+int nrnerf_tn_products(const nrnerf_tn_args* a, void* hip_stream) try {
+    if (!a || a->struct_size != sizeof(nrnerf_tn_args) || !a->out || !a->workspace) return NRNERF_ERR_INVALID;
+    int dev = 0;
+    if (device_of(a->out, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    long long n_sub; int kch;
+    if (!tn_plan(a, cus_of_device(dev), n_sub, kch)) return NRNERF_ERR_INVALID;
+    if (a->workspace_bytes < (size_t)kch * (size_t)a->out_floats * sizeof(float) || ((uintptr_t)a->workspace & 15)) return NRNERF_ERR_WORKSPACE;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    float* parts = (float*)a->workspace;
+    if (launch_tn_clear(parts, a->out_floats, kch, stream) != hipSuccess) return NRNERF_ERR_HIP;
+    bool misaligned = false;
+    TnKernelArgs k{};
+    k.kch = kch; k.n_rows = a->n_rows; k.total = a->out_floats; k.partials = parts;
+    auto flush = [&]() -> bool {
+        if (k.n_sub == 0) return true;
+        const hipError_t rc = launch_tn_products(k, a->is_bf16 == 0, stream);
+        k.n_sub = 0;
+        if (rc == hipErrorInvalidValue) misaligned = true;
+        return rc == hipSuccess;
+    };
+    for (int j = 0; j < a->n_jobs; ++j) {
+        const nrnerf_tn_job& jb = a->jobs[j];
+        for (int o0 = 0; o0 < jb.wo; o0 += 256)
+            for (int k0 = 0; k0 < jb.wi; k0 += 256) {
+                if (k.n_sub == TN_MAX_SUBJOBS && !flush()) return misaligned ? NRNERF_ERR_INVALID : NRNERF_ERR_HIP;
+                k.sub[k.n_sub++] = TnSubJob{jb.a, jb.b, jb.lda, jb.ldb, jb.wo, jb.wi, o0, k0, jb.ldo, (long long)jb.out_offset, (long long)jb.bias_offset};
+            }
+    }
+    if (!flush()) return misaligned ? NRNERF_ERR_INVALID : NRNERF_ERR_HIP;
+    return launch_tn_reduce(parts, a->out_floats, kch, a->out, stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
+
+namespace {
+int encoding_call(const nrnerf_encoding_args* a, bool backward, void* hip_stream) {
+    if (!a || a->struct_size != sizeof(nrnerf_encoding_args) || a->n_rows < 0 || !a->src) return NRNERF_ERR_INVALID;
+    if (a->n_rows == 0) return NRNERF_OK;
+    int dev = 0;
+    if (device_of(a->src, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    EncodingArgs e{a->src, a->src_stride, (long long)a->n_rows, a->n_freqs, a->enc, a->enc_cols, a->enc_is_bf16, a->codes, a->n_lat, a->rows_per_code,
+                   a->d_enc0, a->d_enc1, a->d_enc_stride, a->d_src, a->d_src_stride};
+    const hipError_t rc = launch_encoding_rows(e, backward, (hipStream_t)hip_stream);
+    return rc == hipSuccess ? NRNERF_OK : (rc == hipErrorInvalidValue ? NRNERF_ERR_INVALID : NRNERF_ERR_HIP);
+}
+}  // namespace
+int nrnerf_encoding_forward(const nrnerf_encoding_args* a, void* hip_stream) try { return encoding_call(a, false, hip_stream); } NRN_CATCH
+int nrnerf_encoding_backward(const nrnerf_encoding_args* a, void* hip_stream) try { return encoding_call(a, true, hip_stream); } NRN_CATCH
 
 void nrnerf_model_destroy(nrnerf_model* m) {
     if (!m) return;
@@ -1839,6 +1984,7 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->gen_bend);
     if (!m->gen_fine_is_coarse) free_pass(m->gen_fine);
     free_pass(m->gen_coarse);
+    if (m->adam_barrier) (void)hipFree(m->adam_barrier);
     (void)hipSetDevice(prev);
     delete m;
 }

@@ -214,6 +214,17 @@ def _flat_params(network_fn, network_fine, into=None):
             fb = bv.detach().float() if bv is not None else torch.zeros(wv.shape[0], dtype=torch.float32, device=wv.device)
             parts += [folded, torch.addmv(fb, wv[:, :k1], bf.detach().float()) if bf is not None else fb]
     shapes = tuple(tuple(p.shape) for p in parts)
+    # parameters that already ARE one vector in this order (training.FusedAdam re-homes them so): that vector itself, nothing copied
+    if all(p.dtype == torch.float32 and p.is_contiguous() for p in parts):
+        end = parts[0].data_ptr()
+        for p in parts:
+            if p.data_ptr() != end:
+                break
+            end += 4 * p.numel()
+        else:
+            total = sum(p.numel() for p in parts)
+            flat = parts[0].new_empty(0).set_(parts[0].untyped_storage(), parts[0].storage_offset(), (total,))
+            return flat, None
     if into is None or into[2] != shapes or into[0].device != parts[0].device:
         flat = torch.empty(sum(p.numel() for p in parts), dtype=torch.float32, device=parts[0].device)
         views, o = [], 0
@@ -276,6 +287,11 @@ def _watch_optimizers():
             for group in optimizer.param_groups:
                 for p in group["params"]:
                     p._nrnerf_steps = getattr(p, "_nrnerf_steps", 0) + 1
+            # an optimiser whose step re-packed the handles itself (training.FusedAdam: nrnerf_adam_step) says so: their
+            # fingerprints are brought up to date instead of triggering a second re-pack at the next get_model
+            after = getattr(optimizer, "_nrnerf_after_step", None)
+            if after is not None:
+                after()
         _OPT_HOOK.append(register_optimizer_step_post_hook(_count))
 
 
@@ -614,6 +630,19 @@ def mark_stale(network_fn, replay_stream=None):
                     per[k] = (None, m)
                     if replay_stream is not None:
                         m._train_stream = replay_stream
+
+
+def note_repacked(network_fn, model):
+    """``model`` (a handle of ``network_fn`` from this cache) was just re-packed from the CURRENT parameters by its caller (the fused
+    optimiser step): record their fingerprint, so that the next ``get_model`` serves the handle as it is."""
+    with _cache_lock:
+        per = _cache.get(network_fn)
+        if not per:
+            return
+        for k, (fp, m) in list(per.items()):
+            if m is model:
+                nfine, rb = (k[0]() if k[0] is not None else None), (k[1]() if k[1] is not None else None)
+                per[k] = (_fingerprint([network_fn, nfine, rb]), m)
 
 
 def forget_streams(network_fn):

@@ -386,28 +386,6 @@ class _Trunk(torch.autograd.Function):
         return _split_flat(flat, shapes)
 
 
-def _chunked_tn_product(dy, x):
-    """dy^T x [out, in] with an fp32 result (the weight gradients of _GenericTrunk: dy, x = [samples, out], [samples, in]).
-    The sum runs over ALL samples and the result is small: as ONE GEMM the library picks a kernel without a split along k
-    (measured 573 us for 393 216 x 192 x 192 in bf16, 50 TFLOP/s; 10 of the step's 17 ms) -- so: a batched GEMM over chunks of
-    >= 2048 samples, partial results added (<= 64 MB of them)."""
-    Mx, wo, wi = int(dy.shape[0]), int(dy.shape[1]), int(x.shape[1])
-    B = max(1, min(Mx // 2048, (1 << 24) // max(1, wo * wi)))
-    rows = (Mx // B) * B
-    dy, x = dy.contiguous(), x.contiguous()
-    a3, b3 = dy[:rows].view(B, rows // B, wo).transpose(1, 2), x[:rows].view(B, rows // B, wi)
-    if dy.dtype == torch.float32:
-        out = torch.bmm(a3, b3).sum(0)
-    else:
-        try:
-            out = torch.bmm(a3, b3, out_dtype=torch.float32).sum(0)
-        except (TypeError, RuntimeError):
-            out = torch.bmm(a3, b3).sum(0, dtype=torch.float32)
-    if rows < Mx:
-        out = out + dy[rows:].float().t() @ x[rows:].float()
-    return out
-
-
 class _GenericTrunk(torch.autograd.Function):
     """_Trunk for an architecture outside the compiled set (any depth, width % 4 == 0, at most one skip connection, plain
     output_linear head or the view-dependent one; fp32 or bf16): the run-time-parameterised kernel runs the forward with every
@@ -478,61 +456,156 @@ class _GenericTrunk(torch.autograd.Function):
             a.d_encv = d_encv.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_generic_trunk_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_generic_trunk_backward")
-        # the encoding once more, under autograd: its value for dW of the layers that read it, its backward for the points
-        with torch.enable_grad():
-            p = pts4[:, :3].detach().requires_grad_(ctx.needs_input_grad[0])
-            enc = posenc(p, n_freqs)
-        d_pts, d_codes = None, None
-        d_in = d_enc.sum(0)                 # gradient of the network's input row [encoding | latent code], both layers that read it
-        if ctx.needs_input_grad[0]:
-            d_pts, = torch.autograd.grad(enc, p, d_in[:, :n_enc])
-            d_pts = d_pts.view(N, S, 3)
-        enc = enc.detach()
+        # the gradient wrt the points through the encoding's transposed Jacobian (both layers that read the encoding: added in the kernel),
+        # and the encoding's rows once more as the first operand of those layers' weight gradients (nrnerf_encoding_*: one launch each)
         cdt = acts.dtype
-        enc_c = enc.to(cdt)
-        if ctx.tcb:                         # the input rows as the layers saw them; the codes' gradient: their columns summed over the ray's samples
-            codes = ctx.saved_tensors[-1]
-            enc_c = torch.cat([enc_c, codes.to(cdt)[:, None, :].expand(N, S, n_lat).reshape(M, n_lat)], 1)
-            if ctx.needs_input_grad[4]:
-                d_codes = d_in[:, n_enc:].reshape(N, S, n_lat).sum(1)
+        d_pts, d_codes = None, None
+        if ctx.needs_input_grad[0]:
+            d_pts = _encoding_backward(pts4, 4, n_freqs, d_enc[0], d_enc[1] if skips else None, n_enc + n_lat, M).view(N, S, 4)[..., :3]
+        codes = ctx.saved_tensors[-1] if ctx.tcb else None
+        n_in = n_enc + n_lat
+        enc_c = _encoding_rows(pts4, 4, n_freqs, M, _pad8(n_in), cdt, codes, S)       # [M, n_in padded to whole 16-byte pieces]
+        if ctx.tcb and ctx.needs_input_grad[4]:     # the codes' gradient: their columns of both layers, summed over the ray's samples
+            d_codes = d_enc[:, :, n_enc:].sum(0).reshape(N, S, n_lat).sum(1)
 
-        product = _chunked_tn_product
-
-        grads = []
-        for i in range(D):              # pts_linears[i]: weight, bias (rnh:253-258: layer skip + 1 reads [encoding, activation])
-            if i == 0:
-                gw = product(d_pre[0], enc_c)
-            elif (i - 1) in skips:
-                gw = torch.cat([product(d_pre[i], enc_c), product(d_pre[i], acts[i - 1])], 1)
-            else:
-                gw = product(d_pre[i], acts[i - 1])
-            grads += [gw, d_pre[i].sum(0, dtype=torch.float32)]
+        # every weight and bias gradient, dW = d_pre^T x and db = column sums of d_pre, as ONE call over the two saved arrays
+        # (nrnerf_tn_products) straight into one buffer in _generic_trunk_params order
+        half = int(net.views_linears[0].weight.shape[0]) if views else 0
+        plan, shapes, off = _generic_grad_plan(D, W, n_in, skips, C_out, views, half, 3 + 6 * nv if views else 0)
+        operands = {"g": g.to(cdt), "enc": enc_c}
+        for i in range(D + (2 if views else 0)):
+            operands[("d_pre", i)], operands[("acts", i)] = d_pre[i], acts[i]
         d_dirs = None
-        if not views:
-            gh = torch.zeros(C_out, W, dtype=torch.float32, device=dev)      # output_linear (a 5th channel never reaches a loss)
-            gh[:4] = product(g.to(cdt), acts[D - 1])
-            gb = torch.zeros(C_out, dtype=torch.float32, device=dev)
-            gb[:4] = g.sum(0)
-            grads += [gh, gb]
-        else:
-            # rnh:284-304: sigma = alpha_linear(h); feature = feature_linear(h); hv = relu(views_linears[0]([feature, enc(dir)])); rgb = rgb_linear(hv)
-            half = int(net.views_linears[0].weight.shape[0])
+        if views:
             d3 = ctx.saved_tensors[2]
-            with torch.enable_grad():
-                dl = d3.detach().requires_grad_(ctx.needs_input_grad[5])
-                encv = posenc(dl, nv)
+            n_dir = 3 + 6 * nv
             if ctx.needs_input_grad[5]:
-                d_dirs, = torch.autograd.grad(encv, dl, d_encv)
-                d_dirs = d_dirs.view(N, S, 3)
-            h_last, feature, hv = acts[D - 1], acts[D], acts[D + 1][:, :half]
-            d_feature, d_pre_v = d_pre[D], d_pre[D + 1][:, :half].contiguous()
-            gsum = g.sum(0)
-            grads += [product(g[:, 3:4].to(cdt), h_last), gsum[3:4],                                         # alpha_linear
-                      product(d_feature, h_last), d_feature.sum(0, dtype=torch.float32),                     # feature_linear
-                      torch.cat([product(d_pre_v, feature), product(d_pre_v, encv.detach().to(cdt))], 1),   # views_linears[0] on [feature, enc(dir)]
-                      d_pre_v.sum(0, dtype=torch.float32),
-                      product(g[:, :3].to(cdt), hv), gsum[:3]]                                               # rgb_linear
-        return (d_pts, None, None, None, d_codes, d_dirs, *grads)
+                d_dirs = _encoding_backward(d3, 3, nv, d_encv, None, n_dir, M).view(N, S, 4)[..., :3]
+            operands["encv"] = _encoding_rows(d3, 3, nv, M, _pad8(n_dir), cdt, None, 1)
+        jobs = [(operands[a], ac, operands[b], bc, wo, wi, ldo, ow, ob) for a, ac, b, bc, wo, wi, ldo, ow, ob in plan]
+        flat = _tn_products(jobs, M, off, dev)
+        return (d_pts, None, None, None, d_codes, d_dirs, *_split_flat(flat, shapes))
+
+
+def _generic_grad_plan(D, W, n_in, skips, C_out, views, half=0, n_dir=0):
+    """The products that make up a non-compiled trunk's weight / bias gradients, as (a, first column of a, b, first column of b, wo, wi,
+    ldo, offset of the weight, offset of the bias | None) with a / b naming the saved arrays -- ("d_pre", i), ("acts", i), "enc" (the
+    network's input rows), "encv" (the directions' encoding), "g" (d raw [M, 4]) -- + the parameter shapes in _generic_trunk_params
+    order + the length of the flat result.  out[offset + o * ldo + k] = sum_m a[m, col_a + o] b[m, col_b + k]; bias = column sums of a.
+    Host-only logic (tests/test_training_host.py emulates it against torch autograd)."""
+    plan, shapes, off = [], [], 0
+
+    def param(shape):
+        nonlocal off
+        shapes.append(tuple(int(d) for d in shape))
+        o, n = off, 1
+        for d in shape:
+            n *= int(d)
+        off += n
+        return o
+
+    for i in range(D):              # pts_linears[i]: weight, bias (rnh:253-258: layer skip + 1 reads [encoding, activation])
+        if i == 0:
+            ow = param((W, n_in))
+            plan.append([("d_pre", 0), 0, "enc", 0, W, n_in, n_in, ow, None])
+        elif (i - 1) in skips:
+            ow = param((W, n_in + W))
+            plan.append([("d_pre", i), 0, "enc", 0, W, n_in, n_in + W, ow, None])
+            plan.append([("d_pre", i), 0, ("acts", i - 1), 0, W, W, n_in + W, ow + n_in, None])
+        else:
+            ow = param((W, W))
+            plan.append([("d_pre", i), 0, ("acts", i - 1), 0, W, W, W, ow, None])
+        plan[-1][-1] = param((W,))
+    if not views:
+        ow = param((C_out, W))      # output_linear (a 5th channel never reaches a loss: its row and bias stay zero)
+        plan.append(["g", 0, ("acts", D - 1), 0, 4, W, W, ow, param((C_out,))])
+    else:
+        # rnh:284-304: sigma = alpha_linear(h); feature = feature_linear(h); hv = relu(views_linears[0]([feature, enc(dir)])); rgb = rgb_linear(hv)
+        # saved: acts[D] = feature, acts[D + 1][:, :half] = hv; d_pre[D] = d feature, d_pre[D + 1][:, :half] = d (views layer's pre-activation)
+        ow = param((1, W))
+        plan.append(["g", 3, ("acts", D - 1), 0, 1, W, W, ow, param((1,))])                                # alpha_linear
+        ow = param((W, W))
+        plan.append([("d_pre", D), 0, ("acts", D - 1), 0, W, W, W, ow, param((W,))])                       # feature_linear
+        ow = param((half, W + n_dir))                                                                      # views_linears[0] on [feature, enc(dir)]
+        plan.append([("d_pre", D + 1), 0, ("acts", D), 0, half, W, W + n_dir, ow, None])
+        plan.append([("d_pre", D + 1), 0, "encv", 0, half, n_dir, W + n_dir, ow + W, param((half,))])
+        ow = param((3, half))
+        plan.append(["g", 0, ("acts", D + 1), 0, 3, half, half, ow, param((3,))])                          # rgb_linear
+    return [tuple(p) for p in plan], shapes, off
+
+
+def _pad8(n: int) -> int:
+    return (int(n) + 7) // 8 * 8
+
+
+def _encoding_rows(src, src_stride, n_freqs, M, cols, dtype, codes, rows_per_code):
+    """Embedder.embed (rnh:120-150) of the rows' first three columns as [M, cols] rows of ``dtype`` (+ the rays' codes behind the encoding
+    for the time-conditioned baseline, zero padding behind those): nrnerf_encoding_forward, one launch."""
+    enc = torch.empty(M, cols, dtype=dtype, device=src.device)
+    a = _lib.EncodingArgs()
+    a.struct_size = C.sizeof(_lib.EncodingArgs)
+    a.n_freqs, a.n_rows = int(n_freqs), int(M)
+    a.src, a.src_stride = src.data_ptr(), int(src_stride)
+    a.enc, a.enc_cols, a.enc_is_bf16 = enc.data_ptr(), int(cols), int(dtype == torch.bfloat16)
+    if codes is not None:
+        a.codes, a.n_lat, a.rows_per_code = codes.data_ptr(), int(codes.shape[1]), int(rows_per_code)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().nrnerf_encoding_forward(C.byref(a), _stream(src.device)), "nrnerf_encoding_forward")
+    return enc
+
+
+def _encoding_backward(src, src_stride, n_freqs, d_enc0, d_enc1, d_stride, M):
+    """J^T (d_enc0 [+ d_enc1]) of that encoding: the gradient wrt the rows' first three columns as [M, 4] (column 3 zero), one launch."""
+    out = torch.empty(M, 4, dtype=torch.float32, device=src.device)
+    a = _lib.EncodingArgs()
+    a.struct_size = C.sizeof(_lib.EncodingArgs)
+    a.n_freqs, a.n_rows = int(n_freqs), int(M)
+    a.src, a.src_stride = src.data_ptr(), int(src_stride)
+    a.d_enc0, a.d_enc1, a.d_enc_stride = d_enc0.data_ptr(), (d_enc1.data_ptr() if d_enc1 is not None else None), int(d_stride)
+    a.d_src, a.d_src_stride = out.data_ptr(), 4
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().nrnerf_encoding_backward(C.byref(a), _stream(src.device)), "nrnerf_encoding_backward")
+    return out
+
+
+def _tn_products(jobs, n_rows, total, dev):
+    """nrnerf_tn_products over ``jobs`` = (a tensor, first column of a, b tensor, first column of b, wo, wi, ldo, out offset, bias offset | None):
+    out[offset + o * ldo + k] = sum_m a[m, col_a + o] b[m, col_b + k] (+ the column sums of a at the bias offset) -> the flat fp32 result."""
+    lib = _lib.load()
+    dt = jobs[0][0].dtype
+    es = 2 if dt == torch.bfloat16 else 4
+    arr = (_lib.TnJob * len(jobs))()
+    per, copies = 16 // es, {}
+
+    def operand(t, col, w):
+        """(pointer, leading dimension) of columns [col, col + w) of `t` as the kernel wants them: 16-byte aligned rows padded to whole
+        16-byte pieces -- the arrays the training kernels save qualify as they are whenever the width is a multiple of 8 (bf16) / 4
+        (fp32); anything else (a 100-wide trunk, the [M, 4] head gradient, a column of it) is copied once into a padded buffer"""
+        ptr, ld = t.data_ptr() + es * int(col), int(t.stride(0))
+        if t.stride(1) == 1 and ptr % 16 == 0 and (ld * es) % 16 == 0 and (w + per - 1) // per * per <= ld - 0 and col + (w + per - 1) // per * per <= t.shape[1] + (ld - t.shape[1]):
+            return ptr, ld
+        key = (t.data_ptr(), int(col), int(w))
+        if key not in copies:
+            pad = torch.zeros(t.shape[0], (w + per - 1) // per * per, dtype=dt, device=t.device)
+            pad[:, :w] = t[:, col:col + w]
+            copies[key] = pad
+        return copies[key].data_ptr(), int(copies[key].stride(0))
+
+    for j, (a_t, a_col, b_t, b_col, wo, wi, ldo, ow, ob) in enumerate(jobs):
+        assert a_t.dtype == dt and b_t.dtype == dt
+        (pa, lda), (pb, ldb) = operand(a_t, a_col, wo), operand(b_t, b_col, wi)
+        arr[j] = _lib.TnJob(pa, pb, lda, ldb, int(wo), int(wi), int(ldo), 0, int(ow), -1 if ob is None else int(ob))
+    out = torch.empty(int(total), dtype=torch.float32, device=dev)
+    a = _lib.TnArgs()
+    a.struct_size = C.sizeof(_lib.TnArgs)
+    a.n_jobs, a.is_bf16, a.n_rows, a.out_floats = len(jobs), int(dt == torch.bfloat16), int(n_rows), int(total)
+    a.jobs, a.out = arr, out.data_ptr()
+    with torch.cuda.device(dev):
+        nbytes = int(lib.nrnerf_tn_workspace_bytes(C.byref(a)))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+        _lib.check(lib.nrnerf_tn_products(C.byref(a), _stream(dev)), "nrnerf_tn_products")
+    return out
 
 
 def _generic_trunk_params(net):
@@ -1472,6 +1545,173 @@ def select_codes(codes: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     return _SelectCodes.apply(codes, index)
 
 
+class FusedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam(params, lr, betas, eps)`` -- what train.py:655-658 builds over ``grad_vars`` -- whose ``step()`` AND the device-side
+    re-pack of the networks' packed weights the next forward needs are ONE call = two launches (``nrnerf_adam_step``, csrc/nrnerf_optim.hip)
+    instead of torch's three multi-tensor launches + the copy of the parameters into the library's flat vector + the re-pack launch (144 us
+    of a 1.8 ms step at N_rand = 1024).
+
+        opt = FusedAdam(grad_vars, lr=5e-4, betas=(0.9, 0.999), networks=(network_fn, network_fine))
+
+    ``networks``: the (coarse, fine) modules whose handle the step refreshes.  Their parameters (and their ray bender's) are RE-HOMED at
+    construction: ``p.data`` becomes a view of ONE fp32 vector in the library's canonical order (``nrnerf_model_update_device``), so the
+    kernel updates the parameters in place and packs straight from them -- modules, ``state_dict()`` and checkpoints see ordinary
+    tensors.  Without ``networks`` (or for networks with the view-dependent head, whose packed images need two derived matrices) the step
+    is the fused Adam alone and the next forward re-packs as before.  No weight decay / amsgrad (the reference uses neither).  The state
+    has torch's keys (``step``, ``exp_avg``, ``exp_avg_sq``), so ``state_dict()`` round-trips with ``torch.optim.Adam`` checkpoints
+    (train.py:1680-1698 saves the optimiser's).  ``param_group["lr"]`` is read every step (train.py:1625-1630 decays it on the host); a
+    0-dim device tensor there is passed as a device scalar (a schedule inside ``GraphedStep``).  Capturable: the step count lives on the
+    device."""
+
+    repacks_weights = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, networks=None):
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self._lib = _lib.load()
+        allp = [p for g in self.param_groups for p in g["params"]]
+        if not allp or any(p.device.type != "cuda" or p.dtype != torch.float32 or p.device != allp[0].device for p in allp):
+            raise ValueError("FusedAdam: fp32 parameters on one ROCm device")
+        self._dev = allp[0].device
+        self._networks = None
+        self._flat = None
+        homed = {}
+        if networks is not None:
+            nf, nfine = (networks if isinstance(networks, (tuple, list)) else (networks, None))
+            mods = R._linears_in_canonical_order(nf, nfine)
+            slots = []
+            for lin in mods:
+                slots.append(lin.weight)
+                if getattr(lin, "bias", None) is not None:
+                    slots.append(lin.bias)
+            views = any(getattr(n, "use_viewdirs", False) for n in (nf, nfine) if n is not None)
+            if not views and all(t.device == self._dev and t.dtype == torch.float32 for t in slots):
+                with torch.no_grad():
+                    flat = torch.empty(sum(t.numel() for t in slots), dtype=torch.float32, device=self._dev)
+                    o = 0
+                    for t in slots:
+                        v = flat[o:o + t.numel()].view(t.shape)
+                        v.copy_(t)
+                        t.data = v                    # the module's parameter now lives in the flat vector
+                        homed[t] = o
+                        o += t.numel()
+                self._flat, self._networks = flat, (nf, nfine)
+                self.repacks_weights = True
+        # state: torch's keys; exp_avg / exp_avg_sq of the re-homed parameters are views of two vectors parallel to the flat one
+        self._step = torch.zeros((), dtype=torch.float32, device=self._dev)
+        self._barrier = torch.zeros(2, dtype=torch.int32, device=self._dev)
+        m_flat = torch.zeros_like(self._flat) if self._flat is not None else None
+        v_flat = torch.zeros_like(self._flat) if self._flat is not None else None
+        self._homed = homed
+        for p in allp:
+            if p in homed:
+                o = homed[p]
+                st = dict(step=self._step, exp_avg=m_flat[o:o + p.numel()].view(p.shape), exp_avg_sq=v_flat[o:o + p.numel()].view(p.shape))
+            else:
+                st = dict(step=self._step, exp_avg=torch.zeros_like(p, memory_format=torch.contiguous_format),
+                          exp_avg_sq=torch.zeros_like(p, memory_format=torch.contiguous_format))
+            self.state[p] = st
+        # parameter order of a step: the re-homed ones by their offset (runs merge), then the others
+        self._order = sorted([p for p in allp if p in homed], key=lambda p: homed[p]) + [p for p in allp if p not in homed]
+
+    def load_state_dict(self, state_dict):
+        """torch's checkpoints load INTO the flat state (the loaded tensors are copied, the views stay)."""
+        keep = {p: dict(st) for p, st in self.state.items()}
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            step = None
+            for p, st in list(self.state.items()):
+                old = keep.get(p)
+                if old is None:
+                    continue
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st and st[k] is not old[k]:
+                        old[k].copy_(st[k])
+                if "step" in st and st["step"] is not old["step"]:
+                    step = float(st["step"])
+                self.state[p] = old
+            if step is not None:
+                self._step.fill_(step)
+
+    def _model(self):
+        nf, nfine = self._networks
+        prec = "bf16" if R.get_precision() == "f16" else R.get_precision()
+        nets = [nf] + ([nfine] if nfine is not None else [])
+        return R.get_model(nf, nfine, precision=prec, device=self._dev, flags=_training_handle_flags(nets, R._bender_of(nf)))
+
+    def _nrnerf_after_step(self):
+        if self.repacks_weights and getattr(self, "_stepped_model", None) is not None:
+            R.note_repacked(self._networks[0], self._stepped_model)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = self._lib
+        model = None
+        if self.repacks_weights:
+            try:
+                model = self._model()
+            except R.Unsupported:
+                model = None
+        self._stepped_model = model
+        groups = [g for g in self.param_groups if any(p.grad is not None for p in g["params"])]
+        with torch.cuda.device(self._dev):
+            stream = _stream(self._dev)
+            for gi, group in enumerate(groups):
+                members = set(group["params"])
+                segs = []
+                keep_alive = []
+                for p in self._order:
+                    if p not in members or p.grad is None:
+                        continue
+                    g = p.grad
+                    if g.is_sparse:
+                        raise RuntimeError("FusedAdam does not support sparse gradients")
+                    if g.dtype != torch.float32 or not g.is_contiguous():
+                        g = g.to(torch.float32).contiguous()
+                        keep_alive.append(g)
+                    st = self.state[p]
+                    cur = [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()]
+                    if segs and all(segs[-1][k] + 4 * segs[-1][4] == cur[k] for k in range(4)):
+                        segs[-1][4] += cur[4]              # the run goes on: one segment
+                    else:
+                        segs.append(cur)
+                last_group = gi == len(groups) - 1
+                self.last_segments = len(segs)
+                for c0 in range(0, max(len(segs), 1), _lib.ADAM_MAX_SEGMENTS):
+                    chunk = segs[c0:c0 + _lib.ADAM_MAX_SEGMENTS]
+                    last = last_group and c0 + _lib.ADAM_MAX_SEGMENTS >= len(segs)
+                    a = _lib.AdamArgs()
+                    a.struct_size = C.sizeof(_lib.AdamArgs)
+                    a.n_segments = len(chunk)
+                    for i, (pp, gp, mp, vp, n) in enumerate(chunk):
+                        a.segments[i] = _lib.AdamSegment(pp, gp, mp, vp, n)
+                    lr = group["lr"]
+                    if torch.is_tensor(lr):
+                        lr_t = lr.detach().to(device=self._dev, dtype=torch.float32).reshape(())
+                        keep_alive.append(lr_t)
+                        a.lr_device, a.lr = lr_t.data_ptr(), 0.0
+                    else:
+                        a.lr = float(lr)
+                    a.beta1, a.beta2, a.eps = float(group["betas"][0]), float(group["betas"][1]), float(group["eps"])
+                    # (several launches of one step -- more than ADAM_MAX_SEGMENTS runs, or several groups -- share the step count: only
+                    #  the last one advances it, the others work on a copy)
+                    step_t = self._step if last else self._step.clone()
+                    keep_alive.append(step_t)
+                    a.step = step_t.data_ptr()
+                    a.barrier = self._barrier.data_ptr()
+                    handle = None
+                    if last and model is not None:
+                        a.flat_params, a.n_floats = self._flat.data_ptr(), self._flat.numel()
+                        handle = model.handle
+                    _lib.check(lib.nrnerf_adam_step(handle, C.byref(a), stream), "nrnerf_adam_step")
+            if model is not None:
+                model.note_use(self._dev)
+        return loss
+
+
 class GraphedStep:
     """One whole training iteration -- device-side weight re-pack, forward, loss, backward, optimiser step -- captured in
     a HIP graph and replayed: the ~150 launches of a 1024-ray step (N_rand of the shipped config) cost no host time and no
@@ -1495,9 +1735,14 @@ class GraphedStep:
         self.optimizer = optimizer
         dev = next(iter(self.static.values())).device
 
+        # (an optimiser whose step re-packs the handles itself -- FusedAdam(networks=...) -- leaves them fresh at the end of every
+        #  step, captured or replayed: no refresh at the start of the step, nothing to mark stale after a replay)
+        self.repacks = bool(getattr(optimizer, "repacks_weights", False))
+
         def one():
-            for nf in self.networks:
-                R.mark_stale(nf)                                   # the refresh kernels are part of the captured step
+            if not self.repacks:
+                for nf in self.networks:
+                    R.mark_stale(nf)                               # the refresh kernels are part of the captured step
             loss = step_fn(**self.static)
             loss.backward()
             optimizer.step()
@@ -1535,6 +1780,8 @@ class GraphedStep:
 
     def sync(self):
         """Mark the networks' packed weights stale (done after every replay; kept as a public no-cost call)."""
+        if self.repacks:
+            return
         for nf in self.networks:
             dev = next(nf.parameters()).device
             R.mark_stale(nf, torch.cuda.current_stream(dev) if dev.type == "cuda" else None)
@@ -1574,7 +1821,7 @@ def _fresh_training_modules(cfg, dev, n_importance):
     return rb, coarse, fine
 
 
-def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, regularised, graph=False, repeats=1):
+def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, regularised, graph=False, repeats=1, torch_adam=False):
     import time
 
     from .synthetic import make_rays
@@ -1586,7 +1833,11 @@ def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, reg
             m.requires_grad_(True)
             params += list(m.parameters())
     codes = torch.zeros(8, cfg.latent_size, device=dev, requires_grad=True)
-    opt = torch.optim.Adam(params + [codes], lr=5e-4, betas=(0.9, 0.999), fused=True, capturable=bool(graph))   # train.py:655-658
+    # train.py:655-658: Adam over grad_vars -- as FusedAdam (the step and the weight re-pack in one launch) unless `torch_adam`
+    if torch_adam:
+        opt = torch.optim.Adam(params + [codes], lr=5e-4, betas=(0.9, 0.999), fused=True, capturable=bool(graph))
+    else:
+        opt = FusedAdam(params + [codes], lr=5e-4, betas=(0.9, 0.999), networks=(coarse, fine))
     rays, _ = make_rays(n_rays, 5, cfg)
     rays = rays.to(dev)
     frame = torch.randint(0, 8, (n_rays,), device=dev)
@@ -1650,12 +1901,6 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=None, steps=30, w
     #  rate, which another process' threads on the same host move by a factor of two)
     dt, final = _time_training(cfg, dev, precision, n_rays, rec["N_importance"], steps, warmup, regularised=True, repeats=3)
     dt0, final0 = _time_training(cfg, dev, precision, n_rays, 128, steps, warmup, regularised=False, repeats=3)
-    try:        # the same iteration replayed from a HIP graph (GraphedStep): no host time, no launch gaps
-        dtg, finalg = _time_training(cfg, dev, precision, n_rays, rec["N_importance"], steps, warmup, regularised=True, graph=True, repeats=3)
-        graph = {"rays_per_s": round(n_rays / dtg, 1), "ms_per_step": round(dtg * 1e3, 3), "final_loss": round(finalg, 5),
-                 "what": "the same iteration (weight re-pack, forward, loss, backward, Adam) captured once in a HIP graph and replayed (training.GraphedStep)"}
-    except Exception as e:                                                  # capture is best effort: report, do not fail the bench
-        graph = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     peak = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}[precision]
     S, I = cfg.N_samples, rec["N_importance"]
 
@@ -1675,13 +1920,25 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=None, steps=30, w
         return {"mfma": {"achieved": round(flops / dt_ / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / dt_ / 1e12 / peak, 4)},
                 "hbm": {"achieved": round(hbm / dt_ / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm / dt_ / 8e12, 4),
                         "bytes_per_sample_by_design": per_sample}}
+    try:        # the same iteration replayed from a HIP graph (GraphedStep): no host time, no launch gaps
+        dtg, finalg = _time_training(cfg, dev, precision, n_rays, rec["N_importance"], steps, warmup, regularised=True, graph=True, repeats=3)
+        graph = {"rays_per_s": round(n_rays / dtg, 1), "ms_per_step": round(dtg * 1e3, 3), "final_loss": round(finalg, 5),
+                 "what": "the same iteration (forward, loss, backward, Adam + weight re-pack as one launch) captured once in a HIP graph and replayed (training.GraphedStep)",
+                 "roofline": roof(dtg, I, True)}
+        try:        # round 5's optimiser for continuity: torch.optim.Adam(fused, capturable) + re-pack at the start of the step
+            dtt, _ = _time_training(cfg, dev, precision, n_rays, rec["N_importance"], steps, warmup, regularised=True, graph=True, repeats=3, torch_adam=True)
+            graph["with_torch_adam_ms_per_step"] = round(dtt * 1e3, 3)
+        except Exception as e:
+            graph["with_torch_adam_error"] = f"{type(e).__name__}: {str(e)[:200]}"
+    except Exception as e:                                                  # capture is best effort: report, do not fail the bench
+        graph = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     r = roof(dt, I, True)
     return {"rays_per_s": round(n_rays / dt, 1), "ms_per_step": round(dt * 1e3, 3), "rays_per_step": n_rays,
             "samples_per_ray": f"{S}+{I}", "dtype": precision, "final_loss": round(final, 5),
             "what": "the reference's training iteration with its shipped recipe (configs/example_sequence.txt): render under autograd with "
                     "detailed outputs (perturb, raw_noise_std 1), loss = mse(rgb_map) + mse(rgb0) + 60 x (offsets + 5e-4 rigidity) "
-                    "regulariser + 3 x divergence regulariser (native second-order path) with the increasing schedule, backward, fused "
-                    "Adam step, device-side weight re-pack; all through render.batchify_rays / training.compute_divergence_loss. "
+                    "regulariser + 3 x divergence regulariser (native second-order path) with the increasing schedule, backward, training.FusedAdam ("
+                    "Adam step + device-side weight re-pack as one launch); all through render.batchify_rays / training.compute_divergence_loss. "
                     "Every leg: best of three timed loops",
             "loss_terms": ["mse(rgb_map)", "mse(rgb0)", "offsets", "rigidity", "divergence"],
             "hip_graph": graph,

@@ -42,6 +42,14 @@ def _setenv(name, value):
             os.environ[name] = old
 
 
+def _same_bender(precision):
+    """Round 6: "f16" mode's default stand-alone bender is the single-product 16x16x32 one as well (a third of the three-product bender's
+    MFMAs; its own accuracy statement: test_f16_mode_with_the_single_product_bender_is_at_least_as_accurate_as_bf16_mode and the fitted
+    checkpoints).  The "equally good rounding" statements below compare two TRUNK kernels on the same bent points: for "f16" they keep
+    the 32x32x16 three-product bender on both sides (NRNERF_X16_BENDER=0 -> NRNERF_RENDER_BENDER_32X32)."""
+    return _setenv("NRNERF_X16_BENDER", "0") if precision == "f16" else contextlib.nullcontext()
+
+
 def _assert_x16_is_an_equally_good_rounding(x16, k32, ref32):
     """The 16-bit modes' split-bender path runs its trunk-only fine pass on the 16x16x32 MFMA kernel (nrnerf_net_x16.h) by default
     and on the 32x32x16 kernel (nrnerf_net_mb.h) with NRNERF_X16=0: the same 16-bit products of the same 16-bit-rounded operands,
@@ -336,9 +344,10 @@ def test_split_bender_path_at_full_chunk_size_equals_the_fused_pass():
     for k in a:
         assert torch.equal(torch.nan_to_num(a[k]), torch.nan_to_num(b[k])), k
     ref32 = hip_render(scene, rays, latents, "f32", retraw=True)
-    with _setenv("NRNERF_X16", "1"):                                             # fine pass on the 16x16x32 kernel, coarse pass as above
-        _assert_x16_is_an_equally_good_rounding(hip_render(scene, rays, latents, "f16", retraw=True), a, ref32)
-    _assert_x16_coarse_is_an_equally_good_rounding(hip_render(scene, rays, latents, "f16", retraw=True), a, ref32)
+    with _same_bender("f16"):
+        with _setenv("NRNERF_X16", "1"):                                         # fine pass on the 16x16x32 kernel, coarse pass as above
+            _assert_x16_is_an_equally_good_rounding(hip_render(scene, rays, latents, "f16", retraw=True), a, ref32)
+        _assert_x16_coarse_is_an_equally_good_rounding(hip_render(scene, rays, latents, "f16", retraw=True), a, ref32)
     with _setenv("NRNERF_X16", "0"):                                             # trunk-only pass on the 32x32x16 kernel
         a = hip_render(scene, rays, latents, "bf16", retraw=True)
     b = hip_render(scene, rays, latents, "bf16", retraw=True, detailed=True)
@@ -772,7 +781,8 @@ def test_16bit_kernels_of_every_compiled_variant_track_the_fp32_kernel(variant, 
     scene = make_scene(cfg, 3)
     rays, latents = make_rays(4096, 21, cfg)
     ref = hip_render(scene, rays, latents, "f32", retraw=True)
-    got = hip_render(scene, rays, latents, precision, retraw=True)
+    with _same_bender(precision):       # ("f16": its tight bars are those of the f16 trunk behind the fp32-equivalent three-product bender)
+        got = hip_render(scene, rays, latents, precision, retraw=True)
     # ... and against the ORACLE itself (eager fp32 torch ops on the GPU), so the 16-bit kernels are not only held to
     # another kernel of this library
     with torch.no_grad():
@@ -856,7 +866,8 @@ def test_width_class_kernel_is_an_equally_good_rounding_of_the_generic_kernel(cf
     ref32 = hip_render(scene, rays, latents, "f32", retraw=True)
     with _setenv("NRNERF_X16", "0"):
         gen = hip_render(scene, rays, latents, precision, retraw=True)
-    gx = hip_render(scene, rays, latents, precision, retraw=True)
+    with _same_bender(precision):
+        gx = hip_render(scene, rays, latents, precision, retraw=True)
     assert set(gx) == set(gen) and gx["raw"].shape == gen["raw"].shape
     assert (gx["_z_vals"][:, 1:] >= gx["_z_vals"][:, :-1]).all() and torch.isfinite(gx["raw"]).all()
     assert not torch.equal(gx["rgb0"], gen["rgb0"]), "both renders took the same kernel"
@@ -1150,7 +1161,7 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
         torch.cuda.synchronize()
         return out
 
-    with _setenv("NRNERF_X16", "1"):           # (the fine pass on the 16x16x32 kernel; 2, the default, moves the coarse pass there as well)
+    with _same_bender(precision), _setenv("NRNERF_X16", "1"):      # (the fine pass on the 16x16x32 kernel; 2, the default, moves the coarse pass there as well)
         split16 = run(model, False)
     fused = run(model, True)
     assert "fine_input_pts" in fused and "fine_input_pts" not in split16
@@ -1162,7 +1173,8 @@ def test_split_bender_path_equals_the_fused_fine_pass_bit_for_bit(precision, cfg
         ref32 = run(R.get_model(coarse, fine, precision="f32"), False)
         _assert_x16_is_an_equally_good_rounding(split16, split, ref32)
         if cfg.N_importance > 0:
-            _assert_x16_coarse_is_an_equally_good_rounding(run(model, False), split, ref32)
+            with _same_bender(precision):
+                _assert_x16_coarse_is_an_equally_good_rounding(run(model, False), split, ref32)
     if precision == "bf16":
         _assert_split_equals_fused_up_to_conversion_ties(split, fused, views=cfg.use_viewdirs)
         return
@@ -1454,3 +1466,32 @@ def test_width_class_kernel_with_fused_compositing_equals_the_composite_launch_b
     for k in fused:
         assert torch.equal(torch.nan_to_num(fused[k].float()), torch.nan_to_num(separate[k].float())), k
     assert torch.isfinite(fused["rgb_map"]).all() and float(fused["acc_map"].max()) > 0.5
+
+
+@pytest.mark.parametrize("cfg_kw", [dict(), dict(N_importance=64, bend_depth=7), dict(N_importance=64, netdepth=6, netwidth=192, netwidth_fine=320, multires=8)],
+                         ids=["headline", "deep_bender", "generic_w192_320"])
+def test_f16_mode_with_the_single_product_bender_is_at_least_as_accurate_as_bf16_mode(cfg_kw):
+    """Round 6 (BASELINE config 5 is an "f16" workload): the stand-alone benders of "f16" mode's split path run on the 16x16x32 single-product
+    kernel by default, like "bf16" mode's -- a third of the MFMAs of the three-product bender (11.7 % of a 1080p frame in round 5).  What
+    that costs in accuracy, stated against the exact-fp32 render on the synthetic stress scene: the default "f16" render is (a) closer to
+    fp32 than the "bf16" render of the same call (same bender arithmetic, three more mantissa bits in the trunk), (b) within 6x of the
+    three-product route's error, which stays selectable (NRNERF_X16_BENDER=0 per call, NRNERF_X16_F16=0 per handle), and (c) at least
+    "bf16" mode's PSNR.  The fitted checkpoints hold it to the stated bar against the oracle and the ground truth (test_fitted_checkpoint.py)."""
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 0)
+    rays, latents = make_rays(8192, 3, cfg)
+    ref32 = hip_render(scene, rays, latents, "f32")
+    f16 = hip_render(scene, rays, latents, "f16")
+    bf16 = hip_render(scene, rays, latents, "bf16")
+    with _setenv("NRNERF_X16_BENDER", "0"):
+        f16_three = hip_render(scene, rays, latents, "f16")
+    assert not torch.equal(f16["rgb0"], f16_three["rgb0"]), "both f16 renders took the same bender"
+    for k in ("rgb0", "rgb_map"):
+        e = {n: (o[k].float() - ref32[k].float()).abs().mean().item() for n, o in (("f16", f16), ("bf16", bf16), ("f16_three_product", f16_three))}
+        print(f"[{k}] mean |error| vs the fp32 kernels: {e}; PSNR f16 {psnr(f16[k], ref32[k]):.1f} dB, bf16 {psnr(bf16[k], ref32[k]):.1f} dB, "
+              f"f16 three-product {psnr(f16_three[k], ref32[k]):.1f} dB")
+        assert e["f16"] <= e["bf16"], (k, e)
+        assert e["f16"] <= 6.0 * e["f16_three_product"] + 1e-6, (k, e)
+    # (no absolute bar here: this is the numerical stress scene -- sigma logits ~ N(-2, 6^2) -- on which "bf16" mode sits at 34-37 dB; the
+    #  stated >= 40 dB / <= 0.1 dB bar is held on the fitted checkpoints, tests/test_fitted_checkpoint.py)
+    assert psnr(f16["rgb0"], ref32["rgb0"]) >= psnr(bf16["rgb0"], ref32["rgb0"])

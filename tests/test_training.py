@@ -1318,3 +1318,188 @@ def test_training_loss_with_the_fused_loss_equals_the_eager_terms():
         gf = out[True][1][k]
         scale = float(ge.abs().max()) + 1e-20
         assert float((ge - gf).abs().max()) <= 1e-4 * scale, (k, float((ge - gf).abs().max()) / scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_kw", [dict(N_importance=64), dict(N_importance=64, netwidth=128), dict(N_importance=64, use_viewdirs=True)],
+                         ids=["default", "narrow_128", "viewdirs_not_rehomed"])
+def test_fused_adam_equals_torch_adam_and_leaves_the_packed_weights_fresh(cfg_kw):
+    """training.FusedAdam (nrnerf_adam_step: Adam + the device-side weight re-pack in ONE launch; reference optimiser train.py:655-658):
+    five steps on random gradients must leave the parameters where torch.optim.Adam leaves a copy of them (fp32, <= 1e-5 of the
+    update + a few ulps), a host-side ``param_group["lr"]`` decay is honoured (train.py:1625-1630), the next render uses the stepped weights without
+    another re-pack (equal, bit for bit, to a handle packed from scratch), the state round-trips through torch.optim.Adam's state_dict,
+    and the modules' parameters / state_dict are ordinary tensors although they live in one flat vector."""
+    import copy
+    from nonrigid_nerf_amd import training
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 2)
+    rb, coarse, fine = _modules(scene)
+    rb2, coarse2, fine2 = copy.deepcopy(rb), copy.deepcopy(coarse), copy.deepcopy(fine)
+    coarse2.ray_bender, fine2.ray_bender = (rb2,), (rb2,)
+    codes = torch.zeros(4, cfg.latent_size, device=DEV, requires_grad=True)
+    codes2 = codes.detach().clone().requires_grad_(True)
+    named, named2 = _named(rb, coarse, fine), _named(rb2, coarse2, fine2)
+    params, params2 = list(named.values()) + [codes], list(named2.values()) + [codes2]
+    sd_before = {k: v.detach().clone() for k, v in coarse.state_dict().items()}
+    opt = training.FusedAdam(params, lr=1e-2, betas=(0.9, 0.999), networks=(coarse, fine))
+    ref = torch.optim.Adam(params2, lr=1e-2, betas=(0.9, 0.999))
+    assert opt.repacks_weights == (not cfg.use_viewdirs)
+    for k, v in coarse.state_dict().items():               # re-homing moved the storage, not the values
+        assert torch.equal(v, sd_before[k]), k
+    rays, lat = make_rays(64, 1, cfg)
+    rays, lat = rays.to(DEV), lat.to(DEV)
+    R.set_precision("bf16")
+    kw = dict(N_samples=cfg.N_samples, N_importance=cfg.N_importance, network_fine=fine, additional_pixel_information={"ray_bending_latents": lat})
+
+    def render():
+        with torch.no_grad():
+            return R.render_rays(rays, coarse, **kw)["rgb_map"].clone()
+
+    before = render()
+    g = torch.Generator().manual_seed(0)
+    start = {k: p.detach().clone() for k, p in named.items()}
+    for it in range(5):
+        for (k, p), p2 in zip(list(named.items()) + [("codes", codes)], params2):
+            gr = torch.randn(p.shape, generator=g).to(DEV) * (0.0 if (it == 2 and k == "codes") else 1.0)
+            p.grad, p2.grad = gr.clone(), gr.clone()
+        lr = 1e-2 * (0.5 ** it)
+        for grp in opt.param_groups + ref.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        ref.step()
+    worst = 0.0
+    for (k, p), p2 in zip(list(named.items()) + [("codes", codes)], params2):
+        moved = (p2.detach() - (start[k] if k != "codes" else 0.0)).abs().max().item()
+        worst = max(worst, (p.detach() - p2.detach()).abs().max().item() / max(moved, 1e-12))
+        assert (p.detach() - p2.detach()).abs().max().item() <= 1e-5 * max(moved, 1e-3) + 1e-7, k        # (a few fp32 ulps of the parameter after five steps)
+    print(f"\\n[FusedAdam vs torch.optim.Adam, 5 steps] worst |difference| / |update| over all tensors: {worst:.2e}; "
+          f"segments of the last launch: {opt.last_segments}")
+    launches = []
+    if opt.repacks_weights:
+        model = R.get_model(coarse, fine)
+        lib_update = model.update_from_device
+        model.update_from_device = lambda *a, **k: (launches.append(1), lib_update(*a, **k))[1]
+    after = render()
+    assert not torch.equal(after, before), "the steps did not reach the packed weights"
+    assert not launches, "the render after a fused step re-packed the weights again"
+    R.invalidate(coarse)
+    if cfg.use_viewdirs:        # (the device-side refresh folds feature_linear into the views layer with fp32 device products, the host packer on
+        assert (render() - after).abs().max().item() < 2e-3           #  the host: two roundings of the folded matrix, as test_device_side_weight_refresh_* states)
+    else:
+        assert torch.equal(render(), after), "packed weights after the fused step differ from a fresh pack of the parameters"
+    # state_dict round trip with torch's Adam (the reference checkpoints its optimiser, train.py:1680-1698)
+    sd = opt.state_dict()
+    ref.load_state_dict(copy.deepcopy(sd))
+    opt2 = training.FusedAdam(params, lr=1e-2, networks=(coarse, fine))
+    opt2.load_state_dict(copy.deepcopy(ref.state_dict()))
+    for p in params:
+        assert torch.equal(opt2.state[p]["exp_avg"], opt.state[p]["exp_avg"]) and torch.equal(opt2.state[p]["exp_avg_sq"], opt.state[p]["exp_avg_sq"])
+    assert float(opt2.state[params[0]]["step"]) == 5.0
+    assert all(isinstance(p, torch.nn.Parameter) for p in coarse.parameters())
+
+
+@pytest.mark.gpu
+def test_training_iteration_with_the_fused_optimiser_replayed_from_a_hip_graph():
+    """GraphedStep + FusedAdam(networks=...): the captured iteration has NO re-pack at its start (the optimiser's launch leaves the handles
+    fresh at its end), trains, and after any replay a no-grad render uses the trained weights without a sync() or another re-pack."""
+    from nonrigid_nerf_amd import training
+    cfg = SceneConfig(N_importance=64)
+    rb, coarse, fine = training._fresh_training_modules(cfg, torch.device(DEV), 64)
+    params = []
+    for m in (rb, coarse, fine):
+        m.requires_grad_(True)
+        params += list(m.parameters())
+    codes = torch.zeros(4, cfg.latent_size, device=DEV, requires_grad=True)
+    opt = training.FusedAdam(params + [codes], lr=5e-4, networks=(coarse, fine))
+    rays, _ = make_rays(256, 5, cfg)
+    rays = rays.to(DEV)
+    frame = torch.randint(0, 4, (256,), device=DEV)
+    target = 0.5 + 0.4 * torch.sin(3.0 * rays[:, 3:6])
+    kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=64, N_importance=64, perturb=1.0, raw_noise_std=1.0)
+    R.set_precision("bf16")
+
+    def loss_of(rays, target, frame, global_step):
+        loss, _ = training.training_loss(rays, training.select_codes(codes, frame), target, kw, offsets_loss_weight=60.0, divergence_loss_weight=3.0,
+                                         rigidity_loss_weight=0.0005, global_step=global_step, N_iters=200000, chunk=32768)
+        return loss.mean()
+
+    gstep = torch.zeros((), device=DEV)
+    graphed = training.GraphedStep(loss_of, dict(rays=rays, target=target, frame=frame, global_step=gstep), opt, [coarse])
+    assert graphed.repacks
+    losses = [float(graphed(global_step=gstep.fill_(float(i)))) for i in range(60)]
+    assert all(l == l for l in losses)
+    assert sum(losses[-10:]) / 10 < 0.8 * sum(losses[:5]) / 5, (losses[:5], losses[-10:])
+    with torch.no_grad():
+        got = R.batchify_rays(rays, {"ray_bending_latents": codes[frame].detach()}, chunk=32768, **{**kw, "perturb": 0.0, "raw_noise_std": 0.0})
+        R.invalidate(coarse)
+        want = R.batchify_rays(rays, {"ray_bending_latents": codes[frame].detach()}, chunk=32768, **{**kw, "perturb": 0.0, "raw_noise_std": 0.0})
+    assert torch.equal(got["rgb_map"], want["rgb_map"]), "after a replay the packed weights must be the trained parameters"
+    print(f"\\n[graphed training step, fused optimiser] loss {losses[0]:.4f} -> {losses[-1]:.4f} over 60 replays")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("M,wo,wi,wi2", [(4097, 192, 192, 51), (1000, 100, 320, 27), (70000, 448, 256, 63), (129, 4, 128, 8), (64, 130, 36, 3)])
+def test_tn_products_kernel_vs_einsum(dtype, M, wo, wi, wi2):
+    """nrnerf_tn_products (csrc/nrnerf_gen_train.hip: the weight / bias gradients of a non-compiled trunk over its ROW-MAJOR saved arrays;
+    bf16 through LDS transpose reads, fp32 on 16x16x4 MFMAs) against torch: a product with a bias row, a second product of the same `a`
+    written into the neighbouring columns of the same matrix (the skip layer's [encoding | activation] weight), a sub-matrix operand
+    (column offset + leading dimension, as the view-dependent head's halves), widths that are no multiple of the 128-wide panels or of
+    a 16-byte piece (100 bf16 columns: the element-wise edge path), row counts that are no multiple of the 64-sample tile."""
+    from nonrigid_nerf_amd import training
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn(M, wo + 6, generator=g) * 0.5).to(DEV).to(dtype)
+    b = torch.randn(M, wi, generator=g).to(DEV).to(dtype)
+    b2 = torch.randn(M, wi2, generator=g).to(DEV).to(dtype)
+    ldo = wi + wi2
+    o_w, o_b, o_s = 7, 7 + wo * ldo, 7 + wo * ldo + wo + 5
+    total = o_s + (wo - 2) * wi + 3
+    jobs = [(a, 0, b, 0, wo, wi, ldo, o_w, o_b), (a, 0, b2, 0, wo, wi2, ldo, o_w + wi, None),
+            (a, 2, b, 0, wo - 2, wi, wi, o_s, None)]                      # columns 2.. of a: a sub-matrix operand
+    got = training._tn_products(jobs, M, total, torch.device(DEV))
+    torch.cuda.synchronize()
+    af, bf, b2f = a.double(), b.double(), b2.double()
+    want_w = torch.cat([af[:, :wo].T @ bf, af[:, :wo].T @ b2f], 1)
+    want_s = af[:, 2:wo].T @ bf
+    scale = float(want_w.abs().max())
+    tol = (2e-3 if dtype == torch.bfloat16 else 2e-5) * scale      # (fp32 accumulation of M products; the operands are exact in both modes)
+    assert (got[o_w:o_w + wo * ldo].view(wo, ldo).double() - want_w).abs().max().item() <= tol
+    assert (got[o_b:o_b + wo].double() - af[:, :wo].sum(0)).abs().max().item() <= tol
+    assert (got[o_s:o_s + (wo - 2) * wi].view(wo - 2, wi).double() - want_s).abs().max().item() <= tol
+    covered = torch.zeros(total, dtype=torch.bool)
+    covered[o_w:o_w + wo * ldo] = True
+    covered[o_b:o_b + wo] = True
+    covered[o_s:o_s + (wo - 2) * wi] = True
+    assert bool((got.cpu()[~covered] == 0).all()), "positions no job covers must be zero"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("L,stride,n_lat", [(10, 4, 0), (4, 3, 0), (8, 4, 16), (0, 3, 0)])
+def test_encoding_rows_kernels_vs_torch_autograd(dtype, L, stride, n_lat):
+    """nrnerf_encoding_forward / _backward (Embedder.embed of 3-vectors as rows, rnh:120-150, and its transposed Jacobian; with the
+    time-conditioned baseline's code columns appended) against torch ops under autograd."""
+    from nonrigid_nerf_amd import training
+    g = torch.Generator().manual_seed(5)
+    N, S = 37, 19
+    M = N * S
+    src = (torch.randn(M, stride, generator=g) * 0.7).to(DEV)
+    codes = torch.randn(N, n_lat, generator=g).to(DEV) if n_lat else None
+    n_enc = 3 + 6 * L
+    cols = training._pad8(n_enc + n_lat)
+    enc = training._encoding_rows(src, stride, L, M, cols, dtype, codes, S)
+    p = src[:, :3].detach().clone().requires_grad_(True)
+    want = training.posenc(p, L)
+    tol = 2e-6 if dtype == torch.float32 else 8e-3
+    assert (enc[:, :n_enc].float() - want.detach()).abs().max().item() <= tol
+    if n_lat:
+        assert torch.equal(enc[:, n_enc:n_enc + n_lat].float(), codes.to(dtype).float()[:, None, :].expand(N, S, n_lat).reshape(M, n_lat))
+    assert bool((enc[:, n_enc + n_lat:] == 0).all())
+    d0 = torch.randn(M, n_enc + n_lat, generator=g).to(DEV)
+    d1 = torch.randn(M, n_enc + n_lat, generator=g).to(DEV)
+    for second in (None, d1):
+        got = training._encoding_backward(src, stride, L, d0, second, n_enc + n_lat, M)
+        gsum = d0 if second is None else d0 + d1
+        ref, = torch.autograd.grad(want, p, gsum[:, :n_enc], retain_graph=True)
+        scale = float(ref.abs().max())
+        assert (got[:, :3] - ref).abs().max().item() <= 1e-5 * scale and bool((got[:, 3] == 0).all())

@@ -113,18 +113,61 @@ def test_eligibility_of_training_calls():
         assert why in T.why_not_trainable(cw, fw, 64, 64, False, False, OnGpu11), kw
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("m,wo,wi", [(5, 4, 3), (2048, 8, 8), (18500, 24, 63), (40000, 192, 4), (9000, 1, 192)])
-def test_chunked_weight_gradient_product(m, wo, wi, dtype, tol):
-    """training._chunked_tn_product (the weight gradients of a non-compiled architecture: dy^T x over all samples as a batched GEMM over
-    chunks, partial results added, + the rows that do not fill a chunk) against the plain product in float64."""
-    g = torch.Generator().manual_seed(m + wo)
-    dy, x = torch.randn(m, wo, generator=g), torch.randn(m, wi, generator=g)
-    got = T._chunked_tn_product(dy.to(dtype), x.to(dtype))
-    want = dy.to(dtype).double().t() @ x.to(dtype).double()
-    assert got.dtype == torch.float32 and tuple(got.shape) == (wo, wi)
-    # (bf16: the chunks' partial results may come back rounded to bf16 where the library has no fp32-output batched GEMM)
-    assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max() + m ** 0.5)
+@pytest.mark.parametrize("D,W,skips,views", [(6, 24, (2,), False), (3, 16, (), False), (4, 20, (0,), True), (2, 12, (), True)])
+def test_generic_weight_gradient_plan_against_torch_autograd(D, W, skips, views):
+    """training._generic_grad_plan -- which products of the saved arrays make up a non-compiled trunk's weight / bias gradients, and
+    where each lands in the flat result (nrnerf_tn_products executes the list on the GPU) -- emulated on the CPU with plain matrix
+    products over activations / pre-activation gradients taken from a torch MLP of the reference's shape (rnh:253-306), against that
+    MLP's autograd: every parameter's gradient, in _generic_trunk_params order, positions no product covers zero."""
+    g = torch.Generator().manual_seed(D * 100 + W)
+    M, n_in, n_dir, half, C_out = 50, 9, 6, W // 2, 5
+    lin = lambda o, i: torch.nn.Linear(i, o).double()
+    pts = [lin(W, n_in)] + [lin(W, W + (n_in if (i - 1) in skips else 0)) for i in range(1, D)]
+    x, xv = torch.randn(M, n_in, generator=g).double(), torch.randn(M, n_dir, generator=g).double()
+    acts, pres, h = [], [], x
+    for i, l in enumerate(pts):
+        inp = x if i == 0 else (torch.cat([x, h], -1) if (i - 1) in skips else h)
+        z = l(inp)
+        z.retain_grad()
+        pres.append(z)
+        h = torch.relu(z)
+        acts.append(h)
+    if not views:
+        head = lin(C_out, W)
+        raw = head(h)
+        params = [p for l in pts for p in (l.weight, l.bias)] + [head.weight, head.bias]
+    else:
+        alpha, feat, vl, rgb = lin(1, W), lin(W, W), lin(half, W + n_dir), lin(3, half)
+        f = feat(h)
+        f.retain_grad()
+        zv = vl(torch.cat([f, xv], -1))
+        zv.retain_grad()
+        hv = torch.relu(zv)
+        raw = torch.cat([rgb(hv), alpha(h)], -1)
+        params = [p for l in pts for p in (l.weight, l.bias)] + [alpha.weight, alpha.bias, feat.weight, feat.bias, vl.weight, vl.bias, rgb.weight, rgb.bias]
+    gr = torch.randn(M, 4, generator=g).double()
+    (raw[:, :4] * gr).sum().backward()
+    ops = {"g": gr, "enc": x, "encv": xv}
+    for i in range(D):
+        ops[("acts", i)], ops[("d_pre", i)] = acts[i].detach(), pres[i].grad
+    if views:
+        pad = lambda t: torch.cat([t, torch.zeros(M, W - t.shape[1], dtype=t.dtype)], 1)          # the saved arrays are [M, W] rows
+        ops[("acts", D)], ops[("d_pre", D)] = f.detach(), f.grad
+        ops[("acts", D + 1)], ops[("d_pre", D + 1)] = pad(hv.detach()), pad(zv.grad)
+    plan, shapes, total = T._generic_grad_plan(D, W, n_in, skips, C_out, views, half, n_dir)
+    flat = torch.zeros(total, dtype=torch.float64)
+    for a, ac, b, bc, wo, wi, ldo, ow, ob in plan:
+        prod = ops[a][:, ac:ac + wo].T @ ops[b][:, bc:bc + wi]
+        for o in range(wo):
+            flat[ow + o * ldo: ow + o * ldo + wi] += prod[o]
+        if ob is not None:
+            flat[ob:ob + wo] += ops[a][:, ac:ac + wo].sum(0)
+    assert [tuple(p.shape) for p in params] == shapes and total == sum(p.numel() for p in params)
+    o = 0
+    for p, shp in zip(params, shapes):
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(flat[o:o + p.numel()].view(shp), want, atol=1e-10), shp
+        o += p.numel()
 
 
 def test_which_handle_a_training_call_works_on():
