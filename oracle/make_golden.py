@@ -217,6 +217,14 @@ GRAD_PARAMS_VIEWS = {"bender": ["network.4.weight", "network.0.bias", "rigidity_
                      "fine": ["pts_linears.7.bias", "alpha_linear.bias", "feature_linear.weight", "views_linears.0.bias", "rgb_linear.bias"]}
 
 
+# a NON-COMPILED architecture (--netdepth 6 --netwidth 192 --netwidth_fine 320, 8 frequencies; the run-time-parameterised training kernels):
+# pts_linears.3 is the skip layer of a 6-layer trunk with skips = [2] (its weight has the [encoding | activation] columns)
+GRAD_CFG_GENERIC = dict(netdepth=6, netwidth=192, netwidth_fine=320, multires=8, skips=(2,))
+GRAD_PARAMS_GENERIC = {"bender": ["network.4.weight", "network.0.bias", "rigidity_network.2.weight"],
+                       "coarse": ["pts_linears.0.weight", "pts_linears.3.weight", "pts_linears.5.bias", "output_linear.weight", "output_linear.bias"],
+                       "fine": ["pts_linears.0.bias", "pts_linears.3.weight", "pts_linears.5.weight", "output_linear.weight"]}
+
+
 GRAD_PARAMS_TCB = {"coarse": ["pts_linears.0.weight", "pts_linears.5.bias", "output_linear.weight"],
                    "fine": ["pts_linears.5.weight", "pts_linears.0.bias", "output_linear.bias"]}
 
@@ -353,6 +361,8 @@ def main():
                             **run_gradients(H, T, cfg_kw=dict(use_viewdirs=True, approx_nonrigid_viewdirs=False), grad_params=GRAD_PARAMS_VIEWS))
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_time_conditioned_64_64.npz"),
                             **run_gradients(H, T, cfg_kw=dict(ray_bending=False, time_conditioned_baseline=True), grad_params=GRAD_PARAMS_TCB))
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "gradients_generic_192_320_64_64.npz"),
+                            **run_gradients(H, T, cfg_kw=GRAD_CFG_GENERIC, grad_params=GRAD_PARAMS_GENERIC))
         if "--only-grads" in sys.argv:
             return
     if "--only-train-step" in sys.argv or not [a for a in sys.argv if a.startswith("--case=")]:

@@ -50,8 +50,11 @@ def torch_ops_bender():
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture,cfg_kw", [("gradients_64_64", {}), ("gradients_viewdirs_64_64", dict(use_viewdirs=True)),
                                             ("gradients_exact_viewdirs_64_64", dict(use_viewdirs=True, approx_nonrigid_viewdirs=False)),
-                                            ("gradients_time_conditioned_64_64", dict(ray_bending=False, time_conditioned_baseline=True))],
-                         ids=["default", "viewdirs", "exact_viewdirs", "time_conditioned"])
+                                            ("gradients_time_conditioned_64_64", dict(ray_bending=False, time_conditioned_baseline=True)),
+                                            # a NON-COMPILED architecture (oracle/make_golden.py GRAD_CFG_GENERIC): the run-time-parameterised forward /
+                                            # backward-data programs, nrnerf_tn_products and the encoding kernels against the REFERENCE's autograd
+                                            ("gradients_generic_192_320_64_64", dict(netdepth=6, netwidth=192, netwidth_fine=320, multires=8, skips=(2,)))],
+                         ids=["default", "viewdirs", "exact_viewdirs", "time_conditioned", "generic_192_320"])
 def test_gradients_match_reference_autograd_golden(torch_ops_bender, fixture, cfg_kw):
     """fp32 mode: d(sum rgb_map + sum rgb0) wrt the latent codes and a few parameters of every network, against what the
     reference's own autograd produced on the CPU (train.render under grad, z_samples detached).
@@ -126,7 +129,7 @@ def test_gradients_match_reference_autograd_golden(torch_ops_bender, fixture, cf
           "(ours | the oracle on this device): " + "; ".join(f"{k[6:]} {e:.1e} | {d:.1e}" for k, e, d in report))
 
 
-def _oracle_grads(scene, rays, latents, seed, perturb, noise, detailed_loss, z_override=None, weights=None, **flags):
+def _oracle_grads(scene, rays, latents, seed, perturb, noise, detailed_loss, z_override=None, weights=None, dtype=torch.float32, **flags):
     """``weights``: {(part, name): tensor} to use instead of the scene's (the modules' parameters after an optimiser step)."""
     from oracle import nrnerf_oracle as O
     sc = O.scene_on(scene, DEV)
@@ -136,12 +139,14 @@ def _oracle_grads(scene, rays, latents, seed, perturb, noise, detailed_loss, z_o
         if d is None:
             continue
         for k in d:
-            d[k] = (weights[(part, k)].detach() if weights is not None else d[k]).clone().requires_grad_(True)
+            d[k] = (weights[(part, k)].detach() if weights is not None else d[k]).to(dtype).clone().requires_grad_(True)
             leaves[(part, k)] = d[k]
-    lat = latents.to(DEV).clone().requires_grad_(True)
+    # (dtype = float64: the SAME graph in double precision (the oracle is dtype-generic) -- i.e. how far the
+    #  reference's own fp32 arithmetic is from the exact gradient)
+    lat = latents.to(DEV).to(dtype).clone().requires_grad_(True)
     torch.manual_seed(seed)
     out = O.render_rays(rays.to(DEV), lat, sc, retraw=True, detailed_output=detailed_loss, perturb=perturb, raw_noise_std=noise,
-                        z_fine_override=z_override, **flags)
+                        z_fine_override=(z_override.to(dtype) if z_override is not None else None), dtype=dtype, **flags)
     loss = _loss(out, detailed_loss)
     loss.backward()
     return float(loss.detach()), lat.grad, {k: v.grad for k, v in leaves.items()}, out
@@ -395,16 +400,33 @@ def test_generic_training_sees_an_optimiser_step_in_forward_and_backward_weights
         training.NATIVE_BENDER, training.BATCHED_BENDER, training.SPLIT_FINE_BENDER = saved
     assert calls["dev"] >= 1, "the second call did not take the device-side re-pack"
     _, _, g_ref, _ = _oracle_grads(scene, rays, latents, 0, 0.0, 0.0, False, z_override=z, weights=named)
-    fails, worst = [], 0.0
+    # the yardstick for the bars below ("a measurement, not an allowance"): the oracle's OWN fp32 arithmetic against the same
+    # graph in fp64, per tensor -- behind the bent point sits the 2^9-frequency encoding, so an ulp of the point moves the bender's and,
+    # with the native bender (another fp32 rounding of the bent points), every downstream gradient by this much
+    _, _, g_64, _ = _oracle_grads(scene, rays, latents, 0, 0.0, 0.0, False, z_override=z, weights=named, dtype=torch.float64)
+    fails, worst, worst_ref, by_part = [], 0.0, 0.0, {}
     for (part, name), gr in g_ref.items():
         if gr is None:
             continue
-        err = float((named[(part, name)].grad - gr).abs().max()) / (float(gr.abs().max()) + 1e-12)
-        worst = max(worst, err)
+        scale = float(gr.abs().max()) + 1e-12
+        err = float((named[(part, name)].grad - gr).abs().max()) / scale
+        e3264 = float((gr.double() - g_64[(part, name)]).abs().max()) / scale
+        worst, worst_ref = max(worst, err), max(worst_ref, e3264)
+        w = by_part.setdefault(part, [0.0, 0.0])
+        w[0], w[1] = max(w[0], err), max(w[1], e3264)
         if err > (5e-2 if part == "bender" else (2e-2 if bender == "native" else 2e-3)):
-            fails.append((part, name, err))
-    print(f"\n[generic training after a step, fp32, {bender or 'no'} bender] worst error / scale {worst:.1e}; device re-packs {calls['dev']}")
+            fails.append((part, name, err, e3264))
+    print(f"\n[generic training after a step, fp32, {bender or 'no'} bender] worst error / scale {worst:.1e} (the oracle's fp32 vs fp64 on the same "
+          f"tensors: {worst_ref:.1e}); per part ours | oracle fp32-vs-fp64: " + ", ".join(f"{k} {a:.1e} | {b:.1e}" for k, (a, b) in by_part.items())
+          + f"; device re-packs {calls['dev']}")
     assert not fails, fails
+    # ... and the bars ARE of that size: no part of the model may sit further from the fp32 oracle than 10 x the distance the oracle's
+    # own fp32 arithmetic has from fp64 on that part (or the plain fp32 tolerance of a trunk without a bender in front, 2e-3).  With the
+    # native bender -- another fp32 rounding of the bent points, i.e. a perturbation AT the bender's output -- the trunks downstream are
+    # held to the bender part's figure (measured on the MI355X: bender 1.2e-2 | 3.9e-3, coarse 4.4e-3 | 1.2e-4, fine 1.5e-3 | 1.5e-3)
+    b_bender = by_part.get("bender", [0.0, 0.0])[1] if bender == "native" else 0.0
+    for k, (a, b) in by_part.items():
+        assert a <= max(2e-3, 10.0 * max(b, b_bender)), (k, a, b, b_bender)
 
 
 @pytest.mark.gpu
