@@ -1286,7 +1286,11 @@ void pack_gx16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPas
 
 // ---- models of an architecture outside the compiled set (nrnerf_generic.h)
 int gen_pack_all(const nrnerf_model_desc& d, const FlatLayout* lay, GenProgram& gb, GenProgram& gc, GenProgram& gf) {
-    if (d.exact_viewdirs && d.bender && d.coarse->use_viewdirs) return NRNERF_ERR_UNSUPPORTED;      // Jacobian directions: compiled kernels only
+    // exact Jacobian view directions (rnh:358-385) off the compiled set: the tangent J d comes from the bender's compiled divergence kernel
+    // (ray mode of bend_div_fwd), so the BENDER must have one of the two compiled shapes, and the handle its training images (not "f16")
+    if (d.exact_viewdirs && d.bender && d.coarse->use_viewdirs &&
+        (d.precision == NRNERF_PREC_F16 || !(bender_matches<ArchDefault>(*d.bender) || bender_matches<ArchDeepBend>(*d.bender))))
+        return NRNERF_ERR_UNSUPPORTED;
     int rc = gen_check_mlp(d, *d.coarse);
     if (rc == NRNERF_OK && d.fine) rc = gen_check_mlp(d, *d.fine);
     if (rc == NRNERF_OK && d.fine && (d.fine->time_conditioned != 0) != (d.coarse->time_conditioned != 0)) rc = NRNERF_ERR_INVALID;
@@ -1424,6 +1428,8 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
         }
         m->gen_train_ok = true;
     }
+    m->exact = d.exact_viewdirs != 0 && m->has_bend && m->views;
+    if (m->exact && !(m->bend_train_ok && m->gen_train_ok)) return NRNERF_ERR_UNSUPPORTED;      // (needs bend_div_fwd and the per-sample-direction instantiation)
     // with a bender (the passes then run on ready-made points) and a plain head: the trunks also for the width-class x16 kernel
     if (d.bender && gx16_eligible(d, *d.coarse) && (!d.fine || gx16_eligible(d, *d.fine))) {
         PackedPass pgc, pgf;
@@ -1990,7 +1996,6 @@ void nrnerf_model_destroy(nrnerf_model* m) {
 }
 
 size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples, int32_t n_importance) {
-    (void)model;
     if (n_rays <= 0 || n_samples <= 0 || n_importance < 0) return 0;
     const size_t N = (size_t)n_rays, S = (size_t)n_samples, SF = S + (size_t)n_importance;
     size_t b = align_up(N * S * 4 * sizeof(float), 256);
@@ -2001,6 +2006,7 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
         b += align_up(N * S * 4 * sizeof(float), 256);
         b += align_up(N * (SF - S) * sizeof(float), 256) + align_up(N * (SF - S), 256);
     }
+    if (model && model->generic && model->exact) b += align_up(N * SF * 3 * sizeof(float), 256);      // per-sample Jacobian directions of a pass
     return b;
 }
 
@@ -2049,8 +2055,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     if (I > 0) {
         bent_c = (float*)ws; ws += align_up((size_t)N * S * 4 * sizeof(float), 256);
         z_new = (float*)ws; ws += align_up((size_t)N * I * sizeof(float), 256);
-        rank_new = (uint8_t*)ws;
+        rank_new = (uint8_t*)ws; ws += align_up((size_t)N * I, 256);
     }
+    float* const jdirs = (m->generic && m->exact) ? (float*)ws : nullptr;      // [N, S + I | S, 3]: exact Jacobian directions of the pass in flight
     if (!surface && !split) bent4 = nullptr;
     if ((a->u_fine || a->noise_fine) && I == 0) return NRNERF_ERR_INVALID;
 
@@ -2143,6 +2150,30 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
             const GxMeta& gm = (&pd == &m->gen_coarse) ? m->gx_meta_coarse : m->gx_meta_fine;
             const PassDev& gxu = (m->gen_fine_is_coarse && &pd == &m->gen_fine) ? m->gx_coarse : gx;      // (one network for both passes)
             const GxMeta& gmu = (m->gen_fine_is_coarse && &pd == &m->gen_fine) ? m->gx_meta_coarse : gm;
+            if (m->exact) {
+                // exact Jacobian view directions (rnh:291-294, 358-385): J d of every sample from the bender's divergence kernel in ray mode
+                // (value + tangent chain, fp32), then the network program on the per-sample directions (its training instantiation takes
+                // them; nothing is saved)
+                BendDivArgs t{};
+                t.latents = a->latents; t.lat_stride = a->latent_stride; t.m = (long long)N * nS;
+                t.wstream = m->bend_train_fwd.stream; t.bias = m->bend_train_fwd.bias;
+                t.knobs.has_cutoff = kn.has_cutoff; t.knobs.cutoff = kn.cutoff; t.knobs.has_scaling = kn.has_scaling; t.knobs.scaling = kn.scaling;
+                t.rays = a->rays; t.ray_stride = a->ray_stride; t.zr = zv; t.S = nS; t.lindisp = a->lindisp; t.dirs_out = jdirs;
+                const bool b16 = m->precision != NRNERF_PREC_F32;
+                hipError_t je = (m->gen_compiled_bender == 0) ? launch_bend_div_fwd_a0(t, m->num_cus, stream, b16) : launch_bend_div_fwd_a1(t, m->num_cus, stream, b16);
+                if (je != hipSuccess) return je;
+                GenArgs g = prog;
+                g.mode = 1;
+                g.rays = pts; g.ray_stride = 0; g.latents = nullptr; g.lat_stride = 0;
+                g.z = nullptr; g.lindisp = 0; g.n_rays = N; g.S = nS;
+                g.pts4 = pts; g.dirs_from_pts = 0; g.dirs = jdirs;
+                g.wstream = pd.stream; g.bias = pd.bias;
+                g.raw4 = raw4; g.raw_out = raw_user; g.raw_ch = pd.output_ch; g.bent4 = const_cast<float*>(pts);        // (read: the removal knob, rnh:308-311)
+                g.save = nullptr; g.mask = nullptr; g.save_stride = 0; g.save_w = 0;
+                g.knobs = kn;
+                return timed(slot, "gen_kernel (exact Jacobian directions)", (double)N * nS * pd.algo_flops_per_sample, (double)N * nS * pd.mfma_flops_per_sample,
+                             [&] { return launch_generic_train(m->precision, g, m->num_cus, stream); });
+            }
             if (pts && gxu.stream && !(a->flags & NRNERF_RENDER_NO_X16) && !any_detail(so) && !kn.detailed &&
                 (long long)N * nS < (1ll << 32)) {      // (the kernel's 32-bit sample rows; beyond: the run-time-parameterised kernel below)
                 GxArgs x{};

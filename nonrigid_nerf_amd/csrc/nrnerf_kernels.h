@@ -226,6 +226,13 @@ struct BendDivArgs {
     float* dz_out4;          // backward out [M,4] gradient wrt the offsets (xyz) and the rigidity logit (w)
     float* dtz_out4;         // backward out [M,4] ... wrt their tangents
     float* d_lat;            // backward out [M,LAT] gradient wrt each point's latent inputs
+    // RAY MODE of the forward kernel (rays != nullptr; nrnerf_render's exact Jacobian view directions on a non-compiled architecture,
+    // rnh:358-385): point i = sample i % S of ray i / S -- o + d z, z from `zr` [M] or the coarse spacing between the ray's near and far --,
+    // probe = the ray's unit direction (ray record columns 8..10), latents one row per RAY; pts / e are not read; every saved array,
+    // div, off4 and toff4 may be nullptr (nothing is kept for a backward pass)
+    const float* rays; int ray_stride;
+    const float* zr; int S; int lindisp;
+    float* dirs_out;         // [M,3] or nullptr: (J d) / |J d| + 1e-6 with J d = d + tvec's value (rnh:367-378: eps outside the division)
 };
 hipError_t launch_bend_div_fwd_a0(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);
 hipError_t launch_bend_div_fwd_a1(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);

@@ -306,9 +306,27 @@ __global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
         const long long sidx = blk * 32 + j;
         const bool ok = sidx < a.m;
         const size_t so = ok ? (size_t)sidx : M - 1;
-        const float p[3] = {a.pts[so * 3], a.pts[so * 3 + 1], a.pts[so * 3 + 2]};
-        const float ev[3] = {a.e[so * 3], a.e[so * 3 + 1], a.e[so * 3 + 2]};
-        const float* lat = a.latents + so * (size_t)a.lat_stride;
+        float p[3], ev[3];
+        const float* lat;
+        if (a.rays) {                   // ray mode (BendDivArgs): the sample's point and the ray's unit direction, computed here
+            const size_t ray = so / (size_t)a.S;
+            const int k = (int)(so - ray * (size_t)a.S);
+            const float* rp = a.rays + ray * (size_t)a.ray_stride;
+            float z;
+            if (a.zr) z = a.zr[so];
+            else {                      // train.py:847-852, as the network kernels
+                const float t = lin01(k, a.S), near = rp[6], far = rp[7];
+                if (a.lindisp) z = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, far), t)));
+                else z = __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p[c] = __fadd_rn(rp[c], __fmul_rn(rp[3 + c], z)); ev[c] = rp[8 + c]; }       // train.py:871-873; 380-381
+            lat = a.latents + ray * (size_t)a.lat_stride;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p[c] = a.pts[so * 3 + c]; ev[c] = a.e[so * 3 + c]; }
+            lat = a.latents + so * (size_t)a.lat_stride;
+        }
         auto binval = [&](auto idxc) -> float {
             constexpr int idx = decltype(idxc)::value;
             if constexpr (idx < 3) return p[idx];
@@ -333,7 +351,7 @@ __global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
         // hidden layer `layer`: keep value and tangent (true feature order) and hand both on
         auto keep = [&](void* base, void* tbase, int width, auto lc, auto tc, const f32x16& acc, const f32x16& tacc, auto& out, auto& tout) {
             constexpr int layer = decltype(lc)::value, t = decltype(tc)::value;
-            if (ok) {
+            if (ok && base) {           // (ray mode: nothing is kept)
                 const size_t row = ((size_t)layer * M + so) * width + 32 * t + 4 * h;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -408,9 +426,18 @@ __global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) tv[c] = sc * (tmask * off[c] + mask * toff[c]);
             }
-            a.div[so] = d;
-            *(f32x4*)(a.off4 + so * 4) = f32x4{off[0], off[1], off[2], th};
-            *(f32x4*)(a.toff4 + so * 4) = f32x4{toff[0], toff[1], toff[2], tlogit};
+            if (a.dirs_out) {           // NeRF.exact_nonrigid_viewdirs (rnh:367-378): J d = d + d(masked offsets)/dp . d, normalised, eps OUTSIDE the division
+                const float sc = a.knobs.has_scaling ? a.knobs.scaling : 1.0f;
+                float jd[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) jd[c] = __fadd_rn(ev[c], __fmul_rn(sc, __fadd_rn(__fmul_rn(tmask, off[c]), __fmul_rn(mask, toff[c]))));
+                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(jd[0], jd[0]), __fmul_rn(jd[1], jd[1])), __fmul_rn(jd[2], jd[2])));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.dirs_out[so * 3 + c] = __fadd_rn(__fdiv_rn(jd[c], nrm), 0.000001f);
+            }
+            if (a.div) a.div[so] = d;
+            if (a.off4) *(f32x4*)(a.off4 + so * 4) = f32x4{off[0], off[1], off[2], th};
+            if (a.toff4) *(f32x4*)(a.toff4 + so * 4) = f32x4{toff[0], toff[1], toff[2], tlogit};
         }
     }
 }

@@ -125,6 +125,10 @@ CASES = {
     "generic_viewdirs_96_160": (dict(N_importance=48, N_samples=40, netdepth=7, netwidth=96, netwidth_fine=160, multires=6, multires_views=2,
                                      use_viewdirs=True), 37, 16, False, True, {}),
     "generic_shallow_no_bender": (dict(N_importance=64, netdepth=4, netwidth=64, ray_bending=False), 48, 32768, False, True, {}),
+    # exact Jacobian view directions (approx_nonrigid_viewdirs=False, rnh:358-385) on a NON-COMPILED trunk (--netwidth 192 --netwidth_fine 160,
+    # --netdepth 6), the reference's own bender: the library computes J d with the bender's divergence kernel (round 6)
+    "generic_exact_viewdirs_192": (dict(N_importance=64, netdepth=6, netwidth=192, netwidth_fine=160, skips=(2,), use_viewdirs=True,
+                                        approx_nonrigid_viewdirs=False), 37, 16, False, True, dict(rigidity_test_time_cutoff=0.3, test_time_scaling=0.8)),
     "generic_time_conditioned_448": (dict(N_importance=32, netdepth=8, netwidth=448, multires=12, latent_size=24, ray_bending=False,
                                           time_conditioned_baseline=True, use_viewdirs=True, multires_views=6), 24, 32768, False, True, {}),
 }

@@ -139,7 +139,7 @@ COARSE_KEYS = ["rgb0", "disp0", "acc0", "visibility_weights", "opacity_alpha", "
                                   "exact_viewdirs_knobs", "config4_exact_viewdirs", "narrow_128_64_64", "narrow_128_no_bender",
                                   # architectures outside the compiled set: the run-time-parameterised kernel (csrc/nrnerf_generic.h)
                                   "generic_192_320_detailed", "generic_viewdirs_96_160", "generic_shallow_no_bender",
-                                  "generic_time_conditioned_448"])
+                                  "generic_time_conditioned_448", "generic_exact_viewdirs_192"])
 def test_fp32_mode_matches_reference_golden(name):
     meta, cfg, scene, rays, latents, ref = load_golden(name)
     meta["knobs"], flags = split_knobs(meta["knobs"])

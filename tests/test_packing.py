@@ -1146,16 +1146,25 @@ def test_generic_backward_data_programs_reproduce_autograd(cfg_kw, precision):
             close(outs[6], ev.grad.numpy(), "d direction encoding")
 
 
-def test_compiled_shapes_are_not_generic_and_exact_directions_stay_unsupported_there():
-    """nrnerf_pack_host 7 works for any supported shape (also a compiled one); exact Jacobian directions have no generic kernel."""
-    cfg = SceneConfig(N_importance=64, netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False)
-    scene = make_scene(cfg, 3)
-    rb, coarse, fine = build_modules(scene)
-    desc, keep = build_model_desc(coarse, fine, "f32", 0)
+def test_which_generic_shapes_render_with_exact_jacobian_directions():
+    """nrnerf_pack_host 7 works for any supported shape (also a compiled one).  Exact Jacobian view directions (rnh:358-385) on a
+    non-compiled trunk (round 6): rendered natively when the ray BENDER has one of the two compiled shapes (its divergence kernel
+    supplies J d) and the handle is not an "f16" one (no training images); any other bender / precision stays unsupported there, i.e.
+    goes to the reference."""
     lib = _lib.load()
     info = _lib.PackedInfo()
-    rc = lib.nrnerf_pack_host(C.byref(desc), 7, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)())
-    assert rc == _lib.ERR_UNSUPPORTED
+
+    def status(cfg_kw, precision):
+        rb, coarse, fine = build_modules(make_scene(SceneConfig(N_importance=64, **cfg_kw), 3))
+        desc, keep = build_model_desc(coarse, fine, precision, 0)
+        return lib.nrnerf_pack_host(C.byref(desc), 7, C.byref(info), None, 0, C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)())
+
+    exact = dict(netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False)
+    assert status(exact, "f32") == 0 and status(exact, "bf16") == 0 and status(dict(exact, bend_depth=7), "f32") == 0
+    assert status(exact, "f16") == _lib.ERR_UNSUPPORTED
+    assert status(dict(exact, bend_hidden=96), "f32") == _lib.ERR_UNSUPPORTED
+    assert status(dict(exact, latent_size=16), "f32") == _lib.ERR_UNSUPPORTED
+    coarse = fine = None
     # a width beyond the generic kernel's limit
     cfg = SceneConfig(N_importance=64, netwidth=640)
     rb, coarse, fine = build_modules(make_scene(cfg, 3))
@@ -1184,5 +1193,6 @@ def test_which_architectures_have_a_backward_data_program():
     assert status(dict(netwidth=512, use_viewdirs=True), "bf16") == _lib.ERR_UNSUPPORTED
     assert status(dict(netwidth=190), "f32") == _lib.ERR_UNSUPPORTED                     # (rows of 4 elements)
     exact = dict(netwidth=192, use_viewdirs=True, approx_nonrigid_viewdirs=False)
-    assert status(exact, "f32") == _lib.ERR_UNSUPPORTED
-    assert status(exact, "f32", flags=_lib.MODEL_PY_TRAINING_HANDLE) == 0
+    assert status(exact, "f32") == 0                                   # (round 6: the bender has a compiled shape, nrnerf_render computes J d itself)
+    assert status(dict(exact, bend_hidden=96), "f32") == _lib.ERR_UNSUPPORTED
+    assert status(dict(exact, bend_hidden=96), "f32", flags=_lib.MODEL_PY_TRAINING_HANDLE) == 0
