@@ -13,7 +13,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # fixtures that are not render_rays cases: get_rays outputs, gradients, the fitted-checkpoint data, render_path / surface goldens
 NOT_RENDER_CASES = ("raygen.npz", "gradients_64_64.npz", "example_sequence_96x72.npz", "render_path_2frames.npz",
                     "surface_reduction.npz", "train_step_64_64.npz", "gradients_viewdirs_64_64.npz", "gradients_time_conditioned_64_64.npz",
-                    "gradients_exact_viewdirs_64_64.npz")
+                    "gradients_exact_viewdirs_64_64.npz", "gradients_generic_192_320_64_64.npz")
 GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f not in NOT_RENDER_CASES)
 
 

@@ -76,8 +76,9 @@ def test_oracle_get_rays_matches_reference():
 
 @pytest.mark.parametrize("fixture,cfg_kw", [("gradients_64_64", {}), ("gradients_viewdirs_64_64", dict(use_viewdirs=True)),
                                             ("gradients_exact_viewdirs_64_64", dict(use_viewdirs=True, approx_nonrigid_viewdirs=False)),
-                                            ("gradients_time_conditioned_64_64", dict(ray_bending=False, time_conditioned_baseline=True))],
-                         ids=["default", "viewdirs", "exact_viewdirs", "time_conditioned"])
+                                            ("gradients_time_conditioned_64_64", dict(ray_bending=False, time_conditioned_baseline=True)),
+                                            ("gradients_generic_192_320_64_64", dict(netdepth=6, netwidth=192, netwidth_fine=320, multires=8, skips=(2,)))],
+                         ids=["default", "viewdirs", "exact_viewdirs", "time_conditioned", "generic_192_320"])
 def test_oracle_gradients_match_reference_autograd(fixture, cfg_kw):
     """Groundwork for the backward pass: the oracle is differentiable torch code, and its
     gradients of sum(rgb_map) + sum(rgb0) wrt a few parameters and the latent codes equal what the reference's own
