@@ -656,7 +656,12 @@ typedef struct nrnerf_generic_trunk_args {
     float* d_encv;              /* backward out, view-dependent head: [N*S][3 + 6 multires_views] gradient of the direction encoding */
     const float* latents;       /* forward in, time-conditioned baseline (no bender): [N][latent size] one code per ray; d_enc0 / d_enc1 then
                                  * have 3 + 6 multires + latent size columns, the code's gradient (per sample) in the last ones */
+    void* relu_bits;            /* ABI 8, optional: nrnerf_generic_trunk_bits_bytes() bytes of device memory.  Forward writes which activations
+                                 * passed the relu (one byte per lane and tile pair of the 16x16x32 kernels); a backward call that is handed
+                                 * them runs on those kernels' dataflow (csrc/nrnerf_gx16_bwd.h) instead of the run-time-parameterised one
+                                 * (bf16, plain head: 0 bytes = not available for this handle, pass NULL) */
 } nrnerf_generic_trunk_args;
+size_t nrnerf_generic_trunk_bits_bytes(const nrnerf_model* model, int32_t which, int32_t n_rays, int32_t n_samples);
 int nrnerf_generic_trunk_forward(const nrnerf_model* model, const nrnerf_generic_trunk_args* args, void* hip_stream);
 int nrnerf_generic_trunk_backward(const nrnerf_model* model, const nrnerf_generic_trunk_args* args, void* hip_stream);
 int nrnerf_model_trains_generic(const nrnerf_model* model);

@@ -141,7 +141,7 @@ class GenericTrunkArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("which", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("pts4", C.c_void_p), ("acts", C.c_void_p), ("raw4", C.c_void_p), ("raw", C.c_void_p), ("raw_ch", C.c_int32),
                 ("d_raw4", C.c_void_p), ("d_pre", C.c_void_p), ("d_enc0", C.c_void_p), ("d_enc1", C.c_void_p),
-                ("dirs", C.c_void_p), ("d_encv", C.c_void_p), ("latents", C.c_void_p)]
+                ("dirs", C.c_void_p), ("d_encv", C.c_void_p), ("latents", C.c_void_p), ("relu_bits", C.c_void_p)]
 
 
 class LossArgs(C.Structure):
@@ -303,6 +303,7 @@ EXPORTS = {
     "nrnerf_generic_trunk_forward": (C.c_int, [C.c_void_p, C.POINTER(GenericTrunkArgs), C.c_void_p]),
     "nrnerf_generic_trunk_backward": (C.c_int, [C.c_void_p, C.POINTER(GenericTrunkArgs), C.c_void_p]),
     "nrnerf_model_trains_generic": (C.c_int, [C.c_void_p]),
+    "nrnerf_generic_trunk_bits_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_model_trains_bender": (C.c_int, [C.c_void_p]),
     "nrnerf_loss_forward": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "nrnerf_loss_backward": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),

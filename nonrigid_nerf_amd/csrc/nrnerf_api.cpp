@@ -26,6 +26,7 @@
 #include "nrnerf_loss.h"
 #include "nrnerf_optim.h"
 #include "nrnerf_gen_train.h"
+#include "nrnerf_gx16_bwd_api.h"
 #include "nrnerf_gx16_plan.h"
 #include "nrnerf_plan.h"
 
@@ -1014,6 +1015,8 @@ struct nrnerf_model {
     struct GenTrainNet { int W = 0, D = 0, dv = 0, draw_col = 0, in_w = 0, lat = 0; bool skip = false, views = false; } gen_tn[2];     // [coarse, fine]
     bool gen_fine_is_coarse = false;
     int64_t flat_floats = 0;      // length of the flat parameter vector nrnerf_model_update_device expects
+    PassDev gx_coarse_bwd, gx_fine_bwd;          // backward-data programs of the width-class trunks (nrnerf_gx16_bwd.h), when gx16_trainable
+    GxMeta gx_meta_coarse_bwd, gx_meta_fine_bwd;
     unsigned* adam_barrier = nullptr;   // two words of device memory: the grid barrier of nrnerf_adam_step (nrnerf_optim.hip)
     // profiling (guarded; the render path itself is otherwise read-only on the handle)
     mutable std::mutex prof_mu;
@@ -1284,6 +1287,91 @@ void pack_gx16(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPas
     meta.wc = wc; meta.depth = D; meta.skip = skip; meta.L = L; meta.n_bias_tiles = tiles; meta.views = views ? 1 : 0; meta.LV = d.multires_views;
 }
 
+// The backward-data program of the same trunk (nrnerf_gx16_bwd.h; plain head, bf16): output_linear^T, pts_linears[D-1 .. 1]^T, pts_linears[0]^T,
+// every fragment element (tile t, row r, k-slot (s, g, e)) = W[k feature][column of output row] -- the k feature of a hidden k-step is
+// x16_hidden_feature(s, g, e) (the operand order d z is handed on in), of the d raw k-step the channel 8 g + e < 4; an output row is a hidden
+// feature 16 t + r, or -- the four tiles in front of them in the two layers that read the encoding -- the encoding's slot position.
+// No biases (the table is zeros).  Same stream conventions as pack_gx16.
+void pack_gx16_bwd(const nrnerf_model_desc& d, const nrnerf_mlp_desc& mlp, PackedPass& out, GxMeta& meta, const FlatLayout* lay = nullptr) {
+    using SH = Shape16Fast;
+    const int wc = gx_width_class(mlp.width), D = mlp.depth, skip = gen_skip(mlp), L = d.multires, enc = 3 + 6 * L, W = mlp.width;
+    std::vector<int> kinds, layer_of;
+    kinds.push_back(GX_BHEAD); layer_of.push_back(-1);
+    for (int i = D - 1; i >= 1; --i) { kinds.push_back((i - 1 == skip) ? GX_BSKIP : GX_BHID); layer_of.push_back(i); }
+    kinds.push_back(GX_BIN); layer_of.push_back(0);
+    int units = 0, tiles = 0, mfma = 0;
+    for (int k : kinds) { units += gx_layer_units(wc, k); tiles += gx_layer_tiles(wc, k); }
+    constexpr int TAIL = RING - NRN_RING_LAG_HOST;
+    out.ntiles = tiles; out.nunits = units + TAIL;
+    out.frag_bytes = SH::FRAG_BYTES; out.slot_bytes = SH::UNIT_BYTES;
+    out.stream.assign((size_t)(units + TAIL) * SH::UNIT_BYTES, 0);
+    out.unit_off.assign(units + TAIL + 1, 0);
+    for (int u = 0; u <= units + TAIL; ++u) out.unit_off[u] = (uint32_t)((size_t)u * SH::UNIT_BYTES / 16);
+    out.bias.assign((size_t)tiles * 16, 0.0f);
+    if (lay) {
+        out.src.assign(out.stream.size() / 2, -1);
+        out.fmt.assign(out.stream.size() / 2, 1);
+        out.bias_src.assign(out.bias.size(), -1);
+    }
+    size_t unit0 = 0;
+    for (size_t li = 0; li < kinds.size(); ++li) {
+        const int kind = kinds[li];
+        const Tables T = build_tables_gx(wc, kind);
+        const LayerSpec& sp = T.layers[0];
+        const nrnerf_linear* lin = (kind == GX_BHEAD) ? &mlp.output_linear : &mlp.pts_linears[layer_of[li]];
+        const int64_t wbase = lay ? lay->of(lin->weight) : -1;
+        const int enc_tiles = (kind == GX_BSKIP || kind == GX_BIN) ? 4 : 0;
+        for (int t = 0; t < sp.nt; ++t) {
+            const TileInfo& ti = T.tiles[t];
+            // the column of the layer's weight this output row is the gradient of (-1: none)
+            auto col_of = [&](int r) {
+                if (t < enc_tiles) return gx_enc_col_of_pos(L, 16 * t + r);
+                const int f = 16 * (t - enc_tiles) + r;
+                if (f >= W) return -1;
+                return kind == GX_BSKIP ? enc + f : f;
+            };
+            for (int s = 0; s < sp.ns; ++s) {
+                const size_t fi = unit0 * SH::UNIT_FRAGS + (size_t)ti.gbase + (size_t)s * ti.gstride;
+                uint8_t* fr = out.stream.data() + fi * SH::FRAG_BYTES;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 15, g = lane >> 4;
+                    const int col = (kind == GX_BIN && t >= enc_tiles) ? -1 : col_of(r);
+                    for (int e = 0; e < 8; ++e) {
+                        int row;                     // the weight's ROW = the k feature
+                        if (kind == GX_BHEAD) row = (g == 0 && e < 4) ? e : -1;
+                        else { const int c = x16_hidden_feature(s, g, e); row = c < W ? c : -1; }
+                        if (row >= lin->out_features) row = -1;
+                        const bool live = row >= 0 && col >= 0 && col < lin->in_features;
+                        const float w = live ? lin->weight[(size_t)row * lin->in_features + col] : 0.0f;
+                        const size_t el = fi * (SH::FRAG_BYTES / 2) + (size_t)lane * 8 + e;
+                        if (lay) {
+                            out.src[el] = (live && wbase >= 0) ? (int32_t)(wbase + (int64_t)row * lin->in_features + col) : -1;
+                            out.fmt[el] = 1;
+                        }
+                        const uint16_t q = f32_to_bf16(w);
+                        std::memcpy(fr + (lane * 8 + e) * 2, &q, 2);
+                    }
+                }
+            }
+        }
+        mfma += sp.ns * sp.nt;
+        unit0 += gx_layer_units(wc, kind);
+    }
+    std::memcpy(out.stream.data() + (size_t)units * SH::UNIT_BYTES, out.stream.data(), (size_t)TAIL * SH::UNIT_BYTES);
+    if (lay) {
+        const size_t n = (size_t)TAIL * SH::UNIT_BYTES / 2, o = (size_t)units * SH::UNIT_BYTES / 2;
+        std::copy(out.src.begin(), out.src.begin() + n, out.src.begin() + o);
+        std::copy(out.fmt.begin(), out.fmt.begin() + n, out.fmt.begin() + o);
+    }
+    out.mfma_per_block = mfma;
+    meta.wc = wc; meta.depth = D; meta.skip = skip; meta.L = L; meta.n_bias_tiles = tiles; meta.views = 0; meta.LV = 0;
+}
+// which trunks the x16 training kernels take (forward with saves: gx16_kernel<.., SAVE>; backward-data: gx16_bwd_kernel): bf16, plain head, no
+// latent input columns, width % 4 == 0 (rows of whole 8-byte pieces)
+bool gx16_trainable(const nrnerf_model_desc& d, const nrnerf_mlp_desc& m) {
+    return d.precision == NRNERF_PREC_BF16 && gx16_eligible(d, m) && !m.use_viewdirs && !m.time_conditioned && m.width % 4 == 0;
+}
+
 // ---- models of an architecture outside the compiled set (nrnerf_generic.h)
 int gen_pack_all(const nrnerf_model_desc& d, const FlatLayout* lay, GenProgram& gb, GenProgram& gc, GenProgram& gf) {
     // exact Jacobian view directions (rnh:358-385) off the compiled set: the tangent J d comes from the bender's compiled divergence kernel
@@ -1430,8 +1518,9 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
     }
     m->exact = d.exact_viewdirs != 0 && m->has_bend && m->views;
     if (m->exact && !(m->bend_train_ok && m->gen_train_ok)) return NRNERF_ERR_UNSUPPORTED;      // (needs bend_div_fwd and the per-sample-direction instantiation)
-    // with a bender (the passes then run on ready-made points) and a plain head: the trunks also for the width-class x16 kernel
-    if (d.bender && gx16_eligible(d, *d.coarse) && (!d.fine || gx16_eligible(d, *d.fine))) {
+    // the trunks also for the width-class x16 kernel: rendering passes that run on ready-made points (a bender in front), and the training
+    // forward of any such trunk (its points are always handed in)
+    if (gx16_eligible(d, *d.coarse) && (!d.fine || gx16_eligible(d, *d.fine))) {
         PackedPass pgc, pgf;
         pack_gx16(d, *d.coarse, pgc, m->gx_meta_coarse, &lay);
         rc = upload_pass(pgc, m->gx_coarse);
@@ -1446,6 +1535,18 @@ int create_generic(const nrnerf_model_desc& d, const FlatLayout& lay, nrnerf_mod
             m->gx_fine.algo_flops_per_sample = m->gen_fine.algo_flops_per_sample;
             m->gx_fine.mfma_flops_per_sample = pgf.mfma_per_block * (2.0 * 16 * 16 * 32) / 16.0;
             m->gx_fine.output_ch = d.fine->output_ch;
+        }
+        // ... and their backward-data programs (training: nrnerf_generic_trunk_backward on gx16_bwd_kernel)
+        if (m->gen_train_ok && gx16_trainable(d, *d.coarse) && (!d.fine || gx16_trainable(d, *d.fine))) {
+            PackedPass pbc, pbf;
+            pack_gx16_bwd(d, *d.coarse, pbc, m->gx_meta_coarse_bwd, &lay);
+            rc = upload_pass(pbc, m->gx_coarse_bwd);
+            if (rc != NRNERF_OK) return rc;
+            if (d.fine) {
+                pack_gx16_bwd(d, *d.fine, pbf, m->gx_meta_fine_bwd, &lay);
+                rc = upload_pass(pbf, m->gx_fine_bwd);
+                if (rc != NRNERF_OK) return rc;
+            }
         }
     }
     own.m = nullptr;
@@ -1505,6 +1606,16 @@ int update_generic(nrnerf_model* m, const nrnerf_model_desc& d, hipStream_t stre
         if (rc == NRNERF_OK && d.fine && m->gx_fine.stream) {
             pack_gx16(d, *d.fine, pgf, mf);
             rc = refresh_pass(pgf, m->gx_fine, stream);
+        }
+    }
+    PackedPass pbc, pbf;
+    if (rc == NRNERF_OK && m->gx_coarse_bwd.stream) {
+        GxMeta mc, mf;
+        pack_gx16_bwd(d, *d.coarse, pbc, mc);
+        rc = refresh_pass(pbc, m->gx_coarse_bwd, stream);
+        if (rc == NRNERF_OK && d.fine && m->gx_fine_bwd.stream) {
+            pack_gx16_bwd(d, *d.fine, pbf, mf);
+            rc = refresh_pass(pbf, m->gx_fine_bwd, stream);
         }
     }
     if (hipStreamSynchronize(stream) != hipSuccess && rc == NRNERF_OK) rc = NRNERF_ERR_HIP;      // the packed host images die with this call
@@ -1805,7 +1916,7 @@ template <class EMIT>
 int repack_batches(nrnerf_model* m, const float* flat_params, EMIT&& emit) {
     PassDev* passes[] = {&m->coarse, m->fine_is_coarse ? nullptr : &m->fine, &m->fine_trunk, &m->coarse_trunk, &m->bend_only, &m->fine_trunk_x16, &m->coarse_trunk_x16, &m->bend_x16,
                          &m->coarse_bwd, &m->fine_bwd, &m->bend_train_fwd, &m->bend_train_bwd, &m->coarse_train, &m->fine_train,
-                         &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine, &m->gx_coarse, &m->gx_fine, &m->gen_coarse_bwd, &m->gen_fine_bwd};
+                         &m->gen_bend, &m->gen_coarse, m->gen_fine_is_coarse ? nullptr : &m->gen_fine, &m->gx_coarse, &m->gx_fine, &m->gen_coarse_bwd, &m->gen_fine_bwd, &m->gx_coarse_bwd, &m->gx_fine_bwd};
     for (PassDev* p : passes)
         if (p && p->stream && !p->src) return NRNERF_ERR_UNSUPPORTED;          // (before anything is launched)
     RepackBatchArgs b{};
@@ -1977,6 +2088,8 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     free_pass(m->bend_x16);
     free_pass(m->gx_coarse);
     free_pass(m->gx_fine);
+    free_pass(m->gx_coarse_bwd);
+    free_pass(m->gx_fine_bwd);
     free_pass(m->gen_coarse_bwd);
     free_pass(m->gen_fine_bwd);
     free_pass(m->coarse_trunk);
@@ -2473,6 +2586,19 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
     g.n_rays = a->n_rays; g.S = a->n_samples;
     g.save_stride = M * tn.W; g.save_w = tn.W;
     if (!backward) {
+        // the forward pass on the width-class 16x16x32 kernel (nrnerf_gx16.h, SAVE: activations written from the registers) when it has this
+        // trunk: bf16, plain head, no latent input columns; 0.55 of the matrix pipe's peak instead of the run-time-parameterised kernel's 0.07
+        const PassDev& gx = (fine ? m->gx_fine : m->gx_coarse);
+        const GxMeta& gm = (fine ? m->gx_meta_fine : m->gx_meta_coarse);
+        if (gx.stream && m->precision == NRNERF_PREC_BF16 && !tn.views && tn.lat == 0 && tn.W % 4 == 0 && M < (1ll << 32) &&
+            (long long)a->n_rays * ((a->n_samples + 15) / 16) < (1ll << 31)) {
+            GxArgs x{};
+            x.pts4 = a->pts4; x.raw4 = a->raw4; x.raw_out = a->raw; x.raw_ch = a->raw ? a->raw_ch : 4;
+            x.n_rays = a->n_rays; x.S = a->n_samples; x.wstream = gx.stream; x.bias = gx.bias;
+            x.depth = gm.depth; x.skip = gm.skip; x.L = gm.L; x.n_bias_tiles = gm.n_bias_tiles; x.LV = gm.LV;
+            x.save = a->acts; x.save_stride = M * tn.W; x.save_w = tn.W; x.relu_bits = a->relu_bits;
+            return launch_gx16(m->precision, gm.wc, false, x, m->num_cus, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+        }
         g.mode = 1;
         g.rays = a->pts4; g.ray_stride = 0;                                              // (points are handed in: the ray record is never read)
         g.latents = tn.lat > 0 ? a->latents : nullptr; g.lat_stride = tn.lat;
@@ -2480,6 +2606,17 @@ int generic_trunk_call(const nrnerf_model* m, const nrnerf_generic_trunk_args* a
         g.raw4 = a->raw4; g.raw_out = a->raw; g.raw_ch = a->raw ? a->raw_ch : 4; g.bent4 = nullptr;
         g.save = a->acts; g.mask = nullptr;
     } else {
+        // backward-data on the width-class kernel's dataflow (nrnerf_gx16_bwd.h) when the forward call left its relu bits
+        const PassDev& gxb = (fine ? m->gx_fine_bwd : m->gx_coarse_bwd);
+        const GxMeta& gmb = (fine ? m->gx_meta_fine_bwd : m->gx_meta_coarse_bwd);
+        if (gxb.stream && a->relu_bits && !tn.views && tn.lat == 0 && M < (1ll << 32) && (long long)a->n_rays * ((a->n_samples + 15) / 16) < (1ll << 31)) {
+            GxBwdArgs b{};
+            b.d_raw4 = a->d_raw4; b.relu_bits = a->relu_bits; b.d_pre = a->d_pre; b.save_stride = M * tn.W; b.save_w = tn.W;
+            b.d_enc0 = a->d_enc0; b.d_enc1 = a->d_enc1; b.enc_w = tn.in_w;
+            b.n_rays = a->n_rays; b.S = a->n_samples; b.wstream = gxb.stream; b.bias = gxb.bias;
+            b.depth = gmb.depth; b.skip = gmb.skip; b.L = gmb.L; b.n_bias_tiles = gmb.n_bias_tiles;
+            return launch_gx16_bwd(gmb.wc, b, m->num_cus, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+        }
         g.mode = 2;
         g.rays = a->d_raw4; g.ray_stride = 0;
         g.draw = a->d_raw4; g.draw_ch = 4; g.draw_col = tn.draw_col;
@@ -2510,6 +2647,14 @@ int loss_call(const nrnerf_loss_args* a, bool backward, void* hip_stream) {
 int nrnerf_generic_trunk_forward(const nrnerf_model* m, const nrnerf_generic_trunk_args* a, void* hip_stream) try { return generic_trunk_call(m, a, false, hip_stream); } NRN_CATCH
 int nrnerf_generic_trunk_backward(const nrnerf_model* m, const nrnerf_generic_trunk_args* a, void* hip_stream) try { return generic_trunk_call(m, a, true, hip_stream); } NRN_CATCH
 int nrnerf_model_trains_generic(const nrnerf_model* m) { return m ? ((m->generic && m->gen_train_ok) ? 1 : 0) : NRNERF_ERR_INVALID; }
+size_t nrnerf_generic_trunk_bits_bytes(const nrnerf_model* m, int32_t which, int32_t n_rays, int32_t n_samples) {
+    if (!m || !m->generic || which < 0 || which > 1 || n_rays < 1 || n_samples < 1) return 0;
+    const bool fine = which == 1 && !m->gen_fine_is_coarse;
+    const PassDev& gxb = fine ? m->gx_fine_bwd : m->gx_coarse_bwd;
+    const GxMeta& gmb = fine ? m->gx_meta_fine_bwd : m->gx_meta_coarse_bwd;
+    if (!gxb.stream) return 0;
+    return (size_t)gmb.depth * (size_t)n_rays * (size_t)((n_samples + 15) / 16) * 64 * (size_t)gx16_bits_bytes_per_lane(gmb.wc);
+}
 int nrnerf_loss_forward(const nrnerf_loss_args* a, void* hip_stream) try { return loss_call(a, false, hip_stream); } NRN_CATCH
 int nrnerf_loss_backward(const nrnerf_loss_args* a, void* hip_stream) try { return loss_call(a, true, hip_stream); } NRN_CATCH
 

@@ -76,8 +76,13 @@ struct WRingRT {
 // stage and composites them after the group's last iteration (composite_ray: the composite kernel's own code, same bits); the pass' raw
 // array never reaches HBM and the composite launch goes.  Passes of up to 256 samples (a lane owns 1..4 of them: one code block per
 // case behind a switch -- this kernel is not the one whose last per cent is counted).
-template <class P, int WC, int NB, bool VIEWS, bool FUSE = false>
+// SAVE (training forward of a non-compiled trunk, nrnerf_generic_trunk_forward; plain head): every hidden activation h_i = relu(W_i x_i + b_i)
+// is also written to GxArgs::save as [layer][sample][save_w] rows in the model's 16-bit type -- what nrnerf_generic_trunk_backward masks with
+// and nrnerf_tn_products contracts over -- straight from the registers: a lane holds features 32 p + 4 g .. + 3 and 32 p + 16 + 4 g .. + 3 of
+// its sample, so the four lanes of a sample write 64 contiguous bytes per tile pair (two 8-byte stores each).
+template <class P, int WC, int NB, bool VIEWS, bool FUSE = false, bool SAVE = false>
 __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
+    static_assert(!SAVE || (!VIEWS && !FUSE), "saved activations: the plain head, raw outputs to memory");
     constexpr int WAVES = 4;
     using PE = PolF16;                                                // the encoding's operands are f16 in both modes
     using frag = typename P::frag;
@@ -128,6 +133,7 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
     for (long long b0 = (long long)blockIdx.x * per_wg; FUSE ? (grp < ngroups) : (b0 < nblocks); b0 += (long long)gridDim.x * per_wg) {
         unsigned so[NB];
         bool ok[NB];
+        long long blkid[NB];        // (SAVE) the block's index among all 16-sample blocks, -1: none
         efrag enc[NB][NS_E];
         efrag encv[NB][1];
         static_for<0, NB>([&](auto bc) {
@@ -146,6 +152,7 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
                 const long long blk = blk_ok ? blk_raw : nblocks - 1;
                 ray = (int)(blk / bpr); bir = (int)(blk % bpr);
             }
+            blkid[b] = blk_ok ? (long long)ray * bpr + bir : -1;
             const int sidx = bir * 16 + n;
             ok[b] = blk_ok && sidx < S;
             so[b] = (unsigned)ray * (unsigned)S + (unsigned)(sidx < S ? sidx : S - 1);
@@ -198,14 +205,59 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
 
         frag ha[NB][NS_H], hb[NB][NS_H];
         frag none[NB][1];
+        int lsave = 0;              // (SAVE) index of the layer whose activations the epilogue in flight writes
+        constexpr int MW = (NS_H + 3) / 4;
+        unsigned mbits[NB][MW];     // (SAVE) which of the lane's values passed the relu: one byte per tile pair (GxArgs::relu_bits)
+        auto flush_bits = [&]() {
+            if constexpr (SAVE) {
+                if (a.relu_bits) {
+                    static_for<0, NB>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        if (blkid[b] >= 0) {
+                            unsigned* p = (unsigned*)((char*)a.relu_bits + (((size_t)lsave * nblocks + blkid[b]) * 64 + lane) * (size_t)(4 * MW));
+#pragma unroll
+                            for (int w = 0; w < MW; ++w) p[w] = mbits[b][w];
+                        }
+                    });
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) mbits[b][w] = 0u;
+            }
+        };
+        if constexpr (SAVE) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int w = 0; w < MW; ++w) mbits[b][w] = 0u;
+        }
         auto keep = [&](auto& out) {
             return [&](auto pc, auto kc, const f32x4& d0, const f32x4& d1) {
-                out[decltype(kc)::value][decltype(pc)::value] = x16_pack<P>(d0, d1);
+                constexpr int k = decltype(kc)::value, p = decltype(pc)::value;
+                const frag v = x16_pack<P>(d0, d1);
+                out[k][p] = v;
+                if constexpr (SAVE) {
+                    const int col = 32 * p + 4 * g;
+                    if (ok[k] && col < a.save_w) {          // (save_w % 4 == 0: whole 4-feature pieces)
+                        const u32x4 w = __builtin_bit_cast(u32x4, v);
+                        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                        unsigned short* row = (unsigned short*)a.save + ((size_t)lsave * a.save_stride + (size_t)so[k] * a.save_w);
+                        *(u32x2_*)(row + col) = u32x2_{w[0], w[1]};
+                        if (col + 16 < a.save_w) *(u32x2_*)(row + col + 16) = u32x2_{w[2], w[3]};
+                    }
+                    const u32x4 w = __builtin_bit_cast(u32x4, v);
+                    unsigned byte = 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) byte |= ((w[q] & 0xffffu) ? 1u : 0u) << (2 * q) | ((w[q] >> 16) ? 1u : 0u) << (2 * q + 1);
+                    mbits[k][p >> 2] |= byte << (8 * (p & 3));
+                }
             };
         };
         BP bl = bias_lane0;
         asm volatile("" : "+v"(bl));
         dense_x16<PE, P, PIN, 0, NS_E, 0, NB, PF>(st, bl, enc, none, keep(ha));
+        flush_bits();
         st.template end_layer<PIN>();
         bl += NT * 4;                                   // (f32x4 units: 16 floats per tile)
         // the layers two at a time (ha -> hb -> ha: which array holds the activations is then a compile-time fact in every code block;
@@ -213,9 +265,10 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
         f32x4 raw[NB];
         auto take = [&](auto, auto kc, const f32x4& d0, const f32x4&) { raw[decltype(kc)::value] = d0; };
         auto layer = [&](int l, auto& in, auto& out) __attribute__((always_inline)) {
+            lsave = l;
             asm volatile("" : "+v"(bl));
-            if (l - 1 == skip) { dense_x16<PE, P, PSKIP, 0, NS_E, NS_H, NB, PF>(st, bl, enc, in, keep(out)); st.template end_layer<PSKIP>(); }
-            else { dense_x16<P, P, PHID, 0, NS_H, 0, NB, PF>(st, bl, in, none, keep(out)); st.template end_layer<PHID>(); }
+            if (l - 1 == skip) { dense_x16<PE, P, PSKIP, 0, NS_E, NS_H, NB, PF>(st, bl, enc, in, keep(out)); flush_bits(); st.template end_layer<PSKIP>(); }
+            else { dense_x16<P, P, PHID, 0, NS_H, 0, NB, PF>(st, bl, in, none, keep(out)); flush_bits(); st.template end_layer<PHID>(); }
             bl += NT * 4;
         };
         int l = 1;
@@ -294,7 +347,7 @@ __global__ void __launch_bounds__(4 * 64, 1) gx16_kernel(const GxArgs a) {
     st.drain();
 }
 
-template <class P, int WC, bool VIEWS, bool FUSE>
+template <class P, int WC, bool VIEWS, bool FUSE, bool SAVE = false>
 static hipError_t launch_gx16_tf(const GxArgs& a, int num_cus, hipStream_t stream) {
     constexpr int WAVES = 4, NB = (WC > 256) ? 2 : 4;
     if (!a.pts4 || (!a.raw4 && !FUSE) || a.S < 1 || a.depth < 1 || a.L < 0 || a.L > GX_MAX_L) return hipErrorInvalidValue;
@@ -309,7 +362,7 @@ static hipError_t launch_gx16_tf(const GxArgs& a, int num_cus, hipStream_t strea
     if (VIEWS && (a.LV < 0 || a.LV > GX_MAX_LV)) return hipErrorInvalidValue;
     // sample rows are 32-bit numbers in the kernel (so[], the neighbour's row): refuse what would wrap (launch_bend_x16_t does the same)
     if ((long long)a.n_rays * a.S >= (1ll << 32) || (long long)a.n_rays * ((a.S + 15) / 16) >= (1ll << 31)) return hipErrorInvalidValue;
-    auto kern = gx16_kernel<P, WC, NB, VIEWS, FUSE>;
+    auto kern = gx16_kernel<P, WC, NB, VIEWS, FUSE, SAVE>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return hipErrorUnknown;
     const long long bpr = (a.S + 15) / 16;
     long long want = ((long long)a.n_rays * bpr + WAVES * NB - 1) / (WAVES * NB);
@@ -324,6 +377,14 @@ static hipError_t launch_gx16_tf(const GxArgs& a, int num_cus, hipStream_t strea
 }
 template <class P, int WC, bool VIEWS>
 static hipError_t launch_gx16_t(const GxArgs& a, int num_cus, hipStream_t stream) {
+    if (a.save) {
+        if constexpr (!VIEWS && std::is_same_v<P, PolBF16>) {
+            if (a.fuse_on || a.save_w % 4 != 0 || a.save_w < 4 || a.save_w > WC || a.save_stride < (long long)a.n_rays * a.S * a.save_w) return hipErrorInvalidValue;
+            return launch_gx16_tf<P, WC, false, false, true>(a, num_cus, stream);
+        } else {
+            return hipErrorInvalidValue;          // (training runs in bf16; the view-dependent head keeps the run-time-parameterised kernel)
+        }
+    }
     return a.fuse_on ? launch_gx16_tf<P, WC, VIEWS, true>(a, num_cus, stream) : launch_gx16_tf<P, WC, VIEWS, false>(a, num_cus, stream);
 }
 // rays of one fused-compositing group of the width-class kernel (the API layer's "enough rays to fuse" threshold)

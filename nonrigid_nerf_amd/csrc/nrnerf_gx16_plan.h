@@ -24,7 +24,15 @@
 
 namespace nrn {
 
-enum GxKind : int { GX_IN = 0, GX_HID = 1, GX_SKIP = 2, GX_HEAD = 3, GX_VIEWS = 4, GX_RGB = 5 };
+// BACKWARD-DATA of a plain-head trunk on the same dataflow (round 6; training of a non-compiled architecture, gx16_bwd_kernel): the layers in
+// reverse with transposed weights, no biases.  A layer's input is d z (the gradient wrt its pre-activations, WC / 32 k-steps in operand
+// order), its output the gradient wrt its INPUT -- hidden features (WC / 16 tiles), and for the layers that read the encoding four more
+// tiles IN FRONT of them whose 64 rows are the encoding's slot positions (gx_enc_col):
+//   GX_BHEAD k-steps [d raw (1: position 8 g + e = channel, < 4)] -> WC / 16 tiles        output_linear^T
+//   GX_BHID  k-steps [d z (WC / 32)]                           -> WC / 16 tiles           pts_linears[i]^T
+//   GX_BSKIP k-steps [d z (WC / 32)]                           -> 4 + WC / 16 tiles       pts_linears[skip + 1]^T: [encoding | hidden]
+//   GX_BIN   k-steps [d z (WC / 32)]                           -> 4 tiles                 pts_linears[0]^T: the encoding's gradient
+enum GxKind : int { GX_IN = 0, GX_HID = 1, GX_SKIP = 2, GX_HEAD = 3, GX_VIEWS = 4, GX_RGB = 5, GX_BHEAD = 6, GX_BHID = 7, GX_BSKIP = 8, GX_BIN = 9 };
 constexpr int GX_NS_E = 2;                      // encoding k-steps (3 + 6 L + 1 <= 64: L <= 10)
 constexpr int GX_MAX_L = 10;
 
@@ -40,11 +48,16 @@ constexpr NRN_HD int gx_width_class(int W) { return ((W + 63) / 64) * 64; }
 
 constexpr int GX_MAX_LV = 4;                    // direction frequencies (3 + 6 LV + 1 <= 32)
 constexpr int gx_layer_ns(int wc, int kind) {
+    if (kind == GX_BHEAD) return 1;
     return (kind == GX_IN) ? GX_NS_E : (kind == GX_SKIP ? GX_NS_E + wc / 32 : (kind == GX_VIEWS ? 1 + wc / 32 : (kind == GX_RGB ? wc / 64 : wc / 32)));
 }
 constexpr int gx_layer_tiles(int wc, int kind) {
+    if (kind == GX_BSKIP) return 4 + wc / 16;
+    if (kind == GX_BIN) return 4;
     return (kind == GX_HEAD || kind == GX_RGB) ? 1 : (kind == GX_VIEWS ? wc / 32 + 1 : wc / 16);
 }
+// reference column of encoding position p (0 .. 63: the row of a backward encoding tile, the slot of a forward encoding k-step), -1: none
+constexpr NRN_HD int gx_enc_col_of_pos(int L, int p) { return gx_enc_col(L, p / 32, (p % 32) / 8, p % 8); }
 // (a plain constexpr function of (width class, kind): the kernel instantiates it per template argument, the packer calls it at run time)
 constexpr Tables build_tables_gx(int wc, int kind) {
     Tables T{};

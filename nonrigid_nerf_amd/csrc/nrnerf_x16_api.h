@@ -30,7 +30,14 @@ struct GxArgs {
     int LV;                     // (view-dependent head) direction-encoding frequencies
     int fuse_on;                // the pass' compositing as the kernel's epilogue (a FINAL pass of <= 256 samples; raw4 may then be null)
     CompositeArgs fuse;         // its arguments (raw4 unused, n_importance 0)
+    void* save;                 // (training forward, bf16, plain head) [depth][save_stride] rows of save_w 16-bit values: every hidden activation; or null
+    long long save_stride;      // elements between two layers' arrays (>= n_rays * S * save_w)
+    int save_w;                 // the trunk's width (% 4 == 0)
+    void* relu_bits;            // (with save; optional) [depth][n_blocks of 16 samples][64 lanes][4 * ceil(wc / 128)] bytes: which values passed the relu,
+                                // one byte per lane and tile pair -- what the backward-data kernel (nrnerf_gx16_bwd.h) masks with
 };
+// (the backward-data kernel of such a trunk: nrnerf_gx16_bwd.h / nrnerf_gx16_bwd_api.h; bf16 only)
+constexpr int gx16_bits_bytes_per_lane(int wc) { return 4 * ((wc / 32 + 3) / 4); }
 hipError_t launch_gx16(int precision, int wc, bool views, const GxArgs& a, int num_cus, hipStream_t stream);
 long long gx16_rays_per_group(int wc, int S);          // rays of one fused-compositing group of that kernel
 }  // namespace nrn

@@ -411,6 +411,13 @@ class _GenericTrunk(torch.autograd.Function):
         a.which, a.n_rays, a.n_samples = int(which), N, S
         a.pts4, a.acts, a.raw4, a.raw, a.raw_ch = pts4.data_ptr(), acts.data_ptr(), raw4.data_ptr(), raw.data_ptr(), C_out
         saved = [pts4, acts]
+        # (bf16, plain head: the forward also leaves one relu bit per activation, and the backward call that is handed them runs on the
+        #  16x16x32 kernels' dataflow, csrc/nrnerf_gx16_bwd.h)
+        nbits = int(model.lib.nrnerf_generic_trunk_bits_bytes(model.handle, int(which), N, S))
+        bits = torch.empty(nbits, dtype=torch.uint8, device=dev) if nbits > 0 else None
+        if bits is not None:
+            a.relu_bits = bits.data_ptr()
+        ctx.bits = bits
         if views:
             d3 = dirs.detach().to(torch.float32).reshape(M, 3).contiguous()
             a.dirs = d3.data_ptr()
@@ -450,6 +457,8 @@ class _GenericTrunk(torch.autograd.Function):
         a.which, a.n_rays, a.n_samples = ctx.which, N, S
         a.acts, a.d_raw4, a.d_pre, a.d_enc0 = acts.data_ptr(), g.data_ptr(), d_pre.data_ptr(), d_enc[0].data_ptr()
         a.d_enc1 = d_enc[1].data_ptr() if skips else None
+        if ctx.bits is not None:
+            a.relu_bits = ctx.bits.data_ptr()
         if views:
             nv = (int(net.input_ch_views) - 3) // 6
             d_encv = torch.empty(M, 3 + 6 * nv, dtype=torch.float32, device=dev)
