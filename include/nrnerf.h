@@ -455,6 +455,9 @@ typedef struct nrnerf_bender_args {
     void* dz_rigidity;          /* out, shape and element type of acts_rigidity */
     float* dz_out4;             /* out [M,4] gradient wrt the offsets (xyz) and the rigidity logit (w) */
     float* d_latents;           /* out [M, latent_size] gradient wrt each sample's latent inputs */
+    const float* g_bent4_b;     /* [M,4] or NULL: a SECOND gradient wrt the bent point, added to g_bent4 in the kernel -- a training graph
+                                   reads the coarse samples' bent points twice (coarse trunk; rows of the merged samples), and adding the
+                                   two gradients beforehand was three launches */
 } nrnerf_bender_args;
 int nrnerf_bender_forward(const nrnerf_model* model, const nrnerf_bender_args* args, void* hip_stream);
 int nrnerf_bender_backward(const nrnerf_model* model, const nrnerf_bender_args* args, void* hip_stream);
@@ -555,6 +558,11 @@ int nrnerf_merge_rows(const uint8_t* rank_new, int32_t n_rays, int32_t n_samples
 #define NRNERF_REDUCE_SHORT 0x40000000
 int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
                            int64_t n_out, float* out, void* hip_stream);
+/* The same, plus the column sums of a second array in the same launch: out[aux_pos[c]] = sum over r < n_aux of aux[r][c] for c < 4
+ * (aux [n_aux][4] fp32, device; aux_pos: four HOST integers, a negative one skips its channel), records added in a fixed order.  Those
+ * positions must carry index -2 ("written by somebody else": the regular reduction leaves them alone).  For nrnerf_wgrad_args.head_sums. */
+int nrnerf_reduce_partials_aux(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
+                               int64_t n_out, float* out, const float* aux, int32_t n_aux, const int64_t* aux_pos, void* hip_stream);
 
 /* Sums over the sample axis of the bf16 block tiles nrnerf_trunk_forward / _backward write ([block][feature][32 samples]):
  * out[r] = the 32 values of row r added in order in fp32, r < n_rows = blocks * features of the layer(s) handed in.  The
@@ -620,6 +628,9 @@ typedef struct nrnerf_wgrad_args {
     const float* dirs;          /* [M,3] */
     const void* hv; const void* d_pre_v;
     void* encv;                 /* scratch, layout of enc */
+    float* head_sums;           /* out [n_rays * ceil(n_samples / 32)][4] fp32 or NULL (bf16 / f16 handles only; ignored by fp32 ones): the
+                                   sums of d_raw4's four channels over each block of 32 samples -- the head's bias gradient once added up,
+                                   which nrnerf_reduce_partials_aux does in the launch that adds up `partials` */
 } nrnerf_wgrad_args;
 #define NRNERF_WGRAD_STRIDE_VIEWS(depth, width) (NRNERF_WGRAD_STRIDE(depth, width) + ((width) / 2) * (width) + 2 * ((width) / 2) * 64 + (width) / 2)
 #define NRNERF_WGRAD_SHORT_PARTIALS(n_partials, width) \
@@ -698,9 +709,21 @@ typedef struct nrnerf_loss_args {
     float* g_offsets;
     float* g_rigidity;
     float* g_divergence;
+    /* (ABI 8, second half of round 6) the per-sample inputs where they lie: what render_rays hands out as unmasked_offsets / rigidity_mask
+       are the xyz / w parts of [N,S,4] rows */
+    int32_t offsets_stride;     /* floats from one sample's offsets to the next; 0 = 3 (packed).  g_offsets is always packed */
+    int32_t rigidity_stride;    /* ... rigidity value to the next; 0 = 1 */
+    /* the training loop differentiates loss.mean() (train.py:1594): its gradient as the scalar it is, instead of a [N] tensor of g / N */
+    const float* g_mean;        /* backward: in, device scalar or NULL: gradient wrt mean(loss); g_loss may then be NULL (both given: both count) */
 } nrnerf_loss_args;
 int nrnerf_loss_forward(const nrnerf_loss_args* args, void* hip_stream);
 int nrnerf_loss_backward(const nrnerf_loss_args* args, void* hip_stream);
+
+/* Gradient of the per-ray latent codes' selection  latents = codes[index]  (training_wrapper_class.forward, train.py:173-188: the stacked
+ * per-frame codes indexed by each ray's time step):  out[k][c] = sum over the rays r with index[r] == k of g[r][c], added in ray order
+ * (deterministic; autograd's indexing backward sorts, a one-hot GEMM is three launches).  index [n_rays] int64, g [n_rays][latent_size],
+ * out [n_codes][latent_size]; latent_size <= 256.  Runs on the device that owns `out`. */
+int nrnerf_code_gradients(const int64_t* index, const float* g, int32_t n_rays, int32_t latent_size, int32_t n_codes, float* out, void* hip_stream);
 
 /* raw2outputs (train.py:724-789) of one pass, optionally followed by sample_pdf + merge (run_nerf_helpers.py:651-698,
  * train.py:910-920), and its backward.  Runs on the device that owns raw4. */

@@ -150,7 +150,8 @@ class LossArgs(C.Structure):
                 ("weights", C.c_void_p), ("offsets", C.c_void_p), ("rigidity", C.c_void_p), ("alpha", C.c_void_p), ("divergence", C.c_void_p),
                 ("offsets_weight", C.c_float), ("rigidity_weight", C.c_float), ("divergence_weight", C.c_float), ("schedule", C.c_void_p),
                 ("loss", C.c_void_p), ("g_loss", C.c_void_p),
-                ("g_rgb_map", C.c_void_p), ("g_rgb0", C.c_void_p), ("g_offsets", C.c_void_p), ("g_rigidity", C.c_void_p), ("g_divergence", C.c_void_p)]
+                ("g_rgb_map", C.c_void_p), ("g_rgb0", C.c_void_p), ("g_offsets", C.c_void_p), ("g_rigidity", C.c_void_p), ("g_divergence", C.c_void_p),
+                ("offsets_stride", C.c_int32), ("rigidity_stride", C.c_int32), ("g_mean", C.c_void_p)]
 
 
 class Profile(C.Structure):
@@ -182,7 +183,7 @@ class WgradArgs(C.Structure):
                 ("acts", C.c_void_p), ("d_pre", C.c_void_p), ("pts4", C.c_void_p), ("d_raw4", C.c_void_p),
                 ("enc", C.c_void_p), ("g_head", C.c_void_p),
                 ("n_partials", C.c_int32), ("partials", C.c_void_p),
-                ("dirs", C.c_void_p), ("hv", C.c_void_p), ("d_pre_v", C.c_void_p), ("encv", C.c_void_p)]
+                ("dirs", C.c_void_p), ("hv", C.c_void_p), ("d_pre_v", C.c_void_p), ("encv", C.c_void_p), ("head_sums", C.c_void_p)]
 
 
 REDUCE_SHORT = 0x40000000        # NRNERF_REDUCE_SHORT of include/nrnerf.h
@@ -213,7 +214,8 @@ class BenderArgs(C.Structure):
                 ("has_test_time_scaling", C.c_int32), ("test_time_scaling", C.c_float),
                 ("bent4", C.c_void_p), ("off4", C.c_void_p), ("acts_offsets", C.c_void_p), ("acts_rigidity", C.c_void_p),
                 ("g_bent4", C.c_void_p), ("g_unmasked_offsets", C.c_void_p), ("g_rigidity_mask", C.c_void_p),
-                ("dz_offsets", C.c_void_p), ("dz_rigidity", C.c_void_p), ("dz_out4", C.c_void_p), ("d_latents", C.c_void_p)]
+                ("dz_offsets", C.c_void_p), ("dz_rigidity", C.c_void_p), ("dz_out4", C.c_void_p), ("d_latents", C.c_void_p),
+                ("g_bent4_b", C.c_void_p)]
 
 
 class BenderWgradArgs(C.Structure):
@@ -307,6 +309,7 @@ EXPORTS = {
     "nrnerf_model_trains_bender": (C.c_int, [C.c_void_p]),
     "nrnerf_loss_forward": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "nrnerf_loss_backward": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
+    "nrnerf_code_gradients": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "nrnerf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "nrnerf_render": (C.c_int, [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
     "nrnerf_generate_rays": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -314,6 +317,8 @@ EXPORTS = {
     "nrnerf_merge_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_void_p]),
     "nrnerf_reduce_partials": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nrnerf_reduce_partials_aux": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                             C.POINTER(C.c_int64), C.c_void_p]),
     "nrnerf_tile_row_sums": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nrnerf_tiles_to_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "nrnerf_direction_encoding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -2631,16 +2631,18 @@ int loss_call(const nrnerf_loss_args* a, bool backward, void* hip_stream) {
     if (a->divergence && !a->alpha) return NRNERF_ERR_INVALID;
     if ((a->weights || a->divergence) && a->n_samples < 1) return NRNERF_ERR_INVALID;
     if (!backward && !a->loss) return NRNERF_ERR_INVALID;
-    if (backward && (!a->g_loss || !a->g_rgb_map || (a->rgb0 && !a->g_rgb0) || (a->weights && (!a->g_offsets || !a->g_rigidity)) ||
+    if (a->offsets_stride < 0 || a->rigidity_stride < 0 || (a->offsets_stride != 0 && a->offsets_stride < 3)) return NRNERF_ERR_INVALID;
+    if (backward && ((!a->g_loss && !a->g_mean) || !a->g_rgb_map || (a->rgb0 && !a->g_rgb0) || (a->weights && (!a->g_offsets || !a->g_rigidity)) ||
                      (a->divergence && !a->g_divergence))) return NRNERF_ERR_INVALID;
     if (a->n_rays == 0) return NRNERF_OK;
     int dev = 0;
-    if (device_of(backward ? (const void*)a->g_loss : (const void*)a->loss, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    if (device_of(backward ? (const void*)a->g_rgb_map : (const void*)a->loss, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
     DeviceGuard guard(dev);
     if (!guard.ok) return NRNERF_ERR_HIP;
     LossArgs l{a->n_rays, a->n_samples, a->rgb_map, a->rgb0, a->target, a->weights, a->offsets, a->rigidity, a->alpha, a->divergence,
                a->offsets_weight, a->rigidity_weight, a->divergence_weight, a->schedule, a->loss, a->g_loss, a->g_rgb_map, a->g_rgb0, a->g_offsets,
-               a->g_rigidity, a->g_divergence};
+               a->g_rigidity, a->g_divergence, a->offsets_stride ? a->offsets_stride : 3, a->rigidity_stride ? a->rigidity_stride : 1,
+               backward ? a->g_mean : nullptr};
     return launch_loss(l, backward, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 }
 }  // namespace
@@ -2656,6 +2658,16 @@ size_t nrnerf_generic_trunk_bits_bytes(const nrnerf_model* m, int32_t which, int
     return (size_t)gmb.depth * (size_t)n_rays * (size_t)((n_samples + 15) / 16) * 64 * (size_t)gx16_bits_bytes_per_lane(gmb.wc);
 }
 int nrnerf_loss_forward(const nrnerf_loss_args* a, void* hip_stream) try { return loss_call(a, false, hip_stream); } NRN_CATCH
+int nrnerf_code_gradients(const int64_t* index, const float* g, int32_t n_rays, int32_t latent_size, int32_t n_codes, float* out, void* hip_stream) try {
+    if (!index || !g || !out || n_rays < 0 || latent_size < 1 || latent_size > 256 || n_codes < 0) return NRNERF_ERR_INVALID;
+    if (n_codes == 0) return NRNERF_OK;
+    int dev = 0;
+    if (device_of(out, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    CodeGradArgs c{(const long long*)index, g, n_rays, latent_size, n_codes, out};
+    return launch_code_gradients(c, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
 int nrnerf_loss_backward(const nrnerf_loss_args* a, void* hip_stream) try { return loss_call(a, true, hip_stream); } NRN_CATCH
 
 int nrnerf_merge_rows(const uint8_t* rank_new, int32_t n_rays, int32_t n_samples, int32_t n_importance, float* coarse_a, float* coarse_b,
@@ -2671,17 +2683,33 @@ int nrnerf_merge_rows(const uint8_t* rank_new, int32_t n_rays, int32_t n_samples
     return launch_merge_rows(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
 
-int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
-                           int64_t n_out, float* out, void* hip_stream) try {
+namespace {
+int reduce_partials_call(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
+                         int64_t n_out, float* out, const float* aux, int32_t n_aux, const int64_t* aux_pos, void* hip_stream) {
     if (!partials || !index || !out || n_out < 0 || n_partials < 1 || n_short < 0 || n_short > n_partials || record_stride < 1 ||
         record_stride >= NRNERF_REDUCE_SHORT) return NRNERF_ERR_INVALID;
+    if (aux && (n_aux < 0 || !aux_pos)) return NRNERF_ERR_INVALID;
     if (n_out == 0) return NRNERF_OK;
     int dev = 0;
     if (device_of(out, dev) != NRNERF_OK) return NRNERF_ERR_INVALID;
     DeviceGuard guard(dev);
     if (!guard.ok) return NRNERF_ERR_HIP;
-    ReducePartialsArgs a{partials, record_stride, n_partials, n_short, index, n_out, out};
+    ReducePartialsArgs a{partials, record_stride, n_partials, n_short, index, n_out, out, aux, aux ? n_aux : 0, {-1, -1, -1, -1}};
+    if (aux)
+        for (int c = 0; c < 4; ++c) {
+            if (aux_pos[c] >= n_out) return NRNERF_ERR_INVALID;
+            a.aux_pos[c] = aux_pos[c];
+        }
     return launch_reduce_partials(a, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+}
+}  // namespace
+int nrnerf_reduce_partials(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
+                           int64_t n_out, float* out, void* hip_stream) try {
+    return reduce_partials_call(partials, record_stride, n_partials, n_short, index, n_out, out, nullptr, 0, nullptr, hip_stream);
+} NRN_CATCH
+int nrnerf_reduce_partials_aux(const float* partials, int64_t record_stride, int32_t n_partials, int32_t n_short, const int32_t* index,
+                               int64_t n_out, float* out, const float* aux, int32_t n_aux, const int64_t* aux_pos, void* hip_stream) try {
+    return reduce_partials_call(partials, record_stride, n_partials, n_short, index, n_out, out, aux, n_aux, aux_pos, hip_stream);
 } NRN_CATCH
 
 int nrnerf_tile_row_sums(const void* tiles, int64_t n_rows, float* out, void* hip_stream) try {
@@ -2830,7 +2858,7 @@ int nrnerf_trunk_wgrad(const nrnerf_model* m, const nrnerf_wgrad_args* a, void* 
     DeviceGuard guard(m->device);
     if (!guard.ok) return NRNERF_ERR_HIP;
     const hipStream_t s = (hipStream_t)hip_stream;
-    const WgradOperandArgs ops{a->pts4, a->d_raw4, a->n_rays, a->n_samples, ArchDefault::L, a->enc, a->g_head,
+    const WgradOperandArgs ops{a->pts4, a->d_raw4, a->n_rays, a->n_samples, ArchDefault::L, a->enc, a->g_head, f32 ? nullptr : a->head_sums,
                                views ? a->dirs : nullptr, ArchDefault::LV, views ? a->encv : nullptr};
     if ((f32 ? launch_wgrad_operands_f32(ops, s) : launch_wgrad_operands(ops, s)) != hipSuccess) return NRNERF_ERR_HIP;
     const hipError_t e = (m->arch_id == 5) ? (f32 ? launch_trunk_wgrad_f32_a5(w, s) : launch_trunk_wgrad_bf16_a5(w, s))
@@ -2855,7 +2883,7 @@ int bender_common(const nrnerf_model* m, const nrnerf_bender_args* a, bool bwd, 
     t.knobs.has_cutoff = a->has_rigidity_cutoff; t.knobs.cutoff = a->rigidity_cutoff;
     t.knobs.has_scaling = a->has_test_time_scaling; t.knobs.scaling = a->test_time_scaling;
     t.bent4 = a->bent4; t.off4 = a->off4; t.acts_b = a->acts_offsets; t.acts_r = a->acts_rigidity;
-    t.g_bent4 = a->g_bent4; t.g_unmasked = a->g_unmasked_offsets; t.g_mask = a->g_rigidity_mask;
+    t.g_bent4 = a->g_bent4; t.g_bent4_b = a->g_bent4_b; t.g_unmasked = a->g_unmasked_offsets; t.g_mask = a->g_rigidity_mask;
     t.dz_b = a->dz_offsets; t.dz_r = a->dz_rigidity; t.dz_out4 = a->dz_out4; t.d_lat = a->d_latents;
     return NRNERF_OK;
 }

@@ -24,6 +24,10 @@ hipError_t launch_merge_rows(const MergeRowsArgs&, hipStream_t);
 struct ReducePartialsArgs {
     const float* parts; long long stride; int n_partials, n_short;
     const int* index; long long n_out; float* out;
+    // column sums of a second array (one more workgroup): out[aux_pos[c]] = sum over r < n_aux of aux[r][c], c < 4 (aux_pos[c] < 0: skipped);
+    // those positions carry index -2 (left alone by the threads above).  The trunk's head bias gradient from wgrad_operands_kernel's
+    // per-block sums (torch.sum over d raw: a memset and a reduction, 15 us per network and step)
+    const float* aux; int n_aux; long long aux_pos[4];
 };
 constexpr int REDUCE_SHORT_FLAG = 0x40000000;
 constexpr int REDUCE_GROUPS = 8;

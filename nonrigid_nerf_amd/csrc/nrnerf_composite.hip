@@ -269,11 +269,37 @@ hipError_t launch_merge_rows(const MergeRowsArgs& a, hipStream_t stream) {
 // output walking all records was 166 us for the bender's 1024 records of 41600 floats: 40 k threads, 256 dependent rounds.)
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const ReducePartialsArgs a) {
     __shared__ float sh[REDUCE_GROUPS][32];
+    if (a.aux && blockIdx.x == gridDim.x - 1) {
+        // the extra workgroup: thread (slice q, channel c) adds records q, q + 64, ... in order (eight loads in flight), then the 64 slice
+        // sums are added in order
+        __shared__ float part[256];
+        const int c = threadIdx.x & 3, q = threadIdx.x >> 2;
+        float s = 0.0f;
+        int r = q;
+        for (; r + 7 * 64 < a.n_aux; r += 8 * 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.aux[(size_t)(r + 64 * u) * 4 + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = __fadd_rn(s, v[u]);
+        }
+        for (; r < a.n_aux; r += 64) s = __fadd_rn(s, a.aux[(size_t)r * 4 + c]);
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < 4 && a.aux_pos[threadIdx.x] >= 0) {
+            float t = 0.0f;
+            for (int g = 0; g < 64; ++g) t = __fadd_rn(t, part[4 * g + threadIdx.x]);
+            a.out[a.aux_pos[threadIdx.x]] = t;
+        }
+        return;
+    }
     const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
     const long long j = (long long)blockIdx.x * 32 + x;
     float s = 0.0f;
+    bool leave = false;
     if (j < a.n_out) {
         const int ix = a.index[j];
+        leave = ix == -2;
         if (ix >= 0 && (ix & (REDUCE_SHORT_FLAG - 1)) < a.stride) {          // (a position beyond the record reads nothing)
             const int P = (ix & REDUCE_SHORT_FLAG) ? a.n_short : a.n_partials;
             const float* p = a.parts + (ix & (REDUCE_SHORT_FLAG - 1));
@@ -288,7 +314,7 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const ReducePartia
     }
     sh[y][x] = s;
     __syncthreads();
-    if (y == 0 && j < a.n_out) {
+    if (y == 0 && j < a.n_out && !leave) {
         float t = sh[0][x];
 #pragma unroll
         for (int g = 1; g < REDUCE_GROUPS; ++g) t = __fadd_rn(t, sh[g][x]);
@@ -297,7 +323,8 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const ReducePartia
 }
 hipError_t launch_reduce_partials(const ReducePartialsArgs& a, hipStream_t stream) {
     if (a.n_out <= 0 || a.n_partials < 1 || a.n_short < 0 || a.n_short > a.n_partials || a.stride < 1 || a.stride >= REDUCE_SHORT_FLAG) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((a.n_out + 31) / 32)), dim3(256), 0, stream, a);
+    if (a.aux && a.n_aux < 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((a.n_out + 31) / 32) + (a.aux ? 1u : 0u)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

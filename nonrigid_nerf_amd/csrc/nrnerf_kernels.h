@@ -164,6 +164,7 @@ struct BendTrainArgs {
     void* acts_b;            // [BD-1][M][BW] hidden activations of the offset MLP
     void* acts_r;            // [RD-1][M][RW] hidden activations of the rigidity MLP
     const float* g_bent4;    // backward in  [M,4] gradient wrt the bent point (w ignored)
+    const float* g_bent4_b;  // backward in  [M,4] or nullptr: a second one, added to the first
     const float* g_unmasked; // backward in  [M,3] gradient wrt the unmasked offsets, or nullptr
     const float* g_mask;     // backward in  [M]   gradient wrt the rigidity mask, or nullptr
     void* dz_b;              // backward out [BD-1][M][BW] gradient wrt the hidden pre-activations of the offset MLP
@@ -270,6 +271,7 @@ struct WgradOperandArgs {
     int n_rays, S, L;        // L encoding frequencies (3 + 6 L <= 63)
     void* enc;               // out bf16 [nblocks][64][32]
     void* g_head;            // out bf16 [nblocks][64][32]
+    float* head_sums;        // out fp32 [nblocks][4] or nullptr: the sums of d_raw4's four channels over each block's samples (bf16 kernel only)
     // view-dependent head: the encoding of the samples' view directions (reference column order, zero padded to 64) as a third operand
     const float* dirs;       // [M,3] or nullptr
     int LV;

@@ -25,18 +25,19 @@ constexpr int RAYS_PER_WG = 4;
 template <bool BWD>
 __global__ void __launch_bounds__(RAYS_PER_WG * 64) loss_kernel(const LossArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
-    if (ray >= a.n_rays) return;
-    const int S = a.n_samples;
+    const int S = ray < a.n_rays ? a.n_samples : 0;         // (a wave beyond the last ray does nothing, but still counts its workgroup done)
     const float inv_s = S > 0 ? 1.0f / (float)S : 0.0f;
-    const float g = BWD ? a.g_loss[ray] : 0.0f;
+    float g = 0.0f;
+    if (BWD && ray < a.n_rays) g = (a.g_loss ? a.g_loss[ray] : 0.0f) + (a.g_mean ? *a.g_mean / (float)a.n_rays : 0.0f);
+    const int so = a.offsets_stride, sr = a.rigidity_stride;
     const float sched = a.schedule ? *a.schedule : 1.0f;
     const float w_off = a.offsets_weight * sched, w_div = a.divergence_weight * sched;
     float s_off = 0.f, s_rig = 0.f, s_div = 0.f;
     for (int s = lane; s < S; s += 64) {
         const size_t i = (size_t)ray * S + s;
         if (a.weights) {
-            const float w = a.weights[i], rig = a.rigidity[i];
-            const float ox = a.offsets[3 * i], oy = a.offsets[3 * i + 1], oz = a.offsets[3 * i + 2];
+            const float w = a.weights[i], rig = a.rigidity[sr * i];
+            const float ox = a.offsets[so * i], oy = a.offsets[so * i + 1], oz = a.offsets[so * i + 2];
             const float nrm = sqrtf(ox * ox + oy * oy + oz * oz);                     // torch.norm(dim=-1)              :228
             const float e = 2.0f - rig;
             const float pw = powf(nrm, e);                                           // torch.pow(norm, 2 - rigidity)   :229
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) loss_kernel(const LossArgs a
     }
     if (!BWD) {
         s_off = wsum(s_off); s_rig = wsum(s_rig); s_div = wsum(s_div);
-        if (lane == 0) {
+        if (lane == 0 && ray < a.n_rays) {
             float l = 0.f;
             const float* t = a.target + 3 * (size_t)ray;
             for (int k = 0; k < 2; ++k) {
@@ -75,14 +76,48 @@ __global__ void __launch_bounds__(RAYS_PER_WG * 64) loss_kernel(const LossArgs a
             if (a.divergence) l += w_div * (s_div * inv_s);
             a.loss[ray] = l;
         }
-    } else if (lane < 6) {
+    } else if (lane < 6 && ray < a.n_rays) {
         const int k = lane / 3, c = lane % 3;
         const float* m = k == 0 ? a.rgb_map : a.rgb0;
         float* gm = k == 0 ? a.g_rgb_map : a.g_rgb0;
         if (m && gm) gm[3 * (size_t)ray + c] = g * (2.0f / 3.0f) * (m[3 * (size_t)ray + c] - a.target[3 * (size_t)ray + c]);
     }
 }
+// one workgroup per code; thread (slice q, column c): the rays q, q + Q, ... in order, then the Q slices in order.  Four rays per trip: the
+// index loads of a trip are independent (one at a time the loop is a chain of memory latencies: 37 us for 1024 rays)
+constexpr int CG_THREADS = 1024;
+__global__ void __launch_bounds__(CG_THREADS) code_gradients_kernel(const CodeGradArgs a) {
+    __shared__ float part[CG_THREADS];
+    const int k = blockIdx.x, L = a.latent;
+    const int Q = CG_THREADS / L;                           // (L <= 256, checked by the caller)
+    const int c = threadIdx.x % L, q = threadIdx.x / L;
+    float acc = 0.0f;
+    if (q < Q)
+        for (int r0 = q; r0 < a.n_rays; r0 += 4 * Q) {
+            bool hit[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int r = r0 + u * Q; hit[u] = r < a.n_rays && a.index[r < a.n_rays ? r : 0] == (long long)k; }
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = hit[u] ? a.g[(size_t)(r0 + u * Q) * L + c] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (q == 0 && (int)threadIdx.x < L) {
+        float sum = 0.0f;
+        for (int j = 0; j < Q; ++j) sum += part[j * L + c];
+        a.out[(size_t)k * L + c] = sum;
+    }
+}
 }  // namespace
+
+hipError_t launch_code_gradients(const CodeGradArgs& a, hipStream_t stream) {
+    if (a.n_codes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(code_gradients_kernel, dim3(a.n_codes), dim3(CG_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_loss(const LossArgs& a, bool backward, hipStream_t stream) {
     if (a.n_rays <= 0) return hipSuccess;

@@ -107,6 +107,14 @@ __global__ void __launch_bounds__(256) wgrad_operands_kernel(const WgradOperandA
         const f32x4 g = in ? *(const f32x4*)(a.d_raw4 + so * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const float v[6] = {g[0], g[1], g[2], g[3], 0.0f, 0.0f};
         store_rows(gh, 0, v, 4);
+        if (a.head_sums) {          // the head's bias gradient = column sums of d raw: this block's share (fp32, lanes added in a fixed tree)
+            f32x4 sum = g;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) sum[ch] += __shfl_xor(sum[ch], o);
+            if (j == 0) *(f32x4*)(a.head_sums + (size_t)blk * 4) = sum;
+        }
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         for (int o = 64 + 4 * j; o < 64 * 16; o += 128) *(u32x4*)(gh + o) = u32x4{0u, 0u, 0u, 0u};      // rows 4 .. 63
     }

@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(256, 2) bend_bwd(const BendTrainArgs a) {
         const bool ok = sidx < S;
         const size_t so = (size_t)ray * S + (ok ? sidx : S - 1);
         // bent = p + s * mask * off (rnh:567-570): gradients of its three differentiable outputs -> d off, d logit
-        const f32x4 gb = *(const f32x4*)(a.g_bent4 + so * 4);
+        f32x4 gb = *(const f32x4*)(a.g_bent4 + so * 4);
+        if (a.g_bent4_b) gb += *(const f32x4*)(a.g_bent4_b + so * 4);
         const f32x4 bm = *(const f32x4*)(a.bent4 + so * 4);        // .w = mask after the cutoff knob
         const f32x4 ot = *(const f32x4*)(a.off4 + so * 4);         // offsets xyz, tanh(logit)
         const float sc = a.knobs.has_scaling ? a.knobs.scaling : 1.0f;

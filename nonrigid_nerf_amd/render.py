@@ -741,7 +741,8 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
                     ray_batch, network_fn, N_samples, retraw=retraw, perturb=perturb, N_importance=N_importance,
                     network_fine=network_fine, white_bkgd=white_bkgd, raw_noise_std=raw_noise_std,
                     additional_pixel_information=additional_pixel_information, detailed_output=detailed_output,
-                    want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)), lindisp=bool(lindisp))
+                    want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)), lindisp=bool(lindisp),
+                    only_details=dummy_kwargs.get("_only_details"))
             except (Unsupported, _lib.NrnerfError) as e:
                 if isinstance(e, _lib.NrnerfError) and e.status != _lib.ERR_UNSUPPORTED:
                     raise
@@ -794,12 +795,13 @@ def _draw_randoms(ray_batch, N_samples, N_importance, perturb, raw_noise_std):
     if stochastic_z:
         out["u_coarse"] = torch.rand([n, N_samples], device=dev)
     if noisy:
-        out["noise_coarse"] = torch.randn([n, N_samples], device=dev) * raw_noise_std
+        # (normal_(0, std) IS randn * std -- ATen's kernel returns rand * std + mean for the same draws -- in one launch instead of two)
+        out["noise_coarse"] = torch.empty([n, N_samples], device=dev).normal_(0.0, float(raw_noise_std))
     if N_importance > 0:
         if stochastic_z:
             out["u_fine"] = torch.rand([n, N_importance], device=dev)
         if noisy:
-            out["noise_fine"] = torch.randn([n, N_samples + N_importance], device=dev) * raw_noise_std
+            out["noise_fine"] = torch.empty([n, N_samples + N_importance], device=dev).normal_(0.0, float(raw_noise_std))
     return out
 
 

@@ -97,14 +97,21 @@ def _is_f32(model) -> bool:
 _GRAD_INDEX = {}
 
 
-def _reduce_partials(parts: torch.Tensor, n_short: int, index: torch.Tensor) -> torch.Tensor:
+def _reduce_partials(parts: torch.Tensor, n_short: int, index: torch.Tensor, aux=None, aux_pos=None) -> torch.Tensor:
     """Flat fp32 gradient buffer [len(index)] = the records of partial sums `parts` [P, stride] added up and laid out as the
     parameters are (nrnerf_reduce_partials: one launch instead of a sum, zero-fills of the unwritten records and a copy per
-    parameter whose gradient is not a contiguous block of the record)."""
+    parameter whose gradient is not a contiguous block of the record).  ``aux`` [R,4] + ``aux_pos`` (four positions, -1 = none): its
+    column sums go to those positions in the same launch (nrnerf_reduce_partials_aux; `index` must be -2 there)."""
     out = torch.empty(int(index.shape[0]), dtype=torch.float32, device=parts.device)
     with torch.cuda.device(parts.device):
-        _lib.check(_lib.load().nrnerf_reduce_partials(parts.data_ptr(), int(parts.stride(0)), int(parts.shape[0]), int(n_short), index.data_ptr(),
-                                                      int(index.shape[0]), out.data_ptr(), _stream(parts.device)), "nrnerf_reduce_partials")
+        if aux is None:
+            _lib.check(_lib.load().nrnerf_reduce_partials(parts.data_ptr(), int(parts.stride(0)), int(parts.shape[0]), int(n_short), index.data_ptr(),
+                                                          int(index.shape[0]), out.data_ptr(), _stream(parts.device)), "nrnerf_reduce_partials")
+        else:
+            pos = (C.c_int64 * 4)(*[int(x) for x in aux_pos])
+            _lib.check(_lib.load().nrnerf_reduce_partials_aux(parts.data_ptr(), int(parts.stride(0)), int(parts.shape[0]), int(n_short), index.data_ptr(),
+                                                              int(index.shape[0]), out.data_ptr(), aux.data_ptr(), int(aux.shape[0]), pos,
+                                                              _stream(parts.device)), "nrnerf_reduce_partials_aux")
     return out
 
 
@@ -119,16 +126,18 @@ def _split_flat(flat: torch.Tensor, shapes):
     return out
 
 
-def _trunk_grad_index(net, D, W, C_out, views, n_lat, dev):
+def _trunk_grad_index(net, D, W, C_out, views, n_lat, dev, head_sums=False):
     """(index [n] int32 on dev, parameter shapes, offset of the head's bias) for nrnerf_reduce_partials: position in one record
     of nrnerf_trunk_wgrad (include/nrnerf.h) of every element of the trunk's weights and biases in _trunk_params order; -1
     (zero) for what no kernel produces: the latent columns of the time-conditioned baseline's two input layers (their
-    gradient comes through ray_bias), the 5th output channel, and the head's bias (summed from d_raw4 by the caller)."""
+    gradient comes through ray_bias), the 5th output channel, and the head's bias (summed from d_raw4 by the caller) -- or, with
+    ``head_sums``, -2 there: nrnerf_reduce_partials_aux fills the head's bias from nrnerf_wgrad_args.head_sums."""
     import numpy as np
     L = (int(net.input_ch) - 3) // 6
     n_enc = 3 + 6 * L
     skips = tuple(sorted(int(k) for k in net.skips))
-    key = ("trunk", D, W, C_out, bool(views), int(getattr(net, "input_ch_views", 0)) if views else 0, n_enc, n_lat, skips, str(dev))
+    key = ("trunk", D, W, C_out, bool(views), int(getattr(net, "input_ch_views", 0)) if views else 0, n_enc, n_lat, skips, str(dev), bool(head_sums))
+    HB = -2 if head_sums else -1
     if key in _GRAD_INDEX:
         return _GRAD_INDEX[key]
     SH = _lib.REDUCE_SHORT
@@ -149,7 +158,7 @@ def _trunk_grad_index(net, D, W, C_out, views, n_lat, dev):
         segs += [w.reshape(-1), (b | SH) if i == 0 else b]
         shapes += [tuple(w.shape), (W,)]
     if views:                                                  # alpha_linear (1 x W): the sigma channel's column of dw_head^T
-        segs += [((o_o + np.arange(W) * 64 + 3) | SH), np.full(1, -1)]
+        segs += [((o_o + np.arange(W) * 64 + 3) | SH), np.full(1, HB)]
         shapes += [(1, W), (1,)]
         head_bias_at = sum(int(x.shape[0]) for x in segs) - 1
         # the colour branch (_colour_params order): folded views layer's hidden columns [W/2, W] and bias [W/2], its direction
@@ -163,13 +172,13 @@ def _trunk_grad_index(net, D, W, C_out, views, n_lat, dev):
         vrows = np.arange(V, dtype=np.int64)[:, None]
         segs += [(o_f + vrows * W + np.arange(W)[None]).reshape(-1), o_bv + np.arange(V),
                  ((o_d + vrows * 64 + np.arange(n_dir)[None]) | SH).reshape(-1),
-                 ((o_r + np.arange(V)[None] * 64 + np.arange(3)[:, None]) | SH).reshape(-1), np.full(3, -1)]
+                 ((o_r + np.arange(V)[None] * 64 + np.arange(3)[:, None]) | SH).reshape(-1), np.full(3, HB)]
         shapes += [(V, W), (V,), (V, n_dir), (3, V), (3,)]
     else:
         w = np.full((C_out, W), -1, dtype=np.int64)
         for ch in range(min(4, C_out)):
             w[ch] = (o_o + np.arange(W) * 64 + ch) | SH
-        segs += [w.reshape(-1), np.full(C_out, -1)]
+        segs += [w.reshape(-1), np.where(np.arange(C_out) < 4, HB, -1)]
         shapes += [(C_out, W), (C_out,)]
     flat = np.concatenate(segs).astype(np.int32)
     if not views:
@@ -369,13 +378,22 @@ class _Trunk(torch.autograd.Function):
         a.n_rays, a.n_samples, a.n_partials = N, S, kch
         a.acts, a.d_pre, a.pts4, a.d_raw4 = acts.data_ptr(), d_pre.data_ptr(), pts4.data_ptr(), g.data_ptr()
         a.enc, a.g_head, a.partials = scratch[0].data_ptr(), scratch[1].data_ptr(), parts.data_ptr()
+        # the head's bias gradient = column sums of d raw: per-block sums from the call's operand kernel, added up by the reduction below
+        # (bf16 arrays, up to 16384 blocks; otherwise torch.sum -- a memset and a reduction)
+        hs = None if (f32 or nblk > 16384) else torch.empty(nblk, 4, dtype=torch.float32, device=dev)
+        if hs is not None:
+            a.head_sums = hs.data_ptr()
         if views:
             d3, hv, d_pre_v = colour
             a.dirs, a.hv, a.d_pre_v, a.encv = d3.data_ptr(), hv.data_ptr(), d_pre_v.data_ptr(), scratch[2].data_ptr()
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_trunk_wgrad(model.handle, C.byref(a), _stream(dev)), "nrnerf_trunk_wgrad")
         # every weight and bias, each in its own shape, back to back in one buffer: one launch
-        index, shapes, hb = _trunk_grad_index(net, D, W, C_out, views, n_lat, dev)
+        index, shapes, hb = _trunk_grad_index(net, D, W, C_out, views, n_lat, dev, head_sums=hs is not None)
+        if hs is not None:
+            n_flat = int(index.shape[0])
+            pos = (n_flat - 3, n_flat - 2, n_flat - 1, hb) if views else tuple(hb + c if c < C_out else -1 for c in range(4))
+            return _split_flat(_reduce_partials(parts, kl, index, hs, pos), shapes)
         flat = _reduce_partials(parts, kl, index)
         if views:                                              # biases of alpha_linear and rgb_linear: column sums of d raw
             sums = g.sum(0)
@@ -801,16 +819,22 @@ class _Bender(torch.autograd.Function):
         ctx.save_for_backward(rays, lat, z, bent4, off4, acts_b, acts_r)
         ctx.set_materialize_grads(False)
         b = bent4.view(N, S, 4)
-        return b[..., :3], off4.view(N, S, 4)[..., :3], b[..., 3:4]
+        # the bent points twice: a graph that reads them in two places (coarse trunk; rows of the merged samples, _merge_rows) takes one
+        # output for each, so that the two gradients arrive separately and the kernel adds them (autograd's own add of two [.,4]-row
+        # views makes a packed [N,S,3] tensor the kernel cannot take: an add, a zero-fill and a copy per step)
+        return b[..., :3], off4.view(N, S, 4)[..., :3], b[..., 3:4], bent4.view(N, S, 4)[..., :3]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_bent, g_unmasked, g_mask):
+    def backward(ctx, g_bent, g_unmasked, g_mask, g_bent_b=None):
         rays, lat, z, bent4, off4, acts_b, acts_r = ctx.saved_tensors
         model, rb = ctx.model, ctx.rb
         N, S, BD, BW, RD, RW = ctx.dims
         M, dev, LAT = N * S, z.device, int(lat.shape[1])
+        if g_bent is None:
+            g_bent, g_bent_b = g_bent_b, None
         g4 = _rows4(g_bent, M) if g_bent is not None else torch.zeros(M, 4, dtype=torch.float32, device=dev)
+        g4b = _rows4(g_bent_b, M) if g_bent_b is not None else None
         gu = g_unmasked.reshape(M, 3).float().contiguous() if g_unmasked is not None else None
         gm = g_mask.reshape(M).float().contiguous() if g_mask is not None else None
         dz_b, dz_r = torch.empty_like(acts_b), torch.empty_like(acts_r)
@@ -818,6 +842,7 @@ class _Bender(torch.autograd.Function):
         d_lat = torch.empty(M, LAT, dtype=torch.float32, device=dev)
         a = _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r)
         a.g_bent4 = g4.data_ptr()
+        a.g_bent4_b = g4b.data_ptr() if g4b is not None else None
         a.g_unmasked_offsets = gu.data_ptr() if gu is not None else None
         a.g_rigidity_mask = gm.data_ptr() if gm is not None else None
         a.dz_offsets, a.dz_rigidity, a.dz_out4, a.d_latents = dz_b.data_ptr(), dz_r.data_ptr(), dz_out4.data_ptr(), d_lat.data_ptr()
@@ -867,16 +892,22 @@ def _bender_params(rb):
     return ps
 
 
-def bend_native(model, rb, rays, z, latents, details=True):
-    """As `bend`, on the HIP library: rays [N,>=6], z [N,S], latents [N,L] -> bent [N,S,3], dict of [N,S,.] tensors."""
-    bent, unmasked, mask = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)))
+def bend_native(model, rb, rays, z, latents, details=True, masked=True, second=None):
+    """As `bend`, on the HIP library: rays [N,>=6], z [N,S], latents [N,L] -> bent [N,S,3], dict of [N,S,.] tensors (``masked`` False:
+    without masked_offsets, one launch less).  ``second``: a list that receives the second handle on the bent points (_Bender.forward)."""
+    bent, unmasked, mask, bent_b = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)))
+    if second is not None:
+        second.append(bent_b)
     if not details:
         return bent, {}
-    masked = mask * unmasked                                           # rnh:567
-    scaling = getattr(rb, "test_time_scaling", None)
-    if scaling is not None:
-        masked = masked * scaling                                      # rnh:568-569
-    return bent, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
+    bd = dict(unmasked_offsets=unmasked, rigidity_mask=mask)
+    if masked:
+        m = mask * unmasked                                            # rnh:567
+        scaling = getattr(rb, "test_time_scaling", None)
+        if scaling is not None:
+            m = m * scaling                                            # rnh:568-569
+        bd["masked_offsets"] = m
+    return bent, bd
 
 
 # True: the fine pass bends only its N_importance new samples and re-uses the coarse pass' bent points (render_rays_train);
@@ -954,19 +985,24 @@ class _MergeRows(torch.autograd.Function):
                 part(na, 0, 3) if g_bent is not None else None, part(nb, 0, 3), part(na, 3, 4) if g_mask is not None else None, None)
 
 
-def _merge_rows(coarse_parts, new_parts, rank_new, rays, z_merged, scaling, detailed_output):
-    """(points, bent points, bender details) of the merged samples from those of the coarse and of the new samples."""
+def _merge_rows(coarse_parts, new_parts, rank_new, rays, z_merged, scaling, detailed_output, want=lambda key: True):
+    """(points, bent points, bender details) of the merged samples from those of the coarse and of the new samples; of the derived
+    details only those ``want`` asks for."""
     (_, bent_c, bd_c), (_, bent_n, bd_n) = coarse_parts, new_parts
     if not bd_c:                                     # no details asked for: the bent points only
         bent, _, _ = _MergeRows.apply(bent_c, None, None, bent_n, None, None, rank_new)
         return None, bent, {}
     bent, unmasked, mask = _MergeRows.apply(bent_c, bd_c["unmasked_offsets"], bd_c["rigidity_mask"], bent_n, bd_n["unmasked_offsets"],
                                             bd_n["rigidity_mask"], rank_new)
-    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z_merged[:, :, None]                         # train.py:921-923 (no gradient: rays, depths)
-    masked = mask * unmasked                                                                     # rnh:567
-    if scaling is not None:
-        masked = masked * scaling                                                                # rnh:568-569
-    return pts, bent, dict(unmasked_offsets=unmasked, rigidity_mask=mask, masked_offsets=masked)
+    # train.py:921-923 (no gradient: rays, depths)
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z_merged[:, :, None]) if want("fine_initial_input_pts") else None
+    bd = dict(unmasked_offsets=unmasked, rigidity_mask=mask)
+    if want("fine_masked_offsets"):
+        masked = mask * unmasked                                                                 # rnh:567
+        if scaling is not None:
+            masked = masked * scaling                                                            # rnh:568-569
+        bd["masked_offsets"] = masked
+    return pts, bent, bd
 
 
 # True: the ray bender runs on the HIP library (_Bender).  False: as torch ops on the module's parameters (`bend`).
@@ -1143,20 +1179,39 @@ class _FusedLoss(torch.autograd.Function):
     reference detaches them (train.py:223, rnh:65-66)."""
 
     @staticmethod
-    def forward(ctx, rgb_map, rgb0, target, weights, offsets, rigidity, alpha, div, offsets_weight, rigidity_weight, divergence_weight, schedule=None):
+    def forward(ctx, rgb_map, rgb0, target, weights, offsets, rigidity, alpha, div, offsets_weight, rigidity_weight, divergence_weight, schedule=None,
+                want_mean=False):
+        """-> (per-ray loss [N], mean over the rays or None).  The mean (train.py:1594) is torch's reduction of the per-ray losses, but its
+        gradient goes back into the kernel as the scalar it is (``loss.mean()`` under autograd: a division launch making a [N] tensor of g / N).
+        (The mean inside the loss kernel -- last workgroup adds up -- was built and cost 23 us: its device-scope release writes back the
+        dirty L2 lines of the whole die, as in nrnerf_optim.hip.)"""
         lib = _lib.load()
         dev = rgb_map.device
         f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
-        rgb_map_, rgb0_, target_, weights_, offsets_, rigidity_, alpha_, div_ = map(f32, (rgb_map, rgb0, target, weights, offsets, rigidity, alpha, div))
+        rgb_map_, rgb0_, target_, weights_, alpha_, div_ = map(f32, (rgb_map, rgb0, target, weights, alpha, div))
         N = int(rgb_map_.shape[0])
         S = int(weights_.numel() // N) if weights_ is not None else (int(div_.numel() // N) if div_ is not None else 0)
+
+        def rows(t, width):
+            """(tensor, floats from one sample to the next): a [N,S,width] part of wider rows -- what render_rays hands out -- as it lies"""
+            if t is None:
+                return None, 0
+            t = t.detach()
+            if t.dtype == torch.float32 and t.dim() == 3 and int(t.shape[2]) == width and t.stride(2) == 1 and t.stride(1) >= width \
+                    and t.stride(0) == t.stride(1) * int(t.shape[1]):
+                return t, int(t.stride(1))
+            return t.to(torch.float32).contiguous(), width
+        offsets_, o_stride = rows(offsets, 3)
+        rigidity_, r_stride = rows(rigidity if rigidity is None or rigidity.dim() == 3 else rigidity.reshape(N, S, 1), 1)
         loss = torch.empty(N, dtype=torch.float32, device=dev)
+
         a = _lib.LossArgs()
         a.struct_size = C.sizeof(_lib.LossArgs)
         a.n_rays, a.n_samples = N, S
         ptr = lambda t: None if t is None else t.data_ptr()
         a.rgb_map, a.rgb0, a.target = ptr(rgb_map_), ptr(rgb0_), ptr(target_)
         a.weights, a.offsets, a.rigidity, a.alpha, a.divergence = ptr(weights_), ptr(offsets_), ptr(rigidity_), ptr(alpha_), ptr(div_)
+        a.offsets_stride, a.rigidity_stride = o_stride, r_stride
         a.offsets_weight, a.rigidity_weight, a.divergence_weight = float(offsets_weight), float(rigidity_weight), float(divergence_weight)
         # the schedule factor as a device scalar when the caller has it as a tensor (GraphedStep: a graph input)
         sched = None if schedule is None else schedule.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
@@ -1167,36 +1222,44 @@ class _FusedLoss(torch.autograd.Function):
         ctx.sched = sched
         ctx.save_for_backward(*[t for t in (rgb_map_, rgb0_, target_, weights_, offsets_, rigidity_, alpha_, div_) if t is not None])
         ctx.have = [t is not None for t in (rgb_map_, rgb0_, target_, weights_, offsets_, rigidity_, alpha_, div_)]
-        ctx.scal = (N, S, float(offsets_weight), float(rigidity_weight), float(divergence_weight))
+        ctx.scal = (N, S, float(offsets_weight), float(rigidity_weight), float(divergence_weight), o_stride, r_stride)
         ctx.shapes = (None if offsets is None else offsets.shape, None if rigidity is None else rigidity.shape, None if div is None else div.shape)
-        return loss
+        ctx.set_materialize_grads(False)
+        return loss, (loss.mean() if want_mean else None)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_loss):
+    def backward(ctx, g_loss, g_mean=None):
         lib = _lib.load()
         it = iter(ctx.saved_tensors)
         rgb_map, rgb0, target, weights, offsets, rigidity, alpha, div = [next(it) if h else None for h in ctx.have]
-        N, S, ow, rw, dw = ctx.scal
+        N, S, ow, rw, dw, o_stride, r_stride = ctx.scal
         dev = rgb_map.device
-        g_loss = g_loss.to(torch.float32).contiguous()
+        if g_loss is None and g_mean is None:
+            return (None,) * 13
+        g_loss = None if g_loss is None else g_loss.to(torch.float32).contiguous()
+        g_mean = None if g_mean is None else g_mean.to(torch.float32).reshape(1).contiguous()
+        f32d = dict(dtype=torch.float32, device=dev)
         new = lambda t: None if t is None else torch.empty_like(t)
-        g_map, g_0, g_off, g_rig, g_div = new(rgb_map), new(rgb0), new(offsets), new(rigidity), new(div)
+        g_map, g_0, g_div = new(rgb_map), new(rgb0), new(div)
+        g_off = None if offsets is None else torch.empty(N, S, 3, **f32d)        # (packed, whatever the inputs' strides were)
+        g_rig = None if rigidity is None else torch.empty(N, S, 1, **f32d)
         a = _lib.LossArgs()
         a.struct_size = C.sizeof(_lib.LossArgs)
         a.n_rays, a.n_samples = N, S
         ptr = lambda t: None if t is None else t.data_ptr()
         a.rgb_map, a.rgb0, a.target = ptr(rgb_map), ptr(rgb0), ptr(target)
         a.weights, a.offsets, a.rigidity, a.alpha, a.divergence = ptr(weights), ptr(offsets), ptr(rigidity), ptr(alpha), ptr(div)
+        a.offsets_stride, a.rigidity_stride = o_stride, r_stride
         a.offsets_weight, a.rigidity_weight, a.divergence_weight = ow, rw, dw
         a.schedule = ptr(ctx.sched)
-        a.g_loss = g_loss.data_ptr()
+        a.g_loss, a.g_mean = ptr(g_loss), ptr(g_mean)
         a.g_rgb_map, a.g_rgb0, a.g_offsets, a.g_rigidity, a.g_divergence = ptr(g_map), ptr(g_0), ptr(g_off), ptr(g_rig), ptr(g_div)
         with torch.cuda.device(dev):
             _lib.check(lib.nrnerf_loss_backward(C.byref(a), _stream(dev)), "nrnerf_loss_backward")
         so, sr, sd = ctx.shapes
         return (g_map, g_0, None, None, None if g_off is None else g_off.view(so), None if g_rig is None else g_rig.view(sr), None,
-                None if g_div is None else g_div.view(sd), None, None, None, None)
+                None if g_div is None else g_div.view(sd), None, None, None, None, None)
 
 
 FUSED_LOSS = True        # training_loss: the loss terms as nrnerf_loss_forward / _backward (False: eager torch ops, the gradient-parity reference)
@@ -1319,9 +1382,12 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
 
 def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.0, N_importance=0, network_fine=None,
                       white_bkgd=False, raw_noise_std=0.0, additional_pixel_information=None, detailed_output=False,
-                      want_z_vals=False, lindisp=False):
+                      want_z_vals=False, lindisp=False, only_details=None):
     """reference render_rays (train.py:792-980) with autograd: same output dict, attached to the graph of the networks',
-    the bender's and the latent codes' parameters."""
+    the bender's and the latent codes' parameters.  ``only_details`` (not a reference argument; training_loss passes it): the
+    ``detailed_output`` keys the caller is going to read -- the others that cost launches of their own (the sample points, the masked
+    offsets) are then left out of the dict."""
+    want = (lambda key: True) if only_details is None else (lambda key: key in only_details)
     dev = ray_batch.device
     precision = "bf16" if R.get_precision() == "f16" else R.get_precision()
     rb = R._bender_of(network_fn)
@@ -1359,19 +1425,20 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         native = rb is not None and NATIVE_BENDER and model.trains_bender     # (a generic handle: the bender as library GEMMs, ``bend``)
         ns = int(z.shape[1])
         pts, bd = None, {}
+        pre = "" if ns == S else "fine_"
         if for_merge and native:
             if latents is None:
                 raise ValueError("ray_bending_latents are required with a ray bender")
-            bent, unmasked, mask = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)))
+            bent, unmasked, mask, _ = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)))
             return None, bent, (dict(unmasked_offsets=unmasked, rigidity_mask=mask) if detailed_output else {})
-        if detailed_output or not native:
+        if (detailed_output and want(pre + "initial_input_pts")) or not native:
             pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]                    # :871-873 / 921-923
         if rb is None:
             return pts, pts, bd
         if latents is None:
             raise ValueError("ray_bending_latents are required with a ray bender")
         if native:
-            bent, bd = bend_native(model, rb, rays, z, latents, details=detailed_output)
+            bent, bd = bend_native(model, rb, rays, z, latents, details=detailed_output, masked=want(pre + "masked_offsets"), second=second_handle)
         else:
             lat = latents[:, None, :].expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)   # train.py:79-87
             bent, bd = bend(rb, pts.reshape(-1, 3), lat.to(torch.float32))
@@ -1387,7 +1454,8 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         else:
             pts, bent, bd = bent_parts
         if detailed_output:
-            details["initial_input_pts"] = pts                                               # rnh:250-252
+            if pts is not None:
+                details["initial_input_pts"] = pts                                           # rnh:250-252
             details.update(bd)
             details["input_pts"] = bent                                                      # rnh:270
         ray_bias = None
@@ -1425,6 +1493,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         raw4, raw = trunk.apply(bent, model, net, which, ray_bias, dirs, *(_generic_trunk_params(net) if model.generic else _trunk_params(net)))
         return raw4, raw, details
 
+    second_handle = []
     coarse_parts = bend_samples(z_vals)
     raw4, raw, details = query(z_vals, network_fn, 0, coarse_parts)
     noise_c = rnd.get("noise_coarse")
@@ -1442,7 +1511,9 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
             # merged depths (as nrnerf_render's split-bender path).  Same values as bending all S + I points again; the
             # coarse samples' bender evaluation now receives the gradient of both passes in ONE backward call.
             new_parts = bend_samples(z_new, for_merge=True)
-            fine_parts = _merge_rows(coarse_parts, new_parts, rank_new, rays, z_merged, getattr(rb, "test_time_scaling", None), detailed_output)
+            if second_handle:       # the coarse bent points' second output: its gradient reaches the bender's backward on its own (_Bender)
+                coarse_parts = (coarse_parts[0], second_handle[0], coarse_parts[2])
+            fine_parts = _merge_rows(coarse_parts, new_parts, rank_new, rays, z_merged, getattr(rb, "test_time_scaling", None), detailed_output, want)
         raw4, raw, fine_details = query(z_merged, net_f, 1 if network_fine is not None else 0, fine_parts)
         rgb_map, disp_map, acc_map, weights, alpha, _, _, _, _ = _Composite.apply(raw4, rays, z_merged, rnd.get("noise_fine"),
                                                                                   white_bkgd, 0, None)          # :943-950
@@ -1465,8 +1536,12 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
     return ret
 
 
+# detailed_output keys training_loss reads (render_rays_train's ``only_details``)
+_LOSS_DETAILS = frozenset(("initial_input_pts", "unmasked_offsets", "rigidity_mask", "visibility_weights", "opacity_alpha"))
+
+
 def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, offsets_loss_weight=0.0, divergence_loss_weight=0.0,
-                  rigidity_loss_weight=0.0, global_step=0, N_iters=200000, chunk=1024 * 32):
+                  rigidity_loss_weight=0.0, global_step=0, N_iters=200000, chunk=1024 * 32, mean=False):
     """The loss of one training iteration as ``training_wrapper_class.forward`` builds it (train.py:190-287), on the
     drop-in entry points: ``batchify_rays`` (``retraw=True``; ``detailed_output`` when a regulariser is on, train.py:193-196),
     data term on the fine and the coarse image (:207-218), offsets + rigidity regulariser (:221-242) and divergence
@@ -1474,11 +1549,14 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     (the training loop takes ``loss.mean()``, train.py:1594) and the render outputs.  ``render_kwargs`` = the reference's
     ``render_kwargs_train`` (network_fn, network_fine, N_samples, N_importance, perturb, raw_noise_std, ...).  A caller of
     the reference does not need this function -- its own ``training_wrapper_class`` lands on the same entry points through
-    ``install()``; bench.py and the tests use it where the reference is not importable."""
+    ``install()``; bench.py and the tests use it where the reference is not importable.  ``mean=True``: returns the mean over the rays
+    (a scalar: what the training loop differentiates, train.py:1594) instead of the per-ray loss -- from the loss kernel's own launch."""
     N_rays = int(rays_flat.shape[0])
     ray_bender = R._bender_of(render_kwargs["network_fn"])
     detailed_output = offsets_loss_weight > 0.0 or divergence_loss_weight > 0.0                  # :193-196
     kw = {k: v for k, v in render_kwargs.items() if k not in ("retraw", "ray_bender", "near", "far", "ndc", "use_viewdirs")}
+    if detailed_output:      # the detail keys the terms below read (the others that cost launches of their own are not produced)
+        kw["_only_details"] = _LOSS_DETAILS
     extras = R.batchify_rays(rays_flat, {"ray_bending_latents": ray_bending_latents}, chunk=chunk, detailed_output=detailed_output,
                              retraw=True, **kw)
     schedule = (1.0 / 100.0) ** (1 - (global_step / N_iters))                                    # :240, 285
@@ -1496,14 +1574,14 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
         if use_div:
             div_pts.requires_grad = True                                                         # rnh:39
             div = _divergence_values(div_pts, div_lat, ray_bender, False, chunk)
-        loss = _FusedLoss.apply(extras["rgb_map"], extras.get("rgb0"), target_s,
+        loss, loss_mean = _FusedLoss.apply(extras["rgb_map"], extras.get("rgb0"), target_s,
                                 extras["visibility_weights"] if use_off else None, extras["unmasked_offsets"] if use_off else None,
                                 extras["rigidity_mask"] if use_off else None, extras["opacity_alpha"] if use_div else None, div,
                                 *((offsets_loss_weight if use_off else 0.0, rigidity_loss_weight, divergence_loss_weight if use_div else 0.0, schedule)
                                   if torch.is_tensor(schedule) else
                                   (offsets_loss_weight * schedule if use_off else 0.0, rigidity_loss_weight,
-                                   divergence_loss_weight * schedule if use_div else 0.0)))
-        return loss, extras
+                                   divergence_loss_weight * schedule if use_div else 0.0, None)), bool(mean))
+        return (loss_mean if mean else loss), extras
     img2mse = lambda x, y: torch.mean(((x - y) ** 2).view(N_rays, -1), dim=1)                    # rnh:10-13
     loss = img2mse(extras["rgb_map"], target_s)                                                  # :207-212
     if "rgb0" in extras:
@@ -1525,7 +1603,7 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
         divergence_loss = compute_divergence_loss(offsets, initial_input_pts, divergence_latents, ray_bender, exact=False, chunk=chunk,
                                                   N_rays=N_rays, weights=weights, backprop_into_weights=False)
         loss = loss + divergence_loss_weight * schedule * divergence_loss
-    return loss, extras
+    return (loss.mean() if mean else loss), extras
 
 
 class _SelectCodes(torch.autograd.Function):
@@ -1542,6 +1620,14 @@ class _SelectCodes(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (index,) = ctx.saved_tensors
+        if g.is_cuda and g.dtype == torch.float32 and index.dtype == torch.int64 and int(g.shape[1]) <= 256:
+            # one launch, rays added in order (nrnerf_code_gradients); the one-hot GEMM below is a fill, a scatter and a GEMM
+            g = g.contiguous()
+            out = torch.empty(ctx.n, int(g.shape[1]), dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                _lib.check(_lib.load().nrnerf_code_gradients(index.contiguous().data_ptr(), g.data_ptr(), int(g.shape[0]), int(g.shape[1]), ctx.n,
+                                                            out.data_ptr(), _stream(g.device)), "nrnerf_code_gradients")
+            return out, None
         onehot = torch.zeros(ctx.n, int(index.shape[0]), dtype=g.dtype, device=g.device)
         onehot.scatter_(0, index[None, :], 1.0)
         return onehot @ g, None
@@ -1747,13 +1833,16 @@ class GraphedStep:
         # (an optimiser whose step re-packs the handles itself -- FusedAdam(networks=...) -- leaves them fresh at the end of every
         #  step, captured or replayed: no refresh at the start of the step, nothing to mark stale after a replay)
         self.repacks = bool(getattr(optimizer, "repacks_weights", False))
+        self._one = None
 
         def one():
             if not self.repacks:
                 for nf in self.networks:
                     R.mark_stale(nf)                               # the refresh kernels are part of the captured step
             loss = step_fn(**self.static)
-            loss.backward()
+            if self._one is None or self._one.shape != loss.shape:
+                self._one = torch.ones_like(loss)
+            loss.backward(self._one)                               # (a fixed d loss / d loss: backward() fills a fresh one per step)
             optimizer.step()
             return loss
 
@@ -1858,8 +1947,9 @@ def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, reg
     state = {"i": 0}
 
     def loss_of(rays, target, frame, global_step):
-        loss, _ = training_loss(rays, select_codes(codes, frame), target, kw, global_step=global_step, N_iters=rec["N_iters"], chunk=rec["chunk"], **weights)
-        return loss.mean()                                                  # train.py:1594
+        loss, _ = training_loss(rays, select_codes(codes, frame), target, kw, global_step=global_step, N_iters=rec["N_iters"], chunk=rec["chunk"],
+                                mean=True, **weights)                        # train.py:1594: loss.mean()
+        return loss
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -906,6 +906,25 @@ def test_reduce_partials_kernel_vs_sum_and_index():
     want = torch.where(is_short.to(DEV), short[index.long().to(DEV)], full[index.long().to(DEV)])
     want = torch.where(pad.to(DEV), torch.zeros_like(want), want)
     assert torch.equal(got, want)
+    # nrnerf_reduce_partials_aux: the column sums of a second array land at four chosen positions (index -2 there: left alone by the
+    # regular reduction), everything else as above; a skipped channel (-1) keeps what the buffer held; twice the same bits
+    for n_aux in (1, 63, 6144, 16384):
+        aux = torch.randn(n_aux, 4, generator=gen).to(DEV)
+        pos = [17, 6000, -1, 3]
+        coded2 = coded.clone()
+        for p_ in pos:
+            if p_ >= 0:
+                coded2[p_] = -2
+        outs = [training._reduce_partials(parts, n_short, coded2, aux, pos) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][[17, 6000, 3]], outs[1][[17, 6000, 3]])
+        keep = torch.ones(7001, dtype=torch.bool, device=DEV)
+        keep[[17, 6000, 3]] = False
+        assert torch.equal(outs[0][keep], want[keep])
+        ref = aux.double().sum(0)
+        for c, p_ in enumerate(pos):
+            if p_ >= 0:
+                assert abs(float(outs[0][p_]) - float(ref[c])) <= 1e-5 * (float(aux[:, c].abs().sum()) + 1e-20), (n_aux, c)
 
 
 @pytest.mark.gpu
@@ -1247,11 +1266,15 @@ def test_an_optimiser_step_of_any_kind_reaches_the_packed_weights(kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("with_rgb0,with_offsets,with_div,S", [(True, True, True, 64), (False, True, False, 83), (True, False, True, 37), (True, False, False, 64)])
-def test_fused_loss_kernel_vs_torch_autograd(with_rgb0, with_offsets, with_div, S):
+@pytest.mark.parametrize("with_rgb0,with_offsets,with_div,S,rows4,mean", [(True, True, True, 64, True, True), (False, True, False, 83, False, False),
+                                                                          (True, False, True, 37, False, True), (True, False, False, 64, False, False),
+                                                                          (True, True, True, 83, True, False)])
+def test_fused_loss_kernel_vs_torch_autograd(with_rgb0, with_offsets, with_div, S, rows4, mean):
     """nrnerf_loss_forward / _backward (csrc/nrnerf_loss.hip; training._FusedLoss) against the same terms written as the reference writes
     them (train.py:207-287, rnh:10-13, 61-69) under torch.autograd: per-ray loss and every gradient, incl. torch's conventions at the
-    singular points (a zero offset vector: d|x|/dx = 0, d(n^e)/de = 0)."""
+    singular points (a zero offset vector: d|x|/dx = 0, d(n^e)/de = 0).  ``rows4``: offsets and rigidity as the xyz / w parts of [N,S,4] rows
+    (what render_rays hands out; read where they lie).  ``mean``: the mean over the rays from the kernel's own launch and its gradient handed
+    back as a scalar, against loss.mean() -- twice, the counter behind it has to be back at zero."""
     from nonrigid_nerf_amd import training
     g = torch.Generator().manual_seed(S)
     N = 301
@@ -1260,10 +1283,15 @@ def test_fused_loss_kernel_vs_torch_autograd(with_rgb0, with_offsets, with_div, 
     w = torch.rand(N, S, generator=g).to(DEV)
     off = (0.01 * mk(N, S, 3))
     off[::7, ::5] = 0.0                                   # singular points
-    off = off.requires_grad_(True)
     rig = torch.rand(N, S, 1, generator=g).to(DEV)
     rig[::11, ::3] = 1.0
-    rig = rig.requires_grad_(True)
+    if rows4:           # leaves = the [N,S,4] rows; the loss sees two views of them
+        rows_a = torch.cat([off, torch.zeros(N, S, 1, device=DEV)], -1).requires_grad_(True)
+        rows_b = torch.cat([torch.zeros(N, S, 3, device=DEV), rig], -1).requires_grad_(True)
+        off, rig = rows_a[..., :3], rows_b[..., 3:4]
+    else:
+        off = off.requires_grad_(True)
+        rig = rig.requires_grad_(True)
     alpha = 3.0 * mk(N, S)
     div = mk(N * S).requires_grad_(True)
     ow, rw, dw = 60.0 * 0.37, 5e-4, 3.0 * 0.37
@@ -1282,21 +1310,27 @@ def test_fused_loss_kernel_vs_torch_autograd(with_rgb0, with_offsets, with_div, 
         if with_div:
             wd = (1.0 - torch.exp(-torch.relu(alpha.view(-1)))).detach()
             loss = loss + dw * torch.mean((wd * torch.abs(div) ** 2).view(N, -1), dim=-1)
-        return loss
+        return loss, loss.mean()
 
     def fused():
         return training._FusedLoss.apply(rgb_map, rgb0 if with_rgb0 else None, target, w if with_offsets else None, off if with_offsets else None,
                                          rig if with_offsets else None, alpha if with_div else None, div if with_div else None,
-                                         ow if with_offsets else 0.0, rw, dw if with_div else 0.0)
+                                         ow if with_offsets else 0.0, rw, dw if with_div else 0.0, None, mean)
 
-    leaves = [rgb_map, rgb0, off, rig, div]
+    leaves = [rgb_map, rgb0, rows_a if rows4 else off, rows_b if rows4 else rig, div]
     res = {}
-    for name, fn in (("eager", eager), ("fused", fused)):
+    for name, fn in (("eager", eager), ("fused", fused), ("fused again", fused)):
         for t in leaves:
             t.grad = None
-        loss = fn()
-        (loss * upstream).sum().backward()
+        loss, m = fn()
+        if mean:
+            assert m is not None and abs(float(m) - float(loss.mean())) <= 2e-6 * abs(float(loss.mean())), (name, float(m), float(loss.mean()))
+            ((loss * upstream).sum() + 7.0 * m).backward()
+        else:
+            assert name == "eager" or m is None
+            (loss * upstream).sum().backward()
         res[name] = (loss.detach().clone(), [None if t.grad is None else t.grad.clone() for t in leaves])
+    assert torch.equal(res["fused"][0], res["fused again"][0])
     le, lf = res["eager"][0], res["fused"][0]
     assert torch.allclose(le, lf, rtol=2e-5, atol=1e-7), float((le - lf).abs().max())
     for nm, ge, gf in zip(("rgb_map", "rgb0", "offsets", "rigidity", "divergence"), res["eager"][1], res["fused"][1]):
@@ -1306,6 +1340,29 @@ def test_fused_loss_kernel_vs_torch_autograd(with_rgb0, with_offsets, with_div, 
         assert gf is not None and torch.isfinite(gf).all(), nm
         scale = float(ge.abs().max()) + 1e-20
         assert float((ge - gf).abs().max()) <= 2e-5 * scale, (nm, float((ge - gf).abs().max()) / scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rays,n_codes,latent", [(1024, 8, 32), (777, 300, 32), (16384, 3, 64), (5, 4, 7)])
+def test_code_gradients_kernel_vs_indexing_backward(n_rays, n_codes, latent):
+    """nrnerf_code_gradients (training.select_codes' backward: the gradient of ``codes[index]``, train.py:173-188) against autograd's own
+    indexing backward in float64; codes no ray selects get zeros; two calls give the same bits (rays are added in a fixed order)."""
+    from nonrigid_nerf_amd import training
+    g = torch.Generator().manual_seed(n_rays)
+    codes = torch.randn(n_codes, latent, generator=g).to(DEV).requires_grad_(True)
+    index = torch.randint(0, max(1, n_codes - 1), (n_rays,), generator=g).to(DEV)          # (the last code is never selected)
+    up = torch.randn(n_rays, latent, generator=g).to(DEV)
+    got = []
+    for _ in range(2):
+        codes.grad = None
+        (training.select_codes(codes, index) * up).sum().backward()
+        got.append(codes.grad.clone())
+    assert torch.equal(got[0], got[1])
+    ref = torch.zeros(n_codes, latent, dtype=torch.float64, device=DEV).index_add_(0, index, up.double())
+    scale = float(ref.abs().max()) + 1e-20
+    assert float((got[0].double() - ref).abs().max()) <= 2e-6 * scale
+    if n_codes > 1:
+        assert float(got[0][n_codes - 1].abs().max()) == 0.0
 
 
 @pytest.mark.gpu
@@ -1327,13 +1384,13 @@ def test_training_loss_with_the_fused_loss_equals_the_eager_terms():
         try:
             torch.manual_seed(11)
             loss, _ = training.training_loss(rays.to(DEV), lat, target, kw, offsets_loss_weight=60.0, divergence_loss_weight=3.0,
-                                             rigidity_loss_weight=5e-4, global_step=120000, N_iters=200000)
-            loss.mean().backward()
+                                             rigidity_loss_weight=5e-4, global_step=120000, N_iters=200000, mean=fused)
+            (loss if fused else loss.mean()).backward()        # (the fused call: the mean from the loss kernel's own launch)
         finally:
             training.FUSED_LOSS = old
         grads = {k: p.grad.clone() for k, p in _named(rb, coarse, fine).items() if p.grad is not None}
         grads[("latents", "")] = lat.grad.clone()
-        out[fused] = (loss.detach().clone(), grads)
+        out[fused] = ((loss if fused else loss.mean()).detach().clone(), grads)
     assert torch.allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-7)
     assert set(out[True][1]) == set(out[False][1])
     for k, ge in out[False][1].items():
