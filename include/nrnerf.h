@@ -532,6 +532,15 @@ typedef struct nrnerf_divergence_args {
     float* tangent;             /* forward out [M,3] or NULL: d(masked offsets)/d(point) . probe  (divergence = probe . tangent) */
     const float* g_tangent;     /* backward in [M,3] or NULL: gradient wrt `tangent`; when given it is used INSTEAD of
                                    g_divergence (which may then be NULL) */
+    /* backward, all optional (ABI 8, round 6): the gradients a RENDER pass hands to nrnerf_bender_backward for an evaluation of the bender
+       at the SAME points and latent codes (the coarse samples of a training iteration, whose points the divergence term is taken at,
+       train.py:248-262): wrt the bent points (two of them, added), the unmasked offsets, the rigidity mask -- nrnerf_bender_args' g_bent4,
+       g_bent4_b, g_unmasked_offsets, g_rigidity_mask.  Both backward chains are linear in their cotangents, so with these the ONE call
+       yields d_latents and every weight / bias gradient of both uses (no nrnerf_bender_backward / _wgrad for those samples). */
+    const float* render_g_bent4;
+    const float* render_g_bent4_b;
+    const float* render_g_unmasked_offsets;
+    const float* render_g_rigidity_mask;
 } nrnerf_divergence_args;
 int nrnerf_bender_divergence_forward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);
 int nrnerf_bender_divergence_backward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);

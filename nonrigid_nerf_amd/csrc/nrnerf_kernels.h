@@ -234,6 +234,10 @@ struct BendDivArgs {
     const float* rays; int ray_stride;
     const float* zr; int S; int lindisp;
     float* dirs_out;         // [M,3] or nullptr: (J d) / |J d| + 1e-6 with J d = d + tvec's value (rnh:367-378: eps outside the division)
+    // backward: the cotangents of a RENDER pass that evaluated the bender at the same points (BendTrainArgs' g_bent4 / g_bent4_b / g_unmasked /
+    // g_mask), all optional: added to the value chain's, so that one backward pass + one weight-gradient launch serve the divergence term
+    // and the coarse samples' bender evaluation of a training iteration (both chains are linear in their cotangents)
+    const float* r_g_bent4; const float* r_g_bent4_b; const float* r_g_unmasked; const float* r_g_mask;
 };
 hipError_t launch_bend_div_fwd_a0(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);
 hipError_t launch_bend_div_fwd_a1(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);

@@ -494,6 +494,19 @@ __global__ void __launch_bounds__(256, 2) bend_div_bwd(const BendDivArgs a) {
             g_m += gv[c] * tt[c];
             g_tm += gv[c] * ot[c];
         }
+        if (a.r_g_bent4 || a.r_g_unmasked || a.r_g_mask) {
+            // the render pass' cotangents for the same evaluation (bend_bwd's own first lines): bent = p + sc mask off (rnh:567-570)
+            f32x4 gb = a.r_g_bent4 ? *(const f32x4*)(a.r_g_bent4 + so * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (a.r_g_bent4_b) gb += *(const f32x4*)(a.r_g_bent4_b + so * 4);
+            float rm = a.r_g_mask ? a.r_g_mask[so] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float go = gb[c] * mask * sc + (a.r_g_unmasked ? a.r_g_unmasked[so * 3 + c] : 0.0f);
+                g_off[c] += ok ? go : 0.0f;
+                rm += gb[c] * ot[c] * sc;
+            }
+            g_m += ok ? rm : 0.0f;
+        }
         const float g_logit = cut ? 0.0f : g_m * s2 - g_tm * tlogit * th * (1.0f - th * th);
         const float g_tlogit = cut ? 0.0f : g_tm * s2;
         if (ok && h == 0) {

@@ -798,7 +798,11 @@ class _Bender(torch.autograd.Function):
     (run_nerf_helpers.py:507-577) on the HIP library, fp32.  Gradients: latents and the bender's parameters."""
 
     @staticmethod
-    def forward(ctx, latents, model, rb, rays, z, token):
+    def forward(ctx, latents, model, rb, rays, z, token, share=None):
+        """``share`` (a dict, or None): this evaluation will ALSO carry the divergence regulariser (training_loss: the term is taken at the
+        coarse samples' points, train.py:248-262).  A fifth output -- a one-float handle -- then ties ``_DivergenceOnBender`` to this node:
+        autograd calls this node's backward after the divergence's, and ONE nrnerf_bender_divergence_backward serves both uses (it takes
+        the render pass' cotangents as well): no nrnerf_bender_backward / _wgrad launches of their own for the coarse samples."""
         N, S = int(z.shape[0]), int(z.shape[1])
         M, dev = N * S, z.device
         BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
@@ -822,11 +826,16 @@ class _Bender(torch.autograd.Function):
         # the bent points twice: a graph that reads them in two places (coarse trunk; rows of the merged samples, _merge_rows) takes one
         # output for each, so that the two gradients arrive separately and the kernel adds them (autograd's own add of two [.,4]-row
         # views makes a packed [N,S,3] tensor the kernel cannot take: an add, a zero-fill and a copy per step)
-        return b[..., :3], off4.view(N, S, 4)[..., :3], b[..., 3:4], bent4.view(N, S, 4)[..., :3]
+        ctx.share = share
+        outs = (b[..., :3], off4.view(N, S, 4)[..., :3], b[..., 3:4], bent4.view(N, S, 4)[..., :3])
+        if share is None:
+            return outs
+        share.update(model=model, rb=rb, lat=lat, dims=(N, S))
+        return outs + (torch.empty(1, dtype=torch.float32, device=dev),)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_bent, g_unmasked, g_mask, g_bent_b=None):
+    def backward(ctx, g_bent, g_unmasked, g_mask, g_bent_b=None, _g_handle=None):
         rays, lat, z, bent4, off4, acts_b, acts_r = ctx.saved_tensors
         model, rb = ctx.model, ctx.rb
         N, S, BD, BW, RD, RW = ctx.dims
@@ -837,6 +846,12 @@ class _Bender(torch.autograd.Function):
         g4b = _rows4(g_bent_b, M) if g_bent_b is not None else None
         gu = g_unmasked.reshape(M, 3).float().contiguous() if g_unmasked is not None else None
         gm = g_mask.reshape(M).float().contiguous() if g_mask is not None else None
+        share = getattr(ctx, "share", None)
+        if share is not None and share.get("g_div") is not None:
+            # the divergence term was taken at this evaluation's points: its backward (value + tangent chain) takes this node's cotangents too
+            # (the saved arrays stay in `share` until the graph is freed: a second backward with retain_graph, train.py:1594-1604, finds them)
+            d_lat, flat = _divergence_backward(share, share.pop("g_div"), render=(g4 if g_bent is not None else None, g4b, gu, gm))
+            return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, flat if ctx.needs_input_grad[5] else None, None)
         dz_b, dz_r = torch.empty_like(acts_b), torch.empty_like(acts_r)
         dz_out4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         d_lat = torch.empty(M, LAT, dtype=torch.float32, device=dev)
@@ -849,7 +864,7 @@ class _Bender(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(model.lib.nrnerf_bender_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_backward")
         if not ctx.needs_input_grad[5]:              # frozen bender (e.g. fitting test-time latent codes): no weight gradients
-            return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, None)
+            return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, None, None)
         # every weight / bias gradient of both MLPs in one launch (nrnerf_bender_wgrad): partial sums per wave, added here
         nparts = 4 * max(1, min(_num_cus(dev), (M + 1023) // 1024))
         nj = BD + RD
@@ -864,7 +879,7 @@ class _Bender(torch.autograd.Function):
             _lib.check(model.lib.nrnerf_bender_wgrad(model.handle, C.byref(w), _stream(dev)), "nrnerf_bender_wgrad")
         # added up into ONE flat gradient (the parameters' shapes back to back) for the bender's token
         index, _ = _bender_grad_index(rb, dev, divergence=False)
-        return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index))
+        return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, _reduce_partials(parts.view(nparts, -1), nparts, index), None)
 
 
 def _bender_args(rb, rays, lat, z, N, S, bent4, off4, acts_b, acts_r):
@@ -892,10 +907,14 @@ def _bender_params(rb):
     return ps
 
 
-def bend_native(model, rb, rays, z, latents, details=True, masked=True, second=None):
+def bend_native(model, rb, rays, z, latents, details=True, masked=True, second=None, share=None):
     """As `bend`, on the HIP library: rays [N,>=6], z [N,S], latents [N,L] -> bent [N,S,3], dict of [N,S,.] tensors (``masked`` False:
-    without masked_offsets, one launch less).  ``second``: a list that receives the second handle on the bent points (_Bender.forward)."""
-    bent, unmasked, mask, bent_b = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)))
+    without masked_offsets, one launch less).  ``second``: a list that receives the second handle on the bent points (_Bender.forward);
+    ``share``: _Bender.forward's dict (the divergence regulariser on this evaluation)."""
+    outs = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)), share)
+    bent, unmasked, mask, bent_b = outs[:4]
+    if share is not None:
+        share["handle"] = outs[4]
     if second is not None:
         second.append(bent_b)
     if not details:
@@ -1135,6 +1154,76 @@ def _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r,
     return a
 
 
+def _divergence_backward(saved, g, render=None):
+    """nrnerf_bender_divergence_backward on the arrays a divergence forward saved (``saved``: model, rb, pts, lat_pts, e, div, off4, toff4,
+    acts_b, tacts_b, acts_r, tacts_r) -> (d_latents [M, LAT] per point, the bender's flat parameter gradient).  ``render``: the cotangents
+    (g_bent4 rows, second g_bent4 rows, g_unmasked [M,3], g_mask [M]; each may be None) of a render pass over the same evaluation."""
+    model, rb = saved["model"], saved["rb"]
+    pts, lat, e = saved["pts"], saved["lat_pts"], saved["e"]
+    acts_b, tacts_b, acts_r, tacts_r = saved["acts_b"], saved["tacts_b"], saved["acts_r"], saved["tacts_r"]
+    M, dev, LAT = int(pts.shape[0]), pts.device, int(lat.shape[1])
+    BD, RD = len(rb.network), len(rb.rigidity_network)
+    f32 = dict(dtype=torch.float32, device=dev)
+    g = g.contiguous().float()
+    dz_b, dtz_b, dz_r, dtz_r = torch.empty_like(acts_b), torch.empty_like(acts_b), torch.empty_like(acts_r), torch.empty_like(acts_r)
+    dz_out4, dtz_out4 = torch.empty(M, 4, **f32), torch.empty(M, 4, **f32)
+    d_lat = torch.empty(M, LAT, **f32)
+    nparts = 4 * max(1, min(_num_cus(dev), (M + 1023) // 1024))
+    parts = torch.empty(nparts, BD + RD + 1, _lib.BENDER_WGRAD_SLOT, **f32)
+    a = _divergence_args(rb, pts, lat, e, saved["div"], saved["off4"], saved["toff4"], acts_b, tacts_b, acts_r, tacts_r)
+    a.g_divergence = g.data_ptr()
+    if render is not None:
+        ptr = lambda t: None if t is None else t.data_ptr()
+        a.render_g_bent4, a.render_g_bent4_b, a.render_g_unmasked_offsets, a.render_g_rigidity_mask = [ptr(t) for t in render]
+    a.dz_offsets, a.dtz_offsets, a.dz_rigidity, a.dtz_rigidity = dz_b.data_ptr(), dtz_b.data_ptr(), dz_r.data_ptr(), dtz_r.data_ptr()
+    a.dz_out4, a.dtz_out4, a.d_latents = dz_out4.data_ptr(), dtz_out4.data_ptr(), d_lat.data_ptr()
+    a.n_partials, a.partials = nparts, parts.data_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(model.lib.nrnerf_bender_divergence_backward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_divergence_backward")
+    index, _ = _bender_grad_index(rb, dev, divergence=True)
+    return d_lat, _reduce_partials(parts.view(nparts, -1), nparts, index)
+
+
+class _DivergenceOnBender(torch.autograd.Function):
+    """The divergence regulariser's per-point values e^T J e [M] for an evaluation of the bender that a ``_Bender`` node of the same graph
+    made (``share`` = that node's dict, ``handle`` its fifth output): forward as ``_Divergence``; backward only PARKS the gradient -- the
+    ``_Bender`` node's backward, which autograd runs afterwards (it waits for the handle's gradient), runs the one pass for both uses."""
+
+    @staticmethod
+    def forward(ctx, handle, share, pts, e):
+        model, rb, lat = share["model"], share["rb"], share["lat"]
+        N, S = share["dims"]
+        M, dev = int(pts.shape[0]), pts.device
+        if M != N * S:
+            raise ValueError("the divergence points are not the bender evaluation's points")
+        BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
+        RD, RW = len(rb.rigidity_network), int(rb.rigidity_network[0].weight.shape[0])
+        lat_pts = lat[:, None, :].expand(N, S, lat.shape[1]).reshape(M, -1)                           # train.py:256-262
+        pts = pts.detach().to(torch.float32).contiguous()
+        e = e.detach().to(torch.float32).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        div = torch.empty(M, **f32)
+        off4, toff4 = torch.empty(M, 4, **f32), torch.empty(M, 4, **f32)
+        sd = dict(dtype=torch.float32 if _is_f32(model) else torch.bfloat16, device=dev)
+        acts_b, tacts_b = torch.empty(BD - 1, M, BW, **sd), torch.empty(BD - 1, M, BW, **sd)
+        acts_r, tacts_r = torch.empty(RD - 1, M, RW, **sd), torch.empty(RD - 1, M, RW, **sd)
+        a = _divergence_args(rb, pts, lat_pts, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
+        with torch.cuda.device(dev):
+            _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_divergence_forward")
+        share.update(pts=pts, lat_pts=lat_pts, e=e, div=div, off4=off4, toff4=toff4, acts_b=acts_b, tacts_b=tacts_b, acts_r=acts_r, tacts_r=tacts_r)
+        ctx.share = share
+        ctx.set_materialize_grads(False)
+        return div
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_div):
+        if g_div is None:
+            return None, None, None, None
+        ctx.share["g_div"] = g_div
+        return torch.empty(1, dtype=torch.float32, device=g_div.device), None, None, None       # (the handle's "gradient": never read)
+
+
 def why_no_native_divergence(ray_bender, input_points, point_latents):
     """None when compute_divergence_loss runs on the HIP library."""
     if ray_bender is None:
@@ -1262,6 +1351,10 @@ class _FusedLoss(torch.autograd.Function):
                 None if g_div is None else g_div.view(sd), None, None, None, None, None)
 
 
+# training_loss: the divergence regulariser and the coarse samples' bender evaluation share ONE backward pass (_DivergenceOnBender); False:
+# two separate autograd nodes, as the reference's graph has them (same gradients up to the order of additions)
+SHARED_DIVERGENCE = True
+
 FUSED_LOSS = True        # training_loss: the loss terms as nrnerf_loss_forward / _backward (False: eager torch ops, the gradient-parity reference)
 
 
@@ -1382,11 +1475,12 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
 
 def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.0, N_importance=0, network_fine=None,
                       white_bkgd=False, raw_noise_std=0.0, additional_pixel_information=None, detailed_output=False,
-                      want_z_vals=False, lindisp=False, only_details=None):
+                      want_z_vals=False, lindisp=False, only_details=None, divergence_share=None):
     """reference render_rays (train.py:792-980) with autograd: same output dict, attached to the graph of the networks',
     the bender's and the latent codes' parameters.  ``only_details`` (not a reference argument; training_loss passes it): the
     ``detailed_output`` keys the caller is going to read -- the others that cost launches of their own (the sample points, the masked
-    offsets) are then left out of the dict."""
+    offsets) are then left out of the dict.  ``divergence_share`` (training_loss): a dict the COARSE samples' bender evaluation fills when
+    it runs on the native training kernels (``_Bender.forward``), so that the divergence regulariser can ride on it."""
     want = (lambda key: True) if only_details is None else (lambda key: key in only_details)
     dev = ray_batch.device
     precision = "bf16" if R.get_precision() == "f16" else R.get_precision()
@@ -1429,7 +1523,7 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         if for_merge and native:
             if latents is None:
                 raise ValueError("ray_bending_latents are required with a ray bender")
-            bent, unmasked, mask, _ = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)))
+            bent, unmasked, mask, _ = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)), None)
             return None, bent, (dict(unmasked_offsets=unmasked, rigidity_mask=mask) if detailed_output else {})
         if (detailed_output and want(pre + "initial_input_pts")) or not native:
             pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]                    # :871-873 / 921-923
@@ -1438,7 +1532,8 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         if latents is None:
             raise ValueError("ray_bending_latents are required with a ray bender")
         if native:
-            bent, bd = bend_native(model, rb, rays, z, latents, details=detailed_output, masked=want(pre + "masked_offsets"), second=second_handle)
+            bent, bd = bend_native(model, rb, rays, z, latents, details=detailed_output, masked=want(pre + "masked_offsets"), second=second_handle,
+                                   share=divergence_share if ns == S and not second_handle else None)
         else:
             lat = latents[:, None, :].expand(N, ns, latents.shape[-1]).reshape(N * ns, -1)   # train.py:79-87
             bent, bd = bend(rb, pts.reshape(-1, 3), lat.to(torch.float32))
@@ -1557,6 +1652,9 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     kw = {k: v for k, v in render_kwargs.items() if k not in ("retraw", "ray_bender", "near", "far", "ndc", "use_viewdirs")}
     if detailed_output:      # the detail keys the terms below read (the others that cost launches of their own are not produced)
         kw["_only_details"] = _LOSS_DETAILS
+    share = None
+    if SHARED_DIVERGENCE and FUSED_LOSS and ray_bender is not None and divergence_loss_weight > 0.0 and rays_flat.is_cuda and N_rays <= int(chunk):
+        share = kw["_divergence_share"] = {}         # (one render_rays call: the coarse bender evaluation is the one the term is taken at)
     extras = R.batchify_rays(rays_flat, {"ray_bending_latents": ray_bending_latents}, chunk=chunk, detailed_output=detailed_output,
                              retraw=True, **kw)
     schedule = (1.0 / 100.0) ** (1 - (global_step / N_iters))                                    # :240, 285
@@ -1571,7 +1669,13 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     if FUSED_LOSS and extras["rgb_map"].is_cuda and (not use_div or why_no_native_divergence(ray_bender, div_pts, div_lat) is None):
         # the same terms as below, one launch forward and one backward (nrnerf_loss_forward / _backward)
         div = None
-        if use_div:
+        if use_div and share is not None and "handle" in share:
+            # the term rides on the coarse samples' bender evaluation: one backward pass + one weight-gradient launch for both (_Bender)
+            e = torch.empty_like(div_pts)
+            for i in range(0, int(div_pts.shape[0]), int(chunk)):                                # randn_like per chunk, rnh:52-59, 106
+                e[i:i + chunk, :].normal_()
+            div = _DivergenceOnBender.apply(share["handle"], share, div_pts, e)
+        elif use_div:
             div_pts.requires_grad = True                                                         # rnh:39
             div = _divergence_values(div_pts, div_lat, ray_bender, False, chunk)
         loss, loss_mean = _FusedLoss.apply(extras["rgb_map"], extras.get("rgb0"), target_s,

@@ -1343,6 +1343,51 @@ def test_fused_loss_kernel_vs_torch_autograd(with_rgb0, with_offsets, with_div, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("frozen_bender", [False, True], ids=["trained_bender", "frozen_bender"])
+def test_divergence_term_riding_on_the_coarse_bender_evaluation_gives_the_same_gradients(precision, tol, frozen_bender):
+    """training_loss with SHARED_DIVERGENCE (the divergence regulariser's backward and the coarse samples' bender backward as ONE
+    nrnerf_bender_divergence_backward that takes the render pass' cotangents too -- training._DivergenceOnBender) against the two separate
+    autograd nodes the reference's graph has (train.py:245-287 on top of :221-242): same random draws, same loss, every gradient equal up
+    to the order of additions (fp32) / to the 16-bit arrays' rounding (bf16: the shared pass reads the activations the divergence forward
+    saved, the separate one those of the render's own bender forward); with the bender frozen the latent codes still get both terms."""
+    from nonrigid_nerf_amd import training
+    cfg = SceneConfig(N_importance=64)
+    scene = make_scene(cfg, 1)
+    rays, latents = make_rays(300, 3, cfg)
+    target = torch.rand(300, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+    R.set_precision(precision)
+    out = {}
+    try:
+        for shared in (False, True):
+            rb, coarse, fine = _modules(scene)
+            if frozen_bender:
+                rb.requires_grad_(False)
+            lat = latents.to(DEV).requires_grad_(True)
+            kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=64, N_importance=64, perturb=1.0, raw_noise_std=1.0)
+            old, training.SHARED_DIVERGENCE = training.SHARED_DIVERGENCE, shared
+            try:
+                torch.manual_seed(11)
+                loss, _ = training.training_loss(rays.to(DEV), lat, target, kw, offsets_loss_weight=60.0, divergence_loss_weight=3.0,
+                                                 rigidity_loss_weight=5e-4, global_step=120000, N_iters=200000, mean=True)
+                loss.backward()
+            finally:
+                training.SHARED_DIVERGENCE = old
+            grads = {k: p.grad.clone() for k, p in _named(rb, coarse, fine).items() if p.grad is not None}
+            grads[("latents", "")] = lat.grad.clone()
+            out[shared] = (loss.detach().clone(), grads)
+    finally:
+        R.set_precision("f32")
+    assert torch.allclose(out[True][0], out[False][0], rtol=1e-6, atol=1e-8)        # (the forward is the same launches either way)
+    assert set(out[True][1]) == set(out[False][1])
+    assert frozen_bender == (not any(k[0] == "bender" for k in out[True][1]))
+    for k, ge in out[False][1].items():
+        gs = out[True][1][k]
+        scale = float(ge.abs().max()) + 1e-20
+        assert float((ge - gs).abs().max()) <= tol * scale, (k, float((ge - gs).abs().max()) / scale)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_rays,n_codes,latent", [(1024, 8, 32), (777, 300, 32), (16384, 3, 64), (5, 4, 7)])
 def test_code_gradients_kernel_vs_indexing_backward(n_rays, n_codes, latent):
     """nrnerf_code_gradients (training.select_codes' backward: the gradient of ``codes[index]``, train.py:173-188) against autograd's own
