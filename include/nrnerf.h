@@ -364,6 +364,11 @@ int nrnerf_generate_rays(const nrnerf_camera* cam, float near_plane, float far_p
  * Runs on the device that owns z_out. */
 int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uniforms, int32_t n_rays, int32_t n_samples,
                          int32_t lindisp, float* z_out, void* hip_stream);
+/* The same plus the samples' points in the same launch: points_out [n_rays, n_samples, 3] = o + d z (train.py:871-873), the product and
+ * the sum each rounded to fp32 as torch's two elementwise kernels round them (bit-identical to `rays_o[..., None, :] + rays_d[..., None, :] *
+ * z_vals[..., :, None]`) -- what render_rays hands out as `initial_input_pts` under detailed_output. */
+int nrnerf_sample_depths_points(const float* rays, int32_t ray_stride, const float* uniforms, int32_t n_rays, int32_t n_samples,
+                                int32_t lindisp, float* z_out, float* points_out, void* hip_stream);
 
 /* ---- training support ------------------------------------------------------------------------------------------
  * The reference trains through autograd (training_wrapper_class.forward, train.py:152-287; backward + optimiser step,

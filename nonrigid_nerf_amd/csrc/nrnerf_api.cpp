@@ -2553,6 +2553,18 @@ int nrnerf_sample_depths(const float* rays, int32_t ray_stride, const float* uni
     JitterArgs j{rays, ray_stride, uniforms, n_rays, n_samples, lindisp, z_out};
     return launch_zjitter(j, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
 } NRN_CATCH
+int nrnerf_sample_depths_points(const float* rays, int32_t ray_stride, const float* uniforms, int32_t n_rays, int32_t n_samples,
+                                int32_t lindisp, float* z_out, float* points_out, void* hip_stream) try {
+    if (!rays || !z_out || !points_out || ray_stride < 8 || n_rays < 0 || n_samples < 2 || n_samples > NRNERF_MAX_SAMPLES) return NRNERF_ERR_INVALID;
+    if (n_rays == 0) return NRNERF_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, z_out) != hipSuccess) { (void)hipGetLastError(); return NRNERF_ERR_INVALID; }
+    if (attr.type != hipMemoryTypeDevice) return NRNERF_ERR_INVALID;
+    DeviceGuard guard(attr.device);
+    if (!guard.ok) return NRNERF_ERR_HIP;
+    SamplePointsArgs j{rays, ray_stride, uniforms, n_rays, n_samples, lindisp, z_out, points_out};
+    return launch_sample_points(j, (hipStream_t)hip_stream) == hipSuccess ? NRNERF_OK : NRNERF_ERR_HIP;
+} NRN_CATCH
 
 namespace {
 // the device that owns `ptr` (device memory): NRNERF_OK and `dev`, or NRNERF_ERR_INVALID

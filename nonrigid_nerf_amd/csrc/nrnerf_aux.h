@@ -33,6 +33,16 @@ constexpr int REDUCE_SHORT_FLAG = 0x40000000;
 constexpr int REDUCE_GROUPS = 8;
 hipError_t launch_reduce_partials(const ReducePartialsArgs&, hipStream_t);
 
+// the coarse depths (JitterArgs / zjitter_kernel, train.py:847-868) AND the sample points o + d z (train.py:871-873) in one launch
+struct SamplePointsArgs {
+    const float* rays; int ray_stride;
+    const float* u;          // [N,S] uniforms or nullptr
+    int n_rays, S, lindisp;
+    float* z_out;            // [N,S]
+    float* pts_out;          // [N,S,3]
+};
+hipError_t launch_sample_points(const SamplePointsArgs&, hipStream_t);
+
 // out[r] = sum of the 32 bf16 values of row r of a [rows][32] array (the sample axis of the training path's block tiles), fp32
 hipError_t launch_tile_row_sums(const void* tiles, long long n_rows, float* out, hipStream_t);
 

@@ -189,22 +189,43 @@ static hipError_t launch_epl(const CompositeArgs& a, hipStream_t stream) {
 }
 
 // train.py:855-868: one thread per sample
-__global__ void __launch_bounds__(256) zjitter_kernel(const JitterArgs a) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)a.n_rays * a.S) return;
-    const int ray = (int)(idx / a.S), i = (int)(idx % a.S), S = a.S;
-    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+__device__ __forceinline__ float jittered_depth(const float* rp, const float* u, long long idx, int i, int S, int lindisp) {
     const float near = rp[6], far = rp[7];
     auto zat = [&](int k) {
         const float t = c_lin01(k, S);
-        if (a.lindisp)
+        if (lindisp)
             return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, far), t)));
         return __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, t)), __fmul_rn(far, t));
     };
     const float zi = zat(i);
     const float upper = (i < S - 1) ? __fmul_rn(0.5f, __fadd_rn(zat(i + 1), zi)) : zi;         // :857-858
     const float lower = (i > 0) ? __fmul_rn(0.5f, __fadd_rn(zi, zat(i - 1))) : zi;             // :859
-    a.z_out[idx] = a.u ? __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), a.u[idx])) : zi;   // :868 (no uniforms: the plain spacing)
+    // :868 (no uniforms: the plain spacing).  (hipcc fuses this product into the sum -- one rounding where torch has two; the depths have been
+    // these since round 2 and every stochastic parity figure was measured on them, so it stays)
+    return u ? __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u[idx])) : zi;
+}
+__global__ void __launch_bounds__(256) zjitter_kernel(const JitterArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.n_rays * a.S) return;
+    const int ray = (int)(idx / a.S), i = (int)(idx % a.S);
+    a.z_out[idx] = jittered_depth(a.rays + (size_t)ray * a.ray_stride, a.u, idx, i, a.S, a.lindisp);
+}
+// the same, and the sample's point o + d z (train.py:871-873: a product and a sum, each rounded -- torch's two elementwise launches)
+__global__ void __launch_bounds__(256) sample_points_kernel(const SamplePointsArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.n_rays * a.S) return;
+    const int ray = (int)(idx / a.S), i = (int)(idx % a.S);
+    const float* rp = a.rays + (size_t)ray * a.ray_stride;
+    const float z = jittered_depth(rp, a.u, idx, i, a.S, a.lindisp);
+    a.z_out[idx] = z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.pts_out[idx * 3 + c] = __fadd_rn(rp[c], rounded(rp[3 + c] * z));
+}
+hipError_t launch_sample_points(const SamplePointsArgs& a, hipStream_t stream) {
+    const long long n = (long long)a.n_rays * a.S;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 hipError_t launch_zjitter(const JitterArgs& a, hipStream_t stream) {
     const long long n = (long long)a.n_rays * a.S;

@@ -742,7 +742,8 @@ def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retr
                     network_fine=network_fine, white_bkgd=white_bkgd, raw_noise_std=raw_noise_std,
                     additional_pixel_information=additional_pixel_information, detailed_output=detailed_output,
                     want_z_vals=bool(dummy_kwargs.get("_want_z_vals", False)), lindisp=bool(lindisp),
-                    only_details=dummy_kwargs.get("_only_details"), divergence_share=dummy_kwargs.get("_divergence_share"))
+                    only_details=dummy_kwargs.get("_only_details"), divergence_share=dummy_kwargs.get("_divergence_share"),
+                    randoms=dummy_kwargs.get("_randoms"))
             except (Unsupported, _lib.NrnerfError) as e:
                 if isinstance(e, _lib.NrnerfError) and e.status != _lib.ERR_UNSUPPORTED:
                     raise

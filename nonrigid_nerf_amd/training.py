@@ -1239,7 +1239,7 @@ def why_no_native_divergence(ray_bender, input_points, point_latents):
     return None
 
 
-def _divergence_values(input_points, point_latents, ray_bender, exact, chunk):
+def _divergence_values(input_points, point_latents, ray_bender, exact, chunk, e=None):
     """Per point the (Hutchinson estimate ``e^T J e`` of the, or with ``exact`` the exact) divergence of the masked offsets field, [M], on the
     native kernels (the caller has checked why_no_native_divergence).  The probe vectors are drawn with the reference's own call per
     ``chunk`` of points (``torch.randn_like`` on a [chunk, 3] tensor, rnh:106)."""
@@ -1255,9 +1255,10 @@ def _divergence_values(input_points, point_latents, ray_bender, exact, chunk):
             d = _Divergence.apply(point_latents, model, ray_bender, pts, e, token)
             div = d if div is None else div + d
         return div
-    e = torch.empty_like(pts)                        # divergence_approx (rnh:103-113), one draw per chunk as in rnh:52-59:
-    for i in range(0, M, int(chunk)):                # randn_like(offsets) per chunk = empty_like().normal_(): same draws, no cat
-        e[i:i + chunk, :].normal_()
+    if e is None:
+        e = torch.empty_like(pts)                    # divergence_approx (rnh:103-113), one draw per chunk as in rnh:52-59:
+        for i in range(0, M, int(chunk)):            # randn_like(offsets) per chunk = empty_like().normal_(): same draws, no cat
+            e[i:i + chunk, :].normal_()
     return _Divergence.apply(point_latents, model, ray_bender, pts, e, token)
 
 
@@ -1349,6 +1350,40 @@ class _FusedLoss(torch.autograd.Function):
         so, sr, sd = ctx.shapes
         return (g_map, g_0, None, None, None if g_off is None else g_off.view(so), None if g_rig is None else g_rig.view(sr), None,
                 None if g_div is None else g_div.view(sd), None, None, None, None, None)
+
+
+# training_loss: every uniform number of an iteration from ONE torch.rand call and every normal one from ONE torch.randn call (stratified
+# jitter + sample_pdf's u; sigma noise of both passes + the divergence term's probe vectors) instead of the reference's six calls in the
+# reference's order (train.py:860, 753, rnh:665, 753, 106 per chunk).  Same distributions, another position in the generator's stream: a
+# seeded iteration no longer draws the numbers the reference draws, hence off by default (bench.py's train_step legs turn it on and say so).
+POOLED_DRAWS = False
+
+
+def _pooled_draws(rays_flat, kw, with_probe):
+    """(the dict render._draw_randoms builds, the divergence term's probe vectors [N * N_samples, 3] or None) from two generator calls."""
+    N, dev = int(rays_flat.shape[0]), rays_flat.device
+    S, I = int(kw["N_samples"]), int(kw.get("N_importance", 0))
+    perturb, std = kw.get("perturb", 0.0), kw.get("raw_noise_std", 0.0)
+    stochastic_z, noisy = bool(perturb) and perturb > 0.0, bool(std) and std > 0.0
+    out = {}
+    if stochastic_z:
+        u = torch.rand(N * (S + I), device=dev)
+        out["u_coarse"] = u[:N * S].view(N, S)
+        if I > 0:
+            out["u_fine"] = u[N * S:].view(N, I)
+    n_noise = N * (S + (S + I if I > 0 else 0)) if noisy else 0
+    n_probe = N * S * 3 if with_probe else 0
+    e = None
+    if n_noise + n_probe:
+        nrm = torch.randn(n_noise + n_probe, device=dev)
+        if noisy:
+            noise = nrm[:n_noise] if float(std) == 1.0 else nrm[:n_noise] * float(std)
+            out["noise_coarse"] = noise[:N * S].view(N, S)
+            if I > 0:
+                out["noise_fine"] = noise[N * S:].view(N, S + I)
+        if with_probe:
+            e = nrm[n_noise:].view(N * S, 3)
+    return out, e
 
 
 # training_loss: the divergence regulariser and the coarse samples' bender evaluation share ONE backward pass (_DivergenceOnBender); False:
@@ -1475,12 +1510,13 @@ def why_not_trainable(network_fn, network_fine, N_samples, N_importance, lindisp
 
 def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.0, N_importance=0, network_fine=None,
                       white_bkgd=False, raw_noise_std=0.0, additional_pixel_information=None, detailed_output=False,
-                      want_z_vals=False, lindisp=False, only_details=None, divergence_share=None):
+                      want_z_vals=False, lindisp=False, only_details=None, divergence_share=None, randoms=None):
     """reference render_rays (train.py:792-980) with autograd: same output dict, attached to the graph of the networks',
     the bender's and the latent codes' parameters.  ``only_details`` (not a reference argument; training_loss passes it): the
     ``detailed_output`` keys the caller is going to read -- the others that cost launches of their own (the sample points, the masked
     offsets) are then left out of the dict.  ``divergence_share`` (training_loss): a dict the COARSE samples' bender evaluation fills when
-    it runs on the native training kernels (``_Bender.forward``), so that the divergence regulariser can ride on it."""
+    it runs on the native training kernels (``_Bender.forward``), so that the divergence regulariser can ride on it.  ``randoms``
+    (training_loss with POOLED_DRAWS): the dict ``render._draw_randoms`` would draw, drawn by the caller."""
     want = (lambda key: True) if only_details is None else (lambda key: key in only_details)
     dev = ray_batch.device
     precision = "bf16" if R.get_precision() == "f16" else R.get_precision()
@@ -1505,13 +1541,20 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         raise UnboundLocalError("local variable 'visibility_weights_0' referenced before assignment "
                                 "(reference render_rays cannot do detailed_output with N_importance == 0)")
     # random numbers in the reference's order (train.py:860, 753; run_nerf_helpers.py:665; 753)
-    rnd = R._draw_randoms(rays, S, I, perturb, raw_noise_std) or {}
-    # coarse depths (:847-868): linspace between near and far (or in inverse depth) and the stratified jitter, one launch
+    rnd = randoms if randoms is not None else (R._draw_randoms(rays, S, I, perturb, raw_noise_std) or {})
+    # coarse depths (:847-868): linspace between near and far (or in inverse depth) and the stratified jitter, one launch -- which also
+    # writes the coarse samples' points (:871-873) when the caller reads them (detailed_output's initial_input_pts)
     z_vals = torch.empty(N, S, dtype=torch.float32, device=dev)
     u_c = rnd.get("u_coarse")
+    coarse_pts = torch.empty(N, S, 3, dtype=torch.float32, device=dev) if (detailed_output and want("initial_input_pts")) else None
     with torch.cuda.device(dev):
-        _lib.check(model.lib.nrnerf_sample_depths(rays.data_ptr(), int(rays.shape[1]), u_c.data_ptr() if u_c is not None else None, N, S,
-                                                  int(bool(lindisp)), z_vals.data_ptr(), _stream(dev)), "nrnerf_sample_depths")
+        if coarse_pts is not None:
+            _lib.check(model.lib.nrnerf_sample_depths_points(rays.data_ptr(), int(rays.shape[1]), u_c.data_ptr() if u_c is not None else None, N, S,
+                                                             int(bool(lindisp)), z_vals.data_ptr(), coarse_pts.data_ptr(), _stream(dev)),
+                       "nrnerf_sample_depths_points")
+        else:
+            _lib.check(model.lib.nrnerf_sample_depths(rays.data_ptr(), int(rays.shape[1]), u_c.data_ptr() if u_c is not None else None, N, S,
+                                                      int(bool(lindisp)), z_vals.data_ptr(), _stream(dev)), "nrnerf_sample_depths")
 
     def bend_samples(z, for_merge=False):
         """(points, bent points, bender details) of the samples at depths z [N, ns]; points only when something needs them
@@ -1525,7 +1568,9 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
                 raise ValueError("ray_bending_latents are required with a ray bender")
             bent, unmasked, mask, _ = _Bender.apply(latents, model, rb, rays, z, _param_token(rb, _bender_params(rb)), None)
             return None, bent, (dict(unmasked_offsets=unmasked, rigidity_mask=mask) if detailed_output else {})
-        if (detailed_output and want(pre + "initial_input_pts")) or not native:
+        if z is z_vals and coarse_pts is not None:
+            pts = coarse_pts                                                                 # :871-873, from the depths' own launch
+        elif (detailed_output and want(pre + "initial_input_pts")) or not native:
             pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]                    # :871-873 / 921-923
         if rb is None:
             return pts, pts, bd
@@ -1652,6 +1697,9 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     kw = {k: v for k, v in render_kwargs.items() if k not in ("retraw", "ray_bender", "near", "far", "ndc", "use_viewdirs")}
     if detailed_output:      # the detail keys the terms below read (the others that cost launches of their own are not produced)
         kw["_only_details"] = _LOSS_DETAILS
+    pooled_e = None
+    if POOLED_DRAWS and rays_flat.is_cuda and N_rays <= int(chunk):
+        kw["_randoms"], pooled_e = _pooled_draws(rays_flat, kw, ray_bender is not None and divergence_loss_weight > 0.0 and FUSED_LOSS)
     share = None
     if SHARED_DIVERGENCE and FUSED_LOSS and ray_bender is not None and divergence_loss_weight > 0.0 and rays_flat.is_cuda and N_rays <= int(chunk):
         share = kw["_divergence_share"] = {}         # (one render_rays call: the coarse bender evaluation is the one the term is taken at)
@@ -1661,23 +1709,27 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     use_off = ray_bender is not None and offsets_loss_weight > 0.0
     use_div = ray_bender is not None and divergence_loss_weight > 0.0
     div_pts = div_lat = None
+    riding = use_div and share is not None and "handle" in share      # (then the points and codes are the bender evaluation's own)
     if use_div:
         n_samples = int(extras["initial_input_pts"].shape[1])
         lat = ray_bending_latents
-        div_lat = lat.view(N_rays, 1, -1).expand((N_rays, n_samples, lat.shape[-1])).reshape(-1, lat.shape[-1])                  # :256-262
+        if not riding:
+            div_lat = lat.view(N_rays, 1, -1).expand((N_rays, n_samples, lat.shape[-1])).reshape(-1, lat.shape[-1])              # :256-262
         div_pts = extras["initial_input_pts"].view(-1, 3)
-    if FUSED_LOSS and extras["rgb_map"].is_cuda and (not use_div or why_no_native_divergence(ray_bender, div_pts, div_lat) is None):
+    if FUSED_LOSS and extras["rgb_map"].is_cuda and (not use_div or riding or why_no_native_divergence(ray_bender, div_pts, div_lat) is None):
         # the same terms as below, one launch forward and one backward (nrnerf_loss_forward / _backward)
         div = None
-        if use_div and share is not None and "handle" in share:
+        if riding:
             # the term rides on the coarse samples' bender evaluation: one backward pass + one weight-gradient launch for both (_Bender)
-            e = torch.empty_like(div_pts)
-            for i in range(0, int(div_pts.shape[0]), int(chunk)):                                # randn_like per chunk, rnh:52-59, 106
-                e[i:i + chunk, :].normal_()
+            e = pooled_e
+            if e is None:
+                e = torch.empty_like(div_pts)
+                for i in range(0, int(div_pts.shape[0]), int(chunk)):                            # randn_like per chunk, rnh:52-59, 106
+                    e[i:i + chunk, :].normal_()
             div = _DivergenceOnBender.apply(share["handle"], share, div_pts, e)
         elif use_div:
             div_pts.requires_grad = True                                                         # rnh:39
-            div = _divergence_values(div_pts, div_lat, ray_bender, False, chunk)
+            div = _divergence_values(div_pts, div_lat, ray_bender, False, chunk, e=pooled_e)
         loss, loss_mean = _FusedLoss.apply(extras["rgb_map"], extras.get("rgb0"), target_s,
                                 extras["visibility_weights"] if use_off else None, extras["unmasked_offsets"] if use_off else None,
                                 extras["rigidity_mask"] if use_off else None, extras["opacity_alpha"] if use_div else None, div,
@@ -2065,6 +2117,8 @@ def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, reg
 
     prev = R.get_precision()
     R.set_precision(precision)
+    global POOLED_DRAWS
+    prev_pool, POOLED_DRAWS = POOLED_DRAWS, True       # (two generator calls per iteration instead of six; see POOLED_DRAWS)
     try:
         if graph:
             gstep = torch.zeros((), device=dev)
@@ -2088,6 +2142,7 @@ def _time_training(cfg, dev, precision, n_rays, n_importance, steps, warmup, reg
                 dt = min(dt, (time.perf_counter() - t0) / steps)
     finally:
         R.set_precision(prev)
+        POOLED_DRAWS = prev_pool
     return dt, float(loss.detach())
 
 
@@ -2141,8 +2196,10 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=None, steps=30, w
             "what": "the reference's training iteration with its shipped recipe (configs/example_sequence.txt): render under autograd with "
                     "detailed outputs (perturb, raw_noise_std 1), loss = mse(rgb_map) + mse(rgb0) + 60 x (offsets + 5e-4 rigidity) "
                     "regulariser + 3 x divergence regulariser (native second-order path) with the increasing schedule, backward, training.FusedAdam ("
-                    "Adam step + device-side weight re-pack as one launch); all through render.batchify_rays / training.compute_divergence_loss. "
-                    "Every leg: best of three timed loops",
+                    "Adam step + device-side weight re-pack as two launches); all through render.batchify_rays / training.training_loss. "
+                    "The iteration's random numbers (stratified jitter, sample_pdf's u, sigma noise of both passes, the divergence term's probe "
+                    "vectors) come from ONE torch.rand and ONE torch.randn call (training.POOLED_DRAWS: same distributions, not the reference's six "
+                    "calls in the reference's order). Every leg: best of three timed loops",
             "loss_terms": ["mse(rgb_map)", "mse(rgb0)", "offsets", "rigidity", "divergence"],
             "hip_graph": graph,
             "roofline": {"bound": "hbm", **r["hbm"], "mfma": r["mfma"],

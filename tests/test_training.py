@@ -1388,6 +1388,66 @@ def test_divergence_term_riding_on_the_coarse_bender_evaluation_gives_the_same_g
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lindisp,jitter", [(False, True), (True, True), (False, False)])
+def test_sample_depths_points_kernel_equals_the_reference_expression_bit_for_bit(lindisp, jitter):
+    """nrnerf_sample_depths_points: the coarse depths as nrnerf_sample_depths writes them and, from the same launch, the sample points
+    ``rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]`` (train.py:871-873) with torch's own two roundings."""
+    from nonrigid_nerf_amd import _lib
+    cfg = SceneConfig()
+    rays, _ = make_rays(777, 4, cfg)
+    rays = rays.to(DEV).contiguous()
+    N, S = 777, 37
+    u = torch.rand(N, S, generator=torch.Generator().manual_seed(5)).to(DEV) if jitter else None
+    z0, z1 = torch.empty(N, S, device=DEV), torch.empty(N, S, device=DEV)
+    pts = torch.empty(N, S, 3, device=DEV)
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.nrnerf_sample_depths(rays.data_ptr(), int(rays.shape[1]), u.data_ptr() if jitter else None, N, S, int(lindisp), z0.data_ptr(), st), "d")
+    _lib.check(lib.nrnerf_sample_depths_points(rays.data_ptr(), int(rays.shape[1]), u.data_ptr() if jitter else None, N, S, int(lindisp), z1.data_ptr(),
+                                               pts.data_ptr(), st), "dp")
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1)
+    assert torch.equal(pts, rays[:, None, 0:3] + rays[:, None, 3:6] * z0[:, :, None])
+
+
+@pytest.mark.gpu
+def test_pooled_draws_feed_a_training_iteration_with_the_same_distributions():
+    """training.POOLED_DRAWS: one torch.rand + one torch.randn call per iteration instead of the reference's six -- shapes, ranges and
+    moments of what the kernels receive, the noise scaled by raw_noise_std, and a seeded iteration that is reproducible and differentiable
+    (its numbers are NOT the reference's: another position in the generator's stream, which is why the switch is off by default)."""
+    from nonrigid_nerf_amd import training
+    cfg = SceneConfig(N_importance=64)
+    rays, latents = make_rays(512, 3, cfg)
+    kw = dict(N_samples=64, N_importance=64, perturb=1.0, raw_noise_std=0.5)
+    torch.manual_seed(3)
+    rnd, e = training._pooled_draws(rays.to(DEV), kw, True)
+    assert tuple(rnd["u_coarse"].shape) == (512, 64) and tuple(rnd["u_fine"].shape) == (512, 64)
+    assert tuple(rnd["noise_coarse"].shape) == (512, 64) and tuple(rnd["noise_fine"].shape) == (512, 128) and tuple(e.shape) == (512 * 64, 3)
+    for u in (rnd["u_coarse"], rnd["u_fine"]):
+        assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.01
+    for n_, std in ((rnd["noise_coarse"], 0.5), (rnd["noise_fine"], 0.5), (e, 1.0)):
+        assert abs(float(n_.mean())) < 0.02 * std + 1e-3 and abs(float(n_.std()) - std) < 0.02 * std
+    scene = make_scene(cfg, 1)
+    target = torch.rand(512, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+    R.set_precision("f32")
+    old, training.POOLED_DRAWS = training.POOLED_DRAWS, True
+    try:
+        res = []
+        for _ in range(2):
+            rb, coarse, fine = _modules(scene)
+            lat = latents.to(DEV).requires_grad_(True)
+            kwr = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=64, N_importance=64, perturb=1.0, raw_noise_std=1.0)
+            torch.manual_seed(11)
+            loss, _ = training.training_loss(rays.to(DEV), lat, target, kwr, offsets_loss_weight=60.0, divergence_loss_weight=3.0,
+                                             rigidity_loss_weight=5e-4, global_step=120000, N_iters=200000, mean=True)
+            loss.backward()
+            res.append((float(loss), lat.grad.clone(), rb.network[0].weight.grad.clone()))
+    finally:
+        training.POOLED_DRAWS = old
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert torch.isfinite(res[0][1]).all() and float(res[0][2].abs().max()) > 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_rays,n_codes,latent", [(1024, 8, 32), (777, 300, 32), (16384, 3, 64), (5, 4, 7)])
 def test_code_gradients_kernel_vs_indexing_backward(n_rays, n_codes, latent):
     """nrnerf_code_gradients (training.select_codes' backward: the gradient of ``codes[index]``, train.py:173-188) against autograd's own
