@@ -546,6 +546,10 @@ typedef struct nrnerf_divergence_args {
     const float* render_g_bent4_b;
     const float* render_g_unmasked_offsets;
     const float* render_g_rigidity_mask;
+    /* forward, optional: the rows nrnerf_bender_forward writes as bent4 ([M,4]: bent point xyz + rigidity mask after the cutoff knob) --
+       with it this call IS the render pass' bender evaluation of those samples as well (off4 has the same meaning in both calls), and
+       with render_g_* above neither nrnerf_bender_forward nor _backward / _wgrad runs for them */
+    float* bent4;
 } nrnerf_divergence_args;
 int nrnerf_bender_divergence_forward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);
 int nrnerf_bender_divergence_backward(const nrnerf_model* model, const nrnerf_divergence_args* args, void* hip_stream);

@@ -242,7 +242,7 @@ class DivergenceArgs(C.Structure):
                 ("n_partials", C.c_int32), ("partials", C.c_void_p),
                 ("tangent", C.c_void_p), ("g_tangent", C.c_void_p),
                 ("render_g_bent4", C.c_void_p), ("render_g_bent4_b", C.c_void_p), ("render_g_unmasked_offsets", C.c_void_p),
-                ("render_g_rigidity_mask", C.c_void_p)]
+                ("render_g_rigidity_mask", C.c_void_p), ("bent4", C.c_void_p)]
 
 
 ADAM_MAX_SEGMENTS = 40       # NRNERF_ADAM_MAX_SEGMENTS of include/nrnerf.h

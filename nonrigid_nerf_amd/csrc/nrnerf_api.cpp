@@ -2978,6 +2978,7 @@ int divergence_common(const nrnerf_model* m, const nrnerf_divergence_args* a, bo
     t.knobs.has_scaling = a->has_test_time_scaling; t.knobs.scaling = a->test_time_scaling;
     t.div = a->divergence; t.off4 = a->off4; t.toff4 = a->toff4; t.tvec = a->tangent; t.g_tvec = a->g_tangent;
     t.r_g_bent4 = a->render_g_bent4; t.r_g_bent4_b = a->render_g_bent4_b; t.r_g_unmasked = a->render_g_unmasked_offsets; t.r_g_mask = a->render_g_rigidity_mask;
+    t.bent4 = bwd ? nullptr : a->bent4;
     t.acts_b = a->acts_offsets; t.tacts_b = a->tacts_offsets; t.acts_r = a->acts_rigidity; t.tacts_r = a->tacts_rigidity;
     t.g_div = a->g_divergence; t.dz_b = a->dz_offsets; t.dtz_b = a->dtz_offsets; t.dz_r = a->dz_rigidity; t.dtz_r = a->dtz_rigidity;
     t.dz_out4 = a->dz_out4; t.dtz_out4 = a->dtz_out4; t.d_lat = a->d_latents;

@@ -238,6 +238,9 @@ struct BendDivArgs {
     // g_mask), all optional: added to the value chain's, so that one backward pass + one weight-gradient launch serve the divergence term
     // and the coarse samples' bender evaluation of a training iteration (both chains are linear in their cotangents)
     const float* r_g_bent4; const float* r_g_bent4_b; const float* r_g_unmasked; const float* r_g_mask;
+    // forward, optional: the bent point + rigidity mask rows bend_fwd_train writes (BendTrainArgs::bent4) -- with it the divergence forward
+    // IS the render pass' bender evaluation of those samples (off4 is common to both)
+    float* bent4;
 };
 hipError_t launch_bend_div_fwd_a0(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);
 hipError_t launch_bend_div_fwd_a1(const BendDivArgs&, int num_cus, hipStream_t, bool bf16_arrays);

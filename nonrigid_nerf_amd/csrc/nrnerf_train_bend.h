@@ -437,6 +437,16 @@ __global__ void __launch_bounds__(256, 2) bend_div_fwd(const BendDivArgs a) {
                 for (int c = 0; c < 3; ++c) a.dirs_out[so * 3 + c] = __fadd_rn(__fdiv_rn(jd[c], nrm), 0.000001f);
             }
             if (a.div) a.div[so] = d;
+            if (a.bent4) {              // bend_fwd_train's own output (rnh:567-570): bent = p + scaling * mask * off, .w = the mask after the cutoff
+                float bent[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float mo = __fmul_rn(mask, off[c]);
+                    if (a.knobs.has_scaling) mo = __fmul_rn(mo, a.knobs.scaling);
+                    bent[c] = __fadd_rn(p[c], mo);
+                }
+                *(f32x4*)(a.bent4 + so * 4) = f32x4{bent[0], bent[1], bent[2], mask};
+            }
             if (a.off4) *(f32x4*)(a.off4 + so * 4) = f32x4{off[0], off[1], off[2], th};
             if (a.toff4) *(f32x4*)(a.toff4 + so * 4) = f32x4{toff[0], toff[1], toff[2], tlogit};
         }

@@ -802,7 +802,10 @@ class _Bender(torch.autograd.Function):
         """``share`` (a dict, or None): this evaluation will ALSO carry the divergence regulariser (training_loss: the term is taken at the
         coarse samples' points, train.py:248-262).  A fifth output -- a one-float handle -- then ties ``_DivergenceOnBender`` to this node:
         autograd calls this node's backward after the divergence's, and ONE nrnerf_bender_divergence_backward serves both uses (it takes
-        the render pass' cotangents as well): no nrnerf_bender_backward / _wgrad launches of their own for the coarse samples."""
+        the render pass' cotangents as well): no nrnerf_bender_backward / _wgrad launches of their own for the coarse samples.
+        When the dict already holds the probe vectors ``e`` and the samples' points ``pts`` (training_loss with POOLED_DRAWS: the probes
+        are drawn up front), the divergence FORWARD makes this evaluation too (nrnerf_divergence_args.bent4): no nrnerf_bender_forward
+        launch for the coarse samples either."""
         N, S = int(z.shape[0]), int(z.shape[1])
         M, dev = N * S, z.device
         BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
@@ -811,6 +814,15 @@ class _Bender(torch.autograd.Function):
         z = z.detach().contiguous()
         bent4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         off4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        ctx.fused = share is not None and share.get("e") is not None and share.get("pts") is not None and int(share["pts"].numel()) == 3 * M
+        if ctx.fused:
+            share.update(model=model, rb=rb, lat=lat, dims=(N, S))
+            _divergence_forward(share, share["pts"].reshape(M, 3), share["e"], bent4=bent4, off4=off4)
+            ctx.model, ctx.rb, ctx.dims, ctx.share = model, rb, (N, S, BD, BW, RD, RW), share
+            ctx.save_for_backward(rays, lat, z, bent4, off4)
+            ctx.set_materialize_grads(False)
+            b = bent4.view(N, S, 4)
+            return (b[..., :3], off4.view(N, S, 4)[..., :3], b[..., 3:4], bent4.view(N, S, 4)[..., :3], torch.empty(1, dtype=torch.float32, device=dev))
         # saved arrays: fp32 for an fp32 model, bf16 otherwise (include/nrnerf.h, nrnerf_bender_args): only the weight-gradient
         # kernel reads their values, and in that mode it rounds them to bf16 for the matrix pipe anyway
         sdt = torch.float32 if _is_f32(model) else torch.bfloat16
@@ -836,7 +848,11 @@ class _Bender(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_bent, g_unmasked, g_mask, g_bent_b=None, _g_handle=None):
-        rays, lat, z, bent4, off4, acts_b, acts_r = ctx.saved_tensors
+        if ctx.fused:
+            rays, lat, z, bent4, off4 = ctx.saved_tensors
+            acts_b = acts_r = None
+        else:
+            rays, lat, z, bent4, off4, acts_b, acts_r = ctx.saved_tensors
         model, rb = ctx.model, ctx.rb
         N, S, BD, BW, RD, RW = ctx.dims
         M, dev, LAT = N * S, z.device, int(lat.shape[1])
@@ -847,10 +863,13 @@ class _Bender(torch.autograd.Function):
         gu = g_unmasked.reshape(M, 3).float().contiguous() if g_unmasked is not None else None
         gm = g_mask.reshape(M).float().contiguous() if g_mask is not None else None
         share = getattr(ctx, "share", None)
-        if share is not None and share.get("g_div") is not None:
+        if share is not None and (share.get("g_div") is not None or ctx.fused):
             # the divergence term was taken at this evaluation's points: its backward (value + tangent chain) takes this node's cotangents too
             # (the saved arrays stay in `share` until the graph is freed: a second backward with retain_graph, train.py:1594-1604, finds them)
-            d_lat, flat = _divergence_backward(share, share.pop("g_div"), render=(g4 if g_bent is not None else None, g4b, gu, gm))
+            g_div = share.pop("g_div", None)
+            if g_div is None:            # (the divergence forward made this evaluation, but nobody differentiated the term itself)
+                g_div = torch.zeros(M, dtype=torch.float32, device=dev)
+            d_lat, flat = _divergence_backward(share, g_div, render=(g4 if g_bent is not None else None, g4b, gu, gm))
             return (d_lat.view(N, S, LAT).sum(1), None, None, None, None, flat if ctx.needs_input_grad[5] else None, None)
         dz_b, dz_r = torch.empty_like(acts_b), torch.empty_like(acts_r)
         dz_out4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
@@ -1154,6 +1173,36 @@ def _divergence_args(rb, pts, lat, e, div, off4, toff4, acts_b, tacts_b, acts_r,
     return a
 
 
+def _divergence_forward(share, pts, e, bent4=None, off4=None):
+    """nrnerf_bender_divergence_forward for the evaluation ``share`` describes (model, rb, lat [N, L] per ray, dims): fills ``share`` with the
+    arrays its backward needs and the per-point values ``div``; with ``bent4`` it writes the render pass' rows as well."""
+    model, rb, lat = share["model"], share["rb"], share["lat"]
+    N, S = share["dims"]
+    M, dev = int(pts.shape[0]), pts.device
+    if M != N * S:
+        raise ValueError("the divergence points are not the bender evaluation's points")
+    BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
+    RD, RW = len(rb.rigidity_network), int(rb.rigidity_network[0].weight.shape[0])
+    lat_pts = lat[:, None, :].expand(N, S, lat.shape[1]).reshape(M, -1)                               # train.py:256-262
+    pts = pts.detach().to(torch.float32).contiguous()
+    e = e.detach().to(torch.float32).contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    div = torch.empty(M, **f32)
+    off4 = torch.empty(M, 4, **f32) if off4 is None else off4
+    toff4 = torch.empty(M, 4, **f32)
+    sd = dict(dtype=torch.float32 if _is_f32(model) else torch.bfloat16, device=dev)
+    acts_b, tacts_b = torch.empty(BD - 1, M, BW, **sd), torch.empty(BD - 1, M, BW, **sd)
+    acts_r, tacts_r = torch.empty(RD - 1, M, RW, **sd), torch.empty(RD - 1, M, RW, **sd)
+    a = _divergence_args(rb, pts, lat_pts, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
+    if bent4 is not None:
+        a.bent4 = bent4.data_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_divergence_forward")
+    share.update(pts=pts, lat_pts=lat_pts, e=e, div=div, off4=off4, toff4=toff4, acts_b=acts_b, tacts_b=tacts_b, acts_r=acts_r, tacts_r=tacts_r,
+                 computed=True)
+    return div
+
+
 def _divergence_backward(saved, g, render=None):
     """nrnerf_bender_divergence_backward on the arrays a divergence forward saved (``saved``: model, rb, pts, lat_pts, e, div, off4, toff4,
     acts_b, tacts_b, acts_r, tacts_r) -> (d_latents [M, LAT] per point, the bender's flat parameter gradient).  ``render``: the cotangents
@@ -1191,26 +1240,8 @@ class _DivergenceOnBender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, handle, share, pts, e):
-        model, rb, lat = share["model"], share["rb"], share["lat"]
-        N, S = share["dims"]
-        M, dev = int(pts.shape[0]), pts.device
-        if M != N * S:
-            raise ValueError("the divergence points are not the bender evaluation's points")
-        BD, BW = len(rb.network), int(rb.network[0].weight.shape[0])
-        RD, RW = len(rb.rigidity_network), int(rb.rigidity_network[0].weight.shape[0])
-        lat_pts = lat[:, None, :].expand(N, S, lat.shape[1]).reshape(M, -1)                           # train.py:256-262
-        pts = pts.detach().to(torch.float32).contiguous()
-        e = e.detach().to(torch.float32).contiguous()
-        f32 = dict(dtype=torch.float32, device=dev)
-        div = torch.empty(M, **f32)
-        off4, toff4 = torch.empty(M, 4, **f32), torch.empty(M, 4, **f32)
-        sd = dict(dtype=torch.float32 if _is_f32(model) else torch.bfloat16, device=dev)
-        acts_b, tacts_b = torch.empty(BD - 1, M, BW, **sd), torch.empty(BD - 1, M, BW, **sd)
-        acts_r, tacts_r = torch.empty(RD - 1, M, RW, **sd), torch.empty(RD - 1, M, RW, **sd)
-        a = _divergence_args(rb, pts, lat_pts, e, div, off4, toff4, acts_b, tacts_b, acts_r, tacts_r)
-        with torch.cuda.device(dev):
-            _lib.check(model.lib.nrnerf_bender_divergence_forward(model.handle, C.byref(a), _mstream(model, dev)), "nrnerf_bender_divergence_forward")
-        share.update(pts=pts, lat_pts=lat_pts, e=e, div=div, off4=off4, toff4=toff4, acts_b=acts_b, tacts_b=tacts_b, acts_r=acts_r, tacts_r=tacts_r)
+        # (already made by the _Bender node when it had the probe vectors up front: its divergence forward WAS the bender evaluation)
+        div = share["div"] if share.get("computed") else _divergence_forward(share, pts, e)
         ctx.share = share
         ctx.set_materialize_grads(False)
         return div
@@ -1634,6 +1665,8 @@ def render_rays_train(ray_batch, network_fn, N_samples, retraw=False, perturb=0.
         return raw4, raw, details
 
     second_handle = []
+    if divergence_share is not None and coarse_pts is not None:
+        divergence_share["pts"] = coarse_pts
     coarse_parts = bend_samples(z_vals)
     raw4, raw, details = query(z_vals, network_fn, 0, coarse_parts)
     noise_c = rnd.get("noise_coarse")
@@ -1703,6 +1736,8 @@ def training_loss(rays_flat, ray_bending_latents, target_s, render_kwargs, *, of
     share = None
     if SHARED_DIVERGENCE and FUSED_LOSS and ray_bender is not None and divergence_loss_weight > 0.0 and rays_flat.is_cuda and N_rays <= int(chunk):
         share = kw["_divergence_share"] = {}         # (one render_rays call: the coarse bender evaluation is the one the term is taken at)
+        if pooled_e is not None:
+            share["e"] = pooled_e                    # (probes known up front: the divergence forward can BE that evaluation, _Bender.forward)
     extras = R.batchify_rays(rays_flat, {"ray_bending_latents": ray_bending_latents}, chunk=chunk, detailed_output=detailed_output,
                              retraw=True, **kw)
     schedule = (1.0 / 100.0) ** (1 - (global_step / N_iters))                                    # :240, 285

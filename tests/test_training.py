@@ -1345,12 +1345,15 @@ def test_fused_loss_kernel_vs_torch_autograd(with_rgb0, with_offsets, with_div, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("frozen_bender", [False, True], ids=["trained_bender", "frozen_bender"])
-def test_divergence_term_riding_on_the_coarse_bender_evaluation_gives_the_same_gradients(precision, tol, frozen_bender):
+@pytest.mark.parametrize("pooled", [False, True], ids=["reference_draw_order", "pooled_draws"])
+def test_divergence_term_riding_on_the_coarse_bender_evaluation_gives_the_same_gradients(precision, tol, frozen_bender, pooled):
     """training_loss with SHARED_DIVERGENCE (the divergence regulariser's backward and the coarse samples' bender backward as ONE
     nrnerf_bender_divergence_backward that takes the render pass' cotangents too -- training._DivergenceOnBender) against the two separate
     autograd nodes the reference's graph has (train.py:245-287 on top of :221-242): same random draws, same loss, every gradient equal up
     to the order of additions (fp32) / to the 16-bit arrays' rounding (bf16: the shared pass reads the activations the divergence forward
-    saved, the separate one those of the render's own bender forward); with the bender frozen the latent codes still get both terms."""
+    saved, the separate one those of the render's own bender forward); with the bender frozen the latent codes still get both terms.
+    ``pooled_draws``: the probe vectors are known before the render, so the divergence FORWARD is the coarse samples' bender evaluation too
+    (nrnerf_divergence_args.bent4; no nrnerf_bender_forward launch for them) -- against the separate nodes fed the same pooled numbers."""
     from nonrigid_nerf_amd import training
     cfg = SceneConfig(N_importance=64)
     scene = make_scene(cfg, 1)
@@ -1366,25 +1369,37 @@ def test_divergence_term_riding_on_the_coarse_bender_evaluation_gives_the_same_g
             lat = latents.to(DEV).requires_grad_(True)
             kw = dict(network_fn=coarse, network_fine=fine, network_query_fn=None, N_samples=64, N_importance=64, perturb=1.0, raw_noise_std=1.0)
             old, training.SHARED_DIVERGENCE = training.SHARED_DIVERGENCE, shared
+            old_pool, training.POOLED_DRAWS = training.POOLED_DRAWS, pooled
             try:
                 torch.manual_seed(11)
                 loss, _ = training.training_loss(rays.to(DEV), lat, target, kw, offsets_loss_weight=60.0, divergence_loss_weight=3.0,
                                                  rigidity_loss_weight=5e-4, global_step=120000, N_iters=200000, mean=True)
                 loss.backward()
             finally:
-                training.SHARED_DIVERGENCE = old
+                training.SHARED_DIVERGENCE, training.POOLED_DRAWS = old, old_pool
             grads = {k: p.grad.clone() for k, p in _named(rb, coarse, fine).items() if p.grad is not None}
             grads[("latents", "")] = lat.grad.clone()
             out[shared] = (loss.detach().clone(), grads)
     finally:
         R.set_precision("f32")
-    assert torch.allclose(out[True][0], out[False][0], rtol=1e-6, atol=1e-8)        # (the forward is the same launches either way)
+    # (reference draw order: the forward is the same launches either way; pooled: the bent points come from another kernel's instance of
+    #  the same arithmetic)
+    assert torch.allclose(out[True][0], out[False][0], rtol=(5e-3 if pooled else 1e-6), atol=1e-8)
     assert set(out[True][1]) == set(out[False][1])
     assert frozen_bender == (not any(k[0] == "bender" for k in out[True][1]))
+    # pooled: the two kernels' bent points agree to ONE ulp (1.2e-7, tools/experiments/r06_compare_bender_forwards.py), and an ulp of a bent
+    # point is 1e-2 of the scale of every gradient behind the 2^9 encoding frequency (the golden test's docstring): the loose bar of the
+    # native-bender comparisons applies; the tight check of the shared backward is the reference-draw-order variant
+    # (measured on 300 rays: worst element 8e-2 of a tensor's scale, cosine > 0.999 -- hence direction + a bar on the worst element)
     for k, ge in out[False][1].items():
         gs = out[True][1][k]
         scale = float(ge.abs().max()) + 1e-20
-        assert float((ge - gs).abs().max()) <= tol * scale, (k, float((ge - gs).abs().max()) / scale)
+        err = float((ge - gs).abs().max()) / scale
+        if pooled:
+            cos = float(torch.nn.functional.cosine_similarity(ge.flatten().double(), gs.flatten().double(), dim=0))
+            assert cos >= 0.995 and err <= 0.2, (k, cos, err)
+        else:
+            assert err <= tol, (k, err)
 
 
 @pytest.mark.gpu
