@@ -2225,8 +2225,19 @@ def bench_train_step(scene, cfg, dev, precision="bf16", n_rays=None, steps=30, w
             graph["with_torch_adam_error"] = f"{type(e).__name__}: {str(e)[:200]}"
     except Exception as e:                                                  # capture is best effort: report, do not fail the bench
         graph = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+    launches = None
+    try:        # device launches (kernels + copies) of ONE eager iteration: torch.profiler's device events of 3 steps minus those of 1, halved
+        from torch.profiler import ProfilerActivity, profile
+        counts = []
+        for k in (1, 3):
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                _time_training(cfg, dev, precision, n_rays, rec["N_importance"], k, 2, regularised=True)
+            counts.append(sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA))
+        launches = (counts[1] - counts[0]) // 2
+    except Exception:                                                       # (best effort: the tracer is not part of the measurement)
+        launches = None
     r = roof(dt, I, True)
-    return {"rays_per_s": round(n_rays / dt, 1), "ms_per_step": round(dt * 1e3, 3), "rays_per_step": n_rays,
+    return {"rays_per_s": round(n_rays / dt, 1), "ms_per_step": round(dt * 1e3, 3), "rays_per_step": n_rays, "device_launches_per_step": launches,
             "samples_per_ray": f"{S}+{I}", "dtype": precision, "final_loss": round(final, 5),
             "what": "the reference's training iteration with its shipped recipe (configs/example_sequence.txt): render under autograd with "
                     "detailed outputs (perturb, raw_noise_std 1), loss = mse(rgb_map) + mse(rgb0) + 60 x (offsets + 5e-4 rigidity) "
