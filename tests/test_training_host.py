@@ -251,6 +251,47 @@ def test_trunk_gradient_index_table_matches_the_record_layout(cfg_kw):
         assert torch.equal(got[2 * D], want) and torch.equal(got[2 * D + 1], torch.zeros(C_out, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("cfg_kw", [dict(), dict(use_viewdirs=True)], ids=["default", "viewdirs"])
+def test_trunk_gradient_index_marks_the_head_bias_for_the_aux_reduction(cfg_kw):
+    """training._trunk_grad_index(head_sums=True): exactly the head's bias positions -- output_linear.bias's first four channels, or
+    alpha_linear.bias and rgb_linear.bias -- carry -2 ("filled by nrnerf_reduce_partials_aux from nrnerf_wgrad_args.head_sums"), every
+    other entry equals the plain table's; the positions handed to the aux reduction (training._Trunk._weight_grads) are those."""
+    cfg = SceneConfig(N_importance=64, **cfg_kw)
+    _, coarse, _ = build_modules(make_scene(cfg, 0))
+    D, W = int(coarse.D), int(coarse.W)
+    views = bool(coarse.use_viewdirs)
+    C_out = 4 if views else int(coarse.output_linear.weight.shape[0])
+    plain, shapes, hb = T._trunk_grad_index(coarse, D, W, C_out, views, 0, "cpu")
+    aux, shapes2, hb2 = T._trunk_grad_index(coarse, D, W, C_out, views, 0, "cpu", head_sums=True)
+    assert shapes == shapes2 and hb == hb2
+    n = int(plain.shape[0])
+    pos = (n - 3, n - 2, n - 1, hb) if views else tuple(hb + c for c in range(4))
+    marked = (aux == -2).nonzero().flatten().tolist()
+    assert sorted(marked) == sorted(pos)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[list(pos)] = False
+    assert torch.equal(plain[keep], aux[keep]) and bool((plain[~keep] == -1).all())
+
+
+def test_pooled_draws_partition_two_generator_calls():
+    """training._pooled_draws (POOLED_DRAWS): the dict render._draw_randoms builds and the divergence term's probe vectors as views of ONE
+    uniform and ONE normal draw -- shapes, disjointness, which keys exist for which flags, the noise scaled by raw_noise_std."""
+    rays = torch.zeros(10, 11)
+    torch.manual_seed(0)
+    rnd, e = T._pooled_draws(rays, dict(N_samples=6, N_importance=4, perturb=1.0, raw_noise_std=2.0), True)
+    assert {k: tuple(v.shape) for k, v in rnd.items()} == {"u_coarse": (10, 6), "u_fine": (10, 4), "noise_coarse": (10, 6), "noise_fine": (10, 10)}
+    assert tuple(e.shape) == (60, 3)
+    torch.manual_seed(0)
+    u, nrm = torch.rand(100), torch.randn(160 + 180)
+    assert torch.equal(rnd["u_coarse"].flatten(), u[:60]) and torch.equal(rnd["u_fine"].flatten(), u[60:])
+    assert torch.equal(rnd["noise_coarse"].flatten(), nrm[:60] * 2.0) and torch.equal(rnd["noise_fine"].flatten(), nrm[60:160] * 2.0)
+    assert torch.equal(e.flatten(), nrm[160:])
+    rnd, e = T._pooled_draws(rays, dict(N_samples=6, N_importance=0, perturb=0.0, raw_noise_std=1.0), False)
+    assert set(rnd) == {"noise_coarse"} and e is None
+    rnd, e = T._pooled_draws(rays, dict(N_samples=6, N_importance=4, perturb=1.0, raw_noise_std=0.0), False)
+    assert set(rnd) == {"u_coarse", "u_fine"} and e is None
+
+
 @pytest.mark.parametrize("divergence", [False, True])
 @pytest.mark.parametrize("depth", [5, 7])
 def test_bender_gradient_index_table_matches_the_slots(divergence, depth):
