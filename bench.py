@@ -26,7 +26,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                        render of the same rays and weights (all rays, no exclusions), checker use of oracle/ only;
   "train_step":        the reference's training iteration at its batch size (1024 rays, perturb + raw noise, forward +
                        backward + Adam step + device-side weight refresh) through the same boundary under autograd, with its
-                       own roofline entry; not part of the timed region;
+                       own roofline entry; not part of the timed region.  Top-level figures: the iteration replayed from one HIP
+                       graph (how the library runs it; also under "hip_graph"); the host-bound eager Python loop: "eager_loop";
   "cpu_baseline":      the CPU oracle (a PyTorch-CPU port of the reference path, oracle/nrnerf_oracle.py) timed on this
                        box's host cores on a bounded sample of the same workload (after the GPU section).
 """
