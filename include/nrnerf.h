@@ -192,7 +192,13 @@ typedef enum nrnerf_render_flags {
      * kernels of the split path: a wave owns whole rays, their raw outputs stay in LDS) instead of composite_kernel's own launch: same
      * bits either way.  Neither bit = the library's default for the call (DESIGN.md section 3.3 says which and why, from an A/B on one box). */
     NRNERF_RENDER_COARSE_EPILOGUE_ON = 1u << 6,
-    NRNERF_RENDER_COARSE_EPILOGUE_OFF = 1u << 7
+    NRNERF_RENDER_COARSE_EPILOGUE_OFF = 1u << 7,
+    /* Round 6: FIXED shares of the work, as up to round 5 -- every wave of the 16x16x32 stand-alone bender and every workgroup of the
+     * 16x16x32 trunk kernels owns a fixed 1 / n of the sample blocks -- instead of taking the next piece from a device counter when it has
+     * finished the previous one.  (Measured: the two workgroups of a CU do not run the bender at the same rate, and the eight XCDs do not
+     * run the trunk at the same rate -- 3.7 % between the fastest and the slowest --, so with fixed shares a launch ends with idle CUs.)
+     * Same bits either way: which wave evaluates a sample does not enter the arithmetic. */
+    NRNERF_RENDER_FIXED_SHARES = 1u << 8
 } nrnerf_render_flags;
 
 /* per-kernel device time accumulated between nrnerf_profile_begin/_end (HIP events on the render stream) */

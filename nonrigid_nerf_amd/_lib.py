@@ -89,7 +89,7 @@ MODEL_FORCE_GENERIC, MODEL_NO_X16_F16 = 1 << 0, 1 << 1
 # described to the library without exact_viewdirs, which the run-time-parameterised RENDER kernel does not do (training.render_rays_train)
 MODEL_PY_TRAINING_HANDLE = 1 << 30
 RENDER_FUSED_FINE_BENDER, RENDER_UNFUSED_COMPOSITE, RENDER_SPLIT_COARSE, RENDER_NO_X16, RENDER_X16_FINE_ONLY, RENDER_BENDER_32X32, \
-    RENDER_COARSE_EPILOGUE_ON, RENDER_COARSE_EPILOGUE_OFF = (1 << i for i in range(8))
+    RENDER_COARSE_EPILOGUE_ON, RENDER_COARSE_EPILOGUE_OFF, RENDER_FIXED_SHARES = (1 << i for i in range(9))
 
 
 def model_flags_from_env() -> int:
@@ -103,7 +103,7 @@ def model_flags_from_env() -> int:
 
 
 _RENDER_ENV = ("NRNERF_FUSED_FINE_BENDER", "NRNERF_UNFUSED_COMPOSITE", "NRNERF_SPLIT_COARSE", "NRNERF_X16_BENDER", "NRNERF_X16",
-               "NRNERF_FUSED_COARSE_EPILOGUE")
+               "NRNERF_FUSED_COARSE_EPILOGUE", "NRNERF_FIXED_SHARES")
 _render_flags_cache = (None, 0)
 
 
@@ -133,6 +133,8 @@ def render_flags_from_env() -> int:
         if key[5].strip() not in ("0", "1"):
             raise ValueError(f"NRNERF_FUSED_COARSE_EPILOGUE={key[5]!r}: 0 (composite / sample_pdf / merge as their own launch) or 1 (inside the coarse trunk kernel)")
         f |= RENDER_COARSE_EPILOGUE_ON if key[5].strip() == "1" else RENDER_COARSE_EPILOGUE_OFF
+    if key[6] == "1":
+        f |= RENDER_FIXED_SHARES
     _render_flags_cache = (key, f)
     return f
 

@@ -2108,6 +2108,10 @@ void nrnerf_model_destroy(nrnerf_model* m) {
     delete m;
 }
 
+// work counters of the 16x16x32 stand-alone bender (BendArgs::work_counter): two launches per call, up to 512 counters each, 64 bytes apart
+constexpr int BEND_COUNTERS_PER_LAUNCH = 512;
+// ... and behind them one counter per 16x16x32 trunk launch (NetArgs::work_counter), 64 bytes apart
+constexpr size_t BEND_COUNTER_BYTES = (size_t)2 * BEND_COUNTERS_PER_LAUNCH * 64 + 256;
 size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t n_samples, int32_t n_importance) {
     if (n_rays <= 0 || n_samples <= 0 || n_importance < 0) return 0;
     const size_t N = (size_t)n_rays, S = (size_t)n_samples, SF = S + (size_t)n_importance;
@@ -2120,6 +2124,7 @@ size_t nrnerf_workspace_bytes(const nrnerf_model* model, int32_t n_rays, int32_t
         b += align_up(N * (SF - S) * sizeof(float), 256) + align_up(N * (SF - S), 256);
     }
     if (model && model->generic && model->exact) b += align_up(N * SF * 3 * sizeof(float), 256);      // per-sample Jacobian directions of a pass
+    b += BEND_COUNTER_BYTES;                             // work counters of the stand-alone bender launches (BendArgs::work_counter)
     return b;
 }
 
@@ -2171,6 +2176,26 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         rank_new = (uint8_t*)ws; ws += align_up((size_t)N * I, 256);
     }
     float* const jdirs = (m->generic && m->exact) ? (float*)ws : nullptr;      // [N, S + I | S, 3]: exact Jacobian directions of the pass in flight
+    if (m->generic && m->exact) ws += align_up((size_t)N * SF * 3 * sizeof(float), 256);
+    // one counter per stand-alone bender launch of the call (64 bytes apart), zeroed by ONE memset node ahead of the first launch
+    unsigned* const bend_counters = (unsigned*)ws;
+    bool counters_zeroed = false;
+    auto bend_counter = [&](int which) -> unsigned* {      // (per launch: one counter per pair of co-resident workgroups, 64 bytes apart)
+        if (m->num_cus > BEND_COUNTERS_PER_LAUNCH) return nullptr;                                  // (nullptr: the kernel's fixed shares)
+        if (!counters_zeroed) {
+            if (hipMemsetAsync(bend_counters, 0, BEND_COUNTER_BYTES, stream) != hipSuccess) return nullptr;
+            counters_zeroed = true;
+        }
+        return bend_counters + (size_t)16 * BEND_COUNTERS_PER_LAUNCH * which;
+    };
+    auto trunk_counter = [&](int which) -> unsigned* {     // (0: coarse pass, 1: fine pass; nullptr: fixed shares)
+        if (a->flags & NRNERF_RENDER_FIXED_SHARES) return nullptr;
+        if (!counters_zeroed) {
+            if (hipMemsetAsync(bend_counters, 0, BEND_COUNTER_BYTES, stream) != hipSuccess) return nullptr;
+            counters_zeroed = true;
+        }
+        return bend_counters + (size_t)16 * BEND_COUNTERS_PER_LAUNCH * 2 + 16 * which;
+    };
     if (!surface && !split) bent4 = nullptr;
     if ((a->u_fine || a->noise_fine) && I == 0) return NRNERF_ERR_INVALID;
 
@@ -2206,9 +2231,11 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
     // the stand-alone bender of the split path: the 16x16x32 kernel (nrnerf_bend_x16.h; "bf16" mode's single-product bender) unless the call
     // asks for the 32x32x16 one (NRNERF_RENDER_BENDER_32X32: the bit-identity tests against the fused-bender kernels)
     const bool bend_x16 = m->bend_x16.stream && !(a->flags & (NRNERF_RENDER_BENDER_32X32 | NRNERF_RENDER_NO_X16));
+    if (bend_x16 && !(a->flags & NRNERF_RENDER_FIXED_SHARES)) (void)bend_counter(0);       // (the memset node ahead of every timed launch)
     auto run_bender = [&](BendArgs& b, int slot, int n_samples) -> hipError_t {
         if (bend_x16) {
             b.wstream = m->bend_x16.stream; b.bias = m->bend_x16.bias;
+            b.work_counter = (a->flags & NRNERF_RENDER_FIXED_SHARES) ? nullptr : bend_counter(slot == 5 ? 0 : 1);
             return timed(slot, "bend_kernel_x16", (double)N * n_samples * m->bend_x16.algo_flops_per_sample, (double)N * n_samples * m->bend_x16.mfma_flops_per_sample,
                          [&] { return launch_bend_x16(bender_arch(m->arch_id), b, m->num_cus, stream); });
         }
@@ -2239,6 +2266,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                 b.bent4 = out4; b.knobs = kn;
                 if (bend_x16) {
                     b.wstream = m->bend_x16.stream; b.bias = m->bend_x16.bias;
+                    b.work_counter = (a->flags & NRNERF_RENDER_FIXED_SHARES) ? nullptr : bend_counter(slot == 5 ? 0 : 1);
                     return timed(slot, "bend_kernel_x16", (double)N * nS * m->bend_x16.algo_flops_per_sample, (double)N * nS * m->bend_x16.mfma_flops_per_sample,
                                  [&] { return launch_bend_x16(m->gen_compiled_bender, b, m->num_cus, stream); });
                 }
@@ -2451,7 +2479,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         if (x16_coarse) {
             na.wstream = m->coarse_trunk_x16.stream; na.bias = m->coarse_trunk_x16.bias;
             e = timed(0, (fuse_coarse_epilogue ? "net_kernel_x16 + fused compositing, sample_pdf, merge" : "net_kernel_x16"), (double)N * S * m->coarse_trunk_x16.algo_flops_per_sample, (double)N * S * m->coarse_trunk_x16.mfma_flops_per_sample,
-                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, na, m->num_cus, stream); });
+                      [&] { na.work_counter = trunk_counter(0); return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, na, m->num_cus, stream); });
         } else {
             na.wstream = m->coarse_trunk.stream; na.bias = m->coarse_trunk.bias;
             e = timed(0, "net_kernel (trunk only)", (double)N * S * m->coarse_trunk.algo_flops_per_sample, (double)N * S * m->coarse_trunk.mfma_flops_per_sample,
@@ -2500,7 +2528,7 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
         if (x16) {
             nf.wstream = m->fine_trunk_x16.stream; nf.bias = m->fine_trunk_x16.bias;
             e = timed(2, (fuse_fine ? "net_kernel_x16 + fused compositing" : "net_kernel_x16"), (double)N * SF * m->fine_trunk_x16.algo_flops_per_sample, (double)N * SF * m->fine_trunk_x16.mfma_flops_per_sample,
-                      [&] { return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, nf, m->num_cus, stream); });
+                      [&] { nf.work_counter = trunk_counter(1); return launch_net_x16(m->precision, trunk_arch(m->arch_id), m->views, nf, m->num_cus, stream); });
         } else {
             nf.wstream = m->fine_trunk.stream; nf.bias = m->fine_trunk.bias;
             e = timed(2, (fuse_fine ? "net_kernel (trunk only) + fused compositing" : "net_kernel (trunk only)"), (double)N * SF * m->fine_trunk.algo_flops_per_sample, (double)N * SF * m->fine_trunk.mfma_flops_per_sample,

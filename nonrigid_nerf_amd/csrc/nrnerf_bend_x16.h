@@ -29,6 +29,9 @@ namespace nrn {
 #ifndef NRN_BX16_PF
 #define NRN_BX16_PF 4
 #endif
+#ifndef NRN_BX16_CHUNK
+#define NRN_BX16_CHUNK 2       // groups of NB blocks a wave takes from its counter at a time
+#endif
 
 // PERRAY: a latent code per ray (lat_stride != 0); false: one code for the whole launch (a frame render), read once per wave
 template <class A, int WAVES, int NB, bool PERRAY>
@@ -39,6 +42,9 @@ __global__ void __launch_bounds__(WAVES * 64, NRN_BX16_OCC) bend_kernel_x16(cons
     using ST = WResident<P, PL::NFRAGS>;
     constexpr int NS_B = PL::NS_B, NS_R = PL::NS_R, PF = NRN_BX16_PF;
 
+#ifdef NRN_TIMING
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];     // resident weights | bias table [tile][16 rows]
     float* bias_lds = (float*)(smem + ST::BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -103,10 +109,48 @@ __global__ void __launch_bounds__(WAVES * 64, NRN_BX16_OCC) bend_kernel_x16(cons
             }
         });
     };
+    // Which groups of NB blocks a wave evaluates: group blk0 / NB, then every (grid x WAVES)-th one -- or, with BendArgs::work_counter, chunks
+    // of NRN_BX16_CHUNK consecutive groups taken from the counter as the wave gets to them.  Either way the NEXT group is known one
+    // iteration ahead (its inputs are requested then): the grab of a new chunk is issued before the MLPs and read after them.
+    // The counters: ONE per pair of workgroups that the dispatcher puts on the same CU (workgroups k and k + K of a grid of 2 K), 64 bytes
+    // apart, each over its own 1 / K of the groups -- the imbalance to even out is inside a CU (the older workgroup's waves win the issue
+    // arbitration; so do the older waves of a workgroup), and ONE counter for the whole launch serialises: 300 000 same-address atomics
+    // per frame were 1.4 ms (measured, profiles/r06_bender_dynamic_ab.txt)
+    const int ngroups = (nblocks + NB - 1) / NB;
+    const bool dynamic = a.work_counter != nullptr;
+    const int K = ((int)gridDim.x + NRN_BX16_OCC - 1) / NRN_BX16_OCC, kc = (int)blockIdx.x % K;
+    const int lo = (int)((long long)ngroups * kc / K), hi = dynamic ? (int)((long long)ngroups * (kc + 1) / K) : ngroups;
+    unsigned* const counter = a.work_counter + 16 * kc;
+    auto grab = [&]() -> int {                      // the next chunk of this counter's range (lane 0's value: read with readfirstlane)
+        unsigned c = 0;
+        if (lane == 0) c = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (int)c;
+    };
+    auto chunk_at = [&](int c, int& first, int& end) {      // (beyond the range: an empty chunk at `hi`)
+        const long long f = (long long)lo + (long long)c * NRN_BX16_CHUNK;
+        first = f < hi ? (int)f : hi;
+        end = f + NRN_BX16_CHUNK < hi ? (int)(f + NRN_BX16_CHUNK) : hi;
+    };
+    int grp, grp_end, nxt, nxt_end;
+    if (dynamic) {
+        chunk_at(__builtin_amdgcn_readfirstlane(grab()), grp, grp_end);
+        if (grp + 1 < grp_end) { nxt = grp + 1; nxt_end = grp_end; }
+        else chunk_at(__builtin_amdgcn_readfirstlane(grab()), nxt, nxt_end);
+    } else {
+        grp = blk0 / NB; grp_end = ngroups; nxt = grp + blk_step / NB; nxt_end = ngroups;
+    }
     In cur[NB];
-    if (blk0 < nblocks) load_inputs(blk0, cur);
-    // no barrier below: every wave strides over its own groups of NB blocks
-    for (int blk = blk0; blk < nblocks; blk += blk_step) {
+    if (grp < hi) load_inputs(grp * NB, cur);
+#ifdef NRN_TIMING
+    // (tools/timing_probe_bender.py) slots: 0 iteration, 1 operands, 2 offset MLP, 3 rigidity MLP, 4 tail + stores, 5 iteration in 100 MHz ticks, 7 iterations
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    // no barrier below: every wave works through its own groups of NB blocks
+    for (; grp < hi; ) {
+        const int blk = grp * NB;
+#ifdef NRN_TIMING
+        const unsigned long long t_it = NRN_NOW(), r_it = __builtin_amdgcn_s_memrealtime();
+#endif
         float p[NB][3];
         int out_idx[NB];            // row of this lane's sample in bent4 (-1: nothing to write)
         frag bin[NB][2];            // first-layer operand: k-step 0 = xyz (group 0, elements 0..2), k-step 1 = the latent code
@@ -131,7 +175,15 @@ __global__ void __launch_bounds__(WAVES * 64, NRN_BX16_OCC) bend_kernel_x16(cons
             }
         });
         // `cur` is consumed (points and first-layer operands built): request the next iteration's inputs into the same registers
-        if (blk + blk_step < nblocks) load_inputs(blk + blk_step, cur);
+        if (nxt < hi) load_inputs(nxt * NB, cur);
+        // the group after the next: the next one's successor in its chunk (or stride), or the first of a new chunk -- asked for now
+        const bool new_chunk = dynamic && nxt + 1 >= nxt_end;
+        int grabbed = 0;
+        if (new_chunk) grabbed = grab();
+#ifdef NRN_TIMING
+        NRN_TACC(1, t_it);
+        const unsigned long long t_off = NRN_NOW();
+#endif
 
         frag none[NB][1];
         auto keep = [&](auto& out) {
@@ -154,6 +206,11 @@ __global__ void __launch_bounds__(WAVES * 64, NRN_BX16_OCC) bend_kernel_x16(cons
         };
         if constexpr ((A::BD - 2) % 2 == 1) dense_x16<P, P, PL, PL::L_BEND0 + A::BD - 1, NS_B, 0, NB, PF>(st, bias_lane, hb, none, take_off);
         else dense_x16<P, P, PL, PL::L_BEND0 + A::BD - 1, NS_B, 0, NB, PF>(st, bias_lane, ha, none, take_off);
+#ifdef NRN_TIMING
+        asm volatile("" : "+v"(off[0][0]));
+        NRN_TACC(2, t_off);
+        const unsigned long long t_rig = NRN_NOW();
+#endif
         // ---- rigidity MLP (run_nerf_helpers.py:545-561); input = xyz only: the first-layer operand's xyz k-step again
         frag ra[NB][NS_R], rb[NB][NS_R];
         dense_x16<P, P, PL, PL::L_RIG0, 1, 0, NB, PF>(st, bias_lane, bin, none, keep(ra));
@@ -167,6 +224,11 @@ __global__ void __launch_bounds__(WAVES * 64, NRN_BX16_OCC) bend_kernel_x16(cons
         if constexpr ((A::RD - 2) % 2 == 1) dense_x16<P, P, PL, PL::L_RIG0 + A::RD - 1, NS_R, 0, NB, PF>(st, bias_lane, rb, none, take_logit);
         else dense_x16<P, P, PL, PL::L_RIG0 + A::RD - 1, NS_R, 0, NB, PF>(st, bias_lane, ra, none, take_logit);
 
+#ifdef NRN_TIMING
+        asm volatile("" : "+v"(logit[0]));
+        NRN_TACC(3, t_rig);
+        const unsigned long long t_tail = NRN_NOW();
+#endif
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             float rig_mask = (tanhf(logit[b]) + 1.0f) / 2.0f;                                    // rnh:559-561
@@ -180,7 +242,31 @@ __global__ void __launch_bounds__(WAVES * 64, NRN_BX16_OCC) bend_kernel_x16(cons
             }
             if (out_idx[b] >= 0 && g == 0) *(f32x4*)(a.bent4 + (size_t)out_idx[b] * 4) = f32x4{q[0], q[1], q[2], rig_mask};
         });
+        grp = nxt; grp_end = nxt_end;
+        if (new_chunk) chunk_at(__builtin_amdgcn_readfirstlane(grabbed), nxt, nxt_end);
+        else if (dynamic) { nxt = nxt + 1; }
+        else { nxt = nxt + blk_step / NB; }
+#ifdef NRN_TIMING
+        NRN_TACC(4, t_tail);
+        NRN_TACC(0, t_it);
+        tacc[5] += __builtin_amdgcn_s_memrealtime() - r_it;
+        tacc[7] += 1;
+#endif
     }
+#ifdef NRN_TIMING
+    if (blockIdx.x == 0 && lane == 0 && wave < 6)
+        for (int k = 0; k < 8; ++k) g_nrn_timing[wave][k] += tacc[k];
+    // rows 6 / 7: (start, end) in 100 MHz ticks of wave 0 of the FIRST / LAST workgroup, every 64th workgroup's start in slots 2..7 of row 7
+    if (lane == 0 && wave == 0) {
+        const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) { g_nrn_timing[6][0] = rt_start; g_nrn_timing[6][1] = rt_end; }
+        if (blockIdx.x == gridDim.x - 1) { g_nrn_timing[7][0] = rt_start; g_nrn_timing[7][1] = rt_end; }
+        if (blockIdx.x == 255) { g_nrn_timing[6][2] = rt_start; g_nrn_timing[6][3] = rt_end; }
+        if (blockIdx.x == 256) { g_nrn_timing[6][4] = rt_start; g_nrn_timing[6][5] = rt_end; }
+        if (blockIdx.x == 384) { g_nrn_timing[6][6] = rt_start; g_nrn_timing[6][7] = rt_end; }
+        if (blockIdx.x == 128) { g_nrn_timing[7][2] = rt_start; g_nrn_timing[7][3] = rt_end; }
+    }
+#endif
 }
 
 template <class A>

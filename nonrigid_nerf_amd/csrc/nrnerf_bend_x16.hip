@@ -10,3 +10,12 @@ hipError_t launch_bend_x16(int arch, const BendArgs& a, int num_cus, hipStream_t
     return hipErrorInvalidValue;
 }
 }  // namespace nrn
+
+#ifdef NRN_TIMING
+// reads and clears the per-phase cycle counters of bend_kernel_x16 (tools/timing_probe_bender.py): out[8 waves][8 slots]
+extern "C" int nrnerf_debug_timing_bend_x16(unsigned long long* out) {
+    static const unsigned long long zero[64] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nrn::g_nrn_timing), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(nrn::g_nrn_timing), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

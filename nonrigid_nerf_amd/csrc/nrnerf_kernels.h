@@ -74,6 +74,10 @@ struct NetArgs {
     // fuse.n_importance must be 0: no sampling follows a fused pass); raw4 is then neither written nor needed (may be nullptr).
     int fuse_on;
     CompositeArgs fuse;
+    // net_kernel_x16 only, or nullptr: a device counter, ZERO at launch -- the workgroups then take the next group of rays (fused
+    // compositing) / of blocks from it as they finish the previous one, instead of every gridDim-th one (round 6: the eight XCDs run the
+    // kernel at rates 3.7 % apart, and with fixed shares the launch lasted as long as the slowest one's)
+    unsigned* work_counter;
 };
 
 
@@ -91,6 +95,10 @@ struct BendArgs {
     const float* bias;
     float* bent4;            // [N, out_stride, 4] bent point xyz + rigidity mask
     Knobs knobs;
+    // bend_kernel_x16 only, or nullptr: a device counter, ZERO at launch -- the waves then take chunks of block groups from it as they
+    // finish their previous one instead of a fixed share each (two workgroups share a CU and the older one's waves win the issue
+    // arbitration: with fixed shares the younger workgroup ran on alone for the last fifth of the launch, measured round 6)
+    unsigned* work_counter;
 };
 hipError_t launch_bend(int precision, int arch_id, const BendArgs& a, int num_cus, hipStream_t stream);
 

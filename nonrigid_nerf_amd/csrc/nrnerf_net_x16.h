@@ -170,6 +170,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     static_assert(WAVES == X16Cfg<A>::WAVES, "launched with the architecture's own workgroup size");
     static_assert(A::L == 10, "the encoding's slot layout below is spelt out for ten frequencies (x16_enc_col)");
 
+#ifdef NRN_TIMING
+    const unsigned long long rt_kernel_start = __builtin_amdgcn_s_memrealtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     float* bias_lds = (float*)(smem + RING * P::UNIT_BYTES);
@@ -195,7 +198,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
     const int TG = RW * bpr / NB;
     const long long ngroups = ((long long)a.n_rays + WAVES * RW - 1) / (WAVES * RW);
-    f32x4* const stage0 = (f32x4*)(bias_lds + PL::NTILES * 16);
+    // (16 bytes behind the bias table: the mailbox through which wave 0 hands the workgroup's next group index to the other waves)
+    int* const mailbox = (int*)(bias_lds + PL::NTILES * 16);
+    f32x4* const stage0 = (f32x4*)(bias_lds + PL::NTILES * 16 + 4);
     f32x4* const stage_w = stage0 + (size_t)wave * RW * bpr * 16;
     const CompositeArgs& fa = *(const CompositeArgs*)(stage0 + (size_t)WAVES * RW * bpr * 16);      // (in LDS: see nrnerf_net_mb.h)
     static_assert(sizeof(CompositeArgs) <= 256, "the compositing arguments' LDS slot");
@@ -208,8 +213,30 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         for (int i = tid; i < (int)(sizeof(CompositeArgs) / 4); i += WAVES * 64) dst[i] = src[i];
         __syncthreads();
     }
+    // Which groups (fused compositing: of WAVES * RW rays = TG iterations; else: one iteration's WAVES * NB blocks) a workgroup takes: group
+    // blockIdx.x and every gridDim.x-th one after it, or -- NetArgs::work_counter -- the next index of a device counter whenever it starts a
+    // new group.  The index is needed at the advance point of the group's LAST iteration (the next iteration's points are requested
+    // there); wave 0 asks for it two iterations earlier (an atomic behind the iteration's last LDS-DMA requests, where the point loads
+    // sit: the vector-memory queue retires in order) and publishes it one iteration earlier through the LDS mailbox (slot = index & 1:
+    // rewritten two groups later at the earliest); the ring barriers of the iteration in between order the write before the reads.
+    const bool dyn = a.work_counter != nullptr;
+    const int TGd = fuse ? TG : 1;                                  // iterations per group of the counter's numbering
+    const int tg_pub = ((-2 % TGd) + TGd) % TGd, tg_iss = ((-3 % TGd) + TGd) % TGd;
+    unsigned pend = 0;                                              // (wave 0, lane 0) the index asked for at the previous issue point
+    int kseq = 0;                                                   // this workgroup's groups so far
+    long long first_id = blockIdx.x;
+    if (dyn) {
+        if (tid == 0) {
+            mailbox[0] = (int)atomicAdd(a.work_counter, 1u);
+            if (TGd == 1) { mailbox[1] = (int)atomicAdd(a.work_counter, 1u); pend = atomicAdd(a.work_counter, 1u); }
+            else if (TGd == 2) pend = atomicAdd(a.work_counter, 1u);
+        }
+        __syncthreads();
+        first_id = __builtin_amdgcn_readfirstlane(mailbox[0]);
+        __syncthreads();                                            // (slot 0 is written again at the publish point of index 2)
+    }
     int tg = 0;
-    long long grp = blockIdx.x;
+    long long grp = first_id;
     // (opaque: re-derived inside the loop, gridDim.x is a scalar load from the dispatch packet -- ~4000 cycles per iteration
     //  measured with NRN_TIMING on the path that advances every iteration)
     unsigned gdim = gridDim.x;
@@ -252,7 +279,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     static_for<0, NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         unsigned nb;
-        locate(0, grp, (long long)blockIdx.x * per_wg, b, so[b], ok[b], nb, first[b]);
+        locate(0, grp, first_id * per_wg, b, so[b], ok[b], nb, first[b]);
         q4n[b] = *(const f32x4*)(a.pts4 + (size_t)so[b] * 4);
         if constexpr (VIEWS) q4p[b] = *(const f32x4*)(a.pts4 + (size_t)nb * 4);
     });
@@ -261,7 +288,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     //        6 ring waits + barriers (inside 2), 7 iterations
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (long long b0 = (long long)blockIdx.x * per_wg; fuse ? (grp < ngroups) : (b0 < nblocks); ) {
+    for (long long b0 = first_id * per_wg; fuse ? (grp < ngroups) : (b0 < nblocks); ) {
 #ifdef NRN_TIMING
         const unsigned long long t_it = NRN_NOW(), r_it = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -386,10 +413,20 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         // the next iteration's points, requested behind the ring's last LDS-DMA requests and ahead of everything that is left to do here
         int tg_n = tg;
         long long grp_n = grp, b0_n = b0;
+        const int tgd = fuse ? tg : 0;
+        long long next_id = 0;
+        if (dyn) {
+            if (tgd + 1 == TGd) next_id = __builtin_amdgcn_readfirstlane(mailbox[(kseq + 1) & 1]);      // published an iteration ago
+            if (wave == 0 && lane == 0) {
+                if (tgd == tg_pub) mailbox[(kseq + (TGd == 1 ? 2 : 1)) & 1] = (int)pend;               // (asked for an iteration ago)
+                if (tgd == tg_iss) pend = atomicAdd(a.work_counter, 1u);
+            }
+            if (tgd + 1 == TGd) ++kseq;
+        }
         if constexpr (fuse) {
-            if (tg + 1 == TG) { tg_n = 0; grp_n = grp + gdim; } else tg_n = tg + 1;
+            if (tg + 1 == TG) { tg_n = 0; grp_n = dyn ? next_id : grp + gdim; } else tg_n = tg + 1;
         } else {
-            b0_n = b0 + (long long)gdim * per_wg;
+            b0_n = dyn ? next_id * per_wg : b0 + (long long)gdim * per_wg;
         }
         unsigned so_n[NB];
         bool ok_n[NB];
@@ -449,6 +486,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
         tacc[6] = st.bar_cycles;
         for (int i = 0; i < 8; ++i) g_nrn_timing[wave][i] += tacc[i];
     }
+    // (WAVES == 4: rows 4..7 are free) when the waves 0 of sixteen workgroups spread over the grid left the loop, in 100 MHz ticks: the
+    // spread is the share of the launch that runs with idle CUs
+    // (workgroups 0..7: one per XCD; 8..15 their neighbours on the same XCDs)
+    if (WAVES == 4 && lane == 0 && wave == 0 && blockIdx.x < 16) {
+        const int slot = (int)blockIdx.x;
+        g_nrn_timing[4 + slot / 8][slot % 8] = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) g_nrn_timing[6][0] = rt_kernel_start;
+    }
 #endif
 }
 
@@ -461,7 +506,7 @@ static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t st
     if ((a.fuse_on != 0) != (EPL > 0) || (EPL > 0 && (a.S + 63) / 64 != EPL)) return hipErrorInvalidValue;      // (the dispatcher's job)
     const int bpr = (a.S + 15) / 16;
     const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
-    size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float);
+    size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + 16;      // ring | bias table | mailbox
     if (a.fuse_on) {
         if (a.S > 256 || (a.fuse.n_importance != 0) != SAMPLE || a.fuse.S != a.S) return hipErrorInvalidValue;
         lds += (size_t)WAVES * RW * bpr * 16 * 16 + 256;            // the waves' raw stages + the compositing arguments
@@ -477,7 +522,7 @@ static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t st
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         // the largest request any launch can make: ring + bias table + the fused stages at bpr = 15 (RW = NB)
-        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + (size_t)WAVES * NB * 15 * 256 + 256 +
+        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + 16 + (size_t)WAVES * NB * 15 * 256 + 256 +
                                (SAMPLE ? (size_t)WAVES * (2 * 64 * EPL + 260) * sizeof(float) : 0);
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max < 160 * 1024 ? lds_max : 160 * 1024));
         if (e != hipSuccess) return e;

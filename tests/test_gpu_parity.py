@@ -1427,6 +1427,49 @@ def test_coarse_epilogue_inside_the_trunk_kernel_equals_the_composite_launch_bit
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("cfg_kw,n,one_code,env", [
+    (dict(), 70001, True, {}),                                            # headline shape, one frame code: many more groups than workgroups
+    (dict(N_samples=48, N_importance=37), 3001, False, {}),               # ragged counts (groups of four rays per wave), a code per ray
+    (dict(N_importance=64, bend_depth=7), 257, False, {}),                # the 7-layer bender; fewer groups than workgroups: most get none
+    (dict(N_importance=128, netdepth=6, netwidth=192), 5000, True, {}),   # a non-compiled trunk: the generic route's bender passes
+    (dict(N_importance=64, netwidth=128), 20011, False, {}),              # width 128: eight waves per workgroup
+    (dict(N_importance=64, use_viewdirs=True), 9001, True, {}),           # the view-dependent head behind both trunks
+    (dict(), 9001, True, {"NRNERF_FUSED_COARSE_EPILOGUE": "1"}),          # the coarse pass with its epilogue: a group per iteration, fused
+    (dict(), 9001, True, {"NRNERF_UNFUSED_COMPOSITE": "1"}),              # both passes write raw rows: a group per iteration, not fused
+    (dict(N_samples=128, N_importance=128), 6001, True, {}),              # two iterations per group in the coarse pass' numbering
+], ids=["headline_frame_code", "ragged_per_ray_codes", "deep_bender_tiny", "generic_w192", "narrow_128", "viewdirs", "coarse_epilogue",
+        "unfused_composite", "128_plus_128"])
+def test_dynamic_shares_of_the_work_equal_fixed_shares_bit_for_bit(precision, cfg_kw, n, one_code, env):
+    """Round 6: the waves of the 16x16x32 stand-alone bender and the workgroups of the 16x16x32 trunk kernels take their next piece of work
+    from device counters (BendArgs / NetArgs::work_counter, zeroed by a memset node of the call) instead of owning a fixed share;
+    NRNERF_FIXED_SHARES=1 (nrnerf_render_args.flags: NRNERF_RENDER_FIXED_SHARES) keeps the fixed shares.  Which wave evaluates a sample
+    must not matter: every output the same bits, on repeated calls too (the counters are re-armed per call)."""
+    import contextlib
+    cfg = SceneConfig(**cfg_kw)
+    scene = make_scene(cfg, 4)
+    rays, latents = make_rays(n, 31, cfg)
+    rb, coarse, fine = build_modules(scene, device=DEV)
+    R.set_precision(precision)
+    model = R.get_model(coarse, fine)
+    r = rays.to(DEV)
+    l = latents[:1].to(DEV).expand(n, -1) if one_code else latents.to(DEV)
+    outs = []
+    with contextlib.ExitStack() as stack:
+        for k, v in env.items():
+            stack.enter_context(_setenv(k, v))
+        for fixed in ("1", "0", "0"):
+            with _setenv("NRNERF_FIXED_SHARES", fixed):
+                with torch.no_grad():
+                    outs.append({k: v.clone() for k, v in model.render(r, l, cfg.N_samples, cfg.N_importance, want_z_vals=True, surface=True).items()})
+    torch.cuda.synchronize()
+    for other in outs[1:]:
+        assert set(other) == set(outs[0])
+        for k in other:
+            assert torch.equal(torch.nan_to_num(other[k].float()), torch.nan_to_num(outs[0][k].float())), k
+    assert torch.isfinite(outs[0]["rgb_map"]).all() and float(outs[0]["acc_map"].max()) > 0.5
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
 @pytest.mark.parametrize("cfg_kw,flags,n", [
     (dict(N_importance=128, netdepth=6, netwidth=192, netwidth_fine=320, multires=8), {}, 3001),        # 192 merged samples: three per lane
     (dict(N_samples=48, N_importance=37, netwidth=96), dict(raw_noise_std=1.0), 2049),                  # ragged, noise on sigma

@@ -46,6 +46,9 @@ if "--x16" in sys.argv:
                     print(f"  wave {w}: slots per iteration " + "  ".join(f"[{i}] {row[i] / n:8.0f}" for i in range(7)) + f"  iterations {row[7]}")
                     continue
                 print(f"  wave {w}: " + "  ".join(f"{names[i]} {row[i] / n:8.0f}" for i in (0, 1, 2, 3, 4, 6)) + f"  iterations {row[7]}  clock {mhz:6.0f} MHz")
+            t0 = buf[6 * 8]           # (row 6 slot 0: workgroup 0's start; rows 4, 5: when sixteen workgroups spread over the grid left their loops)
+            ends = [(buf[4 * 8 + k] - t0) / 100.0 for k in range(16) if k != 8 or True]
+            print("  end of the loop of workgroups 0 .. 15 (XCD = index % 8) after workgroup 0's start (us): " + " ".join(f"{e:.0f}" for e in ends))
     sys.exit(0)
 fn = lib.nrnerf_debug_timing_launch_net_a0_bf16_bend
 fn.argtypes, fn.restype = [C.POINTER(C.c_ulonglong)], C.c_int
