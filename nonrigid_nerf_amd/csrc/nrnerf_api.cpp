@@ -2266,7 +2266,9 @@ int nrnerf_render(const nrnerf_model* m, const nrnerf_render_args* a, void* hip_
                 b.bent4 = out4; b.knobs = kn;
                 if (bend_x16) {
                     b.wstream = m->bend_x16.stream; b.bias = m->bend_x16.bias;
-                    b.work_counter = (a->flags & NRNERF_RENDER_FIXED_SHARES) ? nullptr : bend_counter(slot == 5 ? 0 : 1);
+                    // (fixed shares here: with all nS samples of a ray in one launch the counters measured SLOWER -- width 192: 1.72 -> 1.82 ms
+                    //  per fine pass, profiles/r06_dynamic_shares_ab.txt -- where the split path's launches gain 8 %)
+                    b.work_counter = nullptr;
                     return timed(slot, "bend_kernel_x16", (double)N * nS * m->bend_x16.algo_flops_per_sample, (double)N * nS * m->bend_x16.mfma_flops_per_sample,
                                  [&] { return launch_bend_x16(m->gen_compiled_bender, b, m->num_cus, stream); });
                 }

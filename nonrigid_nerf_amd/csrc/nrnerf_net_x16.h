@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
     for (int i = tid; i < PL::NTILES * 16; i += WAVES * 64) bias_lds[i] = a.bias[i];
+    if (tid < 32) bias_lds[PL::NTILES * 16 + tid] = 0.0f;             // (the tile of zeros and the mailbox)
     __syncthreads();
     const __attribute__((address_space(3))) f32x4* bias_lane = (const __attribute__((address_space(3))) f32x4*)(bias_lds + 4 * g);
     asm volatile("" : "+v"(bias_lane));
@@ -198,9 +199,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) net_kernel_x16(const NetArgs a)
     const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
     const int TG = RW * bpr / NB;
     const long long ngroups = ((long long)a.n_rays + WAVES * RW - 1) / (WAVES * RW);
-    // (16 bytes behind the bias table: the mailbox through which wave 0 hands the workgroup's next group index to the other waves)
-    int* const mailbox = (int*)(bias_lds + PL::NTILES * 16);
-    f32x4* const stage0 = (f32x4*)(bias_lds + PL::NTILES * 16 + 4);
+    // (behind the bias table: 64 bytes of zeros, then the mailbox through which wave 0 hands the workgroup's next group index to the
+    //  other waves -- apart from the table, so that nothing that reads a tile past its end can ever see an index)
+    int* const mailbox = (int*)(bias_lds + PL::NTILES * 16 + 16);
+    f32x4* const stage0 = (f32x4*)(bias_lds + PL::NTILES * 16 + 32);
     f32x4* const stage_w = stage0 + (size_t)wave * RW * bpr * 16;
     const CompositeArgs& fa = *(const CompositeArgs*)(stage0 + (size_t)WAVES * RW * bpr * 16);      // (in LDS: see nrnerf_net_mb.h)
     static_assert(sizeof(CompositeArgs) <= 256, "the compositing arguments' LDS slot");
@@ -506,7 +508,7 @@ static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t st
     if ((a.fuse_on != 0) != (EPL > 0) || (EPL > 0 && (a.S + 63) / 64 != EPL)) return hipErrorInvalidValue;      // (the dispatcher's job)
     const int bpr = (a.S + 15) / 16;
     const int RW = (bpr % NB == 0) ? 1 : ((2 * bpr) % NB == 0 ? 2 : NB);
-    size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + 16;      // ring | bias table | mailbox
+    size_t lds = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + 128;     // ring | bias table | a tile of zeros | mailbox
     if (a.fuse_on) {
         if (a.S > 256 || (a.fuse.n_importance != 0) != SAMPLE || a.fuse.S != a.S) return hipErrorInvalidValue;
         lds += (size_t)WAVES * RW * bpr * 16 * 16 + 256;            // the waves' raw stages + the compositing arguments
@@ -522,7 +524,7 @@ static hipError_t launch_net_x16_t(const NetArgs& a, int num_cus, hipStream_t st
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         // the largest request any launch can make: ring + bias table + the fused stages at bpr = 15 (RW = NB)
-        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + 16 + (size_t)WAVES * NB * 15 * 256 + 256 +
+        const size_t lds_max = (size_t)RING * P::UNIT_BYTES + (size_t)PL::NTILES * 16 * sizeof(float) + 128 + (size_t)WAVES * NB * 15 * 256 + 256 +
                                (SAMPLE ? (size_t)WAVES * (2 * 64 * EPL + 260) * sizeof(float) : 0);
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max < 160 * 1024 ? lds_max : 160 * 1024));
         if (e != hipSuccess) return e;
