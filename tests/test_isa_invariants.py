@@ -19,6 +19,19 @@ def test_network_kernels_keep_the_wait_invariants():
     assert not errors, "\n".join(errors)
 
 
+@pytest.mark.skipif(not os.path.isdir(BUILD) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"),
+                    reason="no build directory / no llvm-objdump")
+def test_no_matrix_instruction_runs_under_a_saved_exec_mask_in_the_16x16x32_kernels():
+    """The layers' `asm volatile` LDS reads do not name the exec mask: a lane-divergent region stretched over a layer would run it for some
+    lanes only (round 6, gx16_kernel with a lane-0-only branch in its loop: tools/experiments/README.md).  tools/check_exec_regions.py scans
+    the shipped objects -- net_kernel_x16 with its dynamic shares (lane-0 statements at the advance point) among them."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_exec_regions
+    bad, n = check_exec_regions.offending_regions(BUILD)
+    assert n >= 10, "the 16x16x32 objects are missing from csrc/build"
+    assert not bad, "\n".join(bad)
+
+
 def test_rendering_instantiations_of_the_generic_kernel_do_not_pay_for_its_training_code():
     """csrc/nrnerf_generic.h: the training entry points' code (saved activations, relu masks, the backward-data mode) is compiled into
     instantiations of its own (template parameter TRAIN).  In one kernel it cost the RENDERING instantiations 35 - 95 spilled registers
